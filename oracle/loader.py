@@ -1,0 +1,121 @@
+"""ctypes loader for the CPU oracle (test infrastructure, NOT product code).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (smooth_feedback_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "build", "liboracle.so")
+
+
+class OracleQPParams(C.Structure):
+    """oracle_qp_params (oracle/qp_oracle.h) == QPSolverParams, qp_solver.hpp:29-68."""
+
+    _fields_ = [
+        ("alpha", C.c_float),
+        ("rho", C.c_float),
+        ("sigma", C.c_float),
+        ("scaling", C.c_int32),
+        ("eps_abs", C.c_float),
+        ("eps_rel", C.c_float),
+        ("eps_primal_inf", C.c_float),
+        ("eps_dual_inf", C.c_float),
+        ("max_iter", C.c_int64),
+        ("max_time_ns", C.c_int64),
+        ("stop_check_iter", C.c_uint32),
+        ("polish", C.c_int32),
+        ("polish_iter", C.c_uint32),
+        ("delta", C.c_float),
+        ("verbose", C.c_int32),
+    ]
+
+
+def build(force=False):
+    """Compile the oracle with the committed Makefile (gcc only)."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        L.oracle_qp_params_default.argtypes = [C.POINTER(OracleQPParams)]
+        L.oracle_qp_params_default.restype = None
+        L.oracle_qp_dense_solve_batch.argtypes = [
+            C.POINTER(OracleQPParams), C.c_int64, C.c_int, C.c_int,
+            dp, dp, dp, dp, dp, dp, dp, dp, dp, dp,
+            C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_int,
+        ]
+        L.oracle_qp_dense_solve_batch.restype = C.c_int
+        L.oracle_ldlt_factor.argtypes = [C.c_int, dp, C.c_int, C.POINTER(C.c_int)]
+        L.oracle_ldlt_factor.restype = C.c_int
+        L.oracle_ldlt_solve.argtypes = [C.c_int, dp, C.c_int, C.POINTER(C.c_int), dp]
+        L.oracle_ldlt_solve.restype = None
+        _lib = L
+    return _lib
+
+
+def default_params(**kw):
+    p = OracleQPParams()
+    lib().oracle_qp_params_default(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def qp_dense_solve_batch(P, q, A, l, u, params=None, warm_x=None, warm_y=None, nthreads=1):
+    """Batch-major inputs: P (B,n,n) with P[b] stored COLUMN-major, i.e. P[b].ravel() is the
+    col-major buffer (pass np.asfortranarray-style data flattened); same for A (B, m*n).
+
+    To keep things unambiguous this function takes flat buffers: P (B, n*n), q (B, n),
+    A (B, m*n), l (B, m), u (B, m), all float64 C-contiguous.
+    Returns dict(x, y, obj, iter, code).
+    """
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    l = np.ascontiguousarray(l, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    B, n = q.shape
+    m = l.shape[1]
+    assert P.shape == (B, n * n) and A.shape == (B, m * n) and u.shape == (B, m)
+    if warm_x is not None:
+        warm_x = np.ascontiguousarray(warm_x, dtype=np.float64)
+        warm_y = np.ascontiguousarray(warm_y, dtype=np.float64)
+        assert warm_x.shape == (B, n) and warm_y.shape == (B, m)
+    x = np.zeros((B, n))
+    y = np.zeros((B, m))
+    obj = np.zeros(B)
+    it = np.zeros(B, dtype=np.uint32)
+    code = np.zeros(B, dtype=np.int32)
+    p = params if params is not None else default_params()
+    rc = lib().oracle_qp_dense_solve_batch(
+        C.byref(p), B, n, m, _dp(P), _dp(q), _dp(A), _dp(l), _dp(u), _dp(warm_x), _dp(warm_y),
+        _dp(x), _dp(y), _dp(obj), it.ctypes.data_as(C.POINTER(C.c_uint32)),
+        code.ctypes.data_as(C.POINTER(C.c_int32)), int(nthreads))
+    if rc != 0:
+        raise RuntimeError("oracle_qp_dense_solve_batch failed rc=%d" % rc)
+    return dict(x=x, y=y, obj=obj, iter=it, code=code)
+
+
+def colmajor(M):
+    """Flatten a 2-D (rows, cols) numpy matrix into the col-major buffer the C side expects."""
+    return np.asarray(M, dtype=np.float64).flatten(order="F")

@@ -1,0 +1,92 @@
+/*
+ * ORACLE (test infrastructure, NOT product code).
+ *
+ * CPU restatement, in plain C, of the dense QP path of pettni/smooth_feedback @ v1:
+ *   include/smooth/feedback/qp_solver.hpp  (QPSolver::scale/solve/check_stopping, detail::polish_qp)
+ *   include/smooth/feedback/qp.hpp         (QuadraticProgram, QPSolution, QPSolutionStatus)
+ * and of the one third-party routine on that path that is absent from /root/reference:
+ *   Eigen 3.4.0  Eigen/src/Cholesky/LDLT.h  (LDLT<.,Upper>::compute / solveInPlace; pinned only
+ *   by the reference CI, .github/workflows/build_and_test.yml:29-36).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ *
+ * PARITY STATUS: pinned against every known-answer test of tests/test_qp.cpp (status codes
+ * exactly, primal/objective to the tests' tolerances; see tests/test_oracle_qp_golden.py).
+ * The reference itself cannot be built here (no Eigen / Boost / smooth), so bit-level parity
+ * with a real Eigen build (summation order inside Eigen's products, pivot tie-breaking) is
+ * UNPINNED; the summation orders below are this oracle's own fixed choice and the HIP kernel
+ * follows the same choice so that the two agree bit-for-bit.
+ */
+#ifndef SFB_QP_ORACLE_H
+#define SFB_QP_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same field order / types as sfb_qp_params in include/sfb.h (checked by tests). */
+typedef struct oracle_qp_params {
+  float alpha;            /* qp_solver.hpp:35 */
+  float rho;              /* :37 */
+  float sigma;            /* :39 */
+  int32_t scaling;        /* :42 */
+  float eps_abs;          /* :45 */
+  float eps_rel;          /* :47 */
+  float eps_primal_inf;   /* :49 */
+  float eps_dual_inf;     /* :51 */
+  int64_t max_iter;       /* :54  (<0 : unset / unlimited) */
+  int64_t max_time_ns;    /* :57  (<0 : unset). Wall-clock, nondeterministic; oracle honours it. */
+  uint32_t stop_check_iter; /* :60 */
+  int32_t polish;         /* :63 */
+  uint32_t polish_iter;   /* :65 */
+  float delta;            /* :67 */
+  int32_t verbose;        /* :32 (ignored by the oracle) */
+} oracle_qp_params;
+
+void oracle_qp_params_default(oracle_qp_params *p);
+
+/* QPSolutionStatus values, qp.hpp:82-92 */
+enum {
+  ORACLE_QP_OPTIMAL = 0,
+  ORACLE_QP_POLISH_FAILED = 1,
+  ORACLE_QP_PRIMAL_INFEASIBLE = 2,
+  ORACLE_QP_DUAL_INFEASIBLE = 3,
+  ORACLE_QP_MAX_ITERATIONS = 4,
+  ORACLE_QP_MAX_TIME = 5,
+  ORACLE_QP_UNKNOWN = 6
+};
+
+/*
+ * One dense solve == solve_qp(pbm, prm, warmstart)  (qp_solver.hpp:779-787).
+ * P: n*n col-major, q: n, A: m*n col-major, l,u: m. warm_x / warm_y may be NULL (cold start).
+ * Outputs: x[n], y[m], *obj, *iter, *code.  Returns 0, or -1 on bad arguments / alloc failure.
+ */
+int oracle_qp_dense_solve(const oracle_qp_params *prm, int n, int m, const double *P, const double *q,
+                          const double *A, const double *l, const double *u, const double *warm_x,
+                          const double *warm_y, double *x, double *y, double *obj, uint32_t *iter,
+                          int32_t *code);
+
+/*
+ * Sequential loop over a batch exactly like benchmarks/bench_types.hpp:93, optionally split
+ * statically over nthreads POSIX threads (contiguous chunks). Batch-major contiguous arrays.
+ */
+int oracle_qp_dense_solve_batch(const oracle_qp_params *prm, int64_t batch, int n, int m, const double *P,
+                                const double *q, const double *A, const double *l, const double *u,
+                                const double *warm_x, const double *warm_y, double *x, double *y,
+                                double *obj, uint32_t *iter, int32_t *code, int nthreads);
+
+/*
+ * Restatement of Eigen 3.4 LDLT (unblocked, diagonal pivoting) exposed for unit tests.
+ * W: k*k row-major work matrix, lower triangle (incl. diagonal) holds the symmetric input on
+ * entry and L (unit, strictly lower) + D (diagonal) on exit.  tr[k]: transpositions.
+ * Returns 1 on success (info()==Success), 0 on failure (NumericalIssue).
+ */
+int oracle_ldlt_factor(int k, double *W, int ld, int *tr);
+void oracle_ldlt_solve(int k, const double *W, int ld, const int *tr, double *b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
