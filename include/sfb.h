@@ -1,0 +1,132 @@
+/*
+ * sfb.h -- C-ABI of the MI355X-native batched QP / MPC / EKF engine.
+ *
+ * This is the drop-in boundary for the hot path of pettni/smooth_feedback (reference @ v1).
+ * The reference has no FFI layer: its boundary is a set of C++ templates instantiated in the
+ * caller's translation unit.  Each entry point below names the reference interface it replaces
+ * (file:line relative to the reference tree).  The C++ front in include/smooth_feedback_amd/
+ * keeps the reference's class/function names and forwards to these functions.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ / torch types;
+ *   - every function returns an sfb_status (0 = ok); per-problem results use the reference's
+ *     QPSolutionStatus values (qp.hpp:82-92) in `code[]`; the library never aborts or throws;
+ *   - `*_batch` functions take DEVICE pointers and are asynchronous on `stream` (a hipStream_t,
+ *     NULL = default stream); results are valid after the stream is synchronised;
+ *   - `*_batch_host` functions take HOST pointers, stage through device memory and are synchronous;
+ *   - all floating point data is IEEE fp64; batch items are contiguous, batch-major;
+ *   - there is NO CPU fallback: without a usable HIP device every compute call fails with
+ *     SFB_ERR_NO_DEVICE.
+ */
+#ifndef SFB_H
+#define SFB_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sfb_status {
+  SFB_OK              = 0,
+  SFB_ERR_INVALID_ARG = 1,
+  SFB_ERR_UNSUPPORTED = 2, /* size / option outside what the HIP kernels implement */
+  SFB_ERR_HIP         = 3, /* a HIP runtime call failed; see sfb_last_error() */
+  SFB_ERR_NO_DEVICE   = 4
+} sfb_status;
+
+/* smooth::feedback::QPSolutionStatus, qp.hpp:82-92 (declaration order == value) */
+typedef enum sfb_qp_status {
+  SFB_QP_OPTIMAL           = 0,
+  SFB_QP_POLISH_FAILED     = 1,
+  SFB_QP_PRIMAL_INFEASIBLE = 2,
+  SFB_QP_DUAL_INFEASIBLE   = 3,
+  SFB_QP_MAX_ITERATIONS    = 4,
+  SFB_QP_MAX_TIME          = 5,
+  SFB_QP_UNKNOWN           = 6
+} sfb_qp_status;
+
+/*
+ * smooth::feedback::QPSolverParams, qp_solver.hpp:29-68.  Numeric options are `float` exactly as
+ * in the reference and are widened to double at the same places (:353-356, :587, :593, ...).
+ * std::optional members are encoded with a negative value meaning "unset".
+ */
+typedef struct sfb_qp_params {
+  float alpha;              /* :35  relaxation parameter                (1.6f)  */
+  float rho;                /* :37  first dual step size                (0.1f)  */
+  float sigma;              /* :39  second dual step length             (1e-6f) */
+  int32_t scaling;          /* :42  scale problem                       (1)     */
+  float eps_abs;            /* :45                                      (1e-3f) */
+  float eps_rel;            /* :47                                      (1e-3f) */
+  float eps_primal_inf;     /* :49                                      (1e-4f) */
+  float eps_dual_inf;       /* :51                                      (1e-4f) */
+  int64_t max_iter;         /* :54  optional<uint32_t>; <0 = unset      (-1)    */
+  int64_t max_time_ns;      /* :57  optional<nanoseconds>; <0 = unset   (-1).  Wall-clock limits are
+                                    nondeterministic: the device path REJECTS a set value
+                                    (SFB_ERR_UNSUPPORTED); use max_iter.                       */
+  uint32_t stop_check_iter; /* :60                                      (25)    */
+  int32_t polish;           /* :63                                      (1)     */
+  uint32_t polish_iter;     /* :65                                      (5)     */
+  float delta;              /* :67                                      (1e-6f) */
+  int32_t verbose;          /* :32  ignored on the device path          (0)     */
+} sfb_qp_params;
+
+/* With max_iter unset the reference loops until a stopping test fires (possibly forever, e.g.
+ * stop_check_iter==1, qp_solver.hpp:465).  The device path bounds every solve by this many
+ * iterations and reports SFB_QP_MAX_ITERATIONS (iter == cap) when it is hit. */
+#define SFB_QP_DEVICE_ITER_CAP 20000000
+
+/* Largest n+m the one-QP-per-wavefront dense kernel handles (lane i owns KKT row i). */
+#define SFB_QP_DENSE_MAX_K 64
+
+const char *sfb_version(void);
+/* Thread-local description of the last non-OK status returned on this thread. */
+const char *sfb_last_error(void);
+/* Number of visible HIP devices (0 if none / runtime unusable). */
+sfb_status sfb_device_count(int *count);
+
+/* Defaults of QPSolverParams (qp_solver.hpp:29-68). */
+void sfb_qp_params_default(sfb_qp_params *prm);
+
+/*
+ * Batched dense QP solve:   min 1/2 x'Px + q'x   s.t.  l <= Ax <= u      for `batch` problems.
+ *
+ * Replaces, per batch item, smooth::feedback::solve_qp(pbm, prm, warmstart)
+ * (qp_solver.hpp:779-787) == QPSolver<QuadraticProgram<M,N,double>>(pbm, prm).solve(pbm, warmstart)
+ * (:276, :343-568): scaling (:673-730), rho selection (:361-374), KKT + pivoted LDL' (:399-433),
+ * ADMM loop with stopping tests every stop_check_iter iterations (:447-510, :574-644), polish
+ * (:92-204, :515-539) and un-scaling (:544-548).
+ *
+ * Layout (qp.hpp:31-45, Eigen default column-major), item b at offset b*size:
+ *   P  [batch][n*n]  col-major n x n (upper triangle feeds the KKT matrix, the full matrix is
+ *                    used for residuals/objective exactly as the reference does)
+ *   q  [batch][n]    A [batch][m*n] col-major m x n      l,u [batch][m]  (+-inf allowed)
+ *   warm_x [batch][n], warm_y [batch][m]: previous primal/dual (both NULL = cold start)
+ * Outputs (QPSolution, qp.hpp:95-108):
+ *   x [batch][n] primal, y [batch][m] dual, obj [batch] (nullable), iter [batch] (nullable),
+ *   code [batch] (sfb_qp_status values).
+ * Requires 1 <= n, 1 <= m, n+m <= SFB_QP_DENSE_MAX_K, prm->max_time_ns < 0.
+ */
+sfb_status sfb_qp_dense_solve_batch(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P,
+                                    const double *q, const double *A, const double *l, const double *u,
+                                    const double *warm_x, const double *warm_y, double *x, double *y,
+                                    double *obj, uint32_t *iter, int32_t *code, void *stream);
+
+/* Same with host pointers (H2D copy, solve, D2H copy, synchronous) on the current device. */
+sfb_status sfb_qp_dense_solve_batch_host(const sfb_qp_params *prm, int64_t batch, int n, int m,
+                                         const double *P, const double *q, const double *A, const double *l,
+                                         const double *u, const double *warm_x, const double *warm_y,
+                                         double *x, double *y, double *obj, uint32_t *iter, int32_t *code);
+
+/*
+ * Synthetic workload of the reference benchmark: random_qp(m, n, density, rng)
+ * (benchmarks/bench_types.hpp:19-41) drawn `batch` times from ONE std::default_random_engine
+ * seeded with `seed` (benchmarks/bench.cpp:146,170).  Host buffers, layout as above. CPU only.
+ */
+sfb_status sfb_random_qp_batch(uint32_t seed, int64_t batch, int m, int n, double density, double *P,
+                               double *q, double *A, double *l, double *u);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFB_H */

@@ -1,0 +1,11 @@
+"""smooth_feedback_amd: MI355X-native batched QP / MPC / EKF engine behind the smooth::feedback API.
+
+The compute path is libsfb.so (hand-written HIP for gfx950, C-ABI in include/sfb.h).  This package
+is the thin host-side mirror of the reference interface used by tests and bench.py.
+"""
+from . import _capi  # noqa: F401  (fails loudly if libsfb.so is missing)
+from .qp import (QPBatchSolution, QPSolution, QPSolutionStatus, QPSolver, QPSolverParams,  # noqa: F401
+                 QuadraticProgram, pack_colmajor, random_qp_batch, solve_qp, solve_qp_batch_device,
+                 solve_qp_batch_host)
+
+__version__ = "0.1.0"

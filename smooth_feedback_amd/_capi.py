@@ -1,0 +1,78 @@
+"""ctypes binding of the C-ABI in include/sfb.h (libsfb.so, built in-tree by csrc/Makefile).
+
+The library is the product: there is no Python/CPU fallback.  If libsfb.so is missing the import
+of this module fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsfb.so")
+
+SFB_OK, SFB_ERR_INVALID_ARG, SFB_ERR_UNSUPPORTED, SFB_ERR_HIP, SFB_ERR_NO_DEVICE = range(5)
+
+
+class SfbError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("sfb status %d: %s" % (status, msg))
+        self.status = status
+
+
+class SfbQPParams(C.Structure):
+    """sfb_qp_params == smooth::feedback::QPSolverParams (qp_solver.hpp:29-68)."""
+
+    _fields_ = [
+        ("alpha", C.c_float),
+        ("rho", C.c_float),
+        ("sigma", C.c_float),
+        ("scaling", C.c_int32),
+        ("eps_abs", C.c_float),
+        ("eps_rel", C.c_float),
+        ("eps_primal_inf", C.c_float),
+        ("eps_dual_inf", C.c_float),
+        ("max_iter", C.c_int64),
+        ("max_time_ns", C.c_int64),
+        ("stop_check_iter", C.c_uint32),
+        ("polish", C.c_int32),
+        ("polish_iter", C.c_uint32),
+        ("delta", C.c_float),
+        ("verbose", C.c_int32),
+    ]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libsfb.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C smooth_feedback_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    # torch (when present) bundles its own libamdhip64.so.7; import it first so that exactly one HIP
+    # runtime is mapped into the process and device pointers from torch tensors are valid here.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional plumbing
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, dp, i64, i32 = C.c_void_p, C.c_void_p, C.c_int64, C.c_int
+    L.sfb_version.restype = C.c_char_p
+    L.sfb_last_error.restype = C.c_char_p
+    L.sfb_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.sfb_qp_params_default.argtypes = [C.POINTER(SfbQPParams)]
+    L.sfb_qp_params_default.restype = None
+    L.sfb_qp_dense_solve_batch.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12 + [vp]
+    L.sfb_qp_dense_solve_batch_host.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12
+    L.sfb_random_qp_batch.argtypes = [C.c_uint32, i64, i32, i32, C.c_double] + [dp] * 5
+    return L
+
+
+lib = _load()
+
+
+def check(status):
+    if status != SFB_OK:
+        raise SfbError(status, lib.sfb_last_error().decode())
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib.sfb_device_count(C.byref(n)))
+    return n.value

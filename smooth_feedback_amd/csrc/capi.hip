@@ -1,0 +1,207 @@
+// C-ABI shim (include/sfb.h) over the HIP kernels.  No CPU fallback: every compute entry point
+// needs a HIP device and fails with SFB_ERR_NO_DEVICE / SFB_ERR_HIP otherwise.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/sfb.h"
+#include "qp_dense_kernel.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+sfb_status fail(sfb_status st, const std::string &msg)
+{
+  g_last_error = msg;
+  return st;
+}
+
+sfb_status hip_fail(hipError_t e, const char *what)
+{
+  // clear the sticky error so that later calls report their own failure
+  (void)hipGetLastError();
+  if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver)
+    return fail(SFB_ERR_NO_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+  return fail(SFB_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+sfb_status require_device()
+{
+  int cnt       = 0;
+  hipError_t e  = hipGetDeviceCount(&cnt);
+  if (e != hipSuccess) return hip_fail(e, "hipGetDeviceCount");
+  if (cnt <= 0) return fail(SFB_ERR_NO_DEVICE, "no HIP device visible; the sfb library has no CPU fallback");
+  return SFB_OK;
+}
+
+sfb_status check_qp_args(const sfb_qp_params *prm, int64_t batch, int n, int m, const void *P, const void *q,
+                         const void *A, const void *l, const void *u, const void *wx, const void *wy, const void *x,
+                         const void *y, const void *code)
+{
+  if (!prm) return fail(SFB_ERR_INVALID_ARG, "prm is NULL");
+  if (batch < 0) return fail(SFB_ERR_INVALID_ARG, "batch < 0");
+  if (n < 1 || m < 1) return fail(SFB_ERR_INVALID_ARG, "n and m must be >= 1");
+  if (batch > 0 && (!P || !q || !A || !l || !u || !x || !y || !code))
+    return fail(SFB_ERR_INVALID_ARG, "NULL problem / solution pointer");
+  if ((wx == nullptr) != (wy == nullptr))
+    return fail(SFB_ERR_INVALID_ARG, "warm_x and warm_y must both be given or both be NULL");
+  if (n + m > SFB_QP_DENSE_MAX_K)
+    return fail(SFB_ERR_UNSUPPORTED, "dense kernel needs n+m <= 64 (one QP per wavefront)");
+  if (prm->max_time_ns >= 0)
+    return fail(SFB_ERR_UNSUPPORTED, "max_time is wall-clock and not supported on the device path; use max_iter");
+  if (prm->max_iter > 0xFFFFFFFFll) return fail(SFB_ERR_INVALID_ARG, "max_iter exceeds uint32");
+  if (batch > 0x7FFFFFFFll) return fail(SFB_ERR_UNSUPPORTED, "batch exceeds 2^31-1 per call");
+  return SFB_OK;
+}
+
+sfb::DenseKernelParams make_kernel_params(const sfb_qp_params *prm, int n, int m)
+{
+  sfb::DenseKernelParams kp;
+  kp.n          = n;
+  kp.m          = m;
+  kp.alpha      = static_cast<double>(prm->alpha);  // qp_solver.hpp:354
+  kp.alpha_comp = 1.0 - kp.alpha;                   // :355
+  kp.rho_bar    = static_cast<double>(prm->rho);    // :353
+  kp.sigma      = static_cast<double>(prm->sigma);  // :356
+  kp.eps_abs    = static_cast<double>(prm->eps_abs);
+  kp.eps_rel    = static_cast<double>(prm->eps_rel);
+  kp.eps_pinf   = static_cast<double>(prm->eps_primal_inf);
+  kp.eps_dinf   = static_cast<double>(prm->eps_dual_inf);
+  kp.delta      = static_cast<double>(prm->delta);
+  kp.max_iter   = prm->max_iter < 0 ? (uint32_t)SFB_QP_DEVICE_ITER_CAP : (uint32_t)prm->max_iter;
+  kp.stop_check_iter = prm->stop_check_iter;
+  kp.polish_iter     = prm->polish_iter;
+  kp.scaling         = prm->scaling ? 1 : 0;
+  kp.polish          = prm->polish ? 1 : 0;
+  return kp;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *sfb_version(void) { return "smooth_feedback_amd 0.1.0 (gfx950)"; }
+
+const char *sfb_last_error(void) { return g_last_error.c_str(); }
+
+sfb_status sfb_device_count(int *count)
+{
+  if (!count) return fail(SFB_ERR_INVALID_ARG, "count is NULL");
+  int cnt      = 0;
+  hipError_t e = hipGetDeviceCount(&cnt);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    cnt = 0;
+  }
+  *count = cnt;
+  return SFB_OK;
+}
+
+void sfb_qp_params_default(sfb_qp_params *p)
+{
+  if (!p) return;
+  p->alpha           = 1.6f;
+  p->rho             = 0.1f;
+  p->sigma           = 1e-6f;
+  p->scaling         = 1;
+  p->eps_abs         = 1e-3f;
+  p->eps_rel         = 1e-3f;
+  p->eps_primal_inf  = 1e-4f;
+  p->eps_dual_inf    = 1e-4f;
+  p->max_iter        = -1;
+  p->max_time_ns     = -1;
+  p->stop_check_iter = 25;
+  p->polish          = 1;
+  p->polish_iter     = 5;
+  p->delta           = 1e-6f;
+  p->verbose         = 0;
+}
+
+sfb_status sfb_qp_dense_solve_batch(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P,
+                                    const double *q, const double *A, const double *l, const double *u,
+                                    const double *warm_x, const double *warm_y, double *x, double *y, double *obj,
+                                    uint32_t *iter, int32_t *code, void *stream)
+{
+  sfb_status st = check_qp_args(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, code);
+  if (st != SFB_OK) return st;
+  st = require_device();
+  if (st != SFB_OK) return st;
+  if (batch == 0) return SFB_OK;
+  const sfb::DenseKernelParams kp = make_kernel_params(prm, n, m);
+  hipError_t e = sfb::qp_dense_launch(kp, batch, P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code,
+                                      static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail(e, "qp_dense_kernel launch");
+  return SFB_OK;
+}
+
+sfb_status sfb_qp_dense_solve_batch_host(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P,
+                                         const double *q, const double *A, const double *l, const double *u,
+                                         const double *warm_x, const double *warm_y, double *x, double *y,
+                                         double *obj, uint32_t *iter, int32_t *code)
+{
+  sfb_status st = check_qp_args(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, code);
+  if (st != SFB_OK) return st;
+  st = require_device();
+  if (st != SFB_OK) return st;
+  if (batch == 0) return SFB_OK;
+
+  const size_t B = (size_t)batch, N = (size_t)n, M = (size_t)m;
+  const size_t in_d  = B * (N * N + N + M * N + 2 * M) + (warm_x ? B * (N + M) : 0);
+  const size_t out_d = B * (N + M + 1);
+  char *dev          = nullptr;
+  const size_t bytes = (in_d + out_d) * sizeof(double) + B * (sizeof(uint32_t) + sizeof(int32_t));
+  hipError_t e       = hipMalloc(reinterpret_cast<void **>(&dev), bytes);
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+
+  double *dP = reinterpret_cast<double *>(dev);
+  double *dq = dP + B * N * N;
+  double *dA = dq + B * N;
+  double *dl = dA + B * M * N;
+  double *du = dl + B * M;
+  double *dwx = du + B * M, *dwy = nullptr;
+  double *dx = dwx;
+  if (warm_x) {
+    dwy = dwx + B * N;
+    dx  = dwy + B * M;
+  } else {
+    dwx = nullptr;
+  }
+  double *dy     = dx + B * N;
+  double *dobj   = dy + B * M;
+  uint32_t *dit  = reinterpret_cast<uint32_t *>(dobj + B);
+  int32_t *dcode = reinterpret_cast<int32_t *>(dit + B);
+
+  auto H2D = [&](void *d, const void *h, size_t nb) { return hipMemcpy(d, h, nb, hipMemcpyHostToDevice); };
+  auto D2H = [&](void *h, const void *d, size_t nb) { return hipMemcpy(h, d, nb, hipMemcpyDeviceToHost); };
+  st = SFB_OK;
+  do {
+    if ((e = H2D(dP, P, B * N * N * 8)) != hipSuccess) break;
+    if ((e = H2D(dq, q, B * N * 8)) != hipSuccess) break;
+    if ((e = H2D(dA, A, B * M * N * 8)) != hipSuccess) break;
+    if ((e = H2D(dl, l, B * M * 8)) != hipSuccess) break;
+    if ((e = H2D(du, u, B * M * 8)) != hipSuccess) break;
+    if (warm_x) {
+      if ((e = H2D(dwx, warm_x, B * N * 8)) != hipSuccess) break;
+      if ((e = H2D(dwy, warm_y, B * M * 8)) != hipSuccess) break;
+    }
+    const sfb::DenseKernelParams kp = make_kernel_params(prm, n, m);
+    if ((e = sfb::qp_dense_launch(kp, batch, dP, dq, dA, dl, du, dwx, dwy, dx, dy, dobj, dit, dcode, nullptr)) !=
+        hipSuccess)
+      break;
+    if ((e = hipDeviceSynchronize()) != hipSuccess) break;
+    if ((e = D2H(x, dx, B * N * 8)) != hipSuccess) break;
+    if ((e = D2H(y, dy, B * M * 8)) != hipSuccess) break;
+    if (obj && (e = D2H(obj, dobj, B * 8)) != hipSuccess) break;
+    if (iter && (e = D2H(iter, dit, B * 4)) != hipSuccess) break;
+    if ((e = D2H(code, dcode, B * 4)) != hipSuccess) break;
+  } while (false);
+  if (e != hipSuccess) st = hip_fail(e, "sfb_qp_dense_solve_batch_host");
+  (void)hipFree(dev);
+  return st;
+}
+
+}  // extern "C"

@@ -1,0 +1,138 @@
+// Pivoted LDL' of a small symmetric matrix held in LDS, one wavefront, lane i owns row i (k <= 64).
+//
+// Arithmetic follows Eigen 3.4's LDLT<.,Upper> (the factorisation smooth_feedback uses at
+// qp_solver.hpp:259,428 and :187-188): left-looking, largest-|diagonal| symmetric pivoting on the
+// NOT-yet-updated trailing diagonal, dot-product-then-subtract updates, true divisions.
+// Accumulation order: s = 0; j ascending; s = fma(L(i,j), temp(j), s)  -- identical to
+// oracle/qp_oracle.c so that both produce the same bits.
+#pragma once
+#include <cfloat>
+
+#include "wave_util.h"
+
+namespace sfb {
+
+// W: row-major, leading dimension ld (odd => conflict-free column walks), lower triangle valid.
+// perm[k] (LDS): composed row permutation, (P b)[i] = b[perm[i]].  temp[k] (LDS) scratch.
+// Returns 1 on success, 0 on failure (Eigen info()==NumericalIssue).  Wave-uniform.
+__device__ inline int ldlt_factor_lds(const int k, double *W, const int ld, int *perm, double *temp, const int lane)
+{
+  if (lane < k) perm[lane] = lane;
+  wave_sync();
+  if (k <= 1) return 1;
+
+  int ret = 1, found_zero_pivot = 0;
+  const bool inmat = lane < k;
+
+  for (int kk = 0; kk < k; ++kk) {
+    // pivot: first index of the largest |diag| among rows kk..k-1
+    const double dg = inmat ? W[lane * ld + lane] : 0.0;
+    const bool cand = inmat && lane >= kk;
+    const double a  = cand ? fabs(dg) : -1.0;
+    const double mx = wave_max(a);
+    unsigned long long bal = wave_ballot(cand && a == mx);
+    // all-NaN diagonal: nothing compares equal; keep kk (the oracle's strict '>' does the same)
+    const int p = bal ? (int)__builtin_ctzll(bal) : kk;
+
+    if (p != kk) {
+      if (lane == 0) {
+        const int t = perm[kk];
+        perm[kk]    = perm[p];
+        perm[p]     = t;
+      }
+      if (lane < kk) {  // row(kk).head(kk) <-> row(p).head(kk)
+        const double a1   = W[kk * ld + lane];
+        const double a2   = W[p * ld + lane];
+        W[kk * ld + lane] = a2;
+        W[p * ld + lane]  = a1;
+      } else if (lane == kk) {  // diagonal entries
+        const double a1 = W[kk * ld + kk];
+        const double a2 = W[p * ld + p];
+        W[kk * ld + kk] = a2;
+        W[p * ld + p]   = a1;
+      } else if (lane < p) {  // kk < i < p : W(i,kk) <-> W(p,i)
+        const double a1   = W[lane * ld + kk];
+        const double a2   = W[p * ld + lane];
+        W[lane * ld + kk] = a2;
+        W[p * ld + lane]  = a1;
+      } else if (lane > p && inmat) {  // col(kk).tail <-> col(p).tail
+        const double a1   = W[lane * ld + kk];
+        const double a2   = W[lane * ld + p];
+        W[lane * ld + kk] = a2;
+        W[lane * ld + p]  = a1;
+      }
+      wave_sync();
+    }
+
+    // temp(j) = D(j) * L(kk,j), j < kk
+    if (lane < kk) temp[lane] = W[lane * ld + lane] * W[kk * ld + lane];
+    wave_sync();
+
+    double val = 0.0;
+    if (cand) {
+      double s = 0.0;
+      for (int j = 0; j < kk; ++j) s = fma(W[lane * ld + j], temp[j], s);
+      val = W[lane * ld + kk];
+      if (kk > 0) val -= s;
+    }
+    const double akk = lane_bcast(val, kk);
+    const bool valid = fabs(akk) > 0.0;
+
+    if (kk == 0 && !valid) {
+      // whole diagonal is zero: success iff the strictly lower triangle is zero (perm = identity)
+      bool nz = false;
+      if (inmat)
+        for (int j = 0; j < lane; ++j) nz = nz || !(W[lane * ld + j] == 0.0);
+      return wave_ballot(nz) ? 0 : 1;
+    }
+
+    if (lane == kk) W[kk * ld + kk] = val;
+    if (cand && lane > kk) {
+      if (valid) val = val / akk;
+      W[lane * ld + kk] = val;
+    }
+    if (!valid) {
+      if (wave_ballot(cand && lane > kk && !(val == 0.0))) ret = 0;
+    }
+    if (found_zero_pivot && valid) {
+      ret = 0;
+    } else if (!valid) {
+      found_zero_pivot = 1;
+    }
+    wave_sync();
+  }
+  return ret;
+}
+
+// Generic (runtime k) solve with the factor in LDS:  P b -> L^-1 -> D^-1 -> L^-T -> P^T.
+// `b` is lane i's entry of the right-hand side in ORIGINAL order; returns lane i's entry of the
+// solution in original order.  xch[k] (LDS) scratch.  Same accumulation order as the oracle:
+// forward j ascending, backward j descending.
+__device__ inline double ldlt_solve_lds(const int k, const double *W, const int ld, const int *perm, double *xch,
+                                        double b, const int lane)
+{
+  const bool inmat = lane < k;
+  if (inmat) xch[lane] = b;
+  wave_sync();
+  double x = inmat ? xch[perm[lane]] : 0.0;
+  wave_sync();
+  for (int j = 0; j < k - 1; ++j) {
+    const double xj = lane_bcast(x, j);
+    if (inmat && lane > j) x = fma(-W[lane * ld + j], xj, x);
+  }
+  if (inmat) {
+    const double d = W[lane * ld + lane];
+    x              = (fabs(d) > DBL_MIN) ? x / d : 0.0;
+  }
+  for (int j = k - 1; j > 0; --j) {
+    const double xj = lane_bcast(x, j);
+    if (lane < j) x = fma(-W[j * ld + lane], xj, x);
+  }
+  if (inmat) xch[perm[lane]] = x;
+  wave_sync();
+  const double r = inmat ? xch[lane] : 0.0;
+  wave_sync();
+  return r;
+}
+
+}  // namespace sfb

@@ -1,0 +1,27 @@
+// Host<->kernel interface of the dense QP kernel (internal; the public boundary is include/sfb.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace sfb {
+
+// QPSolverParams (qp_solver.hpp:29-68) with the float members already widened to double exactly as
+// the reference does at :353-356 / :587 / :593 / :605 / :630.
+struct DenseKernelParams {
+  int n, m;
+  double alpha, alpha_comp, rho_bar, sigma;
+  double eps_abs, eps_rel, eps_pinf, eps_dinf, delta;
+  uint32_t max_iter;  // effective bound (prm.max_iter or SFB_QP_DEVICE_ITER_CAP)
+  uint32_t stop_check_iter;
+  uint32_t polish_iter;
+  int scaling, polish;
+};
+
+size_t qp_dense_lds_bytes(int n, int m);
+
+hipError_t qp_dense_launch(const DenseKernelParams &kp, int64_t batch, const double *P, const double *q,
+                           const double *A, const double *l, const double *u, const double *wx, const double *wy,
+                           double *x, double *y, double *obj, uint32_t *iter, int32_t *code, hipStream_t stream);
+
+}  // namespace sfb

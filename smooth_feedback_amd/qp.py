@@ -1,0 +1,203 @@
+"""Python mirror of the reference's QP interface (qp.hpp, qp_solver.hpp) over the C-ABI.
+
+Names, argument meaning and error behaviour follow smooth::feedback:
+  QuadraticProgram (qp.hpp:31-45), QPSolutionStatus (:82-92), QPSolution (:95-108),
+  QPSolverParams (qp_solver.hpp:29-68), QPSolver (:242-757), solve_qp (:779-787).
+The batch entry points (`solve_qp_batch`) are the data-parallel extension this engine adds.
+All numerics run in the HIP kernels; nothing here computes.
+"""
+import ctypes as C
+import enum
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+from . import _capi
+
+
+class QPSolutionStatus(enum.IntEnum):
+    """qp.hpp:82-92"""
+    Optimal = 0
+    PolishFailed = 1
+    PrimalInfeasible = 2
+    DualInfeasible = 3
+    MaxIterations = 4
+    MaxTime = 5
+    Unknown = 6
+
+
+@dataclass
+class QPSolverParams:
+    """qp_solver.hpp:29-68 (float members are rounded to binary32 like the reference's)."""
+    verbose: bool = False
+    alpha: float = 1.6
+    rho: float = 0.1
+    sigma: float = 1e-6
+    scaling: bool = True
+    eps_abs: float = 1e-3
+    eps_rel: float = 1e-3
+    eps_primal_inf: float = 1e-4
+    eps_dual_inf: float = 1e-4
+    max_iter: Optional[int] = None
+    max_time: Optional[float] = None  # seconds; rejected by the device path when set
+    stop_check_iter: int = 25
+    polish: bool = True
+    polish_iter: int = 5
+    delta: float = 1e-6
+
+    def to_c(self):
+        p = _capi.SfbQPParams()
+        _capi.lib.sfb_qp_params_default(C.byref(p))
+        p.verbose = int(self.verbose)
+        p.alpha, p.rho, p.sigma = self.alpha, self.rho, self.sigma
+        p.scaling = int(self.scaling)
+        p.eps_abs, p.eps_rel = self.eps_abs, self.eps_rel
+        p.eps_primal_inf, p.eps_dual_inf = self.eps_primal_inf, self.eps_dual_inf
+        p.max_iter = -1 if self.max_iter is None else int(self.max_iter)
+        p.max_time_ns = -1 if self.max_time is None else int(self.max_time * 1e9)
+        p.stop_check_iter = int(self.stop_check_iter)
+        p.polish = int(self.polish)
+        p.polish_iter = int(self.polish_iter)
+        p.delta = self.delta
+        return p
+
+
+@dataclass
+class QuadraticProgram:
+    """qp.hpp:31-45: min 1/2 x'Px + q'x  s.t.  l <= Ax <= u.  P (n,n), q (n,), A (m,n), l,u (m,)."""
+    P: np.ndarray
+    q: np.ndarray
+    A: np.ndarray
+    l: np.ndarray
+    u: np.ndarray
+
+
+@dataclass
+class QPSolution:
+    """qp.hpp:95-108"""
+    code: QPSolutionStatus = QPSolutionStatus.Unknown
+    iter: int = 0
+    primal: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    dual: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    objective: float = 0.0
+
+
+@dataclass
+class QPBatchSolution:
+    code: np.ndarray
+    iter: np.ndarray
+    primal: np.ndarray
+    dual: np.ndarray
+    objective: np.ndarray
+
+
+def _f64(a, shape):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.shape != shape:
+        raise ValueError("expected shape %s, got %s" % (shape, a.shape))
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def pack_colmajor(M):
+    """(B, rows, cols) -> (B, rows*cols) column-major buffers (Eigen default layout, qp.hpp:35-41)."""
+    M = np.asarray(M, dtype=np.float64)
+    return np.ascontiguousarray(np.transpose(M, (0, 2, 1)).reshape(M.shape[0], -1))
+
+
+def solve_qp_batch_host(P, q, A, l, u, prm: Optional[QPSolverParams] = None, warm_x=None, warm_y=None):
+    """Batched solve_qp on host numpy buffers.  P (B, n*n) and A (B, m*n) are COLUMN-major flat
+    buffers (see pack_colmajor), q (B,n), l,u (B,m).  Calls sfb_qp_dense_solve_batch_host."""
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    l = np.ascontiguousarray(l, dtype=np.float64)
+    if q.ndim != 2 or l.ndim != 2:
+        raise ValueError("q and l must be (batch, n) / (batch, m)")
+    B, n = q.shape
+    m = l.shape[1]
+    P = _f64(P, (B, n * n))
+    A = _f64(A, (B, m * n))
+    u = _f64(u, (B, m))
+    if (warm_x is None) != (warm_y is None):
+        raise ValueError("warm_x and warm_y must be given together")
+    if warm_x is not None:
+        warm_x = _f64(warm_x, (B, n))
+        warm_y = _f64(warm_y, (B, m))
+    x = np.empty((B, n))
+    y = np.empty((B, m))
+    obj = np.empty(B)
+    it = np.empty(B, dtype=np.uint32)
+    code = np.empty(B, dtype=np.int32)
+    cp = (prm or QPSolverParams()).to_c()
+    _capi.check(_capi.lib.sfb_qp_dense_solve_batch_host(
+        C.byref(cp), B, n, m, _ptr(P), _ptr(q), _ptr(A), _ptr(l), _ptr(u), _ptr(warm_x), _ptr(warm_y),
+        _ptr(x), _ptr(y), _ptr(obj), _ptr(it), _ptr(code)))
+    return QPBatchSolution(code=code, iter=it, primal=x, dual=y, objective=obj)
+
+
+def solve_qp_batch_device(B, n, m, dP, dq, dA, dl, du, dx, dy, dobj, diter, dcode, prm=None,
+                          dwarm_x=0, dwarm_y=0, stream=0):
+    """Asynchronous batched solve on DEVICE pointers (ints), e.g. torch tensors' data_ptr().
+    Calls sfb_qp_dense_solve_batch on `stream` (a hipStream_t handle as int, 0 = default)."""
+    cp = (prm or QPSolverParams()).to_c()
+    _capi.check(_capi.lib.sfb_qp_dense_solve_batch(
+        C.byref(cp), B, n, m, dP, dq, dA, dl, du, dwarm_x or None, dwarm_y or None, dx, dy,
+        dobj or None, diter or None, dcode, stream or None))
+
+
+class QPSolver:
+    """QPSolver<QuadraticProgram<M,N,double>>, qp_solver.hpp:242-757 (dense problems, n+m <= 64)."""
+
+    def __init__(self, pbm: Optional[QuadraticProgram] = None, prm: Optional[QPSolverParams] = None):
+        self.prm_ = prm or QPSolverParams()
+        self.sol_ = QPSolution()
+        if pbm is not None:
+            self.analyze(pbm)
+
+    def analyze(self, pbm: QuadraticProgram):
+        """qp_solver.hpp:297-338: size the solution (the device kernel owns its workspace in LDS)."""
+        A = np.asarray(pbm.A)
+        self.sol_.primal = np.zeros(A.shape[1])
+        self.sol_.dual = np.zeros(A.shape[0])
+
+    def sol(self) -> QPSolution:
+        return self.sol_
+
+    def solve(self, pbm: QuadraticProgram, warmstart: Optional[QPSolution] = None) -> QPSolution:
+        """qp_solver.hpp:343-568"""
+        P = np.asarray(pbm.P, dtype=np.float64)
+        A = np.asarray(pbm.A, dtype=np.float64)
+        m, n = A.shape
+        wx = wy = None
+        if warmstart is not None:
+            wx = np.asarray(warmstart.primal, dtype=np.float64).reshape(1, n)
+            wy = np.asarray(warmstart.dual, dtype=np.float64).reshape(1, m)
+        r = solve_qp_batch_host(
+            pack_colmajor(P.reshape(1, n, n)), np.asarray(pbm.q, dtype=np.float64).reshape(1, n),
+            pack_colmajor(A.reshape(1, m, n)), np.asarray(pbm.l, dtype=np.float64).reshape(1, m),
+            np.asarray(pbm.u, dtype=np.float64).reshape(1, m), self.prm_, wx, wy)
+        self.sol_ = QPSolution(code=QPSolutionStatus(int(r.code[0])), iter=int(r.iter[0]), primal=r.primal[0],
+                               dual=r.dual[0], objective=float(r.objective[0]))
+        return self.sol_
+
+
+def solve_qp(pbm: QuadraticProgram, prm: Optional[QPSolverParams] = None,
+             warmstart: Optional[QPSolution] = None) -> QPSolution:
+    """qp_solver.hpp:779-787"""
+    return QPSolver(pbm, prm).solve(pbm, warmstart)
+
+
+def random_qp_batch(seed, batch, m, n, density):
+    """benchmarks/bench_types.hpp:19-41 drawn `batch` times from std::default_random_engine(seed).
+    Returns flat col-major buffers (P, q, A, l, u) as in solve_qp_batch_host."""
+    P = np.empty((batch, n * n))
+    q = np.empty((batch, n))
+    A = np.empty((batch, m * n))
+    l = np.empty((batch, m))
+    u = np.empty((batch, m))
+    _capi.check(_capi.lib.sfb_random_qp_batch(seed, batch, m, n, float(density), _ptr(P), _ptr(q), _ptr(A),
+                                              _ptr(l), _ptr(u)))
+    return P, q, A, l, u

@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """CPU oracle (test infrastructure). Built on demand with gcc."""
+    from oracle import loader
+    loader.lib()
+    return loader
+
+
+@pytest.fixture(scope="session")
+def sfb():
+    """The product package; importing it loads libsfb.so (built by __graft_entry__.build())."""
+    lib_path = os.path.join(ROOT, "smooth_feedback_amd", "libsfb.so")
+    if not os.path.exists(lib_path):
+        import __graft_entry__ as g
+        g.build()
+    import smooth_feedback_amd
+    return smooth_feedback_amd

@@ -1,0 +1,80 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/sfb.h declares.
+No compute call is made here (there is no CPU fallback to call)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    names = set()
+    inc = os.path.join(ROOT, "include")
+    for fn in os.listdir(inc):
+        if fn.endswith(".h"):
+            txt = open(os.path.join(inc, fn)).read()
+            txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+            names |= set(re.findall(r"\b(sfb_[a-z0-9_]+)\s*\(", txt))
+    return names
+
+
+def test_exports_every_declared_symbol(sfb):
+    lib = ctypes.CDLL(sfb._capi.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 6
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_params_struct_matches_oracle_layout(sfb, oracle):
+    a, b = sfb._capi.SfbQPParams, oracle.OracleQPParams
+    assert ctypes.sizeof(a) == ctypes.sizeof(b)
+    assert [(n, t) for n, t in a._fields_] == [(n, t) for n, t in b._fields_]
+    pa, pb = a(), b()
+    sfb._capi.lib.sfb_qp_params_default(ctypes.byref(pa))
+    oracle.lib().oracle_qp_params_default(ctypes.byref(pb))
+    assert bytes(pa) == bytes(pb)
+
+
+def test_argument_errors_do_not_need_a_device(sfb):
+    import numpy as np
+    P, q, A, l, u = sfb.random_qp_batch(5, 2, 20, 10, 1.0)
+    # n + m > 64 is rejected before any device work
+    try:
+        sfb.solve_qp_batch_host(np.zeros((1, 40 * 40)), np.zeros((1, 40)), np.zeros((1, 30 * 40)),
+                                np.zeros((1, 30)), np.zeros((1, 30)))
+        assert False
+    except sfb._capi.SfbError as e:
+        assert e.status == sfb._capi.SFB_ERR_UNSUPPORTED
+    # wall-clock limit is rejected on the device path
+    try:
+        sfb.solve_qp_batch_host(P, q, A, l, u, sfb.QPSolverParams(max_time=1.0))
+        assert False
+    except sfb._capi.SfbError as e:
+        assert e.status == sfb._capi.SFB_ERR_UNSUPPORTED
+
+
+def test_no_silent_cpu_fallback(sfb):
+    """Without a GPU the compute entry point must FAIL, never compute on the CPU."""
+    if sfb._capi.device_count() > 0:
+        return
+    P, q, A, l, u = sfb.random_qp_batch(5, 2, 20, 10, 1.0)
+    try:
+        sfb.solve_qp_batch_host(P, q, A, l, u)
+        assert False, "compute call succeeded without a device"
+    except sfb._capi.SfbError as e:
+        assert e.status in (sfb._capi.SFB_ERR_NO_DEVICE, sfb._capi.SFB_ERR_HIP)
+
+
+def test_random_qp_generator_properties(sfb):
+    """benchmarks/bench_types.hpp:19-41: l = -inf, P = L L' symmetric PSD, u = A v + delta."""
+    import numpy as np
+    P, q, A, l, u = sfb.random_qp_batch(5, 8, 20, 10, 0.3)
+    assert np.all(np.isneginf(l)) and np.all(np.isfinite(u))
+    for b in range(8):
+        Pb = P[b].reshape(10, 10, order="F")
+        assert np.allclose(Pb, Pb.T) and np.linalg.eigvalsh(Pb).min() > -1e-12
+    assert np.all(np.abs(q) <= 1) and np.all(np.abs(A) <= 1)
+    assert 0.15 < np.mean(A != 0) < 0.45
+    P2, *_ = sfb.random_qp_batch(5, 8, 20, 10, 0.3)
+    assert np.array_equal(P, P2)

@@ -1,0 +1,201 @@
+"""Parity of the HIP dense-QP kernel (through the C-ABI) with the CPU oracle.  Needs an MI355X.
+
+Bar: status codes and iteration counts bit-exact; primal/dual within 1e-8 absolute of the oracle
+(BASELINE.json north_star: 'matching reference primal/dual ... to 1e-8').  In practice the kernel
+follows the oracle's operation order, so the tests also report whether results are bit-identical.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from qp_cases import KNOWN_ANSWERS, as_batch, is_approx
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _oracle_params(oracle, prm):
+    return oracle.default_params(
+        alpha=prm.alpha, rho=prm.rho, sigma=prm.sigma, scaling=int(prm.scaling), eps_abs=prm.eps_abs,
+        eps_rel=prm.eps_rel, eps_primal_inf=prm.eps_primal_inf, eps_dual_inf=prm.eps_dual_inf,
+        max_iter=-1 if prm.max_iter is None else prm.max_iter, stop_check_iter=prm.stop_check_iter,
+        polish=int(prm.polish), polish_iter=prm.polish_iter, delta=prm.delta)
+
+
+def _compare(r, ref, tol=TOL):
+    assert np.array_equal(r.code, ref["code"]), np.nonzero(r.code != ref["code"])
+    assert np.array_equal(r.iter, ref["iter"]), np.nonzero(r.iter != ref["iter"])
+    fin = np.isfinite(ref["x"]).all(axis=1) & np.isfinite(ref["y"]).all(axis=1)
+    scale = 1.0 + np.maximum(np.abs(ref["x"]).max(axis=1), np.abs(ref["y"]).max(axis=1))[fin]
+    dx = np.abs(r.primal - ref["x"])[fin].max(axis=1) / scale
+    dy = np.abs(r.dual - ref["y"])[fin].max(axis=1) / scale
+    assert dx.max(initial=0) <= tol and dy.max(initial=0) <= tol, (dx.max(), dy.max())
+    do = np.abs(r.objective - ref["obj"])[fin] / (1.0 + np.abs(ref["obj"])[fin])
+    assert do.max(initial=0) <= 1e-7
+    return bool(np.array_equal(r.primal, ref["x"]) and np.array_equal(r.dual, ref["y"]))
+
+
+@pytest.mark.parametrize("name", sorted(KNOWN_ANSWERS))
+def test_known_answers(sfb, oracle, name):
+    """tests/test_qp.cpp:54-336 through the device path, incl. the hot start from own solution."""
+    case = KNOWN_ANSWERS[name]
+    P, q, A, l, u = as_batch(case)
+    prm = sfb.QPSolverParams(max_iter=100000)
+    r = sfb.solve_qp_batch_host(P, q, A, l, u, prm)
+    code, primal, ptol, objv, otol = case[5:]
+    assert int(r.code[0]) == code
+    if primal is not None:
+        assert is_approx(r.primal[0], primal, ptol)
+    if objv is not None:
+        assert abs(r.objective[0] - objv) <= otol
+    ref = oracle.qp_dense_solve_batch(P, q, A, l, u, params=_oracle_params(oracle, prm))
+    _compare(r, ref)
+    r2 = sfb.solve_qp_batch_host(P, q, A, l, u, prm, warm_x=r.primal, warm_y=r.dual)
+    ref2 = oracle.qp_dense_solve_batch(P, q, A, l, u, params=_oracle_params(oracle, prm), warm_x=ref["x"],
+                                       warm_y=ref["y"])
+    assert int(r2.code[0]) == code
+    _compare(r2, ref2)
+
+
+def test_reference_style_api(sfb):
+    """QuadraticProgram / solve_qp / QPSolver mirror (tests/test_qp.cpp BasicStatic, SolverAPI)."""
+    pbm = sfb.QuadraticProgram(P=np.eye(2), q=np.array([-4, 0.25]), A=np.eye(2), l=np.array([-1., -1.]),
+                               u=np.array([1., 1.]))
+    sol = sfb.solve_qp(pbm, sfb.QPSolverParams(polish=True))
+    assert sol.code == sfb.QPSolutionStatus.Optimal
+    assert is_approx(sol.primal, [1, -0.25], 1e-4)
+    assert abs(sol.objective - (0.5 - 4 - 1 / 32)) < 1e-4
+    hs = sfb.solve_qp(pbm, sfb.QPSolverParams(), sol)
+    assert hs.code == sfb.QPSolutionStatus.Optimal and is_approx(hs.primal, [1, -0.25], 1e-4)
+    s1 = sfb.QPSolver(pbm)
+    a = s1.solve(pbm)
+    b = sfb.QPSolver(pbm).solve(pbm)
+    assert np.array_equal(a.primal, b.primal) and s1.sol() is a
+
+
+@pytest.mark.parametrize("tag", ["default", "bench"])
+def test_golden_fixture(sfb, tag):
+    """Committed golden vectors (tests/golden/make_golden.py; densities 0.05/0.3/1.0, n=10, m=20)."""
+    g = np.load(os.path.join(GOLD, "qp_dense_random.npz"))
+    kw = json.loads(str(g["params_json"]))[tag]
+    prm = sfb.QPSolverParams(**{k: (bool(v) if k in ("polish", "scaling") else v) for k, v in kw.items()})
+    r = sfb.solve_qp_batch_host(g["P"], g["q"], g["A"], g["l"], g["u"], prm)
+    ref = {k: g["%s_%s" % (tag, k)] for k in ("code", "iter", "x", "y", "obj")}
+    _compare(r, ref)
+
+
+@pytest.mark.parametrize("density", [0.05, 0.3, 1.0])
+@pytest.mark.parametrize("tag", ["default", "bench"])
+def test_random_batches_n10_m20(sfb, oracle, density, tag):
+    """BASELINE configs[1] shape (n=10, m=20) at oracle-sized batches."""
+    B = 1024
+    P, q, A, l, u = sfb.random_qp_batch(7, B, 20, 10, density)
+    if tag == "bench":  # benchmarks/bench.cpp:148-153
+        prm = sfb.QPSolverParams(eps_abs=1e-6, eps_rel=1e-6, polish=True, max_iter=10000, scaling=False)
+    else:
+        prm = sfb.QPSolverParams(max_iter=20000)
+    r = sfb.solve_qp_batch_host(P, q, A, l, u, prm)
+    ref = oracle.qp_dense_solve_batch(P, q, A, l, u, params=_oracle_params(oracle, prm), nthreads=8)
+    bit = _compare(r, ref)
+    print("density", density, tag, "bit-identical primal/dual:", bit, "codes", np.bincount(r.code, minlength=7))
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (2, 3), (3, 13), (5, 11), (10, 6), (16, 16), (12, 28), (20, 28),
+                                 (24, 40), (32, 32), (8, 56)])
+def test_other_sizes(sfb, oracle, n, m):
+    """every kernel specialisation (k<=16, <=32, <=48, <=64) incl. ragged sizes and k == 64"""
+    B = 96
+    P, q, A, l, u = sfb.random_qp_batch(11 + n, B, m, n, 0.7)
+    # mix of constraint kinds: two-sided, equality, free rows (exercise all rho classes, qp_solver.hpp:366-373)
+    rng = np.random.default_rng(n * 100 + m)
+    l = np.where(rng.random((B, m)) < 0.4, u - rng.random((B, m)) * 2.0, l)
+    eq = rng.random((B, m)) < 0.1
+    l = np.where(eq, u, l)
+    free = rng.random((B, m)) < 0.1
+    l = np.where(free, -np.inf, l)
+    u = np.where(free, np.inf, u)
+    prm = sfb.QPSolverParams(max_iter=3000)
+    r = sfb.solve_qp_batch_host(P, q, A, l, u, prm)
+    ref = oracle.qp_dense_solve_batch(P, q, A, l, u, params=_oracle_params(oracle, prm), nthreads=8)
+    _compare(r, ref)
+
+
+def test_no_polish_no_scaling_and_stop_check_variants(sfb, oracle):
+    B = 256
+    P, q, A, l, u = sfb.random_qp_batch(3, B, 20, 10, 1.0)
+    for prm in (sfb.QPSolverParams(polish=False, max_iter=2000),
+                sfb.QPSolverParams(scaling=False, max_iter=2000),
+                sfb.QPSolverParams(stop_check_iter=1, max_iter=60),     # never checks: qp_solver.hpp:465
+                sfb.QPSolverParams(stop_check_iter=7, max_iter=2000, alpha=1.0, rho=1.0),
+                sfb.QPSolverParams(max_iter=0), sfb.QPSolverParams(max_iter=1), sfb.QPSolverParams(max_iter=2)):
+        r = sfb.solve_qp_batch_host(P, q, A, l, u, prm)
+        ref = oracle.qp_dense_solve_batch(P, q, A, l, u, params=_oracle_params(oracle, prm), nthreads=8)
+        _compare(r, ref)
+
+
+def test_warm_start_batch(sfb, oracle):
+    B = 256
+    P, q, A, l, u = sfb.random_qp_batch(9, B, 20, 10, 1.0)
+    prm = sfb.QPSolverParams(max_iter=5000)
+    op = _oracle_params(oracle, prm)
+    ref = oracle.qp_dense_solve_batch(P, q, A, l, u, params=op, nthreads=8)
+    wx = np.where(np.isfinite(ref["x"]), ref["x"], 0.0)
+    wy = np.where(np.isfinite(ref["y"]), ref["y"], 0.0)
+    q2 = q + 0.01
+    r = sfb.solve_qp_batch_host(P, q2, A, l, u, prm, warm_x=wx, warm_y=wy)
+    ref2 = oracle.qp_dense_solve_batch(P, q2, A, l, u, params=op, warm_x=wx, warm_y=wy, nthreads=8)
+    _compare(r, ref2)
+
+
+def test_empty_batch_and_device_pointer_api(sfb, oracle):
+    import torch
+    r = sfb.solve_qp_batch_host(np.zeros((0, 100)), np.zeros((0, 10)), np.zeros((0, 200)), np.zeros((0, 20)),
+                                np.zeros((0, 20)))
+    assert r.code.shape == (0,)
+    B, m, n = 512, 20, 10
+    P, q, A, l, u = sfb.random_qp_batch(5, B, m, n, 1.0)
+    dev = torch.device("cuda:0")
+    t = {k: torch.from_numpy(v).to(dev) for k, v in dict(P=P, q=q, A=A, l=l, u=u).items()}
+    x = torch.empty((B, n), dtype=torch.float64, device=dev)
+    y = torch.empty((B, m), dtype=torch.float64, device=dev)
+    obj = torch.empty(B, dtype=torch.float64, device=dev)
+    it = torch.empty(B, dtype=torch.int32, device=dev)
+    code = torch.empty(B, dtype=torch.int32, device=dev)
+    prm = sfb.QPSolverParams(max_iter=4000)
+    stream = torch.cuda.current_stream()
+    sfb.solve_qp_batch_device(B, n, m, t["P"].data_ptr(), t["q"].data_ptr(), t["A"].data_ptr(), t["l"].data_ptr(),
+                              t["u"].data_ptr(), x.data_ptr(), y.data_ptr(), obj.data_ptr(), it.data_ptr(),
+                              code.data_ptr(), prm, stream=stream.cuda_stream)
+    stream.synchronize()
+    ref = oracle.qp_dense_solve_batch(P, q, A, l, u, params=_oracle_params(oracle, prm), nthreads=8)
+    assert np.array_equal(code.cpu().numpy(), ref["code"])
+    assert np.array_equal(it.cpu().numpy().astype(np.uint32), ref["iter"])
+    assert np.abs(x.cpu().numpy() - ref["x"]).max() <= TOL
+
+
+def test_full_size_batch_properties(sfb):
+    """BASELINE configs[1] at full size (65 536 QPs): size-independent properties instead of the
+    oracle: (i) determinism / batch-position independence (a permuted batch gives permuted results),
+    (ii) every Optimal solution satisfies the KKT residual bounds the stopping test promises."""
+    B, m, n = 65536, 20, 10
+    P, q, A, l, u = sfb.random_qp_batch(5, B, m, n, 1.0)
+    prm = sfb.QPSolverParams(eps_abs=1e-6, eps_rel=1e-6, polish=True, max_iter=10000, scaling=False)
+    r = sfb.solve_qp_batch_host(P, q, A, l, u, prm)
+    perm = np.random.default_rng(0).permutation(B)
+    r2 = sfb.solve_qp_batch_host(P[perm], q[perm], A[perm], l[perm], u[perm], prm)
+    assert np.array_equal(r2.code, r.code[perm]) and np.array_equal(r2.iter, r.iter[perm])
+    assert np.array_equal(r2.primal, r.primal[perm]) and np.array_equal(r2.dual, r.dual[perm])
+    opt = r.code == 0
+    assert opt.sum() > B // 4
+    Pm = P.reshape(B, n, n).transpose(0, 2, 1)[opt]
+    Am = A.reshape(B, n, m).transpose(0, 2, 1)[opt]
+    x, y = r.primal[opt], r.dual[opt]
+    Ax = np.einsum("bij,bj->bi", Am, x)
+    assert (Ax - u[opt]).max() <= 1e-5                              # primal feasibility (l = -inf)
+    res = np.einsum("bij,bj->bi", Pm, x) + q[opt] + np.einsum("bji,bj->bi", Am, y)
+    assert np.abs(res).max() <= 1e-4                                # stationarity
+    assert y.min() >= -1e-9                                         # dual sign for upper-bounded rows
+    assert np.abs(y * (Ax - u[opt])).max() <= 1e-4                  # complementarity
