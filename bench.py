@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native batched QP engine.
+
+    python bench.py --gpus N --steps K --warmup W [--workload qp_dense|...]
+
+One "step" = one pass of the hot path (sfb_qp_dense_solve_batch, HIP) over one batch of synthetic
+QPs that is already resident in HBM.  For N > 1 the driver launches one rank per GPU with
+torch.distributed.run; every rank owns an independent shard of the batch (weak scaling: per-GPU
+batch fixed), the data path has no collective, and only the per-QP (code, iter) words are
+gathered over RCCL at the end of each step.  Rank 0 prints ONE JSON line.
+
+The CPU oracle (oracle/) is used here ONLY for the `cpu_baseline` leg and a parity spot-check of a
+bounded sample; it is never the thing measured as `value`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_BYTES_PER_S = 8.0e12  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def qp_dense_algorithmic_bytes(n, m):
+    """P,q,A,l,u in; x,y,obj,iter,code out."""
+    return 8 * (n * n + n + m * n + 2 * m) + 8 * (n + m + 1) + 8
+
+
+class DenseQPWorkload:
+    """BASELINE.json configs[1]: batch = 65 536 random dense fp64 QPs, n=10, m=20, generator and
+    solver parameters of benchmarks/bench.cpp:146-153 / bench_types.hpp:19-41 (density 1.0)."""
+    name = "qp_dense_n10_m20_b65536_density1.0_benchparams"
+
+    def __init__(self, sfb, rank, device, batch=65536, n=10, m=20, density=1.0):
+        self.sfb, self.B, self.n, self.m = sfb, batch, n, m
+        self.prm = sfb.QPSolverParams(eps_abs=1e-6, eps_rel=1e-6, polish=True, max_iter=10000, scaling=False)
+        # std::default_random_engine(5) for rank 0 (the reference's seed), 5 + rank for the other shards
+        self.host = sfb.random_qp_batch(5 + rank, batch, m, n, density)
+        self.dev = [torch.from_numpy(a).to(device) for a in self.host]
+        f64 = dict(dtype=torch.float64, device=device)
+        self.x = torch.empty((batch, n), **f64)
+        self.y = torch.empty((batch, m), **f64)
+        self.obj = torch.empty(batch, **f64)
+        self.out = torch.empty((2, batch), dtype=torch.int32, device=device)  # [iter; code]
+        self.units_per_step = batch
+        self.bytes_per_unit = qp_dense_algorithmic_bytes(n, m)
+
+    def step(self, stream):
+        P, q, A, l, u = self.dev
+        self.sfb.solve_qp_batch_device(self.B, self.n, self.m, P.data_ptr(), q.data_ptr(), A.data_ptr(),
+                                       l.data_ptr(), u.data_ptr(), self.x.data_ptr(), self.y.data_ptr(),
+                                       self.obj.data_ptr(), self.out[0].data_ptr(), self.out[1].data_ptr(),
+                                       self.prm, stream=stream.cuda_stream)
+
+    def small_outputs(self):
+        return self.out
+
+    def cpu_baseline(self, cores, budget_s=15.0):
+        """Oracle (CPU restatement of the reference ADMM) on a bounded sample of the same batch."""
+        from oracle import loader as O
+        op = O.default_params(eps_abs=1e-6, eps_rel=1e-6, polish=1, max_iter=10000, scaling=0)
+        P, q, A, l, u = self.host
+        probe = min(self.B, 64 * cores)
+        t0 = time.perf_counter()
+        O.qp_dense_solve_batch(P[:probe], q[:probe], A[:probe], l[:probe], u[:probe], params=op, nthreads=cores)
+        rate = probe / (time.perf_counter() - t0)
+        S = int(min(self.B, max(probe, rate * budget_s)))
+        t0 = time.perf_counter()
+        ref = O.qp_dense_solve_batch(P[:S], q[:S], A[:S], l[:S], u[:S], params=op, nthreads=cores)
+        dt = time.perf_counter() - t0
+        x = self.x[:S].cpu().numpy()
+        it = self.out[0, :S].cpu().numpy().astype(np.uint32)
+        code = self.out[1, :S].cpu().numpy()
+        fin = np.isfinite(ref["x"]).all(axis=1)
+        parity = {
+            "sample": S,
+            "code_mismatches": int((code != ref["code"]).sum()),
+            "iter_mismatches": int((it != ref["iter"]).sum()),
+            "max_abs_dx": float(np.abs(x - ref["x"])[fin].max(initial=0.0)),
+        }
+        return {"value": S / dt, "unit": "QP solves/s", "cores": cores, "kind": "port",
+                "sample": "first %d QPs of rank 0's batch, oracle/qp_oracle.c (CPU restatement of the "
+                          "reference ADMM, %d pthreads, static partition), %.1f s" % (S, cores, dt)}, parity
+
+
+WORKLOADS = {"qp_dense": DenseQPWorkload}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="qp_dense", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    import smooth_feedback_amd as sfb
+
+    kw = {} if args.batch is None else {"batch": args.batch}
+    wl = WORKLOADS[args.workload](sfb, rank, device, **kw)
+    stream = torch.cuda.current_stream()
+    gathered = None
+    if world > 1:
+        gathered = [torch.empty_like(wl.small_outputs()) for _ in range(world)]
+
+    def one_step():
+        wl.step(stream)
+        if world > 1:  # the only exchange on this path: final gather of the small outputs (RCCL/xGMI)
+            dist.all_gather(gathered, wl.small_outputs())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)   # HIP events on the stream the kernel is launched on
+        wl.step(stream)
+        ev[k][1].record(stream)
+        if world > 1:
+            dist.all_gather(gathered, wl.small_outputs())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank == 0:
+        units = wl.units_per_step * world * args.steps
+        value = units / elapsed
+        achieved = wl.units_per_step * wl.bytes_per_unit / (kern_ms * 1e-3)
+        rec = {
+            "metric": "QP solves/sec",
+            "value": value,
+            "unit": "QP solves/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": wl.name, "per_gpu_batch": wl.B, "global_batch": wl.B * world,
+                       "parallelism": "batch-sharded x%d, gather of (iter,code) only" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_BYTES_PER_S, "traffic": None,
+                         "kernel": "qp_dense_kernel", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_unit": wl.bytes_per_unit,
+                         "note": "iterative latency/FP64-issue-bound kernel: HBM fraction is structurally tiny"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cores = os.cpu_count() or 1
+            rec["cpu_baseline"], rec["parity_vs_oracle"] = wl.cpu_baseline(cores)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

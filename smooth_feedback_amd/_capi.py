@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsfb.so")
+LIB_PATH = os.environ.get("SFB_LIB_PATH") or os.path.join(_HERE, "libsfb.so")  # env: A/B builds only
 
 SFB_OK, SFB_ERR_INVALID_ARG, SFB_ERR_UNSUPPORTED, SFB_ERR_HIP, SFB_ERR_NO_DEVICE = range(5)
 

@@ -22,6 +22,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 #include "../../include/sfb.h"
 #include "ldlt_wave.h"
@@ -292,8 +293,11 @@ __device__ inline void qp_polish(const Lds &s, const DenseKernelParams &kp, cons
 
 // KP: compile-time bound on k (register-resident factor rows);  LC_REGS: keep L's columns in VGPRs
 // too (backward sweep without LDS traffic).
+#ifndef SFB_QP_WAVES_PER_EU
+#define SFB_QP_WAVES_PER_EU 2
+#endif
 template<int KP, bool LC_REGS>
-__global__ void __launch_bounds__(64) qp_dense_kernel(const DenseKernelParams kp, const double *__restrict__ gP,
+__global__ void __launch_bounds__(64, SFB_QP_WAVES_PER_EU) qp_dense_kernel(const DenseKernelParams kp, const double *__restrict__ gP,
                                                       const double *__restrict__ gq, const double *__restrict__ gA,
                                                       const double *__restrict__ gl, const double *__restrict__ gu,
                                                       const double *__restrict__ gwx, const double *__restrict__ gwy,
@@ -418,26 +422,25 @@ __global__ void __launch_bounds__(64) qp_dense_kernel(const DenseKernelParams kp
   uint32_t iter        = 0;
   const uint32_t sci   = kp.stop_check_iter;
   const uint32_t maxit = kp.max_iter;
+  // iter % sci == 1 (:465) without a per-iteration division: checks at 1, 1+sci, ...; never for sci<=1
+  uint32_t next_chk = (sci >= 2) ? 1u : 0xFFFFFFFFu;
   for (; iter != maxit && ret_code < 0; ++iter) {
     // right-hand side :450-451 (already in permuted lane order)
     double t = isx ? (kp.sigma * xs - qc) : (isc ? (zs - rinv * ys) : 0.0);
 
     // K^-1 t : forward sweep, D^-1, backward sweep :462
+    // (steps j >= k-1 multiply zero-padded factor entries: exact no-ops, no per-step branch)
 #pragma unroll
     for (int j = 0; j < KP - 1; ++j) {
-      if (j < k - 1) {
-        const double tj = lane_bcast(t, j);
-        t               = fma(-Lr[j], tj, t);
-      }
+      const double tj = lane_bcast(t, j);
+      t               = fma(-Lr[j], tj, t);
     }
     t = (fabs(dgi) > DBL_MIN) ? t / dgi : 0.0;
     if constexpr (LC_REGS) {
 #pragma unroll
       for (int j = KP - 1; j > 0; --j) {
-        if (j < k) {
-          const double tj = lane_bcast(t, j);
-          t               = fma(-Lc[j], tj, t);
-        }
+        const double tj = lane_bcast(t, j);
+        t               = fma(-Lc[j], tj, t);
       }
     } else {
       for (int j = k - 1; j > 0; --j) {
@@ -447,7 +450,8 @@ __global__ void __launch_bounds__(64) qp_dense_kernel(const DenseKernelParams kp
       }
     }
 
-    const bool chk    = (sci != 0) && (iter % sci == 1);  // :465
+    const bool chk = (iter == next_chk);  // :465
+    if (chk) next_chk += sci;
     const double xold = xs, yold = ys;
 
     // :470-477
@@ -523,7 +527,8 @@ hipError_t qp_dense_launch(const DenseKernelParams &kp, int64_t batch, const dou
                            double *x, double *y, double *obj, uint32_t *iter, int32_t *code, hipStream_t stream)
 {
   const int k        = kp.n + kp.m;
-  const size_t lds   = qp_dense_lds_bytes(kp.n, kp.m);
+  size_t lds         = qp_dense_lds_bytes(kp.n, kp.m);
+  if (const char *pad = getenv("SFB_QP_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments only
   const dim3 grid((unsigned)batch), block(kWave);
 #define SFB_LAUNCH(KPV, LCR)                                                                                   \
   hipLaunchKernelGGL((qp_dense_kernel<KPV, LCR>), grid, block, lds, stream, kp, P, q, A, l, u, wx, wy, x, y, \
