@@ -12,8 +12,11 @@ __device__ __forceinline__ double bcast(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+#ifndef NOPSTR
+#define NOPSTR "s_nop 1\n\t"
+#endif
 template<int J> __device__ __forceinline__ void fmac_dpp(double &t, double negL) {
-  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+  asm volatile(NOPSTR "v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
                : "+v"(t) : "v"(negL), "n"(J));
 }
 
@@ -56,7 +59,7 @@ int main() {
   srand(1);
   for (auto &v : h) v = (rand() / (double)RAND_MAX - 0.5) * 0.1;
   double *din, *dout; long long *dc;
-  hipMalloc(&din, h.size() * 8); hipMalloc(&dout, 64 * 8 * 4096); hipMalloc(&dc, 8 * 4096);
+  hipMalloc(&din, h.size() * 8); hipMalloc(&dout, 64 * 8 * 8192); hipMalloc(&dc, 8 * 8192);
   hipMemcpy(din, h.data(), h.size() * 8, hipMemcpyHostToDevice);
   // CPU reference for the DPP form (MODE 2 == MODE 1 semantics within a 16-lane row) -- 1 rep
   auto run = [&](auto kern, const char *name, int blocks) {
@@ -72,7 +75,7 @@ int main() {
     printf("%-28s blocks=%5d  %7.2f ticks/step (s_memtime, 100MHz?)  wall %8.3f ms -> %7.2f ns/step/wave  out0=%g out17=%g\n",
            name, blocks, (double)c / (reps * 16.0), ms, ms * 1e6 / (reps * 16.0), o[0], o[17]);
   };
-  for (int blocks : {1, 1024, 2048, 4096}) {
+  for (int blocks : {1, 4096, 8192}) {
     run(k<0>, "fma chain", blocks);
     run(k<1>, "readlane+fma", blocks);
     run(k<2>, "fmac_dpp newbcast", blocks);

@@ -38,11 +38,11 @@ struct Lds {
   int *perm, *LU;
 };
 
-__device__ __forceinline__ Lds carve(double *base, int n, int m, int k, int ld)
+__device__ __forceinline__ Lds carve(double *base, int n, int m, int k)
 {
   Lds s;
   double *p = base;
-  s.W    = p; p += k * ld;
+  s.W    = p; p += (k * (k + 1)) >> 1;
   s.P    = p; p += n * n;
   s.A    = p; p += m * n;
   s.q    = p; p += n;
@@ -210,7 +210,7 @@ __device__ inline int qp_check_stopping(const Lds &s, const DenseKernelParams &k
 
 // detail::polish_qp, qp_solver.hpp:92-204 (dense branch).  In: scaled primal in xv[n], scaled dual in
 // yv[m] (LDS, original order).  Out: the same arrays updated on success.  Reuses W/perm/temp.
-__device__ inline void qp_polish(const Lds &s, const DenseKernelParams &kp, const int n, const int m, const int ld,
+__device__ inline void qp_polish(const Lds &s, const DenseKernelParams &kp, const int n, const int m,
                                  const double c, const int lane)
 {
   const double inf = INFINITY, eps = DBL_EPSILON;
@@ -236,20 +236,20 @@ __device__ inline void qp_polish(const Lds &s, const DenseKernelParams &kp, cons
     for (int cc = 0; cc <= r; ++cc) {
       double v = c * s.sx[cc] * s.P[cc + r * n] * sxr;
       if (cc == r) v += kp.delta;
-      s.W[r * ld + cc] = v;
+      s.W[tri(r, cc)] = v;
     }
     h = -c * (sxr * s.q[r]);
   } else if (lane < K) {
     const int a = lane - n, row = s.LU[a];
     const double syr = s.sy[row];
-    for (int j = 0; j < n; ++j) s.W[lane * ld + j] = syr * s.A[row + j * m] * s.sx[j];
-    for (int j = n; j < lane; ++j) s.W[lane * ld + j] = 0.0;
-    s.W[lane * ld + lane] = 0.0 - kp.delta;
+    for (int j = 0; j < n; ++j) s.W[tri(lane, j)] = syr * s.A[row + j * m] * s.sx[j];
+    for (int j = n; j < lane; ++j) s.W[tri(lane, j)] = 0.0;
+    s.W[tri(lane, lane)] = 0.0 - kp.delta;
     h                     = (a < nl) ? syr * s.l[row] : syr * s.u[row];
   }
   wave_sync();
 
-  if (!ldlt_factor_lds(K, s.W, ld, s.perm, s.temp, lane)) return;  // :187-190
+  if (!ldlt_factor_lds(K, s.W, s.perm, s.temp, lane)) return;  // :187-190
 
   // :192-195  t += Hp^-1 (h - Hsym t); Hsym entries are recomputed (same products as above)
   double t = 0.0;
@@ -280,7 +280,7 @@ __device__ inline void qp_polish(const Lds &s, const DenseKernelParams &kp, cons
       res = h - acc;
     }
     wave_sync();
-    const double d = ldlt_solve_lds(K, s.W, ld, s.perm, xch, res, lane);
+    const double d = ldlt_solve_lds(K, s.W, s.perm, xch, res, lane);
     t += d;
   }
   // :199-201
@@ -291,12 +291,67 @@ __device__ inline void qp_polish(const Lds &s, const DenseKernelParams &kp, cons
 
 }  // namespace
 
-// KP: compile-time bound on k (register-resident factor rows);  LC_REGS: keep L's columns in VGPRs
-// too (backward sweep without LDS traffic).
+// Triangular-sweep engines of the ADMM loop (all produce the same bits):
+//   SWEEP_READLANE      k <= KP: rows AND columns of L in VGPRs, pivot broadcast by v_readlane
+//   SWEEP_READLANE_LDS  k <= KP: rows of L in VGPRs, backward sweep reads L' from LDS
+//   SWEEP_DPP32         k <= 32: 16x16 blocks of L in VGPRs, pivot broadcast fused into the FMA by
+//                       DPP row_newbcast (v_fmac_f64_dpp); forward sweep on lanes 0-31 (rows 0,1),
+//                       backward sweep on lanes 32-63 (rows 2,3) sharing the same registers.
+enum { SWEEP_READLANE = 0, SWEEP_READLANE_LDS = 1, SWEEP_DPP32 = 2 };
+
 #ifndef SFB_QP_WAVES_PER_EU
 #define SFB_QP_WAVES_PER_EU 2
 #endif
-template<int KP, bool LC_REGS>
+
+template<int J>
+struct DppSweep {
+  // forward, ascending j: rows 0 / 1 in-row chains and the row-1 update by block 0
+  static __device__ __forceinline__ void fwd_diag0(double &t, const double (&A)[16])
+  {
+    if constexpr (J < 15) {
+      fmac_rowbcast_self<J, 0x1>(t, A[J]);
+      DppSweep<J + 1>::fwd_diag0(t, A);
+    }
+  }
+  static __device__ __forceinline__ void fwd_diag1(double &t, const double (&A)[16])
+  {
+    if constexpr (J < 15) {
+      fmac_rowbcast_self<J, 0x2>(t, A[J]);
+      DppSweep<J + 1>::fwd_diag1(t, A);
+    }
+  }
+  static __device__ __forceinline__ void fwd_off(double &t, const double x, const double (&B)[16])
+  {
+    if constexpr (J < 16) {
+      fmac_rowbcast<J, 0x2>(t, x, B[J]);
+      DppSweep<J + 1>::fwd_off(t, x, B);
+    }
+  }
+  // backward, descending j (J counts 15 -> 0): rows 3 / 2
+  static __device__ __forceinline__ void bwd_diag1(double &t, const double (&A)[16])
+  {
+    if constexpr (J >= 1) {
+      fmac_rowbcast_self<J, 0x8>(t, A[J]);
+      DppSweep<J - 1>::bwd_diag1(t, A);
+    }
+  }
+  static __device__ __forceinline__ void bwd_diag0(double &t, const double (&A)[16])
+  {
+    if constexpr (J >= 1) {
+      fmac_rowbcast_self<J, 0x4>(t, A[J]);
+      DppSweep<J - 1>::bwd_diag0(t, A);
+    }
+  }
+  static __device__ __forceinline__ void bwd_off(double &t, const double x, const double (&B)[16])
+  {
+    if constexpr (J >= 0) {
+      fmac_rowbcast<J, 0x4>(t, x, B[J]);
+      DppSweep<J - 1>::bwd_off(t, x, B);
+    }
+  }
+};
+
+template<int KP, int MODE>
 __global__ void __launch_bounds__(64, SFB_QP_WAVES_PER_EU) qp_dense_kernel(const DenseKernelParams kp, const double *__restrict__ gP,
                                                       const double *__restrict__ gq, const double *__restrict__ gA,
                                                       const double *__restrict__ gl, const double *__restrict__ gu,
@@ -308,9 +363,8 @@ __global__ void __launch_bounds__(64, SFB_QP_WAVES_PER_EU) qp_dense_kernel(const
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane   = threadIdx.x;
   const int n      = kp.n, m = kp.m, k = n + m;
-  const int ld     = k | 1;
   const size_t b   = blockIdx.x;
-  const Lds s      = carve(smem, n, m, k, ld);
+  const Lds s      = carve(smem, n, m, k);
   const double inf = INFINITY;
 
   // ---- load the problem (coalesced, batch-major contiguous) ----
@@ -361,32 +415,62 @@ __global__ void __launch_bounds__(64, SFB_QP_WAVES_PER_EU) qp_dense_kernel(const
     for (int cc = 0; cc <= r; ++cc) {
       double v = c * s.sx[cc] * s.P[cc + r * n] * sxr;
       if (cc == r) v += kp.sigma;
-      s.W[r * ld + cc] = v;
+      s.W[tri(r, cc)] = v;
     }
   } else if (lane < k) {
     const int i      = lane - n;
     const double syi = s.sy[i];
-    for (int j = 0; j < n; ++j) s.W[lane * ld + j] = syi * s.A[i + j * m] * s.sx[j];
-    for (int j = n; j < lane; ++j) s.W[lane * ld + j] = 0.0;
-    s.W[lane * ld + lane] = 1.0 / (-s.rho[i]);
+    for (int j = 0; j < n; ++j) s.W[tri(lane, j)] = syi * s.A[i + j * m] * s.sx[j];
+    for (int j = n; j < lane; ++j) s.W[tri(lane, j)] = 0.0;
+    s.W[tri(lane, lane)] = 1.0 / (-s.rho[i]);
   }
   wave_sync();
 
   // ---- pivoted LDL' :428-433 ----
-  if (!ldlt_factor_lds(k, s.W, ld, s.perm, s.temp, lane)) ret_code = SFB_QP_UNKNOWN;
+  if (!ldlt_factor_lds(k, s.W, s.perm, s.temp, lane)) ret_code = SFB_QP_UNKNOWN;
 
   // ---- register-resident factor: Lr[j] = L(i,j) (j<i), Lc[j] = L(j,i) (j>i), d = D(i) ----
-  double Lr[KP];
+  constexpr bool LC_REGS = (MODE == SWEEP_READLANE);
+  constexpr bool DPP     = (MODE == SWEEP_DPP32);
+  double Lr[DPP ? 1 : KP];
   double Lc[LC_REGS ? KP : 1];
+  double Ad[DPP ? 16 : 1], Bo[DPP ? 16 : 1];  // negated 16x16 blocks (SWEEP_DPP32)
   double dgi = 1.0;
   const bool inmat = lane < k;
+  if constexpr (!DPP) {
 #pragma unroll
-  for (int j = 0; j < KP; ++j) Lr[j] = (inmat && j < lane && j < k) ? s.W[lane * ld + j] : 0.0;
-  if constexpr (LC_REGS) {
+    for (int j = 0; j < KP; ++j) Lr[j] = (inmat && j < lane && j < k) ? s.W[tri(lane, j)] : 0.0;
+    if constexpr (LC_REGS) {
 #pragma unroll
-    for (int j = 0; j < KP; ++j) Lc[j] = (inmat && j > lane && j < k) ? s.W[j * ld + lane] : 0.0;
+      for (int j = 0; j < KP; ++j) Lc[j] = (inmat && j > lane && j < k) ? s.W[tri(j, lane)] : 0.0;
+    }
+  } else {
+    // lane = 16*row + cc.  rows 0,1: forward, system row i = lane;  rows 2,3: backward, column
+    // i = lane - 32.  Ad = diagonal block, Bo = off-diagonal block, zero outside the factor.
+    const int row = lane >> 4, cc = lane & 15;
+    const int i   = (row & 1) * 16 + cc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      double a = 0.0, bb = 0.0;
+      if (i < k) {
+        if (row == 0) {
+          if (j < i) a = s.W[tri(i, j)];
+        } else if (row == 1) {
+          if (16 + j < i) a = s.W[tri(i, 16 + j)];
+          bb = s.W[tri(i, j)];
+        } else if (row == 2) {
+          if (j > i) a = s.W[tri(j, i)];                  // j < 16 <= k is not guaranteed:
+          if (j >= k) a = 0.0;                             //   k < 16 leaves these outside the factor
+          if (16 + j < k) bb = s.W[tri(16 + j, i)];
+        } else {
+          if (16 + j > i && 16 + j < k) a = s.W[tri(16 + j, i)];
+        }
+      }
+      Ad[j] = -a;
+      Bo[j] = -bb;
+    }
   }
-  if (inmat) dgi = s.W[lane * ld + lane];
+  if (inmat) dgi = s.W[tri(lane, lane)];
 
   // ---- lane role: variable v = perm[lane] ----
   const int v     = inmat ? s.perm[lane] : 0;
@@ -430,6 +514,25 @@ __global__ void __launch_bounds__(64, SFB_QP_WAVES_PER_EU) qp_dense_kernel(const
 
     // K^-1 t : forward sweep, D^-1, backward sweep :462
     // (steps j >= k-1 multiply zero-padded factor entries: exact no-ops, no per-step branch)
+    if constexpr (DPP) {
+      double ev, od, lo2, hi2;
+      DppSweep<0>::fwd_diag0(t, Ad);       // rows 0..15, in-row pivot broadcast
+      cross_lane_fence(t);
+      row_swap16(t, ev, od);               // block-0 solution -> row 1
+      DppSweep<0>::fwd_off(t, ev, Bo);     // rows 16..31 -= L10 * x0 (j ascending)
+      DppSweep<0>::fwd_diag1(t, Ad);       // rows 16..31
+      t = (fabs(dgi) > DBL_MIN) ? t / dgi : 0.0;
+      half_swap32(t, lo2, hi2);            // lanes 32..63 <- lanes 0..31
+      t = lo2;
+      DppSweep<15>::bwd_diag1(t, Ad);      // row 3: block 1, j descending
+      cross_lane_fence(t);
+      row_swap16(t, ev, od);               // block-1 solution -> row 2
+      DppSweep<15>::bwd_off(t, od, Bo);    // row 2: block 0 -= L10' * x1 (j descending)
+      DppSweep<15>::bwd_diag0(t, Ad);      // row 2: block 0
+      cross_lane_fence(t);
+      half_swap32(t, lo2, hi2);            // lanes 0..31 <- lanes 32..63
+      t = hi2;
+    } else {
 #pragma unroll
     for (int j = 0; j < KP - 1; ++j) {
       const double tj = lane_bcast(t, j);
@@ -445,9 +548,10 @@ __global__ void __launch_bounds__(64, SFB_QP_WAVES_PER_EU) qp_dense_kernel(const
     } else {
       for (int j = k - 1; j > 0; --j) {
         const double tj = lane_bcast(t, j);
-        const double lj = (lane < j) ? s.W[j * ld + lane] : 0.0;
+        const double lj = (lane < j) ? s.W[tri(j, lane)] : 0.0;
         t               = fma(-lj, tj, t);
       }
+    }
     }
 
     const bool chk = (iter == next_chk);  // :465
@@ -484,7 +588,7 @@ __global__ void __launch_bounds__(64, SFB_QP_WAVES_PER_EU) qp_dense_kernel(const
   wave_sync();
 
   // ---- polish :515-539 (a failed polish leaves Optimal, cf. :537 vs :544) ----
-  if (ret_code == SFB_QP_OPTIMAL && kp.polish) qp_polish(s, kp, n, m, ld, c, lane);
+  if (ret_code == SFB_QP_OPTIMAL && kp.polish) qp_polish(s, kp, n, m, c, lane);
 
   // ---- un-scale and report :544-548 ----
   double xo = 0.0;
@@ -516,8 +620,8 @@ __global__ void __launch_bounds__(64, SFB_QP_WAVES_PER_EU) qp_dense_kernel(const
 
 size_t qp_dense_lds_bytes(int n, int m)
 {
-  const int k = n + m, ld = k | 1;
-  const size_t doubles = (size_t)k * ld + (size_t)n * n + (size_t)m * n + 5 * (size_t)n + 8 * (size_t)m + (size_t)k;
+  const int k = n + m;
+  const size_t doubles = ((size_t)k * (k + 1)) / 2 + (size_t)n * n + (size_t)m * n + 5 * (size_t)n + 8 * (size_t)m + (size_t)k;
   const size_t ints    = (size_t)k + (size_t)m;
   return doubles * sizeof(double) + ((ints * sizeof(int) + 15) / 16) * 16;
 }
@@ -530,17 +634,20 @@ hipError_t qp_dense_launch(const DenseKernelParams &kp, int64_t batch, const dou
   size_t lds         = qp_dense_lds_bytes(kp.n, kp.m);
   if (const char *pad = getenv("SFB_QP_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments only
   const dim3 grid((unsigned)batch), block(kWave);
-#define SFB_LAUNCH(KPV, LCR)                                                                                   \
-  hipLaunchKernelGGL((qp_dense_kernel<KPV, LCR>), grid, block, lds, stream, kp, P, q, A, l, u, wx, wy, x, y, \
+#define SFB_LAUNCH(KPV, MODE)                                                                                   \
+  hipLaunchKernelGGL((qp_dense_kernel<KPV, MODE>), grid, block, lds, stream, kp, P, q, A, l, u, wx, wy, x, y, \
                      obj, iter, code)
-  if (k <= 16) {
-    SFB_LAUNCH(16, true);
+  static const int force_mode = getenv("SFB_QP_SWEEP") ? atoi(getenv("SFB_QP_SWEEP")) : -1;  // A/B only
+  if (k <= 32 && force_mode != SWEEP_READLANE) {
+    SFB_LAUNCH(32, SWEEP_DPP32);
+  } else if (k <= 16) {
+    SFB_LAUNCH(16, SWEEP_READLANE);
   } else if (k <= 32) {
-    SFB_LAUNCH(32, true);
+    SFB_LAUNCH(32, SWEEP_READLANE);
   } else if (k <= 48) {
-    SFB_LAUNCH(48, false);
+    SFB_LAUNCH(48, SWEEP_READLANE_LDS);
   } else {
-    SFB_LAUNCH(64, false);
+    SFB_LAUNCH(64, SWEEP_READLANE_LDS);
   }
 #undef SFB_LAUNCH
   return hipGetLastError();
