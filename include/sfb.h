@@ -118,6 +118,54 @@ sfb_status sfb_qp_dense_solve_batch_host(const sfb_qp_params *prm, int64_t batch
                                          const double *u, const double *warm_x, const double *warm_y,
                                          double *x, double *y, double *obj, uint32_t *iter, int32_t *code);
 
+/* ------------------------------------------------------------------------------------------
+ * Sparse QPs sharing ONE sparsity pattern (a swarm of MPC problems from the same transcription).
+ *
+ * Layout follows QuadraticProgramSparse (qp.hpp:60-79): P in CSC (Eigen::SparseMatrix default)
+ * exactly as the caller stores it -- only entries with col >= row enter the KKT matrix
+ * (qp_solver.hpp:384) while residuals/objective multiply by P as stored (:589,:547) --, A in CSR
+ * (Eigen::RowMajor, qp.hpp:74).  Index arrays are shared by the batch; values are per item:
+ *   Px [batch][nnzP], q [batch][n], Ax [batch][nnzA], l,u [batch][m].
+ * Indices must be strictly ascending inside each column of P / row of A (Eigen compressed form).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct sfb_sparse_qp_plan sfb_sparse_qp_plan; /* opaque */
+
+/*
+ * Symbolic analysis, once per pattern.  Replaces QPSolver<QuadraticProgramSparse>::analyze
+ * (qp_solver.hpp:297-338) and SimplicialLDLT::analyzePattern (:424): KKT pattern, fill-reducing
+ * elimination order, pattern of L.  Host only (no device needed).
+ *   ordering: 0 natural, 1 minimum degree (Eigen's AMD is not reproducible without Eigen; any
+ *   fill-reducing order yields the same algorithm up to rounding);  user_perm (n+m entries,
+ *   new -> old, nullable) overrides `ordering`.
+ */
+sfb_status sfb_sparse_qp_plan_create(int n, int m, const int32_t *P_colptr, const int32_t *P_rowind,
+                                     const int32_t *A_rowptr, const int32_t *A_colind, int ordering,
+                                     const int32_t *user_perm, sfb_sparse_qp_plan **plan);
+void sfb_sparse_qp_plan_destroy(sfb_sparse_qp_plan *plan);
+/* nnz of the KKT upper triangle, nnz of L (strictly lower), bytes of device workspace PER ITEM. */
+sfb_status sfb_sparse_qp_plan_info(const sfb_sparse_qp_plan *plan, int64_t *nnzK, int64_t *nnzL,
+                                   int64_t *workspace_bytes_per_item);
+/* The elimination order in use (n+m entries, new -> old). */
+sfb_status sfb_sparse_qp_plan_get_perm(const sfb_sparse_qp_plan *plan, int32_t *perm);
+
+/*
+ * Batched sparse solve (device pointers, asynchronous on `stream`).  Replaces, per item,
+ * QPSolver<QuadraticProgramSparse<double>>::solve(pbm, warmstart) (qp_solver.hpp:343-568 with the
+ * sparse branches :379-397, :423-426, :452-460) as called by MPC::operator() (mpc.hpp:491).
+ * `workspace`: device buffer of batch * workspace_bytes_per_item bytes (caller-owned, reusable).
+ * Outputs as sfb_qp_dense_solve_batch.
+ */
+sfb_status sfb_sparse_qp_solve_batch(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
+                                     const double *Px, const double *q, const double *Ax, const double *l,
+                                     const double *u, const double *warm_x, const double *warm_y, double *x,
+                                     double *y, double *obj, uint32_t *iter, int32_t *code, void *workspace,
+                                     void *stream);
+/* Same with host pointers (allocates the workspace internally; synchronous). */
+sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
+                                          const double *Px, const double *q, const double *Ax, const double *l,
+                                          const double *u, const double *warm_x, const double *warm_y,
+                                          double *x, double *y, double *obj, uint32_t *iter, int32_t *code);
+
 /*
  * Synthetic workload of the reference benchmark: random_qp(m, n, density, rng)
  * (benchmarks/bench_types.hpp:19-41) drawn `batch` times from ONE std::default_random_engine

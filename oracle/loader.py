@@ -59,6 +59,12 @@ def lib():
             C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_int,
         ]
         L.oracle_qp_dense_solve_batch.restype = C.c_int
+        ip = C.POINTER(C.c_int32)
+        L.oracle_qp_sparse_solve_batch.argtypes = [
+            C.POINTER(OracleQPParams), C.c_int64, C.c_int, C.c_int, ip, ip, dp, dp, ip, ip, dp, dp, dp,
+            ip, dp, dp, dp, dp, dp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_int,
+            C.POINTER(C.c_int64)]
+        L.oracle_qp_sparse_solve_batch.restype = C.c_int
         L.oracle_ldlt_factor.argtypes = [C.c_int, dp, C.c_int, C.POINTER(C.c_int)]
         L.oracle_ldlt_factor.restype = C.c_int
         L.oracle_ldlt_solve.argtypes = [C.c_int, dp, C.c_int, C.POINTER(C.c_int), dp]
@@ -119,3 +125,40 @@ def qp_dense_solve_batch(P, q, A, l, u, params=None, warm_x=None, warm_y=None, n
 def colmajor(M):
     """Flatten a 2-D (rows, cols) numpy matrix into the col-major buffer the C side expects."""
     return np.asarray(M, dtype=np.float64).flatten(order="F")
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
+
+
+def qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Ax, l, u, perm=None, params=None, warm_x=None, warm_y=None,
+                          nthreads=1):
+    """Sparse branch.  P CSC (Pp, Pi) with values Px (B, nnzP); A CSR (Ap, Aj) with values Ax (B, nnzA).
+    perm: elimination order of the (n+m) KKT unknowns (new -> old) or None (natural)."""
+    Pp = np.ascontiguousarray(Pp, dtype=np.int32); Pi = np.ascontiguousarray(Pi, dtype=np.int32)
+    Ap = np.ascontiguousarray(Ap, dtype=np.int32); Aj = np.ascontiguousarray(Aj, dtype=np.int32)
+    q = np.ascontiguousarray(q, dtype=np.float64); l = np.ascontiguousarray(l, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    B, n = q.shape
+    m = l.shape[1]
+    Px = np.ascontiguousarray(Px, dtype=np.float64).reshape(B, -1)
+    Ax = np.ascontiguousarray(Ax, dtype=np.float64).reshape(B, -1)
+    assert Px.shape[1] == Pp[n] and Ax.shape[1] == Ap[m] and len(Pp) == n + 1 and len(Ap) == m + 1
+    if perm is not None:
+        perm = np.ascontiguousarray(perm, dtype=np.int32)
+        assert sorted(perm.tolist()) == list(range(n + m))
+    if warm_x is not None:
+        warm_x = np.ascontiguousarray(warm_x, dtype=np.float64)
+        warm_y = np.ascontiguousarray(warm_y, dtype=np.float64)
+    x = np.zeros((B, n)); y = np.zeros((B, m)); obj = np.zeros(B)
+    it = np.zeros(B, dtype=np.uint32); code = np.zeros(B, dtype=np.int32)
+    nnzL = C.c_int64(0)
+    p = params if params is not None else default_params()
+    rc = lib().oracle_qp_sparse_solve_batch(
+        C.byref(p), B, n, m, _ip(Pp), _ip(Pi), _dp(Px), _dp(q), _ip(Ap), _ip(Aj), _dp(Ax), _dp(l), _dp(u),
+        _ip(perm), _dp(warm_x), _dp(warm_y), _dp(x), _dp(y), _dp(obj),
+        it.ctypes.data_as(C.POINTER(C.c_uint32)), code.ctypes.data_as(C.POINTER(C.c_int32)), int(nthreads),
+        C.byref(nnzL))
+    if rc != 0:
+        raise RuntimeError("oracle_qp_sparse_solve_batch failed rc=%d" % rc)
+    return dict(x=x, y=y, obj=obj, iter=it, code=code, nnzL=nnzL.value)

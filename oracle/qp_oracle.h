@@ -78,6 +78,19 @@ int oracle_qp_dense_solve_batch(const oracle_qp_params *prm, int64_t batch, int 
                                 double *obj, uint32_t *iter, int32_t *code, int nthreads);
 
 /*
+ * Sparse branch (oracle/qp_sparse_oracle.c): QPSolver<QuadraticProgramSparse<double>>::solve for a
+ * batch sharing one sparsity pattern.  P: CSC (Pp[n+1], Pi) as stored; A: CSR (Ap[m+1], Aj)
+ * (qp.hpp:60-79); Px [batch][nnzP], Ax [batch][nnzA].  perm[n+m]: elimination order of the KKT
+ * matrix (new -> old), NULL = natural.  nnzL_out (nullable): fill of the factor.
+ */
+int oracle_qp_sparse_solve_batch(const oracle_qp_params *prm, int64_t batch, int n, int m, const int32_t *Pp,
+                                 const int32_t *Pi, const double *Px, const double *q, const int32_t *Ap,
+                                 const int32_t *Aj, const double *Ax, const double *l, const double *u,
+                                 const int32_t *perm, const double *warm_x, const double *warm_y, double *x,
+                                 double *y, double *obj, uint32_t *iter, int32_t *code, int nthreads,
+                                 int64_t *nnzL_out);
+
+/*
  * Restatement of Eigen 3.4 LDLT (unblocked, diagonal pivoting) exposed for unit tests.
  * W: k*k row-major work matrix, lower triangle (incl. diagonal) holds the symmetric input on
  * entry and L (unit, strictly lower) + D (diagonal) on exit.  tr[k]: transpositions.

@@ -6,6 +6,6 @@ is the thin host-side mirror of the reference interface used by tests and bench.
 from . import _capi  # noqa: F401  (fails loudly if libsfb.so is missing)
 from .qp import (QPBatchSolution, QPSolution, QPSolutionStatus, QPSolver, QPSolverParams,  # noqa: F401
                  QuadraticProgram, pack_colmajor, random_qp_batch, solve_qp, solve_qp_batch_device,
-                 solve_qp_batch_host)
+                 solve_qp_batch_host, QuadraticProgramSparse, SparseQPPlan, solve_qp_sparse)
 
 __version__ = "0.1.0"

@@ -60,6 +60,14 @@ def _load():
     L.sfb_qp_params_default.restype = None
     L.sfb_qp_dense_solve_batch.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12 + [vp]
     L.sfb_qp_dense_solve_batch_host.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12
+    i32p = C.c_void_p
+    L.sfb_sparse_qp_plan_create.argtypes = [i32, i32, i32p, i32p, i32p, i32p, i32, i32p, C.POINTER(C.c_void_p)]
+    L.sfb_sparse_qp_plan_destroy.argtypes = [C.c_void_p]
+    L.sfb_sparse_qp_plan_destroy.restype = None
+    L.sfb_sparse_qp_plan_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.sfb_sparse_qp_plan_get_perm.argtypes = [C.c_void_p, i32p]
+    L.sfb_sparse_qp_solve_batch.argtypes = [C.c_void_p, C.POINTER(SfbQPParams), i64] + [dp] * 12 + [vp, vp]
+    L.sfb_sparse_qp_solve_batch_host.argtypes = [C.c_void_p, C.POINTER(SfbQPParams), i64] + [dp] * 12
     L.sfb_random_qp_batch.argtypes = [C.c_uint32, i64, i32, i32, C.c_double] + [dp] * 5
     return L
 

@@ -8,11 +8,12 @@
 #include <string>
 
 #include "../../include/sfb.h"
+#include "capi_common.h"
 #include "qp_dense_kernel.h"
 
-namespace {
+namespace sfb {
 
-thread_local std::string g_last_error;
+namespace { thread_local std::string g_last_error; }
 
 sfb_status fail(sfb_status st, const std::string &msg)
 {
@@ -38,6 +39,37 @@ sfb_status require_device()
   return SFB_OK;
 }
 
+DenseKernelParams make_kernel_params(const sfb_qp_params *prm, int n, int m)
+{
+  DenseKernelParams kp;
+  kp.n          = n;
+  kp.m          = m;
+  kp.alpha      = static_cast<double>(prm->alpha);  // qp_solver.hpp:354
+  kp.alpha_comp = 1.0 - kp.alpha;                   // :355
+  kp.rho_bar    = static_cast<double>(prm->rho);    // :353
+  kp.sigma      = static_cast<double>(prm->sigma);  // :356
+  kp.eps_abs    = static_cast<double>(prm->eps_abs);
+  kp.eps_rel    = static_cast<double>(prm->eps_rel);
+  kp.eps_pinf   = static_cast<double>(prm->eps_primal_inf);
+  kp.eps_dinf   = static_cast<double>(prm->eps_dual_inf);
+  kp.delta      = static_cast<double>(prm->delta);
+  kp.max_iter   = prm->max_iter < 0 ? (uint32_t)SFB_QP_DEVICE_ITER_CAP : (uint32_t)prm->max_iter;
+  kp.stop_check_iter = prm->stop_check_iter;
+  kp.polish_iter     = prm->polish_iter;
+  kp.scaling         = prm->scaling ? 1 : 0;
+  kp.polish          = prm->polish ? 1 : 0;
+  return kp;
+}
+
+
+}  // namespace sfb
+
+namespace {
+using sfb::fail;
+using sfb::hip_fail;
+using sfb::require_device;
+using sfb::make_kernel_params;
+
 sfb_status check_qp_args(const sfb_qp_params *prm, int64_t batch, int n, int m, const void *P, const void *q,
                          const void *A, const void *l, const void *u, const void *wx, const void *wy, const void *x,
                          const void *y, const void *code)
@@ -58,35 +90,13 @@ sfb_status check_qp_args(const sfb_qp_params *prm, int64_t batch, int n, int m, 
   return SFB_OK;
 }
 
-sfb::DenseKernelParams make_kernel_params(const sfb_qp_params *prm, int n, int m)
-{
-  sfb::DenseKernelParams kp;
-  kp.n          = n;
-  kp.m          = m;
-  kp.alpha      = static_cast<double>(prm->alpha);  // qp_solver.hpp:354
-  kp.alpha_comp = 1.0 - kp.alpha;                   // :355
-  kp.rho_bar    = static_cast<double>(prm->rho);    // :353
-  kp.sigma      = static_cast<double>(prm->sigma);  // :356
-  kp.eps_abs    = static_cast<double>(prm->eps_abs);
-  kp.eps_rel    = static_cast<double>(prm->eps_rel);
-  kp.eps_pinf   = static_cast<double>(prm->eps_primal_inf);
-  kp.eps_dinf   = static_cast<double>(prm->eps_dual_inf);
-  kp.delta      = static_cast<double>(prm->delta);
-  kp.max_iter   = prm->max_iter < 0 ? (uint32_t)SFB_QP_DEVICE_ITER_CAP : (uint32_t)prm->max_iter;
-  kp.stop_check_iter = prm->stop_check_iter;
-  kp.polish_iter     = prm->polish_iter;
-  kp.scaling         = prm->scaling ? 1 : 0;
-  kp.polish          = prm->polish ? 1 : 0;
-  return kp;
-}
-
 }  // namespace
 
 extern "C" {
 
 const char *sfb_version(void) { return "smooth_feedback_amd 0.1.0 (gfx950)"; }
 
-const char *sfb_last_error(void) { return g_last_error.c_str(); }
+const char *sfb_last_error(void) { return sfb::g_last_error.c_str(); }
 
 sfb_status sfb_device_count(int *count)
 {

@@ -1,0 +1,17 @@
+// Shared helpers of the C-ABI translation units (error state, device check, params widening).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/sfb.h"
+#include "qp_dense_kernel.h"
+
+namespace sfb {
+
+sfb_status fail(sfb_status st, const std::string &msg);
+sfb_status hip_fail(hipError_t e, const char *what);
+sfb_status require_device();
+DenseKernelParams make_kernel_params(const sfb_qp_params *prm, int n, int m);
+
+}  // namespace sfb

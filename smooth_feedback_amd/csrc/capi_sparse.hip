@@ -1,0 +1,209 @@
+// C-ABI for the shared-pattern sparse QP path (include/sfb.h).
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/sfb.h"
+#include "capi_common.h"
+#include "qp_sparse_kernel.h"
+#include "sparse_plan.h"
+
+struct sfb_sparse_qp_plan {
+  sfb::SparsePlanHost host;
+  std::mutex mu;
+  struct DevCopy {
+    int32_t *blob = nullptr;
+    sfb::SparsePlanDev dev{};
+  };
+  std::map<int, DevCopy> per_device;  // device ordinal -> uploaded index arrays
+};
+
+namespace {
+
+// upload all index arrays as one blob (once per device)
+sfb_status plan_on_device(sfb_sparse_qp_plan *plan, const sfb::SparsePlanDev **out)
+{
+  int devid = 0;
+  hipError_t e = hipGetDevice(&devid);
+  if (e != hipSuccess) return sfb::hip_fail(e, "hipGetDevice");
+  std::lock_guard<std::mutex> lk(plan->mu);
+  auto it = plan->per_device.find(devid);
+  if (it != plan->per_device.end()) {
+    *out = &it->second.dev;
+    return SFB_OK;
+  }
+  const sfb::SparsePlanHost &h = plan->host;
+  const std::vector<int32_t> *arrs[] = {&h.Pp, &h.Pi, &h.Pcol, &h.Ap, &h.Aj, &h.Arow, &h.Acp, &h.Aci, &h.Acpos,
+                                        &h.Prp, &h.Prj, &h.Prpos, &h.Sp, &h.Sj, &h.Spos, &h.perm, &h.pinv,
+                                        &h.Kp, &h.Ki, &h.Kkind, &h.Kidx, &h.Lp, &h.Li, &h.Rp, &h.Rk, &h.Rpos};
+  constexpr int NA = sizeof(arrs) / sizeof(arrs[0]);
+  size_t off[NA + 1];
+  off[0] = 0;
+  for (int a = 0; a < NA; ++a) off[a + 1] = off[a] + ((arrs[a]->size() + 3) / 4) * 4 + 4;  // 16-B aligned, never empty
+  std::vector<int32_t> blob(off[NA], 0);
+  for (int a = 0; a < NA; ++a) std::copy(arrs[a]->begin(), arrs[a]->end(), blob.begin() + off[a]);
+  sfb_sparse_qp_plan::DevCopy dc;
+  e = hipMalloc(reinterpret_cast<void **>(&dc.blob), blob.size() * sizeof(int32_t));
+  if (e != hipSuccess) return sfb::hip_fail(e, "hipMalloc(plan)");
+  e = hipMemcpy(dc.blob, blob.data(), blob.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(dc.blob);
+    return sfb::hip_fail(e, "hipMemcpy(plan)");
+  }
+  sfb::SparsePlanDev &d = dc.dev;
+  d.n = h.n; d.m = h.m; d.k = h.k; d.nnzP = h.nnzP; d.nnzA = h.nnzA; d.nnzK = h.nnzK; d.nnzL = h.nnzL;
+  const int32_t **ptrs[] = {&d.Pp, &d.Pi, &d.Pcol, &d.Ap, &d.Aj, &d.Arow, &d.Acp, &d.Aci, &d.Acpos,
+                            &d.Prp, &d.Prj, &d.Prpos, &d.Sp, &d.Sj, &d.Spos, &d.perm, &d.pinv,
+                            &d.Kp, &d.Ki, &d.Kkind, &d.Kidx, &d.Lp, &d.Li, &d.Rp, &d.Rk, &d.Rpos};
+  for (int a = 0; a < NA; ++a) *ptrs[a] = dc.blob + off[a];
+  auto ins = plan->per_device.emplace(devid, dc);
+  *out     = &ins.first->second.dev;
+  return SFB_OK;
+}
+
+sfb_status check_sparse_args(const sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch, const void *Px,
+                             const void *q, const void *Ax, const void *l, const void *u, const void *wx,
+                             const void *wy, const void *x, const void *y, const void *code)
+{
+  if (!plan) return sfb::fail(SFB_ERR_INVALID_ARG, "plan is NULL");
+  if (!prm) return sfb::fail(SFB_ERR_INVALID_ARG, "prm is NULL");
+  if (batch < 0) return sfb::fail(SFB_ERR_INVALID_ARG, "batch < 0");
+  if (batch > 0 && (!q || !l || !u || !x || !y || !code || (plan->host.nnzP > 0 && !Px) || (plan->host.nnzA > 0 && !Ax)))
+    return sfb::fail(SFB_ERR_INVALID_ARG, "NULL problem / solution pointer");
+  if ((wx == nullptr) != (wy == nullptr))
+    return sfb::fail(SFB_ERR_INVALID_ARG, "warm_x and warm_y must both be given or both be NULL");
+  if (prm->max_time_ns >= 0)
+    return sfb::fail(SFB_ERR_UNSUPPORTED, "max_time is wall-clock and not supported on the device path; use max_iter");
+  if (prm->max_iter > 0xFFFFFFFFll) return sfb::fail(SFB_ERR_INVALID_ARG, "max_iter exceeds uint32");
+  if (batch > 0x7FFFFFFFll) return sfb::fail(SFB_ERR_UNSUPPORTED, "batch exceeds 2^31-1 per call");
+  if ((size_t)plan->host.k * sizeof(double) > 150 * 1024)
+    return sfb::fail(SFB_ERR_UNSUPPORTED, "n+m too large for the LDS-resident work vector (max 19200)");
+  return SFB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+sfb_status sfb_sparse_qp_plan_create(int n, int m, const int32_t *P_colptr, const int32_t *P_rowind,
+                                     const int32_t *A_rowptr, const int32_t *A_colind, int ordering,
+                                     const int32_t *user_perm, sfb_sparse_qp_plan **plan)
+{
+  if (!plan) return sfb::fail(SFB_ERR_INVALID_ARG, "plan out-pointer is NULL");
+  *plan = nullptr;
+  auto *p = new (std::nothrow) sfb_sparse_qp_plan();
+  if (!p) return sfb::fail(SFB_ERR_INVALID_ARG, "out of memory");
+  const char *msg = "";
+  if (!sfb::build_sparse_plan(n, m, P_colptr, P_rowind, A_rowptr, A_colind, ordering, user_perm, p->host, &msg)) {
+    delete p;
+    return sfb::fail(SFB_ERR_INVALID_ARG, msg);
+  }
+  *plan = p;
+  return SFB_OK;
+}
+
+void sfb_sparse_qp_plan_destroy(sfb_sparse_qp_plan *plan)
+{
+  if (!plan) return;
+  for (auto &kv : plan->per_device)
+    if (kv.second.blob) (void)hipFree(kv.second.blob);
+  delete plan;
+}
+
+sfb_status sfb_sparse_qp_plan_info(const sfb_sparse_qp_plan *plan, int64_t *nnzK, int64_t *nnzL,
+                                   int64_t *workspace_bytes_per_item)
+{
+  if (!plan) return sfb::fail(SFB_ERR_INVALID_ARG, "plan is NULL");
+  if (nnzK) *nnzK = plan->host.nnzK;
+  if (nnzL) *nnzL = plan->host.nnzL;
+  if (workspace_bytes_per_item)
+    *workspace_bytes_per_item =
+      (int64_t)(sfb::qp_sparse_ws_doubles(plan->host.n, plan->host.m, plan->host.nnzL) * sizeof(double));
+  return SFB_OK;
+}
+
+sfb_status sfb_sparse_qp_plan_get_perm(const sfb_sparse_qp_plan *plan, int32_t *perm)
+{
+  if (!plan || !perm) return sfb::fail(SFB_ERR_INVALID_ARG, "NULL argument");
+  std::copy(plan->host.perm.begin(), plan->host.perm.end(), perm);
+  return SFB_OK;
+}
+
+sfb_status sfb_sparse_qp_solve_batch(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
+                                     const double *Px, const double *q, const double *Ax, const double *l,
+                                     const double *u, const double *warm_x, const double *warm_y, double *x,
+                                     double *y, double *obj, uint32_t *iter, int32_t *code, void *workspace,
+                                     void *stream)
+{
+  sfb_status st = check_sparse_args(plan, prm, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, code);
+  if (st != SFB_OK) return st;
+  if (batch > 0 && !workspace) return sfb::fail(SFB_ERR_INVALID_ARG, "workspace is NULL");
+  st = sfb::require_device();
+  if (st != SFB_OK) return st;
+  if (batch == 0) return SFB_OK;
+  const sfb::SparsePlanDev *dev = nullptr;
+  st = plan_on_device(plan, &dev);
+  if (st != SFB_OK) return st;
+  const sfb::DenseKernelParams kp = sfb::make_kernel_params(prm, plan->host.n, plan->host.m);
+  hipError_t e = sfb::qp_sparse_launch(*dev, kp, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code,
+                                       static_cast<double *>(workspace), static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return sfb::hip_fail(e, "qp_sparse_kernel launch");
+  return SFB_OK;
+}
+
+sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
+                                          const double *Px, const double *q, const double *Ax, const double *l,
+                                          const double *u, const double *warm_x, const double *warm_y, double *x,
+                                          double *y, double *obj, uint32_t *iter, int32_t *code)
+{
+  sfb_status st = check_sparse_args(plan, prm, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, code);
+  if (st != SFB_OK) return st;
+  st = sfb::require_device();
+  if (st != SFB_OK) return st;
+  if (batch == 0) return SFB_OK;
+  const sfb::SparsePlanHost &h = plan->host;
+  const size_t B = (size_t)batch, N = (size_t)h.n, M = (size_t)h.m, NP = (size_t)h.nnzP, NA = (size_t)h.nnzA;
+  const size_t wsd  = sfb::qp_sparse_ws_doubles(h.n, h.m, h.nnzL);
+  const size_t in_d = B * (NP + N + NA + 2 * M) + (warm_x ? B * (N + M) : 0), out_d = B * (N + M + 1);
+  const size_t bytes = (in_d + out_d + B * wsd) * sizeof(double) + B * 8;
+  char *devmem = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&devmem), bytes);
+  if (e != hipSuccess) return sfb::hip_fail(e, "hipMalloc");
+  double *dPx = reinterpret_cast<double *>(devmem);
+  double *dq = dPx + B * NP, *dAx = dq + B * N, *dl = dAx + B * NA, *du = dl + B * M;
+  double *dwx = nullptr, *dwy = nullptr, *dx = du + B * M;
+  if (warm_x) { dwx = dx; dwy = dwx + B * N; dx = dwy + B * M; }
+  double *dy = dx + B * N, *dobj = dy + B * M, *dws = dobj + B;
+  uint32_t *dit  = reinterpret_cast<uint32_t *>(dws + B * wsd);
+  int32_t *dcode = reinterpret_cast<int32_t *>(dit + B);
+  auto H2D = [&](void *d, const void *hh, size_t nb) { return nb ? hipMemcpy(d, hh, nb, hipMemcpyHostToDevice) : hipSuccess; };
+  auto D2H = [&](void *hh, const void *d, size_t nb) { return nb ? hipMemcpy(hh, d, nb, hipMemcpyDeviceToHost) : hipSuccess; };
+  do {
+    if ((e = H2D(dPx, Px, B * NP * 8)) != hipSuccess) break;
+    if ((e = H2D(dq, q, B * N * 8)) != hipSuccess) break;
+    if ((e = H2D(dAx, Ax, B * NA * 8)) != hipSuccess) break;
+    if ((e = H2D(dl, l, B * M * 8)) != hipSuccess) break;
+    if ((e = H2D(du, u, B * M * 8)) != hipSuccess) break;
+    if (warm_x) {
+      if ((e = H2D(dwx, warm_x, B * N * 8)) != hipSuccess) break;
+      if ((e = H2D(dwy, warm_y, B * M * 8)) != hipSuccess) break;
+    }
+    st = sfb_sparse_qp_solve_batch(plan, prm, batch, dPx, dq, dAx, dl, du, dwx, dwy, dx, dy, dobj, dit, dcode, dws,
+                                   nullptr);
+    if (st != SFB_OK) break;
+    if ((e = hipDeviceSynchronize()) != hipSuccess) break;
+    if ((e = D2H(x, dx, B * N * 8)) != hipSuccess) break;
+    if ((e = D2H(y, dy, B * M * 8)) != hipSuccess) break;
+    if (obj && (e = D2H(obj, dobj, B * 8)) != hipSuccess) break;
+    if (iter && (e = D2H(iter, dit, B * 4)) != hipSuccess) break;
+    if ((e = D2H(code, dcode, B * 4)) != hipSuccess) break;
+  } while (false);
+  if (e != hipSuccess) st = sfb::hip_fail(e, "sfb_sparse_qp_solve_batch_host");
+  (void)hipFree(devmem);
+  return st;
+}
+
+}  // extern "C"

@@ -1,0 +1,500 @@
+// Batched sparse ADMM QP solver for gfx950: all items share ONE sparsity pattern (e.g. a swarm of
+// MPC problems produced by the same ocp_to_qp transcription), one wavefront per item.
+//
+// Replaces, per item, QPSolver<QuadraticProgramSparse<double>>::solve (reference
+// qp_solver.hpp:343-568 sparse branches :379-397, :423-426, :452-460; scale :673-730;
+// check_stopping :574-644; polish :92-204).  The symbolic work (elimination order, pattern of L)
+// is done once on the host (sparse_plan.cpp) and shared; this kernel does everything numeric.
+// Arithmetic follows oracle/qp_sparse_oracle.c operation for operation (bit-identical results):
+//   - left-looking numeric LDL': column j gathers its source columns kk < j in ascending order;
+//   - forward sweep column-oriented, D^-1 as reciprocal-multiply (:458), backward sweep pushing row
+//     by row from the row-major copy of L;
+//   - polish on the reduced system embedded in the full pattern.
+//
+// Data placement: the dense work/solution vector (k = n+m doubles) lives in LDS; the factor
+// (2 x nnz(L) doubles: column-major for the forward sweep, row-major for the backward sweep) and
+// the ADMM vectors live in a per-item HBM workspace and are streamed with coalesced accesses.  The
+// factor does not fit on chip for MPC-sized problems (k ~ 1.5k), so every ADMM iteration streams
+// it once in each direction: this kernel is HBM-bound by construction.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+
+#include "../../include/sfb.h"
+#include "qp_sparse_kernel.h"
+#include "wave_util.h"
+
+namespace sfb {
+
+namespace {
+
+struct Ws {
+  double *Lx, *LxT, *D, *Dinv, *tv;
+  double *sx, *qc, *xs, *xus, *dxus;
+  double *sy, *rho, *rinv, *lo, *hi, *ys, *zs, *yus, *zus, *dyus, *act;
+};
+
+__device__ __forceinline__ Ws carve_ws(double *base, int n, int m, int nnzL)
+{
+  const int k = n + m;
+  Ws w;
+  double *p = base;
+  w.Lx = p; p += nnzL;  w.LxT = p; p += nnzL;
+  w.D = p; p += k;      w.Dinv = p; p += k;   w.tv = p; p += k;
+  w.sx = p; p += n;     w.qc = p; p += n;     w.xs = p; p += n;   w.xus = p; p += n;  w.dxus = p; p += n;
+  p += n;
+  w.sy = p; p += m;     w.rho = p; p += m;    w.rinv = p; p += m; w.lo = p; p += m;   w.hi = p; p += m;
+  w.ys = p; p += m;     w.zs = p; p += m;     w.yus = p; p += m;  w.zus = p; p += m;  w.dyus = p; p += m;
+  w.act = p; p += m;
+  return w;
+}
+
+struct Item {
+  const double *Px, *q, *Ax, *l, *u;
+};
+
+// value of KKT entry p of the permuted lower pattern.  mode 0: ADMM matrix (qp_solver.hpp:382-395);
+// mode 1: polish matrix H + diag(delta, -delta), inactive rows zeroed (:143-171).
+__device__ __forceinline__ double kkt_value(const SparsePlanDev &pl, const Item &it, const Ws &w, const int p,
+                                            const int mode, const double c, const double sigma, const double delta)
+{
+  const int kind = pl.Kkind[p], idx = pl.Kidx[p];
+  double v;
+  if (kind == K_P) {
+    const int r = pl.Pi[idx], cc = pl.Pcol[idx];
+    if (mode == 0) v = c * w.sx[r] * w.sx[cc] * it.Px[idx];  // :385
+    else v = c * w.sx[cc] * w.sx[r] * it.Px[idx];            // :145
+    if (r == cc) v += (mode == 0) ? sigma : delta;           // :389 / :170
+  } else if (kind == K_A) {
+    const int r = pl.Arow[idx], cc = pl.Aj[idx];
+    v = w.sy[r] * w.sx[cc] * it.Ax[idx];  // :392 / :154
+    if (mode != 0 && w.act[r] == 0.0) v = 0.0;
+  } else if (kind == K_SIGMA) {
+    v = (mode == 0) ? sigma : 0.0 + delta;
+  } else {
+    v = (mode == 0) ? (-1.0 / w.rho[idx]) : 0.0 - delta;  // :395 / :171
+  }
+  return v;
+}
+
+// Left-looking numeric LDL' on the shared pattern; t = LDS work vector (k).  Returns 1 / 0 (zero pivot).
+__device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, const Ws &w, double *t, const int mode,
+                                      const double c, const double sigma, const double delta, const int lane)
+{
+  const int k = pl.k;
+  for (int j = 0; j < k; ++j) {
+    const int c0 = pl.Lp[j], c1 = pl.Lp[j + 1];
+    if (lane == 0) t[j] = 0.0;
+    for (int p = c0 + lane; p < c1; p += kWave) t[pl.Li[p]] = 0.0;
+    wave_sync();
+    for (int p = pl.Kp[j] + lane; p < pl.Kp[j + 1]; p += kWave) t[pl.Ki[p]] = kkt_value(pl, it, w, p, mode, c, sigma, delta);
+    wave_sync();
+    for (int tt = pl.Rp[j]; tt < pl.Rp[j + 1]; ++tt) {  // source columns kk < j, ascending
+      const int kk = pl.Rk[tt], pos = pl.Rpos[tt], end = pl.Lp[kk + 1];
+      const double wv = w.Lx[pos] * w.D[kk];  // L(j,kk) * D(kk)
+      for (int p = pos + lane; p < end; p += kWave) {
+        const int r = pl.Li[p];
+        t[r]        = fma(-w.Lx[p], wv, t[r]);
+      }
+      wave_sync();
+    }
+    const double d = t[j];
+    if (lane == 0) {
+      w.D[j]    = d;
+      w.Dinv[j] = 1.0 / d;
+    }
+    if (d == 0.0) return 0;
+    for (int p = c0 + lane; p < c1; p += kWave) w.Lx[p] = t[pl.Li[p]] / d;
+    wave_sync();
+  }
+  // row-major copy for the backward sweep
+  for (int p = lane; p < pl.nnzL; p += kWave) w.LxT[p] = w.Lx[pl.Rpos[p]];
+  wave_sync();
+  return 1;
+}
+
+// t (LDS, permuted order) <- K^-1 t   (qp_solver.hpp:457-459)
+__device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, double *t, const int lane)
+{
+  const int k = pl.k;
+  for (int j = 0; j < k; ++j) {  // forward, column oriented
+    const int c0 = pl.Lp[j], c1 = pl.Lp[j + 1];
+    if (c0 == c1) continue;
+    const double tj = t[j];
+    for (int p = c0 + lane; p < c1; p += kWave) {
+      const int r = pl.Li[p];
+      t[r]        = fma(-w.Lx[p], tj, t[r]);
+    }
+    wave_sync();
+  }
+  for (int j = lane; j < k; j += kWave) t[j] = w.Dinv[j] * t[j];
+  wave_sync();
+  for (int j = k - 1; j >= 0; --j) {  // backward: row j pushes into its columns
+    const int r0 = pl.Rp[j], r1 = pl.Rp[j + 1];
+    if (r0 == r1) continue;
+    const double tj = t[j];
+    for (int p = r0 + lane; p < r1; p += kWave) {
+      const int cc = pl.Rk[p];
+      t[cc]        = fma(-w.LxT[p], tj, t[cc]);
+    }
+    wave_sync();
+  }
+}
+
+__device__ __forceinline__ double lane_max_abs(const double *v, int len, int lane)
+{
+  double r = 0.0;
+  for (int e = lane; e < len; e += kWave) r = fmax(r, fabs(v[e]));
+  return wave_max(r);
+}
+
+// rows of the sparse products, accumulation order of the oracle (storage order, fma)
+__device__ __forceinline__ double sp_row_A(const SparsePlanDev &pl, const Item &it, int i, const double *v)
+{
+  double s = 0.0;
+  for (int p = pl.Ap[i]; p < pl.Ap[i + 1]; ++p) s = fma(it.Ax[p], v[pl.Aj[p]], s);
+  return s;
+}
+__device__ __forceinline__ double sp_row_At(const SparsePlanDev &pl, const Item &it, int j, const double *v)
+{
+  double s = 0.0;
+  for (int p = pl.Acp[j]; p < pl.Acp[j + 1]; ++p) s = fma(it.Ax[pl.Acpos[p]], v[pl.Aci[p]], s);
+  return s;
+}
+__device__ __forceinline__ double sp_row_P(const SparsePlanDev &pl, const Item &it, int i, const double *v)
+{
+  double s = 0.0;
+  for (int p = pl.Prp[i]; p < pl.Prp[i + 1]; ++p) s = fma(it.Px[pl.Prpos[p]], v[pl.Prj[p]], s);
+  return s;
+}
+
+// QPSolver::check_stopping, qp_solver.hpp:574-644 (xus, yus, zus, dxus, dyus in the workspace).
+__device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it, const Ws &w,
+                                        const DenseKernelParams &kp, const int lane)
+{
+  const int n = pl.n, m = pl.m;
+  const double inf = INFINITY;
+  {  // OPTIMALITY
+    double a = 0.0, r = 0.0, z = 0.0;
+    for (int i = lane; i < m; i += kWave) {
+      const double Ax = sp_row_A(pl, it, i, w.xus), zi = w.zus[i];
+      a = fmax(a, fabs(Ax));
+      r = fmax(r, fabs(Ax - zi));
+      z = fmax(z, fabs(zi));
+    }
+    const double Ax_norm = wave_max(a), r_norm = wave_max(r), z_norm = wave_max(z);
+    if (r_norm <= kp.eps_abs + kp.eps_rel * fmax(Ax_norm, z_norm)) {
+      double pn = 0.0, qn = 0.0, an = 0.0, rn = 0.0;
+      for (int j = lane; j < n; j += kWave) {
+        const double Px = sp_row_P(pl, it, j, w.xus), Aty = sp_row_At(pl, it, j, w.yus), qj = it.q[j];
+        pn = fmax(pn, fabs(Px));
+        qn = fmax(qn, fabs(qj));
+        an = fmax(an, fabs(Aty));
+        rn = fmax(rn, fabs(Px + (qj + Aty)));
+      }
+      const double dual_scale = fmax(fmax(wave_max(pn), wave_max(qn)), wave_max(an));
+      if (wave_max(rn) <= kp.eps_abs + kp.eps_rel * dual_scale) return SFB_QP_OPTIMAL;
+    }
+  }
+  {  // PRIMAL INFEASIBILITY
+    double an = 0.0;
+    for (int j = lane; j < n; j += kWave) an = fmax(an, fabs(sp_row_At(pl, it, j, w.dyus)));
+    const double Aty_norm = wave_max(an);
+    const double Edy_norm = lane_max_abs(w.dyus, m, lane);
+    const double thr      = kp.eps_pinf * Edy_norm;
+    double acc            = 0.0;
+    for (int i = 0; i < m; ++i) {  // sequential certificate sum with early exit (uniform)
+      const double ui = it.u[i], li = it.l[i], dyi = w.dyus[i];
+      if (ui != inf) {
+        acc += ui * fmax(0.0, dyi);
+      } else if (dyi > thr) {
+        acc = inf;
+        break;
+      }
+      if (li != -inf) {
+        acc += li * fmin(0.0, dyi);
+      } else if (dyi < -thr) {
+        acc = inf;
+        break;
+      }
+    }
+    const double mxv = (Aty_norm < acc) ? acc : Aty_norm;
+    if (mxv < thr) return SFB_QP_PRIMAL_INFEASIBLE;
+  }
+  {  // DUAL INFEASIBILITY
+    const double dx_norm = lane_max_abs(w.dxus, n, lane);
+    const double thr     = kp.eps_dinf * dx_norm;
+    double pn            = 0.0;
+    for (int j = lane; j < n; j += kWave) pn = fmax(pn, fabs(sp_row_P(pl, it, j, w.dxus)));
+    const double Pdx_n = wave_max(pn);
+    double qdx         = 0.0;
+    for (int j = 0; j < n; ++j) qdx = fma(it.q[j], w.dxus[j], qdx);
+    bool rowok = true;
+    for (int i = lane; i < m; i += kWave) {
+      const double Adx = sp_row_A(pl, it, i, w.dxus), ui = it.u[i], li = it.l[i];
+      if (ui == inf) rowok = rowok && (Adx >= -thr);
+      else if (li == -inf) rowok = rowok && (Adx <= thr);
+      else rowok = rowok && (fabs(Adx) < thr);
+    }
+    if ((Pdx_n <= thr) && (qdx <= thr) && !wave_ballot(!rowok)) return SFB_QP_DUAL_INFEASIBLE;
+  }
+  return -1;
+}
+
+// detail::polish_qp (sparse), embedded in the full pattern.  In/out: scaled xs / ys in the workspace.
+__device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const Ws &w, const DenseKernelParams &kp,
+                                 double *t, const double c, const int lane)
+{
+  const int n = pl.n, m = pl.m, k = pl.k;
+  const double inf = INFINITY, eps = DBL_EPSILON;
+  for (int i = lane; i < m; i += kWave) {  // :113-123
+    const double yi = w.ys[i];
+    double a        = 0.0;
+    if (yi < -100 * eps && it.l[i] != -inf) a = 1.0;
+    if (yi > 100 * eps && it.u[i] != inf) a = 2.0;
+    w.act[i] = a;
+  }
+  for (int e = lane; e < k; e += kWave) w.tv[e] = 0.0;
+  wave_sync();
+  if (!ldl_numeric_dev(pl, it, w, t, 1, c, kp.sigma, kp.delta, lane)) return;  // :187-190
+  for (uint32_t iter = 0; iter != kp.polish_iter; ++iter) {                      // :193-195
+    for (int i = lane; i < n; i += kWave) {
+      double acc = 0.0;
+      for (int p = pl.Sp[i]; p < pl.Sp[i + 1]; ++p) {
+        const int e = pl.Spos[p], er = pl.Pi[e], ec = pl.Pcol[e];
+        acc = fma(c * w.sx[ec] * w.sx[er] * it.Px[e], w.tv[pl.Sj[p]], acc);
+      }
+      for (int p = pl.Acp[i]; p < pl.Acp[i + 1]; ++p) {
+        const int rr = pl.Aci[p], e = pl.Acpos[p];
+        if (w.act[rr] != 0.0) acc = fma(w.sy[rr] * w.sx[i] * it.Ax[e], w.tv[n + rr], acc);
+      }
+      const double h = -c * (w.sx[i] * it.q[i]);  // :180
+      t[pl.pinv[i]]  = h - acc;
+    }
+    for (int rr = lane; rr < m; rr += kWave) {
+      const double a = w.act[rr];
+      double acc = 0.0, h = 0.0;
+      if (a != 0.0) {
+        for (int p = pl.Ap[rr]; p < pl.Ap[rr + 1]; ++p) acc = fma(w.sy[rr] * w.sx[pl.Aj[p]] * it.Ax[p], w.tv[pl.Aj[p]], acc);
+        h = (a == 1.0) ? w.sy[rr] * it.l[rr] : w.sy[rr] * it.u[rr];  // :181-182
+      }
+      t[pl.pinv[n + rr]] = h - acc;
+    }
+    wave_sync();
+    ldl_solve_dev(pl, w, t, lane);
+    for (int e = lane; e < k; e += kWave) w.tv[e] += t[pl.pinv[e]];
+    wave_sync();
+  }
+  for (int j = lane; j < n; j += kWave) w.xs[j] = w.tv[j];  // :199
+  for (int i = lane; i < m; i += kWave)
+    if (w.act[i] != 0.0) w.ys[i] = w.tv[n + i];             // :200-201
+  wave_sync();
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(64) qp_sparse_kernel(const SparsePlanDev pl, const DenseKernelParams kp,
+                                                       const double *__restrict__ gPx, const double *__restrict__ gq,
+                                                       const double *__restrict__ gAx, const double *__restrict__ gl,
+                                                       const double *__restrict__ gu, const double *__restrict__ gwx,
+                                                       const double *__restrict__ gwy, double *__restrict__ gx,
+                                                       double *__restrict__ gy, double *__restrict__ gobj,
+                                                       uint32_t *__restrict__ giter, int32_t *__restrict__ gcode,
+                                                       double *__restrict__ gws, const size_t ws_doubles)
+{
+  extern __shared__ __attribute__((aligned(16))) double t[];  // k doubles: work / solution vector
+  const int lane = threadIdx.x;
+  const int n = pl.n, m = pl.m, k = pl.k;
+  const size_t b = blockIdx.x;
+  const Item it{gPx + b * (size_t)pl.nnzP, gq + b * (size_t)n, gAx + b * (size_t)pl.nnzA, gl + b * (size_t)m,
+                gu + b * (size_t)m};
+  const Ws w = carve_ws(gws + b * ws_doubles, n, m, pl.nnzL);
+  const double inf = INFINITY;
+
+  // ---- analyze(): :306-308 ----
+  for (int j = lane; j < n; j += kWave) w.sx[j] = 1.0;
+  for (int i = lane; i < m; i += kWave) w.sy[i] = 1.0;
+  wave_sync();
+  double c = 1.0;
+
+  // ---- scale :673-730 ----
+  if (kp.scaling) {
+    // :681-693: column inf-norms of P as stored, then c
+    for (int j = lane; j < n; j += kWave) {
+      double v = 0.0;
+      for (int p = pl.Pp[j]; p < pl.Pp[j + 1]; ++p) v = fmax(v, fabs(it.Px[p]));
+      if (v == 0.0) v = 1.0;
+      t[j] = v;
+    }
+    wave_sync();
+    double sum = t[0];
+    for (int j = 1; j < n; ++j) sum += t[j];
+    const double qn = lane_max_abs(it.q, n, lane);
+    c               = 1.0 / fmax(fmax(1e-6, sum / (double)n), qn);
+    wave_sync();
+    int pass = 0;
+    double crit;
+    do {
+      double cm = 0.0;
+      // new increments into t[0..n) (columns) and t[n..k) (rows), computed from the OLD sx, sy
+      for (int j = lane; j < n; j += kWave) {
+        const double sxc = w.sx[j];
+        double inc       = 0.0;
+        for (int p = pl.Pp[j]; p < pl.Pp[j + 1]; ++p) inc = fmax(inc, fabs(c * w.sx[pl.Pi[p]] * sxc * it.Px[p]));
+        for (int p = pl.Acp[j]; p < pl.Acp[j + 1]; ++p) inc = fmax(inc, fabs(w.sy[pl.Aci[p]] * sxc * it.Ax[pl.Acpos[p]]));
+        if (inc == 0.0) inc = 1.0;
+        t[j] = inc;
+        cm   = fmax(cm, fabs(inc - 1.0));
+      }
+      for (int i = lane; i < m; i += kWave) {
+        const double syr = w.sy[i];
+        double inc       = 0.0;
+        for (int p = pl.Ap[i]; p < pl.Ap[i + 1]; ++p) inc = fmax(inc, fabs(syr * w.sx[pl.Aj[p]] * it.Ax[p]));
+        if (inc == 0.0) inc = 1.0;
+        t[n + i] = inc;
+        cm       = fmax(cm, fabs(inc - 1.0));
+      }
+      wave_sync();
+      for (int j = lane; j < n; j += kWave) w.sx[j] = sqrt(1.0 / fmax(t[j], 1e-8)) * w.sx[j];
+      for (int i = lane; i < m; i += kWave) w.sy[i] = sqrt(1.0 / fmax(t[n + i], 1e-8)) * w.sy[i];
+      crit = wave_max(cm);
+      wave_sync();
+    } while (pass++ < 10 && crit > 0.1);
+  }
+
+  // ---- pre-check, rho and loop constants :361-374, :450, :473-474 ----
+  int ret_code = -1;
+  {
+    bool bad = false;
+    for (int i = lane; i < m; i += kWave) {
+      const double li = it.l[i], ui = it.u[i], syi = w.sy[i];
+      bad = bad || (li == inf) || (ui == -inf) || (ui - li < 0.0);
+      double rho;
+      if (li == -inf && ui == inf) rho = 1e-6;
+      else if (syi * fabs(li - ui) < 1e-5) rho = 1e3 * kp.rho_bar;
+      else rho = kp.rho_bar;
+      w.rho[i]  = rho;
+      w.rinv[i] = 1.0 / rho;
+      w.lo[i]   = syi * li;
+      w.hi[i]   = syi * ui;
+    }
+    for (int j = lane; j < n; j += kWave) w.qc[j] = c * w.sx[j] * it.q[j];
+    if (wave_ballot(bad)) ret_code = SFB_QP_PRIMAL_INFEASIBLE;
+  }
+  wave_sync();
+
+  // ---- KKT fill + numeric factorisation :379-433 ----
+  if (!ldl_numeric_dev(pl, it, w, t, 0, c, kp.sigma, kp.delta, lane)) {
+    ret_code = SFB_QP_UNKNOWN;
+    // Dinv of the remaining columns is never used: the loop below does not run
+  }
+
+  // ---- initial iterate :436-445 ----
+  if (gwx != nullptr) {
+    const double *wx = gwx + b * (size_t)n, *wy = gwy + b * (size_t)m;
+    for (int j = lane; j < n; j += kWave) w.xs[j] = (1.0 / w.sx[j]) * wx[j];
+    for (int i = lane; i < m; i += kWave) {
+      const double syi = w.sy[i];
+      w.ys[i]          = c * ((1.0 / syi) * wy[i]);
+      double acc       = 0.0;
+      for (int p = pl.Ap[i]; p < pl.Ap[i + 1]; ++p) acc = fma(syi * it.Ax[p], wx[pl.Aj[p]], acc);
+      w.zs[i] = acc;
+    }
+  } else {
+    for (int j = lane; j < n; j += kWave) w.xs[j] = 0.0;
+    for (int i = lane; i < m; i += kWave) {
+      w.ys[i] = 0.0;
+      w.zs[i] = 0.0;
+    }
+  }
+  wave_sync();
+
+  // ---- ADMM loop :447-510 ----
+  uint32_t iter        = 0;
+  const uint32_t sci   = kp.stop_check_iter;
+  const uint32_t maxit = kp.max_iter;
+  uint32_t next_chk    = (sci >= 2) ? 1u : 0xFFFFFFFFu;
+  for (; iter != maxit && ret_code < 0; ++iter) {
+    for (int j = lane; j < n; j += kWave) t[pl.pinv[j]] = kp.sigma * w.xs[j] - w.qc[j];            // :450
+    for (int i = lane; i < m; i += kWave) t[pl.pinv[n + i]] = w.zs[i] - w.rinv[i] * w.ys[i];      // :451
+    wave_sync();
+    ldl_solve_dev(pl, w, t, lane);                                                              // :456-460
+    const bool chk = (iter == next_chk);
+    if (chk) next_chk += sci;
+    for (int j = lane; j < n; j += kWave) {  // :470
+      const double xo = w.xs[j], xn = kp.alpha * t[pl.pinv[j]] + kp.alpha_comp * xo;
+      w.xs[j] = xn;
+      if (chk) {
+        const double sxj = w.sx[j];
+        w.xus[j]  = sxj * xn;
+        w.dxus[j] = sxj * (xn - xo);
+      }
+    }
+    for (int i = lane; i < m; i += kWave) {  // :471-477
+      const double nu = t[pl.pinv[n + i]], yo = w.ys[i], zo = w.zs[i], ri = w.rinv[i], rh = w.rho[i];
+      double zn = kp.alpha * (ri * nu) + kp.alpha_comp * (ri * yo) + zo;
+      const double lo = w.lo[i], hi = w.hi[i];
+      zn = (zn < lo) ? lo : zn;
+      zn = (hi < zn) ? hi : zn;
+      const double yn = kp.alpha_comp * yo + kp.alpha * nu + rh * zo - rh * zn;
+      w.ys[i] = yn;
+      w.zs[i] = zn;
+      if (chk) {
+        const double syi = w.sy[i];
+        w.yus[i]  = syi * yn / c;
+        w.zus[i]  = (1.0 / syi) * zn;
+        w.dyus[i] = syi * (yn - yo) / c;
+      }
+    }
+    wave_sync();
+    if (chk) {
+      ret_code = sp_check_stopping(pl, it, w, kp, lane);
+      wave_sync();
+    }
+  }
+
+  // ---- polish :515-539 ----
+  if (ret_code == SFB_QP_OPTIMAL && kp.polish) sp_polish(pl, it, w, kp, t, c, lane);
+
+  // ---- un-scale and report :544-548 ----
+  double *ox = gx + b * (size_t)n, *oy = gy + b * (size_t)m;
+  for (int j = lane; j < n; j += kWave) {
+    const double v = w.sx[j] * w.xs[j];
+    ox[j]    = v;
+    w.xus[j] = v;
+  }
+  for (int i = lane; i < m; i += kWave) oy[i] = w.sy[i] * w.ys[i] / c;
+  wave_sync();
+  if (gobj != nullptr) {
+    for (int i = lane; i < n; i += kWave) {
+      double acc = 0.0;
+      for (int p = pl.Prp[i]; p < pl.Prp[i + 1]; ++p) acc = fma(0.5 * it.Px[pl.Prpos[p]], w.xus[pl.Prj[p]], acc);
+      t[i] = acc + it.q[i];
+    }
+    wave_sync();
+    if (lane == 0) {
+      double o = 0.0;
+      for (int i = 0; i < n; ++i) o = fma(w.xus[i], t[i], o);
+      gobj[b] = o;
+    }
+  }
+  if (lane == 0) {
+    gcode[b] = (ret_code >= 0) ? ret_code : SFB_QP_MAX_ITERATIONS;
+    if (giter != nullptr) giter[b] = iter;
+  }
+}
+
+hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp, int64_t batch, const double *Px,
+                            const double *q, const double *Ax, const double *l, const double *u, const double *wx,
+                            const double *wy, double *x, double *y, double *obj, uint32_t *iter, int32_t *code,
+                            double *workspace, hipStream_t stream)
+{
+  const size_t lds = (size_t)pl.k * sizeof(double);
+  const size_t wsd = qp_sparse_ws_doubles(pl.n, pl.m, pl.nnzL);
+  hipLaunchKernelGGL(qp_sparse_kernel, dim3((unsigned)batch), dim3(kWave), lds, stream, pl, kp, Px, q, Ax, l, u, wx,
+                     wy, x, y, obj, iter, code, workspace, wsd);
+  return hipGetLastError();
+}
+
+}  // namespace sfb

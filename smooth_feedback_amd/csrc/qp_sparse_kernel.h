@@ -1,0 +1,36 @@
+// Host<->kernel interface of the sparse (shared-pattern) QP kernel.  Internal.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "qp_dense_kernel.h"
+
+namespace sfb {
+
+#ifndef SFB_KKT_KINDS
+#define SFB_KKT_KINDS
+enum { K_P = 0, K_A = 1, K_SIGMA = 2, K_RHO = 3 };  // source of a KKT entry (qp_solver.hpp:385,:392,:389,:395)
+#endif
+
+// Device copies of the plan's index arrays (all int32, read-only, shared by the whole batch).
+struct SparsePlanDev {
+  int n, m, k, nnzP, nnzA, nnzK, nnzL;
+  const int32_t *Pp, *Pi, *Pcol, *Ap, *Aj, *Arow;
+  const int32_t *Acp, *Aci, *Acpos, *Prp, *Prj, *Prpos, *Sp, *Sj, *Spos;
+  const int32_t *perm, *pinv, *Kp, *Ki, *Kkind, *Kidx, *Lp, *Li, *Rp, *Rk, *Rpos;
+};
+
+// per-item workspace, in doubles
+inline size_t qp_sparse_ws_doubles(int n, int m, int nnzL)
+{
+  const size_t k = (size_t)n + m;
+  return 2 * (size_t)nnzL + 3 * k + 6 * (size_t)n + 12 * (size_t)m + 8;
+}
+
+hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp, int64_t batch, const double *Px,
+                            const double *q, const double *Ax, const double *l, const double *u, const double *wx,
+                            const double *wy, double *x, double *y, double *obj, uint32_t *iter, int32_t *code,
+                            double *workspace, hipStream_t stream);
+
+}  // namespace sfb

@@ -1,0 +1,235 @@
+#include "sparse_plan.h"
+
+#include <algorithm>
+#include <numeric>
+#include <tuple>
+
+namespace sfb {
+
+namespace {
+
+// transpose a compressed pattern: `outer_ptr` over `nouter` slices with `inner` indices < ninner.
+// Output compressed by inner index, entries ordered by ascending outer index, with positions.
+void transpose_pattern(int nouter, int ninner, const std::vector<int32_t> &outer_ptr,
+                       const std::vector<int32_t> &inner, std::vector<int32_t> &tp, std::vector<int32_t> &ti,
+                       std::vector<int32_t> &tpos)
+{
+  const int nnz = outer_ptr[nouter];
+  tp.assign(ninner + 1, 0);
+  ti.resize(nnz);
+  tpos.resize(nnz);
+  for (int p = 0; p < nnz; ++p) tp[inner[p] + 1]++;
+  for (int i = 0; i < ninner; ++i) tp[i + 1] += tp[i];
+  std::vector<int32_t> fill(ninner, 0);
+  for (int o = 0; o < nouter; ++o)
+    for (int p = outer_ptr[o]; p < outer_ptr[o + 1]; ++p) {
+      const int i       = inner[p];
+      ti[tp[i] + fill[i]]   = o;
+      tpos[tp[i] + fill[i]] = p;
+      fill[i]++;
+    }
+}
+
+// Minimum-degree ordering on the symmetric KKT graph with explicit fill (bitset adjacency).
+// k is at most a few thousand for the problems of this path; O(k^2 * k/64) is fine on the host.
+std::vector<int32_t> min_degree_order(int k, const std::vector<std::pair<int, int>> &edges)
+{
+  const int W = (k + 63) / 64;
+  std::vector<uint64_t> adj((size_t)k * W, 0);
+  auto set  = [&](int a, int b) { adj[(size_t)a * W + (b >> 6)] |= (1ull << (b & 63)); };
+  for (auto [a, b] : edges)
+    if (a != b) { set(a, b); set(b, a); }
+  std::vector<int> deg(k);
+  std::vector<char> done(k, 0);
+  auto degree = [&](int a) {
+    int d = 0;
+    for (int w = 0; w < W; ++w) d += __builtin_popcountll(adj[(size_t)a * W + w]);
+    return d;
+  };
+  for (int a = 0; a < k; ++a) deg[a] = degree(a);
+  std::vector<int32_t> order;
+  order.reserve(k);
+  std::vector<int> nb;
+  for (int step = 0; step < k; ++step) {
+    int best = -1;
+    for (int a = 0; a < k; ++a)
+      if (!done[a] && (best < 0 || deg[a] < deg[best])) best = a;  // ties: lowest index
+    order.push_back(best);
+    done[best] = 1;
+    nb.clear();
+    for (int w = 0; w < W; ++w) {
+      uint64_t bits = adj[(size_t)best * W + w];
+      while (bits) {
+        const int b = (w << 6) + __builtin_ctzll(bits);
+        bits &= bits - 1;
+        nb.push_back(b);
+      }
+    }
+    // eliminate: neighbours become a clique, `best` leaves the graph
+    for (int a : nb) {
+      uint64_t *ra = &adj[(size_t)a * W];
+      const uint64_t *rb = &adj[(size_t)best * W];
+      for (int w = 0; w < W; ++w) ra[w] |= rb[w];
+      ra[a >> 6] &= ~(1ull << (a & 63));
+      ra[best >> 6] &= ~(1ull << (best & 63));
+    }
+    for (int a : nb) deg[a] = degree(a);
+  }
+  return order;
+}
+
+}  // namespace
+
+bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const int32_t *Ap, const int32_t *Aj,
+                       int ordering, const int32_t *user_perm, SparsePlanHost &o, const char **msg)
+{
+  static const char *ok = "";
+  *msg = ok;
+  if (n < 1 || m < 1 || !Pp || !Ap) { *msg = "bad sizes / NULL pattern"; return false; }
+  const int k = n + m;
+  o = SparsePlanHost();
+  o.n = n; o.m = m; o.k = k;
+  o.nnzP = Pp[n]; o.nnzA = Ap[m];
+  if (Pp[0] != 0 || Ap[0] != 0 || o.nnzP < 0 || o.nnzA < 0) { *msg = "pattern pointers must start at 0"; return false; }
+  if ((o.nnzP > 0 && !Pi) || (o.nnzA > 0 && !Aj)) { *msg = "NULL index array"; return false; }
+  o.Pp.assign(Pp, Pp + n + 1); o.Pi.assign(Pi, Pi + o.nnzP);
+  o.Ap.assign(Ap, Ap + m + 1); o.Aj.assign(Aj, Aj + o.nnzA);
+  o.Pcol.resize(o.nnzP); o.Arow.resize(o.nnzA);
+  for (int c = 0; c < n; ++c) {
+    if (Pp[c + 1] < Pp[c]) { *msg = "P column pointers not monotone"; return false; }
+    for (int p = Pp[c]; p < Pp[c + 1]; ++p) {
+      if (Pi[p] < 0 || Pi[p] >= n) { *msg = "P row index out of range"; return false; }
+      if (p > Pp[c] && Pi[p] <= Pi[p - 1]) { *msg = "P row indices must be strictly ascending per column"; return false; }
+      o.Pcol[p] = c;
+    }
+  }
+  for (int r = 0; r < m; ++r) {
+    if (Ap[r + 1] < Ap[r]) { *msg = "A row pointers not monotone"; return false; }
+    for (int p = Ap[r]; p < Ap[r + 1]; ++p) {
+      if (Aj[p] < 0 || Aj[p] >= n) { *msg = "A column index out of range"; return false; }
+      if (p > Ap[r] && Aj[p] <= Aj[p - 1]) { *msg = "A column indices must be strictly ascending per row"; return false; }
+      o.Arow[p] = r;
+    }
+  }
+  transpose_pattern(m, n, o.Ap, o.Aj, o.Acp, o.Aci, o.Acpos);
+  transpose_pattern(n, n, o.Pp, o.Pi, o.Prp, o.Prj, o.Prpos);
+
+  // symmetric view of the upper-stored part of P: row i -> mirrored entries (cols < i), then upper ones
+  {
+    o.Sp.assign(n + 1, 0);
+    for (int c = 0; c < n; ++c)
+      for (int p = Pp[c]; p < Pp[c + 1]; ++p) {
+        const int r = Pi[p];
+        if (c >= r) { o.Sp[r + 1]++; if (r != c) o.Sp[c + 1]++; }
+      }
+    for (int i = 0; i < n; ++i) o.Sp[i + 1] += o.Sp[i];
+    o.Sj.resize(o.Sp[n]); o.Spos.resize(o.Sp[n]);
+    std::vector<int32_t> fill(n, 0);
+    for (int c = 0; c < n; ++c)
+      for (int p = Pp[c]; p < Pp[c + 1]; ++p)
+        if (Pi[p] < c) { o.Sj[o.Sp[c] + fill[c]] = Pi[p]; o.Spos[o.Sp[c] + fill[c]] = p; fill[c]++; }
+    for (int c = 0; c < n; ++c)
+      for (int p = Pp[c]; p < Pp[c + 1]; ++p) {
+        const int r = Pi[p];
+        if (c >= r) { o.Sj[o.Sp[r] + fill[r]] = c; o.Spos[o.Sp[r] + fill[r]] = p; fill[r]++; }
+      }
+  }
+
+  // KKT entries in ORIGINAL indices (upper triangle, qp_solver.hpp:382-395)
+  struct Ent { int r, c, kind, idx; };
+  std::vector<Ent> ents;
+  ents.reserve(o.nnzP + o.nnzA + k);
+  std::vector<char> hasdiag(n, 0);
+  for (int c = 0; c < n; ++c)
+    for (int p = Pp[c]; p < Pp[c + 1]; ++p)
+      if (c >= Pi[p]) {
+        ents.push_back({Pi[p], c, K_P, p});
+        if (Pi[p] == c) hasdiag[c] = 1;
+      }
+  for (int v = 0; v < n; ++v)
+    if (!hasdiag[v]) ents.push_back({v, v, K_SIGMA, v});
+  for (int r = 0; r < m; ++r) {
+    for (int p = Ap[r]; p < Ap[r + 1]; ++p) ents.push_back({Aj[p], n + r, K_A, p});
+    ents.push_back({n + r, n + r, K_RHO, r});
+  }
+
+  // elimination order
+  o.perm.resize(k);
+  if (user_perm) {
+    std::vector<char> seen(k, 0);
+    for (int i = 0; i < k; ++i) {
+      if (user_perm[i] < 0 || user_perm[i] >= k || seen[user_perm[i]]) { *msg = "user_perm is not a permutation"; return false; }
+      seen[user_perm[i]] = 1;
+      o.perm[i] = user_perm[i];
+    }
+  } else if (ordering == 0) {
+    std::iota(o.perm.begin(), o.perm.end(), 0);
+  } else {
+    std::vector<std::pair<int, int>> edges;
+    edges.reserve(ents.size());
+    for (const Ent &e : ents) edges.emplace_back(e.r, e.c);
+    o.perm = min_degree_order(k, edges);
+  }
+  o.pinv.resize(k);
+  for (int i = 0; i < k; ++i) o.pinv[o.perm[i]] = i;
+
+  // permuted lower CSC
+  struct PE { int i, j, kind, idx; };
+  std::vector<PE> pe;
+  pe.reserve(ents.size());
+  for (const Ent &e : ents) {
+    const int a = o.pinv[e.r], b = o.pinv[e.c];
+    pe.push_back({std::max(a, b), std::min(a, b), e.kind, e.idx});
+  }
+  std::sort(pe.begin(), pe.end(), [](const PE &x, const PE &y) { return std::tie(x.j, x.i) < std::tie(y.j, y.i); });
+  o.nnzK = (int)pe.size();
+  o.Kp.assign(k + 1, 0); o.Ki.resize(o.nnzK); o.Kkind.resize(o.nnzK); o.Kidx.resize(o.nnzK);
+  for (int t = 0; t < o.nnzK; ++t) {
+    o.Kp[pe[t].j + 1]++;
+    o.Ki[t] = pe[t].i; o.Kkind[t] = pe[t].kind; o.Kidx[t] = pe[t].idx;
+  }
+  for (int j = 0; j < k; ++j) o.Kp[j + 1] += o.Kp[j];
+
+  // rows of the lower form (strict): row r -> columns j < r
+  std::vector<int32_t> rp(k + 1, 0), rj;
+  for (const PE &e : pe)
+    if (e.i != e.j) rp[e.i + 1]++;
+  for (int r = 0; r < k; ++r) rp[r + 1] += rp[r];
+  rj.resize(rp[k]);
+  {
+    std::vector<int32_t> fill(k, 0);
+    for (const PE &e : pe)
+      if (e.i != e.j) rj[rp[e.i] + fill[e.i]++] = e.j;
+  }
+  // elimination tree + pattern of L by row reach
+  std::vector<int32_t> parent(k, -1), flag(k, -1), lnz(k, 0);
+  for (int r = 0; r < k; ++r) {
+    flag[r] = r;
+    for (int p = rp[r]; p < rp[r + 1]; ++p)
+      for (int i = rj[p]; flag[i] != r; i = parent[i]) {
+        if (parent[i] == -1) parent[i] = r;
+        lnz[i]++;
+        flag[i] = r;
+      }
+  }
+  o.Lp.assign(k + 1, 0);
+  for (int j = 0; j < k; ++j) o.Lp[j + 1] = o.Lp[j] + lnz[j];
+  o.nnzL = o.Lp[k];
+  o.Li.resize(o.nnzL);
+  {
+    std::vector<int32_t> fill(k, 0);
+    std::fill(flag.begin(), flag.end(), -1);
+    for (int r = 0; r < k; ++r) {
+      flag[r] = r;
+      for (int p = rp[r]; p < rp[r + 1]; ++p)
+        for (int i = rj[p]; flag[i] != r; i = parent[i]) {
+          o.Li[o.Lp[i] + fill[i]++] = r;
+          flag[i] = r;
+        }
+    }
+  }
+  transpose_pattern(k, k, o.Lp, o.Li, o.Rp, o.Rk, o.Rpos);
+  return true;
+}
+
+}  // namespace sfb

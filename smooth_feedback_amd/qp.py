@@ -201,3 +201,106 @@ def random_qp_batch(seed, batch, m, n, density):
     _capi.check(_capi.lib.sfb_random_qp_batch(seed, batch, m, n, float(density), _ptr(P), _ptr(q), _ptr(A),
                                               _ptr(l), _ptr(u)))
     return P, q, A, l, u
+
+
+# ------------------------------------------------------------------------------------------------
+# Sparse problems sharing one pattern: QuadraticProgramSparse (qp.hpp:60-79) and the sparse
+# instantiation of QPSolver (qp_solver.hpp sparse branches), as used by MPC::operator() (mpc.hpp:491).
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class QuadraticProgramSparse:
+    """qp.hpp:60-79.  P: scipy.sparse CSC (as stored; only col >= row enters the KKT matrix),
+    A: scipy.sparse CSR, q (n,), l,u (m,)."""
+    P: object
+    q: np.ndarray
+    A: object
+    l: np.ndarray
+    u: np.ndarray
+
+
+class SparseQPPlan:
+    """Symbolic analysis shared by a batch: QPSolver::analyze + SimplicialLDLT::analyzePattern
+    (qp_solver.hpp:297-338, :424).  Host-only; owns an sfb_sparse_qp_plan."""
+
+    def __init__(self, n, m, P_colptr, P_rowind, A_rowptr, A_colind, ordering=1, user_perm=None):
+        self.n, self.m = int(n), int(m)
+        self._keep = [np.ascontiguousarray(a, dtype=np.int32) for a in (P_colptr, P_rowind, A_rowptr, A_colind)]
+        up = None if user_perm is None else np.ascontiguousarray(user_perm, dtype=np.int32)
+        h = C.c_void_p()
+        _capi.check(_capi.lib.sfb_sparse_qp_plan_create(
+            self.n, self.m, *[_ptr(a) if a.size else None for a in self._keep], int(ordering), _ptr(up),
+            C.byref(h)))
+        self._h = h
+        a, b, c_ = C.c_int64(), C.c_int64(), C.c_int64()
+        _capi.check(_capi.lib.sfb_sparse_qp_plan_info(h, C.byref(a), C.byref(b), C.byref(c_)))
+        self.nnzK, self.nnzL, self.workspace_bytes_per_item = a.value, b.value, c_.value
+        self.nnzP, self.nnzA = int(self._keep[0][-1]), int(self._keep[2][-1])
+
+    @classmethod
+    def from_scipy(cls, P, A, **kw):
+        import scipy.sparse as sp
+        P = sp.csc_matrix(P); P.sort_indices()
+        A = sp.csr_matrix(A); A.sort_indices()
+        return cls(A.shape[1], A.shape[0], P.indptr, P.indices, A.indptr, A.indices, **kw)
+
+    @property
+    def perm(self):
+        p = np.empty(self.n + self.m, dtype=np.int32)
+        _capi.check(_capi.lib.sfb_sparse_qp_plan_get_perm(self._h, _ptr(p)))
+        return p
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _capi.lib.sfb_sparse_qp_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve_batch_host(self, Px, q, Ax, l, u, prm: Optional[QPSolverParams] = None, warm_x=None, warm_y=None):
+        """sfb_sparse_qp_solve_batch_host: Px (B, nnzP), q (B, n), Ax (B, nnzA), l,u (B, m)."""
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        B = q.shape[0]
+        Px = _f64(np.reshape(Px, (B, self.nnzP)), (B, self.nnzP))
+        Ax = _f64(np.reshape(Ax, (B, self.nnzA)), (B, self.nnzA))
+        q = _f64(q, (B, self.n)); l = _f64(l, (B, self.m)); u = _f64(u, (B, self.m))
+        if (warm_x is None) != (warm_y is None):
+            raise ValueError("warm_x and warm_y must be given together")
+        if warm_x is not None:
+            warm_x = _f64(warm_x, (B, self.n)); warm_y = _f64(warm_y, (B, self.m))
+        x = np.empty((B, self.n)); y = np.empty((B, self.m)); obj = np.empty(B)
+        it = np.empty(B, dtype=np.uint32); code = np.empty(B, dtype=np.int32)
+        cp = (prm or QPSolverParams()).to_c()
+        _capi.check(_capi.lib.sfb_sparse_qp_solve_batch_host(
+            self._h, C.byref(cp), B, _ptr(Px), _ptr(q), _ptr(Ax), _ptr(l), _ptr(u), _ptr(warm_x), _ptr(warm_y),
+            _ptr(x), _ptr(y), _ptr(obj), _ptr(it), _ptr(code)))
+        return QPBatchSolution(code=code, iter=it, primal=x, dual=y, objective=obj)
+
+    def solve_batch_device(self, B, dPx, dq, dAx, dl, du, dx, dy, dobj, diter, dcode, dworkspace, prm=None,
+                           dwarm_x=0, dwarm_y=0, stream=0):
+        """sfb_sparse_qp_solve_batch on device pointers (ints); asynchronous on `stream`."""
+        cp = (prm or QPSolverParams()).to_c()
+        _capi.check(_capi.lib.sfb_sparse_qp_solve_batch(
+            self._h, C.byref(cp), B, dPx, dq, dAx, dl, du, dwarm_x or None, dwarm_y or None, dx, dy,
+            dobj or None, diter or None, dcode, dworkspace, stream or None))
+
+
+def solve_qp_sparse(pbm: QuadraticProgramSparse, prm: Optional[QPSolverParams] = None,
+                    warmstart: Optional[QPSolution] = None) -> QPSolution:
+    """solve_qp for QuadraticProgramSparse (qp_solver.hpp:779-787, sparse instantiation)."""
+    import scipy.sparse as sp
+    P = sp.csc_matrix(pbm.P); P.sort_indices()
+    A = sp.csr_matrix(pbm.A); A.sort_indices()
+    plan = SparseQPPlan(A.shape[1], A.shape[0], P.indptr, P.indices, A.indptr, A.indices)
+    wx = wy = None
+    if warmstart is not None:
+        wx = np.asarray(warmstart.primal, dtype=np.float64)[None]
+        wy = np.asarray(warmstart.dual, dtype=np.float64)[None]
+    r = plan.solve_batch_host(P.data[None], np.asarray(pbm.q, float)[None], A.data[None],
+                              np.asarray(pbm.l, float)[None], np.asarray(pbm.u, float)[None], prm, wx, wy)
+    plan.close()
+    return QPSolution(code=QPSolutionStatus(int(r.code[0])), iter=int(r.iter[0]), primal=r.primal[0], dual=r.dual[0],
+                      objective=float(r.objective[0]))

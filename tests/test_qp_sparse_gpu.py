@@ -1,0 +1,60 @@
+"""Parity of the HIP sparse (shared-pattern) QP kernel with the sparse CPU oracle.  Needs an MI355X.
+Bar: codes and iteration counts bit-exact, primal/dual within 1e-8 (relative to 1+|value|)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from qp_cases import KNOWN_ANSWERS, is_approx
+from sparse_cases import dense_batch_to_sparse
+from test_qp_dense_gpu import _compare, _oracle_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", sorted(KNOWN_ANSWERS))
+def test_sparse_known_answers(sfb, oracle, name):
+    case = KNOWN_ANSWERS[name]
+    P, q, A, l, u = (np.asarray(t, dtype=np.float64) for t in case[:5])
+    Pc = sp.csc_matrix(P); Pc.eliminate_zeros(); Pc.sort_indices()
+    Ac = sp.csr_matrix(A); Ac.sort_indices()
+    plan = sfb.SparseQPPlan(len(q), len(l), Pc.indptr, Pc.indices, Ac.indptr, Ac.indices)
+    prm = sfb.QPSolverParams(max_iter=100000)
+    r = plan.solve_batch_host(Pc.data[None], q[None], Ac.data[None], l[None], u[None], prm)
+    code, primal, ptol, objv, otol = case[5:]
+    assert int(r.code[0]) == code
+    if primal is not None:
+        assert is_approx(r.primal[0], primal, ptol)
+    if objv is not None:
+        assert abs(r.objective[0] - objv) <= otol
+    ref = oracle.qp_sparse_solve_batch(Pc.indptr, Pc.indices, Pc.data[None], q[None], Ac.indptr, Ac.indices,
+                                       Ac.data[None], l[None], u[None], perm=plan.perm,
+                                       params=_oracle_params(oracle, prm))
+    _compare(r, ref)
+    sol = sfb.solve_qp_sparse(sfb.QuadraticProgramSparse(P=Pc, q=q, A=Ac, l=l, u=u))
+    assert int(sol.code) == code
+
+
+@pytest.mark.parametrize("n,m,density,ordering", [(10, 20, 0.3, 1), (10, 20, 1.0, 0), (6, 9, 0.5, 1), (30, 50, 0.15, 1),
+                                                  (80, 120, 0.05, 1)])
+def test_random_sparse_batches(sfb, oracle, n, m, density, ordering):
+    B = 192
+    P, q, A, l, u = sfb.random_qp_batch(13, B, m, n, density)
+    rng = np.random.default_rng(n + m)
+    l = np.where(rng.random((B, m)) < 0.3, u - 2 * rng.random((B, m)), l)
+    l = np.where(rng.random((B, m)) < 0.1, u, l)
+    Pp, Pi, Px, Ap, Aj, Ax = dense_batch_to_sparse(P, A, n, m, upper_only=(n % 2 == 0))
+    plan = sfb.SparseQPPlan(n, m, Pp, Pi, Ap, Aj, ordering=ordering)
+    for prm in (sfb.QPSolverParams(max_iter=2000), sfb.QPSolverParams(max_iter=600, scaling=False, polish=False)):
+        r = plan.solve_batch_host(Px, q, Ax, l, u, prm)
+        ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Ax, l, u, perm=plan.perm,
+                                           params=_oracle_params(oracle, prm), nthreads=8)
+        bit = _compare(r, ref)
+        print(n, m, "nnzL", plan.nnzL, "bit-identical:", bit, "codes", np.bincount(r.code, minlength=7))
+    # warm start
+    prm = sfb.QPSolverParams(max_iter=2000)
+    ok = np.isfinite(ref["x"]).all(1) & np.isfinite(ref["y"]).all(1)
+    wx, wy = np.where(ok[:, None], ref["x"], 0.0), np.where(ok[:, None], ref["y"], 0.0)
+    r2 = plan.solve_batch_host(Px, q + 0.01, Ax, l, u, prm, warm_x=wx, warm_y=wy)
+    ref2 = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q + 0.01, Ap, Aj, Ax, l, u, perm=plan.perm,
+                                        params=_oracle_params(oracle, prm), warm_x=wx, warm_y=wy, nthreads=8)
+    _compare(r2, ref2)
