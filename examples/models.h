@@ -1,0 +1,35 @@
+/* Example / test harness around the C++ host front (include/smooth_feedback_amd/*.hpp): concrete MPC
+ * models with a C interface so that Python tests and bench.py can drive the host-side assembly.
+ * NOT part of the product C-ABI (that is include/sfb.h); built into libsfb_models.so. */
+#ifndef SFBX_MODELS_H
+#define SFBX_MODELS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* variant 6 : X = Bundle<SE2,R3>, U = R2   -- the vehicle of examples/mpc_asif_vehicle.cpp:42-79
+ * variant 12: X = Bundle<SE2,R3,SE2,R3>, U = R2 -- two such vehicles driven by one input pair
+ *             (synthetic: matches BASELINE.json's "nx=12, nu=2" problem size n = m = 740 at K = 50) */
+int sfbx_mpc_dims(int variant, int K, int *n, int *m, int *nnzP, int *nnzA, int *Nx, int *Nu, int *N);
+/* pattern (+ P values, identical for all agents).  Arrays sized by sfbx_mpc_dims. */
+int sfbx_mpc_pattern(int variant, int K, double tf, int32_t *Pp, int32_t *Pi, double *Pval, int32_t *Ap, int32_t *Aj);
+/* Assemble `batch` agents: agent b runs at time t_b = 0.025*(b % 400) from x_b = xdes(t_b) (+) xi_b,
+ * xi_b ~ U(-0.5,0.5)^Nx from std::mt19937_64(seed + b).  Aval [batch][nnzA], l,u [batch][m]. */
+int sfbx_mpc_assemble_batch(int variant, int K, double tf, int64_t batch, uint64_t seed, double *Aval, double *l,
+                            double *u, int threads);
+/* Closed loop of tests/test_mpc.cpp:34-117 (SE2 state, R2 input, f = (u0, 0, u1), -1 <= u <= 1):
+ * three consecutive MPC calls with warm start, then three without. u_out[6][2], codes[6]. Needs a GPU. */
+int sfbx_test_mpc_se2(double *u_out, int32_t *codes, int32_t *traj_sizes);
+/* Swarm tick through MPCSwarm (host assembly + one batched GPU solve): returns u0 [batch][2], codes. */
+int sfbx_mpc_swarm_step(int variant, int K, double tf, int64_t batch, uint64_t seed, int ticks, double *u0,
+                        int32_t *codes, uint32_t *iters);
+/* group identities for the tests: returns max abs error over a set of checks */
+double sfbx_lie_selftest(void);
+/* mesh: nodes (N+1), weights (N+1), Dus ((K+1)*K col-major) for `n` intervals of K points */
+int sfbx_mesh(int n_ivals, int K, double *nodes, double *weights, double *Dus);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

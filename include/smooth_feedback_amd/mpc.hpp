@@ -1,0 +1,429 @@
+// Host side of the MPC path: re-linearise around (xdes, udes), transcribe to a sparse QP in error
+// coordinates on an LGR mesh, solve the QP(s) on the GPU through the C-ABI, return udes(0) (+) du_0.
+//
+// Mirrors smooth::feedback::MPC (reference mpc.hpp:405-519) and the transcription it calls:
+//   ocp_to_qp_allocate        ocp_to_qp.hpp:40-114   variable/row layout and sparsity pattern
+//   ocp_to_qp_update_cost     :117-195 (+ mesh_integrate, mesh_function.hpp:273-419)  -- ctor only
+//   ocp_to_qp_update_dyn      :198-276
+//   ocp_to_qp_update_cr       :279-323
+//   ocp_to_qp_update_ce       :326-373 with MPCCE (mpc.hpp:275-302)
+// Deviations, all on the host: time is a double (seconds) instead of a chrono-like T; Jacobians of
+// user functions are analytic when the functor has `jacobian(...)`, else forward differences with
+// step sqrt(eps) (the reference's default without the autodiff header); weights are taken at
+// construction (in reference v1 set_weights() never reaches the QP: cost is transcribed only in
+// the constructor, mpc.hpp:423 vs :593-598).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <functional>
+#include <optional>
+#include <limits>
+#include <memory>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "lie.hpp"
+#include "mesh.hpp"
+#include "qp.hpp"
+
+namespace smooth_feedback_amd {
+
+/// mpc.hpp:309-333
+struct MPCParams {
+  std::size_t K{10};
+  double tf{1};
+  bool warmstart{true};
+  QPSolverParams qp{};
+};
+
+/// mpc.hpp:344-356
+template<class X, class U>
+struct MPCWeights {
+  Mat<X::Dof, X::Dof> Q   = Mat<X::Dof, X::Dof>::Identity();
+  Mat<X::Dof, X::Dof> Qtf = Mat<X::Dof, X::Dof>::Identity();
+  Mat<U::Dof, U::Dof> R   = Mat<U::Dof, U::Dof>::Identity();
+};
+
+template<class X, class U, int Ncr_, class F, class CR, int Kmesh = 4>
+class MPC {
+public:
+  static constexpr int Nx = X::Dof, Nu = U::Dof, Ncr = Ncr_;
+  using TangentX = Vec<Nx>;
+
+  MPC(F f, CR cr, Vec<Ncr> crl, Vec<Ncr> cru, MPCParams prm = {}, MPCWeights<X, U> w = {})
+      : f_(std::move(f)), cr_(std::move(cr)), crl_(crl), cru_(cru), prm_(std::move(prm)),
+        mesh_(int((prm_.K + Kmesh - 1) / Kmesh), Kmesh), solver_(std::make_shared<SparseQPSolver>(prm_.qp))
+  {
+    xdes_ = [](double) { return X::Identity(); };
+    dxdes_ = [](double) { return TangentX{}; };
+    udes_ = [](double) { return U::Identity(); };
+    allocate(w);
+  }
+
+  // ---- desired trajectories (absolute time), mpc.hpp:524-586 ----
+  void set_xdes(std::function<X(double)> x_des, std::function<TangentX(double)> dx_des)
+  {
+    xdes_ = std::move(x_des);
+    dxdes_ = std::move(dx_des);
+  }
+  /// derivative by central differences of x(t) (the reference autodiffs / finite-differences x(t))
+  void set_xdes(std::function<X(double)> x_des)
+  {
+    auto xd = x_des;
+    dxdes_  = [xd](double t) {
+      const double h = 1e-6;
+      TangentX d     = rminus(xd(t + h), xd(t - h));
+      for (auto & v : d) v /= (2 * h);
+      return d;
+    };
+    xdes_ = std::move(x_des);
+  }
+  void set_udes(std::function<U(double)> u_des) { udes_ = std::move(u_des); }
+  void reset_warmstart() { warm_.reset(); }
+
+  // ---- sizes / pattern ----
+  int N() const { return mesh_.N_colloc(); }
+  int nvar() const { return Nx * (N() + 1) + Nu * N(); }
+  int ncon() const { return Nx * N() + Ncr * N() + Nx; }
+  int uvar_B() const { return Nx * (N() + 1); }
+  const QuadraticProgramSparse & qp() const { return qp_; }
+  const Mesh & mesh() const { return mesh_; }
+  const MPCParams & params() const { return prm_; }
+  SparseQPSolver & solver() { return *solver_; }
+
+  /// Numeric part of MPC::operator() before the solve (mpc.hpp:473-486): writes the values of A (in
+  /// the pattern of qp().A_*), l and u for current time t and state x.  Thread-safe (const).
+  void assemble(double t, const X & x, double * Aval, double * l, double * u) const
+  {
+    const int Nn = N();
+    const double tf = prm_.tf;
+    for (int p = 0; p < (int)qp_.A_val.size(); ++p) Aval[p] = 0.0;  // set_zero(A.middleRows(...)), :236
+    // --- ocp_to_qp_update_dyn :240-275 ---
+    for (int s = 0, M = 0; s < mesh_.N_ivals(); M += Kmesh, ++s) {
+      const double alpha = mesh_.alpha(s);
+      for (int i = 0; i < Kmesh; ++i) {
+        const int node   = M + i;
+        const double t_i = tf * mesh_.node(node);
+        const X xl       = xdes_(t + t_i);
+        const TangentX dxl = dxdes_(t + t_i);
+        const U ul       = udes_(t + t_i);
+        Vec<Nx> fv;
+        Mat<Nx, Nx> dfdx;
+        Mat<Nx, Nu> dfdu;
+        dyn_jacobian(xl, ul, fv, dfdx, dfdu);
+        Mat<Nx, Nx> adm{};
+        if constexpr (!X::IsCommutative) {
+          TangentX s2;
+          for (int d = 0; d < Nx; ++d) s2[d] = fv[d] + dxl[d];
+          adm = X::ad(s2);
+        }
+        for (int d = 0; d < Nx; ++d) {
+          const int row = dcon_B() + node * Nx + d;
+          int p         = qp_.A_rowptr[row];
+          for (int j = 0; j <= Kmesh; ++j) {  // x blocks of the interval, ascending column order
+            const double dc = alpha * mesh_.D(j, i);
+            if (j == i) {
+              for (int c = 0; c < Nx; ++c) {
+                double v = 0.0;
+                v += tf * dfdx(d, c);                                       // :258
+                if constexpr (!X::IsCommutative) v += (-tf / 2) * adm(d, c);  // :262-264
+                if (c == d) v -= dc;                                        // :266-270
+                Aval[p++] = v;
+              }
+            } else {
+              double v = 0.0;
+              v -= dc;
+              Aval[p++] = v;
+            }
+          }
+          for (int c = 0; c < Nu; ++c) Aval[p++] = 0.0 + tf * dfdu(d, c);  // :259
+          l[row] = -tf * (fv[d] - dxl[d]);                                // :272-273
+          u[row] = l[row];
+        }
+      }
+    }
+    // --- ocp_to_qp_update_cr :279-323 (always evaluated here; the reference skips it when cr has no
+    //     set_time, which leaves the constructor-time values -- identical for time-invariant cr) ---
+    for (int node = 0; node < Nn; ++node) {
+      const double t_i = tf * mesh_.node(node);
+      const X xl       = xdes_(t + t_i);
+      const U ul       = udes_(t + t_i);
+      Vec<Ncr> cv;
+      Mat<Ncr, Nx> dcdx;
+      Mat<Ncr, Nu> dcdu;
+      cr_jacobian(xl, ul, cv, dcdx, dcdu);
+      for (int d = 0; d < Ncr; ++d) {
+        const int row = crcon_B() + node * Ncr + d;
+        int p         = qp_.A_rowptr[row];
+        for (int c = 0; c < Nx; ++c) Aval[p++] = dcdx(d, c);
+        for (int c = 0; c < Nu; ++c) Aval[p++] = dcdu(d, c);
+        l[row] = crl_[d] - cv[d];  // :321
+        u[row] = cru_[d] - cv[d];  // :322
+      }
+    }
+    // --- ocp_to_qp_update_ce :326-373 with MPCCE: ce = x0 (-) x0_fix linearised at xl(0) ---
+    {
+      const X xl0      = xdes_(t);
+      const TangentX e = rminus(xl0, x);  // MPCCE::operator(), mpc.hpp:288-291
+      const auto J     = X::dr_expinv(e); // MPCCE::jacobian,  mpc.hpp:293-301
+      for (int d = 0; d < Nx; ++d) {
+        const int row = cecon_B() + d;
+        int p         = qp_.A_rowptr[row];
+        for (int c = 0; c < Nx; ++c) Aval[p++] = J(d, c);
+        l[row] = 0.0 - e[d];  // :371  cel - ceval
+        u[row] = 0.0 - e[d];  // :372
+      }
+    }
+  }
+
+  /// mpc.hpp:518   udes(0) (+) primal[uvar_B : +Nu]
+  U input_from_primal(double t, const double * primal) const
+  {
+    typename U::Tangent du{};
+    for (int c = 0; c < Nu; ++c) du[c] = primal[uvar_B() + c];
+    return rplus(udes_(t), du);
+  }
+
+  /// MPC::operator(), mpc.hpp:458-519
+  std::pair<U, QPSolutionStatus> operator()(double t, const X & x, std::vector<U> * u_traj = nullptr,
+                                            std::vector<X> * x_traj = nullptr)
+  {
+    assemble(t, x, qp_.A_val.data(), qp_.l.data(), qp_.u.data());
+    if (!solver_->analyzed()) solver_->analyze(qp_);
+    const QPSolution sol = solver_->solve(qp_, warm_ ? &*warm_ : nullptr);  // :491
+    const int Nn = N();
+    if (u_traj) {  // :494-500
+      u_traj->resize(Nn);
+      for (int i = 0; i < Nn; ++i) {
+        typename U::Tangent du{};
+        for (int c = 0; c < Nu; ++c) du[c] = sol.primal[uvar_B() + i * Nu + c];
+        (*u_traj)[i] = rplus(udes_(t + prm_.tf * mesh_.node(i)), du);
+      }
+    }
+    if (x_traj) {  // :501-507
+      x_traj->resize(Nn + 1);
+      for (int i = 0; i <= Nn; ++i) {
+        TangentX dx{};
+        for (int c = 0; c < Nx; ++c) dx[c] = sol.primal[i * Nx + c];
+        (*x_traj)[i] = rplus(xdes_(t + prm_.tf * mesh_.node(i)), dx);
+      }
+    }
+    if (prm_.warmstart &&
+        (sol.code == QPSolutionStatus::Optimal || sol.code == QPSolutionStatus::MaxTime ||
+         sol.code == QPSolutionStatus::MaxIterations))
+      warm_ = sol;  // :510-516
+    return {input_from_primal(t, sol.primal.data()), sol.code};
+  }
+
+private:
+  int dcon_B() const { return 0; }
+  int crcon_B() const { return Nx * N(); }
+  int cecon_B() const { return Nx * N() + Ncr * N(); }
+
+  // ocp_to_qp_allocate (:40-114) + constructor-time cost (:117-195; MPCIntegrand/MPCObj hessians,
+  // mpc.hpp:110-114, :198-227)
+  void allocate(const MPCWeights<X, U> & w)
+  {
+    const int Nn = N();
+    qp_.n = nvar();
+    qp_.m = ncon();
+    qp_.q.assign(qp_.n, 0.0);  // dF of the integrand and dtheta/dx vanish at the linearisation point
+    qp_.l.assign(qp_.m, 0.0);
+    qp_.u.assign(qp_.m, 0.0);
+    // A pattern, CSR, rows [dyn | cr | ce], columns [x_0..x_N | u_0..u_{N-1}]  (:56, :63-69)
+    qp_.A_rowptr.assign(1, 0);
+    for (int s = 0, M = 0; s < mesh_.N_ivals(); M += Kmesh, ++s)
+      for (int i = 0; i < Kmesh; ++i)
+        for (int d = 0; d < Nx; ++d) {
+          for (int j = 0; j <= Kmesh; ++j) {
+            if (j == i)
+              for (int c = 0; c < Nx; ++c) qp_.A_colind.push_back((M + j) * Nx + c);
+            else
+              qp_.A_colind.push_back((M + j) * Nx + d);
+          }
+          for (int c = 0; c < Nu; ++c) qp_.A_colind.push_back(uvar_B() + (M + i) * Nu + c);
+          qp_.A_rowptr.push_back((int)qp_.A_colind.size());
+        }
+    for (int node = 0; node < Nn; ++node)
+      for (int d = 0; d < Ncr; ++d) {
+        for (int c = 0; c < Nx; ++c) qp_.A_colind.push_back(node * Nx + c);
+        for (int c = 0; c < Nu; ++c) qp_.A_colind.push_back(uvar_B() + node * Nu + c);
+        qp_.A_rowptr.push_back((int)qp_.A_colind.size());
+      }
+    for (int d = 0; d < Nx; ++d) {
+      for (int c = 0; c < Nx; ++c) qp_.A_colind.push_back(c);
+      qp_.A_rowptr.push_back((int)qp_.A_colind.size());
+    }
+    qp_.A_val.assign(qp_.A_colind.size(), 0.0);
+
+    // P (upper triangle, CSC): per node  w_i*tf*Q on x_i, w_i*tf*R on u_i (R entries guarded by
+    // Q(i,j) != 0 exactly like mpc.hpp:219-223); x_0 block += 0.5*Qtf (MPCObj writes Qtf into the
+    // x0 block, mpc.hpp:110-114, ocp_to_qp.hpp:189); x_N has no stored entry.
+    std::vector<std::vector<std::pair<int, double>>> cols(qp_.n);
+    auto add = [&](int r, int c, double v) {
+      if (r > c) return;  // upper_only
+      for (auto & e : cols[c])
+        if (e.first == r) { e.second += v; return; }
+      cols[c].push_back({r, v});
+    };
+    for (int i = 0; i < Nn; ++i) {
+      const double sc = (mesh_.weight(i) * 1.0) * (prm_.tf - 0.0);  // wl * (tf - t0)
+      for (int c = 0; c < Nx; ++c)
+        for (int r = 0; r < Nx; ++r)
+          if (w.Q(r, c) != 0) add(i * Nx + r, i * Nx + c, sc * w.Q(r, c));
+      for (int c = 0; c < Nu; ++c)
+        for (int r = 0; r < Nu; ++r)
+          if (w.Q(r, c) != 0) add(uvar_B() + i * Nu + r, uvar_B() + i * Nu + c, sc * w.R(r, c));
+    }
+    for (int c = 0; c < Nx; ++c)
+      for (int r = 0; r < Nx; ++r)
+        if (w.Qtf(r, c) != 0) add(r, c, 0.5 * w.Qtf(r, c));
+    qp_.P_colptr.assign(1, 0);
+    for (int c = 0; c < qp_.n; ++c) {
+      std::sort(cols[c].begin(), cols[c].end());
+      for (auto & e : cols[c]) {
+        qp_.P_rowind.push_back(e.first);
+        qp_.P_val.push_back(e.second);
+      }
+      qp_.P_colptr.push_back((int)qp_.P_rowind.size());
+    }
+  }
+
+  // f and its right-Jacobians at (x, u)
+  void dyn_jacobian(const X & x, const U & u, Vec<Nx> & fv, Mat<Nx, Nx> & dfdx, Mat<Nx, Nu> & dfdu) const
+  {
+    fv = f_(x, u);
+    if constexpr (requires(const F & ff) { ff.jacobian(x, u, dfdx, dfdu); }) {
+      f_.jacobian(x, u, dfdx, dfdu);
+    } else {
+      const double h = std::sqrt(std::numeric_limits<double>::epsilon());
+      for (int c = 0; c < Nx; ++c) {
+        TangentX e{};
+        e[c]          = h;
+        const auto f2 = f_(rplus(x, e), u);
+        for (int r = 0; r < Nx; ++r) dfdx(r, c) = (f2[r] - fv[r]) / h;
+      }
+      for (int c = 0; c < Nu; ++c) {
+        typename U::Tangent e{};
+        e[c]          = h;
+        const auto f2 = f_(x, rplus(u, e));
+        for (int r = 0; r < Nx; ++r) dfdu(r, c) = (f2[r] - fv[r]) / h;
+      }
+    }
+  }
+  void cr_jacobian(const X & x, const U & u, Vec<Ncr> & cv, Mat<Ncr, Nx> & dcdx, Mat<Ncr, Nu> & dcdu) const
+  {
+    cv = cr_(x, u);
+    if constexpr (requires(const CR & cc) { cc.jacobian(x, u, dcdx, dcdu); }) {
+      cr_.jacobian(x, u, dcdx, dcdu);
+    } else {
+      const double h = std::sqrt(std::numeric_limits<double>::epsilon());
+      for (int c = 0; c < Nx; ++c) {
+        TangentX e{};
+        e[c]          = h;
+        const auto c2 = cr_(rplus(x, e), u);
+        for (int r = 0; r < Ncr; ++r) dcdx(r, c) = (c2[r] - cv[r]) / h;
+      }
+      for (int c = 0; c < Nu; ++c) {
+        typename U::Tangent e{};
+        e[c]          = h;
+        const auto c2 = cr_(x, rplus(u, e));
+        for (int r = 0; r < Ncr; ++r) dcdu(r, c) = (c2[r] - cv[r]) / h;
+      }
+    }
+  }
+
+  F f_;
+  CR cr_;
+  Vec<Ncr> crl_, cru_;
+  MPCParams prm_;
+  Mesh mesh_;
+  std::function<X(double)> xdes_;
+  std::function<TangentX(double)> dxdes_;
+  std::function<U(double)> udes_;
+  QuadraticProgramSparse qp_;
+  std::shared_ptr<SparseQPSolver> solver_;
+  std::optional<QPSolution> warm_;
+};
+
+/// A swarm of agents running the same MPC (same model, horizon and weights => same QP pattern),
+/// each with its own time and state: host threads assemble, ONE batched GPU solve.
+template<class MPCT>
+class MPCSwarm {
+public:
+  explicit MPCSwarm(MPCT & proto, int64_t agents, int threads = 0)
+      : mpc_(proto), B_(agents), threads_(threads > 0 ? threads : (int)std::max(1u, std::thread::hardware_concurrency()))
+  {
+    const auto & qp = mpc_.qp();
+    nA_ = (int)qp.A_val.size();
+    nP_ = (int)qp.P_val.size();
+    Px_.resize((size_t)B_ * nP_);
+    q_.assign((size_t)B_ * qp.n, 0.0);
+    Ax_.resize((size_t)B_ * nA_);
+    l_.resize((size_t)B_ * qp.m);
+    u_.resize((size_t)B_ * qp.m);
+    x_.resize((size_t)B_ * qp.n);
+    y_.resize((size_t)B_ * qp.m);
+    iter_.resize(B_);
+    code_.resize(B_);
+    for (int64_t b = 0; b < B_; ++b) std::copy(qp.P_val.begin(), qp.P_val.end(), Px_.begin() + (size_t)b * nP_);
+  }
+
+  /// one control tick for all agents: returns inputs and per-agent status codes
+  template<class XT, class UT>
+  void step(const std::vector<double> & t, const std::vector<XT> & xs, std::vector<UT> & us,
+            std::vector<QPSolutionStatus> & codes)
+  {
+    const auto & qp = mpc_.qp();
+    parallel_for([&](int64_t b) {
+      mpc_.assemble(t[b], xs[b], &Ax_[(size_t)b * nA_], &l_[(size_t)b * qp.m], &u_[(size_t)b * qp.m]);
+    });
+    if (!mpc_.solver().analyzed()) mpc_.solver().analyze(qp);
+    const bool warm = mpc_.params().warmstart && have_warm_;
+    if (warm) { wx_ = x_; wy_ = y_; }
+    mpc_.solver().solve_batch(B_, Px_.data(), q_.data(), Ax_.data(), l_.data(), u_.data(), warm ? wx_.data() : nullptr,
+                              warm ? wy_.data() : nullptr, x_.data(), y_.data(), nullptr, iter_.data(), code_.data());
+    us.resize(B_);
+    codes.resize(B_);
+    bool all_storable = true;
+    for (int64_t b = 0; b < B_; ++b) {
+      us[b]    = mpc_.input_from_primal(t[b], &x_[(size_t)b * qp.n]);
+      codes[b] = static_cast<QPSolutionStatus>(code_[b]);
+      all_storable = all_storable && (code_[b] == 0 || code_[b] == 4 || code_[b] == 5);
+      if (!(code_[b] == 0 || code_[b] == 4 || code_[b] == 5)) {  // mpc.hpp:510-516: do not keep it
+        std::fill(x_.begin() + (size_t)b * qp.n, x_.begin() + (size_t)(b + 1) * qp.n, 0.0);
+        std::fill(y_.begin() + (size_t)b * qp.m, y_.begin() + (size_t)(b + 1) * qp.m, 0.0);
+      }
+    }
+    have_warm_ = true;
+  }
+  const std::vector<uint32_t> & iterations() const { return iter_; }
+  const std::vector<double> & Ax() const { return Ax_; }
+  const std::vector<double> & l() const { return l_; }
+  const std::vector<double> & u() const { return u_; }
+  const std::vector<double> & Px() const { return Px_; }
+  const std::vector<double> & primal() const { return x_; }
+
+private:
+  template<class Fn>
+  void parallel_for(Fn && fn)
+  {
+    const int T = (int)std::min<int64_t>(threads_, B_);
+    std::vector<std::thread> th;
+    for (int k = 0; k < T; ++k)
+      th.emplace_back([&, k] {
+        for (int64_t b = B_ * k / T; b < B_ * (k + 1) / T; ++b) fn(b);
+      });
+    for (auto & t : th) t.join();
+  }
+  MPCT & mpc_;
+  int64_t B_;
+  int threads_, nA_ = 0, nP_ = 0;
+  bool have_warm_ = false;
+  std::vector<double> Px_, q_, Ax_, l_, u_, x_, y_, wx_, wy_;
+  std::vector<uint32_t> iter_;
+  std::vector<int32_t> code_;
+};
+
+}  // namespace smooth_feedback_amd
