@@ -33,3 +33,8 @@ t100 = timed(sfb.QPSolverParams(max_iter=100, stop_check_iter=1, polish=False))
 per_it = (t100 - t50) / 50
 bytes_it = 2 * plan.nnzL * 8 * B
 print("setup+factor %.2f ms | per ADMM iteration %.3f ms (whole batch) -> factor stream %.1f GB/s" % (t_setup, per_it, bytes_it / per_it / 1e6))
+itc = it.cpu().numpy()
+print("iteration percentiles 50/90/99/99.9/max:", [int(np.percentile(itc, p)) for p in (50, 90, 99, 99.9, 100)], " #>300:", int((itc > 300).sum()))
+for cap in (200, 400):
+    ms = timed(sfb.QPSolverParams(max_iter=cap))
+    print("max_iter=%d: %.2f ms -> %.0f solves/s ; codes %s" % (cap, ms, B / ms * 1e3, np.bincount(code.cpu().numpy(), minlength=7)))

@@ -38,7 +38,8 @@ sfb_status plan_on_device(sfb_sparse_qp_plan *plan, const sfb::SparsePlanDev **o
   const sfb::SparsePlanHost &h = plan->host;
   const std::vector<int32_t> *arrs[] = {&h.Pp, &h.Pi, &h.Pcol, &h.Ap, &h.Aj, &h.Arow, &h.Acp, &h.Aci, &h.Acpos,
                                         &h.Prp, &h.Prj, &h.Prpos, &h.Sp, &h.Sj, &h.Spos, &h.perm, &h.pinv,
-                                        &h.Kp, &h.Ki, &h.Kkind, &h.Kidx, &h.Lp, &h.Li, &h.Rp, &h.Rk, &h.Rpos};
+                                        &h.Kp, &h.Ki, &h.Kkind, &h.Kidx, &h.Lp, &h.Li, &h.Rp, &h.Rk, &h.Rpos,
+                                        &h.fdesc, &h.bdesc};
   constexpr int NA = sizeof(arrs) / sizeof(arrs[0]);
   size_t off[NA + 1];
   off[0] = 0;
@@ -57,7 +58,9 @@ sfb_status plan_on_device(sfb_sparse_qp_plan *plan, const sfb::SparsePlanDev **o
   d.n = h.n; d.m = h.m; d.k = h.k; d.nnzP = h.nnzP; d.nnzA = h.nnzA; d.nnzK = h.nnzK; d.nnzL = h.nnzL;
   const int32_t **ptrs[] = {&d.Pp, &d.Pi, &d.Pcol, &d.Ap, &d.Aj, &d.Arow, &d.Acp, &d.Aci, &d.Acpos,
                             &d.Prp, &d.Prj, &d.Prpos, &d.Sp, &d.Sj, &d.Spos, &d.perm, &d.pinv,
-                            &d.Kp, &d.Ki, &d.Kkind, &d.Kidx, &d.Lp, &d.Li, &d.Rp, &d.Rk, &d.Rpos};
+                            &d.Kp, &d.Ki, &d.Kkind, &d.Kidx, &d.Lp, &d.Li, &d.Rp, &d.Rk, &d.Rpos,
+                            &d.fdesc, &d.bdesc};
+  d.fblocks = h.fblocks; d.bblocks = h.bblocks;
   for (int a = 0; a < NA; ++a) *ptrs[a] = dc.blob + off[a];
   auto ins = plan->per_device.emplace(devid, dc);
   *out     = &ins.first->second.dev;

@@ -79,6 +79,13 @@ __device__ __forceinline__ double kkt_value(const SparsePlanDev &pl, const Item 
 }
 
 // Left-looking numeric LDL' on the shared pattern; t = LDS work vector (k).  Returns 1 / 0 (zero pivot).
+//
+// Column j gathers its source columns kk < j (row structure of L, ascending).  All sources of a
+// column are complete before the column starts, so their descriptors (position, length, the
+// multiplier L(j,kk)*D(kk)) are fetched 64 at a time with vector gathers and the first 64-entry
+// chunk of source s + DEPTH is prefetched while source s is applied: the memory latency of the
+// factor stream is paid once per column instead of once per source.
+template<int DEPTH>
 __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, const Ws &w, double *t, const int mode,
                                       const double c, const double sigma, const double delta, const int lane)
 {
@@ -90,15 +97,55 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
     wave_sync();
     for (int p = pl.Kp[j] + lane; p < pl.Kp[j + 1]; p += kWave) t[pl.Ki[p]] = kkt_value(pl, it, w, p, mode, c, sigma, delta);
     wave_sync();
-    for (int tt = pl.Rp[j]; tt < pl.Rp[j + 1]; ++tt) {  // source columns kk < j, ascending
-      const int kk = pl.Rk[tt], pos = pl.Rpos[tt], end = pl.Lp[kk + 1];
-      const double wv = w.Lx[pos] * w.D[kk];  // L(j,kk) * D(kk)
-      for (int p = pos + lane; p < end; p += kWave) {
-        const int r = pl.Li[p];
-        t[r]        = fma(-w.Lx[p], wv, t[r]);
+    const int r0 = pl.Rp[j], r1 = pl.Rp[j + 1];
+    for (int g0 = r0; g0 < r1; g0 += kWave) {  // groups of <= 64 source columns, ascending
+      const int gcnt = min(kWave, r1 - g0);
+      int pos = 0, len = 0;
+      double wv = 0.0;
+      if (lane < gcnt) {
+        const int kk = pl.Rk[g0 + lane];
+        pos          = pl.Rpos[g0 + lane];
+        len          = pl.Lp[kk + 1] - pos;
+        wv           = w.Lx[pos] * w.D[kk];  // L(j,kk) * D(kk)
       }
-      wave_sync();
+      double lx[DEPTH];
+      int li[DEPTH];
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {  // first chunk of sources 0..DEPTH-1 (lanes beyond gcnt hold len = 0)
+        const int ps = __builtin_amdgcn_readlane(pos, d), ln = __builtin_amdgcn_readlane(len, d);
+        const bool on = lane < ln;
+        lx[d] = on ? w.Lx[ps + lane] : 0.0;
+        li[d] = on ? pl.Li[ps + lane] : 0;
+      }
+      for (int s0 = 0; s0 < gcnt; s0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+          const int sidx = s0 + d;  // < 64 + DEPTH: readlane index is taken mod 64 below
+          if (sidx < gcnt) {
+            const int ps = __builtin_amdgcn_readlane(pos, sidx), ln = __builtin_amdgcn_readlane(len, sidx);
+            const double ws = lane_bcast(wv, sidx);
+            if (lane < ln) {
+              const int r = li[d];
+              t[r]        = fma(-lx[d], ws, t[r]);
+            }
+            for (int off = kWave; off < ln; off += kWave) {  // rare: suffix longer than one chunk
+              if (off + lane < ln) {
+                const int r = pl.Li[ps + off + lane];
+                t[r]        = fma(-w.Lx[ps + off + lane], ws, t[r]);
+              }
+            }
+          }
+          const int sn = s0 + d + DEPTH;  // prefetch the first chunk of source sn
+          if (sn < gcnt) {
+            const int ps2 = __builtin_amdgcn_readlane(pos, sn), ln2 = __builtin_amdgcn_readlane(len, sn);
+            const bool on = lane < ln2;
+            lx[d] = on ? w.Lx[ps2 + lane] : 0.0;
+            li[d] = on ? pl.Li[ps2 + lane] : 0;
+          }
+        }
+      }
     }
+    wave_sync();
     const double d = t[j];
     if (lane == 0) {
       w.D[j]    = d;
@@ -114,32 +161,67 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
   return 1;
 }
 
+// One triangular sweep over a precomputed chunk schedule (sparse_plan.h): for every chunk
+//   t[idx[start + lane]] = fma(-vals[start + lane], t[pivot], t[idx[start + lane]])   (lane < count).
+// The factor is streamed from HBM: chunk c + DEPTH is fetched while chunk c is applied, so the
+// memory latency is overlapped with the (serially dependent) LDS updates.  Descriptors come 64 at a
+// time with one vector load and are handed out with v_readlane.  Order of operations == the plain
+// column-by-column loop, so results are unchanged.
+template<int DEPTH>
+__device__ inline void sweep_dev(const int32_t *__restrict__ desc, const int blocks, const double *vals,
+                                 const int32_t *__restrict__ idx, double *t, const int lane)
+{
+  const int2 *d2 = reinterpret_cast<const int2 *>(desc);
+  int2 dv        = d2[lane];
+  double lx[DEPTH];
+  int li[DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    const int st = __builtin_amdgcn_readlane(dv.x, d), meta = __builtin_amdgcn_readlane(dv.y, d);
+    const bool on = lane < (meta >> 24);
+    lx[d] = on ? vals[st + lane] : 0.0;
+    li[d] = on ? idx[st + lane] : 0;
+  }
+  for (int blk = 0; blk < blocks; ++blk) {
+    const int2 dvn = d2[(blk + 1) * 64 + lane];  // the schedule is padded by one block
+    for (int cc = 0; cc < 64; cc += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        const int c    = cc + d;
+        const int meta = __builtin_amdgcn_readlane(dv.y, c);
+        const int piv = meta & 0xFFFFFF, cnt = meta >> 24;
+        const double tj = t[piv];
+        if (lane < cnt) {
+          const int r = li[d];
+          t[r]        = fma(-lx[d], tj, t[r]);
+        }
+        const int cn = c + DEPTH;  // prefetch
+        int st2, meta2;
+        if (cn < 64) {
+          st2   = __builtin_amdgcn_readlane(dv.x, cn);
+          meta2 = __builtin_amdgcn_readlane(dv.y, cn);
+        } else {
+          st2   = __builtin_amdgcn_readlane(dvn.x, cn - 64);
+          meta2 = __builtin_amdgcn_readlane(dvn.y, cn - 64);
+        }
+        const bool on = lane < (meta2 >> 24);
+        lx[d] = on ? vals[st2 + lane] : 0.0;
+        li[d] = on ? idx[st2 + lane] : 0;
+      }
+    }
+    dv = dvn;
+  }
+  wave_sync();
+}
+
 // t (LDS, permuted order) <- K^-1 t   (qp_solver.hpp:457-459)
 __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, double *t, const int lane)
 {
   const int k = pl.k;
-  for (int j = 0; j < k; ++j) {  // forward, column oriented
-    const int c0 = pl.Lp[j], c1 = pl.Lp[j + 1];
-    if (c0 == c1) continue;
-    const double tj = t[j];
-    for (int p = c0 + lane; p < c1; p += kWave) {
-      const int r = pl.Li[p];
-      t[r]        = fma(-w.Lx[p], tj, t[r]);
-    }
-    wave_sync();
-  }
+  sweep_dev<16>(pl.fdesc, pl.fblocks, w.Lx, pl.Li, t, lane);   // forward, column oriented
   for (int j = lane; j < k; j += kWave) t[j] = w.Dinv[j] * t[j];
   wave_sync();
-  for (int j = k - 1; j >= 0; --j) {  // backward: row j pushes into its columns
-    const int r0 = pl.Rp[j], r1 = pl.Rp[j + 1];
-    if (r0 == r1) continue;
-    const double tj = t[j];
-    for (int p = r0 + lane; p < r1; p += kWave) {
-      const int cc = pl.Rk[p];
-      t[cc]        = fma(-w.LxT[p], tj, t[cc]);
-    }
-    wave_sync();
-  }
+  sweep_dev<16>(pl.bdesc, pl.bblocks, w.LxT, pl.Rk, t, lane);  // backward: row j pushes into its columns
 }
 
 __device__ __forceinline__ double lane_max_abs(const double *v, int len, int lane)
@@ -257,7 +339,7 @@ __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const 
   }
   for (int e = lane; e < k; e += kWave) w.tv[e] = 0.0;
   wave_sync();
-  if (!ldl_numeric_dev(pl, it, w, t, 1, c, kp.sigma, kp.delta, lane)) return;  // :187-190
+  if (!ldl_numeric_dev<8>(pl, it, w, t, 1, c, kp.sigma, kp.delta, lane)) return;  // :187-190
   for (uint32_t iter = 0; iter != kp.polish_iter; ++iter) {                      // :193-195
     for (int i = lane; i < n; i += kWave) {
       double acc = 0.0;
@@ -385,7 +467,7 @@ __global__ void __launch_bounds__(64) qp_sparse_kernel(const SparsePlanDev pl, c
   wave_sync();
 
   // ---- KKT fill + numeric factorisation :379-433 ----
-  if (!ldl_numeric_dev(pl, it, w, t, 0, c, kp.sigma, kp.delta, lane)) {
+  if (!ldl_numeric_dev<8>(pl, it, w, t, 0, c, kp.sigma, kp.delta, lane)) {
     ret_code = SFB_QP_UNKNOWN;
     // Dinv of the remaining columns is never used: the loop below does not run
   }

@@ -19,6 +19,8 @@ struct SparsePlanDev {
   const int32_t *Pp, *Pi, *Pcol, *Ap, *Aj, *Arow;
   const int32_t *Acp, *Aci, *Acpos, *Prp, *Prj, *Prpos, *Sp, *Sj, *Spos;
   const int32_t *perm, *pinv, *Kp, *Ki, *Kkind, *Kidx, *Lp, *Li, *Rp, *Rk, *Rpos;
+  const int32_t *fdesc, *bdesc;  // sweep schedules (int2 per chunk), see sparse_plan.h
+  int fblocks, bblocks;
 };
 
 // per-item workspace, in doubles

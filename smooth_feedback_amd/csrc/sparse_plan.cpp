@@ -229,6 +229,25 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
     }
   }
   transpose_pattern(k, k, o.Lp, o.Li, o.Rp, o.Rk, o.Rpos);
+
+  // sweep schedules
+  auto build = [&](const std::vector<int32_t> &ptr, bool descending, std::vector<int32_t> &desc, int &blocks) {
+    desc.clear();
+    for (int t = 0; t < k; ++t) {
+      const int j = descending ? k - 1 - t : t;
+      for (int p = ptr[j]; p < ptr[j + 1]; p += 64) {
+        const int cnt = std::min(64, ptr[j + 1] - p);
+        desc.push_back(p);
+        desc.push_back(j | (cnt << 24));
+      }
+    }
+    const int nchunks = (int)desc.size() / 2;
+    blocks            = (nchunks + 63) / 64;
+    desc.resize((size_t)(blocks + 1) * 64 * 2, 0);  // empty chunks: start 0, pivot 0, count 0
+  };
+  if (k >= (1 << 24)) { *msg = "n+m too large for the sweep schedule encoding"; return false; }
+  build(o.Lp, false, o.fdesc, o.fblocks);
+  build(o.Rp, true, o.bdesc, o.bblocks);
   return true;
 }
 

@@ -27,6 +27,10 @@ struct SparsePlanHost {
   std::vector<int32_t> Kp, Ki, Kkind, Kidx;    // permuted KKT, lower CSC
   std::vector<int32_t> Lp, Li;                 // strictly-lower pattern of L (col-major, rows ascending)
   std::vector<int32_t> Rp, Rk, Rpos;           // row structure of L
+  // Sweep schedules: chunks of <= 64 entries, descriptor = {start, pivot | count << 24}, padded with
+  // empty chunks to a multiple of 64 plus one extra block (the kernel prefetches ahead branch-free).
+  std::vector<int32_t> fdesc, bdesc;           // forward (columns ascending) / backward (rows descending)
+  int fblocks = 0, bblocks = 0;                // number of 64-chunk blocks (without the extra block)
 };
 
 // ordering: 0 = natural, 1 = minimum degree (default); user_perm (k entries, new->old) overrides.
