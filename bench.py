@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native batched QP engine.
 
-    python bench.py --gpus N --steps K --warmup W [--workload qp_dense|...]
+    python bench.py --gpus N --steps K --warmup W [--workload mpc|qp_dense]
 
-One "step" = one pass of the hot path (sfb_qp_dense_solve_batch, HIP) over one batch of synthetic
-QPs that is already resident in HBM.  For N > 1 the driver launches one rank per GPU with
+One "step" = one pass of the hot path over one batch of synthetic QPs that is already resident in
+HBM: by default the MPC configuration the BASELINE metric is quoted on (8 192 agents, nx=12, nu=2,
+K=50 -> sparse QPs with n = m = 740, sfb_sparse_qp_solve_batch); `--workload qp_dense` runs
+BASELINE configs[1] (65 536 dense QPs n=10, m=20, sfb_qp_dense_solve_batch).  For N > 1 the driver launches one rank per GPU with
 torch.distributed.run; every rank owns an independent shard of the batch (weak scaling: per-GPU
 batch fixed), the data path has no collective, and only the per-QP (code, iter) words are
 gathered over RCCL at the end of each step.  Rank 0 prints ONE JSON line.
@@ -89,15 +91,100 @@ class DenseQPWorkload:
                           "reference ADMM, %d pthreads, static partition), %.1f s" % (S, cores, dt)}, parity
 
 
-WORKLOADS = {"qp_dense": DenseQPWorkload}
+class MPCWorkload:
+    """BASELINE.json configs[2] (the configuration the metric string is quoted on): a swarm of
+    SE2xR3-type vehicles, nx=12, nu=2, K=50 (13 LGR intervals x 4 nodes, N=52 => n = m = 740 per QP),
+    transcribed on the host by the C++ front (examples/models.cpp over include/smooth_feedback_amd/
+    mpc.hpp, mirroring mpc.hpp:458-519 / ocp_to_qp.hpp), default MPCParams.qp, cold start.
+    Agent b: t_b = 0.025 (b mod 400), x_b = xdes(t_b) (+) U(-0.5,0.5)^12."""
+
+    def __init__(self, sfb, rank, device, batch=8192, variant=12, K=50):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import models_lib as M
+        self.sfb, self.B = sfb, batch
+        d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
+        self.d, self.pat = d, (Pp, Pi, Pv, Ap, Aj)
+        self.name = "mpc_qp_nx%d_nu%d_K%d_b%d_default_qp_params" % (d["Nx"], d["Nu"], K, batch)
+        t0 = time.perf_counter()
+        Av, l, u = M.mpc_assemble_batch(variant, K, batch, seed=1000003 * rank + 3, threads=os.cpu_count() or 8)
+        self.host_assembly_s = time.perf_counter() - t0
+        self.plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj)
+        self.prm = sfb.QPSolverParams()  # MPCParams.qp{} defaults (mpc.hpp:332)
+        self.host = (np.tile(Pv, (batch, 1)), np.zeros((batch, d["n"])), Av, l, u)
+        self.dev = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in self.host]
+        f64 = dict(dtype=torch.float64, device=device)
+        self.x = torch.empty((batch, d["n"]), **f64)
+        self.y = torch.empty((batch, d["m"]), **f64)
+        self.obj = torch.empty(batch, **f64)
+        self.out = torch.empty((2, batch), dtype=torch.int32, device=device)
+        self.ws = torch.empty(batch * self.plan.workspace_bytes_per_item // 8, **f64)
+        self.units_per_step = batch
+        n, m = d["n"], d["m"]
+        # SURVEY.md section 8(d): values of P, q, A, l, u in; x, y, obj, iter, code out
+        self.bytes_per_unit = 8 * (d["nnzP"] + n + d["nnzA"] + 2 * m) + 8 * (n + m) + 16
+        self.ub = d["Nx"] * (d["N"] + 1)
+        self.small = torch.empty((batch, 4), **f64)  # u0 (2), code, iter: what an MPC tick returns
+
+    def step(self, stream):
+        Px, q, Ax, l, u = self.dev
+        self.plan.solve_batch_device(self.B, Px.data_ptr(), q.data_ptr(), Ax.data_ptr(), l.data_ptr(), u.data_ptr(),
+                                     self.x.data_ptr(), self.y.data_ptr(), self.obj.data_ptr(),
+                                     self.out[0].data_ptr(), self.out[1].data_ptr(), self.ws.data_ptr(), self.prm,
+                                     stream=stream.cuda_stream)
+
+    def small_outputs(self):
+        self.small[:, 0:2] = self.x[:, self.ub:self.ub + 2]
+        self.small[:, 2] = self.out[1]
+        self.small[:, 3] = self.out[0]
+        return self.small
+
+    def extra(self):
+        it = self.out[0].cpu().numpy().astype(np.int64)
+        code = self.out[1].cpu().numpy()
+        return {"iterations": {"mean": float(it.mean()), "p50": int(np.percentile(it, 50)),
+                               "p99": int(np.percentile(it, 99)), "max": int(it.max())},
+                "codes": np.bincount(code, minlength=7).tolist(), "nnzL": int(self.plan.nnzL),
+                "factor_stream_bytes_per_iteration_per_qp": int(16 * self.plan.nnzL),
+                "host_assembly_s": self.host_assembly_s}
+
+    def cpu_baseline(self, cores, budget_s=20.0):
+        from oracle import loader as O
+        Pp, Pi, Pv, Ap, Aj = self.pat
+        Px, q, Av, l, u = self.host
+        op = O.default_params()  # max_iter unset, like the device run (device cap 2e7 is never reached here)
+        S = int(min(self.B, max(cores, 2 * cores)))
+        t0 = time.perf_counter()
+        ref = O.qp_sparse_solve_batch(Pp, Pi, Px[:S], q[:S], Ap, Aj, Av[:S], l[:S], u[:S], perm=self.plan.perm,
+                                      params=op, nthreads=cores)
+        dt = time.perf_counter() - t0
+        if dt < budget_s / 4 and S < self.B:  # grow the sample towards the budget
+            S2 = int(min(self.B, S * max(2, int(budget_s / 2 / max(dt, 1e-3)))))
+            t0 = time.perf_counter()
+            ref = O.qp_sparse_solve_batch(Pp, Pi, Px[:S2], q[:S2], Ap, Aj, Av[:S2], l[:S2], u[:S2],
+                                          perm=self.plan.perm, params=op, nthreads=cores)
+            dt, S = time.perf_counter() - t0, S2
+        x = self.x[:S].cpu().numpy()
+        it = self.out[0, :S].cpu().numpy().astype(np.uint32)
+        code = self.out[1, :S].cpu().numpy()
+        du = np.abs(x[:, self.ub:self.ub + 2] - ref["x"][:, self.ub:self.ub + 2])
+        parity = {"sample": S, "code_mismatches": int((code != ref["code"]).sum()),
+                  "iter_mismatches": int((it != ref["iter"]).sum()), "max_abs_du0": float(du.max()),
+                  "max_abs_dx": float(np.abs(x - ref["x"]).max())}
+        return {"value": S / dt, "unit": "QP solves/s", "cores": cores, "kind": "port",
+                "sample": "first %d agents of rank 0's batch, oracle/qp_sparse_oracle.c (CPU restatement of the "
+                          "reference's sparse ADMM path with the same elimination order, %d pthreads), %.1f s"
+                          % (S, cores, dt)}, parity
+
+
+WORKLOADS = {"mpc": MPCWorkload, "qp_dense": DenseQPWorkload}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="qp_dense", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="mpc", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -124,6 +211,7 @@ def main():
     wl = WORKLOADS[args.workload](sfb, rank, device, **kw)
     stream = torch.cuda.current_stream()
     gathered = None
+    kernel_name = "qp_sparse_kernel" if args.workload == "mpc" else "qp_dense_kernel"
     if world > 1:
         gathered = [torch.empty_like(wl.small_outputs()) for _ in range(world)]
 
@@ -178,10 +266,18 @@ def main():
                        "parallelism": "batch-sharded x%d, gather of (iter,code) only" % world},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_BYTES_PER_S, "traffic": None,
-                         "kernel": "qp_dense_kernel", "kernel_ms": kern_ms,
+                         "kernel": kernel_name, "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_unit": wl.bytes_per_unit,
-                         "note": "iterative latency/FP64-issue-bound kernel: HBM fraction is structurally tiny"},
+                         "note": "achieved = SURVEY 8(d) algorithmic I/O bytes / kernel time; the ADMM iterations "
+                                 "re-stream the LDL' factor from HBM (sparse kernel) or are FP64-issue bound (dense "
+                                 "kernel), so the I/O-only fraction is small by construction -- see DESIGN.md"},
         }
+        if hasattr(wl, "extra"):
+            rec["workload_stats"] = wl.extra()
+            ws = rec["workload_stats"]
+            if "factor_stream_bytes_per_iteration_per_qp" in ws:
+                eff = ws["factor_stream_bytes_per_iteration_per_qp"] * ws["iterations"]["mean"] * wl.units_per_step
+                rec["roofline"]["factor_stream_GBps"] = eff / (kern_ms * 1e-3) / 1e9
         if not args.no_cpu_baseline and world == 1:
             cores = os.cpu_count() or 1
             rec["cpu_baseline"], rec["parity_vs_oracle"] = wl.cpu_baseline(cores)
