@@ -108,7 +108,7 @@ class MPCWorkload:
         t0 = time.perf_counter()
         Av, l, u = M.mpc_assemble_batch(variant, K, batch, seed=1000003 * rank + 3, threads=os.cpu_count() or 8)
         self.host_assembly_s = time.perf_counter() - t0
-        self.plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj)
+        self.plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K))
         self.prm = sfb.QPSolverParams()  # MPCParams.qp{} defaults (mpc.hpp:332)
         self.host = (np.tile(Pv, (batch, 1)), np.zeros((batch, d["n"])), Av, l, u)
         self.dev = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in self.host]

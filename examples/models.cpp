@@ -193,6 +193,18 @@ int sfbx_mpc_pattern(int variant, int K, double tf, int32_t * Pp, int32_t * Pi, 
   return -1;
 }
 
+int sfbx_mpc_stage(int variant, int K, int32_t * stage)
+{
+  auto fill = [&](const auto & mpc) {
+    const auto st = mpc.elimination_stage();
+    std::copy(st.begin(), st.end(), stage);
+    return 0;
+  };
+  if (variant == 6) { auto mpc = make6(K, 5.0); return fill(mpc); }
+  if (variant == 12) { auto mpc = make12(K, 5.0); return fill(mpc); }
+  return -1;
+}
+
 int sfbx_mpc_assemble_batch(int variant, int K, double tf, int64_t batch, uint64_t seed, double * Aval, double * l,
                             double * u, int threads)
 {

@@ -14,6 +14,8 @@ extern "C" {
 int sfbx_mpc_dims(int variant, int K, int *n, int *m, int *nnzP, int *nnzA, int *Nx, int *Nu, int *N);
 /* pattern (+ P values, identical for all agents).  Arrays sized by sfbx_mpc_dims. */
 int sfbx_mpc_pattern(int variant, int K, double tf, int32_t *Pp, int32_t *Pi, double *Pval, int32_t *Ap, int32_t *Aj);
+/* elimination stages (n+m entries) suggested by the MPC front for the solver's ordering */
+int sfbx_mpc_stage(int variant, int K, int32_t *stage);
 /* Assemble `batch` agents: agent b runs at time t_b = 0.025*(b % 400) from x_b = xdes(t_b) (+) xi_b,
  * xi_b ~ U(-0.5,0.5)^Nx from std::mt19937_64(seed + b).  Aval [batch][nnzA], l,u [batch][m]. */
 int sfbx_mpc_assemble_batch(int variant, int K, double tf, int64_t batch, uint64_t seed, double *Aval, double *l,

@@ -141,6 +141,14 @@ typedef struct sfb_sparse_qp_plan sfb_sparse_qp_plan; /* opaque */
 sfb_status sfb_sparse_qp_plan_create(int n, int m, const int32_t *P_colptr, const int32_t *P_rowind,
                                      const int32_t *A_rowptr, const int32_t *A_colind, int ordering,
                                      const int32_t *user_perm, sfb_sparse_qp_plan **plan);
+/* Same with a constrained minimum-degree order: stage[n+m] (nullable) -- unknowns (variables 0..n-1,
+ * constraint duals n..n+m-1) of a lower stage are eliminated before any of a higher stage.  An MPC
+ * transcription marks the states shared by neighbouring mesh intervals as stage 1: shorter
+ * elimination tree and less fill than unconstrained minimum degree. */
+sfb_status sfb_sparse_qp_plan_create_staged(int n, int m, const int32_t *P_colptr, const int32_t *P_rowind,
+                                            const int32_t *A_rowptr, const int32_t *A_colind, int ordering,
+                                            const int32_t *user_perm, const int32_t *stage,
+                                            sfb_sparse_qp_plan **plan);
 void sfb_sparse_qp_plan_destroy(sfb_sparse_qp_plan *plan);
 /* nnz of the KKT upper triangle, nnz of L (strictly lower), bytes of device workspace PER ITEM. */
 sfb_status sfb_sparse_qp_plan_info(const sfb_sparse_qp_plan *plan, int64_t *nnzK, int64_t *nnzL,

@@ -91,6 +91,24 @@ public:
   const Mesh & mesh() const { return mesh_; }
   const MPCParams & params() const { return prm_; }
   SparseQPSolver & solver() { return *solver_; }
+  /// Elimination stages for the solver's constrained minimum-degree order: the states shared by
+  /// neighbouring mesh intervals (x at nodes 0, Kmesh, 2 Kmesh, ..., N) and the rows pinning x_0 are
+  /// eliminated last, everything interior to an interval first.
+  std::vector<int32_t> elimination_stage() const
+  {
+    std::vector<int32_t> st(nvar() + ncon(), 0);
+    for (int node = 0; node <= N(); node += Kmesh)
+      for (int c = 0; c < Nx; ++c) st[node * Nx + c] = 1;
+    for (int d = 0; d < Nx; ++d) st[nvar() + cecon_B() + d] = 1;
+    return st;
+  }
+  void analyze_solver()
+  {
+    if (!solver_->analyzed()) {
+      const auto st = elimination_stage();
+      solver_->analyze(qp_, nullptr, st.data());
+    }
+  }
 
   /// Numeric part of MPC::operator() before the solve (mpc.hpp:473-486): writes the values of A (in
   /// the pattern of qp().A_*), l and u for current time t and state x.  Thread-safe (const).
@@ -190,7 +208,7 @@ public:
                                             std::vector<X> * x_traj = nullptr)
   {
     assemble(t, x, qp_.A_val.data(), qp_.l.data(), qp_.u.data());
-    if (!solver_->analyzed()) solver_->analyze(qp_);
+    analyze_solver();
     const QPSolution sol = solver_->solve(qp_, warm_ ? &*warm_ : nullptr);  // :491
     const int Nn = N();
     if (u_traj) {  // :494-500
@@ -379,7 +397,7 @@ public:
     parallel_for([&](int64_t b) {
       mpc_.assemble(t[b], xs[b], &Ax_[(size_t)b * nA_], &l_[(size_t)b * qp.m], &u_[(size_t)b * qp.m]);
     });
-    if (!mpc_.solver().analyzed()) mpc_.solver().analyze(qp);
+    mpc_.analyze_solver();
     const bool warm = mpc_.params().warmstart && have_warm_;
     if (warm) { wx_ = x_; wy_ = y_; }
     mpc_.solver().solve_batch(B_, Px_.data(), q_.data(), Ax_.data(), l_.data(), u_.data(), warm ? wx_.data() : nullptr,

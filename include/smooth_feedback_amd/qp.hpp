@@ -99,14 +99,15 @@ public:
   ~SparseQPSolver() { sfb_sparse_qp_plan_destroy(plan_); }
 
   /// qp_solver.hpp:297-338 (+ SimplicialLDLT::analyzePattern :424)
-  void analyze(const QuadraticProgramSparse & pbm, const int32_t * user_perm = nullptr)
+  void analyze(const QuadraticProgramSparse & pbm, const int32_t * user_perm = nullptr,
+               const int32_t * stage = nullptr)
   {
     sfb_sparse_qp_plan_destroy(plan_);
     plan_ = nullptr;
     n_ = pbm.n; m_ = pbm.m;
     nnzP_ = (int)pbm.P_val.size(); nnzA_ = (int)pbm.A_val.size();
-    sfb_check(sfb_sparse_qp_plan_create(pbm.n, pbm.m, pbm.P_colptr.data(), pbm.P_rowind.data(), pbm.A_rowptr.data(),
-                                        pbm.A_colind.data(), 1, user_perm, &plan_));
+    sfb_check(sfb_sparse_qp_plan_create_staged(pbm.n, pbm.m, pbm.P_colptr.data(), pbm.P_rowind.data(),
+                                               pbm.A_rowptr.data(), pbm.A_colind.data(), 1, user_perm, stage, &plan_));
   }
   bool analyzed() const { return plan_ != nullptr; }
   int64_t nnzL() const

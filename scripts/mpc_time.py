@@ -8,7 +8,7 @@ import models_lib as M
 variant = int(os.environ.get("VARIANT", 12)); K = int(os.environ.get("K", 50)); B = int(os.environ.get("B", 2048))
 d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
 t0 = time.time(); Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=3, threads=64); ta = time.time() - t0
-plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj)
+plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K))
 dev = torch.device("cuda:0")
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 dPx, dq, dAx, dl, du = T(np.tile(Pv, (B, 1))), T(np.zeros((B, d["n"]))), T(Av), T(l), T(u)

@@ -62,6 +62,7 @@ def _load():
     L.sfb_qp_dense_solve_batch_host.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12
     i32p = C.c_void_p
     L.sfb_sparse_qp_plan_create.argtypes = [i32, i32, i32p, i32p, i32p, i32p, i32, i32p, C.POINTER(C.c_void_p)]
+    L.sfb_sparse_qp_plan_create_staged.argtypes = [i32, i32, i32p, i32p, i32p, i32p, i32, i32p, i32p, C.POINTER(C.c_void_p)]
     L.sfb_sparse_qp_plan_destroy.argtypes = [C.c_void_p]
     L.sfb_sparse_qp_plan_destroy.restype = None
     L.sfb_sparse_qp_plan_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]

@@ -38,8 +38,8 @@ sfb_status plan_on_device(sfb_sparse_qp_plan *plan, const sfb::SparsePlanDev **o
   const sfb::SparsePlanHost &h = plan->host;
   const std::vector<int32_t> *arrs[] = {&h.Pp, &h.Pi, &h.Pcol, &h.Ap, &h.Aj, &h.Arow, &h.Acp, &h.Aci, &h.Acpos,
                                         &h.Prp, &h.Prj, &h.Prpos, &h.Sp, &h.Sj, &h.Spos, &h.perm, &h.pinv,
-                                        &h.Kp, &h.Ki, &h.Kkind, &h.Kidx, &h.Lp, &h.Li, &h.Rp, &h.Rk, &h.Rpos,
-                                        &h.fdesc, &h.bdesc};
+                                        &h.Kp, &h.Ki, &h.Kkind, &h.Kidx, &h.Lp, &h.Li, &h.Rp, &h.Rk, &h.Rpos, &h.Rlen,
+                                        &h.fmap, &h.fidx, &h.bmap, &h.bidx};
   constexpr int NA = sizeof(arrs) / sizeof(arrs[0]);
   size_t off[NA + 1];
   off[0] = 0;
@@ -58,9 +58,9 @@ sfb_status plan_on_device(sfb_sparse_qp_plan *plan, const sfb::SparsePlanDev **o
   d.n = h.n; d.m = h.m; d.k = h.k; d.nnzP = h.nnzP; d.nnzA = h.nnzA; d.nnzK = h.nnzK; d.nnzL = h.nnzL;
   const int32_t **ptrs[] = {&d.Pp, &d.Pi, &d.Pcol, &d.Ap, &d.Aj, &d.Arow, &d.Acp, &d.Aci, &d.Acpos,
                             &d.Prp, &d.Prj, &d.Prpos, &d.Sp, &d.Sj, &d.Spos, &d.perm, &d.pinv,
-                            &d.Kp, &d.Ki, &d.Kkind, &d.Kidx, &d.Lp, &d.Li, &d.Rp, &d.Rk, &d.Rpos,
-                            &d.fdesc, &d.bdesc};
-  d.fblocks = h.fblocks; d.bblocks = h.bblocks;
+                            &d.Kp, &d.Ki, &d.Kkind, &d.Kidx, &d.Lp, &d.Li, &d.Rp, &d.Rk, &d.Rpos, &d.Rlen,
+                            &d.fmap, &d.fidx, &d.bmap, &d.bidx};
+  d.fsteps = h.fsteps; d.bsteps = h.bsteps;
   for (int a = 0; a < NA; ++a) *ptrs[a] = dc.blob + off[a];
   auto ins = plan->per_device.emplace(devid, dc);
   *out     = &ins.first->second.dev;
@@ -82,7 +82,7 @@ sfb_status check_sparse_args(const sfb_sparse_qp_plan *plan, const sfb_qp_params
     return sfb::fail(SFB_ERR_UNSUPPORTED, "max_time is wall-clock and not supported on the device path; use max_iter");
   if (prm->max_iter > 0xFFFFFFFFll) return sfb::fail(SFB_ERR_INVALID_ARG, "max_iter exceeds uint32");
   if (batch > 0x7FFFFFFFll) return sfb::fail(SFB_ERR_UNSUPPORTED, "batch exceeds 2^31-1 per call");
-  if ((size_t)plan->host.k * sizeof(double) > 150 * 1024)
+  if ((size_t)(plan->host.k + 1) * sizeof(double) > 150 * 1024)
     return sfb::fail(SFB_ERR_UNSUPPORTED, "n+m too large for the LDS-resident work vector (max 19200)");
   return SFB_OK;
 }
@@ -95,14 +95,28 @@ sfb_status sfb_sparse_qp_plan_create(int n, int m, const int32_t *P_colptr, cons
                                      const int32_t *A_rowptr, const int32_t *A_colind, int ordering,
                                      const int32_t *user_perm, sfb_sparse_qp_plan **plan)
 {
+  return sfb_sparse_qp_plan_create_staged(n, m, P_colptr, P_rowind, A_rowptr, A_colind, ordering, user_perm, nullptr,
+                                          plan);
+}
+
+sfb_status sfb_sparse_qp_plan_create_staged(int n, int m, const int32_t *P_colptr, const int32_t *P_rowind,
+                                            const int32_t *A_rowptr, const int32_t *A_colind, int ordering,
+                                            const int32_t *user_perm, const int32_t *stage,
+                                            sfb_sparse_qp_plan **plan)
+{
   if (!plan) return sfb::fail(SFB_ERR_INVALID_ARG, "plan out-pointer is NULL");
   *plan = nullptr;
   auto *p = new (std::nothrow) sfb_sparse_qp_plan();
   if (!p) return sfb::fail(SFB_ERR_INVALID_ARG, "out of memory");
   const char *msg = "";
-  if (!sfb::build_sparse_plan(n, m, P_colptr, P_rowind, A_rowptr, A_colind, ordering, user_perm, p->host, &msg)) {
+  if (!sfb::build_sparse_plan(n, m, P_colptr, P_rowind, A_rowptr, A_colind, ordering, user_perm, stage, p->host,
+                              &msg)) {
     delete p;
     return sfb::fail(SFB_ERR_INVALID_ARG, msg);
+  }
+  if ((size_t)p->host.nnzK > (size_t)(p->host.bsteps + sfb::kSweepPadDev) * 64) {  // Kval aliases LxB
+    delete p;
+    return sfb::fail(SFB_ERR_UNSUPPORTED, "pattern with more KKT entries than padded factor slots");
   }
   *plan = p;
   return SFB_OK;
@@ -124,7 +138,7 @@ sfb_status sfb_sparse_qp_plan_info(const sfb_sparse_qp_plan *plan, int64_t *nnzK
   if (nnzL) *nnzL = plan->host.nnzL;
   if (workspace_bytes_per_item)
     *workspace_bytes_per_item =
-      (int64_t)(sfb::qp_sparse_ws_doubles(plan->host.n, plan->host.m, plan->host.nnzL) * sizeof(double));
+      (int64_t)(sfb::qp_sparse_ws_doubles(plan->host.n, plan->host.m, plan->host.nnzL, plan->host.fsteps, plan->host.bsteps) * sizeof(double));
   return SFB_OK;
 }
 
@@ -169,7 +183,7 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
   if (batch == 0) return SFB_OK;
   const sfb::SparsePlanHost &h = plan->host;
   const size_t B = (size_t)batch, N = (size_t)h.n, M = (size_t)h.m, NP = (size_t)h.nnzP, NA = (size_t)h.nnzA;
-  const size_t wsd  = sfb::qp_sparse_ws_doubles(h.n, h.m, h.nnzL);
+  const size_t wsd  = sfb::qp_sparse_ws_doubles(h.n, h.m, h.nnzL, h.fsteps, h.bsteps);
   const size_t in_d = B * (NP + N + NA + 2 * M) + (warm_x ? B * (N + M) : 0), out_d = B * (N + M + 1);
   const size_t bytes = (in_d + out_d + B * wsd) * sizeof(double) + B * 8;
   char *devmem = nullptr;

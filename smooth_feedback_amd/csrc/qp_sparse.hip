@@ -25,22 +25,29 @@
 #include "qp_sparse_kernel.h"
 #include "wave_util.h"
 
+#ifndef SFB_SWEEP_DEPTH
+#define SFB_SWEEP_DEPTH 16
+#endif
+
 namespace sfb {
 
 namespace {
 
 struct Ws {
-  double *Lx, *LxT, *D, *Dinv, *tv;
+  double *Lx, *LxF, *LxB, *D, *Dinv, *tv, *Kval;
   double *sx, *qc, *xs, *xus, *dxus;
   double *sy, *rho, *rinv, *lo, *hi, *ys, *zs, *yus, *zus, *dyus, *act;
 };
 
-__device__ __forceinline__ Ws carve_ws(double *base, int n, int m, int nnzL)
+__device__ __forceinline__ Ws carve_ws(double *base, int n, int m, int nnzL, int fsteps, int bsteps)
 {
   const int k = n + m;
   Ws w;
   double *p = base;
-  w.Lx = p; p += nnzL;  w.LxT = p; p += nnzL;
+  w.Lx = p; p += nnzL;
+  w.LxF = p; p += (size_t)(fsteps + kSweepPadDev) * 64;
+  w.LxB = p; p += (size_t)(bsteps + kSweepPadDev) * 64;
+  w.Kval = w.LxB;  // KKT values, only alive during a factorisation (LxB is rewritten at its end)
   w.D = p; p += k;      w.Dinv = p; p += k;   w.tv = p; p += k;
   w.sx = p; p += n;     w.qc = p; p += n;     w.xs = p; p += n;   w.xus = p; p += n;  w.dxus = p; p += n;
   p += n;
@@ -90,12 +97,15 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
                                       const double c, const double sigma, const double delta, const int lane)
 {
   const int k = pl.k;
+  // all KKT values in one fully parallel pass (the gathers behind kkt_value are 3-4 loads deep)
+  for (int p = lane; p < pl.nnzK; p += kWave) w.Kval[p] = kkt_value(pl, it, w, p, mode, c, sigma, delta);
+  wave_sync();
   for (int j = 0; j < k; ++j) {
     const int c0 = pl.Lp[j], c1 = pl.Lp[j + 1];
     if (lane == 0) t[j] = 0.0;
     for (int p = c0 + lane; p < c1; p += kWave) t[pl.Li[p]] = 0.0;
     wave_sync();
-    for (int p = pl.Kp[j] + lane; p < pl.Kp[j + 1]; p += kWave) t[pl.Ki[p]] = kkt_value(pl, it, w, p, mode, c, sigma, delta);
+    for (int p = pl.Kp[j] + lane; p < pl.Kp[j + 1]; p += kWave) t[pl.Ki[p]] = w.Kval[p];
     wave_sync();
     const int r0 = pl.Rp[j], r1 = pl.Rp[j + 1];
     for (int g0 = r0; g0 < r1; g0 += kWave) {  // groups of <= 64 source columns, ascending
@@ -105,7 +115,7 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
       if (lane < gcnt) {
         const int kk = pl.Rk[g0 + lane];
         pos          = pl.Rpos[g0 + lane];
-        len          = pl.Lp[kk + 1] - pos;
+        len          = pl.Rlen[g0 + lane];
         wv           = w.Lx[pos] * w.D[kk];  // L(j,kk) * D(kk)
       }
       double lx[DEPTH];
@@ -155,61 +165,47 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
     for (int p = c0 + lane; p < c1; p += kWave) w.Lx[p] = t[pl.Li[p]] / d;
     wave_sync();
   }
-  // row-major copy for the backward sweep
-  for (int p = lane; p < pl.nnzL; p += kWave) w.LxT[p] = w.Lx[pl.Rpos[p]];
+  // schedule-ordered copies of the factor for the two sweeps (padding slots carry 0)
+  for (int q = lane; q < (pl.fsteps + kSweepPadDev) * kWave; q += kWave) {
+    const int src = pl.fmap[q];
+    w.LxF[q]      = (src >= 0) ? w.Lx[src] : 0.0;
+  }
+  for (int q = lane; q < (pl.bsteps + kSweepPadDev) * kWave; q += kWave) {
+    const int src = pl.bmap[q];
+    w.LxB[q]      = (src >= 0) ? w.Lx[src] : 0.0;
+  }
   wave_sync();
   return 1;
 }
 
-// One triangular sweep over a precomputed chunk schedule (sparse_plan.h): for every chunk
-//   t[idx[start + lane]] = fma(-vals[start + lane], t[pivot], t[idx[start + lane]])   (lane < count).
-// The factor is streamed from HBM: chunk c + DEPTH is fetched while chunk c is applied, so the
-// memory latency is overlapped with the (serially dependent) LDS updates.  Descriptors come 64 at a
-// time with one vector load and are handed out with v_readlane.  Order of operations == the plain
-// column-by-column loop, so results are unchanged.
+// One triangular sweep over a packed schedule (sparse_plan.h): step s, lane l applies
+//   t[tgt] = fma(-vals[64 s + l], t[piv], t[tgt]),   (tgt, piv) = idx[64 s + l].
+// Branch-free; the factor is streamed from HBM DEPTH steps ahead of its use, so memory latency is
+// overlapped with the serially dependent LDS updates.  t has k+1 entries, t[k] is the padding slot.
 template<int DEPTH>
-__device__ inline void sweep_dev(const int32_t *__restrict__ desc, const int blocks, const double *vals,
-                                 const int32_t *__restrict__ idx, double *t, const int lane)
+__device__ inline void sweep_dev(const int32_t *__restrict__ idx, const int steps, const double *vals, double *t,
+                                 const int lane)
 {
-  const int2 *d2 = reinterpret_cast<const int2 *>(desc);
-  int2 dv        = d2[lane];
+  static_assert(DEPTH <= kSweepPadDev, "schedule padding must cover the prefetch distance");
   double lx[DEPTH];
-  int li[DEPTH];
+  int ix[DEPTH];
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) {
-    const int st = __builtin_amdgcn_readlane(dv.x, d), meta = __builtin_amdgcn_readlane(dv.y, d);
-    const bool on = lane < (meta >> 24);
-    lx[d] = on ? vals[st + lane] : 0.0;
-    li[d] = on ? idx[st + lane] : 0;
+    lx[d] = vals[d * kWave + lane];
+    ix[d] = idx[d * kWave + lane];
   }
-  for (int blk = 0; blk < blocks; ++blk) {
-    const int2 dvn = d2[(blk + 1) * 64 + lane];  // the schedule is padded by one block
-    for (int cc = 0; cc < 64; cc += DEPTH) {
+  for (int s0 = 0; s0 < steps; s0 += DEPTH) {
 #pragma unroll
-      for (int d = 0; d < DEPTH; ++d) {
-        const int c    = cc + d;
-        const int meta = __builtin_amdgcn_readlane(dv.y, c);
-        const int piv = meta & 0xFFFFFF, cnt = meta >> 24;
-        const double tj = t[piv];
-        if (lane < cnt) {
-          const int r = li[d];
-          t[r]        = fma(-lx[d], tj, t[r]);
-        }
-        const int cn = c + DEPTH;  // prefetch
-        int st2, meta2;
-        if (cn < 64) {
-          st2   = __builtin_amdgcn_readlane(dv.x, cn);
-          meta2 = __builtin_amdgcn_readlane(dv.y, cn);
-        } else {
-          st2   = __builtin_amdgcn_readlane(dvn.x, cn - 64);
-          meta2 = __builtin_amdgcn_readlane(dvn.y, cn - 64);
-        }
-        const bool on = lane < (meta2 >> 24);
-        lx[d] = on ? vals[st2 + lane] : 0.0;
-        li[d] = on ? idx[st2 + lane] : 0;
+    for (int d = 0; d < DEPTH; ++d) {
+      if (s0 + d < steps) {  // uniform
+        const unsigned pk = (unsigned)ix[d];
+        const int r = pk & 0xFFFFu, pv = pk >> 16;
+        t[r]        = fma(-lx[d], t[pv], t[r]);
       }
+      const int sn = s0 + d + DEPTH;  // always inside the padded arrays
+      lx[d]        = vals[sn * kWave + lane];
+      ix[d]        = idx[sn * kWave + lane];
     }
-    dv = dvn;
   }
   wave_sync();
 }
@@ -218,10 +214,10 @@ __device__ inline void sweep_dev(const int32_t *__restrict__ desc, const int blo
 __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, double *t, const int lane)
 {
   const int k = pl.k;
-  sweep_dev<16>(pl.fdesc, pl.fblocks, w.Lx, pl.Li, t, lane);   // forward, column oriented
+  sweep_dev<SFB_SWEEP_DEPTH>(pl.fidx, pl.fsteps, w.LxF, t, lane);  // forward (column oriented order)
   for (int j = lane; j < k; j += kWave) t[j] = w.Dinv[j] * t[j];
   wave_sync();
-  sweep_dev<16>(pl.bdesc, pl.bblocks, w.LxT, pl.Rk, t, lane);  // backward: row j pushes into its columns
+  sweep_dev<SFB_SWEEP_DEPTH>(pl.bidx, pl.bsteps, w.LxB, t, lane);  // backward (rows pushing, descending order)
 }
 
 __device__ __forceinline__ double lane_max_abs(const double *v, int len, int lane)
@@ -385,13 +381,14 @@ __global__ void __launch_bounds__(64) qp_sparse_kernel(const SparsePlanDev pl, c
                                                        uint32_t *__restrict__ giter, int32_t *__restrict__ gcode,
                                                        double *__restrict__ gws, const size_t ws_doubles)
 {
-  extern __shared__ __attribute__((aligned(16))) double t[];  // k doubles: work / solution vector
+  extern __shared__ __attribute__((aligned(16))) double t[];  // k + 1 doubles: work / solution vector
   const int lane = threadIdx.x;
   const int n = pl.n, m = pl.m, k = pl.k;
   const size_t b = blockIdx.x;
   const Item it{gPx + b * (size_t)pl.nnzP, gq + b * (size_t)n, gAx + b * (size_t)pl.nnzA, gl + b * (size_t)m,
                 gu + b * (size_t)m};
-  const Ws w = carve_ws(gws + b * ws_doubles, n, m, pl.nnzL);
+  const Ws w = carve_ws(gws + b * ws_doubles, n, m, pl.nnzL, pl.fsteps, pl.bsteps);
+  if (lane == 0) t[k] = 0.0;  // padding slot of the packed sweeps
   const double inf = INFINITY;
 
   // ---- analyze(): :306-308 ----
@@ -572,8 +569,8 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
                             const double *wy, double *x, double *y, double *obj, uint32_t *iter, int32_t *code,
                             double *workspace, hipStream_t stream)
 {
-  const size_t lds = (size_t)pl.k * sizeof(double);
-  const size_t wsd = qp_sparse_ws_doubles(pl.n, pl.m, pl.nnzL);
+  const size_t lds = (size_t)(pl.k + 2) * sizeof(double);
+  const size_t wsd = qp_sparse_ws_doubles(pl.n, pl.m, pl.nnzL, pl.fsteps, pl.bsteps);
   hipLaunchKernelGGL(qp_sparse_kernel, dim3((unsigned)batch), dim3(kWave), lds, stream, pl, kp, Px, q, Ax, l, u, wx,
                      wy, x, y, obj, iter, code, workspace, wsd);
   return hipGetLastError();

@@ -18,16 +18,19 @@ struct SparsePlanDev {
   int n, m, k, nnzP, nnzA, nnzK, nnzL;
   const int32_t *Pp, *Pi, *Pcol, *Ap, *Aj, *Arow;
   const int32_t *Acp, *Aci, *Acpos, *Prp, *Prj, *Prpos, *Sp, *Sj, *Spos;
-  const int32_t *perm, *pinv, *Kp, *Ki, *Kkind, *Kidx, *Lp, *Li, *Rp, *Rk, *Rpos;
-  const int32_t *fdesc, *bdesc;  // sweep schedules (int2 per chunk), see sparse_plan.h
-  int fblocks, bblocks;
+  const int32_t *perm, *pinv, *Kp, *Ki, *Kkind, *Kidx, *Lp, *Li, *Rp, *Rk, *Rpos, *Rlen;
+  const int32_t *fmap, *fidx, *bmap, *bidx;  // packed sweep schedules, see sparse_plan.h
+  int fsteps, bsteps;
 };
 
 // per-item workspace, in doubles
-inline size_t qp_sparse_ws_doubles(int n, int m, int nnzL)
+constexpr int kSweepPadDev = 16;  // == SparsePlanHost::kSweepPad
+inline size_t qp_sparse_ws_doubles(int n, int m, int nnzL, int fsteps, int bsteps)
 {
   const size_t k = (size_t)n + m;
-  return 2 * (size_t)nnzL + 3 * k + 6 * (size_t)n + 12 * (size_t)m + 8;
+  return (size_t)nnzL + (size_t)(fsteps + bsteps + 2 * kSweepPadDev) * 64 + 3 * k + 6 * (size_t)n + 12 * (size_t)m + 8;
+  // (the KKT value buffer of the factorisation aliases the forward-sweep copy LxF: nnzK <= nnzL + k <= its size
+  //  is checked at plan creation)
 }
 
 hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp, int64_t batch, const double *Px,

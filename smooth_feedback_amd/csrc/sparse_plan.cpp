@@ -1,6 +1,7 @@
 #include "sparse_plan.h"
 
 #include <algorithm>
+#include <array>
 #include <numeric>
 #include <tuple>
 
@@ -32,7 +33,7 @@ void transpose_pattern(int nouter, int ninner, const std::vector<int32_t> &outer
 
 // Minimum-degree ordering on the symmetric KKT graph with explicit fill (bitset adjacency).
 // k is at most a few thousand for the problems of this path; O(k^2 * k/64) is fine on the host.
-std::vector<int32_t> min_degree_order(int k, const std::vector<std::pair<int, int>> &edges)
+std::vector<int32_t> min_degree_order(int k, const std::vector<std::pair<int, int>> &edges, const int32_t *stage)
 {
   const int W = (k + 63) / 64;
   std::vector<uint64_t> adj((size_t)k * W, 0);
@@ -51,9 +52,13 @@ std::vector<int32_t> min_degree_order(int k, const std::vector<std::pair<int, in
   order.reserve(k);
   std::vector<int> nb;
   for (int step = 0; step < k; ++step) {
-    int best = -1;
-    for (int a = 0; a < k; ++a)
-      if (!done[a] && (best < 0 || deg[a] < deg[best])) best = a;  // ties: lowest index
+    int best = -1;  // lowest stage first, then minimum degree, ties: lowest index
+    for (int a = 0; a < k; ++a) {
+      if (done[a]) continue;
+      if (best < 0) { best = a; continue; }
+      const int sa = stage ? stage[a] : 0, sb = stage ? stage[best] : 0;
+      if (sa < sb || (sa == sb && deg[a] < deg[best])) best = a;
+    }
     order.push_back(best);
     done[best] = 1;
     nb.clear();
@@ -81,7 +86,8 @@ std::vector<int32_t> min_degree_order(int k, const std::vector<std::pair<int, in
 }  // namespace
 
 bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const int32_t *Ap, const int32_t *Aj,
-                       int ordering, const int32_t *user_perm, SparsePlanHost &o, const char **msg)
+                       int ordering, const int32_t *user_perm, const int32_t *stage, SparsePlanHost &o,
+                       const char **msg)
 {
   static const char *ok = "";
   *msg = ok;
@@ -168,7 +174,7 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
     std::vector<std::pair<int, int>> edges;
     edges.reserve(ents.size());
     for (const Ent &e : ents) edges.emplace_back(e.r, e.c);
-    o.perm = min_degree_order(k, edges);
+    o.perm = min_degree_order(k, edges, stage);
   }
   o.pinv.resize(k);
   for (int i = 0; i < k; ++i) o.pinv[o.perm[i]] = i;
@@ -229,25 +235,51 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
     }
   }
   transpose_pattern(k, k, o.Lp, o.Li, o.Rp, o.Rk, o.Rpos);
+  o.Rlen.resize(o.nnzL);
+  for (int t = 0; t < o.nnzL; ++t) o.Rlen[t] = o.Lp[o.Rk[t] + 1] - o.Rpos[t];
 
-  // sweep schedules
-  auto build = [&](const std::vector<int32_t> &ptr, bool descending, std::vector<int32_t> &desc, int &blocks) {
-    desc.clear();
+  // packed sweep schedules (see sparse_plan.h)
+  if (k + 1 >= (1 << 16)) { *msg = "n+m too large for the packed sweep encoding (max 65534)"; return false; }
+  auto build = [&](bool forward, std::vector<int32_t> &xmap, std::vector<int32_t> &xidx, int &steps) {
+    std::vector<int32_t> last_write(k, -1), fill;
+    std::vector<std::vector<std::array<int32_t, 3>>> slots;  // per step: (pos, tgt, piv)
     for (int t = 0; t < k; ++t) {
-      const int j = descending ? k - 1 - t : t;
-      for (int p = ptr[j]; p < ptr[j + 1]; p += 64) {
-        const int cnt = std::min(64, ptr[j + 1] - p);
-        desc.push_back(p);
-        desc.push_back(j | (cnt << 24));
+      const int j = forward ? t : k - 1 - t;
+      const int p0 = forward ? o.Lp[j] : o.Rp[j], p1 = forward ? o.Lp[j + 1] : o.Rp[j + 1];
+      if (p0 == p1) continue;
+      int s = last_write[j] + 1;
+      for (int p = p0; p < p1; ++p) s = std::max(s, last_write[forward ? o.Li[p] : o.Rk[p]] + 1);
+      int p = p0;
+      while (p < p1) {
+        if ((int)slots.size() <= s) { slots.resize(s + 1); fill.resize(s + 1, 0); }
+        while (fill[s] >= 64) {
+          ++s;
+          if ((int)slots.size() <= s) { slots.resize(s + 1); fill.resize(s + 1, 0); }
+        }
+        const int room = 64 - fill[s];
+        const int take = std::min(room, p1 - p);
+        for (int q = 0; q < take; ++q, ++p) {
+          const int tgt = forward ? o.Li[p] : o.Rk[p];
+          const int pos = forward ? p : o.Rpos[p];
+          slots[s].push_back({pos, tgt, j});
+          last_write[tgt] = s;
+        }
+        fill[s] += take;
+        if (p < p1) ++s;
       }
     }
-    const int nchunks = (int)desc.size() / 2;
-    blocks            = (nchunks + 63) / 64;
-    desc.resize((size_t)(blocks + 1) * 64 * 2, 0);  // empty chunks: start 0, pivot 0, count 0
+    steps = (int)slots.size();
+    const size_t total = (size_t)(steps + SparsePlanHost::kSweepPad) * 64;
+    xmap.assign(total, -1);
+    xidx.assign(total, k | (k << 16));
+    for (int s = 0; s < steps; ++s)
+      for (size_t q = 0; q < slots[s].size(); ++q) {
+        xmap[(size_t)s * 64 + q] = slots[s][q][0];
+        xidx[(size_t)s * 64 + q] = slots[s][q][1] | (slots[s][q][2] << 16);
+      }
   };
-  if (k >= (1 << 24)) { *msg = "n+m too large for the sweep schedule encoding"; return false; }
-  build(o.Lp, false, o.fdesc, o.fblocks);
-  build(o.Rp, true, o.bdesc, o.bblocks);
+  build(true, o.fmap, o.fidx, o.fsteps);
+  build(false, o.bmap, o.bidx, o.bsteps);
   return true;
 }
 

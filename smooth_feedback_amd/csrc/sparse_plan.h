@@ -27,15 +27,28 @@ struct SparsePlanHost {
   std::vector<int32_t> Kp, Ki, Kkind, Kidx;    // permuted KKT, lower CSC
   std::vector<int32_t> Lp, Li;                 // strictly-lower pattern of L (col-major, rows ascending)
   std::vector<int32_t> Rp, Rk, Rpos;           // row structure of L
-  // Sweep schedules: chunks of <= 64 entries, descriptor = {start, pivot | count << 24}, padded with
-  // empty chunks to a multiple of 64 plus one extra block (the kernel prefetches ahead branch-free).
-  std::vector<int32_t> fdesc, bdesc;           // forward (columns ascending) / backward (rows descending)
-  int fblocks = 0, bblocks = 0;                // number of 64-chunk blocks (without the extra block)
+  std::vector<int32_t> Rlen;                   // Lp[Rk+1] - Rpos: length of the source-column suffix
+  // Packed sweep schedules.  A sweep is a sequence of STEPS of 64 slots; slot = one update
+  //   t[tgt] = fma(-L, t[piv], t[tgt]).
+  // Columns (forward) / rows (backward) are list-scheduled in their sequential order into the
+  // earliest step such that (i) the pivot is final (every earlier update of t[piv] sits in an
+  // earlier step) and (ii) for every target the order of its updates is the sequential one (two
+  // updates of one target never share a step).  The arithmetic and its order per entry are thus
+  // exactly those of the column-by-column loop, with fewer, fuller, branch-free steps.
+  //   xmap[q]  : position in the column-major values of L feeding slot q, or -1 (padding)
+  //   xidx[q]  : tgt | piv << 16   (padding: both = k, a scratch slot of the LDS vector)
+  // Arrays are padded by kSweepPad extra all-padding steps so the kernel can prefetch branch-free.
+  static constexpr int kSweepPad = 16;
+  std::vector<int32_t> fmap, fidx, bmap, bidx;
+  int fsteps = 0, bsteps = 0;
 };
 
 // ordering: 0 = natural, 1 = minimum degree (default); user_perm (k entries, new->old) overrides.
-// Returns false on malformed input (msg set).
+// stage (k entries, nullable): constrained minimum degree -- unknowns of a lower stage are
+// eliminated before any unknown of a higher stage (e.g. interval separators of an MPC horizon last:
+// shorter elimination tree, less fill).  Returns false on malformed input (msg set).
 bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const int32_t *Ap, const int32_t *Aj,
-                       int ordering, const int32_t *user_perm, SparsePlanHost &out, const char **msg);
+                       int ordering, const int32_t *user_perm, const int32_t *stage, SparsePlanHost &out,
+                       const char **msg);
 
 }  // namespace sfb

@@ -222,13 +222,16 @@ class SparseQPPlan:
     """Symbolic analysis shared by a batch: QPSolver::analyze + SimplicialLDLT::analyzePattern
     (qp_solver.hpp:297-338, :424).  Host-only; owns an sfb_sparse_qp_plan."""
 
-    def __init__(self, n, m, P_colptr, P_rowind, A_rowptr, A_colind, ordering=1, user_perm=None):
+    def __init__(self, n, m, P_colptr, P_rowind, A_rowptr, A_colind, ordering=1, user_perm=None, stage=None):
         self.n, self.m = int(n), int(m)
         self._keep = [np.ascontiguousarray(a, dtype=np.int32) for a in (P_colptr, P_rowind, A_rowptr, A_colind)]
         up = None if user_perm is None else np.ascontiguousarray(user_perm, dtype=np.int32)
+        st = None if stage is None else np.ascontiguousarray(stage, dtype=np.int32)
+        if st is not None and st.shape != (self.n + self.m,):
+            raise ValueError("stage must have n+m entries")
         h = C.c_void_p()
-        _capi.check(_capi.lib.sfb_sparse_qp_plan_create(
-            self.n, self.m, *[_ptr(a) if a.size else None for a in self._keep], int(ordering), _ptr(up),
+        _capi.check(_capi.lib.sfb_sparse_qp_plan_create_staged(
+            self.n, self.m, *[_ptr(a) if a.size else None for a in self._keep], int(ordering), _ptr(up), _ptr(st),
             C.byref(h)))
         self._h = h
         a, b, c_ = C.c_int64(), C.c_int64(), C.c_int64()

@@ -53,3 +53,10 @@ def mesh(n_ivals, K):
     nodes = np.zeros(N + 1); w = np.zeros(N + 1); D = np.zeros((K + 1) * K)
     assert lib().sfbx_mesh(n_ivals, K, _p(nodes), _p(w), _p(D)) == 0
     return nodes, w, D.reshape(K, K + 1).T  # D[j, i]
+
+
+def mpc_stage(variant, K):
+    d = mpc_dims(variant, K)
+    st = np.zeros(d["n"] + d["m"], np.int32)
+    assert lib().sfbx_mpc_stage(variant, K, _p(st)) == 0
+    return st

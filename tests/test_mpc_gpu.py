@@ -20,7 +20,7 @@ def test_mpc_qp_batch_matches_oracle(sfb, oracle, variant, K, batch):
     Av, l, u = M.mpc_assemble_batch(variant, K, batch, seed=3)
     Px = np.tile(Pv, (batch, 1))
     q = np.zeros((batch, d["n"]))
-    plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj)
+    plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K))
     prm = sfb.QPSolverParams(max_iter=4000)
     r = plan.solve_batch_host(Px, q, Av, l, u, prm)
     ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l, u, perm=plan.perm,
