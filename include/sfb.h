@@ -174,6 +174,37 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
                                           const double *u, const double *warm_x, const double *warm_y,
                                           double *x, double *y, double *obj, uint32_t *iter, int32_t *code);
 
+/* ------------------------------------------------------------------------------------------
+ * Batched Lie-group EKF: covariance propagation and Kalman update for `batch` independent filters.
+ *
+ * Replaces the matrix part of smooth::feedback::EKF<G>::predict / ::update (ekf.hpp:79-103,
+ * :116-139).  The caller (host) keeps what needs the user's callbacks on the group:
+ *   predict: A = -ad(f(t,g)) + d^r f/dx at the estimate (ekf.hpp:86-87) and the state step
+ *            g <- g (+) dt f (:97);     update: H = d^r h/dx (:119), r = y (-) h(g), g <- g (+) delta (:137).
+ * One predict call is ONE explicit-Euler substep of the covariance ODE (the default stepper,
+ * ekf.hpp:30,:96); substepping and re-linearisation are the caller's loop exactly as in :93-102.
+ * Layout: item-major contiguous, matrices column-major (Eigen default): P, A, Q [batch][dof*dof],
+ * H [batch][ny*dof], R [batch][ny*ny], r [batch][ny], delta [batch][dof].  Only the upper triangles
+ * of Q and R are read (ekf.hpp:77,:114).  q_shared / r_shared / dt_shared != 0: Q / R / dt point to
+ * ONE matrix / scalar used by every item.  info[batch] (nullable): 0 ok, 1 = LDLT of S failed.
+ * Supported sizes: dof in {2,3,4,6}, ny in {1,2,3} (one filter per lane, register-resident).
+ * Device pointers, asynchronous on `stream`; P is updated in place.
+ * ---------------------------------------------------------------------------------------- */
+sfb_status sfb_ekf_predict_batch(int64_t batch, int dof, const double *A, const double *Q, int q_shared,
+                                 const double *dt, int dt_shared, double *P, void *stream);
+sfb_status sfb_ekf_update_batch(int64_t batch, int dof, int ny, const double *H, const double *R, int r_shared,
+                                const double *r, double *P, double *delta, int32_t *info, void *stream);
+/* predict immediately followed by update in one launch (one pass over P). */
+sfb_status sfb_ekf_predict_update_batch(int64_t batch, int dof, int ny, const double *A, const double *Q,
+                                        int q_shared, const double *dt, int dt_shared, const double *H,
+                                        const double *R, int r_shared, const double *r, double *P,
+                                        double *delta, int32_t *info, void *stream);
+/* Host-pointer variants (stage through device memory, synchronous).  Pass NULL A to skip predict,
+ * NULL H to skip update. */
+sfb_status sfb_ekf_step_batch_host(int64_t batch, int dof, int ny, const double *A, const double *Q, int q_shared,
+                                   const double *dt, int dt_shared, const double *H, const double *R,
+                                   int r_shared, const double *r, double *P, double *delta, int32_t *info);
+
 /*
  * Synthetic workload of the reference benchmark: random_qp(m, n, density, rng)
  * (benchmarks/bench_types.hpp:19-41) drawn `batch` times from ONE std::default_random_engine

@@ -65,6 +65,11 @@ def lib():
             ip, dp, dp, dp, dp, dp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_int,
             C.POINTER(C.c_int64)]
         L.oracle_qp_sparse_solve_batch.restype = C.c_int
+        L.oracle_ekf_predict_batch.argtypes = [C.c_int64, C.c_int, dp, dp, C.c_int, dp, C.c_int, dp]
+        L.oracle_ekf_predict_batch.restype = None
+        L.oracle_ekf_update_batch.argtypes = [C.c_int64, C.c_int, C.c_int, dp, dp, C.c_int, dp, dp, dp,
+                                              C.POINTER(C.c_int32)]
+        L.oracle_ekf_update_batch.restype = None
         L.oracle_ldlt_factor.argtypes = [C.c_int, dp, C.c_int, C.POINTER(C.c_int)]
         L.oracle_ldlt_factor.restype = C.c_int
         L.oracle_ldlt_solve.argtypes = [C.c_int, dp, C.c_int, C.POINTER(C.c_int), dp]
@@ -162,3 +167,25 @@ def qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Ax, l, u, perm=None, params=Non
     if rc != 0:
         raise RuntimeError("oracle_qp_sparse_solve_batch failed rc=%d" % rc)
     return dict(x=x, y=y, obj=obj, iter=it, code=code, nnzL=nnzL.value)
+
+
+def ekf_predict_batch(A, Q, dt, P):
+    """A, P: (B, dof*dof) col-major flat; Q: (B, dof*dof) or (dof*dof,) shared; dt: (B,) or scalar.
+    Returns the new P (B, dof*dof)."""
+    A = np.ascontiguousarray(A, dtype=np.float64); P = np.array(P, dtype=np.float64, order="C")
+    B, nn = A.shape
+    dof = int(round(nn ** 0.5))
+    Q = np.ascontiguousarray(Q, dtype=np.float64); dt = np.ascontiguousarray(np.atleast_1d(dt), dtype=np.float64)
+    lib().oracle_ekf_predict_batch(B, dof, _dp(A), _dp(Q), int(Q.ndim == 1), _dp(dt), int(dt.size == 1), _dp(P))
+    return P
+
+
+def ekf_update_batch(H, R, r, P, dof):
+    """H: (B, ny*dof), R: (B, ny*ny) or (ny*ny,) shared, r: (B, ny), P: (B, dof*dof). Returns (P_new, delta, info)."""
+    H = np.ascontiguousarray(H, dtype=np.float64); r = np.ascontiguousarray(r, dtype=np.float64)
+    P = np.array(P, dtype=np.float64, order="C"); R = np.ascontiguousarray(R, dtype=np.float64)
+    B, ny = r.shape
+    delta = np.zeros((B, dof)); info = np.zeros(B, dtype=np.int32)
+    lib().oracle_ekf_update_batch(B, dof, ny, _dp(H), _dp(R), int(R.ndim == 1), _dp(r), _dp(P), _dp(delta),
+                                  info.ctypes.data_as(C.POINTER(C.c_int32)))
+    return P, delta, info

@@ -99,6 +99,14 @@ int oracle_qp_sparse_solve_batch(const oracle_qp_params *prm, int64_t batch, int
 int oracle_ldlt_factor(int k, double *W, int ld, int *tr);
 void oracle_ldlt_solve(int k, const double *W, int ld, const int *tr, double *b);
 
+/* EKF matrix part (oracle/ekf_oracle.c), ekf.hpp:84-102 (Euler substep) and :119-138. */
+void oracle_ekf_predict(int dof, const double *A, const double *Q, double dt, double *P);
+int oracle_ekf_update(int dof, int ny, const double *H, const double *R, const double *r, double *P, double *delta);
+void oracle_ekf_predict_batch(int64_t batch, int dof, const double *A, const double *Q, int q_shared, const double *dt,
+                              int dt_shared, double *P);
+void oracle_ekf_update_batch(int64_t batch, int dof, int ny, const double *H, const double *R, int r_shared,
+                             const double *r, double *P, double *delta, int32_t *info);
+
 #ifdef __cplusplus
 }
 #endif

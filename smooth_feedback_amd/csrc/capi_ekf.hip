@@ -1,0 +1,109 @@
+// C-ABI for the batched EKF path (include/sfb.h).
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "../../include/sfb.h"
+#include "capi_common.h"
+#include "ekf_kernel.h"
+
+namespace {
+
+sfb_status ekf_common(int64_t batch, int dof, int ny, const double *A, const double *Q, int q_shared, const double *dt,
+                      int dt_shared, const double *H, const double *R, int r_shared, const double *r, double *P,
+                      double *delta, int32_t *info, bool predict, bool update, void *stream)
+{
+  if (batch < 0) return sfb::fail(SFB_ERR_INVALID_ARG, "batch < 0");
+  if (!predict && !update) return sfb::fail(SFB_ERR_INVALID_ARG, "nothing to do");
+  if (batch > 0 && !P) return sfb::fail(SFB_ERR_INVALID_ARG, "P is NULL");
+  if (predict && batch > 0 && (!A || !Q || !dt)) return sfb::fail(SFB_ERR_INVALID_ARG, "predict needs A, Q, dt");
+  if (update && batch > 0 && (!H || !R || !r || !delta)) return sfb::fail(SFB_ERR_INVALID_ARG, "update needs H, R, r, delta");
+  if (!sfb::ekf_supported(dof, ny, update))
+    return sfb::fail(SFB_ERR_UNSUPPORTED, "EKF kernels support dof in {2,3,4,6} and ny in {1,2,3}");
+  sfb_status st = sfb::require_device();
+  if (st != SFB_OK) return st;
+  if (batch == 0) return SFB_OK;
+  sfb::EkfArgs a{};
+  a.batch = batch; a.A = A; a.Q = Q; a.dt = dt; a.q_shared = q_shared; a.dt_shared = dt_shared;
+  a.H = H; a.R = R; a.r = r; a.r_shared = r_shared; a.delta = delta; a.info = info; a.P = P;
+  hipError_t e = sfb::ekf_launch(a, dof, ny, predict, update, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return sfb::hip_fail(e, "ekf_kernel launch");
+  return SFB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+sfb_status sfb_ekf_predict_batch(int64_t batch, int dof, const double *A, const double *Q, int q_shared,
+                                 const double *dt, int dt_shared, double *P, void *stream)
+{
+  return ekf_common(batch, dof, 1, A, Q, q_shared, dt, dt_shared, nullptr, nullptr, 0, nullptr, P, nullptr, nullptr,
+                    true, false, stream);
+}
+
+sfb_status sfb_ekf_update_batch(int64_t batch, int dof, int ny, const double *H, const double *R, int r_shared,
+                                const double *r, double *P, double *delta, int32_t *info, void *stream)
+{
+  return ekf_common(batch, dof, ny, nullptr, nullptr, 0, nullptr, 0, H, R, r_shared, r, P, delta, info, false, true,
+                    stream);
+}
+
+sfb_status sfb_ekf_predict_update_batch(int64_t batch, int dof, int ny, const double *A, const double *Q, int q_shared,
+                                        const double *dt, int dt_shared, const double *H, const double *R,
+                                        int r_shared, const double *r, double *P, double *delta, int32_t *info,
+                                        void *stream)
+{
+  return ekf_common(batch, dof, ny, A, Q, q_shared, dt, dt_shared, H, R, r_shared, r, P, delta, info, true, true,
+                    stream);
+}
+
+sfb_status sfb_ekf_step_batch_host(int64_t batch, int dof, int ny, const double *A, const double *Q, int q_shared,
+                                   const double *dt, int dt_shared, const double *H, const double *R, int r_shared,
+                                   const double *r, double *P, double *delta, int32_t *info)
+{
+  const bool predict = A != nullptr, update = H != nullptr;
+  if (batch < 0 || (!predict && !update) || (batch > 0 && !P)) return sfb::fail(SFB_ERR_INVALID_ARG, "bad arguments");
+  if (!sfb::ekf_supported(dof, ny, update))
+    return sfb::fail(SFB_ERR_UNSUPPORTED, "EKF kernels support dof in {2,3,4,6} and ny in {1,2,3}");
+  sfb_status st = sfb::require_device();
+  if (st != SFB_OK) return st;
+  if (batch == 0) return SFB_OK;
+  const size_t B = (size_t)batch, nn = (size_t)dof * dof, mn = (size_t)ny * dof, mm = (size_t)ny * ny;
+  struct Buf { const void *h; size_t bytes; void **d; };
+  double *dA = nullptr, *dQ = nullptr, *ddt = nullptr, *dH = nullptr, *dR = nullptr, *dr = nullptr, *dP = nullptr,
+         *ddelta = nullptr;
+  int32_t *dinfo = nullptr;
+  std::vector<void *> owned;
+  hipError_t e = hipSuccess;
+  auto up = [&](const double *h, size_t cnt, double **d) {
+    if (e != hipSuccess || !h) return;
+    e = hipMalloc(reinterpret_cast<void **>(d), cnt * 8);
+    if (e != hipSuccess) return;
+    owned.push_back(*d);
+    e = hipMemcpy(*d, h, cnt * 8, hipMemcpyHostToDevice);
+  };
+  up(P, B * nn, &dP);
+  if (predict) { up(A, B * nn, &dA); up(Q, q_shared ? nn : B * nn, &dQ); up(dt, dt_shared ? 1 : B, &ddt); }
+  if (update) {
+    up(H, B * mn, &dH); up(R, r_shared ? mm : B * mm, &dR); up(r, B * ny, &dr);
+    if (e == hipSuccess) { e = hipMalloc(reinterpret_cast<void **>(&ddelta), B * dof * 8); if (e == hipSuccess) owned.push_back(ddelta); }
+    if (e == hipSuccess && info) { e = hipMalloc(reinterpret_cast<void **>(&dinfo), B * 4); if (e == hipSuccess) owned.push_back(dinfo); }
+  }
+  st = SFB_OK;
+  if (e == hipSuccess) {
+    st = ekf_common(batch, dof, ny, dA, dQ, q_shared, ddt, dt_shared, dH, dR, r_shared, dr, dP, ddelta, dinfo, predict,
+                    update, nullptr);
+    if (st == SFB_OK) {
+      e = hipDeviceSynchronize();
+      if (e == hipSuccess) e = hipMemcpy(P, dP, B * nn * 8, hipMemcpyDeviceToHost);
+      if (e == hipSuccess && update) e = hipMemcpy(delta, ddelta, B * dof * 8, hipMemcpyDeviceToHost);
+      if (e == hipSuccess && update && info) e = hipMemcpy(info, dinfo, B * 4, hipMemcpyDeviceToHost);
+    }
+  }
+  for (void *p : owned) (void)hipFree(p);
+  if (e != hipSuccess) return sfb::hip_fail(e, "sfb_ekf_step_batch_host");
+  return st;
+}
+
+}  // extern "C"

@@ -1,0 +1,375 @@
+// Batched Lie-group EKF covariance kernels for gfx950: ONE FILTER PER LANE, all small matrices in
+// registers, item-major (AoS) HBM layout staged through LDS so that every global access is a
+// coalesced 512-byte wave transaction.
+//
+// Replaces the matrix part of smooth::feedback::EKF (reference ekf.hpp):
+//   predict  :84-89 + euler step :96     P <- P + dt * symU(A P + P A' + Q)
+//   update   :119-138                    S = triU(H symU(P) H' + R); K = (ldlt(symU(S)).solve(H P))';
+//                                        delta = K r;  P <- symU((I - K H) P)
+// The host keeps what needs the user's callbacks: A = -ad(f) + d^r f/dx at the estimate, H = d^r h/dx,
+// r = y (-) h(g), and applies g <- g (+) delta.  Arithmetic order == oracle/ekf_oracle.c (k-ascending
+// fma chains, pivoted LDL' as in ldlt of Eigen 3.4), so results are bit-identical to the oracle.
+// These kernels are pure streaming: ~1.4 KB of I/O and ~1.5 kflop per item => HBM-bound.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+
+#include "../../include/sfb.h"
+#include "ekf_kernel.h"
+#include "wave_util.h"
+
+namespace sfb {
+
+namespace {
+
+// ---- coalesced tile I/O: 64 items x W doubles, contiguous in HBM, one item per lane in LDS ----
+template<int W>
+__device__ __forceinline__ void tile_load(const double *__restrict__ g, int64_t item0, int64_t nitems, double *lds,
+                                          int lane)
+{
+  constexpr int WP = W | 1;  // odd stride: conflict-free per-lane walks
+  const int64_t total = (nitems - item0 < kWave ? nitems - item0 : kWave) * W;
+  const double *src   = g + item0 * W;
+#pragma unroll
+  for (int c = 0; c < W; ++c) {
+    const int idx = c * kWave + lane;
+    if (idx < total) lds[(idx / W) * WP + (idx % W)] = src[idx];
+  }
+}
+template<int W>
+__device__ __forceinline__ void tile_store(double *__restrict__ g, int64_t item0, int64_t nitems, const double *lds,
+                                           int lane)
+{
+  constexpr int WP = W | 1;
+  const int64_t total = (nitems - item0 < kWave ? nitems - item0 : kWave) * W;
+  double *dst         = g + item0 * W;
+#pragma unroll
+  for (int c = 0; c < W; ++c) {
+    const int idx = c * kWave + lane;
+    if (idx < total) dst[idx] = lds[(idx / W) * WP + (idx % W)];
+  }
+}
+
+// ---- pivoted LDL' of a tiny symmetric matrix, fully unrolled (static register indices) ----
+// W lower (row-major W[i][j], j <= i).  Same algorithm/ordering as oracle_ldlt_factor.
+template<int M>
+struct SmallLdlt {
+  double W[M][M];
+  int tr[M];
+  bool ok;
+
+  __device__ __forceinline__ void swap_rc(int kk, int p)  // symmetric swap kk <-> p (p > kk), static loops
+  {
+#pragma unroll
+    for (int pc = 1; pc < M; ++pc) {
+      if (pc == p) {
+#pragma unroll
+        for (int kc = 0; kc < M - 1; ++kc) {
+          if (kc == kk && kc < pc) {
+#pragma unroll
+            for (int t = 0; t < M; ++t)
+              if (t < kc) { const double a = W[kc][t]; W[kc][t] = W[pc][t]; W[pc][t] = a; }
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+              if (i > pc) { const double a = W[i][kc]; W[i][kc] = W[i][pc]; W[i][pc] = a; }
+            { const double a = W[kc][kc]; W[kc][kc] = W[pc][pc]; W[pc][pc] = a; }
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+              if (i > kc && i < pc) { const double a = W[i][kc]; W[i][kc] = W[pc][i]; W[pc][i] = a; }
+          }
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void factor()
+  {
+    ok = true;
+    if constexpr (M == 1) {
+      tr[0] = 0;
+      return;
+    }
+    bool found_zero = false, finished = false;
+    double temp[M];
+#pragma unroll
+    for (int kk = 0; kk < M; ++kk) {
+      if (!finished) {
+        int p       = kk;
+        double best = fabs(W[kk][kk]);
+#pragma unroll
+        for (int i = kk + 1; i < M; ++i) {
+          const double a = fabs(W[i][i]);
+          if (a > best) { best = a; p = i; }
+        }
+        tr[kk] = p;
+        if (p != kk) swap_rc(kk, p);
+        if (kk > 0) {
+#pragma unroll
+          for (int j = 0; j < kk; ++j) temp[j] = W[j][j] * W[kk][j];
+          double s = 0.0;
+#pragma unroll
+          for (int j = 0; j < kk; ++j) s = fma(W[kk][j], temp[j], s);
+          W[kk][kk] -= s;
+#pragma unroll
+          for (int i = kk + 1; i < M; ++i) {
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < kk; ++j) t = fma(W[i][j], temp[j], t);
+            W[i][kk] -= t;
+          }
+        }
+        const double akk = W[kk][kk];
+        const bool valid = fabs(akk) > 0.0;
+        if (kk == 0 && !valid) {
+#pragma unroll
+          for (int j = 0; j < M; ++j) {
+            tr[j] = j;
+#pragma unroll
+            for (int i = j + 1; i < M; ++i) ok = ok && (W[i][j] == 0.0);
+          }
+          finished = true;
+        } else {
+          if (valid) {
+#pragma unroll
+            for (int i = kk + 1; i < M; ++i) W[i][kk] /= akk;
+          } else {
+#pragma unroll
+            for (int i = kk + 1; i < M; ++i) ok = ok && (W[i][kk] == 0.0);
+          }
+          if (found_zero && valid) ok = false;
+          else if (!valid) found_zero = true;
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void solve(double (&b)[M]) const  // P b, L^-1, D^-1 (|d|<=DBL_MIN -> 0), L^-T, P^T
+  {
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+#pragma unroll
+      for (int pc = 0; pc < M; ++pc)
+        if (pc > i && tr[i] == pc) { const double a = b[i]; b[i] = b[pc]; b[pc] = a; }
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      double s = b[i];
+#pragma unroll
+      for (int j = 0; j < i; ++j) s = fma(-W[i][j], b[j], s);
+      b[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      const double d = W[i][i];
+      b[i]           = (fabs(d) > DBL_MIN) ? b[i] / d : 0.0;
+    }
+#pragma unroll
+    for (int i = M - 1; i >= 0; --i) {
+      double s = b[i];
+#pragma unroll
+      for (int j = M - 1; j > i; --j) s = fma(-W[j][i], b[j], s);
+      b[i] = s;
+    }
+#pragma unroll
+    for (int i = M - 1; i >= 0; --i) {
+#pragma unroll
+      for (int pc = 0; pc < M; ++pc)
+        if (pc > i && tr[i] == pc) { const double a = b[i]; b[i] = b[pc]; b[pc] = a; }
+    }
+  }
+};
+
+}  // namespace
+
+// One launch = optional predict (Euler substep) followed by optional update, fused per item.
+template<int N, int M, bool PREDICT, bool UPDATE>
+__global__ void __launch_bounds__(64) ekf_kernel(const EkfArgs a)
+{
+  constexpr int NN = N * N, NP = NN | 1;
+  constexpr int WMAX = (NN > M * N ? NN : M * N) > M * M ? (NN > M * N ? NN : M * N) : M * M;
+  constexpr int TILE = (WMAX | 1) * kWave;
+  __shared__ double lds[TILE];
+  const int lane      = threadIdx.x;
+  const int64_t item0 = (int64_t)blockIdx.x * kWave;
+  const int64_t item  = item0 + lane;
+  const bool live     = item < a.batch;
+
+  double P[NN];
+  tile_load<NN>(a.P, item0, a.batch, lds, lane);
+  wave_sync();
+#pragma unroll
+  for (int e = 0; e < NN; ++e) P[e] = live ? lds[lane * NP + e] : 0.0;
+  wave_sync();
+
+  if constexpr (PREDICT) {
+    double A[NN];
+    tile_load<NN>(a.A, item0, a.batch, lds, lane);
+    wave_sync();
+#pragma unroll
+    for (int e = 0; e < NN; ++e) A[e] = live ? lds[lane * NP + e] : 0.0;
+    wave_sync();
+    if (!a.q_shared) {
+      tile_load<NN>(a.Q, item0, a.batch, lds, lane);
+      wave_sync();
+    }
+    const double dt = live ? (a.dt_shared ? a.dt[0] : a.dt[item]) : 0.0;
+    double Pn[NN];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+#pragma unroll
+      for (int i = 0; i <= j; ++i) {
+        double m1 = 0.0, m2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) m1 = fma(A[i + k * N], P[k + j * N], m1);
+#pragma unroll
+        for (int k = 0; k < N; ++k) m2 = fma(P[i + k * N], A[j + k * N], m2);
+        const double q = a.q_shared ? a.Q[i + j * N] : (live ? lds[lane * NP + i + j * N] : 0.0);
+        const double s = (m1 + m2) + q;  // ekf.hpp:88, upper triangle mirrored
+        Pn[i + j * N]  = P[i + j * N] + dt * s;
+        if (i != j) Pn[j + i * N] = P[j + i * N] + dt * s;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < NN; ++e) P[e] = Pn[e];
+    wave_sync();
+  }
+
+  if constexpr (UPDATE) {
+    constexpr int MN = M * N, MNP = MN | 1;
+    double H[MN];
+    tile_load<MN>(a.H, item0, a.batch, lds, lane);
+    wave_sync();
+#pragma unroll
+    for (int e = 0; e < MN; ++e) H[e] = live ? lds[lane * MNP + e] : 0.0;
+    wave_sync();
+
+    double T[MN], HP[MN];  // H * symU(P), H * P   (ekf.hpp:129, :134)
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+#pragma unroll
+      for (int aa = 0; aa < M; ++aa) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) s1 = fma(H[aa + k * M], (k <= j) ? P[k + j * N] : P[j + k * N], s1);
+#pragma unroll
+        for (int k = 0; k < N; ++k) s2 = fma(H[aa + k * M], P[k + j * N], s2);
+        T[aa + j * M]  = s1;
+        HP[aa + j * M] = s2;
+      }
+    }
+    SmallLdlt<M> F;
+    {
+      constexpr int MM = M * M, MMP = MM | 1;
+      if (!a.r_shared) {
+        tile_load<MM>(a.R, item0, a.batch, lds, lane);
+        wave_sync();
+      }
+#pragma unroll
+      for (int b = 0; b < M; ++b) {
+#pragma unroll
+        for (int aa = 0; aa < M; ++aa) {
+          if (aa <= b) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) s = fma(T[aa + k * M], H[b + k * M], s);
+            const double rr = a.r_shared ? a.R[aa + b * M] : (live ? lds[lane * MMP + aa + b * M] : ((aa == b) ? 1.0 : 0.0));
+            F.W[b][aa]      = s + rr;
+          } else {
+            F.W[b][aa] = 0.0;
+          }
+        }
+      }
+      wave_sync();
+    }
+    F.factor();
+    double X[MN];  // S^-1 (H P), column by column
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      double col[M];
+#pragma unroll
+      for (int aa = 0; aa < M; ++aa) col[aa] = HP[aa + j * M];
+      F.solve(col);
+#pragma unroll
+      for (int aa = 0; aa < M; ++aa) X[aa + j * M] = col[aa];
+    }
+    // delta = K r, K = X'   (:137)
+    double rv[M];
+#pragma unroll
+    for (int aa = 0; aa < M; ++aa) rv[aa] = live ? a.r[item * M + aa] : 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int aa = 0; aa < M; ++aa) s = fma(X[aa + i * M], rv[aa], s);
+      if (live) a.delta[item * N + i] = s;
+    }
+    if (a.info != nullptr && live) a.info[item] = F.ok ? 0 : 1;
+    // P = symU((I - K H) P)   (:138)
+    double IK[NN];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int aa = 0; aa < M; ++aa) s = fma(X[aa + i * M], H[aa + k * M], s);
+        IK[i + k * N] = ((i == k) ? 1.0 : 0.0) - s;
+      }
+    }
+    double Pn[NN];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+#pragma unroll
+      for (int i = 0; i <= j; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) s = fma(IK[i + k * N], P[k + j * N], s);
+        Pn[i + j * N] = s;
+        Pn[j + i * N] = s;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < NN; ++e) P[e] = Pn[e];
+  }
+
+  // ---- write P back (coalesced through LDS) ----
+  if (live) {
+#pragma unroll
+    for (int e = 0; e < NN; ++e) lds[lane * NP + e] = P[e];
+  }
+  wave_sync();
+  tile_store<NN>(a.P, item0, a.batch, lds, lane);
+}
+
+template<int N, int M>
+static hipError_t launch_nm(const EkfArgs &a, bool predict, bool update, hipStream_t stream)
+{
+  const dim3 grid((unsigned)((a.batch + kWave - 1) / kWave)), block(kWave);
+  if (predict && update) hipLaunchKernelGGL((ekf_kernel<N, M, true, true>), grid, block, 0, stream, a);
+  else if (predict) hipLaunchKernelGGL((ekf_kernel<N, M, true, false>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((ekf_kernel<N, M, false, true>), grid, block, 0, stream, a);
+  return hipGetLastError();
+}
+
+bool ekf_supported(int dof, int ny, bool update)
+{
+  const bool nok = dof == 2 || dof == 3 || dof == 4 || dof == 6;
+  if (!update) return nok;
+  return nok && ny >= 1 && ny <= 3;
+}
+
+hipError_t ekf_launch(const EkfArgs &a, int dof, int ny, bool predict, bool update, hipStream_t stream)
+{
+  if (!update) ny = 1;
+#define SFB_EKF_CASE(N, M) \
+  if (dof == N && ny == M) return launch_nm<N, M>(a, predict, update, stream);
+  SFB_EKF_CASE(2, 1) SFB_EKF_CASE(2, 2) SFB_EKF_CASE(2, 3)
+  SFB_EKF_CASE(3, 1) SFB_EKF_CASE(3, 2) SFB_EKF_CASE(3, 3)
+  SFB_EKF_CASE(4, 1) SFB_EKF_CASE(4, 2) SFB_EKF_CASE(4, 3)
+  SFB_EKF_CASE(6, 1) SFB_EKF_CASE(6, 2) SFB_EKF_CASE(6, 3)
+#undef SFB_EKF_CASE
+  return hipErrorInvalidValue;
+}
+
+}  // namespace sfb

@@ -1,0 +1,26 @@
+// Host<->kernel interface of the batched EKF covariance kernels.  Internal.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace sfb {
+
+struct EkfArgs {
+  int64_t batch;
+  // predict
+  const double *A, *Q, *dt;
+  int q_shared, dt_shared;
+  // update
+  const double *H, *R, *r;
+  int r_shared;
+  double *delta;
+  int32_t *info;
+  // state
+  double *P;
+};
+
+bool ekf_supported(int dof, int ny, bool update);
+hipError_t ekf_launch(const EkfArgs &a, int dof, int ny, bool predict, bool update, hipStream_t stream);
+
+}  // namespace sfb

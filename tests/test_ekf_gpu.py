@@ -1,0 +1,99 @@
+"""Parity of the HIP EKF kernels with the CPU oracle (bit-exact is expected: same operation order),
+the reference's linear-KF identities through the device path, and size-independent properties at
+BASELINE configs[4] scale.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _spd(rng, B, n):
+    G = rng.uniform(-1, 1, (B, n, n))
+    return np.eye(n)[None] + G @ G.transpose(0, 2, 1) / n
+
+
+def _flat(M):  # (B, r, c) -> col-major flat (B, r*c)
+    return np.ascontiguousarray(M.transpose(0, 2, 1).reshape(M.shape[0], -1))
+
+
+@pytest.mark.parametrize("dof,ny", [(6, 3), (3, 3), (2, 1), (4, 2), (6, 1), (3, 2), (2, 3)])
+@pytest.mark.parametrize("B", [1, 63, 1000])
+def test_predict_update_matches_oracle(sfb, oracle, dof, ny, B):
+    rng = np.random.default_rng(dof * 100 + ny * 10 + B)
+    P = _flat(_spd(rng, B, dof)); A = _flat(rng.uniform(-1, 1, (B, dof, dof)))
+    Q = _flat(0.1 * np.tile(np.eye(dof), (B, 1, 1)) + 0.01 * rng.uniform(-1, 1, (B, dof, dof)))
+    dt = rng.uniform(0.01, 0.05, B)
+    H = _flat(rng.uniform(-1, 1, (B, ny, dof))); R = _flat(0.1 * np.tile(np.eye(ny), (B, 1, 1)) + 0.01 * _spd(rng, B, ny))
+    r = rng.uniform(-1, 1, (B, ny))
+    # separate calls
+    P1, _, _ = sfb.ekf_step_batch_host(P, dof, A=A, Q=Q, dt=dt)
+    ref1 = oracle.ekf_predict_batch(A, Q, dt, P)
+    assert np.array_equal(P1, ref1)
+    P2, d2, i2 = sfb.ekf_step_batch_host(P1, dof, H=H, R=R, r=r)
+    ref2, dref, iref = oracle.ekf_update_batch(H, R, r, ref1, dof)
+    assert np.array_equal(i2, iref) and np.array_equal(P2, ref2) and np.array_equal(d2, dref)
+    # fused launch, shared Q / R / dt
+    Qs, Rs = Q[0].copy(), R[0].copy()
+    P3, d3, i3 = sfb.ekf_step_batch_host(P, dof, A=A, Q=Qs, dt=0.025, H=H, R=Rs, r=r)
+    refp = oracle.ekf_predict_batch(A, Qs, 0.025, P)
+    ref3, dref3, _ = oracle.ekf_update_batch(H, Rs, r, refp, dof)
+    assert np.array_equal(P3, ref3) and np.array_equal(d3, dref3) and (i3 == 0).all()
+
+
+def test_update_linear_identities_on_device(sfb):
+    """tests/test_ekf.cpp:50-103 through the device path (tolerance 1e-6 as in the reference)."""
+    rng = np.random.default_rng(3)
+    B, Nx, Ny = 200, 3, 3
+    P = np.stack([np.diag(rng.uniform(-1, 1, Nx) + 1.1) for _ in range(B)])
+    H = rng.uniform(-1, 1, (B, Ny, Nx)); R = np.stack([np.diag(rng.uniform(-1, 1, Ny) + 1.1) for _ in range(B)])
+    r = rng.uniform(-1, 1, (B, Ny))
+    Pn, delta, info = sfb.ekf_step_batch_host(_flat(P), Nx, H=_flat(H), R=_flat(R), r=r)
+    S = H @ P @ H.transpose(0, 2, 1) + R
+    K = P @ H.transpose(0, 2, 1) @ np.linalg.inv(S)
+    assert np.allclose(delta, np.einsum("bij,bj->bi", K, r), rtol=1e-6, atol=1e-12)
+    Pexp = (np.eye(Nx)[None] - K @ H) @ P
+    assert np.allclose(Pn.reshape(B, Nx, Nx).transpose(0, 2, 1), Pexp, rtol=1e-6, atol=1e-12)
+
+
+def test_unsupported_sizes_fail_loudly(sfb):
+    with pytest.raises(sfb._capi.SfbError) as e:
+        sfb.ekf_step_batch_host(np.zeros((4, 100)), 10, H=np.zeros((4, 30)), R=np.zeros((4, 9)), r=np.zeros((4, 3)))
+    assert e.value.status == sfb._capi.SFB_ERR_UNSUPPORTED
+
+
+def test_full_size_properties(sfb, oracle):
+    """BASELINE configs[4]: 1 048 576 filters, Dof 6 / Ny 3, fused predict+update.  Properties:
+    (i) a permuted batch gives permuted results (lane/position independence), (ii) P stays
+    symmetric positive definite and the update never increases trace(P) relative to the predicted
+    covariance, (iii) a 4096-item slice is bit-identical to the oracle."""
+    import torch
+    rng = np.random.default_rng(0)
+    B, n, m = 1 << 20, 6, 3
+    P = _flat(_spd(rng, B, n)); A = _flat(rng.uniform(-1, 1, (B, n, n)))
+    H = _flat(rng.uniform(-1, 1, (B, m, n))); r = rng.uniform(-1, 1, (B, m))
+    Q, R = (0.1 * np.eye(n)).flatten(), (0.1 * np.eye(m)).flatten()
+    dev = torch.device("cuda:0")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    def run(idx):
+        dP, dA, dH, dr = T(P[idx]), T(A[idx]), T(H[idx]), T(r[idx])
+        dQ, dR, ddt = T(Q), T(R), T(np.array([0.025]))
+        dd = torch.empty((len(idx), n), dtype=torch.float64, device=dev)
+        sfb.ekf_predict_update_batch_device(len(idx), n, m, dA.data_ptr(), dQ.data_ptr(), 1, ddt.data_ptr(), 1,
+                                            dH.data_ptr(), dR.data_ptr(), 1, dr.data_ptr(), dP.data_ptr(), dd.data_ptr(),
+                                            stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return dP.cpu().numpy(), dd.cpu().numpy()
+    ident = np.arange(B)
+    P1, d1 = run(ident)
+    perm = rng.permutation(B)
+    P2, d2 = run(perm)
+    assert np.array_equal(P2, P1[perm]) and np.array_equal(d2, d1[perm])
+    Pm = P1.reshape(B, n, n)
+    assert np.array_equal(Pm, Pm.transpose(0, 2, 1))
+    sub = Pm[::257]
+    assert np.linalg.eigvalsh(sub).min() > 0
+    Ppred = oracle.ekf_predict_batch(A[:4096], Q, 0.025, P[:4096])
+    ref, dref, _ = oracle.ekf_update_batch(H[:4096], R, r[:4096], Ppred, n)
+    assert np.array_equal(P1[:4096], ref) and np.array_equal(d1[:4096], dref)
+    tr_pred = Ppred.reshape(-1, n, n).trace(axis1=1, axis2=2)
+    assert (ref.reshape(-1, n, n).trace(axis1=1, axis2=2) <= tr_pred + 1e-12).all()

@@ -1,0 +1,49 @@
+"""Pins the EKF CPU oracle (oracle/ekf_oracle.c) against the reference's own analytic checks:
+tests/test_ekf.cpp:50-103 (UpdateLinear: textbook linear Kalman update) and :105-153 (PredictLinear:
+covariance propagation vs expm(A tau); here with the default Euler stepper and a small step)."""
+import numpy as np
+import pytest
+import scipy.linalg as sl
+
+
+@pytest.mark.parametrize("Nx,Ny", [(3, 3), (10, 3), (3, 10), (6, 3)])
+def test_update_linear(oracle, Nx, Ny):
+    rng = np.random.default_rng(Nx * 10 + Ny)
+    for _ in range(10):
+        x, xhat = rng.uniform(-1, 1, Nx), rng.uniform(-1, 1, Nx)
+        P = np.diag(rng.uniform(-1, 1, Nx) + 1.1)
+        H, h = rng.uniform(-1, 1, (Ny, Nx)), rng.uniform(-1, 1, Ny)
+        R = np.diag(rng.uniform(-1, 1, Ny) + 1.1)
+        r = (H @ x + h) - (H @ xhat + h)
+        Pn, delta, info = oracle.ekf_update_batch(H.flatten("F")[None], R.flatten("F")[None], r[None],
+                                                  P.flatten("F")[None], Nx)
+        S = H @ P @ H.T + R
+        K = P @ H.T @ np.linalg.inv(S)
+        assert info[0] == 0
+        assert np.allclose(xhat + delta[0], xhat + K @ r, rtol=1e-6, atol=1e-12)          # :100
+        assert np.allclose(Pn[0].reshape(Nx, Nx, order="F"), (np.eye(Nx) - K @ H) @ P, rtol=1e-6, atol=1e-12)  # :101
+
+
+@pytest.mark.parametrize("Nx", [3, 6])
+def test_predict_linear(oracle, Nx):
+    rng = np.random.default_rng(Nx)
+    A = rng.uniform(-1, 1, (Nx, Nx))
+    P = np.diag(rng.uniform(-1, 1, Nx) + 1.1)
+    tau, steps = 0.7, 7000
+    Pc = P.flatten("F")[None].copy()
+    for _ in range(steps):
+        Pc = oracle.ekf_predict_batch(A.flatten("F")[None], np.zeros(Nx * Nx), tau / steps, Pc)
+    F = sl.expm(A * tau)
+    assert np.allclose(Pc[0].reshape(Nx, Nx, order="F"), F @ P @ F.T, rtol=1e-3, atol=1e-3)     # :149 tolerance
+
+
+def test_predict_uses_upper_triangle_of_the_sum(oracle):
+    """ekf.hpp:88: dcov = (A cov + cov A' + Q).selfadjointView<Upper>(): a non-symmetric Q only
+    contributes through its upper triangle."""
+    rng = np.random.default_rng(5)
+    n = 4
+    A, P, Q = rng.uniform(-1, 1, (n, n)), np.eye(n), rng.uniform(-1, 1, (n, n))
+    Pn = oracle.ekf_predict_batch(A.flatten("F")[None], Q.flatten("F")[None], 0.1, P.flatten("F")[None])
+    S = A @ P + P @ A.T + Q
+    S = np.triu(S) + np.triu(S, 1).T
+    assert np.allclose(Pn[0].reshape(n, n, order="F"), P + 0.1 * S, atol=1e-15)
