@@ -176,7 +176,62 @@ class MPCWorkload:
                           % (S, cores, dt)}, parity
 
 
-WORKLOADS = {"mpc": MPCWorkload, "qp_dense": DenseQPWorkload}
+class EKFWorkload:
+    """BASELINE.json configs[4]: 1 048 576 independent SE2xR3 filters (Dof 6, Ny 3), one fused
+    predict (Euler substep, ekf.hpp:84-96) + update (ekf.hpp:119-138) per item per launch, per-item
+    A, Q, H, R, r (P = I + GG'/6, Q = 0.1 I, R = 0.1 I3, dt = 0.025)."""
+
+    def __init__(self, sfb, rank, device, batch=1 << 20, dof=6, ny=3):
+        self.sfb, self.B, self.n, self.m = sfb, batch, dof, ny
+        self.name = "ekf_predict_update_dof%d_ny%d_b%d" % (dof, ny, batch)
+        rng = np.random.default_rng(7 + rank)
+        n, m, B = dof, ny, batch
+        G = rng.uniform(-1, 1, (B, n, n))
+        flat = lambda M: np.ascontiguousarray(M.transpose(0, 2, 1).reshape(M.shape[0], -1))
+        self.host = dict(P=flat(np.eye(n)[None] + G @ G.transpose(0, 2, 1) / n), A=flat(rng.uniform(-1, 1, (B, n, n))),
+                         Q=np.tile((0.1 * np.eye(n)).flatten(), (B, 1)), H=flat(rng.uniform(-1, 1, (B, m, n))),
+                         R=np.tile((0.1 * np.eye(m)).flatten(), (B, 1)), r=rng.uniform(-1, 1, (B, m)),
+                         dt=np.full(B, 0.025))
+        self.dev = {k: torch.from_numpy(v).to(device) for k, v in self.host.items()}
+        self.P0 = self.dev["P"].clone()
+        self.delta = torch.empty((B, n), dtype=torch.float64, device=device)
+        self.units_per_step = B
+        # in: P, A, Q (36 each), H 18, R 9, r 3, dt 1; out: P 36, delta 6
+        self.bytes_per_unit = 8 * (3 * n * n + m * n + m * m + m + 1) + 8 * (n * n + n)
+        self.small = self.delta
+
+    def pre_step(self):
+        self.dev["P"].copy_(self.P0)  # every step filters the same prior; outside the kernel's HIP events
+
+    def step(self, stream):
+        d = self.dev
+        self.sfb.ekf_predict_update_batch_device(self.B, self.n, self.m, d["A"].data_ptr(), d["Q"].data_ptr(), 0,
+                                                 d["dt"].data_ptr(), 0, d["H"].data_ptr(), d["R"].data_ptr(), 0,
+                                                 d["r"].data_ptr(), d["P"].data_ptr(), self.delta.data_ptr(),
+                                                 stream=stream.cuda_stream)
+
+    def small_outputs(self):
+        return self.delta
+
+    def cpu_baseline(self, cores, budget_s=15.0):
+        from oracle import loader as O
+        h = self.host
+        S = min(self.B, 200000)
+        t0 = time.perf_counter()
+        Pp = O.ekf_predict_batch(h["A"][:S], h["Q"][:S], h["dt"][:S], h["P"][:S])
+        Pn, dref, _ = O.ekf_update_batch(h["H"][:S], h["R"][:S], h["r"][:S], Pp, self.n)
+        dt = time.perf_counter() - t0
+        P = self.dev["P"][:S].cpu().numpy()
+        delta = self.delta[:S].cpu().numpy()
+        parity = {"sample": S, "P_bit_identical": bool(np.array_equal(P, Pn)),
+                  "delta_bit_identical": bool(np.array_equal(delta, dref)),
+                  "max_abs_dP": float(np.abs(P - Pn).max()), "max_abs_ddelta": float(np.abs(delta - dref).max())}
+        return {"value": S / dt, "unit": "EKF steps/s", "cores": 1, "kind": "port",
+                "sample": "first %d filters of rank 0's batch, oracle/ekf_oracle.c (scalar C restatement of "
+                          "ekf.hpp:84-96,119-138), 1 thread, %.1f s" % (S, dt)}, parity
+
+
+WORKLOADS = {"mpc": MPCWorkload, "qp_dense": DenseQPWorkload, "ekf": EKFWorkload}
 
 
 def main():
@@ -211,11 +266,13 @@ def main():
     wl = WORKLOADS[args.workload](sfb, rank, device, **kw)
     stream = torch.cuda.current_stream()
     gathered = None
-    kernel_name = "qp_sparse_kernel" if args.workload == "mpc" else "qp_dense_kernel"
+    kernel_name = {"mpc": "qp_sparse_kernel", "qp_dense": "qp_dense_kernel", "ekf": "ekf_kernel"}[args.workload]
     if world > 1:
         gathered = [torch.empty_like(wl.small_outputs()) for _ in range(world)]
 
     def one_step():
+        if hasattr(wl, "pre_step"):
+            wl.pre_step()
         wl.step(stream)
         if world > 1:  # the only exchange on this path: final gather of the small outputs (RCCL/xGMI)
             dist.all_gather(gathered, wl.small_outputs())
@@ -231,6 +288,8 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
+        if hasattr(wl, "pre_step"):
+            wl.pre_step()
         ev[k][0].record(stream)   # HIP events on the stream the kernel is launched on
         wl.step(stream)
         ev[k][1].record(stream)
@@ -250,9 +309,9 @@ def main():
         value = units / elapsed
         achieved = wl.units_per_step * wl.bytes_per_unit / (kern_ms * 1e-3)
         rec = {
-            "metric": "QP solves/sec",
+            "metric": "EKF predict+update steps/sec" if args.workload == "ekf" else "QP solves/sec",
             "value": value,
-            "unit": "QP solves/s",
+            "unit": "EKF steps/s" if args.workload == "ekf" else "QP solves/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,

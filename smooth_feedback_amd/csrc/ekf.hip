@@ -29,12 +29,37 @@ __device__ __forceinline__ void tile_load(const double *__restrict__ g, int64_t 
                                           int lane)
 {
   constexpr int WP = W | 1;  // odd stride: conflict-free per-lane walks
-  const int64_t total = (nitems - item0 < kWave ? nitems - item0 : kWave) * W;
-  const double *src   = g + item0 * W;
+  const int total  = (int)(nitems - item0 < kWave ? nitems - item0 : kWave) * W;
+  const double *src = g + item0 * W;
+  // all global loads first (independent, one wait), then the LDS scatter
+  if constexpr (W % 2 == 0) {
+    constexpr int W2 = W / 2;  // 16-byte loads; a pair never straddles two items
+    const double2 *src2 = reinterpret_cast<const double2 *>(src);
+    double2 v[W2];
 #pragma unroll
-  for (int c = 0; c < W; ++c) {
-    const int idx = c * kWave + lane;
-    if (idx < total) lds[(idx / W) * WP + (idx % W)] = src[idx];
+    for (int c = 0; c < W2; ++c) {
+      const int idx = c * kWave + lane;
+      v[c]          = (2 * idx < total) ? src2[idx] : double2{0.0, 0.0};
+    }
+#pragma unroll
+    for (int c = 0; c < W2; ++c) {
+      const int idx = 2 * (c * kWave + lane);
+      const int o   = (idx / W) * WP + (idx % W);
+      lds[o]        = v[c].x;
+      lds[o + 1]    = v[c].y;
+    }
+  } else {
+    double v[W];
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+      const int idx = c * kWave + lane;
+      v[c]          = (idx < total) ? src[idx] : 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+      const int idx = c * kWave + lane;
+      lds[(idx / W) * WP + (idx % W)] = v[c];
+    }
   }
 }
 template<int W>
@@ -42,12 +67,24 @@ __device__ __forceinline__ void tile_store(double *__restrict__ g, int64_t item0
                                            int lane)
 {
   constexpr int WP = W | 1;
-  const int64_t total = (nitems - item0 < kWave ? nitems - item0 : kWave) * W;
-  double *dst         = g + item0 * W;
+  const int total  = (int)(nitems - item0 < kWave ? nitems - item0 : kWave) * W;
+  double *dst      = g + item0 * W;
+  if constexpr (W % 2 == 0) {
+    constexpr int W2 = W / 2;
+    double2 *dst2    = reinterpret_cast<double2 *>(dst);
 #pragma unroll
-  for (int c = 0; c < W; ++c) {
-    const int idx = c * kWave + lane;
-    if (idx < total) dst[idx] = lds[(idx / W) * WP + (idx % W)];
+    for (int c = 0; c < W2; ++c) {
+      const int i2  = c * kWave + lane;
+      const int idx = 2 * i2;
+      const int o   = (idx / W) * WP + (idx % W);
+      if (idx < total) dst2[i2] = double2{lds[o], lds[o + 1]};
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+      const int idx = c * kWave + lane;
+      if (idx < total) dst[idx] = lds[(idx / W) * WP + (idx % W)];
+    }
   }
 }
 
