@@ -38,3 +38,4 @@ print("iteration percentiles 50/90/99/99.9/max:", [int(np.percentile(itc, p)) fo
 for cap in (200, 400):
     ms = timed(sfb.QPSolverParams(max_iter=cap))
     print("max_iter=%d: %.2f ms -> %.0f solves/s ; codes %s" % (cap, ms, B / ms * 1e3, np.bincount(code.cpu().numpy(), minlength=7)))
+print("breakdown: setup(scaling on) %.2f | scaling off %.2f ms" % (timed(sfb.QPSolverParams(max_iter=0, polish=False)), timed(sfb.QPSolverParams(max_iter=0, polish=False, scaling=False))))

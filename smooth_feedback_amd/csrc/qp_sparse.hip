@@ -18,6 +18,7 @@
 // it once in each direction: this kernel is HBM-bound by construction.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 
@@ -34,7 +35,7 @@ namespace sfb {
 namespace {
 
 struct Ws {
-  double *Lx, *LxF, *LxB, *D, *Dinv, *tv, *Kval;
+  double *Lx, *LxF, *LxB, *D, *Dinv, *tv;  // Lx, D and one scratch double are contiguous (accumulators)
   double *sx, *qc, *xs, *xus, *dxus;
   double *sy, *rho, *rinv, *lo, *hi, *ys, *zs, *yus, *zus, *dyus, *act;
 };
@@ -45,10 +46,11 @@ __device__ __forceinline__ Ws carve_ws(double *base, int n, int m, int nnzL, int
   Ws w;
   double *p = base;
   w.Lx = p; p += nnzL;
+  w.D = p; p += k;
+  p += 1;  // scratch accumulator of the padding slots
   w.LxF = p; p += (size_t)(fsteps + kSweepPadDev) * 64;
   w.LxB = p; p += (size_t)(bsteps + kSweepPadDev) * 64;
-  w.Kval = w.LxB;  // KKT values, only alive during a factorisation (LxB is rewritten at its end)
-  w.D = p; p += k;      w.Dinv = p; p += k;   w.tv = p; p += k;
+  w.Dinv = p; p += k;   w.tv = p; p += k;
   w.sx = p; p += n;     w.qc = p; p += n;     w.xs = p; p += n;   w.xus = p; p += n;  w.dxus = p; p += n;
   p += n;
   w.sy = p; p += m;     w.rho = p; p += m;    w.rinv = p; p += m; w.lo = p; p += m;   w.hi = p; p += m;
@@ -85,84 +87,57 @@ __device__ __forceinline__ double kkt_value(const SparsePlanDev &pl, const Item 
   return v;
 }
 
-// Left-looking numeric LDL' on the shared pattern; t = LDS work vector (k).  Returns 1 / 0 (zero pivot).
-//
-// Column j gathers its source columns kk < j (row structure of L, ascending).  All sources of a
-// column are complete before the column starts, so their descriptors (position, length, the
-// multiplier L(j,kk)*D(kk)) are fetched 64 at a time with vector gathers and the first 64-entry
-// chunk of source s + DEPTH is prefetched while source s is applied: the memory latency of the
-// factor stream is paid once per column instead of once per source.
+// Numeric LDL' on the shared pattern, RIGHT-LOOKING over a static schedule (sparse_plan.h): the
+// accumulators [L values | D] live in the item's HBM workspace; when column kk is final (divide by
+// D(kk)), its entries and multipliers L(.,kk)*D(kk) are staged in LDS and every pair of its rows
+// updates one accumulator, 64 independent slots per step.  Each accumulator sees its sources in
+// ascending order, so the arithmetic equals the oracle's left-looking loop bit for bit, but a step is
+// ~15 instructions for 64 useful lanes instead of ~45 instructions for ~14.
+// t = LDS scratch (>= 2*(maxcol+1) doubles).  Returns 1 / 0 (zero pivot).
 template<int DEPTH>
 __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, const Ws &w, double *t, const int mode,
                                       const double c, const double sigma, const double delta, const int lane)
 {
-  const int k = pl.k;
-  // all KKT values in one fully parallel pass (the gathers behind kkt_value are 3-4 loads deep)
-  for (int p = lane; p < pl.nnzK; p += kWave) w.Kval[p] = kkt_value(pl, it, w, p, mode, c, sigma, delta);
+  const int k = pl.k, nnzL = pl.nnzL, mc = pl.maxcol;
+  double *ACC  = w.Lx;          // [0, nnzL): L entries, [nnzL, nnzL+k): D, [nnzL+k]: scratch
+  double *colv = t;             // L(r_e, kk)
+  double *wv   = t + (mc + 1);  // L(r_e, kk) * D(kk)
+  for (int p = lane; p < nnzL + k + 1; p += kWave) ACC[p] = 0.0;
+  if (lane == 0) {
+    colv[mc] = 0.0;  // entry used by padding slots
+    wv[mc]   = 0.0;
+  }
   wave_sync();
-  for (int j = 0; j < k; ++j) {
-    const int c0 = pl.Lp[j], c1 = pl.Lp[j + 1];
-    if (lane == 0) t[j] = 0.0;
-    for (int p = c0 + lane; p < c1; p += kWave) t[pl.Li[p]] = 0.0;
-    wave_sync();
-    for (int p = pl.Kp[j] + lane; p < pl.Kp[j + 1]; p += kWave) t[pl.Ki[p]] = w.Kval[p];
-    wave_sync();
-    const int r0 = pl.Rp[j], r1 = pl.Rp[j + 1];
-    for (int g0 = r0; g0 < r1; g0 += kWave) {  // groups of <= 64 source columns, ascending
-      const int gcnt = min(kWave, r1 - g0);
-      int pos = 0, len = 0;
-      double wv = 0.0;
-      if (lane < gcnt) {
-        const int kk = pl.Rk[g0 + lane];
-        pos          = pl.Rpos[g0 + lane];
-        len          = pl.Rlen[g0 + lane];
-        wv           = w.Lx[pos] * w.D[kk];  // L(j,kk) * D(kk)
-      }
-      double lx[DEPTH];
-      int li[DEPTH];
-#pragma unroll
-      for (int d = 0; d < DEPTH; ++d) {  // first chunk of sources 0..DEPTH-1 (lanes beyond gcnt hold len = 0)
-        const int ps = __builtin_amdgcn_readlane(pos, d), ln = __builtin_amdgcn_readlane(len, d);
-        const bool on = lane < ln;
-        lx[d] = on ? w.Lx[ps + lane] : 0.0;
-        li[d] = on ? pl.Li[ps + lane] : 0;
-      }
-      for (int s0 = 0; s0 < gcnt; s0 += DEPTH) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-          const int sidx = s0 + d;  // < 64 + DEPTH: readlane index is taken mod 64 below
-          if (sidx < gcnt) {
-            const int ps = __builtin_amdgcn_readlane(pos, sidx), ln = __builtin_amdgcn_readlane(len, sidx);
-            const double ws = lane_bcast(wv, sidx);
-            if (lane < ln) {
-              const int r = li[d];
-              t[r]        = fma(-lx[d], ws, t[r]);
-            }
-            for (int off = kWave; off < ln; off += kWave) {  // rare: suffix longer than one chunk
-              if (off + lane < ln) {
-                const int r = pl.Li[ps + off + lane];
-                t[r]        = fma(-w.Lx[ps + off + lane], ws, t[r]);
-              }
-            }
-          }
-          const int sn = s0 + d + DEPTH;  // prefetch the first chunk of source sn
-          if (sn < gcnt) {
-            const int ps2 = __builtin_amdgcn_readlane(pos, sn), ln2 = __builtin_amdgcn_readlane(len, sn);
-            const bool on = lane < ln2;
-            lx[d] = on ? w.Lx[ps2 + lane] : 0.0;
-            li[d] = on ? pl.Li[ps2 + lane] : 0;
-          }
-        }
-      }
-    }
-    wave_sync();
-    const double d = t[j];
-    if (lane == 0) {
-      w.D[j]    = d;
-      w.Dinv[j] = 1.0 / d;
-    }
+  for (int p = lane; p < pl.nnzK; p += kWave) ACC[pl.Kmap[p]] = kkt_value(pl, it, w, p, mode, c, sigma, delta);
+  wave_sync();
+  for (int kk = 0; kk < k; ++kk) {
+    const int c0 = pl.Lp[kk], cnt = pl.Lp[kk + 1] - c0;
+    const double d = ACC[nnzL + kk];
+    if (lane == 0) w.Dinv[kk] = 1.0 / d;
     if (d == 0.0) return 0;
-    for (int p = c0 + lane; p < c1; p += kWave) w.Lx[p] = t[pl.Li[p]] / d;
+    for (int e = lane; e < cnt; e += kWave) {
+      const double v = ACC[c0 + e] / d;
+      ACC[c0 + e]    = v;
+      colv[e]        = v;
+      wv[e]          = v * d;
+    }
+    wave_sync();
+    const int s1 = pl.rptr[kk + 1];
+    for (int s = pl.rptr[kk]; s < s1; s += DEPTH) {
+      int tp[DEPTH];
+      unsigned ab[DEPTH];
+      double acc[DEPTH];
+#pragma unroll
+      for (int dd = 0; dd < DEPTH; ++dd) {  // the schedule arrays are padded: reading past s1 is safe
+        tp[dd] = pl.rtgt[(s + dd) * kWave + lane];
+        ab[dd] = (unsigned)pl.rab[(s + dd) * kWave + lane];
+      }
+#pragma unroll
+      for (int dd = 0; dd < DEPTH; ++dd) acc[dd] = (s + dd < s1) ? ACC[tp[dd]] : 0.0;
+#pragma unroll
+      for (int dd = 0; dd < DEPTH; ++dd)
+        if (s + dd < s1) ACC[tp[dd]] = fma(-colv[ab[dd] & 0xFFFFu], wv[ab[dd] >> 16], acc[dd]);
+    }
     wave_sync();
   }
   // schedule-ordered copies of the factor for the two sweeps (padding slots carry 0)
@@ -569,7 +544,7 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
                             const double *wy, double *x, double *y, double *obj, uint32_t *iter, int32_t *code,
                             double *workspace, hipStream_t stream)
 {
-  const size_t lds = (size_t)(pl.k + 2) * sizeof(double);
+  const size_t lds = (size_t)std::max(pl.k + 2, 2 * pl.maxcol + 4) * sizeof(double);
   const size_t wsd = qp_sparse_ws_doubles(pl.n, pl.m, pl.nnzL, pl.fsteps, pl.bsteps);
   hipLaunchKernelGGL(qp_sparse_kernel, dim3((unsigned)batch), dim3(kWave), lds, stream, pl, kp, Px, q, Ax, l, u, wx,
                      wy, x, y, obj, iter, code, workspace, wsd);

@@ -21,6 +21,8 @@ struct SparsePlanDev {
   const int32_t *perm, *pinv, *Kp, *Ki, *Kkind, *Kidx, *Lp, *Li, *Rp, *Rk, *Rpos, *Rlen;
   const int32_t *fmap, *fidx, *bmap, *bidx;  // packed sweep schedules, see sparse_plan.h
   int fsteps, bsteps;
+  const int32_t *Kmap, *rptr, *rtgt, *rab;   // right-looking factorisation schedule
+  int rsteps, maxcol;
 };
 
 // per-item workspace, in doubles
@@ -29,6 +31,7 @@ inline size_t qp_sparse_ws_doubles(int n, int m, int nnzL, int fsteps, int bstep
 {
   const size_t k = (size_t)n + m;
   return (size_t)nnzL + (size_t)(fsteps + bsteps + 2 * kSweepPadDev) * 64 + 3 * k + 6 * (size_t)n + 12 * (size_t)m + 8;
+  // (accumulator layout of the factorisation: [L values | D | 1 scratch] is contiguous at the start of the block)
   // (the KKT value buffer of the factorisation aliases the forward-sweep copy LxF: nnzK <= nnzL + k <= its size
   //  is checked at plan creation)
 }

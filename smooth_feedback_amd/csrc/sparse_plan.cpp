@@ -238,6 +238,55 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
   o.Rlen.resize(o.nnzL);
   for (int t = 0; t < o.nnzL; ++t) o.Rlen[t] = o.Lp[o.Rk[t] + 1] - o.Rpos[t];
 
+  // right-looking factorisation schedule (see sparse_plan.h)
+  {
+    std::vector<int32_t> where(k, -1);  // row -> position in the column currently scattered
+    auto pos_in_col = [&](int col, int row) {  // binary search: rows ascending
+      const int32_t *b = o.Li.data() + o.Lp[col], *e = o.Li.data() + o.Lp[col + 1];
+      const int32_t *it = std::lower_bound(b, e, row);
+      return (it != e && *it == row) ? (int)(it - o.Li.data()) : -1;
+    };
+    o.Kmap.resize(o.nnzK);
+    for (int j = 0; j < k; ++j)
+      for (int p = o.Kp[j]; p < o.Kp[j + 1]; ++p) {
+        const int i = o.Ki[p];
+        o.Kmap[p]   = (i == j) ? o.nnzL + j : pos_in_col(j, i);
+        if (o.Kmap[p] < 0) { *msg = "internal: KKT entry outside the pattern of L"; return false; }
+      }
+    o.rptr.assign(k + 1, 0);
+    o.maxcol = 0;
+    for (int kk = 0; kk < k; ++kk) {
+      const int cnt = o.Lp[kk + 1] - o.Lp[kk];
+      o.maxcol      = std::max(o.maxcol, cnt);
+      const int64_t slots = (int64_t)cnt * (cnt + 1) / 2;
+      o.rptr[kk + 1] = o.rptr[kk] + (int)((slots + 63) / 64);
+    }
+    o.rsteps = o.rptr[k];
+    if (o.maxcol >= (1 << 16)) { *msg = "column of L too long for the update encoding"; return false; }
+    o.rtgt.assign((size_t)(o.rsteps + SparsePlanHost::kSweepPad) * 64, o.nnzL + k);
+    o.rab.assign((size_t)(o.rsteps + SparsePlanHost::kSweepPad) * 64, 0);
+    // padding slots use a = b = maxcol (an extra zero entry of the column buffers) -> acc -= 0 * 0
+    for (auto &v : o.rab) v = o.maxcol | (o.maxcol << 16);
+    for (int kk = 0; kk < k; ++kk) {
+      const int c0 = o.Lp[kk], cnt = o.Lp[kk + 1] - c0;
+      size_t q = (size_t)o.rptr[kk] * 64;
+      for (int b = 0; b < cnt; ++b) {
+        const int j = o.Li[c0 + b];
+        // target column j: row r_a for a > b, diagonal for a == b
+        o.rtgt[q] = o.nnzL + j;
+        o.rab[q]  = b | (b << 16);
+        ++q;
+        for (int a = b + 1; a < cnt; ++a) {
+          const int pos = pos_in_col(j, o.Li[c0 + a]);
+          if (pos < 0) { *msg = "internal: fill entry missing from the pattern of L"; return false; }
+          o.rtgt[q] = pos;
+          o.rab[q]  = a | (b << 16);
+          ++q;
+        }
+      }
+    }
+  }
+
   // packed sweep schedules (see sparse_plan.h)
   if (k + 1 >= (1 << 16)) { *msg = "n+m too large for the packed sweep encoding (max 65534)"; return false; }
   auto build = [&](bool forward, std::vector<int32_t> &xmap, std::vector<int32_t> &xidx, int &steps) {

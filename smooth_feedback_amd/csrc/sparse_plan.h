@@ -38,6 +38,17 @@ struct SparsePlanHost {
   //   xmap[q]  : position in the column-major values of L feeding slot q, or -1 (padding)
   //   xidx[q]  : tgt | piv << 16   (padding: both = k, a scratch slot of the LDS vector)
   // Arrays are padded by kSweepPad extra all-padding steps so the kernel can prefetch branch-free.
+  // Right-looking factorisation schedule.  When column kk is final it updates, for every pair of its
+  // rows (r_a >= r_b), the accumulator of entry (r_a, r_b) [the diagonal D(r_b) when a == b]:
+  //   acc -= L(r_a,kk) * (L(r_b,kk) * D(kk)).
+  // All updates issued by one column hit distinct accumulators and columns are processed in order,
+  // so every accumulator receives its updates in ascending source order -- the same arithmetic as the
+  // left-looking loop of the oracle -- while a step is 64 independent, fully packed slots.
+  //   Kmap[p]  : accumulator index of KKT entry p   (accumulators: [L values (nnzL) | D (k) | scratch])
+  //   rptr[kk] : first 64-slot step of column kk (rptr[k] = total steps);  per slot:
+  //   rtgt[q]  : accumulator index (padding: nnzL + k),  rab[q] = a | b << 16 (entry numbers in column kk)
+  std::vector<int32_t> Kmap, rptr, rtgt, rab;
+  int rsteps = 0, maxcol = 0;
   static constexpr int kSweepPad = 16;
   std::vector<int32_t> fmap, fidx, bmap, bidx;
   int fsteps = 0, bsteps = 0;
