@@ -49,7 +49,7 @@ __device__ __forceinline__ Ws carve_ws(double *base, int n, int m, int nnzL, int
   w.D = p; p += k;
   p += 1;  // scratch accumulator of the padding slots
   w.LxF = p; p += (size_t)(fsteps + kSweepPadDev) * 64;
-  w.LxB = p; p += (size_t)(bsteps + kSweepPadDev) * 64;
+  w.LxB = p; p += (size_t)(bsteps + kSweepPadDev) * 64 * kBwdWidthDev;
   w.Dinv = p; p += k;   w.tv = p; p += k;
   w.sx = p; p += n;     w.qc = p; p += n;     w.xs = p; p += n;   w.xus = p; p += n;  w.dxus = p; p += n;
   p += n;
@@ -145,7 +145,7 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
     const int src = pl.fmap[q];
     w.LxF[q]      = (src >= 0) ? w.Lx[src] : 0.0;
   }
-  for (int q = lane; q < (pl.bsteps + kSweepPadDev) * kWave; q += kWave) {
+  for (int q = lane; q < (pl.bsteps + kSweepPadDev) * kWave * kBwdWidthDev; q += kWave) {
     const int src = pl.bmap[q];
     w.LxB[q]      = (src >= 0) ? w.Lx[src] : 0.0;
   }
@@ -153,34 +153,54 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
   return 1;
 }
 
-// One triangular sweep over a packed schedule (sparse_plan.h): step s, lane l applies
-//   t[tgt] = fma(-vals[64 s + l], t[piv], t[tgt]),   (tgt, piv) = idx[64 s + l].
-// Branch-free; the factor is streamed from HBM DEPTH steps ahead of its use, so memory latency is
-// overlapped with the serially dependent LDS updates.  t has k+1 entries, t[k] is the padding slot.
-template<int DEPTH>
+// One triangular sweep over a packed schedule (sparse_plan.h): step s, slot w, lane l applies
+//   t[tgt] = fma(-vals[q], t[piv], t[tgt]),   (tgt, piv) = idx[q],  q = (s * WIDTH + w) * 64 + l.
+// The WIDTH slots of a lane within a step are independent (distinct targets, final pivots), so their
+// LDS reads are issued together.  Branch-free; the factor is streamed from HBM DEPTH steps ahead of
+// its use, so memory latency is overlapped with the serially dependent LDS updates.  t has k+1
+// entries, t[k] is the padding slot.
+template<int DEPTH, int WIDTH>
 __device__ inline void sweep_dev(const int32_t *__restrict__ idx, const int steps, const double *vals, double *t,
                                  const int lane)
 {
   static_assert(DEPTH <= kSweepPadDev, "schedule padding must cover the prefetch distance");
-  double lx[DEPTH];
-  int ix[DEPTH];
+  vals += lane;  // per-lane stream pointers live in VGPRs: the hot loop needs no (spilled) SGPR bases
+  idx += lane;
+  double lx[DEPTH][WIDTH];
+  int ix[DEPTH][WIDTH];
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) {
-    lx[d] = vals[d * kWave + lane];
-    ix[d] = idx[d * kWave + lane];
+#pragma unroll
+    for (int wv = 0; wv < WIDTH; ++wv) {
+      lx[d][wv] = vals[(d * WIDTH + wv) * kWave];
+      ix[d][wv] = idx[(d * WIDTH + wv) * kWave];
+    }
   }
+  vals += DEPTH * WIDTH * kWave;
+  idx += DEPTH * WIDTH * kWave;
   for (int s0 = 0; s0 < steps; s0 += DEPTH) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
       if (s0 + d < steps) {  // uniform
-        const unsigned pk = (unsigned)ix[d];
-        const int r = pk & 0xFFFFu, pv = pk >> 16;
-        t[r]        = fma(-lx[d], t[pv], t[r]);
+        double tp[WIDTH], tr[WIDTH];
+#pragma unroll
+        for (int wv = 0; wv < WIDTH; ++wv) {
+          const unsigned pk = (unsigned)ix[d][wv];
+          tp[wv] = t[pk >> 16];
+          tr[wv] = t[pk & 0xFFFFu];
+        }
+#pragma unroll
+        for (int wv = 0; wv < WIDTH; ++wv) t[(unsigned)ix[d][wv] & 0xFFFFu] = fma(-lx[d][wv], tp[wv], tr[wv]);
       }
-      const int sn = s0 + d + DEPTH;  // always inside the padded arrays
-      lx[d]        = vals[sn * kWave + lane];
-      ix[d]        = idx[sn * kWave + lane];
+      // prefetch step s0 + d + DEPTH (always inside the padded arrays)
+#pragma unroll
+      for (int wv = 0; wv < WIDTH; ++wv) {
+        lx[d][wv] = vals[(d * WIDTH + wv) * kWave];
+        ix[d][wv] = idx[(d * WIDTH + wv) * kWave];
+      }
     }
+    vals += DEPTH * WIDTH * kWave;
+    idx += DEPTH * WIDTH * kWave;
   }
   wave_sync();
 }
@@ -189,10 +209,10 @@ __device__ inline void sweep_dev(const int32_t *__restrict__ idx, const int step
 __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, double *t, const int lane)
 {
   const int k = pl.k;
-  sweep_dev<SFB_SWEEP_DEPTH>(pl.fidx, pl.fsteps, w.LxF, t, lane);  // forward (column oriented order)
+  sweep_dev<SFB_SWEEP_DEPTH, 1>(pl.fidx, pl.fsteps, w.LxF, t, lane);  // forward (column oriented order)
   for (int j = lane; j < k; j += kWave) t[j] = w.Dinv[j] * t[j];
   wave_sync();
-  sweep_dev<SFB_SWEEP_DEPTH>(pl.bidx, pl.bsteps, w.LxB, t, lane);  // backward (rows pushing, descending order)
+  sweep_dev<SFB_SWEEP_DEPTH / 2, kBwdWidthDev>(pl.bidx, pl.bsteps, w.LxB, t, lane);  // backward (rows pushing, descending)
 }
 
 __device__ __forceinline__ double lane_max_abs(const double *v, int len, int lane)

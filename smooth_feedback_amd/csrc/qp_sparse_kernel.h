@@ -27,10 +27,11 @@ struct SparsePlanDev {
 
 // per-item workspace, in doubles
 constexpr int kSweepPadDev = 16;  // == SparsePlanHost::kSweepPad
+constexpr int kBwdWidthDev = 2;   // == SparsePlanHost::kBwdWidth
 inline size_t qp_sparse_ws_doubles(int n, int m, int nnzL, int fsteps, int bsteps)
 {
   const size_t k = (size_t)n + m;
-  return (size_t)nnzL + (size_t)(fsteps + bsteps + 2 * kSweepPadDev) * 64 + 3 * k + 6 * (size_t)n + 12 * (size_t)m + 8;
+  return (size_t)nnzL + (size_t)(fsteps + kSweepPadDev) * 64 + (size_t)(bsteps + kSweepPadDev) * 64 * kBwdWidthDev + 3 * k + 6 * (size_t)n + 12 * (size_t)m + 8;
   // (accumulator layout of the factorisation: [L values | D | 1 scratch] is contiguous at the start of the block)
   // (the KKT value buffer of the factorisation aliases the forward-sweep copy LxF: nnzK <= nnzL + k <= its size
   //  is checked at plan creation)

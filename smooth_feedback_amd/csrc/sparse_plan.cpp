@@ -289,7 +289,8 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
 
   // packed sweep schedules (see sparse_plan.h)
   if (k + 1 >= (1 << 16)) { *msg = "n+m too large for the packed sweep encoding (max 65534)"; return false; }
-  auto build = [&](bool forward, std::vector<int32_t> &xmap, std::vector<int32_t> &xidx, int &steps) {
+  auto build = [&](bool forward, int width, std::vector<int32_t> &xmap, std::vector<int32_t> &xidx, int &steps) {
+    const int cap = 64 * width;
     std::vector<int32_t> last_write(k, -1), fill;
     std::vector<std::vector<std::array<int32_t, 3>>> slots;  // per step: (pos, tgt, piv)
     for (int t = 0; t < k; ++t) {
@@ -301,11 +302,11 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
       int p = p0;
       while (p < p1) {
         if ((int)slots.size() <= s) { slots.resize(s + 1); fill.resize(s + 1, 0); }
-        while (fill[s] >= 64) {
+        while (fill[s] >= cap) {
           ++s;
           if ((int)slots.size() <= s) { slots.resize(s + 1); fill.resize(s + 1, 0); }
         }
-        const int room = 64 - fill[s];
+        const int room = cap - fill[s];
         const int take = std::min(room, p1 - p);
         for (int q = 0; q < take; ++q, ++p) {
           const int tgt = forward ? o.Li[p] : o.Rk[p];
@@ -318,17 +319,17 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
       }
     }
     steps = (int)slots.size();
-    const size_t total = (size_t)(steps + SparsePlanHost::kSweepPad) * 64;
+    const size_t total = (size_t)(steps + SparsePlanHost::kSweepPad) * cap;
     xmap.assign(total, -1);
     xidx.assign(total, k | (k << 16));
     for (int s = 0; s < steps; ++s)
       for (size_t q = 0; q < slots[s].size(); ++q) {
-        xmap[(size_t)s * 64 + q] = slots[s][q][0];
-        xidx[(size_t)s * 64 + q] = slots[s][q][1] | (slots[s][q][2] << 16);
+        xmap[(size_t)s * cap + q] = slots[s][q][0];
+        xidx[(size_t)s * cap + q] = slots[s][q][1] | (slots[s][q][2] << 16);
       }
   };
-  build(true, o.fmap, o.fidx, o.fsteps);
-  build(false, o.bmap, o.bidx, o.bsteps);
+  build(true, 1, o.fmap, o.fidx, o.fsteps);
+  build(false, SparsePlanHost::kBwdWidth, o.bmap, o.bidx, o.bsteps);
   return true;
 }
 

@@ -50,6 +50,9 @@ struct SparsePlanHost {
   std::vector<int32_t> Kmap, rptr, rtgt, rab;
   int rsteps = 0, maxcol = 0;
   static constexpr int kSweepPad = 16;
+  // The backward sweep is scheduled with kBwdWidth = 2 slots per lane and step (its per-target chains
+  // are short, so wider steps halve the number of dependent steps); layout [step][slot][lane].
+  static constexpr int kBwdWidth = 2;
   std::vector<int32_t> fmap, fidx, bmap, bidx;
   int fsteps = 0, bsteps = 0;
 };
