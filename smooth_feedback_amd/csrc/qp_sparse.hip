@@ -181,7 +181,7 @@ __device__ inline void sweep_dev(const int32_t *__restrict__ idx, const int step
   for (int s0 = 0; s0 < steps; s0 += DEPTH) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-      if (s0 + d < steps) {  // uniform
+      {  // `steps` is a multiple of the padding block (all-padding steps are no-ops): no bounds test
         double tp[WIDTH], tr[WIDTH];
 #pragma unroll
         for (int wv = 0; wv < WIDTH; ++wv) {

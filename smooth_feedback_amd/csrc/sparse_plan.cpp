@@ -319,6 +319,8 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
       }
     }
     steps = (int)slots.size();
+    steps = ((steps + SparsePlanHost::kSweepPad - 1) / SparsePlanHost::kSweepPad) * SparsePlanHost::kSweepPad;  // whole prefetch blocks
+    slots.resize(steps);
     const size_t total = (size_t)(steps + SparsePlanHost::kSweepPad) * cap;
     xmap.assign(total, -1);
     xidx.assign(total, k | (k << 16));
