@@ -61,7 +61,7 @@ sfb_status plan_on_device(sfb_sparse_qp_plan *plan, const sfb::SparsePlanDev **o
                             &d.Prp, &d.Prj, &d.Prpos, &d.Sp, &d.Sj, &d.Spos, &d.perm, &d.pinv,
                             &d.Kp, &d.Ki, &d.Kkind, &d.Kidx, &d.Lp, &d.Li, &d.Rp, &d.Rk, &d.Rpos, &d.Rlen,
                             &d.fmap, &d.fidx, &d.bmap, &d.bidx, &d.Kmap, &d.rptr, &d.rtgt, &d.rab};
-  d.fsteps = h.fsteps; d.bsteps = h.bsteps; d.rsteps = h.rsteps; d.maxcol = h.maxcol;
+  d.funits = h.funits; d.bunits = h.bunits; d.rsteps = h.rsteps; d.maxcol = h.maxcol;
   for (int a = 0; a < NA; ++a) *ptrs[a] = dc.blob + off[a];
   auto ins = plan->per_device.emplace(devid, dc);
   *out     = &ins.first->second.dev;
@@ -135,7 +135,7 @@ sfb_status sfb_sparse_qp_plan_info(const sfb_sparse_qp_plan *plan, int64_t *nnzK
   if (nnzL) *nnzL = plan->host.nnzL;
   if (workspace_bytes_per_item)
     *workspace_bytes_per_item =
-      (int64_t)(sfb::qp_sparse_ws_doubles(plan->host.n, plan->host.m, plan->host.nnzL, plan->host.fsteps, plan->host.bsteps) * sizeof(double));
+      (int64_t)(sfb::qp_sparse_ws_doubles(plan->host.n, plan->host.m, plan->host.nnzL, plan->host.funits, plan->host.bunits) * sizeof(double));
   return SFB_OK;
 }
 
@@ -180,7 +180,7 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
   if (batch == 0) return SFB_OK;
   const sfb::SparsePlanHost &h = plan->host;
   const size_t B = (size_t)batch, N = (size_t)h.n, M = (size_t)h.m, NP = (size_t)h.nnzP, NA = (size_t)h.nnzA;
-  const size_t wsd  = sfb::qp_sparse_ws_doubles(h.n, h.m, h.nnzL, h.fsteps, h.bsteps);
+  const size_t wsd  = sfb::qp_sparse_ws_doubles(h.n, h.m, h.nnzL, h.funits, h.bunits);
   const size_t in_d = B * (NP + N + NA + 2 * M) + (warm_x ? B * (N + M) : 0), out_d = B * (N + M + 1);
   const size_t bytes = (in_d + out_d + B * wsd) * sizeof(double) + B * 8;
   char *devmem = nullptr;

@@ -27,7 +27,7 @@
 #include "wave_util.h"
 
 #ifndef SFB_SWEEP_DEPTH
-#define SFB_SWEEP_DEPTH 16
+#define SFB_SWEEP_DEPTH 8  // units (2 slots per lane each) in flight per sweep
 #endif
 
 namespace sfb {
@@ -40,7 +40,7 @@ struct Ws {
   double *sy, *rho, *rinv, *lo, *hi, *ys, *zs, *yus, *zus, *dyus, *act;
 };
 
-__device__ __forceinline__ Ws carve_ws(double *base, int n, int m, int nnzL, int fsteps, int bsteps)
+__device__ __forceinline__ Ws carve_ws(double *base, int n, int m, int nnzL, int funits, int bunits)
 {
   const int k = n + m;
   Ws w;
@@ -48,8 +48,8 @@ __device__ __forceinline__ Ws carve_ws(double *base, int n, int m, int nnzL, int
   w.Lx = p; p += nnzL;
   w.D = p; p += k;
   p += 1;  // scratch accumulator of the padding slots
-  w.LxF = p; p += (size_t)(fsteps + kSweepPadDev) * 64;
-  w.LxB = p; p += (size_t)(bsteps + kSweepPadDev) * 64 * kBwdWidthDev;
+  w.LxF = p; p += (size_t)(funits + kSweepPadDev) * 128;
+  w.LxB = p; p += (size_t)(bunits + kSweepPadDev) * 128;
   w.Dinv = p; p += k;   w.tv = p; p += k;
   w.sx = p; p += n;     w.qc = p; p += n;     w.xs = p; p += n;   w.xus = p; p += n;  w.dxus = p; p += n;
   p += n;
@@ -141,11 +141,11 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
     wave_sync();
   }
   // schedule-ordered copies of the factor for the two sweeps (padding slots carry 0)
-  for (int q = lane; q < (pl.fsteps + kSweepPadDev) * kWave; q += kWave) {
+  for (int q = lane; q < (pl.funits + kSweepPadDev) * 2 * kWave; q += kWave) {
     const int src = pl.fmap[q];
     w.LxF[q]      = (src >= 0) ? w.Lx[src] : 0.0;
   }
-  for (int q = lane; q < (pl.bsteps + kSweepPadDev) * kWave * kBwdWidthDev; q += kWave) {
+  for (int q = lane; q < (pl.bunits + kSweepPadDev) * 2 * kWave; q += kWave) {
     const int src = pl.bmap[q];
     w.LxB[q]      = (src >= 0) ? w.Lx[src] : 0.0;
   }
@@ -153,55 +153,75 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
   return 1;
 }
 
-// One triangular sweep over a packed schedule (sparse_plan.h): step s, slot w, lane l applies
-//   t[tgt] = fma(-vals[q], t[piv], t[tgt]),   (tgt, piv) = idx[q],  q = (s * WIDTH + w) * 64 + l.
-// The WIDTH slots of a lane within a step are independent (distinct targets, final pivots), so their
-// LDS reads are issued together.  Branch-free; the factor is streamed from HBM DEPTH steps ahead of
-// its use, so memory latency is overlapped with the serially dependent LDS updates.  t has k+1
-// entries, t[k] is the padding slot.
-template<int DEPTH, int WIDTH>
-__device__ inline void sweep_dev(const int32_t *__restrict__ idx, const int steps, const double *vals, double *t,
+// Stream loads of the sweeps are hand-issued: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` at the head
+// of a software-pipelined loop, which drains the whole prefetch queue every DEPTH steps and exposes one
+// full memory latency per block (measured: 107 ns per step for a lone wave vs a 100-cycle LDS chain).
+// With inline-asm loads the compiler tracks nothing and the counted waits below are exact: loads
+// return in order, so before consuming the data of one step at most (DEPTH-1) steps' loads may remain
+// in flight.
+typedef double vdouble2 __attribute__((ext_vector_type(2)));  // native vectors: usable as asm register operands
+typedef int vint2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void stream_load(vdouble2 &v, const vdouble2 *p)
+{
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p));
+}
+__device__ __forceinline__ void stream_load(vint2 &v, const vint2 *p)
+{
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p));
+}
+template<int N>
+__device__ __forceinline__ void stream_wait(vdouble2 &a, vint2 &b)
+{
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+
+// One triangular sweep over a packed schedule (sparse_plan.h).  A UNIT holds two slots per lane,
+//   t[tgt] = fma(-val, t[piv], t[tgt]),   (tgt, piv) = idx,
+// fetched with one 16-byte and one 8-byte load.  SEQ (forward sweep): the two slots are consecutive
+// dependent steps and are applied one after the other; !SEQ (backward sweep): they belong to one step
+// of 128 independent slots and their LDS reads are issued together.  Branch-free; DEPTH units
+// (= 2 x DEPTH slots per lane) are in flight ahead of their use so the ~1.7 us HBM latency of a lone
+// wave is covered; t has k+1 entries, t[k] is the padding slot; `units` is a multiple of kSweepPadDev.
+template<int DEPTH, bool SEQ>
+__device__ inline void sweep_dev(const int32_t *__restrict__ idx, const int units, const double *vals, double *t,
                                  const int lane)
 {
-  static_assert(DEPTH <= kSweepPadDev, "schedule padding must cover the prefetch distance");
-  vals += lane;  // per-lane stream pointers live in VGPRs: the hot loop needs no (spilled) SGPR bases
-  idx += lane;
-  double lx[DEPTH][WIDTH];
-  int ix[DEPTH][WIDTH];
+  static_assert(DEPTH <= kSweepPadDev && kSweepPadDev % DEPTH == 0, "schedule padding must cover the prefetch distance");
+  static_assert(2 * DEPTH <= 62, "vmcnt is a 6-bit counter");
+  const vdouble2 *vp = reinterpret_cast<const vdouble2 *>(vals) + lane;  // per-lane stream pointers (VGPRs)
+  const vint2 *ip    = reinterpret_cast<const vint2 *>(idx) + lane;
+  vdouble2 lx[DEPTH];
+  vint2 ix[DEPTH];
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) {
-#pragma unroll
-    for (int wv = 0; wv < WIDTH; ++wv) {
-      lx[d][wv] = vals[(d * WIDTH + wv) * kWave];
-      ix[d][wv] = idx[(d * WIDTH + wv) * kWave];
-    }
+    stream_load(lx[d], vp + d * kWave);
+    stream_load(ix[d], ip + d * kWave);
   }
-  vals += DEPTH * WIDTH * kWave;
-  idx += DEPTH * WIDTH * kWave;
-  for (int s0 = 0; s0 < steps; s0 += DEPTH) {
+  vp += DEPTH * kWave;
+  ip += DEPTH * kWave;
+  for (int u0 = 0; u0 < units; u0 += DEPTH) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-      {  // `steps` is a multiple of the padding block (all-padding steps are no-ops): no bounds test
-        double tp[WIDTH], tr[WIDTH];
-#pragma unroll
-        for (int wv = 0; wv < WIDTH; ++wv) {
-          const unsigned pk = (unsigned)ix[d][wv];
-          tp[wv] = t[pk >> 16];
-          tr[wv] = t[pk & 0xFFFFu];
-        }
-#pragma unroll
-        for (int wv = 0; wv < WIDTH; ++wv) t[(unsigned)ix[d][wv] & 0xFFFFu] = fma(-lx[d][wv], tp[wv], tr[wv]);
+      stream_wait<2 * (DEPTH - 1)>(lx[d], ix[d]);  // this unit's two loads are the oldest in flight
+      const unsigned p0 = (unsigned)ix[d].x, p1 = (unsigned)ix[d].y;
+      if constexpr (SEQ) {
+        t[p0 & 0xFFFFu] = fma(-lx[d].x, t[p0 >> 16], t[p0 & 0xFFFFu]);
+        t[p1 & 0xFFFFu] = fma(-lx[d].y, t[p1 >> 16], t[p1 & 0xFFFFu]);
+      } else {
+        const double a0 = t[p0 >> 16], b0 = t[p0 & 0xFFFFu], a1 = t[p1 >> 16], b1 = t[p1 & 0xFFFFu];
+        t[p0 & 0xFFFFu] = fma(-lx[d].x, a0, b0);
+        t[p1 & 0xFFFFu] = fma(-lx[d].y, a1, b1);
       }
-      // prefetch step s0 + d + DEPTH (always inside the padded arrays)
-#pragma unroll
-      for (int wv = 0; wv < WIDTH; ++wv) {
-        lx[d][wv] = vals[(d * WIDTH + wv) * kWave];
-        ix[d][wv] = idx[(d * WIDTH + wv) * kWave];
-      }
+      stream_load(lx[d], vp + d * kWave);  // unit u0 + d + DEPTH (always inside the padded arrays)
+      stream_load(ix[d], ip + d * kWave);
     }
-    vals += DEPTH * WIDTH * kWave;
-    idx += DEPTH * WIDTH * kWave;
+    vp += DEPTH * kWave;
+    ip += DEPTH * kWave;
   }
+  // the trailing prefetches (padding) are never consumed: retire them before their registers are reused
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) stream_wait<0>(lx[d], ix[d]);
   wave_sync();
 }
 
@@ -209,10 +229,17 @@ __device__ inline void sweep_dev(const int32_t *__restrict__ idx, const int step
 __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, double *t, const int lane)
 {
   const int k = pl.k;
-  sweep_dev<SFB_SWEEP_DEPTH, 1>(pl.fidx, pl.fsteps, w.LxF, t, lane);  // forward (column oriented order)
-  for (int j = lane; j < k; j += kWave) t[j] = w.Dinv[j] * t[j];
+  sweep_dev<SFB_SWEEP_DEPTH, true>(pl.fidx, pl.funits, w.LxF, t, lane);   // forward (column oriented order)
+  for (int j0 = lane; j0 < k; j0 += kWave * 8) {  // D^-1 (:458), loads batched
+    double dv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dv[e] = (j0 + e * kWave < k) ? w.Dinv[j0 + e * kWave] : 0.0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (j0 + e * kWave < k) t[j0 + e * kWave] = dv[e] * t[j0 + e * kWave];
+  }
   wave_sync();
-  sweep_dev<SFB_SWEEP_DEPTH / 2, kBwdWidthDev>(pl.bidx, pl.bsteps, w.LxB, t, lane);  // backward (rows pushing, descending)
+  sweep_dev<SFB_SWEEP_DEPTH, false>(pl.bidx, pl.bunits, w.LxB, t, lane);  // backward (rows pushing, descending)
 }
 
 __device__ __forceinline__ double lane_max_abs(const double *v, int len, int lane)
@@ -382,7 +409,7 @@ __global__ void __launch_bounds__(64) qp_sparse_kernel(const SparsePlanDev pl, c
   const size_t b = blockIdx.x;
   const Item it{gPx + b * (size_t)pl.nnzP, gq + b * (size_t)n, gAx + b * (size_t)pl.nnzA, gl + b * (size_t)m,
                 gu + b * (size_t)m};
-  const Ws w = carve_ws(gws + b * ws_doubles, n, m, pl.nnzL, pl.fsteps, pl.bsteps);
+  const Ws w = carve_ws(gws + b * ws_doubles, n, m, pl.nnzL, pl.funits, pl.bunits);
   if (lane == 0) t[k] = 0.0;  // padding slot of the packed sweeps
   const double inf = INFINITY;
 
@@ -490,35 +517,101 @@ __global__ void __launch_bounds__(64) qp_sparse_kernel(const SparsePlanDev pl, c
   const uint32_t maxit = kp.max_iter;
   uint32_t next_chk    = (sci >= 2) ? 1u : 0xFFFFFFFFu;
   for (; iter != maxit && ret_code < 0; ++iter) {
-    for (int j = lane; j < n; j += kWave) t[pl.pinv[j]] = kp.sigma * w.xs[j] - w.qc[j];            // :450
-    for (int i = lane; i < m; i += kWave) t[pl.pinv[n + i]] = w.zs[i] - w.rinv[i] * w.ys[i];      // :451
+    // element-wise phases: the loads of UNR strided elements are issued together (one memory round
+    // trip per UNR elements instead of one per element -- matters for a wave that runs alone)
+    constexpr int UNR = 4;
+    for (int j0 = lane; j0 < n; j0 += kWave * UNR) {  // :450
+      double xv[UNR], qv[UNR];
+      int pv[UNR];
+#pragma unroll
+      for (int e = 0; e < UNR; ++e) {
+        const int j = j0 + e * kWave;
+        const bool on = j < n;
+        xv[e] = on ? w.xs[j] : 0.0;
+        qv[e] = on ? w.qc[j] : 0.0;
+        pv[e] = on ? pl.pinv[j] : k;
+      }
+#pragma unroll
+      for (int e = 0; e < UNR; ++e)
+        if (j0 + e * kWave < n) t[pv[e]] = kp.sigma * xv[e] - qv[e];
+    }
+    for (int i0 = lane; i0 < m; i0 += kWave * UNR) {  // :451
+      double zv[UNR], rv[UNR], yv[UNR];
+      int pv[UNR];
+#pragma unroll
+      for (int e = 0; e < UNR; ++e) {
+        const int i = i0 + e * kWave;
+        const bool on = i < m;
+        zv[e] = on ? w.zs[i] : 0.0;
+        rv[e] = on ? w.rinv[i] : 0.0;
+        yv[e] = on ? w.ys[i] : 0.0;
+        pv[e] = on ? pl.pinv[n + i] : k;
+      }
+#pragma unroll
+      for (int e = 0; e < UNR; ++e)
+        if (i0 + e * kWave < m) t[pv[e]] = zv[e] - rv[e] * yv[e];
+    }
     wave_sync();
     ldl_solve_dev(pl, w, t, lane);                                                              // :456-460
     const bool chk = (iter == next_chk);
     if (chk) next_chk += sci;
-    for (int j = lane; j < n; j += kWave) {  // :470
-      const double xo = w.xs[j], xn = kp.alpha * t[pl.pinv[j]] + kp.alpha_comp * xo;
-      w.xs[j] = xn;
-      if (chk) {
-        const double sxj = w.sx[j];
-        w.xus[j]  = sxj * xn;
-        w.dxus[j] = sxj * (xn - xo);
+    for (int j0 = lane; j0 < n; j0 += kWave * UNR) {  // :470
+      double xo[UNR], sxj[UNR];
+      int pv[UNR];
+#pragma unroll
+      for (int e = 0; e < UNR; ++e) {
+        const int j = j0 + e * kWave;
+        const bool on = j < n;
+        xo[e]  = on ? w.xs[j] : 0.0;
+        pv[e]  = on ? pl.pinv[j] : k;
+        sxj[e] = (on && chk) ? w.sx[j] : 0.0;
+      }
+#pragma unroll
+      for (int e = 0; e < UNR; ++e) {
+        const int j = j0 + e * kWave;
+        if (j < n) {
+          const double xn = kp.alpha * t[pv[e]] + kp.alpha_comp * xo[e];
+          w.xs[j] = xn;
+          if (chk) {
+            w.xus[j]  = sxj[e] * xn;
+            w.dxus[j] = sxj[e] * (xn - xo[e]);
+          }
+        }
       }
     }
-    for (int i = lane; i < m; i += kWave) {  // :471-477
-      const double nu = t[pl.pinv[n + i]], yo = w.ys[i], zo = w.zs[i], ri = w.rinv[i], rh = w.rho[i];
-      double zn = kp.alpha * (ri * nu) + kp.alpha_comp * (ri * yo) + zo;
-      const double lo = w.lo[i], hi = w.hi[i];
-      zn = (zn < lo) ? lo : zn;
-      zn = (hi < zn) ? hi : zn;
-      const double yn = kp.alpha_comp * yo + kp.alpha * nu + rh * zo - rh * zn;
-      w.ys[i] = yn;
-      w.zs[i] = zn;
-      if (chk) {
-        const double syi = w.sy[i];
-        w.yus[i]  = syi * yn / c;
-        w.zus[i]  = (1.0 / syi) * zn;
-        w.dyus[i] = syi * (yn - yo) / c;
+    for (int i0 = lane; i0 < m; i0 += kWave * UNR) {  // :471-477
+      double yo[UNR], zo[UNR], ri[UNR], rh[UNR], lo[UNR], hi[UNR], syi[UNR];
+      int pv[UNR];
+#pragma unroll
+      for (int e = 0; e < UNR; ++e) {
+        const int i = i0 + e * kWave;
+        const bool on = i < m;
+        yo[e] = on ? w.ys[i] : 0.0;
+        zo[e] = on ? w.zs[i] : 0.0;
+        ri[e] = on ? w.rinv[i] : 0.0;
+        rh[e] = on ? w.rho[i] : 0.0;
+        lo[e] = on ? w.lo[i] : 0.0;
+        hi[e] = on ? w.hi[i] : 0.0;
+        pv[e] = on ? pl.pinv[n + i] : k;
+        syi[e] = (on && chk) ? w.sy[i] : 1.0;
+      }
+#pragma unroll
+      for (int e = 0; e < UNR; ++e) {
+        const int i = i0 + e * kWave;
+        if (i < m) {
+          const double nu = t[pv[e]];
+          double zn = kp.alpha * (ri[e] * nu) + kp.alpha_comp * (ri[e] * yo[e]) + zo[e];
+          zn = (zn < lo[e]) ? lo[e] : zn;
+          zn = (hi[e] < zn) ? hi[e] : zn;
+          const double yn = kp.alpha_comp * yo[e] + kp.alpha * nu + rh[e] * zo[e] - rh[e] * zn;
+          w.ys[i] = yn;
+          w.zs[i] = zn;
+          if (chk) {
+            w.yus[i]  = syi[e] * yn / c;
+            w.zus[i]  = (1.0 / syi[e]) * zn;
+            w.dyus[i] = syi[e] * (yn - yo[e]) / c;
+          }
+        }
       }
     }
     wave_sync();
@@ -565,7 +658,7 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
                             double *workspace, hipStream_t stream)
 {
   const size_t lds = (size_t)std::max(pl.k + 2, 2 * pl.maxcol + 4) * sizeof(double);
-  const size_t wsd = qp_sparse_ws_doubles(pl.n, pl.m, pl.nnzL, pl.fsteps, pl.bsteps);
+  const size_t wsd = qp_sparse_ws_doubles(pl.n, pl.m, pl.nnzL, pl.funits, pl.bunits);
   hipLaunchKernelGGL(qp_sparse_kernel, dim3((unsigned)batch), dim3(kWave), lds, stream, pl, kp, Px, q, Ax, l, u, wx,
                      wy, x, y, obj, iter, code, workspace, wsd);
   return hipGetLastError();

@@ -20,18 +20,17 @@ struct SparsePlanDev {
   const int32_t *Acp, *Aci, *Acpos, *Prp, *Prj, *Prpos, *Sp, *Sj, *Spos;
   const int32_t *perm, *pinv, *Kp, *Ki, *Kkind, *Kidx, *Lp, *Li, *Rp, *Rk, *Rpos, *Rlen;
   const int32_t *fmap, *fidx, *bmap, *bidx;  // packed sweep schedules, see sparse_plan.h
-  int fsteps, bsteps;
+  int funits, bunits;
   const int32_t *Kmap, *rptr, *rtgt, *rab;   // right-looking factorisation schedule
   int rsteps, maxcol;
 };
 
 // per-item workspace, in doubles
 constexpr int kSweepPadDev = 16;  // == SparsePlanHost::kSweepPad
-constexpr int kBwdWidthDev = 2;   // == SparsePlanHost::kBwdWidth
-inline size_t qp_sparse_ws_doubles(int n, int m, int nnzL, int fsteps, int bsteps)
+inline size_t qp_sparse_ws_doubles(int n, int m, int nnzL, int funits, int bunits)
 {
   const size_t k = (size_t)n + m;
-  return (size_t)nnzL + (size_t)(fsteps + kSweepPadDev) * 64 + (size_t)(bsteps + kSweepPadDev) * 64 * kBwdWidthDev + 3 * k + 6 * (size_t)n + 12 * (size_t)m + 8;
+  return (size_t)nnzL + (size_t)(funits + bunits + 2 * kSweepPadDev) * 128 + 3 * k + 6 * (size_t)n + 12 * (size_t)m + 8;
   // (accumulator layout of the factorisation: [L values | D | 1 scratch] is contiguous at the start of the block)
   // (the KKT value buffer of the factorisation aliases the forward-sweep copy LxF: nnzK <= nnzL + k <= its size
   //  is checked at plan creation)

@@ -289,8 +289,8 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
 
   // packed sweep schedules (see sparse_plan.h)
   if (k + 1 >= (1 << 16)) { *msg = "n+m too large for the packed sweep encoding (max 65534)"; return false; }
-  auto build = [&](bool forward, int width, std::vector<int32_t> &xmap, std::vector<int32_t> &xidx, int &steps) {
-    const int cap = 64 * width;
+  auto build = [&](bool forward, std::vector<int32_t> &xmap, std::vector<int32_t> &xidx, int &units) {
+    const int cap = forward ? 64 : 128;  // slots per dependent step
     std::vector<int32_t> last_write(k, -1), fill;
     std::vector<std::vector<std::array<int32_t, 3>>> slots;  // per step: (pos, tgt, piv)
     for (int t = 0; t < k; ++t) {
@@ -306,8 +306,7 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
           ++s;
           if ((int)slots.size() <= s) { slots.resize(s + 1); fill.resize(s + 1, 0); }
         }
-        const int room = cap - fill[s];
-        const int take = std::min(room, p1 - p);
+        const int take = std::min(cap - fill[s], p1 - p);
         for (int q = 0; q < take; ++q, ++p) {
           const int tgt = forward ? o.Li[p] : o.Rk[p];
           const int pos = forward ? p : o.Rpos[p];
@@ -318,20 +317,22 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
         if (p < p1) ++s;
       }
     }
-    steps = (int)slots.size();
-    steps = ((steps + SparsePlanHost::kSweepPad - 1) / SparsePlanHost::kSweepPad) * SparsePlanHost::kSweepPad;  // whole prefetch blocks
-    slots.resize(steps);
-    const size_t total = (size_t)(steps + SparsePlanHost::kSweepPad) * cap;
+    const int steps = (int)slots.size();
+    units           = forward ? (steps + 1) / 2 : steps;
+    units = ((units + SparsePlanHost::kSweepPad - 1) / SparsePlanHost::kSweepPad) * SparsePlanHost::kSweepPad;
+    const size_t total = (size_t)(units + SparsePlanHost::kSweepPad) * 128;
     xmap.assign(total, -1);
     xidx.assign(total, k | (k << 16));
     for (int s = 0; s < steps; ++s)
-      for (size_t q = 0; q < slots[s].size(); ++q) {
-        xmap[(size_t)s * cap + q] = slots[s][q][0];
-        xidx[(size_t)s * cap + q] = slots[s][q][1] | (slots[s][q][2] << 16);
+      for (size_t e = 0; e < slots[s].size(); ++e) {
+        // forward: step s -> unit s/2, slot s%2, lane e;   backward: step s -> unit s, slot e/64, lane e%64
+        const size_t q = forward ? ((size_t)(s / 2) * 64 + e) * 2 + (s & 1) : ((size_t)s * 64 + (e & 63)) * 2 + (e >> 6);
+        xmap[q] = slots[s][e][0];
+        xidx[q] = slots[s][e][1] | (slots[s][e][2] << 16);
       }
   };
-  build(true, 1, o.fmap, o.fidx, o.fsteps);
-  build(false, SparsePlanHost::kBwdWidth, o.bmap, o.bidx, o.bsteps);
+  build(true, o.fmap, o.fidx, o.funits);
+  build(false, o.bmap, o.bidx, o.bunits);
   return true;
 }
 

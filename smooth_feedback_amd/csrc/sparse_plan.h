@@ -37,7 +37,14 @@ struct SparsePlanHost {
   // exactly those of the column-by-column loop, with fewer, fuller, branch-free steps.
   //   xmap[q]  : position in the column-major values of L feeding slot q, or -1 (padding)
   //   xidx[q]  : tgt | piv << 16   (padding: both = k, a scratch slot of the LDS vector)
-  // Arrays are padded by kSweepPad extra all-padding steps so the kernel can prefetch branch-free.
+  // Storage is in UNITS of 2 slots per lane, layout [unit][lane][2] (one 16-byte value load and one
+  // 8-byte index load per lane and unit):  forward  unit u = steps 2u and 2u+1 (applied one after the
+  // other), backward unit u = ONE step of 128 independent slots (its per-target chains are short, so
+  // wider steps halve the number of dependent steps).  Unit counts are multiples of kSweepPad and the
+  // arrays carry kSweepPad extra all-padding units so the kernel prefetches branch-free.
+  static constexpr int kSweepPad = 16;
+  std::vector<int32_t> fmap, fidx, bmap, bidx;
+  int funits = 0, bunits = 0;
   // Right-looking factorisation schedule.  When column kk is final it updates, for every pair of its
   // rows (r_a >= r_b), the accumulator of entry (r_a, r_b) [the diagonal D(r_b) when a == b]:
   //   acc -= L(r_a,kk) * (L(r_b,kk) * D(kk)).
@@ -49,12 +56,6 @@ struct SparsePlanHost {
   //   rtgt[q]  : accumulator index (padding: nnzL + k),  rab[q] = a | b << 16 (entry numbers in column kk)
   std::vector<int32_t> Kmap, rptr, rtgt, rab;
   int rsteps = 0, maxcol = 0;
-  static constexpr int kSweepPad = 16;
-  // The backward sweep is scheduled with kBwdWidth = 2 slots per lane and step (its per-target chains
-  // are short, so wider steps halve the number of dependent steps); layout [step][slot][lane].
-  static constexpr int kBwdWidth = 2;
-  std::vector<int32_t> fmap, fidx, bmap, bidx;
-  int fsteps = 0, bsteps = 0;
 };
 
 // ordering: 0 = natural, 1 = minimum degree (default); user_perm (k entries, new->old) overrides.
