@@ -8,6 +8,7 @@
 #include <thread>
 #include <vector>
 
+#include <smooth_feedback_amd/ekf.hpp>
 #include <smooth_feedback_amd/mpc.hpp>
 
 using namespace smooth_feedback_amd;
@@ -293,6 +294,76 @@ double sfbx_lie_selftest(void)
     for (int i = 0; i < 6; ++i) err = std::max(err, std::fabs(t62[i] - t6[i]));
   }
   return err;
+}
+
+int sfbx_test_ekf(double * err)
+{
+  try {
+    std::mt19937_64 rng(5);
+    std::uniform_real_distribution<double> d(-1.0, 1.0);
+    // PredictTimeCut (tests/test_ekf.cpp:155-180): constant velocity b, tau = 0.7, dt = 0.5 -> xhat + b tau
+    {
+      EKF<Rn<2>> ekf;
+      Rn<2> xhat; xhat.v = {d(rng), d(rng)};
+      Mat<2, 2> P{}; P(0, 0) = d(rng) + 1.1; P(1, 1) = d(rng) + 1.1;
+      ekf.reset(xhat, P);
+      const Vec<2> b{d(rng), d(rng)};
+      Mat<2, 2> Q{}; Q(0, 0) = d(rng) + 1.1; Q(1, 1) = d(rng) + 1.1;
+      ekf.predict([&](double, const Rn<2> &) { return b; }, Q, 0.7, 0.5);
+      const auto e = ekf.estimate();
+      err[0] = std::max(std::fabs(e.v[0] - (xhat.v[0] + 0.7 * b[0])), std::fabs(e.v[1] - (xhat.v[1] + 0.7 * b[1])));
+    }
+    // UpdateLinear (tests/test_ekf.cpp:50-103), Nx = Ny = 3, diagonal P and R
+    err[1] = err[2] = 0.0;
+    for (int it = 0; it < 10; ++it) {
+      EKF<Rn<3>> ekf;
+      Rn<3> xhat; Vec<3> x, hoff;
+      Mat<3, 3> P{}, H{}, R{};
+      for (int i = 0; i < 3; ++i) { xhat.v[i] = d(rng); x[i] = d(rng); hoff[i] = d(rng); P(i, i) = d(rng) + 1.1; R(i, i) = d(rng) + 1.1; }
+      for (auto & v : H.a) v = d(rng);
+      ekf.reset(xhat, P);
+      const Vec<3> y = [&] { Vec<3> t = H * x; for (int i = 0; i < 3; ++i) t[i] += hoff[i]; return t; }();
+      ekf.update<3>([&](const Rn<3> & g) { Vec<3> t = H * g.v; for (int i = 0; i < 3; ++i) t[i] += hoff[i]; return t; }, y, R);
+      // textbook: S = H P H' + R (diag P), K = P H' S^-1 by solving S z = r
+      Mat<3, 3> S = R;
+      for (int a = 0; a < 3; ++a) for (int b2 = 0; b2 < 3; ++b2) for (int k2 = 0; k2 < 3; ++k2) S(a, b2) += H(a, k2) * P(k2, k2) * H(b2, k2);
+      Vec<3> r; { Vec<3> hx = H * xhat.v; for (int i = 0; i < 3; ++i) r[i] = y[i] - (hx[i] + hoff[i]); }
+      // solve S z = r (Gaussian elimination, 3x3)
+      double M[3][4];
+      for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) M[i][j] = S(i, j); M[i][3] = r[i]; }
+      for (int c = 0; c < 3; ++c) {
+        int piv = c; for (int i = c + 1; i < 3; ++i) if (std::fabs(M[i][c]) > std::fabs(M[piv][c])) piv = i;
+        for (int j = 0; j < 4; ++j) std::swap(M[c][j], M[piv][j]);
+        for (int i = c + 1; i < 3; ++i) { const double fct = M[i][c] / M[c][c]; for (int j = c; j < 4; ++j) M[i][j] -= fct * M[c][j]; }
+      }
+      Vec<3> z;
+      for (int i = 2; i >= 0; --i) { double sacc = M[i][3]; for (int j = i + 1; j < 3; ++j) sacc -= M[i][j] * z[j]; z[i] = sacc / M[i][i]; }
+      const auto est = ekf.estimate();
+      for (int i = 0; i < 3; ++i) {
+        double xe = xhat.v[i];
+        for (int a = 0; a < 3; ++a) xe += P(i, i) * H(a, i) * z[a];
+        err[1] = std::max(err[1], std::fabs(est.v[i] - xe));
+      }
+      // covariance: trace must not increase and stays symmetric
+      const auto Pn = ekf.covariance();
+      double tr0 = 0, tr1 = 0;
+      for (int i = 0; i < 3; ++i) { tr0 += P(i, i); tr1 += Pn(i, i); for (int j = 0; j < 3; ++j) err[2] = std::max(err[2], std::fabs(Pn(i, j) - Pn(j, i))); }
+      if (tr1 > tr0 + 1e-12) err[2] = 1.0;
+    }
+    // SE2 smoke (tests/test_ekf.cpp:31-48 NoCrash, on SE2): predict with substeps, then a position measurement
+    {
+      EKF<SE2> ekf;
+      ekf.reset(SE2::Identity(), Mat<3, 3>::Identity());
+      ekf.predict([](double, const SE2 &) { return Vec<3>{1.0, 0.0, 0.3}; }, Mat<3, 3>::Identity(), 1.0, 0.6);
+      ekf.update<2>([](const SE2 & g) { return Vec<2>{g.x, g.y}; }, Vec<2>{1.0, 0.2}, Mat<2, 2>::Identity());
+      ekf.predict([](double, const SE2 &) { return Vec<3>{1.0, 0.0, 0.3}; }, Mat<3, 3>::Identity(), 1.0, 0.1);
+      const auto Pn = ekf.covariance();
+      for (const double v : Pn.a) if (!std::isfinite(v)) return -3;
+    }
+  } catch (const std::exception &) {
+    return -2;
+  }
+  return 0;
 }
 
 int sfbx_mesh(int n_ivals, int K, double * nodes, double * weights, double * Dus)

@@ -28,6 +28,10 @@ int sfbx_mpc_swarm_step(int variant, int K, double tf, int64_t batch, uint64_t s
                         int32_t *codes, uint32_t *iters);
 /* group identities for the tests: returns max abs error over a set of checks */
 double sfbx_lie_selftest(void);
+/* EKF<G> front (include/smooth_feedback_amd/ekf.hpp) against the reference's own checks: PredictTimeCut
+ * (tests/test_ekf.cpp:155-180), UpdateLinear (:50-103, R^3 / Ny 3) and an SE2 predict+update smoke.
+ * Returns 0 and writes max errors: err[0] time-cut, err[1] linear update state, err[2] linear update cov. Needs a GPU. */
+int sfbx_test_ekf(double *err);
 /* mesh: nodes (N+1), weights (N+1), Dus ((K+1)*K col-major) for `n` intervals of K points */
 int sfbx_mesh(int n_ivals, int K, double *nodes, double *weights, double *Dus);
 

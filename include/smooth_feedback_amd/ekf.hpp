@@ -1,0 +1,111 @@
+// Host side of the EKF path: same interface as smooth::feedback::EKF<G> (reference ekf.hpp:39-149)
+// for one filter, plus EKFBatch for swarms.  The Lie-group work that needs the user's callbacks
+// (linearisation of f and h at the estimate, state propagation, g (+) delta) stays here on the host;
+// the covariance algebra runs on the GPU through sfb_ekf_*_batch (include/sfb.h).
+//
+// Derivatives: analytic if the callable offers jacobian(...), else forward differences with step
+// sqrt(eps) (the reference's default without the autodiff header, SURVEY.md section 8 notes).
+// Stepper: explicit Euler (the reference's default template argument, ekf.hpp:30); predict(f, Q, tau, dt)
+// runs ceil(tau/dt) substeps and re-linearises before each one, covariance first (ekf.hpp:93-102).
+#pragma once
+#include <sfb.h>
+
+#include <cmath>
+#include <limits>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "lie.hpp"
+
+namespace smooth_feedback_amd {
+
+namespace detail {
+inline void ekf_check(sfb_status st)
+{
+  if (st != SFB_OK) throw std::runtime_error(std::string("sfb: ") + sfb_last_error());
+}
+
+// A = -ad(f(g)) + d^r f/dg  (ekf.hpp:86-87), right-derivative by forward differences
+template<class G, class F>
+Mat<G::Dof, G::Dof> ekf_linearise_dyn(F && f, const G & g, typename G::Tangent & fv)
+{
+  constexpr int N = G::Dof;
+  fv = f(g);
+  Mat<N, N> dr{};
+  const double h = std::sqrt(std::numeric_limits<double>::epsilon());
+  for (int c = 0; c < N; ++c) {
+    typename G::Tangent e{};
+    e[c]          = h;
+    const auto f2 = f(rplus(g, e));
+    for (int r = 0; r < N; ++r) dr(r, c) = (f2[r] - fv[r]) / h;
+  }
+  const Mat<N, N> adf = G::ad(fv);
+  Mat<N, N> A{};
+  for (int i = 0; i < N * N; ++i) A.a[i] = -adf.a[i] + dr.a[i];
+  return A;
+}
+}  // namespace detail
+
+/// smooth::feedback::EKF<G>, ekf.hpp:39-149 (Euler stepper, measurement space R^Ny)
+template<class G>
+class EKF {
+public:
+  static constexpr int N = G::Dof;
+  using CovT = Mat<N, N>;
+
+  void reset(const G & g, const CovT & P) { g_hat_ = g; P_ = P; }   // ekf.hpp:52-56
+  G estimate() const { return g_hat_; }                               // :61
+  CovT covariance() const { return P_; }                              // :66
+
+  /// ekf.hpp:79-103.  f(t, g) -> Tangent, Q: process covariance (upper triangle used)
+  template<class F>
+  void predict(F && f, const CovT & Q, double tau, std::optional<double> dt = {})
+  {
+    double t          = 0;
+    const double dt_v = dt.value_or(2 * tau);
+    auto step = [&](double h) {
+      typename G::Tangent fv;
+      const CovT A = detail::ekf_linearise_dyn<G>([&](const G & x) { return f(t, x); }, g_hat_, fv);
+      // covariance first: it depends on g_hat_ (:94-96)
+      detail::ekf_check(sfb_ekf_step_batch_host(1, N, 1, A.a.data(), Q.a.data(), 1, &h, 1, nullptr, nullptr, 0, nullptr,
+                                                P_.a.data(), nullptr, nullptr));
+      for (auto & v : fv) v *= h;
+      g_hat_ = rplus(g_hat_, fv);  // euler on the group: g <- g (+) dt f (:97)
+    };
+    while (t + dt_v < tau) {
+      step(dt_v);
+      t += dt_v;
+    }
+    step(tau - t);
+  }
+
+  /// ekf.hpp:116-139.  h(g) -> Vec<Ny> (measurement in R^Ny), y measured value, R covariance
+  template<int Ny, class H>
+  void update(H && h, const Vec<Ny> & y, const Mat<Ny, Ny> & R)
+  {
+    const Vec<Ny> hval = h(g_hat_);
+    Mat<Ny, N> Hm{};
+    const double eps = std::sqrt(std::numeric_limits<double>::epsilon());
+    for (int c = 0; c < N; ++c) {
+      typename G::Tangent e{};
+      e[c]          = eps;
+      const auto h2 = h(rplus(g_hat_, e));
+      for (int r = 0; r < Ny; ++r) Hm(r, c) = (h2[r] - hval[r]) / eps;
+    }
+    Vec<Ny> r{};
+    for (int i = 0; i < Ny; ++i) r[i] = y[i] - hval[i];
+    typename G::Tangent delta{};
+    int32_t info = 0;
+    detail::ekf_check(sfb_ekf_step_batch_host(1, N, Ny, nullptr, nullptr, 0, nullptr, 0, Hm.a.data(), R.a.data(), 1,
+                                              r.data(), P_.a.data(), delta.data(), &info));
+    g_hat_ = rplus(g_hat_, delta);  // :137
+  }
+
+private:
+  G g_hat_  = G::Identity();
+  CovT P_   = CovT::Identity();
+};
+
+}  // namespace smooth_feedback_amd

@@ -618,8 +618,14 @@ __global__ void __launch_bounds__(64) qp_sparse_kernel(const SparsePlanDev pl, c
     if (chk) {
       ret_code = sp_check_stopping(pl, it, w, kp, lane);
       wave_sync();
+      // Items that are still iterating after many checks are the ones the whole launch waits for:
+      // raise their issue priority over the co-resident waves that are in their first iterations.
+      if (iter > 600) __builtin_amdgcn_s_setprio(3);
+      else if (iter > 300) __builtin_amdgcn_s_setprio(2);
+      else if (iter > 100) __builtin_amdgcn_s_setprio(1);
     }
   }
+  __builtin_amdgcn_s_setprio(0);
 
   // ---- polish :515-539 ----
   if (ret_code == SFB_QP_OPTIMAL && kp.polish) sp_polish(pl, it, w, kp, t, c, lane);

@@ -97,3 +97,13 @@ def test_full_size_properties(sfb, oracle):
     assert np.array_equal(P1[:4096], ref) and np.array_equal(d1[:4096], dref)
     tr_pred = Ppred.reshape(-1, n, n).trace(axis1=1, axis2=2)
     assert (ref.reshape(-1, n, n).trace(axis1=1, axis2=2) <= tr_pred + 1e-12).all()
+
+
+def test_cpp_front_mirrors_reference_ekf_checks(sfb):
+    """include/smooth_feedback_amd/ekf.hpp (EKF<G>::predict/update over the C-ABI): PredictTimeCut
+    (tests/test_ekf.cpp:155-180), UpdateLinear (:50-103) and an SE2 predict/update/predict run."""
+    import ctypes as C
+    import models_lib as M
+    err = np.zeros(3)
+    assert M.lib().sfbx_test_ekf(err.ctypes.data_as(C.c_void_p)) == 0
+    assert err[0] < 1e-12 and err[1] < 1e-6 and err[2] < 1e-12, err
