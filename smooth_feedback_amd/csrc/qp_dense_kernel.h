@@ -18,7 +18,19 @@ struct DenseKernelParams {
   int scaling, polish;
 };
 
+// Batch-major device arrays of one call (include/sfb.h: sfb_qp_dense_solve_batch)
+struct QpBatch {
+  const double *P, *q, *A, *l, *u, *wx, *wy;
+  double *x, *y, *obj;
+  uint32_t *iter;
+  int32_t *code;
+};
+
 size_t qp_dense_lds_bytes(int n, int m);
+size_t qp_dense4_lds_bytes(int n, int m);
+
+// k = n+m <= 32: four QPs per wavefront, persistent grid with a device-side queue (qp_dense4.hip)
+hipError_t qp_dense4_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream);
 
 hipError_t qp_dense_launch(const DenseKernelParams &kp, int64_t batch, const double *P, const double *q,
                            const double *A, const double *l, const double *u, const double *wx, const double *wy,
