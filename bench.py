@@ -234,6 +234,30 @@ class EKFWorkload:
 WORKLOADS = {"mpc": MPCWorkload, "qp_dense": DenseQPWorkload, "ekf": EKFWorkload}
 
 
+# FETCH_SIZE on gfx950 reports 1/2 of the bytes of 16-byte-per-lane coalesced reads (MI355X_MICROARCH.md,
+# HBM section); for the 8-byte-per-lane reads of the dense kernel the factor was calibrated on its exactly
+# known read volume (profiles/README.md).  WRITE_SIZE matched the known write volume of the EKF kernel.
+FETCH_CORRECTION = {"mpc": 2.0, "ekf": 2.0, "qp_dense": 1.0 / 0.58}
+
+
+def pmc_traffic(workload, workload_name):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1_<workload>/summary.json,
+    written by scripts/profile_all.sh + scripts/summarize_profiles.py for this very bench command), or None
+    when there is no summary for this workload configuration."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_%s" % workload, "summary.json")
+    try:
+        with open(path) as f:
+            s = json.load(f)
+        if s["bench_line_under_profiler"]["config"]["workload"] != workload_name:
+            return None, None
+        rd = s["FETCH_SIZE"]["mean_per_dispatch_KB"] * 1024.0 * FETCH_CORRECTION[workload]
+        wr = s["WRITE_SIZE"]["mean_per_dispatch_KB"] * 1024.0
+        return rd + wr, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x%.2f, %s" % (
+            FETCH_CORRECTION[workload], os.path.relpath(path, os.path.dirname(os.path.abspath(__file__))))
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,7 +290,7 @@ def main():
     wl = WORKLOADS[args.workload](sfb, rank, device, **kw)
     stream = torch.cuda.current_stream()
     gathered = None
-    kernel_name = {"mpc": "qp_sparse_kernel", "qp_dense": "qp_dense_kernel", "ekf": "ekf_kernel"}[args.workload]
+    kernel_name = {"mpc": "qp_sparse_kernel", "qp_dense": "qp_dense4_kernel", "ekf": "ekf_kernel"}[args.workload]
     if world > 1:
         gathered = [torch.empty_like(wl.small_outputs()) for _ in range(world)]
 
@@ -331,6 +355,10 @@ def main():
                                  "re-stream the LDL' factor from HBM (sparse kernel) or are FP64-issue bound (dense "
                                  "kernel), so the I/O-only fraction is small by construction -- see DESIGN.md"},
         }
+        if world == 1:
+            rec["roofline"]["traffic"], src = pmc_traffic(args.workload, wl.name)
+            if src:
+                rec["roofline"]["traffic_source"] = src
         if hasattr(wl, "extra"):
             rec["workload_stats"] = wl.extra()
             ws = rec["workload_stats"]
