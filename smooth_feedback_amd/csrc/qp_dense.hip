@@ -282,7 +282,8 @@ hipError_t qp_dense_launch(const DenseKernelParams &kp, int64_t batch, const dou
                            double *x, double *y, double *obj, uint32_t *iter, int32_t *code, hipStream_t stream)
 {
   const int k        = kp.n + kp.m;
-  static const int dense4 = getenv("SFB_QP_DENSE4") ? atoi(getenv("SFB_QP_DENSE4")) : 1;  // A/B only
+  const char *env4 = getenv("SFB_QP_DENSE4");  // A/B and tests: 0 selects the one-QP-per-wave kernels
+  const int dense4 = env4 ? atoi(env4) : 1;
   if (k <= 32 && dense4) {
     const QpBatch g{P, q, A, l, u, wx, wy, x, y, obj, iter, code};
     return qp_dense4_launch(kp, batch, g, stream);

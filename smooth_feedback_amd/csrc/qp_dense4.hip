@@ -661,7 +661,11 @@ hipError_t qp_dense4_launch(const DenseKernelParams &kp, int64_t batch, const Qp
   static const int occ_cap = getenv("SFB_QP4_WAVES_PER_CU") ? atoi(getenv("SFB_QP4_WAVES_PER_CU")) : 8;  // A/B only
   if (per_cu > occ_cap) per_cu = occ_cap;  // 2 waves per SIMD (VGPR budget of the kernel)
   if (per_cu < 1) per_cu = 1;
-  const int64_t max_waves = (int64_t)ncu * per_cu;
+  int64_t max_waves = (int64_t)ncu * per_cu;
+  if (const char *cap = getenv("SFB_QP4_MAX_WAVES")) {  // tests: small grids exercise the slot refill path
+    const int64_t c = atoll(cap);
+    if (c >= 1 && c < max_waves) max_waves = c;
+  }
   const dim3 grid((unsigned)(batch < max_waves ? batch : max_waves)), block(kWave);
   if (k <= 16) {
     hipLaunchKernelGGL((qp_dense4_kernel<1>), grid, block, lds, stream, kp, g, queue, (unsigned)batch);

@@ -199,3 +199,75 @@ def test_full_size_batch_properties(sfb):
     assert np.abs(res).max() <= 1e-4                                # stationarity
     assert y.min() >= -1e-3                                         # dual sign (polished duals: approx.)
     assert np.abs(y * (Ax - u[opt])).max() <= 1e-4                  # complementarity
+
+
+@pytest.fixture
+def env_knob():
+    """Set kernel-selection environment knobs of libsfb.so (read at every launch) for one test."""
+    saved = {}
+
+    def set_(**kw):
+        for k, v in kw.items():
+            saved.setdefault(k, os.environ.get(k))
+            os.environ[k] = str(v)
+
+    yield set_
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+@pytest.mark.parametrize("waves", [1, 3])
+@pytest.mark.parametrize("n,m", [(10, 20), (4, 9)])
+def test_four_per_wave_slot_refill(sfb, oracle, env_knob, waves, n, m):
+    """qp_dense4_kernel with a grid of 1 / 3 persistent waves: every slot is refilled many times from the
+    device-side queue, at different iterations (the queue hands out problems of 2 ... max_iter iterations),
+    for ragged batch sizes, aligned and unaligned max_iter and several stop_check_iter."""
+    env_knob(SFB_QP4_MAX_WAVES=waves)
+    for B, prm in ((1, sfb.QPSolverParams(max_iter=500)),
+                   (2, sfb.QPSolverParams(max_iter=26)),
+                   (3, sfb.QPSolverParams(max_iter=27)),
+                   (5, sfb.QPSolverParams(max_iter=51, stop_check_iter=2)),
+                   (61, sfb.QPSolverParams(max_iter=700)),
+                   (97, sfb.QPSolverParams(max_iter=333, stop_check_iter=3, polish=False)),
+                   (64, sfb.QPSolverParams(max_iter=40, stop_check_iter=1)),
+                   (50, sfb.QPSolverParams(max_iter=300, stop_check_iter=1000)),
+                   (131, sfb.QPSolverParams(eps_abs=1e-6, eps_rel=1e-6, max_iter=1500, scaling=False))):
+        P, q, A, l, u = sfb.random_qp_batch(100 + B, B, m, n, 0.8)
+        l[::7] = -np.inf                       # one-sided rows
+        l[3::11] = u[3::11]                    # equality rows
+        if B > 10:
+            l[5], u[5] = 1.0, -1.0             # u < l: PrimalInfeasible before the first iteration (:361-364)
+        r = sfb.solve_qp_batch_host(P, q, A, l, u, prm)
+        ref = oracle.qp_dense_solve_batch(P, q, A, l, u, params=_oracle_params(oracle, prm), nthreads=8)
+        _compare(r, ref)
+    # warm start through the refill path
+    B = 77
+    P, q, A, l, u = sfb.random_qp_batch(9, B, m, n, 1.0)
+    prm = sfb.QPSolverParams(max_iter=2000)
+    op = _oracle_params(oracle, prm)
+    ref = oracle.qp_dense_solve_batch(P, q, A, l, u, params=op, nthreads=8)
+    wx = np.where(np.isfinite(ref["x"]), ref["x"], 0.0)
+    wy = np.where(np.isfinite(ref["y"]), ref["y"], 0.0)
+    r = sfb.solve_qp_batch_host(P, q + 0.02, A, l, u, prm, warm_x=wx, warm_y=wy)
+    ref2 = oracle.qp_dense_solve_batch(P, q + 0.02, A, l, u, params=op, warm_x=wx, warm_y=wy, nthreads=8)
+    _compare(r, ref2)
+
+
+@pytest.mark.parametrize("n,m", [(10, 20), (5, 11), (16, 16)])
+def test_one_per_wave_kernels_still_agree(sfb, oracle, env_knob, n, m):
+    """k <= 32 through the one-QP-per-wavefront kernels (SFB_QP_DENSE4=0): same bits as the four-per-wave
+    kernel and the oracle."""
+    B = 300
+    P, q, A, l, u = sfb.random_qp_batch(21, B, m, n, 0.9)
+    prm = sfb.QPSolverParams(max_iter=3000)
+    r4 = sfb.solve_qp_batch_host(P, q, A, l, u, prm)
+    env_knob(SFB_QP_DENSE4=0)
+    r1 = sfb.solve_qp_batch_host(P, q, A, l, u, prm)
+    ref = oracle.qp_dense_solve_batch(P, q, A, l, u, params=_oracle_params(oracle, prm), nthreads=8)
+    _compare(r1, ref)
+    _compare(r4, ref)
+    assert np.array_equal(r1.primal, r4.primal, equal_nan=True) and np.array_equal(r1.dual, r4.dual, equal_nan=True)
+    assert np.array_equal(r1.iter, r4.iter) and np.array_equal(r1.code, r4.code)
