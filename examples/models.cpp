@@ -8,6 +8,7 @@
 #include <thread>
 #include <vector>
 
+#include <smooth_feedback_amd/asif.hpp>
 #include <smooth_feedback_amd/ekf.hpp>
 #include <smooth_feedback_amd/mpc.hpp>
 
@@ -378,3 +379,148 @@ int sfbx_mesh(int n_ivals, int K, double * nodes, double * weights, double * Dus
 }
 
 }  // extern "C"
+
+// ---- ASIF ----
+namespace {
+// safe set and backup controller of examples/mpc_asif_vehicle.cpp:95-104: stay 0.7 away from (0, -2.3); the
+// direction is evaluated at the query point and treated as constant by the differentiation, as in the example
+Vec<1> vehicle_h(double, const X6 & x)
+{
+  const double dx = x.part<0>().x - 0.0, dy = x.part<0>().y - (-2.3);
+  const double nrm = std::sqrt(dx * dx + dy * dy);
+  return {(dx * dx + dy * dy) / nrm - 0.7};
+}
+U2 vehicle_bu(double, const X6 & x)
+{
+  U2 u;
+  u.v = {0.2 * x.part<1>().v[0], -0.5};
+  return u;
+}
+ASIFilterParams<U2> vehicle_asif_params(int K)
+{
+  ASIFilterParams<U2> p;
+  p.T        = 2.5;
+  p.nh       = 1;
+  p.u_weight = {20.0, 1.0};
+  p.ulim.rows = 2;
+  p.ulim.A    = {1, 0, 0, 1};
+  p.ulim.l    = {-0.2, -0.5};
+  p.ulim.u    = {0.5, 0.5};
+  p.asif.K          = (size_t)K;
+  p.asif.alpha      = 5;
+  p.asif.dt         = 0.01;
+  p.asif.relax_cost = 100;
+  p.qp.polish       = false;
+  return p;
+}
+void copy_qp(const QuadraticProgram & qp, double * P, double * q, double * A, double * l, double * u)
+{
+  std::copy(qp.P.begin(), qp.P.end(), P);
+  std::copy(qp.q.begin(), qp.q.end(), q);
+  std::copy(qp.A.begin(), qp.A.end(), A);
+  std::copy(qp.l.begin(), qp.l.end(), l);
+  std::copy(qp.u.begin(), qp.u.end(), u);
+}
+}  // namespace
+
+int sfbx_asif_basic_qp(const double * x0, const double * udes, double * P, double * q, double * A, double * l, double * u)
+{
+  ASIFProblem<SE2, U2> pbm;
+  pbm.x0      = SE2::FromAngle(x0[0], x0[1], x0[2]);
+  pbm.u_des.v = {udes[0], udes[1]};
+  pbm.ulim.rows = 2;
+  pbm.ulim.A    = {1, 0, 0, 1};
+  pbm.ulim.l    = {-1, -1};
+  pbm.ulim.u    = {1, 1};
+  ASIFtoQPParams prm;
+  prm.K = 3;
+  const auto qp = asif_to_qp<SE2, U2>(
+    pbm, prm, [](const SE2 &, const U2 & uu) { return Vec<3>{uu.v[0], 0.0, uu.v[1]}; },
+    [](double, const SE2 & g) { return Vec<2>{g.x, g.y}; },
+    [](double, const SE2 &) { U2 b; b.v = {-0.1, 1.0}; return b; });
+  if (qp.n != 3 || qp.m != 9) return 1;
+  copy_qp(qp, P, q, A, l, u);
+  return 0;
+}
+
+int sfbx_test_asif(int which, double * u_out, int32_t * code, uint32_t * iter, int32_t * dims, double * P, double * q,
+                   double * A, double * l, double * u, double * x, double * y)
+{
+  try {
+    auto report = [&](const QuadraticProgram & qp, const QPSolution & sol, QPSolutionStatus c) {
+      dims[0] = qp.n; dims[1] = qp.m;
+      copy_qp(qp, P, q, A, l, u);
+      std::copy(sol.primal.begin(), sol.primal.end(), x);
+      std::copy(sol.dual.begin(), sol.dual.end(), y);
+      *code = (int32_t)c;
+      *iter = sol.iter;
+    };
+    if (which == 0) {
+      using U3 = Rn<3>;
+      auto f   = [](const SO3 &, const U3 & uu) { return uu.v; };
+      ASIFilterParams<U3> prm;
+      prm.nh     = 3;
+      prm.asif.K = 100;
+      ASIFilter<SO3, U3, decltype(f)> asif(f, prm);
+      const SO3 g = SO3::exp({0.3, -0.5, 0.8});
+      const auto [ua, c] = asif(g, U3{}, [](double, const SO3 & gg) { return gg.log(); },
+                                [](double, const SO3 &) { U3 b; b.v = {1, 1, 1}; return b; });
+      for (int i = 0; i < 3; ++i) u_out[i] = ua.v[i];
+      report(asif.qp(), asif.last_solution(), c);
+    } else {
+      VehicleDyn6 f;
+      ASIFilter<X6, U2, VehicleDyn6> asif(f, vehicle_asif_params(which == 1 ? 200 : 10));
+      X6 xx = xdes6(3.7);
+      xx.part<0>() = SE2::FromAngle(-2.0, 0.9, -1.9);  // heading towards the obstacle, 1 m away
+      U2 ud; ud.v = {0.4, 0.1};
+      const auto [ua, c] = asif(xx, ud, vehicle_h, vehicle_bu);
+      u_out[0] = ua.v[0]; u_out[1] = ua.v[1]; u_out[2] = 0.0;
+      report(asif.qp(), asif.last_solution(), c);
+    }
+    return 0;
+  } catch (const std::exception &) {
+    return 1;
+  }
+}
+
+int sfbx_asif_swarm_step(int64_t batch, uint64_t seed, int K, int ticks, double * u_out, int32_t * codes, uint32_t * iters,
+                         double * P, double * q, double * A, double * l, double * u, double * x, double * y, double * wx,
+                         double * wy)
+{
+  try {
+    const int n = 3, m = K + 3;
+    ASIFSwarm<X6, U2, VehicleDyn6> swarm(VehicleDyn6{}, (size_t)batch, vehicle_asif_params(K));
+    std::vector<X6> g((size_t)batch);
+    std::vector<U2> ud((size_t)batch);
+    std::vector<double> tb((size_t)batch);
+    for (int64_t b = 0; b < batch; ++b) {
+      tb[b] = 0.025 * double(b % 400);
+      g[b]  = perturbed(xdes6(tb[b]), seed + (uint64_t)b);
+      std::mt19937_64 rng(seed + 7919u * (uint64_t)b);
+      std::uniform_real_distribution<double> d(-0.5, 0.5);
+      ud[b].v = {d(rng), d(rng)};
+    }
+    auto hb  = [](size_t, double t, const X6 & xx) { return vehicle_h(t, xx); };
+    auto bub = [](size_t, double t, const X6 & xx) { return vehicle_bu(t, xx); };
+    std::vector<U2> out;
+    for (int tick = 0; tick < ticks; ++tick) {
+      if (tick > 0) {  // move every vehicle 25 ms along its filtered input (explicit Euler)
+        for (int64_t b = 0; b < batch; ++b) {
+          auto dx = VehicleDyn6{}(g[b], out[b]);
+          for (auto & v : dx) v *= 0.025;
+          g[b] = rplus(g[b], dx);
+        }
+      }
+      if (tick == ticks - 1) swarm.copy_warm_start(wx, wy);
+      out = swarm(g, ud, hb, bub);
+    }
+    for (int64_t b = 0; b < batch; ++b) { u_out[2 * b] = out[b].v[0]; u_out[2 * b + 1] = out[b].v[1]; }
+    std::copy(swarm.codes().begin(), swarm.codes().end(), codes);
+    std::copy(swarm.iterations().begin(), swarm.iterations().end(), iters);
+    swarm.copy_problem(P, q, A, l, u, x, y);
+    (void)n; (void)m;
+    return 0;
+  } catch (const std::exception &) {
+    return 1;
+  }
+}

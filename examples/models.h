@@ -32,6 +32,22 @@ double sfbx_lie_selftest(void);
  * (tests/test_ekf.cpp:155-180), UpdateLinear (:50-103, R^3 / Ny 3) and an SE2 predict+update smoke.
  * Returns 0 and writes max errors: err[0] time-cut, err[1] linear update state, err[2] linear update cov. Needs a GPU. */
 int sfbx_test_ekf(double *err);
+/* asif_to_qp() (include/smooth_feedback_amd/asif.hpp) for the case of tests/test_asif.cpp:37-95: X = SE2, f = (u0, 0, u1),
+ * h = position (nh = 2), bu = (-0.1, 1), K = 3, input box [-1,1]^2 around c = 0, T = 1, alpha = 1, dt = 0.1.
+ * x0 = (angle, px, py).  Out, column-major: P[9] q[3] A[9*3] l[9] u[9].  Host only (no GPU). */
+int sfbx_asif_basic_qp(const double *x0, const double *udes, double *P, double *q, double *A, double *l, double *u);
+/* ASIFilter on the GPU.  which = 0: the SO3 filter of tests/test_asif.cpp:103-131 (K = 100, nh = 3: n = 4, m = 301,
+ * sparse-kernel path); which = 1: the vehicle filter of examples/mpc_asif_vehicle.cpp:95-129 (K = 200: n = 3, m = 203,
+ * polish off); which = 2: the same vehicle with the default K = 10 (n = 3, m = 13: dense-kernel path).
+ * Out: u[3], code, iter, and the QP that was solved (sized by dims[0] = n, dims[1] = m) with its primal/dual. */
+int sfbx_test_asif(int which, double *u_out, int32_t *code, uint32_t *iter, int32_t *dims, double *P, double *q,
+                   double *A, double *l, double *u, double *x, double *y);
+/* ASIFSwarm: `batch` vehicles (state = xdes(t_b) (+) xi_b as in sfbx_mpc_assemble_batch, u_des ~ U(-0.5,0.5)^2),
+ * K constraint instances, `ticks` consecutive calls (warm start from tick 2).  Out for the LAST tick: filtered
+ * u [batch][2], codes, iters, the QPs [batch][...] (n = 3, m = K + 3) and their primal/dual solutions. */
+int sfbx_asif_swarm_step(int64_t batch, uint64_t seed, int K, int ticks, double *u_out, int32_t *codes, uint32_t *iters,
+                         double *P, double *q, double *A, double *l, double *u, double *x, double *y, double *wx,
+                         double *wy);
 /* mesh: nodes (N+1), weights (N+1), Dus ((K+1)*K col-major) for `n` intervals of K points */
 int sfbx_mesh(int n_ivals, int K, double *nodes, double *weights, double *Dus);
 

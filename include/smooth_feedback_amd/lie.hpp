@@ -3,7 +3,7 @@
 // The reference gets this from pettni/smooth (absent here): right-invariant conventions
 //   rplus(g, a) = g * exp(a),  rminus(a, b) = log(b^-1 * a),  body velocities d^r x_t = f
 // (reference README.md:17-18, mpc.hpp:498,505,518, ekf.hpp:137).  Only what the hot path's callers
-// need is restated: R^n, SE(2) and Bundle<...> with exp/log, ad and dr_expinv (the inverse right
+// need is restated: R^n, SE(2), SO(3) and Bundle<...> with exp/log, ad and dr_expinv (the inverse right
 // Jacobian used by MPCCE::jacobian, mpc.hpp:293-301).  Semantics as summarised in SURVEY.md section
 // 8 ("smooth semantics the host side must restate"); parity with the real library is pinned only
 // by group identities (tests), not by golden values.
@@ -145,6 +145,70 @@ struct SE2 {
   {
     const double th = a[2], th2 = th * th;
     const double k  = (th2 < 1e-8) ? (1.0 / 12.0 + th2 / 720.0) : (1.0 / th2 - (1.0 + std::cos(th)) / (2.0 * th * std::sin(th)));
+    const Mat<3, 3> A = ad(a);
+    return Mat<3, 3>::Identity() + 0.5 * A + k * (A * A);
+  }
+};
+
+// ---- SO(3): unit quaternion (w, x, y, z), tangent = body angular velocity ----
+struct SO3 {
+  static constexpr int Dof           = 3;
+  static constexpr bool IsCommutative = false;
+  using Tangent                      = Vec<3>;
+  double w = 1, x = 0, y = 0, z = 0;
+
+  static SO3 Identity() { return SO3{}; }
+  static SO3 exp(const Tangent &a)
+  {
+    const double th2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+    double A, B;  // A = sin(th/2)/th, B = cos(th/2)
+    if (th2 < 1e-10) {
+      A = 0.5 - th2 / 48.0;
+      B = 1.0 - th2 / 8.0;
+    } else {
+      const double th = std::sqrt(th2);
+      A = std::sin(0.5 * th) / th;
+      B = std::cos(0.5 * th);
+    }
+    return SO3{B, A * a[0], A * a[1], A * a[2]};
+  }
+  Tangent log() const
+  {
+    const double s2 = x * x + y * y + z * z;
+    double k;  // angle / sin(angle/2), with the shortest rotation (w >= 0 branch)
+    const double ww = (w < 0) ? -w : w, sgn = (w < 0) ? -1.0 : 1.0;
+    if (s2 < 1e-10) {
+      k = 2.0 / ww - 2.0 / 3.0 * s2 / (ww * ww * ww);
+    } else {
+      const double sn = std::sqrt(s2);
+      k               = 2.0 * std::atan2(sn, ww) / sn;
+    }
+    return {sgn * k * x, sgn * k * y, sgn * k * z};
+  }
+  SO3 inverse() const { return SO3{w, -x, -y, -z}; }
+  friend SO3 operator*(const SO3 &a, const SO3 &b)
+  {
+    SO3 r{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+          a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+    const double nrm = std::sqrt(r.w * r.w + r.x * r.x + r.y * r.y + r.z * r.z);
+    r.w /= nrm; r.x /= nrm; r.y /= nrm; r.z /= nrm;
+    return r;
+  }
+  friend SO3 rplus(const SO3 &g, const Tangent &a) { return g * exp(a); }
+  friend Tangent rminus(const SO3 &a, const SO3 &b) { return (b.inverse() * a).log(); }
+
+  static Mat<3, 3> ad(const Tangent &a)  // = hat(a)
+  {
+    Mat<3, 3> m{};
+    m(0, 1) = -a[2]; m(0, 2) = a[1];
+    m(1, 0) = a[2];  m(1, 2) = -a[0];
+    m(2, 0) = -a[1]; m(2, 1) = a[0];
+    return m;
+  }
+  static Mat<3, 3> dr_expinv(const Tangent &a)
+  {
+    const double th2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], th = std::sqrt(th2);
+    const double k   = (th2 < 1e-8) ? (1.0 / 12.0 + th2 / 720.0) : (1.0 / th2 - (1.0 + std::cos(th)) / (2.0 * th * std::sin(th)));
     const Mat<3, 3> A = ad(a);
     return Mat<3, 3>::Identity() + 0.5 * A + k * (A * A);
   }

@@ -60,3 +60,38 @@ def mpc_stage(variant, K):
     st = np.zeros(d["n"] + d["m"], np.int32)
     assert lib().sfbx_mpc_stage(variant, K, _p(st)) == 0
     return st
+
+
+def asif_basic_qp(x0, udes):
+    """asif_to_qp of tests/test_asif.cpp:37-95 (host only): dict P (3,3), q, A (9,3), l, u."""
+    x0 = np.asarray(x0, dtype=np.float64); udes = np.asarray(udes, dtype=np.float64)
+    P = np.zeros(9); q = np.zeros(3); A = np.zeros(27); l = np.zeros(9); u = np.zeros(9)
+    assert lib().sfbx_asif_basic_qp(_p(x0), _p(udes), _p(P), _p(q), _p(A), _p(l), _p(u)) == 0
+    return dict(P=P.reshape(3, 3).T, q=q, A=A.reshape(3, 9).T, l=l, u=u)
+
+
+def test_asif(which):
+    """ASIFilter on the GPU (see models.h): dict u, code, iter, n, m and the QP (flat column-major) + x, y."""
+    nmax, mmax = 8, 512
+    u_out = np.zeros(3); code = C.c_int32(-1); it = C.c_uint32(0); dims = np.zeros(2, np.int32)
+    P = np.zeros(nmax * nmax); q = np.zeros(nmax); A = np.zeros(mmax * nmax); l = np.zeros(mmax); u = np.zeros(mmax)
+    x = np.zeros(nmax); y = np.zeros(mmax)
+    rc = lib().sfbx_test_asif(which, _p(u_out), C.byref(code), C.byref(it), _p(dims), _p(P), _p(q), _p(A), _p(l), _p(u),
+                              _p(x), _p(y))
+    assert rc == 0
+    n, m = int(dims[0]), int(dims[1])
+    return dict(u=u_out, code=code.value, iter=it.value, n=n, m=m, P=P[:n * n].copy(), q=q[:n].copy(),
+                A=A[:m * n].copy(), l=l[:m].copy(), ub=u[:m].copy(), x=x[:n].copy(), y=y[:m].copy())
+
+
+def asif_swarm_step(batch, K, ticks=1, seed=0):
+    n, m = 3, K + 3
+    out = dict(u=np.zeros((batch, 2)), code=np.zeros(batch, np.int32), iter=np.zeros(batch, np.uint32),
+               P=np.zeros((batch, n * n)), q=np.zeros((batch, n)), A=np.zeros((batch, m * n)), l=np.zeros((batch, m)),
+               ub=np.zeros((batch, m)), x=np.zeros((batch, n)), y=np.zeros((batch, m)), wx=np.zeros((batch, n)),
+               wy=np.zeros((batch, m)))
+    rc = lib().sfbx_asif_swarm_step(C.c_int64(batch), C.c_uint64(seed), K, ticks, _p(out["u"]), _p(out["code"]),
+                                    _p(out["iter"]), _p(out["P"]), _p(out["q"]), _p(out["A"]), _p(out["l"]), _p(out["ub"]),
+                                    _p(out["x"]), _p(out["y"]), _p(out["wx"]), _p(out["wy"]))
+    assert rc == 0
+    return out

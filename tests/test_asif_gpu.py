@@ -1,0 +1,68 @@
+"""ASI filter front (include/smooth_feedback_amd/asif.hpp) on the GPU: the reference's own filter test, and the QPs
+the front hands to libsfb.so re-solved by the dense CPU oracle.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+import models_lib as M
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_solve(oracle, r, batch=False, polish=False, warm=None):
+    prm = oracle.default_params(polish=int(polish))
+    two = (lambda a: a) if batch else (lambda a: a[None, :])
+    kw = {}
+    if warm is not None:
+        kw = dict(warm_x=two(warm[0]), warm_y=two(warm[1]))
+    return oracle.qp_dense_solve_batch(two(r["P"]), two(r["q"]), two(r["A"]), two(r["l"]), two(r["ub"]), params=prm,
+                                       nthreads=8, **kw)
+
+
+def test_filter_so3_reference_case():
+    """tests/test_asif.cpp:103-131: K = 100, nh = 3 (n = 4, m = 301) -> Optimal."""
+    r = M.test_asif(0)
+    assert (r["n"], r["m"]) == (4, 301)
+    assert r["code"] == 0
+    assert np.all(np.isfinite(r["u"]))
+
+
+def test_vehicle_default_size_is_bit_identical_to_the_dense_oracle(oracle):
+    """K = 10: n = 3, m = 13 -> the dense kernel; same bits as the oracle on the QP the front assembled."""
+    r = M.test_asif(2)
+    assert (r["n"], r["m"]) == (3, 13)
+    ref = _oracle_solve(oracle, r)
+    assert r["code"] == ref["code"][0] == 0
+    assert r["iter"] == ref["iter"][0]
+    assert np.array_equal(r["x"], ref["x"][0]) and np.array_equal(r["y"], ref["y"][0])
+    # the filter must brake: the nominal input drives towards the obstacle
+    assert r["u"][0] < 0.4 - 1e-3 and -0.2 - 1e-6 <= r["u"][0] and abs(r["u"][1]) <= 0.5 + 1e-6
+
+
+def test_vehicle_example_size_matches_the_dense_oracle(oracle):
+    """examples/mpc_asif_vehicle.cpp:105-129: K = 200 (n = 3, m = 203, polish off) goes through the sparse kernel
+    with a full pattern: a different (non-pivoted) factorisation order than the dense solver, hence tolerance."""
+    r = M.test_asif(1)
+    assert (r["n"], r["m"]) == (3, 203)
+    ref = _oracle_solve(oracle, r)
+    assert r["code"] == ref["code"][0] == 0
+    assert abs(int(r["iter"]) - int(ref["iter"][0])) <= 25
+    assert np.abs(r["x"] - ref["x"][0]).max() <= 2e-3 * (1 + np.abs(ref["x"][0]).max())   # eps_abs = eps_rel = 1e-3, no polish
+    if r["iter"] == ref["iter"][0]:
+        assert np.abs(r["x"] - ref["x"][0]).max() <= 1e-8
+
+
+@pytest.mark.parametrize("ticks", [1, 3])
+def test_swarm_is_bit_identical_to_the_dense_oracle(oracle, ticks):
+    """1 000 vehicles, K = 10 (k = 16, four QPs per wavefront), cold and warm-started ticks."""
+    B = 1000
+    r = M.asif_swarm_step(B, 10, ticks=ticks, seed=5)
+    ref = _oracle_solve(oracle, r, batch=True, warm=(r["wx"], r["wy"]))
+    assert np.array_equal(r["code"], ref["code"])
+    assert np.array_equal(r["iter"], ref["iter"])
+    assert np.array_equal(r["x"], ref["x"]) and np.array_equal(r["y"], ref["y"])
+    assert (r["code"] == 0).mean() > 0.95
+    ok = r["code"] == 0                   # input box of the example, to the ADMM tolerance (polish is off)
+    assert np.all(r["u"][ok, 0] <= 0.5 + 1e-2) and np.all(r["u"][ok, 0] >= -0.2 - 1e-2)
+    assert np.all(np.abs(r["u"][ok, 1]) <= 0.5 + 1e-2)
+    if ticks > 1:
+        assert np.abs(r["wx"]).max() > 0      # the last tick really was warm-started

@@ -1,0 +1,90 @@
+"""Host side of the ASI filter (include/smooth_feedback_amd/asif.hpp) against an independent numpy restatement of
+asif_to_qp_update (reference asif_func.hpp:104-199) with ANALYTIC derivatives, on the case of the reference's
+own test (tests/test_asif.cpp:37-95), plus that test's structural assertions.  No GPU needed."""
+import numpy as np
+import pytest
+
+import models_lib as M
+
+
+def se2_exp(a):
+    vx, vy, w = a
+    if abs(w) < 1e-9:
+        A, B = 1.0 - w * w / 6, w / 2
+    else:
+        A, B = np.sin(w) / w, (1 - np.cos(w)) / w
+    return np.array([w, A * vx - B * vy, B * vx + A * vy])  # (angle, x, y)
+
+
+def se2_mul(g, h):
+    th, x, y = g
+    c, s = np.cos(th), np.sin(th)
+    return np.array([th + h[0], x + c * h[1] - s * h[2], y + s * h[1] + c * h[2]])
+
+
+def se2_ad(a):
+    vx, vy, w = a
+    return np.array([[0, -w, vy], [w, 0, -vx], [0, 0, 0.0]])
+
+
+def restate_basic(x0, udes, K=3, T=1.0, alpha=1.0, dtmax=0.1, relax=100.0):
+    """asif_func.hpp:139-198 for f = (u0, 0, u1), h = position, bu = (-0.1, 1), input box [-1, 1]^2."""
+    nu, nh = 2, 2
+    Mrows = K * nh + 2 + 1
+    A = np.zeros((Mrows, nu + 1)); l = np.zeros(Mrows); u = np.zeros(Mrows)
+    tau = T / K
+    dt = min(dtmax, tau)
+    t, x, S = 0.0, np.array(x0, dtype=float), np.eye(3)
+    f0 = np.array([udes[0], 0.0, udes[1]])
+    df0du = np.array([[1.0, 0], [0, 0], [0, 1.0]])
+    fcl = np.array([-0.1, 0.0, 1.0])
+    for k in range(K):
+        c, s = np.cos(x[0]), np.sin(x[0])
+        hval = x[1:3]
+        dh_dx = np.array([[c, -s, 0.0], [s, c, 0.0]])     # d^r position / dx
+        dh_dx0 = dh_dx @ S
+        A[k * nh:(k + 1) * nh, :nu] = dh_dx0 @ df0du
+        l[k * nh:(k + 1) * nh] = -0.0 - alpha * hval - dh_dx0 @ f0
+        u[k * nh:(k + 1) * nh] = np.inf
+        dt_act = min(dt, tau * (k + 1) - t)                # fixed per interval (:175)
+        while t < tau * (k + 1):
+            x = se2_mul(x, se2_exp(dt_act * fcl))          # state first ...
+            S = S + dt_act * ((-se2_ad(fcl)) @ S)          # ... then the sensitivity (bu, f do not depend on x)
+            t += dt_act
+    A[:K * nh, nu] = 1.0
+    A[K * nh:K * nh + 2, :nu] = np.eye(2)
+    l[K * nh:K * nh + 2] = -1.0 - udes
+    u[K * nh:K * nh + 2] = 1.0 - udes
+    A[K * nh + 2, nu] = 1.0
+    l[K * nh + 2], u[K * nh + 2] = 0.0, np.inf
+    P = np.diag([1.0, 1.0, relax])
+    return dict(P=P, q=np.zeros(3), A=A, l=l, u=u)
+
+
+@pytest.mark.parametrize("x0", [(0.3, 0.5, -0.2), (-2.1, 1.5, 0.7), (0.0, 0.0, 0.0)])
+def test_asif_to_qp_matches_numpy_restatement(x0):
+    udes = np.array([0.5, 0.5])
+    got = M.asif_basic_qp(x0, udes)
+    ref = restate_basic(x0, udes)
+    for k in ("P", "q", "A", "l"):
+        assert np.allclose(got[k], ref[k], rtol=0, atol=2e-6), (k, np.abs(got[k] - ref[k]).max())
+    assert np.array_equal(np.isinf(got["u"]), np.isinf(ref["u"]))
+    fin = np.isfinite(ref["u"])
+    assert np.allclose(got["u"][fin], ref["u"][fin], atol=2e-6)
+
+
+def test_structure_asserted_by_the_reference_test():
+    """tests/test_asif.cpp:69-94"""
+    K, Nu, Nh, niq = 3, 2, 2, 2
+    udes = np.array([0.5, 0.5])
+    qp = M.asif_basic_qp((0.9, -0.4, 1.3), udes)
+    assert qp["P"].shape == (Nu + 1, Nu + 1) and qp["q"].shape == (Nu + 1,)
+    assert qp["A"].shape == (Nh * K + niq + 1, Nu + 1)
+    A = qp["A"]
+    assert np.allclose(A[:Nh * K, Nu], 1.0)                      # A = [BAR 1; A_u 0; 0 1]
+    assert np.allclose(A[Nh * K:Nh * K + niq, :Nu], np.eye(2))
+    assert np.allclose(A[Nh * K + niq], [0, 0, 1])
+    assert np.all(qp["u"][:Nh * K] == np.inf)
+    assert np.allclose(qp["l"][Nh * K:Nh * K + niq], -1.0 - udes)
+    assert np.allclose(qp["u"][Nh * K:Nh * K + niq], 1.0 - udes)
+    assert qp["l"][Nh * K + niq] == 0 and qp["u"][Nh * K + niq] == np.inf
