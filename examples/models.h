@@ -1,4 +1,4 @@
-/* Example / test harness around the C++ host front (include/smooth_feedback_amd/*.hpp): concrete MPC
+/* Example / test harness around the C++ host front (the headers under include/smooth_feedback_amd): concrete MPC
  * models with a C interface so that Python tests and bench.py can drive the host-side assembly.
  * NOT part of the product C-ABI (that is include/sfb.h); built into libsfb_models.so. */
 #ifndef SFBX_MODELS_H
