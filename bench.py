@@ -288,13 +288,19 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # SFB_BENCH_SHARE_DEVICE=1 (test hook for 1-GPU boxes): all ranks use cuda:0 and rendezvous over gloo
+    share = os.environ.get("SFB_BENCH_SHARE_DEVICE") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)  # RCCL over xGMI
 
     import smooth_feedback_amd as sfb
 

@@ -1,0 +1,47 @@
+"""bench.py contract on a GPU box: one JSON line with the required keys (N = 1), and the N > 1 code path
+(barrier, gather of the small outputs, max-over-ranks timing) with two ranks sharing cuda:0 over gloo
+(SFB_BENCH_SHARE_DEVICE=1; the driver runs the real thing over RCCL on 8 GPUs)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_roofline_and_cpu_baseline():
+    out = subprocess.run([sys.executable, "bench.py", "--workload", "qp_dense", "--batch", "8192", "--steps", "2",
+                          "--warmup", "1"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert KEYS <= set(d) and {"cpu_baseline", "parity_vs_oracle"} <= set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f64" and d["value"] > 0
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"])
+    assert d["parity_vs_oracle"]["code_mismatches"] == 0 and d["parity_vs_oracle"]["iter_mismatches"] == 0
+    assert d["parity_vs_oracle"]["max_abs_dx"] <= 1e-8
+
+
+def test_two_ranks_code_path():
+    env = dict(os.environ, SFB_BENCH_SHARE_DEVICE="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2",
+                          "--workload", "qp_dense", "--batch", "4096", "--steps", "2", "--warmup", "1"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert KEYS <= set(d)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 2 * 4096 and d["config"]["per_gpu_batch"] == 4096
+    assert d["value"] > 0 and "cpu_baseline" not in d
