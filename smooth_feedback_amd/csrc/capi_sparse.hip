@@ -40,7 +40,7 @@ sfb_status plan_on_device(sfb_sparse_qp_plan *plan, const sfb::SparsePlanDev **o
   const std::vector<int32_t> *arrs[] = {&h.Pp, &h.Pi, &h.Pcol, &h.Ap, &h.Aj, &h.Arow, &h.Acp, &h.Aci, &h.Acpos,
                                         &h.Prp, &h.Prj, &h.Prpos, &h.Sp, &h.Sj, &h.Spos, &h.perm, &h.pinv,
                                         &h.Kp, &h.Ki, &h.Kkind, &h.Kidx, &h.Lp, &h.Li, &h.Rp, &h.Rk, &h.Rpos, &h.Rlen,
-                                        &h.fmap, &h.fidx, &h.bmap, &h.bidx, &h.Kmap, &h.rptr, &h.rtgt, &h.rab};
+                                        &h.fmap, &h.fidx, &h.bmap, &h.bidx, &h.Kmap, &h.rptr, &h.rtgt, &h.rab, &h.snptr, &h.poff, &h.pmap};
   constexpr int NA = sizeof(arrs) / sizeof(arrs[0]);
   size_t off[NA + 1];
   off[0] = 0;
@@ -60,8 +60,8 @@ sfb_status plan_on_device(sfb_sparse_qp_plan *plan, const sfb::SparsePlanDev **o
   const int32_t **ptrs[] = {&d.Pp, &d.Pi, &d.Pcol, &d.Ap, &d.Aj, &d.Arow, &d.Acp, &d.Aci, &d.Acpos,
                             &d.Prp, &d.Prj, &d.Prpos, &d.Sp, &d.Sj, &d.Spos, &d.perm, &d.pinv,
                             &d.Kp, &d.Ki, &d.Kkind, &d.Kidx, &d.Lp, &d.Li, &d.Rp, &d.Rk, &d.Rpos, &d.Rlen,
-                            &d.fmap, &d.fidx, &d.bmap, &d.bidx, &d.Kmap, &d.rptr, &d.rtgt, &d.rab};
-  d.funits = h.funits; d.bunits = h.bunits; d.rsteps = h.rsteps; d.maxcol = h.maxcol;
+                            &d.fmap, &d.fidx, &d.bmap, &d.bidx, &d.Kmap, &d.rptr, &d.rtgt, &d.rab, &d.snptr, &d.poff, &d.pmap};
+  d.funits = h.funits; d.bunits = h.bunits; d.rsteps = h.rsteps; d.maxcol = h.maxcol; d.nsn = h.nsn; d.lds_doubles = h.lds_doubles;
   for (int a = 0; a < NA; ++a) *ptrs[a] = dc.blob + off[a];
   auto ins = plan->per_device.emplace(devid, dc);
   *out     = &ins.first->second.dev;
@@ -83,7 +83,7 @@ sfb_status check_sparse_args(const sfb_sparse_qp_plan *plan, const sfb_qp_params
     return sfb::fail(SFB_ERR_UNSUPPORTED, "max_time is wall-clock and not supported on the device path; use max_iter");
   if (prm->max_iter > 0xFFFFFFFFll) return sfb::fail(SFB_ERR_INVALID_ARG, "max_iter exceeds uint32");
   if (batch > 0x7FFFFFFFll) return sfb::fail(SFB_ERR_UNSUPPORTED, "batch exceeds 2^31-1 per call");
-  if ((size_t)(std::max(plan->host.k + 2, 2 * plan->host.maxcol + 4)) * sizeof(double) > 150 * 1024)
+  if ((size_t)plan->host.lds_doubles * sizeof(double) > 150 * 1024)
     return sfb::fail(SFB_ERR_UNSUPPORTED, "n+m too large for the LDS-resident work vector (max 19200)");
   return SFB_OK;
 }

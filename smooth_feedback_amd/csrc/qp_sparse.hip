@@ -87,43 +87,76 @@ __device__ __forceinline__ double kkt_value(const SparsePlanDev &pl, const Item 
   return v;
 }
 
-// Numeric LDL' on the shared pattern, RIGHT-LOOKING over a static schedule (sparse_plan.h): the
-// accumulators [L values | D] live in the item's HBM workspace; when column kk is final (divide by
-// D(kk)), its entries and multipliers L(.,kk)*D(kk) are staged in LDS and every pair of its rows
-// updates one accumulator, 64 independent slots per step.  Each accumulator sees its sources in
-// ascending order, so the arithmetic equals the oracle's left-looking loop bit for bit, but a step is
-// ~15 instructions for 64 useful lanes instead of ~45 instructions for ~14.
-// t = LDS scratch (>= 2*(maxcol+1) doubles).  Returns 1 / 0 (zero pivot).
+// Numeric LDL' on the shared pattern, RIGHT-LOOKING and SUPERNODAL over a static schedule
+// (sparse_plan.h).  The accumulators [L values | D] live in the item's HBM workspace.  Per supernode
+// (columns j0 .. j0+w-1 with nested structure, R = w + |struct(last)| rows):
+//   1. its own accumulators (a dense w x R panel) are loaded into LDS;
+//   2. the panel is eliminated there column by column: divide by D, stage the entries L(.,j) and the
+//      multipliers L(.,j) D(j), update the later panel columns;
+//   3. every TRAILING accumulator (a pair of rows of struct(last)) receives the w updates of the
+//      supernode with ONE read-modify-write, 64 independent slots per step (schedule of column `last`).
+// Every accumulator still sees its sources in ascending column order, fma(-L(a,j), L(b,j) D(j), acc), so
+// the arithmetic equals the oracle's left-looking loop bit for bit; what changes is the HBM traffic:
+// the trailing accumulators are touched once per supernode instead of once per column (MPC pattern:
+// 270 k instead of 711 k read-modify-writes) and there are two memory round trips per supernode
+// instead of two per column.
+// t = LDS scratch of pl.lds_doubles doubles (the plan caps w so that 2 w R fits).  Returns 1 / 0 (zero pivot).
 template<int DEPTH>
 __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, const Ws &w, double *t, const int mode,
                                       const double c, const double sigma, const double delta, const int lane)
 {
-  const int k = pl.k, nnzL = pl.nnzL, mc = pl.maxcol;
-  double *ACC  = w.Lx;          // [0, nnzL): L entries, [nnzL, nnzL+k): D, [nnzL+k]: scratch
-  double *colv = t;             // L(r_e, kk)
-  double *wv   = t + (mc + 1);  // L(r_e, kk) * D(kk)
+  const int k = pl.k, nnzL = pl.nnzL;
+  double *ACC = w.Lx;  // [0, nnzL): L entries, [nnzL, nnzL+k): D, [nnzL+k]: scratch
   for (int p = lane; p < nnzL + k + 1; p += kWave) ACC[p] = 0.0;
-  if (lane == 0) {
-    colv[mc] = 0.0;  // entry used by padding slots
-    wv[mc]   = 0.0;
-  }
   wave_sync();
   for (int p = lane; p < pl.nnzK; p += kWave) ACC[pl.Kmap[p]] = kkt_value(pl, it, w, p, mode, c, sigma, delta);
   wave_sync();
-  for (int kk = 0; kk < k; ++kk) {
-    const int c0 = pl.Lp[kk], cnt = pl.Lp[kk + 1] - c0;
-    const double d = ACC[nnzL + kk];
-    if (lane == 0) w.Dinv[kk] = 1.0 / d;
-    if (d == 0.0) return 0;
-    for (int e = lane; e < cnt; e += kWave) {
-      const double v = ACC[c0 + e] / d;
-      ACC[c0 + e]    = v;
-      colv[e]        = v;
-      wv[e]          = v * d;
+  for (int sn = 0; sn < pl.nsn; ++sn) {
+    const int j0 = pl.snptr[sn], wd = pl.snptr[sn + 1] - j0;
+    const int R  = pl.Lp[j0 + 1] - pl.Lp[j0] + 1;  // panel rows: the w columns themselves, then struct(last)
+    double *pan  = t;                                // pan[jj * R + r], r >= jj: accumulators, then L(r, j0+jj)
+    double *mul  = t + wd * R;                       // mul[jj * R + r] = L(r, j0+jj) * D(j0+jj)
+    // 1. panel accumulators -> LDS (gather through the panel map, DEPTH loads in flight per lane)
+    const int32_t *pm = pl.pmap + pl.poff[sn];
+    const int npan    = wd * R;
+    for (int q0 = lane; q0 < npan; q0 += kWave * DEPTH) {
+      int src[DEPTH];
+      double v[DEPTH];
+#pragma unroll
+      for (int dd = 0; dd < DEPTH; ++dd) src[dd] = pm[q0 + dd * kWave];  // the map is padded
+#pragma unroll
+      for (int dd = 0; dd < DEPTH; ++dd) v[dd] = ACC[src[dd]];
+#pragma unroll
+      for (int dd = 0; dd < DEPTH; ++dd)
+        if (q0 + dd * kWave < npan) pan[q0 + dd * kWave] = v[dd];
     }
-    wave_sync();
-    const int s1 = pl.rptr[kk + 1];
-    for (int s = pl.rptr[kk]; s < s1; s += DEPTH) {
+    wave_lds_fence();
+    // 2. eliminate the panel (LDS only)
+    for (int jj = 0; jj < wd; ++jj) {
+      const double d = pan[jj * R + jj];
+      if (d == 0.0) return 0;
+      for (int r = jj + 1 + lane; r < R; r += kWave) {
+        const double v  = pan[jj * R + r] / d;
+        pan[jj * R + r] = v;
+        mul[jj * R + r] = v * d;
+      }
+      wave_lds_fence();
+      for (int rb = jj + 1; rb < wd; ++rb)  // later panel columns, rows ra >= rb
+        for (int ra = rb + lane; ra < R; ra += kWave)
+          pan[rb * R + ra] = fma(-pan[jj * R + ra], mul[jj * R + rb], pan[rb * R + ra]);
+      wave_lds_fence();
+    }
+    // final D, 1/D and L values of the panel -> workspace (fire and forget)
+    for (int q = lane; q < npan; q += kWave) {
+      const int dst = pm[q];
+      if (dst != nnzL + k) ACC[dst] = pan[q];
+    }
+    for (int jj = lane; jj < wd; jj += kWave) w.Dinv[j0 + jj] = 1.0 / pan[jj * R + jj];
+    // 3. trailing accumulators: pairs (a >= b) of entries of column `last`, local rows w + a, w + b
+    const int last = j0 + wd - 1;
+    const int s1   = pl.rptr[last + 1];
+    const int pad  = nnzL + k;
+    for (int s = pl.rptr[last]; s < s1; s += DEPTH) {
       int tp[DEPTH];
       unsigned ab[DEPTH];
       double acc[DEPTH];
@@ -131,12 +164,19 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
       for (int dd = 0; dd < DEPTH; ++dd) {  // the schedule arrays are padded: reading past s1 is safe
         tp[dd] = pl.rtgt[(s + dd) * kWave + lane];
         ab[dd] = (unsigned)pl.rab[(s + dd) * kWave + lane];
+        if (s + dd >= s1) tp[dd] = pad;
       }
 #pragma unroll
-      for (int dd = 0; dd < DEPTH; ++dd) acc[dd] = (s + dd < s1) ? ACC[tp[dd]] : 0.0;
+      for (int dd = 0; dd < DEPTH; ++dd) acc[dd] = (tp[dd] != pad) ? ACC[tp[dd]] : 0.0;
 #pragma unroll
-      for (int dd = 0; dd < DEPTH; ++dd)
-        if (s + dd < s1) ACC[tp[dd]] = fma(-colv[ab[dd] & 0xFFFFu], wv[ab[dd] >> 16], acc[dd]);
+      for (int dd = 0; dd < DEPTH; ++dd) {
+        if (tp[dd] != pad) {
+          const int ra = wd + (int)(ab[dd] & 0xFFFFu), rb = wd + (int)(ab[dd] >> 16);
+          double v = acc[dd];
+          for (int jj = 0; jj < wd; ++jj) v = fma(-pan[jj * R + ra], mul[jj * R + rb], v);
+          ACC[tp[dd]] = v;
+        }
+      }
     }
     wave_sync();
   }
@@ -663,7 +703,7 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
                             const double *wy, double *x, double *y, double *obj, uint32_t *iter, int32_t *code,
                             double *workspace, hipStream_t stream)
 {
-  const size_t lds = (size_t)std::max(pl.k + 2, 2 * pl.maxcol + 4) * sizeof(double);
+  const size_t lds = (size_t)pl.lds_doubles * sizeof(double);
   const size_t wsd = qp_sparse_ws_doubles(pl.n, pl.m, pl.nnzL, pl.funits, pl.bunits);
   hipLaunchKernelGGL(qp_sparse_kernel, dim3((unsigned)batch), dim3(kWave), lds, stream, pl, kp, Px, q, Ax, l, u, wx,
                      wy, x, y, obj, iter, code, workspace, wsd);

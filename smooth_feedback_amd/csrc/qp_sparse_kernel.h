@@ -23,6 +23,8 @@ struct SparsePlanDev {
   int funits, bunits;
   const int32_t *Kmap, *rptr, *rtgt, *rab;   // right-looking factorisation schedule
   int rsteps, maxcol;
+  const int32_t *snptr, *poff, *pmap;        // supernodes of the factorisation and their panel maps
+  int nsn, lds_doubles;
 };
 
 // per-item workspace, in doubles

@@ -287,6 +287,39 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
     }
   }
 
+  // supernodes (see sparse_plan.h)
+  {
+    o.lds_doubles = std::max(k + 2, 2 * o.maxcol + 4);
+    o.snptr.clear();
+    int j0 = 0;
+    while (j0 < k) {
+      const int R    = (o.Lp[j0 + 1] - o.Lp[j0]) + 1;           // rows of the panel: j0 itself + struct(j0)
+      const int wmax = std::max(1, o.lds_doubles / (2 * R));
+      int w = 1;
+      while (w < wmax && j0 + w < k) {
+        const int j = j0 + w - 1;  // does column j+1 continue the supernode?
+        const int cj = o.Lp[j + 1] - o.Lp[j], cn = o.Lp[j + 2] - o.Lp[j + 1];
+        if (cj >= 1 && o.Li[o.Lp[j]] == j + 1 && cj == cn + 1) ++w;
+        else break;
+      }
+      o.snptr.push_back(j0);
+      j0 += w;
+    }
+    o.nsn = (int)o.snptr.size();
+    o.snptr.push_back(k);
+    o.poff.assign(o.nsn + 1, 0);
+    o.pmap.clear();
+    for (int s = 0; s < o.nsn; ++s) {
+      const int c0 = o.snptr[s], w = o.snptr[s + 1] - c0, R = (o.Lp[c0 + 1] - o.Lp[c0]) + 1;
+      o.poff[s] = (int)o.pmap.size();
+      for (int jj = 0; jj < w; ++jj)
+        for (int r = 0; r < R; ++r)
+          o.pmap.push_back(r < jj ? o.nnzL + k : (r == jj ? o.nnzL + c0 + jj : o.Lp[c0 + jj] + (r - jj - 1)));
+    }
+    o.poff[o.nsn] = (int)o.pmap.size();
+    for (int pad = 0; pad < 64 * SparsePlanHost::kSweepPad; ++pad) o.pmap.push_back(o.nnzL + k);  // branch-free batched reads
+  }
+
   // packed sweep schedules (see sparse_plan.h)
   if (k + 1 >= (1 << 16)) { *msg = "n+m too large for the packed sweep encoding (max 65534)"; return false; }
   auto build = [&](bool forward, std::vector<int32_t> &xmap, std::vector<int32_t> &xidx, int &units) {

@@ -56,6 +56,17 @@ struct SparsePlanHost {
   //   rtgt[q]  : accumulator index (padding: nnzL + k),  rab[q] = a | b << 16 (entry numbers in column kk)
   std::vector<int32_t> Kmap, rptr, rtgt, rab;
   int rsteps = 0, maxcol = 0;
+  // Supernodes: runs of consecutive columns j0..j1 with struct(j) = {j+1} u struct(j+1).  All columns of a
+  // supernode update the SAME trailing accumulators (pairs of rows of struct(j1)), so the kernel eliminates
+  // the supernode's own (dense) panel in LDS and then applies its w rank-1 updates to every trailing
+  // accumulator with ONE read-modify-write (sources still in ascending order -> same bits), using the
+  // schedule of column j1.  Widths are capped so that the panel and its multipliers, 2 w (cnt(j0)+1)
+  // doubles, fit the kernel's LDS scratch of lds_doubles.
+  //   snptr[s] : first column of supernode s (snptr[nsn] = k)
+  //   poff[s]  : start of the supernode's panel map;  pmap[poff[s] + jj * R + r] = accumulator index of panel
+  //              entry (row r, column jj) for r >= jj (r == jj: D), else the scratch accumulator nnzL + k
+  std::vector<int32_t> snptr, poff, pmap;
+  int nsn = 0, lds_doubles = 0;
 };
 
 // ordering: 0 = natural, 1 = minimum degree (default); user_perm (k entries, new->old) overrides.

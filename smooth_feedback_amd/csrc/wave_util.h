@@ -98,4 +98,14 @@ __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1u
 // compiler (and is a cheap s_barrier for a 64-thread block).
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
 
+// LDS-only ordering for a single-wave workgroup: the hardware executes one wave's LDS operations in
+// order, so phases that communicate across lanes through LDS only need the COMPILER to keep them in
+// program order.  No s_barrier and, unlike wave_sync(), no s_waitcnt vmcnt(0) that would drain the
+// wave's outstanding global stores.
+__device__ __forceinline__ void wave_lds_fence()
+{
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 }  // namespace sfb
