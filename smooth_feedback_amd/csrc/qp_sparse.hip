@@ -116,6 +116,22 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
     const int R  = pl.Lp[j0 + 1] - pl.Lp[j0] + 1;  // panel rows: the w columns themselves, then struct(last)
     double *pan  = t;                                // pan[jj * R + r], r >= jj: accumulators, then L(r, j0+jj)
     double *mul  = t + wd * R;                       // mul[jj * R + r] = L(r, j0+jj) * D(j0+jj)
+    // The first DEPTH steps of trailing accumulators do not depend on this supernode's panel: their loads
+    // are issued together with the panel's (one memory round trip instead of two per supernode).
+    const int last = j0 + wd - 1;
+    const int s0 = pl.rptr[last], s1 = pl.rptr[last + 1];
+    const int pad = nnzL + k;
+    int tp0[DEPTH];
+    unsigned ab0[DEPTH];
+    double acc0[DEPTH];
+#pragma unroll
+    for (int dd = 0; dd < DEPTH; ++dd) {  // the schedule arrays are padded: reading past s1 is safe
+      tp0[dd] = pl.rtgt[(s0 + dd) * kWave + lane];
+      ab0[dd] = (unsigned)pl.rab[(s0 + dd) * kWave + lane];
+      if (s0 + dd >= s1) tp0[dd] = pad;
+    }
+#pragma unroll
+    for (int dd = 0; dd < DEPTH; ++dd) acc0[dd] = (tp0[dd] != pad) ? ACC[tp0[dd]] : 0.0;
     // 1. panel accumulators -> LDS (gather through the panel map, DEPTH loads in flight per lane)
     const int32_t *pm = pl.pmap + pl.poff[sn];
     const int npan    = wd * R;
@@ -153,15 +169,21 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
     }
     for (int jj = lane; jj < wd; jj += kWave) w.Dinv[j0 + jj] = 1.0 / pan[jj * R + jj];
     // 3. trailing accumulators: pairs (a >= b) of entries of column `last`, local rows w + a, w + b
-    const int last = j0 + wd - 1;
-    const int s1   = pl.rptr[last + 1];
-    const int pad  = nnzL + k;
-    for (int s = pl.rptr[last]; s < s1; s += DEPTH) {
+#pragma unroll
+    for (int dd = 0; dd < DEPTH; ++dd) {
+      if (tp0[dd] != pad) {
+        const int ra = wd + (int)(ab0[dd] & 0xFFFFu), rb = wd + (int)(ab0[dd] >> 16);
+        double v = acc0[dd];
+        for (int jj = 0; jj < wd; ++jj) v = fma(-pan[jj * R + ra], mul[jj * R + rb], v);
+        ACC[tp0[dd]] = v;
+      }
+    }
+    for (int s = s0 + DEPTH; s < s1; s += DEPTH) {
       int tp[DEPTH];
       unsigned ab[DEPTH];
       double acc[DEPTH];
 #pragma unroll
-      for (int dd = 0; dd < DEPTH; ++dd) {  // the schedule arrays are padded: reading past s1 is safe
+      for (int dd = 0; dd < DEPTH; ++dd) {
         tp[dd] = pl.rtgt[(s + dd) * kWave + lane];
         ab[dd] = (unsigned)pl.rab[(s + dd) * kWave + lane];
         if (s + dd >= s1) tp[dd] = pad;
@@ -434,7 +456,7 @@ __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const 
 
 }  // namespace
 
-__global__ void __launch_bounds__(64) qp_sparse_kernel(const SparsePlanDev pl, const DenseKernelParams kp,
+__global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl, const DenseKernelParams kp,
                                                        const double *__restrict__ gPx, const double *__restrict__ gq,
                                                        const double *__restrict__ gAx, const double *__restrict__ gl,
                                                        const double *__restrict__ gu, const double *__restrict__ gwx,
