@@ -308,7 +308,7 @@ def main():
     wl = WORKLOADS[args.workload](sfb, rank, device, **kw)
     stream = torch.cuda.current_stream()
     gathered = None
-    kernel_name = {"mpc": "qp_sparse_kernel", "qp_dense": "qp_dense4_kernel", "ekf": "ekf_kernel"}[args.workload]
+    kernel_name = {"mpc": "qp_sparse_kernel", "qp_dense": "qp_dense4_iterate_kernel (+ setup and finish kernels of the same launch)", "ekf": "ekf_kernel"}[args.workload]
     if world > 1:
         gathered = [torch.empty_like(wl.small_outputs()) for _ in range(world)]
 

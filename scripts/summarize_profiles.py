@@ -4,7 +4,10 @@ kernel's duration and of the FETCH_SIZE / WRITE_SIZE counters, each from its own
 import csv, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ("qp_sparse_kernel", "qp_dense_kernel", "qp_dense4_kernel", "ekf_kernel")
+# product kernels; a launch of the dense path is three kernels (setup / iterate / finish): counters are summed
+# over all of them and divided by the number of launches (= dispatches of the dominant kernel)
+KERNELS = ("qp_sparse_kernel", "qp_dense_kernel", "qp_dense4_", "ekf_kernel")
+DOMINANT = ("qp_sparse_kernel", "qp_dense_kernel", "qp_dense4_iterate_kernel", "ekf_kernel")
 
 
 def main(tag):
@@ -23,13 +26,15 @@ def main(tag):
             path = os.path.join(src, sub, "p_counter_collection.csv")
             if not os.path.exists(path):
                 continue
-            vals = {}
+            total, launches = 0.0, set()
             with open(path) as f:
                 for r in csv.DictReader(f):
                     if r["Counter_Name"] == ctr and any(k in r["Kernel_Name"] for k in KERNELS):
-                        vals[r["Dispatch_Id"]] = vals.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
-            if vals:
-                out[ctr] = {"dispatches": len(vals), "mean_per_dispatch_KB": sum(vals.values()) / len(vals)}
+                        total += float(r["Counter_Value"])
+                        if any(k in r["Kernel_Name"] for k in DOMINANT):
+                            launches.add(r["Dispatch_Id"])
+            if launches:
+                out[ctr] = {"dispatches": len(launches), "mean_per_dispatch_KB": total / len(launches)}
         for line in open(os.path.join(src, "trace.log")):
             if line.startswith('{"metric"'):
                 out["bench_line_under_profiler"] = json.loads(line)

@@ -22,7 +22,7 @@ __device__ __forceinline__ int tri(const int i, const int j) { return ((i * (i +
 __device__ inline int ldlt_factor_lds(const int k, double *W, int *perm, double *temp, const int lane)
 {
   if (lane < k) perm[lane] = lane;
-  wave_sync();
+  wave_lds_fence();
   if (k <= 1) return 1;
 
   int ret = 1, found_zero_pivot = 0;
@@ -65,12 +65,12 @@ __device__ inline int ldlt_factor_lds(const int k, double *W, int *perm, double 
         W[tri(lane, kk)] = a2;
         W[tri(lane, p)]  = a1;
       }
-      wave_sync();
+      wave_lds_fence();
     }
 
     // temp(j) = D(j) * L(kk,j), j < kk
     if (lane < kk) temp[lane] = W[tri(lane, lane)] * W[tri(kk, lane)];
-    wave_sync();
+    wave_lds_fence();
 
     double val = 0.0;
     if (cand) {
@@ -103,7 +103,7 @@ __device__ inline int ldlt_factor_lds(const int k, double *W, int *perm, double 
     } else if (!valid) {
       found_zero_pivot = 1;
     }
-    wave_sync();
+    wave_lds_fence();
   }
   return ret;
 }
@@ -117,9 +117,9 @@ __device__ inline double ldlt_solve_lds(const int k, const double *W, const int 
 {
   const bool inmat = lane < k;
   if (inmat) xch[lane] = b;
-  wave_sync();
+  wave_lds_fence();
   double x = inmat ? xch[perm[lane]] : 0.0;
-  wave_sync();
+  wave_lds_fence();
   for (int j = 0; j < k - 1; ++j) {
     const double xj = lane_bcast(x, j);
     if (inmat && lane > j) x = fma(-W[tri(lane, j)], xj, x);
@@ -133,9 +133,9 @@ __device__ inline double ldlt_solve_lds(const int k, const double *W, const int 
     if (lane < j) x = fma(-W[tri(j, lane)], xj, x);
   }
   if (inmat) xch[perm[lane]] = x;
-  wave_sync();
+  wave_lds_fence();
   const double r = inmat ? xch[lane] : 0.0;
-  wave_sync();
+  wave_lds_fence();
   return r;
 }
 

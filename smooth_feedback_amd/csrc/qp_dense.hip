@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(64, SFB_QP_WAVES_PER_EU) qp_dense_kernel(const
   if (gwx != nullptr) {
     if (lane < n) s.xv[lane] = gwx[b * n + lane];
     if (lane < m) s.yv[lane] = gwy[b * m + lane];
-    wave_sync();
+    wave_lds_fence();
     if (isx) xs = (1.0 / sxv) * s.xv[xi];
     if (isc) {
       ys       = c * ((1.0 / syv) * s.yv[ci]);
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(64, SFB_QP_WAVES_PER_EU) qp_dense_kernel(const
       for (int j = 0; j < n; ++j) t = fma(syv * s.A[ci + j * m], s.xv[j], t);
       zs = t;
     }
-    wave_sync();
+    wave_lds_fence();
   }
 
   // ---- ADMM loop :447-510 ----
@@ -255,16 +255,16 @@ __global__ void __launch_bounds__(64, SFB_QP_WAVES_PER_EU) qp_dense_kernel(const
         s.zus[ci]  = (1.0 / syv) * zs;
         s.dyus[ci] = syv * (ys - yold) / c;
       }
-      wave_sync();
+      wave_lds_fence();
       ret_code = qp_check_stopping(s, kp, n, m, lane);
-      wave_sync();
+      wave_lds_fence();
     }
   }
 
   // ---- scaled iterate back to original order ----
   if (isx) s.xv[xi] = xs;
   if (isc) s.yv[ci] = ys;
-  wave_sync();
+  wave_lds_fence();
 
   qp_finish(s, kp, n, m, c, b, g, lane, ret_code, iter);
 }

@@ -12,9 +12,15 @@
 //     a persistent grid of waves, each slot takes the next problem when its own finishes.  New
 //     problems start only on iterations that are multiples of stop_check_iter, which keeps the
 //     stopping checks of the four slots on the same iteration; the check itself runs row-parallel;
-//   - problem setup (scaling, KKT, pivoted LDL'), polish and reporting are the wave-wide routines of
-//     qp_dense_common.h working on the slot's LDS area; the other three slots just wait (setup is a
-//     few iterations' worth of time against hundreds to thousands of iterations per problem).
+//   - the wave-wide parts of a solve do not run in this kernel at all.  A launch is three kernels:
+//       setup    one wavefront per QP (massively parallel): scaling, KKT, pivoted LDL' (qp_dense_common.h),
+//                then every lane writes the registers of "its" lane of the iterate kernel (factor blocks,
+//                scaled bounds, rho, initial iterate) to the QP's record in a per-launch workspace;
+//       iterate  four QPs per wavefront, persistent; a refill is ~80 coalesced loads per lane of one
+//                row, a finished slot scatters its iterate into the record;
+//       finish   one wavefront per QP: polish, un-scale, objective, report.
+//     Setup and finish thus keep the parallelism of the one-QP-per-wave kernel (they dominate batches of
+//     easy problems), and the lockstep loop never waits for them.
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -41,39 +47,19 @@ __device__ __forceinline__ double row_max16(double v)
   return v;
 }
 
-struct Lds4 {
-  int shared_doubles;  // W, temp, rho, perm, LU (setup / polish scratch, one problem at a time)
-  int slot_doubles;    // stride of a slot area
-};
-
-__host__ __device__ inline Lds4 lds4_layout(int n, int m)
+// LDS of the iterate kernel: one area per slot with what the stopping checks need
+__host__ __device__ inline int slot4_doubles(int n, int m)
 {
-  const int k = n + m;
-  Lds4 L;
-  int sh = (k * (k + 1)) / 2 + k + m + (k + m + 1) / 2;  // W, temp, rho, (perm, LU as ints)
-  sh     = (sh + 1) & ~1;
-  L.shared_doubles = sh;
   int sl = n * n + m * n + 4 * n + 7 * m + 2;  // P A | q sx xv dxus | l u sy yv zus dyus (+1 m spare) | cval
   // rows of a wave read the same offsets of different slots: stride = 16 mod 32 doubles puts
   // neighbouring slots on complementary LDS banks
-  sl = ((sl + 15) & ~31) + 16;
-  L.slot_doubles = sl;
-  return L;
+  return ((sl + 15) & ~31) + 16;
 }
-
-// view of slot `slot` (shared scratch + the slot's own arrays)
-__device__ __forceinline__ Lds slot_view(double *base, const Lds4 &L, const int n, const int m, const int slot,
-                                         double *&cval)
+__device__ __forceinline__ Lds slot_view(double *base, const int n, const int m, const int slot, double *&cval)
 {
-  const int k = n + m;
   Lds s;
-  double *p = base;
-  s.W    = p; p += (k * (k + 1)) >> 1;
-  s.temp = p; p += k;
-  s.rho  = p; p += m;
-  s.perm = reinterpret_cast<int *>(p);
-  s.LU   = s.perm + k;
-  p      = base + L.shared_doubles + slot * L.slot_doubles;
+  double *p = base + slot * slot4_doubles(n, m);
+  s.W = nullptr; s.temp = nullptr; s.rho = nullptr; s.perm = nullptr; s.LU = nullptr;  // setup / finish kernels only
   s.P    = p; p += n * n;
   s.A    = p; p += m * n;
   s.q    = p; p += n;
@@ -84,10 +70,34 @@ __device__ __forceinline__ Lds slot_view(double *base, const Lds4 &L, const int 
   s.xv   = p; p += n;
   s.yv   = p; p += m;
   s.zus  = p; p += m;
-  s.dxus = p; p += n;   // dxus | dyus contiguous: qp_polish uses them as one k-vector
+  s.dxus = p; p += n;
   s.dyus = p; p += m;
   cval   = p;
   return s;
+}
+
+// Record of one QP in the launch workspace (doubles).  Lane registers of the iterate kernel are stored
+// field-major, [reg][16 lanes], so that a row reads them with coalesced loads:
+//   regs 0..15 D0 | (NB = 2: 16..31 D1, 32..47 F10, 48..63 B10) | per block b: ws zs rinv rho lo hi dg role+4 idx
+struct Rec4 {
+  int nreg, reg_state, off_sx, off_sy, off_c, off_xs, off_ys, off_code, off_iter, size;
+};
+template<int NB>
+__host__ __device__ inline Rec4 rec4_layout(int n, int m)
+{
+  Rec4 r;
+  r.reg_state = (NB > 1) ? 64 : 16;
+  r.nreg      = r.reg_state + 8 * NB;
+  int o       = 16 * r.nreg;
+  r.off_sx = o; o += n;
+  r.off_sy = o; o += m;
+  r.off_c  = o; o += 1;
+  r.off_xs = o; o += n;   // scaled iterate, original order: initial (setup), final (iterate)
+  r.off_ys = o; o += m;
+  r.off_code = o; o += 1;  // -1: still to be iterated / ran into max_iter
+  r.off_iter = o; o += 1;
+  r.size = (o + 1) & ~1;
+  return r;
 }
 
 // QPSolver::check_stopping (qp_solver.hpp:574-644), ROW-PARALLEL: every 16-lane row checks its own
@@ -347,14 +357,99 @@ __device__ __forceinline__ void sweep_bwd(double (&t)[NB], const Factor<NB> &f)
 
 }  // namespace
 
+// ---- kernel 1: setup, one wavefront per QP ----
 template<int NB>
-__global__ void __launch_bounds__(64, 2) qp_dense4_kernel(const DenseKernelParams kp, const QpBatch g,
-                                                          unsigned *__restrict__ queue, const unsigned batch)
+__global__ void __launch_bounds__(64) qp_dense4_setup_kernel(const DenseKernelParams kp, const QpBatch g,
+                                                             double *__restrict__ wsp)
+{
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const int n = kp.n, m = kp.m, k = n + m;
+  const size_t b = blockIdx.x;
+  const Lds S    = carve(smem, n, m, k);
+  const Rec4 R   = rec4_layout<NB>(n, m);
+  double *rec    = wsp + b * (size_t)R.size;
+  double c;
+  const int rc    = qp_setup(S, kp, n, m, b, g, lane, c);
+  const bool warm = g.wx != nullptr;
+  if (warm) {
+    if (lane < n) S.xv[lane] = g.wx[b * n + lane];
+    if (lane < m) S.yv[lane] = g.wy[b * m + lane];
+  }
+  wave_lds_fence();
+  if (lane < 16 * NB) {  // lane = system row i = 16 blk + cc  ->  registers of lane cc, block blk
+    const int blk = lane >> 4, cc = lane & 15, i = lane;
+    const bool inmat = i < k;
+    const int v      = inmat ? S.perm[i] : 0;
+    const bool isx   = inmat && v < n;
+    const bool isc   = inmat && v >= n;
+    const int xi = isx ? v : 0, ci = isc ? v - n : 0;
+    const double sxv = isx ? S.sx[xi] : 1.0;
+    const double syv = isc ? S.sy[ci] : 1.0;
+    const double rho = isc ? S.rho[ci] : 1.0;
+    double ws = 0.0, zs = 0.0;
+    if (warm) {  // :436-445
+      if (isx) ws = (1.0 / sxv) * S.xv[xi];
+      if (isc) {
+        ws       = c * ((1.0 / syv) * S.yv[ci]);
+        double t = 0.0;
+        for (int j = 0; j < n; ++j) t = fma(syv * S.A[ci + j * m], S.xv[j], t);
+        zs = t;
+      }
+    }
+    double *lr = rec + cc;
+    double *st = lr + (R.reg_state + 8 * blk) * 16;
+    st[0 * 16] = ws;
+    st[1 * 16] = zs;
+    st[2 * 16] = 1.0 / rho;                                                     // rho_.cwiseInverse()
+    st[3 * 16] = rho;
+    st[4 * 16] = isx ? c * sxv * S.q[xi] : (isc ? syv * S.l[ci] : 0.0);        // :450 / :473
+    st[5 * 16] = isc ? syv * S.u[ci] : 0.0;                                     // :474
+    st[6 * 16] = inmat ? S.W[tri(i, i)] : 1.0;
+    st[7 * 16] = (double)((isx ? 1 : (isc ? 2 : 0)) + 4 * (isx ? xi : ci));
+    // factor blocks (zero outside the factor: padded steps are exact no-ops), see struct Factor
+    const int i0 = cc, i1 = 16 + cc;
+    for (int j = 0; j < 16; ++j) {
+      if (blk == 0) {
+        double d0 = 0.0;
+        if (j < i0 && i0 < k) d0 = -S.W[tri(i0, j)];
+        if (j > i0 && j < k) d0 = -S.W[tri(j, i0)];
+        lr[j * 16] = d0;
+        if constexpr (NB > 1) lr[(48 + j) * 16] = (16 + j < k && i0 < k) ? -S.W[tri(16 + j, i0)] : 0.0;  // B10
+      } else {
+        double d1 = 0.0;
+        if (j < cc && i1 < k) d1 = -S.W[tri(i1, 16 + j)];
+        if (j > cc && 16 + j < k) d1 = -S.W[tri(16 + j, i1)];
+        lr[(16 + j) * 16] = d1;
+        lr[(32 + j) * 16] = (i1 < k) ? -S.W[tri(i1, j)] : 0.0;  // F10
+      }
+    }
+  }
+  if (lane < n) {
+    rec[R.off_sx + lane] = S.sx[lane];
+    rec[R.off_xs + lane] = warm ? (1.0 / S.sx[lane]) * S.xv[lane] : 0.0;
+  }
+  if (lane < m) {
+    rec[R.off_sy + lane] = S.sy[lane];
+    rec[R.off_ys + lane] = warm ? c * ((1.0 / S.sy[lane]) * S.yv[lane]) : 0.0;
+  }
+  if (lane == 0) {
+    rec[R.off_c]    = c;
+    rec[R.off_code] = (double)rc;
+    rec[R.off_iter] = 0.0;
+  }
+}
+
+// ---- kernel 2: the ADMM loops, four QPs per wavefront, persistent ----
+template<int NB>
+__global__ void __launch_bounds__(64, 2) qp_dense4_iterate_kernel(const DenseKernelParams kp, const QpBatch g,
+                                                                  double *__restrict__ wsp,
+                                                                  unsigned *__restrict__ queue, const unsigned batch)
 {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x, row = lane >> 4, cc = lane & 15;
-  const int n = kp.n, m = kp.m, k = n + m;
-  const Lds4 L = lds4_layout(n, m);
+  const int n = kp.n, m = kp.m;
+  const Rec4 R = rec4_layout<NB>(n, m);
 
   // ---- per-lane state: block b of this lane is system row 16 b + cc of the row's slot ----
   Factor<NB> f;
@@ -389,102 +484,103 @@ __global__ void __launch_bounds__(64, 2) qp_dense4_kernel(const DenseKernelParam
   uint32_t phase       = 0;         // iteration index of every running slot, mod sci
   bool qempty          = false;
 
-  // scaled iterate of slot s -> its LDS area, then polish / un-scale / report
+  // scaled iterate of slot s -> its record (original order), status and iteration count
   auto finish_slot = [&](const int s, const int code, const uint32_t iters) {
-    double *cval;
-    const Lds S = slot_view(smem, L, n, m, s, cval);
+    double *rec = wsp + (size_t)qb[s] * (size_t)R.size;
     if (row == s) {
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        if (role[b] == 1) S.xv[idx[b]] = ws[b];
-        if (role[b] == 2) S.yv[idx[b]] = ws[b];
+        if (role[b] == 1) rec[R.off_xs + idx[b]] = ws[b];
+        if (role[b] == 2) rec[R.off_ys + idx[b]] = ws[b];
         role[b] = 0;
         ws[b] = 0.0; zs[b] = 0.0; lo[b] = 0.0;
       }
+      if (cc == 0) {
+        rec[R.off_code] = (double)code;
+        rec[R.off_iter] = (double)iters;
+      }
     }
-    wave_sync();
-    const double c = cval[0];
-    qp_finish(S, kp, n, m, c, (size_t)qb[s], g, lane, code, iters);
   };
 
   for (;;) {
-    // ---- refill empty slots ----
+    // ---- refill empty slots: one ticket fetch for all of them, then every row loads its own QP ----
     if (!aligned || phase == 0) {
+      for (;;) {
+        unsigned nfree = 0;
 #pragma unroll
-      for (int s = 0; s < kSlots; ++s) {
-        while (qb[s] < 0 && !qempty) {
-          unsigned nb = 0;
-          if (lane == 0) nb = atomicAdd(queue, 1u);
-          nb = __builtin_amdgcn_readfirstlane(nb);
-          if (nb >= batch) {
-            qempty = true;
-            break;
-          }
-          double *cval;
-          const Lds S = slot_view(smem, L, n, m, s, cval);
-          double c;
-          const int rc = qp_setup(S, kp, n, m, (size_t)nb, g, lane, c);
-          if (lane == 0) cval[0] = c;
-          const bool warm = g.wx != nullptr;
-          if (warm) {
-            if (lane < n) S.xv[lane] = g.wx[(size_t)nb * n + lane];
-            if (lane < m) S.yv[lane] = g.wy[(size_t)nb * m + lane];
-          }
-          wave_sync();
-          if (row == s) {
+        for (int s = 0; s < kSlots; ++s) nfree += (qb[s] < 0) ? 1u : 0u;
+        if (nfree == 0 || qempty) break;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(queue, nfree);
+        base = __builtin_amdgcn_readfirstlane(base);
+        int tk[kSlots];
+        int mine = -1;  // ticket of this lane's row, if the row is being refilled
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-              const int i      = 16 * b + cc;
-              const bool inmat = i < k;
-              const int v      = inmat ? S.perm[i] : 0;
-              const bool isx   = inmat && v < n;
-              const bool isc   = inmat && v >= n;
-              const int xi = isx ? v : 0, ci = isc ? v - n : 0;
-              role[b] = isx ? 1 : (isc ? 2 : 0);
-              idx[b]  = isx ? xi : ci;
-              const double sxv = isx ? S.sx[xi] : 1.0;
-              const double syv = isc ? S.sy[ci] : 1.0;
-              rho[b]  = isc ? S.rho[ci] : 1.0;
-              rinv[b] = 1.0 / rho[b];                                             // rho_.cwiseInverse()
-              lo[b]   = isx ? c * sxv * S.q[xi] : (isc ? syv * S.l[ci] : 0.0);   // :450 / :473
-              hi[b]   = isc ? syv * S.u[ci] : 0.0;                                // :474
-              dg[b]   = inmat ? S.W[tri(i, i)] : 1.0;
-              ws[b]   = 0.0;
-              zs[b]   = 0.0;
-              if (warm) {  // :436-445
-                if (isx) ws[b] = (1.0 / sxv) * S.xv[xi];
-                if (isc) {
-                  ws[b]    = c * ((1.0 / syv) * S.yv[ci]);
-                  double t = 0.0;
-                  for (int j = 0; j < n; ++j) t = fma(syv * S.A[ci + j * m], S.xv[j], t);
-                  zs[b] = t;
-                }
-              }
-            }
-            // factor blocks (zero outside the factor: padded steps are exact no-ops)
-            const int i0 = cc, i1 = 16 + cc;
+        for (int s = 0; s < kSlots; ++s) {
+          tk[s] = -1;
+          if (qb[s] < 0) {
+            if (base < batch) tk[s] = (int)base;
+            else qempty = true;
+            ++base;
+          }
+          if (row == s) mine = tk[s];
+        }
+        bool accepted = false;
+        if (mine >= 0) {
+          const double *rec = wsp + (size_t)mine * (size_t)R.size;
+          // a QP that ended in setup (pre-check, failed factorisation) is reported by the finish kernel
+          accepted = rec[R.off_code] < 0.0;
+          if (accepted) {
+            const double *lr = rec + cc;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-              double d0 = 0.0;
-              if (j < i0 && i0 < k) d0 = -S.W[tri(i0, j)];
-              if (j > i0 && j < k) d0 = -S.W[tri(j, i0)];
-              f.D0[j] = d0;
+              f.D0[j] = lr[j * 16];
               if constexpr (NB > 1) {
-                double d1 = 0.0;
-                if (j < cc && i1 < k) d1 = -S.W[tri(i1, 16 + j)];
-                if (j > cc && 16 + j < k) d1 = -S.W[tri(16 + j, i1)];
-                f.D1[j]  = d1;
-                f.F10[j] = (i1 < k) ? -S.W[tri(i1, j)] : 0.0;
-                f.B10[j] = (16 + j < k && i0 < k) ? -S.W[tri(16 + j, i0)] : 0.0;
+                f.D1[j]  = lr[(16 + j) * 16];
+                f.F10[j] = lr[(32 + j) * 16];
+                f.B10[j] = lr[(48 + j) * 16];
               }
             }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              const double *st = lr + (R.reg_state + 8 * b) * 16;
+              ws[b]   = st[0 * 16];
+              zs[b]   = st[1 * 16];
+              rinv[b] = st[2 * 16];
+              rho[b]  = st[3 * 16];
+              lo[b]   = st[4 * 16];
+              hi[b]   = st[5 * 16];
+              dg[b]   = st[6 * 16];
+              const int ri = (int)st[7 * 16];
+              role[b] = ri & 3;
+              idx[b]  = ri >> 2;
+            }
+            // what the stopping checks need, in the slot's LDS area (the 16 lanes of the row copy)
+            double *cval;
+            const Lds S     = slot_view(smem, n, m, row, cval);
+            const size_t nb = (size_t)mine;
+            const double *P = g.P + nb * (size_t)(n * n), *A = g.A + nb * (size_t)(m * n);
+            for (int e = cc; e < n * n; e += 16) S.P[e] = P[e];
+            for (int e = cc; e < m * n; e += 16) S.A[e] = A[e];
+            for (int e = cc; e < n; e += 16) {
+              S.q[e]  = g.q[nb * n + e];
+              S.sx[e] = rec[R.off_sx + e];
+            }
+            for (int e = cc; e < m; e += 16) {
+              S.l[e]  = g.l[nb * m + e];
+              S.u[e]  = g.u[nb * m + e];
+              S.sy[e] = rec[R.off_sy + e];
+            }
+            if (cc == 0) cval[0] = rec[R.off_c];
           }
-          wave_sync();
-          qb[s] = (int)nb;
-          it[s] = 0;
-          if (rc >= 0 || maxit == 0) {  // ends before the first iteration
-            finish_slot(s, rc, 0);
-            qb[s] = -1;
+        }
+        wave_lds_fence();
+        const unsigned long long acc = wave_ballot(accepted);
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) {
+          if (tk[s] >= 0 && ((acc >> (16 * s)) & 1ull)) {
+            qb[s] = tk[s];
+            it[s] = 0;
           }
         }
       }
@@ -579,7 +675,7 @@ __global__ void __launch_bounds__(64, 2) qp_dense4_kernel(const DenseKernelParam
     int res        = -1;
     if (chk) {  // :479-509
       double *cval;
-      const Lds S    = slot_view(smem, L, n, m, row, cval);
+      const Lds S    = slot_view(smem, n, m, row, cval);
       const double c = cval[0];
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -595,9 +691,9 @@ __global__ void __launch_bounds__(64, 2) qp_dense4_kernel(const DenseKernelParam
           S.dyus[idx[b]]   = syv * (ws[b] - wold[b]) / c;
         }
       }
-      wave_sync();
+      wave_lds_fence();
       res = check_rows<NB>(S, kp, n, m, cc);
-      wave_sync();
+      wave_lds_fence();
     }
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) {
@@ -614,11 +710,42 @@ __global__ void __launch_bounds__(64, 2) qp_dense4_kernel(const DenseKernelParam
   }
 }
 
-size_t qp_dense4_lds_bytes(int n, int m)
+// ---- kernel 3: polish, un-scale, report; one wavefront per QP ----
+template<int NB>
+__global__ void __launch_bounds__(64) qp_dense4_finish_kernel(const DenseKernelParams kp, const QpBatch g,
+                                                              const double *__restrict__ wsp)
 {
-  const Lds4 L = lds4_layout(n, m);
-  return ((size_t)L.shared_doubles + (size_t)kSlots * L.slot_doubles) * sizeof(double);
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const int n = kp.n, m = kp.m, k = n + m;
+  const size_t b    = blockIdx.x;
+  const Lds S       = carve(smem, n, m, k);
+  const Rec4 R      = rec4_layout<NB>(n, m);
+  const double *rec = wsp + b * (size_t)R.size;
+  {
+    const double *P = g.P + b * (size_t)(n * n), *A = g.A + b * (size_t)(m * n);
+    for (int e = lane; e < n * n; e += kWave) S.P[e] = P[e];
+    for (int e = lane; e < m * n; e += kWave) S.A[e] = A[e];
+    if (lane < n) {
+      S.q[lane]  = g.q[b * n + lane];
+      S.sx[lane] = rec[R.off_sx + lane];
+      S.xv[lane] = rec[R.off_xs + lane];
+    }
+    if (lane < m) {
+      S.l[lane]  = g.l[b * m + lane];
+      S.u[lane]  = g.u[b * m + lane];
+      S.sy[lane] = rec[R.off_sy + lane];
+      S.yv[lane] = rec[R.off_ys + lane];
+    }
+  }
+  const double c      = rec[R.off_c];
+  const int code      = (int)rec[R.off_code];
+  const uint32_t iter = (uint32_t)rec[R.off_iter];
+  wave_lds_fence();
+  qp_finish(S, kp, n, m, c, b, g, lane, code, iter);
 }
+
+size_t qp_dense4_lds_bytes(int n, int m) { return (size_t)kSlots * slot4_doubles(n, m) * sizeof(double); }
 
 // device-side ticket counters, one per launch in flight (zeroed on the launch's stream)
 static unsigned *ticket_pool(int &index)
@@ -635,6 +762,52 @@ static unsigned *ticket_pool(int &index)
   }
   index = (int)(__atomic_fetch_add(&next[dev], 1u, __ATOMIC_RELAXED) % kPool);
   return pool[dev];
+}
+
+template<int NB>
+static hipError_t launch4(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, unsigned *queue, int ncu,
+                          hipStream_t stream)
+{
+  // per-launch workspace of QP records, stream-ordered (no device synchronisation in the steady state)
+  const Rec4 R       = rec4_layout<NB>(kp.n, kp.m);
+  const size_t bytes = (size_t)batch * (size_t)R.size * sizeof(double);
+  double *wsp        = nullptr;
+  bool async_alloc   = true;
+  hipError_t e       = hipMallocAsync(reinterpret_cast<void **>(&wsp), bytes, stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    async_alloc = false;
+    e           = hipMalloc(reinterpret_cast<void **>(&wsp), bytes);
+    if (e != hipSuccess) return e;
+  }
+  const dim3 block(kWave), full((unsigned)batch);
+  const size_t lds1 = qp_dense_lds_bytes(kp.n, kp.m);
+  hipLaunchKernelGGL((qp_dense4_setup_kernel<NB>), full, block, lds1, stream, kp, g, wsp);
+
+  const size_t lds = qp_dense4_lds_bytes(kp.n, kp.m);
+  int per_cu       = (int)((160u * 1024u) / lds);
+  const char *occ  = getenv("SFB_QP4_WAVES_PER_CU");  // A/B only
+  const int occ_cap = occ ? atoi(occ) : (NB > 1 ? 8 : 16);
+  if (per_cu > occ_cap) per_cu = occ_cap;  // waves per SIMD the VGPR budget of the kernel allows: 2 (NB = 2) / 4
+  if (per_cu < 1) per_cu = 1;
+  int64_t max_waves = (int64_t)ncu * per_cu;
+  if (const char *cap = getenv("SFB_QP4_MAX_WAVES")) {  // tests: small grids exercise the slot refill path
+    const int64_t c = atoll(cap);
+    if (c >= 1 && c < max_waves) max_waves = c;
+  }
+  const dim3 grid((unsigned)(batch < max_waves ? batch : max_waves));
+  if (kp.max_iter != 0)  // nothing to iterate otherwise: the finish kernel reports the initial iterate
+    hipLaunchKernelGGL((qp_dense4_iterate_kernel<NB>), grid, block, lds, stream, kp, g, wsp, queue, (unsigned)batch);
+  hipLaunchKernelGGL((qp_dense4_finish_kernel<NB>), full, block, lds1, stream, kp, g, wsp);
+  e = hipGetLastError();
+  if (async_alloc) {
+    const hipError_t e2 = hipFreeAsync(wsp, stream);
+    if (e == hipSuccess) e = e2;
+  } else {
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(wsp);
+  }
+  return e;
 }
 
 hipError_t qp_dense4_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream)
@@ -654,25 +827,7 @@ hipError_t qp_dense4_launch(const DenseKernelParams &kp, int64_t batch, const Qp
   unsigned *queue = pool + 16 * ti;
   e = hipMemsetAsync(queue, 0, sizeof(unsigned), stream);
   if (e != hipSuccess) return e;
-
-  const int k      = kp.n + kp.m;
-  const size_t lds = qp_dense4_lds_bytes(kp.n, kp.m);
-  int per_cu       = (int)((160u * 1024u) / lds);
-  static const int occ_cap = getenv("SFB_QP4_WAVES_PER_CU") ? atoi(getenv("SFB_QP4_WAVES_PER_CU")) : 8;  // A/B only
-  if (per_cu > occ_cap) per_cu = occ_cap;  // 2 waves per SIMD (VGPR budget of the kernel)
-  if (per_cu < 1) per_cu = 1;
-  int64_t max_waves = (int64_t)ncu * per_cu;
-  if (const char *cap = getenv("SFB_QP4_MAX_WAVES")) {  // tests: small grids exercise the slot refill path
-    const int64_t c = atoll(cap);
-    if (c >= 1 && c < max_waves) max_waves = c;
-  }
-  const dim3 grid((unsigned)(batch < max_waves ? batch : max_waves)), block(kWave);
-  if (k <= 16) {
-    hipLaunchKernelGGL((qp_dense4_kernel<1>), grid, block, lds, stream, kp, g, queue, (unsigned)batch);
-  } else {
-    hipLaunchKernelGGL((qp_dense4_kernel<2>), grid, block, lds, stream, kp, g, queue, (unsigned)batch);
-  }
-  return hipGetLastError();
+  return (kp.n + kp.m <= 16) ? launch4<1>(kp, batch, g, queue, ncu, stream) : launch4<2>(kp, batch, g, queue, ncu, stream);
 }
 
 }  // namespace sfb

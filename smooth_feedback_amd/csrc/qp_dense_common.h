@@ -60,7 +60,7 @@ __device__ inline double qp_scale(const Lds &s, const int n, const int m, const 
     if (t == 0.0) t = 1.0;
     s.temp[lane] = t;
   }
-  wave_sync();
+  wave_lds_fence();
   // :693
   double sum = s.temp[0];
   for (int j = 1; j < n; ++j) sum += s.temp[j];
@@ -68,7 +68,7 @@ __device__ inline double qp_scale(const Lds &s, const int n, const int m, const 
   double qn         = 0.0;
   for (int j = 0; j < n; ++j) qn = fmax(qn, fabs(s.q[j]));
   const double c = 1.0 / fmax(fmax(1e-6, mean), qn);
-  wave_sync();
+  wave_lds_fence();
 
   int iter = 0;
   double crit;
@@ -83,12 +83,12 @@ __device__ inline double qp_scale(const Lds &s, const int n, const int m, const 
       for (int col = 0; col < n; ++col) inc = fmax(inc, fabs(syr * s.sx[col] * s.A[ci + col * m]));
     }
     if (inc == 0.0) inc = 1.0;
-    wave_sync();  // every lane has read the old sx/sy
+    wave_lds_fence();  // every lane has read the old sx/sy
     const double f = sqrt(1.0 / fmax(inc, 1e-8));
     if (isx) s.sx[lane] = f * s.sx[lane];
     if (isc) s.sy[ci] = f * s.sy[ci];
     crit = wave_max((isx || isc) ? fabs(inc - 1.0) : 0.0);
-    wave_sync();
+    wave_lds_fence();
   } while (iter++ < 10 && crit > 0.1);
   return c;
 }
@@ -208,7 +208,7 @@ __device__ inline void qp_polish(const Lds &s, const DenseKernelParams &kp, cons
   if (isL) s.LU[__popcll(bL & lanemask_lt(lane))] = lane;
   if (isU) s.LU[nl + __popcll(bU & lanemask_lt(lane))] = lane;
   const int na = nl + nu, K = n + na;
-  wave_sync();
+  wave_lds_fence();
 
   // Hp (lower, row r per lane) :159-177 and h :179-182
   double h = 0.0;
@@ -229,7 +229,7 @@ __device__ inline void qp_polish(const Lds &s, const DenseKernelParams &kp, cons
     s.W[tri(lane, lane)] = 0.0 - kp.delta;
     h                     = (a < nl) ? syr * s.l[row] : syr * s.u[row];
   }
-  wave_sync();
+  wave_lds_fence();
 
   if (!ldlt_factor_lds(K, s.W, s.perm, s.temp, lane)) return;  // :187-190
 
@@ -239,7 +239,7 @@ __device__ inline void qp_polish(const Lds &s, const DenseKernelParams &kp, cons
   double *xch = s.temp;
   for (uint32_t it = 0; it != kp.polish_iter; ++it) {
     if (lane < K) tv[lane] = t;
-    wave_sync();
+    wave_lds_fence();
     double res = 0.0;
     if (lane < n) {
       const int r      = lane;
@@ -261,14 +261,14 @@ __device__ inline void qp_polish(const Lds &s, const DenseKernelParams &kp, cons
       for (int j = 0; j < n; ++j) acc = fma(syr * s.A[row + j * m] * s.sx[j], tv[j], acc);
       res = h - acc;
     }
-    wave_sync();
+    wave_lds_fence();
     const double d = ldlt_solve_lds(K, s.W, s.perm, xch, res, lane);
     t += d;
   }
   // :199-201
   if (lane < n) s.xv[lane] = t;
   else if (lane < K) s.yv[s.LU[lane - n]] = t;
-  wave_sync();
+  wave_lds_fence();
 }
 
 
@@ -294,7 +294,7 @@ __device__ inline int qp_setup(const Lds &s, const DenseKernelParams &kp, const 
     if (lane < n) s.sx[lane] = 1.0;  // analyze(): :306-308
     if (lane < m) s.sy[lane] = 1.0;
   }
-  wave_sync();
+  wave_lds_fence();
 
   // ---- scaling :347 ----
   c = 1.0;
@@ -319,7 +319,7 @@ __device__ inline int qp_setup(const Lds &s, const DenseKernelParams &kp, const 
     }
     if (wave_ballot(bad)) ret_code = SFB_QP_PRIMAL_INFEASIBLE;
   }
-  wave_sync();
+  wave_lds_fence();
 
   // ---- KKT (lower triangle, row r per lane) :399-404 ----
   if (lane < n) {
@@ -337,7 +337,7 @@ __device__ inline int qp_setup(const Lds &s, const DenseKernelParams &kp, const 
     for (int j = n; j < lane; ++j) s.W[tri(lane, j)] = 0.0;
     s.W[tri(lane, lane)] = 1.0 / (-s.rho[i]);
   }
-  wave_sync();
+  wave_lds_fence();
 
   // ---- pivoted LDL' :428-433 ----
   if (!ldlt_factor_lds(k, s.W, s.perm, s.temp, lane)) ret_code = SFB_QP_UNKNOWN;
@@ -360,14 +360,14 @@ __device__ inline void qp_finish(const Lds &s, const DenseKernelParams &kp, cons
     s.dxus[lane]    = xo;
   }
   if (lane < m) g.y[b * m + lane] = s.sy[lane] * s.yv[lane] / c;
-  wave_sync();
+  wave_lds_fence();
   if (g.obj != nullptr) {
     if (lane < n) {
       double acc = 0.0;
       for (int j = 0; j < n; ++j) acc = fma(0.5 * s.P[lane + j * n], s.dxus[j], acc);
       s.temp[lane] = acc + s.q[lane];
     }
-    wave_sync();
+    wave_lds_fence();
     if (lane == 0) {
       double o = 0.0;
       for (int i = 0; i < n; ++i) o = fma(s.dxus[i], s.temp[i], o);
@@ -378,7 +378,7 @@ __device__ inline void qp_finish(const Lds &s, const DenseKernelParams &kp, cons
     g.code[b] = (ret_code >= 0) ? ret_code : SFB_QP_MAX_ITERATIONS;
     if (g.iter != nullptr) g.iter[b] = iter;
   }
-  wave_sync();
+  wave_lds_fence();
 }
 
 }  // namespace sfb
