@@ -168,7 +168,9 @@ sfb_status sfb_sparse_qp_solve_batch(sfb_sparse_qp_plan *plan, const sfb_qp_para
                                      const double *u, const double *warm_x, const double *warm_y, double *x,
                                      double *y, double *obj, uint32_t *iter, int32_t *code, void *workspace,
                                      void *stream);
-/* Same with host pointers (allocates the workspace internally; synchronous). */
+/* Same with host pointers (synchronous).  The device buffers are owned by the plan and kept between calls
+ * (grow-only, freed by sfb_sparse_qp_plan_destroy) -- the analogue of the working memory a QPSolver object
+ * keeps between solves (qp_solver.hpp:242-338); host-pointer calls on ONE plan are serialised. */
 sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
                                           const double *Px, const double *q, const double *Ax, const double *l,
                                           const double *u, const double *warm_x, const double *warm_y,

@@ -20,6 +20,12 @@ struct sfb_sparse_qp_plan {
     sfb::SparsePlanDev dev{};
   };
   std::map<int, DevCopy> per_device;  // device ordinal -> uploaded index arrays
+  // Device memory of the host-pointer entry point, kept between calls like the working memory a
+  // smooth::feedback::QPSolver object keeps between solves (qp_solver.hpp:242-338): a swarm that ticks at
+  // a fixed batch size allocates its ~1.3 MB per agent once, not every tick.  Guarded by host_mu (calls
+  // with host pointers on one plan are serialised; device-pointer calls bring their own workspace).
+  std::mutex host_mu;
+  std::map<int, std::pair<char *, size_t>> host_ws;  // device ordinal -> (buffer, bytes)
 };
 
 namespace {
@@ -124,6 +130,8 @@ void sfb_sparse_qp_plan_destroy(sfb_sparse_qp_plan *plan)
   if (!plan) return;
   for (auto &kv : plan->per_device)
     if (kv.second.blob) (void)hipFree(kv.second.blob);
+  for (auto &kv : plan->host_ws)
+    if (kv.second.first) (void)hipFree(kv.second.first);
   delete plan;
 }
 
@@ -183,9 +191,22 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
   const size_t wsd  = sfb::qp_sparse_ws_doubles(h.n, h.m, h.nnzL, h.funits, h.bunits);
   const size_t in_d = B * (NP + N + NA + 2 * M) + (warm_x ? B * (N + M) : 0), out_d = B * (N + M + 1);
   const size_t bytes = (in_d + out_d + B * wsd) * sizeof(double) + B * 8;
-  char *devmem = nullptr;
-  hipError_t e = hipMalloc(reinterpret_cast<void **>(&devmem), bytes);
-  if (e != hipSuccess) return sfb::hip_fail(e, "hipMalloc");
+  int devid    = 0;
+  hipError_t e = hipGetDevice(&devid);
+  if (e != hipSuccess) return sfb::hip_fail(e, "hipGetDevice");
+  std::lock_guard<std::mutex> host_lock(plan->host_mu);
+  auto &cache = plan->host_ws[devid];
+  if (cache.second < bytes) {  // grow-only
+    if (cache.first) (void)hipFree(cache.first);
+    cache = {nullptr, 0};
+    e     = hipMalloc(reinterpret_cast<void **>(&cache.first), bytes);
+    if (e != hipSuccess) {
+      cache = {nullptr, 0};
+      return sfb::hip_fail(e, "hipMalloc");
+    }
+    cache.second = bytes;
+  }
+  char *devmem = cache.first;
   double *dPx = reinterpret_cast<double *>(devmem);
   double *dq = dPx + B * NP, *dAx = dq + B * N, *dl = dAx + B * NA, *du = dl + B * M;
   double *dwx = nullptr, *dwy = nullptr, *dx = du + B * M;
@@ -216,7 +237,6 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
     if ((e = D2H(code, dcode, B * 4)) != hipSuccess) break;
   } while (false);
   if (e != hipSuccess) st = sfb::hip_fail(e, "sfb_sparse_qp_solve_batch_host");
-  (void)hipFree(devmem);
   return st;
 }
 
