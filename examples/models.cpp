@@ -524,3 +524,43 @@ int sfbx_asif_swarm_step(int64_t batch, uint64_t seed, int K, int ticks, double 
     return 1;
   }
 }
+
+namespace {
+template<int Nx>
+void predict_linear_case(const double * Ac, const double * Fc, double * err)
+{
+  Mat<Nx, Nx> A{}, F{};
+  for (int i = 0; i < Nx * Nx; ++i) { A.a[i] = Ac[i]; F.a[i] = Fc[i]; }
+  std::mt19937_64 rng(11 + Nx);
+  std::uniform_real_distribution<double> d(-1.0, 1.0);
+  EKF<Rn<Nx>, EKFStepper::RK4> ekf;
+  Rn<Nx> xhat;
+  Mat<Nx, Nx> P{};
+  for (int i = 0; i < Nx; ++i) { xhat.v[i] = d(rng); P(i, i) = d(rng) + 1.1; }
+  ekf.reset(xhat, P);
+  ekf.predict([&](double, const Rn<Nx> & x) { return A * x.v; }, Mat<Nx, Nx>::Zero(), 0.7, 1e-3);
+  const Vec<Nx> xe = F * xhat.v;
+  Mat<Nx, Nx> Ft{};
+  for (int r = 0; r < Nx; ++r) for (int c = 0; c < Nx; ++c) Ft(r, c) = F(c, r);
+  const Mat<Nx, Nx> Pe = F * P * Ft;
+  double nx = 0, dx = 0, np = 0, dp = 0;
+  const auto est = ekf.estimate();
+  const auto cov = ekf.covariance();
+  for (int i = 0; i < Nx; ++i) { nx = std::max(nx, std::fabs(xe[i])); dx = std::max(dx, std::fabs(xe[i] - est.v[i])); }
+  for (int i = 0; i < Nx * Nx; ++i) { np = std::max(np, std::fabs(Pe.a[i])); dp = std::max(dp, std::fabs(Pe.a[i] - cov.a[i])); }
+  err[0] = std::max(err[0], dx / nx);
+  err[1] = std::max(err[1], dp / np);
+}
+}  // namespace
+
+int sfbx_test_ekf_predict_linear(const double * A3, const double * F3, const double * A6, const double * F6, double * err)
+{
+  try {
+    err[0] = err[1] = 0.0;
+    predict_linear_case<3>(A3, F3, err);
+    predict_linear_case<6>(A6, F6, err);
+    return 0;
+  } catch (const std::exception &) {
+    return 1;
+  }
+}

@@ -32,6 +32,10 @@ double sfbx_lie_selftest(void);
  * (tests/test_ekf.cpp:155-180), UpdateLinear (:50-103, R^3 / Ny 3) and an SE2 predict+update smoke.
  * Returns 0 and writes max errors: err[0] time-cut, err[1] linear update state, err[2] linear update cov. Needs a GPU. */
 int sfbx_test_ekf(double *err);
+/* PredictLinear (tests/test_ekf.cpp:104-153) with EKF<R^Nx, RK4>, dt = 1e-3, tau = 0.7, Q = 0, Nx in {3, 6}:
+ * err[0] = max relative error of the estimate vs expm(A tau) xhat, err[1] = of the covariance vs F P F'.
+ * The exact F (Nx*Nx, column-major, for Nx = 3 then 6) is supplied by the caller.  Needs a GPU. */
+int sfbx_test_ekf_predict_linear(const double *A3, const double *F3, const double *A6, const double *F6, double *err);
 /* asif_to_qp() (include/smooth_feedback_amd/asif.hpp) for the case of tests/test_asif.cpp:37-95: X = SE2, f = (u0, 0, u1),
  * h = position (nh = 2), bu = (-0.1, 1), K = 3, input box [-1,1]^2 around c = 0, T = 1, alpha = 1, dt = 0.1.
  * x0 = (angle, px, py).  Out, column-major: P[9] q[3] A[9*3] l[9] u[9].  Host only (no GPU). */

@@ -196,6 +196,13 @@ sfb_status sfb_ekf_predict_batch(int64_t batch, int dof, const double *A, const 
                                  const double *dt, int dt_shared, double *P, void *stream);
 sfb_status sfb_ekf_update_batch(int64_t batch, int dof, int ny, const double *H, const double *R, int r_shared,
                                 const double *r, double *P, double *delta, int32_t *info, void *stream);
+/* predict with an explicit choice of the stepper (ekf.hpp:27-31: the Stp template argument): ONE step of the
+ * covariance ODE dP/dt = symU(A P + P A' + Q), A frozen during the step (ekf.hpp:86-96), by explicit Euler
+ * (SFB_EKF_EULER == sfb_ekf_predict_batch) or by boost::numeric::odeint::runge_kutta4 (SFB_EKF_RK4, the stepper
+ * tests/test_ekf.cpp:113-115 instantiates).  The state step g <- stepper(g) stays on the host. */
+typedef enum { SFB_EKF_EULER = 0, SFB_EKF_RK4 = 1 } sfb_ekf_stepper;
+sfb_status sfb_ekf_predict_stepper_batch(int stepper, int64_t batch, int dof, const double *A, const double *Q,
+                                         int q_shared, const double *dt, int dt_shared, double *P, void *stream);
 /* predict immediately followed by update in one launch (one pass over P). */
 sfb_status sfb_ekf_predict_update_batch(int64_t batch, int dof, int ny, const double *A, const double *Q,
                                         int q_shared, const double *dt, int dt_shared, const double *H,
@@ -203,6 +210,8 @@ sfb_status sfb_ekf_predict_update_batch(int64_t batch, int dof, int ny, const do
                                         double *delta, int32_t *info, void *stream);
 /* Host-pointer variants (stage through device memory, synchronous).  Pass NULL A to skip predict,
  * NULL H to skip update. */
+sfb_status sfb_ekf_predict_stepper_batch_host(int stepper, int64_t batch, int dof, const double *A, const double *Q,
+                                              int q_shared, const double *dt, int dt_shared, double *P);
 sfb_status sfb_ekf_step_batch_host(int64_t batch, int dof, int ny, const double *A, const double *Q, int q_shared,
                                    const double *dt, int dt_shared, const double *H, const double *R,
                                    int r_shared, const double *r, double *P, double *delta, int32_t *info);

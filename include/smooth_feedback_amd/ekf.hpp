@@ -5,8 +5,10 @@
 //
 // Derivatives: analytic if the callable offers jacobian(...), else forward differences with step
 // sqrt(eps) (the reference's default without the autodiff header, SURVEY.md section 8 notes).
-// Stepper: explicit Euler (the reference's default template argument, ekf.hpp:30); predict(f, Q, tau, dt)
-// runs ceil(tau/dt) substeps and re-linearises before each one, covariance first (ekf.hpp:93-102).
+// Stepper (ekf.hpp:27-31, the Stp template argument): explicit Euler (the reference's default) or
+// runge_kutta4 (the one tests/test_ekf.cpp:113-115 instantiates); predict(f, Q, tau, dt) runs ceil(tau/dt)
+// substeps and re-linearises before each one, covariance first (ekf.hpp:93-102).  The state is stepped on
+// the group with the same tableau (stage states g (+) dt a_ij k_j, result g (+) dt sum b_i k_i).
 #pragma once
 #include <sfb.h>
 
@@ -48,8 +50,10 @@ Mat<G::Dof, G::Dof> ekf_linearise_dyn(F && f, const G & g, typename G::Tangent &
 }
 }  // namespace detail
 
-/// smooth::feedback::EKF<G>, ekf.hpp:39-149 (Euler stepper, measurement space R^Ny)
-template<class G>
+enum class EKFStepper { Euler = SFB_EKF_EULER, RK4 = SFB_EKF_RK4 };
+
+/// smooth::feedback::EKF<G, DT, Stp>, ekf.hpp:39-149 (measurement space R^Ny)
+template<class G, EKFStepper Stp = EKFStepper::Euler>
 class EKF {
 public:
   static constexpr int N = G::Dof;
@@ -69,10 +73,21 @@ public:
       typename G::Tangent fv;
       const CovT A = detail::ekf_linearise_dyn<G>([&](const G & x) { return f(t, x); }, g_hat_, fv);
       // covariance first: it depends on g_hat_ (:94-96)
-      detail::ekf_check(sfb_ekf_step_batch_host(1, N, 1, A.a.data(), Q.a.data(), 1, &h, 1, nullptr, nullptr, 0, nullptr,
-                                                P_.a.data(), nullptr, nullptr));
-      for (auto & v : fv) v *= h;
-      g_hat_ = rplus(g_hat_, fv);  // euler on the group: g <- g (+) dt f (:97)
+      detail::ekf_check(sfb_ekf_predict_stepper_batch_host(static_cast<int>(Stp), 1, N, A.a.data(), Q.a.data(), 1, &h, 1,
+                                                           P_.a.data()));
+      if constexpr (Stp == EKFStepper::Euler) {
+        for (auto & v : fv) v *= h;
+        g_hat_ = rplus(g_hat_, fv);  // euler on the group: g <- g (+) dt f (:97)
+      } else {
+        auto scaled = [](typename G::Tangent k, double c) { for (auto & v : k) v *= c; return k; };
+        const auto k1 = fv;
+        const auto k2 = f(t + 0.5 * h, rplus(g_hat_, scaled(k1, 0.5 * h)));
+        const auto k3 = f(t + 0.5 * h, rplus(g_hat_, scaled(k2, 0.5 * h)));
+        const auto k4 = f(t + h, rplus(g_hat_, scaled(k3, h)));
+        typename G::Tangent d{};
+        for (int i = 0; i < N; ++i) d[i] = h * (1.0 / 6.0) * k1[i] + h * (1.0 / 3.0) * k2[i] + h * (1.0 / 3.0) * k3[i] + h * (1.0 / 6.0) * k4[i];
+        g_hat_ = rplus(g_hat_, d);
+      }
     };
     while (t + dt_v < tau) {
       step(dt_v);

@@ -9,8 +9,8 @@
  * device path.  Matrices are column-major (Eigen default), item-major contiguous.
  *
  * PARITY STATUS: pinned by the reference's own analytic checks (tests/test_ekf.cpp:50-103 linear
- * Kalman update identities, :105-153 propagation against expm with many small Euler steps) in
- * tests/test_oracle_ekf.py; summation orders inside Eigen's small products are unpinned, the fixed
+ * Kalman update identities, :105-153 propagation against expm, with many small Euler steps and with the
+ * test's own runge_kutta4 stepper) in tests/test_oracle_ekf.py; summation orders inside Eigen's small products are unpinned, the fixed
  * order used here (k ascending, fma) is shared with the HIP kernel.
  */
 #include <math.h>
@@ -35,6 +35,42 @@ void oracle_ekf_predict(int dof, const double *A, const double *Q, double dt, do
     }
   for (int e = 0; e < n * n; ++e) P[e] = P[e] + dt * dP[e];
   free(dP);
+}
+
+/* Covariance right-hand side  dP = symU(A P + P A' + Q)  (ekf.hpp:84-89), all n*n entries written */
+static void ekf_cov_rhs(int n, const double *A, const double *Q, const double *P, double *dP)
+{
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i <= j; ++i) {
+      double m1 = 0.0, m2 = 0.0;
+      for (int k = 0; k < n; ++k) m1 = fma(A[i + k * n], P[k + j * n], m1);
+      for (int k = 0; k < n; ++k) m2 = fma(P[i + k * n], A[j + k * n], m2);
+      const double s = (m1 + m2) + Q[i + j * n];
+      dP[i + j * n]  = s;
+      dP[j + i * n]  = s;
+    }
+}
+
+/* One step of boost::numeric::odeint::runge_kutta4 (the stepper tests/test_ekf.cpp:113-115 instantiates;
+ * explicit_generic_rk with a = {1/2; 0,1/2; 0,0,1}, b = {1/6,1/3,1/3,1/6}) on the covariance ODE with A
+ * frozen (ekf.hpp:86-96).  Stage states  P + (dt a_ij) k_j ; result  P + (dt b1) k1 + (dt b2) k2 + (dt b3) k3
+ * + (dt b4) k4  accumulated left to right (odeint's scale_sum5).  Zero tableau entries add exact zeros. */
+void oracle_ekf_predict_rk4(int dof, const double *A, const double *Q, double dt, double *P)
+{
+  const int n = dof, nn = dof * dof;
+  double *k  = (double *)malloc(sizeof(double) * (size_t)nn);
+  double *Pi = (double *)malloc(sizeof(double) * (size_t)nn);
+  double *S  = (double *)malloc(sizeof(double) * (size_t)nn);
+  const double b1 = dt * (1.0 / 6.0), b2 = dt * (1.0 / 3.0), c2 = dt * 0.5, c4 = dt * 1.0;
+  ekf_cov_rhs(n, A, Q, P, k);                                   /* k1 */
+  for (int e = 0; e < nn; ++e) { S[e] = P[e] + b1 * k[e]; Pi[e] = P[e] + c2 * k[e]; }
+  ekf_cov_rhs(n, A, Q, Pi, k);                                  /* k2 */
+  for (int e = 0; e < nn; ++e) { S[e] = S[e] + b2 * k[e]; Pi[e] = P[e] + c2 * k[e]; }
+  ekf_cov_rhs(n, A, Q, Pi, k);                                  /* k3 */
+  for (int e = 0; e < nn; ++e) { S[e] = S[e] + b2 * k[e]; Pi[e] = P[e] + c4 * k[e]; }
+  ekf_cov_rhs(n, A, Q, Pi, k);                                  /* k4 */
+  for (int e = 0; e < nn; ++e) P[e] = S[e] + b1 * k[e];
+  free(k); free(Pi); free(S);
 }
 
 /* ekf.hpp:119-138.  H: ny x dof, R: ny x ny (upper used), r = y (-) h(g): ny.  Outputs: delta (dof)
@@ -105,6 +141,14 @@ void oracle_ekf_predict_batch(int64_t batch, int dof, const double *A, const dou
   for (int64_t b = 0; b < batch; ++b)
     oracle_ekf_predict(dof, A + (size_t)b * nn, q_shared ? Q : Q + (size_t)b * nn, dt_shared ? dt[0] : dt[b],
                        P + (size_t)b * nn);
+}
+void oracle_ekf_predict_rk4_batch(int64_t batch, int dof, const double *A, const double *Q, int q_shared,
+                                  const double *dt, int dt_shared, double *P)
+{
+  const size_t nn = (size_t)dof * dof;
+  for (int64_t b = 0; b < batch; ++b)
+    oracle_ekf_predict_rk4(dof, A + (size_t)b * nn, q_shared ? Q : Q + (size_t)b * nn, dt_shared ? dt[0] : dt[b],
+                           P + (size_t)b * nn);
 }
 void oracle_ekf_update_batch(int64_t batch, int dof, int ny, const double *H, const double *R, int r_shared,
                              const double *r, double *P, double *delta, int32_t *info)

@@ -67,6 +67,8 @@ def lib():
         L.oracle_qp_sparse_solve_batch.restype = C.c_int
         L.oracle_ekf_predict_batch.argtypes = [C.c_int64, C.c_int, dp, dp, C.c_int, dp, C.c_int, dp]
         L.oracle_ekf_predict_batch.restype = None
+        L.oracle_ekf_predict_rk4_batch.argtypes = [C.c_int64, C.c_int, dp, dp, C.c_int, dp, C.c_int, dp]
+        L.oracle_ekf_predict_rk4_batch.restype = None
         L.oracle_ekf_update_batch.argtypes = [C.c_int64, C.c_int, C.c_int, dp, dp, C.c_int, dp, dp, dp,
                                               C.POINTER(C.c_int32)]
         L.oracle_ekf_update_batch.restype = None
@@ -169,14 +171,15 @@ def qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Ax, l, u, perm=None, params=Non
     return dict(x=x, y=y, obj=obj, iter=it, code=code, nnzL=nnzL.value)
 
 
-def ekf_predict_batch(A, Q, dt, P):
+def ekf_predict_batch(A, Q, dt, P, stepper="euler"):
     """A, P: (B, dof*dof) col-major flat; Q: (B, dof*dof) or (dof*dof,) shared; dt: (B,) or scalar.
-    Returns the new P (B, dof*dof)."""
+    stepper: "euler" (ekf.hpp:30 default) or "rk4" (odeint runge_kutta4).  Returns the new P (B, dof*dof)."""
     A = np.ascontiguousarray(A, dtype=np.float64); P = np.array(P, dtype=np.float64, order="C")
     B, nn = A.shape
     dof = int(round(nn ** 0.5))
     Q = np.ascontiguousarray(Q, dtype=np.float64); dt = np.ascontiguousarray(np.atleast_1d(dt), dtype=np.float64)
-    lib().oracle_ekf_predict_batch(B, dof, _dp(A), _dp(Q), int(Q.ndim == 1), _dp(dt), int(dt.size == 1), _dp(P))
+    fn = lib().oracle_ekf_predict_rk4_batch if stepper == "rk4" else lib().oracle_ekf_predict_batch
+    fn(B, dof, _dp(A), _dp(Q), int(Q.ndim == 1), _dp(dt), int(dt.size == 1), _dp(P))
     return P
 
 

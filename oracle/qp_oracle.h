@@ -101,6 +101,9 @@ void oracle_ldlt_solve(int k, const double *W, int ld, const int *tr, double *b)
 
 /* EKF matrix part (oracle/ekf_oracle.c), ekf.hpp:84-102 (Euler substep) and :119-138. */
 void oracle_ekf_predict(int dof, const double *A, const double *Q, double dt, double *P);
+void oracle_ekf_predict_rk4(int dof, const double *A, const double *Q, double dt, double *P);
+void oracle_ekf_predict_rk4_batch(int64_t batch, int dof, const double *A, const double *Q, int q_shared,
+                                  const double *dt, int dt_shared, double *P);
 int oracle_ekf_update(int dof, int ny, const double *H, const double *R, const double *r, double *P, double *delta);
 void oracle_ekf_predict_batch(int64_t batch, int dof, const double *A, const double *Q, int q_shared, const double *dt,
                               int dt_shared, double *P);

@@ -8,7 +8,7 @@ from .qp import (QPBatchSolution, QPSolution, QPSolutionStatus, QPSolver, QPSolv
                  QuadraticProgram, pack_colmajor, random_qp_batch, solve_qp, solve_qp_batch_device,
                  solve_qp_batch_host, QuadraticProgramSparse, SparseQPPlan, solve_qp_sparse)
 
-from .ekf import (ekf_predict_batch_device, ekf_predict_update_batch_device, ekf_step_batch_host,  # noqa: F401
-                  ekf_update_batch_device)
+from .ekf import (ekf_predict_batch_device, ekf_predict_batch_host, ekf_predict_stepper_batch_device,  # noqa: F401
+                  ekf_predict_update_batch_device, ekf_step_batch_host, ekf_update_batch_device)
 
 __version__ = "0.1.0"

@@ -70,6 +70,8 @@ def _load():
     L.sfb_sparse_qp_solve_batch.argtypes = [C.c_void_p, C.POINTER(SfbQPParams), i64] + [dp] * 12 + [vp, vp]
     L.sfb_sparse_qp_solve_batch_host.argtypes = [C.c_void_p, C.POINTER(SfbQPParams), i64] + [dp] * 12
     L.sfb_ekf_predict_batch.argtypes = [i64, i32, dp, dp, i32, dp, i32, dp, vp]
+    L.sfb_ekf_predict_stepper_batch.argtypes = [i32, i64, i32, dp, dp, i32, dp, i32, dp, vp]
+    L.sfb_ekf_predict_stepper_batch_host.argtypes = [i32, i64, i32, dp, dp, i32, dp, i32, dp]
     L.sfb_ekf_update_batch.argtypes = [i64, i32, i32, dp, dp, i32, dp, dp, dp, dp, vp]
     L.sfb_ekf_predict_update_batch.argtypes = [i64, i32, i32, dp, dp, i32, dp, i32, dp, dp, i32, dp, dp, dp, dp, vp]
     L.sfb_ekf_step_batch_host.argtypes = [i64, i32, i32, dp, dp, i32, dp, i32, dp, dp, i32, dp, dp, dp, dp]

@@ -42,6 +42,59 @@ sfb_status sfb_ekf_predict_batch(int64_t batch, int dof, const double *A, const 
                     true, false, stream);
 }
 
+sfb_status sfb_ekf_predict_stepper_batch(int stepper, int64_t batch, int dof, const double *A, const double *Q,
+                                         int q_shared, const double *dt, int dt_shared, double *P, void *stream)
+{
+  if (stepper == SFB_EKF_EULER) return sfb_ekf_predict_batch(batch, dof, A, Q, q_shared, dt, dt_shared, P, stream);
+  if (stepper != SFB_EKF_RK4) return sfb::fail(SFB_ERR_INVALID_ARG, "unknown stepper");
+  if (batch < 0) return sfb::fail(SFB_ERR_INVALID_ARG, "batch < 0");
+  if (batch > 0 && (!A || !Q || !dt || !P)) return sfb::fail(SFB_ERR_INVALID_ARG, "predict needs A, Q, dt, P");
+  if (!sfb::ekf_supported(dof, 1, false)) return sfb::fail(SFB_ERR_UNSUPPORTED, "EKF kernels support dof in {2,3,4,6}");
+  sfb_status st = sfb::require_device();
+  if (st != SFB_OK) return st;
+  if (batch == 0) return SFB_OK;
+  sfb::EkfArgs a{};
+  a.batch = batch; a.A = A; a.Q = Q; a.dt = dt; a.q_shared = q_shared; a.dt_shared = dt_shared; a.P = P;
+  hipError_t e = sfb::ekf_rk4_launch(a, dof, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return sfb::hip_fail(e, "ekf_rk4_kernel launch");
+  return SFB_OK;
+}
+
+sfb_status sfb_ekf_predict_stepper_batch_host(int stepper, int64_t batch, int dof, const double *A, const double *Q,
+                                              int q_shared, const double *dt, int dt_shared, double *P)
+{
+  if (stepper == SFB_EKF_EULER)
+    return sfb_ekf_step_batch_host(batch, dof, 1, A, Q, q_shared, dt, dt_shared, nullptr, nullptr, 0, nullptr, P,
+                                   nullptr, nullptr);
+  if (stepper != SFB_EKF_RK4) return sfb::fail(SFB_ERR_INVALID_ARG, "unknown stepper");
+  if (batch < 0 || (batch > 0 && (!A || !Q || !dt || !P))) return sfb::fail(SFB_ERR_INVALID_ARG, "bad arguments");
+  if (!sfb::ekf_supported(dof, 1, false)) return sfb::fail(SFB_ERR_UNSUPPORTED, "EKF kernels support dof in {2,3,4,6}");
+  sfb_status st = sfb::require_device();
+  if (st != SFB_OK) return st;
+  if (batch == 0) return SFB_OK;
+  const size_t B = (size_t)batch, nn = (size_t)dof * dof;
+  const size_t nQ = q_shared ? nn : B * nn, nT = dt_shared ? 1 : B;
+  double *dev = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&dev), (2 * B * nn + nQ + nT) * sizeof(double));
+  if (e != hipSuccess) return sfb::hip_fail(e, "hipMalloc");
+  double *dP = dev, *dA = dP + B * nn, *dQ = dA + B * nn, *ddt = dQ + nQ;
+  e = hipMemcpy(dP, P, B * nn * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dA, A, B * nn * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dQ, Q, nQ * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(ddt, dt, nT * 8, hipMemcpyHostToDevice);
+  st = SFB_OK;
+  if (e == hipSuccess) {
+    st = sfb_ekf_predict_stepper_batch(stepper, batch, dof, dA, dQ, q_shared, ddt, dt_shared, dP, nullptr);
+    if (st == SFB_OK) {
+      e = hipDeviceSynchronize();
+      if (e == hipSuccess) e = hipMemcpy(P, dP, B * nn * 8, hipMemcpyDeviceToHost);
+    }
+  }
+  (void)hipFree(dev);
+  if (e != hipSuccess) return sfb::hip_fail(e, "sfb_ekf_predict_stepper_batch_host");
+  return st;
+}
+
 sfb_status sfb_ekf_update_batch(int64_t batch, int dof, int ny, const double *H, const double *R, int r_shared,
                                 const double *r, double *P, double *delta, int32_t *info, void *stream)
 {

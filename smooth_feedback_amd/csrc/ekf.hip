@@ -379,6 +379,113 @@ __global__ void __launch_bounds__(64) ekf_kernel(const EkfArgs a)
   tile_store<NN>(a.P, item0, a.batch, lds, lane);
 }
 
+// Predict with boost::numeric::odeint::runge_kutta4 on the covariance ODE, A frozen during the step
+// (ekf.hpp:86-96 with the stepper of tests/test_ekf.cpp:113-115); same stage formulas, coefficients and
+// accumulation order as oracle_ekf_predict_rk4.  One filter per lane: P, the stage state, the running
+// sum and the upper triangle of the current slope stay in registers; A is re-read from its LDS tile at
+// every use (four right-hand sides), the second tile stages P and Q.
+template<int N>
+__global__ void __launch_bounds__(64) ekf_rk4_kernel(const EkfArgs a)
+{
+  constexpr int NN = N * N, NP = NN | 1, NT = N * (N + 1) / 2, TILE = NP * kWave;
+  __shared__ double ldsA[TILE];
+  __shared__ double ldsS[TILE];
+  const int lane      = threadIdx.x;
+  const int64_t item0 = (int64_t)blockIdx.x * kWave;
+  const int64_t item  = item0 + lane;
+  const bool live     = item < a.batch;
+
+  double P[NN];
+  tile_load<NN>(a.P, item0, a.batch, ldsS, lane);
+  tile_load<NN>(a.A, item0, a.batch, ldsA, lane);
+  wave_sync();
+#pragma unroll
+  for (int e = 0; e < NN; ++e) P[e] = live ? ldsS[lane * NP + e] : 0.0;
+  wave_sync();
+  double qv[NT];
+  if (!a.q_shared) {
+    tile_load<NN>(a.Q, item0, a.batch, ldsS, lane);
+    wave_sync();
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+#pragma unroll
+    for (int i = 0; i <= j; ++i)
+      qv[i + j * (j + 1) / 2] = a.q_shared ? a.Q[i + j * N] : (live ? ldsS[lane * NP + i + j * N] : 0.0);
+  const double *Al = ldsA + lane * NP;  // lanes past the end of the batch read the zeros tile_load put there
+  const double dt  = live ? (a.dt_shared ? a.dt[0] : a.dt[item]) : 0.0;
+  const double b1 = dt * (1.0 / 6.0), b2 = dt * (1.0 / 3.0), c2 = dt * 0.5, c4 = dt * 1.0;
+
+  double X[NN], S[NN], kv[NT];
+  auto rhs = [&]() {  // kv = upper triangle of symU(A X + X A' + Q)   (ekf.hpp:88)
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+#pragma unroll
+      for (int i = 0; i <= j; ++i) {
+        double m1 = 0.0, m2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) m1 = fma(Al[i + k * N], X[k + j * N], m1);
+#pragma unroll
+        for (int k = 0; k < N; ++k) m2 = fma(X[i + k * N], Al[j + k * N], m2);
+        kv[i + j * (j + 1) / 2] = (m1 + m2) + qv[i + j * (j + 1) / 2];
+      }
+    }
+  };
+  auto kof = [&](int r, int c) { return (r <= c) ? kv[r + c * (c + 1) / 2] : kv[c + r * (r + 1) / 2]; };
+#pragma unroll
+  for (int e = 0; e < NN; ++e) X[e] = P[e];
+  rhs();  // k1
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      const double kk = kof(r, c);
+      S[r + c * N]    = P[r + c * N] + b1 * kk;
+      X[r + c * N]    = P[r + c * N] + c2 * kk;
+    }
+  rhs();  // k2
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      const double kk = kof(r, c);
+      S[r + c * N]    = S[r + c * N] + b2 * kk;
+      X[r + c * N]    = P[r + c * N] + c2 * kk;
+    }
+  rhs();  // k3
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      const double kk = kof(r, c);
+      S[r + c * N]    = S[r + c * N] + b2 * kk;
+      X[r + c * N]    = P[r + c * N] + c4 * kk;
+    }
+  rhs();  // k4
+  wave_sync();
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < N; ++c)
+#pragma unroll
+      for (int r = 0; r < N; ++r) ldsS[lane * NP + r + c * N] = S[r + c * N] + b1 * kof(r, c);
+  }
+  wave_sync();
+  tile_store<NN>(a.P, item0, a.batch, ldsS, lane);
+}
+
+hipError_t ekf_rk4_launch(const EkfArgs &a, int dof, hipStream_t stream)
+{
+  const dim3 grid((unsigned)((a.batch + kWave - 1) / kWave)), block(kWave);
+  switch (dof) {
+    case 2: hipLaunchKernelGGL((ekf_rk4_kernel<2>), grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL((ekf_rk4_kernel<3>), grid, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL((ekf_rk4_kernel<4>), grid, block, 0, stream, a); break;
+    case 6: hipLaunchKernelGGL((ekf_rk4_kernel<6>), grid, block, 0, stream, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 template<int N, int M>
 static hipError_t launch_nm(const EkfArgs &a, bool predict, bool update, hipStream_t stream)
 {

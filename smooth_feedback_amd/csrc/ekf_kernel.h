@@ -22,5 +22,7 @@ struct EkfArgs {
 
 bool ekf_supported(int dof, int ny, bool update);
 hipError_t ekf_launch(const EkfArgs &a, int dof, int ny, bool predict, bool update, hipStream_t stream);
+// predict with one runge_kutta4 step instead of one Euler step (uses A, Q, dt, P of the arguments)
+hipError_t ekf_rk4_launch(const EkfArgs &a, int dof, hipStream_t stream);
 
 }  // namespace sfb

@@ -50,6 +50,26 @@ def ekf_step_batch_host(P, dof, A=None, Q=None, dt=None, H=None, R=None, r=None)
     return P, delta, info
 
 
+STEPPERS = {"euler": 0, "rk4": 1}  # sfb_ekf_stepper
+
+
+def ekf_predict_batch_host(P, dof, A, Q, dt, stepper="euler"):
+    """One predict step on host buffers with the chosen stepper (sfb_ekf_predict_stepper_batch_host):
+    "euler" (ekf.hpp:30 default) or "rk4" (odeint runge_kutta4, tests/test_ekf.cpp:113-115).  Returns P_new."""
+    P = np.array(P, dtype=np.float64, order="C")
+    B, nn = P.shape[0], dof * dof
+    A, _ = _mat(A, B, nn); Q, qs = _mat(Q, B, nn, True)
+    dt = np.ascontiguousarray(np.atleast_1d(dt), dtype=np.float64)
+    _capi.check(_capi.lib.sfb_ekf_predict_stepper_batch_host(STEPPERS[stepper], B, dof, _ptr(A), _ptr(Q), qs, _ptr(dt),
+                                                             int(dt.size == 1), _ptr(P)))
+    return P
+
+
+def ekf_predict_stepper_batch_device(stepper, B, dof, dA, dQ, q_shared, ddt, dt_shared, dP, stream=0):
+    _capi.check(_capi.lib.sfb_ekf_predict_stepper_batch(STEPPERS[stepper], B, dof, dA, dQ, int(q_shared), ddt,
+                                                        int(dt_shared), dP, stream or None))
+
+
 def ekf_predict_update_batch_device(B, dof, ny, dA, dQ, q_shared, ddt, dt_shared, dH, dR, r_shared, dr, dP, ddelta,
                                     dinfo=0, stream=0):
     """sfb_ekf_predict_update_batch on device pointers (ints), asynchronous on `stream`."""

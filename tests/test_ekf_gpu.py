@@ -107,3 +107,40 @@ def test_cpp_front_mirrors_reference_ekf_checks(sfb):
     err = np.zeros(3)
     assert M.lib().sfbx_test_ekf(err.ctypes.data_as(C.c_void_p)) == 0
     assert err[0] < 1e-12 and err[1] < 1e-6 and err[2] < 1e-12, err
+
+
+@pytest.mark.parametrize("dof", [2, 3, 4, 6])
+@pytest.mark.parametrize("B", [1, 65, 3000])
+def test_rk4_predict_matches_oracle(sfb, oracle, dof, B):
+    """sfb_ekf_predict_stepper_batch(SFB_EKF_RK4): same bits as the oracle's runge_kutta4 step, per-item and
+    shared Q / dt, non-symmetric P and Q included; the Euler selector is the plain predict."""
+    rng = np.random.default_rng(900 + dof * 10 + B)
+    P = _flat(_spd(rng, B, dof) + 0.05 * rng.uniform(-1, 1, (B, dof, dof)))
+    A = _flat(rng.uniform(-1, 1, (B, dof, dof)))
+    Q = _flat(0.1 * np.tile(np.eye(dof), (B, 1, 1)) + 0.02 * rng.uniform(-1, 1, (B, dof, dof)))
+    dt = rng.uniform(0.005, 0.1, B)
+    got = sfb.ekf_predict_batch_host(P, dof, A, Q, dt, stepper="rk4")
+    ref = oracle.ekf_predict_batch(A, Q, dt, P, stepper="rk4")
+    assert np.array_equal(got, ref)
+    got = sfb.ekf_predict_batch_host(P, dof, A, Q[0].copy(), 0.025, stepper="rk4")
+    ref = oracle.ekf_predict_batch(A, Q[0].copy(), 0.025, P, stepper="rk4")
+    assert np.array_equal(got, ref)
+    got = sfb.ekf_predict_batch_host(P, dof, A, Q, dt, stepper="euler")
+    assert np.array_equal(got, oracle.ekf_predict_batch(A, Q, dt, P))
+
+
+def test_cpp_front_predict_linear_with_rk4(sfb):
+    """tests/test_ekf.cpp:104-153 through EKF<R^Nx, RK4> (include/smooth_feedback_amd/ekf.hpp): 700 substeps of
+    1e-3, estimate and covariance against expm.  The reference asserts 1e-3 relative."""
+    import ctypes as C
+    import scipy.linalg as sl
+    import models_lib as M
+    rng = np.random.default_rng(77)
+    A3, A6 = rng.uniform(-1, 1, (3, 3)), rng.uniform(-1, 1, (6, 6))
+    F3, F6 = sl.expm(0.7 * A3), sl.expm(0.7 * A6)
+    err = np.zeros(2)
+    cm = lambda a: np.ascontiguousarray(a.flatten("F"))
+    bufs = [cm(A3), cm(F3), cm(A6), cm(F6)]
+    rc = M.lib().sfbx_test_ekf_predict_linear(*[b.ctypes.data_as(C.c_void_p) for b in bufs], err.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    assert err[0] < 1e-6 and err[1] < 1e-6, err

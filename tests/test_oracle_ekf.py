@@ -47,3 +47,38 @@ def test_predict_uses_upper_triangle_of_the_sum(oracle):
     S = A @ P + P @ A.T + Q
     S = np.triu(S) + np.triu(S, 1).T
     assert np.allclose(Pn[0].reshape(n, n, order="F"), P + 0.1 * S, atol=1e-15)
+
+
+@pytest.mark.parametrize("Nx", [3, 6, 9])
+def test_predict_linear_rk4(oracle, Nx):
+    """tests/test_ekf.cpp:104-153 as written there: runge_kutta4 stepper, dt = 1e-3, tau = 0.7, Q = 0 ->
+    P(tau) = F P F', F = expm(A tau).  RK4 at this step reaches the exact solution to ~1e-12; the reference
+    asserts 1e-3."""
+    rng = np.random.default_rng(40 + Nx)
+    A = rng.uniform(-1, 1, (Nx, Nx))
+    P = np.diag(rng.uniform(-1, 1, Nx) + 1.1)
+    tau, dt = 0.7, 1e-3
+    Pc = P.flatten("F")[None].copy()
+    t = 0.0
+    while t + dt < tau:                      # ekf.hpp:93-101: fixed steps, then the remainder
+        Pc = oracle.ekf_predict_batch(A.flatten("F")[None], np.zeros(Nx * Nx), dt, Pc, stepper="rk4")
+        t += dt
+    Pc = oracle.ekf_predict_batch(A.flatten("F")[None], np.zeros(Nx * Nx), tau - t, Pc, stepper="rk4")
+    F = sl.expm(A * tau)
+    assert np.allclose(Pc[0].reshape(Nx, Nx, order="F"), F @ P @ F.T, rtol=1e-9, atol=1e-9)
+
+
+def test_rk4_step_matches_a_numpy_transcription(oracle):
+    """One step against the textbook RK4 formulas in numpy (symmetrised right-hand side, Q != 0)."""
+    rng = np.random.default_rng(3)
+    n, dt = 6, 0.05
+    A, Q = rng.uniform(-1, 1, (n, n)), np.diag(rng.uniform(0.1, 1.0, n))
+    G = rng.uniform(-1, 1, (n, n)); P = np.eye(n) + G @ G.T / n
+
+    def f(Pm):
+        S = A @ Pm + Pm @ A.T + Q
+        return np.triu(S) + np.triu(S, 1).T
+    k1 = f(P); k2 = f(P + dt / 2 * k1); k3 = f(P + dt / 2 * k2); k4 = f(P + dt * k3)
+    ref = P + dt / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+    got = oracle.ekf_predict_batch(A.flatten("F")[None], Q.flatten("F")[None], dt, P.flatten("F")[None], stepper="rk4")
+    assert np.allclose(got[0].reshape(n, n, order="F"), ref, rtol=1e-13, atol=1e-13)
