@@ -291,7 +291,7 @@ __device__ inline void sweep_dev(const int32_t *__restrict__ idx, const int unit
 __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, double *t, const int lane)
 {
   const int k = pl.k;
-  sweep_dev<SFB_SWEEP_DEPTH, true>(pl.fidx, pl.funits, w.LxF, t, lane);   // forward (column oriented order)
+  sweep_dev<SFB_SWEEP_DEPTH, false>(pl.fidx, pl.funits, w.LxF, t, lane);  // forward (column oriented order)
   for (int j0 = lane; j0 < k; j0 += kWave * 8) {  // D^-1 (:458), loads batched
     double dv[8];
 #pragma unroll

@@ -323,43 +323,80 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
   // packed sweep schedules (see sparse_plan.h)
   if (k + 1 >= (1 << 16)) { *msg = "n+m too large for the packed sweep encoding (max 65534)"; return false; }
   auto build = [&](bool forward, std::vector<int32_t> &xmap, std::vector<int32_t> &xidx, int &units) {
-    const int cap = forward ? 64 : 128;  // slots per dependent step
-    std::vector<int32_t> last_write(k, -1), fill;
-    std::vector<std::vector<std::array<int32_t, 3>>> slots;  // per step: (pos, tgt, piv)
+    const int cap = 128;  // slots per dependent step
+    // Critical-path list scheduling.  Slot = one entry of L, enumerated in the sequential sweep order.  It
+    // depends on (a) the previous update of its target (per-target order = the sequential one) and (b) the
+    // last update of its pivot (the pivot must be final).  Steps are filled with the ready slots of greatest
+    // height (longest chain of dependants), which keeps the schedule close to max(critical path, slots/cap).
+    struct Slot { int32_t pos, tgt, piv; };
+    std::vector<Slot> sl;
+    sl.reserve(o.nnzL);
+    std::vector<int32_t> col_first(k + 1, 0);  // slots with pivot j (in order of t): [col_first[t], col_first[t+1])
     for (int t = 0; t < k; ++t) {
       const int j = forward ? t : k - 1 - t;
+      col_first[t] = (int32_t)sl.size();
       const int p0 = forward ? o.Lp[j] : o.Rp[j], p1 = forward ? o.Lp[j + 1] : o.Rp[j + 1];
-      if (p0 == p1) continue;
-      int s = last_write[j] + 1;
-      for (int p = p0; p < p1; ++p) s = std::max(s, last_write[forward ? o.Li[p] : o.Rk[p]] + 1);
-      int p = p0;
-      while (p < p1) {
-        if ((int)slots.size() <= s) { slots.resize(s + 1); fill.resize(s + 1, 0); }
-        while (fill[s] >= cap) {
-          ++s;
-          if ((int)slots.size() <= s) { slots.resize(s + 1); fill.resize(s + 1, 0); }
+      for (int p = p0; p < p1; ++p) sl.push_back({forward ? p : o.Rpos[p], forward ? o.Li[p] : o.Rk[p], j});
+    }
+    col_first[k] = (int32_t)sl.size();
+    const int ns = (int)sl.size();
+    auto tof = [&](int j) { return forward ? j : k - 1 - j; };  // position of pivot j in the processing order
+    std::vector<int32_t> prev_same(ns, -1), next_same(ns, -1), last_upd(k, -1);
+    for (int q = 0; q < ns; ++q) {
+      const int tg = sl[q].tgt;
+      if (last_upd[tg] >= 0) { prev_same[q] = last_upd[tg]; next_same[last_upd[tg]] = q; }
+      last_upd[tg] = q;
+    }
+    // heights, reverse order (every dependant of a slot has a larger number)
+    std::vector<int32_t> height(ns, 1), colh(k, 0);
+    for (int q = ns - 1; q >= 0; --q) {
+      int h = 0;
+      if (next_same[q] >= 0) h = height[next_same[q]];
+      else h = std::max(h, (int)colh[sl[q].tgt]);  // last update of its target: the target's own slots wait for it
+      height[q] = h + 1;
+      colh[sl[q].piv] = std::max(colh[sl[q].piv], height[q]);
+    }
+    std::vector<int32_t> npred(ns, 0);
+    for (int q = 0; q < ns; ++q) npred[q] = (prev_same[q] >= 0 ? 1 : 0) + (last_upd[sl[q].piv] >= 0 ? 1 : 0);
+    std::vector<std::vector<std::array<int32_t, 3>>> slots;  // per step: (pos, tgt, piv)
+    std::vector<std::pair<int32_t, int32_t>> heap;          // (height, -slot): ready slots
+    std::vector<int32_t> arriving;                           // become ready for the NEXT step
+    for (int q = 0; q < ns; ++q)
+      if (npred[q] == 0) heap.emplace_back(height[q], -q);
+    std::make_heap(heap.begin(), heap.end());
+    int done = 0;
+    while (done < ns) {
+      slots.emplace_back();
+      arriving.clear();
+      for (int c = 0; c < cap && !heap.empty(); ++c) {
+        std::pop_heap(heap.begin(), heap.end());
+        const int q = -heap.back().second;
+        heap.pop_back();
+        slots.back().push_back({sl[q].pos, sl[q].tgt, sl[q].piv});
+        ++done;
+        if (next_same[q] >= 0) {
+          if (--npred[next_same[q]] == 0) arriving.push_back(next_same[q]);
+        } else {  // target final: release its own slots
+          const int tt = tof(sl[q].tgt);
+          for (int r = col_first[tt]; r < col_first[tt + 1]; ++r)
+            if (--npred[r] == 0) arriving.push_back(r);
         }
-        const int take = std::min(cap - fill[s], p1 - p);
-        for (int q = 0; q < take; ++q, ++p) {
-          const int tgt = forward ? o.Li[p] : o.Rk[p];
-          const int pos = forward ? p : o.Rpos[p];
-          slots[s].push_back({pos, tgt, j});
-          last_write[tgt] = s;
-        }
-        fill[s] += take;
-        if (p < p1) ++s;
+      }
+      for (int q : arriving) {
+        heap.emplace_back(height[q], -q);
+        std::push_heap(heap.begin(), heap.end());
       }
     }
     const int steps = (int)slots.size();
-    units           = forward ? (steps + 1) / 2 : steps;
+    units           = steps;
     units = ((units + SparsePlanHost::kSweepPad - 1) / SparsePlanHost::kSweepPad) * SparsePlanHost::kSweepPad;
     const size_t total = (size_t)(units + SparsePlanHost::kSweepPad) * 128;
     xmap.assign(total, -1);
     xidx.assign(total, k | (k << 16));
     for (int s = 0; s < steps; ++s)
       for (size_t e = 0; e < slots[s].size(); ++e) {
-        // forward: step s -> unit s/2, slot s%2, lane e;   backward: step s -> unit s, slot e/64, lane e%64
-        const size_t q = forward ? ((size_t)(s / 2) * 64 + e) * 2 + (s & 1) : ((size_t)s * 64 + (e & 63)) * 2 + (e >> 6);
+        // step s -> unit s, slot e/64, lane e%64
+        const size_t q = ((size_t)s * 64 + (e & 63)) * 2 + (e >> 6);
         xmap[q] = slots[s][e][0];
         xidx[q] = slots[s][e][1] | (slots[s][e][2] << 16);
       }
