@@ -238,14 +238,14 @@ __device__ __forceinline__ void stream_wait(vdouble2 &a, vint2 &b)
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
 }
 
-// One triangular sweep over a packed schedule (sparse_plan.h).  A UNIT holds two slots per lane,
+// One triangular sweep over a packed schedule (sparse_plan.h).  A UNIT is one step of 128 independent
+// slots, two per lane,
 //   t[tgt] = fma(-val, t[piv], t[tgt]),   (tgt, piv) = idx,
-// fetched with one 16-byte and one 8-byte load.  SEQ (forward sweep): the two slots are consecutive
-// dependent steps and are applied one after the other; !SEQ (backward sweep): they belong to one step
-// of 128 independent slots and their LDS reads are issued together.  Branch-free; DEPTH units
+// fetched with one 16-byte and one 8-byte load; the LDS reads of both slots are issued together (one
+// LDS round trip per unit on the dependent chain of a lone wave).  Branch-free; DEPTH units
 // (= 2 x DEPTH slots per lane) are in flight ahead of their use so the ~1.7 us HBM latency of a lone
 // wave is covered; t has k+1 entries, t[k] is the padding slot; `units` is a multiple of kSweepPadDev.
-template<int DEPTH, bool SEQ>
+template<int DEPTH>
 __device__ inline void sweep_dev(const int32_t *__restrict__ idx, const int units, const double *vals, double *t,
                                  const int lane)
 {
@@ -267,14 +267,9 @@ __device__ inline void sweep_dev(const int32_t *__restrict__ idx, const int unit
     for (int d = 0; d < DEPTH; ++d) {
       stream_wait<2 * (DEPTH - 1)>(lx[d], ix[d]);  // this unit's two loads are the oldest in flight
       const unsigned p0 = (unsigned)ix[d].x, p1 = (unsigned)ix[d].y;
-      if constexpr (SEQ) {
-        t[p0 & 0xFFFFu] = fma(-lx[d].x, t[p0 >> 16], t[p0 & 0xFFFFu]);
-        t[p1 & 0xFFFFu] = fma(-lx[d].y, t[p1 >> 16], t[p1 & 0xFFFFu]);
-      } else {
-        const double a0 = t[p0 >> 16], b0 = t[p0 & 0xFFFFu], a1 = t[p1 >> 16], b1 = t[p1 & 0xFFFFu];
-        t[p0 & 0xFFFFu] = fma(-lx[d].x, a0, b0);
-        t[p1 & 0xFFFFu] = fma(-lx[d].y, a1, b1);
-      }
+      const double a0 = t[p0 >> 16], b0 = t[p0 & 0xFFFFu], a1 = t[p1 >> 16], b1 = t[p1 & 0xFFFFu];
+      t[p0 & 0xFFFFu] = fma(-lx[d].x, a0, b0);
+      t[p1 & 0xFFFFu] = fma(-lx[d].y, a1, b1);
       stream_load(lx[d], vp + d * kWave);  // unit u0 + d + DEPTH (always inside the padded arrays)
       stream_load(ix[d], ip + d * kWave);
     }
@@ -291,7 +286,7 @@ __device__ inline void sweep_dev(const int32_t *__restrict__ idx, const int unit
 __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, double *t, const int lane)
 {
   const int k = pl.k;
-  sweep_dev<SFB_SWEEP_DEPTH, false>(pl.fidx, pl.funits, w.LxF, t, lane);  // forward (column oriented order)
+  sweep_dev<SFB_SWEEP_DEPTH>(pl.fidx, pl.funits, w.LxF, t, lane);  // forward (column oriented order)
   for (int j0 = lane; j0 < k; j0 += kWave * 8) {  // D^-1 (:458), loads batched
     double dv[8];
 #pragma unroll
@@ -301,7 +296,7 @@ __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, doubl
       if (j0 + e * kWave < k) t[j0 + e * kWave] = dv[e] * t[j0 + e * kWave];
   }
   wave_sync();
-  sweep_dev<SFB_SWEEP_DEPTH, false>(pl.bidx, pl.bunits, w.LxB, t, lane);  // backward (rows pushing, descending)
+  sweep_dev<SFB_SWEEP_DEPTH>(pl.bidx, pl.bunits, w.LxB, t, lane);  // backward (rows pushing, descending)
 }
 
 __device__ __forceinline__ double lane_max_abs(const double *v, int len, int lane)
@@ -581,7 +576,10 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
   for (; iter != maxit && ret_code < 0; ++iter) {
     // element-wise phases: the loads of UNR strided elements are issued together (one memory round
     // trip per UNR elements instead of one per element -- matters for a wave that runs alone)
-    constexpr int UNR = 4;
+    // (the batch sizes are what the 168-VGPR budget of three waves per SIMD allows)
+    constexpr int UNR_A = 8, UNR_B = 4;
+    {
+    constexpr int UNR = UNR_A;
     for (int j0 = lane; j0 < n; j0 += kWave * UNR) {  // :450
       double xv[UNR], qv[UNR];
       int pv[UNR];
@@ -613,10 +611,13 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
       for (int e = 0; e < UNR; ++e)
         if (i0 + e * kWave < m) t[pv[e]] = zv[e] - rv[e] * yv[e];
     }
+    }
     wave_sync();
     ldl_solve_dev(pl, w, t, lane);                                                              // :456-460
     const bool chk = (iter == next_chk);
     if (chk) next_chk += sci;
+    {
+    constexpr int UNR = UNR_A;
     for (int j0 = lane; j0 < n; j0 += kWave * UNR) {  // :470
       double xo[UNR], sxj[UNR];
       int pv[UNR];
@@ -641,6 +642,9 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
         }
       }
     }
+    }
+    {
+    constexpr int UNR = UNR_B;
     for (int i0 = lane; i0 < m; i0 += kWave * UNR) {  // :471-477
       double yo[UNR], zo[UNR], ri[UNR], rh[UNR], lo[UNR], hi[UNR], syi[UNR];
       int pv[UNR];
@@ -675,6 +679,7 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
           }
         }
       }
+    }
     }
     wave_sync();
     if (chk) {
