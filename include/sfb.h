@@ -76,7 +76,10 @@ typedef struct sfb_qp_params {
  * iterations and reports SFB_QP_MAX_ITERATIONS (iter == cap) when it is hit. */
 #define SFB_QP_DEVICE_ITER_CAP 20000000
 
-/* Largest n+m the one-QP-per-wavefront dense kernel handles (lane i owns KKT row i). */
+/* Largest n+m the register/LDS-resident dense kernels handle (lane i owns KKT row i).  Larger dense problems
+ * are accepted by the same entry points and run on the shared-pattern sparse kernel with a full pattern: same
+ * ADMM, same stopping tests on the same matrix entries, but a fill-reducing elimination order without pivoting
+ * instead of the pivoted dense LDL' -- results agree with the dense solver to rounding, not bit for bit. */
 #define SFB_QP_DENSE_MAX_K 64
 
 const char *sfb_version(void);
@@ -105,7 +108,7 @@ void sfb_qp_params_default(sfb_qp_params *prm);
  * Outputs (QPSolution, qp.hpp:95-108):
  *   x [batch][n] primal, y [batch][m] dual, obj [batch] (nullable), iter [batch] (nullable),
  *   code [batch] (sfb_qp_status values).
- * Requires 1 <= n, 1 <= m, n+m <= SFB_QP_DENSE_MAX_K, prm->max_time_ns < 0.
+ * Requires 1 <= n, 1 <= m, prm->max_time_ns < 0 (n+m > SFB_QP_DENSE_MAX_K: see there; n+m <= 19 198).
  */
 sfb_status sfb_qp_dense_solve_batch(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P,
                                     const double *q, const double *A, const double *l, const double *u,

@@ -4,10 +4,10 @@
 // backup trajectory and its sensitivity are integrated here on the host (explicit Euler, as the
 // reference does with odeint, asif_func.hpp:121-122,175-179); the resulting small dense QP
 // (n = nu + 1, m = K nh + nu_ineq + 1) is solved on the GPU through the C-ABI:
-//   n + m <= 64  ->  sfb_qp_dense_solve_batch_host   (the dense kernels; the defaults K = 10, nh = 1 give k = 14)
-//   larger       ->  the shared-pattern sparse kernel with a full pattern (n = 3, m = 203 in
-//                    examples/mpc_asif_vehicle.cpp:105-129); same ADMM, different (non-pivoted)
-//                    factorisation order, so parity with the dense oracle is to tolerance there.
+//   sfb_qp_dense_solve_batch_host: the dense kernels for n + m <= 64 (the defaults K = 10, nh = 1 give k = 14);
+//   behind the same call, larger problems (n = 3, m = 203 in examples/mpc_asif_vehicle.cpp:105-129) run on the
+//   shared-pattern sparse kernel with a full pattern -- same ADMM, different (non-pivoted) factorisation order,
+//   so parity with the dense oracle is to tolerance there.
 // ASIFSwarm filters a batch of agents with ONE launch.
 //
 // Derivatives of f, h and bu: forward differences with step sqrt(eps) (the reference differentiates
@@ -210,62 +210,24 @@ struct ASIFilterParams {
 };
 
 namespace detail {
-/// Dense QPs of one shape on the GPU: the dense kernels for n + m <= 64, else the shared-pattern sparse
-/// kernel with a full pattern (P upper triangle, A full).
+/// Dense QPs of one shape on the GPU through the dense entry point: the register/LDS-resident dense kernels
+/// for n + m <= 64, the shared-pattern sparse kernel with a full pattern behind the same call for larger ones.
 class DenseQPBackend {
 public:
-  DenseQPBackend(int n, int m, const QPSolverParams & prm) : n_(n), m_(m), prm_(prm)
-  {
-    if (n + m > SFB_QP_DENSE_MAX_K) {
-      QuadraticProgramSparse pat;
-      pat.n = n;
-      pat.m = m;
-      pat.P_colptr.push_back(0);
-      for (int c = 0; c < n; ++c) {
-        for (int r = 0; r <= c; ++r) pat.P_rowind.push_back(r);
-        pat.P_colptr.push_back((int32_t)pat.P_rowind.size());
-      }
-      pat.A_rowptr.push_back(0);
-      for (int r = 0; r < m; ++r) {
-        for (int c = 0; c < n; ++c) pat.A_colind.push_back(c);
-        pat.A_rowptr.push_back((int32_t)pat.A_colind.size());
-      }
-      pat.P_val.assign(pat.P_rowind.size(), 0.0);
-      pat.A_val.assign(pat.A_colind.size(), 0.0);
-      sparse_ = std::make_unique<SparseQPSolver>(prm);
-      sparse_->analyze(pat);
-    }
-  }
+  DenseQPBackend(int n, int m, const QPSolverParams & prm) : n_(n), m_(m), prm_(prm) {}
 
   /// B problems, batch-major dense column-major arrays as in sfb_qp_dense_solve_batch_host
   void solve_batch(int64_t B, const double * P, const double * q, const double * A, const double * l, const double * u,
                    const double * wx, const double * wy, double * x, double * y, double * obj, uint32_t * iter,
                    int32_t * code)
   {
-    if (!sparse_) {
-      const sfb_qp_params c = prm_.to_c();
-      sfb_check(sfb_qp_dense_solve_batch_host(&c, B, n_, m_, P, q, A, l, u, wx, wy, x, y, obj, iter, code));
-      return;
-    }
-    const int nnzP = n_ * (n_ + 1) / 2, nnzA = n_ * m_;
-    Px_.resize((size_t)B * nnzP);
-    Ax_.resize((size_t)B * nnzA);
-    for (int64_t b = 0; b < B; ++b) {
-      size_t o = (size_t)b * nnzP;
-      for (int c = 0; c < n_; ++c)
-        for (int r = 0; r <= c; ++r) Px_[o++] = P[(size_t)b * n_ * n_ + (size_t)r + (size_t)c * n_];
-      o = (size_t)b * nnzA;
-      for (int r = 0; r < m_; ++r)
-        for (int c = 0; c < n_; ++c) Ax_[o++] = A[(size_t)b * m_ * n_ + (size_t)r + (size_t)c * m_];
-    }
-    sparse_->solve_batch(B, Px_.data(), q, Ax_.data(), l, u, wx, wy, x, y, obj, iter, code);
+    const sfb_qp_params c = prm_.to_c();
+    sfb_check(sfb_qp_dense_solve_batch_host(&c, B, n_, m_, P, q, A, l, u, wx, wy, x, y, obj, iter, code));
   }
 
 private:
   int n_, m_;
   QPSolverParams prm_;
-  std::unique_ptr<SparseQPSolver> sparse_;
-  std::vector<double> Px_, Ax_;
 };
 }  // namespace detail
 

@@ -71,7 +71,8 @@ inline void sfb_check(sfb_status st)
   if (st != SFB_OK) throw std::runtime_error(std::string("sfb: ") + sfb_last_error());
 }
 
-/// solve_qp for dense problems (qp_solver.hpp:779-787), n + m <= 64
+/// solve_qp for dense problems (qp_solver.hpp:779-787); n + m <= 64 runs on the dense kernels, larger problems on
+/// the sparse kernel with a full pattern (include/sfb.h, SFB_QP_DENSE_MAX_K)
 inline QPSolution solve_qp(const QuadraticProgram & pbm, const QPSolverParams & prm = {},
                            const QPSolution * warmstart = nullptr)
 {

@@ -5,7 +5,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/sfb.h"
 #include "capi_common.h"
@@ -81,13 +84,77 @@ sfb_status check_qp_args(const sfb_qp_params *prm, int64_t batch, int n, int m, 
     return fail(SFB_ERR_INVALID_ARG, "NULL problem / solution pointer");
   if ((wx == nullptr) != (wy == nullptr))
     return fail(SFB_ERR_INVALID_ARG, "warm_x and warm_y must both be given or both be NULL");
-  if (n + m > SFB_QP_DENSE_MAX_K)
-    return fail(SFB_ERR_UNSUPPORTED, "dense kernel needs n+m <= 64 (one QP per wavefront)");
   if (prm->max_time_ns >= 0)
     return fail(SFB_ERR_UNSUPPORTED, "max_time is wall-clock and not supported on the device path; use max_iter");
   if (prm->max_iter > 0xFFFFFFFFll) return fail(SFB_ERR_INVALID_ARG, "max_iter exceeds uint32");
   if (batch > 0x7FFFFFFFll) return fail(SFB_ERR_UNSUPPORTED, "batch exceeds 2^31-1 per call");
   return SFB_OK;
+}
+
+// ---- dense problems with n+m > SFB_QP_DENSE_MAX_K: the shared-pattern sparse kernel with a FULL pattern ----
+// P (n x n, column-major, all entries stored) IS the CSC value array of a full pattern, so the stopping tests
+// and the objective see the same matrix entries in the same order as the dense kernels; only A has to be
+// re-laid out by rows.  What differs from the reference's dense solver is the factorisation order (fill-reducing
+// elimination order without pivoting instead of pivoted dense LDL'), i.e. rounding.
+__global__ void __launch_bounds__(64) dense_A_to_rows_kernel(const double *__restrict__ A, double *__restrict__ Ax,
+                                                             const int n, const int m)
+{
+  const size_t off = (size_t)blockIdx.x * (size_t)(m * n);
+  for (int e = threadIdx.x; e < m * n; e += 64) {
+    const int r = e / n, c = e - r * n;
+    Ax[off + e] = A[off + r + (size_t)c * m];
+  }
+}
+
+sfb_status dense_via_sparse(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P, const double *q,
+                            const double *A, const double *l, const double *u, const double *wx, const double *wy,
+                            double *x, double *y, double *obj, uint32_t *iter, int32_t *code, hipStream_t stream)
+{
+  static std::mutex mu;
+  static std::map<std::pair<int, int>, sfb_sparse_qp_plan *> plans;  // one symbolic analysis per shape, kept
+  sfb_sparse_qp_plan *plan = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = plans.find({n, m});
+    if (it == plans.end()) {
+      std::vector<int32_t> Pp(n + 1), Pi((size_t)n * n), Ap(m + 1), Aj((size_t)m * n);
+      for (int c = 0; c <= n; ++c) Pp[c] = c * n;
+      for (int c = 0; c < n; ++c)
+        for (int r = 0; r < n; ++r) Pi[(size_t)c * n + r] = r;
+      for (int r = 0; r <= m; ++r) Ap[r] = r * n;
+      for (int r = 0; r < m; ++r)
+        for (int c = 0; c < n; ++c) Aj[(size_t)r * n + c] = c;
+      const sfb_status st = sfb_sparse_qp_plan_create(n, m, Pp.data(), Pi.data(), Ap.data(), Aj.data(), 1, nullptr, &plan);
+      if (st != SFB_OK) return st;
+      plans[{n, m}] = plan;
+    } else {
+      plan = it->second;
+    }
+  }
+  int64_t wsb = 0;
+  sfb_status st = sfb_sparse_qp_plan_info(plan, nullptr, nullptr, &wsb);
+  if (st != SFB_OK) return st;
+  const size_t abytes = (size_t)batch * (size_t)m * n * sizeof(double);
+  const size_t bytes  = abytes + (size_t)batch * (size_t)wsb;
+  char *buf           = nullptr;
+  bool async_alloc    = true;
+  hipError_t e        = hipMallocAsync(reinterpret_cast<void **>(&buf), bytes, stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    async_alloc = false;
+    e           = hipMalloc(reinterpret_cast<void **>(&buf), bytes);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+  }
+  double *Ax = reinterpret_cast<double *>(buf);
+  hipLaunchKernelGGL(dense_A_to_rows_kernel, dim3((unsigned)batch), dim3(64), 0, stream, A, Ax, n, m);
+  st = sfb_sparse_qp_solve_batch(plan, prm, batch, P, q, Ax, l, u, wx, wy, x, y, obj, iter, code, buf + abytes, stream);
+  if (async_alloc) {
+    (void)hipFreeAsync(buf, stream);
+  } else {
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(buf);
+  }
+  return st;
 }
 
 }  // namespace
@@ -141,6 +208,9 @@ sfb_status sfb_qp_dense_solve_batch(const sfb_qp_params *prm, int64_t batch, int
   st = require_device();
   if (st != SFB_OK) return st;
   if (batch == 0) return SFB_OK;
+  if (n + m > SFB_QP_DENSE_MAX_K)
+    return dense_via_sparse(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code,
+                            static_cast<hipStream_t>(stream));
   const sfb::DenseKernelParams kp = make_kernel_params(prm, n, m);
   hipError_t e = sfb::qp_dense_launch(kp, batch, P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code,
                                       static_cast<hipStream_t>(stream));
@@ -198,10 +268,8 @@ sfb_status sfb_qp_dense_solve_batch_host(const sfb_qp_params *prm, int64_t batch
       if ((e = H2D(dwx, warm_x, B * N * 8)) != hipSuccess) break;
       if ((e = H2D(dwy, warm_y, B * M * 8)) != hipSuccess) break;
     }
-    const sfb::DenseKernelParams kp = make_kernel_params(prm, n, m);
-    if ((e = sfb::qp_dense_launch(kp, batch, dP, dq, dA, dl, du, dwx, dwy, dx, dy, dobj, dit, dcode, nullptr)) !=
-        hipSuccess)
-      break;
+    st = sfb_qp_dense_solve_batch(prm, batch, n, m, dP, dq, dA, dl, du, dwx, dwy, dx, dy, dobj, dit, dcode, nullptr);
+    if (st != SFB_OK) break;
     if ((e = hipDeviceSynchronize()) != hipSuccess) break;
     if ((e = D2H(x, dx, B * N * 8)) != hipSuccess) break;
     if ((e = D2H(y, dy, B * M * 8)) != hipSuccess) break;

@@ -39,13 +39,12 @@ def test_params_struct_matches_oracle_layout(sfb, oracle):
 def test_argument_errors_do_not_need_a_device(sfb):
     import numpy as np
     P, q, A, l, u = sfb.random_qp_batch(5, 2, 20, 10, 1.0)
-    # n + m > 64 is rejected before any device work
+    # sizes the solver cannot take are rejected before any device work
     try:
-        sfb.solve_qp_batch_host(np.zeros((1, 40 * 40)), np.zeros((1, 40)), np.zeros((1, 30 * 40)),
-                                np.zeros((1, 30)), np.zeros((1, 30)))
+        sfb.solve_qp_batch_host(np.zeros((1, 0)), np.zeros((1, 0)), np.zeros((1, 0)), np.zeros((1, 3)), np.zeros((1, 3)))
         assert False
     except sfb._capi.SfbError as e:
-        assert e.status == sfb._capi.SFB_ERR_UNSUPPORTED
+        assert e.status == sfb._capi.SFB_ERR_INVALID_ARG
     # wall-clock limit is rejected on the device path
     try:
         sfb.solve_qp_batch_host(P, q, A, l, u, sfb.QPSolverParams(max_time=1.0))

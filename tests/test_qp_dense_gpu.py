@@ -271,3 +271,28 @@ def test_one_per_wave_kernels_still_agree(sfb, oracle, env_knob, n, m):
     _compare(r4, ref)
     assert np.array_equal(r1.primal, r4.primal, equal_nan=True) and np.array_equal(r1.dual, r4.dual, equal_nan=True)
     assert np.array_equal(r1.iter, r4.iter) and np.array_equal(r1.code, r4.code)
+
+
+@pytest.mark.parametrize("n,m", [(40, 30), (64, 96), (3, 203)])
+def test_larger_dense_problems_run_on_the_sparse_kernel(sfb, oracle, n, m):
+    """n + m > 64 through the SAME dense entry point (full-pattern sparse kernel): status codes as the dense
+    oracle, iteration counts equal up to one stopping-check interval, solutions to tolerance (different
+    factorisation order, include/sfb.h)."""
+    B = 48
+    P, q, A, l, u = sfb.random_qp_batch(200 + n, B, m, n, 0.6)
+    rng = np.random.default_rng(n + m)
+    l = np.where(rng.random((B, m)) < 0.5, u - 1.0 - rng.random((B, m)), l)
+    prm = sfb.QPSolverParams(max_iter=4000)
+    r = sfb.solve_qp_batch_host(P, q, A, l, u, prm)
+    ref = oracle.qp_dense_solve_batch(P, q, A, l, u, params=_oracle_params(oracle, prm), nthreads=8)
+    assert np.array_equal(r.code, ref["code"])
+    assert np.abs(r.iter.astype(np.int64) - ref["iter"].astype(np.int64)).max() <= 25
+    same = r.iter == ref["iter"]
+    opt = (ref["code"] == 0) & same
+    if m < 3 * n:
+        assert opt.sum() >= B // 2      # (3, 203): random rows mostly contradict each other -> PrimalInfeasible
+    if opt.sum() == 0:
+        return
+    scale = 1.0 + np.abs(ref["x"][opt]).max(axis=1)
+    assert (np.abs(r.primal[opt] - ref["x"][opt]).max(axis=1) / scale).max() <= 1e-6
+    assert (np.abs(r.objective[opt] - ref["obj"][opt]) / (1.0 + np.abs(ref["obj"][opt]))).max() <= 1e-6
