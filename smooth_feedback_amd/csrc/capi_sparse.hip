@@ -67,7 +67,7 @@ sfb_status plan_on_device(sfb_sparse_qp_plan *plan, const sfb::SparsePlanDev **o
                             &d.Prp, &d.Prj, &d.Prpos, &d.Sp, &d.Sj, &d.Spos, &d.perm, &d.pinv,
                             &d.Kp, &d.Ki, &d.Kkind, &d.Kidx, &d.Lp, &d.Li, &d.Rp, &d.Rk, &d.Rpos, &d.Rlen,
                             &d.fmap, &d.fidx, &d.bmap, &d.bidx, &d.Kmap, &d.rptr, &d.rtgt, &d.rab, &d.snptr, &d.poff, &d.pmap};
-  d.funits = h.funits; d.bunits = h.bunits; d.rsteps = h.rsteps; d.maxcol = h.maxcol; d.nsn = h.nsn; d.lds_doubles = h.lds_doubles;
+  d.funits = h.funits; d.bunits = h.bunits; d.idx_scale = h.idx_scale; d.rsteps = h.rsteps; d.maxcol = h.maxcol; d.nsn = h.nsn; d.lds_doubles = h.lds_doubles;
   for (int a = 0; a < NA; ++a) *ptrs[a] = dc.blob + off[a];
   auto ins = plan->per_device.emplace(devid, dc);
   *out     = &ins.first->second.dev;

@@ -245,7 +245,7 @@ __device__ __forceinline__ void stream_wait(vdouble2 &a, vint2 &b)
 // LDS round trip per unit on the dependent chain of a lone wave).  Branch-free; DEPTH units
 // (= 2 x DEPTH slots per lane) are in flight ahead of their use so the ~1.7 us HBM latency of a lone
 // wave is covered; t has k+1 entries, t[k] is the padding slot; `units` is a multiple of kSweepPadDev.
-template<int DEPTH>
+template<int DEPTH, bool BYTEOFF>
 __device__ inline void sweep_dev(const int32_t *__restrict__ idx, const int units, const double *vals, double *t,
                                  const int lane)
 {
@@ -267,9 +267,13 @@ __device__ inline void sweep_dev(const int32_t *__restrict__ idx, const int unit
     for (int d = 0; d < DEPTH; ++d) {
       stream_wait<2 * (DEPTH - 1)>(lx[d], ix[d]);  // this unit's two loads are the oldest in flight
       const unsigned p0 = (unsigned)ix[d].x, p1 = (unsigned)ix[d].y;
-      const double a0 = t[p0 >> 16], b0 = t[p0 & 0xFFFFu], a1 = t[p1 >> 16], b1 = t[p1 & 0xFFFFu];
-      t[p0 & 0xFFFFu] = fma(-lx[d].x, a0, b0);
-      t[p1 & 0xFFFFu] = fma(-lx[d].y, a1, b1);
+      // (tgt, piv) as byte offsets (BYTEOFF, plan.idx_scale == 8) or element indices
+      auto at = [&](unsigned v) -> double & {
+        return BYTEOFF ? *reinterpret_cast<double *>(reinterpret_cast<char *>(t) + v) : t[v];
+      };
+      const double a0 = at(p0 >> 16), b0 = at(p0 & 0xFFFFu), a1 = at(p1 >> 16), b1 = at(p1 & 0xFFFFu);
+      at(p0 & 0xFFFFu) = fma(-lx[d].x, a0, b0);
+      at(p1 & 0xFFFFu) = fma(-lx[d].y, a1, b1);
       stream_load(lx[d], vp + d * kWave);  // unit u0 + d + DEPTH (always inside the padded arrays)
       stream_load(ix[d], ip + d * kWave);
     }
@@ -286,7 +290,9 @@ __device__ inline void sweep_dev(const int32_t *__restrict__ idx, const int unit
 __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, double *t, const int lane)
 {
   const int k = pl.k;
-  sweep_dev<SFB_SWEEP_DEPTH>(pl.fidx, pl.funits, w.LxF, t, lane);  // forward (column oriented order)
+  const bool bo = pl.idx_scale == 8;
+  if (bo) sweep_dev<SFB_SWEEP_DEPTH, true>(pl.fidx, pl.funits, w.LxF, t, lane);  // forward (column oriented order)
+  else sweep_dev<SFB_SWEEP_DEPTH, false>(pl.fidx, pl.funits, w.LxF, t, lane);
   for (int j0 = lane; j0 < k; j0 += kWave * 8) {  // D^-1 (:458), loads batched
     double dv[8];
 #pragma unroll
@@ -296,7 +302,8 @@ __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, doubl
       if (j0 + e * kWave < k) t[j0 + e * kWave] = dv[e] * t[j0 + e * kWave];
   }
   wave_sync();
-  sweep_dev<SFB_SWEEP_DEPTH>(pl.bidx, pl.bunits, w.LxB, t, lane);  // backward (rows pushing, descending)
+  if (bo) sweep_dev<SFB_SWEEP_DEPTH, true>(pl.bidx, pl.bunits, w.LxB, t, lane);  // backward (rows pushing, descending)
+  else sweep_dev<SFB_SWEEP_DEPTH, false>(pl.bidx, pl.bunits, w.LxB, t, lane);
 }
 
 __device__ __forceinline__ double lane_max_abs(const double *v, int len, int lane)

@@ -322,6 +322,7 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
 
   // packed sweep schedules (see sparse_plan.h)
   if (k + 1 >= (1 << 16)) { *msg = "n+m too large for the packed sweep encoding (max 65534)"; return false; }
+  o.idx_scale = ((k + 1) * 8 < (1 << 16)) ? 8 : 1;
   auto build = [&](bool forward, std::vector<int32_t> &xmap, std::vector<int32_t> &xidx, int &units) {
     const int cap = 128;  // slots per dependent step
     // Critical-path list scheduling.  Slot = one entry of L, enumerated in the sequential sweep order.  It
@@ -392,13 +393,16 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
     units = ((units + SparsePlanHost::kSweepPad - 1) / SparsePlanHost::kSweepPad) * SparsePlanHost::kSweepPad;
     const size_t total = (size_t)(units + SparsePlanHost::kSweepPad) * 128;
     xmap.assign(total, -1);
-    xidx.assign(total, k | (k << 16));
+    // indices are stored as BYTE offsets into the work vector when they fit 16 bits (saves the kernel four
+    // shifts per unit on the dependent chain of a lone wave), else as element indices
+    const int sc = o.idx_scale;
+    xidx.assign(total, (k * sc) | ((k * sc) << 16));
     for (int s = 0; s < steps; ++s)
       for (size_t e = 0; e < slots[s].size(); ++e) {
         // step s -> unit s, slot e/64, lane e%64
         const size_t q = ((size_t)s * 64 + (e & 63)) * 2 + (e >> 6);
         xmap[q] = slots[s][e][0];
-        xidx[q] = slots[s][e][1] | (slots[s][e][2] << 16);
+        xidx[q] = (slots[s][e][1] * sc) | ((slots[s][e][2] * sc) << 16);
       }
   };
   build(true, o.fmap, o.fidx, o.funits);

@@ -37,13 +37,14 @@ struct SparsePlanHost {
   // list scheduling: among the ready slots those with the longest chain of dependants go first (MPC
   // pattern: 384 + 336 steps for 2 x 41 030 entries; critical paths 285 / 218, width bound 321).
   //   xmap[q]  : position in the column-major values of L feeding slot q, or -1 (padding)
-  //   xidx[q]  : tgt | piv << 16   (padding: both = k, a scratch slot of the LDS vector)
+  //   xidx[q]  : (tgt | piv << 16) * idx_scale   (padding: both = k, a scratch slot of the LDS vector);
+  //              idx_scale = 8 (byte offsets) when (k+1)*8 < 65536, else 1
   // Storage: unit u, lane l, slot s at [(u * 64 + l) * 2 + s] (one 16-byte value load and one 8-byte index
   // load per lane and unit).  Unit counts are multiples of kSweepPad and the arrays carry kSweepPad extra
   // all-padding units so the kernel prefetches branch-free.
   static constexpr int kSweepPad = 16;
   std::vector<int32_t> fmap, fidx, bmap, bidx;
-  int funits = 0, bunits = 0;
+  int funits = 0, bunits = 0, idx_scale = 1;
   // Right-looking factorisation schedule.  When column kk is final it updates, for every pair of its
   // rows (r_a >= r_b), the accumulator of entry (r_a, r_b) [the diagonal D(r_b) when a == b]:
   //   acc -= L(r_a,kk) * (L(r_b,kk) * D(kk)).
