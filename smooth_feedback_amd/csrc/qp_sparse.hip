@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
+#include <utility>
 #include <cfloat>
 #include <cmath>
 
@@ -224,13 +226,19 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
 typedef double vdouble2 __attribute__((ext_vector_type(2)));  // native vectors: usable as asm register operands
 typedef int vint2 __attribute__((ext_vector_type(2)));
 
+// OFF: byte offset folded into the instruction (13-bit signed immediate), so that the units of one prefetch
+// block share their address registers instead of paying a 64-bit add each
+template<int OFF>
 __device__ __forceinline__ void stream_load(vdouble2 &v, const vdouble2 *p)
 {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p));
+  static_assert(OFF >= 0 && OFF < 4096, "immediate offset of global_load");
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF));
 }
+template<int OFF>
 __device__ __forceinline__ void stream_load(vint2 &v, const vint2 *p)
 {
-  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p));
+  static_assert(OFF >= 0 && OFF < 4096, "immediate offset of global_load");
+  asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF));
 }
 template<int N>
 __device__ __forceinline__ void stream_wait(vdouble2 &a, vint2 &b)
@@ -251,34 +259,40 @@ __device__ inline void sweep_dev(const int32_t *__restrict__ idx, const int unit
 {
   static_assert(DEPTH <= kSweepPadDev && kSweepPadDev % DEPTH == 0, "schedule padding must cover the prefetch distance");
   static_assert(2 * DEPTH <= 62, "vmcnt is a 6-bit counter");
-  const vdouble2 *vp = reinterpret_cast<const vdouble2 *>(vals) + lane;  // per-lane stream pointers (VGPRs)
-  const vint2 *ip    = reinterpret_cast<const vint2 *>(idx) + lane;
+  static_assert(DEPTH <= 8, "two value pointers cover 8 units of 1 KB with 12-bit offsets");
+  // per-lane stream pointers (VGPRs): values of units d < 4 / d >= 4 of a block, indices of all units
+  const vdouble2 *vp0 = reinterpret_cast<const vdouble2 *>(vals) + lane;
+  const vdouble2 *vp1 = vp0 + 4 * kWave;
+  const vint2 *ip     = reinterpret_cast<const vint2 *>(idx) + lane;
   vdouble2 lx[DEPTH];
   vint2 ix[DEPTH];
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) {
-    stream_load(lx[d], vp + d * kWave);
-    stream_load(ix[d], ip + d * kWave);
-  }
-  vp += DEPTH * kWave;
-  ip += DEPTH * kWave;
+  auto issue = [&]<int D>(std::integral_constant<int, D>) {
+    if constexpr (D < 4) stream_load<D * kWave * 16>(lx[D], vp0);
+    else stream_load<(D - 4) * kWave * 16>(lx[D], vp1);
+    stream_load<D * kWave * 8>(ix[D], ip);
+  };
+  auto for_units = [&]<int... D>(std::integer_sequence<int, D...>, auto &&fn) { (fn(std::integral_constant<int, D>{}), ...); };
+  for_units(std::make_integer_sequence<int, DEPTH>{}, issue);
+  auto advance = [&] {
+    vp0 += DEPTH * kWave;
+    vp1 += DEPTH * kWave;
+    ip += DEPTH * kWave;
+  };
+  advance();
   for (int u0 = 0; u0 < units; u0 += DEPTH) {
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-      stream_wait<2 * (DEPTH - 1)>(lx[d], ix[d]);  // this unit's two loads are the oldest in flight
-      const unsigned p0 = (unsigned)ix[d].x, p1 = (unsigned)ix[d].y;
+    for_units(std::make_integer_sequence<int, DEPTH>{}, [&]<int D>(std::integral_constant<int, D> dd) {
+      stream_wait<2 * (DEPTH - 1)>(lx[D], ix[D]);  // this unit's two loads are the oldest in flight
+      const unsigned p0 = (unsigned)ix[D].x, p1 = (unsigned)ix[D].y;
       // (tgt, piv) as byte offsets (BYTEOFF, plan.idx_scale == 8) or element indices
       auto at = [&](unsigned v) -> double & {
         return BYTEOFF ? *reinterpret_cast<double *>(reinterpret_cast<char *>(t) + v) : t[v];
       };
       const double a0 = at(p0 >> 16), b0 = at(p0 & 0xFFFFu), a1 = at(p1 >> 16), b1 = at(p1 & 0xFFFFu);
-      at(p0 & 0xFFFFu) = fma(-lx[d].x, a0, b0);
-      at(p1 & 0xFFFFu) = fma(-lx[d].y, a1, b1);
-      stream_load(lx[d], vp + d * kWave);  // unit u0 + d + DEPTH (always inside the padded arrays)
-      stream_load(ix[d], ip + d * kWave);
-    }
-    vp += DEPTH * kWave;
-    ip += DEPTH * kWave;
+      at(p0 & 0xFFFFu) = fma(-lx[D].x, a0, b0);
+      at(p1 & 0xFFFFu) = fma(-lx[D].y, a1, b1);
+      issue(dd);  // unit u0 + D + DEPTH (always inside the padded arrays)
+    });
+    advance();
   }
   // the trailing prefetches (padding) are never consumed: retire them before their registers are reused
 #pragma unroll
