@@ -49,7 +49,7 @@ __device__ __forceinline__ Ws carve_ws(double *base, int n, int m, int nnzL, int
   double *p = base;
   w.Lx = p; p += nnzL;
   w.D = p; p += k;
-  p += 1;  // scratch accumulator of the padding slots
+  p += 2;  // scratch accumulator of the padding slots, always-zero accumulator
   w.LxF = p; p += (size_t)(funits + kSweepPadDev) * 128;
   w.LxB = p; p += (size_t)(bunits + kSweepPadDev) * 128;
   w.Dinv = p; p += k;   w.tv = p; p += k;
@@ -89,39 +89,38 @@ __device__ __forceinline__ double kkt_value(const SparsePlanDev &pl, const Item 
   return v;
 }
 
-// Numeric LDL' on the shared pattern, RIGHT-LOOKING and SUPERNODAL over a static schedule
-// (sparse_plan.h).  The accumulators [L values | D] live in the item's HBM workspace.  Per supernode
-// (columns j0 .. j0+w-1 with nested structure, R = w + |struct(last)| rows):
-//   1. its own accumulators (a dense w x R panel) are loaded into LDS;
+// Numeric LDL' on the shared pattern, RIGHT-LOOKING over RELAXED SUPERNODES with a static schedule
+// (sparse_plan.h).  The accumulators [L values | D] live in the item's HBM workspace.  Per group of
+// consecutive columns j0 .. j0+w-1 (R = w + |U| panel rows, U = union of the members' remaining structures):
+//   1. its own accumulators (a dense w x R panel, explicit zeros where a member has no entry) are loaded into
+//      LDS together with the first block of trailing accumulators (one memory round trip);
 //   2. the panel is eliminated there column by column: divide by D, stage the entries L(.,j) and the
 //      multipliers L(.,j) D(j), update the later panel columns;
-//   3. every TRAILING accumulator (a pair of rows of struct(last)) receives the w updates of the
-//      supernode with ONE read-modify-write, 64 independent slots per step (schedule of column `last`).
+//   3. every TRAILING accumulator (a pair of rows of U) receives the w updates of the group with ONE
+//      read-modify-write, 64 independent slots per step.
 // Every accumulator still sees its sources in ascending column order, fma(-L(a,j), L(b,j) D(j), acc), so
-// the arithmetic equals the oracle's left-looking loop bit for bit; what changes is the HBM traffic:
-// the trailing accumulators are touched once per supernode instead of once per column (MPC pattern:
-// 270 k instead of 711 k read-modify-writes) and there are two memory round trips per supernode
-// instead of two per column.
+// the arithmetic equals the oracle's left-looking loop bit for bit (zero entries contribute exact zeros);
+// what changes is the HBM traffic and the number of dependent memory round trips: for the MPC pattern
+// 81 k accumulator touches and 2 x 207 round trips per factorisation instead of 711 k and 2 x 1 480.
 // t = LDS scratch of pl.lds_doubles doubles (the plan caps w so that 2 w R fits).  Returns 1 / 0 (zero pivot).
 template<int DEPTH>
 __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, const Ws &w, double *t, const int mode,
                                       const double c, const double sigma, const double delta, const int lane)
 {
   const int k = pl.k, nnzL = pl.nnzL;
-  double *ACC = w.Lx;  // [0, nnzL): L entries, [nnzL, nnzL+k): D, [nnzL+k]: scratch
-  for (int p = lane; p < nnzL + k + 1; p += kWave) ACC[p] = 0.0;
+  double *ACC = w.Lx;  // [0, nnzL): L entries, [nnzL, nnzL+k): D, [nnzL+k]: scratch, [nnzL+k+1]: always zero
+  for (int p = lane; p < nnzL + k + 2; p += kWave) ACC[p] = 0.0;
   wave_sync();
   for (int p = lane; p < pl.nnzK; p += kWave) ACC[pl.Kmap[p]] = kkt_value(pl, it, w, p, mode, c, sigma, delta);
   wave_sync();
   for (int sn = 0; sn < pl.nsn; ++sn) {
     const int j0 = pl.snptr[sn], wd = pl.snptr[sn + 1] - j0;
-    const int R  = pl.Lp[j0 + 1] - pl.Lp[j0] + 1;  // panel rows: the w columns themselves, then struct(last)
+    const int R  = pl.snR[sn];  // panel rows: the w columns themselves, then the union U of their structures
     double *pan  = t;                                // pan[jj * R + r], r >= jj: accumulators, then L(r, j0+jj)
     double *mul  = t + wd * R;                       // mul[jj * R + r] = L(r, j0+jj) * D(j0+jj)
     // The first DEPTH steps of trailing accumulators do not depend on this supernode's panel: their loads
     // are issued together with the panel's (one memory round trip instead of two per supernode).
-    const int last = j0 + wd - 1;
-    const int s0 = pl.rptr[last], s1 = pl.rptr[last + 1];
+    const int s0 = pl.rptr[sn], s1 = pl.rptr[sn + 1];
     const int pad = nnzL + k;
     int tp0[DEPTH];
     unsigned ab0[DEPTH];
@@ -167,10 +166,10 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
     // final D, 1/D and L values of the panel -> workspace (fire and forget)
     for (int q = lane; q < npan; q += kWave) {
       const int dst = pm[q];
-      if (dst != nnzL + k) ACC[dst] = pan[q];
+      if (dst < nnzL + k) ACC[dst] = pan[q];  // not the scratch / zero accumulators
     }
     for (int jj = lane; jj < wd; jj += kWave) w.Dinv[j0 + jj] = 1.0 / pan[jj * R + jj];
-    // 3. trailing accumulators: pairs (a >= b) of entries of column `last`, local rows w + a, w + b
+    // 3. trailing accumulators: pairs (a >= b) of rows of U, local rows w + a, w + b
 #pragma unroll
     for (int dd = 0; dd < DEPTH; ++dd) {
       if (tp0[dd] != pad) {

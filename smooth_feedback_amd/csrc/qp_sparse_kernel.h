@@ -23,7 +23,7 @@ struct SparsePlanDev {
   int funits, bunits, idx_scale;
   const int32_t *Kmap, *rptr, *rtgt, *rab;   // right-looking factorisation schedule
   int rsteps, maxcol;
-  const int32_t *snptr, *poff, *pmap;        // supernodes of the factorisation and their panel maps
+  const int32_t *snptr, *snR, *poff, *pmap;  // (relaxed) supernodes of the factorisation and their panel maps
   int nsn, lds_doubles;
 };
 
@@ -33,7 +33,7 @@ inline size_t qp_sparse_ws_doubles(int n, int m, int nnzL, int funits, int bunit
 {
   const size_t k = (size_t)n + m;
   return (size_t)nnzL + (size_t)(funits + bunits + 2 * kSweepPadDev) * 128 + 3 * k + 6 * (size_t)n + 12 * (size_t)m + 8;
-  // (accumulator layout of the factorisation: [L values | D | 1 scratch] is contiguous at the start of the block)
+  // (accumulator layout of the factorisation: [L values | D | scratch | zero] is contiguous at the start of the block)
   // (the KKT value buffer of the factorisation aliases the forward-sweep copy LxF: nnzK <= nnzL + k <= its size
   //  is checked at plan creation)
 }

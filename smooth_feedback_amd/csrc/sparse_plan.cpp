@@ -1,6 +1,7 @@
 #include "sparse_plan.h"
 
 #include <algorithm>
+#include <iterator>
 #include <array>
 #include <numeric>
 #include <tuple>
@@ -253,71 +254,88 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
         o.Kmap[p]   = (i == j) ? o.nnzL + j : pos_in_col(j, i);
         if (o.Kmap[p] < 0) { *msg = "internal: KKT entry outside the pattern of L"; return false; }
       }
-    o.rptr.assign(k + 1, 0);
     o.maxcol = 0;
-    for (int kk = 0; kk < k; ++kk) {
-      const int cnt = o.Lp[kk + 1] - o.Lp[kk];
-      o.maxcol      = std::max(o.maxcol, cnt);
-      const int64_t slots = (int64_t)cnt * (cnt + 1) / 2;
-      o.rptr[kk + 1] = o.rptr[kk] + (int)((slots + 63) / 64);
-    }
-    o.rsteps = o.rptr[k];
+    for (int kk = 0; kk < k; ++kk) o.maxcol = std::max(o.maxcol, o.Lp[kk + 1] - o.Lp[kk]);
     if (o.maxcol >= (1 << 16)) { *msg = "column of L too long for the update encoding"; return false; }
-    o.rtgt.assign((size_t)(o.rsteps + SparsePlanHost::kSweepPad) * 64, o.nnzL + k);
-    o.rab.assign((size_t)(o.rsteps + SparsePlanHost::kSweepPad) * 64, 0);
-    // padding slots use a = b = maxcol (an extra zero entry of the column buffers) -> acc -= 0 * 0
-    for (auto &v : o.rab) v = o.maxcol | (o.maxcol << 16);
-    for (int kk = 0; kk < k; ++kk) {
-      const int c0 = o.Lp[kk], cnt = o.Lp[kk + 1] - c0;
-      size_t q = (size_t)o.rptr[kk] * 64;
-      for (int b = 0; b < cnt; ++b) {
-        const int j = o.Li[c0 + b];
-        // target column j: row r_a for a > b, diagonal for a == b
-        o.rtgt[q] = o.nnzL + j;
-        o.rab[q]  = b | (b << 16);
-        ++q;
-        for (int a = b + 1; a < cnt; ++a) {
-          const int pos = pos_in_col(j, o.Li[c0 + a]);
-          if (pos < 0) { *msg = "internal: fill entry missing from the pattern of L"; return false; }
-          o.rtgt[q] = pos;
-          o.rab[q]  = a | (b << 16);
-          ++q;
-        }
-      }
-    }
-  }
-
-  // supernodes (see sparse_plan.h)
-  {
     o.lds_doubles = std::max(k + 2, 2 * o.maxcol + 4);
-    o.snptr.clear();
+
+    // ---- relaxed supernodes (see sparse_plan.h) ----
+    // Greedy grouping of consecutive columns: the panel rows are the columns themselves plus the union U of
+    // their remaining row structures.  A column joins while the panel and its multipliers (2 w R doubles)
+    // fit the LDS scratch, w <= 16, and the union grows by at most kRelax rows over the larger of the two
+    // structures (explicit zeros cost LDS work, not HBM traffic).
+    constexpr int kRelax = 4, kMaxWidth = 16;
+    const int ZERO = o.nnzL + k + 1, SCRATCH = o.nnzL + k;  // accumulator indices: always-zero entry, padding sink
+    o.snptr.clear(); o.snR.clear(); o.poff.clear(); o.pmap.clear(); o.rptr.clear(); o.rtgt.clear(); o.rab.clear();
+    o.rptr.push_back(0);
     int j0 = 0;
     while (j0 < k) {
-      const int R    = (o.Lp[j0 + 1] - o.Lp[j0]) + 1;           // rows of the panel: j0 itself + struct(j0)
-      const int wmax = std::max(1, o.lds_doubles / (2 * R));
+      std::vector<int32_t> U(o.Li.begin() + o.Lp[j0], o.Li.begin() + o.Lp[j0 + 1]);  // sorted rows outside the panel
       int w = 1;
-      while (w < wmax && j0 + w < k) {
-        const int j = j0 + w - 1;  // does column j+1 continue the supernode?
-        const int cj = o.Lp[j + 1] - o.Lp[j], cn = o.Lp[j + 2] - o.Lp[j + 1];
-        if (cj >= 1 && o.Li[o.Lp[j]] == j + 1 && cj == cn + 1) ++w;
-        else break;
+      while (j0 + w < k && w < kMaxWidth) {
+        const int jn = j0 + w;
+        std::vector<int32_t> Un;
+        std::set_union(U.begin(), U.end(), o.Li.begin() + o.Lp[jn], o.Li.begin() + o.Lp[jn + 1], std::back_inserter(Un));
+        Un.erase(std::remove_if(Un.begin(), Un.end(), [&](int32_t r) { return r <= jn; }), Un.end());
+        const int Rn = (w + 1) + (int)Un.size();
+        if (2 * (w + 1) * Rn > o.lds_doubles) break;
+        int ubase = 0;
+        for (int32_t r : U) ubase += (r != jn);
+        const int base = std::max(ubase, o.Lp[jn + 1] - o.Lp[jn]);
+        if ((int)Un.size() - base > kRelax) break;
+        U.swap(Un);
+        ++w;
       }
+      const int nu = (int)U.size(), R = w + nu;
       o.snptr.push_back(j0);
+      o.snR.push_back(R);
+      // panel map: entry (row r, member jj), r >= jj; rows of L that are not in the member's structure are zeros
+      o.poff.push_back((int)o.pmap.size());
+      for (int jj = 0; jj < w; ++jj)
+        for (int r = 0; r < R; ++r) {
+          int src = SCRATCH;
+          if (r == jj) src = o.nnzL + j0 + jj;
+          else if (r > jj) {
+            const int g = (r < w) ? j0 + r : U[r - w];
+            const int pos = pos_in_col(j0 + jj, g);
+            src = (pos >= 0) ? pos : ZERO;
+          }
+          o.pmap.push_back(src);
+        }
+      // trailing schedule: pairs (a >= b) of U whose accumulator exists and is touched by some member
+      std::vector<std::array<int32_t, 2>> slots;
+      for (int bq = 0; bq < nu; ++bq)
+        for (int aq = bq; aq < nu; ++aq) {
+          const int rb = U[bq], ra = U[aq];
+          int tgt;
+          if (aq == bq) tgt = o.nnzL + rb;
+          else {
+            tgt = pos_in_col(rb, ra);
+            if (tgt < 0) continue;
+          }
+          bool touched = false;
+          for (int jj = 0; jj < w && !touched; ++jj)
+            touched = pos_in_col(j0 + jj, ra) >= 0 && pos_in_col(j0 + jj, rb) >= 0;
+          if (!touched) continue;
+          slots.push_back({tgt, aq | (bq << 16)});
+        }
+      const int steps = (int)((slots.size() + 63) / 64);
+      const size_t q0 = o.rtgt.size();
+      o.rtgt.resize(q0 + (size_t)steps * 64, SCRATCH);
+      o.rab.resize(q0 + (size_t)steps * 64, 0);
+      for (size_t e = 0; e < slots.size(); ++e) { o.rtgt[q0 + e] = slots[e][0]; o.rab[q0 + e] = slots[e][1]; }
+      o.rptr.push_back(o.rptr.back() + steps);
       j0 += w;
     }
     o.nsn = (int)o.snptr.size();
     o.snptr.push_back(k);
-    o.poff.assign(o.nsn + 1, 0);
-    o.pmap.clear();
-    for (int s = 0; s < o.nsn; ++s) {
-      const int c0 = o.snptr[s], w = o.snptr[s + 1] - c0, R = (o.Lp[c0 + 1] - o.Lp[c0]) + 1;
-      o.poff[s] = (int)o.pmap.size();
-      for (int jj = 0; jj < w; ++jj)
-        for (int r = 0; r < R; ++r)
-          o.pmap.push_back(r < jj ? o.nnzL + k : (r == jj ? o.nnzL + c0 + jj : o.Lp[c0 + jj] + (r - jj - 1)));
+    o.poff.push_back((int)o.pmap.size());
+    o.rsteps = o.rptr.back();
+    for (int pad = 0; pad < 64 * SparsePlanHost::kSweepPad; ++pad) {  // branch-free batched reads past the end
+      o.pmap.push_back(SCRATCH);
+      o.rtgt.push_back(SCRATCH);
+      o.rab.push_back(0);
     }
-    o.poff[o.nsn] = (int)o.pmap.size();
-    for (int pad = 0; pad < 64 * SparsePlanHost::kSweepPad; ++pad) o.pmap.push_back(o.nnzL + k);  // branch-free batched reads
   }
 
   // packed sweep schedules (see sparse_plan.h)

@@ -45,28 +45,27 @@ struct SparsePlanHost {
   static constexpr int kSweepPad = 16;
   std::vector<int32_t> fmap, fidx, bmap, bidx;
   int funits = 0, bunits = 0, idx_scale = 1;
-  // Right-looking factorisation schedule.  When column kk is final it updates, for every pair of its
-  // rows (r_a >= r_b), the accumulator of entry (r_a, r_b) [the diagonal D(r_b) when a == b]:
-  //   acc -= L(r_a,kk) * (L(r_b,kk) * D(kk)).
-  // All updates issued by one column hit distinct accumulators and columns are processed in order,
-  // so every accumulator receives its updates in ascending source order -- the same arithmetic as the
-  // left-looking loop of the oracle -- while a step is 64 independent, fully packed slots.
-  //   Kmap[p]  : accumulator index of KKT entry p   (accumulators: [L values (nnzL) | D (k) | scratch])
-  //   rptr[kk] : first 64-slot step of column kk (rptr[k] = total steps);  per slot:
-  //   rtgt[q]  : accumulator index (padding: nnzL + k),  rab[q] = a | b << 16 (entry numbers in column kk)
-  std::vector<int32_t> Kmap, rptr, rtgt, rab;
-  int rsteps = 0, maxcol = 0;
-  // Supernodes: runs of consecutive columns j0..j1 with struct(j) = {j+1} u struct(j+1).  All columns of a
-  // supernode update the SAME trailing accumulators (pairs of rows of struct(j1)), so the kernel eliminates
-  // the supernode's own (dense) panel in LDS and then applies its w rank-1 updates to every trailing
-  // accumulator with ONE read-modify-write (sources still in ascending order -> same bits), using the
-  // schedule of column j1.  Widths are capped so that the panel and its multipliers, 2 w (cnt(j0)+1)
-  // doubles, fit the kernel's LDS scratch of lds_doubles.
-  //   snptr[s] : first column of supernode s (snptr[nsn] = k)
-  //   poff[s]  : start of the supernode's panel map;  pmap[poff[s] + jj * R + r] = accumulator index of panel
-  //              entry (row r, column jj) for r >= jj (r == jj: D), else the scratch accumulator nnzL + k
-  std::vector<int32_t> snptr, poff, pmap;
-  int nsn = 0, lds_doubles = 0;
+  // Right-looking, supernodal factorisation schedule.  Accumulators: [L values (nnzL) | D (k) | scratch | zero];
+  // Kmap[p] = accumulator of KKT entry p.  When a column j is final it updates, for every pair of its rows
+  // (r_a >= r_b), the accumulator of entry (r_a, r_b) [the diagonal D(r_b) when a == b]:
+  //   acc = fma(-L(r_a,j), L(r_b,j) * D(j), acc),
+  // and every accumulator receives these updates in ascending order of j -- the arithmetic of the oracle's
+  // left-looking loop.
+  // RELAXED SUPERNODES: consecutive columns j0 .. j0+w-1 are grouped (greedily, see sparse_plan.cpp); the panel
+  // of a group has R = w + |U| rows, the columns themselves and the union U of their remaining row structures
+  // (entries of a member outside its own structure are explicit zeros: they stay exactly zero and contribute
+  // exact zeros).  The kernel eliminates the panel in LDS and then gives every TRAILING accumulator (a pair of
+  // rows of U) the w updates of the group with ONE read-modify-write, in ascending member order.  MPC pattern:
+  // 207 groups and 81 k accumulator touches per factorisation instead of 1 480 columns and 711 k touches.
+  //   snptr[s] : first column of group s (snptr[nsn] = k);   snR[s] : panel rows R
+  //   poff[s]  : start of the panel map;  pmap[poff[s] + jj * R + r] = accumulator of panel entry (row r, member jj)
+  //              for r >= jj (r == jj: D; "zero" where L has no entry), else the scratch accumulator
+  //   rptr[s]  : first 64-slot step of the trailing schedule of group s (rptr[nsn] = rsteps);  per slot:
+  //   rtgt[q]  : accumulator index (padding: scratch),  rab[q] = a | b << 16 (positions in U)
+  // Group widths are capped so that the panel and its multipliers, 2 w R doubles, fit the kernel's LDS
+  // scratch of lds_doubles.
+  std::vector<int32_t> Kmap, rptr, rtgt, rab, snptr, snR, poff, pmap;
+  int rsteps = 0, maxcol = 0, nsn = 0, lds_doubles = 0;
 };
 
 // ordering: 0 = natural, 1 = minimum degree (default); user_perm (k entries, new->old) overrides.
