@@ -514,24 +514,67 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
     int pass = 0;
     double crit;
     do {
-      double cm = 0.0;
-      // new increments into t[0..n) (columns) and t[n..k) (rows), computed from the OLD sx, sy
-      for (int j = lane; j < n; j += kWave) {
-        const double sxc = w.sx[j];
-        double inc       = 0.0;
-        for (int p = pl.Pp[j]; p < pl.Pp[j + 1]; ++p) inc = fmax(inc, fabs(c * w.sx[pl.Pi[p]] * sxc * it.Px[p]));
-        for (int p = pl.Acp[j]; p < pl.Acp[j + 1]; ++p) inc = fmax(inc, fabs(w.sy[pl.Aci[p]] * sxc * it.Ax[pl.Acpos[p]]));
-        if (inc == 0.0) inc = 1.0;
-        t[j] = inc;
-        cm   = fmax(cm, fabs(inc - 1.0));
+      // New increments into t[0..n) (columns) and t[n..k) (rows), computed from the OLD sx, sy.  An increment
+      // is a maximum over the entries of a column / row, so the entries are simply streamed in storage order
+      // (batched, independent loads) and folded in with LDS atomic maxima: same values as the nested
+      // per-column / per-row loops of the reference (:698-717) -- a maximum does not depend on the order, and
+      // |sy sx A| is the same product for the column and the row an entry belongs to.
+      for (int e = lane; e < k; e += kWave) t[e] = 0.0;
+      wave_sync();
+      constexpr int UB = 8;
+      for (int p0 = lane; p0 < pl.nnzP; p0 += kWave * UB) {
+        int rr[UB], cc[UB];
+        double pv[UB], sr[UB], sc[UB];
+#pragma unroll
+        for (int e = 0; e < UB; ++e) {
+          const int p = p0 + e * kWave;
+          const bool on = p < pl.nnzP;
+          rr[e] = on ? pl.Pi[p] : 0;
+          cc[e] = on ? pl.Pcol[p] : 0;
+          pv[e] = on ? it.Px[p] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < UB; ++e) {
+          sr[e] = w.sx[rr[e]];
+          sc[e] = w.sx[cc[e]];
+        }
+#pragma unroll
+        for (int e = 0; e < UB; ++e)
+          if (p0 + e * kWave < pl.nnzP)
+            __hip_atomic_fetch_max(&t[cc[e]], fabs(c * sr[e] * sc[e] * pv[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      for (int i = lane; i < m; i += kWave) {
-        const double syr = w.sy[i];
-        double inc       = 0.0;
-        for (int p = pl.Ap[i]; p < pl.Ap[i + 1]; ++p) inc = fmax(inc, fabs(syr * w.sx[pl.Aj[p]] * it.Ax[p]));
+      for (int p0 = lane; p0 < pl.nnzA; p0 += kWave * UB) {
+        int rr[UB], cc[UB];
+        double av[UB], sr[UB], sc[UB];
+#pragma unroll
+        for (int e = 0; e < UB; ++e) {
+          const int p = p0 + e * kWave;
+          const bool on = p < pl.nnzA;
+          rr[e] = on ? pl.Arow[p] : 0;
+          cc[e] = on ? pl.Aj[p] : 0;
+          av[e] = on ? it.Ax[p] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < UB; ++e) {
+          sr[e] = w.sy[rr[e]];
+          sc[e] = w.sx[cc[e]];
+        }
+#pragma unroll
+        for (int e = 0; e < UB; ++e) {
+          if (p0 + e * kWave < pl.nnzA) {
+            const double v = fabs(sr[e] * sc[e] * av[e]);
+            __hip_atomic_fetch_max(&t[cc[e]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_max(&t[n + rr[e]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+      wave_sync();
+      double cm = 0.0;
+      for (int e = lane; e < k; e += kWave) {
+        double inc = t[e];
         if (inc == 0.0) inc = 1.0;
-        t[n + i] = inc;
-        cm       = fmax(cm, fabs(inc - 1.0));
+        t[e] = inc;
+        cm   = fmax(cm, fabs(inc - 1.0));
       }
       wave_sync();
       for (int j = lane; j < n; j += kWave) w.sx[j] = sqrt(1.0 / fmax(t[j], 1e-8)) * w.sx[j];
