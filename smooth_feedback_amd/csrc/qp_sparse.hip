@@ -326,32 +326,61 @@ __device__ __forceinline__ double lane_max_abs(const double *v, int len, int lan
   return wave_max(r);
 }
 
-// rows of the sparse products, accumulation order of the oracle (storage order, fma)
-__device__ __forceinline__ double sp_row_A(const SparsePlanDev &pl, const Item &it, int i, const double *v)
+// rows of the sparse products, accumulation order of the oracle (storage order, fma).  The entries of a row
+// are fetched in chunks of UB: indices / positions first (independent loads), then the values and vector
+// entries they point to (independent again), then the fma chain -- two memory round trips per chunk instead
+// of two per ENTRY (a stopping check of a lone wave cost five ADMM iterations before).
+constexpr int kRowChunk = 8;
+template<class PosF, class IdxF>
+__device__ __forceinline__ double sp_row_dot(const int p0, const int p1, const double *vals, PosF pos, IdxF idx,
+                                             const double *v)
 {
   double s = 0.0;
-  for (int p = pl.Ap[i]; p < pl.Ap[i + 1]; ++p) s = fma(it.Ax[p], v[pl.Aj[p]], s);
+  for (int q = p0; q < p1; q += kRowChunk) {
+    int ps[kRowChunk], ix[kRowChunk];
+    double a[kRowChunk], x[kRowChunk];
+#pragma unroll
+    for (int e = 0; e < kRowChunk; ++e) {
+      const bool on = q + e < p1;
+      ps[e] = on ? pos(q + e) : 0;
+      ix[e] = on ? idx(q + e) : 0;
+    }
+#pragma unroll
+    for (int e = 0; e < kRowChunk; ++e) {
+      a[e] = vals[ps[e]];
+      x[e] = v[ix[e]];
+    }
+#pragma unroll
+    for (int e = 0; e < kRowChunk; ++e)
+      if (q + e < p1) s = fma(a[e], x[e], s);
+  }
   return s;
+}
+__device__ __forceinline__ double sp_row_A(const SparsePlanDev &pl, const Item &it, int i, const double *v)
+{
+  return sp_row_dot(pl.Ap[i], pl.Ap[i + 1], it.Ax, [](int p) { return p; }, [&](int p) { return pl.Aj[p]; }, v);
 }
 __device__ __forceinline__ double sp_row_At(const SparsePlanDev &pl, const Item &it, int j, const double *v)
 {
-  double s = 0.0;
-  for (int p = pl.Acp[j]; p < pl.Acp[j + 1]; ++p) s = fma(it.Ax[pl.Acpos[p]], v[pl.Aci[p]], s);
-  return s;
+  return sp_row_dot(pl.Acp[j], pl.Acp[j + 1], it.Ax, [&](int p) { return pl.Acpos[p]; },
+                    [&](int p) { return pl.Aci[p]; }, v);
 }
 __device__ __forceinline__ double sp_row_P(const SparsePlanDev &pl, const Item &it, int i, const double *v)
 {
-  double s = 0.0;
-  for (int p = pl.Prp[i]; p < pl.Prp[i + 1]; ++p) s = fma(it.Px[pl.Prpos[p]], v[pl.Prj[p]], s);
-  return s;
+  return sp_row_dot(pl.Prp[i], pl.Prp[i + 1], it.Px, [&](int p) { return pl.Prpos[p]; },
+                    [&](int p) { return pl.Prj[p]; }, v);
 }
 
 // QPSolver::check_stopping, qp_solver.hpp:574-644 (xus, yus, zus, dxus, dyus in the workspace).
+// t: LDS scratch (the work vector is free between the update phase of one iteration and the right-hand side of
+// the next).  The two order-dependent scalar sums of the test (:607-621, :633) are fed from LDS: their inputs
+// are fetched by all lanes in parallel, chunk by chunk, and only the dependent add / fma chain is sequential.
 __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it, const Ws &w,
-                                        const DenseKernelParams &kp, const int lane)
+                                        const DenseKernelParams &kp, double *t, const int lane)
 {
   const int n = pl.n, m = pl.m;
   const double inf = INFINITY;
+  const int chunk  = (pl.k + 1) / 2;  // pairs of doubles that fit the work vector
   {  // OPTIMALITY
     double a = 0.0, r = 0.0, z = 0.0;
     for (int i = lane; i < m; i += kWave) {
@@ -380,22 +409,25 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
     const double Aty_norm = wave_max(an);
     const double Edy_norm = lane_max_abs(w.dyus, m, lane);
     const double thr      = kp.eps_pinf * Edy_norm;
-    double acc            = 0.0;
-    for (int i = 0; i < m; ++i) {  // sequential certificate sum with early exit (uniform)
-      const double ui = it.u[i], li = it.l[i], dyi = w.dyus[i];
-      if (ui != inf) {
-        acc += ui * fmax(0.0, dyi);
-      } else if (dyi > thr) {
-        acc = inf;
-        break;
+    // Certificate sum, sequential over the rows with an early exit to +inf (:607-621).  Equivalent form: the
+    // result is +inf iff SOME row has an unbounded side with dy beyond the threshold; otherwise it is the
+    // ordered sum of u_i max(0,dy_i) then l_i min(0,dy_i) over the rows, where a skipped term adds +0.0 (exact:
+    // the running sum starts at +0.0 and therefore is never -0.0).
+    double acc = 0.0;
+    bool brk   = false;
+    for (int c0 = 0; c0 < m; c0 += chunk) {
+      const int c1 = min(m, c0 + chunk);
+      for (int i = c0 + lane; i < c1; i += kWave) {
+        const double ui = it.u[i], li = it.l[i], dyi = w.dyus[i];
+        t[2 * (i - c0)]     = (ui != inf) ? ui * fmax(0.0, dyi) : 0.0;
+        t[2 * (i - c0) + 1] = (li != -inf) ? li * fmin(0.0, dyi) : 0.0;
+        brk = brk || (ui == inf && dyi > thr) || (li == -inf && dyi < -thr);
       }
-      if (li != -inf) {
-        acc += li * fmin(0.0, dyi);
-      } else if (dyi < -thr) {
-        acc = inf;
-        break;
-      }
+      wave_sync();
+      for (int e = 0; e < 2 * (c1 - c0); ++e) acc += t[e];
+      wave_sync();
     }
+    if (wave_ballot(brk)) acc = inf;
     const double mxv = (Aty_norm < acc) ? acc : Aty_norm;
     if (mxv < thr) return SFB_QP_PRIMAL_INFEASIBLE;
   }
@@ -405,8 +437,17 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
     double pn            = 0.0;
     for (int j = lane; j < n; j += kWave) pn = fmax(pn, fabs(sp_row_P(pl, it, j, w.dxus)));
     const double Pdx_n = wave_max(pn);
-    double qdx         = 0.0;
-    for (int j = 0; j < n; ++j) qdx = fma(it.q[j], w.dxus[j], qdx);
+    double qdx         = 0.0;  // q' dx, sequential fma chain (:633) fed from LDS
+    for (int c0 = 0; c0 < n; c0 += chunk) {
+      const int c1 = min(n, c0 + chunk);
+      for (int j = c0 + lane; j < c1; j += kWave) {
+        t[2 * (j - c0)]     = it.q[j];
+        t[2 * (j - c0) + 1] = w.dxus[j];
+      }
+      wave_sync();
+      for (int e = 0; e < c1 - c0; ++e) qdx = fma(t[2 * e], t[2 * e + 1], qdx);
+      wave_sync();
+    }
     bool rowok = true;
     for (int i = lane; i < m; i += kWave) {
       const double Adx = sp_row_A(pl, it, i, w.dxus), ui = it.u[i], li = it.l[i];
@@ -746,7 +787,7 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
     }
     wave_sync();
     if (chk) {
-      ret_code = sp_check_stopping(pl, it, w, kp, lane);
+      ret_code = sp_check_stopping(pl, it, w, kp, t, lane);
       wave_sync();
       // Items that are still iterating after many checks are the ones the whole launch waits for:
       // raise their issue priority over the co-resident waves that are in their first iterations.
