@@ -364,7 +364,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": wl.name, "per_gpu_batch": wl.B, "global_batch": wl.B * world,
-                       "parallelism": "batch-sharded x%d, gather of (iter,code) only" % world},
+                       "parallelism": "batch-sharded x%d, one gather of the small per-item outputs (u0 / code / iter)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_BYTES_PER_S, "traffic": None,
                          "kernel": kernel_name, "kernel_ms": kern_ms,
