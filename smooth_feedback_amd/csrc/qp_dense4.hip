@@ -8,10 +8,14 @@
 //     triangular sweep stays inside the row (no row swaps) and one instruction stream advances four
 //     QPs in lockstep.  The L10 block update is interleaved with the L00 chain (step J of one is the
 //     wait state of the other);
-//   - iteration counts differ per QP, so slots are refilled from a device-side queue (atomic ticket):
-//     a persistent grid of waves, each slot takes the next problem when its own finishes.  New
-//     problems start only on iterations that are multiples of stop_check_iter, which keeps the
-//     stopping checks of the four slots on the same iteration; the check itself runs row-parallel;
+//   - iteration counts differ per QP (2 ... max_iter), so the grid is persistent and slots are refilled from
+//     a device-side queue.  The queue is TIME-SLICED: a QP that has held its slot for a slice of iterations
+//     while others are waiting goes back to the end of the queue (its iterate and iteration count are in
+//     its record anyway) -- round-robin among the long runners, so that they finish together at the end of
+//     the launch instead of the last-started one running alone (greedy list scheduling left a third of the
+//     benchmark batch's time to that tail).  Problems start / resume only on iterations that are multiples
+//     of stop_check_iter, which keeps the stopping checks of the four slots on the same iteration; the
+//     check itself runs row-parallel;
 //   - the wave-wide parts of a solve do not run in this kernel at all.  A launch is three kernels:
 //       setup    one wavefront per QP (massively parallel): scaling, KKT, pivoted LDL' (qp_dense_common.h),
 //                then every lane writes the registers of "its" lane of the iterate kernel (factor blocks,
@@ -482,7 +486,22 @@ __global__ void __launch_bounds__(64, 2) qp_dense4_iterate_kernel(const DenseKer
   const uint32_t maxit = kp.max_iter;
   const bool aligned   = sci >= 2;  // iter % sci == 1 never holds for sci <= 1 (:465)
   uint32_t phase       = 0;         // iteration index of every running slot, mod sci
-  bool qempty          = false;
+  // Queue (zeroed by the launcher).  FRESH QPs are handed out in index order by a ticket counter; SUSPENDED ones
+  // go through a ring: push j writes (j+1) << 32 | id+1 into ring[j % batch] (after the previous user of that
+  // entry has cleared it), pop ticket t -- also a plain atomicAdd, wait-free -- may be ahead of the pushes: the
+  // slot then keeps its ticket and polls its ring entry at the following refill points.
+  unsigned *const q_fresh = queue, *const q_rhead = queue + 16, *const q_tail = queue + 32, *const q_done = queue + 48;
+  unsigned long long *const ring = reinterpret_cast<unsigned long long *>(queue + 64);
+  constexpr unsigned kNone = 0xFFFFFFFFu;
+  uint32_t it0[kSlots];    // iteration count at which the slot took its QP
+  unsigned pend[kSlots];   // ring ticket the (empty) slot is waiting for
+#pragma unroll
+  for (int s = 0; s < kSlots; ++s) {
+    it0[s]  = 0;
+    pend[s] = kNone;
+  }
+  bool fresh_left      = true;
+  const uint32_t slice = aligned ? 20u * sci : 512u;  // iterations a QP may hold a slot while others wait
 
   // scaled iterate of slot s -> its record (original order), status and iteration count
   auto finish_slot = [&](const int s, const int code, const uint32_t iters) {
@@ -500,37 +519,110 @@ __global__ void __launch_bounds__(64, 2) qp_dense4_iterate_kernel(const DenseKer
         rec[R.off_iter] = (double)iters;
       }
     }
+    if (lane == 0) atomicAdd(q_done, 1u);
   };
-
-  for (;;) {
-    // ---- refill empty slots: one ticket fetch for all of them, then every row loads its own QP ----
-    if (!aligned || phase == 0) {
-      for (;;) {
-        unsigned nfree = 0;
+  // slot s gives its QP back to the queue: iterate and iteration count -> record, id -> ring
+  auto suspend_slot = [&](const int s) {
+    double *rec = wsp + (size_t)qb[s] * (size_t)R.size;
+    if (row == s) {
+      double *lr = rec + cc;
 #pragma unroll
-        for (int s = 0; s < kSlots; ++s) nfree += (qb[s] < 0) ? 1u : 0u;
-        if (nfree == 0 || qempty) break;
-        unsigned base = 0;
-        if (lane == 0) base = atomicAdd(queue, nfree);
-        base = __builtin_amdgcn_readfirstlane(base);
+      for (int b = 0; b < NB; ++b) {
+        double *st = lr + (R.reg_state + 8 * b) * 16;
+        st[0 * 16] = ws[b];
+        st[1 * 16] = zs[b];
+        role[b] = 0;
+        ws[b] = 0.0; zs[b] = 0.0; lo[b] = 0.0;
+      }
+      if (cc == 0) rec[R.off_iter] = (double)it[s];
+    }
+    __threadfence();  // the record is complete (device scope) before the id can be popped
+    if (lane == 0) {
+      const unsigned j           = atomicAdd(q_tail, 1u);
+      unsigned long long *slot   = ring + (j % batch);
+      const unsigned long long v = ((unsigned long long)(j + 1u) << 32) | ((unsigned)qb[s] + 1u);
+      while (atomicCAS(slot, 0ull, v) != 0ull) __builtin_amdgcn_s_sleep(1);
+    }
+    qb[s] = -1;
+  };
+  for (;;) {
+    // ---- refill point: hand long runners back if others are waiting, then take QPs for the empty slots,
+    //      every row loads its own ----
+    if (!aligned || phase == 0) {
+      bool due = false;
+#pragma unroll
+      for (int s = 0; s < kSlots; ++s) due = due || (qb[s] >= 0 && it[s] - it0[s] >= slice);
+      if (due) {
+        unsigned waiting = 0;
+        if (lane == 0) {
+          const unsigned fr = __hip_atomic_load(q_fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned h  = __hip_atomic_load(q_rhead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned p  = __hip_atomic_load(q_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          waiting = (fr < batch || (int)(p - h) > 0) ? 1u : 0u;  // QPs that have no slot
+        }
+        if (__builtin_amdgcn_readfirstlane(waiting)) {
+#pragma unroll
+          for (int s = 0; s < kSlots; ++s)
+            if (qb[s] >= 0 && it[s] - it0[s] >= slice) suspend_slot(s);
+        } else {
+#pragma unroll
+          for (int s = 0; s < kSlots; ++s)
+            if (qb[s] >= 0 && it[s] - it0[s] >= slice) it0[s] = it[s];  // nobody waits: a fresh slice
+        }
+      }
+      for (;;) {
         int tk[kSlots];
-        int mine = -1;  // ticket of this lane's row, if the row is being refilled
+        int mine = -1;  // QP of this lane's row, if the row is being refilled
+        bool got_any = false;
+        unsigned nfree = 0;
 #pragma unroll
         for (int s = 0; s < kSlots; ++s) {
           tk[s] = -1;
+          nfree += (qb[s] < 0 && pend[s] == kNone) ? 1u : 0u;
+        }
+        unsigned base = batch;
+        if (fresh_left && nfree != 0) {
+          if (lane == 0) base = atomicAdd(q_fresh, nfree);
+          base = __builtin_amdgcn_readfirstlane(base);
+        }
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) {
           if (qb[s] < 0) {
-            if (base < batch) tk[s] = (int)base;
-            else qempty = true;
-            ++base;
+            if (pend[s] == kNone) {
+              if (base < batch) {
+                tk[s] = (int)base++;
+              } else {  // no fresh QP left: queue up for a suspended one
+                fresh_left = false;
+                unsigned t = 0;
+                if (lane == 0) t = atomicAdd(q_rhead, 1u);
+                pend[s] = __builtin_amdgcn_readfirstlane(t);
+              }
+            }
+            if (pend[s] != kNone) {
+              unsigned long long e = 0;
+              if (lane == 0) e = __hip_atomic_load(ring + (pend[s] % batch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)e);
+              const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(e >> 32));
+              if (hi32 == pend[s] + 1u) {  // my entry has arrived
+                if (lane == 0) __hip_atomic_store(ring + (pend[s] % batch), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tk[s]   = (int)(lo32 - 1u);
+                pend[s] = kNone;
+              }
+            }
+            got_any = got_any || tk[s] >= 0;
           }
           if (row == s) mine = tk[s];
         }
+        if (!got_any) break;
+        __threadfence();  // records of resumed QPs were written by other waves
         bool accepted = false;
+        uint32_t my_it = 0;
         if (mine >= 0) {
           const double *rec = wsp + (size_t)mine * (size_t)R.size;
           // a QP that ended in setup (pre-check, failed factorisation) is reported by the finish kernel
           accepted = rec[R.off_code] < 0.0;
           if (accepted) {
+            my_it = (uint32_t)rec[R.off_iter];
             const double *lr = rec + cc;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -578,9 +670,14 @@ __global__ void __launch_bounds__(64, 2) qp_dense4_iterate_kernel(const DenseKer
         const unsigned long long acc = wave_ballot(accepted);
 #pragma unroll
         for (int s = 0; s < kSlots; ++s) {
-          if (tk[s] >= 0 && ((acc >> (16 * s)) & 1ull)) {
-            qb[s] = tk[s];
-            it[s] = 0;
+          if (tk[s] >= 0) {
+            if ((acc >> (16 * s)) & 1ull) {
+              qb[s]  = tk[s];
+              it[s]  = (uint32_t)__builtin_amdgcn_readlane((int)my_it, 16 * s);
+              it0[s] = it[s];
+            } else if (lane == 0) {
+              atomicAdd(q_done, 1u);  // ended in the setup kernel
+            }
           }
         }
       }
@@ -597,11 +694,16 @@ __global__ void __launch_bounds__(64, 2) qp_dense4_iterate_kernel(const DenseKer
       }
     }
     if (!any) {
-      if (qempty) break;
+      unsigned d = 0;
+      if (lane == 0) d = __hip_atomic_load(q_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__builtin_amdgcn_readfirstlane(d) >= batch) break;  // every QP has left the loop
+      __builtin_amdgcn_s_sleep(8);                             // others still hold QPs that may come back
       phase = 0;  // nothing is running: any iteration can be iteration 0
       continue;
     }
-    want = want && !qempty;
+    // come back at the next refill point if a slot is empty or a slice runs out before the next event
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) want = want || (qb[s] >= 0 && it[s] - it0[s] + sci >= slice);
 
     // ---- plain iterations up to the next event: a stopping check (phase == 1), a slot reaching
     //      max_iter, or a refill point.  The tight loop keeps only factor + iterate state live. ----
@@ -747,30 +849,15 @@ __global__ void __launch_bounds__(64) qp_dense4_finish_kernel(const DenseKernelP
 
 size_t qp_dense4_lds_bytes(int n, int m) { return (size_t)kSlots * slot4_doubles(n, m) * sizeof(double); }
 
-// device-side ticket counters, one per launch in flight (zeroed on the launch's stream)
-static unsigned *ticket_pool(int &index)
-{
-  constexpr int kPool = 256, kMaxDev = 64;
-  static unsigned *pool[kMaxDev] = {};
-  static unsigned next[kMaxDev]  = {};
-  static std::mutex mtx;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
-  std::lock_guard<std::mutex> lock(mtx);
-  if (!pool[dev]) {
-    if (hipMalloc(&pool[dev], kPool * 64) != hipSuccess) return nullptr;  // one counter per 64-byte line
-  }
-  index = (int)(__atomic_fetch_add(&next[dev], 1u, __ATOMIC_RELAXED) % kPool);
-  return pool[dev];
-}
-
 template<int NB>
-static hipError_t launch4(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, unsigned *queue, int ncu,
-                          hipStream_t stream)
+static hipError_t launch4(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, int ncu, hipStream_t stream)
 {
-  // per-launch workspace of QP records, stream-ordered (no device synchronisation in the steady state)
-  const Rec4 R       = rec4_layout<NB>(kp.n, kp.m);
-  const size_t bytes = (size_t)batch * (size_t)R.size * sizeof(double);
+  // per-launch workspace: QP records, then the queue (4 counters on their own cache lines + ring of `batch`
+  // 8-byte entries); stream-ordered allocation (no device synchronisation in the steady state)
+  const Rec4 R        = rec4_layout<NB>(kp.n, kp.m);
+  const size_t rbytes = (size_t)batch * (size_t)R.size * sizeof(double);
+  const size_t qbytes = 64 * sizeof(unsigned) + (size_t)batch * sizeof(unsigned long long);
+  const size_t bytes  = rbytes + qbytes;
   double *wsp        = nullptr;
   bool async_alloc   = true;
   hipError_t e       = hipMallocAsync(reinterpret_cast<void **>(&wsp), bytes, stream);
@@ -780,6 +867,9 @@ static hipError_t launch4(const DenseKernelParams &kp, int64_t batch, const QpBa
     e           = hipMalloc(reinterpret_cast<void **>(&wsp), bytes);
     if (e != hipSuccess) return e;
   }
+  unsigned *queue = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(wsp) + rbytes);
+  e               = hipMemsetAsync(queue, 0, qbytes, stream);
+  if (e != hipSuccess) return e;
   const dim3 block(kWave), full((unsigned)batch);
   const size_t lds1 = qp_dense_lds_bytes(kp.n, kp.m);
   hipLaunchKernelGGL((qp_dense4_setup_kernel<NB>), full, block, lds1, stream, kp, g, wsp);
@@ -821,13 +911,7 @@ hipError_t qp_dense4_launch(const DenseKernelParams &kp, int64_t batch, const Qp
     if (e != hipSuccess) return e;
   }
   const int ncu = (dev >= 0 && dev < 64 && cus[dev] > 0) ? cus[dev] : 256;
-  int ti = 0;
-  unsigned *pool = ticket_pool(ti);
-  if (!pool) return hipErrorOutOfMemory;
-  unsigned *queue = pool + 16 * ti;
-  e = hipMemsetAsync(queue, 0, sizeof(unsigned), stream);
-  if (e != hipSuccess) return e;
-  return (kp.n + kp.m <= 16) ? launch4<1>(kp, batch, g, queue, ncu, stream) : launch4<2>(kp, batch, g, queue, ncu, stream);
+  return (kp.n + kp.m <= 16) ? launch4<1>(kp, batch, g, ncu, stream) : launch4<2>(kp, batch, g, ncu, stream);
 }
 
 }  // namespace sfb
