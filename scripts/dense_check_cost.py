@@ -17,5 +17,8 @@ def run(prm):
     e0.record(s); go(); e1.record(s); torch.cuda.synchronize()
     return e0.elapsed_time(e1)
 kw = dict(max_iter=1200, scaling=False, polish=False, eps_abs=1e-30, eps_rel=1e-30, eps_primal_inf=1e-30, eps_dual_inf=1e-30)
-a = run(sfb.QPSolverParams(stop_check_iter=1, **kw)); b = run(sfb.QPSolverParams(stop_check_iter=25, **kw))
-print("1200 iterations: no checks %.2f ms, checks every 25 %.2f ms -> +%.1f %%" % (a, b, 100 * (b - a) / a))
+a = run(sfb.QPSolverParams(stop_check_iter=1, **kw))
+for sci in (25, 50, 100, 300):
+    b = run(sfb.QPSolverParams(stop_check_iter=sci, **kw))
+    print("1200 iterations: no checks %.2f ms, checks every %d: %.2f ms -> +%.1f %% = %.2f us per check and wave" % (
+        a, sci, b, 100 * (b - a) / a, (b - a) * 1e3 / (1200 / sci) / (B / 8192.0)))

@@ -448,7 +448,8 @@ __global__ void __launch_bounds__(64) qp_dense4_setup_kernel(const DenseKernelPa
 template<int NB>
 __global__ void __launch_bounds__(64, 2) qp_dense4_iterate_kernel(const DenseKernelParams kp, const QpBatch g,
                                                                   double *__restrict__ wsp,
-                                                                  unsigned *__restrict__ queue, const unsigned batch)
+                                                                  unsigned *__restrict__ queue, const unsigned batch,
+                                                                  const unsigned slice_checks)
 {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x, row = lane >> 4, cc = lane & 15;
@@ -501,7 +502,8 @@ __global__ void __launch_bounds__(64, 2) qp_dense4_iterate_kernel(const DenseKer
     pend[s] = kNone;
   }
   bool fresh_left      = true;
-  const uint32_t slice = aligned ? 20u * sci : 512u;  // iterations a QP may hold a slot while others wait
+  // iterations a QP may hold a slot while others wait (a multiple of the check interval)
+  const uint32_t slice = aligned ? slice_checks * sci : slice_checks * 25u;
 
   // scaled iterate of slot s -> its record (original order), status and iteration count
   auto finish_slot = [&](const int s, const int code, const uint32_t iters) {
@@ -886,8 +888,11 @@ static hipError_t launch4(const DenseKernelParams &kp, int64_t batch, const QpBa
     if (c >= 1 && c < max_waves) max_waves = c;
   }
   const dim3 grid((unsigned)(batch < max_waves ? batch : max_waves));
+  unsigned slice_checks = 80;  // time slice in stopping-check intervals (2 000 iterations at the default 25)
+  if (const char *sl = getenv("SFB_QP4_SLICE")) slice_checks = (unsigned)atoi(sl) > 0 ? (unsigned)atoi(sl) : 1u;  // A/B, tests
   if (kp.max_iter != 0)  // nothing to iterate otherwise: the finish kernel reports the initial iterate
-    hipLaunchKernelGGL((qp_dense4_iterate_kernel<NB>), grid, block, lds, stream, kp, g, wsp, queue, (unsigned)batch);
+    hipLaunchKernelGGL((qp_dense4_iterate_kernel<NB>), grid, block, lds, stream, kp, g, wsp, queue, (unsigned)batch,
+                       slice_checks);
   hipLaunchKernelGGL((qp_dense4_finish_kernel<NB>), full, block, lds1, stream, kp, g, wsp);
   e = hipGetLastError();
   if (async_alloc) {
