@@ -502,6 +502,7 @@ __global__ void __launch_bounds__(64, 2) qp_dense4_iterate_kernel(const DenseKer
     pend[s] = kNone;
   }
   bool fresh_left      = true;
+  unsigned local_done  = 0;  // QPs this wave has finished since its last report to q_done
   // iterations a QP may hold a slot while others wait (a multiple of the check interval)
   const uint32_t slice = aligned ? slice_checks * sci : slice_checks * 25u;
 
@@ -521,7 +522,7 @@ __global__ void __launch_bounds__(64, 2) qp_dense4_iterate_kernel(const DenseKer
         rec[R.off_iter] = (double)iters;
       }
     }
-    if (lane == 0) atomicAdd(q_done, 1u);
+    ++local_done;
   };
   // slot s gives its QP back to the queue: iterate and iteration count -> record, id -> ring
   auto suspend_slot = [&](const int s) {
@@ -575,7 +576,7 @@ __global__ void __launch_bounds__(64, 2) qp_dense4_iterate_kernel(const DenseKer
       for (;;) {
         int tk[kSlots];
         int mine = -1;  // QP of this lane's row, if the row is being refilled
-        bool got_any = false;
+        bool got_any = false, resumed = false;
         unsigned nfree = 0;
 #pragma unroll
         for (int s = 0; s < kSlots; ++s) {
@@ -609,6 +610,7 @@ __global__ void __launch_bounds__(64, 2) qp_dense4_iterate_kernel(const DenseKer
                 if (lane == 0) __hip_atomic_store(ring + (pend[s] % batch), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 tk[s]   = (int)(lo32 - 1u);
                 pend[s] = kNone;
+                resumed = true;
               }
             }
             got_any = got_any || tk[s] >= 0;
@@ -616,7 +618,7 @@ __global__ void __launch_bounds__(64, 2) qp_dense4_iterate_kernel(const DenseKer
           if (row == s) mine = tk[s];
         }
         if (!got_any) break;
-        __threadfence();  // records of resumed QPs were written by other waves
+        if (resumed) __threadfence();  // records of resumed QPs were written by other waves
         bool accepted = false;
         uint32_t my_it = 0;
         if (mine >= 0) {
@@ -677,8 +679,8 @@ __global__ void __launch_bounds__(64, 2) qp_dense4_iterate_kernel(const DenseKer
               qb[s]  = tk[s];
               it[s]  = (uint32_t)__builtin_amdgcn_readlane((int)my_it, 16 * s);
               it0[s] = it[s];
-            } else if (lane == 0) {
-              atomicAdd(q_done, 1u);  // ended in the setup kernel
+            } else {
+              ++local_done;  // ended in the setup kernel
             }
           }
         }
@@ -697,7 +699,11 @@ __global__ void __launch_bounds__(64, 2) qp_dense4_iterate_kernel(const DenseKer
     }
     if (!any) {
       unsigned d = 0;
-      if (lane == 0) d = __hip_atomic_load(q_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) {  // report (one atomic per idle period, not per QP), then look at the total
+        if (local_done != 0) atomicAdd(q_done, local_done);
+        d = __hip_atomic_load(q_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      local_done = 0;
       if (__builtin_amdgcn_readfirstlane(d) >= batch) break;  // every QP has left the loop
       __builtin_amdgcn_s_sleep(8);                             // others still hold QPs that may come back
       phase = 0;  // nothing is running: any iteration can be iteration 0
