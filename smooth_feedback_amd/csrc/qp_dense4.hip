@@ -152,16 +152,13 @@ __device__ inline int check_rows(const Lds &s, const DenseKernelParams &kp, cons
     }
   }
 
-  // PRIMAL INFEASIBILITY :598-621
+  // PRIMAL INFEASIBILITY :598-621.  The verdict is max(|A'dy|, certificate sum) < thr; the expensive A'dy is
+  // only formed when the certificate sum does not already rule the verdict out (same result, NaN included).
   if (res < 0) {
-    double a1 = 0.0, a2 = 0.0;
+    double a2 = 0.0;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int i = cc + 16 * b;
-      a1          = fmax(a1, ln[b] ? fabs(row_At(s, n, m, i, s.dyus)) : 0.0);
-      a2          = fmax(a2, lm[b] ? fabs(s.dyus[i]) : 0.0);
-    }
-    const double Aty_norm = row_max16(a1), Edy_norm = row_max16(a2);
+    for (int b = 0; b < NB; ++b) a2 = fmax(a2, lm[b] ? fabs(s.dyus[cc + 16 * b]) : 0.0);
+    const double Edy_norm = row_max16(a2);
     const double thr      = kp.eps_pinf * Edy_norm;
     double acc            = 0.0;  // sequential with early exit, every lane of the row runs it
     for (int i = 0; i < m; ++i) {
@@ -179,44 +176,52 @@ __device__ inline int check_rows(const Lds &s, const DenseKernelParams &kp, cons
         break;
       }
     }
-    const double mxv = (Aty_norm < acc) ? acc : Aty_norm;  // std::max(a,b) = (a<b)?b:a
-    if (mxv < thr) res = SFB_QP_PRIMAL_INFEASIBLE;
+    if (!(acc >= thr)) {
+      double a1 = 0.0;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) a1 = fmax(a1, ln[b] ? fabs(row_At(s, n, m, cc + 16 * b, s.dyus)) : 0.0);
+      const double Aty_norm = row_max16(a1);
+      const double mxv      = (Aty_norm < acc) ? acc : Aty_norm;  // std::max(a,b) = (a<b)?b:a
+      if (mxv < thr) res = SFB_QP_PRIMAL_INFEASIBLE;
+    }
   }
 
-  // DUAL INFEASIBILITY :625-641
+  // DUAL INFEASIBILITY :625-641: |P dx| <= thr, q'dx <= thr and the row conditions on A dx; evaluated cheapest
+  // first, the later ones only while the verdict is still open.
   if (res < 0) {
     double a1 = 0.0, a2 = 0.0;
-    double Adx[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const int i = cc + 16 * b;
-      Adx[b]      = lm[b] ? row_A(s, n, m, i, s.dxus) : 0.0;
       a1          = fmax(a1, ln[b] ? fabs(s.dxus[i]) : 0.0);
       a2          = fmax(a2, ln[b] ? fabs(row_P(s, n, i, s.dxus)) : 0.0);
     }
     const double dx_norm = row_max16(a1), Pdx_n = row_max16(a2);
-    double qdx           = 0.0;
-    for (int j = 0; j < n; ++j) qdx = fma(s.q[j], s.dxus[j], qdx);
-    const double thr = kp.eps_dinf * dx_norm;
-    const bool ok    = (Pdx_n <= thr) && (qdx <= thr);
-    double viol      = 0.0;
+    const double thr     = kp.eps_dinf * dx_norm;
+    if (Pdx_n <= thr) {
+      double qdx = 0.0;
+      for (int j = 0; j < n; ++j) qdx = fma(s.q[j], s.dxus[j], qdx);
+      if (qdx <= thr) {
+        double viol = 0.0;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      if (lm[b]) {
-        const int i     = cc + 16 * b;
-        const double ui = s.u[i], li = s.l[i];
-        bool rowok;
-        if (ui == inf) {
-          rowok = Adx[b] >= -thr;
-        } else if (li == -inf) {
-          rowok = Adx[b] <= thr;
-        } else {
-          rowok = fabs(Adx[b]) < thr;
+        for (int b = 0; b < NB; ++b) {
+          if (lm[b]) {
+            const int i      = cc + 16 * b;
+            const double Adx = row_A(s, n, m, i, s.dxus), ui = s.u[i], li = s.l[i];
+            bool rowok;
+            if (ui == inf) {
+              rowok = Adx >= -thr;
+            } else if (li == -inf) {
+              rowok = Adx <= thr;
+            } else {
+              rowok = fabs(Adx) < thr;
+            }
+            if (!rowok) viol = 1.0;
+          }
         }
-        if (!rowok) viol = 1.0;
+        if (row_max16(viol) == 0.0) res = SFB_QP_DUAL_INFEASIBLE;
       }
     }
-    if (ok && row_max16(viol) == 0.0) res = SFB_QP_DUAL_INFEASIBLE;
   }
   return res;
 }
