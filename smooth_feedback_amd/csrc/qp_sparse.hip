@@ -403,10 +403,8 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
       if (wave_max(rn) <= kp.eps_abs + kp.eps_rel * dual_scale) return SFB_QP_OPTIMAL;
     }
   }
-  {  // PRIMAL INFEASIBILITY
-    double an = 0.0;
-    for (int j = lane; j < n; j += kWave) an = fmax(an, fabs(sp_row_At(pl, it, j, w.dyus)));
-    const double Aty_norm = wave_max(an);
+  {  // PRIMAL INFEASIBILITY: max(|A'dy|, certificate sum) < thr.  The cheap certificate sum is formed first and
+     // A'dy only when the sum leaves the verdict open (same result, NaN included).
     const double Edy_norm = lane_max_abs(w.dyus, m, lane);
     const double thr      = kp.eps_pinf * Edy_norm;
     // Certificate sum, sequential over the rows with an early exit to +inf (:607-621).  Equivalent form: the
@@ -428,16 +426,23 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
       wave_sync();
     }
     if (wave_ballot(brk)) acc = inf;
-    const double mxv = (Aty_norm < acc) ? acc : Aty_norm;
-    if (mxv < thr) return SFB_QP_PRIMAL_INFEASIBLE;
+    if (!(acc >= thr)) {
+      double an = 0.0;
+      for (int j = lane; j < n; j += kWave) an = fmax(an, fabs(sp_row_At(pl, it, j, w.dyus)));
+      const double Aty_norm = wave_max(an);
+      const double mxv      = (Aty_norm < acc) ? acc : Aty_norm;
+      if (mxv < thr) return SFB_QP_PRIMAL_INFEASIBLE;
+    }
   }
-  {  // DUAL INFEASIBILITY
+  {  // DUAL INFEASIBILITY: |P dx| <= thr, q'dx <= thr and the row conditions on A dx, each evaluated only while
+     // the verdict is still open.
     const double dx_norm = lane_max_abs(w.dxus, n, lane);
     const double thr     = kp.eps_dinf * dx_norm;
     double pn            = 0.0;
     for (int j = lane; j < n; j += kWave) pn = fmax(pn, fabs(sp_row_P(pl, it, j, w.dxus)));
     const double Pdx_n = wave_max(pn);
-    double qdx         = 0.0;  // q' dx, sequential fma chain (:633) fed from LDS
+    if (!(Pdx_n <= thr)) return -1;
+    double qdx = 0.0;  // q' dx, sequential fma chain (:633) fed from LDS
     for (int c0 = 0; c0 < n; c0 += chunk) {
       const int c1 = min(n, c0 + chunk);
       for (int j = c0 + lane; j < c1; j += kWave) {
@@ -448,6 +453,7 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
       for (int e = 0; e < c1 - c0; ++e) qdx = fma(t[2 * e], t[2 * e + 1], qdx);
       wave_sync();
     }
+    if (!(qdx <= thr)) return -1;
     bool rowok = true;
     for (int i = lane; i < m; i += kWave) {
       const double Adx = sp_row_A(pl, it, i, w.dxus), ui = it.u[i], li = it.l[i];
@@ -455,7 +461,7 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
       else if (li == -inf) rowok = rowok && (Adx <= thr);
       else rowok = rowok && (fabs(Adx) < thr);
     }
-    if ((Pdx_n <= thr) && (qdx <= thr) && !wave_ballot(!rowok)) return SFB_QP_DUAL_INFEASIBLE;
+    if (!wave_ballot(!rowok)) return SFB_QP_DUAL_INFEASIBLE;
   }
   return -1;
 }
