@@ -141,10 +141,10 @@ int fill_pattern(const M & mpc, int32_t * Pp, int32_t * Pi, double * Pval, int32
   return 0;
 }
 
-template<class M, class XF, class X>
+template<class M, class XF, class X, class Swarm = MPCSwarm<M>>
 int swarm_step(M & mpc, XF xdes, int64_t batch, uint64_t seed, int ticks, double * u0, int32_t * codes, uint32_t * iters)
 {
-  MPCSwarm<M> swarm(mpc, batch);
+  Swarm swarm(mpc, batch);
   std::vector<double> t(batch);
   std::vector<X> xs(batch);
   for (int64_t b = 0; b < batch; ++b) {
@@ -170,6 +170,23 @@ int swarm_step(M & mpc, XF xdes, int64_t batch, uint64_t seed, int ticks, double
   }
   return 0;
 }
+template<class M, class XF>
+int records_batch(M & mpc, XF xdes, int64_t batch, uint64_t seed, double * rec, int threads)
+{
+  const int64_t rd = M::record_doubles(mpc.N());
+  const int T = std::max(1, std::min<int>(threads > 0 ? threads : (int)std::thread::hardware_concurrency(), (int)std::max<int64_t>(1, batch)));
+  std::vector<std::thread> th;
+  for (int k = 0; k < T; ++k)
+    th.emplace_back([&, k] {
+      for (int64_t b = batch * k / T; b < batch * (k + 1) / T; ++b) {
+        const double t = 0.025 * double(b % 400);
+        mpc.fill_record(t, perturbed(xdes(t), seed + (uint64_t)b), rec + (size_t)b * rd);
+      }
+    });
+  for (auto & t : th) t.join();
+  return 0;
+}
+
 Vec<6> mpc_dyn(MPC6 &, const X6 & x, const U2 & u) { return VehicleDyn6{}(x, u); }
 Vec<12> mpc_dyn(MPC12 &, const X12 & x, const U2 & u) { return VehicleDyn12{}(x, u); }
 
@@ -212,6 +229,44 @@ int sfbx_mpc_assemble_batch(int variant, int K, double tf, int64_t batch, uint64
 {
   if (variant == 6) { auto mpc = make6(K, tf); return assemble_batch(mpc, xdes6, batch, seed, Aval, l, u, threads); }
   if (variant == 12) { auto mpc = make12(K, tf); return assemble_batch(mpc, xdes12, batch, seed, Aval, l, u, threads); }
+  return -1;
+}
+
+int sfbx_mpc_layout(int variant, int K, double tf, int32_t * dims, double * alpha, double * D, int32_t * kind,
+                    int32_t * dof, double * crl, double * cru)
+{
+  auto fill = [&](const auto & mpc) {
+    auto L = mpc.device_layout();
+    dims[0] = L->c.nx; dims[1] = L->c.nu; dims[2] = L->c.ncr; dims[3] = L->c.kmesh; dims[4] = L->c.nivals; dims[5] = L->c.nparts;
+    std::copy(L->alpha.begin(), L->alpha.end(), alpha);
+    std::copy(L->D.begin(), L->D.end(), D);
+    std::copy(L->kind.begin(), L->kind.end(), kind);
+    std::copy(L->dof.begin(), L->dof.end(), dof);
+    std::copy(L->crl.begin(), L->crl.end(), crl);
+    std::copy(L->cru.begin(), L->cru.end(), cru);
+    return 0;
+  };
+  if (variant == 6) { auto mpc = make6(K, tf); return fill(mpc); }
+  if (variant == 12) { auto mpc = make12(K, tf); return fill(mpc); }
+  return -1;
+}
+
+int sfbx_mpc_records(int variant, int K, double tf, int64_t batch, uint64_t seed, double * rec, int threads)
+{
+  if (variant == 6) { auto mpc = make6(K, tf); return records_batch(mpc, xdes6, batch, seed, rec, threads); }
+  if (variant == 12) { auto mpc = make12(K, tf); return records_batch(mpc, xdes12, batch, seed, rec, threads); }
+  return -1;
+}
+
+int sfbx_mpc_swarm_device_step(int variant, int K, double tf, int64_t batch, uint64_t seed, int ticks, double * u0,
+                               int32_t * codes, uint32_t * iters)
+{
+  try {
+    if (variant == 6) { auto mpc = make6(K, tf); return swarm_step<MPC6, decltype(&xdes6), X6, MPCSwarmDevice<MPC6>>(mpc, xdes6, batch, seed, ticks, u0, codes, iters); }
+    if (variant == 12) { auto mpc = make12(K, tf); return swarm_step<MPC12, decltype(&xdes12), X12, MPCSwarmDevice<MPC12>>(mpc, xdes12, batch, seed, ticks, u0, codes, iters); }
+  } catch (const std::exception &) {
+    return -2;
+  }
   return -1;
 }
 

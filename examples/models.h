@@ -26,6 +26,15 @@ int sfbx_test_mpc_se2(double *u_out, int32_t *codes, int32_t *traj_sizes);
 /* Swarm tick through MPCSwarm (host assembly + one batched GPU solve): returns u0 [batch][2], codes. */
 int sfbx_mpc_swarm_step(int variant, int K, double tf, int64_t batch, uint64_t seed, int ticks, double *u0,
                         int32_t *codes, uint32_t *iters);
+/* Device-side assembly (sfb_mpc_assemble_batch / sfb_mpc_swarm, include/sfb.h): the layout of the variant's
+ * transcription -- dims = {nx, nu, ncr, kmesh, nivals, nparts}, alpha [nivals], D [(kmesh+1)*kmesh], kind / dof
+ * [nparts], crl / cru [ncr] --, the linearisation records of the agents of sfbx_mpc_assemble_batch
+ * (rec [batch][record doubles]) and the swarm tick of sfbx_mpc_swarm_step through MPCSwarmDevice. */
+int sfbx_mpc_layout(int variant, int K, double tf, int32_t *dims, double *alpha, double *D, int32_t *kind,
+                    int32_t *dof, double *crl, double *cru);
+int sfbx_mpc_records(int variant, int K, double tf, int64_t batch, uint64_t seed, double *rec, int threads);
+int sfbx_mpc_swarm_device_step(int variant, int K, double tf, int64_t batch, uint64_t seed, int ticks, double *u0,
+                               int32_t *codes, uint32_t *iters);
 /* group identities for the tests: returns max abs error over a set of checks */
 double sfbx_lie_selftest(void);
 /* EKF<G> front (include/smooth_feedback_amd/ekf.hpp) against the reference's own checks: PredictTimeCut

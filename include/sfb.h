@@ -180,6 +180,86 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
                                           double *x, double *y, double *obj, uint32_t *iter, int32_t *code);
 
 /* ------------------------------------------------------------------------------------------
+ * Device-side MPC assembly and the device-resident swarm.
+ *
+ * sfb_mpc_assemble_batch replaces, per agent, the numeric fill of the QP that MPC::operator() does before
+ * the solve (mpc.hpp:473-486): ocp_to_qp_update_dyn (ocp_to_qp.hpp:240-275), ocp_to_qp_update_cr (:279-323)
+ * and ocp_to_qp_update_ce (:326-373) -- given the per-node linearisation that needs the user's callbacks
+ * (dynamics f, its right-Jacobians, the desired trajectory), which stays on the host.  The kernel performs
+ * the arithmetic of those functions in their order, including ad(f + dxdes) of the state group (:262-264),
+ * so A, l, u equal the host transcription bit for bit.
+ *
+ * Constraint rows [dyn (N*nx) | cr (N*ncr) | ce (nx)], variables [x_0..x_N (nx each) | u_0..u_{N-1} (nu each)],
+ * N = kmesh * nivals collocation nodes; A in CSR with the pattern of ocp_to_qp_allocate (:56-69):
+ *   dyn row (node M+i of interval starting at node M, component d):
+ *        for j = 0..kmesh: block j == i -> nx entries (columns of x_{M+i}), else 1 entry (component d of x_{M+j});
+ *        then nu entries (u_{M+i})                                   => kmesh + nx + nu entries
+ *   cr row: nx entries (x_node) then nu entries (u_node);   ce row: nx entries (x_0).
+ *
+ * Per-agent record of the linearisation ("stage blocks"), contiguous doubles, matrices ROW-major (d, c):
+ *   [ f (N*nx) | dxdes (N*nx) | dfdx (N*nx*nx) | dfdu (N*nx*nu) | c (N*ncr) | dcdx (N*ncr*nx) | dcdu (N*ncr*nu)
+ *     | e (nx) | J (nx*nx) ]
+ *   f, dfdx, dfdu: dynamics and right-Jacobians at (xdes(t+t_i), udes(t+t_i)); dxdes: body velocity of the
+ *   desired trajectory; c, dcdx, dcdu: running constraint and Jacobians; e = xdes(t) (-) x and
+ *   J = d^r exp^{-1}(e) (MPCCE, mpc.hpp:288-301).
+ * If shared_jac is given (time-invariant linearisation: group-linear model on a fixed trajectory), the
+ * Jacobians [dfdx | dfdu | dcdx | dcdu] are read from that ONE record and the per-agent record shrinks to
+ *   [ f | dxdes | c | e | J ].
+ * ---------------------------------------------------------------------------------------- */
+typedef enum { SFB_LIE_RN = 0, SFB_LIE_SE2 = 1, SFB_LIE_SO3 = 2 } sfb_lie_kind;
+
+typedef struct sfb_mpc_layout {
+  int32_t nx, nu, ncr;      /* dof of state and input, running-constraint rows per node */
+  int32_t kmesh, nivals;    /* collocation nodes per interval, intervals */
+  double tf;                /* horizon (MPCParams::tf, mpc.hpp:322) */
+  const double *alpha;      /* [nivals] interval scale alpha of interval_diffmat_unscaled (ocp_to_qp.hpp:243)  */
+  const double *D;          /* [(kmesh+1)*kmesh] differentiation matrix, D[j*kmesh + i] = Dus(j, i) (:243,:268) */
+  int32_t nparts;           /* components of the state bundle, in order; 0 = commutative state (no ad term) */
+  const int32_t *part_kind; /* [nparts] sfb_lie_kind */
+  const int32_t *part_dof;  /* [nparts] sums to nx (SE2 and SO3: 3) */
+  const double *crl, *cru;  /* [ncr] bounds of the running constraint (OCP::crl / cru as set by the MPC constructor) */
+} sfb_mpc_layout;
+
+/* doubles in one per-agent record (shared_jac == 0: with the Jacobians) and in the shared Jacobian record */
+int64_t sfb_mpc_record_doubles(const sfb_mpc_layout *layout, int shared_jac);
+int64_t sfb_mpc_shared_jac_doubles(const sfb_mpc_layout *layout);
+/* nnz of A for the layout */
+int64_t sfb_mpc_nnzA(const sfb_mpc_layout *layout);
+
+/* Device pointers, asynchronous on `stream`.  records [batch][record_doubles], shared_jac nullable,
+ * Ax [batch][nnzA], l, u [batch][m = N*nx + N*ncr + nx].  layout and its arrays are host memory. */
+sfb_status sfb_mpc_assemble_batch(const sfb_mpc_layout *layout, int64_t batch, const double *records,
+                                  const double *shared_jac, double *Ax, double *l, double *u, void *stream);
+
+/*
+ * A swarm of `agents` MPC controllers with one transcription, resident on the device: P, q (constant over
+ * ticks: set by the constructor, mpc.hpp:423), the warm start each agent keeps between calls (mpc.hpp:509-516) and all solver
+ * memory stay in HBM.  One tick = upload the records, assemble, solve, store the warm starts, download the
+ * small outputs.  Replaces the loop `for each agent: u = mpc(t, x)` (MPC::operator(), mpc.hpp:458-519).
+ *   plan: pattern of the transcription's QP (its A pattern is checked against the layout); must outlive the swarm.
+ *   Px [nnzP], q [n]: host, shared by all agents.
+ */
+typedef struct sfb_mpc_swarm sfb_mpc_swarm; /* opaque */
+sfb_status sfb_mpc_swarm_create(sfb_sparse_qp_plan *plan, const sfb_mpc_layout *layout, const double *Px,
+                                const double *q, int64_t agents, sfb_mpc_swarm **swarm);
+void sfb_mpc_swarm_destroy(sfb_mpc_swarm *swarm);
+/* forget the warm starts (MPC::reset_warmstart, mpc.hpp:603) */
+sfb_status sfb_mpc_swarm_reset_warmstart(sfb_mpc_swarm *swarm);
+/*
+ * One tick, host pointers, synchronous.  records / shared_jac as above (host).  warmstart != 0: every agent
+ * starts from the last solution it stored; a solution is stored when its code is Optimal, MaxTime or
+ * MaxIterations (mpc.hpp:510-516), otherwise the agent keeps the older one.
+ * Outputs (host): du0 [agents][nu] = primal entries of u_0 (the caller applies udes(t) (+) du0, mpc.hpp:518),
+ * iter [agents] (nullable), code [agents], primal [agents][n] and dual [agents][m] (both nullable: full
+ * solution for x_traj / u_traj, mpc.hpp:494-507).
+ */
+sfb_status sfb_mpc_swarm_step_host(sfb_mpc_swarm *swarm, const sfb_qp_params *prm, const double *records,
+                                   const double *shared_jac, int warmstart, double *du0, uint32_t *iter,
+                                   int32_t *code, double *primal, double *dual);
+/* Device buffers of the last tick (Ax [agents][nnzA], l, u [agents][m]) for inspection; valid until the next call. */
+sfb_status sfb_mpc_swarm_debug_buffers(sfb_mpc_swarm *swarm, const double **Ax, const double **l, const double **u);
+
+/* ------------------------------------------------------------------------------------------
  * Batched Lie-group EKF: covariance propagation and Kalman update for `batch` independent filters.
  *
  * Replaces the matrix part of smooth::feedback::EKF<G>::predict / ::update (ekf.hpp:79-103,

@@ -11,7 +11,10 @@
 #include <array>
 #include <cmath>
 #include <cstddef>
+#include <cstdint>
 #include <tuple>
+#include <utility>
+#include <vector>
 
 namespace smooth_feedback_amd {
 
@@ -286,6 +289,26 @@ private:
     });
     return m;
   }
+};
+
+// ---- components of a group as (kind, dof) pairs, for ad() on the device (sfb_lie_kind in sfb.h) ----
+template<class G>
+struct LieParts;
+template<int N>
+struct LieParts<Rn<N>> {
+  static void append(std::vector<int32_t> &kind, std::vector<int32_t> &dof) { kind.push_back(0); dof.push_back(N); }
+};
+template<>
+struct LieParts<SE2> {
+  static void append(std::vector<int32_t> &kind, std::vector<int32_t> &dof) { kind.push_back(1); dof.push_back(3); }
+};
+template<>
+struct LieParts<SO3> {
+  static void append(std::vector<int32_t> &kind, std::vector<int32_t> &dof) { kind.push_back(2); dof.push_back(3); }
+};
+template<class... Gs>
+struct LieParts<Bundle<Gs...>> {
+  static void append(std::vector<int32_t> &kind, std::vector<int32_t> &dof) { (LieParts<Gs>::append(kind, dof), ...); }
 };
 
 }  // namespace smooth_feedback_amd

@@ -195,11 +195,84 @@ public:
     }
   }
 
+  /// Description of this transcription for the device-side assembly (sfb_mpc_layout, sfb.h); owns the arrays.
+  struct DeviceLayout {
+    std::vector<double> alpha, D, crl, cru;
+    std::vector<int32_t> kind, dof;
+    sfb_mpc_layout c{};
+  };
+  std::unique_ptr<DeviceLayout> device_layout() const
+  {
+    auto L = std::make_unique<DeviceLayout>();
+    for (int s = 0; s < mesh_.N_ivals(); ++s) L->alpha.push_back(mesh_.alpha(s));
+    L->D.resize((size_t)(Kmesh + 1) * Kmesh);
+    for (int j = 0; j <= Kmesh; ++j)
+      for (int i = 0; i < Kmesh; ++i) L->D[(size_t)j * Kmesh + i] = mesh_.D(j, i);
+    for (int d = 0; d < Ncr; ++d) { L->crl.push_back(crl_[d]); L->cru.push_back(cru_[d]); }
+    if constexpr (!X::IsCommutative) LieParts<X>::append(L->kind, L->dof);
+    L->c = sfb_mpc_layout{Nx, Nu, Ncr, Kmesh, mesh_.N_ivals(), prm_.tf, L->alpha.data(), L->D.data(),
+                          (int32_t)L->kind.size(), L->kind.data(), L->dof.data(), L->crl.data(), L->cru.data()};
+    return L;
+  }
+  static constexpr int64_t record_doubles(int Nn)
+  {
+    return (int64_t)Nn * (2 * Nx + Nx * Nx + Nx * Nu + Ncr + Ncr * Nx + Ncr * Nu) + Nx + Nx * Nx;
+  }
+  /// The part of assemble() that needs the user's callbacks: linearisation of dynamics, running constraint
+  /// and initial-state constraint at (xdes, udes) for time t and state x, as one record of
+  /// sfb_mpc_assemble_batch (layout in sfb.h; matrices row-major).  Thread-safe (const).
+  void fill_record(double t, const X & x, double * rec) const
+  {
+    const int Nn = N();
+    const double tf = prm_.tf;
+    double *f = rec, *dx = f + Nn * Nx, *dfx = dx + Nn * Nx, *dfu = dfx + Nn * Nx * Nx, *cc = dfu + Nn * Nx * Nu,
+           *dcx = cc + Nn * Ncr, *dcu = dcx + Nn * Ncr * Nx, *e0 = dcu + Nn * Ncr * Nu, *Jm = e0 + Nx;
+    for (int node = 0; node < Nn; ++node) {
+      const double t_i   = tf * mesh_.node(node);
+      const X xl         = xdes_(t + t_i);
+      const TangentX dxl = dxdes_(t + t_i);
+      const U ul         = udes_(t + t_i);
+      Vec<Nx> fv;
+      Mat<Nx, Nx> dfdx;
+      Mat<Nx, Nu> dfdu;
+      dyn_jacobian(xl, ul, fv, dfdx, dfdu);
+      Vec<Ncr> cv;
+      Mat<Ncr, Nx> dcdx;
+      Mat<Ncr, Nu> dcdu;
+      cr_jacobian(xl, ul, cv, dcdx, dcdu);
+      for (int d = 0; d < Nx; ++d) {
+        f[node * Nx + d]  = fv[d];
+        dx[node * Nx + d] = dxl[d];
+        for (int c = 0; c < Nx; ++c) dfx[(node * Nx + d) * Nx + c] = dfdx(d, c);
+        for (int c = 0; c < Nu; ++c) dfu[(node * Nx + d) * Nu + c] = dfdu(d, c);
+      }
+      for (int d = 0; d < Ncr; ++d) {
+        cc[node * Ncr + d] = cv[d];
+        for (int c = 0; c < Nx; ++c) dcx[(node * Ncr + d) * Nx + c] = dcdx(d, c);
+        for (int c = 0; c < Nu; ++c) dcu[(node * Ncr + d) * Nu + c] = dcdu(d, c);
+      }
+    }
+    const X xl0      = xdes_(t);
+    const TangentX e = rminus(xl0, x);
+    const auto J     = X::dr_expinv(e);
+    for (int d = 0; d < Nx; ++d) {
+      e0[d] = e[d];
+      for (int c = 0; c < Nx; ++c) Jm[d * Nx + c] = J(d, c);
+    }
+  }
+
   /// mpc.hpp:518   udes(0) (+) primal[uvar_B : +Nu]
   U input_from_primal(double t, const double * primal) const
   {
     typename U::Tangent du{};
     for (int c = 0; c < Nu; ++c) du[c] = primal[uvar_B() + c];
+    return rplus(udes_(t), du);
+  }
+
+  U input_from_du0(double t, const double * du0) const
+  {
+    typename U::Tangent du{};
+    for (int c = 0; c < Nu; ++c) du[c] = du0[c];
     return rplus(udes_(t), du);
   }
 
@@ -398,23 +471,24 @@ public:
       mpc_.assemble(t[b], xs[b], &Ax_[(size_t)b * nA_], &l_[(size_t)b * qp.m], &u_[(size_t)b * qp.m]);
     });
     mpc_.analyze_solver();
-    const bool warm = mpc_.params().warmstart && have_warm_;
-    if (warm) { wx_ = x_; wy_ = y_; }
+    // an agent without a stored solution starts from zeros, which IS the cold start (qp_solver.hpp:436-445)
+    const bool warm = mpc_.params().warmstart;
+    if (warm && wx_.empty()) {
+      wx_.assign((size_t)B_ * qp.n, 0.0);
+      wy_.assign((size_t)B_ * qp.m, 0.0);
+    }
     mpc_.solver().solve_batch(B_, Px_.data(), q_.data(), Ax_.data(), l_.data(), u_.data(), warm ? wx_.data() : nullptr,
                               warm ? wy_.data() : nullptr, x_.data(), y_.data(), nullptr, iter_.data(), code_.data());
     us.resize(B_);
     codes.resize(B_);
-    bool all_storable = true;
     for (int64_t b = 0; b < B_; ++b) {
       us[b]    = mpc_.input_from_primal(t[b], &x_[(size_t)b * qp.n]);
       codes[b] = static_cast<QPSolutionStatus>(code_[b]);
-      all_storable = all_storable && (code_[b] == 0 || code_[b] == 4 || code_[b] == 5);
-      if (!(code_[b] == 0 || code_[b] == 4 || code_[b] == 5)) {  // mpc.hpp:510-516: do not keep it
-        std::fill(x_.begin() + (size_t)b * qp.n, x_.begin() + (size_t)(b + 1) * qp.n, 0.0);
-        std::fill(y_.begin() + (size_t)b * qp.m, y_.begin() + (size_t)(b + 1) * qp.m, 0.0);
+      if (warm && (code_[b] == 0 || code_[b] == 4 || code_[b] == 5)) {  // mpc.hpp:510-516; otherwise the older one stays
+        std::copy(x_.begin() + (size_t)b * qp.n, x_.begin() + (size_t)(b + 1) * qp.n, wx_.begin() + (size_t)b * qp.n);
+        std::copy(y_.begin() + (size_t)b * qp.m, y_.begin() + (size_t)(b + 1) * qp.m, wy_.begin() + (size_t)b * qp.m);
       }
     }
-    have_warm_ = true;
   }
   const std::vector<uint32_t> & iterations() const { return iter_; }
   const std::vector<double> & Ax() const { return Ax_; }
@@ -438,8 +512,78 @@ private:
   MPCT & mpc_;
   int64_t B_;
   int threads_, nA_ = 0, nP_ = 0;
-  bool have_warm_ = false;
   std::vector<double> Px_, q_, Ax_, l_, u_, x_, y_, wx_, wy_;
+  std::vector<uint32_t> iter_;
+  std::vector<int32_t> code_;
+};
+
+/// The same swarm resident on the device (sfb_mpc_swarm, sfb.h): the host only linearises (fill_record);
+/// assembly of A, l, u, the solve and the warm starts stay in HBM, and only du_0, code and iter come back.
+template<class MPCT>
+class MPCSwarmDevice {
+public:
+  explicit MPCSwarmDevice(MPCT & proto, int64_t agents, int threads = 0)
+      : mpc_(proto), B_(agents), threads_(threads > 0 ? threads : (int)std::max(1u, std::thread::hardware_concurrency()))
+  {
+    mpc_.analyze_solver();
+    layout_ = mpc_.device_layout();
+    recd_   = MPCT::record_doubles(mpc_.N());
+    rec_.resize((size_t)B_ * recd_);
+    du0_.resize((size_t)B_ * MPCT::Nu);
+    iter_.resize(B_);
+    code_.resize(B_);
+    const auto & qp = mpc_.qp();
+    sfb_check(sfb_mpc_swarm_create(mpc_.solver().plan(), &layout_->c, qp.P_val.data(), qp.q.data(), B_, &swarm_));
+  }
+  MPCSwarmDevice(const MPCSwarmDevice &)             = delete;
+  MPCSwarmDevice & operator=(const MPCSwarmDevice &) = delete;
+  ~MPCSwarmDevice() { sfb_mpc_swarm_destroy(swarm_); }
+
+  void reset_warmstart() { sfb_check(sfb_mpc_swarm_reset_warmstart(swarm_)); }
+
+  /// one control tick for all agents; primal / dual (nullable) receive the full solutions
+  template<class XT, class UT>
+  void step(const std::vector<double> & t, const std::vector<XT> & xs, std::vector<UT> & us,
+            std::vector<QPSolutionStatus> & codes, std::vector<double> * primal = nullptr,
+            std::vector<double> * dual = nullptr)
+  {
+    const auto & qp = mpc_.qp();
+    parallel_for([&](int64_t b) { mpc_.fill_record(t[b], xs[b], &rec_[(size_t)b * recd_]); });
+    if (primal) primal->resize((size_t)B_ * qp.n);
+    if (dual) dual->resize((size_t)B_ * qp.m);
+    const sfb_qp_params c = mpc_.solver().params().to_c();
+    sfb_check(sfb_mpc_swarm_step_host(swarm_, &c, rec_.data(), nullptr, mpc_.params().warmstart ? 1 : 0, du0_.data(),
+                                      iter_.data(), code_.data(), primal ? primal->data() : nullptr,
+                                      dual ? dual->data() : nullptr));
+    us.resize(B_);
+    codes.resize(B_);
+    for (int64_t b = 0; b < B_; ++b) {
+      us[b]    = mpc_.input_from_du0(t[b], &du0_[(size_t)b * MPCT::Nu]);
+      codes[b] = static_cast<QPSolutionStatus>(code_[b]);
+    }
+  }
+  const std::vector<uint32_t> & iterations() const { return iter_; }
+  const std::vector<double> & records() const { return rec_; }
+  sfb_mpc_swarm * handle() { return swarm_; }
+
+private:
+  template<class Fn>
+  void parallel_for(Fn && fn)
+  {
+    const int T = (int)std::min<int64_t>(threads_, B_);
+    std::vector<std::thread> th;
+    for (int k = 0; k < T; ++k)
+      th.emplace_back([&, k] {
+        for (int64_t b = B_ * k / T; b < B_ * (k + 1) / T; ++b) fn(b);
+      });
+    for (auto & t : th) t.join();
+  }
+  MPCT & mpc_;
+  int64_t B_, recd_ = 0;
+  int threads_;
+  std::unique_ptr<typename MPCT::DeviceLayout> layout_;
+  sfb_mpc_swarm * swarm_ = nullptr;
+  std::vector<double> rec_, du0_;
   std::vector<uint32_t> iter_;
   std::vector<int32_t> code_;
 };

@@ -10,5 +10,6 @@ from .qp import (QPBatchSolution, QPSolution, QPSolutionStatus, QPSolver, QPSolv
 
 from .ekf import (ekf_predict_batch_device, ekf_predict_batch_host, ekf_predict_stepper_batch_device,  # noqa: F401
                   ekf_predict_update_batch_device, ekf_step_batch_host, ekf_update_batch_device)
+from .mpc import LIE_RN, LIE_SE2, LIE_SO3, MPCLayout, MPCSwarm  # noqa: F401
 
 __version__ = "0.1.0"

@@ -40,6 +40,16 @@ class SfbQPParams(C.Structure):
     ]
 
 
+class SfbMPCLayout(C.Structure):
+    """sfb_mpc_layout (include/sfb.h)."""
+
+    _fields_ = [
+        ("nx", C.c_int32), ("nu", C.c_int32), ("ncr", C.c_int32), ("kmesh", C.c_int32), ("nivals", C.c_int32),
+        ("tf", C.c_double), ("alpha", C.c_void_p), ("D", C.c_void_p), ("nparts", C.c_int32),
+        ("part_kind", C.c_void_p), ("part_dof", C.c_void_p), ("crl", C.c_void_p), ("cru", C.c_void_p),
+    ]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -75,6 +85,20 @@ def _load():
     L.sfb_ekf_update_batch.argtypes = [i64, i32, i32, dp, dp, i32, dp, dp, dp, dp, vp]
     L.sfb_ekf_predict_update_batch.argtypes = [i64, i32, i32, dp, dp, i32, dp, i32, dp, dp, i32, dp, dp, dp, dp, vp]
     L.sfb_ekf_step_batch_host.argtypes = [i64, i32, i32, dp, dp, i32, dp, i32, dp, dp, i32, dp, dp, dp, dp]
+    lay = C.POINTER(SfbMPCLayout)
+    L.sfb_mpc_record_doubles.argtypes = [lay, i32]
+    L.sfb_mpc_record_doubles.restype = i64
+    L.sfb_mpc_shared_jac_doubles.argtypes = [lay]
+    L.sfb_mpc_shared_jac_doubles.restype = i64
+    L.sfb_mpc_nnzA.argtypes = [lay]
+    L.sfb_mpc_nnzA.restype = i64
+    L.sfb_mpc_assemble_batch.argtypes = [lay, i64, dp, dp, dp, dp, dp, vp]
+    L.sfb_mpc_swarm_create.argtypes = [vp, lay, dp, dp, i64, C.POINTER(C.c_void_p)]
+    L.sfb_mpc_swarm_destroy.argtypes = [vp]
+    L.sfb_mpc_swarm_destroy.restype = None
+    L.sfb_mpc_swarm_reset_warmstart.argtypes = [vp]
+    L.sfb_mpc_swarm_step_host.argtypes = [vp, C.POINTER(SfbQPParams), dp, dp, i32, dp, dp, dp, dp, dp]
+    L.sfb_mpc_swarm_debug_buffers.argtypes = [vp] + [C.POINTER(C.c_void_p)] * 3
     L.sfb_random_qp_batch.argtypes = [C.c_uint32, i64, i32, i32, C.c_double] + [dp] * 5
     return L
 

@@ -13,5 +13,7 @@ sfb_status fail(sfb_status st, const std::string &msg);
 sfb_status hip_fail(hipError_t e, const char *what);
 sfb_status require_device();
 DenseKernelParams make_kernel_params(const sfb_qp_params *prm, int n, int m);
+struct SparsePlanHost;
+const SparsePlanHost &plan_host(const sfb_sparse_qp_plan *plan);  // capi_sparse.hip
 
 }  // namespace sfb

@@ -1,0 +1,313 @@
+// C-ABI of the device-side MPC assembly and of the device-resident swarm (include/sfb.h).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/sfb.h"
+#include "capi_common.h"
+#include "mpc_kernel.h"
+#include "qp_sparse_kernel.h"
+#include "sparse_plan.h"
+
+namespace {
+
+struct Sizes {
+  int64_t N, dyn_f, dyn_jx, dyn_ju, cr_c, cr_jx, cr_ju, ce_e, ce_J;
+};
+Sizes sizes_of(const sfb_mpc_layout *L)
+{
+  Sizes s{};
+  s.N      = (int64_t)L->kmesh * L->nivals;
+  s.dyn_f  = s.N * L->nx;
+  s.dyn_jx = s.N * L->nx * L->nx;
+  s.dyn_ju = s.N * L->nx * L->nu;
+  s.cr_c   = s.N * L->ncr;
+  s.cr_jx  = s.N * L->ncr * L->nx;
+  s.cr_ju  = s.N * L->ncr * L->nu;
+  s.ce_e   = L->nx;
+  s.ce_J   = (int64_t)L->nx * L->nx;
+  return s;
+}
+
+sfb_status check_layout(const sfb_mpc_layout *L)
+{
+  if (!L) return sfb::fail(SFB_ERR_INVALID_ARG, "layout is NULL");
+  if (L->nx < 1 || L->nu < 1 || L->ncr < 0 || L->kmesh < 1 || L->nivals < 1)
+    return sfb::fail(SFB_ERR_INVALID_ARG, "layout: nx, nu, kmesh, nivals must be >= 1 and ncr >= 0");
+  if (!L->alpha || !L->D || (L->ncr > 0 && (!L->crl || !L->cru)))
+    return sfb::fail(SFB_ERR_INVALID_ARG, "layout: alpha, D (and crl, cru when ncr > 0) must be given");
+  if (L->nparts < 0 || (L->nparts > 0 && (!L->part_kind || !L->part_dof)))
+    return sfb::fail(SFB_ERR_INVALID_ARG, "layout: part_kind / part_dof missing");
+  if (L->nivals > sfb::kMpcMaxIvals || L->kmesh > sfb::kMpcMaxKmesh || L->nx > sfb::kMpcMaxNx || L->ncr > sfb::kMpcMaxNcr)
+    return sfb::fail(SFB_ERR_UNSUPPORTED, "layout: supported up to 128 intervals, 8 nodes per interval, nx 24, ncr 16");
+  int dof = 0;
+  for (int g = 0; g < L->nparts; ++g) {
+    const int k = L->part_kind[g], d = L->part_dof[g];
+    if (k != SFB_LIE_RN && k != SFB_LIE_SE2 && k != SFB_LIE_SO3) return sfb::fail(SFB_ERR_INVALID_ARG, "layout: unknown part kind");
+    if (d < 1 || ((k == SFB_LIE_SE2 || k == SFB_LIE_SO3) && d != 3)) return sfb::fail(SFB_ERR_INVALID_ARG, "layout: bad part dof");
+    dof += d;
+  }
+  if (L->nparts > 0 && dof != L->nx) return sfb::fail(SFB_ERR_INVALID_ARG, "layout: part dofs do not sum to nx");
+  return SFB_OK;
+}
+
+// ad(a) of the bundle as a sign/index table (lie.hpp: SE2::ad, SO3::ad = hat)
+void fill_params(const sfb_mpc_layout *L, bool shared, sfb::MpcAsmParams &p)
+{
+  std::memset(&p, 0, sizeof(p));
+  const Sizes s = sizes_of(L);
+  p.nx = L->nx; p.nu = L->nu; p.ncr = L->ncr; p.kmesh = L->kmesh; p.nivals = L->nivals; p.N = (int)s.N;
+  p.rowlen_dyn = L->kmesh + L->nx + L->nu;
+  p.nnz_dyn    = (int)(s.dyn_f * p.rowlen_dyn);
+  p.nnz_cr     = (int)(s.cr_c * (L->nx + L->nu));
+  p.nnzA       = p.nnz_dyn + p.nnz_cr + L->nx * L->nx;
+  p.m          = (int)(s.dyn_f + s.cr_c + L->nx);
+  p.tf         = L->tf;
+  int64_t o = 0;
+  p.o_f = (int)o; o += s.dyn_f;
+  p.o_dx = (int)o; o += s.dyn_f;
+  if (!shared) {
+    p.o_dfdx = (int)o; o += s.dyn_jx;
+    p.o_dfdu = (int)o; o += s.dyn_ju;
+  }
+  p.o_c = (int)o; o += s.cr_c;
+  if (!shared) {
+    p.o_dcdx = (int)o; o += s.cr_jx;
+    p.o_dcdu = (int)o; o += s.cr_ju;
+  }
+  p.o_e = (int)o; o += s.ce_e;
+  p.o_J = (int)o; o += s.ce_J;
+  p.rec_doubles = o;
+  if (shared) {
+    p.o_dfdx = 0;
+    p.o_dfdu = (int)s.dyn_jx;
+    p.o_dcdx = (int)(s.dyn_jx + s.dyn_ju);
+    p.o_dcdu = (int)(s.dyn_jx + s.dyn_ju + s.cr_jx);
+  }
+  for (int i = 0; i < L->nivals; ++i) p.alpha[i] = L->alpha[i];
+  for (int i = 0; i < (L->kmesh + 1) * L->kmesh; ++i) p.D[i] = L->D[i];
+  for (int i = 0; i < L->ncr; ++i) { p.crl[i] = L->crl[i]; p.cru[i] = L->cru[i]; }
+  int off = 0;
+  for (int g = 0; g < L->nparts; ++g) {
+    const int k = L->part_kind[g];
+    auto set = [&](int r, int c, int src, int sign) { p.adsrc[(off + r) * L->nx + (off + c)] = (int8_t)(sign * (off + src + 1)); };
+    if (k == SFB_LIE_SE2 || k == SFB_LIE_SO3) {
+      p.has_ad = 1;
+      set(0, 1, 2, -1); set(0, 2, 1, +1);
+      set(1, 0, 2, +1); set(1, 2, 0, -1);
+      if (k == SFB_LIE_SO3) { set(2, 0, 1, -1); set(2, 1, 0, +1); }
+    }
+    off += L->part_dof[g];
+  }
+  // a bundle with a non-commutative part takes the ad branch for all of its entries (the zero ones add -0.0)
+}
+
+}  // namespace
+
+struct sfb_mpc_swarm {
+  sfb_sparse_qp_plan *plan = nullptr;
+  sfb::MpcAsmParams rec_own{}, rec_shared{};
+  int64_t agents = 0, shared_doubles = 0;
+  int n = 0, m = 0, nnzP = 0, nnzA = 0, nu = 0, uoff = 0, devid = 0;
+  size_t wsd = 0;
+  char *mem = nullptr;
+  double *Px = nullptr, *q = nullptr, *Ax = nullptr, *l = nullptr, *u = nullptr, *x = nullptr, *y = nullptr, *wx = nullptr,
+         *wy = nullptr, *rec = nullptr, *shared = nullptr, *du0 = nullptr, *ws = nullptr;
+  uint32_t *iter = nullptr;
+  int32_t *code = nullptr;
+  std::mutex mu;
+};
+
+extern "C" {
+
+int64_t sfb_mpc_record_doubles(const sfb_mpc_layout *layout, int shared_jac)
+{
+  if (check_layout(layout) != SFB_OK) return -1;
+  sfb::MpcAsmParams p;
+  fill_params(layout, shared_jac != 0, p);
+  return p.rec_doubles;
+}
+
+int64_t sfb_mpc_shared_jac_doubles(const sfb_mpc_layout *layout)
+{
+  if (check_layout(layout) != SFB_OK) return -1;
+  const Sizes s = sizes_of(layout);
+  return s.dyn_jx + s.dyn_ju + s.cr_jx + s.cr_ju;
+}
+
+int64_t sfb_mpc_nnzA(const sfb_mpc_layout *layout)
+{
+  if (check_layout(layout) != SFB_OK) return -1;
+  sfb::MpcAsmParams p;
+  fill_params(layout, false, p);
+  return p.nnzA;
+}
+
+sfb_status sfb_mpc_assemble_batch(const sfb_mpc_layout *layout, int64_t batch, const double *records,
+                                  const double *shared_jac, double *Ax, double *l, double *u, void *stream)
+{
+  sfb_status st = check_layout(layout);
+  if (st != SFB_OK) return st;
+  if (batch < 0) return sfb::fail(SFB_ERR_INVALID_ARG, "batch < 0");
+  if (batch > 0 && (!records || !Ax || !l || !u)) return sfb::fail(SFB_ERR_INVALID_ARG, "NULL record / output pointer");
+  st = sfb::require_device();
+  if (st != SFB_OK) return st;
+  if (batch == 0) return SFB_OK;
+  sfb::MpcAsmParams p;
+  fill_params(layout, shared_jac != nullptr, p);
+  hipError_t e = sfb::mpc_assemble_launch(p, batch, records, shared_jac, Ax, l, u, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return sfb::hip_fail(e, "mpc_assemble_kernel launch");
+  return SFB_OK;
+}
+
+sfb_status sfb_mpc_swarm_create(sfb_sparse_qp_plan *plan, const sfb_mpc_layout *layout, const double *Px,
+                                const double *q, int64_t agents, sfb_mpc_swarm **swarm)
+{
+  if (!swarm) return sfb::fail(SFB_ERR_INVALID_ARG, "swarm is NULL");
+  *swarm = nullptr;
+  if (!plan) return sfb::fail(SFB_ERR_INVALID_ARG, "plan is NULL");
+  sfb_status st = check_layout(layout);
+  if (st != SFB_OK) return st;
+  if (agents < 1 || agents > 0x7FFFFFFFll) return sfb::fail(SFB_ERR_INVALID_ARG, "agents must be in [1, 2^31-1]");
+  const sfb::SparsePlanHost &h = sfb::plan_host(plan);
+  sfb::MpcAsmParams p, ps;
+  fill_params(layout, false, p);
+  fill_params(layout, true, ps);
+  const int n = layout->nx * (p.N + 1) + layout->nu * p.N;
+  if (h.n != n || h.m != p.m || h.nnzA != p.nnzA) return sfb::fail(SFB_ERR_INVALID_ARG, "plan does not have the sizes of the layout's QP");
+  {  // the pattern of A must be the one the kernel writes (ocp_to_qp_allocate :56-69)
+    std::vector<int32_t> Aj;
+    Aj.reserve(p.nnzA);
+    const int nx = layout->nx, nu = layout->nu, km = layout->kmesh, uB = nx * (p.N + 1);
+    for (int node = 0; node < p.N; ++node)
+      for (int d = 0; d < nx; ++d) {
+        const int M = (node / km) * km, i = node - M;
+        for (int j = 0; j <= km; ++j) {
+          if (j == i)
+            for (int c = 0; c < nx; ++c) Aj.push_back((M + j) * nx + c);
+          else
+            Aj.push_back((M + j) * nx + d);
+        }
+        for (int c = 0; c < nu; ++c) Aj.push_back(uB + node * nu + c);
+        if (h.Ap[node * nx + d + 1] != (int)Aj.size()) return sfb::fail(SFB_ERR_INVALID_ARG, "plan: A row pointers differ from the MPC layout");
+      }
+    for (int node = 0; node < p.N; ++node)
+      for (int d = 0; d < layout->ncr; ++d) {
+        for (int c = 0; c < nx; ++c) Aj.push_back(node * nx + c);
+        for (int c = 0; c < nu; ++c) Aj.push_back(uB + node * nu + c);
+      }
+    for (int d = 0; d < nx; ++d)
+      for (int c = 0; c < nx; ++c) Aj.push_back(c);
+    if (Aj != h.Aj) return sfb::fail(SFB_ERR_INVALID_ARG, "plan: A pattern differs from the MPC layout");
+  }
+  if ((h.nnzP > 0 && !Px) || !q) return sfb::fail(SFB_ERR_INVALID_ARG, "Px / q is NULL");
+  st = sfb::require_device();
+  if (st != SFB_OK) return st;
+  auto *S = new sfb_mpc_swarm;
+  S->plan = plan; S->rec_own = p; S->rec_shared = ps; S->agents = agents;
+  S->n = n; S->m = p.m; S->nnzP = h.nnzP; S->nnzA = p.nnzA; S->nu = layout->nu; S->uoff = layout->nx * (p.N + 1);
+  S->shared_doubles = sfb_mpc_shared_jac_doubles(layout);
+  S->wsd = sfb::qp_sparse_ws_doubles(h.n, h.m, h.nnzL, h.funits, h.bunits);
+  hipError_t e = hipGetDevice(&S->devid);
+  const size_t B = (size_t)agents, N = (size_t)n, M = (size_t)p.m;
+  const size_t doubles = B * ((size_t)h.nnzP + N + (size_t)p.nnzA + 2 * M + 2 * (N + M) + (size_t)p.rec_doubles + (size_t)layout->nu + S->wsd) +
+                         (size_t)S->shared_doubles + (size_t)h.nnzP + N;
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&S->mem), doubles * sizeof(double) + B * 8);
+  if (e != hipSuccess) {
+    delete S;
+    return sfb::hip_fail(e, "hipMalloc(swarm)");
+  }
+  double *d = reinterpret_cast<double *>(S->mem);
+  S->Px = d; d += B * h.nnzP;
+  S->q = d; d += B * N;
+  S->Ax = d; d += B * p.nnzA;
+  S->l = d; d += B * M;
+  S->u = d; d += B * M;
+  S->x = d; d += B * N;
+  S->y = d; d += B * M;
+  S->wx = d; d += B * N;
+  S->wy = d; d += B * M;
+  S->rec = d; d += B * p.rec_doubles;
+  S->shared = d; d += S->shared_doubles;
+  S->du0 = d; d += B * layout->nu;
+  double *stage = d; d += h.nnzP + N;  // one copy of Px and q, replicated below
+  S->ws = d; d += B * S->wsd;
+  S->iter = reinterpret_cast<uint32_t *>(d);
+  S->code = reinterpret_cast<int32_t *>(S->iter + B);
+  do {
+    if (h.nnzP > 0 && (e = hipMemcpy(stage, Px, (size_t)h.nnzP * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
+    if ((e = hipMemcpy(stage + h.nnzP, q, N * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
+    if ((e = sfb::mpc_replicate_launch(stage, h.nnzP, agents, S->Px, nullptr)) != hipSuccess) break;
+    if ((e = sfb::mpc_replicate_launch(stage + h.nnzP, (int64_t)N, agents, S->q, nullptr)) != hipSuccess) break;
+    if ((e = hipMemset(S->wx, 0, B * (N + M) * 8)) != hipSuccess) break;  // wx and wy are adjacent
+    e = hipDeviceSynchronize();
+  } while (false);
+  if (e != hipSuccess) {
+    (void)hipFree(S->mem);
+    delete S;
+    return sfb::hip_fail(e, "sfb_mpc_swarm_create");
+  }
+  *swarm = S;
+  return SFB_OK;
+}
+
+void sfb_mpc_swarm_destroy(sfb_mpc_swarm *swarm)
+{
+  if (!swarm) return;
+  if (swarm->mem) (void)hipFree(swarm->mem);
+  delete swarm;
+}
+
+sfb_status sfb_mpc_swarm_reset_warmstart(sfb_mpc_swarm *S)
+{
+  if (!S) return sfb::fail(SFB_ERR_INVALID_ARG, "swarm is NULL");
+  std::lock_guard<std::mutex> lk(S->mu);
+  // an all-zero warm start IS the cold start of qp_solver.hpp:436-445 (x = y = 0 and z = A x = 0)
+  hipError_t e = hipMemset(S->wx, 0, (size_t)S->agents * ((size_t)S->n + S->m) * 8);
+  if (e != hipSuccess) return sfb::hip_fail(e, "hipMemset");
+  return SFB_OK;
+}
+
+sfb_status sfb_mpc_swarm_step_host(sfb_mpc_swarm *S, const sfb_qp_params *prm, const double *records,
+                                   const double *shared_jac, int warmstart, double *du0, uint32_t *iter,
+                                   int32_t *code, double *primal, double *dual)
+{
+  if (!S) return sfb::fail(SFB_ERR_INVALID_ARG, "swarm is NULL");
+  if (!prm || !records || !du0 || !code) return sfb::fail(SFB_ERR_INVALID_ARG, "NULL params / records / output pointer");
+  std::lock_guard<std::mutex> lk(S->mu);
+  const size_t B = (size_t)S->agents;
+  const sfb::MpcAsmParams &p = shared_jac ? S->rec_shared : S->rec_own;
+  hipError_t e = hipSuccess;
+  sfb_status st = SFB_OK;
+  do {
+    if ((e = hipMemcpy(S->rec, records, B * (size_t)p.rec_doubles * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
+    if (shared_jac && (e = hipMemcpy(S->shared, shared_jac, (size_t)S->shared_doubles * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
+    if ((e = sfb::mpc_assemble_launch(p, S->agents, S->rec, shared_jac ? S->shared : nullptr, S->Ax, S->l, S->u, nullptr)) != hipSuccess) break;
+    st = sfb_sparse_qp_solve_batch(S->plan, prm, S->agents, S->Px, S->q, S->Ax, S->l, S->u, warmstart ? S->wx : nullptr,
+                                   warmstart ? S->wy : nullptr, S->x, S->y, nullptr, S->iter, S->code, S->ws, nullptr);
+    if (st != SFB_OK) break;
+    if ((e = sfb::mpc_store_launch(S->agents, S->n, S->m, S->uoff, S->nu, warmstart != 0, S->x, S->y, S->code, S->wx, S->wy,
+                                   S->du0, nullptr)) != hipSuccess) break;
+    if ((e = hipMemcpy(du0, S->du0, B * (size_t)S->nu * 8, hipMemcpyDeviceToHost)) != hipSuccess) break;
+    if (iter && (e = hipMemcpy(iter, S->iter, B * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
+    if ((e = hipMemcpy(code, S->code, B * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
+    if (primal && (e = hipMemcpy(primal, S->x, B * (size_t)S->n * 8, hipMemcpyDeviceToHost)) != hipSuccess) break;
+    if (dual && (e = hipMemcpy(dual, S->y, B * (size_t)S->m * 8, hipMemcpyDeviceToHost)) != hipSuccess) break;
+  } while (false);
+  if (e != hipSuccess) st = sfb::hip_fail(e, "sfb_mpc_swarm_step_host");
+  return st;
+}
+
+sfb_status sfb_mpc_swarm_debug_buffers(sfb_mpc_swarm *S, const double **Ax, const double **l, const double **u)
+{
+  if (!S) return sfb::fail(SFB_ERR_INVALID_ARG, "swarm is NULL");
+  if (Ax) *Ax = S->Ax;
+  if (l) *l = S->l;
+  if (u) *u = S->u;
+  return SFB_OK;
+}
+
+}  // extern "C"

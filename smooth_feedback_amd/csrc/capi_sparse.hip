@@ -28,6 +28,10 @@ struct sfb_sparse_qp_plan {
   std::map<int, std::pair<char *, size_t>> host_ws;  // device ordinal -> (buffer, bytes)
 };
 
+namespace sfb {
+const SparsePlanHost &plan_host(const sfb_sparse_qp_plan *plan) { return plan->host; }
+}  // namespace sfb
+
 namespace {
 
 // upload all index arrays as one blob (once per device)

@@ -1,0 +1,139 @@
+// Device-side numeric fill of the MPC QP: the arithmetic of ocp_to_qp_update_dyn (ocp_to_qp.hpp:240-275),
+// ocp_to_qp_update_cr (:279-323) and ocp_to_qp_update_ce (:326-373) for a batch of agents, from per-node
+// linearisation records (include/sfb.h).  Pure streaming work: every thread produces ONE entry of A (or one
+// row of l, u) -- consecutive threads write consecutive addresses; the records are read through the cache
+// (each Jacobian entry is read once, the small vectors a few times).  HBM-bound: algorithmic bytes per agent =
+// record + A values + l + u.
+#include <hip/hip_runtime.h>
+
+#include "../../include/sfb.h"
+#include "mpc_kernel.h"
+
+namespace sfb {
+
+__global__ void __launch_bounds__(256) mpc_assemble_kernel(const MpcAsmParams p, const double *__restrict__ records,
+                                                           const double *__restrict__ shared_jac,
+                                                           double *__restrict__ gAx, double *__restrict__ gl,
+                                                           double *__restrict__ gu)
+{
+  const int64_t b  = blockIdx.y;
+  const int idx    = blockIdx.x * 256 + threadIdx.x;
+  const double *rec = records + b * p.rec_doubles;
+  const double *jac = shared_jac ? shared_jac : rec;
+  const int nx = p.nx, nu = p.nu, ncr = p.ncr, kmesh = p.kmesh;
+  const double tf = p.tf;
+  if (idx < p.nnzA) {
+    double v;
+    if (idx < p.nnz_dyn) {  // ocp_to_qp_update_dyn :240-275
+      const int row = idx / p.rowlen_dyn, pos = idx - row * p.rowlen_dyn;
+      const int node = row / nx, d = row - node * nx;
+      const int s = node / kmesh, i = node - s * kmesh;
+      const double alpha = p.alpha[s];
+      if (pos >= kmesh + nx) {  // u block :259
+        const int c = pos - (kmesh + nx);
+        v           = 0.0 + tf * jac[p.o_dfdu + (node * nx + d) * nu + c];
+      } else if (pos >= i && pos < i + nx) {  // x block of the node itself
+        const int c = pos - i;
+        v           = 0.0;
+        v += tf * jac[p.o_dfdx + (node * nx + d) * nx + c];  // :258
+        if (p.has_ad) {                                      // :262-264   -tf/2 ad(f + dxdes)
+          const int code = p.adsrc[d * nx + c];
+          double a       = 0.0;
+          if (code != 0) {
+            const int k     = (code > 0 ? code : -code) - 1;
+            const double sk = rec[p.o_f + node * nx + k] + rec[p.o_dx + node * nx + k];
+            a               = (code > 0) ? sk : -sk;
+          }
+          v += (-tf / 2) * a;
+        }
+        if (c == d) v -= alpha * p.D[i * kmesh + i];  // :266-270
+      } else {  // the other nodes of the interval: -alpha D(j, i) on the diagonal
+        const int j = (pos < i) ? pos : pos - nx + 1;
+        v           = 0.0;
+        v -= alpha * p.D[j * kmesh + i];
+      }
+    } else if (idx < p.nnz_dyn + p.nnz_cr) {  // ocp_to_qp_update_cr :279-323
+      const int q = idx - p.nnz_dyn, row = q / (nx + nu), pos = q - row * (nx + nu);
+      v           = (pos < nx) ? jac[p.o_dcdx + row * nx + pos] : jac[p.o_dcdu + row * nu + (pos - nx)];
+    } else {  // ocp_to_qp_update_ce :326-373
+      v = rec[p.o_J + (idx - p.nnz_dyn - p.nnz_cr)];
+    }
+    gAx[b * p.nnzA + idx] = v;
+  } else if (idx < p.nnzA + p.m) {
+    const int r = idx - p.nnzA;
+    double lo, hi;
+    if (r < p.N * nx) {  // :272-273
+      lo = -tf * (rec[p.o_f + r] - rec[p.o_dx + r]);
+      hi = lo;
+    } else if (r < p.N * (nx + ncr)) {  // :321-322
+      const int q = r - p.N * nx, d = q % ncr;
+      const double cv = rec[p.o_c + q];
+      lo = p.crl[d] - cv;
+      hi = p.cru[d] - cv;
+    } else {  // :371-372
+      lo = 0.0 - rec[p.o_e + (r - p.N * (nx + ncr))];
+      hi = lo;
+    }
+    gl[b * p.m + r] = lo;
+    gu[b * p.m + r] = hi;
+  }
+}
+
+__global__ void __launch_bounds__(256) mpc_replicate_kernel(const double *__restrict__ src, const int64_t len,
+                                                            double *__restrict__ out)
+{
+  const int64_t b = blockIdx.y;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < len; e += (int64_t)gridDim.x * 256) out[b * len + e] = src[e];
+}
+
+__global__ void __launch_bounds__(64) mpc_store_kernel(const int n, const int m, const int uoff, const int nu,
+                                                       const int store, const double *__restrict__ x,
+                                                       const double *__restrict__ y, const int32_t *__restrict__ code,
+                                                       double *__restrict__ wx, double *__restrict__ wy,
+                                                       double *__restrict__ du0)
+{
+  const int64_t b = blockIdx.x;
+  const int lane  = threadIdx.x;
+  const double *xb = x + b * n, *yb = y + b * m;
+  for (int c = lane; c < nu; c += 64) du0[b * nu + c] = xb[uoff + c];
+  const int32_t cd = code[b];
+  if (store && (cd == SFB_QP_OPTIMAL || cd == SFB_QP_MAX_TIME || cd == SFB_QP_MAX_ITERATIONS)) {
+    for (int j = lane; j < n; j += 64) wx[b * n + j] = xb[j];
+    for (int i = lane; i < m; i += 64) wy[b * m + i] = yb[i];
+  }
+}
+
+hipError_t mpc_assemble_launch(const MpcAsmParams &p, int64_t batch, const double *records, const double *shared_jac,
+                               double *Ax, double *l, double *u, hipStream_t stream)
+{
+  const int blocks = (p.nnzA + p.m + 255) / 256;
+  for (int64_t b0 = 0; b0 < batch; b0 += 65535) {  // gridDim.y limit
+    const int64_t nb = (batch - b0 < 65535) ? batch - b0 : 65535;
+    hipLaunchKernelGGL(mpc_assemble_kernel, dim3(blocks, (unsigned)nb), dim3(256), 0, stream, p,
+                       records + b0 * p.rec_doubles, shared_jac, Ax + b0 * p.nnzA, l + b0 * p.m, u + b0 * p.m);
+  }
+  return hipGetLastError();
+}
+
+hipError_t mpc_replicate_launch(const double *src, int64_t len, int64_t batch, double *out, hipStream_t stream)
+{
+  if (len == 0) return hipSuccess;
+  int64_t blocks = (len + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
+    const int64_t nb = (batch - b0 < 65535) ? batch - b0 : 65535;
+    hipLaunchKernelGGL(mpc_replicate_kernel, dim3((unsigned)blocks, (unsigned)nb), dim3(256), 0, stream, src, len,
+                       out + b0 * len);
+  }
+  return hipGetLastError();
+}
+
+hipError_t mpc_store_launch(int64_t batch, int n, int m, int uoff, int nu, int store, const double *x, const double *y,
+                            const int32_t *code, double *wx, double *wy, double *du0, hipStream_t stream)
+{
+  hipLaunchKernelGGL(mpc_store_kernel, dim3((unsigned)batch), dim3(64), 0, stream, n, m, uoff, nu, store, x, y, code, wx,
+                     wy, du0);
+  return hipGetLastError();
+}
+
+}  // namespace sfb

@@ -1,0 +1,37 @@
+// Host<->kernel interface of the device-side MPC assembly.  Internal.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace sfb {
+
+constexpr int kMpcMaxIvals = 128, kMpcMaxKmesh = 8, kMpcMaxNx = 24, kMpcMaxNcr = 16;
+
+// Everything the kernel needs besides the records travels as kernel argument (< 4 KB).
+struct MpcAsmParams {
+  int nx, nu, ncr, kmesh, nivals, N;
+  int rowlen_dyn, nnz_dyn, nnz_cr, nnzA, m;
+  int has_ad;
+  double tf;
+  // offsets (doubles) inside the per-agent record and inside the record holding the Jacobians (which is the
+  // per-agent record unless the Jacobians are shared)
+  int o_f, o_dx, o_c, o_e, o_J, o_dfdx, o_dfdu, o_dcdx, o_dcdu;
+  int64_t rec_doubles;
+  double alpha[kMpcMaxIvals];
+  double D[(kMpcMaxKmesh + 1) * kMpcMaxKmesh];
+  double crl[kMpcMaxNcr], cru[kMpcMaxNcr];
+  // ad(s) of the state group as a table over (d, c): 0 -> 0.0, +(k+1) -> s[k], -(k+1) -> -s[k]
+  int8_t adsrc[kMpcMaxNx * kMpcMaxNx];
+};
+
+hipError_t mpc_assemble_launch(const MpcAsmParams &p, int64_t batch, const double *records, const double *shared_jac,
+                               double *Ax, double *l, double *u, hipStream_t stream);
+// out[b][:] = src[:] for every b
+hipError_t mpc_replicate_launch(const double *src, int64_t len, int64_t batch, double *out, hipStream_t stream);
+// after a solve: agents whose code is Optimal / MaxIterations / MaxTime store (x, y) as their warm start
+// (mpc.hpp:510-516); du0[b] = x[b][uoff : uoff + nu]
+hipError_t mpc_store_launch(int64_t batch, int n, int m, int uoff, int nu, int store, const double *x, const double *y,
+                            const int32_t *code, double *wx, double *wy, double *du0, hipStream_t stream);
+
+}  // namespace sfb

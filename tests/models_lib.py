@@ -95,3 +95,31 @@ def asif_swarm_step(batch, K, ticks=1, seed=0):
                                     _p(out["x"]), _p(out["y"]), _p(out["wx"]), _p(out["wy"]))
     assert rc == 0
     return out
+
+
+def mpc_layout(variant, K, tf=5.0):
+    """MPCLayout (smooth_feedback_amd.mpc) of the variant's transcription, from the C++ front (MPC::device_layout)."""
+    import smooth_feedback_amd as sfb
+    dims = np.zeros(6, np.int32); alpha = np.zeros(128); D = np.zeros(72); kind = np.zeros(16, np.int32)
+    dof = np.zeros(16, np.int32); crl = np.zeros(16); cru = np.zeros(16)
+    assert lib().sfbx_mpc_layout(variant, K, C.c_double(tf), _p(dims), _p(alpha), _p(D), _p(kind), _p(dof), _p(crl), _p(cru)) == 0
+    nx, nu, ncr, kmesh, nivals, nparts = [int(v) for v in dims]
+    return sfb.MPCLayout(nx, nu, ncr, kmesh, nivals, tf, alpha[:nivals], D[:(kmesh + 1) * kmesh].reshape(kmesh + 1, kmesh),
+                         parts=[(int(kind[g]), int(dof[g])) for g in range(nparts)], crl=crl[:ncr], cru=cru[:ncr])
+
+
+def mpc_records(variant, K, batch, seed=0, tf=5.0, threads=8):
+    """Linearisation records (MPC::fill_record) of the agents of mpc_assemble_batch."""
+    L = mpc_layout(variant, K, tf)
+    rec = np.zeros((batch, L.record_doubles()))
+    assert lib().sfbx_mpc_records(variant, K, C.c_double(tf), C.c_int64(batch), C.c_uint64(seed), _p(rec), threads) == 0
+    return L, rec
+
+
+def mpc_swarm_step(variant, K, batch, ticks, seed=1, tf=5.0, device=False):
+    """`ticks` closed-loop ticks through MPCSwarm (host assembly) or MPCSwarmDevice; outputs of the last tick."""
+    u0 = np.zeros((batch, 2)); codes = np.zeros(batch, np.int32); iters = np.zeros(batch, np.uint32)
+    fn = lib().sfbx_mpc_swarm_device_step if device else lib().sfbx_mpc_swarm_step
+    rc = fn(variant, K, C.c_double(tf), C.c_int64(batch), C.c_uint64(seed), ticks, _p(u0), _p(codes), _p(iters))
+    assert rc == 0, rc
+    return u0, codes, iters

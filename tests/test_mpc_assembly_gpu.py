@@ -1,0 +1,91 @@
+"""Device-side MPC assembly (sfb_mpc_assemble_batch) and the device-resident swarm (sfb_mpc_swarm) on the GPU:
+A, l, u bit-identical to the host transcription; swarm ticks bit-identical to host assembly + batched solve,
+cold and warm-started.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+import models_lib as M
+
+pytestmark = pytest.mark.gpu
+
+
+def _assemble_on_device(L, rec, shared=None):
+    import torch
+    B = rec.shape[0]
+    d_rec = torch.from_numpy(rec).cuda()
+    d_sh = torch.from_numpy(shared).cuda() if shared is not None else None
+    dA = torch.full((B, L.nnzA), np.nan, dtype=torch.float64, device="cuda")
+    dl = torch.full((B, L.m), np.nan, dtype=torch.float64, device="cuda")
+    du = torch.full((B, L.m), np.nan, dtype=torch.float64, device="cuda")
+    L.assemble_batch_device(B, d_rec.data_ptr(), dA.data_ptr(), dl.data_ptr(), du.data_ptr(),
+                            d_sh.data_ptr() if d_sh is not None else 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return dA.cpu().numpy(), dl.cpu().numpy(), du.cpu().numpy()
+
+
+@pytest.mark.parametrize("variant,K,batch", [(6, 10, 7), (6, 50, 33), (12, 50, 300)])
+def test_device_assembly_is_bit_identical_to_the_host_transcription(sfb, variant, K, batch):
+    Av, l, u = M.mpc_assemble_batch(variant, K, batch, seed=9)
+    L, rec = M.mpc_records(variant, K, batch, seed=9)
+    A2, l2, u2 = _assemble_on_device(L, rec)
+    assert np.array_equal(A2, Av) and np.array_equal(l2, l) and np.array_equal(u2, u)
+    # time-invariant linearisation: Jacobians read from ONE shared record
+    own, shared = L.split_shared(rec)
+    A3, l3, u3 = _assemble_on_device(L, own, shared)
+    assert np.array_equal(A3, Av) and np.array_equal(l3, l) and np.array_equal(u3, u)
+
+
+def test_swarm_tick_equals_host_assembly_plus_solve(sfb):
+    """One tick of sfb_mpc_swarm from records == SparseQPPlan.solve_batch_host on the host transcription,
+    bit for bit, cold; then a second tick warm-started from what the swarm kept on the device."""
+    variant, K, B = 12, 50, 96
+    d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
+    plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K))
+    prm = sfb.QPSolverParams(max_iter=4000)
+    Px = np.tile(Pv, (B, 1)); q = np.zeros((B, d["n"]))
+    L, rec = M.mpc_records(variant, K, B, seed=21)
+    Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=21)
+    swarm = sfb.MPCSwarm(plan, L, Pv, np.zeros(d["n"]), B)
+    du0, code, it, x, y = swarm.step_host(rec, prm, full=True)
+    r = plan.solve_batch_host(Px, q, Av, l, u, prm)
+    ub = d["Nx"] * (d["N"] + 1)
+    assert np.array_equal(code, r.code) and np.array_equal(it, r.iter)
+    assert np.array_equal(x, r.primal) and np.array_equal(y, r.dual) and np.array_equal(du0, r.primal[:, ub:ub + 2])
+    assert (code == 0).all()
+    # tick 2: other states, warm start = solutions of tick 1 (all storable)
+    L, rec2 = M.mpc_records(variant, K, B, seed=22)
+    Av2, l2, u2 = M.mpc_assemble_batch(variant, K, B, seed=22)
+    du0b, codeb, itb = swarm.step_host(rec2, prm)
+    r2 = plan.solve_batch_host(Px, q, Av2, l2, u2, prm, warm_x=r.primal, warm_y=r.dual)
+    assert np.array_equal(codeb, r2.code) and np.array_equal(itb, r2.iter) and np.array_equal(du0b, r2.primal[:, ub:ub + 2])
+    # an agent whose solve is not storable keeps its OLDER warm start (mpc.hpp:510-516): make tick 3 infeasible for
+    # agent 0 (c = +inf puts an upper bound at -inf: PrimalInfeasible, qp_solver.hpp:361-374), then tick 4 must start
+    # it from tick 2's solution
+    rec3 = rec2.copy()
+    N, nx, nu, ncr = L.N, L.nx, L.nu, L.ncr
+    o_c = N * (2 * nx + nx * nx + nx * nu)
+    rec3[0, o_c] = np.inf
+    _, code3, _, x3, y3 = swarm.step_host(rec3, prm, full=True)
+    assert code3[0] == 2 and (code3[1:] == 0).all()
+    du0d, coded, itd = swarm.step_host(rec2, prm)
+    wx = x3.copy(); wy = y3.copy()
+    wx[0], wy[0] = r2.primal[0], r2.dual[0]                                                   # what agent 0 kept
+    r4 = plan.solve_batch_host(Px, q, Av2, l2, u2, prm, warm_x=wx, warm_y=wy)
+    assert np.array_equal(coded, r4.code) and np.array_equal(itd, r4.iter) and np.array_equal(du0d, r4.primal[:, ub:ub + 2])
+    # no warm start requested: cold solve, and the stored warm starts are forgotten by reset_warmstart()
+    du0e, codee, ite = swarm.step_host(rec, prm, warmstart=False)
+    assert np.array_equal(ite, it) and np.array_equal(du0e, du0)
+    swarm.reset_warmstart()
+    du0f, codef, itf = swarm.step_host(rec, prm)
+    assert np.array_equal(itf, it) and np.array_equal(du0f, du0)
+    swarm.close()
+
+
+@pytest.mark.parametrize("variant,K,B", [(6, 30, 64), (12, 50, 40)])
+def test_device_swarm_front_matches_host_swarm_front(sfb, variant, K, B):
+    """MPCSwarmDevice (records -> device assembly, device-resident warm start) against MPCSwarm (host assembly,
+    warm start through the host) over three closed-loop ticks: same inputs, codes and iteration counts."""
+    u_h, c_h, i_h = M.mpc_swarm_step(variant, K, B, 3)
+    u_d, c_d, i_d = M.mpc_swarm_step(variant, K, B, 3, device=True)
+    assert np.array_equal(c_h, c_d) and np.array_equal(i_h, i_d) and np.array_equal(u_h, u_d)
+    assert (c_d == 0).all() and np.all(np.abs(u_d) <= 0.5 + 1e-6)
