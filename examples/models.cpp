@@ -2,6 +2,7 @@
 #include "models.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <optional>
 #include <random>
@@ -141,6 +142,8 @@ int fill_pattern(const M & mpc, int32_t * Pp, int32_t * Pi, double * Pval, int32
   return 0;
 }
 
+std::vector<double> g_tick_seconds;  // wall time of every swarm.step() of the last swarm_step call
+
 template<class M, class XF, class X, class Swarm = MPCSwarm<M>>
 int swarm_step(M & mpc, XF xdes, int64_t batch, uint64_t seed, int ticks, double * u0, int32_t * codes, uint32_t * iters)
 {
@@ -153,8 +156,11 @@ int swarm_step(M & mpc, XF xdes, int64_t batch, uint64_t seed, int ticks, double
   }
   std::vector<U2> us;
   std::vector<QPSolutionStatus> cs;
+  g_tick_seconds.assign(ticks, 0.0);
   for (int k = 0; k < ticks; ++k) {
+    const auto t0 = std::chrono::steady_clock::now();
     swarm.step(t, xs, us, cs);
+    g_tick_seconds[k] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     // crude closed loop: integrate the state with the applied input for one 25 ms tick
     for (int64_t b = 0; b < batch; ++b) {
       auto f = mpc_dyn(mpc, xs[b], us[b]);
@@ -256,6 +262,12 @@ int sfbx_mpc_records(int variant, int K, double tf, int64_t batch, uint64_t seed
   if (variant == 6) { auto mpc = make6(K, tf); return records_batch(mpc, xdes6, batch, seed, rec, threads); }
   if (variant == 12) { auto mpc = make12(K, tf); return records_batch(mpc, xdes12, batch, seed, rec, threads); }
   return -1;
+}
+
+int sfbx_last_tick_seconds(double * out, int n)
+{
+  for (int k = 0; k < n && k < (int)g_tick_seconds.size(); ++k) out[k] = g_tick_seconds[k];
+  return (int)g_tick_seconds.size();
 }
 
 int sfbx_mpc_swarm_device_step(int variant, int K, double tf, int64_t batch, uint64_t seed, int ticks, double * u0,

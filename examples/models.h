@@ -35,6 +35,8 @@ int sfbx_mpc_layout(int variant, int K, double tf, int32_t *dims, double *alpha,
 int sfbx_mpc_records(int variant, int K, double tf, int64_t batch, uint64_t seed, double *rec, int threads);
 int sfbx_mpc_swarm_device_step(int variant, int K, double tf, int64_t batch, uint64_t seed, int ticks, double *u0,
                                int32_t *codes, uint32_t *iters);
+/* wall seconds of every swarm.step() of the last sfbx_mpc_swarm[_device]_step call; returns their number */
+int sfbx_last_tick_seconds(double *out, int n);
 /* group identities for the tests: returns max abs error over a set of checks */
 double sfbx_lie_selftest(void);
 /* EKF<G> front (include/smooth_feedback_amd/ekf.hpp) against the reference's own checks: PredictTimeCut

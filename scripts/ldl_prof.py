@@ -1,0 +1,11 @@
+import os, sys
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import numpy as np, torch
+import smooth_feedback_amd as sfb
+import models_lib as M
+B = int(os.environ.get("B", 8192))
+d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(12, 50)
+Av, l, u = M.mpc_assemble_batch(12, 50, B, seed=3, threads=64)
+plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(12, 50))
+r = plan.solve_batch_host(np.tile(Pv, (B, 1)), np.zeros((B, d["n"])), Av, l, u, sfb.QPSolverParams(max_iter=0, polish=False))
+print("done", B)

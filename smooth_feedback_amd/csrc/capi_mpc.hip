@@ -1,6 +1,9 @@
 // C-ABI of the device-side MPC assembly and of the device-resident swarm (include/sfb.h).
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -282,13 +285,27 @@ sfb_status sfb_mpc_swarm_step_host(sfb_mpc_swarm *S, const sfb_qp_params *prm, c
   const sfb::MpcAsmParams &p = shared_jac ? S->rec_shared : S->rec_own;
   hipError_t e = hipSuccess;
   sfb_status st = SFB_OK;
+  // SFB_MPC_TIMING=1: synchronise after every stage and print the wall time of each (diagnostics only)
+  static const bool timing = [] { const char *v = getenv("SFB_MPC_TIMING"); return v && v[0] == '1'; }();
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto t0 = now();
+  auto lap = [&](const char *what) {
+    if (!timing) return;
+    (void)hipDeviceSynchronize();
+    const auto t1 = now();
+    fprintf(stderr, "[sfb_mpc_swarm] %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  };
   do {
     if ((e = hipMemcpy(S->rec, records, B * (size_t)p.rec_doubles * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
     if (shared_jac && (e = hipMemcpy(S->shared, shared_jac, (size_t)S->shared_doubles * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
+    lap("H2D");
     if ((e = sfb::mpc_assemble_launch(p, S->agents, S->rec, shared_jac ? S->shared : nullptr, S->Ax, S->l, S->u, nullptr)) != hipSuccess) break;
+    lap("assemble");
     st = sfb_sparse_qp_solve_batch(S->plan, prm, S->agents, S->Px, S->q, S->Ax, S->l, S->u, warmstart ? S->wx : nullptr,
                                    warmstart ? S->wy : nullptr, S->x, S->y, nullptr, S->iter, S->code, S->ws, nullptr);
     if (st != SFB_OK) break;
+    lap("solve");
     if ((e = sfb::mpc_store_launch(S->agents, S->n, S->m, S->uoff, S->nu, warmstart != 0, S->x, S->y, S->code, S->wx, S->wy,
                                    S->du0, nullptr)) != hipSuccess) break;
     if ((e = hipMemcpy(du0, S->du0, B * (size_t)S->nu * 8, hipMemcpyDeviceToHost)) != hipSuccess) break;
@@ -296,6 +313,7 @@ sfb_status sfb_mpc_swarm_step_host(sfb_mpc_swarm *S, const sfb_qp_params *prm, c
     if ((e = hipMemcpy(code, S->code, B * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
     if (primal && (e = hipMemcpy(primal, S->x, B * (size_t)S->n * 8, hipMemcpyDeviceToHost)) != hipSuccess) break;
     if (dual && (e = hipMemcpy(dual, S->y, B * (size_t)S->m * 8, hipMemcpyDeviceToHost)) != hipSuccess) break;
+    lap("store+D2H");
   } while (false);
   if (e != hipSuccess) st = sfb::hip_fail(e, "sfb_mpc_swarm_step_host");
   return st;

@@ -89,6 +89,33 @@ __device__ __forceinline__ double kkt_value(const SparsePlanDev &pl, const Item 
   return v;
 }
 
+// One block of DEPTH trailing accumulators per lane: v = fma(-L(a, j), L(b, j) D(j), v) over the columns j of the
+// supernode in ascending order, the DEPTH chains advancing together.
+template<int DEPTH>
+__device__ __forceinline__ void trailing_block(const double *pan, const double *mul, const int R, const int wd,
+                                               const int (&tp)[DEPTH], const unsigned (&ab)[DEPTH], double (&v)[DEPTH],
+                                               double *ACC)
+{
+  int ra[DEPTH], rb[DEPTH];
+#pragma unroll
+  for (int dd = 0; dd < DEPTH; ++dd) {
+    ra[dd] = wd + (int)(ab[dd] & 0xFFFFu);
+    rb[dd] = wd + (int)(ab[dd] >> 16);
+  }
+  for (int jj = 0; jj < wd; ++jj) {
+    double a[DEPTH], b[DEPTH];
+#pragma unroll
+    for (int dd = 0; dd < DEPTH; ++dd) {
+      a[dd] = pan[jj * R + ra[dd]];
+      b[dd] = mul[jj * R + rb[dd]];
+    }
+#pragma unroll
+    for (int dd = 0; dd < DEPTH; ++dd) v[dd] = fma(-a[dd], b[dd], v[dd]);
+  }
+#pragma unroll
+  for (int dd = 0; dd < DEPTH; ++dd) ACC[tp[dd]] = v[dd];
+}
+
 // Numeric LDL' on the shared pattern, RIGHT-LOOKING over RELAXED SUPERNODES with a static schedule
 // (sparse_plan.h).  The accumulators [L values | D] live in the item's HBM workspace.  Per group of
 // consecutive columns j0 .. j0+w-1 (R = w + |U| panel rows, U = union of the members' remaining structures):
@@ -108,11 +135,19 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
                                       const double c, const double sigma, const double delta, const int lane)
 {
   const int k = pl.k, nnzL = pl.nnzL;
+#ifdef SFB_PROF_LDL
+  unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, pc = __builtin_amdgcn_s_memtime();
+#define SFB_LAP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[i] += now_ - pc; pc = now_; }
+#else
+#define SFB_LAP(i)
+#endif
   double *ACC = w.Lx;  // [0, nnzL): L entries, [nnzL, nnzL+k): D, [nnzL+k]: scratch, [nnzL+k+1]: always zero
   for (int p = lane; p < nnzL + k + 2; p += kWave) ACC[p] = 0.0;
+  for (int p = lane; p < pl.nzlist; p += kWave) ACC[pl.zlist[p]] = 0.0;  // padding slots of the sweep copies
   wave_sync();
   for (int p = lane; p < pl.nnzK; p += kWave) ACC[pl.Kmap[p]] = kkt_value(pl, it, w, p, mode, c, sigma, delta);
   wave_sync();
+  SFB_LAP(0)
   for (int sn = 0; sn < pl.nsn; ++sn) {
     const int j0 = pl.snptr[sn], wd = pl.snptr[sn + 1] - j0;
     const int R  = pl.snR[sn];  // panel rows: the w columns themselves, then the union U of their structures
@@ -129,10 +164,13 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
     for (int dd = 0; dd < DEPTH; ++dd) {  // the schedule arrays are padded: reading past s1 is safe
       tp0[dd] = pl.rtgt[(s0 + dd) * kWave + lane];
       ab0[dd] = (unsigned)pl.rab[(s0 + dd) * kWave + lane];
-      if (s0 + dd >= s1) tp0[dd] = pad;
+      if (s0 + dd >= s1) {
+        tp0[dd] = pad;
+        ab0[dd] = 0u;
+      }
     }
 #pragma unroll
-    for (int dd = 0; dd < DEPTH; ++dd) acc0[dd] = (tp0[dd] != pad) ? ACC[tp0[dd]] : 0.0;
+    for (int dd = 0; dd < DEPTH; ++dd) acc0[dd] = ACC[tp0[dd]];
     // 1. panel accumulators -> LDS (gather through the panel map, DEPTH loads in flight per lane)
     const int32_t *pm = pl.pmap + pl.poff[sn];
     const int npan    = wd * R;
@@ -148,6 +186,7 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
         if (q0 + dd * kWave < npan) pan[q0 + dd * kWave] = v[dd];
     }
     wave_lds_fence();
+    SFB_LAP(1)
     // 2. eliminate the panel (LDS only)
     for (int jj = 0; jj < wd; ++jj) {
       const double d = pan[jj * R + jj];
@@ -163,22 +202,21 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
           pan[rb * R + ra] = fma(-pan[jj * R + ra], mul[jj * R + rb], pan[rb * R + ra]);
       wave_lds_fence();
     }
+    SFB_LAP(2)
     // final D, 1/D and L values of the panel -> workspace (fire and forget)
-    for (int q = lane; q < npan; q += kWave) {
-      const int dst = pm[q];
-      if (dst < nnzL + k) ACC[dst] = pan[q];  // not the scratch / zero accumulators
+    {
+      const int32_t *pf = pl.pmapF + pl.poff[sn], *pb = pl.pmapB + pl.poff[sn];
+      for (int q = lane; q < npan; q += kWave) {
+        const double v = pan[q];
+        ACC[pf[q]] = v;  // slot of L(r, j) in the forward-sweep copy (others: scratch accumulator)
+        ACC[pb[q]] = v;  // ... and in the backward-sweep copy
+      }
     }
     for (int jj = lane; jj < wd; jj += kWave) w.Dinv[j0 + jj] = 1.0 / pan[jj * R + jj];
     // 3. trailing accumulators: pairs (a >= b) of rows of U, local rows w + a, w + b
-#pragma unroll
-    for (int dd = 0; dd < DEPTH; ++dd) {
-      if (tp0[dd] != pad) {
-        const int ra = wd + (int)(ab0[dd] & 0xFFFFu), rb = wd + (int)(ab0[dd] >> 16);
-        double v = acc0[dd];
-        for (int jj = 0; jj < wd; ++jj) v = fma(-pan[jj * R + ra], mul[jj * R + rb], v);
-        ACC[tp0[dd]] = v;
-      }
-    }
+    // (the DEPTH chains of a block advance together, column by column: 2 x DEPTH LDS reads in flight per lane
+    //  instead of one dependent pair; padding slots compute on row 0 and land in the scratch accumulator)
+    trailing_block<DEPTH>(pan, mul, R, wd, tp0, ab0, acc0, ACC);
     for (int s = s0 + DEPTH; s < s1; s += DEPTH) {
       int tp[DEPTH];
       unsigned ab[DEPTH];
@@ -187,32 +225,26 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
       for (int dd = 0; dd < DEPTH; ++dd) {
         tp[dd] = pl.rtgt[(s + dd) * kWave + lane];
         ab[dd] = (unsigned)pl.rab[(s + dd) * kWave + lane];
-        if (s + dd >= s1) tp[dd] = pad;
-      }
-#pragma unroll
-      for (int dd = 0; dd < DEPTH; ++dd) acc[dd] = (tp[dd] != pad) ? ACC[tp[dd]] : 0.0;
-#pragma unroll
-      for (int dd = 0; dd < DEPTH; ++dd) {
-        if (tp[dd] != pad) {
-          const int ra = wd + (int)(ab[dd] & 0xFFFFu), rb = wd + (int)(ab[dd] >> 16);
-          double v = acc[dd];
-          for (int jj = 0; jj < wd; ++jj) v = fma(-pan[jj * R + ra], mul[jj * R + rb], v);
-          ACC[tp[dd]] = v;
+        if (s + dd >= s1) {
+          tp[dd] = pad;
+          ab[dd] = 0u;
         }
       }
+#pragma unroll
+      for (int dd = 0; dd < DEPTH; ++dd) acc[dd] = ACC[tp[dd]];
+      trailing_block<DEPTH>(pan, mul, R, wd, tp, ab, acc, ACC);
     }
     wave_sync();
+    SFB_LAP(3)
   }
-  // schedule-ordered copies of the factor for the two sweeps (padding slots carry 0)
-  for (int q = lane; q < (pl.funits + kSweepPadDev) * 2 * kWave; q += kWave) {
-    const int src = pl.fmap[q];
-    w.LxF[q]      = (src >= 0) ? w.Lx[src] : 0.0;
-  }
-  for (int q = lane; q < (pl.bunits + kSweepPadDev) * 2 * kWave; q += kWave) {
-    const int src = pl.bmap[q];
-    w.LxB[q]      = (src >= 0) ? w.Lx[src] : 0.0;
-  }
+  // (the schedule-ordered copies of the factor for the two sweeps were written entry by entry above)
   wave_sync();
+  SFB_LAP(4)
+#ifdef SFB_PROF_LDL
+  if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
+    printf("[ldl block %u mode %d] fill %llu  panel-load %llu  panel-elim %llu  trailing %llu  copies %llu  (x10 ns)\n",
+           blockIdx.x, mode, pt[0], pt[1], pt[2], pt[3], pt[4]);
+#endif
   return 1;
 }
 
