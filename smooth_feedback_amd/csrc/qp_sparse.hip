@@ -121,8 +121,10 @@ __device__ __forceinline__ void trailing_block(const double *pan, const double *
 // consecutive columns j0 .. j0+w-1 (R = w + |U| panel rows, U = union of the members' remaining structures):
 //   1. its own accumulators (a dense w x R panel, explicit zeros where a member has no entry) are loaded into
 //      LDS together with the first block of trailing accumulators (one memory round trip);
-//   2. the panel is eliminated there column by column: divide by D, stage the entries L(.,j) and the
-//      multipliers L(.,j) D(j), update the later panel columns;
+//   2. the panel is eliminated column by column: divide by D, stage the entries L(.,j) and the multipliers
+//      L(.,j) D(j), update the later panel columns -- in REGISTERS when the panel has at most 64 rows (lane r holds
+//      row r, pivots and multipliers are v_readlane broadcasts: no LDS round trip on the dependent chain; the MPC
+//      pattern has R <= 58), else in LDS;
 //   3. every TRAILING accumulator (a pair of rows of U) receives the w updates of the group with ONE
 //      read-modify-write, 64 independent slots per step.
 // Every accumulator still sees its sources in ascending column order, fma(-L(a,j), L(b,j) D(j), acc), so
@@ -130,6 +132,8 @@ __device__ __forceinline__ void trailing_block(const double *pan, const double *
 // what changes is the HBM traffic and the number of dependent memory round trips: for the MPC pattern
 // 81 k accumulator touches and 2 x 207 round trips per factorisation instead of 711 k and 2 x 1 480.
 // t = LDS scratch of pl.lds_doubles doubles (the plan caps w so that 2 w R fits).  Returns 1 / 0 (zero pivot).
+constexpr int kPanelCols = 16;  // == the plan's widest supernode (sparse_plan.cpp kMaxWidth)
+
 template<int DEPTH>
 __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, const Ws &w, double *t, const int mode,
                                       const double c, const double sigma, const double delta, const int lane)
@@ -143,7 +147,6 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
 #endif
   double *ACC = w.Lx;  // [0, nnzL): L entries, [nnzL, nnzL+k): D, [nnzL+k]: scratch, [nnzL+k+1]: always zero
   for (int p = lane; p < nnzL + k + 2; p += kWave) ACC[p] = 0.0;
-  for (int p = lane; p < pl.nzlist; p += kWave) ACC[pl.zlist[p]] = 0.0;  // padding slots of the sweep copies
   wave_sync();
   for (int p = lane; p < pl.nnzK; p += kWave) ACC[pl.Kmap[p]] = kkt_value(pl, it, w, p, mode, c, sigma, delta);
   wave_sync();
@@ -171,9 +174,43 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
     }
 #pragma unroll
     for (int dd = 0; dd < DEPTH; ++dd) acc0[dd] = ACC[tp0[dd]];
-    // 1. panel accumulators -> LDS (gather through the panel map, DEPTH loads in flight per lane)
     const int32_t *pm = pl.pmap + pl.poff[sn];
     const int npan    = wd * R;
+    if (R <= kWave) {
+      // 1 + 2, register form (the usual case): lane r holds row r of the panel, one register per member column.
+      // Pivots and multipliers travel by v_readlane broadcasts; no LDS round trip and no fence on the dependent
+      // chain of the elimination.  Same operations per entry as the LDS form below: divide by D, multiply back,
+      // fma(-L(ra, j), L(rb, j) D(j), .) in ascending j.  Entries above the diagonal hold garbage and are never used.
+      double reg[kPanelCols];
+      {
+        int src[kPanelCols];
+#pragma unroll
+        for (int jj = 0; jj < kPanelCols; ++jj)
+          src[jj] = (jj < wd && lane < R) ? pm[jj * R + lane] : pad + 1;  // pad + 1: the always-zero accumulator
+#pragma unroll
+        for (int jj = 0; jj < kPanelCols; ++jj) reg[jj] = ACC[src[jj]];
+      }
+      SFB_LAP(1)
+#pragma unroll
+      for (int jj = 0; jj < kPanelCols; ++jj) {
+        if (jj < wd) {
+          const double d = lane_bcast(reg[jj], jj);
+          if (d == 0.0) return 0;
+          const double v  = reg[jj] / d;
+          const double mv = v * d;
+          if (lane > jj) reg[jj] = v;
+          if (lane < R) {  // final column jj: L(r, j) below the diagonal, D on it; multipliers for the trailing update
+            pan[jj * R + lane] = reg[jj];
+            mul[jj * R + lane] = mv;
+          }
+#pragma unroll
+          for (int rb = jj + 1; rb < kPanelCols; ++rb)
+            if (rb < wd) reg[rb] = fma(-v, lane_bcast(mv, rb), reg[rb]);
+        }
+      }
+      wave_lds_fence();
+    } else {
+    // 1. panel accumulators -> LDS (gather through the panel map, DEPTH loads in flight per lane)
     for (int q0 = lane; q0 < npan; q0 += kWave * DEPTH) {
       int src[DEPTH];
       double v[DEPTH];
@@ -202,15 +239,12 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
           pan[rb * R + ra] = fma(-pan[jj * R + ra], mul[jj * R + rb], pan[rb * R + ra]);
       wave_lds_fence();
     }
+    }
     SFB_LAP(2)
     // final D, 1/D and L values of the panel -> workspace (fire and forget)
-    {
-      const int32_t *pf = pl.pmapF + pl.poff[sn], *pb = pl.pmapB + pl.poff[sn];
-      for (int q = lane; q < npan; q += kWave) {
-        const double v = pan[q];
-        ACC[pf[q]] = v;  // slot of L(r, j) in the forward-sweep copy (others: scratch accumulator)
-        ACC[pb[q]] = v;  // ... and in the backward-sweep copy
-      }
+    for (int q = lane; q < npan; q += kWave) {
+      const int dst = pm[q];
+      if (dst < nnzL + k) ACC[dst] = pan[q];  // not the scratch / zero accumulators
     }
     for (int jj = lane; jj < wd; jj += kWave) w.Dinv[j0 + jj] = 1.0 / pan[jj * R + jj];
     // 3. trailing accumulators: pairs (a >= b) of rows of U, local rows w + a, w + b
@@ -237,7 +271,17 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
     wave_sync();
     SFB_LAP(3)
   }
-  // (the schedule-ordered copies of the factor for the two sweeps were written entry by entry above)
+  // Schedule-ordered copies of the factor for the two sweeps (padding slots carry 0).  A streaming pass: writing
+  // the final values straight into the copies from the panels (scattered 8-byte writes) is quicker for a lone
+  // wave but costs the batch more HBM traffic than this gather + coalesced write -- measured.
+  for (int q = lane; q < (pl.funits + kSweepPadDev) * 2 * kWave; q += kWave) {
+    const int src = pl.fmap[q];
+    w.LxF[q]      = (src >= 0) ? w.Lx[src] : 0.0;
+  }
+  for (int q = lane; q < (pl.bunits + kSweepPadDev) * 2 * kWave; q += kWave) {
+    const int src = pl.bmap[q];
+    w.LxB[q]      = (src >= 0) ? w.Lx[src] : 0.0;
+  }
   wave_sync();
   SFB_LAP(4)
 #ifdef SFB_PROF_LDL

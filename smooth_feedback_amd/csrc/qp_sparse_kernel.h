@@ -24,8 +24,7 @@ struct SparsePlanDev {
   const int32_t *Kmap, *rptr, *rtgt, *rab;   // right-looking factorisation schedule
   int rsteps, maxcol;
   const int32_t *snptr, *snR, *poff, *pmap;  // (relaxed) supernodes of the factorisation and their panel maps
-  const int32_t *pmapF, *pmapB, *zlist;      // final values -> sweep-ordered copies; padding slots to zero
-  int nsn, lds_doubles, nzlist;
+  int nsn, lds_doubles;
 };
 
 // per-item workspace, in doubles
@@ -35,7 +34,7 @@ inline size_t qp_sparse_ws_doubles(int n, int m, int nnzL, int funits, int bunit
   const size_t k = (size_t)n + m;
   return (size_t)nnzL + (size_t)(funits + bunits + 2 * kSweepPadDev) * 128 + 3 * k + 6 * (size_t)n + 12 * (size_t)m + 8;
   // (accumulator layout of the factorisation: [L values | D | scratch | zero] is contiguous at the start of the block,
-  //  followed by the forward- and backward-sweep copies of the factor: pmapF / pmapB / zlist are offsets from its start)
+  //  followed by the forward- and backward-sweep copies of the factor)
 }
 
 hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp, int64_t batch, const double *Px,

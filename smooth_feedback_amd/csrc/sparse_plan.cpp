@@ -1,6 +1,8 @@
 #include "sparse_plan.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <iterator>
 #include <array>
 #include <numeric>
@@ -328,6 +330,20 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
       j0 += w;
     }
     o.nsn = (int)o.snptr.size();
+    if (const char *dbg = getenv("SFB_PLAN_DEBUG"); dbg && dbg[0] == '1') {  // diagnostics: supernode shapes
+      int maxR = 0, over64 = 0;
+      long long panel = 0;
+      for (int sn = 0; sn < o.nsn; ++sn) {
+        const int w = (sn + 1 < o.nsn ? o.snptr[sn + 1] : k) - o.snptr[sn], R = o.snR[sn];
+        maxR = std::max(maxR, R);
+        over64 += R > 64;
+        panel += (long long)w * R;
+        fprintf(stderr, "[sfb plan] supernode %d: columns %d..%d (w=%d) R=%d steps=%d\n", sn, o.snptr[sn], o.snptr[sn] + w - 1, w, R,
+                o.rptr[sn + 1] - o.rptr[sn]);
+      }
+      fprintf(stderr, "[sfb plan] %d supernodes, max R %d, %d with R > 64, panel entries %lld, trailing steps %d\n", o.nsn, maxR,
+              over64, panel, o.rptr.back());
+    }
     o.snptr.push_back(k);
     o.poff.push_back((int)o.pmap.size());
     o.rsteps = o.rptr.back();
@@ -426,33 +442,6 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
   build(true, o.fmap, o.fidx, o.funits);
   build(false, o.bmap, o.bidx, o.bunits);
 
-  // Where the final value of every panel entry goes: straight into the schedule-ordered copies of the factor
-  // that the two sweeps stream (offsets relative to the accumulator block, which the copies follow in the
-  // workspace); entries that are not values of L (diagonal, explicit zeros, unused upper part) go to the scratch
-  // accumulator.  zlist = the padding slots of both copies, which must read as 0.
-  {
-    const int32_t SCRATCH = o.nnzL + k;
-    const int64_t baseF = (int64_t)o.nnzL + k + 2, baseB = baseF + (int64_t)(o.funits + SparsePlanHost::kSweepPad) * 128;
-    const int64_t end = baseB + (int64_t)(o.bunits + SparsePlanHost::kSweepPad) * 128;
-    if (end >= (int64_t)1 << 31) { *msg = "factor too large for 32-bit workspace offsets"; return false; }
-    std::vector<int32_t> posF(o.nnzL, -1), posB(o.nnzL, -1);
-    for (size_t q = 0; q < o.fmap.size(); ++q)
-      if (o.fmap[q] >= 0) posF[o.fmap[q]] = (int32_t)(baseF + (int64_t)q);
-      else o.zlist.push_back((int32_t)(baseF + (int64_t)q));
-    for (size_t q = 0; q < o.bmap.size(); ++q)
-      if (o.bmap[q] >= 0) posB[o.bmap[q]] = (int32_t)(baseB + (int64_t)q);
-      else o.zlist.push_back((int32_t)(baseB + (int64_t)q));
-    o.pmapF.assign(o.pmap.size(), SCRATCH);
-    o.pmapB.assign(o.pmap.size(), SCRATCH);
-    for (size_t q = 0; q < o.pmap.size(); ++q)
-      if (o.pmap[q] < o.nnzL) {
-        if (posF[o.pmap[q]] < 0 || posB[o.pmap[q]] < 0) { *msg = "internal: entry of L missing from a sweep schedule"; return false; }
-        o.pmapF[q] = posF[o.pmap[q]];
-        o.pmapB[q] = posB[o.pmap[q]];
-      }
-    o.nzlist = (int)o.zlist.size();
-    for (int pad = 0; pad < 64 * SparsePlanHost::kSweepPad; ++pad) o.zlist.push_back(SCRATCH);
-  }
   return true;
 }
 

@@ -64,11 +64,7 @@ struct SparsePlanHost {
   //   rtgt[q]  : accumulator index (padding: scratch),  rab[q] = a | b << 16 (positions in U)
   // Group widths are capped so that the panel and its multipliers, 2 w R doubles, fit the kernel's LDS
   // scratch of lds_doubles.
-  //   pmapF / pmapB : like pmap, the slot of the entry's FINAL value in the forward / backward copy of the factor
-  //              (offset from the accumulator block; non-L entries -> scratch);  zlist[nzlist] = padding slots of
-  //              the two copies (to be zeroed)
-  std::vector<int32_t> Kmap, rptr, rtgt, rab, snptr, snR, poff, pmap, pmapF, pmapB, zlist;
-  int nzlist = 0;
+  std::vector<int32_t> Kmap, rptr, rtgt, rab, snptr, snR, poff, pmap;
   int rsteps = 0, maxcol = 0, nsn = 0, lds_doubles = 0;
 };
 
