@@ -274,14 +274,23 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
   // Schedule-ordered copies of the factor for the two sweeps (padding slots carry 0).  A streaming pass: writing
   // the final values straight into the copies from the panels (scattered 8-byte writes) is quicker for a lone
   // wave but costs the batch more HBM traffic than this gather + coalesced write -- measured.
-  for (int q = lane; q < (pl.funits + kSweepPadDev) * 2 * kWave; q += kWave) {
-    const int src = pl.fmap[q];
-    w.LxF[q]      = (src >= 0) ? w.Lx[src] : 0.0;
-  }
-  for (int q = lane; q < (pl.bunits + kSweepPadDev) * 2 * kWave; q += kWave) {
-    const int src = pl.bmap[q];
-    w.LxB[q]      = (src >= 0) ? w.Lx[src] : 0.0;
-  }
+  // (branch-free, DEPTH gathers in flight per lane: padding slots read the always-zero accumulator; the copies'
+  //  lengths are multiples of kSweepPadDev * 128 >= DEPTH * 64)
+  auto gather_copy = [&](const int32_t *__restrict__ map, double *__restrict__ dst, const int total) {
+    for (int q0 = lane; q0 < total; q0 += kWave * DEPTH) {
+      int src[DEPTH];
+      double v[DEPTH];
+#pragma unroll
+      for (int dd = 0; dd < DEPTH; ++dd) src[dd] = map[q0 + dd * kWave];
+#pragma unroll
+      for (int dd = 0; dd < DEPTH; ++dd) v[dd] = ACC[src[dd] >= 0 ? src[dd] : nnzL + k + 1];
+#pragma unroll
+      for (int dd = 0; dd < DEPTH; ++dd) dst[q0 + dd * kWave] = v[dd];
+    }
+  };
+  static_assert(kSweepPadDev * 2 >= DEPTH, "copy loop assumes whole blocks");
+  gather_copy(pl.fmap, w.LxF, (pl.funits + kSweepPadDev) * 2 * kWave);
+  gather_copy(pl.bmap, w.LxB, (pl.bunits + kSweepPadDev) * 2 * kWave);
   wave_sync();
   SFB_LAP(4)
 #ifdef SFB_PROF_LDL
