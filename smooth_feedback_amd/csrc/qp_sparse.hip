@@ -18,6 +18,8 @@
 // it once in each direction: this kernel is HBM-bound by construction.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <type_traits>
 #include <utility>
@@ -324,6 +326,26 @@ __device__ __forceinline__ void stream_load(vint2 &v, const vint2 *p)
   static_assert(OFF >= 0 && OFF < 4096, "immediate offset of global_load");
   asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF));
 }
+// the same 16-byte load with the lanes outside `mask` switched off (they keep their register content and
+// generate no memory request); exec is all ones around the sweeps (wave-uniform control flow)
+typedef int sint8 __attribute__((ext_vector_type(8)));
+// `shift` = 64 - (number of leading lanes that load): exec = all ones >> shift
+template<int OFF>
+__device__ __forceinline__ void stream_load_masked(vdouble2 &v, const vdouble2 *p, const int shift)
+{
+  static_assert(OFF >= 0 && OFF < 4096, "immediate offset of global_load");
+  asm volatile("s_lshr_b64 exec, -1, %2\n\tglobal_load_dwordx4 %0, %1, off offset:%3\n\ts_mov_b64 exec, -1"
+               : "+v"(v)
+               : "v"(p), "s"(shift), "n"(OFF)
+               : "scc");  // s_lshr writes SCC
+}
+// lane-mask shifts of 8 consecutive units (32 bytes) by ONE scalar load; the wait is a separate statement placed
+// behind the first unit's LDS round trip
+__device__ __forceinline__ void mask_fetch(sint8 &m, const int32_t *tab, const int byte_off)
+{
+  asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(m) : "s"(tab), "s"(byte_off));
+}
+__device__ __forceinline__ void mask_wait(sint8 &m) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m)); }
 template<int N>
 __device__ __forceinline__ void stream_wait(vdouble2 &a, vint2 &b)
 {
@@ -338,9 +360,14 @@ __device__ __forceinline__ void stream_wait(vdouble2 &a, vint2 &b)
 // (= 2 x DEPTH slots per lane) are in flight ahead of their use so the ~1.7 us HBM latency of a lone
 // wave is covered; t has k+1 entries, t[k] is the padding slot; `units` is a multiple of kSweepPadDev.
 template<int DEPTH, bool BYTEOFF>
-__device__ inline void sweep_dev(const int32_t *__restrict__ idx, const int units, const double *vals, double *t,
-                                 const int lane)
+__device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const int units, const double *vals, double *t,
+                                 const int lane, const int32_t *__restrict__ mask32, int full0, int full1, const bool lean)
 {
+  // lean == false (few waves left on the chip: latency matters, HBM traffic does not): every block issues plain loads
+  if (!lean) {
+    full0 = 0;
+    full1 = units + 2 * DEPTH;
+  }
   static_assert(DEPTH <= kSweepPadDev && kSweepPadDev % DEPTH == 0, "schedule padding must cover the prefetch distance");
   static_assert(2 * DEPTH <= 62, "vmcnt is a 6-bit counter");
   static_assert(DEPTH <= 8, "two value pointers cover 8 units of 1 KB with 12-bit offsets");
@@ -348,22 +375,51 @@ __device__ inline void sweep_dev(const int32_t *__restrict__ idx, const int unit
   const vdouble2 *vp0 = reinterpret_cast<const vdouble2 *>(vals) + lane;
   const vdouble2 *vp1 = vp0 + 4 * kWave;
   const vint2 *ip     = reinterpret_cast<const vint2 *>(idx) + lane;
+  static_assert(DEPTH == 8, "one scalar load fetches the lane-mask shifts of a block of 8 units");
   vdouble2 lx[DEPTH];
   vint2 ix[DEPTH];
-  auto issue = [&]<int D>(std::integral_constant<int, D>) {
-    if constexpr (D < 4) stream_load<D * kWave * 16>(lx[D], vp0);
-    else stream_load<(D - 4) * kWave * 16>(lx[D], vp1);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) lx[d] = vdouble2{0.0, 0.0};  // masked lanes keep what the register holds
+  // Value loads of partially filled units are masked to the lanes that carry slots (sparse_plan.h): the padding
+  // of the schedule then costs no HBM traffic.  Units in [full0, full1) are full: plain loads, no mask fetch.
+  auto issue = [&]<int D, bool MASKED>(std::integral_constant<int, D>, std::bool_constant<MASKED>, const sint8 &mk) {
+    if constexpr (MASKED) {
+      if constexpr (D < 4) stream_load_masked<D * kWave * 16>(lx[D], vp0, mk[D]);
+      else stream_load_masked<(D - 4) * kWave * 16>(lx[D], vp1, mk[D]);
+    } else {
+      if constexpr (D < 4) stream_load<D * kWave * 16>(lx[D], vp0);
+      else stream_load<(D - 4) * kWave * 16>(lx[D], vp1);
+    }
     stream_load<D * kWave * 8>(ix[D], ip);
   };
   auto for_units = [&]<int... D>(std::integer_sequence<int, D...>, auto &&fn) { (fn(std::integral_constant<int, D>{}), ...); };
-  for_units(std::make_integer_sequence<int, DEPTH>{}, issue);
   auto advance = [&] {
     vp0 += DEPTH * kWave;
     vp1 += DEPTH * kWave;
     ip += DEPTH * kWave;
   };
+  sint8 mk;  // mask shifts of the units the current block issues
+  {  // the table pointer as a scalar (it may live in a VGPR lane after register spilling)
+    const unsigned long long a = reinterpret_cast<unsigned long long>(mask32);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    mask32 = reinterpret_cast<const int32_t *>(((unsigned long long)hi << 32) | lo);
+  }
+  if (lean) {
+    mask_fetch(mk, mask32, 0);
+    mask_wait(mk);
+    for_units(std::make_integer_sequence<int, DEPTH>{},
+              [&]<int D>(std::integral_constant<int, D> dd) { issue(dd, std::true_type{}, mk); });
+  } else {
+    for_units(std::make_integer_sequence<int, DEPTH>{},
+              [&]<int D>(std::integral_constant<int, D> dd) { issue(dd, std::false_type{}, mk); });
+  }
   advance();
-  for (int u0 = 0; u0 < units; u0 += DEPTH) {
+  // one block of DEPTH units: consume unit u0 + D, then issue the loads of unit u0 + D + DEPTH (their mask shifts are
+  // fetched at the head of the block and awaited behind the first unit's LDS round trip)
+  auto block = [&]<bool MASKED>(std::bool_constant<MASKED> msk, const int u0) {
+    sint8 mk;
+    if constexpr (MASKED) mask_fetch(mk, mask32, __builtin_amdgcn_readfirstlane((u0 + DEPTH) * 4));
     for_units(std::make_integer_sequence<int, DEPTH>{}, [&]<int D>(std::integral_constant<int, D> dd) {
       stream_wait<2 * (DEPTH - 1)>(lx[D], ix[D]);  // this unit's two loads are the oldest in flight
       const unsigned p0 = (unsigned)ix[D].x, p1 = (unsigned)ix[D].y;
@@ -374,10 +430,17 @@ __device__ inline void sweep_dev(const int32_t *__restrict__ idx, const int unit
       const double a0 = at(p0 >> 16), b0 = at(p0 & 0xFFFFu), a1 = at(p1 >> 16), b1 = at(p1 & 0xFFFFu);
       at(p0 & 0xFFFFu) = fma(-lx[D].x, a0, b0);
       at(p1 & 0xFFFFu) = fma(-lx[D].y, a1, b1);
-      issue(dd);  // unit u0 + D + DEPTH (always inside the padded arrays)
+      if constexpr (D == 0 && MASKED) mask_wait(mk);  // behind the LDS round trip above
+      issue(dd, msk, mk);  // unit u0 + D + DEPTH (always inside the padded arrays)
     });
     advance();
-  }
+  };
+  // blocks whose TARGETS [u0 + DEPTH, u0 + 2 DEPTH) lie inside the full run issue unmasked loads
+  const int r0 = max(0, min(units, full0 - DEPTH)), r1 = max(r0, min(units, full1 - DEPTH));  // (!lean: r0 = 0, r1 = units)
+  int u0 = 0;
+  for (; u0 < r0; u0 += DEPTH) block(std::true_type{}, u0);
+  for (; u0 < r1; u0 += DEPTH) block(std::false_type{}, u0);
+  for (; u0 < units; u0 += DEPTH) block(std::true_type{}, u0);
   // the trailing prefetches (padding) are never consumed: retire them before their registers are reused
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) stream_wait<0>(lx[d], ix[d]);
@@ -385,12 +448,12 @@ __device__ inline void sweep_dev(const int32_t *__restrict__ idx, const int unit
 }
 
 // t (LDS, permuted order) <- K^-1 t   (qp_solver.hpp:457-459)
-__device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, double *t, const int lane)
+__device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, double *t, const int lane, const bool lean)
 {
   const int k = pl.k;
   const bool bo = pl.idx_scale == 8;
-  if (bo) sweep_dev<SFB_SWEEP_DEPTH, true>(pl.fidx, pl.funits, w.LxF, t, lane);  // forward (column oriented order)
-  else sweep_dev<SFB_SWEEP_DEPTH, false>(pl.fidx, pl.funits, w.LxF, t, lane);
+  if (bo) sweep_dev<SFB_SWEEP_DEPTH, true>(pl.fidx, pl.funits, w.LxF, t, lane, pl.fmask, pl.ffull0, pl.ffull1, lean);  // forward (column oriented order)
+  else sweep_dev<SFB_SWEEP_DEPTH, false>(pl.fidx, pl.funits, w.LxF, t, lane, pl.fmask, pl.ffull0, pl.ffull1, lean);
   for (int j0 = lane; j0 < k; j0 += kWave * 8) {  // D^-1 (:458), loads batched
     double dv[8];
 #pragma unroll
@@ -400,8 +463,8 @@ __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, doubl
       if (j0 + e * kWave < k) t[j0 + e * kWave] = dv[e] * t[j0 + e * kWave];
   }
   wave_sync();
-  if (bo) sweep_dev<SFB_SWEEP_DEPTH, true>(pl.bidx, pl.bunits, w.LxB, t, lane);  // backward (rows pushing, descending)
-  else sweep_dev<SFB_SWEEP_DEPTH, false>(pl.bidx, pl.bunits, w.LxB, t, lane);
+  if (bo) sweep_dev<SFB_SWEEP_DEPTH, true>(pl.bidx, pl.bunits, w.LxB, t, lane, pl.bmask, pl.bfull0, pl.bfull1, lean);  // backward (rows pushing, descending)
+  else sweep_dev<SFB_SWEEP_DEPTH, false>(pl.bidx, pl.bunits, w.LxB, t, lane, pl.bmask, pl.bfull0, pl.bfull1, lean);
 }
 
 __device__ __forceinline__ double lane_max_abs(const double *v, int len, int lane)
@@ -553,7 +616,7 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
 
 // detail::polish_qp (sparse), embedded in the full pattern.  In/out: scaled xs / ys in the workspace.
 __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const Ws &w, const DenseKernelParams &kp,
-                                 double *t, const double c, const int lane)
+                                 double *t, const double c, const int lane, const bool lean)
 {
   const int n = pl.n, m = pl.m, k = pl.k;
   const double inf = INFINITY, eps = DBL_EPSILON;
@@ -591,7 +654,7 @@ __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const 
       t[pl.pinv[n + rr]] = h - acc;
     }
     wave_sync();
-    ldl_solve_dev(pl, w, t, lane);
+    ldl_solve_dev(pl, w, t, lane, lean);
     for (int e = lane; e < k; e += kWave) w.tv[e] += t[pl.pinv[e]];
     wave_sync();
   }
@@ -603,6 +666,8 @@ __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const 
 
 }  // namespace
 
+__device__ int g_sparse_active = 0;  // resident waves of qp_sparse_kernel (all launches), see the kernel
+
 __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl, const DenseKernelParams kp,
                                                        const double *__restrict__ gPx, const double *__restrict__ gq,
                                                        const double *__restrict__ gAx, const double *__restrict__ gl,
@@ -610,10 +675,18 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
                                                        const double *__restrict__ gwy, double *__restrict__ gx,
                                                        double *__restrict__ gy, double *__restrict__ gobj,
                                                        uint32_t *__restrict__ giter, int32_t *__restrict__ gcode,
-                                                       double *__restrict__ gws, const size_t ws_doubles)
+                                                       double *__restrict__ gws, const size_t ws_doubles,
+                                                       const int lean_waves)
 {
   extern __shared__ __attribute__((aligned(16))) double t[];  // k + 1 doubles: work / solution vector
   const int lane = threadIdx.x;
+  // Waves of this kernel resident on the device right now.  While there are many, the launch is HBM-bound and the
+  // sweeps skip the padding of the factor stream (masked loads: fewer bytes, a few more instructions); when only
+  // stragglers are left, latency is what counts and they switch to plain loads.  A heuristic only: both forms
+  // compute the same thing.
+  int seen = 0;
+  if (lane == 0) seen = atomicAdd(&g_sparse_active, 1);
+  bool lean = (gridDim.x > (unsigned)lean_waves) || __builtin_amdgcn_readfirstlane(seen) >= lean_waves;
   const int n = pl.n, m = pl.m, k = pl.k;
   const size_t b = blockIdx.x;
   const Item it{gPx + b * (size_t)pl.nnzP, gq + b * (size_t)n, gAx + b * (size_t)pl.nnzA, gl + b * (size_t)m,
@@ -808,7 +881,7 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
     }
     }
     wave_sync();
-    ldl_solve_dev(pl, w, t, lane);                                                              // :456-460
+    ldl_solve_dev(pl, w, t, lane, lean);                                                        // :456-460
     const bool chk = (iter == next_chk);
     if (chk) next_chk += sci;
     {
@@ -880,6 +953,8 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
     if (chk) {
       ret_code = sp_check_stopping(pl, it, w, kp, t, lane);
       wave_sync();
+      lean = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_sparse_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >
+             lean_waves;
       // Items that are still iterating after many checks are the ones the whole launch waits for:
       // raise their issue priority over the co-resident waves that are in their first iterations.
       if (iter > 600) __builtin_amdgcn_s_setprio(3);
@@ -890,7 +965,7 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
   __builtin_amdgcn_s_setprio(0);
 
   // ---- polish :515-539 ----
-  if (ret_code == SFB_QP_OPTIMAL && kp.polish) sp_polish(pl, it, w, kp, t, c, lane);
+  if (ret_code == SFB_QP_OPTIMAL && kp.polish) sp_polish(pl, it, w, kp, t, c, lane, lean);
 
   // ---- un-scale and report :544-548 ----
   double *ox = gx + b * (size_t)n, *oy = gy + b * (size_t)m;
@@ -917,6 +992,7 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
   if (lane == 0) {
     gcode[b] = (ret_code >= 0) ? ret_code : SFB_QP_MAX_ITERATIONS;
     if (giter != nullptr) giter[b] = iter;
+    atomicSub(&g_sparse_active, 1);
   }
 }
 
@@ -927,8 +1003,11 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
 {
   const size_t lds = (size_t)pl.lds_doubles * sizeof(double);
   const size_t wsd = qp_sparse_ws_doubles(pl.n, pl.m, pl.nnzL, pl.funits, pl.bunits);
+  // below this many resident waves the sweeps use plain loads (see the kernel); SFB_SP_LEAN_WAVES overrides (tuning)
+  const char *lw        = getenv("SFB_SP_LEAN_WAVES");
+  const int lean_waves  = lw ? atoi(lw) : 512;
   hipLaunchKernelGGL(qp_sparse_kernel, dim3((unsigned)batch), dim3(kWave), lds, stream, pl, kp, Px, q, Ax, l, u, wx,
-                     wy, x, y, obj, iter, code, workspace, wsd);
+                     wy, x, y, obj, iter, code, workspace, wsd, lean_waves);
   return hipGetLastError();
 }
 

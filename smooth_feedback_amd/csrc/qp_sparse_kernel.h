@@ -20,7 +20,8 @@ struct SparsePlanDev {
   const int32_t *Acp, *Aci, *Acpos, *Prp, *Prj, *Prpos, *Sp, *Sj, *Spos;
   const int32_t *perm, *pinv, *Kp, *Ki, *Kkind, *Kidx, *Lp, *Li, *Rp, *Rk, *Rpos, *Rlen;
   const int32_t *fmap, *fidx, *bmap, *bidx;  // packed sweep schedules, see sparse_plan.h
-  int funits, bunits, idx_scale;
+  const int32_t *fmask, *bmask;              // lane-mask shifts of the units' value loads (one word per unit)
+  int funits, bunits, idx_scale, ffull0, ffull1, bfull0, bfull1;
   const int32_t *Kmap, *rptr, *rtgt, *rab;   // right-looking factorisation schedule
   int rsteps, maxcol;
   const int32_t *snptr, *snR, *poff, *pmap;  // (relaxed) supernodes of the factorisation and their panel maps

@@ -357,7 +357,8 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
   // packed sweep schedules (see sparse_plan.h)
   if (k + 1 >= (1 << 16)) { *msg = "n+m too large for the packed sweep encoding (max 65534)"; return false; }
   o.idx_scale = ((k + 1) * 8 < (1 << 16)) ? 8 : 1;
-  auto build = [&](bool forward, std::vector<int32_t> &xmap, std::vector<int32_t> &xidx, int &units) {
+  auto build = [&](bool forward, std::vector<int32_t> &xmap, std::vector<int32_t> &xidx, int &units,
+                   std::vector<int32_t> &xmask, int &full0, int &full1) {
     const int cap = 128;  // slots per dependent step
     // Critical-path list scheduling.  Slot = one entry of L, enumerated in the sequential sweep order.  It
     // depends on (a) the previous update of its target (per-target order = the sequential one) and (b) the
@@ -423,6 +424,11 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
       }
     }
     const int steps = (int)slots.size();
+    if (const char *dbg = getenv("SFB_PLAN_DEBUG"); dbg && dbg[0] == '1') {  // diagnostics: fill of the sweep units
+      fprintf(stderr, "[sfb plan] %s sweep: %d units, slots per unit:", forward ? "forward" : "backward", steps);
+      for (int s = 0; s < steps; ++s) fprintf(stderr, " %d", (int)slots[s].size());
+      fprintf(stderr, "\n");
+    }
     units           = steps;
     units = ((units + SparsePlanHost::kSweepPad - 1) / SparsePlanHost::kSweepPad) * SparsePlanHost::kSweepPad;
     const size_t total = (size_t)(units + SparsePlanHost::kSweepPad) * 128;
@@ -431,16 +437,36 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
     // shifts per unit on the dependent chain of a lone wave), else as element indices
     const int sc = o.idx_scale;
     xidx.assign(total, (k * sc) | ((k * sc) << 16));
-    for (int s = 0; s < steps; ++s)
+    // lane masks of the units' VALUE loads (stored as the shift 64 - lanes): the slots of a step occupy the leading
+    // ceil(c/2) lanes, two per lane, so a unit with c slots touches only those lanes' 16 bytes -- the
+    // other lanes are masked off and their cache lines never leave HBM (their slots are padding: target = pivot =
+    // the scratch entry k, whatever value the register holds).  full0/full1: the longest run of completely filled
+    // units, cut to multiples of 8; the kernel uses unmasked loads there.
+    xmask.assign((size_t)units + 2 * SparsePlanHost::kSweepPad, 63);  // padding units: lane 0 only
+    for (int s = 0; s < steps; ++s) {
+      const int lanes = std::max(1, ((int)slots[s].size() + 1) / 2);
+      xmask[s]        = 64 - lanes;  // exec = all ones >> (64 - lanes)
       for (size_t e = 0; e < slots[s].size(); ++e) {
-        // step s -> unit s, slot e/64, lane e%64
-        const size_t q = ((size_t)s * 64 + (e & 63)) * 2 + (e >> 6);
+        // step s -> unit s, lane e % lanes, slot e / lanes: the leading `lanes` lanes carry everything, and slots
+        // that follow each other in the sweep order (neighbouring rows of one column) sit in neighbouring lanes
+        // (LDS banks); a full unit is lane e % 64, slot e / 64
+        const size_t q = ((size_t)s * 64 + (e % (size_t)lanes)) * 2 + (e / (size_t)lanes);
         xmap[q] = slots[s][e][0];
         xidx[q] = (slots[s][e][1] * sc) | ((slots[s][e][2] * sc) << 16);
       }
+    }
+    full0 = full1 = 0;
+    for (int s = 0; s < steps;) {
+      if ((int)slots[s].size() != cap) { ++s; continue; }
+      int e = s;
+      while (e < steps && (int)slots[e].size() == cap) ++e;
+      const int a = ((s + 7) / 8) * 8, b = (e / 8) * 8;
+      if (b - a > full1 - full0) { full0 = a; full1 = b; }
+      s = e;
+    }
   };
-  build(true, o.fmap, o.fidx, o.funits);
-  build(false, o.bmap, o.bidx, o.bunits);
+  build(true, o.fmap, o.fidx, o.funits, o.fmask, o.ffull0, o.ffull1);
+  build(false, o.bmap, o.bidx, o.bunits, o.bmask, o.bfull0, o.bfull1);
 
   return true;
 }

@@ -40,11 +40,13 @@ struct SparsePlanHost {
   //   xidx[q]  : (tgt | piv << 16) * idx_scale   (padding: both = k, a scratch slot of the LDS vector);
   //              idx_scale = 8 (byte offsets) when (k+1)*8 < 65536, else 1
   // Storage: unit u, lane l, slot s at [(u * 64 + l) * 2 + s] (one 16-byte value load and one 8-byte index
-  // load per lane and unit).  Unit counts are multiples of kSweepPad and the arrays carry kSweepPad extra
+  // load per lane and unit); the c slots of a step occupy the leading ceil(c/2) lanes (slot e: lane e % lanes, slot e / lanes).  Unit counts are multiples of kSweepPad and the arrays carry kSweepPad extra
   // all-padding units so the kernel prefetches branch-free.
   static constexpr int kSweepPad = 16;
-  std::vector<int32_t> fmap, fidx, bmap, bidx;
-  int funits = 0, bunits = 0, idx_scale = 1;
+  //   xmask[u] : 64 - (leading lanes of unit u's value load that carry slots);
+  //              [full0, full1) : run of completely filled units (multiples of 8), loaded unmasked
+  std::vector<int32_t> fmap, fidx, bmap, bidx, fmask, bmask;
+  int funits = 0, bunits = 0, idx_scale = 1, ffull0 = 0, ffull1 = 0, bfull0 = 0, bfull1 = 0;
   // Right-looking, supernodal factorisation schedule.  Accumulators: [L values (nnzL) | D (k) | scratch | zero];
   // Kmap[p] = accumulator of KKT entry p.  When a column j is final it updates, for every pair of its rows
   // (r_a >= r_b), the accumulator of entry (r_a, r_b) [the diagonal D(r_b) when a == b]:

@@ -12,8 +12,25 @@ from test_qp_dense_gpu import _compare, _oracle_params
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["auto", "masked", "plain"])
+def sweep_mode(request):
+    """The sparse kernel streams the factor with plain loads or, while many waves are resident, with loads masked
+    to the lanes that carry entries (no HBM traffic for the padding of the sweep schedule).  'auto' is the
+    product's choice (plain for these small batches); the other two force one form (SFB_SP_LEAN_WAVES is read at
+    every launch).  All three must agree with the oracle bit for bit."""
+    import os
+    old = os.environ.get("SFB_SP_LEAN_WAVES")
+    if request.param != "auto":
+        os.environ["SFB_SP_LEAN_WAVES"] = "-1" if request.param == "masked" else "1000000000"
+    yield request.param
+    if old is None:
+        os.environ.pop("SFB_SP_LEAN_WAVES", None)
+    else:
+        os.environ["SFB_SP_LEAN_WAVES"] = old
+
+
 @pytest.mark.parametrize("variant,K,batch", [(6, 10, 48), (6, 50, 32), (12, 50, 24)])
-def test_mpc_qp_batch_matches_oracle(sfb, oracle, variant, K, batch):
+def test_mpc_qp_batch_matches_oracle(sfb, oracle, variant, K, batch, sweep_mode):
     """BASELINE configs[2] problem (variant 12, K=50: n = m = 740) at oracle-sized batches; default
     MPCParams.qp (eps 1e-3, scaling, polish), cold start and warm start from the previous solution."""
     d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)

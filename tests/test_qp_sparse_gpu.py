@@ -11,6 +11,9 @@ from test_qp_dense_gpu import _compare, _oracle_params
 pytestmark = pytest.mark.gpu
 
 
+from test_mpc_gpu import sweep_mode  # noqa: E402,F401  (fixture: plain / masked factor stream)
+
+
 @pytest.mark.parametrize("name", sorted(KNOWN_ANSWERS))
 def test_sparse_known_answers(sfb, oracle, name):
     case = KNOWN_ANSWERS[name]
@@ -36,7 +39,7 @@ def test_sparse_known_answers(sfb, oracle, name):
 
 @pytest.mark.parametrize("n,m,density,ordering", [(10, 20, 0.3, 1), (10, 20, 1.0, 0), (6, 9, 0.5, 1), (30, 50, 0.15, 1),
                                                   (80, 120, 0.05, 1)])
-def test_random_sparse_batches(sfb, oracle, n, m, density, ordering):
+def test_random_sparse_batches(sfb, oracle, n, m, density, ordering, sweep_mode):
     B = 192
     P, q, A, l, u = sfb.random_qp_batch(13, B, m, n, density)
     rng = np.random.default_rng(n + m)
