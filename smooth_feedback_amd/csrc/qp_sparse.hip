@@ -314,11 +314,16 @@ typedef int vint2 __attribute__((ext_vector_type(2)));
 
 // OFF: byte offset folded into the instruction (13-bit signed immediate), so that the units of one prefetch
 // block share their address registers instead of paying a 64-bit add each
-template<int OFF>
+// NT (used while the launch is bandwidth-bound): the factor values are streamed once per sweep and not reused before
+// thousands of other waves' streams have passed -- they should not push the schedule (index) arrays, which every
+// wave re-reads, out of the L2.  When only a few waves are left their factors DO stay cached between iterations:
+// plain loads then.
+template<int OFF, bool NT = false>
 __device__ __forceinline__ void stream_load(vdouble2 &v, const vdouble2 *p)
 {
   static_assert(OFF >= 0 && OFF < 4096, "immediate offset of global_load");
-  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF));
+  if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(v) : "v"(p), "n"(OFF));
+  else asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF));
 }
 template<int OFF>
 __device__ __forceinline__ void stream_load(vint2 &v, const vint2 *p)
@@ -334,7 +339,7 @@ template<int OFF>
 __device__ __forceinline__ void stream_load_masked(vdouble2 &v, const vdouble2 *p, const int shift)
 {
   static_assert(OFF >= 0 && OFF < 4096, "immediate offset of global_load");
-  asm volatile("s_lshr_b64 exec, -1, %2\n\tglobal_load_dwordx4 %0, %1, off offset:%3\n\ts_mov_b64 exec, -1"
+  asm volatile("s_lshr_b64 exec, -1, %2\n\tglobal_load_dwordx4 %0, %1, off offset:%3 nt\n\ts_mov_b64 exec, -1"
                : "+v"(v)
                : "v"(p), "s"(shift), "n"(OFF)
                : "scc");  // s_lshr writes SCC
@@ -359,15 +364,11 @@ __device__ __forceinline__ void stream_wait(vdouble2 &a, vint2 &b)
 // LDS round trip per unit on the dependent chain of a lone wave).  Branch-free; DEPTH units
 // (= 2 x DEPTH slots per lane) are in flight ahead of their use so the ~1.7 us HBM latency of a lone
 // wave is covered; t has k+1 entries, t[k] is the padding slot; `units` is a multiple of kSweepPadDev.
-template<int DEPTH, bool BYTEOFF>
+template<int DEPTH, bool BYTEOFF, bool LEAN>
 __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const int units, const double *vals, double *t,
-                                 const int lane, const int32_t *__restrict__ mask32, int full0, int full1, const bool lean)
+                                 const int lane, const int32_t *__restrict__ mask32, const int full0, const int full1)
 {
   // lean == false (few waves left on the chip: latency matters, HBM traffic does not): every block issues plain loads
-  if (!lean) {
-    full0 = 0;
-    full1 = units + 2 * DEPTH;
-  }
   static_assert(DEPTH <= kSweepPadDev && kSweepPadDev % DEPTH == 0, "schedule padding must cover the prefetch distance");
   static_assert(2 * DEPTH <= 62, "vmcnt is a 6-bit counter");
   static_assert(DEPTH <= 8, "two value pointers cover 8 units of 1 KB with 12-bit offsets");
@@ -382,13 +383,15 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
   for (int d = 0; d < DEPTH; ++d) lx[d] = vdouble2{0.0, 0.0};  // masked lanes keep what the register holds
   // Value loads of partially filled units are masked to the lanes that carry slots (sparse_plan.h): the padding
   // of the schedule then costs no HBM traffic.  Units in [full0, full1) are full: plain loads, no mask fetch.
-  auto issue = [&]<int D, bool MASKED>(std::integral_constant<int, D>, std::bool_constant<MASKED>, const sint8 &mk) {
-    if constexpr (MASKED) {
+  // MODE 0: plain cached loads (latency mode); 1: non-temporal loads (full units, bandwidth mode); 2: non-temporal
+  // loads masked to the lanes that carry slots (partially filled units, bandwidth mode)
+  auto issue = [&]<int D, int MODE>(std::integral_constant<int, D>, std::integral_constant<int, MODE>, const sint8 &mk) {
+    if constexpr (MODE == 2) {
       if constexpr (D < 4) stream_load_masked<D * kWave * 16>(lx[D], vp0, mk[D]);
       else stream_load_masked<(D - 4) * kWave * 16>(lx[D], vp1, mk[D]);
     } else {
-      if constexpr (D < 4) stream_load<D * kWave * 16>(lx[D], vp0);
-      else stream_load<(D - 4) * kWave * 16>(lx[D], vp1);
+      if constexpr (D < 4) stream_load<D * kWave * 16, MODE == 1>(lx[D], vp0);
+      else stream_load<(D - 4) * kWave * 16, MODE == 1>(lx[D], vp1);
     }
     stream_load<D * kWave * 8>(ix[D], ip);
   };
@@ -405,19 +408,20 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
     mask32 = reinterpret_cast<const int32_t *>(((unsigned long long)hi << 32) | lo);
   }
-  if (lean) {
+  if constexpr (LEAN) {
     mask_fetch(mk, mask32, 0);
     mask_wait(mk);
     for_units(std::make_integer_sequence<int, DEPTH>{},
-              [&]<int D>(std::integral_constant<int, D> dd) { issue(dd, std::true_type{}, mk); });
+              [&]<int D>(std::integral_constant<int, D> dd) { issue(dd, std::integral_constant<int, 2>{}, mk); });
   } else {
     for_units(std::make_integer_sequence<int, DEPTH>{},
-              [&]<int D>(std::integral_constant<int, D> dd) { issue(dd, std::false_type{}, mk); });
+              [&]<int D>(std::integral_constant<int, D> dd) { issue(dd, std::integral_constant<int, 0>{}, mk); });
   }
   advance();
   // one block of DEPTH units: consume unit u0 + D, then issue the loads of unit u0 + D + DEPTH (their mask shifts are
   // fetched at the head of the block and awaited behind the first unit's LDS round trip)
-  auto block = [&]<bool MASKED>(std::bool_constant<MASKED> msk, const int u0) {
+  auto block = [&]<int MODE>(std::integral_constant<int, MODE> msk, const int u0) {
+    constexpr bool MASKED = MODE == 2;
     sint8 mk;
     if constexpr (MASKED) mask_fetch(mk, mask32, __builtin_amdgcn_readfirstlane((u0 + DEPTH) * 4));
     for_units(std::make_integer_sequence<int, DEPTH>{}, [&]<int D>(std::integral_constant<int, D> dd) {
@@ -436,11 +440,15 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
     advance();
   };
   // blocks whose TARGETS [u0 + DEPTH, u0 + 2 DEPTH) lie inside the full run issue unmasked loads
-  const int r0 = max(0, min(units, full0 - DEPTH)), r1 = max(r0, min(units, full1 - DEPTH));  // (!lean: r0 = 0, r1 = units)
+  const int r0 = max(0, min(units, full0 - DEPTH)), r1 = max(r0, min(units, full1 - DEPTH));
   int u0 = 0;
-  for (; u0 < r0; u0 += DEPTH) block(std::true_type{}, u0);
-  for (; u0 < r1; u0 += DEPTH) block(std::false_type{}, u0);
-  for (; u0 < units; u0 += DEPTH) block(std::true_type{}, u0);
+  if constexpr (LEAN) {
+    for (; u0 < r0; u0 += DEPTH) block(std::integral_constant<int, 2>{}, u0);
+    for (; u0 < r1; u0 += DEPTH) block(std::integral_constant<int, 1>{}, u0);
+    for (; u0 < units; u0 += DEPTH) block(std::integral_constant<int, 2>{}, u0);
+  } else {
+    for (; u0 < units; u0 += DEPTH) block(std::integral_constant<int, 0>{}, u0);
+  }
   // the trailing prefetches (padding) are never consumed: retire them before their registers are reused
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) stream_wait<0>(lx[d], ix[d]);
@@ -452,8 +460,16 @@ __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, doubl
 {
   const int k = pl.k;
   const bool bo = pl.idx_scale == 8;
-  if (bo) sweep_dev<SFB_SWEEP_DEPTH, true>(pl.fidx, pl.funits, w.LxF, t, lane, pl.fmask, pl.ffull0, pl.ffull1, lean);  // forward (column oriented order)
-  else sweep_dev<SFB_SWEEP_DEPTH, false>(pl.fidx, pl.funits, w.LxF, t, lane, pl.fmask, pl.ffull0, pl.ffull1, lean);
+  auto sweep = [&](const int32_t *idx, const int units, const double *vals, const int32_t *mask, const int f0, const int f1) {
+    if (lean) {
+      if (bo) sweep_dev<SFB_SWEEP_DEPTH, true, true>(idx, units, vals, t, lane, mask, f0, f1);
+      else sweep_dev<SFB_SWEEP_DEPTH, false, true>(idx, units, vals, t, lane, mask, f0, f1);
+    } else {
+      if (bo) sweep_dev<SFB_SWEEP_DEPTH, true, false>(idx, units, vals, t, lane, mask, f0, f1);
+      else sweep_dev<SFB_SWEEP_DEPTH, false, false>(idx, units, vals, t, lane, mask, f0, f1);
+    }
+  };
+  sweep(pl.fidx, pl.funits, w.LxF, pl.fmask, pl.ffull0, pl.ffull1);  // forward (column oriented order)
   for (int j0 = lane; j0 < k; j0 += kWave * 8) {  // D^-1 (:458), loads batched
     double dv[8];
 #pragma unroll
@@ -463,8 +479,7 @@ __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, doubl
       if (j0 + e * kWave < k) t[j0 + e * kWave] = dv[e] * t[j0 + e * kWave];
   }
   wave_sync();
-  if (bo) sweep_dev<SFB_SWEEP_DEPTH, true>(pl.bidx, pl.bunits, w.LxB, t, lane, pl.bmask, pl.bfull0, pl.bfull1, lean);  // backward (rows pushing, descending)
-  else sweep_dev<SFB_SWEEP_DEPTH, false>(pl.bidx, pl.bunits, w.LxB, t, lane, pl.bmask, pl.bfull0, pl.bfull1, lean);
+  sweep(pl.bidx, pl.bunits, w.LxB, pl.bmask, pl.bfull0, pl.bfull1);  // backward (rows pushing, descending)
 }
 
 __device__ __forceinline__ double lane_max_abs(const double *v, int len, int lane)
