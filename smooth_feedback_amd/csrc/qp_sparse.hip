@@ -287,7 +287,7 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
 #pragma unroll
       for (int dd = 0; dd < DEPTH; ++dd) v[dd] = ACC[src[dd] >= 0 ? src[dd] : nnzL + k + 1];
 #pragma unroll
-      for (int dd = 0; dd < DEPTH; ++dd) dst[q0 + dd * kWave] = v[dd];
+      for (int dd = 0; dd < DEPTH; ++dd) __builtin_nontemporal_store(v[dd], &dst[q0 + dd * kWave]);  // read again only by the sweeps
     }
   };
   static_assert(kSweepPadDev * 2 >= DEPTH, "copy loop assumes whole blocks");
@@ -856,12 +856,16 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
   const uint32_t sci   = kp.stop_check_iter;
   const uint32_t maxit = kp.max_iter;
   uint32_t next_chk    = (sci >= 2) ? 1u : 0xFFFFFFFFu;
+  bool need_rhs        = true;
   for (; iter != maxit && ret_code < 0; ++iter) {
     // element-wise phases: the loads of UNR strided elements are issued together (one memory round
     // trip per UNR elements instead of one per element -- matters for a wave that runs alone)
     // (the batch sizes are what the 168-VGPR budget of three waves per SIMD allows)
     constexpr int UNR_A = 8, UNR_B = 4;
-    {
+    // The right-hand side of the NEXT solve is written by the update phase below from the values it has just
+    // computed (same expressions, no re-read of x, z, y, 1/rho); only the first iteration and the one after a
+    // stopping check (which uses t as scratch) build it here.
+    if (need_rhs) {
     constexpr int UNR = UNR_A;
     for (int j0 = lane; j0 < n; j0 += kWave * UNR) {  // :450
       double xv[UNR], qv[UNR];
@@ -899,16 +903,18 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
     ldl_solve_dev(pl, w, t, lane, lean);                                                        // :456-460
     const bool chk = (iter == next_chk);
     if (chk) next_chk += sci;
+    need_rhs = chk;
     {
     constexpr int UNR = UNR_A;
     for (int j0 = lane; j0 < n; j0 += kWave * UNR) {  // :470
-      double xo[UNR], sxj[UNR];
+      double xo[UNR], sxj[UNR], qv[UNR];
       int pv[UNR];
 #pragma unroll
       for (int e = 0; e < UNR; ++e) {
         const int j = j0 + e * kWave;
         const bool on = j < n;
         xo[e]  = on ? w.xs[j] : 0.0;
+        qv[e]  = on ? w.qc[j] : 0.0;
         pv[e]  = on ? pl.pinv[j] : k;
         sxj[e] = (on && chk) ? w.sx[j] : 0.0;
       }
@@ -917,7 +923,8 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
         const int j = j0 + e * kWave;
         if (j < n) {
           const double xn = kp.alpha * t[pv[e]] + kp.alpha_comp * xo[e];
-          w.xs[j] = xn;
+          w.xs[j]  = xn;
+          t[pv[e]] = kp.sigma * xn - qv[e];  // rhs of the next solve (:450)
           if (chk) {
             w.xus[j]  = sxj[e] * xn;
             w.dxus[j] = sxj[e] * (xn - xo[e]);
@@ -953,8 +960,9 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
           zn = (zn < lo[e]) ? lo[e] : zn;
           zn = (hi[e] < zn) ? hi[e] : zn;
           const double yn = kp.alpha_comp * yo[e] + kp.alpha * nu + rh[e] * zo[e] - rh[e] * zn;
-          w.ys[i] = yn;
-          w.zs[i] = zn;
+          w.ys[i]  = yn;
+          w.zs[i]  = zn;
+          t[pv[e]] = zn - ri[e] * yn;  // rhs of the next solve (:451)
           if (chk) {
             w.yus[i]  = syi[e] * yn / c;
             w.zus[i]  = (1.0 / syi[e]) * zn;
