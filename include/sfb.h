@@ -171,6 +171,15 @@ sfb_status sfb_sparse_qp_solve_batch(sfb_sparse_qp_plan *plan, const sfb_qp_para
                                      const double *u, const double *warm_x, const double *warm_y, double *x,
                                      double *y, double *obj, uint32_t *iter, int32_t *code, void *workspace,
                                      void *stream);
+/* Same with a launch order: order[batch] (device, nullable) is a permutation of 0..batch-1, launch position -> item.
+ * The results do not depend on it.  A caller that can predict the iteration counts (an MPC swarm: those of the
+ * previous tick) puts the longest-running items first, so that they run alongside the bulk of the batch instead of
+ * finishing alone at the end of the launch. */
+sfb_status sfb_sparse_qp_solve_batch_ordered(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
+                                             const double *Px, const double *q, const double *Ax, const double *l,
+                                             const double *u, const double *warm_x, const double *warm_y, double *x,
+                                             double *y, double *obj, uint32_t *iter, int32_t *code, void *workspace,
+                                             const int32_t *order, void *stream);
 /* Same with host pointers (synchronous).  The device buffers are owned by the plan and kept between calls
  * (grow-only, freed by sfb_sparse_qp_plan_destroy) -- the analogue of the working memory a QPSolver object
  * keeps between solves (qp_solver.hpp:242-338); host-pointer calls on ONE plan are serialised. */
@@ -236,6 +245,8 @@ sfb_status sfb_mpc_assemble_batch(const sfb_mpc_layout *layout, int64_t batch, c
  * ticks: set by the constructor, mpc.hpp:423), the warm start each agent keeps between calls (mpc.hpp:509-516) and all solver
  * memory stay in HBM.  One tick = upload the records, assemble, solve, store the warm starts, download the
  * small outputs.  Replaces the loop `for each agent: u = mpc(t, x)` (MPC::operator(), mpc.hpp:458-519).
+ * Warm-started ticks launch the agents in descending order of their previous tick's iteration count
+ * (sfb_sparse_qp_solve_batch_ordered).
  *   plan: pattern of the transcription's QP (its A pattern is checked against the layout); must outlive the swarm.
  *   Px [nnzP], q [n]: host, shared by all agents.
  */

@@ -1,6 +1,7 @@
 // C-ABI of the device-side MPC assembly and of the device-resident swarm (include/sfb.h).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -120,7 +121,10 @@ struct sfb_mpc_swarm {
   double *Px = nullptr, *q = nullptr, *Ax = nullptr, *l = nullptr, *u = nullptr, *x = nullptr, *y = nullptr, *wx = nullptr,
          *wy = nullptr, *rec = nullptr, *shared = nullptr, *du0 = nullptr, *ws = nullptr;
   uint32_t *iter = nullptr;
-  int32_t *code = nullptr;
+  int32_t *code = nullptr, *order = nullptr;
+  std::vector<uint32_t> h_iter;   // iteration counts of the last tick (host), for the launch order of the next
+  std::vector<int32_t> h_order;
+  bool have_order = false;
   std::mutex mu;
 };
 
@@ -218,7 +222,7 @@ sfb_status sfb_mpc_swarm_create(sfb_sparse_qp_plan *plan, const sfb_mpc_layout *
   const size_t B = (size_t)agents, N = (size_t)n, M = (size_t)p.m;
   const size_t doubles = B * ((size_t)h.nnzP + N + (size_t)p.nnzA + 2 * M + 2 * (N + M) + (size_t)p.rec_doubles + (size_t)layout->nu + S->wsd) +
                          (size_t)S->shared_doubles + (size_t)h.nnzP + N;
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&S->mem), doubles * sizeof(double) + B * 8);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&S->mem), doubles * sizeof(double) + B * 12);
   if (e != hipSuccess) {
     delete S;
     return sfb::hip_fail(e, "hipMalloc(swarm)");
@@ -239,7 +243,10 @@ sfb_status sfb_mpc_swarm_create(sfb_sparse_qp_plan *plan, const sfb_mpc_layout *
   double *stage = d; d += h.nnzP + N;  // one copy of Px and q, replicated below
   S->ws = d; d += B * S->wsd;
   S->iter = reinterpret_cast<uint32_t *>(d);
-  S->code = reinterpret_cast<int32_t *>(S->iter + B);
+  S->code  = reinterpret_cast<int32_t *>(S->iter + B);
+  S->order = S->code + B;
+  S->h_iter.assign(B, 0);
+  S->h_order.resize(B);
   do {
     if (h.nnzP > 0 && (e = hipMemcpy(stage, Px, (size_t)h.nnzP * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
     if ((e = hipMemcpy(stage + h.nnzP, q, N * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
@@ -271,6 +278,7 @@ sfb_status sfb_mpc_swarm_reset_warmstart(sfb_mpc_swarm *S)
   // an all-zero warm start IS the cold start of qp_solver.hpp:436-445 (x = y = 0 and z = A x = 0)
   hipError_t e = hipMemset(S->wx, 0, (size_t)S->agents * ((size_t)S->n + S->m) * 8);
   if (e != hipSuccess) return sfb::hip_fail(e, "hipMemset");
+  S->have_order = false;
   return SFB_OK;
 }
 
@@ -302,14 +310,27 @@ sfb_status sfb_mpc_swarm_step_host(sfb_mpc_swarm *S, const sfb_qp_params *prm, c
     lap("H2D");
     if ((e = sfb::mpc_assemble_launch(p, S->agents, S->rec, shared_jac ? S->shared : nullptr, S->Ax, S->l, S->u, nullptr)) != hipSuccess) break;
     lap("assemble");
-    st = sfb_sparse_qp_solve_batch(S->plan, prm, S->agents, S->Px, S->q, S->Ax, S->l, S->u, warmstart ? S->wx : nullptr,
-                                   warmstart ? S->wy : nullptr, S->x, S->y, nullptr, S->iter, S->code, S->ws, nullptr);
+    // Warm-started ticks: the agents that iterated longest in the previous tick are launched first (their counts
+    // change little from tick to tick), so the stragglers overlap with the bulk of the batch.
+    static const bool no_order = [] { const char *v = getenv("SFB_MPC_NO_ORDER"); return v && v[0] == '1'; }();  // A/B knob
+    const bool ordered = warmstart && S->have_order && !no_order;
+    if (ordered && (e = hipMemcpy(S->order, S->h_order.data(), B * 4, hipMemcpyHostToDevice)) != hipSuccess) break;
+    st = sfb_sparse_qp_solve_batch_ordered(S->plan, prm, S->agents, S->Px, S->q, S->Ax, S->l, S->u,
+                                           warmstart ? S->wx : nullptr, warmstart ? S->wy : nullptr, S->x, S->y, nullptr,
+                                           S->iter, S->code, S->ws, ordered ? S->order : nullptr, nullptr);
     if (st != SFB_OK) break;
     lap("solve");
     if ((e = sfb::mpc_store_launch(S->agents, S->n, S->m, S->uoff, S->nu, warmstart != 0, S->x, S->y, S->code, S->wx, S->wy,
                                    S->du0, nullptr)) != hipSuccess) break;
     if ((e = hipMemcpy(du0, S->du0, B * (size_t)S->nu * 8, hipMemcpyDeviceToHost)) != hipSuccess) break;
-    if (iter && (e = hipMemcpy(iter, S->iter, B * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
+    if ((e = hipMemcpy(S->h_iter.data(), S->iter, B * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
+    if (iter) std::memcpy(iter, S->h_iter.data(), B * 4);
+    {
+      for (size_t b = 0; b < B; ++b) S->h_order[b] = (int32_t)b;
+      std::stable_sort(S->h_order.begin(), S->h_order.end(),
+                       [&](int32_t a, int32_t c) { return S->h_iter[a] > S->h_iter[c]; });
+      S->have_order = true;
+    }
     if ((e = hipMemcpy(code, S->code, B * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
     if (primal && (e = hipMemcpy(primal, S->x, B * (size_t)S->n * 8, hipMemcpyDeviceToHost)) != hipSuccess) break;
     if (dual && (e = hipMemcpy(dual, S->y, B * (size_t)S->m * 8, hipMemcpyDeviceToHost)) != hipSuccess) break;

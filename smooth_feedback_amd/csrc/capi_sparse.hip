@@ -158,11 +158,11 @@ sfb_status sfb_sparse_qp_plan_get_perm(const sfb_sparse_qp_plan *plan, int32_t *
   return SFB_OK;
 }
 
-sfb_status sfb_sparse_qp_solve_batch(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
+sfb_status sfb_sparse_qp_solve_batch_ordered(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
                                      const double *Px, const double *q, const double *Ax, const double *l,
                                      const double *u, const double *warm_x, const double *warm_y, double *x,
                                      double *y, double *obj, uint32_t *iter, int32_t *code, void *workspace,
-                                     void *stream)
+                                             const int32_t *order, void *stream)
 {
   sfb_status st = check_sparse_args(plan, prm, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, code);
   if (st != SFB_OK) return st;
@@ -175,9 +175,19 @@ sfb_status sfb_sparse_qp_solve_batch(sfb_sparse_qp_plan *plan, const sfb_qp_para
   if (st != SFB_OK) return st;
   const sfb::DenseKernelParams kp = sfb::make_kernel_params(prm, plan->host.n, plan->host.m);
   hipError_t e = sfb::qp_sparse_launch(*dev, kp, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code,
-                                       static_cast<double *>(workspace), static_cast<hipStream_t>(stream));
+                                       static_cast<double *>(workspace), static_cast<hipStream_t>(stream), order);
   if (e != hipSuccess) return sfb::hip_fail(e, "qp_sparse_kernel launch");
   return SFB_OK;
+}
+
+sfb_status sfb_sparse_qp_solve_batch(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
+                                     const double *Px, const double *q, const double *Ax, const double *l,
+                                     const double *u, const double *warm_x, const double *warm_y, double *x,
+                                     double *y, double *obj, uint32_t *iter, int32_t *code, void *workspace,
+                                     void *stream)
+{
+  return sfb_sparse_qp_solve_batch_ordered(plan, prm, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code,
+                                           workspace, nullptr, stream);
 }
 
 sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,

@@ -691,7 +691,7 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
                                                        double *__restrict__ gy, double *__restrict__ gobj,
                                                        uint32_t *__restrict__ giter, int32_t *__restrict__ gcode,
                                                        double *__restrict__ gws, const size_t ws_doubles,
-                                                       const int lean_waves)
+                                                       const int lean_waves, const int32_t *__restrict__ order)
 {
   extern __shared__ __attribute__((aligned(16))) double t[];  // k + 1 doubles: work / solution vector
   const int lane = threadIdx.x;
@@ -703,10 +703,12 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
   if (lane == 0) seen = atomicAdd(&g_sparse_active, 1);
   bool lean = (gridDim.x > (unsigned)lean_waves) || __builtin_amdgcn_readfirstlane(seen) >= lean_waves;
   const int n = pl.n, m = pl.m, k = pl.k;
-  const size_t b = blockIdx.x;
+  // launch position -> item: with `order` the caller puts the items it expects to iterate longest first, so that
+  // they run alongside the bulk of the batch instead of finishing alone (the workspace stays per launch position)
+  const size_t b = order ? (size_t)order[blockIdx.x] : (size_t)blockIdx.x;
   const Item it{gPx + b * (size_t)pl.nnzP, gq + b * (size_t)n, gAx + b * (size_t)pl.nnzA, gl + b * (size_t)m,
                 gu + b * (size_t)m};
-  const Ws w = carve_ws(gws + b * ws_doubles, n, m, pl.nnzL, pl.funits, pl.bunits);
+  const Ws w = carve_ws(gws + (size_t)blockIdx.x * ws_doubles, n, m, pl.nnzL, pl.funits, pl.bunits);
   if (lane == 0) t[k] = 0.0;  // padding slot of the packed sweeps
   const double inf = INFINITY;
 
@@ -1022,7 +1024,7 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
 hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp, int64_t batch, const double *Px,
                             const double *q, const double *Ax, const double *l, const double *u, const double *wx,
                             const double *wy, double *x, double *y, double *obj, uint32_t *iter, int32_t *code,
-                            double *workspace, hipStream_t stream)
+                            double *workspace, hipStream_t stream, const int32_t *order)
 {
   const size_t lds = (size_t)pl.lds_doubles * sizeof(double);
   const size_t wsd = qp_sparse_ws_doubles(pl.n, pl.m, pl.nnzL, pl.funits, pl.bunits);
@@ -1030,7 +1032,7 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
   const char *lw        = getenv("SFB_SP_LEAN_WAVES");
   const int lean_waves  = lw ? atoi(lw) : 512;
   hipLaunchKernelGGL(qp_sparse_kernel, dim3((unsigned)batch), dim3(kWave), lds, stream, pl, kp, Px, q, Ax, l, u, wx,
-                     wy, x, y, obj, iter, code, workspace, wsd, lean_waves);
+                     wy, x, y, obj, iter, code, workspace, wsd, lean_waves, order);
   return hipGetLastError();
 }
 

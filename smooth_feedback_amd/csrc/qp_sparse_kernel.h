@@ -41,6 +41,6 @@ inline size_t qp_sparse_ws_doubles(int n, int m, int nnzL, int funits, int bunit
 hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp, int64_t batch, const double *Px,
                             const double *q, const double *Ax, const double *l, const double *u, const double *wx,
                             const double *wy, double *x, double *y, double *obj, uint32_t *iter, int32_t *code,
-                            double *workspace, hipStream_t stream);
+                            double *workspace, hipStream_t stream, const int32_t *order = nullptr);
 
 }  // namespace sfb

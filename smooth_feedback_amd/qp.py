@@ -283,12 +283,13 @@ class SparseQPPlan:
         return QPBatchSolution(code=code, iter=it, primal=x, dual=y, objective=obj)
 
     def solve_batch_device(self, B, dPx, dq, dAx, dl, du, dx, dy, dobj, diter, dcode, dworkspace, prm=None,
-                           dwarm_x=0, dwarm_y=0, stream=0):
-        """sfb_sparse_qp_solve_batch on device pointers (ints); asynchronous on `stream`."""
+                           dwarm_x=0, dwarm_y=0, stream=0, dorder=0):
+        """sfb_sparse_qp_solve_batch[_ordered] on device pointers (ints); asynchronous on `stream`.
+        dorder: int32 permutation (launch position -> item), 0 = natural order."""
         cp = (prm or QPSolverParams()).to_c()
-        _capi.check(_capi.lib.sfb_sparse_qp_solve_batch(
+        _capi.check(_capi.lib.sfb_sparse_qp_solve_batch_ordered(
             self._h, C.byref(cp), B, dPx, dq, dAx, dl, du, dwarm_x or None, dwarm_y or None, dx, dy,
-            dobj or None, diter or None, dcode, dworkspace, stream or None))
+            dobj or None, diter or None, dcode, dworkspace, dorder or None, stream or None))
 
 
 def solve_qp_sparse(pbm: QuadraticProgramSparse, prm: Optional[QPSolverParams] = None,

@@ -85,3 +85,34 @@ def test_mpc_swarm_tick(sfb):
     assert rc == 0
     assert (codes == 0).all()
     assert np.all(np.abs(u0) <= 0.5 + 1e-6)
+
+
+def test_launch_order_does_not_change_results(sfb):
+    """sfb_sparse_qp_solve_batch_ordered: any permutation of the launch order gives the same solutions, bit for bit
+    (the MPC swarm launches last tick's long-running agents first)."""
+    import torch
+    variant, K, B = 6, 30, 200
+    d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
+    Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=5)
+    plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K))
+    prm = sfb.QPSolverParams(max_iter=4000)
+    dev = torch.device("cuda:0")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    dPx, dq, dAx, dl, du = T(np.tile(Pv, (B, 1))), T(np.zeros((B, d["n"]))), T(Av), T(l), T(u)
+    ws = torch.empty(B * plan.workspace_bytes_per_item // 8, dtype=torch.float64, device=dev)
+    out = []
+    rng = np.random.default_rng(0)
+    for order in (None, np.arange(B, dtype=np.int32)[::-1].copy(), rng.permutation(B).astype(np.int32)):
+        x = torch.full((B, d["n"]), np.nan, dtype=torch.float64, device=dev)
+        y = torch.full((B, d["m"]), np.nan, dtype=torch.float64, device=dev)
+        it = torch.zeros(B, dtype=torch.int32, device=dev); code = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        dord = T(order) if order is not None else None
+        plan.solve_batch_device(B, dPx.data_ptr(), dq.data_ptr(), dAx.data_ptr(), dl.data_ptr(), du.data_ptr(), x.data_ptr(),
+                                y.data_ptr(), 0, it.data_ptr(), code.data_ptr(), ws.data_ptr(), prm,
+                                stream=torch.cuda.current_stream().cuda_stream, dorder=dord.data_ptr() if dord is not None else 0)
+        torch.cuda.synchronize()
+        out.append((x.cpu().numpy(), y.cpu().numpy(), it.cpu().numpy(), code.cpu().numpy()))
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
+            assert np.array_equal(a, b)
+    assert (out[0][3] == 0).all()
