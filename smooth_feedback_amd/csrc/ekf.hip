@@ -23,6 +23,8 @@ namespace sfb {
 
 namespace {
 
+typedef double vd2 __attribute__((ext_vector_type(2)));
+
 // ---- coalesced tile I/O: 64 items x W doubles, contiguous in HBM, one item per lane in LDS ----
 template<int W>
 __device__ __forceinline__ void tile_load(const double *__restrict__ g, int64_t item0, int64_t nitems, double *lds,
@@ -34,12 +36,13 @@ __device__ __forceinline__ void tile_load(const double *__restrict__ g, int64_t 
   // all global loads first (independent, one wait), then the LDS scatter
   if constexpr (W % 2 == 0) {
     constexpr int W2 = W / 2;  // 16-byte loads; a pair never straddles two items
-    const double2 *src2 = reinterpret_cast<const double2 *>(src);
-    double2 v[W2];
+    // (non-temporal: every byte of the batch is touched exactly once per launch)
+    const vd2 *src2 = reinterpret_cast<const vd2 *>(src);
+    vd2 v[W2];
 #pragma unroll
     for (int c = 0; c < W2; ++c) {
       const int idx = c * kWave + lane;
-      v[c]          = (2 * idx < total) ? src2[idx] : double2{0.0, 0.0};
+      v[c]          = (2 * idx < total) ? __builtin_nontemporal_load(&src2[idx]) : vd2{0.0, 0.0};
     }
 #pragma unroll
     for (int c = 0; c < W2; ++c) {
@@ -53,7 +56,7 @@ __device__ __forceinline__ void tile_load(const double *__restrict__ g, int64_t 
 #pragma unroll
     for (int c = 0; c < W; ++c) {
       const int idx = c * kWave + lane;
-      v[c]          = (idx < total) ? src[idx] : 0.0;
+      v[c]          = (idx < total) ? __builtin_nontemporal_load(&src[idx]) : 0.0;
     }
 #pragma unroll
     for (int c = 0; c < W; ++c) {
@@ -71,19 +74,19 @@ __device__ __forceinline__ void tile_store(double *__restrict__ g, int64_t item0
   double *dst      = g + item0 * W;
   if constexpr (W % 2 == 0) {
     constexpr int W2 = W / 2;
-    double2 *dst2    = reinterpret_cast<double2 *>(dst);
+    vd2 *dst2        = reinterpret_cast<vd2 *>(dst);
 #pragma unroll
     for (int c = 0; c < W2; ++c) {
       const int i2  = c * kWave + lane;
       const int idx = 2 * i2;
       const int o   = (idx / W) * WP + (idx % W);
-      if (idx < total) dst2[i2] = double2{lds[o], lds[o + 1]};
+      if (idx < total) __builtin_nontemporal_store(vd2{lds[o], lds[o + 1]}, &dst2[i2]);
     }
   } else {
 #pragma unroll
     for (int c = 0; c < W; ++c) {
       const int idx = c * kWave + lane;
-      if (idx < total) dst[idx] = lds[(idx / W) * WP + (idx % W)];
+      if (idx < total) __builtin_nontemporal_store(lds[(idx / W) * WP + (idx % W)], &dst[idx]);
     }
   }
 }
