@@ -49,7 +49,7 @@ sfb_status plan_on_device(sfb_sparse_qp_plan *plan, const sfb::SparsePlanDev **o
   const sfb::SparsePlanHost &h = plan->host;
   const std::vector<int32_t> *arrs[] = {&h.Pp, &h.Pi, &h.Pcol, &h.Ap, &h.Aj, &h.Arow, &h.Acp, &h.Aci, &h.Acpos,
                                         &h.Prp, &h.Prj, &h.Prpos, &h.Sp, &h.Sj, &h.Spos, &h.perm, &h.pinv,
-                                        &h.Kp, &h.Ki, &h.Kkind, &h.Kidx, &h.Lp, &h.Li, &h.Rp, &h.Rk, &h.Rpos, &h.Rlen,
+                                        &h.Kp, &h.Ki, &h.Kdesc, &h.Lp, &h.Li, &h.Rp, &h.Rk, &h.Rpos, &h.Rlen,
                                         &h.fmap, &h.fidx, &h.bmap, &h.bidx, &h.Kmap, &h.rptr, &h.rtgt, &h.rab, &h.snptr, &h.snR, &h.poff, &h.pmap, &h.fmask, &h.bmask};
   constexpr int NA = sizeof(arrs) / sizeof(arrs[0]);
   size_t off[NA + 1];
@@ -69,7 +69,7 @@ sfb_status plan_on_device(sfb_sparse_qp_plan *plan, const sfb::SparsePlanDev **o
   d.n = h.n; d.m = h.m; d.k = h.k; d.nnzP = h.nnzP; d.nnzA = h.nnzA; d.nnzK = h.nnzK; d.nnzL = h.nnzL;
   const int32_t **ptrs[] = {&d.Pp, &d.Pi, &d.Pcol, &d.Ap, &d.Aj, &d.Arow, &d.Acp, &d.Aci, &d.Acpos,
                             &d.Prp, &d.Prj, &d.Prpos, &d.Sp, &d.Sj, &d.Spos, &d.perm, &d.pinv,
-                            &d.Kp, &d.Ki, &d.Kkind, &d.Kidx, &d.Lp, &d.Li, &d.Rp, &d.Rk, &d.Rpos, &d.Rlen,
+                            &d.Kp, &d.Ki, &d.Kdesc, &d.Lp, &d.Li, &d.Rp, &d.Rk, &d.Rpos, &d.Rlen,
                             &d.fmap, &d.fidx, &d.bmap, &d.bidx, &d.Kmap, &d.rptr, &d.rtgt, &d.rab, &d.snptr, &d.snR, &d.poff, &d.pmap, &d.fmask, &d.bmask};
   d.funits = h.funits; d.bunits = h.bunits; d.ffull0 = h.ffull0; d.ffull1 = h.ffull1; d.bfull0 = h.bfull0; d.bfull1 = h.bfull1; d.idx_scale = h.idx_scale; d.rsteps = h.rsteps; d.maxcol = h.maxcol; d.nsn = h.nsn; d.lds_doubles = h.lds_doubles;
   for (int a = 0; a < NA; ++a) *ptrs[a] = dc.blob + off[a];

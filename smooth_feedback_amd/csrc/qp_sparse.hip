@@ -67,28 +67,55 @@ struct Item {
   const double *Px, *q, *Ax, *l, *u;
 };
 
-// value of KKT entry p of the permuted lower pattern.  mode 0: ADMM matrix (qp_solver.hpp:382-395);
-// mode 1: polish matrix H + diag(delta, -delta), inactive rows zeroed (:143-171).
-__device__ __forceinline__ double kkt_value(const SparsePlanDev &pl, const Item &it, const Ws &w, const int p,
-                                            const int mode, const double c, const double sigma, const double delta)
+// KKT fill: every entry p of the permuted lower pattern goes to its accumulator.  mode 0: ADMM matrix
+// (qp_solver.hpp:382-395); mode 1: polish matrix H + diag(delta, -delta), inactive rows zeroed (:143-171).
+// Batched: the descriptors {kind, idx, row, col} of U entries per lane are fetched together, then everything they
+// point to (scaling factors, the P / A / rho value), then the values are formed and stored -- two memory round
+// trips per U entries instead of four per entry.  The arrays are padded (constant entries that land in the scratch
+// accumulator), so the batches are branch-free.
+typedef int vint4k __attribute__((ext_vector_type(4)));
+template<int U>
+__device__ __forceinline__ void kkt_fill(const SparsePlanDev &pl, const Item &it, const Ws &w, double *ACC, const int mode,
+                                         const double c, const double sigma, const double delta, const int lane)
 {
-  const int kind = pl.Kkind[p], idx = pl.Kidx[p];
-  double v;
-  if (kind == K_P) {
-    const int r = pl.Pi[idx], cc = pl.Pcol[idx];
-    if (mode == 0) v = c * w.sx[r] * w.sx[cc] * it.Px[idx];  // :385
-    else v = c * w.sx[cc] * w.sx[r] * it.Px[idx];            // :145
-    if (r == cc) v += (mode == 0) ? sigma : delta;           // :389 / :170
-  } else if (kind == K_A) {
-    const int r = pl.Arow[idx], cc = pl.Aj[idx];
-    v = w.sy[r] * w.sx[cc] * it.Ax[idx];  // :392 / :154
-    if (mode != 0 && w.act[r] == 0.0) v = 0.0;
-  } else if (kind == K_SIGMA) {
-    v = (mode == 0) ? sigma : 0.0 + delta;
-  } else {
-    v = (mode == 0) ? (-1.0 / w.rho[idx]) : 0.0 - delta;  // :395 / :171
+  const vint4k *desc = reinterpret_cast<const vint4k *>(pl.Kdesc);
+  for (int p0 = lane; p0 < pl.nnzK; p0 += kWave * U) {
+    vint4k d[U];
+    int mp[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      d[u]  = desc[p0 + u * kWave];
+      mp[u] = pl.Kmap[p0 + u * kWave];
+    }
+    double s1[U], s2[U], val[U], ac[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kind = d[u].x, idx = d[u].y, r = d[u].z, cc = d[u].w;
+      const bool isP = kind == K_P, isA = kind == K_A;
+      s1[u]  = (isP || isA) ? (isP ? w.sx : w.sy)[r] : 0.0;
+      s2[u]  = (isP || isA) ? w.sx[cc] : 0.0;
+      val[u] = isP ? it.Px[idx] : (isA ? it.Ax[idx] : (kind == K_RHO ? w.rho[idx] : 0.0));
+      ac[u]  = (isA && mode != 0) ? w.act[r] : 1.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kind = d[u].x, r = d[u].z, cc = d[u].w;
+      double v;
+      if (kind == K_P) {
+        if (mode == 0) v = c * s1[u] * s2[u] * val[u];  // :385   c sx[r] sx[c] P
+        else v = c * s2[u] * s1[u] * val[u];            // :145   c sx[c] sx[r] P
+        if (r == cc) v += (mode == 0) ? sigma : delta;  // :389 / :170
+      } else if (kind == K_A) {
+        v = s1[u] * s2[u] * val[u];  // :392 / :154   sy[r] sx[c] A
+        if (ac[u] == 0.0) v = 0.0;
+      } else if (kind == K_SIGMA) {
+        v = (mode == 0) ? sigma : 0.0 + delta;
+      } else {
+        v = (mode == 0) ? (-1.0 / val[u]) : 0.0 - delta;  // :395 / :171
+      }
+      ACC[mp[u]] = v;
+    }
   }
-  return v;
 }
 
 // One block of DEPTH trailing accumulators per lane: v = fma(-L(a, j), L(b, j) D(j), v) over the columns j of the
@@ -150,7 +177,7 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
   double *ACC = w.Lx;  // [0, nnzL): L entries, [nnzL, nnzL+k): D, [nnzL+k]: scratch, [nnzL+k+1]: always zero
   for (int p = lane; p < nnzL + k + 2; p += kWave) ACC[p] = 0.0;
   wave_sync();
-  for (int p = lane; p < pl.nnzK; p += kWave) ACC[pl.Kmap[p]] = kkt_value(pl, it, w, p, mode, c, sigma, delta);
+  kkt_fill<4>(pl, it, w, ACC, mode, c, sigma, delta, lane);
   wave_sync();
   SFB_LAP(0)
   for (int sn = 0; sn < pl.nsn; ++sn) {

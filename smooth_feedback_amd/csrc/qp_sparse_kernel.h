@@ -18,7 +18,7 @@ struct SparsePlanDev {
   int n, m, k, nnzP, nnzA, nnzK, nnzL;
   const int32_t *Pp, *Pi, *Pcol, *Ap, *Aj, *Arow;
   const int32_t *Acp, *Aci, *Acpos, *Prp, *Prj, *Prpos, *Sp, *Sj, *Spos;
-  const int32_t *perm, *pinv, *Kp, *Ki, *Kkind, *Kidx, *Lp, *Li, *Rp, *Rk, *Rpos, *Rlen;
+  const int32_t *perm, *pinv, *Kp, *Ki, *Kdesc, *Lp, *Li, *Rp, *Rk, *Rpos, *Rlen;
   const int32_t *fmap, *fidx, *bmap, *bidx;  // packed sweep schedules, see sparse_plan.h
   const int32_t *fmask, *bmask;              // lane-mask shifts of the units' value loads (one word per unit)
   int funits, bunits, idx_scale, ffull0, ffull1, bfull0, bfull1;

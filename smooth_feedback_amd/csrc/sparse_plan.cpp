@@ -256,6 +256,18 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
         o.Kmap[p]   = (i == j) ? o.nnzL + j : pos_in_col(j, i);
         if (o.Kmap[p] < 0) { *msg = "internal: KKT entry outside the pattern of L"; return false; }
       }
+    // descriptor of every KKT entry for the kernel's batched fill: {kind, idx, r, c} with the row / column of the
+    // source entry resolved here (pattern only), + the accumulator it goes to; padded for branch-free batches
+    o.Kdesc.assign((size_t)(o.nnzK + 64 * 8) * 4, 0);
+    for (int p = 0; p < o.nnzK; ++p) {
+      const int kind = o.Kkind[p], idx = o.Kidx[p];
+      int r = 0, c = 0;
+      if (kind == K_P) { r = o.Pi[idx]; c = o.Pcol[idx]; }
+      else if (kind == K_A) { r = o.Arow[idx]; c = o.Aj[idx]; }
+      o.Kdesc[4 * (size_t)p] = kind; o.Kdesc[4 * (size_t)p + 1] = idx; o.Kdesc[4 * (size_t)p + 2] = r; o.Kdesc[4 * (size_t)p + 3] = c;
+    }
+    for (size_t p = o.nnzK; p < (size_t)o.nnzK + 64 * 8; ++p) o.Kdesc[4 * p] = K_SIGMA;  // padding: constant, to scratch
+    o.Kmap.resize((size_t)o.nnzK + 64 * 8, o.nnzL + k);
     o.maxcol = 0;
     for (int kk = 0; kk < k; ++kk) o.maxcol = std::max(o.maxcol, o.Lp[kk + 1] - o.Lp[kk]);
     if (o.maxcol >= (1 << 16)) { *msg = "column of L too long for the update encoding"; return false; }

@@ -67,6 +67,7 @@ struct SparsePlanHost {
   // Group widths are capped so that the panel and its multipliers, 2 w R doubles, fit the kernel's LDS
   // scratch of lds_doubles.
   std::vector<int32_t> Kmap, rptr, rtgt, rab, snptr, snR, poff, pmap;
+  std::vector<int32_t> Kdesc;  // per KKT entry {kind, idx, row, col of the source entry}; Kdesc and Kmap are padded by 512 entries
   int rsteps = 0, maxcol = 0, nsn = 0, lds_doubles = 0;
 };
 
