@@ -72,6 +72,11 @@ def test_swarm_tick_equals_host_assembly_plus_solve(sfb):
     wx[0], wy[0] = r2.primal[0], r2.dual[0]                                                   # what agent 0 kept
     r4 = plan.solve_batch_host(Px, q, Av2, l2, u2, prm, warm_x=wx, warm_y=wy)
     assert np.array_equal(coded, r4.code) and np.array_equal(itd, r4.iter) and np.array_equal(du0d, r4.primal[:, ub:ub + 2])
+    # the shared-Jacobian form of the records gives the same tick (the vehicle's Jacobians do not depend on the agent)
+    own, shared = L.split_shared(rec2)
+    du0s, codes_, its = swarm.step_host(own, prm, shared_jac=shared)
+    r5 = plan.solve_batch_host(Px, q, Av2, l2, u2, prm, warm_x=r4.primal, warm_y=r4.dual)
+    assert np.array_equal(codes_, r5.code) and np.array_equal(its, r5.iter) and np.array_equal(du0s, r5.primal[:, ub:ub + 2])
     # no warm start requested: cold solve, and the stored warm starts are forgotten by reset_warmstart()
     du0e, codee, ite = swarm.step_host(rec, prm, warmstart=False)
     assert np.array_equal(ite, it) and np.array_equal(du0e, du0)
