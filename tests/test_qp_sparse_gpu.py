@@ -61,3 +61,25 @@ def test_random_sparse_batches(sfb, oracle, n, m, density, ordering, sweep_mode)
     ref2 = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q + 0.01, Ap, Aj, Ax, l, u, perm=plan.perm,
                                         params=_oracle_params(oracle, prm), warm_x=wx, warm_y=wy, nthreads=8)
     _compare(r2, ref2)
+
+
+def test_large_banded_problem_uses_element_indices(sfb, oracle, sweep_mode):
+    """n + m = 9 000 > 8 190: the sweep schedules store element indices instead of 16-bit byte offsets and the
+    work vector takes 72 KB of LDS per wave.  Tridiagonal P, three entries per row of A; bit-identical to the oracle."""
+    import scipy.sparse as sp
+    n, m, B = 5000, 4000, 3
+    rng = np.random.default_rng(1)
+    Pm = sp.diags([np.full(n, 2.0), np.full(n - 1, -0.5)], [0, 1], format="csc"); Pm.sort_indices()
+    rows = np.repeat(np.arange(m), 3); cols = (np.arange(m)[:, None] + np.arange(3)[None, :]).ravel() % n
+    Am = sp.csr_matrix((np.ones(3 * m), (rows, cols)), shape=(m, n)); Am.sort_indices()
+    plan = sfb.SparseQPPlan(n, m, Pm.indptr, Pm.indices, Am.indptr, Am.indices)
+    Px = np.tile(Pm.data, (B, 1)) * (1 + 0.1 * rng.random((B, Pm.nnz)))
+    Ax = rng.uniform(-1, 1, (B, Am.nnz))
+    q = rng.uniform(-1, 1, (B, n)); u = rng.uniform(0.5, 1.5, (B, m))
+    l = np.where(rng.random((B, m)) < 0.5, -np.inf, u - 1.0)
+    prm = sfb.QPSolverParams(max_iter=300)
+    r = plan.solve_batch_host(Px, q, Ax, l, u, prm)
+    ref = oracle.qp_sparse_solve_batch(Pm.indptr.astype(np.int32), Pm.indices.astype(np.int32), Px, q,
+                                       Am.indptr.astype(np.int32), Am.indices.astype(np.int32), Ax, l, u, perm=plan.perm,
+                                       params=_oracle_params(oracle, prm), nthreads=3)
+    assert _compare(r, ref)
