@@ -169,7 +169,7 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
 {
   const int k = pl.k, nnzL = pl.nnzL;
 #ifdef SFB_PROF_LDL
-  unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, pc = __builtin_amdgcn_s_memtime();
+  unsigned long long pt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pc = __builtin_amdgcn_s_memtime();
 #define SFB_LAP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[i] += now_ - pc; pc = now_; }
 #else
 #define SFB_LAP(i)
@@ -211,14 +211,12 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
       // chain of the elimination.  Same operations per entry as the LDS form below: divide by D, multiply back,
       // fma(-L(ra, j), L(rb, j) D(j), .) in ascending j.  Entries above the diagonal hold garbage and are never used.
       double reg[kPanelCols];
-      {
-        int src[kPanelCols];
+      int src[kPanelCols];
 #pragma unroll
-        for (int jj = 0; jj < kPanelCols; ++jj)
-          src[jj] = (jj < wd && lane < R) ? pm[jj * R + lane] : pad + 1;  // pad + 1: the always-zero accumulator
+      for (int jj = 0; jj < kPanelCols; ++jj)
+        src[jj] = (jj < wd && lane < R) ? pm[jj * R + lane] : pad + 1;  // pad + 1: the always-zero accumulator
 #pragma unroll
-        for (int jj = 0; jj < kPanelCols; ++jj) reg[jj] = ACC[src[jj]];
-      }
+      for (int jj = 0; jj < kPanelCols; ++jj) reg[jj] = ACC[src[jj]];
       SFB_LAP(1)
 #pragma unroll
       for (int jj = 0; jj < kPanelCols; ++jj) {
@@ -237,6 +235,12 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
             if (rb < wd) reg[rb] = fma(-v, lane_bcast(mv, rb), reg[rb]);
         }
       }
+      // final D and L values of the panel -> workspace, straight from the registers and with the indices the panel
+      // was gathered with (no reload of the map, no LDS read; entries above the diagonal and explicit zeros map to
+      // the scratch / zero accumulators and are skipped)
+#pragma unroll
+      for (int jj = 0; jj < kPanelCols; ++jj)
+        if (src[jj] < pad) ACC[src[jj]] = reg[jj];
       wave_lds_fence();
     } else {
     // 1. panel accumulators -> LDS (gather through the panel map, DEPTH loads in flight per lane)
@@ -268,18 +272,20 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
           pan[rb * R + ra] = fma(-pan[jj * R + ra], mul[jj * R + rb], pan[rb * R + ra]);
       wave_lds_fence();
     }
+    for (int q = lane; q < npan; q += kWave) {  // final D and L values of the panel -> workspace (fire and forget)
+      const int dst = pm[q];
+      if (dst < pad) ACC[dst] = pan[q];  // not the scratch / zero accumulators
+    }
     }
     SFB_LAP(2)
-    // final D, 1/D and L values of the panel -> workspace (fire and forget)
-    for (int q = lane; q < npan; q += kWave) {
-      const int dst = pm[q];
-      if (dst < nnzL + k) ACC[dst] = pan[q];  // not the scratch / zero accumulators
-    }
+    SFB_LAP(5)
     for (int jj = lane; jj < wd; jj += kWave) w.Dinv[j0 + jj] = 1.0 / pan[jj * R + jj];
+    SFB_LAP(6)
     // 3. trailing accumulators: pairs (a >= b) of rows of U, local rows w + a, w + b
     // (the DEPTH chains of a block advance together, column by column: 2 x DEPTH LDS reads in flight per lane
     //  instead of one dependent pair; padding slots compute on row 0 and land in the scratch accumulator)
     trailing_block<DEPTH>(pan, mul, R, wd, tp0, ab0, acc0, ACC);
+    SFB_LAP(7)
     for (int s = s0 + DEPTH; s < s1; s += DEPTH) {
       int tp[DEPTH];
       unsigned ab[DEPTH];
@@ -297,8 +303,9 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
       for (int dd = 0; dd < DEPTH; ++dd) acc[dd] = ACC[tp[dd]];
       trailing_block<DEPTH>(pan, mul, R, wd, tp, ab, acc, ACC);
     }
-    wave_sync();
     SFB_LAP(3)
+    wave_sync();
+    SFB_LAP(8)
   }
   // Schedule-ordered copies of the factor for the two sweeps (padding slots carry 0).  A streaming pass: writing
   // the final values straight into the copies from the panels (scattered 8-byte writes) is quicker for a lone
@@ -324,8 +331,8 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
   SFB_LAP(4)
 #ifdef SFB_PROF_LDL
   if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
-    printf("[ldl block %u mode %d] fill %llu  panel-load %llu  panel-elim %llu  trailing %llu  copies %llu  (x10 ns)\n",
-           blockIdx.x, mode, pt[0], pt[1], pt[2], pt[3], pt[4]);
+    printf("[ldl block %u mode %d] fill %llu  panel-load %llu  panel-elim %llu  finals %llu  dinv %llu  block0 %llu  blocks1+ %llu  sync %llu  copies %llu  (cycles)\n",
+           blockIdx.x, mode, pt[0], pt[1], pt[2], pt[5], pt[6], pt[7], pt[3], pt[8], pt[4]);
 #endif
   return 1;
 }
