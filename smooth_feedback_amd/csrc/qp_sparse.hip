@@ -680,25 +680,79 @@ __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const 
   wave_sync();
   if (!ldl_numeric_dev<8>(pl, it, w, t, 1, c, kp.sigma, kp.delta, lane)) return;  // :187-190
   for (uint32_t iter = 0; iter != kp.polish_iter; ++iter) {                      // :193-195
+    // residual rows h - K tv (:193-195), entries in storage order as in the oracle.  Like sp_row_dot the entries of
+    // a row are fetched in chunks: positions / indices first, then everything they point to, then the fma chain
+    // (two memory round trips per chunk of 8 entries instead of three per entry).
+    constexpr int U = kRowChunk;
     for (int i = lane; i < n; i += kWave) {
       double acc = 0.0;
-      for (int p = pl.Sp[i]; p < pl.Sp[i + 1]; ++p) {
-        const int e = pl.Spos[p], er = pl.Pi[e], ec = pl.Pcol[e];
-        acc = fma(c * w.sx[ec] * w.sx[er] * it.Px[e], w.tv[pl.Sj[p]], acc);
+      const double sxi = w.sx[i];
+      for (int q = pl.Sp[i], q1 = pl.Sp[i + 1]; q < q1; q += U) {  // P as selfadjointView<Upper>: entry (min, max)
+        int e[U], j[U];
+        double pv[U], sj[U], xv[U];
+#pragma unroll
+        for (int a = 0; a < U; ++a) {
+          const bool on = q + a < q1;
+          e[a] = on ? pl.Spos[q + a] : 0;
+          j[a] = on ? pl.Sj[q + a] : 0;
+        }
+#pragma unroll
+        for (int a = 0; a < U; ++a) {
+          pv[a] = it.Px[e[a]];
+          sj[a] = w.sx[j[a]];
+          xv[a] = w.tv[j[a]];
+        }
+#pragma unroll
+        for (int a = 0; a < U; ++a)
+          if (q + a < q1) {
+            const double s_ec = (j[a] > i) ? sj[a] : sxi, s_er = (j[a] > i) ? sxi : sj[a];  // row er <= column ec
+            acc = fma(c * s_ec * s_er * pv[a], xv[a], acc);
+          }
       }
-      for (int p = pl.Acp[i]; p < pl.Acp[i + 1]; ++p) {
-        const int rr = pl.Aci[p], e = pl.Acpos[p];
-        if (w.act[rr] != 0.0) acc = fma(w.sy[rr] * w.sx[i] * it.Ax[e], w.tv[n + rr], acc);
+      for (int q = pl.Acp[i], q1 = pl.Acp[i + 1]; q < q1; q += U) {  // column i of A, active rows only
+        int rr[U], e[U];
+        double av[U], sr[U], xv[U], ac[U];
+#pragma unroll
+        for (int a = 0; a < U; ++a) {
+          const bool on = q + a < q1;
+          rr[a] = on ? pl.Aci[q + a] : 0;
+          e[a]  = on ? pl.Acpos[q + a] : 0;
+        }
+#pragma unroll
+        for (int a = 0; a < U; ++a) {
+          ac[a] = w.act[rr[a]];
+          sr[a] = w.sy[rr[a]];
+          av[a] = it.Ax[e[a]];
+          xv[a] = w.tv[n + rr[a]];
+        }
+#pragma unroll
+        for (int a = 0; a < U; ++a)
+          if (q + a < q1 && ac[a] != 0.0) acc = fma(sr[a] * sxi * av[a], xv[a], acc);
       }
-      const double h = -c * (w.sx[i] * it.q[i]);  // :180
+      const double h = -c * (sxi * it.q[i]);  // :180
       t[pl.pinv[i]]  = h - acc;
     }
     for (int rr = lane; rr < m; rr += kWave) {
-      const double a = w.act[rr];
+      const double a_ = w.act[rr];
       double acc = 0.0, h = 0.0;
-      if (a != 0.0) {
-        for (int p = pl.Ap[rr]; p < pl.Ap[rr + 1]; ++p) acc = fma(w.sy[rr] * w.sx[pl.Aj[p]] * it.Ax[p], w.tv[pl.Aj[p]], acc);
-        h = (a == 1.0) ? w.sy[rr] * it.l[rr] : w.sy[rr] * it.u[rr];  // :181-182
+      if (a_ != 0.0) {
+        const double syr = w.sy[rr];
+        for (int q = pl.Ap[rr], q1 = pl.Ap[rr + 1]; q < q1; q += U) {
+          int j[U];
+          double av[U], sj[U], xv[U];
+#pragma unroll
+          for (int a = 0; a < U; ++a) j[a] = (q + a < q1) ? pl.Aj[q + a] : 0;
+#pragma unroll
+          for (int a = 0; a < U; ++a) {
+            av[a] = (q + a < q1) ? it.Ax[q + a] : 0.0;
+            sj[a] = w.sx[j[a]];
+            xv[a] = w.tv[j[a]];
+          }
+#pragma unroll
+          for (int a = 0; a < U; ++a)
+            if (q + a < q1) acc = fma(syr * sj[a] * av[a], xv[a], acc);
+        }
+        h = (a_ == 1.0) ? syr * it.l[rr] : syr * it.u[rr];  // :181-182
       }
       t[pl.pinv[n + rr]] = h - acc;
     }
@@ -875,7 +929,20 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
       const double syi = w.sy[i];
       w.ys[i]          = c * ((1.0 / syi) * wy[i]);
       double acc       = 0.0;
-      for (int p = pl.Ap[i]; p < pl.Ap[i + 1]; ++p) acc = fma(syi * it.Ax[p], wx[pl.Aj[p]], acc);
+      for (int q = pl.Ap[i], q1 = pl.Ap[i + 1]; q < q1; q += kRowChunk) {  // chunked like sp_row_dot
+        int j[kRowChunk];
+        double av[kRowChunk], xv[kRowChunk];
+#pragma unroll
+        for (int a = 0; a < kRowChunk; ++a) {
+          j[a]  = (q + a < q1) ? pl.Aj[q + a] : 0;
+          av[a] = (q + a < q1) ? it.Ax[q + a] : 0.0;
+        }
+#pragma unroll
+        for (int a = 0; a < kRowChunk; ++a) xv[a] = wx[j[a]];
+#pragma unroll
+        for (int a = 0; a < kRowChunk; ++a)
+          if (q + a < q1) acc = fma(syi * av[a], xv[a], acc);
+      }
       w.zs[i] = acc;
     }
   } else {
