@@ -452,6 +452,16 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
               [&]<int D>(std::integral_constant<int, D> dd) { issue(dd, std::integral_constant<int, 0>{}, mk); });
   }
   advance();
+  // (tgt, piv) of the two slots of a unit as byte offsets (BYTEOFF, plan.idx_scale == 8) or element indices
+  struct Addr { unsigned t0, p0, t1, p1; };
+  auto extract = [](const vint2 &v) { const unsigned a = (unsigned)v.x, b = (unsigned)v.y; return Addr{a & 0xFFFFu, a >> 16, b & 0xFFFFu, b >> 16}; };
+  auto at = [&](unsigned v) -> double & {
+    return BYTEOFF ? *reinterpret_cast<double *>(reinterpret_cast<char *>(t) + v) : t[v];
+  };
+  // Software pipeline over the units: the addresses of unit u+1 are unpacked (and its stream loads awaited) while
+  // the LDS reads of unit u are in flight, so that only [reads -> fma -> writes] is left on the dependent chain.
+  stream_wait<2 * (DEPTH - 1)>(lx[0], ix[0]);
+  Addr cur = extract(ix[0]);
   // one block of DEPTH units: consume unit u0 + D, then issue the loads of unit u0 + D + DEPTH (their mask shifts are
   // fetched at the head of the block and awaited behind the first unit's LDS round trip)
   auto block = [&]<int MODE>(std::integral_constant<int, MODE> msk, const int u0) {
@@ -459,17 +469,15 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
     sint8 mk;
     if constexpr (MASKED) mask_fetch(mk, mask32, __builtin_amdgcn_readfirstlane((u0 + DEPTH) * 4));
     for_units(std::make_integer_sequence<int, DEPTH>{}, [&]<int D>(std::integral_constant<int, D> dd) {
-      stream_wait<2 * (DEPTH - 1)>(lx[D], ix[D]);  // this unit's two loads are the oldest in flight
-      const unsigned p0 = (unsigned)ix[D].x, p1 = (unsigned)ix[D].y;
-      // (tgt, piv) as byte offsets (BYTEOFF, plan.idx_scale == 8) or element indices
-      auto at = [&](unsigned v) -> double & {
-        return BYTEOFF ? *reinterpret_cast<double *>(reinterpret_cast<char *>(t) + v) : t[v];
-      };
-      const double a0 = at(p0 >> 16), b0 = at(p0 & 0xFFFFu), a1 = at(p1 >> 16), b1 = at(p1 & 0xFFFFu);
-      at(p0 & 0xFFFFu) = fma(-lx[D].x, a0, b0);
-      at(p1 & 0xFFFFu) = fma(-lx[D].y, a1, b1);
+      constexpr int N = (D + 1) % DEPTH;  // the unit after this one (N == 0: unit 0 of the next block, issued at D == 0)
+      const double a0 = at(cur.p0), b0 = at(cur.t0), a1 = at(cur.p1), b1 = at(cur.t1);
+      stream_wait<2 * (DEPTH - 2)>(lx[N], ix[N]);  // six younger units are in flight behind unit N
+      const Addr nxt = extract(ix[N]);
+      at(cur.t0) = fma(-lx[D].x, a0, b0);
+      at(cur.t1) = fma(-lx[D].y, a1, b1);
       if constexpr (D == 0 && MASKED) mask_wait(mk);  // behind the LDS round trip above
       issue(dd, msk, mk);  // unit u0 + D + DEPTH (always inside the padded arrays)
+      cur = nxt;
     });
     advance();
   };
