@@ -409,6 +409,9 @@ def main():
             rec["roofline"]["traffic"], src = pmc_traffic(args.workload, wl.name)
             if src:
                 rec["roofline"]["traffic_source"] = src
+            if rec["roofline"]["traffic"]:  # what the kernel actually moves through HBM, as a rate and a fraction of peak
+                rec["roofline"]["traffic_GBps"] = rec["roofline"]["traffic"] / (kern_ms * 1e-3) / 1e9
+                rec["roofline"]["traffic_frac"] = rec["roofline"]["traffic"] / (kern_ms * 1e-3) / HBM_PEAK_BYTES_PER_S
         if hasattr(wl, "extra"):
             rec["workload_stats"] = wl.extra()
             ws = rec["workload_stats"]
