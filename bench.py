@@ -63,6 +63,13 @@ class DenseQPWorkload:
     def small_outputs(self):
         return self.out
 
+    def extra(self):
+        it = self.out[0].cpu().numpy().astype(np.int64)
+        code = self.out[1].cpu().numpy()
+        return {"iterations": {"mean": float(it.mean()), "p50": int(np.percentile(it, 50)),
+                               "p99": int(np.percentile(it, 99)), "max": int(it.max())},
+                "codes": np.bincount(code, minlength=7).tolist()}
+
     def cpu_baseline(self, cores, budget_s=15.0):
         """Oracle (CPU restatement of the reference ADMM) on a bounded sample of the same batch."""
         from oracle import loader as O
