@@ -14,12 +14,16 @@
 // with its default diff::Type, autodiff when that header is present).
 #pragma once
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <limits>
 #include <memory>
 #include <optional>
 #include <type_traits>
 #include <utility>
+#include <thread>
 #include <vector>
 
 #include "lie.hpp"
@@ -294,20 +298,40 @@ public:
   template<class H, class BU>
   std::vector<U> operator()(const std::vector<G> & g, const std::vector<U> & u_des, H && h, BU && bu)
   {
-    for (std::size_t b = 0; b < B_; ++b) {
-      ASIFProblem<G, U> pbm{prm_.T, g[b], u_des[b], prm_.u_weight, prm_.ulim};
-      asif_to_qp_update<G, U>(
-        qp_, pbm, prm_.asif, f_, [&](double t, const G & x) { return h(b, t, x); },
-        [&](double t, const G & x) { return bu(b, t, x); });
-      std::copy(qp_.P.begin(), qp_.P.end(), P_.begin() + b * n_ * n_);
-      std::copy(qp_.q.begin(), qp_.q.end(), q_.begin() + b * n_);
-      std::copy(qp_.A.begin(), qp_.A.end(), A_.begin() + b * m_ * n_);
-      std::copy(qp_.l.begin(), qp_.l.end(), l_.begin() + b * m_);
-      std::copy(qp_.u.begin(), qp_.u.end(), u_.begin() + b * m_);
+    const auto T0 = std::chrono::steady_clock::now();
+    // assembly (sensitivity ODE of every agent, asif_func.hpp:145-179) on the host cores, one scratch QP per thread;
+    // h, bu and the dynamics must be callable concurrently for different agents
+    {
+      // one thread per physical core (the ODE is floating-point bound: SMT siblings only add overhead, measured);
+      // SFB_ASIF_THREADS overrides
+      const char * tenv = getenv("SFB_ASIF_THREADS");
+      const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+      const int T = (int)std::min<std::size_t>(tenv ? (unsigned)std::max(1, atoi(tenv)) : (hw >= 16 ? hw / 2 : hw), B_);
+      std::vector<std::thread> th;
+      for (int k = 0; k < T; ++k)
+        th.emplace_back([&, k] {
+          QuadraticProgram qp = qp_;  // same layout, private values
+          for (std::size_t b = B_ * k / T; b < B_ * (k + 1) / T; ++b) {
+            ASIFProblem<G, U> pbm{prm_.T, g[b], u_des[b], prm_.u_weight, prm_.ulim};
+            asif_to_qp_update<G, U>(
+              qp, pbm, prm_.asif, f_, [&](double t, const G & x) { return h(b, t, x); },
+              [&](double t, const G & x) { return bu(b, t, x); });
+            std::copy(qp.P.begin(), qp.P.end(), P_.begin() + b * n_ * n_);
+            std::copy(qp.q.begin(), qp.q.end(), q_.begin() + b * n_);
+            std::copy(qp.A.begin(), qp.A.end(), A_.begin() + b * m_ * n_);
+            std::copy(qp.l.begin(), qp.l.end(), l_.begin() + b * m_);
+            std::copy(qp.u.begin(), qp.u.end(), u_.begin() + b * m_);
+          }
+        });
+      for (auto & t : th) t.join();
     }
+    const auto T1 = std::chrono::steady_clock::now();
+    if (getenv("SFB_ASIF_TIMING")) fprintf(stderr, "[asif swarm] assembly of %zu agents %.1f ms\n", B_, std::chrono::duration<double, std::milli>(T1 - T0).count());
     backend_->solve_batch((int64_t)B_, P_.data(), q_.data(), A_.data(), l_.data(), u_.data(),
                           have_warm_ ? wx_.data() : nullptr, have_warm_ ? wy_.data() : nullptr, x_.data(), y_.data(),
                           nullptr, iter_.data(), code_.data());
+    const auto T2 = std::chrono::steady_clock::now();
+    if (getenv("SFB_ASIF_TIMING")) fprintf(stderr, "[asif swarm] solve (host entry point) %.1f ms\n", std::chrono::duration<double, std::milli>(T2 - T1).count());
     std::vector<U> out(B_);
     for (std::size_t b = 0; b < B_; ++b) {
       typename U::Tangent du{};
