@@ -106,8 +106,7 @@ class MPCWorkload:
     Agent b: t_b = 0.025 (b mod 400), x_b = xdes(t_b) (+) U(-0.5,0.5)^12."""
 
     def __init__(self, sfb, rank, device, batch=8192, variant=12, K=50):
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import models_lib as M
+        from examples import models_lib as M
         self.sfb, self.B = sfb, batch
         d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
         self.d, self.pat = d, (Pp, Pi, Pv, Ap, Aj)
@@ -115,7 +114,12 @@ class MPCWorkload:
         t0 = time.perf_counter()
         Av, l, u = M.mpc_assemble_batch(variant, K, batch, seed=1000003 * rank + 3, threads=os.cpu_count() or 8)
         self.host_assembly_s = time.perf_counter() - t0
-        self.plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K))
+        # Structure probe, as the C++ front does (MPCSwarm::step): stored entries of A that are zero in a sample of the
+        # batch are declared explicit zeros (ocp_to_qp writes dense Jacobian blocks) and left out of the analysis;
+        # the kernel verifies the declaration for every agent (whole-pattern fallback otherwise).  SFB_BENCH_NO_PRUNE=1
+        # analyses everything that is stored (A/B knob).
+        keep = None if os.environ.get("SFB_BENCH_NO_PRUNE") == "1" else np.any(Av[:: max(1, batch // 64)] != 0.0, axis=0)
+        self.plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K), keep=keep)
         self.prm = sfb.QPSolverParams()  # MPCParams.qp{} defaults (mpc.hpp:332)
         self.host = (np.tile(Pv, (batch, 1)), np.zeros((batch, d["n"])), Av, l, u)
         self.dev = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in self.host]
@@ -124,7 +128,7 @@ class MPCWorkload:
         self.y = torch.empty((batch, d["m"]), **f64)
         self.obj = torch.empty(batch, **f64)
         self.out = torch.empty((2, batch), dtype=torch.int32, device=device)
-        self.ws = torch.empty(batch * self.plan.workspace_bytes_per_item // 8, **f64)
+        self.ws = torch.empty((self.plan.workspace_bytes(batch) + 7) // 8, **f64)
         self.units_per_step = batch
         n, m = d["n"], d["m"]
         # values of P, q, A, l, u in; x, y, obj, iter, code out
@@ -182,6 +186,8 @@ class MPCWorkload:
         return {"iterations": {"mean": float(it.mean()), "p50": int(np.percentile(it, 50)),
                                "p99": int(np.percentile(it, 99)), "max": int(it.max())},
                 "codes": np.bincount(code, minlength=7).tolist(), "nnzL": int(self.plan.nnzL),
+                "nnzA_stored": int(self.plan.nnzA), "nnzA_analysed": int(self.plan.nnzA_kept),
+                "nnzL_whole_pattern_same_order": int(self.plan.nnzL_fallback),
                 "factor_stream_bytes_per_iteration_per_qp": int(16 * self.plan.nnzL),
                 "host_assembly_s": self.host_assembly_s}
 

@@ -1,4 +1,5 @@
-"""ctypes loader of the example/test harness library (examples/models.cpp -> libsfb_models.so)."""
+"""ctypes loader of the example harness library (examples/models.cpp -> libsfb_models.so): concrete MPC / ASIF / EKF
+models behind the C++ host front, used by bench.py, scripts/ and tests/ (`from examples import models_lib`)."""
 import ctypes as C
 import os
 import subprocess

@@ -152,10 +152,31 @@ sfb_status sfb_sparse_qp_plan_create_staged(int n, int m, const int32_t *P_colpt
                                             const int32_t *A_rowptr, const int32_t *A_colind, int ordering,
                                             const int32_t *user_perm, const int32_t *stage,
                                             sfb_sparse_qp_plan **plan);
+/*
+ * Same for a transcription that stores entries of A which are zero for EVERY item (the reference's ocp_to_qp
+ * writes dense Jacobian blocks: block_add, utils/sparse.hpp:33-50, ocp_to_qp.hpp:258-264 -- two thirds of the
+ * stored entries of the SE2 x R^3 MPC problem are explicit zeros).  A_keep[nnzA] (nullable): 0 = the caller
+ * declares this stored entry zero in every item solved with the plan.  The KKT pattern, the elimination order
+ * and the pattern of L are built from the kept entries only (the headline MPC pattern: nnz(L) 41 030 -> 13 710);
+ * the value arrays keep the caller's layout.  Exactness: a zero entry contributes exact zeros to every sum it
+ * takes part in, so the results equal those of the whole pattern under the same elimination order up to the
+ * sign of zeros.  The declaration is CHECKED on the device for every item: an item with a non-zero (or NaN)
+ * masked entry is solved on the whole pattern instead (same elimination order), by fallback launches inside
+ * the same call -- a wrong mask costs time, never correctness.
+ */
+sfb_status sfb_sparse_qp_plan_create_pruned(int n, int m, const int32_t *P_colptr, const int32_t *P_rowind,
+                                            const int32_t *A_rowptr, const int32_t *A_colind, int ordering,
+                                            const int32_t *user_perm, const int32_t *stage, const uint8_t *A_keep,
+                                            sfb_sparse_qp_plan **plan);
 void sfb_sparse_qp_plan_destroy(sfb_sparse_qp_plan *plan);
-/* nnz of the KKT upper triangle, nnz of L (strictly lower), bytes of device workspace PER ITEM. */
+/* nnz of the KKT upper triangle, nnz of L (strictly lower), bytes of device workspace PER ITEM (batch times this
+ * always suffices; sfb_sparse_qp_plan_workspace_bytes is the exact requirement of a call). */
 sfb_status sfb_sparse_qp_plan_info(const sfb_sparse_qp_plan *plan, int64_t *nnzK, int64_t *nnzL,
                                    int64_t *workspace_bytes_per_item);
+/* Exact device workspace of one call with `batch` items. */
+sfb_status sfb_sparse_qp_plan_workspace_bytes(const sfb_sparse_qp_plan *plan, int64_t batch, int64_t *bytes);
+/* Pruned plans: kept entries of A and nnz(L) of the fallback (whole-pattern) analysis; otherwise nnzA and nnz(L). */
+sfb_status sfb_sparse_qp_plan_pruned_info(const sfb_sparse_qp_plan *plan, int64_t *nnzA_kept, int64_t *nnzL_fallback);
 /* The elimination order in use (n+m entries, new -> old). */
 sfb_status sfb_sparse_qp_plan_get_perm(const sfb_sparse_qp_plan *plan, int32_t *perm);
 
@@ -163,7 +184,8 @@ sfb_status sfb_sparse_qp_plan_get_perm(const sfb_sparse_qp_plan *plan, int32_t *
  * Batched sparse solve (device pointers, asynchronous on `stream`).  Replaces, per item,
  * QPSolver<QuadraticProgramSparse<double>>::solve(pbm, warmstart) (qp_solver.hpp:343-568 with the
  * sparse branches :379-397, :423-426, :452-460) as called by MPC::operator() (mpc.hpp:491).
- * `workspace`: device buffer of batch * workspace_bytes_per_item bytes (caller-owned, reusable).
+ * `workspace`: device buffer of sfb_sparse_qp_plan_workspace_bytes(plan, batch) bytes (batch *
+ * workspace_bytes_per_item always suffices), 16-byte aligned, caller-owned, reusable.
  * Outputs as sfb_qp_dense_solve_batch.
  */
 sfb_status sfb_sparse_qp_solve_batch(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,

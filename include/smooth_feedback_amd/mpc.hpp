@@ -35,6 +35,10 @@ struct MPCParams {
   double tf{1};
   bool warmstart{true};
   QPSolverParams qp{};
+  /// (not in the reference) Analyse the QP on the entries of A that are non-zero at the probed linearisations
+  /// instead of on everything ocp_to_qp stores (dense Jacobian blocks: block_add, utils/sparse.hpp:33-50).  Exact
+  /// (explicit zeros contribute exact zeros) and verified per solve on the device, see analyze_solver().
+  bool prune_explicit_zeros{true};
 };
 
 /// mpc.hpp:344-356
@@ -66,6 +70,7 @@ public:
   {
     xdes_ = std::move(x_des);
     dxdes_ = std::move(dx_des);
+    structure_changed();
   }
   /// derivative by central differences of x(t) (the reference autodiffs / finite-differences x(t))
   void set_xdes(std::function<X(double)> x_des)
@@ -78,8 +83,13 @@ public:
       return d;
     };
     xdes_ = std::move(x_des);
+    structure_changed();
   }
-  void set_udes(std::function<U(double)> u_des) { udes_ = std::move(u_des); }
+  void set_udes(std::function<U(double)> u_des)
+  {
+    udes_ = std::move(u_des);
+    structure_changed();
+  }
   void reset_warmstart() { warm_.reset(); }
 
   // ---- sizes / pattern ----
@@ -102,11 +112,42 @@ public:
     for (int d = 0; d < Nx; ++d) st[nvar() + cecon_B() + d] = 1;
     return st;
   }
-  void analyze_solver()
+  /// OR the non-zero entries of A at (t, x) into keep (one byte per stored entry of A).
+  void probe_structure(double t, const X & x, std::vector<uint8_t> & keep) const
+  {
+    std::vector<double> Av(qp_.A_val.size()), lv(qp_.m), uv(qp_.m);
+    assemble(t, x, Av.data(), lv.data(), uv.data());
+    keep.resize(Av.size(), 0);
+    for (size_t e = 0; e < Av.size(); ++e) keep[e] |= !(Av[e] == 0.0);
+  }
+  /// probe at a few ticks after t from perturbed states on the desired trajectory (deterministic)
+  void probe_default(double t, std::vector<uint8_t> & keep) const
+  {
+    uint64_t lcg = 0x9E3779B97F4A7C15ull;
+    for (int s = 0; s < 6; ++s) {
+      const double ts = t + s * prm_.tf / double(N());
+      TangentX xi{};
+      for (auto & v : xi) {
+        lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+        v   = (double(lcg >> 11) / 9007199254740992.0 - 0.5);
+      }
+      probe_structure(ts, rplus(xdes_(ts), xi), keep);
+    }
+  }
+  void probe_values(const double * Aval, std::vector<uint8_t> & keep) const
+  {
+    keep.resize(qp_.A_val.size(), 0);
+    for (size_t e = 0; e < keep.size(); ++e) keep[e] |= !(Aval[e] == 0.0);
+  }
+  /// Symbolic analysis of the QP (once).  `keep` (nullable): the stored entries of A seen non-zero in a sample of
+  /// the linearisations this controller will solve (probe_structure); everything else is declared an explicit
+  /// zero and left out of the KKT pattern.  The declaration is checked on the device for every solve, and a
+  /// problem that violates it is solved on the whole pattern (sfb_sparse_qp_plan_create_pruned).
+  void analyze_solver(const std::vector<uint8_t> * keep = nullptr)
   {
     if (!solver_->analyzed()) {
       const auto st = elimination_stage();
-      solver_->analyze(qp_, nullptr, st.data());
+      solver_->analyze(qp_, nullptr, st.data(), (keep && prm_.prune_explicit_zeros) ? keep->data() : nullptr);
     }
   }
 
@@ -281,7 +322,12 @@ public:
                                             std::vector<X> * x_traj = nullptr)
   {
     assemble(t, x, qp_.A_val.data(), qp_.l.data(), qp_.u.data());
-    analyze_solver();
+    if (!solver_->analyzed()) {
+      std::vector<uint8_t> keep;
+      probe_values(qp_.A_val.data(), keep);
+      probe_default(t, keep);
+      analyze_solver(&keep);
+    }
     const QPSolution sol = solver_->solve(qp_, warm_ ? &*warm_ : nullptr);  // :491
     const int Nn = N();
     if (u_traj) {  // :494-500
@@ -308,6 +354,11 @@ public:
   }
 
 private:
+  // a new linearisation trajectory may have other explicit zeros: probe and analyse again at the next solve
+  void structure_changed()
+  {
+    if (prm_.prune_explicit_zeros && solver_->analyzed()) solver_->reset();
+  }
   int dcon_B() const { return 0; }
   int crcon_B() const { return Nx * N(); }
   int cecon_B() const { return Nx * N() + Ncr * N(); }
@@ -470,7 +521,12 @@ public:
     parallel_for([&](int64_t b) {
       mpc_.assemble(t[b], xs[b], &Ax_[(size_t)b * nA_], &l_[(size_t)b * qp.m], &u_[(size_t)b * qp.m]);
     });
-    mpc_.analyze_solver();
+    if (!mpc_.solver().analyzed()) {  // structure from a sample of this batch (up to 64 agents, evenly spaced)
+      std::vector<uint8_t> keep;
+      const int64_t S = std::min<int64_t>(B_, 64);
+      for (int64_t s = 0; s < S; ++s) mpc_.probe_values(&Ax_[(size_t)(s * B_ / S) * nA_], keep);
+      mpc_.analyze_solver(&keep);
+    }
     // an agent without a stored solution starts from zeros, which IS the cold start (qp_solver.hpp:436-445)
     const bool warm = mpc_.params().warmstart;
     if (warm && wx_.empty()) {
@@ -522,10 +578,15 @@ private:
 template<class MPCT>
 class MPCSwarmDevice {
 public:
-  explicit MPCSwarmDevice(MPCT & proto, int64_t agents, int threads = 0)
+  /// t_probe: a time in the range the agents will run at (the structure of the linearisation is probed there)
+  explicit MPCSwarmDevice(MPCT & proto, int64_t agents, int threads = 0, double t_probe = 0.0)
       : mpc_(proto), B_(agents), threads_(threads > 0 ? threads : (int)std::max(1u, std::thread::hardware_concurrency()))
   {
-    mpc_.analyze_solver();
+    if (!mpc_.solver().analyzed()) {
+      std::vector<uint8_t> keep;
+      mpc_.probe_default(t_probe, keep);
+      mpc_.analyze_solver(&keep);
+    }
     layout_ = mpc_.device_layout();
     recd_   = MPCT::record_doubles(mpc_.N());
     rec_.resize((size_t)B_ * recd_);

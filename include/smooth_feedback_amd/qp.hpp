@@ -100,17 +100,27 @@ public:
   ~SparseQPSolver() { sfb_sparse_qp_plan_destroy(plan_); }
 
   /// qp_solver.hpp:297-338 (+ SimplicialLDLT::analyzePattern :424)
+  /// A_keep (nullable, one byte per stored entry of A): 0 = the entry is zero in every problem solved with this
+  /// analysis (explicit zeros of dense Jacobian blocks); see sfb_sparse_qp_plan_create_pruned -- checked per item
+  /// on the device, a wrong declaration costs time, not correctness.
   void analyze(const QuadraticProgramSparse & pbm, const int32_t * user_perm = nullptr,
-               const int32_t * stage = nullptr)
+               const int32_t * stage = nullptr, const uint8_t * A_keep = nullptr)
   {
     sfb_sparse_qp_plan_destroy(plan_);
     plan_ = nullptr;
     n_ = pbm.n; m_ = pbm.m;
     nnzP_ = (int)pbm.P_val.size(); nnzA_ = (int)pbm.A_val.size();
-    sfb_check(sfb_sparse_qp_plan_create_staged(pbm.n, pbm.m, pbm.P_colptr.data(), pbm.P_rowind.data(),
-                                               pbm.A_rowptr.data(), pbm.A_colind.data(), 1, user_perm, stage, &plan_));
+    sfb_check(sfb_sparse_qp_plan_create_pruned(pbm.n, pbm.m, pbm.P_colptr.data(), pbm.P_rowind.data(),
+                                               pbm.A_rowptr.data(), pbm.A_colind.data(), 1, user_perm, stage, A_keep,
+                                               &plan_));
   }
   bool analyzed() const { return plan_ != nullptr; }
+  /// forget the analysis (the next solve analyses again)
+  void reset()
+  {
+    sfb_sparse_qp_plan_destroy(plan_);
+    plan_ = nullptr;
+  }
   int64_t nnzL() const
   {
     int64_t v = 0;

@@ -1,9 +1,8 @@
 """ASIFSwarm ticks (host sensitivity ODE + assembly, one batched dense-QP solve on the GPU): wall time per tick."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
-import models_lib as M
+from examples import models_lib as M
 B = int(os.environ.get("B", 65536)); K = int(os.environ.get("K", 10))
 M.asif_swarm_step(256, K, ticks=1)
 for ticks in (1, 3):

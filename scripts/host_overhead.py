@@ -1,10 +1,9 @@
 """Host-pointer entry point vs device-resident entry point of the sparse path (8192 MPC agents): what malloc + PCIe cost."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 import smooth_feedback_amd as sfb
-import models_lib as M
+from examples import models_lib as M
 variant, K, B = 12, 50, int(os.environ.get("B", 8192))
 d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
 t0 = time.perf_counter(); Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=3, threads=64); print("assembly %.3f s" % (time.perf_counter() - t0))
@@ -21,7 +20,7 @@ pin = [torch.from_numpy(a).pin_memory() for a in (Px, q, Av, l, u)]
 t0 = time.perf_counter(); [a.to(dev, non_blocking=True) for a in pin]; torch.cuda.synchronize(); print("torch H2D (pinned) %.3f s" % (time.perf_counter() - t0))
 x = torch.empty((B, d["n"]), dtype=torch.float64, device=dev); y = torch.empty((B, d["m"]), dtype=torch.float64, device=dev)
 obj = torch.empty(B, dtype=torch.float64, device=dev); it = torch.empty(B, dtype=torch.int32, device=dev); code = torch.empty(B, dtype=torch.int32, device=dev)
-t0 = time.perf_counter(); ws = torch.empty(B * plan.workspace_bytes_per_item // 8, dtype=torch.float64, device=dev); torch.cuda.synchronize(); print("workspace alloc %.3f s (%.1f GB)" % (time.perf_counter() - t0, ws.numel() * 8 / 1e9))
+t0 = time.perf_counter(); ws = torch.empty((plan.workspace_bytes(B) + 7) // 8, dtype=torch.float64, device=dev); torch.cuda.synchronize(); print("workspace alloc %.3f s (%.1f GB)" % (time.perf_counter() - t0, ws.numel() * 8 / 1e9))
 s = torch.cuda.current_stream()
 for rep in range(2):
     t0 = time.perf_counter()

@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np, torch
 import smooth_feedback_amd as sfb
-import models_lib as M
+from examples import models_lib as M
 B = int(os.environ.get("B", 8192))
 d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(12, 50)
 Av, l, u = M.mpc_assemble_batch(12, 50, B, seed=3, threads=64)

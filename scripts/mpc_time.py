@@ -1,20 +1,20 @@
 """Timing of the sparse MPC QP kernel on device-resident data (variant 12, K=50 by default)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 import smooth_feedback_amd as sfb
-import models_lib as M
+from examples import models_lib as M
 variant = int(os.environ.get("VARIANT", 12)); K = int(os.environ.get("K", 50)); B = int(os.environ.get("B", 2048))
 d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
 t0 = time.time(); Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=3, threads=64); ta = time.time() - t0
-plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K))
+keep = None if os.environ.get("NO_PRUNE") == "1" else np.any(Av[:: max(1, B // 64)] != 0.0, axis=0)
+plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K), keep=keep)
 dev = torch.device("cuda:0")
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 dPx, dq, dAx, dl, du = T(np.tile(Pv, (B, 1))), T(np.zeros((B, d["n"]))), T(Av), T(l), T(u)
 x = torch.empty((B, d["n"]), dtype=torch.float64, device=dev); y = torch.empty((B, d["m"]), dtype=torch.float64, device=dev)
 obj = torch.empty(B, dtype=torch.float64, device=dev); it = torch.empty(B, dtype=torch.int32, device=dev); code = torch.empty(B, dtype=torch.int32, device=dev)
-ws = torch.empty(B * plan.workspace_bytes_per_item // 8, dtype=torch.float64, device=dev)
+ws = torch.empty((plan.workspace_bytes(B) + 7) // 8, dtype=torch.float64, device=dev)
 s = torch.cuda.current_stream()
 def run(prm):
     plan.solve_batch_device(B, dPx.data_ptr(), dq.data_ptr(), dAx.data_ptr(), dl.data_ptr(), du.data_ptr(), x.data_ptr(), y.data_ptr(),
@@ -24,7 +24,7 @@ def timed(prm):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(s); run(prm); e1.record(s); torch.cuda.synchronize()
     return e0.elapsed_time(e1)
-print("variant", variant, "K", K, "B", B, "n=m", d["n"], "nnzL", plan.nnzL, "host assembly s", round(ta, 3))
+print("variant", variant, "K", K, "B", B, "n=m", d["n"], "nnzL", plan.nnzL, "nnzA analysed", plan.nnzA_kept, "of", plan.nnzA, "host assembly s", round(ta, 3))
 ms = timed(sfb.QPSolverParams(max_iter=4000))
 print("default params: %.2f ms -> %.0f MPC-QP solves/s ; iters mean %.1f max %d ; codes %s" % (ms, B / ms * 1e3, it.float().mean().item(), it.max().item(), np.bincount(code.cpu().numpy(), minlength=7)))
 t_setup = timed(sfb.QPSolverParams(max_iter=0, polish=False))

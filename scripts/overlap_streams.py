@@ -2,10 +2,9 @@
 own workspace and outputs): the tail of one launch (only long-running agents left) overlaps with the bulk of the next."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 import smooth_feedback_amd as sfb
-import models_lib as M
+from examples import models_lib as M
 variant, K, B, STEPS = 12, 50, 8192, int(os.environ.get("STEPS", 8))
 d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
 Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=3, threads=64)
@@ -17,7 +16,7 @@ prm = sfb.QPSolverParams(max_iter=4000)
 def bufs():
     return dict(x=torch.empty((B, d["n"]), dtype=torch.float64, device=dev), y=torch.empty((B, d["m"]), dtype=torch.float64, device=dev),
                 it=torch.empty(B, dtype=torch.int32, device=dev), code=torch.empty(B, dtype=torch.int32, device=dev),
-                ws=torch.empty(B * plan.workspace_bytes_per_item // 8, dtype=torch.float64, device=dev))
+                ws=torch.empty((plan.workspace_bytes(B) + 7) // 8, dtype=torch.float64, device=dev))
 for S in (1, 2, 3):
     sets = [bufs() for _ in range(S)]
     streams = [torch.cuda.Stream() for _ in range(S)]

@@ -2,10 +2,9 @@
 full solve without polish, full solve.  Use with SFB_LIB_PATH to compare builds on one box."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 import smooth_feedback_amd as sfb
-import models_lib as M
+from examples import models_lib as M
 variant, K, B, REPS = 12, 50, int(os.environ.get("B", 8192)), int(os.environ.get("REPS", 5))
 d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
 Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=3, threads=64)
@@ -15,7 +14,7 @@ T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 dPx, dq, dAx, dl, du = T(np.tile(Pv, (B, 1))), T(np.zeros((B, d["n"]))), T(Av), T(l), T(u)
 x = torch.empty((B, d["n"]), dtype=torch.float64, device=dev); y = torch.empty((B, d["m"]), dtype=torch.float64, device=dev)
 obj = torch.empty(B, dtype=torch.float64, device=dev); it = torch.empty(B, dtype=torch.int32, device=dev); code = torch.empty(B, dtype=torch.int32, device=dev)
-ws = torch.empty(B * plan.workspace_bytes_per_item // 8, dtype=torch.float64, device=dev)
+ws = torch.empty((plan.workspace_bytes(B) + 7) // 8, dtype=torch.float64, device=dev)
 s = torch.cuda.current_stream()
 def timed(prm):
     def go():

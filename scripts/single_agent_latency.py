@@ -2,10 +2,9 @@
 point: cold start and warm start, wall time and kernel time."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 import smooth_feedback_amd as sfb
-import models_lib as M
+from examples import models_lib as M
 variant = int(os.environ.get("VARIANT", 12)); K = int(os.environ.get("K", 50)); B = int(os.environ.get("B", 1))
 d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
 plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K))

@@ -2,9 +2,8 @@
 cold (first) and warm-started (later) ticks.  VARIANT/K/B from the environment."""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
-import models_lib as M
+from examples import models_lib as M
 variant = int(os.environ.get("VARIANT", 12)); K = int(os.environ.get("K", 50)); B = int(os.environ.get("B", 8192))
 u0 = np.zeros((B, 2)); codes = np.zeros(B, np.int32); iters = np.zeros(B, np.uint32)
 DEVICE = int(os.environ.get("DEVICE", 0))   # 1: MPCSwarmDevice (records -> device assembly, device-resident warm start)

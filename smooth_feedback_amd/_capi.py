@@ -73,6 +73,10 @@ def _load():
     i32p = C.c_void_p
     L.sfb_sparse_qp_plan_create.argtypes = [i32, i32, i32p, i32p, i32p, i32p, i32, i32p, C.POINTER(C.c_void_p)]
     L.sfb_sparse_qp_plan_create_staged.argtypes = [i32, i32, i32p, i32p, i32p, i32p, i32, i32p, i32p, C.POINTER(C.c_void_p)]
+    L.sfb_sparse_qp_plan_create_pruned.argtypes = [i32, i32, i32p, i32p, i32p, i32p, i32, i32p, i32p, C.c_void_p,
+                                                   C.POINTER(C.c_void_p)]
+    L.sfb_sparse_qp_plan_workspace_bytes.argtypes = [C.c_void_p, i64, C.POINTER(C.c_int64)]
+    L.sfb_sparse_qp_plan_pruned_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.sfb_sparse_qp_plan_destroy.argtypes = [C.c_void_p]
     L.sfb_sparse_qp_plan_destroy.restype = None
     L.sfb_sparse_qp_plan_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]

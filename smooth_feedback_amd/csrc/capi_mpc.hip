@@ -116,7 +116,7 @@ struct sfb_mpc_swarm {
   sfb::MpcAsmParams rec_own{}, rec_shared{};
   int64_t agents = 0, shared_doubles = 0;
   int n = 0, m = 0, nnzP = 0, nnzA = 0, nu = 0, uoff = 0, devid = 0;
-  size_t wsd = 0;
+  size_t wsd = 0;  // solver workspace of the whole swarm, in doubles
   char *mem = nullptr;
   double *Px = nullptr, *q = nullptr, *Ax = nullptr, *l = nullptr, *u = nullptr, *x = nullptr, *y = nullptr, *wx = nullptr,
          *wy = nullptr, *rec = nullptr, *shared = nullptr, *du0 = nullptr, *ws = nullptr;
@@ -179,7 +179,7 @@ sfb_status sfb_mpc_swarm_create(sfb_sparse_qp_plan *plan, const sfb_mpc_layout *
   sfb_status st = check_layout(layout);
   if (st != SFB_OK) return st;
   if (agents < 1 || agents > 0x7FFFFFFFll) return sfb::fail(SFB_ERR_INVALID_ARG, "agents must be in [1, 2^31-1]");
-  const sfb::SparsePlanHost &h = sfb::plan_host(plan);
+  const sfb::SparsePlanHost &h = sfb::plan_io(plan);
   sfb::MpcAsmParams p, ps;
   fill_params(layout, false, p);
   fill_params(layout, true, ps);
@@ -217,10 +217,15 @@ sfb_status sfb_mpc_swarm_create(sfb_sparse_qp_plan *plan, const sfb_mpc_layout *
   S->plan = plan; S->rec_own = p; S->rec_shared = ps; S->agents = agents;
   S->n = n; S->m = p.m; S->nnzP = h.nnzP; S->nnzA = p.nnzA; S->nu = layout->nu; S->uoff = layout->nx * (p.N + 1);
   S->shared_doubles = sfb_mpc_shared_jac_doubles(layout);
-  S->wsd = sfb::qp_sparse_ws_doubles(h.n, h.m, h.nnzL, h.funits, h.bunits);
+  {
+    int64_t wsb = 0;
+    st = sfb_sparse_qp_plan_workspace_bytes(plan, agents, &wsb);
+    if (st != SFB_OK) { delete S; return st; }
+    S->wsd = ((size_t)wsb + 7) / 8;  // doubles, whole batch
+  }
   hipError_t e = hipGetDevice(&S->devid);
   const size_t B = (size_t)agents, N = (size_t)n, M = (size_t)p.m;
-  const size_t doubles = B * ((size_t)h.nnzP + N + (size_t)p.nnzA + 2 * M + 2 * (N + M) + (size_t)p.rec_doubles + (size_t)layout->nu + S->wsd) +
+  const size_t doubles = B * ((size_t)h.nnzP + N + (size_t)p.nnzA + 2 * M + 2 * (N + M) + (size_t)p.rec_doubles + (size_t)layout->nu) + S->wsd +
                          (size_t)S->shared_doubles + (size_t)h.nnzP + N;
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&S->mem), doubles * sizeof(double) + B * 12);
   if (e != hipSuccess) {
@@ -241,7 +246,7 @@ sfb_status sfb_mpc_swarm_create(sfb_sparse_qp_plan *plan, const sfb_mpc_layout *
   S->shared = d; d += S->shared_doubles;
   S->du0 = d; d += B * layout->nu;
   double *stage = d; d += h.nnzP + N;  // one copy of Px and q, replicated below
-  S->ws = d; d += B * S->wsd;
+  S->ws = d; d += S->wsd;
   S->iter = reinterpret_cast<uint32_t *>(d);
   S->code  = reinterpret_cast<int32_t *>(S->iter + B);
   S->order = S->code + B;

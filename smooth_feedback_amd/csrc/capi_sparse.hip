@@ -13,11 +13,16 @@
 #include "sparse_plan.h"
 
 struct sfb_sparse_qp_plan {
-  sfb::SparsePlanHost host;
+  sfb::SparsePlanHost host;  // what the kernel works on: the caller's pattern, or (pruned plan) its kept entries only
+  // Pruned plans (sfb_sparse_qp_plan_create_pruned): `full` is the caller's whole pattern analysed with the SAME
+  // elimination order -- the plan of the fallback launch for items whose masked entries are not all zero.
+  bool pruned = false;
+  sfb::SparsePlanHost full;
+  std::vector<int32_t> Aorig, Amasked;  // kept entry -> position in the caller's value array; masked positions
   std::mutex mu;
   struct DevCopy {
-    int32_t *blob = nullptr;
-    sfb::SparsePlanDev dev{};
+    int32_t *blob = nullptr, *blob_full = nullptr;
+    sfb::SparsePlanDev dev{}, dev_full{};
   };
   std::map<int, DevCopy> per_device;  // device ordinal -> uploaded index arrays
   // Device memory of the host-pointer entry point, kept between calls like the working memory a
@@ -30,12 +35,52 @@ struct sfb_sparse_qp_plan {
 
 namespace sfb {
 const SparsePlanHost &plan_host(const sfb_sparse_qp_plan *plan) { return plan->host; }
+const SparsePlanHost &plan_io(const sfb_sparse_qp_plan *plan) { return plan->pruned ? plan->full : plan->host; }
 }  // namespace sfb
 
 namespace {
 
-// upload all index arrays as one blob (once per device)
-sfb_status plan_on_device(sfb_sparse_qp_plan *plan, const sfb::SparsePlanDev **out)
+// upload all index arrays of one host plan as one blob
+sfb_status upload_plan(const sfb::SparsePlanHost &h, const std::vector<int32_t> *Aorig, const std::vector<int32_t> *Amasked,
+                       int nnzA_io, int32_t **blob_out, sfb::SparsePlanDev &d)
+{
+  static const std::vector<int32_t> none;
+  const std::vector<int32_t> *arrs[] = {&h.Pp, &h.Pi, &h.Pcol, &h.Ap, &h.Aj, &h.Arow, &h.Acp, &h.Aci, &h.Acpos,
+                                        &h.Prp, &h.Prj, &h.Prpos, &h.Sp, &h.Sj, &h.Spos, &h.perm, &h.pinv,
+                                        &h.Kp, &h.Ki, &h.Kdesc, &h.Lp, &h.Li, &h.Rp, &h.Rk, &h.Rpos, &h.Rlen,
+                                        &h.fmap, &h.fidx, &h.bmap, &h.bidx, &h.Kmap, &h.rptr, &h.rtgt, &h.rab, &h.snptr, &h.snR, &h.poff, &h.pmap, &h.fmask, &h.bmask,
+                                        Aorig ? Aorig : &none, Amasked ? Amasked : &none};
+  constexpr int NA = sizeof(arrs) / sizeof(arrs[0]);
+  size_t off[NA + 1];
+  off[0] = 0;
+  for (int a = 0; a < NA; ++a) off[a + 1] = off[a] + ((arrs[a]->size() + 3) / 4) * 4 + 4;  // 16-B aligned, never empty
+  std::vector<int32_t> blob(off[NA], 0);
+  for (int a = 0; a < NA; ++a) std::copy(arrs[a]->begin(), arrs[a]->end(), blob.begin() + off[a]);
+  int32_t *dblob = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&dblob), blob.size() * sizeof(int32_t));
+  if (e != hipSuccess) return sfb::hip_fail(e, "hipMalloc(plan)");
+  e = hipMemcpy(dblob, blob.data(), blob.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(dblob);
+    return sfb::hip_fail(e, "hipMemcpy(plan)");
+  }
+  d.n = h.n; d.m = h.m; d.k = h.k; d.nnzP = h.nnzP; d.nnzA = h.nnzA; d.nnzK = h.nnzK; d.nnzL = h.nnzL;
+  const int32_t **ptrs[] = {&d.Pp, &d.Pi, &d.Pcol, &d.Ap, &d.Aj, &d.Arow, &d.Acp, &d.Aci, &d.Acpos,
+                            &d.Prp, &d.Prj, &d.Prpos, &d.Sp, &d.Sj, &d.Spos, &d.perm, &d.pinv,
+                            &d.Kp, &d.Ki, &d.Kdesc, &d.Lp, &d.Li, &d.Rp, &d.Rk, &d.Rpos, &d.Rlen,
+                            &d.fmap, &d.fidx, &d.bmap, &d.bidx, &d.Kmap, &d.rptr, &d.rtgt, &d.rab, &d.snptr, &d.snR, &d.poff, &d.pmap, &d.fmask, &d.bmask,
+                            &d.Aorig, &d.Amasked};
+  d.funits = h.funits; d.bunits = h.bunits; d.ffull0 = h.ffull0; d.ffull1 = h.ffull1; d.bfull0 = h.bfull0; d.bfull1 = h.bfull1; d.idx_scale = h.idx_scale; d.rsteps = h.rsteps; d.maxcol = h.maxcol; d.nsn = h.nsn; d.lds_doubles = h.lds_doubles;
+  for (int a = 0; a < NA; ++a) *ptrs[a] = dblob + off[a];
+  d.nnzA_io = nnzA_io;
+  d.nmasked = 0;
+  if (!Aorig) d.Aorig = d.Amasked = nullptr;
+  *blob_out = dblob;
+  return SFB_OK;
+}
+
+// device copies of the plan's index arrays (once per device)
+sfb_status plan_on_device(sfb_sparse_qp_plan *plan, const sfb_sparse_qp_plan::DevCopy **out)
 {
   int devid = 0;
   hipError_t e = hipGetDevice(&devid);
@@ -43,39 +88,53 @@ sfb_status plan_on_device(sfb_sparse_qp_plan *plan, const sfb::SparsePlanDev **o
   std::lock_guard<std::mutex> lk(plan->mu);
   auto it = plan->per_device.find(devid);
   if (it != plan->per_device.end()) {
-    *out = &it->second.dev;
+    *out = &it->second;
     return SFB_OK;
   }
-  const sfb::SparsePlanHost &h = plan->host;
-  const std::vector<int32_t> *arrs[] = {&h.Pp, &h.Pi, &h.Pcol, &h.Ap, &h.Aj, &h.Arow, &h.Acp, &h.Aci, &h.Acpos,
-                                        &h.Prp, &h.Prj, &h.Prpos, &h.Sp, &h.Sj, &h.Spos, &h.perm, &h.pinv,
-                                        &h.Kp, &h.Ki, &h.Kdesc, &h.Lp, &h.Li, &h.Rp, &h.Rk, &h.Rpos, &h.Rlen,
-                                        &h.fmap, &h.fidx, &h.bmap, &h.bidx, &h.Kmap, &h.rptr, &h.rtgt, &h.rab, &h.snptr, &h.snR, &h.poff, &h.pmap, &h.fmask, &h.bmask};
-  constexpr int NA = sizeof(arrs) / sizeof(arrs[0]);
-  size_t off[NA + 1];
-  off[0] = 0;
-  for (int a = 0; a < NA; ++a) off[a + 1] = off[a] + ((arrs[a]->size() + 3) / 4) * 4 + 4;  // 16-B aligned, never empty
-  std::vector<int32_t> blob(off[NA], 0);
-  for (int a = 0; a < NA; ++a) std::copy(arrs[a]->begin(), arrs[a]->end(), blob.begin() + off[a]);
   sfb_sparse_qp_plan::DevCopy dc;
-  e = hipMalloc(reinterpret_cast<void **>(&dc.blob), blob.size() * sizeof(int32_t));
-  if (e != hipSuccess) return sfb::hip_fail(e, "hipMalloc(plan)");
-  e = hipMemcpy(dc.blob, blob.data(), blob.size() * sizeof(int32_t), hipMemcpyHostToDevice);
-  if (e != hipSuccess) {
-    (void)hipFree(dc.blob);
-    return sfb::hip_fail(e, "hipMemcpy(plan)");
+  sfb_status st;
+  if (plan->pruned) {
+    st = upload_plan(plan->host, &plan->Aorig, &plan->Amasked, plan->full.nnzA, &dc.blob, dc.dev);
+    if (st != SFB_OK) return st;
+    dc.dev.nmasked = plan->full.nnzA - plan->host.nnzA;
+    st = upload_plan(plan->full, nullptr, nullptr, plan->full.nnzA, &dc.blob_full, dc.dev_full);
+    if (st != SFB_OK) {
+      (void)hipFree(dc.blob);
+      return st;
+    }
+  } else {
+    st = upload_plan(plan->host, nullptr, nullptr, plan->host.nnzA, &dc.blob, dc.dev);
+    if (st != SFB_OK) return st;
   }
-  sfb::SparsePlanDev &d = dc.dev;
-  d.n = h.n; d.m = h.m; d.k = h.k; d.nnzP = h.nnzP; d.nnzA = h.nnzA; d.nnzK = h.nnzK; d.nnzL = h.nnzL;
-  const int32_t **ptrs[] = {&d.Pp, &d.Pi, &d.Pcol, &d.Ap, &d.Aj, &d.Arow, &d.Acp, &d.Aci, &d.Acpos,
-                            &d.Prp, &d.Prj, &d.Prpos, &d.Sp, &d.Sj, &d.Spos, &d.perm, &d.pinv,
-                            &d.Kp, &d.Ki, &d.Kdesc, &d.Lp, &d.Li, &d.Rp, &d.Rk, &d.Rpos, &d.Rlen,
-                            &d.fmap, &d.fidx, &d.bmap, &d.bidx, &d.Kmap, &d.rptr, &d.rtgt, &d.rab, &d.snptr, &d.snR, &d.poff, &d.pmap, &d.fmask, &d.bmask};
-  d.funits = h.funits; d.bunits = h.bunits; d.ffull0 = h.ffull0; d.ffull1 = h.ffull1; d.bfull0 = h.bfull0; d.bfull1 = h.bfull1; d.idx_scale = h.idx_scale; d.rsteps = h.rsteps; d.maxcol = h.maxcol; d.nsn = h.nsn; d.lds_doubles = h.lds_doubles;
-  for (int a = 0; a < NA; ++a) *ptrs[a] = dc.blob + off[a];
   auto ins = plan->per_device.emplace(devid, dc);
-  *out     = &ins.first->second.dev;
+  *out     = &ins.first->second;
   return SFB_OK;
+}
+
+// Workspace of one call.  Plain plan: batch items of the plan's per-item block.  Pruned plan: the larger of that and
+// ONE item of the fallback plan (the fallback launches reuse the memory of the first launch), then the fallback list
+// (count + batch entries).
+struct WsLayout {
+  size_t item_bytes, fb_item_bytes, main_bytes, fb_off, total;
+  int64_t fb_cap;  // items one fallback launch can hold
+};
+WsLayout ws_layout(const sfb_sparse_qp_plan *plan, int64_t batch)
+{
+  const sfb::SparsePlanHost &h = plan->host;
+  WsLayout L{};
+  L.item_bytes = sfb::qp_sparse_ws_doubles(h.n, h.m, h.nnzL, h.funits, h.bunits, plan->pruned ? h.nnzA : 0) * sizeof(double);
+  L.main_bytes = (size_t)batch * L.item_bytes;
+  if (plan->pruned) {
+    const sfb::SparsePlanHost &f = plan->full;
+    L.fb_item_bytes = sfb::qp_sparse_ws_doubles(f.n, f.m, f.nnzL, f.funits, f.bunits, 0) * sizeof(double);
+    L.main_bytes    = std::max(L.main_bytes, L.fb_item_bytes);
+    L.fb_cap        = std::max<int64_t>(1, std::min<int64_t>(batch, (int64_t)(L.main_bytes / L.fb_item_bytes)));
+    L.fb_off        = L.main_bytes;
+    L.total         = L.fb_off + (((size_t)batch + 2) * sizeof(int32_t) + 7) / 8 * 8;
+  } else {
+    L.total = L.main_bytes;
+  }
+  return L;
 }
 
 sfb_status check_sparse_args(const sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch, const void *Px,
@@ -85,7 +144,7 @@ sfb_status check_sparse_args(const sfb_sparse_qp_plan *plan, const sfb_qp_params
   if (!plan) return sfb::fail(SFB_ERR_INVALID_ARG, "plan is NULL");
   if (!prm) return sfb::fail(SFB_ERR_INVALID_ARG, "prm is NULL");
   if (batch < 0) return sfb::fail(SFB_ERR_INVALID_ARG, "batch < 0");
-  if (batch > 0 && (!q || !l || !u || !x || !y || !code || (plan->host.nnzP > 0 && !Px) || (plan->host.nnzA > 0 && !Ax)))
+  if (batch > 0 && (!q || !l || !u || !x || !y || !code || (plan->host.nnzP > 0 && !Px) || (sfb::plan_io(plan).nnzA > 0 && !Ax)))
     return sfb::fail(SFB_ERR_INVALID_ARG, "NULL problem / solution pointer");
   if ((wx == nullptr) != (wy == nullptr))
     return sfb::fail(SFB_ERR_INVALID_ARG, "warm_x and warm_y must both be given or both be NULL");
@@ -93,7 +152,7 @@ sfb_status check_sparse_args(const sfb_sparse_qp_plan *plan, const sfb_qp_params
     return sfb::fail(SFB_ERR_UNSUPPORTED, "max_time is wall-clock and not supported on the device path; use max_iter");
   if (prm->max_iter > 0xFFFFFFFFll) return sfb::fail(SFB_ERR_INVALID_ARG, "max_iter exceeds uint32");
   if (batch > 0x7FFFFFFFll) return sfb::fail(SFB_ERR_UNSUPPORTED, "batch exceeds 2^31-1 per call");
-  if ((size_t)plan->host.lds_doubles * sizeof(double) > 150 * 1024)
+  if ((size_t)std::max(plan->host.lds_doubles, plan->pruned ? plan->full.lds_doubles : 0) * sizeof(double) > 150 * 1024)
     return sfb::fail(SFB_ERR_UNSUPPORTED, "n+m too large for the LDS-resident work vector (max 19200)");
   return SFB_OK;
 }
@@ -115,16 +174,62 @@ sfb_status sfb_sparse_qp_plan_create_staged(int n, int m, const int32_t *P_colpt
                                             const int32_t *user_perm, const int32_t *stage,
                                             sfb_sparse_qp_plan **plan)
 {
+  return sfb_sparse_qp_plan_create_pruned(n, m, P_colptr, P_rowind, A_rowptr, A_colind, ordering, user_perm, stage, nullptr,
+                                          plan);
+}
+
+sfb_status sfb_sparse_qp_plan_create_pruned(int n, int m, const int32_t *P_colptr, const int32_t *P_rowind,
+                                            const int32_t *A_rowptr, const int32_t *A_colind, int ordering,
+                                            const int32_t *user_perm, const int32_t *stage, const uint8_t *A_keep,
+                                            sfb_sparse_qp_plan **plan)
+{
   if (!plan) return sfb::fail(SFB_ERR_INVALID_ARG, "plan out-pointer is NULL");
   *plan = nullptr;
   auto *p = new (std::nothrow) sfb_sparse_qp_plan();
   if (!p) return sfb::fail(SFB_ERR_INVALID_ARG, "out of memory");
   const char *msg = "";
-  if (!sfb::build_sparse_plan(n, m, P_colptr, P_rowind, A_rowptr, A_colind, ordering, user_perm, stage, p->host,
-                              &msg)) {
+  bool any_masked = false;
+  if (A_keep && n >= 1 && m >= 1 && A_rowptr && A_rowptr[0] == 0 && A_rowptr[m] >= 0)
+    for (int e = 0; e < A_rowptr[m] && !any_masked; ++e) any_masked = A_keep[e] == 0;
+  if (!any_masked) {
+    if (!sfb::build_sparse_plan(n, m, P_colptr, P_rowind, A_rowptr, A_colind, ordering, user_perm, stage, p->host, &msg)) {
+      delete p;
+      return sfb::fail(SFB_ERR_INVALID_ARG, msg);
+    }
+    *plan = p;
+    return SFB_OK;
+  }
+  // compressed pattern of A: the kept entries, in storage order
+  const int nnzA = A_rowptr[m];
+  std::vector<int32_t> Ap(m + 1, 0), Aj;
+  Aj.reserve(nnzA);
+  for (int r = 0; r < m; ++r) {
+    if (A_rowptr[r + 1] < A_rowptr[r] || A_rowptr[r + 1] > nnzA) {
+      delete p;
+      return sfb::fail(SFB_ERR_INVALID_ARG, "A row pointers not monotone");
+    }
+    for (int e = A_rowptr[r]; e < A_rowptr[r + 1]; ++e)
+      if (A_keep[e]) {
+        Aj.push_back(A_colind[e]);
+        p->Aorig.push_back(e);
+      } else {
+        p->Amasked.push_back(e);
+      }
+    Ap[r + 1] = (int32_t)Aj.size();
+  }
+  // kernel plan on the kept entries; fallback plan on the whole pattern with the SAME elimination order, so that
+  // an item's result does not depend on which of the two solved it (up to the sign of zeros)
+  bool ok = sfb::build_sparse_plan(n, m, P_colptr, P_rowind, Ap.data(), Aj.data(), ordering, user_perm, stage, p->host, &msg);
+  if (ok) ok = sfb::build_sparse_plan(n, m, P_colptr, P_rowind, A_rowptr, A_colind, ordering, p->host.perm.data(), nullptr, p->full, &msg);
+  if (!ok) {
     delete p;
     return sfb::fail(SFB_ERR_INVALID_ARG, msg);
   }
+  p->pruned = true;
+  // padding for the kernel's branch-free batches: repeat a valid position
+  const int32_t lastk = p->Aorig.empty() ? 0 : p->Aorig.back(), lastm = p->Amasked.back();
+  p->Aorig.resize(p->Aorig.size() + 512, lastk);
+  p->Amasked.resize(p->Amasked.size() + 512, lastm);
   *plan = p;
   return SFB_OK;
 }
@@ -132,8 +237,10 @@ sfb_status sfb_sparse_qp_plan_create_staged(int n, int m, const int32_t *P_colpt
 void sfb_sparse_qp_plan_destroy(sfb_sparse_qp_plan *plan)
 {
   if (!plan) return;
-  for (auto &kv : plan->per_device)
+  for (auto &kv : plan->per_device) {
     if (kv.second.blob) (void)hipFree(kv.second.blob);
+    if (kv.second.blob_full) (void)hipFree(kv.second.blob_full);
+  }
   for (auto &kv : plan->host_ws)
     if (kv.second.first) (void)hipFree(kv.second.first);
   delete plan;
@@ -145,9 +252,28 @@ sfb_status sfb_sparse_qp_plan_info(const sfb_sparse_qp_plan *plan, int64_t *nnzK
   if (!plan) return sfb::fail(SFB_ERR_INVALID_ARG, "plan is NULL");
   if (nnzK) *nnzK = plan->host.nnzK;
   if (nnzL) *nnzL = plan->host.nnzL;
-  if (workspace_bytes_per_item)
-    *workspace_bytes_per_item =
-      (int64_t)(sfb::qp_sparse_ws_doubles(plan->host.n, plan->host.m, plan->host.nnzL, plan->host.funits, plan->host.bunits) * sizeof(double));
+  if (workspace_bytes_per_item) {
+    // batch * this many bytes always suffice; sfb_sparse_qp_plan_workspace_bytes is exact (pruned plans need the
+    // room of one fallback item whatever the batch size, which this per-item figure has to include)
+    const WsLayout L1 = ws_layout(plan, 1);
+    *workspace_bytes_per_item = (int64_t)(plan->pruned ? L1.total : L1.item_bytes);
+  }
+  return SFB_OK;
+}
+
+sfb_status sfb_sparse_qp_plan_workspace_bytes(const sfb_sparse_qp_plan *plan, int64_t batch, int64_t *bytes)
+{
+  if (!plan || !bytes) return sfb::fail(SFB_ERR_INVALID_ARG, "NULL argument");
+  if (batch < 0) return sfb::fail(SFB_ERR_INVALID_ARG, "batch < 0");
+  *bytes = (int64_t)ws_layout(plan, batch).total;
+  return SFB_OK;
+}
+
+sfb_status sfb_sparse_qp_plan_pruned_info(const sfb_sparse_qp_plan *plan, int64_t *nnzA_kept, int64_t *nnzL_fallback)
+{
+  if (!plan) return sfb::fail(SFB_ERR_INVALID_ARG, "plan is NULL");
+  if (nnzA_kept) *nnzA_kept = plan->host.nnzA;
+  if (nnzL_fallback) *nnzL_fallback = plan->pruned ? plan->full.nnzL : plan->host.nnzL;
   return SFB_OK;
 }
 
@@ -170,13 +296,33 @@ sfb_status sfb_sparse_qp_solve_batch_ordered(sfb_sparse_qp_plan *plan, const sfb
   st = sfb::require_device();
   if (st != SFB_OK) return st;
   if (batch == 0) return SFB_OK;
-  const sfb::SparsePlanDev *dev = nullptr;
-  st = plan_on_device(plan, &dev);
+  const sfb_sparse_qp_plan::DevCopy *dc = nullptr;
+  st = plan_on_device(plan, &dc);
   if (st != SFB_OK) return st;
   const sfb::DenseKernelParams kp = sfb::make_kernel_params(prm, plan->host.n, plan->host.m);
-  hipError_t e = sfb::qp_sparse_launch(*dev, kp, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code,
-                                       static_cast<double *>(workspace), static_cast<hipStream_t>(stream), order);
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  if (!plan->pruned) {
+    hipError_t e = sfb::qp_sparse_launch(dc->dev, kp, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code,
+                                         static_cast<double *>(workspace), hs, order);
+    if (e != hipSuccess) return sfb::hip_fail(e, "qp_sparse_kernel launch");
+    return SFB_OK;
+  }
+  // Pruned plan: the first launch solves every item whose masked entries are zero and lists the others; the
+  // fallback launches (full pattern, same elimination order) work through the list, fb_cap items per launch,
+  // in the memory of the first.  The list is empty unless the caller's mask was wrong for an item: the fallback
+  // launches then cost a few microseconds of empty blocks.
+  const WsLayout L = ws_layout(plan, batch);
+  int32_t *fb = reinterpret_cast<int32_t *>(static_cast<char *>(workspace) + L.fb_off);
+  hipError_t e = hipMemsetAsync(fb, 0, sizeof(int32_t), hs);
+  if (e != hipSuccess) return sfb::hip_fail(e, "hipMemsetAsync");
+  e = sfb::qp_sparse_launch(dc->dev, kp, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code,
+                            static_cast<double *>(workspace), hs, order, fb, 0);
   if (e != hipSuccess) return sfb::hip_fail(e, "qp_sparse_kernel launch");
+  for (int64_t base = 0; base < batch; base += L.fb_cap) {
+    e = sfb::qp_sparse_launch(dc->dev_full, kp, std::min(L.fb_cap, batch - base), Px, q, Ax, l, u, warm_x, warm_y, x, y, obj,
+                              iter, code, static_cast<double *>(workspace), hs, nullptr, fb, 1 + (int)base);
+    if (e != hipSuccess) return sfb::hip_fail(e, "qp_sparse_kernel fallback launch");
+  }
   return SFB_OK;
 }
 
@@ -200,11 +346,11 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
   st = sfb::require_device();
   if (st != SFB_OK) return st;
   if (batch == 0) return SFB_OK;
-  const sfb::SparsePlanHost &h = plan->host;
+  const sfb::SparsePlanHost &h = sfb::plan_io(plan);  // the caller's pattern (strides of the value arrays)
   const size_t B = (size_t)batch, N = (size_t)h.n, M = (size_t)h.m, NP = (size_t)h.nnzP, NA = (size_t)h.nnzA;
-  const size_t wsd  = sfb::qp_sparse_ws_doubles(h.n, h.m, h.nnzL, h.funits, h.bunits);
+  const size_t wsb  = ws_layout(plan, batch).total;  // multiple of 8
   const size_t in_d = B * (NP + N + NA + 2 * M) + (warm_x ? B * (N + M) : 0), out_d = B * (N + M + 1);
-  const size_t bytes = (in_d + out_d + B * wsd) * sizeof(double) + B * 8;
+  const size_t bytes = (in_d + out_d) * sizeof(double) + wsb + B * 8;
   int devid    = 0;
   hipError_t e = hipGetDevice(&devid);
   if (e != hipSuccess) return sfb::hip_fail(e, "hipGetDevice");
@@ -226,7 +372,7 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
   double *dwx = nullptr, *dwy = nullptr, *dx = du + B * M;
   if (warm_x) { dwx = dx; dwy = dwx + B * N; dx = dwy + B * M; }
   double *dy = dx + B * N, *dobj = dy + B * M, *dws = dobj + B;
-  uint32_t *dit  = reinterpret_cast<uint32_t *>(dws + B * wsd);
+  uint32_t *dit  = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(dws) + wsb);
   int32_t *dcode = reinterpret_cast<int32_t *>(dit + B);
   auto H2D = [&](void *d, const void *hh, size_t nb) { return nb ? hipMemcpy(d, hh, nb, hipMemcpyHostToDevice) : hipSuccess; };
   auto D2H = [&](void *hh, const void *d, size_t nb) { return nb ? hipMemcpy(hh, d, nb, hipMemcpyDeviceToHost) : hipSuccess; };

@@ -42,6 +42,7 @@ struct Ws {
   double *Lx, *LxF, *LxB, *D, *Dinv, *tv;  // Lx, D and one scratch double are contiguous (accumulators)
   double *sx, *qc, *xs, *xus, *dxus;
   double *sy, *rho, *rinv, *lo, *hi, *ys, *zs, *yus, *zus, *dyus, *act;
+  double *Axc;  // pruned plans: the item's kept entries of A, compacted (qp_sparse_kernel.h)
 };
 
 __device__ __forceinline__ Ws carve_ws(double *base, int n, int m, int nnzL, int funits, int bunits)
@@ -60,6 +61,7 @@ __device__ __forceinline__ Ws carve_ws(double *base, int n, int m, int nnzL, int
   w.sy = p; p += m;     w.rho = p; p += m;    w.rinv = p; p += m; w.lo = p; p += m;   w.hi = p; p += m;
   w.ys = p; p += m;     w.zs = p; p += m;     w.yus = p; p += m;  w.zus = p; p += m;  w.dyus = p; p += m;
   w.act = p; p += m;
+  w.Axc = p;
   return w;
 }
 
@@ -775,36 +777,59 @@ __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const 
   wave_sync();
 }
 
-}  // namespace
+__device__ int g_sparse_active = 0;  // resident waves of qp_sparse_kernel (all launches of the process), see the kernel
 
-__device__ int g_sparse_active = 0;  // resident waves of qp_sparse_kernel (all launches), see the kernel
-
-__global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl, const DenseKernelParams kp,
-                                                       const double *__restrict__ gPx, const double *__restrict__ gq,
-                                                       const double *__restrict__ gAx, const double *__restrict__ gl,
-                                                       const double *__restrict__ gu, const double *__restrict__ gwx,
-                                                       const double *__restrict__ gwy, double *__restrict__ gx,
-                                                       double *__restrict__ gy, double *__restrict__ gobj,
-                                                       uint32_t *__restrict__ giter, int32_t *__restrict__ gcode,
-                                                       double *__restrict__ gws, const size_t ws_doubles,
-                                                       const int lean_waves, const int32_t *__restrict__ order)
+// One item, start to finish.  `slot` = workspace slot of this launch position.  Returns false when the item was
+// handed to the fallback list (pruned plan, a masked entry of A is not zero) and left unsolved.
+__device__ __forceinline__ bool sp_solve_item(const SparsePlanDev &pl, const DenseKernelParams &kp, const double *__restrict__ gPx,
+                                              const double *__restrict__ gq, const double *__restrict__ gAx,
+                                              const double *__restrict__ gl, const double *__restrict__ gu,
+                                              const double *__restrict__ gwx, const double *__restrict__ gwy,
+                                              double *__restrict__ gx, double *__restrict__ gy, double *__restrict__ gobj,
+                                              uint32_t *__restrict__ giter, int32_t *__restrict__ gcode,
+                                              double *__restrict__ gws, const size_t ws_doubles, const int lean_waves,
+                                              bool lean, const size_t b, const size_t slot, int32_t *__restrict__ fb,
+                                              double *t, const int lane)
 {
-  extern __shared__ __attribute__((aligned(16))) double t[];  // k + 1 doubles: work / solution vector
-  const int lane = threadIdx.x;
-  // Waves of this kernel resident on the device right now.  While there are many, the launch is HBM-bound and the
-  // sweeps skip the padding of the factor stream (masked loads: fewer bytes, a few more instructions); when only
-  // stragglers are left, latency is what counts and they switch to plain loads.  A heuristic only: both forms
-  // compute the same thing.
-  int seen = 0;
-  if (lane == 0) seen = atomicAdd(&g_sparse_active, 1);
-  bool lean = (gridDim.x > (unsigned)lean_waves) || __builtin_amdgcn_readfirstlane(seen) >= lean_waves;
   const int n = pl.n, m = pl.m, k = pl.k;
-  // launch position -> item: with `order` the caller puts the items it expects to iterate longest first, so that
-  // they run alongside the bulk of the batch instead of finishing alone (the workspace stays per launch position)
-  const size_t b = order ? (size_t)order[blockIdx.x] : (size_t)blockIdx.x;
-  const Item it{gPx + b * (size_t)pl.nnzP, gq + b * (size_t)n, gAx + b * (size_t)pl.nnzA, gl + b * (size_t)m,
-                gu + b * (size_t)m};
-  const Ws w = carve_ws(gws + (size_t)blockIdx.x * ws_doubles, n, m, pl.nnzL, pl.funits, pl.bunits);
+  Item it{gPx + b * (size_t)pl.nnzP, gq + b * (size_t)n, gAx + b * (size_t)pl.nnzA_io, gl + b * (size_t)m,
+          gu + b * (size_t)m};
+  const Ws w = carve_ws(gws + slot * ws_doubles, n, m, pl.nnzL, pl.funits, pl.bunits);
+  if (pl.Aorig != nullptr) {
+    // Pruned plan.  GUARD: the entries of A the plan's creator declared structurally zero must be zero (NaN counts
+    // as non-zero) -- otherwise the item goes to the fallback list and is solved on the full pattern by the second
+    // launch of the call.  Then the kept entries are compacted into the workspace: everything below works on the
+    // compressed pattern.  (Amasked / Aorig are padded: branch-free batches.)
+    constexpr int UB = 8;
+    bool bad = false;
+    for (int p0 = lane; p0 < pl.nmasked; p0 += kWave * UB) {
+      int src[UB];
+      double v[UB];
+#pragma unroll
+      for (int e = 0; e < UB; ++e) src[e] = pl.Amasked[p0 + e * kWave];
+#pragma unroll
+      for (int e = 0; e < UB; ++e) v[e] = it.Ax[src[e]];
+#pragma unroll
+      for (int e = 0; e < UB; ++e) bad = bad || !(v[e] == 0.0);
+    }
+    if (wave_ballot(bad)) {
+      if (lane == 0) fb[1 + atomicAdd(&fb[0], 1)] = (int32_t)b;
+      return false;
+    }
+    for (int p0 = lane; p0 < pl.nnzA; p0 += kWave * UB) {
+      int src[UB];
+      double v[UB];
+#pragma unroll
+      for (int e = 0; e < UB; ++e) src[e] = pl.Aorig[p0 + e * kWave];
+#pragma unroll
+      for (int e = 0; e < UB; ++e) v[e] = it.Ax[src[e]];
+#pragma unroll
+      for (int e = 0; e < UB; ++e)
+        if (p0 + e * kWave < pl.nnzA) w.Axc[p0 + e * kWave] = v[e];
+    }
+    it.Ax = w.Axc;
+    wave_sync();
+  }
   if (lane == 0) t[k] = 0.0;  // padding slot of the packed sweeps
   const double inf = INFINITY;
 
@@ -1126,22 +1151,60 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
   if (lane == 0) {
     gcode[b] = (ret_code >= 0) ? ret_code : SFB_QP_MAX_ITERATIONS;
     if (giter != nullptr) giter[b] = iter;
-    atomicSub(&g_sparse_active, 1);
   }
+  return true;
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl, const DenseKernelParams kp,
+                                                       const double *__restrict__ gPx, const double *__restrict__ gq,
+                                                       const double *__restrict__ gAx, const double *__restrict__ gl,
+                                                       const double *__restrict__ gu, const double *__restrict__ gwx,
+                                                       const double *__restrict__ gwy, double *__restrict__ gx,
+                                                       double *__restrict__ gy, double *__restrict__ gobj,
+                                                       uint32_t *__restrict__ giter, int32_t *__restrict__ gcode,
+                                                       double *__restrict__ gws, const size_t ws_doubles,
+                                                       const int lean_waves, const int32_t *__restrict__ order,
+                                                       int32_t *__restrict__ fb, const int fb_mode)
+{
+  extern __shared__ __attribute__((aligned(16))) double t[];  // k + 1 doubles: work / solution vector
+  const int lane = threadIdx.x;
+  // fallback launch: block i takes entry fb_mode - 1 + i of the list the first launch of the call has written
+  int pos = blockIdx.x;
+  if (fb_mode != 0) {
+    pos += fb_mode - 1;
+    if (pos >= __builtin_amdgcn_readfirstlane(fb[0])) return;
+  }
+  // Waves of this kernel resident on the device right now.  While there are many, the launch is HBM-bound and the
+  // sweeps skip the padding of the factor stream (masked loads: fewer bytes, a few more instructions); when only
+  // stragglers are left, latency is what counts and they switch to plain loads.  A heuristic only: both forms
+  // compute the same thing.  (The counter is balanced by every wave that exits; it is shared by all launches of the
+  // process on purpose -- independent batches on other streams fill the chip just the same.)
+  int seen = 0;
+  if (lane == 0) seen = atomicAdd(&g_sparse_active, 1);
+  const bool lean = (gridDim.x > (unsigned)lean_waves) || __builtin_amdgcn_readfirstlane(seen) >= lean_waves;
+  // launch position -> item: with `order` the caller puts the items it expects to iterate longest first, so that
+  // they run alongside the bulk of the batch instead of finishing alone (the workspace stays per launch position)
+  const size_t b = fb_mode != 0 ? (size_t)fb[1 + pos] : (order ? (size_t)order[pos] : (size_t)pos);
+  sp_solve_item(pl, kp, gPx, gq, gAx, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode, gws, ws_doubles, lean_waves, lean, b,
+                (size_t)blockIdx.x, fb, t, lane);
+  if (lane == 0) atomicSub(&g_sparse_active, 1);
 }
 
 hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp, int64_t batch, const double *Px,
                             const double *q, const double *Ax, const double *l, const double *u, const double *wx,
                             const double *wy, double *x, double *y, double *obj, uint32_t *iter, int32_t *code,
-                            double *workspace, hipStream_t stream, const int32_t *order)
+                            double *workspace, hipStream_t stream, const int32_t *order, int32_t *fb, int fb_mode)
 {
+  if ((pl.Aorig != nullptr || fb_mode != 0) && fb == nullptr) return hipErrorInvalidValue;
   const size_t lds = (size_t)pl.lds_doubles * sizeof(double);
-  const size_t wsd = qp_sparse_ws_doubles(pl.n, pl.m, pl.nnzL, pl.funits, pl.bunits);
+  const size_t wsd = qp_sparse_ws_doubles(pl);
   // below this many resident waves the sweeps use plain loads (see the kernel); SFB_SP_LEAN_WAVES overrides (tuning)
   const char *lw        = getenv("SFB_SP_LEAN_WAVES");
   const int lean_waves  = lw ? atoi(lw) : 512;
   hipLaunchKernelGGL(qp_sparse_kernel, dim3((unsigned)batch), dim3(kWave), lds, stream, pl, kp, Px, q, Ax, l, u, wx,
-                     wy, x, y, obj, iter, code, workspace, wsd, lean_waves, order);
+                     wy, x, y, obj, iter, code, workspace, wsd, lean_waves, order, fb, fb_mode);
   return hipGetLastError();
 }
 

@@ -26,21 +26,40 @@ struct SparsePlanDev {
   int rsteps, maxcol;
   const int32_t *snptr, *snR, *poff, *pmap;  // (relaxed) supernodes of the factorisation and their panel maps
   int nsn, lds_doubles;
+  // Pruned plans (sfb_sparse_qp_plan_create_pruned): the arrays above describe the COMPRESSED pattern of A (kept
+  // entries only, nnzA of them); the caller's value array still has nnzA_io entries per item.  Aorig[p] = position
+  // of kept entry p in the caller's array, Amasked[0..nmasked) = positions of the entries declared zero (padded by
+  // 512 entries that repeat the last one).  Aorig == nullptr: no mask, the kernel reads the caller's array directly.
+  int nnzA_io, nmasked;
+  const int32_t *Aorig, *Amasked;
 };
 
 // per-item workspace, in doubles
 constexpr int kSweepPadDev = 16;  // == SparsePlanHost::kSweepPad
-inline size_t qp_sparse_ws_doubles(int n, int m, int nnzL, int funits, int bunits)
+inline size_t qp_sparse_ws_doubles(int n, int m, int nnzL, int funits, int bunits, int nnzA_compact = 0)
 {
   const size_t k = (size_t)n + m;
-  return (size_t)nnzL + (size_t)(funits + bunits + 2 * kSweepPadDev) * 128 + 3 * k + 6 * (size_t)n + 12 * (size_t)m + 8;
+  // nnzA_compact: kept entries of A of a pruned plan (the kernel compacts the item's values into its workspace)
+  return (size_t)nnzL + (size_t)(funits + bunits + 2 * kSweepPadDev) * 128 + 3 * k + 6 * (size_t)n + 12 * (size_t)m + 8 +
+         (((size_t)nnzA_compact + 1) & ~(size_t)1);
   // (accumulator layout of the factorisation: [L values | D | scratch | zero] is contiguous at the start of the block,
   //  followed by the forward- and backward-sweep copies of the factor)
 }
 
+inline size_t qp_sparse_ws_doubles(const SparsePlanDev &pl)
+{
+  return qp_sparse_ws_doubles(pl.n, pl.m, pl.nnzL, pl.funits, pl.bunits, pl.Aorig ? pl.nnzA : 0);
+}
+
+// One launch over `batch` items (launch position -> item through `order`, nullable).
+//   fb (nullable unless the plan is pruned or fb_mode != 0): fallback list of the call, fb[0] = count,
+//   fb[1 + i] = item.  fb_mode 0: a pruned plan appends the items whose masked entries are not all zero and leaves
+//   them unsolved; fb_mode 1: `pl` is the fallback plan (full pattern), the grid of `batch` blocks works through the
+//   list (block i takes entries i, i + batch, ...), the workspace holds `batch` items of THIS plan.
 hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp, int64_t batch, const double *Px,
                             const double *q, const double *Ax, const double *l, const double *u, const double *wx,
                             const double *wy, double *x, double *y, double *obj, uint32_t *iter, int32_t *code,
-                            double *workspace, hipStream_t stream, const int32_t *order = nullptr);
+                            double *workspace, hipStream_t stream, const int32_t *order = nullptr, int32_t *fb = nullptr,
+                            int fb_mode = 0);
 
 }  // namespace sfb

@@ -222,22 +222,40 @@ class SparseQPPlan:
     """Symbolic analysis shared by a batch: QPSolver::analyze + SimplicialLDLT::analyzePattern
     (qp_solver.hpp:297-338, :424).  Host-only; owns an sfb_sparse_qp_plan."""
 
-    def __init__(self, n, m, P_colptr, P_rowind, A_rowptr, A_colind, ordering=1, user_perm=None, stage=None):
+    def __init__(self, n, m, P_colptr, P_rowind, A_rowptr, A_colind, ordering=1, user_perm=None, stage=None,
+                 keep=None):
+        """keep (nnzA bools, optional): False = the stored entry of A is zero in every item solved with this plan
+        (sfb_sparse_qp_plan_create_pruned: analysed without it, checked per item on the device, whole-pattern
+        fallback for items that violate it)."""
         self.n, self.m = int(n), int(m)
         self._keep = [np.ascontiguousarray(a, dtype=np.int32) for a in (P_colptr, P_rowind, A_rowptr, A_colind)]
         up = None if user_perm is None else np.ascontiguousarray(user_perm, dtype=np.int32)
         st = None if stage is None else np.ascontiguousarray(stage, dtype=np.int32)
         if st is not None and st.shape != (self.n + self.m,):
             raise ValueError("stage must have n+m entries")
+        kp = None
+        if keep is not None:
+            kp = np.ascontiguousarray(np.asarray(keep) != 0, dtype=np.uint8)
+            if kp.shape != (int(self._keep[2][-1]),):
+                raise ValueError("keep must have nnzA entries")
         h = C.c_void_p()
-        _capi.check(_capi.lib.sfb_sparse_qp_plan_create_staged(
+        _capi.check(_capi.lib.sfb_sparse_qp_plan_create_pruned(
             self.n, self.m, *[_ptr(a) if a.size else None for a in self._keep], int(ordering), _ptr(up), _ptr(st),
-            C.byref(h)))
+            _ptr(kp), C.byref(h)))
         self._h = h
         a, b, c_ = C.c_int64(), C.c_int64(), C.c_int64()
         _capi.check(_capi.lib.sfb_sparse_qp_plan_info(h, C.byref(a), C.byref(b), C.byref(c_)))
         self.nnzK, self.nnzL, self.workspace_bytes_per_item = a.value, b.value, c_.value
         self.nnzP, self.nnzA = int(self._keep[0][-1]), int(self._keep[2][-1])
+        _capi.check(_capi.lib.sfb_sparse_qp_plan_pruned_info(h, C.byref(a), C.byref(b)))
+        self.nnzA_kept, self.nnzL_fallback = a.value, b.value
+        self.pruned = self.nnzA_kept != self.nnzA
+
+    def workspace_bytes(self, batch):
+        """Exact device workspace of one call (sfb_sparse_qp_plan_workspace_bytes)."""
+        v = C.c_int64()
+        _capi.check(_capi.lib.sfb_sparse_qp_plan_workspace_bytes(self._h, int(batch), C.byref(v)))
+        return v.value
 
     @classmethod
     def from_scipy(cls, P, A, **kw):

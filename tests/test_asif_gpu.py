@@ -3,7 +3,7 @@ the front hands to libsfb.so re-solved by the dense CPU oracle.  Needs an MI355X
 import numpy as np
 import pytest
 
-import models_lib as M
+from examples import models_lib as M
 
 pytestmark = pytest.mark.gpu
 

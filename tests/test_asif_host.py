@@ -4,7 +4,7 @@ own test (tests/test_asif.cpp:37-95), plus that test's structural assertions.  N
 import numpy as np
 import pytest
 
-import models_lib as M
+from examples import models_lib as M
 
 
 def se2_exp(a):

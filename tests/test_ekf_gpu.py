@@ -103,7 +103,7 @@ def test_cpp_front_mirrors_reference_ekf_checks(sfb):
     """include/smooth_feedback_amd/ekf.hpp (EKF<G>::predict/update over the C-ABI): PredictTimeCut
     (tests/test_ekf.cpp:155-180), UpdateLinear (:50-103) and an SE2 predict/update/predict run."""
     import ctypes as C
-    import models_lib as M
+    from examples import models_lib as M
     err = np.zeros(3)
     assert M.lib().sfbx_test_ekf(err.ctypes.data_as(C.c_void_p)) == 0
     assert err[0] < 1e-12 and err[1] < 1e-6 and err[2] < 1e-12, err
@@ -134,7 +134,7 @@ def test_cpp_front_predict_linear_with_rk4(sfb):
     1e-3, estimate and covariance against expm.  The reference asserts 1e-3 relative."""
     import ctypes as C
     import scipy.linalg as sl
-    import models_lib as M
+    from examples import models_lib as M
     rng = np.random.default_rng(77)
     A3, A6 = rng.uniform(-1, 1, (3, 3)), rng.uniform(-1, 1, (6, 6))
     F3, F6 = sl.expm(0.7 * A3), sl.expm(0.7 * A6)

@@ -4,7 +4,7 @@ cold and warm-started.  Needs an MI355X."""
 import numpy as np
 import pytest
 
-import models_lib as M
+from examples import models_lib as M
 
 pytestmark = pytest.mark.gpu
 

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-import models_lib as M
+from examples import models_lib as M
 
 
 def assemble_from_records(L, rec, shared=None):

@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-import models_lib as M
+from examples import models_lib as M
 from test_qp_dense_gpu import _compare, _oracle_params
 
 pytestmark = pytest.mark.gpu
@@ -60,6 +60,67 @@ def test_mpc_qp_batch_matches_oracle(sfb, oracle, variant, K, batch, sweep_mode)
     assert r2.iter.mean() <= r.iter.mean()
 
 
+@pytest.mark.parametrize("variant,K,batch", [(6, 10, 48), (6, 50, 32), (12, 50, 24)])
+def test_mpc_pruned_plan_equals_whole_pattern_oracle(sfb, oracle, variant, K, batch, sweep_mode):
+    """sfb_sparse_qp_plan_create_pruned: the kernel analyses only the stored entries of A that are non-zero in a
+    sample of the batch (the rest are explicit zeros of ocp_to_qp's dense Jacobian blocks) and must reproduce the
+    oracle run on the WHOLE stored pattern with the same elimination order: codes, iterations, primal, dual and
+    objective compare equal (numpy equality: zeros may differ in sign).  Cold and warm start."""
+    d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
+    Av, l, u = M.mpc_assemble_batch(variant, K, batch, seed=3)
+    Px = np.tile(Pv, (batch, 1))
+    q = np.zeros((batch, d["n"]))
+    keep = np.any(Av[:8] != 0.0, axis=0)          # probe a few agents; the device guard covers the rest
+    plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K), keep=keep)
+    assert plan.pruned and plan.nnzL < plan.nnzL_fallback
+    prm = sfb.QPSolverParams(max_iter=4000)
+    op = _oracle_params(oracle, prm)
+    r = plan.solve_batch_host(Px, q, Av, l, u, prm)
+    ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l, u, perm=plan.perm, params=op, nthreads=8)
+    assert ref["nnzL"] == plan.nnzL_fallback
+    for a, b in ((r.code, ref["code"]), (r.iter, ref["iter"]), (r.primal, ref["x"]), (r.dual, ref["y"]),
+                 (r.objective, ref["obj"])):
+        assert np.array_equal(a, b)
+    assert (r.code == 0).all()
+    l2, u2 = l + 1e-3 * (l == u), u + 1e-3 * (l == u)
+    r2 = plan.solve_batch_host(Px, q, Av, l2, u2, prm, warm_x=r.primal, warm_y=r.dual)
+    ref2 = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l2, u2, perm=plan.perm, params=op, warm_x=ref["x"],
+                                        warm_y=ref["y"], nthreads=8)
+    for a, b in ((r2.code, ref2["code"]), (r2.iter, ref2["iter"]), (r2.primal, ref2["x"]), (r2.dual, ref2["y"])):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("batch,nbad", [(1, 1), (40, 7), (40, 40), (300, 3)])
+def test_pruned_plan_guard_falls_back_to_the_whole_pattern(sfb, oracle, batch, nbad):
+    """Items whose masked entries are NOT all zero are detected on the device and solved on the whole pattern by
+    the fallback launches of the same call (same elimination order); the other items of the batch are unaffected.
+    Every item equals the whole-pattern oracle.  Batch sizes cover: one item (the fallback item needs more
+    workspace than the pruned one), several fallback launches (workspace of the first launch reused), all items bad."""
+    variant, K = 6, 10
+    d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
+    Av, l, u = M.mpc_assemble_batch(variant, K, batch, seed=11)
+    keep = np.any(Av != 0.0, axis=0)
+    plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K), keep=keep)
+    rng = np.random.default_rng(5)
+    bad = rng.choice(batch, nbad, replace=False)
+    masked = np.nonzero(~keep)[0]
+    for b in bad:                                   # a few masked entries become non-zero (one of them NaN-free but tiny)
+        for e in rng.choice(masked, 3, replace=False):
+            Av[b, e] = rng.uniform(-0.3, 0.3)
+    Px, q = np.tile(Pv, (batch, 1)), np.zeros((batch, d["n"]))
+    prm = sfb.QPSolverParams(max_iter=4000)
+    r = plan.solve_batch_host(Px, q, Av, l, u, prm)
+    ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l, u, perm=plan.perm,
+                                       params=_oracle_params(oracle, prm), nthreads=8)
+    for a, b in ((r.code, ref["code"]), (r.iter, ref["iter"]), (r.primal, ref["x"]), (r.dual, ref["y"]),
+                 (r.objective, ref["obj"])):
+        assert np.array_equal(a, b, equal_nan=True)
+    # the perturbed items really are different problems (the guard had something to catch)
+    plain = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, user_perm=plan.perm)
+    rp = plain.solve_batch_host(Px, q, Av, l, u, prm)
+    assert np.array_equal(rp.primal, r.primal, equal_nan=True) and np.array_equal(rp.iter, r.iter)
+
+
 def test_mpc_closed_loop_like_reference_test(sfb):
     """tests/test_mpc.cpp:83-117: Optimal on consecutive calls, u1 ~ u2 ~ u3 with and without warm start,
     trajectory sizes."""
@@ -99,7 +160,7 @@ def test_launch_order_does_not_change_results(sfb):
     dev = torch.device("cuda:0")
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     dPx, dq, dAx, dl, du = T(np.tile(Pv, (B, 1))), T(np.zeros((B, d["n"]))), T(Av), T(l), T(u)
-    ws = torch.empty(B * plan.workspace_bytes_per_item // 8, dtype=torch.float64, device=dev)
+    ws = torch.empty((plan.workspace_bytes(B) + 7) // 8, dtype=torch.float64, device=dev)
     out = []
     rng = np.random.default_rng(0)
     for order in (None, np.arange(B, dtype=np.int32)[::-1].copy(), rng.permutation(B).astype(np.int32)):

@@ -4,7 +4,7 @@ sizes, and the transcription values against an independent numpy restatement of
 ocp_to_qp_update_dyn/cr/ce (ocp_to_qp.hpp:198-373) for the SE2xR3 vehicle.  CPU only."""
 import numpy as np
 
-import models_lib as M
+from examples import models_lib as M
 
 
 def test_lie_group_identities():

@@ -84,3 +84,56 @@ def test_plan_rejects_malformed_patterns(sfb):
         sfb.SparseQPPlan(2, 2, [0, 1, 2], [0, 1], [0, 2, 3], [1, 0, 1])       # unsorted row of A
     with pytest.raises(sfb._capi.SfbError):
         sfb.SparseQPPlan(2, 2, [0, 1, 2], [0, 1], [0, 1, 2], [0, 1], user_perm=[0, 0, 1, 2])
+
+
+def _compress(Ap, Aj, keep):
+    rows = np.repeat(np.arange(len(Ap) - 1), np.diff(Ap))
+    cnt = np.zeros(len(Ap), np.int64)
+    np.add.at(cnt, rows[keep] + 1, 1)
+    return np.cumsum(cnt).astype(np.int32), np.ascontiguousarray(Aj[keep])
+
+
+@pytest.mark.parametrize("variant,K,B", [(6, 10, 12), (12, 50, 6)])
+def test_explicit_zeros_can_be_left_out_of_the_analysis(oracle, sfb, variant, K, B):
+    """The exactness argument behind sfb_sparse_qp_plan_create_pruned, checked on the CPU: ocp_to_qp stores dense
+    Jacobian blocks (block_add, utils/sparse.hpp:33-50; ocp_to_qp.hpp:258-264), most of whose entries are 0.0 in
+    every agent.  Solving on the kept entries only gives the results of the whole stored pattern under the same
+    elimination order: codes, iterations, primal, dual, objective all compare equal (zeros may differ in sign)."""
+    from examples import models_lib as M
+    d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
+    Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=3)
+    keep = np.any(Av != 0.0, axis=0)
+    assert keep.sum() < 0.5 * keep.size           # the headline pattern: 4 076 of 12 832 stored entries
+    plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K), keep=keep)
+    whole = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K))
+    assert plan.pruned and not whole.pruned
+    assert plan.nnzA == keep.size and plan.nnzA_kept == int(keep.sum())
+    assert plan.nnzL < 0.5 * whole.nnzL
+    if (variant, K) == (12, 50):
+        assert (whole.nnzL, plan.nnzL) == (41030, 13710)
+    # workspace: exact requirement of a call vs the per-item bound
+    assert plan.workspace_bytes(1) <= plan.workspace_bytes_per_item
+    assert plan.workspace_bytes(4096) <= 4096 * plan.workspace_bytes_per_item
+    assert plan.workspace_bytes(4096) < whole.workspace_bytes(4096)
+    Ap2, Aj2 = _compress(Ap, Aj, keep)
+    Px, q = np.tile(Pv, (B, 1)), np.zeros((B, d["n"]))
+    prm = oracle.default_params(max_iter=4000)
+    full = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l, u, perm=plan.perm, params=prm, nthreads=4)
+    comp = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap2, Aj2, np.ascontiguousarray(Av[:, keep]), l, u,
+                                        perm=plan.perm, params=prm, nthreads=4)
+    assert full["nnzL"] == plan.nnzL_fallback and comp["nnzL"] == plan.nnzL
+    for key in ("code", "iter", "x", "y", "obj"):
+        assert np.array_equal(full[key], comp[key]), key
+    assert (full["code"] == 0).all()
+
+
+def test_pruned_plan_argument_checks(sfb):
+    Pp, Pi, Ap, Aj = [0, 1, 2], [0, 1], [0, 2, 4], [0, 1, 0, 1]
+    with pytest.raises(ValueError):
+        sfb.SparseQPPlan(2, 2, Pp, Pi, Ap, Aj, keep=[1, 0, 1])           # wrong length
+    p = sfb.SparseQPPlan(2, 2, Pp, Pi, Ap, Aj, keep=[1, 1, 1, 1])           # nothing masked: a plain plan
+    assert not p.pruned and p.nnzA_kept == 4
+    p = sfb.SparseQPPlan(2, 2, Pp, Pi, Ap, Aj, keep=[1, 0, 0, 1])
+    assert p.pruned and p.nnzA_kept == 2 and p.nnzL <= p.nnzL_fallback
+    p = sfb.SparseQPPlan(2, 2, Pp, Pi, Ap, Aj, keep=[0, 0, 0, 0])           # every stored entry declared zero
+    assert p.pruned and p.nnzA_kept == 0
