@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <optional>
 #include <random>
 #include <thread>
@@ -221,7 +222,8 @@ int sfbx_mpc_pattern(int variant, int K, double tf, int32_t * Pp, int32_t * Pi, 
 int sfbx_mpc_stage(int variant, int K, int32_t * stage)
 {
   auto fill = [&](const auto & mpc) {
-    const auto st = mpc.elimination_stage();
+    const char * flat = getenv("SFB_MPC_STAGE");  // A/B knob: "flat" = separators eliminated as a chain
+    const auto st = mpc.elimination_stage(!(flat && flat[0] == 'f'));
     std::copy(st.begin(), st.end(), stage);
     return 0;
   };

@@ -101,15 +101,34 @@ public:
   const Mesh & mesh() const { return mesh_; }
   const MPCParams & params() const { return prm_; }
   SparseQPSolver & solver() { return *solver_; }
-  /// Elimination stages for the solver's constrained minimum-degree order: the states shared by
-  /// neighbouring mesh intervals (x at nodes 0, Kmesh, 2 Kmesh, ..., N) and the rows pinning x_0 are
-  /// eliminated last, everything interior to an interval first.
-  std::vector<int32_t> elimination_stage() const
+  /// Elimination stages for the solver's constrained minimum-degree order (unknowns of a lower stage are eliminated
+  /// before any of a higher stage).  Stage 0: everything interior to a mesh interval -- the intervals decouple once
+  /// the states they share (x at nodes 0, Kmesh, 2 Kmesh, ..., N: the separators) are held back.  The separators,
+  /// a block-tridiagonal chain after the interiors are gone, are ordered by NESTED DISSECTION of the chain (middle
+  /// separator last, recursively): the dependent chain of the triangular sweeps then grows with the logarithm of
+  /// the number of intervals instead of linearly (headline problem: 161 + 119 sweep steps instead of 213 + 189 for
+  /// 8 % more entries in L).  The rows pinning x_0 go with separator 0.  nested == false: all separators in one
+  /// stage (eliminated as a chain).
+  std::vector<int32_t> elimination_stage(bool nested = true) const
   {
     std::vector<int32_t> st(nvar() + ncon(), 0);
-    for (int node = 0; node <= N(); node += Kmesh)
-      for (int c = 0; c < Nx; ++c) st[node * Nx + c] = 1;
-    for (int d = 0; d < Nx; ++d) st[nvar() + cecon_B() + d] = 1;
+    const int nsep = N() / Kmesh + 1;
+    std::vector<int32_t> lv(nsep, 1);
+    if (nested) {
+      int depth = 1;
+      while ((1 << depth) - 1 < nsep) ++depth;  // levels of the dissection tree
+      std::function<void(int, int, int)> rec = [&](int lo, int hi, int level) {
+        if (lo > hi) return;
+        const int mid = (lo + hi) / 2;
+        lv[mid]       = level;
+        rec(lo, mid - 1, level - 1);
+        rec(mid + 1, hi, level - 1);
+      };
+      rec(0, nsep - 1, depth);
+    }
+    for (int s = 0; s < nsep; ++s)
+      for (int c = 0; c < Nx; ++c) st[s * Kmesh * Nx + c] = lv[s];
+    for (int d = 0; d < Nx; ++d) st[nvar() + cecon_B() + d] = lv[0];
     return st;
   }
   /// OR the non-zero entries of A at (t, x) into keep (one byte per stored entry of A).

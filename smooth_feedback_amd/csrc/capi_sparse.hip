@@ -54,7 +54,8 @@ sfb_status upload_plan(const sfb::SparsePlanHost &h, const std::vector<int32_t> 
   size_t off[NA + 1];
   off[0] = 0;
   for (int a = 0; a < NA; ++a) off[a + 1] = off[a] + ((arrs[a]->size() + 3) / 4) * 4 + 4;  // 16-B aligned, never empty
-  std::vector<int32_t> blob(off[NA], 0);
+  const size_t self_words = (sizeof(sfb::SparsePlanDev) + 15) / 16 * 4;               // the struct itself, at the end
+  std::vector<int32_t> blob(off[NA] + self_words, 0);
   for (int a = 0; a < NA; ++a) std::copy(arrs[a]->begin(), arrs[a]->end(), blob.begin() + off[a]);
   int32_t *dblob = nullptr;
   hipError_t e = hipMalloc(reinterpret_cast<void **>(&dblob), blob.size() * sizeof(int32_t));
@@ -73,8 +74,14 @@ sfb_status upload_plan(const sfb::SparsePlanHost &h, const std::vector<int32_t> 
   d.funits = h.funits; d.bunits = h.bunits; d.ffull0 = h.ffull0; d.ffull1 = h.ffull1; d.bfull0 = h.bfull0; d.bfull1 = h.bfull1; d.idx_scale = h.idx_scale; d.rsteps = h.rsteps; d.maxcol = h.maxcol; d.nsn = h.nsn; d.lds_doubles = h.lds_doubles;
   for (int a = 0; a < NA; ++a) *ptrs[a] = dblob + off[a];
   d.nnzA_io = nnzA_io;
-  d.nmasked = 0;
+  d.nmasked = Amasked ? (int)Amasked->size() - 512 : 0;  // without the padding
   if (!Aorig) d.Aorig = d.Amasked = nullptr;
+  d.self = reinterpret_cast<const sfb::SparsePlanDev *>(dblob + off[NA]);
+  e      = hipMemcpy(dblob + off[NA], &d, sizeof(d), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(dblob);
+    return sfb::hip_fail(e, "hipMemcpy(plan struct)");
+  }
   *blob_out = dblob;
   return SFB_OK;
 }
@@ -96,7 +103,6 @@ sfb_status plan_on_device(sfb_sparse_qp_plan *plan, const sfb_sparse_qp_plan::De
   if (plan->pruned) {
     st = upload_plan(plan->host, &plan->Aorig, &plan->Amasked, plan->full.nnzA, &dc.blob, dc.dev);
     if (st != SFB_OK) return st;
-    dc.dev.nmasked = plan->full.nnzA - plan->host.nnzA;
     st = upload_plan(plan->full, nullptr, nullptr, plan->full.nnzA, &dc.blob_full, dc.dev_full);
     if (st != SFB_OK) {
       (void)hipFree(dc.blob);
@@ -113,9 +119,9 @@ sfb_status plan_on_device(sfb_sparse_qp_plan *plan, const sfb_sparse_qp_plan::De
 
 // Workspace of one call.  Plain plan: batch items of the plan's per-item block.  Pruned plan: the larger of that and
 // ONE item of the fallback plan (the fallback launches reuse the memory of the first launch), then the fallback list
-// (count + batch entries).
+// (count + batch entries).  Both: the queue of a time-sliced launch at the end.
 struct WsLayout {
-  size_t item_bytes, fb_item_bytes, main_bytes, fb_off, total;
+  size_t item_bytes, fb_item_bytes, main_bytes, fb_off, queue_off, total;
   int64_t fb_cap;  // items one fallback launch can hold
 };
 WsLayout ws_layout(const sfb_sparse_qp_plan *plan, int64_t batch)
@@ -130,10 +136,11 @@ WsLayout ws_layout(const sfb_sparse_qp_plan *plan, int64_t batch)
     L.main_bytes    = std::max(L.main_bytes, L.fb_item_bytes);
     L.fb_cap        = std::max<int64_t>(1, std::min<int64_t>(batch, (int64_t)(L.main_bytes / L.fb_item_bytes)));
     L.fb_off        = L.main_bytes;
-    L.total         = L.fb_off + (((size_t)batch + 2) * sizeof(int32_t) + 7) / 8 * 8;
+    L.queue_off     = L.fb_off + (((size_t)batch + 2) * sizeof(int32_t) + 15) / 16 * 16;
   } else {
-    L.total = L.main_bytes;
+    L.queue_off = L.main_bytes;
   }
+  L.total = L.queue_off + (sfb::qp_sparse_queue_bytes(batch) + 15) / 16 * 16;  // queue of a time-sliced launch
   return L;
 }
 
@@ -256,7 +263,7 @@ sfb_status sfb_sparse_qp_plan_info(const sfb_sparse_qp_plan *plan, int64_t *nnzK
     // batch * this many bytes always suffice; sfb_sparse_qp_plan_workspace_bytes is exact (pruned plans need the
     // room of one fallback item whatever the batch size, which this per-item figure has to include)
     const WsLayout L1 = ws_layout(plan, 1);
-    *workspace_bytes_per_item = (int64_t)(plan->pruned ? L1.total : L1.item_bytes);
+    *workspace_bytes_per_item = (int64_t)L1.total;
   }
   return SFB_OK;
 }
@@ -301,9 +308,11 @@ sfb_status sfb_sparse_qp_solve_batch_ordered(sfb_sparse_qp_plan *plan, const sfb
   if (st != SFB_OK) return st;
   const sfb::DenseKernelParams kp = sfb::make_kernel_params(prm, plan->host.n, plan->host.m);
   hipStream_t hs = static_cast<hipStream_t>(stream);
+  const WsLayout L = ws_layout(plan, batch);
+  int32_t *queue   = reinterpret_cast<int32_t *>(static_cast<char *>(workspace) + L.queue_off);
   if (!plan->pruned) {
     hipError_t e = sfb::qp_sparse_launch(dc->dev, kp, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code,
-                                         static_cast<double *>(workspace), hs, order);
+                                         static_cast<double *>(workspace), hs, order, nullptr, 0, queue);
     if (e != hipSuccess) return sfb::hip_fail(e, "qp_sparse_kernel launch");
     return SFB_OK;
   }
@@ -311,12 +320,11 @@ sfb_status sfb_sparse_qp_solve_batch_ordered(sfb_sparse_qp_plan *plan, const sfb
   // fallback launches (full pattern, same elimination order) work through the list, fb_cap items per launch,
   // in the memory of the first.  The list is empty unless the caller's mask was wrong for an item: the fallback
   // launches then cost a few microseconds of empty blocks.
-  const WsLayout L = ws_layout(plan, batch);
   int32_t *fb = reinterpret_cast<int32_t *>(static_cast<char *>(workspace) + L.fb_off);
   hipError_t e = hipMemsetAsync(fb, 0, sizeof(int32_t), hs);
   if (e != hipSuccess) return sfb::hip_fail(e, "hipMemsetAsync");
   e = sfb::qp_sparse_launch(dc->dev, kp, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code,
-                            static_cast<double *>(workspace), hs, order, fb, 0);
+                            static_cast<double *>(workspace), hs, order, fb, 0, queue);
   if (e != hipSuccess) return sfb::hip_fail(e, "qp_sparse_kernel launch");
   for (int64_t base = 0; base < batch; base += L.fb_cap) {
     e = sfb::qp_sparse_launch(dc->dev_full, kp, std::min(L.fb_cap, batch - base), Px, q, Ax, l, u, warm_x, warm_y, x, y, obj,

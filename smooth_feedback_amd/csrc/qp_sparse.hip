@@ -42,6 +42,7 @@ struct Ws {
   double *Lx, *LxF, *LxB, *D, *Dinv, *tv;  // Lx, D and one scratch double are contiguous (accumulators)
   double *sx, *qc, *xs, *xus, *dxus;
   double *sy, *rho, *rinv, *lo, *hi, *ys, *zs, *yus, *zus, *dyus, *act;
+  double *hdr;  // 8 doubles: state of a suspended item (time-sliced launches): c, iter, next_chk
   double *Axc;  // pruned plans: the item's kept entries of A, compacted (qp_sparse_kernel.h)
 };
 
@@ -61,6 +62,7 @@ __device__ __forceinline__ Ws carve_ws(double *base, int n, int m, int nnzL, int
   w.sy = p; p += m;     w.rho = p; p += m;    w.rinv = p; p += m; w.lo = p; p += m;   w.hi = p; p += m;
   w.ys = p; p += m;     w.zs = p; p += m;     w.yus = p; p += m;  w.zus = p; p += m;  w.dyus = p; p += m;
   w.act = p; p += m;
+  w.hdr = p; p += 8;
   w.Axc = p;
   return w;
 }
@@ -779,22 +781,55 @@ __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const 
 
 __device__ int g_sparse_active = 0;  // resident waves of qp_sparse_kernel (all launches of the process), see the kernel
 
-// One item, start to finish.  `slot` = workspace slot of this launch position.  Returns false when the item was
-// handed to the fallback list (pruned plan, a masked entry of A is not zero) and left unsolved.
-__device__ __forceinline__ bool sp_solve_item(const SparsePlanDev &pl, const DenseKernelParams &kp, const double *__restrict__ gPx,
-                                              const double *__restrict__ gq, const double *__restrict__ gAx,
-                                              const double *__restrict__ gl, const double *__restrict__ gu,
-                                              const double *__restrict__ gwx, const double *__restrict__ gwy,
-                                              double *__restrict__ gx, double *__restrict__ gy, double *__restrict__ gobj,
-                                              uint32_t *__restrict__ giter, int32_t *__restrict__ gcode,
-                                              double *__restrict__ gws, const size_t ws_doubles, const int lean_waves,
-                                              bool lean, const size_t b, const size_t slot, int32_t *__restrict__ fb,
-                                              double *t, const int lane)
+// Queue of a time-sliced launch (device memory, zeroed by the launcher; counters on their own cache lines):
+//   q[kQFresh]  fresh items handed out so far (ticket counter, items 0 .. batch-1 in launch order)
+//   q[kQHead], q[kQTail]  ring of SUSPENDED items: pushes reserve q[kQTail]++, pops claim q[kQHead] by CAS
+//   q[kQRing + i]  ring entries (item + 1, 0 = empty), capacity = batch
+constexpr int kQFresh = 0, kQHead = 16, kQTail = 32, kQRing = 48;
+
+enum { SP_DONE = 0, SP_FALLBACK = 1, SP_SUSPENDED = 2 };
+
+// One item.  `slot` = workspace slot.  resume == false: from the start (guard, scaling, factorisation, initial
+// iterate); resume == true: continue an item another block has suspended (its state is in its workspace).
+// Runs until the item is finished (SP_DONE), or -- time-sliced launches only, queue != nullptr -- until the item
+// has used its slice while others are waiting for a wave (SP_SUSPENDED: state saved, the caller queues the item).
+// SP_FALLBACK: pruned plan and a masked entry of A is not zero: the item went to the fallback list, unsolved.
+__device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const DenseKernelParams &kp, const double *__restrict__ gPx,
+                                             const double *__restrict__ gq, const double *__restrict__ gAx,
+                                             const double *__restrict__ gl, const double *__restrict__ gu,
+                                             const double *__restrict__ gwx, const double *__restrict__ gwy,
+                                             double *__restrict__ gx, double *__restrict__ gy, double *__restrict__ gobj,
+                                             uint32_t *__restrict__ giter, int32_t *__restrict__ gcode,
+                                             double *__restrict__ gws, const size_t ws_doubles, const int lean_waves,
+                                             bool lean, const size_t b, const size_t slot, int32_t *__restrict__ fb,
+                                             double *t, const int lane, const bool resume, const int32_t *queue,
+                                             const int batch, const uint32_t slice)
 {
   const int n = pl.n, m = pl.m, k = pl.k;
   Item it{gPx + b * (size_t)pl.nnzP, gq + b * (size_t)n, gAx + b * (size_t)pl.nnzA_io, gl + b * (size_t)m,
           gu + b * (size_t)m};
   const Ws w = carve_ws(gws + slot * ws_doubles, n, m, pl.nnzL, pl.funits, pl.bunits);
+#ifdef SFB_SP_TIMELINE  // profiling build (scripts/build_prof.sh): wall-clock stamps (100 MHz) of the item's phases
+  unsigned long long tl0 = wall_clock64(), tl1 = 0, tl2 = 0;
+#endif
+  double c = 1.0;
+  int ret_code = -1;
+  uint32_t iter = 0;
+  const uint32_t sci   = kp.stop_check_iter;
+  const uint32_t maxit = kp.max_iter;
+  uint32_t next_chk    = (sci >= 2) ? 1u : 0xFFFFFFFFu;
+  if (lane == 0) t[k] = 0.0;  // padding slot of the packed sweeps
+  const double inf = INFINITY;
+  if (resume) {
+    c        = w.hdr[0];
+    iter     = (uint32_t)w.hdr[1];
+    next_chk = (uint32_t)w.hdr[2];
+#ifdef SFB_SP_TIMELINE
+    tl0 = (unsigned long long)w.hdr[4];
+    tl1 = (unsigned long long)w.hdr[5];
+#endif
+    if (pl.Aorig != nullptr) it.Ax = w.Axc;
+  } else {
   if (pl.Aorig != nullptr) {
     // Pruned plan.  GUARD: the entries of A the plan's creator declared structurally zero must be zero (NaN counts
     // as non-zero) -- otherwise the item goes to the fallback list and is solved on the full pattern by the second
@@ -814,7 +849,7 @@ __device__ __forceinline__ bool sp_solve_item(const SparsePlanDev &pl, const Den
     }
     if (wave_ballot(bad)) {
       if (lane == 0) fb[1 + atomicAdd(&fb[0], 1)] = (int32_t)b;
-      return false;
+      return SP_FALLBACK;
     }
     for (int p0 = lane; p0 < pl.nnzA; p0 += kWave * UB) {
       int src[UB];
@@ -830,14 +865,11 @@ __device__ __forceinline__ bool sp_solve_item(const SparsePlanDev &pl, const Den
     it.Ax = w.Axc;
     wave_sync();
   }
-  if (lane == 0) t[k] = 0.0;  // padding slot of the packed sweeps
-  const double inf = INFINITY;
 
   // ---- analyze(): :306-308 ----
   for (int j = lane; j < n; j += kWave) w.sx[j] = 1.0;
   for (int i = lane; i < m; i += kWave) w.sy[i] = 1.0;
   wave_sync();
-  double c = 1.0;
 
   // ---- scale :673-730 ----
   if (kp.scaling) {
@@ -928,7 +960,6 @@ __device__ __forceinline__ bool sp_solve_item(const SparsePlanDev &pl, const Den
   }
 
   // ---- pre-check, rho and loop constants :361-374, :450, :473-474 ----
-  int ret_code = -1;
   {
     bool bad = false;
     for (int i = lane; i < m; i += kWave) {
@@ -954,6 +985,9 @@ __device__ __forceinline__ bool sp_solve_item(const SparsePlanDev &pl, const Den
     // Dinv of the remaining columns is never used: the loop below does not run
   }
 
+#ifdef SFB_SP_TIMELINE
+  tl1 = wall_clock64();
+#endif
   // ---- initial iterate :436-445 ----
   if (gwx != nullptr) {
     const double *wx = gwx + b * (size_t)n, *wy = gwy + b * (size_t)m;
@@ -986,12 +1020,10 @@ __device__ __forceinline__ bool sp_solve_item(const SparsePlanDev &pl, const Den
     }
   }
   wave_sync();
+  }  // !resume
 
   // ---- ADMM loop :447-510 ----
-  uint32_t iter        = 0;
-  const uint32_t sci   = kp.stop_check_iter;
-  const uint32_t maxit = kp.max_iter;
-  uint32_t next_chk    = (sci >= 2) ? 1u : 0xFFFFFFFFu;
+  const uint32_t iter0 = iter;  // start of this slice
   bool need_rhs        = true;
   for (; iter != maxit && ret_code < 0; ++iter) {
     // element-wise phases: the loads of UNR strided elements are issued together (one memory round
@@ -1119,10 +1151,40 @@ __device__ __forceinline__ bool sp_solve_item(const SparsePlanDev &pl, const Den
       if (iter > 600) __builtin_amdgcn_s_setprio(3);
       else if (iter > 300) __builtin_amdgcn_s_setprio(2);
       else if (iter > 100) __builtin_amdgcn_s_setprio(1);
+      // Time slicing: an item that has used its slice gives its wave back when fresh items are left or suspended
+      // ones are waiting -- the long runners then share the waves round-robin and finish together, instead of
+      // the ones that happened to start late running alone at the end of the launch.  Everything an item needs
+      // to continue is in its workspace already (iterate, factor, scaling); a stopping check is the natural
+      // point: the next iteration rebuilds its right-hand side anyway.
+      if (queue != nullptr && ret_code < 0 && iter + 1 != maxit && iter + 1 - iter0 >= slice) {
+        int wait = 0;
+        if (lane == 0) {
+          const int fresh = __hip_atomic_load(&queue[kQFresh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int head  = __hip_atomic_load(&queue[kQHead], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int tail  = __hip_atomic_load(&queue[kQTail], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          wait            = (fresh < batch) || (tail - head > 0);
+        }
+        if (__builtin_amdgcn_readfirstlane(wait)) {
+          if (lane == 0) {
+            w.hdr[0] = c;
+            w.hdr[1] = (double)(iter + 1);
+            w.hdr[2] = (double)next_chk;
+#ifdef SFB_SP_TIMELINE
+            w.hdr[4] = (double)tl0;
+            w.hdr[5] = (double)tl1;
+#endif
+          }
+          __builtin_amdgcn_s_setprio(0);
+          return SP_SUSPENDED;
+        }
+      }
     }
   }
   __builtin_amdgcn_s_setprio(0);
 
+#ifdef SFB_SP_TIMELINE
+  tl2 = wall_clock64();
+#endif
   // ---- polish :515-539 ----
   if (ret_code == SFB_QP_OPTIMAL && kp.polish) sp_polish(pl, it, w, kp, t, c, lane, lean);
 
@@ -1151,13 +1213,16 @@ __device__ __forceinline__ bool sp_solve_item(const SparsePlanDev &pl, const Den
   if (lane == 0) {
     gcode[b] = (ret_code >= 0) ? ret_code : SFB_QP_MAX_ITERATIONS;
     if (giter != nullptr) giter[b] = iter;
+#ifdef SFB_SP_TIMELINE  // the stamps replace the first four dual entries (profiling build only)
+    oy[0] = (double)tl0; oy[1] = (double)tl1; oy[2] = (double)tl2; oy[3] = (double)wall_clock64();
+#endif
   }
-  return true;
+  return SP_DONE;
 }
 
 }  // namespace
 
-__global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl, const DenseKernelParams kp,
+__global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev *__restrict__ plp, const DenseKernelParams kp,
                                                        const double *__restrict__ gPx, const double *__restrict__ gq,
                                                        const double *__restrict__ gAx, const double *__restrict__ gl,
                                                        const double *__restrict__ gu, const double *__restrict__ gwx,
@@ -1166,45 +1231,128 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev pl
                                                        uint32_t *__restrict__ giter, int32_t *__restrict__ gcode,
                                                        double *__restrict__ gws, const size_t ws_doubles,
                                                        const int lean_waves, const int32_t *__restrict__ order,
-                                                       int32_t *__restrict__ fb, const int fb_mode)
+                                                       int32_t *__restrict__ fb, const int fb_mode,
+                                                       int32_t *__restrict__ queue, const int batch, const uint32_t slice)
 {
   extern __shared__ __attribute__((aligned(16))) double t[];  // k + 1 doubles: work / solution vector
-  const int lane = threadIdx.x;
-  // fallback launch: block i takes entry fb_mode - 1 + i of the list the first launch of the call has written
-  int pos = blockIdx.x;
-  if (fb_mode != 0) {
-    pos += fb_mode - 1;
-    if (pos >= __builtin_amdgcn_readfirstlane(fb[0])) return;
+  // The plan (some forty pointers) is read from device memory where it is used: as a by-value kernel argument it
+  // would sit in SGPRs for the whole life of the persistent loop below and push the kernel into register spills.
+  const SparsePlanDev &pl = *plp;
+  const int lane0 = threadIdx.x;
+  // queue == nullptr: ONE ITEM PER BLOCK (batches that fit the chip at once, and the fallback launches of a pruned
+  // plan: block i takes entry fb_mode - 1 + i of the list the first launch of the call has written).
+  // queue != nullptr: TIME-SLICED LAUNCH: a persistent grid (as many blocks as the chip holds) works through the
+  // batch.  Fresh items first, in launch order; an item that has used its slice while others wait goes to the back
+  // of a ring and is continued later by whichever block is free (its state lives in ITS workspace slot = item).
+  for (bool first = true;; first = false) {
+    const int lane = lane0;
+    int item = -1, resume = 0;
+    if (queue == nullptr) {
+      if (first) {
+        item = blockIdx.x;
+        if (fb_mode != 0) {
+          const int pos = fb_mode - 1 + (int)blockIdx.x;
+          item          = (pos < __builtin_amdgcn_readfirstlane(fb[0])) ? fb[1 + pos] : -1;
+        } else if (order) {
+          item = order[blockIdx.x];
+        }
+      }
+    } else if (lane == 0) {
+      if (__hip_atomic_load(&queue[kQFresh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < batch) {
+        const int tk = atomicAdd(&queue[kQFresh], 1);
+        if (tk < batch) item = order ? order[tk] : tk;
+      }
+      while (item < 0) {
+        const int head = __hip_atomic_load(&queue[kQHead], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int tail = __hip_atomic_load(&queue[kQTail], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tail - head <= 0) break;  // nobody waits: once the fresh items are out, no item is suspended any more
+        if (atomicCAS(&queue[kQHead], head, head + 1) != head) continue;
+        int32_t *e = &queue[kQRing + (unsigned)head % (unsigned)batch];
+        int v;
+        while ((v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) __builtin_amdgcn_s_sleep(4);
+        __hip_atomic_store(e, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        item   = v - 1;
+        resume = 1;
+      }
+    }
+    item   = __builtin_amdgcn_readfirstlane(item);
+    resume = __builtin_amdgcn_readfirstlane(resume);
+    if (item < 0) break;
+    if (resume) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the suspending block's stores (other CU / XCD)
+    wave_sync();
+    // Waves busy with an item right now (all launches of the process).  While there are many, the launch is
+    // HBM-bound and the sweeps skip the padding of the factor stream (masked loads: fewer bytes, a few more
+    // instructions); when only stragglers are left, latency is what counts and they switch to plain loads.  A
+    // heuristic only: both forms compute the same thing.  (Balanced by every wave when it is done; shared by all
+    // launches on purpose -- independent batches on other streams fill the chip just the same.)
+    int seen = 0;
+    if (lane == 0) seen = atomicAdd(&g_sparse_active, 1);
+    const bool lean = ((queue == nullptr ? (int)gridDim.x : batch) > lean_waves) || __builtin_amdgcn_readfirstlane(seen) >= lean_waves;
+    // workspace slot: the launch position for one-item-per-block launches, the item for time-sliced ones
+    const int st = sp_solve_item(pl, kp, gPx, gq, gAx, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode, gws, ws_doubles,
+                                 lean_waves, lean, (size_t)item, queue == nullptr ? (size_t)blockIdx.x : (size_t)item, fb, t,
+                                 lane, resume != 0, queue, batch, slice);
+    wave_sync();
+    if (lane == 0) {
+      atomicSub(&g_sparse_active, 1);
+      if (st == SP_SUSPENDED) {
+        // publish the item's state (plain and non-temporal stores of this wave) before its id enters the ring
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int tl = atomicAdd(&queue[kQTail], 1);
+        int32_t *e   = &queue[kQRing + (unsigned)tl % (unsigned)batch];
+        while (__hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) __builtin_amdgcn_s_sleep(4);
+        __hip_atomic_store(e, item + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    wave_sync();
+    if (queue == nullptr) break;
   }
-  // Waves of this kernel resident on the device right now.  While there are many, the launch is HBM-bound and the
-  // sweeps skip the padding of the factor stream (masked loads: fewer bytes, a few more instructions); when only
-  // stragglers are left, latency is what counts and they switch to plain loads.  A heuristic only: both forms
-  // compute the same thing.  (The counter is balanced by every wave that exits; it is shared by all launches of the
-  // process on purpose -- independent batches on other streams fill the chip just the same.)
-  int seen = 0;
-  if (lane == 0) seen = atomicAdd(&g_sparse_active, 1);
-  const bool lean = (gridDim.x > (unsigned)lean_waves) || __builtin_amdgcn_readfirstlane(seen) >= lean_waves;
-  // launch position -> item: with `order` the caller puts the items it expects to iterate longest first, so that
-  // they run alongside the bulk of the batch instead of finishing alone (the workspace stays per launch position)
-  const size_t b = fb_mode != 0 ? (size_t)fb[1 + pos] : (order ? (size_t)order[pos] : (size_t)pos);
-  sp_solve_item(pl, kp, gPx, gq, gAx, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode, gws, ws_doubles, lean_waves, lean, b,
-                (size_t)blockIdx.x, fb, t, lane);
-  if (lane == 0) atomicSub(&g_sparse_active, 1);
+}
+
+// blocks of qp_sparse_kernel the device holds at once with `lds` bytes of dynamic LDS each (cached per device)
+static int sparse_resident_blocks(size_t lds)
+{
+  int dev = 0, per_cu = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qp_sparse_kernel, kWave, lds) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  return per_cu * cus;
 }
 
 hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp, int64_t batch, const double *Px,
                             const double *q, const double *Ax, const double *l, const double *u, const double *wx,
                             const double *wy, double *x, double *y, double *obj, uint32_t *iter, int32_t *code,
-                            double *workspace, hipStream_t stream, const int32_t *order, int32_t *fb, int fb_mode)
+                            double *workspace, hipStream_t stream, const int32_t *order, int32_t *fb, int fb_mode,
+                            int32_t *queue)
 {
   if ((pl.Aorig != nullptr || fb_mode != 0) && fb == nullptr) return hipErrorInvalidValue;
-  const size_t lds = (size_t)pl.lds_doubles * sizeof(double);
+  size_t lds = (size_t)pl.lds_doubles * sizeof(double);
+  // SFB_SP_WAVES_PER_CU (tuning): cap the resident workgroups per CU by padding the LDS request
+  if (const char *wpc = getenv("SFB_SP_WAVES_PER_CU"); wpc && atoi(wpc) > 0)
+    lds = std::max(lds, std::min<size_t>(160 * 1024, (size_t)(160 * 1024 / atoi(wpc)) & ~(size_t)15));
   const size_t wsd = qp_sparse_ws_doubles(pl);
-  // below this many resident waves the sweeps use plain loads (see the kernel); SFB_SP_LEAN_WAVES overrides (tuning)
+  // below this many busy waves the sweeps use plain loads (see the kernel); SFB_SP_LEAN_WAVES overrides (tuning)
   const char *lw        = getenv("SFB_SP_LEAN_WAVES");
   const int lean_waves  = lw ? atoi(lw) : 512;
-  hipLaunchKernelGGL(qp_sparse_kernel, dim3((unsigned)batch), dim3(kWave), lds, stream, pl, kp, Px, q, Ax, l, u, wx,
-                     wy, x, y, obj, iter, code, workspace, wsd, lean_waves, order, fb, fb_mode);
+  // Time slicing (see the kernel): only when the batch does not fit the chip at once.  SFB_SP_SLICE = iterations
+  // per slice (0 = off: one block per item, the hardware dispatcher is the queue).
+  const char *sl   = getenv("SFB_SP_SLICE");
+  const int slice  = sl ? atoi(sl) : 50;
+  unsigned grid    = (unsigned)batch;
+  int32_t *qarg    = nullptr;
+  if (queue != nullptr && fb_mode == 0 && slice > 0) {
+    int resident = sparse_resident_blocks(lds);
+    if (const char *g = getenv("SFB_SP_GRID"); g && atoi(g) > 0) resident = std::min(resident, atoi(g));  // tests: force slicing
+    if (resident > 0 && batch > resident) {
+      hipError_t e = hipMemsetAsync(queue, 0, qp_sparse_queue_bytes(batch), stream);
+      if (e != hipSuccess) return e;
+      grid = (unsigned)resident;
+      qarg = queue;
+    }
+  }
+  hipLaunchKernelGGL(qp_sparse_kernel, dim3(grid), dim3(kWave), lds, stream, pl.self, kp, Px, q, Ax, l, u, wx, wy, x, y, obj, iter,
+                     code, workspace, wsd, lean_waves, order, fb, fb_mode, qarg, (int)batch, (uint32_t)std::max(1, slice));
   return hipGetLastError();
 }
 

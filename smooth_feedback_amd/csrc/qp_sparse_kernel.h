@@ -32,6 +32,7 @@ struct SparsePlanDev {
   // 512 entries that repeat the last one).  Aorig == nullptr: no mask, the kernel reads the caller's array directly.
   int nnzA_io, nmasked;
   const int32_t *Aorig, *Amasked;
+  const SparsePlanDev *self;  // device copy of this struct (what the kernel is handed)
 };
 
 // per-item workspace, in doubles
@@ -40,7 +41,7 @@ inline size_t qp_sparse_ws_doubles(int n, int m, int nnzL, int funits, int bunit
 {
   const size_t k = (size_t)n + m;
   // nnzA_compact: kept entries of A of a pruned plan (the kernel compacts the item's values into its workspace)
-  return (size_t)nnzL + (size_t)(funits + bunits + 2 * kSweepPadDev) * 128 + 3 * k + 6 * (size_t)n + 12 * (size_t)m + 8 +
+  return (size_t)nnzL + (size_t)(funits + bunits + 2 * kSweepPadDev) * 128 + 3 * k + 6 * (size_t)n + 12 * (size_t)m + 16 +
          (((size_t)nnzA_compact + 1) & ~(size_t)1);
   // (accumulator layout of the factorisation: [L values | D | scratch | zero] is contiguous at the start of the block,
   //  followed by the forward- and backward-sweep copies of the factor)
@@ -54,12 +55,16 @@ inline size_t qp_sparse_ws_doubles(const SparsePlanDev &pl)
 // One launch over `batch` items (launch position -> item through `order`, nullable).
 //   fb (nullable unless the plan is pruned or fb_mode != 0): fallback list of the call, fb[0] = count,
 //   fb[1 + i] = item.  fb_mode 0: a pruned plan appends the items whose masked entries are not all zero and leaves
-//   them unsolved; fb_mode 1: `pl` is the fallback plan (full pattern), the grid of `batch` blocks works through the
-//   list (block i takes entries i, i + batch, ...), the workspace holds `batch` items of THIS plan.
+//   them unsolved; fb_mode = 1 + base: `pl` is the fallback plan (full pattern), block i of the grid of `batch` blocks
+//   takes list entry base + i (and exits if there is none), the workspace holds `batch` items of THIS plan.
 hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp, int64_t batch, const double *Px,
                             const double *q, const double *Ax, const double *l, const double *u, const double *wx,
                             const double *wy, double *x, double *y, double *obj, uint32_t *iter, int32_t *code,
                             double *workspace, hipStream_t stream, const int32_t *order = nullptr, int32_t *fb = nullptr,
-                            int fb_mode = 0);
+                            int fb_mode = 0, int32_t *queue = nullptr);
+
+// Queue memory of a time-sliced launch (qp_sparse.hip): counters + a ring of `batch` entries.  Passed as `queue`
+// (device memory, need not be initialised); nullptr = never time-slice.
+inline size_t qp_sparse_queue_bytes(int64_t batch) { return ((size_t)batch + 48) * sizeof(int32_t); }
 
 }  // namespace sfb

@@ -121,6 +121,41 @@ def test_pruned_plan_guard_falls_back_to_the_whole_pattern(sfb, oracle, batch, n
     assert np.array_equal(rp.primal, r.primal, equal_nan=True) and np.array_equal(rp.iter, r.iter)
 
 
+@pytest.mark.parametrize("grid,slice_iters", [(7, 25), (32, 50), (64, 1)])
+def test_time_sliced_launch_equals_one_block_per_item(sfb, oracle, grid, slice_iters, monkeypatch):
+    """Batches larger than the chip holds run on a persistent grid: an item that has used its slice while others
+    wait is suspended (its state stays in its workspace) and continued later by another block.  Forced here with a
+    tiny grid and short slices (SFB_SP_GRID / SFB_SP_SLICE are test / tuning knobs read at every launch): the results
+    must equal the one-block-per-item launch and the oracle bit for bit, for a plain and for a pruned plan, cold
+    and warm start, and with some items on the fallback path."""
+    variant, K, B = 6, 10, 150
+    d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
+    Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=21)
+    keep = np.any(Av != 0.0, axis=0)
+    Av[5, np.nonzero(~keep)[0][3]] = 0.125      # one item violates the mask: fallback launch next to the sliced one
+    Px, q = np.tile(Pv, (B, 1)), np.zeros((B, d["n"]))
+    prm = sfb.QPSolverParams(max_iter=4000)
+    for kp in (None, keep):
+        plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K), keep=kp)
+        monkeypatch.setenv("SFB_SP_SLICE", "0")
+        base = plan.solve_batch_host(Px, q, Av, l, u, prm)
+        monkeypatch.setenv("SFB_SP_SLICE", str(slice_iters))
+        monkeypatch.setenv("SFB_SP_GRID", str(grid))
+        r = plan.solve_batch_host(Px, q, Av, l, u, prm)
+        r2 = plan.solve_batch_host(Px, q, Av, l, u, prm, warm_x=0.5 * r.primal, warm_y=0.5 * r.dual)
+        monkeypatch.delenv("SFB_SP_GRID")
+        monkeypatch.setenv("SFB_SP_SLICE", "0")
+        base2 = plan.solve_batch_host(Px, q, Av, l, u, prm, warm_x=0.5 * r.primal, warm_y=0.5 * r.dual)
+        for a, b in ((r, base), (r2, base2)):
+            assert np.array_equal(a.code, b.code) and np.array_equal(a.iter, b.iter)
+            assert np.array_equal(a.primal, b.primal) and np.array_equal(a.dual, b.dual)
+            assert np.array_equal(a.objective, b.objective)
+        assert r.iter.max() > 3 * max(25, slice_iters)      # items were suspended several times
+        ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l, u, perm=plan.perm,
+                                           params=_oracle_params(oracle, prm), nthreads=8)
+        assert np.array_equal(r.iter, ref["iter"]) and np.array_equal(r.primal, ref["x"])
+
+
 def test_mpc_closed_loop_like_reference_test(sfb):
     """tests/test_mpc.cpp:83-117: Optimal on consecutive calls, u1 ~ u2 ~ u3 with and without warm start,
     trajectory sizes."""

@@ -46,7 +46,10 @@ def test_problem_sizes_match_the_baseline_config():
     nodes, w, _ = M.mesh(13, 4)
     assert np.allclose(Pv[:12], w[0] * 5.0 + 0.5) and np.allclose(Pv[12:24], w[1] * 5.0)
     st = M.mpc_stage(12, 50)
-    assert st.sum() == 12 * 14 + 12                             # separators + the rows pinning x_0
+    assert (st > 0).sum() == 12 * 14 + 12                       # separators + the rows pinning x_0 are held back
+    sep = st[np.arange(14) * 4 * 12]                            # ... in nested-dissection order of the chain of
+    assert sep.max() == 4 and (sep == 4).sum() == 1             # 14 separators: one root, levels 1..4
+    assert all(sep[i] != sep[i + 1] for i in range(13))         # neighbours never share a level
 
 
 # ---- independent numpy restatement of the transcription for the vehicle (variant 6) ----

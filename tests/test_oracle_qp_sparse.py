@@ -110,7 +110,7 @@ def test_explicit_zeros_can_be_left_out_of_the_analysis(oracle, sfb, variant, K,
     assert plan.nnzA == keep.size and plan.nnzA_kept == int(keep.sum())
     assert plan.nnzL < 0.5 * whole.nnzL
     if (variant, K) == (12, 50):
-        assert (whole.nnzL, plan.nnzL) == (41030, 13710)
+        assert (whole.nnzL, plan.nnzL) == (42182, 14862)   # separators in nested-dissection order (MPC front)
     # workspace: exact requirement of a call vs the per-item bound
     assert plan.workspace_bytes(1) <= plan.workspace_bytes_per_item
     assert plan.workspace_bytes(4096) <= 4096 * plan.workspace_bytes_per_item
