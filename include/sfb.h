@@ -179,6 +179,11 @@ sfb_status sfb_sparse_qp_plan_workspace_bytes(const sfb_sparse_qp_plan *plan, in
 sfb_status sfb_sparse_qp_plan_pruned_info(const sfb_sparse_qp_plan *plan, int64_t *nnzA_kept, int64_t *nnzL_fallback);
 /* The elimination order in use (n+m entries, new -> old). */
 sfb_status sfb_sparse_qp_plan_get_perm(const sfb_sparse_qp_plan *plan, int32_t *perm);
+/* The order in which the numeric factorisation sums the contributions to an entry of L: rank[n+m] of every
+ * column of the permuted matrix (a postorder of the plan's elimination tree; sources are summed in ascending
+ * rank).  A floating-point detail, exposed so that a CPU restatement can reproduce the factor bit for bit.
+ * fallback != 0: the order of a pruned plan's whole-pattern fallback analysis. */
+sfb_status sfb_sparse_qp_plan_get_factor_order(const sfb_sparse_qp_plan *plan, int fallback, int32_t *rank);
 
 /*
  * Batched sparse solve (device pointers, asynchronous on `stream`).  Replaces, per item,

@@ -65,6 +65,11 @@ def lib():
             ip, dp, dp, dp, dp, dp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_int,
             C.POINTER(C.c_int64)]
         L.oracle_qp_sparse_solve_batch.restype = C.c_int
+        L.oracle_qp_sparse_solve_batch_ordered.argtypes = [
+            C.POINTER(OracleQPParams), C.c_int64, C.c_int, C.c_int, ip, ip, dp, dp, ip, ip, dp, dp, dp,
+            ip, ip, dp, dp, dp, dp, dp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_int,
+            C.POINTER(C.c_int64)]
+        L.oracle_qp_sparse_solve_batch_ordered.restype = C.c_int
         L.oracle_ekf_predict_batch.argtypes = [C.c_int64, C.c_int, dp, dp, C.c_int, dp, C.c_int, dp]
         L.oracle_ekf_predict_batch.restype = None
         L.oracle_ekf_predict_rk4_batch.argtypes = [C.c_int64, C.c_int, dp, dp, C.c_int, dp, C.c_int, dp]
@@ -139,9 +144,11 @@ def _ip(a):
 
 
 def qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Ax, l, u, perm=None, params=None, warm_x=None, warm_y=None,
-                          nthreads=1):
+                          nthreads=1, forder=None):
     """Sparse branch.  P CSC (Pp, Pi) with values Px (B, nnzP); A CSR (Ap, Aj) with values Ax (B, nnzA).
-    perm: elimination order of the (n+m) KKT unknowns (new -> old) or None (natural)."""
+    perm: elimination order of the (n+m) KKT unknowns (new -> old) or None (natural).
+    forder: accumulation order of the numeric factorisation (rank of every permuted column) or None (postorder of
+    the elimination tree)."""
     Pp = np.ascontiguousarray(Pp, dtype=np.int32); Pi = np.ascontiguousarray(Pi, dtype=np.int32)
     Ap = np.ascontiguousarray(Ap, dtype=np.int32); Aj = np.ascontiguousarray(Aj, dtype=np.int32)
     q = np.ascontiguousarray(q, dtype=np.float64); l = np.ascontiguousarray(l, dtype=np.float64)
@@ -161,9 +168,12 @@ def qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Ax, l, u, perm=None, params=Non
     it = np.zeros(B, dtype=np.uint32); code = np.zeros(B, dtype=np.int32)
     nnzL = C.c_int64(0)
     p = params if params is not None else default_params()
-    rc = lib().oracle_qp_sparse_solve_batch(
+    if forder is not None:
+        forder = np.ascontiguousarray(forder, dtype=np.int32)
+        assert sorted(forder.tolist()) == list(range(n + m))
+    rc = lib().oracle_qp_sparse_solve_batch_ordered(
         C.byref(p), B, n, m, _ip(Pp), _ip(Pi), _dp(Px), _dp(q), _ip(Ap), _ip(Aj), _dp(Ax), _dp(l), _dp(u),
-        _ip(perm), _dp(warm_x), _dp(warm_y), _dp(x), _dp(y), _dp(obj),
+        _ip(perm), _ip(forder), _dp(warm_x), _dp(warm_y), _dp(x), _dp(y), _dp(obj),
         it.ctypes.data_as(C.POINTER(C.c_uint32)), code.ctypes.data_as(C.POINTER(C.c_int32)), int(nthreads),
         C.byref(nnzL))
     if rc != 0:

@@ -89,6 +89,19 @@ int oracle_qp_sparse_solve_batch(const oracle_qp_params *prm, int64_t batch, int
                                  const int32_t *perm, const double *warm_x, const double *warm_y, double *x,
                                  double *y, double *obj, uint32_t *iter, int32_t *code, int nthreads,
                                  int64_t *nnzL_out);
+/*
+ * Same with an explicit ACCUMULATION ORDER of the numeric factorisation: forder[n+m] (nullable) = rank of every
+ * column of the permuted matrix; the sources of an entry of L are summed in ascending rank.  NULL = a postorder of
+ * the elimination tree (children ascending).  Any order is a valid summation order; it is an input so that a
+ * problem analysed WITHOUT its explicit zeros (the product's pruned plans) and the same problem with them can be
+ * made to sum in the same order -- their elimination trees differ, hence their postorders.
+ */
+int oracle_qp_sparse_solve_batch_ordered(const oracle_qp_params *prm, int64_t batch, int n, int m, const int32_t *Pp,
+                                         const int32_t *Pi, const double *Px, const double *q, const int32_t *Ap,
+                                         const int32_t *Aj, const double *Ax, const double *l, const double *u,
+                                         const int32_t *perm, const int32_t *forder, const double *warm_x,
+                                         const double *warm_y, double *x, double *y, double *obj, uint32_t *iter,
+                                         int32_t *code, int nthreads, int64_t *nnzL_out);
 
 /*
  * Restatement of Eigen 3.4 LDLT (unblocked, diagonal pivoting) exposed for unit tests.

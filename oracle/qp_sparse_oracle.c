@@ -13,8 +13,10 @@
  * the dense oracle on the same problems (tests/test_oracle_qp_sparse.py).  UNPINNED: Eigen's AMD
  * ordering cannot be reproduced without Eigen, so the elimination order is an INPUT here (`perm`,
  * any fill-reducing permutation of the KKT matrix); the numeric factorisation computes the same
- * L, D as SimplicialLDLT for that order but accumulates each entry over source columns in
- * ascending order (left-looking) instead of Eigen's etree-reach order; the backward sweep pushes
+ * L, D as SimplicialLDLT for that order but accumulates each entry over its source columns in the
+ * order of a POSTORDER of the elimination tree (children in ascending order; left-looking) instead
+ * of Eigen's etree-reach order -- both are topological orders of the same dependencies, Eigen's
+ * depends on the storage order of each row of the permuted matrix; the backward sweep pushes
  * row by row (descending) instead of Eigen's per-row dot product.  The polish step factorises the
  * reduced KKT system EMBEDDED in the full pattern (inactive rows zeroed, diagonal -delta), which is
  * algebraically the reference's reduced system with a different (fixed) elimination order.
@@ -38,6 +40,8 @@ typedef struct {
   int *Kp, *Ki, *Kkind, *Kidx; /* lower CSC of the permuted KKT: column j, rows i >= j           */
   int *Lp, *Li;           /* strictly lower pattern of L, column-major, rows ascending           */
   int *Rp, *Rk, *Rpos;    /* row structure of L: row j -> (source column kk < j ascending, pos)   */
+  int *RFk, *RFpos;       /* the same lists sorted by the POSTORDER rank of kk: the order in which
+                             the numeric factorisation accumulates the sources of row j            */
 } ksym;
 
 enum { K_P = 0, K_A = 1, K_SIGMA = 2, K_RHO = 3 };
@@ -45,7 +49,7 @@ enum { K_P = 0, K_A = 1, K_SIGMA = 2, K_RHO = 3 };
 static void ksym_free(ksym *s)
 {
   free(s->perm); free(s->pinv); free(s->Kp); free(s->Ki); free(s->Kkind); free(s->Kidx);
-  free(s->Lp); free(s->Li); free(s->Rp); free(s->Rk); free(s->Rpos);
+  free(s->Lp); free(s->Li); free(s->Rp); free(s->Rk); free(s->Rpos); free(s->RFk); free(s->RFpos);
 }
 
 typedef struct { int i, j, kind, idx; } kent;
@@ -57,7 +61,7 @@ static int kent_cmp(const void *a, const void *b)
 }
 
 static int ksym_build(ksym *s, int n, int m, const int32_t *Pp, const int32_t *Pi, const int32_t *Ap,
-                      const int32_t *Aj, const int32_t *perm_in)
+                      const int32_t *Aj, const int32_t *perm_in, const int32_t *forder)
 {
   memset(s, 0, sizeof(*s));
   const int k = n + m;
@@ -157,6 +161,41 @@ static int ksym_build(ksym *s, int n, int m, const int32_t *Pp, const int32_t *P
       s->Rpos[s->Rp[r] + fill[r]] = p;
       fill[r]++;
     }
+  /* postorder of the elimination tree: depth first from every root in ascending order, children in
+   * ascending order; rank[j] = position of column j in it */
+  {
+    int *head = (int *)malloc(sizeof(int) * (size_t)k), *next = (int *)malloc(sizeof(int) * (size_t)k);
+    int *stack = (int *)malloc(sizeof(int) * (size_t)k), *rank = (int *)malloc(sizeof(int) * (size_t)k);
+    for (int j = 0; j < k; ++j) head[j] = next[j] = -1;
+    for (int j = k - 1; j >= 0; --j)
+      if (parent[j] >= 0) { next[j] = head[parent[j]]; head[parent[j]] = j; }
+    int cnt = 0;
+    for (int r = 0; r < k; ++r) {
+      if (parent[r] >= 0) continue;
+      int sp = 0;
+      stack[sp++] = r;
+      while (sp > 0) {
+        const int v = stack[sp - 1], c = head[v];
+        if (c >= 0) { head[v] = next[c]; stack[sp++] = c; }
+        else { rank[v] = cnt++; --sp; }
+      }
+    }
+    /* an explicit accumulation order (rank of every column of the permuted matrix) overrides the postorder:
+     * ANY order of a row's sources is a valid summation order for the left-looking loop below */
+    if (forder)
+      for (int j = 0; j < k; ++j) rank[j] = forder[j];
+    s->RFk   = (int *)malloc(sizeof(int) * (size_t)(s->nnzL > 0 ? s->nnzL : 1));
+    s->RFpos = (int *)malloc(sizeof(int) * (size_t)(s->nnzL > 0 ? s->nnzL : 1));
+    for (int j = 0; j < k; ++j) { /* insertion sort of each row's sources by rank (rows are short) */
+      for (int t = s->Rp[j]; t < s->Rp[j + 1]; ++t) {
+        const int kk = s->Rk[t], pos = s->Rpos[t];
+        int q = t;
+        while (q > s->Rp[j] && rank[s->RFk[q - 1]] > rank[kk]) { s->RFk[q] = s->RFk[q - 1]; s->RFpos[q] = s->RFpos[q - 1]; --q; }
+        s->RFk[q] = kk; s->RFpos[q] = pos;
+      }
+    }
+    free(head); free(next); free(stack); free(rank);
+  }
   free(rp); free(rj); free(fill); free(parent); free(flag); free(lnz);
   return 0;
 }
@@ -170,8 +209,8 @@ static int ldl_numeric(const ksym *s, const double *Kval, double *Lx, double *D,
     work[j] = 0.0;
     for (int p = s->Lp[j]; p < s->Lp[j + 1]; ++p) work[s->Li[p]] = 0.0;
     for (int p = s->Kp[j]; p < s->Kp[j + 1]; ++p) work[s->Ki[p]] = Kval[p];
-    for (int t = s->Rp[j]; t < s->Rp[j + 1]; ++t) { /* source columns kk < j, ascending */
-      const int kk = s->Rk[t], pos = s->Rpos[t];
+    for (int t = s->Rp[j]; t < s->Rp[j + 1]; ++t) { /* source columns kk < j, in postorder of the elimination tree */
+      const int kk = s->RFk[t], pos = s->RFpos[t];
       const double w = Lx[pos] * D[kk]; /* L(j,kk) * D(kk) */
       for (int p = pos; p < s->Lp[kk + 1]; ++p) work[s->Li[p]] = fma(-Lx[p], w, work[s->Li[p]]);
     }
@@ -597,9 +636,20 @@ int oracle_qp_sparse_solve_batch(const oracle_qp_params *prm, int64_t batch, int
                                  double *y, double *obj, uint32_t *iter, int32_t *code, int nthreads,
                                  int64_t *nnzL_out)
 {
+  return oracle_qp_sparse_solve_batch_ordered(prm, batch, n, m, Pp, Pi, Px, q, Ap, Aj, Ax, l, u, perm, NULL, warm_x, warm_y, x,
+                                              y, obj, iter, code, nthreads, nnzL_out);
+}
+
+int oracle_qp_sparse_solve_batch_ordered(const oracle_qp_params *prm, int64_t batch, int n, int m, const int32_t *Pp,
+                                         const int32_t *Pi, const double *Px, const double *q, const int32_t *Ap,
+                                         const int32_t *Aj, const double *Ax, const double *l, const double *u,
+                                         const int32_t *perm, const int32_t *forder, const double *warm_x,
+                                         const double *warm_y, double *x, double *y, double *obj, uint32_t *iter,
+                                         int32_t *code, int nthreads, int64_t *nnzL_out)
+{
   if (!prm || n < 1 || m < 1 || batch < 0 || !Pp || !Pi || !Ap || !Aj || !code) return -1;
   ksym S;
-  if (ksym_build(&S, n, m, Pp, Pi, Ap, Aj, perm)) return -1;
+  if (ksym_build(&S, n, m, Pp, Pi, Ap, Aj, perm, forder)) return -1;
   if (nnzL_out) *nnzL_out = S.nnzL;
   sp_shared sh;
   memset(&sh, 0, sizeof(sh));

@@ -81,6 +81,7 @@ def _load():
     L.sfb_sparse_qp_plan_destroy.restype = None
     L.sfb_sparse_qp_plan_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.sfb_sparse_qp_plan_get_perm.argtypes = [C.c_void_p, i32p]
+    L.sfb_sparse_qp_plan_get_factor_order.argtypes = [C.c_void_p, i32, i32p]
     L.sfb_sparse_qp_solve_batch.argtypes = [C.c_void_p, C.POINTER(SfbQPParams), i64] + [dp] * 12 + [vp, vp]
     L.sfb_sparse_qp_solve_batch_ordered.argtypes = [C.c_void_p, C.POINTER(SfbQPParams), i64] + [dp] * 12 + [vp, vp, vp]
     L.sfb_sparse_qp_solve_batch_host.argtypes = [C.c_void_p, C.POINTER(SfbQPParams), i64] + [dp] * 12

@@ -49,6 +49,7 @@ sfb_status upload_plan(const sfb::SparsePlanHost &h, const std::vector<int32_t> 
                                         &h.Prp, &h.Prj, &h.Prpos, &h.Sp, &h.Sj, &h.Spos, &h.perm, &h.pinv,
                                         &h.Kp, &h.Ki, &h.Kdesc, &h.Lp, &h.Li, &h.Rp, &h.Rk, &h.Rpos, &h.Rlen,
                                         &h.fmap, &h.fidx, &h.bmap, &h.bidx, &h.Kmap, &h.rptr, &h.rtgt, &h.rab, &h.snptr, &h.snR, &h.poff, &h.pmap, &h.fmask, &h.bmask,
+                                        &h.f2s, &h.seg, &h.pmapL, &h.rsplit, &h.KmapL, &h.KdescT, &h.KmapT, &h.ztop,
                                         Aorig ? Aorig : &none, Amasked ? Amasked : &none};
   constexpr int NA = sizeof(arrs) / sizeof(arrs[0]);
   size_t off[NA + 1];
@@ -70,8 +71,9 @@ sfb_status upload_plan(const sfb::SparsePlanHost &h, const std::vector<int32_t> 
                             &d.Prp, &d.Prj, &d.Prpos, &d.Sp, &d.Sj, &d.Spos, &d.perm, &d.pinv,
                             &d.Kp, &d.Ki, &d.Kdesc, &d.Lp, &d.Li, &d.Rp, &d.Rk, &d.Rpos, &d.Rlen,
                             &d.fmap, &d.fidx, &d.bmap, &d.bidx, &d.Kmap, &d.rptr, &d.rtgt, &d.rab, &d.snptr, &d.snR, &d.poff, &d.pmap, &d.fmask, &d.bmask,
+                            &d.f2s, &d.seg, &d.pmapL, &d.rsplit, &d.KmapL, &d.KdescT, &d.KmapT, &d.ztop,
                             &d.Aorig, &d.Amasked};
-  d.funits = h.funits; d.bunits = h.bunits; d.ffull0 = h.ffull0; d.ffull1 = h.ffull1; d.bfull0 = h.bfull0; d.bfull1 = h.bfull1; d.idx_scale = h.idx_scale; d.rsteps = h.rsteps; d.maxcol = h.maxcol; d.nsn = h.nsn; d.lds_doubles = h.lds_doubles;
+  d.funits = h.funits; d.bunits = h.bunits; d.ffull0 = h.ffull0; d.ffull1 = h.ffull1; d.bfull0 = h.bfull0; d.bfull1 = h.bfull1; d.idx_scale = h.idx_scale; d.rsteps = h.rsteps; d.maxcol = h.maxcol; d.nsn = h.nsn; d.lds_doubles = h.lds_doubles; d.nseg = h.nseg; d.nnzKT = h.nnzKT; d.nztop = h.nztop;
   for (int a = 0; a < NA; ++a) *ptrs[a] = dblob + off[a];
   d.nnzA_io = nnzA_io;
   d.nmasked = Amasked ? (int)Amasked->size() - 512 : 0;  // without the padding
@@ -117,12 +119,11 @@ sfb_status plan_on_device(sfb_sparse_qp_plan *plan, const sfb_sparse_qp_plan::De
   return SFB_OK;
 }
 
-// Workspace of one call.  Plain plan: batch items of the plan's per-item block.  Pruned plan: the larger of that and
-// ONE item of the fallback plan (the fallback launches reuse the memory of the first launch), then the fallback list
-// (count + batch entries).  Both: the queue of a time-sliced launch at the end.
+// Workspace of one call: batch items of the plan's per-item block; for a pruned plan a pool of whole-pattern slots
+// (items that violate the mask are solved there, inside the same launch); the launch's auxiliary memory (queue of a
+// time-sliced launch, pool flags) at the end.
 struct WsLayout {
-  size_t item_bytes, fb_item_bytes, main_bytes, fb_off, queue_off, total;
-  int64_t fb_cap;  // items one fallback launch can hold
+  size_t item_bytes, main_bytes, pool_off, aux_off, total;
 };
 WsLayout ws_layout(const sfb_sparse_qp_plan *plan, int64_t batch)
 {
@@ -130,17 +131,15 @@ WsLayout ws_layout(const sfb_sparse_qp_plan *plan, int64_t batch)
   WsLayout L{};
   L.item_bytes = sfb::qp_sparse_ws_doubles(h.n, h.m, h.nnzL, h.funits, h.bunits, plan->pruned ? h.nnzA : 0) * sizeof(double);
   L.main_bytes = (size_t)batch * L.item_bytes;
+  L.pool_off   = L.main_bytes;
+  size_t pool  = 0;
   if (plan->pruned) {
     const sfb::SparsePlanHost &f = plan->full;
-    L.fb_item_bytes = sfb::qp_sparse_ws_doubles(f.n, f.m, f.nnzL, f.funits, f.bunits, 0) * sizeof(double);
-    L.main_bytes    = std::max(L.main_bytes, L.fb_item_bytes);
-    L.fb_cap        = std::max<int64_t>(1, std::min<int64_t>(batch, (int64_t)(L.main_bytes / L.fb_item_bytes)));
-    L.fb_off        = L.main_bytes;
-    L.queue_off     = L.fb_off + (((size_t)batch + 2) * sizeof(int32_t) + 15) / 16 * 16;
-  } else {
-    L.queue_off = L.main_bytes;
+    pool = (size_t)std::min<int64_t>(batch, sfb::qp_sparse_fallback_slots()) *
+           sfb::qp_sparse_ws_doubles(f.n, f.m, f.nnzL, f.funits, f.bunits, 0) * sizeof(double);
   }
-  L.total = L.queue_off + (sfb::qp_sparse_queue_bytes(batch) + 15) / 16 * 16;  // queue of a time-sliced launch
+  L.aux_off = L.pool_off + pool;
+  L.total   = L.aux_off + (sfb::qp_sparse_aux_bytes(batch) + 15) / 16 * 16;
   return L;
 }
 
@@ -260,8 +259,8 @@ sfb_status sfb_sparse_qp_plan_info(const sfb_sparse_qp_plan *plan, int64_t *nnzK
   if (nnzK) *nnzK = plan->host.nnzK;
   if (nnzL) *nnzL = plan->host.nnzL;
   if (workspace_bytes_per_item) {
-    // batch * this many bytes always suffice; sfb_sparse_qp_plan_workspace_bytes is exact (pruned plans need the
-    // room of one fallback item whatever the batch size, which this per-item figure has to include)
+    // batch * this many bytes always suffice; sfb_sparse_qp_plan_workspace_bytes is exact (a pruned plan's pool of
+    // whole-pattern slots and the launch's auxiliary memory do not grow with the batch beyond 64 items)
     const WsLayout L1 = ws_layout(plan, 1);
     *workspace_bytes_per_item = (int64_t)L1.total;
   }
@@ -291,6 +290,14 @@ sfb_status sfb_sparse_qp_plan_get_perm(const sfb_sparse_qp_plan *plan, int32_t *
   return SFB_OK;
 }
 
+sfb_status sfb_sparse_qp_plan_get_factor_order(const sfb_sparse_qp_plan *plan, int fallback, int32_t *rank)
+{
+  if (!plan || !rank) return sfb::fail(SFB_ERR_INVALID_ARG, "NULL argument");
+  const sfb::SparsePlanHost &h = (fallback && plan->pruned) ? plan->full : plan->host;
+  for (int f = 0; f < h.k; ++f) rank[h.f2s[f]] = f;
+  return SFB_OK;
+}
+
 sfb_status sfb_sparse_qp_solve_batch_ordered(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
                                      const double *Px, const double *q, const double *Ax, const double *l,
                                      const double *u, const double *warm_x, const double *warm_y, double *x,
@@ -307,30 +314,13 @@ sfb_status sfb_sparse_qp_solve_batch_ordered(sfb_sparse_qp_plan *plan, const sfb
   st = plan_on_device(plan, &dc);
   if (st != SFB_OK) return st;
   const sfb::DenseKernelParams kp = sfb::make_kernel_params(prm, plan->host.n, plan->host.m);
-  hipStream_t hs = static_cast<hipStream_t>(stream);
+  hipStream_t hs   = static_cast<hipStream_t>(stream);
   const WsLayout L = ws_layout(plan, batch);
-  int32_t *queue   = reinterpret_cast<int32_t *>(static_cast<char *>(workspace) + L.queue_off);
-  if (!plan->pruned) {
-    hipError_t e = sfb::qp_sparse_launch(dc->dev, kp, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code,
-                                         static_cast<double *>(workspace), hs, order, nullptr, 0, queue);
-    if (e != hipSuccess) return sfb::hip_fail(e, "qp_sparse_kernel launch");
-    return SFB_OK;
-  }
-  // Pruned plan: the first launch solves every item whose masked entries are zero and lists the others; the
-  // fallback launches (full pattern, same elimination order) work through the list, fb_cap items per launch,
-  // in the memory of the first.  The list is empty unless the caller's mask was wrong for an item: the fallback
-  // launches then cost a few microseconds of empty blocks.
-  int32_t *fb = reinterpret_cast<int32_t *>(static_cast<char *>(workspace) + L.fb_off);
-  hipError_t e = hipMemsetAsync(fb, 0, sizeof(int32_t), hs);
-  if (e != hipSuccess) return sfb::hip_fail(e, "hipMemsetAsync");
-  e = sfb::qp_sparse_launch(dc->dev, kp, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code,
-                            static_cast<double *>(workspace), hs, order, fb, 0, queue);
+  char *wsc        = static_cast<char *>(workspace);
+  hipError_t e     = sfb::qp_sparse_launch(dc->dev, kp, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code,
+                                           reinterpret_cast<double *>(wsc), hs, order, reinterpret_cast<int32_t *>(wsc + L.aux_off),
+                                           plan->pruned ? &dc->dev_full : nullptr, reinterpret_cast<double *>(wsc + L.pool_off));
   if (e != hipSuccess) return sfb::hip_fail(e, "qp_sparse_kernel launch");
-  for (int64_t base = 0; base < batch; base += L.fb_cap) {
-    e = sfb::qp_sparse_launch(dc->dev_full, kp, std::min(L.fb_cap, batch - base), Px, q, Ax, l, u, warm_x, warm_y, x, y, obj,
-                              iter, code, static_cast<double *>(workspace), hs, nullptr, fb, 1 + (int)base);
-    if (e != hipSuccess) return sfb::hip_fail(e, "qp_sparse_kernel fallback launch");
-  }
   return SFB_OK;
 }
 

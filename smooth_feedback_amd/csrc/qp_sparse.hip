@@ -38,6 +38,10 @@ namespace sfb {
 
 namespace {
 
+// A value every lane holds identically (loaded from the shared plan), as a scalar: loop bounds and branch conditions
+// built from it then compile to scalar compares and branches instead of exec-masked ones.
+__device__ __forceinline__ int uni(const int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 struct Ws {
   double *Lx, *LxF, *LxB, *D, *Dinv, *tv;  // Lx, D and one scratch double are contiguous (accumulators)
   double *sx, *qc, *xs, *xus, *dxus;
@@ -71,30 +75,33 @@ struct Item {
   const double *Px, *q, *Ax, *l, *u;
 };
 
-// KKT fill: every entry p of the permuted lower pattern goes to its accumulator.  mode 0: ADMM matrix
+// KKT fill: every entry of the permuted lower pattern goes to its accumulator.  mode 0: ADMM matrix
 // (qp_solver.hpp:382-395); mode 1: polish matrix H + diag(delta, -delta), inactive rows zeroed (:143-171).
 // Batched: the descriptors {kind, idx, row, col} of U entries per lane are fetched together, then everything they
 // point to (scaling factors, the P / A / rho value), then the values are formed and stored -- two memory round
-// trips per U entries instead of four per entry.  The arrays are padded (constant entries that land in the scratch
-// accumulator), so the batches are branch-free.
+// trips per U entries instead of four per entry.  [p_begin, p_end): entries of the descriptor array `desc4` /
+// accumulator map `map` to fill; entries past p_end are fetched (the arrays are padded) but not stored.
 typedef int vint4k __attribute__((ext_vector_type(4)));
 template<int U>
-__device__ __forceinline__ void kkt_fill(const SparsePlanDev &pl, const Item &it, const Ws &w, double *ACC, const int mode,
+__device__ __forceinline__ void kkt_fill(const int32_t *__restrict__ desc4, const int32_t *__restrict__ map, const int p_begin,
+                                         const int p_end, const Item &it, const Ws &w, double *ACC, const int mode,
                                          const double c, const double sigma, const double delta, const int lane)
 {
-  const vint4k *desc = reinterpret_cast<const vint4k *>(pl.Kdesc);
-  for (int p0 = lane; p0 < pl.nnzK; p0 += kWave * U) {
+  const vint4k *desc = reinterpret_cast<const vint4k *>(desc4);
+  for (int p0 = p_begin + lane; p0 < p_end; p0 += kWave * U) {
     vint4k d[U];
     int mp[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       d[u]  = desc[p0 + u * kWave];
-      mp[u] = pl.Kmap[p0 + u * kWave];
+      mp[u] = map[p0 + u * kWave];
     }
     double s1[U], s2[U], val[U], ac[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int kind = d[u].x, idx = d[u].y, r = d[u].z, cc = d[u].w;
+      const bool on  = p0 + u * kWave < p_end;
+      const int kind = on ? d[u].x : K_SIGMA, idx = d[u].y, r = d[u].z, cc = d[u].w;
+      d[u].x         = kind;
       const bool isP = kind == K_P, isA = kind == K_A;
       s1[u]  = (isP || isA) ? (isP ? w.sx : w.sy)[r] : 0.0;
       s2[u]  = (isP || isA) ? w.sx[cc] : 0.0;
@@ -117,14 +124,16 @@ __device__ __forceinline__ void kkt_fill(const SparsePlanDev &pl, const Item &it
       } else {
         v = (mode == 0) ? (-1.0 / val[u]) : 0.0 - delta;  // :395 / :171
       }
-      ACC[mp[u]] = v;
+      if (p0 + u * kWave < p_end) ACC[mp[u]] = v;
     }
   }
 }
 
 // One block of DEPTH trailing accumulators per lane: v = fma(-L(a, j), L(b, j) D(j), v) over the columns j of the
-// supernode in ascending order, the DEPTH chains advancing together.
-template<int DEPTH>
+// supernode in ascending order, the DEPTH chains advancing together.  PIPE: the LDS reads of column j + 1 are issued
+// before the fmas of column j (2 DEPTH reads, then DEPTH dependent fmas per column otherwise); costs 2 DEPTH more
+// registers.
+template<int DEPTH, bool PIPE>
 __device__ __forceinline__ void trailing_block(const double *pan, const double *mul, const int R, const int wd,
                                                const int (&tp)[DEPTH], const unsigned (&ab)[DEPTH], double (&v)[DEPTH],
                                                double *ACC)
@@ -135,64 +144,253 @@ __device__ __forceinline__ void trailing_block(const double *pan, const double *
     ra[dd] = wd + (int)(ab[dd] & 0xFFFFu);
     rb[dd] = wd + (int)(ab[dd] >> 16);
   }
-  for (int jj = 0; jj < wd; ++jj) {
+  if constexpr (PIPE) {
     double a[DEPTH], b[DEPTH];
 #pragma unroll
     for (int dd = 0; dd < DEPTH; ++dd) {
-      a[dd] = pan[jj * R + ra[dd]];
-      b[dd] = mul[jj * R + rb[dd]];
+      a[dd] = pan[ra[dd]];
+      b[dd] = mul[rb[dd]];
     }
+    for (int jj = 0; jj < wd; ++jj) {
+      const int jn = (jj + 1 < wd) ? jj + 1 : jj;  // (the last column is read once more: no branch in the loop)
+      double an[DEPTH], bn[DEPTH];
 #pragma unroll
-    for (int dd = 0; dd < DEPTH; ++dd) v[dd] = fma(-a[dd], b[dd], v[dd]);
+      for (int dd = 0; dd < DEPTH; ++dd) {
+        an[dd] = pan[jn * R + ra[dd]];
+        bn[dd] = mul[jn * R + rb[dd]];
+      }
+#pragma unroll
+      for (int dd = 0; dd < DEPTH; ++dd) v[dd] = fma(-a[dd], b[dd], v[dd]);
+#pragma unroll
+      for (int dd = 0; dd < DEPTH; ++dd) {
+        a[dd] = an[dd];
+        b[dd] = bn[dd];
+      }
+    }
+  } else {
+    for (int jj = 0; jj < wd; ++jj) {
+      double a[DEPTH], b[DEPTH];
+#pragma unroll
+      for (int dd = 0; dd < DEPTH; ++dd) {
+        a[dd] = pan[jj * R + ra[dd]];
+        b[dd] = mul[jj * R + rb[dd]];
+      }
+#pragma unroll
+      for (int dd = 0; dd < DEPTH; ++dd) v[dd] = fma(-a[dd], b[dd], v[dd]);
+    }
   }
 #pragma unroll
   for (int dd = 0; dd < DEPTH; ++dd) ACC[tp[dd]] = v[dd];
 }
 
-// Numeric LDL' on the shared pattern, RIGHT-LOOKING over RELAXED SUPERNODES with a static schedule
-// (sparse_plan.h).  The accumulators [L values | D] live in the item's HBM workspace.  Per group of
-// consecutive columns j0 .. j0+w-1 (R = w + |U| panel rows, U = union of the members' remaining structures):
-//   1. its own accumulators (a dense w x R panel, explicit zeros where a member has no entry) are loaded into
-//      LDS together with the first block of trailing accumulators (one memory round trip);
-//   2. the panel is eliminated column by column: divide by D, stage the entries L(.,j) and the multipliers
-//      L(.,j) D(j), update the later panel columns -- in REGISTERS when the panel has at most 64 rows (lane r holds
-//      row r, pivots and multipliers are v_readlane broadcasts: no LDS round trip on the dependent chain; the MPC
-//      pattern has R <= 58), else in LDS;
-//   3. every TRAILING accumulator (a pair of rows of U) receives the w updates of the group with ONE
-//      read-modify-write, 64 independent slots per step.
-// Every accumulator still sees its sources in ascending column order, fma(-L(a,j), L(b,j) D(j), acc), so
-// the arithmetic equals the oracle's left-looking loop bit for bit (zero entries contribute exact zeros);
-// what changes is the HBM traffic and the number of dependent memory round trips: for the MPC pattern
-// 81 k accumulator touches and 2 x 207 round trips per factorisation instead of 711 k and 2 x 1 480.
-// t = LDS scratch of pl.lds_doubles doubles (the plan caps w so that 2 w R fits).  Returns 1 / 0 (zero pivot).
 constexpr int kPanelCols = 16;  // == the plan's widest supernode (sparse_plan.cpp kMaxWidth)
 
+// Elimination of a panel of at most 64 rows in REGISTERS: lane r holds row r, one register per member column.
+// Pivots and multipliers travel by v_readlane broadcasts; no LDS round trip and no fence on the dependent chain.
+// Per entry: divide by D, multiply back, fma(-L(ra, j), L(rb, j) D(j), .) in ascending j.  Entries above the
+// diagonal hold garbage and are never used.  Stages L(., j) in pan and L(., j) D(j) in mul for the trailing
+// updates.  W = width class (wd <= W): the updates of the later columns run branch-free over all W registers --
+// registers beyond wd belong to no column, collect garbage and are never stored -- so that the scheduler can
+// overlap them with the next column's division chain (one scalar branch per COLUMN is all that is left).
+// Returns false on a zero pivot.
+template<int W>
+__device__ __forceinline__ bool panel_eliminate_w(double (&reg)[kPanelCols], const int wd, const int R, double *pan,
+                                                  double *mul, const int lane)
+{
+#pragma unroll
+  for (int jj = 0; jj < W; ++jj) {
+    if (jj < wd) {
+      const double d = lane_bcast(reg[jj], jj);
+      if (d == 0.0) return false;
+      const double v  = reg[jj] / d;
+      const double mv = v * d;
+      if (lane > jj) reg[jj] = v;
+      if (lane < R) {  // final column jj: L(r, j) below the diagonal, D on it; multipliers for the trailing update
+        pan[jj * R + lane] = reg[jj];
+        mul[jj * R + lane] = mv;
+      }
+#pragma unroll
+      for (int rb = jj + 1; rb < W; ++rb) reg[rb] = fma(-v, lane_bcast(mv, rb), reg[rb]);
+    }
+  }
+  return true;
+}
+__device__ __forceinline__ bool panel_eliminate(double (&reg)[kPanelCols], const int wd, const int R, double *pan, double *mul,
+                                                const int lane)
+{
+  // (dispatching on narrower width classes for narrow supernodes was tried: the register allocator then spills)
+  return panel_eliminate_w<kPanelCols>(reg, wd, R, pan, mul, lane);
+}
+
+// Numeric LDL' on the shared pattern, RIGHT-LOOKING over RELAXED SUPERNODES with a static schedule
+// (sparse_plan.h), in the factorisation numbering F (a postorder of the elimination tree).  Accumulators
+// [L values | D | sink | zero]: every accumulator sees its sources in ascending column order,
+// fma(-L(a,j), L(b,j) D(j), acc) -- the arithmetic of the oracle's left-looking loop with its sources in the same
+// order, bit for bit (zero entries contribute exact zeros).  The columns come in SEGMENTS:
+//  * an LDS SEGMENT is a subtree of the elimination tree whose accumulators fit the item's LDS (the work vector
+//    is free during the factorisation).  Its KKT entries are filled into LDS, its supernodes gather their panels
+//    from LDS and update each other in LDS: no HBM round trip on the dependent chain.  Final values of L and D
+//    leave for the workspace straight from the registers (nobody reads them back before the sweep copies are
+//    built), and only the updates to ancestors OUTSIDE the subtree are read-modify-writes in HBM;
+//  * a TOP segment (columns whose subtrees do not fit: the separators of an MPC horizon) keeps its accumulators
+//    in the item's HBM workspace: per supernode the panel and the first block of trailing accumulators are
+//    fetched in one round trip, eliminated, and every trailing accumulator receives the group's updates with ONE
+//    read-modify-write.
+// Per supernode (R = w + |U| panel rows, U = union of the members' remaining structures): the panel (w x R, explicit
+// zeros where a member has no entry) is eliminated in registers when R <= 64 (always inside LDS segments), else in
+// LDS.  MPC pattern: 13 on-chip subtrees (the mesh intervals: 938 accumulators, 8 supernodes each) and 13
+// supernodes of separators in HBM, 118 supernodes in all.
+// t = LDS of pl.lds_doubles doubles.  Returns 1 / 0 (zero pivot).
 template<int DEPTH>
 __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, const Ws &w, double *t, const int mode,
                                       const double c, const double sigma, const double delta, const int lane)
 {
-  const int k = pl.k, nnzL = pl.nnzL;
+  const int k = uni(pl.k), nnzL = uni(pl.nnzL);
 #ifdef SFB_PROF_LDL
-  unsigned long long pt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pc = __builtin_amdgcn_s_memtime();
+  unsigned long long pt[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pc = __builtin_amdgcn_s_memtime();
 #define SFB_LAP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[i] += now_ - pc; pc = now_; }
 #else
 #define SFB_LAP(i)
 #endif
-  double *ACC = w.Lx;  // [0, nnzL): L entries, [nnzL, nnzL+k): D, [nnzL+k]: scratch, [nnzL+k+1]: always zero
-  for (int p = lane; p < nnzL + k + 2; p += kWave) ACC[p] = 0.0;
+  double *ACC   = w.Lx;  // [0, nnzL): L entries, [nnzL, nnzL+k): D, [nnzL+k]: sink, [nnzL+k+1]: always zero
+  const int pad = nnzL + k;
+  for (int z = 0, nz = uni(pl.nztop); z < nz; ++z) {  // accumulators of the top columns (the others never live in HBM)
+    const int z0 = uni(pl.ztop[2 * z]), zn = uni(pl.ztop[2 * z + 1]);
+    for (int p = lane; p < zn; p += kWave) ACC[z0 + p] = 0.0;
+  }
   wave_sync();
-  kkt_fill<4>(pl, it, w, ACC, mode, c, sigma, delta, lane);
+  kkt_fill<4>(pl.KdescT, pl.KmapT, 0, uni(pl.nnzKT), it, w, ACC, mode, c, sigma, delta, lane);
   wave_sync();
   SFB_LAP(0)
-  for (int sn = 0; sn < pl.nsn; ++sn) {
-    const int j0 = pl.snptr[sn], wd = pl.snptr[sn + 1] - j0;
-    const int R  = pl.snR[sn];  // panel rows: the w columns themselves, then the union U of their structures
+  for (int sg = 0, nseg = uni(pl.nseg); sg < nseg; ++sg) {
+    const int32_t *sgp = pl.seg + 10 * sg;
+    const int sn0 = uni(sgp[0]), sn1 = uni(sgp[1]), on_chip = uni(sgp[4]);
+    if (on_chip) {
+      // ---------------- LDS segment ----------------
+      const int accN = uni(sgp[6]), kp0 = uni(sgp[7]), kp1 = uni(sgp[8]), nLs = uni(sgp[5]);
+      const int gL = uni(sgp[9]), gD = nnzL + uni(sgp[2]) - nLs;  // LDS offset -> accumulator: + gL (L entries), + gD (diagonal)
+      const int zero = accN + 1;                  // LDS: [0, accN) accumulators, accN sink, accN + 1 always zero
+      double *scr    = t + ((accN + 2 + 1) & ~1);  // panel scratch behind them
+      for (int e = lane; e < accN + 2; e += kWave) t[e] = 0.0;
+      wave_lds_fence();
+      kkt_fill<4>(pl.Kdesc, pl.KmapL, kp0, kp1, it, w, t, mode, c, sigma, delta, lane);
+      wave_lds_fence();
+      SFB_LAP(1)
+      // Supernodes of the segment.  Software pipeline over the supernodes: while one is being eliminated, the panel
+      // map of the next is on its way from the L2, and the first block of accumulators OUTSIDE the subtree that
+      // this supernode updates (they do not depend on its panel) is on its way from HBM.
+      constexpr int DL = 4;  // trailing accumulators per lane and block inside an LDS segment
+      int j0 = uni(pl.snptr[sn0]), wd = uni(pl.snptr[sn0 + 1]) - j0, R = uni(pl.snR[sn0]);
+      int srcL[kPanelCols];
+      {
+        const int32_t *pmL = pl.pmapL + uni(pl.poff[sn0]);
+#pragma unroll
+        for (int jj = 0; jj < kPanelCols; ++jj) srcL[jj] = (jj < wd && lane < R) ? pmL[jj * R + lane] : zero;
+      }
+      for (int sn = sn0; sn < sn1; ++sn) {
+        const int s0 = uni(pl.rptr[sn]), sp = uni(pl.rsplit[sn]), s1 = uni(pl.rptr[sn + 1]);
+        double *pan = scr, *mul = scr + wd * R;
+        // first block of outside accumulators
+        int tpx[DL];
+        unsigned abx[DL];
+        double accx[DL];
+#pragma unroll
+        for (int dd = 0; dd < DL; ++dd) {  // the schedule arrays are padded: reading past s1 is safe
+          tpx[dd] = pl.rtgt[(sp + dd) * kWave + lane];
+          abx[dd] = (unsigned)pl.rab[(sp + dd) * kWave + lane];
+          if (sp + dd >= s1) {
+            tpx[dd] = pad;
+            abx[dd] = 0u;
+          }
+        }
+#pragma unroll
+        for (int dd = 0; dd < DL; ++dd) accx[dd] = ACC[tpx[dd]];
+        // panel of this supernode from LDS
+        double reg[kPanelCols];
+#pragma unroll
+        for (int jj = 0; jj < kPanelCols; ++jj) reg[jj] = t[srcL[jj]];
+        // panel map of the next one
+        const int snn = (sn + 1 < sn1) ? sn + 1 : sn;
+        const int j0n = uni(pl.snptr[snn]), wdn = uni(pl.snptr[snn + 1]) - j0n, Rn = uni(pl.snR[snn]);
+        int srcN[kPanelCols];
+        {
+          const int32_t *pmN = pl.pmapL + uni(pl.poff[snn]);
+#pragma unroll
+          for (int jj = 0; jj < kPanelCols; ++jj) srcN[jj] = (jj < wdn && lane < Rn) ? pmN[jj * Rn + lane] : zero;
+        }
+        SFB_LAP(8)
+        if (!panel_eliminate(reg, wd, R, pan, mul, lane)) return 0;
+        SFB_LAP(9)
+        // final D and L values -> workspace, straight from the registers (entries above the diagonal and explicit
+        // zeros map to the sink / zero accumulators and are skipped); D also stays on chip for the 1 / D pass below
+#pragma unroll
+        for (int jj = 0; jj < kPanelCols; ++jj) {
+          if (srcL[jj] < accN) ACC[srcL[jj] + (srcL[jj] < nLs ? gL : gD)] = reg[jj];
+          if (jj < wd && lane == jj) t[srcL[jj]] = reg[jj];
+        }
+        wave_lds_fence();
+        SFB_LAP(10)
+        // trailing accumulators on chip: pairs (a >= b) of rows of U, local rows w + a, w + b
+        for (int s = s0; s < sp; s += DL) {
+          int tp[DL];
+          unsigned ab[DL];
+          double acc[DL];
+#pragma unroll
+          for (int dd = 0; dd < DL; ++dd) {  // the schedule arrays are padded: reading past sp is safe
+            tp[dd] = pl.rtgt[(s + dd) * kWave + lane];
+            ab[dd] = (unsigned)pl.rab[(s + dd) * kWave + lane];
+            if (s + dd >= sp) {
+              tp[dd] = accN;
+              ab[dd] = 0u;
+            }
+          }
+#pragma unroll
+          for (int dd = 0; dd < DL; ++dd) acc[dd] = t[tp[dd]];
+          trailing_block<DL, true>(pan, mul, R, wd, tp, ab, acc, t);
+        }
+        SFB_LAP(11)
+        // ... and the ones of ancestors outside the subtree, in HBM
+        trailing_block<DL, true>(pan, mul, R, wd, tpx, abx, accx, ACC);
+        for (int s = sp + DL; s < s1; s += DL) {
+          int tp[DL];
+          unsigned ab[DL];
+          double acc[DL];
+#pragma unroll
+          for (int dd = 0; dd < DL; ++dd) {
+            tp[dd] = pl.rtgt[(s + dd) * kWave + lane];
+            ab[dd] = (unsigned)pl.rab[(s + dd) * kWave + lane];
+            if (s + dd >= s1) {
+              tp[dd] = pad;
+              ab[dd] = 0u;
+            }
+          }
+#pragma unroll
+          for (int dd = 0; dd < DL; ++dd) acc[dd] = ACC[tp[dd]];
+          trailing_block<DL, true>(pan, mul, R, wd, tp, ab, acc, ACC);
+        }
+        wave_lds_fence();
+        SFB_LAP(12)
+        j0 = j0n; wd = wdn; R = Rn;
+#pragma unroll
+        for (int jj = 0; jj < kPanelCols; ++jj) srcL[jj] = srcN[jj];
+      }
+      {  // 1 / D of the segment's columns (the sweeps multiply by the reciprocal, qp_solver.hpp:458), in S numbering
+        const int c0 = uni(sgp[2]), c1 = uni(sgp[3]);
+        for (int j = c0 + lane; j < c1; j += kWave) w.Dinv[pl.f2s[j]] = 1.0 / t[nLs + (j - c0)];
+      }
+      SFB_LAP(2)
+      wave_sync();  // the HBM updates of this segment are complete before a later segment gathers them
+      continue;
+    }
+    // ---------------- top segment: accumulators in HBM ----------------
+    for (int sn = sn0; sn < sn1; ++sn) {
+    const int j0 = uni(pl.snptr[sn]), wd = uni(pl.snptr[sn + 1]) - j0;
+    const int R  = uni(pl.snR[sn]);  // panel rows: the w columns themselves, then the union U of their structures
     double *pan  = t;                                // pan[jj * R + r], r >= jj: accumulators, then L(r, j0+jj)
     double *mul  = t + wd * R;                       // mul[jj * R + r] = L(r, j0+jj) * D(j0+jj)
     // The first DEPTH steps of trailing accumulators do not depend on this supernode's panel: their loads
     // are issued together with the panel's (one memory round trip instead of two per supernode).
-    const int s0 = pl.rptr[sn], s1 = pl.rptr[sn + 1];
-    const int pad = nnzL + k;
+    const int s0 = uni(pl.rsplit[sn]), s1 = uni(pl.rptr[sn + 1]);  // (no on-chip steps here: rsplit == rptr)
     int tp0[DEPTH];
     unsigned ab0[DEPTH];
     double acc0[DEPTH];
@@ -207,13 +405,10 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
     }
 #pragma unroll
     for (int dd = 0; dd < DEPTH; ++dd) acc0[dd] = ACC[tp0[dd]];
-    const int32_t *pm = pl.pmap + pl.poff[sn];
+    const int32_t *pm = pl.pmap + uni(pl.poff[sn]);
     const int npan    = wd * R;
     if (R <= kWave) {
-      // 1 + 2, register form (the usual case): lane r holds row r of the panel, one register per member column.
-      // Pivots and multipliers travel by v_readlane broadcasts; no LDS round trip and no fence on the dependent
-      // chain of the elimination.  Same operations per entry as the LDS form below: divide by D, multiply back,
-      // fma(-L(ra, j), L(rb, j) D(j), .) in ascending j.  Entries above the diagonal hold garbage and are never used.
+      // register form (the usual case): gather, eliminate, write the final values back with the gather indices
       double reg[kPanelCols];
       int src[kPanelCols];
 #pragma unroll
@@ -221,27 +416,8 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
         src[jj] = (jj < wd && lane < R) ? pm[jj * R + lane] : pad + 1;  // pad + 1: the always-zero accumulator
 #pragma unroll
       for (int jj = 0; jj < kPanelCols; ++jj) reg[jj] = ACC[src[jj]];
-      SFB_LAP(1)
-#pragma unroll
-      for (int jj = 0; jj < kPanelCols; ++jj) {
-        if (jj < wd) {
-          const double d = lane_bcast(reg[jj], jj);
-          if (d == 0.0) return 0;
-          const double v  = reg[jj] / d;
-          const double mv = v * d;
-          if (lane > jj) reg[jj] = v;
-          if (lane < R) {  // final column jj: L(r, j) below the diagonal, D on it; multipliers for the trailing update
-            pan[jj * R + lane] = reg[jj];
-            mul[jj * R + lane] = mv;
-          }
-#pragma unroll
-          for (int rb = jj + 1; rb < kPanelCols; ++rb)
-            if (rb < wd) reg[rb] = fma(-v, lane_bcast(mv, rb), reg[rb]);
-        }
-      }
-      // final D and L values of the panel -> workspace, straight from the registers and with the indices the panel
-      // was gathered with (no reload of the map, no LDS read; entries above the diagonal and explicit zeros map to
-      // the scratch / zero accumulators and are skipped)
+      SFB_LAP(3)
+      if (!panel_eliminate(reg, wd, R, pan, mul, lane)) return 0;
 #pragma unroll
       for (int jj = 0; jj < kPanelCols; ++jj)
         if (src[jj] < pad) ACC[src[jj]] = reg[jj];
@@ -260,7 +436,7 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
         if (q0 + dd * kWave < npan) pan[q0 + dd * kWave] = v[dd];
     }
     wave_lds_fence();
-    SFB_LAP(1)
+    SFB_LAP(3)
     // 2. eliminate the panel (LDS only)
     for (int jj = 0; jj < wd; ++jj) {
       const double d = pan[jj * R + jj];
@@ -278,18 +454,15 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
     }
     for (int q = lane; q < npan; q += kWave) {  // final D and L values of the panel -> workspace (fire and forget)
       const int dst = pm[q];
-      if (dst < pad) ACC[dst] = pan[q];  // not the scratch / zero accumulators
+      if (dst < pad) ACC[dst] = pan[q];  // not the sink / zero accumulators
     }
     }
-    SFB_LAP(2)
-    SFB_LAP(5)
-    for (int jj = lane; jj < wd; jj += kWave) w.Dinv[j0 + jj] = 1.0 / pan[jj * R + jj];
-    SFB_LAP(6)
+    SFB_LAP(4)
+    for (int jj = lane; jj < wd; jj += kWave) w.Dinv[pl.f2s[j0 + jj]] = 1.0 / pan[jj * R + jj];
     // 3. trailing accumulators: pairs (a >= b) of rows of U, local rows w + a, w + b
     // (the DEPTH chains of a block advance together, column by column: 2 x DEPTH LDS reads in flight per lane
-    //  instead of one dependent pair; padding slots compute on row 0 and land in the scratch accumulator)
-    trailing_block<DEPTH>(pan, mul, R, wd, tp0, ab0, acc0, ACC);
-    SFB_LAP(7)
+    //  instead of one dependent pair; padding slots compute on row 0 and land in the sink accumulator)
+    trailing_block<DEPTH, false>(pan, mul, R, wd, tp0, ab0, acc0, ACC);
     for (int s = s0 + DEPTH; s < s1; s += DEPTH) {
       int tp[DEPTH];
       unsigned ab[DEPTH];
@@ -305,11 +478,12 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
       }
 #pragma unroll
       for (int dd = 0; dd < DEPTH; ++dd) acc[dd] = ACC[tp[dd]];
-      trailing_block<DEPTH>(pan, mul, R, wd, tp, ab, acc, ACC);
+      trailing_block<DEPTH, false>(pan, mul, R, wd, tp, ab, acc, ACC);
     }
-    SFB_LAP(3)
+    SFB_LAP(5)
     wave_sync();
-    SFB_LAP(8)
+    SFB_LAP(6)
+    }
   }
   // Schedule-ordered copies of the factor for the two sweeps (padding slots carry 0).  A streaming pass: writing
   // the final values straight into the copies from the panels (scattered 8-byte writes) is quicker for a lone
@@ -329,14 +503,15 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
     }
   };
   static_assert(kSweepPadDev * 2 >= DEPTH, "copy loop assumes whole blocks");
-  gather_copy(pl.fmap, w.LxF, (pl.funits + kSweepPadDev) * 2 * kWave);
-  gather_copy(pl.bmap, w.LxB, (pl.bunits + kSweepPadDev) * 2 * kWave);
   wave_sync();
-  SFB_LAP(4)
+  gather_copy(pl.fmap, w.LxF, (uni(pl.funits) + kSweepPadDev) * 2 * kWave);
+  gather_copy(pl.bmap, w.LxB, (uni(pl.bunits) + kSweepPadDev) * 2 * kWave);
+  wave_sync();
+  SFB_LAP(7)
 #ifdef SFB_PROF_LDL
   if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
-    printf("[ldl block %u mode %d] fill %llu  panel-load %llu  panel-elim %llu  finals %llu  dinv %llu  block0 %llu  blocks1+ %llu  sync %llu  copies %llu  (cycles)\n",
-           blockIdx.x, mode, pt[0], pt[1], pt[2], pt[5], pt[6], pt[7], pt[3], pt[8], pt[4]);
+    printf("[ldl block %u mode %d] zero+top fill %llu  lds fill %llu  lds segments: panel-load %llu elim %llu finals+dinv %llu trailing-lds %llu trailing-hbm %llu rest %llu | top: panel-load %llu  panel-elim %llu  trailing %llu  sync %llu  copies %llu  (cycles)\n",
+           blockIdx.x, mode, pt[0], pt[1], pt[8], pt[9], pt[10], pt[11], pt[12], pt[2], pt[3], pt[4], pt[5], pt[6], pt[7]);
 #endif
   return 1;
 }
@@ -504,8 +679,8 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
 // t (LDS, permuted order) <- K^-1 t   (qp_solver.hpp:457-459)
 __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, double *t, const int lane, const bool lean)
 {
-  const int k = pl.k;
-  const bool bo = pl.idx_scale == 8;
+  const int k = uni(pl.k);
+  const bool bo = uni(pl.idx_scale) == 8;
   auto sweep = [&](const int32_t *idx, const int units, const double *vals, const int32_t *mask, const int f0, const int f1) {
     if (lean) {
       if (bo) sweep_dev<SFB_SWEEP_DEPTH, true, true>(idx, units, vals, t, lane, mask, f0, f1);
@@ -515,7 +690,7 @@ __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, doubl
       else sweep_dev<SFB_SWEEP_DEPTH, false, false>(idx, units, vals, t, lane, mask, f0, f1);
     }
   };
-  sweep(pl.fidx, pl.funits, w.LxF, pl.fmask, pl.ffull0, pl.ffull1);  // forward (column oriented order)
+  sweep(pl.fidx, uni(pl.funits), w.LxF, pl.fmask, uni(pl.ffull0), uni(pl.ffull1));  // forward (column oriented order)
   for (int j0 = lane; j0 < k; j0 += kWave * 8) {  // D^-1 (:458), loads batched
     double dv[8];
 #pragma unroll
@@ -525,7 +700,7 @@ __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, doubl
       if (j0 + e * kWave < k) t[j0 + e * kWave] = dv[e] * t[j0 + e * kWave];
   }
   wave_sync();
-  sweep(pl.bidx, pl.bunits, w.LxB, pl.bmask, pl.bfull0, pl.bfull1);  // backward (rows pushing, descending)
+  sweep(pl.bidx, uni(pl.bunits), w.LxB, pl.bmask, uni(pl.bfull0), uni(pl.bfull1));  // backward (rows pushing, descending)
 }
 
 __device__ __forceinline__ double lane_max_abs(const double *v, int len, int lane)
@@ -587,9 +762,9 @@ __device__ __forceinline__ double sp_row_P(const SparsePlanDev &pl, const Item &
 __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it, const Ws &w,
                                         const DenseKernelParams &kp, double *t, const int lane)
 {
-  const int n = pl.n, m = pl.m;
+  const int n = uni(pl.n), m = uni(pl.m);
   const double inf = INFINITY;
-  const int chunk  = (pl.k + 1) / 2;  // pairs of doubles that fit the work vector
+  const int chunk  = (uni(pl.k) + 1) / 2;  // pairs of doubles that fit the work vector
   {  // OPTIMALITY
     double a = 0.0, r = 0.0, z = 0.0;
     for (int i = lane; i < m; i += kWave) {
@@ -679,7 +854,7 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
 __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const Ws &w, const DenseKernelParams &kp,
                                  double *t, const double c, const int lane, const bool lean)
 {
-  const int n = pl.n, m = pl.m, k = pl.k;
+  const int n = uni(pl.n), m = uni(pl.m), k = uni(pl.k);
   const double inf = INFINITY, eps = DBL_EPSILON;
   for (int i = lane; i < m; i += kWave) {  // :113-123
     const double yi = w.ys[i];
@@ -787,13 +962,32 @@ __device__ int g_sparse_active = 0;  // resident waves of qp_sparse_kernel (all 
 //   q[kQRing + i]  ring entries (item + 1, 0 = empty), capacity = batch
 constexpr int kQFresh = 0, kQHead = 16, kQTail = 32, kQRing = 48;
 
-enum { SP_DONE = 0, SP_FALLBACK = 1, SP_SUSPENDED = 2 };
+enum { SP_DONE = 0, SP_SUSPENDED = 2 };
 
-// One item.  `slot` = workspace slot.  resume == false: from the start (guard, scaling, factorisation, initial
-// iterate); resume == true: continue an item another block has suspended (its state is in its workspace).
+// GUARD of a pruned plan: the entries of A the plan's creator declared zero must be zero in this item (NaN counts
+// as non-zero).  Amasked is padded: branch-free batches.
+__device__ __forceinline__ bool sp_guard_ok(const SparsePlanDev &pl, const double *__restrict__ Ax, const int lane)
+{
+  constexpr int UB = 8;
+  const int nmasked = uni(pl.nmasked);
+  bool bad = false;
+  for (int p0 = lane; p0 < nmasked; p0 += kWave * UB) {
+    int src[UB];
+    double v[UB];
+#pragma unroll
+    for (int e = 0; e < UB; ++e) src[e] = pl.Amasked[p0 + e * kWave];
+#pragma unroll
+    for (int e = 0; e < UB; ++e) v[e] = Ax[src[e]];
+#pragma unroll
+    for (int e = 0; e < UB; ++e) bad = bad || !(v[e] == 0.0);
+  }
+  return wave_ballot(bad) == 0ull;
+}
+
+// One item.  `slot` = workspace slot.  resume == false: from the start (scaling, factorisation, initial iterate);
+// resume == true: continue an item another block has suspended (its state is in its workspace).
 // Runs until the item is finished (SP_DONE), or -- time-sliced launches only, queue != nullptr -- until the item
 // has used its slice while others are waiting for a wave (SP_SUSPENDED: state saved, the caller queues the item).
-// SP_FALLBACK: pruned plan and a masked entry of A is not zero: the item went to the fallback list, unsolved.
 __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const DenseKernelParams &kp, const double *__restrict__ gPx,
                                              const double *__restrict__ gq, const double *__restrict__ gAx,
                                              const double *__restrict__ gl, const double *__restrict__ gu,
@@ -801,14 +995,15 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
                                              double *__restrict__ gx, double *__restrict__ gy, double *__restrict__ gobj,
                                              uint32_t *__restrict__ giter, int32_t *__restrict__ gcode,
                                              double *__restrict__ gws, const size_t ws_doubles, const int lean_waves,
-                                             bool lean, const size_t b, const size_t slot, int32_t *__restrict__ fb,
-                                             double *t, const int lane, const bool resume, const int32_t *queue,
-                                             const int batch, const uint32_t slice)
+                                             bool lean, const size_t b, const size_t slot, double *t, const int lane,
+                                             const bool resume, const int32_t *queue, const int batch,
+                                             const uint32_t slice)
 {
-  const int n = pl.n, m = pl.m, k = pl.k;
-  Item it{gPx + b * (size_t)pl.nnzP, gq + b * (size_t)n, gAx + b * (size_t)pl.nnzA_io, gl + b * (size_t)m,
+  const int n = uni(pl.n), m = uni(pl.m), k = uni(pl.k);
+  const int nnzP = uni(pl.nnzP), nnzA = uni(pl.nnzA);  // (nnzA: what the kernel works on, the kept entries of a pruned plan)
+  Item it{gPx + b * (size_t)nnzP, gq + b * (size_t)n, gAx + b * (size_t)uni(pl.nnzA_io), gl + b * (size_t)m,
           gu + b * (size_t)m};
-  const Ws w = carve_ws(gws + slot * ws_doubles, n, m, pl.nnzL, pl.funits, pl.bunits);
+  const Ws w = carve_ws(gws + slot * ws_doubles, n, m, uni(pl.nnzL), uni(pl.funits), uni(pl.bunits));
 #ifdef SFB_SP_TIMELINE  // profiling build (scripts/build_prof.sh): wall-clock stamps (100 MHz) of the item's phases
   unsigned long long tl0 = wall_clock64(), tl1 = 0, tl2 = 0;
 #endif
@@ -831,27 +1026,10 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     if (pl.Aorig != nullptr) it.Ax = w.Axc;
   } else {
   if (pl.Aorig != nullptr) {
-    // Pruned plan.  GUARD: the entries of A the plan's creator declared structurally zero must be zero (NaN counts
-    // as non-zero) -- otherwise the item goes to the fallback list and is solved on the full pattern by the second
-    // launch of the call.  Then the kept entries are compacted into the workspace: everything below works on the
-    // compressed pattern.  (Amasked / Aorig are padded: branch-free batches.)
+    // Pruned plan (its guard has passed, see the kernel): the kept entries of A are compacted into the workspace;
+    // everything below works on the compressed pattern.  (Aorig is padded: branch-free batches.)
     constexpr int UB = 8;
-    bool bad = false;
-    for (int p0 = lane; p0 < pl.nmasked; p0 += kWave * UB) {
-      int src[UB];
-      double v[UB];
-#pragma unroll
-      for (int e = 0; e < UB; ++e) src[e] = pl.Amasked[p0 + e * kWave];
-#pragma unroll
-      for (int e = 0; e < UB; ++e) v[e] = it.Ax[src[e]];
-#pragma unroll
-      for (int e = 0; e < UB; ++e) bad = bad || !(v[e] == 0.0);
-    }
-    if (wave_ballot(bad)) {
-      if (lane == 0) fb[1 + atomicAdd(&fb[0], 1)] = (int32_t)b;
-      return SP_FALLBACK;
-    }
-    for (int p0 = lane; p0 < pl.nnzA; p0 += kWave * UB) {
+    for (int p0 = lane; p0 < nnzA; p0 += kWave * UB) {
       int src[UB];
       double v[UB];
 #pragma unroll
@@ -860,7 +1038,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
       for (int e = 0; e < UB; ++e) v[e] = it.Ax[src[e]];
 #pragma unroll
       for (int e = 0; e < UB; ++e)
-        if (p0 + e * kWave < pl.nnzA) w.Axc[p0 + e * kWave] = v[e];
+        if (p0 + e * kWave < nnzA) w.Axc[p0 + e * kWave] = v[e];
     }
     it.Ax = w.Axc;
     wave_sync();
@@ -897,13 +1075,13 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
       for (int e = lane; e < k; e += kWave) t[e] = 0.0;
       wave_sync();
       constexpr int UB = 8;
-      for (int p0 = lane; p0 < pl.nnzP; p0 += kWave * UB) {
+      for (int p0 = lane; p0 < nnzP; p0 += kWave * UB) {
         int rr[UB], cc[UB];
         double pv[UB], sr[UB], sc[UB];
 #pragma unroll
         for (int e = 0; e < UB; ++e) {
           const int p = p0 + e * kWave;
-          const bool on = p < pl.nnzP;
+          const bool on = p < nnzP;
           rr[e] = on ? pl.Pi[p] : 0;
           cc[e] = on ? pl.Pcol[p] : 0;
           pv[e] = on ? it.Px[p] : 0.0;
@@ -915,16 +1093,16 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
         }
 #pragma unroll
         for (int e = 0; e < UB; ++e)
-          if (p0 + e * kWave < pl.nnzP)
+          if (p0 + e * kWave < nnzP)
             __hip_atomic_fetch_max(&t[cc[e]], fabs(c * sr[e] * sc[e] * pv[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      for (int p0 = lane; p0 < pl.nnzA; p0 += kWave * UB) {
+      for (int p0 = lane; p0 < nnzA; p0 += kWave * UB) {
         int rr[UB], cc[UB];
         double av[UB], sr[UB], sc[UB];
 #pragma unroll
         for (int e = 0; e < UB; ++e) {
           const int p = p0 + e * kWave;
-          const bool on = p < pl.nnzA;
+          const bool on = p < nnzA;
           rr[e] = on ? pl.Arow[p] : 0;
           cc[e] = on ? pl.Aj[p] : 0;
           av[e] = on ? it.Ax[p] : 0.0;
@@ -936,7 +1114,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
         }
 #pragma unroll
         for (int e = 0; e < UB; ++e) {
-          if (p0 + e * kWave < pl.nnzA) {
+          if (p0 + e * kWave < nnzA) {
             const double v = fabs(sr[e] * sc[e] * av[e]);
             __hip_atomic_fetch_max(&t[cc[e]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_max(&t[n + rr[e]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1222,6 +1400,10 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
 
 }  // namespace
 
+// Launch-wide auxiliary memory (zeroed by the launcher): the queue of a time-sliced launch, then the flags of the
+// fallback pool of a pruned plan (kFbSlots ints, 0 = free).
+constexpr int kFbSlots = 64;
+
 __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev *__restrict__ plp, const DenseKernelParams kp,
                                                        const double *__restrict__ gPx, const double *__restrict__ gq,
                                                        const double *__restrict__ gAx, const double *__restrict__ gl,
@@ -1231,32 +1413,22 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev *_
                                                        uint32_t *__restrict__ giter, int32_t *__restrict__ gcode,
                                                        double *__restrict__ gws, const size_t ws_doubles,
                                                        const int lean_waves, const int32_t *__restrict__ order,
-                                                       int32_t *__restrict__ fb, const int fb_mode,
-                                                       int32_t *__restrict__ queue, const int batch, const uint32_t slice)
+                                                       int32_t *__restrict__ queue, const int batch, const uint32_t slice,
+                                                       const SparsePlanDev *__restrict__ plf, double *__restrict__ gwsf,
+                                                       const size_t wsf_doubles, int32_t *__restrict__ fbflags)
 {
-  extern __shared__ __attribute__((aligned(16))) double t[];  // k + 1 doubles: work / solution vector
+  extern __shared__ __attribute__((aligned(16))) double t[];  // work / solution vector, factorisation scratch
   // The plan (some forty pointers) is read from device memory where it is used: as a by-value kernel argument it
-  // would sit in SGPRs for the whole life of the persistent loop below and push the kernel into register spills.
-  const SparsePlanDev &pl = *plp;
-  const int lane0 = threadIdx.x;
-  // queue == nullptr: ONE ITEM PER BLOCK (batches that fit the chip at once, and the fallback launches of a pruned
-  // plan: block i takes entry fb_mode - 1 + i of the list the first launch of the call has written).
+  // would sit in SGPRs for the whole life of the loop below and push the kernel into register spills.
+  const int lane = threadIdx.x;
+  // queue == nullptr: ONE ITEM PER BLOCK (batches that fit the chip at once).
   // queue != nullptr: TIME-SLICED LAUNCH: a persistent grid (as many blocks as the chip holds) works through the
   // batch.  Fresh items first, in launch order; an item that has used its slice while others wait goes to the back
   // of a ring and is continued later by whichever block is free (its state lives in ITS workspace slot = item).
   for (bool first = true;; first = false) {
-    const int lane = lane0;
     int item = -1, resume = 0;
     if (queue == nullptr) {
-      if (first) {
-        item = blockIdx.x;
-        if (fb_mode != 0) {
-          const int pos = fb_mode - 1 + (int)blockIdx.x;
-          item          = (pos < __builtin_amdgcn_readfirstlane(fb[0])) ? fb[1 + pos] : -1;
-        } else if (order) {
-          item = order[blockIdx.x];
-        }
-      }
+      if (first) item = order ? order[blockIdx.x] : (int)blockIdx.x;
     } else if (lane == 0) {
       if (__hip_atomic_load(&queue[kQFresh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < batch) {
         const int tk = atomicAdd(&queue[kQFresh], 1);
@@ -1280,6 +1452,23 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev *_
     if (item < 0) break;
     if (resume) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the suspending block's stores (other CU / XCD)
     wave_sync();
+    // Pruned plan: the declaration "these stored entries of A are zero" is checked for the item.  An item that
+    // violates it is solved on the WHOLE pattern (plan plf, same elimination order) right here, in a workspace slot
+    // of the small fallback pool (whole-pattern items need more room); it runs to completion, never time-sliced.
+    const SparsePlanDev *use = plp;
+    double *wsb              = gws;
+    size_t wsd = ws_doubles, slot = (queue == nullptr) ? (size_t)blockIdx.x : (size_t)item;
+    int fbslot = -1;
+    if (plf != nullptr && !resume && !sp_guard_ok(*plp, gAx + (size_t)item * (size_t)uni(plp->nnzA_io), lane)) {
+      if (lane == 0) {
+        for (int probe = blockIdx.x % kFbSlots;; probe = (probe + 1) % kFbSlots) {
+          if (atomicCAS(&fbflags[probe], 0, 1) == 0) { fbslot = probe; break; }
+          __builtin_amdgcn_s_sleep(8);
+        }
+      }
+      fbslot = __builtin_amdgcn_readfirstlane(fbslot);
+      use = plf; wsb = gwsf; wsd = wsf_doubles; slot = (size_t)fbslot;
+    }
     // Waves busy with an item right now (all launches of the process).  While there are many, the launch is
     // HBM-bound and the sweeps skip the padding of the factor stream (masked loads: fewer bytes, a few more
     // instructions); when only stragglers are left, latency is what counts and they switch to plain loads.  A
@@ -1288,13 +1477,12 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev *_
     int seen = 0;
     if (lane == 0) seen = atomicAdd(&g_sparse_active, 1);
     const bool lean = ((queue == nullptr ? (int)gridDim.x : batch) > lean_waves) || __builtin_amdgcn_readfirstlane(seen) >= lean_waves;
-    // workspace slot: the launch position for one-item-per-block launches, the item for time-sliced ones
-    const int st = sp_solve_item(pl, kp, gPx, gq, gAx, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode, gws, ws_doubles,
-                                 lean_waves, lean, (size_t)item, queue == nullptr ? (size_t)blockIdx.x : (size_t)item, fb, t,
-                                 lane, resume != 0, queue, batch, slice);
+    const int st = sp_solve_item(*use, kp, gPx, gq, gAx, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode, wsb, wsd, lean_waves,
+                                 lean, (size_t)item, slot, t, lane, resume != 0, fbslot >= 0 ? nullptr : queue, batch, slice);
     wave_sync();
     if (lane == 0) {
       atomicSub(&g_sparse_active, 1);
+      if (fbslot >= 0) __hip_atomic_store(&fbflags[fbslot], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       if (st == SP_SUSPENDED) {
         // publish the item's state (plain and non-temporal stores of this wave) before its id enters the ring
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1310,7 +1498,7 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev *_
   }
 }
 
-// blocks of qp_sparse_kernel the device holds at once with `lds` bytes of dynamic LDS each (cached per device)
+// blocks of qp_sparse_kernel the device holds at once with `lds` bytes of dynamic LDS each
 static int sparse_resident_blocks(size_t lds)
 {
   int dev = 0, per_cu = 0, cus = 0;
@@ -1320,14 +1508,18 @@ static int sparse_resident_blocks(size_t lds)
   return per_cu * cus;
 }
 
+size_t qp_sparse_aux_bytes(int64_t batch) { return ((size_t)batch + kQRing + kFbSlots) * sizeof(int32_t); }
+int qp_sparse_fallback_slots() { return kFbSlots; }
+
 hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp, int64_t batch, const double *Px,
                             const double *q, const double *Ax, const double *l, const double *u, const double *wx,
                             const double *wy, double *x, double *y, double *obj, uint32_t *iter, int32_t *code,
-                            double *workspace, hipStream_t stream, const int32_t *order, int32_t *fb, int fb_mode,
-                            int32_t *queue)
+                            double *workspace, hipStream_t stream, const int32_t *order, int32_t *aux,
+                            const SparsePlanDev *fallback, double *fallback_ws)
 {
-  if ((pl.Aorig != nullptr || fb_mode != 0) && fb == nullptr) return hipErrorInvalidValue;
-  size_t lds = (size_t)pl.lds_doubles * sizeof(double);
+  if (pl.Aorig != nullptr && (fallback == nullptr || fallback_ws == nullptr || aux == nullptr)) return hipErrorInvalidValue;
+  const bool pruned = pl.Aorig != nullptr;
+  size_t lds = (size_t)std::max(pl.lds_doubles, pruned ? fallback->lds_doubles : 0) * sizeof(double);
   // SFB_SP_WAVES_PER_CU (tuning): cap the resident workgroups per CU by padding the LDS request
   if (const char *wpc = getenv("SFB_SP_WAVES_PER_CU"); wpc && atoi(wpc) > 0)
     lds = std::max(lds, std::min<size_t>(160 * 1024, (size_t)(160 * 1024 / atoi(wpc)) & ~(size_t)15));
@@ -1341,18 +1533,24 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
   const int slice  = sl ? atoi(sl) : 50;
   unsigned grid    = (unsigned)batch;
   int32_t *qarg    = nullptr;
-  if (queue != nullptr && fb_mode == 0 && slice > 0) {
+  bool sliced      = false;
+  if (aux != nullptr && slice > 0) {
     int resident = sparse_resident_blocks(lds);
     if (const char *g = getenv("SFB_SP_GRID"); g && atoi(g) > 0) resident = std::min(resident, atoi(g));  // tests: force slicing
     if (resident > 0 && batch > resident) {
-      hipError_t e = hipMemsetAsync(queue, 0, qp_sparse_queue_bytes(batch), stream);
-      if (e != hipSuccess) return e;
-      grid = (unsigned)resident;
-      qarg = queue;
+      grid   = (unsigned)resident;
+      qarg   = aux;
+      sliced = true;
     }
   }
+  if (sliced || pruned) {
+    hipError_t e = hipMemsetAsync(aux, 0, qp_sparse_aux_bytes(batch), stream);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(qp_sparse_kernel, dim3(grid), dim3(kWave), lds, stream, pl.self, kp, Px, q, Ax, l, u, wx, wy, x, y, obj, iter,
-                     code, workspace, wsd, lean_waves, order, fb, fb_mode, qarg, (int)batch, (uint32_t)std::max(1, slice));
+                     code, workspace, wsd, lean_waves, order, qarg, (int)batch, (uint32_t)std::max(1, slice),
+                     pruned ? fallback->self : nullptr, fallback_ws, pruned ? qp_sparse_ws_doubles(*fallback) : 0,
+                     aux ? aux + batch + kQRing : nullptr);
   return hipGetLastError();
 }
 

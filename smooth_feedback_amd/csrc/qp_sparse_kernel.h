@@ -30,6 +30,9 @@ struct SparsePlanDev {
   // entries only, nnzA of them); the caller's value array still has nnzA_io entries per item.  Aorig[p] = position
   // of kept entry p in the caller's array, Amasked[0..nmasked) = positions of the entries declared zero (padded by
   // 512 entries that repeat the last one).  Aorig == nullptr: no mask, the kernel reads the caller's array directly.
+  // factorisation numbering and LDS-resident subtrees (sparse_plan.h)
+  const int32_t *f2s, *seg, *pmapL, *rsplit, *KmapL, *KdescT, *KmapT, *ztop;
+  int nseg, nnzKT, nztop;
   int nnzA_io, nmasked;
   const int32_t *Aorig, *Amasked;
   const SparsePlanDev *self;  // device copy of this struct (what the kernel is handed)
@@ -53,18 +56,17 @@ inline size_t qp_sparse_ws_doubles(const SparsePlanDev &pl)
 }
 
 // One launch over `batch` items (launch position -> item through `order`, nullable).
-//   fb (nullable unless the plan is pruned or fb_mode != 0): fallback list of the call, fb[0] = count,
-//   fb[1 + i] = item.  fb_mode 0: a pruned plan appends the items whose masked entries are not all zero and leaves
-//   them unsolved; fb_mode = 1 + base: `pl` is the fallback plan (full pattern), block i of the grid of `batch` blocks
-//   takes list entry base + i (and exits if there is none), the workspace holds `batch` items of THIS plan.
+//   aux (device, qp_sparse_aux_bytes(batch) bytes, need not be initialised; nullable for plain plans = never
+//   time-slice): queue of a time-sliced launch + flags of the fallback pool.
+//   fallback / fallback_ws: pruned plans only -- the whole-pattern plan and a pool of qp_sparse_fallback_slots()
+//   workspace slots of ITS per-item size: an item whose masked entries are not all zero is solved there, inside
+//   the same launch.
 hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp, int64_t batch, const double *Px,
                             const double *q, const double *Ax, const double *l, const double *u, const double *wx,
                             const double *wy, double *x, double *y, double *obj, uint32_t *iter, int32_t *code,
-                            double *workspace, hipStream_t stream, const int32_t *order = nullptr, int32_t *fb = nullptr,
-                            int fb_mode = 0, int32_t *queue = nullptr);
-
-// Queue memory of a time-sliced launch (qp_sparse.hip): counters + a ring of `batch` entries.  Passed as `queue`
-// (device memory, need not be initialised); nullptr = never time-slice.
-inline size_t qp_sparse_queue_bytes(int64_t batch) { return ((size_t)batch + 48) * sizeof(int32_t); }
+                            double *workspace, hipStream_t stream, const int32_t *order = nullptr, int32_t *aux = nullptr,
+                            const SparsePlanDev *fallback = nullptr, double *fallback_ws = nullptr);
+size_t qp_sparse_aux_bytes(int64_t batch);
+int qp_sparse_fallback_slots();
 
 }  // namespace sfb

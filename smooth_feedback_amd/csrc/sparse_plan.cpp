@@ -179,18 +179,43 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
     for (const Ent &e : ents) edges.emplace_back(e.r, e.c);
     o.perm = min_degree_order(k, edges, stage);
   }
-  o.pinv.resize(k);
-  for (int i = 0; i < k; ++i) o.pinv[o.perm[i]] = i;
-
-  // permuted lower CSC
+  // permuted lower CSC + elimination tree (numbering S: the elimination order `perm`)
   struct PE { int i, j, kind, idx; };
   std::vector<PE> pe;
-  pe.reserve(ents.size());
-  for (const Ent &e : ents) {
-    const int a = o.pinv[e.r], b = o.pinv[e.c];
-    pe.push_back({std::max(a, b), std::min(a, b), e.kind, e.idx});
+  std::vector<int32_t> rp, rj, parent, flag(k, -1), lnz;
+  {
+    o.pinv.resize(k);
+    for (int i = 0; i < k; ++i) o.pinv[o.perm[i]] = i;
+    pe.reserve(ents.size());
+    for (const Ent &e : ents) {
+      const int a = o.pinv[e.r], b = o.pinv[e.c];
+      pe.push_back({std::max(a, b), std::min(a, b), e.kind, e.idx});
+    }
+    std::sort(pe.begin(), pe.end(), [](const PE &x, const PE &y) { return std::tie(x.j, x.i) < std::tie(y.j, y.i); });
+    // rows of the lower form (strict): row r -> columns j < r
+    rp.assign(k + 1, 0);
+    for (const PE &e : pe)
+      if (e.i != e.j) rp[e.i + 1]++;
+    for (int r = 0; r < k; ++r) rp[r + 1] += rp[r];
+    rj.resize(rp[k]);
+    {
+      std::vector<int32_t> fill(k, 0);
+      for (const PE &e : pe)
+        if (e.i != e.j) rj[rp[e.i] + fill[e.i]++] = e.j;
+    }
+    // elimination tree + column counts by row reach
+    parent.assign(k, -1);
+    lnz.assign(k, 0);
+    for (int r = 0; r < k; ++r) {
+      flag[r] = r;
+      for (int p = rp[r]; p < rp[r + 1]; ++p)
+        for (int i = rj[p]; flag[i] != r; i = parent[i]) {
+          if (parent[i] == -1) parent[i] = r;
+          lnz[i]++;
+          flag[i] = r;
+        }
+    }
   }
-  std::sort(pe.begin(), pe.end(), [](const PE &x, const PE &y) { return std::tie(x.j, x.i) < std::tie(y.j, y.i); });
   o.nnzK = (int)pe.size();
   o.Kp.assign(k + 1, 0); o.Ki.resize(o.nnzK); o.Kkind.resize(o.nnzK); o.Kidx.resize(o.nnzK);
   for (int t = 0; t < o.nnzK; ++t) {
@@ -198,29 +223,6 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
     o.Ki[t] = pe[t].i; o.Kkind[t] = pe[t].kind; o.Kidx[t] = pe[t].idx;
   }
   for (int j = 0; j < k; ++j) o.Kp[j + 1] += o.Kp[j];
-
-  // rows of the lower form (strict): row r -> columns j < r
-  std::vector<int32_t> rp(k + 1, 0), rj;
-  for (const PE &e : pe)
-    if (e.i != e.j) rp[e.i + 1]++;
-  for (int r = 0; r < k; ++r) rp[r + 1] += rp[r];
-  rj.resize(rp[k]);
-  {
-    std::vector<int32_t> fill(k, 0);
-    for (const PE &e : pe)
-      if (e.i != e.j) rj[rp[e.i] + fill[e.i]++] = e.j;
-  }
-  // elimination tree + pattern of L by row reach
-  std::vector<int32_t> parent(k, -1), flag(k, -1), lnz(k, 0);
-  for (int r = 0; r < k; ++r) {
-    flag[r] = r;
-    for (int p = rp[r]; p < rp[r + 1]; ++p)
-      for (int i = rj[p]; flag[i] != r; i = parent[i]) {
-        if (parent[i] == -1) parent[i] = r;
-        lnz[i]++;
-        flag[i] = r;
-      }
-  }
   o.Lp.assign(k + 1, 0);
   for (int j = 0; j < k; ++j) o.Lp[j + 1] = o.Lp[j] + lnz[j];
   o.nnzL = o.Lp[k];
@@ -241,130 +243,316 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
   o.Rlen.resize(o.nnzL);
   for (int t = 0; t < o.nnzL; ++t) o.Rlen[t] = o.Lp[o.Rk[t] + 1] - o.Rpos[t];
 
-  // right-looking factorisation schedule (see sparse_plan.h)
+  // ---- factorisation numbering F: a POSTORDER of the elimination tree (children in ascending order) ----
+  // Same tree, same pattern of L; every subtree becomes a contiguous range of columns.  The numeric factorisation
+  // (accumulators, supernodes, the order in which an accumulator receives its updates) lives in F; the triangular
+  // sweeps keep the numbering S of `perm`.  rankF[S column] = F column, f2s = inverse.
+  std::vector<int32_t> rankF(k), parF(k, -1);
   {
-    std::vector<int32_t> where(k, -1);  // row -> position in the column currently scattered
+    std::vector<int32_t> head(k, -1), next(k, -1), stack;
+    for (int j = k - 1; j >= 0; --j)
+      if (parent[j] >= 0) { next[j] = head[parent[j]]; head[parent[j]] = j; }
+    o.f2s.clear();
+    o.f2s.reserve(k);
+    for (int r = 0; r < k; ++r) {
+      if (parent[r] >= 0) continue;
+      stack.push_back(r);
+      while (!stack.empty()) {
+        const int v = stack.back(), c = head[v];
+        if (c >= 0) { head[v] = next[c]; stack.push_back(c); }
+        else { rankF[v] = (int32_t)o.f2s.size(); o.f2s.push_back(v); stack.pop_back(); }
+      }
+    }
+    for (int j = 0; j < k; ++j)
+      if (parent[j] >= 0) parF[rankF[j]] = rankF[parent[j]];
+  }
+  // pattern of L in F (column-major, rows ascending) and the position of every S entry in it
+  std::vector<int32_t> FLp(k + 1, 0), FLi(o.nnzL), posF(o.nnzL);
+  {
+    std::vector<std::pair<int32_t, int32_t>> tmp;
+    for (int jF = 0; jF < k; ++jF) {
+      const int jS = o.f2s[jF];
+      tmp.clear();
+      for (int p = o.Lp[jS]; p < o.Lp[jS + 1]; ++p) tmp.emplace_back(rankF[o.Li[p]], p);
+      std::sort(tmp.begin(), tmp.end());
+      FLp[jF + 1] = FLp[jF] + (int)tmp.size();
+      for (size_t e = 0; e < tmp.size(); ++e) {
+        if (tmp[e].first <= jF) { *msg = "internal: postorder does not keep ancestors behind"; return false; }
+        FLi[FLp[jF] + e]   = tmp[e].first;
+        posF[tmp[e].second] = FLp[jF] + (int)e;
+      }
+    }
+  }
+  // KKT entries in F (lower CSC): {row, kind, idx}
+  std::vector<int32_t> FKp(k + 1, 0), FKi(o.nnzK), FKkind(o.nnzK), FKidx(o.nnzK);
+  {
+    std::vector<std::array<int32_t, 4>> fe;
+    fe.reserve(o.nnzK);
+    for (int jS = 0; jS < k; ++jS)
+      for (int p = o.Kp[jS]; p < o.Kp[jS + 1]; ++p) fe.push_back({rankF[jS], rankF[o.Ki[p]], o.Kkind[p], o.Kidx[p]});
+    std::sort(fe.begin(), fe.end());
+    for (int t = 0; t < o.nnzK; ++t) {
+      if (fe[t][1] < fe[t][0]) { *msg = "internal: KKT entry above the diagonal in the factorisation numbering"; return false; }
+      FKp[fe[t][0] + 1]++;
+      FKi[t] = fe[t][1]; FKkind[t] = fe[t][2]; FKidx[t] = fe[t][3];
+    }
+    for (int j = 0; j < k; ++j) FKp[j + 1] += FKp[j];
+  }
+
+  // right-looking factorisation schedule (see sparse_plan.h), everything in F
+  {
     auto pos_in_col = [&](int col, int row) {  // binary search: rows ascending
-      const int32_t *b = o.Li.data() + o.Lp[col], *e = o.Li.data() + o.Lp[col + 1];
+      const int32_t *b = FLi.data() + FLp[col], *e = FLi.data() + FLp[col + 1];
       const int32_t *it = std::lower_bound(b, e, row);
-      return (it != e && *it == row) ? (int)(it - o.Li.data()) : -1;
+      return (it != e && *it == row) ? (int)(it - FLi.data()) : -1;
     };
     o.Kmap.resize(o.nnzK);
     for (int j = 0; j < k; ++j)
-      for (int p = o.Kp[j]; p < o.Kp[j + 1]; ++p) {
-        const int i = o.Ki[p];
+      for (int p = FKp[j]; p < FKp[j + 1]; ++p) {
+        const int i = FKi[p];
         o.Kmap[p]   = (i == j) ? o.nnzL + j : pos_in_col(j, i);
         if (o.Kmap[p] < 0) { *msg = "internal: KKT entry outside the pattern of L"; return false; }
       }
-    // descriptor of every KKT entry for the kernel's batched fill: {kind, idx, r, c} with the row / column of the
-    // source entry resolved here (pattern only), + the accumulator it goes to; padded for branch-free batches
-    o.Kdesc.assign((size_t)(o.nnzK + 64 * 8) * 4, 0);
-    for (int p = 0; p < o.nnzK; ++p) {
-      const int kind = o.Kkind[p], idx = o.Kidx[p];
-      int r = 0, c = 0;
-      if (kind == K_P) { r = o.Pi[idx]; c = o.Pcol[idx]; }
-      else if (kind == K_A) { r = o.Arow[idx]; c = o.Aj[idx]; }
-      o.Kdesc[4 * (size_t)p] = kind; o.Kdesc[4 * (size_t)p + 1] = idx; o.Kdesc[4 * (size_t)p + 2] = r; o.Kdesc[4 * (size_t)p + 3] = c;
-    }
-    for (size_t p = o.nnzK; p < (size_t)o.nnzK + 64 * 8; ++p) o.Kdesc[4 * p] = K_SIGMA;  // padding: constant, to scratch
-    o.Kmap.resize((size_t)o.nnzK + 64 * 8, o.nnzL + k);
     o.maxcol = 0;
-    for (int kk = 0; kk < k; ++kk) o.maxcol = std::max(o.maxcol, o.Lp[kk + 1] - o.Lp[kk]);
+    for (int kk = 0; kk < k; ++kk) o.maxcol = std::max(o.maxcol, FLp[kk + 1] - FLp[kk]);
     if (o.maxcol >= (1 << 16)) { *msg = "column of L too long for the update encoding"; return false; }
-    o.lds_doubles = std::max(k + 2, 2 * o.maxcol + 4);
+    // LDS per item: the work vector of the sweeps (k + 1), the panel scratch of the widest column, and room for the
+    // accumulators of a subtree (below)
+    constexpr int kLdsTarget = 2048;
+    o.lds_doubles = std::max(std::max(k + 2, 2 * o.maxcol + 4), kLdsTarget);
+
+    // ---- LDS-resident subtrees ----
+    // A subtree of the elimination tree (a contiguous column range [c0, c1) in F) whose accumulators -- its
+    // nL entries of L and its c1 - c0 diagonal entries -- fit the item's LDS is factorised ON CHIP: KKT fill,
+    // panel gathers and the updates between its columns never touch HBM (they are the dependent memory round trips
+    // that bound the factorisation of a lone wave); only the final values and the updates to ancestors outside
+    // the subtree go to the workspace.  Updates reach an accumulator only from descendants of its column, so a
+    // subtree's accumulators are touched by its own columns alone, and processing the segments in ascending column
+    // order keeps the ascending-source order of every update sequence.  Maximal fitting subtrees are chosen
+    // top-down; columns outside them ("top") keep their accumulators in HBM.
+    std::vector<int32_t> fdesc(k);  // first descendant: subtree(j) = [fdesc[j], j]
+    for (int j = 0; j < k; ++j) fdesc[j] = j;
+    for (int j = 0; j < k; ++j)
+      if (parF[j] >= 0) fdesc[parF[j]] = std::min(fdesc[parF[j]], fdesc[j]);
+    std::vector<int32_t> maxR1(k);  // largest single-column panel (1 + column count) inside subtree(j)
+    for (int j = 0; j < k; ++j) maxR1[j] = 1 + FLp[j + 1] - FLp[j];
+    for (int j = 0; j < k; ++j)
+      if (parF[j] >= 0) maxR1[parF[j]] = std::max(maxR1[parF[j]], maxR1[j]);
+    struct Seg { int c0, c1, lds, nL, accN, sn0, sn1; };
+    std::vector<Seg> segs;
+    {
+      constexpr int kMinCols = 8;
+      std::vector<char> in_lds(k, 0);
+      const char *no_lds = getenv("SFB_PLAN_NO_LDS");  // A/B knob: every column a top column (accumulators in HBM)
+      for (int j = (no_lds && no_lds[0] == '1') ? -1 : k - 1; j >= 0;) {
+        const int c0 = fdesc[j], nc = j - c0 + 1, nL = FLp[j + 1] - FLp[c0];
+        const int reserve = std::max(2 * maxR1[j], 384);  // panel + multipliers of the supernodes formed below
+        if (nc >= kMinCols && maxR1[j] <= 64 && nL + nc + 2 + reserve <= o.lds_doubles) {
+          for (int c = c0; c <= j; ++c) in_lds[c] = 1;
+          j = c0 - 1;
+        } else {
+          --j;
+        }
+      }
+      for (int c = 0; c < k;) {  // maximal runs: LDS subtrees (one per root found above) and top columns
+        int e = c + 1;
+        if (in_lds[c]) {
+          // the run [c, e) must be ONE subtree: extend to the root whose first descendant is c
+          while (e < k && in_lds[e] && fdesc[e] >= c) ++e;
+          // e - 1 is the root only if fdesc[e - 1] == c; a run of several sibling subtrees is split at roots
+          int root = e - 1;
+          while (fdesc[root] != c) --root;
+          e = root + 1;
+          segs.push_back({c, e, 1, FLp[e] - FLp[c], FLp[e] - FLp[c] + (e - c), 0, 0});
+        } else {
+          while (e < k && !in_lds[e]) ++e;
+          segs.push_back({c, e, 0, 0, 0, 0, 0});
+        }
+        c = e;
+      }
+    }
 
     // ---- relaxed supernodes (see sparse_plan.h) ----
-    // Greedy grouping of consecutive columns: the panel rows are the columns themselves plus the union U of
-    // their remaining row structures.  A column joins while the panel and its multipliers (2 w R doubles)
-    // fit the LDS scratch, w <= 16, and the union grows by at most kRelax rows over the larger of the two
-    // structures (explicit zeros cost LDS work, not HBM traffic).
+    // Greedy grouping of consecutive columns of one segment: the panel rows are the columns themselves plus the
+    // union U of their remaining row structures.  A column joins while the panel and its multipliers (2 w R
+    // doubles) fit the LDS scratch (what the segment's accumulators leave of it), w <= 16, and the union grows by
+    // at most kRelax rows over the larger of the two structures (explicit zeros cost LDS work, not HBM traffic).
     constexpr int kRelax = 4, kMaxWidth = 16;
     const int ZERO = o.nnzL + k + 1, SCRATCH = o.nnzL + k;  // accumulator indices: always-zero entry, padding sink
-    o.snptr.clear(); o.snR.clear(); o.poff.clear(); o.pmap.clear(); o.rptr.clear(); o.rtgt.clear(); o.rab.clear();
+    o.snptr.clear(); o.snR.clear(); o.poff.clear(); o.pmap.clear(); o.pmapL.clear(); o.rptr.clear(); o.rsplit.clear();
+    o.rtgt.clear(); o.rab.clear();
     o.rptr.push_back(0);
-    int j0 = 0;
-    while (j0 < k) {
-      std::vector<int32_t> U(o.Li.begin() + o.Lp[j0], o.Li.begin() + o.Lp[j0 + 1]);  // sorted rows outside the panel
-      int w = 1;
-      while (j0 + w < k && w < kMaxWidth) {
-        const int jn = j0 + w;
-        std::vector<int32_t> Un;
-        std::set_union(U.begin(), U.end(), o.Li.begin() + o.Lp[jn], o.Li.begin() + o.Lp[jn + 1], std::back_inserter(Un));
-        Un.erase(std::remove_if(Un.begin(), Un.end(), [&](int32_t r) { return r <= jn; }), Un.end());
-        const int Rn = (w + 1) + (int)Un.size();
-        if (2 * (w + 1) * Rn > o.lds_doubles) break;
-        int ubase = 0;
-        for (int32_t r : U) ubase += (r != jn);
-        const int base = std::max(ubase, o.Lp[jn + 1] - o.Lp[jn]);
-        if ((int)Un.size() - base > kRelax) break;
-        U.swap(Un);
-        ++w;
+    for (Seg &sg : segs) {
+      sg.sn0 = (int)o.snptr.size();
+      const int scratch = sg.lds ? o.lds_doubles - ((sg.accN + 2 + 1) & ~1) : o.lds_doubles;
+      // accumulator -> LDS offset inside an LDS segment: [L entries | D | sink | zero]
+      auto lds_off = [&](int g) {
+        if (g == SCRATCH) return sg.accN;
+        if (g == ZERO) return sg.accN + 1;
+        if (g < o.nnzL) return (g >= FLp[sg.c0] && g < FLp[sg.c1]) ? g - FLp[sg.c0] : -1;
+        const int j = g - o.nnzL;
+        return (j >= sg.c0 && j < sg.c1) ? sg.nL + (j - sg.c0) : -1;
+      };
+      int j0 = sg.c0;
+      while (j0 < sg.c1) {
+        std::vector<int32_t> U(FLi.begin() + FLp[j0], FLi.begin() + FLp[j0 + 1]);  // sorted rows outside the panel
+        int w = 1;
+        while (j0 + w < sg.c1 && w < kMaxWidth) {
+          const int jn = j0 + w;
+          std::vector<int32_t> Un;
+          std::set_union(U.begin(), U.end(), FLi.begin() + FLp[jn], FLi.begin() + FLp[jn + 1], std::back_inserter(Un));
+          Un.erase(std::remove_if(Un.begin(), Un.end(), [&](int32_t r) { return r <= jn; }), Un.end());
+          const int Rn = (w + 1) + (int)Un.size();
+          if (2 * (w + 1) * Rn > scratch) break;
+          if (sg.lds && Rn > 64) break;  // on-chip segments eliminate their panels in registers (lane = row)
+          int ubase = 0;
+          for (int32_t r : U) ubase += (r != jn);
+          const int base = std::max(ubase, FLp[jn + 1] - FLp[jn]);
+          if ((int)Un.size() - base > kRelax) break;
+          U.swap(Un);
+          ++w;
+        }
+        const int nu = (int)U.size(), R = w + nu;
+        if (2 * w * R > scratch) { *msg = "internal: panel does not fit the LDS scratch"; return false; }
+        o.snptr.push_back(j0);
+        o.snR.push_back(R);
+        // panel map: entry (row r, member jj), r >= jj; rows of L that are not in the member's structure are zeros
+        o.poff.push_back((int)o.pmap.size());
+        for (int jj = 0; jj < w; ++jj)
+          for (int r = 0; r < R; ++r) {
+            int src = SCRATCH;
+            if (r == jj) src = o.nnzL + j0 + jj;
+            else if (r > jj) {
+              const int g = (r < w) ? j0 + r : U[r - w];
+              const int pos = pos_in_col(j0 + jj, g);
+              src = (pos >= 0) ? pos : ZERO;
+            }
+            o.pmap.push_back(src);
+            o.pmapL.push_back(sg.lds ? lds_off(src) : 0);
+            if (sg.lds && o.pmapL.back() < 0) { *msg = "internal: panel entry outside its LDS segment"; return false; }
+          }
+        // trailing schedule: pairs (a >= b) of U whose accumulator exists and is touched by some member; inside an
+        // LDS segment first the slots whose accumulator is on chip (target = LDS offset), then the others
+        std::vector<std::array<int32_t, 2>> slots[2];
+        for (int bq = 0; bq < nu; ++bq)
+          for (int aq = bq; aq < nu; ++aq) {
+            const int rb = U[bq], ra = U[aq];
+            int tgt;
+            if (aq == bq) tgt = o.nnzL + rb;
+            else {
+              tgt = pos_in_col(rb, ra);
+              if (tgt < 0) continue;
+            }
+            bool touched = false;
+            for (int jj = 0; jj < w && !touched; ++jj)
+              touched = pos_in_col(j0 + jj, ra) >= 0 && pos_in_col(j0 + jj, rb) >= 0;
+            if (!touched) continue;
+            const int off = sg.lds ? lds_off(tgt) : -1;
+            if (off >= 0) slots[0].push_back({off, aq | (bq << 16)});
+            else slots[1].push_back({tgt, aq | (bq << 16)});
+          }
+        int total = 0;
+        for (int part = 0; part < 2; ++part) {
+          const int steps = (int)((slots[part].size() + 63) / 64);
+          const size_t q0 = o.rtgt.size();
+          o.rtgt.resize(q0 + (size_t)steps * 64, part == 0 ? sg.accN : SCRATCH);  // padding: the sink of that space
+          o.rab.resize(q0 + (size_t)steps * 64, 0);
+          for (size_t e = 0; e < slots[part].size(); ++e) { o.rtgt[q0 + e] = slots[part][e][0]; o.rab[q0 + e] = slots[part][e][1]; }
+          total += steps;
+          if (part == 0) o.rsplit.push_back(o.rptr.back() + steps);
+        }
+        o.rptr.push_back(o.rptr.back() + total);
+        j0 += w;
       }
-      const int nu = (int)U.size(), R = w + nu;
-      o.snptr.push_back(j0);
-      o.snR.push_back(R);
-      // panel map: entry (row r, member jj), r >= jj; rows of L that are not in the member's structure are zeros
-      o.poff.push_back((int)o.pmap.size());
-      for (int jj = 0; jj < w; ++jj)
-        for (int r = 0; r < R; ++r) {
-          int src = SCRATCH;
-          if (r == jj) src = o.nnzL + j0 + jj;
-          else if (r > jj) {
-            const int g = (r < w) ? j0 + r : U[r - w];
-            const int pos = pos_in_col(j0 + jj, g);
-            src = (pos >= 0) ? pos : ZERO;
-          }
-          o.pmap.push_back(src);
-        }
-      // trailing schedule: pairs (a >= b) of U whose accumulator exists and is touched by some member
-      std::vector<std::array<int32_t, 2>> slots;
-      for (int bq = 0; bq < nu; ++bq)
-        for (int aq = bq; aq < nu; ++aq) {
-          const int rb = U[bq], ra = U[aq];
-          int tgt;
-          if (aq == bq) tgt = o.nnzL + rb;
-          else {
-            tgt = pos_in_col(rb, ra);
-            if (tgt < 0) continue;
-          }
-          bool touched = false;
-          for (int jj = 0; jj < w && !touched; ++jj)
-            touched = pos_in_col(j0 + jj, ra) >= 0 && pos_in_col(j0 + jj, rb) >= 0;
-          if (!touched) continue;
-          slots.push_back({tgt, aq | (bq << 16)});
-        }
-      const int steps = (int)((slots.size() + 63) / 64);
-      const size_t q0 = o.rtgt.size();
-      o.rtgt.resize(q0 + (size_t)steps * 64, SCRATCH);
-      o.rab.resize(q0 + (size_t)steps * 64, 0);
-      for (size_t e = 0; e < slots.size(); ++e) { o.rtgt[q0 + e] = slots[e][0]; o.rab[q0 + e] = slots[e][1]; }
-      o.rptr.push_back(o.rptr.back() + steps);
-      j0 += w;
+      sg.sn1 = (int)o.snptr.size();
     }
     o.nsn = (int)o.snptr.size();
-    if (const char *dbg = getenv("SFB_PLAN_DEBUG"); dbg && dbg[0] == '1') {  // diagnostics: supernode shapes
-      int maxR = 0, over64 = 0;
-      long long panel = 0;
+    // segment table {sn0, sn1, c0, c1, lds, nL, accN, first K entry, last K entry + 1, first L entry}
+    o.nseg = (int)segs.size();
+    o.seg.clear();
+    for (const Seg &sg : segs)
+      for (int v : {sg.sn0, sg.sn1, sg.c0, sg.c1, sg.lds, sg.nL, sg.accN, (int)FKp[sg.c0], (int)FKp[sg.c1], (int)FLp[sg.c0]}) o.seg.push_back(v);
+    // KKT fill.  Kdesc: {kind, idx, r, c} of every entry in F order (row / column of the source entry resolved
+    // here), Kmap its accumulator, KmapL its LDS offset inside an LDS segment; KdescT / KmapT: the entries of the
+    // TOP columns only (their accumulators live in HBM), padded for branch-free batches.
+    std::vector<char> col_lds(k, 0);
+    for (const Seg &sg : segs)
+      if (sg.lds) std::fill(col_lds.begin() + sg.c0, col_lds.begin() + sg.c1, 1);
+    o.Kdesc.assign((size_t)(o.nnzK + 64 * 8) * 4, 0);
+    o.KmapL.assign((size_t)o.nnzK + 64 * 8, 0);
+    o.KdescT.clear(); o.KmapT.clear();
+    {
+      size_t si = 0;
+      for (int j = 0; j < k; ++j) {
+        while (segs[si].c1 <= j) ++si;
+        const Seg &sg = segs[si];
+        for (int p = FKp[j]; p < FKp[j + 1]; ++p) {
+          const int kind = FKkind[p], idx = FKidx[p];
+          int r = 0, c = 0;
+          if (kind == K_P) { r = o.Pi[idx]; c = o.Pcol[idx]; }
+          else if (kind == K_A) { r = o.Arow[idx]; c = o.Aj[idx]; }
+          const int32_t d4[4] = {kind, idx, r, c};
+          std::copy(d4, d4 + 4, o.Kdesc.begin() + 4 * (size_t)p);
+          if (sg.lds) {
+            const int g = o.Kmap[p];
+            o.KmapL[p]  = (g < o.nnzL) ? g - FLp[sg.c0] : sg.nL + (g - o.nnzL - sg.c0);
+          } else {
+            o.KdescT.insert(o.KdescT.end(), d4, d4 + 4);
+            o.KmapT.push_back(o.Kmap[p]);
+          }
+        }
+      }
+    }
+    o.nnzKT = (int)o.KmapT.size();
+    for (int pad = 0; pad < 64 * 8; ++pad) {
+      const int32_t d4[4] = {K_SIGMA, 0, 0, 0};  // padding: a constant, to the scratch accumulator
+      o.KdescT.insert(o.KdescT.end(), d4, d4 + 4);
+      o.KmapT.push_back(SCRATCH);
+    }
+    for (size_t p = o.nnzK; p < (size_t)o.nnzK + 64 * 8; ++p) o.Kdesc[4 * p] = K_SIGMA;
+    o.Kmap.resize((size_t)o.nnzK + 64 * 8, SCRATCH);
+    // accumulator ranges of the top columns (what the kernel zeroes in HBM before the fill): {start, length} pairs
+    o.ztop.clear();
+    for (const Seg &sg : segs)
+      if (!sg.lds) {
+        o.ztop.push_back(FLp[sg.c0]); o.ztop.push_back(FLp[sg.c1] - FLp[sg.c0]);
+        o.ztop.push_back(o.nnzL + sg.c0); o.ztop.push_back(sg.c1 - sg.c0);
+      }
+    o.ztop.push_back(SCRATCH); o.ztop.push_back(2);
+    o.nztop = (int)o.ztop.size() / 2;
+    if (const char *dbg = getenv("SFB_PLAN_DEBUG"); dbg && dbg[0] == '1') {  // diagnostics: segments and supernodes
+      int maxR = 0, over64 = 0, nlds = 0, cols_lds = 0;
+      long long panel = 0, acc_lds = 0, ext = 0, internal = 0;
+      for (const Seg &sg : segs) {
+        nlds += sg.lds; cols_lds += sg.lds ? sg.c1 - sg.c0 : 0; acc_lds += sg.lds ? sg.accN : 0;
+        fprintf(stderr, "[sfb plan] segment columns %d..%d %s accumulators %d supernodes %d\n", sg.c0, sg.c1 - 1, sg.lds ? "LDS" : "top",
+                sg.lds ? sg.accN : FLp[sg.c1] - FLp[sg.c0] + sg.c1 - sg.c0, sg.sn1 - sg.sn0);
+      }
       for (int sn = 0; sn < o.nsn; ++sn) {
         const int w = (sn + 1 < o.nsn ? o.snptr[sn + 1] : k) - o.snptr[sn], R = o.snR[sn];
         maxR = std::max(maxR, R);
         over64 += R > 64;
         panel += (long long)w * R;
-        fprintf(stderr, "[sfb plan] supernode %d: columns %d..%d (w=%d) R=%d steps=%d\n", sn, o.snptr[sn], o.snptr[sn] + w - 1, w, R,
-                o.rptr[sn + 1] - o.rptr[sn]);
+        internal += o.rsplit[sn] - o.rptr[sn];
+        ext += o.rptr[sn + 1] - o.rsplit[sn];
       }
-      fprintf(stderr, "[sfb plan] %d supernodes, max R %d, %d with R > 64, panel entries %lld, trailing steps %d\n", o.nsn, maxR,
-              over64, panel, o.rptr.back());
+      fprintf(stderr, "[sfb plan] %d supernodes, max R %d, %d with R > 64, panel entries %lld, trailing steps %d on chip + %d in HBM; "
+              "%d segments, %d on chip with %d columns and %lld accumulators of %d; lds_doubles %d\n", o.nsn, maxR, over64, panel,
+              (int)internal, (int)ext, (int)segs.size(), nlds, cols_lds, acc_lds, o.nnzL + k, o.lds_doubles);
     }
     o.snptr.push_back(k);
     o.poff.push_back((int)o.pmap.size());
+    o.rsplit.push_back(o.rptr.back());
     o.rsteps = o.rptr.back();
     for (int pad = 0; pad < 64 * SparsePlanHost::kSweepPad; ++pad) {  // branch-free batched reads past the end
       o.pmap.push_back(SCRATCH);
+      o.pmapL.push_back(0);
       o.rtgt.push_back(SCRATCH);
       o.rab.push_back(0);
     }
   }
+  // the sweeps enumerate the entries of L in S; their values are gathered from the accumulators (F positions)
+  auto acc_of = [&](int posS) { return posF[posS]; };
 
   // packed sweep schedules (see sparse_plan.h)
   if (k + 1 >= (1 << 16)) { *msg = "n+m too large for the packed sweep encoding (max 65534)"; return false; }
@@ -463,7 +651,7 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
         // that follow each other in the sweep order (neighbouring rows of one column) sit in neighbouring lanes
         // (LDS banks); a full unit is lane e % 64, slot e / 64
         const size_t q = ((size_t)s * 64 + (e % (size_t)lanes)) * 2 + (e / (size_t)lanes);
-        xmap[q] = slots[s][e][0];
+        xmap[q] = acc_of(slots[s][e][0]);
         xidx[q] = (slots[s][e][1] * sc) | ((slots[s][e][2] * sc) << 16);
       }
     }

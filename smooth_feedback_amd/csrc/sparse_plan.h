@@ -69,6 +69,21 @@ struct SparsePlanHost {
   std::vector<int32_t> Kmap, rptr, rtgt, rab, snptr, snR, poff, pmap;
   std::vector<int32_t> Kdesc;  // per KKT entry {kind, idx, row, col of the source entry}; Kdesc and Kmap are padded by 512 entries
   int rsteps = 0, maxcol = 0, nsn = 0, lds_doubles = 0;
+  // FACTORISATION NUMBERING.  All of the above (accumulator positions, supernodes, K entries) is in F, a postorder
+  // of the elimination tree of `perm` (children ascending): subtrees are contiguous column ranges, consecutive
+  // columns share structure (wider supernodes), and an accumulator receives its updates in ascending F order.
+  // The sweeps stay in S (= perm): f2s[F column] = S column (Dinv is stored in S), the sweep maps point at F positions.
+  std::vector<int32_t> f2s;
+  // LDS-RESIDENT SUBTREES (sparse_plan.cpp): the columns are cut into segments, each either a subtree whose
+  // accumulators fit the item's LDS ("lds": factorised on chip) or a run of top columns (accumulators in HBM).
+  //   seg[10 s ..] = {first supernode, last + 1, first column, last + 1, lds, nL, accN = nL + columns,
+  //                  first K entry, last + 1, first L entry}; LDS layout of a segment: [L entries | D | sink | zero | panel scratch]
+  //   pmapL  : LDS offsets of the panel entries (parallel to pmap; 0 outside LDS segments)
+  //   rsplit[s] : first HBM step of supernode s's trailing schedule; steps [rptr[s], rsplit[s]) target LDS offsets
+  //   KmapL  : LDS offset of every K entry of an LDS segment;  KdescT / KmapT (nnzKT entries, padded): the K
+  //            entries of the top columns;  ztop: {start, length} accumulator ranges the kernel zeroes in HBM
+  std::vector<int32_t> seg, pmapL, rsplit, KmapL, KdescT, KmapT, ztop;
+  int nseg = 0, nnzKT = 0, nztop = 0;
 };
 
 // ordering: 0 = natural, 1 = minimum degree (default); user_perm (k entries, new->old) overrides.

@@ -270,6 +270,13 @@ class SparseQPPlan:
         _capi.check(_capi.lib.sfb_sparse_qp_plan_get_perm(self._h, _ptr(p)))
         return p
 
+    def factor_order(self, fallback=False):
+        """Rank of every permuted column in the summation order of the numeric factorisation
+        (sfb_sparse_qp_plan_get_factor_order); fallback: of a pruned plan's whole-pattern analysis."""
+        r = np.empty(self.n + self.m, dtype=np.int32)
+        _capi.check(_capi.lib.sfb_sparse_qp_plan_get_factor_order(self._h, int(bool(fallback)), _ptr(r)))
+        return r
+
     def close(self):
         if getattr(self, "_h", None):
             _capi.lib.sfb_sparse_qp_plan_destroy(self._h)

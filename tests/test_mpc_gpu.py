@@ -40,7 +40,7 @@ def test_mpc_qp_batch_matches_oracle(sfb, oracle, variant, K, batch, sweep_mode)
     plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K))
     prm = sfb.QPSolverParams(max_iter=4000)
     r = plan.solve_batch_host(Px, q, Av, l, u, prm)
-    ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l, u, perm=plan.perm,
+    ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l, u, perm=plan.perm, forder=plan.factor_order(),
                                        params=_oracle_params(oracle, prm), nthreads=8)
     bit = _compare(r, ref)
     assert (r.code == 0).all(), np.bincount(r.code, minlength=7)   # MPC problems are feasible: Optimal
@@ -54,7 +54,7 @@ def test_mpc_qp_batch_matches_oracle(sfb, oracle, variant, K, batch, sweep_mode)
     # warm start from the solution of a slightly different problem
     r2 = plan.solve_batch_host(Px, q, Av, l + 1e-3 * (l == u), u + 1e-3 * (l == u), prm, warm_x=r.primal, warm_y=r.dual)
     ref2 = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l + 1e-3 * (l == u), u + 1e-3 * (l == u),
-                                        perm=plan.perm, params=_oracle_params(oracle, prm), warm_x=ref["x"],
+                                        perm=plan.perm, forder=plan.factor_order(), params=_oracle_params(oracle, prm), warm_x=ref["x"],
                                         warm_y=ref["y"], nthreads=8)
     _compare(r2, ref2)
     assert r2.iter.mean() <= r.iter.mean()
@@ -76,7 +76,7 @@ def test_mpc_pruned_plan_equals_whole_pattern_oracle(sfb, oracle, variant, K, ba
     prm = sfb.QPSolverParams(max_iter=4000)
     op = _oracle_params(oracle, prm)
     r = plan.solve_batch_host(Px, q, Av, l, u, prm)
-    ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l, u, perm=plan.perm, params=op, nthreads=8)
+    ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l, u, perm=plan.perm, forder=plan.factor_order(), params=op, nthreads=8)
     assert ref["nnzL"] == plan.nnzL_fallback
     for a, b in ((r.code, ref["code"]), (r.iter, ref["iter"]), (r.primal, ref["x"]), (r.dual, ref["y"]),
                  (r.objective, ref["obj"])):
@@ -84,18 +84,18 @@ def test_mpc_pruned_plan_equals_whole_pattern_oracle(sfb, oracle, variant, K, ba
     assert (r.code == 0).all()
     l2, u2 = l + 1e-3 * (l == u), u + 1e-3 * (l == u)
     r2 = plan.solve_batch_host(Px, q, Av, l2, u2, prm, warm_x=r.primal, warm_y=r.dual)
-    ref2 = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l2, u2, perm=plan.perm, params=op, warm_x=ref["x"],
+    ref2 = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l2, u2, perm=plan.perm, forder=plan.factor_order(), params=op, warm_x=ref["x"],
                                         warm_y=ref["y"], nthreads=8)
     for a, b in ((r2.code, ref2["code"]), (r2.iter, ref2["iter"]), (r2.primal, ref2["x"]), (r2.dual, ref2["y"])):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("batch,nbad", [(1, 1), (40, 7), (40, 40), (300, 3)])
+@pytest.mark.parametrize("batch,nbad", [(1, 1), (40, 7), (40, 40), (300, 3), (200, 150)])
 def test_pruned_plan_guard_falls_back_to_the_whole_pattern(sfb, oracle, batch, nbad):
-    """Items whose masked entries are NOT all zero are detected on the device and solved on the whole pattern by
-    the fallback launches of the same call (same elimination order); the other items of the batch are unaffected.
-    Every item equals the whole-pattern oracle.  Batch sizes cover: one item (the fallback item needs more
-    workspace than the pruned one), several fallback launches (workspace of the first launch reused), all items bad."""
+    """Items whose masked entries are NOT all zero are detected on the device and solved on the whole pattern
+    (same elimination order) inside the same launch, in a pool of 64 whole-pattern workspace slots; the other items
+    of the batch are unaffected.  Every item equals the whole-pattern oracle.  Cases: one item, a few, all items
+    bad, more bad items than pool slots (slots are reused as their items finish)."""
     variant, K = 6, 10
     d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
     Av, l, u = M.mpc_assemble_batch(variant, K, batch, seed=11)
@@ -110,15 +110,23 @@ def test_pruned_plan_guard_falls_back_to_the_whole_pattern(sfb, oracle, batch, n
     Px, q = np.tile(Pv, (batch, 1)), np.zeros((batch, d["n"]))
     prm = sfb.QPSolverParams(max_iter=4000)
     r = plan.solve_batch_host(Px, q, Av, l, u, prm)
-    ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l, u, perm=plan.perm,
-                                       params=_oracle_params(oracle, prm), nthreads=8)
-    for a, b in ((r.code, ref["code"]), (r.iter, ref["iter"]), (r.primal, ref["x"]), (r.dual, ref["y"]),
-                 (r.objective, ref["obj"])):
-        assert np.array_equal(a, b, equal_nan=True)
-    # the perturbed items really are different problems (the guard had something to catch)
+    # the whole-pattern oracle with the plan's elimination order; the items on the fallback path sum the
+    # contributions to an entry of L in the order of the whole-pattern analysis, the others in that of the pruned one
+    isbad = np.zeros(batch, bool); isbad[bad] = True
+    for sel, fo in ((~isbad, plan.factor_order()), (isbad, plan.factor_order(fallback=True))):
+        if not sel.any():
+            continue
+        ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px[sel], q[sel], Ap, Aj, Av[sel], l[sel], u[sel], perm=plan.perm, forder=fo,
+                                           params=_oracle_params(oracle, prm), nthreads=8)
+        for a, b in ((r.code, ref["code"]), (r.iter, ref["iter"]), (r.primal, ref["x"]), (r.dual, ref["y"]),
+                     (r.objective, ref["obj"])):
+            assert np.array_equal(a[sel], b, equal_nan=True)
+    # a plain plan of the whole pattern with the same elimination order IS the fallback analysis
     plain = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, user_perm=plan.perm)
+    assert np.array_equal(plain.factor_order(), plan.factor_order(fallback=True))
     rp = plain.solve_batch_host(Px, q, Av, l, u, prm)
-    assert np.array_equal(rp.primal, r.primal, equal_nan=True) and np.array_equal(rp.iter, r.iter)
+    assert np.array_equal(rp.primal[isbad], r.primal[isbad], equal_nan=True) and np.array_equal(rp.iter[isbad], r.iter[isbad])
+    assert np.allclose(rp.primal[~isbad], r.primal[~isbad], rtol=0, atol=1e-6)
 
 
 @pytest.mark.parametrize("grid,slice_iters", [(7, 25), (32, 50), (64, 1)])
@@ -151,9 +159,14 @@ def test_time_sliced_launch_equals_one_block_per_item(sfb, oracle, grid, slice_i
             assert np.array_equal(a.primal, b.primal) and np.array_equal(a.dual, b.dual)
             assert np.array_equal(a.objective, b.objective)
         assert r.iter.max() > 3 * max(25, slice_iters)      # items were suspended several times
-        ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l, u, perm=plan.perm,
+        ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l, u, perm=plan.perm, forder=plan.factor_order(),
                                            params=_oracle_params(oracle, prm), nthreads=8)
-        assert np.array_equal(r.iter, ref["iter"]) and np.array_equal(r.primal, ref["x"])
+        ok = np.ones(B, bool)
+        ok[5] = kp is None                        # pruned plan: item 5 went through the fallback analysis
+        assert np.array_equal(r.iter[ok], ref["iter"][ok]) and np.array_equal(r.primal[ok], ref["x"][ok])
+        ref5 = oracle.qp_sparse_solve_batch(Pp, Pi, Px[5:6], q[5:6], Ap, Aj, Av[5:6], l[5:6], u[5:6], perm=plan.perm,
+                                            forder=plan.factor_order(fallback=True), params=_oracle_params(oracle, prm))
+        assert np.array_equal(r.iter[5:6], ref5["iter"]) and np.array_equal(r.primal[5:6], ref5["x"])
 
 
 def test_mpc_closed_loop_like_reference_test(sfb):

@@ -118,9 +118,16 @@ def test_explicit_zeros_can_be_left_out_of_the_analysis(oracle, sfb, variant, K,
     Ap2, Aj2 = _compress(Ap, Aj, keep)
     Px, q = np.tile(Pv, (B, 1)), np.zeros((B, d["n"]))
     prm = oracle.default_params(max_iter=4000)
-    full = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l, u, perm=plan.perm, params=prm, nthreads=4)
+    # (the summation order of the factorisation is a postorder of the elimination tree, which differs between the
+    #  two patterns: the whole-pattern run is told to use the pruned one's; the pruned run finds it by itself)
+    full = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l, u, perm=plan.perm, forder=plan.factor_order(), params=prm, nthreads=4)
     comp = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap2, Aj2, np.ascontiguousarray(Av[:, keep]), l, u,
                                         perm=plan.perm, params=prm, nthreads=4)
+    comp2 = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap2, Aj2, np.ascontiguousarray(Av[:, keep]), l, u,
+                                         perm=plan.perm, forder=plan.factor_order(), params=prm, nthreads=4)
+    assert np.array_equal(comp["x"], comp2["x"]) and np.array_equal(comp["iter"], comp2["iter"])
+    fo = plan.factor_order()
+    assert sorted(fo.tolist()) == list(range(d["n"] + d["m"]))
     assert full["nnzL"] == plan.nnzL_fallback and comp["nnzL"] == plan.nnzL
     for key in ("code", "iter", "x", "y", "obj"):
         assert np.array_equal(full[key], comp[key]), key

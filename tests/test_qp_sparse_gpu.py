@@ -30,7 +30,7 @@ def test_sparse_known_answers(sfb, oracle, name):
     if objv is not None:
         assert abs(r.objective[0] - objv) <= otol
     ref = oracle.qp_sparse_solve_batch(Pc.indptr, Pc.indices, Pc.data[None], q[None], Ac.indptr, Ac.indices,
-                                       Ac.data[None], l[None], u[None], perm=plan.perm,
+                                       Ac.data[None], l[None], u[None], perm=plan.perm, forder=plan.factor_order(),
                                        params=_oracle_params(oracle, prm))
     _compare(r, ref)
     sol = sfb.solve_qp_sparse(sfb.QuadraticProgramSparse(P=Pc, q=q, A=Ac, l=l, u=u))
@@ -49,7 +49,7 @@ def test_random_sparse_batches(sfb, oracle, n, m, density, ordering, sweep_mode)
     plan = sfb.SparseQPPlan(n, m, Pp, Pi, Ap, Aj, ordering=ordering)
     for prm in (sfb.QPSolverParams(max_iter=2000), sfb.QPSolverParams(max_iter=600, scaling=False, polish=False)):
         r = plan.solve_batch_host(Px, q, Ax, l, u, prm)
-        ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Ax, l, u, perm=plan.perm,
+        ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Ax, l, u, perm=plan.perm, forder=plan.factor_order(),
                                            params=_oracle_params(oracle, prm), nthreads=8)
         bit = _compare(r, ref)
         print(n, m, "nnzL", plan.nnzL, "bit-identical:", bit, "codes", np.bincount(r.code, minlength=7))
@@ -58,7 +58,7 @@ def test_random_sparse_batches(sfb, oracle, n, m, density, ordering, sweep_mode)
     ok = np.isfinite(ref["x"]).all(1) & np.isfinite(ref["y"]).all(1)
     wx, wy = np.where(ok[:, None], ref["x"], 0.0), np.where(ok[:, None], ref["y"], 0.0)
     r2 = plan.solve_batch_host(Px, q + 0.01, Ax, l, u, prm, warm_x=wx, warm_y=wy)
-    ref2 = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q + 0.01, Ap, Aj, Ax, l, u, perm=plan.perm,
+    ref2 = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q + 0.01, Ap, Aj, Ax, l, u, perm=plan.perm, forder=plan.factor_order(),
                                         params=_oracle_params(oracle, prm), warm_x=wx, warm_y=wy, nthreads=8)
     _compare(r2, ref2)
 
@@ -80,6 +80,6 @@ def test_large_banded_problem_uses_element_indices(sfb, oracle, sweep_mode):
     prm = sfb.QPSolverParams(max_iter=300)
     r = plan.solve_batch_host(Px, q, Ax, l, u, prm)
     ref = oracle.qp_sparse_solve_batch(Pm.indptr.astype(np.int32), Pm.indices.astype(np.int32), Px, q,
-                                       Am.indptr.astype(np.int32), Am.indices.astype(np.int32), Ax, l, u, perm=plan.perm,
+                                       Am.indptr.astype(np.int32), Am.indices.astype(np.int32), Ax, l, u, perm=plan.perm, forder=plan.factor_order(),
                                        params=_oracle_params(oracle, prm), nthreads=3)
     assert _compare(r, ref)
