@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native batched QP engine.
 
-    python bench.py --gpus N --steps K --warmup W [--workload mpc|qp_dense]
+    python bench.py --gpus N --steps K --warmup W [--workload mpc|qp_dense|ekf]
 
 One "step" = one pass of the hot path over one batch of synthetic QPs that is already resident in
 HBM: by default the MPC configuration the BASELINE metric is quoted on (8 192 agents, nx=12, nu=2,
@@ -10,6 +10,9 @@ BASELINE configs[1] (65 536 dense QPs n=10, m=20, sfb_qp_dense_solve_batch).  Fo
 torch.distributed.run; every rank owns an independent shard of the batch (weak scaling: per-GPU
 batch fixed), the data path has no collective, and only the per-QP (code, iter) words are
 gathered over RCCL at the end of each step.  Rank 0 prints ONE JSON line.
+
+The single-GPU default run also reports the other two BASELINE configurations (`secondary`: dense QPs,
+EKF ticks) with their own kernel time, roofline and parity figures, so that ONE driver-run line covers all three.
 
 The CPU oracle (oracle/) is used here ONLY for the `cpu_baseline` leg and a parity spot-check of a
 bounded sample; it is never the thing measured as `value`.
@@ -70,11 +73,33 @@ class DenseQPWorkload:
                                "p99": int(np.percentile(it, 99)), "max": int(it.max())},
                 "codes": np.bincount(code, minlength=7).tolist()}
 
+    def roofline_alt(self, kern_ms):
+        """The dense kernels are bound by dependent FP64 work, not by HBM (SURVEY.md section 8d caveat for cfg2):
+        algorithmic flops of the batch -- k^3/3 for the factorisation, 2k^2 + 10m + 3n per ADMM iteration, six
+        mat-vecs per stopping check, the polish factorisation and its five refinement solves for Optimal QPs --
+        against the vector FP64 peak."""
+        n, m = self.n, self.m
+        k = n + m
+        it = self.out[0].cpu().numpy().astype(np.float64)
+        opt = (self.out[1].cpu().numpy() == 0)
+        na = n + m / 2.0
+        flops = (k ** 3 / 3.0 + it * (2 * k * k + 10 * m + 3 * n) + np.ceil(it / 25.0) * (4 * n * n + 8 * m * n)
+                 + opt * (na ** 3 / 3.0 + 15 * na * na)).sum()
+        ach = flops / (kern_ms * 1e-3)
+        return {"bound": "fp64_valu", "achieved": ach / 1e12, "peak": FP64_VALU_PEAK / 1e12, "unit": "TFLOP/s",
+                "frac": ach / FP64_VALU_PEAK, "flops_per_launch": float(flops),
+                "note": "algorithmic flops (SURVEY 8d model) / kernel time; the triangular solves are chains of dependent "
+                        "fp64 fmas, so the issue-slot utilisation (DESIGN.md: SIMD-cycles per QP-iteration) is the tighter view"}
+
     def cpu_baseline(self, cores, budget_s=15.0):
         """Oracle (CPU restatement of the reference ADMM) on a bounded sample of the same batch."""
         from oracle import loader as O
         op = O.default_params(eps_abs=1e-6, eps_rel=1e-6, polish=1, max_iter=10000, scaling=0)
         P, q, A, l, u = self.host
+        s1 = min(self.B, 512)   # single core, sequential over the batch exactly like benchmarks/bench_types.hpp:93
+        t0 = time.perf_counter()
+        O.qp_dense_solve_batch(P[:s1], q[:s1], A[:s1], l[:s1], u[:s1], params=op, nthreads=1)
+        single = {"value": s1 / (time.perf_counter() - t0), "cores": 1, "sample": "first %d QPs" % s1}
         probe = min(self.B, 64 * cores)
         t0 = time.perf_counter()
         O.qp_dense_solve_batch(P[:probe], q[:probe], A[:probe], l[:probe], u[:probe], params=op, nthreads=cores)
@@ -95,7 +120,8 @@ class DenseQPWorkload:
         }
         return {"value": S / dt, "unit": "QP solves/s", "cores": cores, "kind": "port",
                 "sample": "first %d QPs of rank 0's batch, oracle/qp_oracle.c (CPU restatement of the "
-                          "reference ADMM, %d pthreads, static partition), %.1f s" % (S, cores, dt)}, parity
+                          "reference ADMM, %d pthreads, static partition), %.1f s" % (S, cores, dt),
+                "single_core": single}, parity
 
 
 class MPCWorkload:
@@ -192,10 +218,17 @@ class MPCWorkload:
                 "host_assembly_s": self.host_assembly_s}
 
     def cpu_baseline(self, cores, budget_s=20.0):
+        """The oracle on the WHOLE stored pattern (explicit zeros included, as the reference's SimplicialLDLT
+        factorises them) with the plan's elimination and summation orders: baseline and parity check in one."""
         from oracle import loader as O
         Pp, Pi, Pv, Ap, Aj = self.pat
         Px, q, Av, l, u = self.host
         op = O.default_params()  # max_iter unset, like the device run (device cap 2e7 is never reached here)
+        s1 = min(self.B, 24)     # single core, one agent after the other like a loop over MPC::operator()
+        t0 = time.perf_counter()
+        O.qp_sparse_solve_batch(Pp, Pi, Px[:s1], q[:s1], Ap, Aj, Av[:s1], l[:s1], u[:s1], perm=self.plan.perm,
+                                forder=self.plan.factor_order(), params=op, nthreads=1)
+        single = {"value": s1 / (time.perf_counter() - t0), "cores": 1, "sample": "first %d agents" % s1}
         S = int(min(self.B, max(cores, 2 * cores)))
         t0 = time.perf_counter()
         ref = O.qp_sparse_solve_batch(Pp, Pi, Px[:S], q[:S], Ap, Aj, Av[:S], l[:S], u[:S], perm=self.plan.perm, forder=self.plan.factor_order(),
@@ -216,8 +249,8 @@ class MPCWorkload:
                   "max_abs_dx": float(np.abs(x - ref["x"]).max())}
         return {"value": S / dt, "unit": "QP solves/s", "cores": cores, "kind": "port",
                 "sample": "first %d agents of rank 0's batch, oracle/qp_sparse_oracle.c (CPU restatement of the "
-                          "reference's sparse ADMM path with the same elimination order, %d pthreads), %.1f s"
-                          % (S, cores, dt)}, parity
+                          "reference's sparse ADMM path on the whole stored pattern, same elimination order, %d pthreads), %.1f s"
+                          % (S, cores, dt), "single_core": single}, parity
 
 
 class EKFWorkload:
@@ -293,25 +326,94 @@ WORKLOADS = {"mpc": MPCWorkload, "qp_dense": DenseQPWorkload, "ekf": EKFWorkload
 # FETCH_SIZE on gfx950 reports 1/2 of the bytes of 16-byte-per-lane coalesced reads (MI355X_MICROARCH.md,
 # HBM section); for the 8-byte-per-lane reads of the dense kernel the factor was calibrated on its exactly
 # known read volume (profiles/README.md).  WRITE_SIZE matched the known write volume of the EKF kernel.
+# The sparse kernel mixes 16-byte streams (factor, vectors) with 8-byte gathers (factorisation, checks): x2 is exact
+# for the former (~85 % of its reads) and over-counts the latter, so its traffic figure is an upper bound (~ +10 %).
 FETCH_CORRECTION = {"mpc": 2.0, "ekf": 2.0, "qp_dense": 1.0 / 0.58}
+PROFILE_TAG = "r2"
+FP64_VALU_PEAK = 78.6e12  # MI355X vector FP64 (half the 157.3 TFLOP/s FP32 vector rate of MI355X_MICROARCH.md)
+
+
+def source_hash():
+    """sha256 over the kernel sources: a committed PMC summary is only quoted for the build it was measured on."""
+    import hashlib
+    root = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha256()
+    d = os.path.join(root, "smooth_feedback_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode()); h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(workload, workload_name):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r1_<workload>/summary.json,
-    written by scripts/profile_all.sh + scripts/summarize_profiles.py for this very bench command), or None
-    when there is no summary for this workload configuration."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_%s" % workload, "summary.json")
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/<tag>_<workload>/summary.json,
+    written by scripts/profile_one.sh + scripts/summarize_profiles.py for this very bench command).  None when
+    there is no summary for this workload configuration OR the kernel sources have changed since it was taken."""
+    root = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(root, "profiles", "%s_%s" % (PROFILE_TAG, workload), "summary.json")
     try:
         with open(path) as f:
             s = json.load(f)
         if s["bench_line_under_profiler"]["config"]["workload"] != workload_name:
-            return None, None
+            return None, "no PMC summary for this workload configuration"
+        if s.get("source_hash") != source_hash():
+            return None, "PMC summary %s is of another build (source hash differs): traffic not quoted" % os.path.relpath(path, root)
         rd = s["FETCH_SIZE"]["mean_per_dispatch_KB"] * 1024.0 * FETCH_CORRECTION[workload]
         wr = s["WRITE_SIZE"]["mean_per_dispatch_KB"] * 1024.0
         return rd + wr, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x%.2f, %s" % (
-            FETCH_CORRECTION[workload], os.path.relpath(path, os.path.dirname(os.path.abspath(__file__))))
+            FETCH_CORRECTION[workload], os.path.relpath(path, root))
     except (OSError, KeyError, ValueError):
-        return None, None
+        return None, "no PMC summary"
+
+
+KERNEL_NAME = {"mpc": "qp_sparse_kernel", "qp_dense": "qp_dense4_iterate_kernel (+ setup and finish kernels of the same launch)",
+               "ekf": "ekf_kernel"}
+
+
+def roofline_of(workload, wl, kern_ms, with_traffic):
+    achieved = wl.units_per_step * wl.bytes_per_unit / (kern_ms * 1e-3)
+    r = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_BYTES_PER_S, "traffic": None, "kernel": KERNEL_NAME[workload], "kernel_ms": kern_ms,
+         "algorithmic_bytes_per_unit": wl.bytes_per_unit}
+    if workload != "ekf":
+        r["note"] = ("achieved = SURVEY 8(d) algorithmic I/O bytes / kernel time; the ADMM iterations re-stream the LDL' "
+                     "factor from HBM (sparse kernel) or are FP64-issue bound (dense kernel), so the I/O-only fraction is "
+                     "small by construction -- see DESIGN.md")
+    if with_traffic:
+        r["traffic"], r["traffic_source"] = pmc_traffic(workload, wl.name)
+        if r["traffic"]:  # what the kernel actually moves through HBM, as a rate and a fraction of peak
+            r["traffic_GBps"] = r["traffic"] / (kern_ms * 1e-3) / 1e9
+            r["traffic_frac"] = r["traffic"] / (kern_ms * 1e-3) / HBM_PEAK_BYTES_PER_S
+    return r
+
+
+def secondary_line(sfb, workload, device, steps=3):
+    """One of the other BASELINE configurations, measured the same way as the headline (HIP events on the launch
+    stream, inputs resident in HBM) with a bounded parity / CPU sample: reported under `secondary`."""
+    wl = WORKLOADS[workload](sfb, 0, device)
+    stream = torch.cuda.current_stream()
+    wl.step(stream)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ev[k][0].record(stream)
+        wl.step(stream)
+        ev[k][1].record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    rec = {"value": wl.units_per_step * steps / elapsed, "unit": "EKF steps/s" if workload == "ekf" else "QP solves/s",
+           "steps": steps, "ms_per_step": elapsed / steps * 1e3, "dtype": "f64",
+           "config": {"workload": wl.name, "per_gpu_batch": wl.B},
+           "roofline": roofline_of(workload, wl, kern_ms, True)}
+    if hasattr(wl, "extra"):
+        rec["workload_stats"] = wl.extra()
+    if hasattr(wl, "roofline_alt"):
+        rec["roofline_alt"] = wl.roofline_alt(kern_ms)
+    rec["cpu_baseline"], rec["parity_vs_oracle"] = wl.cpu_baseline(os.cpu_count() or 1, budget_s=4.0)
+    return rec
 
 
 def main():
@@ -354,7 +456,6 @@ def main():
     wl = WORKLOADS[args.workload](sfb, rank, device, **kw)
     stream = torch.cuda.current_stream()
     gathered = None
-    kernel_name = {"mpc": "qp_sparse_kernel", "qp_dense": "qp_dense4_iterate_kernel (+ setup and finish kernels of the same launch)", "ekf": "ekf_kernel"}[args.workload]
     if world > 1:
         gathered = [torch.empty_like(wl.small_outputs()) for _ in range(world)]
 
@@ -395,7 +496,6 @@ def main():
     if rank == 0:
         units = wl.units_per_step * world * args.steps
         value = units / elapsed
-        achieved = wl.units_per_step * wl.bytes_per_unit / (kern_ms * 1e-3)
         rec = {
             "metric": "EKF predict+update steps/sec" if args.workload == "ekf" else "QP solves/sec",
             "value": value,
@@ -411,32 +511,25 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl.name, "per_gpu_batch": wl.B, "global_batch": wl.B * world,
                        "parallelism": "batch-sharded x%d, one gather of the small per-item outputs (u0 / code / iter)" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_BYTES_PER_S, "traffic": None,
-                         "kernel": kernel_name, "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_unit": wl.bytes_per_unit,
-                         "note": "achieved = SURVEY 8(d) algorithmic I/O bytes / kernel time; the ADMM iterations "
-                                 "re-stream the LDL' factor from HBM (sparse kernel) or are FP64-issue bound (dense "
-                                 "kernel), so the I/O-only fraction is small by construction -- see DESIGN.md"},
+            "roofline": roofline_of(args.workload, wl, kern_ms, world == 1),
         }
-        if world == 1:
-            rec["roofline"]["traffic"], src = pmc_traffic(args.workload, wl.name)
-            if src:
-                rec["roofline"]["traffic_source"] = src
-            if rec["roofline"]["traffic"]:  # what the kernel actually moves through HBM, as a rate and a fraction of peak
-                rec["roofline"]["traffic_GBps"] = rec["roofline"]["traffic"] / (kern_ms * 1e-3) / 1e9
-                rec["roofline"]["traffic_frac"] = rec["roofline"]["traffic"] / (kern_ms * 1e-3) / HBM_PEAK_BYTES_PER_S
         if hasattr(wl, "extra"):
             rec["workload_stats"] = wl.extra()
             ws = rec["workload_stats"]
             if "factor_stream_bytes_per_iteration_per_qp" in ws:
                 eff = ws["factor_stream_bytes_per_iteration_per_qp"] * ws["iterations"]["mean"] * wl.units_per_step
                 rec["roofline"]["factor_stream_GBps"] = eff / (kern_ms * 1e-3) / 1e9
+        if hasattr(wl, "roofline_alt"):
+            rec["roofline_alt"] = wl.roofline_alt(kern_ms)
         if world == 1 and hasattr(wl, "pipelined") and not args.no_pipelined:
             rec["pipelined"] = wl.pipelined(max(4, 2 * args.steps))
         if not args.no_cpu_baseline and world == 1:
             cores = os.cpu_count() or 1
             rec["cpu_baseline"], rec["parity_vs_oracle"] = wl.cpu_baseline(cores)
+        if world == 1 and not args.no_secondary and not args.no_cpu_baseline and args.batch is None:
+            del wl  # free the headline workload's device memory first
+            torch.cuda.empty_cache()
+            rec["secondary"] = {w: secondary_line(sfb, w, device) for w in sorted(WORKLOADS) if w != args.workload}
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.barrier()

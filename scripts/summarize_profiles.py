@@ -4,6 +4,7 @@ kernel's duration and of the FETCH_SIZE / WRITE_SIZE counters, each from its own
 import csv, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 # product kernels; a launch of the dense path is three kernels (setup / iterate / finish): counters are summed
 # over all of them and divided by the number of launches (= dispatches of the dominant kernel)
 KERNELS = ("qp_sparse_kernel", "qp_dense_kernel", "qp_dense4_", "ekf_kernel")
@@ -18,7 +19,8 @@ def main(tag):
         dst = os.path.join(ROOT, "profiles", "%s_%s" % (tag, wl))
         os.makedirs(dst, exist_ok=True)
         shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(dst, "kernel_stats.csv"))
-        out = {"kernel_stats": []}
+        from bench import source_hash
+        out = {"source_hash": source_hash(), "kernel_stats": []}  # bench.py quotes the traffic only for this build
         with open(os.path.join(src, "trace", "t_kernel_stats.csv")) as f:
             for r in csv.DictReader(f):
                 out["kernel_stats"].append({k: r[k] for k in ("Name", "Calls", "AverageNs", "Percentage")})
