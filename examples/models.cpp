@@ -633,3 +633,14 @@ int sfbx_test_ekf_predict_linear(const double * A3, const double * F3, const dou
     return 1;
   }
 }
+
+int sfbx_test_ekf_predict_linear9(const double * A9, const double * F9, double * err)
+{
+  try {
+    err[0] = err[1] = 0.0;
+    predict_linear_case<9>(A9, F9, err);
+    return 0;
+  } catch (const std::exception &) {
+    return 1;
+  }
+}

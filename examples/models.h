@@ -47,6 +47,8 @@ int sfbx_test_ekf(double *err);
  * err[0] = max relative error of the estimate vs expm(A tau) xhat, err[1] = of the covariance vs F P F'.
  * The exact F (Nx*Nx, column-major, for Nx = 3 then 6) is supplied by the caller.  Needs a GPU. */
 int sfbx_test_ekf_predict_linear(const double *A3, const double *F3, const double *A6, const double *F6, double *err);
+/* the third size of the reference's test, Nx = 9 (tests/test_ekf.cpp:152): the generic one-filter-per-wave kernel */
+int sfbx_test_ekf_predict_linear9(const double *A9, const double *F9, double *err);
 /* asif_to_qp() (include/smooth_feedback_amd/asif.hpp) for the case of tests/test_asif.cpp:37-95: X = SE2, f = (u0, 0, u1),
  * h = position (nh = 2), bu = (-0.1, 1), K = 3, input box [-1,1]^2 around c = 0, T = 1, alpha = 1, dt = 0.1.
  * x0 = (angle, px, py).  Out, column-major: P[9] q[3] A[9*3] l[9] u[9].  Host only (no GPU). */

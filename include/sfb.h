@@ -310,7 +310,9 @@ sfb_status sfb_mpc_swarm_debug_buffers(sfb_mpc_swarm *swarm, const double **Ax, 
  * H [batch][ny*dof], R [batch][ny*ny], r [batch][ny], delta [batch][dof].  Only the upper triangles
  * of Q and R are read (ekf.hpp:77,:114).  q_shared / r_shared / dt_shared != 0: Q / R / dt point to
  * ONE matrix / scalar used by every item.  info[batch] (nullable): 0 ok, 1 = LDLT of S failed.
- * Supported sizes: dof in {2,3,4,6}, ny in {1,2,3} (one filter per lane, register-resident).
+ * Supported sizes: dof, ny <= 16.  dof in {2,3,4,6} with ny in {1,2,3} run one filter per lane, register-resident
+ * (the streaming kernels of the benchmark configuration); every other size (the reference's own tests use
+ * (dof, ny) = (10,3), (3,10) and dof = 9) runs one filter per wavefront with its matrices in LDS.
  * Device pointers, asynchronous on `stream`; P is updated in place.
  * ---------------------------------------------------------------------------------------- */
 sfb_status sfb_ekf_predict_batch(int64_t batch, int dof, const double *A, const double *Q, int q_shared,
@@ -318,12 +320,22 @@ sfb_status sfb_ekf_predict_batch(int64_t batch, int dof, const double *A, const 
 sfb_status sfb_ekf_update_batch(int64_t batch, int dof, int ny, const double *H, const double *R, int r_shared,
                                 const double *r, double *P, double *delta, int32_t *info, void *stream);
 /* predict with an explicit choice of the stepper (ekf.hpp:27-31: the Stp template argument): ONE step of the
- * covariance ODE dP/dt = symU(A P + P A' + Q), A frozen during the step (ekf.hpp:86-96), by explicit Euler
- * (SFB_EKF_EULER == sfb_ekf_predict_batch) or by boost::numeric::odeint::runge_kutta4 (SFB_EKF_RK4, the stepper
- * tests/test_ekf.cpp:113-115 instantiates).  The state step g <- stepper(g) stays on the host. */
+ * covariance ODE dP/dt = symU(A P + P A' + Q) by explicit Euler (SFB_EKF_EULER == sfb_ekf_predict_batch) or by
+ * boost::numeric::odeint::runge_kutta4 (SFB_EKF_RK4, the stepper tests/test_ekf.cpp:113-115 instantiates) with ONE
+ * A for all four stages -- exact for dynamics f(t, x) that do not depend on t explicitly; see
+ * sfb_ekf_predict_rk4_batch otherwise.  The state step g <- stepper(g) stays on the host. */
 typedef enum { SFB_EKF_EULER = 0, SFB_EKF_RK4 = 1 } sfb_ekf_stepper;
 sfb_status sfb_ekf_predict_stepper_batch(int stepper, int64_t batch, int dof, const double *A, const double *Q,
                                          int q_shared, const double *dt, int dt_shared, double *P, void *stream);
+/* runge_kutta4 step of the covariance ODE with the linearisation at the stage times: the reference evaluates
+ * A = -ad(f(t_s, g)) + d^r f/dx|_(t_s, g) inside cov_ode (ekf.hpp:84-89) at t_s = t (A), t + dt/2 (A_mid, stages 2
+ * and 3) and t + dt (A_end); g is frozen during the covariance step (:96).  A_mid == A_end == NULL: A everywhere. */
+sfb_status sfb_ekf_predict_rk4_batch(int64_t batch, int dof, const double *A, const double *A_mid, const double *A_end,
+                                     const double *Q, int q_shared, const double *dt, int dt_shared, double *P,
+                                     void *stream);
+sfb_status sfb_ekf_predict_rk4_batch_host(int64_t batch, int dof, const double *A, const double *A_mid,
+                                          const double *A_end, const double *Q, int q_shared, const double *dt,
+                                          int dt_shared, double *P);
 /* predict immediately followed by update in one launch (one pass over P). */
 sfb_status sfb_ekf_predict_update_batch(int64_t batch, int dof, int ny, const double *A, const double *Q,
                                         int q_shared, const double *dt, int dt_shared, const double *H,

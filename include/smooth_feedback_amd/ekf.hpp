@@ -73,8 +73,17 @@ public:
       typename G::Tangent fv;
       const CovT A = detail::ekf_linearise_dyn<G>([&](const G & x) { return f(t, x); }, g_hat_, fv);
       // covariance first: it depends on g_hat_ (:94-96)
-      detail::ekf_check(sfb_ekf_predict_stepper_batch_host(static_cast<int>(Stp), 1, N, A.a.data(), Q.a.data(), 1, &h, 1,
-                                                           P_.a.data()));
+      if constexpr (Stp == EKFStepper::Euler) {
+        detail::ekf_check(sfb_ekf_predict_stepper_batch_host(SFB_EKF_EULER, 1, N, A.a.data(), Q.a.data(), 1, &h, 1, P_.a.data()));
+      } else {
+        // runge_kutta4 calls cov_ode at t, t + h/2 (twice) and t + h, and cov_ode linearises f(t_stage, .) at the
+        // (frozen) estimate each time (:84-89): for dynamics that depend on t the three matrices differ
+        typename G::Tangent fs;
+        const CovT Am = detail::ekf_linearise_dyn<G>([&](const G & x) { return f(t + 0.5 * h, x); }, g_hat_, fs);
+        const CovT Ae = detail::ekf_linearise_dyn<G>([&](const G & x) { return f(t + h, x); }, g_hat_, fs);
+        detail::ekf_check(sfb_ekf_predict_rk4_batch_host(1, N, A.a.data(), Am.a.data(), Ae.a.data(), Q.a.data(), 1, &h, 1,
+                                                         P_.a.data()));
+      }
       if constexpr (Stp == EKFStepper::Euler) {
         for (auto & v : fv) v *= h;
         g_hat_ = rplus(g_hat_, fv);  // euler on the group: g <- g (+) dt f (:97)

@@ -52,23 +52,31 @@ static void ekf_cov_rhs(int n, const double *A, const double *Q, const double *P
 }
 
 /* One step of boost::numeric::odeint::runge_kutta4 (the stepper tests/test_ekf.cpp:113-115 instantiates;
- * explicit_generic_rk with a = {1/2; 0,1/2; 0,0,1}, b = {1/6,1/3,1/3,1/6}) on the covariance ODE with A
- * frozen (ekf.hpp:86-96).  Stage states  P + (dt a_ij) k_j ; result  P + (dt b1) k1 + (dt b2) k2 + (dt b3) k3
+ * explicit_generic_rk with a = {1/2; 0,1/2; 0,0,1}, b = {1/6,1/3,1/3,1/6}) on the covariance ODE with ONE A
+ * for all stages (time-invariant dynamics; oracle_ekf_predict_rk4_tv below takes the A of every stage time).  Stage states  P + (dt a_ij) k_j ; result  P + (dt b1) k1 + (dt b2) k2 + (dt b3) k3
  * + (dt b4) k4  accumulated left to right (odeint's scale_sum5).  Zero tableau entries add exact zeros. */
 void oracle_ekf_predict_rk4(int dof, const double *A, const double *Q, double dt, double *P)
+{
+  oracle_ekf_predict_rk4_tv(dof, A, A, A, Q, dt, P);
+}
+
+/* The same with the linearisation re-evaluated at the stage times as cov_ode does (ekf.hpp:84-89): A0 at t,
+ * Am at t + dt/2 (stages 2 and 3), Ae at t + dt (stage 4).  The state g is frozen during the covariance step. */
+void oracle_ekf_predict_rk4_tv(int dof, const double *A0, const double *Am, const double *Ae, const double *Q, double dt,
+                               double *P)
 {
   const int n = dof, nn = dof * dof;
   double *k  = (double *)malloc(sizeof(double) * (size_t)nn);
   double *Pi = (double *)malloc(sizeof(double) * (size_t)nn);
   double *S  = (double *)malloc(sizeof(double) * (size_t)nn);
   const double b1 = dt * (1.0 / 6.0), b2 = dt * (1.0 / 3.0), c2 = dt * 0.5, c4 = dt * 1.0;
-  ekf_cov_rhs(n, A, Q, P, k);                                   /* k1 */
+  ekf_cov_rhs(n, A0, Q, P, k);                                  /* k1 */
   for (int e = 0; e < nn; ++e) { S[e] = P[e] + b1 * k[e]; Pi[e] = P[e] + c2 * k[e]; }
-  ekf_cov_rhs(n, A, Q, Pi, k);                                  /* k2 */
+  ekf_cov_rhs(n, Am, Q, Pi, k);                                 /* k2 */
   for (int e = 0; e < nn; ++e) { S[e] = S[e] + b2 * k[e]; Pi[e] = P[e] + c2 * k[e]; }
-  ekf_cov_rhs(n, A, Q, Pi, k);                                  /* k3 */
+  ekf_cov_rhs(n, Am, Q, Pi, k);                                 /* k3 */
   for (int e = 0; e < nn; ++e) { S[e] = S[e] + b2 * k[e]; Pi[e] = P[e] + c4 * k[e]; }
-  ekf_cov_rhs(n, A, Q, Pi, k);                                  /* k4 */
+  ekf_cov_rhs(n, Ae, Q, Pi, k);                                 /* k4 */
   for (int e = 0; e < nn; ++e) P[e] = S[e] + b1 * k[e];
   free(k); free(Pi); free(S);
 }
@@ -149,6 +157,14 @@ void oracle_ekf_predict_rk4_batch(int64_t batch, int dof, const double *A, const
   for (int64_t b = 0; b < batch; ++b)
     oracle_ekf_predict_rk4(dof, A + (size_t)b * nn, q_shared ? Q : Q + (size_t)b * nn, dt_shared ? dt[0] : dt[b],
                            P + (size_t)b * nn);
+}
+void oracle_ekf_predict_rk4_tv_batch(int64_t batch, int dof, const double *A0, const double *Am, const double *Ae,
+                                     const double *Q, int q_shared, const double *dt, int dt_shared, double *P)
+{
+  const size_t nn = (size_t)dof * dof;
+  for (int64_t b = 0; b < batch; ++b)
+    oracle_ekf_predict_rk4_tv(dof, A0 + (size_t)b * nn, Am + (size_t)b * nn, Ae + (size_t)b * nn,
+                              q_shared ? Q : Q + (size_t)b * nn, dt_shared ? dt[0] : dt[b], P + (size_t)b * nn);
 }
 void oracle_ekf_update_batch(int64_t batch, int dof, int ny, const double *H, const double *R, int r_shared,
                              const double *r, double *P, double *delta, int32_t *info)

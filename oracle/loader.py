@@ -74,6 +74,8 @@ def lib():
         L.oracle_ekf_predict_batch.restype = None
         L.oracle_ekf_predict_rk4_batch.argtypes = [C.c_int64, C.c_int, dp, dp, C.c_int, dp, C.c_int, dp]
         L.oracle_ekf_predict_rk4_batch.restype = None
+        L.oracle_ekf_predict_rk4_tv_batch.argtypes = [C.c_int64, C.c_int, dp, dp, dp, dp, C.c_int, dp, C.c_int, dp]
+        L.oracle_ekf_predict_rk4_tv_batch.restype = None
         L.oracle_ekf_update_batch.argtypes = [C.c_int64, C.c_int, C.c_int, dp, dp, C.c_int, dp, dp, dp,
                                               C.POINTER(C.c_int32)]
         L.oracle_ekf_update_batch.restype = None
@@ -181,13 +183,20 @@ def qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Ax, l, u, perm=None, params=Non
     return dict(x=x, y=y, obj=obj, iter=it, code=code, nnzL=nnzL.value)
 
 
-def ekf_predict_batch(A, Q, dt, P, stepper="euler"):
+def ekf_predict_batch(A, Q, dt, P, stepper="euler", A_mid=None, A_end=None):
     """A, P: (B, dof*dof) col-major flat; Q: (B, dof*dof) or (dof*dof,) shared; dt: (B,) or scalar.
-    stepper: "euler" (ekf.hpp:30 default) or "rk4" (odeint runge_kutta4).  Returns the new P (B, dof*dof)."""
+    stepper: "euler" (ekf.hpp:30 default) or "rk4" (odeint runge_kutta4).  A_mid / A_end (rk4 only): the linearisation
+    at t + dt/2 and t + dt.  Returns the new P (B, dof*dof)."""
     A = np.ascontiguousarray(A, dtype=np.float64); P = np.array(P, dtype=np.float64, order="C")
     B, nn = A.shape
     dof = int(round(nn ** 0.5))
     Q = np.ascontiguousarray(Q, dtype=np.float64); dt = np.ascontiguousarray(np.atleast_1d(dt), dtype=np.float64)
+    if A_mid is not None:
+        assert stepper == "rk4"
+        A_mid = np.ascontiguousarray(A_mid, dtype=np.float64); A_end = np.ascontiguousarray(A_end, dtype=np.float64)
+        lib().oracle_ekf_predict_rk4_tv_batch(B, dof, _dp(A), _dp(A_mid), _dp(A_end), _dp(Q), int(Q.ndim == 1), _dp(dt),
+                                              int(dt.size == 1), _dp(P))
+        return P
     fn = lib().oracle_ekf_predict_rk4_batch if stepper == "rk4" else lib().oracle_ekf_predict_batch
     fn(B, dof, _dp(A), _dp(Q), int(Q.ndim == 1), _dp(dt), int(dt.size == 1), _dp(P))
     return P

@@ -115,6 +115,12 @@ void oracle_ldlt_solve(int k, const double *W, int ld, const int *tr, double *b)
 /* EKF matrix part (oracle/ekf_oracle.c), ekf.hpp:84-102 (Euler substep) and :119-138. */
 void oracle_ekf_predict(int dof, const double *A, const double *Q, double dt, double *P);
 void oracle_ekf_predict_rk4(int dof, const double *A, const double *Q, double dt, double *P);
+/* ... with the linearisation of every stage time (A0 at t, Am at t + dt/2, Ae at t + dt), as cov_ode re-evaluates it
+ * (ekf.hpp:84-89) for dynamics that depend on t explicitly */
+void oracle_ekf_predict_rk4_tv(int dof, const double *A0, const double *Am, const double *Ae, const double *Q, double dt,
+                               double *P);
+void oracle_ekf_predict_rk4_tv_batch(int64_t batch, int dof, const double *A0, const double *Am, const double *Ae,
+                                     const double *Q, int q_shared, const double *dt, int dt_shared, double *P);
 void oracle_ekf_predict_rk4_batch(int64_t batch, int dof, const double *A, const double *Q, int q_shared,
                                   const double *dt, int dt_shared, double *P);
 int oracle_ekf_update(int dof, int ny, const double *H, const double *R, const double *r, double *P, double *delta);

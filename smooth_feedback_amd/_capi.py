@@ -88,6 +88,8 @@ def _load():
     L.sfb_ekf_predict_batch.argtypes = [i64, i32, dp, dp, i32, dp, i32, dp, vp]
     L.sfb_ekf_predict_stepper_batch.argtypes = [i32, i64, i32, dp, dp, i32, dp, i32, dp, vp]
     L.sfb_ekf_predict_stepper_batch_host.argtypes = [i32, i64, i32, dp, dp, i32, dp, i32, dp]
+    L.sfb_ekf_predict_rk4_batch.argtypes = [i64, i32, dp, dp, dp, dp, i32, dp, i32, dp, vp]
+    L.sfb_ekf_predict_rk4_batch_host.argtypes = [i64, i32, dp, dp, dp, dp, i32, dp, i32, dp]
     L.sfb_ekf_update_batch.argtypes = [i64, i32, i32, dp, dp, i32, dp, dp, dp, dp, vp]
     L.sfb_ekf_predict_update_batch.argtypes = [i64, i32, i32, dp, dp, i32, dp, i32, dp, dp, i32, dp, dp, dp, dp, vp]
     L.sfb_ekf_step_batch_host.argtypes = [i64, i32, i32, dp, dp, i32, dp, i32, dp, dp, i32, dp, dp, dp, dp]

@@ -12,11 +12,13 @@
 // These kernels are pure streaming: ~1.4 KB of I/O and ~1.5 kflop per item => HBM-bound.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 
 #include "../../include/sfb.h"
 #include "ekf_kernel.h"
+#include "ldlt_wave.h"
 #include "wave_util.h"
 
 namespace sfb {
@@ -382,9 +384,10 @@ __global__ void __launch_bounds__(64) ekf_kernel(const EkfArgs a)
   tile_store<NN>(a.P, item0, a.batch, lds, lane);
 }
 
-// Predict with boost::numeric::odeint::runge_kutta4 on the covariance ODE, A frozen during the step
-// (ekf.hpp:86-96 with the stepper of tests/test_ekf.cpp:113-115); same stage formulas, coefficients and
-// accumulation order as oracle_ekf_predict_rk4.  One filter per lane: P, the stage state, the running
+// Predict with boost::numeric::odeint::runge_kutta4 on the covariance ODE (ekf.hpp:86-96 with the stepper of
+// tests/test_ekf.cpp:113-115); same stage formulas, coefficients and accumulation order as oracle_ekf_predict_rk4.
+// The reference re-evaluates A = -ad(f(t_s, g)) + d^r f/dx at every stage time t_s (cov_ode, :84-89; g is frozen
+// during the covariance step): A at t, A_mid at t + dt/2 (stages 2, 3), A_end at t + dt; nullptr = same as A.  One filter per lane: P, the stage state, the running
 // sum and the upper triangle of the current slope stay in registers; A is re-read from its LDS tile at
 // every use (four right-hand sides), the second tile stages P and Q.
 template<int N>
@@ -446,6 +449,11 @@ __global__ void __launch_bounds__(64) ekf_rk4_kernel(const EkfArgs a)
       S[r + c * N]    = P[r + c * N] + b1 * kk;
       X[r + c * N]    = P[r + c * N] + c2 * kk;
     }
+  if (a.A_mid != nullptr) {  // time-dependent dynamics: the linearisation at t + dt/2 (stages 2 and 3, ekf.hpp:84-89)
+    wave_sync();
+    tile_load<NN>(a.A_mid, item0, a.batch, ldsA, lane);
+    wave_sync();
+  }
   rhs();  // k2
 #pragma unroll
   for (int c = 0; c < N; ++c)
@@ -464,6 +472,11 @@ __global__ void __launch_bounds__(64) ekf_rk4_kernel(const EkfArgs a)
       S[r + c * N]    = S[r + c * N] + b2 * kk;
       X[r + c * N]    = P[r + c * N] + c4 * kk;
     }
+  if (a.A_end != nullptr) {  // ... and at t + dt (stage 4)
+    wave_sync();
+    tile_load<NN>(a.A_end, item0, a.batch, ldsA, lane);
+    wave_sync();
+  }
   rhs();  // k4
   wave_sync();
   if (live) {
@@ -476,6 +489,150 @@ __global__ void __launch_bounds__(64) ekf_rk4_kernel(const EkfArgs a)
   tile_store<NN>(a.P, item0, a.batch, ldsS, lane);
 }
 
+// ---- generic sizes: ONE FILTER PER WAVEFRONT, matrices in LDS, lanes over matrix entries ----
+// Any dof, ny <= kEkfMaxDim (the reference's EKF is a template over arbitrary Dof / Ny: its own tests use (10,3),
+// (3,10) and Nx = 9, tests/test_ekf.cpp:93-103,148-153).  Same operations in the same order as the per-lane
+// kernels and the oracle: every entry is a k-ascending fma chain; the innovation covariance is factorised by the
+// wave-wide pivoted LDL' of the dense QP kernels (ldlt_wave.h: lane i owns row i).  mode: 0 no predict, 1 Euler,
+// 2 runge_kutta4.
+__global__ void __launch_bounds__(64) ekf_generic_kernel(const EkfArgs a, const int N, const int M, const int mode,
+                                                         const int update)
+{
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  const int NN = N * N, MN = M * N, BUF = NN > MN ? NN : MN;  // (ny may exceed dof)
+  double *P = sm, *A = P + BUF, *Q = A + BUF, *K = Q + BUF, *X = K + BUF, *S = X + BUF;  // predict
+  double *H = K, *T = X, *HP = S;                                                        // update reuses the stage buffers
+  double *Xs = S + BUF, *W = Xs + kEkfMaxDim * kEkfMaxDim, *temp = W + kEkfMaxDim * (kEkfMaxDim + 1) / 2, *xch = temp + kEkfMaxDim;
+  int *perm = reinterpret_cast<int *>(xch + kEkfMaxDim);
+  double *IK = reinterpret_cast<double *>(perm + kEkfMaxDim);
+  double *gP = a.P + b * NN;
+  for (int e = lane; e < NN; e += kWave) P[e] = gP[e];
+  wave_sync();
+  if (mode != 0) {
+    const double *gQ = a.q_shared ? a.Q : a.Q + b * NN;
+    const double *gA = a.A + b * NN;
+    for (int e = lane; e < NN; e += kWave) { A[e] = gA[e]; Q[e] = gQ[e]; }
+    const double dt = a.dt_shared ? a.dt[0] : a.dt[b];
+    wave_sync();
+    // K = symU(A Z + Z A' + Q): upper entries computed, mirrored (ekf.hpp:88)
+    auto rhs = [&](const double *Z) {
+      for (int e = lane; e < NN; e += kWave) {
+        const int i = e % N, j = e / N;
+        if (i <= j) {
+          double m1 = 0.0, m2 = 0.0;
+          for (int k = 0; k < N; ++k) m1 = fma(A[i + k * N], Z[k + j * N], m1);
+          for (int k = 0; k < N; ++k) m2 = fma(Z[i + k * N], A[j + k * N], m2);
+          const double s = (m1 + m2) + Q[i + j * N];
+          K[i + j * N]   = s;
+          K[j + i * N]   = s;
+        }
+      }
+      wave_sync();
+    };
+    auto reload_A = [&](const double *g) {
+      if (g == nullptr) return;
+      wave_sync();
+      for (int e = lane; e < NN; e += kWave) A[e] = g[b * NN + e];
+      wave_sync();
+    };
+    if (mode == 1) {
+      rhs(P);
+      for (int e = lane; e < NN; e += kWave) P[e] = P[e] + dt * K[e];
+    } else {
+      const double b1 = dt * (1.0 / 6.0), b2 = dt * (1.0 / 3.0), c2 = dt * 0.5, c4 = dt * 1.0;
+      rhs(P);  // k1
+      for (int e = lane; e < NN; e += kWave) { S[e] = P[e] + b1 * K[e]; X[e] = P[e] + c2 * K[e]; }
+      reload_A(a.A_mid);
+      wave_sync();
+      rhs(X);  // k2
+      for (int e = lane; e < NN; e += kWave) { S[e] = S[e] + b2 * K[e]; X[e] = P[e] + c2 * K[e]; }
+      wave_sync();
+      rhs(X);  // k3
+      for (int e = lane; e < NN; e += kWave) { S[e] = S[e] + b2 * K[e]; X[e] = P[e] + c4 * K[e]; }
+      reload_A(a.A_end);
+      wave_sync();
+      rhs(X);  // k4
+      for (int e = lane; e < NN; e += kWave) P[e] = S[e] + b1 * K[e];
+    }
+    wave_sync();
+  }
+  if (update) {
+    const double *gH = a.H + b * MN, *gR = a.r_shared ? a.R : a.R + b * (size_t)(M * M);
+    for (int e = lane; e < MN; e += kWave) H[e] = gH[e];
+    wave_sync();
+    for (int e = lane; e < MN; e += kWave) {  // T = H symU(P), HP = H P   (ekf.hpp:129, :134)
+      const int aa = e % M, j = e / M;
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = 0; k < N; ++k) s1 = fma(H[aa + k * M], (k <= j) ? P[k + j * N] : P[j + k * N], s1);
+      for (int k = 0; k < N; ++k) s2 = fma(H[aa + k * M], P[k + j * N], s2);
+      T[e]  = s1;
+      HP[e] = s2;
+    }
+    wave_sync();
+    for (int e = lane; e < M * M; e += kWave) {  // S = triU(H Psym H' + R), stored as the packed lower triangle
+      const int aa = e % M, bb = e / M;
+      if (aa <= bb) {
+        double s = 0.0;
+        for (int k = 0; k < N; ++k) s = fma(T[aa + k * M], H[bb + k * M], s);
+        W[tri(bb, aa)] = s + gR[aa + bb * M];
+      }
+    }
+    wave_sync();
+    const int ok = ldlt_factor_lds(M, W, perm, temp, lane);
+    wave_sync();
+    for (int j = 0; j < N; ++j) {  // X = S^-1 (H P), column by column
+      const double v = ldlt_solve_lds(M, W, perm, xch, lane < M ? HP[lane + j * M] : 0.0, lane);
+      if (lane < M) Xs[lane + j * M] = v;
+    }
+    wave_sync();
+    if (lane < N) {  // delta = K r, K = X'   (:137)
+      double s = 0.0;
+      for (int aa = 0; aa < M; ++aa) s = fma(Xs[aa + lane * M], a.r[b * M + aa], s);
+      a.delta[b * N + lane] = s;
+    }
+    if (a.info != nullptr && lane == 0) a.info[b] = ok ? 0 : 1;
+    for (int e = lane; e < NN; e += kWave) {  // I - K H
+      const int i = e % N, k = e / N;
+      double s = 0.0;
+      for (int aa = 0; aa < M; ++aa) s = fma(Xs[aa + i * M], H[aa + k * M], s);
+      IK[e] = ((i == k) ? 1.0 : 0.0) - s;
+    }
+    wave_sync();
+    double *Pn = A;  // P = symU((I - K H) P)   (:138)
+    for (int e = lane; e < NN; e += kWave) {
+      const int i = e % N, j = e / N;
+      if (i <= j) {
+        double s = 0.0;
+        for (int k = 0; k < N; ++k) s = fma(IK[i + k * N], P[k + j * N], s);
+        Pn[i + j * N] = s;
+        Pn[j + i * N] = s;
+      }
+    }
+    wave_sync();
+    for (int e = lane; e < NN; e += kWave) gP[e] = Pn[e];
+    return;
+  }
+  for (int e = lane; e < NN; e += kWave) gP[e] = P[e];
+}
+
+static hipError_t ekf_generic_launch(const EkfArgs &a, int dof, int ny, int mode, bool update, hipStream_t stream)
+{
+  if (a.batch > 0x7FFFFFFFll) return hipErrorInvalidValue;
+  constexpr int D = kEkfMaxDim;
+  const int buf    = std::max(dof * dof, dof * ny);
+  const size_t lds = (size_t)(6 * buf + D * D + D * (D + 1) / 2 + 2 * D + D / 2 + 1 + dof * dof) * sizeof(double);
+  hipLaunchKernelGGL(ekf_generic_kernel, dim3((unsigned)a.batch), dim3(kWave), lds, stream, a, dof, ny, mode, update ? 1 : 0);
+  return hipGetLastError();
+}
+
+static bool ekf_fast(int dof, int ny, bool update)
+{
+  const bool nok = dof == 2 || dof == 3 || dof == 4 || dof == 6;
+  return update ? (nok && ny >= 1 && ny <= 3) : nok;
+}
+
 hipError_t ekf_rk4_launch(const EkfArgs &a, int dof, hipStream_t stream)
 {
   const dim3 grid((unsigned)((a.batch + kWave - 1) / kWave)), block(kWave);
@@ -484,7 +641,7 @@ hipError_t ekf_rk4_launch(const EkfArgs &a, int dof, hipStream_t stream)
     case 3: hipLaunchKernelGGL((ekf_rk4_kernel<3>), grid, block, 0, stream, a); break;
     case 4: hipLaunchKernelGGL((ekf_rk4_kernel<4>), grid, block, 0, stream, a); break;
     case 6: hipLaunchKernelGGL((ekf_rk4_kernel<6>), grid, block, 0, stream, a); break;
-    default: return hipErrorInvalidValue;
+    default: return ekf_generic_launch(a, dof, 1, 2, false, stream);
   }
   return hipGetLastError();
 }
@@ -501,14 +658,13 @@ static hipError_t launch_nm(const EkfArgs &a, bool predict, bool update, hipStre
 
 bool ekf_supported(int dof, int ny, bool update)
 {
-  const bool nok = dof == 2 || dof == 3 || dof == 4 || dof == 6;
-  if (!update) return nok;
-  return nok && ny >= 1 && ny <= 3;
+  return dof >= 1 && dof <= kEkfMaxDim && (!update || (ny >= 1 && ny <= kEkfMaxDim));
 }
 
 hipError_t ekf_launch(const EkfArgs &a, int dof, int ny, bool predict, bool update, hipStream_t stream)
 {
   if (!update) ny = 1;
+  if (!ekf_fast(dof, ny, update)) return ekf_generic_launch(a, dof, ny, predict ? 1 : 0, update, stream);
 #define SFB_EKF_CASE(N, M) \
   if (dof == N && ny == M) return launch_nm<N, M>(a, predict, update, stream);
   SFB_EKF_CASE(2, 1) SFB_EKF_CASE(2, 2) SFB_EKF_CASE(2, 3)

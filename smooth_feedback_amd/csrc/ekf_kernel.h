@@ -11,6 +11,8 @@ struct EkfArgs {
   // predict
   const double *A, *Q, *dt;
   int q_shared, dt_shared;
+  // runge_kutta4 predict only: the linearisation at the stage times t + dt/2 and t + dt (nullptr: A at all stages)
+  const double *A_mid, *A_end;
   // update
   const double *H, *R, *r;
   int r_shared;
@@ -20,6 +22,9 @@ struct EkfArgs {
   double *P;
 };
 
+// largest dof / ny of the generic kernel (one filter per wavefront, matrices in LDS); the register-resident
+// one-filter-per-lane kernels cover dof in {2,3,4,6} x ny in {1,2,3}
+constexpr int kEkfMaxDim = 16;
 bool ekf_supported(int dof, int ny, bool update);
 hipError_t ekf_launch(const EkfArgs &a, int dof, int ny, bool predict, bool update, hipStream_t stream);
 // predict with one runge_kutta4 step instead of one Euler step (uses A, Q, dt, P of the arguments)

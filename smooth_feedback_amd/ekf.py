@@ -53,13 +53,22 @@ def ekf_step_batch_host(P, dof, A=None, Q=None, dt=None, H=None, R=None, r=None)
 STEPPERS = {"euler": 0, "rk4": 1}  # sfb_ekf_stepper
 
 
-def ekf_predict_batch_host(P, dof, A, Q, dt, stepper="euler"):
+def ekf_predict_batch_host(P, dof, A, Q, dt, stepper="euler", A_mid=None, A_end=None):
     """One predict step on host buffers with the chosen stepper (sfb_ekf_predict_stepper_batch_host):
-    "euler" (ekf.hpp:30 default) or "rk4" (odeint runge_kutta4, tests/test_ekf.cpp:113-115).  Returns P_new."""
+    "euler" (ekf.hpp:30 default) or "rk4" (odeint runge_kutta4, tests/test_ekf.cpp:113-115).  A_mid / A_end (rk4):
+    the linearisation at t + dt/2 and t + dt for dynamics that depend on t (sfb_ekf_predict_rk4_batch_host).
+    Returns P_new."""
     P = np.array(P, dtype=np.float64, order="C")
     B, nn = P.shape[0], dof * dof
     A, _ = _mat(A, B, nn); Q, qs = _mat(Q, B, nn, True)
     dt = np.ascontiguousarray(np.atleast_1d(dt), dtype=np.float64)
+    if A_mid is not None:
+        if stepper != "rk4":
+            raise ValueError("A_mid / A_end are runge_kutta4 stage matrices")
+        A_mid, _ = _mat(A_mid, B, nn); A_end, _ = _mat(A_end, B, nn)
+        _capi.check(_capi.lib.sfb_ekf_predict_rk4_batch_host(B, dof, _ptr(A), _ptr(A_mid), _ptr(A_end), _ptr(Q), qs, _ptr(dt),
+                                                             int(dt.size == 1), _ptr(P)))
+        return P
     _capi.check(_capi.lib.sfb_ekf_predict_stepper_batch_host(STEPPERS[stepper], B, dof, _ptr(A), _ptr(Q), qs, _ptr(dt),
                                                              int(dt.size == 1), _ptr(P)))
     return P

@@ -57,8 +57,80 @@ def test_update_linear_identities_on_device(sfb):
 
 def test_unsupported_sizes_fail_loudly(sfb):
     with pytest.raises(sfb._capi.SfbError) as e:
-        sfb.ekf_step_batch_host(np.zeros((4, 100)), 10, H=np.zeros((4, 30)), R=np.zeros((4, 9)), r=np.zeros((4, 3)))
+        sfb.ekf_step_batch_host(np.zeros((4, 17 * 17)), 17, H=np.zeros((4, 51)), R=np.zeros((4, 9)), r=np.zeros((4, 3)))
     assert e.value.status == sfb._capi.SFB_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("dof,ny", [(10, 3), (3, 10), (9, 1), (5, 5), (1, 1), (16, 16), (7, 2), (6, 4)])
+@pytest.mark.parametrize("B", [1, 130])
+def test_generic_sizes_match_oracle(sfb, oracle, dof, ny, B):
+    """The sizes outside the register-resident kernels run one filter per wavefront with the matrices in LDS --
+    among them the ones the reference's own tests instantiate: test_update_linear<10,3>, <3,10>
+    (tests/test_ekf.cpp:93-103) and test_predict_linear<9> (:148-153).  Bit-identical to the oracle: Euler and
+    runge_kutta4 predict, update, fused predict + update, shared and per-item Q / R / dt."""
+    rng = np.random.default_rng(dof * 1000 + ny * 10 + B)
+    P = _flat(_spd(rng, B, dof)); A = _flat(rng.uniform(-1, 1, (B, dof, dof)))
+    Q = _flat(0.1 * np.tile(np.eye(dof), (B, 1, 1)) + 0.01 * rng.uniform(-1, 1, (B, dof, dof)))
+    dt = rng.uniform(0.01, 0.05, B)
+    H = _flat(rng.uniform(-1, 1, (B, ny, dof))); R = _flat(0.1 * np.tile(np.eye(ny), (B, 1, 1)) + 0.01 * _spd(rng, B, ny))
+    r = rng.uniform(-1, 1, (B, ny))
+    P1, _, _ = sfb.ekf_step_batch_host(P, dof, A=A, Q=Q, dt=dt)
+    ref1 = oracle.ekf_predict_batch(A, Q, dt, P)
+    assert np.array_equal(P1, ref1)
+    P2, d2, i2 = sfb.ekf_step_batch_host(P1, dof, H=H, R=R, r=r)
+    ref2, dref, iref = oracle.ekf_update_batch(H, R, r, ref1, dof)
+    assert np.array_equal(i2, iref) and np.array_equal(P2, ref2) and np.array_equal(d2, dref)
+    Qs, Rs = Q[0].copy(), R[0].copy()
+    P3, d3, i3 = sfb.ekf_step_batch_host(P, dof, A=A, Q=Qs, dt=0.025, H=H, R=Rs, r=r)
+    refp = oracle.ekf_predict_batch(A, Qs, 0.025, P)
+    ref3, dref3, _ = oracle.ekf_update_batch(H, Rs, r, refp, dof)
+    assert np.array_equal(P3, ref3) and np.array_equal(d3, dref3) and (i3 == 0).all()
+    got = sfb.ekf_predict_batch_host(P, dof, A, Q, dt, stepper="rk4")
+    assert np.array_equal(got, oracle.ekf_predict_batch(A, Q, dt, P, stepper="rk4"))
+
+
+def test_update_linear_identities_reference_sizes(sfb):
+    """tests/test_ekf.cpp:93-103: test_update_linear<3,3>, <10,3>, <3,10> -- the textbook linear Kalman update
+    through the device path, tolerance 1e-6 as in the reference."""
+    rng = np.random.default_rng(5)
+    for Nx, Ny in ((3, 3), (10, 3), (3, 10)):
+        B = 10
+        P = np.stack([np.diag(rng.uniform(-1, 1, Nx) + 1.1) for _ in range(B)])
+        H = rng.uniform(-1, 1, (B, Ny, Nx)); R = np.stack([np.diag(rng.uniform(-1, 1, Ny) + 1.1) for _ in range(B)])
+        r = rng.uniform(-1, 1, (B, Ny))
+        Pn, delta, info = sfb.ekf_step_batch_host(_flat(P), Nx, H=_flat(H), R=_flat(R), r=r)
+        S = H @ P @ H.transpose(0, 2, 1) + R
+        K = P @ H.transpose(0, 2, 1) @ np.linalg.inv(S)
+        assert np.allclose(delta, np.einsum("bij,bj->bi", K, r), rtol=1e-6, atol=1e-10)
+        assert np.allclose(Pn.reshape(B, Nx, Nx).transpose(0, 2, 1), (np.eye(Nx)[None] - K @ H) @ P, rtol=1e-6, atol=1e-10)
+
+
+@pytest.mark.parametrize("dof", [3, 6, 9])
+def test_rk4_with_stage_linearisations(sfb, oracle, dof):
+    """Dynamics that depend on t explicitly: the reference's cov_ode re-linearises at every runge_kutta4 stage time
+    (ekf.hpp:84-89), so the step takes A(t), A(t + dt/2), A(t + dt).  Bit-identical to the oracle; equal to the
+    single-A step when the three coincide; and for dP/dt = A(t) P + P A(t)' with A(t) = a(t) A0 (commuting) the
+    step reproduces expm(s A0) P expm(s A0)', s = int a, to RK4 accuracy -- which the frozen-A step does not."""
+    import scipy.linalg as sl
+    rng = np.random.default_rng(40 + dof)
+    B = 70
+    P = _flat(_spd(rng, B, dof)); Q = np.zeros(dof * dof)
+    A0 = rng.uniform(-1, 1, (B, dof, dof))
+    t0, h = 0.3, 0.05
+    a = lambda t: 1.0 + 4.0 * t
+    A, Am, Ae = _flat(a(t0) * A0), _flat(a(t0 + h / 2) * A0), _flat(a(t0 + h) * A0)
+    got = sfb.ekf_predict_batch_host(P, dof, A, Q, h, stepper="rk4", A_mid=Am, A_end=Ae)
+    ref = oracle.ekf_predict_batch(A, Q, h, P, stepper="rk4", A_mid=Am, A_end=Ae)
+    assert np.array_equal(got, ref)
+    same = sfb.ekf_predict_batch_host(P, dof, A, Q, h, stepper="rk4", A_mid=A, A_end=A)
+    assert np.array_equal(same, sfb.ekf_predict_batch_host(P, dof, A, Q, h, stepper="rk4"))
+    s_int = h * (1.0 + 4.0 * (t0 + h / 2))
+    frozen = sfb.ekf_predict_batch_host(P, dof, A, Q, h, stepper="rk4")
+    Pm = P.reshape(B, dof, dof).transpose(0, 2, 1)
+    exact = np.stack([sl.expm(s_int * A0[b]) @ Pm[b] @ sl.expm(s_int * A0[b]).T for b in range(B)])
+    err_tv = np.abs(got.reshape(B, dof, dof).transpose(0, 2, 1) - exact).max()
+    err_fr = np.abs(frozen.reshape(B, dof, dof).transpose(0, 2, 1) - exact).max()
+    assert err_tv < 2e-3 and err_fr > 20 * err_tv, (err_tv, err_fr)
 
 
 def test_full_size_properties(sfb, oracle):
@@ -109,7 +181,7 @@ def test_cpp_front_mirrors_reference_ekf_checks(sfb):
     assert err[0] < 1e-12 and err[1] < 1e-6 and err[2] < 1e-12, err
 
 
-@pytest.mark.parametrize("dof", [2, 3, 4, 6])
+@pytest.mark.parametrize("dof", [2, 3, 4, 6, 9])
 @pytest.mark.parametrize("B", [1, 65, 3000])
 def test_rk4_predict_matches_oracle(sfb, oracle, dof, B):
     """sfb_ekf_predict_stepper_batch(SFB_EKF_RK4): same bits as the oracle's runge_kutta4 step, per-item and
@@ -142,5 +214,10 @@ def test_cpp_front_predict_linear_with_rk4(sfb):
     cm = lambda a: np.ascontiguousarray(a.flatten("F"))
     bufs = [cm(A3), cm(F3), cm(A6), cm(F6)]
     rc = M.lib().sfbx_test_ekf_predict_linear(*[b.ctypes.data_as(C.c_void_p) for b in bufs], err.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    assert err[0] < 1e-6 and err[1] < 1e-6, err
+    A9 = rng.uniform(-1, 1, (9, 9))       # test_predict_linear<9> (:152): beyond the register-resident kernels
+    bufs = [cm(A9), cm(sl.expm(0.7 * A9))]
+    rc = M.lib().sfbx_test_ekf_predict_linear9(*[b.ctypes.data_as(C.c_void_p) for b in bufs], err.ctypes.data_as(C.c_void_p))
     assert rc == 0
     assert err[0] < 1e-6 and err[1] < 1e-6, err

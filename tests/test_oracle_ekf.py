@@ -82,3 +82,25 @@ def test_rk4_step_matches_a_numpy_transcription(oracle):
     ref = P + dt / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
     got = oracle.ekf_predict_batch(A.flatten("F")[None], Q.flatten("F")[None], dt, P.flatten("F")[None], stepper="rk4")
     assert np.allclose(got[0].reshape(n, n, order="F"), ref, rtol=1e-13, atol=1e-13)
+
+
+def test_rk4_with_stage_linearisations_oracle(oracle):
+    """oracle_ekf_predict_rk4_tv: A at the stage times (cov_ode re-linearises f(t_stage, .), ekf.hpp:84-89).  For
+    A(t) = a(t) A0 the exact propagation is expm(s A0) P expm(s A0)' with s = int a dt; the stage-wise step is
+    fourth-order accurate, the frozen-A step only first-order in the variation of a."""
+    import scipy.linalg as sl
+    rng = np.random.default_rng(8)
+    n, t0 = 4, 0.2
+    A0 = rng.uniform(-1, 1, (n, n)); G = rng.uniform(-1, 1, (n, n)); P0 = np.eye(n) + G @ G.T / n
+    a = lambda t: 1.0 + 3.0 * t
+    errs = []
+    for h in (0.1, 0.05):
+        fl = lambda M: np.ascontiguousarray(M.flatten("F"))[None]
+        got = oracle.ekf_predict_batch(fl(a(t0) * A0), np.zeros(n * n), h, fl(P0), stepper="rk4",
+                                       A_mid=fl(a(t0 + h / 2) * A0), A_end=fl(a(t0 + h) * A0))
+        s_int = h * (1.0 + 3.0 * (t0 + h / 2))
+        exact = sl.expm(s_int * A0) @ P0 @ sl.expm(s_int * A0).T
+        errs.append(np.abs(got.reshape(n, n).T - exact).max())
+    assert errs[0] < 1e-3 and errs[1] < errs[0] / 12       # ~ h^5 per step
+    same = oracle.ekf_predict_batch(fl(A0), np.zeros(n * n), 0.05, fl(P0), stepper="rk4", A_mid=fl(A0), A_end=fl(A0))
+    assert np.array_equal(same, oracle.ekf_predict_batch(fl(A0), np.zeros(n * n), 0.05, fl(P0), stepper="rk4"))
