@@ -296,6 +296,52 @@ int sfbx_mpc_swarm_step(int variant, int K, double tf, int64_t batch, uint64_t s
   return -1;
 }
 
+int sfbx_test_ocp_to_qp_parabola(double * out)
+{
+  // tests/test_ocp_to_qp.cpp:41-107: double integrator x = (p, v), f = (v, u), Mesh<5,5> refined to two intervals
+  // (K = 10), tf = 2, linearised around xl(t) = (0.05 t^2, 0.1 t), ul = 0.1; the exact trajectory
+  // x(t) = (3 - 0.3 t + 0.05 t^2, -0.3 + 0.1 t), u = 0.1 must satisfy l <= A var <= u to 1e-8 (:105-106).
+  // Here through the MPC transcription (same collocation rows; the MPC pins x_0 where that OCP boxes x_f).
+  using X2 = Rn<2>;
+  using U1 = Rn<1>;
+  struct Dyn {
+    Vec<2> operator()(const X2 & x, const U1 & u) const { return {x.v[1], u.v[0]}; }
+  };
+  struct Cr {
+    Vec<1> operator()(const X2 &, const U1 & u) const { return {u.v[0]}; }
+  };
+  MPCParams p;
+  p.K = 10; p.tf = 2.0;
+  MPC<X2, U1, 1, Dyn, Cr, 5> mpc(Dyn{}, Cr{}, {-1.0}, {1.0}, p);
+  mpc.set_xdes([](double t) { X2 x; x.v = {0.05 * t * t, 0.1 * t}; return x; }, [](double t) { return Vec<2>{0.1 * t, 0.1}; });
+  mpc.set_udes([](double) { U1 u; u.v = {0.1}; return u; });
+  auto xtraj = [](double t) { X2 x; x.v = {3.0 - 0.3 * t + 0.05 * t * t, -0.3 + 0.1 * t}; return x; };
+  const auto & qp = mpc.qp();
+  std::vector<double> Av(qp.A_val.size()), l(qp.m), u(qp.m), var(qp.n);
+  mpc.assemble(0.0, xtraj(0.0), Av.data(), l.data(), u.data());
+  const int N = mpc.N();
+  for (int i = 0; i <= N; ++i) {
+    const auto x = xtraj(p.tf * mpc.mesh().node(i));
+    var[2 * i] = x.v[0]; var[2 * i + 1] = x.v[1];
+  }
+  for (int i = 0; i < N; ++i) var[mpc.uvar_B() + i] = 0.1;
+  // NOTE the MPC works in error coordinates around (xdes, udes): the exact trajectory enters as its deviation
+  for (int i = 0; i <= N; ++i) {
+    const double t = p.tf * mpc.mesh().node(i);
+    var[2 * i] -= 0.05 * t * t; var[2 * i + 1] -= 0.1 * t;
+  }
+  for (int i = 0; i < N; ++i) var[mpc.uvar_B() + i] -= 0.1;
+  double lo = 1e300, hi = 1e300;  // min(A var - l), min(u - A var) over all rows (dyn, cr, ce)
+  for (int r = 0; r < qp.m; ++r) {
+    double s = 0.0;
+    for (int q = qp.A_rowptr[r]; q < qp.A_rowptr[r + 1]; ++q) s += Av[q] * var[qp.A_colind[q]];
+    lo = std::min(lo, s - l[r]);
+    hi = std::min(hi, u[r] - s);
+  }
+  out[0] = lo; out[1] = hi; out[2] = (double)N; out[3] = (double)qp.n; out[4] = (double)qp.m; out[5] = (double)mpc.mesh().N_ivals();
+  return 0;
+}
+
 int sfbx_test_mpc_se2(double * u_out, int32_t * codes, int32_t * traj_sizes)
 {
   // tests/test_mpc.cpp:34-58,77-117

@@ -23,6 +23,9 @@ int sfbx_mpc_assemble_batch(int variant, int K, double tf, int64_t batch, uint64
 /* Closed loop of tests/test_mpc.cpp:34-117 (SE2 state, R2 input, f = (u0, 0, u1), -1 <= u <= 1):
  * three consecutive MPC calls with warm start, then three without. u_out[6][2], codes[6]. Needs a GPU. */
 int sfbx_test_mpc_se2(double *u_out, int32_t *codes, int32_t *traj_sizes);
+/* tests/test_ocp_to_qp.cpp:41-107 through the MPC transcription (double integrator, two intervals of 5 LGR nodes, tf = 2):
+ * out = {min(A var - l), min(u - A var), N, n, m, intervals} for the exact parabola trajectory.  Host only (no GPU). */
+int sfbx_test_ocp_to_qp_parabola(double *out);
 /* Swarm tick through MPCSwarm (host assembly + one batched GPU solve): returns u0 [batch][2], codes. */
 int sfbx_mpc_swarm_step(int variant, int K, double tf, int64_t batch, uint64_t seed, int ticks, double *u0,
                         int32_t *codes, uint32_t *iters);

@@ -124,3 +124,16 @@ def test_transcription_values_match_numpy_restatement():
         assert np.allclose(Ad, A, atol=1e-12), np.abs(Ad - A).max()
         assert np.allclose(l[b], lo, atol=1e-12) and np.allclose(u[b], hi, atol=1e-12)
         assert np.abs(e).max() <= 0.5 + 0.3      # the perturbation really is U(-0.5, 0.5)^6 (log of a nearby element)
+
+
+def test_exact_parabola_satisfies_the_transcription():
+    """The reference's only numeric pin on ocp_to_qp (tests/test_ocp_to_qp.cpp:84-106): for the double integrator on
+    Mesh<5,5> refined to two intervals, tf = 2, linearised around xl(t) = (0.05 t^2, 0.1 t), ul = 0.1, the exact
+    trajectory x(t) = (3 - 0.3 t + 0.05 t^2, -0.3 + 0.1 t), u = 0.1 satisfies l <= A var <= u to 1e-8: LGR
+    collocation differentiates a quadratic exactly.  Same rows through the C++ MPC front (error coordinates)."""
+    import ctypes as C
+    out = np.zeros(6)
+    assert M.lib().sfbx_test_ocp_to_qp_parabola(out.ctypes.data_as(C.c_void_p)) == 0
+    lo, hi, N, n, m, nivals = out
+    assert (N, nivals) == (10, 2) and n == 2 * 11 + 10 and m == 2 * 10 + 10 + 2
+    assert lo >= -1e-8 and hi >= -1e-8, (lo, hi)
