@@ -487,6 +487,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    gather_check = None
+    if world > 1:  # the gathered rows: this rank's own came back unchanged, every peer sent something
+        own = wl.small_outputs()
+        gather_check = {"own_rows_intact": bool(torch.equal(gathered[rank], own)),
+                        "peer_rows_received": all(bool((gathered[r] != 0).any()) for r in range(world) if r != rank)}
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -513,6 +518,8 @@ def main():
                        "parallelism": "batch-sharded x%d, one gather of the small per-item outputs (u0 / code / iter)" % world},
             "roofline": roofline_of(args.workload, wl, kern_ms, world == 1),
         }
+        if gather_check is not None:
+            rec["gather_check"] = gather_check
         if hasattr(wl, "extra"):
             rec["workload_stats"] = wl.extra()
             ws = rec["workload_stats"]

@@ -16,7 +16,12 @@
  *   - `*_batch_host` functions take HOST pointers, stage through device memory and are synchronous;
  *   - all floating point data is IEEE fp64; batch items are contiguous, batch-major;
  *   - there is NO CPU fallback: without a usable HIP device every compute call fails with
- *     SFB_ERR_NO_DEVICE.
+ *     SFB_ERR_NO_DEVICE;
+ *   - DEVICES: every call works on the calling thread's CURRENT HIP device (hipSetDevice); the library never
+ *     switches devices.  Several GPUs = one process (or one thread with its own current device) per GPU, each
+ *     with its own plans' device copies, workspaces and streams -- items are independent, so a batch is sharded
+ *     by slicing the arrays (bench.py --gpus N: one rank per GPU, one gather of the small outputs).  Objects
+ *     that own device memory (sfb_mpc_swarm) remember their device and refuse calls from another one.
  */
 #ifndef SFB_H
 #define SFB_H

@@ -433,9 +433,11 @@ private:
       for (int c = 0; c < Nx; ++c)
         for (int r = 0; r < Nx; ++r)
           if (w.Q(r, c) != 0) add(i * Nx + r, i * Nx + c, sc * w.Q(r, c));
+      // (the reference guards the R entries with Q(r, c) != 0, mpc.hpp:219-223: kept for bit parity of the pattern;
+      //  where Q has no such entry -- Nu > Nx -- the R entry is kept instead of reading out of range)
       for (int c = 0; c < Nu; ++c)
         for (int r = 0; r < Nu; ++r)
-          if (w.Q(r, c) != 0) add(uvar_B() + i * Nu + r, uvar_B() + i * Nu + c, sc * w.R(r, c));
+          if (r >= Nx || c >= Nx || w.Q(r, c) != 0) add(uvar_B() + i * Nu + r, uvar_B() + i * Nu + c, sc * w.R(r, c));
     }
     for (int c = 0; c < Nx; ++c)
       for (int r = 0; r < Nx; ++r)

@@ -147,6 +147,11 @@ sfb_status dense_via_sparse(const sfb_qp_params *prm, int64_t batch, int n, int 
   }
   double *Ax = reinterpret_cast<double *>(buf);
   hipLaunchKernelGGL(dense_A_to_rows_kernel, dim3((unsigned)batch), dim3(64), 0, stream, A, Ax, n, m);
+  if ((e = hipGetLastError()) != hipSuccess) {
+    if (async_alloc) (void)hipFreeAsync(buf, stream);
+    else (void)hipFree(buf);
+    return hip_fail(e, "dense_A_to_rows_kernel launch");
+  }
   st = sfb_sparse_qp_solve_batch(plan, prm, batch, P, q, Ax, l, u, wx, wy, x, y, obj, iter, code, buf + abytes, stream);
   if (async_alloc) {
     (void)hipFreeAsync(buf, stream);
@@ -232,10 +237,28 @@ sfb_status sfb_qp_dense_solve_batch_host(const sfb_qp_params *prm, int64_t batch
   const size_t B = (size_t)batch, N = (size_t)n, M = (size_t)m;
   const size_t in_d  = B * (N * N + N + M * N + 2 * M) + (warm_x ? B * (N + M) : 0);
   const size_t out_d = B * (N + M + 1);
-  char *dev          = nullptr;
+  // Staging memory of the host-pointer entry point, kept per device between calls (grow-only): ASIFilter solves ONE
+  // small QP per tick through here, and a hipMalloc / hipFree pair per call would dominate its latency.  Host-pointer
+  // calls are serialised by the lock (they are synchronous anyway).
+  static std::mutex stage_mu;
+  static std::map<int, std::pair<char *, size_t>> stage;
   const size_t bytes = (in_d + out_d) * sizeof(double) + B * (sizeof(uint32_t) + sizeof(int32_t));
-  hipError_t e       = hipMalloc(reinterpret_cast<void **>(&dev), bytes);
-  if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+  int devid          = 0;
+  hipError_t e       = hipGetDevice(&devid);
+  if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+  std::lock_guard<std::mutex> stage_lock(stage_mu);
+  auto &cache = stage[devid];
+  if (cache.second < bytes) {
+    if (cache.first) (void)hipFree(cache.first);
+    cache = {nullptr, 0};
+    e     = hipMalloc(reinterpret_cast<void **>(&cache.first), bytes);
+    if (e != hipSuccess) {
+      cache = {nullptr, 0};
+      return hip_fail(e, "hipMalloc");
+    }
+    cache.second = bytes;
+  }
+  char *dev = cache.first;
 
   double *dP = reinterpret_cast<double *>(dev);
   double *dq = dP + B * N * N;
@@ -278,7 +301,6 @@ sfb_status sfb_qp_dense_solve_batch_host(const sfb_qp_params *prm, int64_t batch
     if ((e = D2H(code, dcode, B * 4)) != hipSuccess) break;
   } while (false);
   if (e != hipSuccess) st = hip_fail(e, "sfb_qp_dense_solve_batch_host");
-  (void)hipFree(dev);
   return st;
 }
 

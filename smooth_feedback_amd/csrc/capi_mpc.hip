@@ -276,9 +276,22 @@ void sfb_mpc_swarm_destroy(sfb_mpc_swarm *swarm)
   delete swarm;
 }
 
+namespace {
+// the swarm's memory lives on the device that was current when it was created
+sfb_status check_swarm_device(const sfb_mpc_swarm *S)
+{
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return sfb::hip_fail(e, "hipGetDevice");
+  if (dev != S->devid) return sfb::fail(SFB_ERR_INVALID_ARG, "swarm was created on another HIP device than the current one");
+  return SFB_OK;
+}
+}  // namespace
+
 sfb_status sfb_mpc_swarm_reset_warmstart(sfb_mpc_swarm *S)
 {
   if (!S) return sfb::fail(SFB_ERR_INVALID_ARG, "swarm is NULL");
+  if (sfb_status sd = check_swarm_device(S); sd != SFB_OK) return sd;
   std::lock_guard<std::mutex> lk(S->mu);
   // an all-zero warm start IS the cold start of qp_solver.hpp:436-445 (x = y = 0 and z = A x = 0)
   hipError_t e = hipMemset(S->wx, 0, (size_t)S->agents * ((size_t)S->n + S->m) * 8);
@@ -293,6 +306,7 @@ sfb_status sfb_mpc_swarm_step_host(sfb_mpc_swarm *S, const sfb_qp_params *prm, c
 {
   if (!S) return sfb::fail(SFB_ERR_INVALID_ARG, "swarm is NULL");
   if (!prm || !records || !du0 || !code) return sfb::fail(SFB_ERR_INVALID_ARG, "NULL params / records / output pointer");
+  if (sfb_status sd = check_swarm_device(S); sd != SFB_OK) return sd;
   std::lock_guard<std::mutex> lk(S->mu);
   const size_t B = (size_t)S->agents;
   const sfb::MpcAsmParams &p = shared_jac ? S->rec_shared : S->rec_own;

@@ -493,11 +493,14 @@ __global__ void __launch_bounds__(64, 2) qp_dense4_iterate_kernel(const DenseKer
   const bool aligned   = sci >= 2;  // iter % sci == 1 never holds for sci <= 1 (:465)
   uint32_t phase       = 0;         // iteration index of every running slot, mod sci
   // Queue (zeroed by the launcher).  FRESH QPs are handed out in index order by a ticket counter; SUSPENDED ones
-  // go through a ring: push j writes (j+1) << 32 | id+1 into ring[j % batch] (after the previous user of that
+  // go through a ring of ring_n = 2 * batch entries: push j writes (j+1) << 32 | id+1 into ring[j % ring_n] (after the previous user of that
   // entry has cleared it), pop ticket t -- also a plain atomicAdd, wait-free -- may be ahead of the pushes: the
   // slot then keeps its ticket and polls its ring entry at the following refill points.
   unsigned *const q_fresh = queue, *const q_rhead = queue + 16, *const q_tail = queue + 32, *const q_done = queue + 48;
   unsigned long long *const ring = reinterpret_cast<unsigned long long *>(queue + 64);
+  // (twice the number of QPs: a push can then never land on the entry of a ticket its own wave still holds --
+  //  entries are only cleared by the holder of their ticket, which with batch entries could make a wave wait for itself)
+  const unsigned ring_n = 2u * batch;
   constexpr unsigned kNone = 0xFFFFFFFFu;
   uint32_t it0[kSlots];    // iteration count at which the slot took its QP
   unsigned pend[kSlots];   // ring ticket the (empty) slot is waiting for
@@ -547,7 +550,7 @@ __global__ void __launch_bounds__(64, 2) qp_dense4_iterate_kernel(const DenseKer
     __threadfence();  // the record is complete (device scope) before the id can be popped
     if (lane == 0) {
       const unsigned j           = atomicAdd(q_tail, 1u);
-      unsigned long long *slot   = ring + (j % batch);
+      unsigned long long *slot   = ring + (j % ring_n);
       const unsigned long long v = ((unsigned long long)(j + 1u) << 32) | ((unsigned)qb[s] + 1u);
       while (atomicCAS(slot, 0ull, v) != 0ull) __builtin_amdgcn_s_sleep(1);
     }
@@ -608,11 +611,11 @@ __global__ void __launch_bounds__(64, 2) qp_dense4_iterate_kernel(const DenseKer
             }
             if (pend[s] != kNone) {
               unsigned long long e = 0;
-              if (lane == 0) e = __hip_atomic_load(ring + (pend[s] % batch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (lane == 0) e = __hip_atomic_load(ring + (pend[s] % ring_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)e);
               const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(e >> 32));
               if (hi32 == pend[s] + 1u) {  // my entry has arrived
-                if (lane == 0) __hip_atomic_store(ring + (pend[s] % batch), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(ring + (pend[s] % ring_n), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 tk[s]   = (int)(lo32 - 1u);
                 pend[s] = kNone;
                 resumed = true;
@@ -869,7 +872,7 @@ static hipError_t launch4(const DenseKernelParams &kp, int64_t batch, const QpBa
   // 8-byte entries); stream-ordered allocation (no device synchronisation in the steady state)
   const Rec4 R        = rec4_layout<NB>(kp.n, kp.m);
   const size_t rbytes = (size_t)batch * (size_t)R.size * sizeof(double);
-  const size_t qbytes = 64 * sizeof(unsigned) + (size_t)batch * sizeof(unsigned long long);
+  const size_t qbytes = 64 * sizeof(unsigned) + 2 * (size_t)batch * sizeof(unsigned long long);
   const size_t bytes  = rbytes + qbytes;
   double *wsp        = nullptr;
   bool async_alloc   = true;
@@ -882,7 +885,11 @@ static hipError_t launch4(const DenseKernelParams &kp, int64_t batch, const QpBa
   }
   unsigned *queue = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(wsp) + rbytes);
   e               = hipMemsetAsync(queue, 0, qbytes, stream);
-  if (e != hipSuccess) return e;
+  if (e != hipSuccess) {
+    if (async_alloc) (void)hipFreeAsync(wsp, stream);
+    else (void)hipFree(wsp);
+    return e;
+  }
   const dim3 block(kWave), full((unsigned)batch);
   const size_t lds1 = qp_dense_lds_bytes(kp.n, kp.m);
   hipLaunchKernelGGL((qp_dense4_setup_kernel<NB>), full, block, lds1, stream, kp, g, wsp);

@@ -33,15 +33,38 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline():
     assert d["parity_vs_oracle"]["max_abs_dx"] <= 1e-8
 
 
-def test_two_ranks_code_path():
+@pytest.mark.parametrize("workload,batch,port", [("qp_dense", 4096, 29533), ("mpc", 96, 29541), ("ekf", 70000, 29549)])
+def test_two_ranks_code_path(workload, batch, port):
+    """Every workload through the N > 1 path: per-rank shard, barrier, ONE gather of the small per-item outputs per
+    step (for mpc: u_0, code, iter sliced out of the solution), max-over-ranks timing; rank 0 checks that its own
+    rows come back from the gather unchanged and that the other rank's rows differ from a zero fill."""
     env = dict(os.environ, SFB_BENCH_SHARE_DEVICE="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2",
-                          "--workload", "qp_dense", "--batch", "4096", "--steps", "2", "--warmup", "1"],
-                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
+                          "--workload", workload, "--batch", str(batch), "--steps", "2", "--warmup", "1"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
     assert KEYS <= set(d)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
-    assert d["config"]["global_batch"] == 2 * 4096 and d["config"]["per_gpu_batch"] == 4096
-    assert d["value"] > 0 and "cpu_baseline" not in d
+    assert d["config"]["global_batch"] == 2 * batch and d["config"]["per_gpu_batch"] == batch
+    assert d["value"] > 0 and "cpu_baseline" not in d and "secondary" not in d
+    assert d["gather_check"] == {"own_rows_intact": True, "peer_rows_received": True}
+
+
+def test_default_line_carries_the_secondary_workloads():
+    """The driver's command (no flags): headline = BASELINE configs[2], plus the other two configurations under
+    `secondary`, each with its own roofline, CPU baseline and parity figures; the dense one with the FP64-VALU view."""
+    out = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1"], cwd=ROOT, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert d["config"]["workload"].startswith("mpc_qp_nx12_nu2_K50_b8192")
+    assert set(d["secondary"]) == {"qp_dense", "ekf"}
+    for k, v in d["secondary"].items():
+        assert v["value"] > 0 and {"bound", "achieved", "peak", "frac", "traffic", "kernel_ms"} <= set(v["roofline"])
+        assert "cpu_baseline" in v and "parity_vs_oracle" in v
+    assert d["secondary"]["qp_dense"]["roofline_alt"]["bound"] == "fp64_valu"
+    assert d["secondary"]["ekf"]["parity_vs_oracle"]["P_bit_identical"]
+    assert d["parity_vs_oracle"]["iter_mismatches"] == 0 and d["parity_vs_oracle"]["max_abs_dx"] == 0.0
+    assert d["cpu_baseline"]["single_core"]["cores"] == 1
