@@ -81,11 +81,16 @@ typedef struct sfb_qp_params {
  * iterations and reports SFB_QP_MAX_ITERATIONS (iter == cap) when it is hit. */
 #define SFB_QP_DEVICE_ITER_CAP 20000000
 
-/* Largest n+m the register/LDS-resident dense kernels handle (lane i owns KKT row i).  Larger dense problems
- * are accepted by the same entry points and run on the shared-pattern sparse kernel with a full pattern: same
- * ADMM, same stopping tests on the same matrix entries, but a fill-reducing elimination order without pivoting
- * instead of the pivoted dense LDL' -- results agree with the dense solver to rounding, not bit for bit. */
+/* Largest n+m the register/LDS-resident dense kernels handle (lane i owns KKT row i).  Larger dense problems are
+ * accepted by the same entry points:
+ *   n+m <= SFB_QP_DENSE_BIG_MAX_K: one QP per wavefront with the KKT matrix and its PIVOTED dense LDL'
+ *     (Eigen::LDLT<.,Upper>, qp_solver.hpp:259,:428,:462) in a per-QP HBM workspace -- same arithmetic as the
+ *     small kernels, bit-identical to the dense CPU restatement (the reference's ASIF example, n = 3, m = 203, and
+ *     test, n = 4, m = 301, are of this size);
+ *   beyond: the shared-pattern sparse kernel with a full pattern -- same ADMM and stopping tests on the same
+ *     matrix entries, but a fill-reducing elimination order without pivoting: agreement to rounding only. */
 #define SFB_QP_DENSE_MAX_K 64
+#define SFB_QP_DENSE_BIG_MAX_K 1024
 
 const char *sfb_version(void);
 /* Thread-local description of the last non-OK status returned on this thread. */
@@ -114,6 +119,7 @@ void sfb_qp_params_default(sfb_qp_params *prm);
  *   x [batch][n] primal, y [batch][m] dual, obj [batch] (nullable), iter [batch] (nullable),
  *   code [batch] (sfb_qp_status values).
  * Requires 1 <= n, 1 <= m, prm->max_time_ns < 0 (n+m > SFB_QP_DENSE_MAX_K: see there; n+m <= 19 198).
+ * Stream-ordered working memory (hipMallocAsync) is taken per call for n+m > 16.
  */
 sfb_status sfb_qp_dense_solve_batch(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P,
                                     const double *q, const double *A, const double *l, const double *u,

@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -91,7 +92,36 @@ sfb_status check_qp_args(const sfb_qp_params *prm, int64_t batch, int n, int m, 
   return SFB_OK;
 }
 
-// ---- dense problems with n+m > SFB_QP_DENSE_MAX_K: the shared-pattern sparse kernel with a FULL pattern ----
+// ---- dense problems with SFB_QP_DENSE_MAX_K < n+m <= 1024: the pivoted dense LDL' with the factor in HBM ----
+// (bit-identical to the dense oracle, i.e. to the reference's dense branch as far as that is pinned)
+sfb_status dense_big(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P, const double *q, const double *A,
+                     const double *l, const double *u, const double *wx, const double *wy, double *x, double *y, double *obj,
+                     uint32_t *iter, int32_t *code, hipStream_t stream)
+{
+  const size_t bytes = (size_t)batch * sfb::qp_dense_big_ws_doubles(n, m) * sizeof(double);
+  char *buf          = nullptr;
+  bool async_alloc   = true;
+  hipError_t e       = hipMallocAsync(reinterpret_cast<void **>(&buf), bytes, stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    async_alloc = false;
+    e           = hipMalloc(reinterpret_cast<void **>(&buf), bytes);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+  }
+  const sfb::DenseKernelParams kp = make_kernel_params(prm, n, m);
+  const sfb::QpBatch g{P, q, A, l, u, wx, wy, x, y, obj, iter, code};
+  e = sfb::qp_dense_big_launch(kp, batch, g, reinterpret_cast<double *>(buf), stream);
+  if (async_alloc) {
+    (void)hipFreeAsync(buf, stream);
+  } else {
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(buf);
+  }
+  if (e != hipSuccess) return hip_fail(e, "qp_dense_big_kernel launch");
+  return SFB_OK;
+}
+
+// ---- dense problems beyond that: the shared-pattern sparse kernel with a FULL pattern ----
 // P (n x n, column-major, all entries stored) IS the CSC value array of a full pattern, so the stopping tests
 // and the objective see the same matrix entries in the same order as the dense kernels; only A has to be
 // re-laid out by rows.  What differs from the reference's dense solver is the factorisation order (fill-reducing
@@ -213,9 +243,14 @@ sfb_status sfb_qp_dense_solve_batch(const sfb_qp_params *prm, int64_t batch, int
   st = require_device();
   if (st != SFB_OK) return st;
   if (batch == 0) return SFB_OK;
-  if (n + m > SFB_QP_DENSE_MAX_K)
+  if (n + m > SFB_QP_DENSE_MAX_K) {
+    // SFB_QP_DENSE_BIG=0 (A/B, tests): route these sizes to the un-pivoted sparse kernel as well
+    static const bool big_off = [] { const char *v = getenv("SFB_QP_DENSE_BIG"); return v && v[0] == '0'; }();
+    if (n + m <= sfb::kDenseBigMaxK && !big_off)
+      return dense_big(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code, static_cast<hipStream_t>(stream));
     return dense_via_sparse(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code,
                             static_cast<hipStream_t>(stream));
+  }
   const sfb::DenseKernelParams kp = make_kernel_params(prm, n, m);
   hipError_t e = sfb::qp_dense_launch(kp, batch, P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code,
                                       static_cast<hipStream_t>(stream));

@@ -18,12 +18,16 @@ def _oracle_solve(oracle, r, batch=False, polish=False, warm=None):
                                        nthreads=8, **kw)
 
 
-def test_filter_so3_reference_case():
-    """tests/test_asif.cpp:103-131: K = 100, nh = 3 (n = 4, m = 301) -> Optimal."""
+def test_filter_so3_reference_case(oracle):
+    """tests/test_asif.cpp:103-131: K = 100, nh = 3 (n = 4, m = 301) -> Optimal; the QP the front assembled, solved by
+    the pivoted dense LDL' kernel for n + m > 64, equals the dense oracle bit for bit."""
     r = M.test_asif(0)
     assert (r["n"], r["m"]) == (4, 301)
     assert r["code"] == 0
     assert np.all(np.isfinite(r["u"]))
+    ref = _oracle_solve(oracle, r, polish=True)
+    assert r["code"] == ref["code"][0] and r["iter"] == ref["iter"][0]
+    assert np.array_equal(r["x"], ref["x"][0]) and np.array_equal(r["y"], ref["y"][0])
 
 
 def test_vehicle_default_size_is_bit_identical_to_the_dense_oracle(oracle):
@@ -38,17 +42,15 @@ def test_vehicle_default_size_is_bit_identical_to_the_dense_oracle(oracle):
     assert r["u"][0] < 0.4 - 1e-3 and -0.2 - 1e-6 <= r["u"][0] and abs(r["u"][1]) <= 0.5 + 1e-6
 
 
-def test_vehicle_example_size_matches_the_dense_oracle(oracle):
-    """examples/mpc_asif_vehicle.cpp:105-129: K = 200 (n = 3, m = 203, polish off) goes through the sparse kernel
-    with a full pattern: a different (non-pivoted) factorisation order than the dense solver, hence tolerance."""
+def test_vehicle_example_size_is_bit_identical_to_the_dense_oracle(oracle):
+    """examples/mpc_asif_vehicle.cpp:105-129: K = 200 (n = 3, m = 203, polish off): the pivoted dense LDL' kernel for
+    n + m > 64 -- same bits as the dense oracle on the QP the front assembled."""
     r = M.test_asif(1)
     assert (r["n"], r["m"]) == (3, 203)
     ref = _oracle_solve(oracle, r)
     assert r["code"] == ref["code"][0] == 0
-    assert abs(int(r["iter"]) - int(ref["iter"][0])) <= 25
-    assert np.abs(r["x"] - ref["x"][0]).max() <= 2e-3 * (1 + np.abs(ref["x"][0]).max())   # eps_abs = eps_rel = 1e-3, no polish
-    if r["iter"] == ref["iter"][0]:
-        assert np.abs(r["x"] - ref["x"][0]).max() <= 1e-8
+    assert r["iter"] == ref["iter"][0]
+    assert np.array_equal(r["x"], ref["x"][0]) and np.array_equal(r["y"], ref["y"][0])
 
 
 @pytest.mark.parametrize("ticks", [1, 3])
