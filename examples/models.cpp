@@ -296,6 +296,95 @@ int sfbx_mpc_swarm_step(int variant, int K, double tf, int64_t batch, uint64_t s
   return -1;
 }
 
+}  // extern "C"
+
+#include <smooth/feedback/qp_solver.hpp>  // the reference's include path and namespace (forwarding header)
+
+namespace {
+// tests/test_qp.cpp:37-52 StaticProperties
+static_assert(std::is_copy_assignable_v<smooth::feedback::QPSolver<smooth::feedback::QuadraticProgram<-1, -1>>>);
+static_assert(std::is_copy_constructible_v<smooth::feedback::QPSolver<smooth::feedback::QuadraticProgram<-1, -1>>>);
+static_assert(std::is_move_assignable_v<smooth::feedback::QPSolver<smooth::feedback::QuadraticProgram<-1, -1>>>);
+static_assert(std::is_move_constructible_v<smooth::feedback::QPSolver<smooth::feedback::QuadraticProgram<-1, -1>>>);
+static_assert(std::is_copy_assignable_v<smooth::feedback::QPSolver<smooth::feedback::QuadraticProgramSparse<double>>>);
+static_assert(std::is_copy_constructible_v<smooth::feedback::QPSolver<smooth::feedback::QuadraticProgramSparse<double>>>);
+static_assert(std::is_move_assignable_v<smooth::feedback::QPSolver<smooth::feedback::QuadraticProgramSparse<double>>>);
+static_assert(std::is_move_constructible_v<smooth::feedback::QPSolver<smooth::feedback::QuadraticProgramSparse<double>>>);
+
+template<class Pbm>
+int five_copies(const Pbm & problem, double * primal_out)
+{
+  // tests/test_qp.cpp:338-372 / :374-415: a solver, its copy, a copy-assigned, a moved-to and a move-assigned one
+  const smooth::feedback::QPSolverParams test_prm{.verbose = false, .polish = true};
+  smooth::feedback::QPSolver solver1(problem, test_prm);
+  auto sol1 = solver1.solve(problem);
+  auto solver2 = solver1;
+  auto sol2    = solver2.solve(problem);
+  smooth::feedback::QPSolver<Pbm> solver3;
+  solver3   = solver1;
+  auto sol3 = solver3.solve(problem);
+  auto solver4 = std::move(solver1);
+  auto sol4    = solver4.solve(problem);
+  smooth::feedback::QPSolver<Pbm> solver5;
+  solver5   = std::move(solver2);
+  auto sol5 = solver5.solve(problem);
+  int k = 0;
+  for (const auto * s : {&sol1, &sol2, &sol3, &sol4, &sol5}) {
+    if (s->code != smooth::feedback::QPSolutionStatus::Optimal) return 10 + k;
+    for (double v : s->primal) primal_out[k++] = v;
+  }
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int sfbx_test_qp_solver_api(double * primal_dense, double * primal_sparse, double * primal_partial)
+{
+  try {
+    // TwoDimensional data of tests/test_qp.cpp:340-346
+    const double inf = std::numeric_limits<double>::infinity();
+    smooth::feedback::QuadraticProgram<2, 2> problem;
+    problem.P = {0.0100131, 0, 0, 0.01};
+    problem.q = {-0.329554, 0.536459};
+    problem.A = {-0.0639209, -0.467, -0.168, 0};  // column-major [[-0.0639209, -0.168], [-0.467, 0]]
+    problem.l = {-inf, -inf};
+    problem.u = {-0.034974, 0.46571};
+    if (int rc = five_copies(problem, primal_dense)) return rc;
+    smooth::feedback::QuadraticProgramSparse sp;  // :383-388 sparseView(): structural zeros dropped
+    sp.n = 2; sp.m = 2;
+    sp.P_colptr = {0, 1, 2}; sp.P_rowind = {0, 1}; sp.P_val = {0.0100131, 0.01};
+    sp.A_rowptr = {0, 2, 3}; sp.A_colind = {0, 1, 0}; sp.A_val = {-0.0639209, -0.168, -0.467};
+    sp.q = problem.q; sp.l = problem.l; sp.u = problem.u;
+    if (int rc = five_copies(sp, primal_sparse)) return 100 + rc;
+    // PartialDynamic (:124-147): static N, dynamic M -- P = I, q = (-4, .25), A = I, -1 <= x <= 1
+    smooth::feedback::QuadraticProgram<-1, 2> pd;
+    pd.resize(2, 2);
+    pd.P = {1, 0, 0, 1}; pd.q = {-4, 0.25}; pd.A = {1, 0, 0, 1}; pd.l = {-1, -1}; pd.u = {1, 1};
+    const auto sol = smooth::feedback::solve_qp(pd, smooth::feedback::QPSolverParams{.polish = true});
+    if (sol.code != smooth::feedback::QPSolutionStatus::Optimal) return 200;
+    primal_partial[0] = sol.primal[0]; primal_partial[1] = sol.primal[1]; primal_partial[2] = sol.objective;
+    // hot start from its own solution (:69-72)
+    const auto hs = smooth::feedback::solve_qp(pd, smooth::feedback::QPSolverParams{.polish = true}, sol);
+    if (hs.code != smooth::feedback::QPSolutionStatus::Optimal) return 201;
+    primal_partial[3] = hs.primal[0]; primal_partial[4] = hs.primal[1];
+    // a static size that does not match the data is refused
+    smooth::feedback::QuadraticProgram<3, 2> bad;
+    bad.resize(2, 2);
+    try {
+      smooth::feedback::QPSolver<decltype(bad)> s(bad);
+      return 202;
+    } catch (const std::invalid_argument &) {}
+    // the OSQP comparator's parameter mapping (compat/osqp.hpp:54-80)
+    const auto os = smooth::feedback::osqp_settings_from(smooth::feedback::QPSolverParams{.max_iter = 77, .stop_check_iter = 10});
+    if (os.max_iter != 77 || os.check_termination != 10 || os.adaptive_rho != 0 || os.scaled_termination != 0 || os.time_limit != 0.0)
+      return 203;
+    return 0;
+  } catch (const std::exception &) {
+    return -1;
+  }
+}
+
 int sfbx_test_ocp_to_qp_parabola(double * out)
 {
   // tests/test_ocp_to_qp.cpp:41-107: double integrator x = (p, v), f = (v, u), Mesh<5,5> refined to two intervals
@@ -528,7 +617,7 @@ ASIFilterParams<U2> vehicle_asif_params(int K)
   p.qp.polish       = false;
   return p;
 }
-void copy_qp(const QuadraticProgram & qp, double * P, double * q, double * A, double * l, double * u)
+void copy_qp(const QuadraticProgram<> & qp, double * P, double * q, double * A, double * l, double * u)
 {
   std::copy(qp.P.begin(), qp.P.end(), P);
   std::copy(qp.q.begin(), qp.q.end(), q);
@@ -562,7 +651,7 @@ int sfbx_test_asif(int which, double * u_out, int32_t * code, uint32_t * iter, i
                    double * A, double * l, double * u, double * x, double * y)
 {
   try {
-    auto report = [&](const QuadraticProgram & qp, const QPSolution & sol, QPSolutionStatus c) {
+    auto report = [&](const QuadraticProgram<> & qp, const QPSolution<> & sol, QPSolutionStatus c) {
       dims[0] = qp.n; dims[1] = qp.m;
       copy_qp(qp, P, q, A, l, u);
       std::copy(sol.primal.begin(), sol.primal.end(), x);

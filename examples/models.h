@@ -26,6 +26,11 @@ int sfbx_test_mpc_se2(double *u_out, int32_t *codes, int32_t *traj_sizes);
 /* tests/test_ocp_to_qp.cpp:41-107 through the MPC transcription (double integrator, two intervals of 5 LGR nodes, tf = 2):
  * out = {min(A var - l), min(u - A var), N, n, m, intervals} for the exact parabola trajectory.  Host only (no GPU). */
 int sfbx_test_ocp_to_qp_parabola(double *out);
+/* tests/test_qp.cpp StaticProperties (:37-52, static_asserts in models.cpp), SolverAPI (:338-372), SparseSolverAPI
+ * (:374-415) and PartialDynamic (:124-147) through the reference's include path <smooth/feedback/qp_solver.hpp> and
+ * namespace: primal_dense / primal_sparse [5][2] = the five solvers' primal (original, copy, copy-assigned, moved,
+ * move-assigned); primal_partial = {x0, x1, objective, hot-start x0, x1}.  Returns 0 on success.  Needs a GPU. */
+int sfbx_test_qp_solver_api(double *primal_dense, double *primal_sparse, double *primal_partial);
 /* Swarm tick through MPCSwarm (host assembly + one batched GPU solve): returns u0 [batch][2], codes. */
 int sfbx_mpc_swarm_step(int variant, int K, double tf, int64_t batch, uint64_t seed, int ticks, double *u0,
                         int32_t *codes, uint32_t *iters);

@@ -66,9 +66,12 @@ typedef struct sfb_qp_params {
   float eps_primal_inf;     /* :49                                      (1e-4f) */
   float eps_dual_inf;       /* :51                                      (1e-4f) */
   int64_t max_iter;         /* :54  optional<uint32_t>; <0 = unset      (-1)    */
-  int64_t max_time_ns;      /* :57  optional<nanoseconds>; <0 = unset   (-1).  Wall-clock limits are
-                                    nondeterministic: the device path REJECTS a set value
-                                    (SFB_ERR_UNSUPPORTED); use max_iter.                       */
+  int64_t max_time_ns;      /* :57  optional<nanoseconds>; <0 = unset   (-1).  As in the reference (:504-507) the
+                                    limit is tested at stopping checks that leave the status open, against
+                                    the time since THIS problem's solve started -- here on the device clock
+                                    (10 ns ticks), per batch item, time spent suspended in a time-sliced
+                                    launch included.  Wall-clock limits are nondeterministic by nature:
+                                    prefer max_iter for reproducible runs.                       */
   uint32_t stop_check_iter; /* :60                                      (25)    */
   int32_t polish;           /* :63                                      (1)     */
   uint32_t polish_iter;     /* :65                                      (5)     */
@@ -118,7 +121,7 @@ void sfb_qp_params_default(sfb_qp_params *prm);
  * Outputs (QPSolution, qp.hpp:95-108):
  *   x [batch][n] primal, y [batch][m] dual, obj [batch] (nullable), iter [batch] (nullable),
  *   code [batch] (sfb_qp_status values).
- * Requires 1 <= n, 1 <= m, prm->max_time_ns < 0 (n+m > SFB_QP_DENSE_MAX_K: see there; n+m <= 19 198).
+ * Requires 1 <= n, 1 <= m (n+m > SFB_QP_DENSE_MAX_K: see there; n+m <= 19 198).
  * Stream-ordered working memory (hipMallocAsync) is taken per call for n+m > 16.
  */
 sfb_status sfb_qp_dense_solve_batch(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P,

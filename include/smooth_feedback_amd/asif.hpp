@@ -70,7 +70,7 @@ struct ASIFtoQPParams {
 
 /// asif_func.hpp:78-99: M = K nh + nu_ineq + 1 rows, N = nu + 1 variables, all zero
 template<class X, class U>
-void asif_to_qp_allocate(QuadraticProgram & qp, std::size_t K, std::size_t nu_ineq, std::size_t nh)
+void asif_to_qp_allocate(QuadraticProgram<> & qp, std::size_t K, std::size_t nu_ineq, std::size_t nh)
 {
   const int M = int(K * nh + nu_ineq + 1), N = U::Dof + 1;
   qp.n = N;
@@ -103,7 +103,7 @@ Mat<NO, G::Dof> dr_fd(Fun && fun, const G & g, const Vec<NO> & f0)
 
 /// asif_func.hpp:104-199.  f(x, u) -> Tangent<X>, h(t, x) -> Vec<nh>, bu(t, x) -> U
 template<class X, class U, class F, class H, class BU>
-void asif_to_qp_update(QuadraticProgram & qp, const ASIFProblem<X, U> & pbm, const ASIFtoQPParams & prm, F && f, H && h,
+void asif_to_qp_update(QuadraticProgram<> & qp, const ASIFProblem<X, U> & pbm, const ASIFtoQPParams & prm, F && f, H && h,
                        BU && bu)
 {
   constexpr int nx = X::Dof, nu = U::Dof;
@@ -192,11 +192,11 @@ void asif_to_qp_update(QuadraticProgram & qp, const ASIFProblem<X, U> & pbm, con
 
 /// asif_func.hpp:245-260
 template<class X, class U, class F, class H, class BU>
-QuadraticProgram asif_to_qp(const ASIFProblem<X, U> & pbm, const ASIFtoQPParams & prm, F && f, H && h, BU && bu)
+QuadraticProgram<> asif_to_qp(const ASIFProblem<X, U> & pbm, const ASIFtoQPParams & prm, F && f, H && h, BU && bu)
 {
   using HVal       = std::decay_t<decltype(h(0.0, pbm.x0))>;
   constexpr int nh = int(std::tuple_size<HVal>::value);
-  QuadraticProgram qp;
+  QuadraticProgram<> qp;
   asif_to_qp_allocate<X, U>(qp, prm.K, pbm.ulim.rows, nh);
   asif_to_qp_update<X, U>(qp, pbm, prm, std::forward<F>(f), std::forward<H>(h), std::forward<BU>(bu));
   return qp;
@@ -251,7 +251,7 @@ public:
   {
     ASIFProblem<G, U> pbm{prm_.T, g, u_des, prm_.u_weight, prm_.ulim};
     asif_to_qp_update<G, U>(qp_, pbm, prm_.asif, f_, std::forward<H>(h), std::forward<BU>(bu));
-    QPSolution sol;
+    QPSolution<> sol;
     sol.primal.resize(qp_.n);
     sol.dual.resize(qp_.m);
     int32_t code = 6;
@@ -266,15 +266,15 @@ public:
     return {rplus(u_des, du), sol.code};  // :101
   }
 
-  const QuadraticProgram & qp() const { return qp_; }
-  const QPSolution & last_solution() const { return last_; }
+  const QuadraticProgram<> & qp() const { return qp_; }
+  const QPSolution<> & last_solution() const { return last_; }
 
 private:
   Dyn f_;
-  QuadraticProgram qp_;
+  QuadraticProgram<> qp_;
   ASIFilterParams<U> prm_;
-  std::optional<QPSolution> warmstart_;
-  QPSolution last_;
+  std::optional<QPSolution<>> warmstart_;
+  QPSolution<> last_;
   std::unique_ptr<detail::DenseQPBackend> backend_;
 };
 
@@ -310,7 +310,7 @@ public:
       std::vector<std::thread> th;
       for (int k = 0; k < T; ++k)
         th.emplace_back([&, k] {
-          QuadraticProgram qp = qp_;  // same layout, private values
+          QuadraticProgram<> qp = qp_;  // same layout, private values
           for (std::size_t b = B_ * k / T; b < B_ * (k + 1) / T; ++b) {
             ASIFProblem<G, U> pbm{prm_.T, g[b], u_des[b], prm_.u_weight, prm_.ulim};
             asif_to_qp_update<G, U>(
@@ -366,7 +366,7 @@ private:
   Dyn f_;
   std::size_t B_;
   ASIFilterParams<U> prm_;
-  QuadraticProgram qp_;
+  QuadraticProgram<> qp_;
   int n_ = 0, m_ = 0;
   std::unique_ptr<detail::DenseQPBackend> backend_;
   std::vector<double> P_, q_, A_, l_, u_, x_, y_, wx_, wy_;

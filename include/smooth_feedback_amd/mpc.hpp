@@ -97,7 +97,7 @@ public:
   int nvar() const { return Nx * (N() + 1) + Nu * N(); }
   int ncon() const { return Nx * N() + Ncr * N() + Nx; }
   int uvar_B() const { return Nx * (N() + 1); }
-  const QuadraticProgramSparse & qp() const { return qp_; }
+  const QuadraticProgramSparse<> & qp() const { return qp_; }
   const Mesh & mesh() const { return mesh_; }
   const MPCParams & params() const { return prm_; }
   SparseQPSolver & solver() { return *solver_; }
@@ -347,7 +347,7 @@ public:
       probe_default(t, keep);
       analyze_solver(&keep);
     }
-    const QPSolution sol = solver_->solve(qp_, warm_ ? &*warm_ : nullptr);  // :491
+    const QPSolution<> sol = solver_->solve(qp_, warm_ ? &*warm_ : nullptr);  // :491
     const int Nn = N();
     if (u_traj) {  // :494-500
       u_traj->resize(Nn);
@@ -505,9 +505,9 @@ private:
   std::function<X(double)> xdes_;
   std::function<TangentX(double)> dxdes_;
   std::function<U(double)> udes_;
-  QuadraticProgramSparse qp_;
+  QuadraticProgramSparse<> qp_;
   std::shared_ptr<SparseQPSolver> solver_;
-  std::optional<QPSolution> warm_;
+  std::optional<QPSolution<>> warm_;
 };
 
 /// A swarm of agents running the same MPC (same model, horizon and weights => same QP pattern),

@@ -1,13 +1,26 @@
-// C++ front of the QP path: same names and meaning as smooth::feedback (reference qp.hpp,
-// qp_solver.hpp), storage in plain std::vector (no Eigen here), numerics in libsfb.so (HIP).
+// C++ front of the QP path: same names, template parameters and semantics as smooth::feedback (reference qp.hpp,
+// qp_solver.hpp), storage in plain std::vector (no Eigen in this tree), numerics in libsfb.so (HIP).
+//
+//   QuadraticProgram<M, N, Scalar>       qp.hpp:31-45    M, N static or -1 (dynamic), mixed allowed
+//   QuadraticProgramSparse<Scalar>       qp.hpp:60-79    P CSC as stored, A CSR
+//   QPSolutionStatus, QPSolution<M,N,S>  qp.hpp:82-108
+//   QPSolverParams                       qp_solver.hpp:29-68
+//   QPSolver<Pbm>::{analyze, solve, sol} qp_solver.hpp:242-757   copyable and movable like the reference's
+//   solve_qp(pbm, prm, warmstart)        qp_solver.hpp:779-787
+// Scalar must be double (the device path is fp64).  include/smooth/feedback/*.hpp forward to these headers and alias
+// the namespace, so reference-style `smooth::feedback::QPSolver<...>` spellings compile against this tree.
 #pragma once
 #include <sfb.h>
 
 #include <chrono>
 #include <cstdint>
+#include <functional>
+#include <limits>
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace smooth_feedback_amd {
@@ -41,14 +54,26 @@ struct QPSolverParams {
   }
 };
 
-/// qp.hpp:31-45 (dynamic sizes; P n x n and A m x n column-major like Eigen's default)
+/// qp.hpp:31-45.  P (n x n) and A (m x n) column-major like Eigen's default; M, N >= 0 fix a size at compile time
+/// (checked against the data at solve time), -1 leaves it to n / m.
+template<int M = -1, int N = -1, class Scalar = double>
 struct QuadraticProgram {
-  int n = 0, m = 0;
+  static_assert(std::is_same_v<Scalar, double>, "the device path is fp64");
+  static constexpr int RowsAtCompileTime = M, ColsAtCompileTime = N;
+  int n = N >= 0 ? N : 0, m = M >= 0 ? M : 0;
   std::vector<double> P, q, A, l, u;
+  QuadraticProgram() { if (M >= 0 && N >= 0) resize(N, M); }
+  void resize(int n_, int m_)
+  {
+    n = n_; m = m_;
+    P.assign((size_t)n * n, 0.0); q.assign(n, 0.0); A.assign((size_t)m * n, 0.0); l.assign(m, 0.0); u.assign(m, 0.0);
+  }
 };
 
-/// qp.hpp:60-79: P CSC, A CSR
+/// qp.hpp:60-79: P CSC (Eigen::SparseMatrix default), A CSR (Eigen::RowMajor)
+template<class Scalar = double>
 struct QuadraticProgramSparse {
+  static_assert(std::is_same_v<Scalar, double>, "the device path is fp64");
   int n = 0, m = 0;
   std::vector<int32_t> P_colptr, P_rowind;
   std::vector<double> P_val;
@@ -59,6 +84,7 @@ struct QuadraticProgramSparse {
 };
 
 /// qp.hpp:95-108
+template<int M = -1, int N = -1, class Scalar = double>
 struct QPSolution {
   QPSolutionStatus code = QPSolutionStatus::Unknown;
   uint32_t iter         = 0;
@@ -71,94 +97,186 @@ inline void sfb_check(sfb_status st)
   if (st != SFB_OK) throw std::runtime_error(std::string("sfb: ") + sfb_last_error());
 }
 
-/// solve_qp for dense problems (qp_solver.hpp:779-787); n + m <= 64 runs on the dense kernels, larger problems on
-/// the sparse kernel with a full pattern (include/sfb.h, SFB_QP_DENSE_MAX_K)
-inline QPSolution solve_qp(const QuadraticProgram & pbm, const QPSolverParams & prm = {},
-                           const QPSolution * warmstart = nullptr)
-{
-  QPSolution sol;
-  sol.primal.resize(pbm.n);
-  sol.dual.resize(pbm.m);
-  int32_t code       = 6;
-  const sfb_qp_params c = prm.to_c();
-  sfb_check(sfb_qp_dense_solve_batch_host(&c, 1, pbm.n, pbm.m, pbm.P.data(), pbm.q.data(), pbm.A.data(), pbm.l.data(),
-                                          pbm.u.data(), warmstart ? warmstart->primal.data() : nullptr,
-                                          warmstart ? warmstart->dual.data() : nullptr, sol.primal.data(),
-                                          sol.dual.data(), &sol.objective, &sol.iter, &code));
-  sol.code = static_cast<QPSolutionStatus>(code);
-  return sol;
-}
+namespace detail {
+template<class T> struct is_sparse_qp : std::false_type {};
+template<class S> struct is_sparse_qp<QuadraticProgramSparse<S>> : std::true_type {};
 
-/// QPSolver<QuadraticProgramSparse>: analyze() once per pattern, solve() for batches sharing it
-/// (qp_solver.hpp:242-757, sparse instantiation).
-class SparseQPSolver {
-public:
-  SparseQPSolver() = default;
-  explicit SparseQPSolver(const QPSolverParams & prm) : prm_(prm) {}
-  SparseQPSolver(const SparseQPSolver &)             = delete;
-  SparseQPSolver & operator=(const SparseQPSolver &) = delete;
-  ~SparseQPSolver() { sfb_sparse_qp_plan_destroy(plan_); }
-
-  /// qp_solver.hpp:297-338 (+ SimplicialLDLT::analyzePattern :424)
-  /// A_keep (nullable, one byte per stored entry of A): 0 = the entry is zero in every problem solved with this
-  /// analysis (explicit zeros of dense Jacobian blocks); see sfb_sparse_qp_plan_create_pruned -- checked per item
-  /// on the device, a wrong declaration costs time, not correctness.
-  void analyze(const QuadraticProgramSparse & pbm, const int32_t * user_perm = nullptr,
-               const int32_t * stage = nullptr, const uint8_t * A_keep = nullptr)
+/// Owner of the symbolic analysis of a sparse pattern.  Copy semantics of the reference's detail::LDLTWrapper
+/// (qp_solver.hpp:209-231): a COPY starts without an analysis (it is redone at the next solve), a move takes it over.
+struct PlanHolder {
+  sfb_sparse_qp_plan * plan = nullptr;
+  PlanHolder() = default;
+  PlanHolder(const PlanHolder &) {}
+  PlanHolder(PlanHolder && o) noexcept : plan(o.plan) { o.plan = nullptr; }
+  PlanHolder & operator=(const PlanHolder & o)
   {
-    sfb_sparse_qp_plan_destroy(plan_);
-    plan_ = nullptr;
-    n_ = pbm.n; m_ = pbm.m;
-    nnzP_ = (int)pbm.P_val.size(); nnzA_ = (int)pbm.A_val.size();
-    sfb_check(sfb_sparse_qp_plan_create_pruned(pbm.n, pbm.m, pbm.P_colptr.data(), pbm.P_rowind.data(),
-                                               pbm.A_rowptr.data(), pbm.A_colind.data(), 1, user_perm, stage, A_keep,
-                                               &plan_));
+    if (this != &o) reset();
+    return *this;
   }
-  bool analyzed() const { return plan_ != nullptr; }
+  PlanHolder & operator=(PlanHolder && o) noexcept
+  {
+    if (this != &o) { reset(); plan = o.plan; o.plan = nullptr; }
+    return *this;
+  }
+  ~PlanHolder() { reset(); }
+  void reset()
+  {
+    sfb_sparse_qp_plan_destroy(plan);
+    plan = nullptr;
+  }
+};
+}  // namespace detail
+
+/// QPSolver<Pbm>, qp_solver.hpp:242-757.  Pbm = QuadraticProgram<M, N> (dense kernels) or QuadraticProgramSparse<>
+/// (analyze() = symbolic analysis once per pattern, solve() / solve_batch() for problems that share it).
+template<class Pbm>
+class QPSolver {
+public:
+  static constexpr bool sparse = detail::is_sparse_qp<Pbm>::value;
+  using Solution               = QPSolution<>;
+
+  QPSolver(const QPSolverParams & prm = {}) : prm_(prm) {}                         // :267
+  QPSolver(const Pbm & pbm, const QPSolverParams & prm = {}) : prm_(prm) { analyze(pbm); }  // :276
+  QPSolver(const QPSolver &)                = default;
+  QPSolver(QPSolver &&) noexcept            = default;
+  QPSolver & operator=(const QPSolver &)    = default;
+  QPSolver & operator=(QPSolver &&) noexcept = default;
+  ~QPSolver()                               = default;
+
+  /// :292
+  const Solution & sol() const { return sol_; }
+
+  /// :297-338.  Dense: sizes the solution.  Sparse: + SimplicialLDLT::analyzePattern (:424): KKT pattern, elimination
+  /// order, pattern of L.  user_perm / stage / A_keep: see sfb_sparse_qp_plan_create_pruned (A_keep, one byte per
+  /// stored entry of A: 0 = the entry is zero in every problem solved with this analysis -- checked per item on the
+  /// device, a wrong declaration costs time, not correctness).
+  void analyze(const Pbm & pbm, const int32_t * user_perm = nullptr, const int32_t * stage = nullptr,
+               const uint8_t * A_keep = nullptr)
+  {
+    n_ = pbm.n; m_ = pbm.m;
+    sol_.primal.assign(n_, 0.0);
+    sol_.dual.assign(m_, 0.0);
+    if constexpr (sparse) {
+      holder_.reset();
+      sfb_check(sfb_sparse_qp_plan_create_pruned(pbm.n, pbm.m, pbm.P_colptr.data(), pbm.P_rowind.data(), pbm.A_rowptr.data(),
+                                                 pbm.A_colind.data(), 1, user_perm, stage, A_keep, &holder_.plan));
+    } else {
+      (void)user_perm; (void)stage; (void)A_keep;
+      if ((Pbm::RowsAtCompileTime >= 0 && Pbm::RowsAtCompileTime != pbm.m) ||
+          (Pbm::ColsAtCompileTime >= 0 && Pbm::ColsAtCompileTime != pbm.n))
+        throw std::invalid_argument("QPSolver: problem does not have its static size");
+    }
+    analyzed_ = true;
+  }
+  bool analyzed() const
+  {
+    if constexpr (sparse) return holder_.plan != nullptr;
+    else return analyzed_;
+  }
   /// forget the analysis (the next solve analyses again)
   void reset()
   {
-    sfb_sparse_qp_plan_destroy(plan_);
-    plan_ = nullptr;
-  }
-  int64_t nnzL() const
-  {
-    int64_t v = 0;
-    sfb_sparse_qp_plan_info(plan_, nullptr, &v, nullptr);
-    return v;
+    holder_.reset();
+    analyzed_ = false;
   }
 
-  /// batched solve on host buffers: Px [B][nnzP], q [B][n], Ax [B][nnzA], l,u [B][m]
+  /// :343-344.  The returned reference is valid until the next solve (as in the reference).
+  const Solution & solve(const Pbm & pbm, std::optional<std::reference_wrapper<const Solution>> warmstart = {})
+  {
+    return solve(pbm, warmstart ? &warmstart->get() : nullptr);
+  }
+  const Solution & solve(const Pbm & pbm, const Solution * warmstart)
+  {
+    if (!analyzed() || n_ != pbm.n || m_ != pbm.m) analyze(pbm);
+    int32_t code          = 6;
+    const sfb_qp_params c = prm_.to_c();
+    const double * wx = warmstart ? warmstart->primal.data() : nullptr;
+    const double * wy = warmstart ? warmstart->dual.data() : nullptr;
+    if constexpr (sparse) {
+      sfb_check(sfb_sparse_qp_solve_batch_host(holder_.plan, &c, 1, pbm.P_val.data(), pbm.q.data(), pbm.A_val.data(),
+                                               pbm.l.data(), pbm.u.data(), wx, wy, sol_.primal.data(), sol_.dual.data(),
+                                               &sol_.objective, &sol_.iter, &code));
+    } else {
+      sfb_check(sfb_qp_dense_solve_batch_host(&c, 1, pbm.n, pbm.m, pbm.P.data(), pbm.q.data(), pbm.A.data(), pbm.l.data(),
+                                              pbm.u.data(), wx, wy, sol_.primal.data(), sol_.dual.data(), &sol_.objective,
+                                              &sol_.iter, &code));
+    }
+    sol_.code = static_cast<QPSolutionStatus>(code);
+    return sol_;
+  }
+
+  /// Batched solve on host buffers for problems sharing the analysed pattern (sparse): Px [B][nnzP], q [B][n],
+  /// Ax [B][nnzA], l, u [B][m]; dense: P [B][n*n], A [B][m*n] column-major.
   void solve_batch(int64_t B, const double * Px, const double * q, const double * Ax, const double * l, const double * u,
                    const double * warm_x, const double * warm_y, double * x, double * y, double * obj, uint32_t * iter,
                    int32_t * code)
   {
     const sfb_qp_params c = prm_.to_c();
-    sfb_check(sfb_sparse_qp_solve_batch_host(plan_, &c, B, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code));
+    if constexpr (sparse) {
+      if (!holder_.plan) throw std::logic_error("QPSolver::solve_batch: analyze() first");
+      sfb_check(sfb_sparse_qp_solve_batch_host(holder_.plan, &c, B, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code));
+    } else {
+      sfb_check(sfb_qp_dense_solve_batch_host(&c, B, n_, m_, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code));
+    }
   }
 
-  /// qp_solver.hpp:343-568 for one problem with the analysed pattern
-  QPSolution solve(const QuadraticProgramSparse & pbm, const QPSolution * warmstart = nullptr)
+  int64_t nnzL() const
   {
-    if (!plan_) analyze(pbm);
-    QPSolution sol;
-    sol.primal.resize(n_);
-    sol.dual.resize(m_);
-    int32_t code = 6;
-    solve_batch(1, pbm.P_val.data(), pbm.q.data(), pbm.A_val.data(), pbm.l.data(), pbm.u.data(),
-                warmstart ? warmstart->primal.data() : nullptr, warmstart ? warmstart->dual.data() : nullptr,
-                sol.primal.data(), sol.dual.data(), &sol.objective, &sol.iter, &code);
-    sol.code = static_cast<QPSolutionStatus>(code);
-    return sol;
+    int64_t v = 0;
+    if constexpr (sparse) sfb_sparse_qp_plan_info(holder_.plan, nullptr, &v, nullptr);
+    return v;
   }
-
   const QPSolverParams & params() const { return prm_; }
-  sfb_sparse_qp_plan * plan() { return plan_; }
+  sfb_sparse_qp_plan * plan() { return holder_.plan; }
 
 private:
   QPSolverParams prm_{};
-  sfb_sparse_qp_plan * plan_ = nullptr;
-  int n_ = 0, m_ = 0, nnzP_ = 0, nnzA_ = 0;
+  detail::PlanHolder holder_;
+  bool analyzed_ = false;
+  int n_ = 0, m_ = 0;
+  Solution sol_;
 };
+
+template<class Pbm> QPSolver(const Pbm &, const QPSolverParams &) -> QPSolver<Pbm>;
+template<class Pbm> QPSolver(const Pbm &) -> QPSolver<Pbm>;
+
+using SparseQPSolver = QPSolver<QuadraticProgramSparse<double>>;
+
+/// solve_qp, qp_solver.hpp:779-787: n + m <= 64 runs on the register / LDS-resident dense kernels, up to 1024 on the
+/// pivoted dense kernel with the factor in HBM, sparse problems on the shared-pattern kernel (include/sfb.h)
+template<class Pbm>
+QPSolution<> solve_qp(const Pbm & pbm, const QPSolverParams & prm = {},
+                      std::optional<std::reference_wrapper<const QPSolution<>>> warmstart = {})
+{
+  QPSolver<Pbm> solver(pbm, prm);
+  return solver.solve(pbm, warmstart);
+}
+template<class Pbm>
+QPSolution<> solve_qp(const Pbm & pbm, const QPSolverParams & prm, const QPSolution<> * warmstart)
+{
+  QPSolver<Pbm> solver(pbm, prm);
+  return solver.solve(pbm, warmstart);
+}
+
+/// The parameter mapping of the reference's OSQP comparator (compat/osqp.hpp:54-80): what solve_qp_osqp sets on an
+/// OSQPSettings before osqp_setup.  OSQP itself is not part of this tree; field names are OSQP's.
+struct OsqpSettingsView {
+  int verbose, scaling, check_termination, polish, polish_refine_iter, adaptive_rho, scaled_termination;
+  double sigma, alpha, rho, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf, delta, time_limit;
+  long long max_iter;
+};
+inline OsqpSettingsView osqp_settings_from(const QPSolverParams & prm)
+{
+  OsqpSettingsView s{};
+  s.verbose = prm.verbose; s.sigma = prm.sigma; s.alpha = prm.alpha; s.rho = prm.rho;
+  s.eps_abs = prm.eps_abs; s.eps_rel = prm.eps_rel; s.eps_prim_inf = prm.eps_primal_inf; s.eps_dual_inf = prm.eps_dual_inf;
+  s.scaling = prm.scaling; s.check_termination = (int)prm.stop_check_iter; s.polish = prm.polish;
+  s.polish_refine_iter = (int)prm.polish_iter; s.delta = prm.delta;
+  s.adaptive_rho       = 0;  // the reference's solver keeps rho fixed per constraint class (:68)
+  s.scaled_termination = 0;  // stopping tests on the unscaled problem
+  s.max_iter   = prm.max_iter ? (long long)*prm.max_iter : std::numeric_limits<long long>::max();
+  s.time_limit = prm.max_time ? std::chrono::duration<double>(*prm.max_time).count() : 0.0;
+  return s;
+}
 
 }  // namespace smooth_feedback_amd

@@ -27,6 +27,7 @@
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "qp_oracle.h"
 
@@ -540,6 +541,8 @@ static int sp_solve_one(const sp_shared *sh, const sp_aux *aux, const oracle_qp_
     else if (w->sy[i] * fabs(l[i] - u[i]) < 1e-5) w->rho[i] = 1e3 * rho_bar;
     else w->rho[i] = rho_bar;
   }
+  struct timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0); /* :376 */
   sp_fill_K2(w, aux, 0, NULL, w->Kval);
   if (!ldl_numeric(s, w->Kval, w->Lx, w->D, w->work)) ret_code = ORACLE_QP_UNKNOWN; /* :423-433 */
   for (int j = 0; j < k; ++j) w->Dinv[j] = 1.0 / w->D[j]; /* vectorD().cwiseInverse() :458 */
@@ -585,6 +588,12 @@ static int sp_solve_one(const sp_shared *sh, const sp_aux *aux, const oracle_qp_
       for (int j = 0; j < n; ++j) w->dx_us[j] = w->sx[j] * (w->primal[j] - w->dx_us[j]);
       for (int i = 0; i < m; ++i) w->dy_us[i] = w->sy[i] * (w->dual[i] - w->dy_us[i]) / w->c;
       ret_code = sp_check_stopping(w);
+      if (ret_code < 0 && prm->max_time_ns >= 0) { /* :504-507 */
+        struct timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        const int64_t el = (int64_t)(t1.tv_sec - t0.tv_sec) * 1000000000LL + (t1.tv_nsec - t0.tv_nsec);
+        if (el > prm->max_time_ns) ret_code = ORACLE_QP_MAX_TIME;
+      }
     }
   }
   if (ret_code == ORACLE_QP_OPTIMAL && prm->polish) (void)sp_polish(w, aux);

@@ -58,6 +58,7 @@ DenseKernelParams make_kernel_params(const sfb_qp_params *prm, int n, int m)
   kp.eps_dinf   = static_cast<double>(prm->eps_dual_inf);
   kp.delta      = static_cast<double>(prm->delta);
   kp.max_iter   = prm->max_iter < 0 ? (uint32_t)SFB_QP_DEVICE_ITER_CAP : (uint32_t)prm->max_iter;
+  kp.max_time_ns = prm->max_time_ns < 0 ? -1 : prm->max_time_ns;
   kp.stop_check_iter = prm->stop_check_iter;
   kp.polish_iter     = prm->polish_iter;
   kp.scaling         = prm->scaling ? 1 : 0;
@@ -85,8 +86,6 @@ sfb_status check_qp_args(const sfb_qp_params *prm, int64_t batch, int n, int m, 
     return fail(SFB_ERR_INVALID_ARG, "NULL problem / solution pointer");
   if ((wx == nullptr) != (wy == nullptr))
     return fail(SFB_ERR_INVALID_ARG, "warm_x and warm_y must both be given or both be NULL");
-  if (prm->max_time_ns >= 0)
-    return fail(SFB_ERR_UNSUPPORTED, "max_time is wall-clock and not supported on the device path; use max_iter");
   if (prm->max_iter > 0xFFFFFFFFll) return fail(SFB_ERR_INVALID_ARG, "max_iter exceeds uint32");
   if (batch > 0x7FFFFFFFll) return fail(SFB_ERR_UNSUPPORTED, "batch exceeds 2^31-1 per call");
   return SFB_OK;

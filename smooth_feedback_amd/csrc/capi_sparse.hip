@@ -154,8 +154,6 @@ sfb_status check_sparse_args(const sfb_sparse_qp_plan *plan, const sfb_qp_params
     return sfb::fail(SFB_ERR_INVALID_ARG, "NULL problem / solution pointer");
   if ((wx == nullptr) != (wy == nullptr))
     return sfb::fail(SFB_ERR_INVALID_ARG, "warm_x and warm_y must both be given or both be NULL");
-  if (prm->max_time_ns >= 0)
-    return sfb::fail(SFB_ERR_UNSUPPORTED, "max_time is wall-clock and not supported on the device path; use max_iter");
   if (prm->max_iter > 0xFFFFFFFFll) return sfb::fail(SFB_ERR_INVALID_ARG, "max_iter exceeds uint32");
   if (batch > 0x7FFFFFFFll) return sfb::fail(SFB_ERR_UNSUPPORTED, "batch exceeds 2^31-1 per call");
   if ((size_t)std::max(plan->host.lds_doubles, plan->pruned ? plan->full.lds_doubles : 0) * sizeof(double) > 150 * 1024)

@@ -106,6 +106,7 @@ __global__ void __launch_bounds__(64, SFB_QP_WAVES_PER_EU) qp_dense_kernel(const
 
   const QpBatch g{gP, gq, gA, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode};
   double c     = 1.0;
+  const unsigned long long t0_ticks = wall_clock64();  // (:376 takes it after scaling; setup is microseconds here)
   int ret_code = qp_setup(s, kp, n, m, b, g, lane, c);
 
   // ---- register-resident factor: Lr[j] = L(i,j) (j<i), Lc[j] = L(j,i) (j>i), d = D(i) ----
@@ -257,6 +258,7 @@ __global__ void __launch_bounds__(64, SFB_QP_WAVES_PER_EU) qp_dense_kernel(const
       }
       wave_lds_fence();
       ret_code = qp_check_stopping(s, kp, n, m, lane);
+      if (ret_code < 0 && max_time_exceeded(kp.max_time_ns, t0_ticks)) ret_code = SFB_QP_MAX_TIME;  // :504-507
       wave_lds_fence();
     }
   }
@@ -284,7 +286,7 @@ hipError_t qp_dense_launch(const DenseKernelParams &kp, int64_t batch, const dou
   const int k        = kp.n + kp.m;
   const char *env4 = getenv("SFB_QP_DENSE4");  // A/B and tests: 0 selects the one-QP-per-wave kernels
   const int dense4 = env4 ? atoi(env4) : 1;
-  if (k <= 32 && dense4) {
+  if (k <= 32 && dense4 && kp.max_time_ns < 0) {  // (a time limit is implemented by the one-QP-per-wave kernels)
     const QpBatch g{P, q, A, l, u, wx, wy, x, y, obj, iter, code};
     return qp_dense4_launch(kp, batch, g, stream);
   }

@@ -316,6 +316,7 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
   }
   wave_sync();
 
+  const unsigned long long t0_ticks = wall_clock64();  // :376
   // ---- dense KKT fill :399-404 (row-major lower triangle of the k x k array H) ----
   for (int r = 0; r < n; ++r)
     for (int cc = lane; cc <= r; cc += kWave) {
@@ -471,6 +472,7 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
         wave_sync();
       }
       ret_code = code;
+      if (ret_code < 0 && max_time_exceeded(kp.max_time_ns, t0_ticks)) ret_code = SFB_QP_MAX_TIME;  // :504-507
     }
   }
 

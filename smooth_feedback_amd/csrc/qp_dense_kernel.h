@@ -13,6 +13,7 @@ struct DenseKernelParams {
   double alpha, alpha_comp, rho_bar, sigma;
   double eps_abs, eps_rel, eps_pinf, eps_dinf, delta;
   uint32_t max_iter;  // effective bound (prm.max_iter or SFB_QP_DEVICE_ITER_CAP)
+  long long max_time_ns;  // qp_solver.hpp:504-507, < 0 = unset; measured per item on the device clock (see sfb.h)
   uint32_t stop_check_iter;
   uint32_t polish_iter;
   int scaling, polish;

@@ -1015,10 +1015,12 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
   uint32_t next_chk    = (sci >= 2) ? 1u : 0xFFFFFFFFu;
   if (lane == 0) t[k] = 0.0;  // padding slot of the packed sweeps
   const double inf = INFINITY;
+  unsigned long long t0_ticks = wall_clock64();  // start of the item's solve (:376), kept across suspensions
   if (resume) {
     c        = w.hdr[0];
     iter     = (uint32_t)w.hdr[1];
     next_chk = (uint32_t)w.hdr[2];
+    t0_ticks = (unsigned long long)w.hdr[3];
 #ifdef SFB_SP_TIMELINE
     tl0 = (unsigned long long)w.hdr[4];
     tl1 = (unsigned long long)w.hdr[5];
@@ -1321,6 +1323,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     wave_sync();
     if (chk) {
       ret_code = sp_check_stopping(pl, it, w, kp, t, lane);
+      if (ret_code < 0 && max_time_exceeded(kp.max_time_ns, t0_ticks)) ret_code = SFB_QP_MAX_TIME;  // :504-507
       wave_sync();
       lean = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_sparse_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >
              lean_waves;
@@ -1347,6 +1350,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
             w.hdr[0] = c;
             w.hdr[1] = (double)(iter + 1);
             w.hdr[2] = (double)next_chk;
+            w.hdr[3] = (double)t0_ticks;  // (exact: below 2^53 ticks of 10 ns)
 #ifdef SFB_SP_TIMELINE
             w.hdr[4] = (double)tl0;
             w.hdr[5] = (double)tl1;

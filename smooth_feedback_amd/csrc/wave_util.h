@@ -90,6 +90,13 @@ __device__ __forceinline__ void half_swap32(const double t, double &low_dup, dou
   swap_settle(low_dup, high_dup);
 }
 
+// QPSolverParams::max_time (qp_solver.hpp:504-507): the reference compares a steady clock with the time its solve
+// started, at every stopping check that leaves the status open.  Device equivalent: the constant 100 MHz wall clock.
+__device__ __forceinline__ bool max_time_exceeded(const long long max_time_ns, const unsigned long long t0_ticks)
+{
+  return max_time_ns >= 0 && (long long)((wall_clock64() - t0_ticks) * 10ull) > max_time_ns;
+}
+
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __ballot(p ? 1 : 0); }
 
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }

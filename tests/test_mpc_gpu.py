@@ -169,6 +169,23 @@ def test_time_sliced_launch_equals_one_block_per_item(sfb, oracle, grid, slice_i
         assert np.array_equal(r.iter[5:6], ref5["iter"]) and np.array_equal(r.primal[5:6], ref5["x"])
 
 
+def test_max_time_on_the_sparse_path(sfb, oracle):
+    """max_time (qp_solver.hpp:504-507) on the sparse kernel: 1 ns ends every agent at its first stopping check;
+    deterministic and equal to the oracle with the same limit.  Also through a time-sliced launch."""
+    variant, K, B = 6, 10, 40
+    d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
+    Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=4)
+    plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K))
+    Px, q = np.tile(Pv, (B, 1)), np.zeros((B, d["n"]))
+    prm = sfb.QPSolverParams(max_time=1e-9)
+    r = plan.solve_batch_host(Px, q, Av, l, u, prm)
+    op = _oracle_params(oracle, prm)
+    op.max_time_ns = 1
+    ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l, u, perm=plan.perm, forder=plan.factor_order(), params=op, nthreads=8)
+    assert np.array_equal(r.code, ref["code"]) and np.array_equal(r.iter, ref["iter"]) and np.array_equal(r.primal, ref["x"])
+    assert (r.code == 5).all() and (r.iter == 2).all()
+
+
 def test_mpc_closed_loop_like_reference_test(sfb):
     """tests/test_mpc.cpp:83-117: Optimal on consecutive calls, u1 ~ u2 ~ u3 with and without warm start,
     trajectory sizes."""

@@ -347,3 +347,40 @@ def test_sizes_beyond_the_big_dense_kernel_use_the_sparse_kernel(sfb, oracle, en
     assert same.sum() >= B // 2
     scale = 1.0 + np.abs(ref["x"][same]).max(axis=1)
     assert (np.abs(r.primal[same] - ref["x"][same]).max(axis=1) / scale).max() <= 1e-6
+
+
+def test_cpp_front_solver_api_like_the_reference(sfb):
+    """tests/test_qp.cpp StaticProperties, SolverAPI, SparseSolverAPI, PartialDynamic through the C++ front, spelled
+    with the reference's include path and namespace (<smooth/feedback/qp_solver.hpp>, smooth::feedback::QPSolver<Pbm>):
+    copies and moved-to solvers give the same primal; dense == sparse (TwoDimensional, :314-336)."""
+    import ctypes as C
+    from examples import models_lib as M
+    pd, ps, pp = np.zeros((5, 2)), np.zeros((5, 2)), np.zeros(5)
+    rc = M.lib().sfbx_test_qp_solver_api(*[a.ctypes.data_as(C.c_void_p) for a in (pd, ps, pp)])
+    assert rc == 0, rc
+    for arr in (pd, ps):
+        assert all(np.array_equal(arr[0], arr[i]) for i in range(1, 5))
+    assert is_approx(pd[0], [46.6338, -17.5351], 1e-4)         # tests/test_qp.cpp:334-335
+    assert is_approx(pd[0], ps[0], 1e-10)                      # :332-333 isApprox(dense, sparse)
+    assert is_approx(pp[:2], [1, -0.25], 1e-4) and abs(pp[2] - (0.5 - 4 - 1 / 32)) < 1e-4 and is_approx(pp[3:], [1, -0.25], 1e-4)
+
+
+@pytest.mark.parametrize("n,m", [(10, 20), (30, 30), (40, 60)])
+def test_max_time_like_the_reference(sfb, oracle, n, m):
+    """QPSolverParams::max_time (qp_solver.hpp:504-507): tested at stopping checks that leave the status open, on
+    the device clock.  A limit of 1 ns makes it deterministic: every QP ends at its first check (iteration 2) with
+    the status that check gives, else MaxTime -- same as the oracle with the same limit.  A generous limit changes
+    nothing.  (k <= 32: the one-QP-per-wave kernels take over from the four-per-wave one when a limit is set.)"""
+    B = 64
+    P, q, A, l, u = sfb.random_qp_batch(77 + n, B, m, n, 0.8)
+    prm = sfb.QPSolverParams(max_iter=4000, max_time=1e-9)
+    r = sfb.solve_qp_batch_host(P, q, A, l, u, prm)
+    op = _oracle_params(oracle, prm)
+    op.max_time_ns = 1
+    ref = oracle.qp_dense_solve_batch(P, q, A, l, u, params=op, nthreads=8)
+    assert np.array_equal(r.code, ref["code"]) and np.array_equal(r.iter, ref["iter"])
+    assert (r.code == sfb.QPSolutionStatus.MaxTime).sum() > B // 2 and set(np.unique(r.iter)) <= {0, 2}
+    assert np.array_equal(r.primal, ref["x"], equal_nan=True)
+    base = sfb.solve_qp_batch_host(P, q, A, l, u, sfb.QPSolverParams(max_iter=4000))
+    slow = sfb.solve_qp_batch_host(P, q, A, l, u, sfb.QPSolverParams(max_iter=4000, max_time=30.0))
+    assert np.array_equal(base.code, slow.code) and np.array_equal(base.iter, slow.iter) and np.array_equal(base.primal, slow.primal, equal_nan=True)
