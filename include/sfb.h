@@ -76,7 +76,9 @@ typedef struct sfb_qp_params {
   int32_t polish;           /* :63                                      (1)     */
   uint32_t polish_iter;     /* :65                                      (5)     */
   float delta;              /* :67                                      (1e-6f) */
-  int32_t verbose;          /* :32  ignored on the device path          (0)     */
+  int32_t verbose;          /* :32  host-pointer entry points print a summary of the call (phase times,
+                                    status histogram, iteration statistics); ignored by the asynchronous
+                                    device-pointer entry points                 (0)     */
 } sfb_qp_params;
 
 /* With max_iter unset the reference loops until a stopping test fires (possibly forever, e.g.

@@ -2,6 +2,8 @@
 // needs a HIP device and fails with SFB_ERR_NO_DEVICE / SFB_ERR_HIP otherwise.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -41,6 +43,28 @@ sfb_status require_device()
   if (e != hipSuccess) return hip_fail(e, "hipGetDeviceCount");
   if (cnt <= 0) return fail(SFB_ERR_NO_DEVICE, "no HIP device visible; the sfb library has no CPU fallback");
   return SFB_OK;
+}
+
+void verbose_report(const char *what, int64_t batch, int n, int m, double h2d_ms, double solve_ms, double d2h_ms,
+                    const int32_t *code, const uint32_t *iter)
+{
+  static const char *names[7] = {"Optimal", "PolishFailed", "PrimalInfeasible", "DualInfeasible", "MaxIterations", "MaxTime", "Unknown"};
+  long long hist[7] = {0, 0, 0, 0, 0, 0, 0};
+  uint32_t imin = 0xFFFFFFFFu, imax = 0;
+  double isum = 0.0;
+  for (int64_t b = 0; b < batch; ++b) {
+    if (code[b] >= 0 && code[b] < 7) hist[code[b]]++;
+    if (iter) { imin = std::min(imin, iter[b]); imax = std::max(imax, iter[b]); isum += iter[b]; }
+  }
+  std::printf("[sfb] %s: %lld problem(s), n = %d, m = %d\n", what, (long long)batch, n, m);
+  std::printf("[sfb]   time: upload %.3f ms | solve on device (scaling, factorisation, ADMM, polish) %.3f ms | download %.3f ms\n",
+              h2d_ms, solve_ms, d2h_ms);
+  std::printf("[sfb]   status:");
+  for (int c = 0; c < 7; ++c)
+    if (hist[c]) std::printf(" %s %lld", names[c], hist[c]);
+  if (iter && batch > 0) std::printf("\n[sfb]   iterations: min %u, mean %.1f, max %u", imin, isum / (double)batch, imax);
+  std::printf("\n");
+  std::fflush(stdout);
 }
 
 DenseKernelParams make_kernel_params(const sfb_qp_params *prm, int n, int m)
@@ -315,6 +339,10 @@ sfb_status sfb_qp_dense_solve_batch_host(const sfb_qp_params *prm, int64_t batch
   auto H2D = [&](void *d, const void *h, size_t nb) { return hipMemcpy(d, h, nb, hipMemcpyHostToDevice); };
   auto D2H = [&](void *h, const void *d, size_t nb) { return hipMemcpy(h, d, nb, hipMemcpyDeviceToHost); };
   st = SFB_OK;
+  using clk = std::chrono::steady_clock;
+  auto ms   = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto tv0 = clk::now();
+  auto tv1 = tv0, tv2 = tv0;
   do {
     if ((e = H2D(dP, P, B * N * N * 8)) != hipSuccess) break;
     if ((e = H2D(dq, q, B * N * 8)) != hipSuccess) break;
@@ -325,9 +353,11 @@ sfb_status sfb_qp_dense_solve_batch_host(const sfb_qp_params *prm, int64_t batch
       if ((e = H2D(dwx, warm_x, B * N * 8)) != hipSuccess) break;
       if ((e = H2D(dwy, warm_y, B * M * 8)) != hipSuccess) break;
     }
+    tv1 = clk::now();
     st = sfb_qp_dense_solve_batch(prm, batch, n, m, dP, dq, dA, dl, du, dwx, dwy, dx, dy, dobj, dit, dcode, nullptr);
     if (st != SFB_OK) break;
     if ((e = hipDeviceSynchronize()) != hipSuccess) break;
+    tv2 = clk::now();
     if ((e = D2H(x, dx, B * N * 8)) != hipSuccess) break;
     if ((e = D2H(y, dy, B * M * 8)) != hipSuccess) break;
     if (obj && (e = D2H(obj, dobj, B * 8)) != hipSuccess) break;
@@ -335,6 +365,15 @@ sfb_status sfb_qp_dense_solve_batch_host(const sfb_qp_params *prm, int64_t batch
     if ((e = D2H(code, dcode, B * 4)) != hipSuccess) break;
   } while (false);
   if (e != hipSuccess) st = hip_fail(e, "sfb_qp_dense_solve_batch_host");
+  if (st == SFB_OK && prm->verbose) {
+    std::vector<uint32_t> itv;
+    if (!iter) {
+      itv.resize(B);
+      if (hipMemcpy(itv.data(), dit, B * 4, hipMemcpyDeviceToHost) != hipSuccess) itv.clear();
+    }
+    sfb::verbose_report("dense QP batch", batch, n, m, ms(tv0, tv1), ms(tv1, tv2), ms(tv2, clk::now()), code,
+                        iter ? iter : (itv.empty() ? nullptr : itv.data()));
+  }
   return st;
 }
 

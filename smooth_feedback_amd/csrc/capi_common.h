@@ -13,6 +13,10 @@ sfb_status fail(sfb_status st, const std::string &msg);
 sfb_status hip_fail(hipError_t e, const char *what);
 sfb_status require_device();
 DenseKernelParams make_kernel_params(const sfb_qp_params *prm, int n, int m);
+// QPSolverParams::verbose on the host-pointer entry points (qp_solver.hpp:409-420, :550-565 print a per-phase time
+// breakdown and the outcome): one summary of the call -- phase times, status histogram, iteration statistics.
+void verbose_report(const char *what, int64_t batch, int n, int m, double h2d_ms, double solve_ms, double d2h_ms,
+                    const int32_t *code, const uint32_t *iter);
 struct SparsePlanHost;
 const SparsePlanHost &plan_host(const sfb_sparse_qp_plan *plan);  // capi_sparse.hip: the pattern the kernel works on
 const SparsePlanHost &plan_io(const sfb_sparse_qp_plan *plan);    // the caller's pattern (== plan_host unless pruned)

@@ -2,6 +2,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <map>
 #include <mutex>
 #include <string>
@@ -372,6 +374,10 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
   int32_t *dcode = reinterpret_cast<int32_t *>(dit + B);
   auto H2D = [&](void *d, const void *hh, size_t nb) { return nb ? hipMemcpy(d, hh, nb, hipMemcpyHostToDevice) : hipSuccess; };
   auto D2H = [&](void *hh, const void *d, size_t nb) { return nb ? hipMemcpy(hh, d, nb, hipMemcpyDeviceToHost) : hipSuccess; };
+  using clk = std::chrono::steady_clock;
+  auto ms   = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto tv0 = clk::now();
+  auto tv1 = tv0, tv2 = tv0;
   do {
     if ((e = H2D(dPx, Px, B * NP * 8)) != hipSuccess) break;
     if ((e = H2D(dq, q, B * N * 8)) != hipSuccess) break;
@@ -382,10 +388,12 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
       if ((e = H2D(dwx, warm_x, B * N * 8)) != hipSuccess) break;
       if ((e = H2D(dwy, warm_y, B * M * 8)) != hipSuccess) break;
     }
+    tv1 = clk::now();
     st = sfb_sparse_qp_solve_batch(plan, prm, batch, dPx, dq, dAx, dl, du, dwx, dwy, dx, dy, dobj, dit, dcode, dws,
                                    nullptr);
     if (st != SFB_OK) break;
     if ((e = hipDeviceSynchronize()) != hipSuccess) break;
+    tv2 = clk::now();
     if ((e = D2H(x, dx, B * N * 8)) != hipSuccess) break;
     if ((e = D2H(y, dy, B * M * 8)) != hipSuccess) break;
     if (obj && (e = D2H(obj, dobj, B * 8)) != hipSuccess) break;
@@ -393,6 +401,17 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
     if ((e = D2H(code, dcode, B * 4)) != hipSuccess) break;
   } while (false);
   if (e != hipSuccess) st = sfb::hip_fail(e, "sfb_sparse_qp_solve_batch_host");
+  if (st == SFB_OK && prm->verbose) {
+    std::vector<uint32_t> itv;
+    if (!iter) {
+      itv.resize(B);
+      if (hipMemcpy(itv.data(), dit, B * 4, hipMemcpyDeviceToHost) != hipSuccess) itv.clear();
+    }
+    std::printf("[sfb] sparse plan: nnz(K) %d, nnz(L) %d%s\n", plan->host.nnzK, plan->host.nnzL,
+                plan->pruned ? " (explicit zeros of A left out; whole-pattern fallback per item)" : "");
+    sfb::verbose_report("sparse QP batch", batch, h.n, h.m, ms(tv0, tv1), ms(tv1, tv2), ms(tv2, clk::now()), code,
+                        iter ? iter : (itv.empty() ? nullptr : itv.data()));
+  }
   return st;
 }
 

@@ -34,6 +34,16 @@ namespace {
 constexpr int kBigMaxK = 1024;
 constexpr int kRB      = kBigMaxK / kWave;  // row blocks per lane at the largest size
 
+// The sweeps and the factorisation are real (outlined) device functions: a plain `double *` parameter is a GENERIC
+// pointer there and every access through it becomes a flat_load / flat_store (slow path into LDS, waits on both
+// counters).  Their LDS arguments are therefore re-typed to the LDS address space on entry -> ds_read / ds_write.
+using lds_d = __attribute__((address_space(3))) double;
+using lds_i = __attribute__((address_space(3))) int;
+#define LDS_D(name, arg) lds_d *const name = (lds_d *)(arg)
+#define LDS_CD(name, arg) const lds_d *const name = (const lds_d *)(arg)
+#define LDS_I(name, arg) lds_i *const name = (lds_i *)(arg)
+#define LDS_CI(name, arg) const lds_i *const name = (const lds_i *)(arg)
+
 __device__ __forceinline__ int ubig(const int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // smallest index among the lanes' candidates (cand >= 0), wave-uniform
@@ -42,13 +52,16 @@ __device__ __forceinline__ int wave_min_index(const int cand)
   return (int)(-wave_max(-(double)cand));  // exact: indices are far below 2^53
 }
 
-// Eigen 3.4 LDLT<., Upper> == oracle_ldlt_factor (oracle/qp_oracle.c:67-151) on the row-major lower triangle W
-// (leading dimension ld, K x K), in global memory.  perm[K] (LDS): composed transpositions, (P b)[i] = b[perm[i]].
+// Eigen 3.4 LDLT<., Upper> == oracle_ldlt_factor (oracle/qp_oracle.c:67-151) on the lower triangle W (K x K, leading
+// dimension ld) in global memory, stored COLUMN-major: element (i, j), i >= j, at W[j * ld + i] -- the update of column
+// kk reads, for every earlier column j, the entries of rows kk.. (lane = row): contiguous in this layout.  perm[K] (LDS): composed transpositions, (P b)[i] = b[perm[i]].
 // temp[K] (LDS) scratch.  Returns 1 on success, 0 on failure (info() == NumericalIssue).  Wave-uniform.
-__device__ inline int big_ldlt_factor(const int K, double *__restrict__ W, const int ld, int *perm, double *temp,
+__device__ inline int big_ldlt_factor(const int K, double *__restrict__ W, const int ld, int *perm_, double *temp_,
                                       const int lane)
 {
-#define WB(i, j) W[(size_t)(i) * (size_t)ld + (size_t)(j)]
+  LDS_I(perm, perm_);
+  LDS_D(temp, temp_);
+#define WB(i, j) W[(size_t)(j) * (size_t)ld + (size_t)(i)]
   for (int i = lane; i < K; i += kWave) perm[i] = i;
   wave_sync();
   if (K <= 1) return 1;
@@ -83,9 +96,8 @@ __device__ inline int big_ldlt_factor(const int K, double *__restrict__ W, const
     wave_sync();
     if (kk > 0) {
       for (int i = kk + lane; i < K; i += kWave) {  // rows kk (the diagonal) .. K-1: dot, then subtract
-        const double *row = &WB(i, 0);
-        double s          = 0.0;
-        for (int j = 0; j < kk; ++j) s = fma(row[j], temp[j], s);
+        double s = 0.0;
+        for (int j = 0; j < kk; ++j) s = fma(WB(i, j), temp[j], s);
         WB(i, kk) -= s;
       }
       wave_sync();
@@ -112,73 +124,344 @@ __device__ inline int big_ldlt_factor(const int K, double *__restrict__ W, const
 #undef WB
 }
 
-// LT(j, i) = W(i, j) for i > j (column j of L contiguous), Dg[i] = W(i, i)
-__device__ inline void big_transpose(const int K, const double *__restrict__ W, const int ld, double *__restrict__ LT,
-                                     double *__restrict__ Dg, const int lane)
+constexpr int kBW = 16;  // column block of the triangular sweeps
+constexpr int kDiagCacheK = 384;  // up to this size the diagonal blocks of L are kept in LDS (k * 16 doubles)
+// Compact on-chip copy of the OFF-diagonal part of L for factors that are almost empty (a safety filter: n = 3
+// variables, hundreds of barrier rows with a diagonal (2,2) block): per 16-column block the rows that have a
+// non-zero entry in it, each with its 16 values.  big_row_cap(k) rows in all (forward and backward lists share the
+// pool); a factor with more keeps streaming its non-zero tiles from the workspace.
+__host__ __device__ constexpr int big_row_cap(const int k) { return (k <= kDiagCacheK) ? k + 128 : 192; }
+constexpr int kBP     = 17;  // row stride of the 16-wide tiles kept in LDS (odd: lane = row reads hit distinct banks)
+
+// W(i, j) = LT(j, i) for i >= j (row i of L contiguous), Dg[i] = W(i, i), and the non-zero maps of the tiles the
+// blocked sweeps work on: fnz[jb * RB + r] != 0 iff L has a non-zero entry in rows 64 r .. 64 r + 63, columns
+// 16 jb .. 16 jb + 15 (forward sweep); bnz[jb * RB + r] the same for rows 16 jb .. + 15, columns 64 r .. + 63
+// (backward sweep).  An all-zero tile contributes exact zeros to every chain it takes part in and is skipped --
+// the KKT matrix of a safety filter (n = 3 variables, hundreds of barrier rows, a diagonal (2,2) block) leaves L
+// almost empty.
+template<int RB>
+__device__ inline void big_transpose(const int K, double *__restrict__ W, const int ld, const double *__restrict__ LT,
+                                     double *__restrict__ Dg, int *fnz_, int *bnz_, double *dblk_, double *LDg_, int *cidx_,
+                                     double *cval_, int *cflag_, const int cap, const int lane)
 {
-  for (int i = 0; i < K; ++i)
-    for (int j = lane; j < i; j += kWave) LT[(size_t)j * ld + i] = W[(size_t)i * ld + j];
+  LDS_I(fnz, fnz_);
+  LDS_I(bnz, bnz_);
+  LDS_D(dblk, dblk_);
+  LDS_D(LDg, LDg_);
+  LDS_I(cidx, cidx_);
+  LDS_D(cval, cval_);
+  LDS_I(cflag, cflag_);
+  // the factor arrives column-major in LT (column j of L contiguous: the forward sweep's layout); W gets the row-major
+  // copy with the diagonal (row i of L contiguous: the backward sweep's layout)
+  for (int j = 0; j < K; ++j)
+    for (int i = j + lane; i < K; i += kWave) W[(size_t)i * ld + j] = LT[(size_t)j * ld + i];
+  wave_sync();
+  // cidx: [0, nb] forward block offsets, [nb + 1, 2 nb + 1] backward block offsets, nb flags "the diagonal block has
+  // entries below its diagonal", then the rows of the lists (forward lists first, one pool of big_row_cap(K) rows);
+  // cval: the rows' 16 values (stride kBP); cflag[0]: the lists are complete
+  {
+    const int nbk = (K + kBW - 1) / kBW;
+    lds_i *const foff = cidx, *const boff = cidx + nbk + 1, *const dflag = boff + nbk + 1, *const rows = dflag + nbk;
+    int np = 0;
+    for (int dir = 0; dir < 2; ++dir) {
+      lds_i *const off = dir ? boff : foff;
+      for (int jb = 0; jb < nbk; ++jb) {
+        const int j0 = jb * kBW;
+        if (lane == 0) off[jb] = np;
+        const int ibeg = dir ? 0 : j0 + kBW, iend = dir ? j0 : K;
+        for (int i0 = ibeg - ibeg % kWave; i0 < iend; i0 += kWave) {
+          const int i = i0 + lane;
+          bool nz = false;
+          double v[kBW];
+#pragma unroll
+          for (int jj = 0; jj < kBW; ++jj) {
+            const int j = j0 + jj;
+            v[jj] = (i >= ibeg && i < iend && j < K) ? (dir ? W[(size_t)j * ld + i] : W[(size_t)i * ld + j]) : 0.0;
+            nz    = nz || !(v[jj] == 0.0);
+          }
+          const unsigned long long mk = wave_ballot(nz);
+          const int pp = np + __popcll(mk & lanemask_lt(lane));
+          if (nz && pp < cap) {
+            rows[pp] = i;
+#pragma unroll
+            for (int jj = 0; jj < kBW; ++jj) cval[pp * kBP + jj] = v[jj];
+          }
+          np += __popcll(mk);
+        }
+        if (dir == 0) {  // diagonal block: lane = row
+          bool nz = false;
+          const int i = j0 + (lane & (kBW - 1));
+          for (int cc = 0; cc < (lane & (kBW - 1)); ++cc) nz = nz || (i < K && !(W[(size_t)i * ld + j0 + cc] == 0.0));
+          const unsigned long long mk = wave_ballot(nz);
+          if (lane == 0) dflag[jb] = (mk != 0ull || dblk_ == nullptr) ? 1 : 0;
+        }
+      }
+      if (lane == 0) off[nbk] = np;
+    }
+    if (lane == 0) cflag[0] = (np <= cap) ? 1 : 0;
+  }
+  for (int i = lane; i < K; i += kWave) LDg[i] = W[(size_t)i * ld + i];
+  if (dblk_ != nullptr) {  // dblk[jb][r][c] = L(16 jb + r, 16 jb + c), r > c (other entries 0)
+    const int nbk = (K + kBW - 1) / kBW;
+    for (int e = lane; e < nbk * kBW * kBW; e += kWave) {
+      const int jb = e / (kBW * kBW), r = (e / kBW) % kBW, cc = e % kBW, i = jb * kBW + r, j = jb * kBW + cc;
+      dblk[(jb * kBW + r) * kBP + cc] = (r > cc && i < K) ? W[(size_t)i * ld + j] : 0.0;
+    }
+  }
   for (int i = lane; i < K; i += kWave) Dg[i] = W[(size_t)i * ld + i];
+  const int nb = (K + kBW - 1) / kBW;
+  for (int jb = 0; jb < nb; ++jb)
+    for (int r = 0; r < RB; ++r) {
+      const int i = lane + kWave * r;
+      bool nzf = false, nzb = false;
+      for (int jj = 0; jj < kBW; ++jj) {
+        const int j = jb * kBW + jj;
+        if (j < K && i < K && i > j) nzf = nzf || !(W[(size_t)i * ld + j] == 0.0);
+        if (j < K && i < j) nzb = nzb || !(W[(size_t)j * ld + i] == 0.0);
+      }
+      const unsigned long long bf = wave_ballot(nzf), bb = wave_ballot(nzb);
+      if (lane == 0) { fnz[jb * RB + r] = bf != 0ull; bnz[jb * RB + r] = bb != 0ull; }
+    }
   wave_sync();
 }
 
 // LDLT::_solve_impl == oracle_ldlt_solve: t (LDS, K entries, original order) <- P^T L^-T D^-1 L^-1 P t.
-// Forward: column j ascending pushes into rows i > j (every row sees j ascending); backward: row j descending
-// pushes into columns i < j (every entry sees j descending); |d| <= DBL_MIN -> 0, true division.
+// Per row the oracle subtracts L(i, j) t_j for j ascending (forward) / L(j, i) t_j for j descending (backward); here
+// the columns come in BLOCKS of 16: the 16 rows of the diagonal block are finished first (in registers: lane = row,
+// the pivot travels by v_readlane), then every other row takes the block's 16 updates in the same ascending
+// (descending) order -- ONE memory round trip per block instead of one per column.  |d| <= DBL_MIN -> 0, true division.
+#ifdef SFB_BIG_PROF
+__device__ unsigned long long g_bigprof[8];
+#define BP_T(x) const unsigned long long x = wall_clock64()
+#define BP_ADD(i, a, b) if (lane == 0 && blockIdx.x == 0) g_bigprof[i] += (b) - (a)
+#else
+#define BP_T(x)
+#define BP_ADD(i, a, b)
+#endif
 template<int RB>
 __device__ inline void big_solve(const int K, const double *__restrict__ W, const double *__restrict__ LT,
-                                 const double *__restrict__ Dg, const int ld, const int *perm, double *t, double *temp,
-                                 const int lane)
+                                 const double *__restrict__ Dg, const int ld, const int *perm_, const int *fnz_, const int *bnz_,
+                                 const double *dblk_, const double *LDg_, const int *cidx_, const double *cval_,
+                                 const int *cflag_, double *t_, double *temp_, const int lane)
 {
+  LDS_CI(perm, perm_);
+  LDS_CI(fnz, fnz_);
+  LDS_CI(bnz, bnz_);
+  LDS_CD(dblk, dblk_);
+  LDS_CD(LDg, LDg_);
+  LDS_CI(cidx, cidx_);
+  LDS_CD(cval, cval_);
+  LDS_CI(cflag, cflag_);
+  LDS_D(t, t_);
+  LDS_D(temp, temp_);
+  const int nbk0    = (K + kBW - 1) / kBW;
+  const bool compact = cflag[0] != 0;  // wave-uniform (LDS)
+  const lds_i *const foff = cidx, *const boff = cidx + nbk0 + 1, *const dflag = boff + nbk0 + 1, *const frow = dflag + nbk0,
+                     *const brow = frow;
+  const lds_d *const fval = cval, *const bval = cval;
+  BP_T(p0);
   for (int i = lane; i < K; i += kWave) temp[i] = t[perm[i]];
   wave_sync();
   for (int i = lane; i < K; i += kWave) t[i] = temp[i];
   wave_sync();
-  double cur[RB], nxt[RB];
-  auto load_col = [&](double (&v)[RB], const int j) {  // L(i, j), i = lane + 64 r, i > j
+  const int nb = (K + kBW - 1) / kBW;
+  BP_T(p1);
+  BP_ADD(0, p0, p1);
+  constexpr int RC = 2;  // row blocks handled per memory round trip (register budget)
+  // The hot loops are written branch-free: loads go to clamped (always valid) addresses and lanes / columns that do
+  // not take part are switched off by selects -- predicated `if`s compile to exec-mask juggling and branches that
+  // cost more than the arithmetic.  Only the wave-uniform skip of an all-zero tile is a (scalar) branch.
+  // ---- forward ----
+  for (int jb = 0; jb < nb; ++jb) {
+    const int j0 = jb * kBW, l0 = j0 % kWave, rb = j0 / kWave, nbw = (K - j0 < kBW) ? K - j0 : kBW;
+    const bool inblk = lane >= l0 && lane < l0 + nbw;
+    const int lrow   = inblk ? lane - l0 : 0, iblk = j0 + lrow;
+    double dv[kBW], tb[kBW];
+    // wave-uniform shortcuts: a diagonal block without entries below its diagonal needs no chain, a block no other
+    // row depends on needs no broadcast -- the constraint columns of a safety filter are both in the backward sweep
+    const int e0 = compact ? ubig(foff[jb]) : 0, e1 = compact ? ubig(foff[jb + 1]) : 0;
+    const bool chain = !compact || ubig(dflag[jb]) != 0;
+    if (compact && !chain && e0 == e1) continue;
+    // everything the block needs is requested up front (one LDS / memory latency, not one per column): the diagonal
+    // block, and the first 64 of the rows below it that have entries in the block
+    if (!chain) {
+    } else if (dblk_ != nullptr) {  // (lanes outside the block read its first row: empty, like the entries on and above the diagonal)
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      const int i = lane + kWave * r;
-      v[r]        = (i > j && i < K) ? LT[(size_t)j * ld + i] : 0.0;
+      for (int jj = 0; jj < kBW; ++jj) dv[jj] = dblk[(jb * kBW + lrow) * kBP + jj];
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < kBW; ++jj) {
+        const double v = LT[(size_t)(j0 + ((jj < nbw) ? jj : 0)) * ld + iblk];
+        dv[jj]         = (inblk && jj < nbw && lrow > jj) ? v : 0.0;
+      }
     }
-  };
-  load_col(cur, 0);
-  for (int j = 0; j < K - 1; ++j) {
-    if (j + 1 < K - 1) load_col(nxt, j + 1);
-    const double tj = t[j];
+    const bool eon = e0 + lane < e1;
+    const int ec   = eon ? e0 + lane : 0;
+    double fv[kBW];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      const int i = lane + kWave * r;
-      if (i > j && i < K) t[i] = fma(-cur[r], tj, t[i]);
+    for (int jj = 0; jj < kBW; ++jj) fv[jj] = fval[ec * kBP + jj];
+    const int erow = eon ? frow[ec] : 0;
+    double esv     = t[erow];
+    double treg    = t[iblk];
+    BP_T(q0);
+    if (chain) {
+#pragma unroll
+      for (int jj = 0; jj < kBW; ++jj) {
+        tb[jj]          = lane_bcast(treg, l0 + ((jj < nbw) ? jj : 0));
+        const double nv = fma(-dv[jj], tb[jj], treg);
+        treg            = (dv[jj] != 0.0) ? nv : treg;  // (a zero entry leaves the row untouched, NaN pivots included)
+      }
+      if (inblk) t[iblk] = treg;
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < kBW; ++jj) tb[jj] = lane_bcast(treg, l0 + ((jj < nbw) ? jj : 0));
+    }
+    BP_T(q1);
+    BP_ADD(2, q0, q1);
+    if (compact) {  // the few rows below the block that have entries in it, from LDS
+#pragma unroll
+      for (int jj = 0; jj < kBW; ++jj) {
+        const double nv = fma(-fv[jj], tb[jj], esv);
+        esv             = (eon && fv[jj] != 0.0) ? nv : esv;
+      }
+      if (eon) t[erow] = esv;
+      for (int e = e0 + kWave + lane; e < e1; e += kWave) {
+        const int i = frow[e];
+        double sv   = t[i];
+#pragma unroll
+        for (int jj = 0; jj < kBW; ++jj) {
+          const double lvv = fval[e * kBP + jj];
+          const double nv  = fma(-lvv, tb[jj], sv);
+          sv               = (lvv != 0.0) ? nv : sv;
+        }
+        t[i] = sv;
+      }
+    } else
+    for (int r0 = rb; r0 < RB; r0 += RC) {
+      bool any = false;
+#pragma unroll
+      for (int rr = 0; rr < RC; ++rr) any = any || (r0 + rr < RB && fnz[jb * RB + ((r0 + rr < RB) ? r0 + rr : 0)] != 0);
+      if (!any) continue;  // wave-uniform
+      double lv[RC][kBW];
+      int ic[RC];
+      bool on[RC];
+#pragma unroll
+      for (int rr = 0; rr < RC; ++rr) {
+        const int i = lane + kWave * (r0 + rr);
+        on[rr]      = i >= j0 + kBW && i < K;
+        ic[rr]      = on[rr] ? i : K - 1;
+#pragma unroll
+        for (int jj = 0; jj < kBW; ++jj) lv[rr][jj] = LT[(size_t)(j0 + ((jj < nbw) ? jj : 0)) * ld + ic[rr]];
+      }
+#pragma unroll
+      for (int rr = 0; rr < RC; ++rr) {
+        double sv = t[ic[rr]];
+#pragma unroll
+        for (int jj = 0; jj < kBW; ++jj) {
+          const double nv = fma(-lv[rr][jj], tb[jj], sv);
+          sv              = (jj < nbw && lv[rr][jj] != 0.0) ? nv : sv;
+        }
+        if (on[rr]) t[ic[rr]] = sv;
+      }
     }
     wave_lds_fence();
-#pragma unroll
-    for (int r = 0; r < RB; ++r) cur[r] = nxt[r];
+    BP_T(q2);
+    BP_ADD(3, q1, q2);
   }
+  BP_T(p2);
+  BP_ADD(1, p1, p2);
   for (int i = lane; i < K; i += kWave) {
-    const double d = Dg[i];
+    const double d = LDg[i];
     t[i]           = (fabs(d) > DBL_MIN) ? t[i] / d : 0.0;
   }
   wave_lds_fence();
-  auto load_row = [&](double (&v)[RB], const int j) {  // L(j, i), i = lane + 64 r, i < j
+  // ---- backward ----
+  for (int jb = nb - 1; jb >= 0; --jb) {
+    const int j0 = jb * kBW, l0 = j0 % kWave, rb = j0 / kWave, nbw = (K - j0 < kBW) ? K - j0 : kBW;
+    const bool inblk = lane >= l0 && lane < l0 + nbw;
+    const int lrow   = inblk ? lane - l0 : 0, iblk = j0 + lrow, lcol = inblk ? lane - l0 : kBW - 1;
+    double dv[kBW], tb[kBW];
+    const int e0 = compact ? ubig(boff[jb]) : 0, e1 = compact ? ubig(boff[jb + 1]) : 0;
+    const bool chain = !compact || ubig(dflag[jb]) != 0;
+    if (compact && !chain && e0 == e1) continue;
+    if (!chain) {
+    } else if (dblk_ != nullptr) {  // (lanes outside the block read its last column: empty)
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      const int i = lane + kWave * r;
-      v[r]        = (i < j) ? W[(size_t)j * ld + i] : 0.0;
+      for (int jj = 0; jj < kBW; ++jj) dv[jj] = dblk[(jb * kBW + jj) * kBP + lcol];
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < kBW; ++jj) {
+        const double v = W[(size_t)(j0 + ((jj < nbw) ? jj : 0)) * ld + iblk];
+        dv[jj]         = (inblk && jj < nbw && lrow < jj) ? v : 0.0;
+      }
     }
-  };
-  load_row(cur, K - 1);
-  for (int j = K - 1; j > 0; --j) {
-    if (j - 1 > 0) load_row(nxt, j - 1);
-    const double tj = t[j];
+    const bool eon = e0 + lane < e1;
+    const int ec   = eon ? e0 + lane : 0;
+    double fv[kBW];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      const int i = lane + kWave * r;
-      if (i < j) t[i] = fma(-cur[r], tj, t[i]);
+    for (int jj = 0; jj < kBW; ++jj) fv[jj] = bval[ec * kBP + jj];
+    const int erow = eon ? brow[ec] : 0;
+    double esv     = t[erow];
+    double treg    = t[iblk];
+    if (chain) {
+#pragma unroll
+      for (int jj = kBW - 1; jj >= 0; --jj) {
+        tb[jj]          = lane_bcast(treg, l0 + ((jj < nbw) ? jj : 0));
+        const double nv = fma(-dv[jj], tb[jj], treg);
+        treg            = (dv[jj] != 0.0) ? nv : treg;
+      }
+      if (inblk) t[iblk] = treg;
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < kBW; ++jj) tb[jj] = lane_bcast(treg, l0 + ((jj < nbw) ? jj : 0));
+    }
+    if (compact) {
+#pragma unroll
+      for (int jj = kBW - 1; jj >= 0; --jj) {
+        const double nv = fma(-fv[jj], tb[jj], esv);
+        esv             = (eon && fv[jj] != 0.0) ? nv : esv;
+      }
+      if (eon) t[erow] = esv;
+      for (int e = e0 + kWave + lane; e < e1; e += kWave) {
+        const int i = brow[e];
+        double sv   = t[i];
+#pragma unroll
+        for (int jj = kBW - 1; jj >= 0; --jj) {
+          const double lvv = bval[e * kBP + jj];
+          const double nv  = fma(-lvv, tb[jj], sv);
+          sv               = (lvv != 0.0) ? nv : sv;
+        }
+        t[i] = sv;
+      }
+    } else
+    for (int r0 = 0; r0 <= rb; r0 += RC) {
+      bool any = false;
+#pragma unroll
+      for (int rr = 0; rr < RC; ++rr) any = any || (r0 + rr <= rb && bnz[jb * RB + ((r0 + rr < RB) ? r0 + rr : 0)] != 0);
+      if (!any) continue;  // wave-uniform
+      double lv[RC][kBW];
+      int ic[RC];
+      bool on[RC];
+#pragma unroll
+      for (int rr = 0; rr < RC; ++rr) {
+        const int i = lane + kWave * (r0 + rr);
+        on[rr]      = i < j0;
+        ic[rr]      = on[rr] ? i : 0;
+#pragma unroll
+        for (int jj = 0; jj < kBW; ++jj) lv[rr][jj] = W[(size_t)(j0 + ((jj < nbw) ? jj : 0)) * ld + ic[rr]];
+      }
+#pragma unroll
+      for (int rr = 0; rr < RC; ++rr) {
+        double sv = t[ic[rr]];
+#pragma unroll
+        for (int jj = kBW - 1; jj >= 0; --jj) {
+          const double nv = fma(-lv[rr][jj], tb[jj], sv);
+          sv              = (jj < nbw && lv[rr][jj] != 0.0) ? nv : sv;
+        }
+        if (on[rr]) t[ic[rr]] = sv;
+      }
     }
     wave_lds_fence();
-#pragma unroll
-    for (int r = 0; r < RB; ++r) cur[r] = nxt[r];
   }
   for (int i = lane; i < K; i += kWave) temp[perm[i]] = t[i];
   wave_sync();
@@ -209,7 +492,11 @@ size_t qp_dense_big_ws_doubles(int n, int m)
 size_t qp_dense_big_lds_bytes(int n, int m)
 {
   const size_t k = (size_t)n + m;
-  return (3 * k + (size_t)n + 2 * (size_t)m + 8) * sizeof(double) + ((k + 1) / 2 * 2) * sizeof(int);
+  const size_t rb = (k + 63) / 64 <= 2 ? 2 : ((k + 63) / 64 <= 4 ? 4 : ((k + 63) / 64 <= 8 ? 8 : 16));
+  const size_t tiles = ((k + 15) / 16) * rb;  // non-zero maps of the sweep tiles, forward and backward
+  const size_t dcache = (k <= (size_t)kDiagCacheK) ? ((k + 15) / 16) * 16 * kBP : 0;
+  return (4 * k + 2 * (size_t)n + 6 * (size_t)m + 8 + dcache + (size_t)big_row_cap((int)k) * kBP) * sizeof(double) +
+         ((k + 1) / 2 * 2 + 2 * tiles + 3 * ((k + 15) / 16 + 1) + (size_t)big_row_cap((int)k) + 4) * sizeof(int);
 }
 
 template<int RB>
@@ -225,7 +512,16 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
   // LDS: work vector t (k), scratch temp (k + 8: the polish system is never larger than k), second scratch (k),
   // iterate x (n), y (m), z (m), permutation (k ints)
   double *t = sm, *temp = t + k, *aux = temp + k + 8, *xs = aux + k, *ys = xs + n, *zs = ys + m;
-  int *perm = reinterpret_cast<int *>(zs + m);
+  // the per-iteration constants of the ADMM loop (a lone wave pays a memory round trip per phase otherwise)
+  double *Lrho = zs + m, *Lrinv = Lrho + m, *Llo = Lrinv + m, *Lhi = Llo + m, *Lqc = Lhi + m;
+  // diagonal 16 x 16 blocks of L for the blocked sweeps, cached in LDS while they fit (k <= kDiagCacheK)
+  double *dblk = Lqc + n;
+  double *LDg  = dblk + ((k <= kDiagCacheK) ? (size_t)((k + kBW - 1) / kBW) * kBW * kBP : 0);  // diagonal of the factor
+  double *cval = LDg + k;                                                                        // compact off-diagonal rows
+  const int rcap = big_row_cap(k);
+  int *perm = reinterpret_cast<int *>(cval + rcap * kBP);
+  int *fnz = perm + (k + 1) / 2 * 2, *bnz = fnz + ((k + kBW - 1) / kBW) * RB;
+  int *cidx = bnz + ((k + kBW - 1) / kBW) * RB, *cflag = cidx + 3 * ((k + kBW - 1) / kBW + 1) + rcap;
   BigWs w;
   {
     double *p = gws + b * wsd;
@@ -308,33 +604,36 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
       else if (syi * fabs(li - ui) < 1e-5) rho = 1e3 * kp.rho_bar;
       else rho = kp.rho_bar;
       w.rho[i]  = rho;
-      w.rinv[i] = 1.0 / rho;
-      w.lo[i]   = syi * li;
-      w.hi[i]   = syi * ui;
+      Lrho[i]   = rho;
+      Lrinv[i]  = 1.0 / rho;
+      Llo[i]    = syi * li;
+      Lhi[i]    = syi * ui;
     }
     if (wave_ballot(bad)) ret_code = SFB_QP_PRIMAL_INFEASIBLE;
+    for (int j = lane; j < n; j += kWave) Lqc[j] = c * w.sx[j] * q[j];  // (c sx_j) q_j of the right-hand side (:450)
   }
   wave_sync();
 
   const unsigned long long t0_ticks = wall_clock64();  // :376
-  // ---- dense KKT fill :399-404 (row-major lower triangle of the k x k array H) ----
-  for (int r = 0; r < n; ++r)
-    for (int cc = lane; cc <= r; cc += kWave) {
+  // ---- dense KKT fill :399-404 (lower triangle of the k x k array LT, column-major: (i, j) at LT[j k + i]) ----
+  for (int cc = 0; cc < n; ++cc)
+    for (int r = cc + lane; r < n; r += kWave) {
       double v = c * w.sx[cc] * PM(cc, r) * w.sx[r];
       if (cc == r) v += kp.sigma;
-      w.H[(size_t)r * k + cc] = v;
+      w.LT[(size_t)cc * k + r] = v;
     }
   for (int e = lane; e < m * n; e += kWave) {
     const int i = e % m, j = e / m;
-    w.H[(size_t)(n + i) * k + j] = w.sy[i] * A[e] * w.sx[j];
+    w.LT[(size_t)j * k + (n + i)] = w.sy[i] * A[e] * w.sx[j];
   }
-  for (int i = 0; i < m; ++i) {
-    for (int i2 = lane; i2 < i; i2 += kWave) w.H[(size_t)(n + i) * k + (n + i2)] = 0.0;
-    if (lane == 0) w.H[(size_t)(n + i) * k + (n + i)] = 1.0 / (-w.rho[i]);
+  for (int i2 = 0; i2 < m; ++i2) {
+    for (int i = i2 + 1 + lane; i < m; i += kWave) w.LT[(size_t)(n + i2) * k + (n + i)] = 0.0;
+    if (lane == 0) w.LT[(size_t)(n + i2) * k + (n + i2)] = 1.0 / (-w.rho[i2]);
   }
   wave_sync();
-  if (!big_ldlt_factor(k, w.H, k, perm, temp, lane)) ret_code = SFB_QP_UNKNOWN;  // :428-433
-  big_transpose(k, w.H, k, w.LT, w.Dg, lane);
+  if (!big_ldlt_factor(k, w.LT, k, perm, temp, lane)) ret_code = SFB_QP_UNKNOWN;  // :428-433
+  const bool dcache = k <= kDiagCacheK;
+  big_transpose<RB>(k, w.H, k, w.LT, w.Dg, fnz, bnz, dcache ? dblk : nullptr, LDg, cidx, cval, cflag, rcap, lane);
 
   // ---- initial iterate :436-445 ----
   if (g.wx != nullptr) {
@@ -380,10 +679,13 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
   const uint32_t sci   = kp.stop_check_iter;
   const uint32_t maxit = kp.max_iter;
   for (; iter != maxit && ret_code < 0; ++iter) {
-    for (int j = lane; j < n; j += kWave) t[j] = kp.sigma * xs[j] - c * w.sx[j] * q[j];      // :450
-    for (int i = lane; i < m; i += kWave) t[n + i] = zs[i] - w.rinv[i] * ys[i];             // :451
+    for (int j = lane; j < n; j += kWave) t[j] = kp.sigma * xs[j] - Lqc[j];                  // :450
+    for (int i = lane; i < m; i += kWave) t[n + i] = zs[i] - Lrinv[i] * ys[i];              // :451
     wave_sync();
-    big_solve<RB>(k, w.H, w.LT, w.Dg, k, perm, t, temp, lane);                              // :462
+    BP_T(s0);
+    big_solve<RB>(k, w.H, w.LT, w.Dg, k, perm, fnz, bnz, dcache ? dblk : nullptr, LDg, cidx, cval, cflag, t, temp, lane);  // :462
+    BP_T(s1);
+    BP_ADD(5, s0, s1);
     const bool chk = (sci != 0) && (iter % sci == 1);                                       // :465
     for (int j = lane; j < n; j += kWave) {                                                 // :470
       const double xo = xs[j], xn = kp.alpha * t[j] + kp.alpha_comp * xo;
@@ -394,10 +696,10 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
       }
     }
     for (int i = lane; i < m; i += kWave) {                                                 // :471-477
-      const double ri = w.rinv[i], rh = w.rho[i], yo = ys[i], zo = zs[i], nu = t[n + i];
+      const double ri = Lrinv[i], rh = Lrho[i], yo = ys[i], zo = zs[i], nu = t[n + i];
       double zn = kp.alpha * (ri * nu) + kp.alpha_comp * (ri * yo) + zo;
-      zn        = (zn < w.lo[i]) ? w.lo[i] : zn;
-      zn        = (w.hi[i] < zn) ? w.hi[i] : zn;
+      zn        = (zn < Llo[i]) ? Llo[i] : zn;
+      zn        = (Lhi[i] < zn) ? Lhi[i] : zn;
       const double yn = kp.alpha_comp * yo + kp.alpha * nu + rh * zo - rh * zn;
       ys[i] = yn;
       zs[i] = zn;
@@ -476,6 +778,13 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
     }
   }
 
+#ifdef SFB_BIG_PROF
+  if (lane == 0 && blockIdx.x == 0) {
+    printf("bigprof iters %u compact %d | x10ns: perm-in %llu forward %llu (chains %llu rest %llu) solve %llu loop %llu\n", iter, cflag[0],
+           g_bigprof[0], g_bigprof[1], g_bigprof[2], g_bigprof[3], g_bigprof[5], wall_clock64() - t0_ticks);
+    for (int i = 0; i < 8; ++i) g_bigprof[i] = 0;
+  }
+#endif
   // ---- polish :92-204, :515-539 (on the scaled iterate; a failed factorisation leaves the ADMM solution) ----
   if (ret_code == SFB_QP_OPTIMAL && kp.polish) {
     const double eps = DBL_EPSILON;
@@ -499,16 +808,17 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
     }
     wave_sync();
     const int na = nl + nu, K = n + na;
-    // Hs: the symmetric K x K matrix of the residual; Hp = Hs + diag(delta, -delta) lower row-major for the LDLT (:159-177)
-    double *Hs = w.Hs, *Hp = w.H;
-    for (int e = lane; e < K * K; e += kWave) { Hs[e] = 0.0; Hp[e] = 0.0; }
+    // Hs: the symmetric K x K matrix of the residual; Hp = Hs + diag(delta, -delta), lower triangle column-major in LT
+    // for the LDLT (:159-177); its factor's row-major copy goes to H
+    double *Hs = w.Hs, *Hp = w.H, *Hc = w.LT;
+    for (int e = lane; e < K * K; e += kWave) { Hs[e] = 0.0; Hc[e] = 0.0; }
     wave_sync();
     for (int i = 0; i < n; ++i)
       for (int j = i + lane; j < n; j += kWave) {
         const double v           = c * w.sx[i] * PM(i, j) * w.sx[j];  // :161 upper entry (i, j)
         Hs[(size_t)i * K + j]    = v;
         Hs[(size_t)j * K + i]    = v;
-        Hp[(size_t)j * K + i]    = v;
+        Hc[(size_t)i * K + j]    = v;
       }
     for (int e = lane; e < m * n; e += kWave) {
       const int row = e % m, j = e / m;
@@ -518,12 +828,12 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
         const double v = w.sy[row] * A[e] * w.sx[j];  // :163
         Hs[(size_t)j * K + col] = v;
         Hs[(size_t)col * K + j] = v;
-        Hp[(size_t)col * K + j] = v;
+        Hc[(size_t)j * K + col] = v;
       }
     }
     wave_sync();
-    for (int i = lane; i < n; i += kWave) Hp[(size_t)i * K + i] += kp.delta;
-    for (int a = lane; a < na; a += kWave) Hp[(size_t)(n + a) * K + (n + a)] -= kp.delta;
+    for (int i = lane; i < n; i += kWave) Hc[(size_t)i * K + i] += kp.delta;
+    for (int a = lane; a < na; a += kWave) Hc[(size_t)(n + a) * K + (n + a)] -= kp.delta;
     // h (:179-182) and t = 0
     for (int j = lane; j < n; j += kWave) w.hx[j] = -c * (w.sx[j] * q[j]);
     for (int i = lane; i < m; i += kWave) {
@@ -533,17 +843,16 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
     }
     for (int e = lane; e < K; e += kWave) aux[e] = 0.0;  // aux = t of the refinement
     wave_sync();
-    if (big_ldlt_factor(K, Hp, K, perm, temp, lane)) {
-      big_transpose(K, Hp, K, w.LT, w.Dg, lane);
+    if (big_ldlt_factor(K, Hc, K, perm, temp, lane)) {
+      big_transpose<RB>(K, Hp, K, w.LT, w.Dg, fnz, bnz, dcache ? dblk : nullptr, LDg, cidx, cval, cflag, rcap, lane);
       for (uint32_t it = 0; it != kp.polish_iter; ++it) {  // :193-195  t += Hp^-1 (h - Hs t)
         for (int i = lane; i < K; i += kWave) {
-          const double *row = Hs + (size_t)i * K;
-          double s          = 0.0;
-          for (int j = 0; j < K; ++j) s = fma(row[j], aux[j], s);
+          double s = 0.0;
+          for (int j = 0; j < K; ++j) s = fma(Hs[(size_t)j * K + i], aux[j], s);  // (Hs is symmetric: column i == row i)
           t[i] = ((i < n) ? w.hx[i] : w.Ax[i - n]) - s;
         }
         wave_sync();
-        big_solve<RB>(K, Hp, w.LT, w.Dg, K, perm, t, temp, lane);
+        big_solve<RB>(K, Hp, w.LT, w.Dg, K, perm, fnz, bnz, dcache ? dblk : nullptr, LDg, cidx, cval, cflag, t, temp, lane);
         for (int i = lane; i < K; i += kWave) aux[i] += t[i];
         wave_sync();
       }

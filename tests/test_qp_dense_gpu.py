@@ -384,3 +384,14 @@ def test_max_time_like_the_reference(sfb, oracle, n, m):
     base = sfb.solve_qp_batch_host(P, q, A, l, u, sfb.QPSolverParams(max_iter=4000))
     slow = sfb.solve_qp_batch_host(P, q, A, l, u, sfb.QPSolverParams(max_iter=4000, max_time=30.0))
     assert np.array_equal(base.code, slow.code) and np.array_equal(base.iter, slow.iter) and np.array_equal(base.primal, slow.primal, equal_nan=True)
+
+
+def test_verbose_prints_a_summary_of_the_call(sfb, capfd):
+    """QPSolverParams::verbose (qp_solver.hpp:409-420, :550-565 print phase times and the outcome): the host-pointer
+    entry points print one summary per call."""
+    P, q, A, l, u = sfb.random_qp_batch(5, 32, 20, 10, 1.0)
+    sfb.solve_qp_batch_host(P, q, A, l, u, sfb.QPSolverParams(max_iter=500, verbose=True))
+    out = capfd.readouterr().out
+    assert "[sfb] dense QP batch: 32 problem(s), n = 10, m = 20" in out and "status:" in out and "iterations: min" in out
+    sfb.solve_qp_batch_host(P, q, A, l, u, sfb.QPSolverParams(max_iter=500))
+    assert "[sfb]" not in capfd.readouterr().out
