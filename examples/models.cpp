@@ -431,6 +431,53 @@ int sfbx_test_ocp_to_qp_parabola(double * out)
   return 0;
 }
 
+int sfbx_test_mpc_doubleintegrator(int ticks, double * u_out, uint32_t * iters, int32_t * codes, double * u_ref, uint32_t * iters_ref,
+                                   int64_t * reuse_count, double * seconds)
+{
+  // examples/mpc_doubleintegrator.cpp:31-101: x = (p, v), f = (v, u), -0.5 <= u <= 0.5, K = 20, tf = 5,
+  // xdes(t) = (-0.5 sin 0.3 t, 0), 50 ms ticks, closed loop (here integrated exactly: u is constant over a tick).
+  // A linear system: the QP matrices are the same at every tick, only l and u move -- the solver front recognises
+  // that and the kernel keeps scaling and factor (sfb_qp_params::reuse_factor).  Second closed loop with the
+  // reuse switched off (SFB_QP_NO_REUSE=1): inputs and iteration counts must be identical.
+  using X2 = Rn<2>;
+  using U1 = Rn<1>;
+  struct Dyn {
+    Vec<2> operator()(const X2 & x, const U1 & u) const { return {x.v[1], u.v[0]}; }
+  };
+  struct Cr {
+    Vec<1> operator()(const X2 &, const U1 & u) const { return {u.v[0]}; }
+  };
+  try {
+    for (int pass = 0; pass < 2; ++pass) {
+      setenv("SFB_QP_NO_REUSE", pass ? "1" : "0", 1);
+      MPCParams p;
+      p.K = 20; p.tf = 5.0;
+      MPC<X2, U1, 1, Dyn, Cr> mpc(Dyn{}, Cr{}, {-0.5}, {0.5}, p);
+      mpc.set_xdes([](double t) { X2 x; x.v = {-0.5 * std::sin(0.3 * t), 0.0}; return x; },
+                   [](double t) { return Vec<2>{-0.15 * std::cos(0.3 * t), 0.0}; });
+      mpc.set_udes([](double) { U1 u; u.v = {0.0}; return u; });
+      X2 x; x.v = {0.6, -0.2};
+      const double dt = 0.05;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int k = 0; k < ticks; ++k) {
+        const auto [u, code] = mpc(k * dt, x);
+        (pass ? u_ref : u_out)[k]      = u.v[0];
+        (pass ? iters_ref : iters)[k]  = mpc.solver().sol().iter;
+        if (!pass) codes[k] = (int32_t)code;
+        x.v = {x.v[0] + dt * x.v[1] + 0.5 * dt * dt * u.v[0], x.v[1] + dt * u.v[0]};
+      }
+      seconds[pass] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (!pass) *reuse_count = mpc.solver().factor_reuse_count();
+    }
+    unsetenv("SFB_QP_NO_REUSE");
+    return 0;
+  } catch (const std::exception & e) {
+    unsetenv("SFB_QP_NO_REUSE");
+    std::fprintf(stderr, "sfbx_test_mpc_doubleintegrator: %s\n", e.what());
+    return -1;
+  }
+}
+
 int sfbx_test_mpc_se2(double * u_out, int32_t * codes, int32_t * traj_sizes)
 {
   // tests/test_mpc.cpp:34-58,77-117

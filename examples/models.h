@@ -23,6 +23,12 @@ int sfbx_mpc_assemble_batch(int variant, int K, double tf, int64_t batch, uint64
 /* Closed loop of tests/test_mpc.cpp:34-117 (SE2 state, R2 input, f = (u0, 0, u1), -1 <= u <= 1):
  * three consecutive MPC calls with warm start, then three without. u_out[6][2], codes[6]. Needs a GPU. */
 int sfbx_test_mpc_se2(double *u_out, int32_t *codes, int32_t *traj_sizes);
+/* examples/mpc_doubleintegrator.cpp:31-101 in closed loop for `ticks` ticks of 50 ms (time-invariant QP matrices: the
+ * solver front flags every tick after the first as reuse_factor), then the same loop with the reuse switched off:
+ * u_out / iters / codes [ticks] and u_ref / iters_ref [ticks]; reuse_count = flagged solves of the first loop;
+ * seconds[2] = wall time of the two loops.  Needs a GPU. */
+int sfbx_test_mpc_doubleintegrator(int ticks, double *u_out, uint32_t *iters, int32_t *codes, double *u_ref, uint32_t *iters_ref,
+                                   int64_t *reuse_count, double *seconds);
 /* tests/test_ocp_to_qp.cpp:41-107 through the MPC transcription (double integrator, two intervals of 5 LGR nodes, tf = 2):
  * out = {min(A var - l), min(u - A var), N, n, m, intervals} for the exact parabola trajectory.  Host only (no GPU). */
 int sfbx_test_ocp_to_qp_parabola(double *out);

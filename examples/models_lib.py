@@ -124,3 +124,12 @@ def mpc_swarm_step(variant, K, batch, ticks, seed=1, tf=5.0, device=False):
     rc = fn(variant, K, C.c_double(tf), C.c_int64(batch), C.c_uint64(seed), ticks, _p(u0), _p(codes), _p(iters))
     assert rc == 0, rc
     return u0, codes, iters
+
+
+def mpc_doubleintegrator(ticks):
+    """examples/mpc_doubleintegrator.cpp in closed loop, with the factor reuse of the solver front and without."""
+    u = np.zeros(ticks); it = np.zeros(ticks, np.uint32); codes = np.zeros(ticks, np.int32)
+    ur = np.zeros(ticks); itr = np.zeros(ticks, np.uint32); cnt = C.c_int64(0); sec = np.zeros(2)
+    rc = lib().sfbx_test_mpc_doubleintegrator(ticks, _p(u), _p(it), _p(codes), _p(ur), _p(itr), C.byref(cnt), _p(sec))
+    assert rc == 0, rc
+    return dict(u=u, iter=it, code=codes, u_ref=ur, iter_ref=itr, reuse_count=cnt.value, seconds=sec)

@@ -79,6 +79,20 @@ typedef struct sfb_qp_params {
   int32_t verbose;          /* :32  host-pointer entry points print a summary of the call (phase times,
                                     status histogram, iteration statistics); ignored by the asynchronous
                                     device-pointer entry points                 (0)     */
+  int32_t reuse_factor;     /* NOT in the reference (which re-scales and re-factorises on every solve(), reusing
+                                    only the symbolic analysis, :424-426).  Shared-pattern sparse entry points only;
+                                    the dense kernels ignore it.  Non-zero = the caller vouches that P and A of
+                                    EVERY item are bit-identical to what the previous call with the same plan,
+                                    workspace, batch, sigma and scaling solved for that item (a time-invariant
+                                    MPC: only q, l, u move between ticks).  The kernel then keeps, per item,
+                                    whatever that call left in the workspace and this call would recompute to the
+                                    same bits: the compacted A, the scaling when c (which depends on |q|) comes
+                                    out the same, and the LDL' factor when additionally the rho vector (which
+                                    rows are equalities) is unchanged -- otherwise it recomputes.  Results are
+                                    bit-identical to a call without the flag by construction.  The first call
+                                    on a workspace may set it too (nothing to keep yet).  Ignored for items a
+                                    pruned plan's guard sends to the fallback pool and in launches with an
+                                    explicit order (their workspace slots are not the items').   (0)     */
 } sfb_qp_params;
 
 /* With max_iter unset the reference loops until a stopping test fires (possibly forever, e.g.

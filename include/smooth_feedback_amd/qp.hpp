@@ -14,6 +14,7 @@
 
 #include <chrono>
 #include <cstdint>
+#include <cstring>
 #include <functional>
 #include <limits>
 #include <optional>
@@ -40,6 +41,9 @@ struct QPSolverParams {
   bool polish              = true;
   uint32_t polish_iter     = 5;
   float delta              = 1e-6f;
+  /// extension (sfb.h, sfb_qp_params::reuse_factor): P and A are bit-identical to the previous solve on this solver's
+  /// workspace -- scaling and factorisation are kept where provably unchanged; results do not depend on the flag
+  bool reuse_factor = false;
 
   sfb_qp_params to_c() const
   {
@@ -50,6 +54,7 @@ struct QPSolverParams {
     c.max_iter = max_iter ? int64_t(*max_iter) : -1;
     c.max_time_ns = max_time ? int64_t(max_time->count()) : -1;
     c.stop_check_iter = stop_check_iter; c.polish = polish; c.polish_iter = polish_iter; c.delta = delta;
+    c.reuse_factor = reuse_factor;
     return c;
   }
 };
@@ -158,6 +163,7 @@ public:
     sol_.dual.assign(m_, 0.0);
     if constexpr (sparse) {
       holder_.reset();
+      last_P_.clear(); last_A_.clear();
       sfb_check(sfb_sparse_qp_plan_create_pruned(pbm.n, pbm.m, pbm.P_colptr.data(), pbm.P_rowind.data(), pbm.A_rowptr.data(),
                                                  pbm.A_colind.data(), 1, user_perm, stage, A_keep, &holder_.plan));
     } else {
@@ -188,8 +194,18 @@ public:
   const Solution & solve(const Pbm & pbm, const Solution * warmstart)
   {
     if (!analyzed() || n_ != pbm.n || m_ != pbm.m) analyze(pbm);
-    int32_t code          = 6;
-    const sfb_qp_params c = prm_.to_c();
+    int32_t code    = 6;
+    sfb_qp_params c = prm_.to_c();
+    if constexpr (sparse) {
+      // A time-invariant problem family (a linear MPC: only q, l, u move between ticks) presents the very same
+      // matrices again: tell the kernel, which then keeps the scaling and the factor it still holds for them
+      // (sfb_qp_params::reuse_factor -- same results, bit for bit).
+      const bool same = last_P_.size() == pbm.P_val.size() && last_A_.size() == pbm.A_val.size() && !last_A_.empty() &&
+                        std::memcmp(last_P_.data(), pbm.P_val.data(), last_P_.size() * sizeof(double)) == 0 &&
+                        std::memcmp(last_A_.data(), pbm.A_val.data(), last_A_.size() * sizeof(double)) == 0;
+      if (same) { c.reuse_factor = 1; ++reuse_count_; }
+      else { last_P_ = pbm.P_val; last_A_ = pbm.A_val; }
+    }
     const double * wx = warmstart ? warmstart->primal.data() : nullptr;
     const double * wy = warmstart ? warmstart->dual.data() : nullptr;
     if constexpr (sparse) {
@@ -220,6 +236,9 @@ public:
     }
   }
 
+  /// solves that found the previous solve's matrices again and were flagged reuse_factor
+  int64_t factor_reuse_count() const { return reuse_count_; }
+
   int64_t nnzL() const
   {
     int64_t v = 0;
@@ -233,6 +252,8 @@ private:
   QPSolverParams prm_{};
   detail::PlanHolder holder_;
   bool analyzed_ = false;
+  std::vector<double> last_P_, last_A_;  // sparse: the matrices of the previous solve() (factor reuse)
+  int64_t reuse_count_ = 0;
   int n_ = 0, m_ = 0;
   Solution sol_;
 };

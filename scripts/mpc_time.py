@@ -39,3 +39,8 @@ for cap in (200, 400):
     ms = timed(sfb.QPSolverParams(max_iter=cap))
     print("max_iter=%d: %.2f ms -> %.0f solves/s ; codes %s" % (cap, ms, B / ms * 1e3, np.bincount(code.cpu().numpy(), minlength=7)))
 print("breakdown: setup(scaling on) %.2f | scaling off %.2f ms" % (timed(sfb.QPSolverParams(max_iter=0, polish=False)), timed(sfb.QPSolverParams(max_iter=0, polish=False, scaling=False))))
+# factor reuse (sfb_qp_params::reuse_factor): the same matrices again, as a time-invariant MPC presents them every tick
+ms_plain = timed(sfb.QPSolverParams(max_iter=4000))
+ms_reuse = timed(sfb.QPSolverParams(max_iter=4000, reuse_factor=True))
+print("same matrices again: %.2f ms without reuse_factor, %.2f ms with (%.0f solves/s)" % (ms_plain, ms_reuse, B / ms_reuse * 1e3))
+print("   setup only (max_iter 0, no polish): %.2f ms without, %.2f ms with" % (timed(sfb.QPSolverParams(max_iter=0, polish=False)), timed(sfb.QPSolverParams(max_iter=0, polish=False, reuse_factor=True))))

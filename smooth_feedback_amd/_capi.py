@@ -37,6 +37,7 @@ class SfbQPParams(C.Structure):
         ("polish_iter", C.c_uint32),
         ("delta", C.c_float),
         ("verbose", C.c_int32),
+        ("reuse_factor", C.c_int32),
     ]
 
 

@@ -87,6 +87,8 @@ DenseKernelParams make_kernel_params(const sfb_qp_params *prm, int n, int m)
   kp.polish_iter     = prm->polish_iter;
   kp.scaling         = prm->scaling ? 1 : 0;
   kp.polish          = prm->polish ? 1 : 0;
+  kp.reuse           = prm->reuse_factor ? 1 : 0;
+  if (const char *nr = std::getenv("SFB_QP_NO_REUSE"); nr && nr[0] == '1') kp.reuse = 0;  // A/B knob (tests, timing)
   return kp;
 }
 
@@ -254,6 +256,7 @@ void sfb_qp_params_default(sfb_qp_params *p)
   p->polish_iter     = 5;
   p->delta           = 1e-6f;
   p->verbose         = 0;
+  p->reuse_factor    = 0;
 }
 
 sfb_status sfb_qp_dense_solve_batch(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P,

@@ -33,6 +33,7 @@ struct sfb_sparse_qp_plan {
   // with host pointers on one plan are serialised; device-pointer calls bring their own workspace).
   std::mutex host_mu;
   std::map<int, std::pair<char *, size_t>> host_ws;  // device ordinal -> (buffer, bytes)
+  std::map<int, int64_t> host_batch;  // device ordinal -> batch of the last call whose workspace content is still in the buffer
 };
 
 namespace sfb {
@@ -363,14 +364,22 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
       return sfb::hip_fail(e, "hipMalloc");
     }
     cache.second = bytes;
+    plan->host_batch[devid] = -1;
   }
+  // reuse_factor refers to "the previous call on this workspace": the workspace sits at the start of the cached
+  // buffer, so it is the same memory, item for item, exactly when the batch size is that of the previous call
+  sfb_qp_params prm_call = *prm;
+  if (plan->host_batch[devid] != batch) prm_call.reuse_factor = 0;
+  plan->host_batch[devid] = batch;
+  prm = &prm_call;
   char *devmem = cache.first;
-  double *dPx = reinterpret_cast<double *>(devmem);
+  double *dws = reinterpret_cast<double *>(devmem);
+  double *dPx = reinterpret_cast<double *>(devmem + wsb);
   double *dq = dPx + B * NP, *dAx = dq + B * N, *dl = dAx + B * NA, *du = dl + B * M;
   double *dwx = nullptr, *dwy = nullptr, *dx = du + B * M;
   if (warm_x) { dwx = dx; dwy = dwx + B * N; dx = dwy + B * M; }
-  double *dy = dx + B * N, *dobj = dy + B * M, *dws = dobj + B;
-  uint32_t *dit  = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(dws) + wsb);
+  double *dy = dx + B * N, *dobj = dy + B * M;
+  uint32_t *dit  = reinterpret_cast<uint32_t *>(dobj + B);
   int32_t *dcode = reinterpret_cast<int32_t *>(dit + B);
   auto H2D = [&](void *d, const void *hh, size_t nb) { return nb ? hipMemcpy(d, hh, nb, hipMemcpyHostToDevice) : hipSuccess; };
   auto D2H = [&](void *hh, const void *d, size_t nb) { return nb ? hipMemcpy(hh, d, nb, hipMemcpyDeviceToHost) : hipSuccess; };

@@ -17,6 +17,7 @@ struct DenseKernelParams {
   uint32_t stop_check_iter;
   uint32_t polish_iter;
   int scaling, polish;
+  int reuse;  // sfb_qp_params::reuse_factor (shared-pattern sparse kernel only)
 };
 
 // Batch-major device arrays of one call (include/sfb.h: sfb_qp_dense_solve_batch)

@@ -46,9 +46,13 @@ struct Ws {
   double *Lx, *LxF, *LxB, *D, *Dinv, *tv;  // Lx, D and one scratch double are contiguous (accumulators)
   double *sx, *qc, *xs, *xus, *dxus;
   double *sy, *rho, *rinv, *lo, *hi, *ys, *zs, *yus, *zus, *dyus, *act;
-  double *hdr;  // 8 doubles: state of a suspended item (time-sliced launches): c, iter, next_chk
+  double *hdr;  // 16 doubles: [0..5] state of a suspended item (time-sliced launches): c, iter, next_chk, t0;
+                //             [6..9] what the ADMM factor in this workspace belongs to (reuse_factor, see kHdr*)
   double *Axc;  // pruned plans: the item's kept entries of A, compacted (qp_sparse_kernel.h)
 };
+// reuse_factor: the header of an item whose workspace holds a successful ADMM factorisation
+constexpr int kHdrStamp = 6, kHdrC = 7, kHdrSigma = 8, kHdrScaling = 9;
+constexpr unsigned long long kFactorStamp = 0x5FB0FAC7A11CE5EDull;
 
 __device__ __forceinline__ Ws carve_ws(double *base, int n, int m, int nnzL, int funits, int bunits)
 {
@@ -66,9 +70,23 @@ __device__ __forceinline__ Ws carve_ws(double *base, int n, int m, int nnzL, int
   w.sy = p; p += m;     w.rho = p; p += m;    w.rinv = p; p += m; w.lo = p; p += m;   w.hi = p; p += m;
   w.ys = p; p += m;     w.zs = p; p += m;     w.yus = p; p += m;  w.zus = p; p += m;  w.dyus = p; p += m;
   w.act = p; p += m;
-  w.hdr = p; p += 8;
+  w.hdr = p; p += 16;
   w.Axc = p;
   return w;
+}
+// the same workspace with the factor fields redirected to the second factor block (polish of a reuse_factor call)
+__device__ __forceinline__ Ws polish_ws(const Ws &w, double *base, const size_t off, int n, int m, int nnzL, int funits, int bunits)
+{
+  const int k = n + m;
+  Ws v = w;
+  double *p = base + off;
+  v.Lx = p; p += nnzL;
+  v.D = p; p += k;
+  p += 2;
+  v.LxF = p; p += (size_t)(funits + kSweepPadDev) * 128;
+  v.LxB = p; p += (size_t)(bunits + kSweepPadDev) * 128;
+  v.Dinv = p;
+  return v;
 }
 
 struct Item {
@@ -851,7 +869,8 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
 }
 
 // detail::polish_qp (sparse), embedded in the full pattern.  In/out: scaled xs / ys in the workspace.
-__device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const Ws &w, const DenseKernelParams &kp,
+// wf: the workspace view whose factor fields the polish factorisation may overwrite (w itself, or polish_ws(w))
+__device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const Ws &w, const Ws &wf, const DenseKernelParams &kp,
                                  double *t, const double c, const int lane, const bool lean)
 {
   const int n = uni(pl.n), m = uni(pl.m), k = uni(pl.k);
@@ -865,7 +884,7 @@ __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const 
   }
   for (int e = lane; e < k; e += kWave) w.tv[e] = 0.0;
   wave_sync();
-  if (!ldl_numeric_dev<8>(pl, it, w, t, 1, c, kp.sigma, kp.delta, lane)) return;  // :187-190
+  if (!ldl_numeric_dev<8>(pl, it, wf, t, 1, c, kp.sigma, kp.delta, lane)) return;  // :187-190
   for (uint32_t iter = 0; iter != kp.polish_iter; ++iter) {                      // :193-195
     // residual rows h - K tv (:193-195), entries in storage order as in the oracle.  Like sp_row_dot the entries of
     // a row are fetched in chunks: positions / indices first, then everything they point to, then the fma chain
@@ -944,7 +963,7 @@ __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const 
       t[pl.pinv[n + rr]] = h - acc;
     }
     wave_sync();
-    ldl_solve_dev(pl, w, t, lane, lean);
+    ldl_solve_dev(pl, wf, t, lane, lean);
     for (int e = lane; e < k; e += kWave) w.tv[e] += t[pl.pinv[e]];
     wave_sync();
   }
@@ -997,7 +1016,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
                                              double *__restrict__ gws, const size_t ws_doubles, const int lean_waves,
                                              bool lean, const size_t b, const size_t slot, double *t, const int lane,
                                              const bool resume, const int32_t *queue, const int batch,
-                                             const uint32_t slice)
+                                             const uint32_t slice, const bool allow_reuse)
 {
   const int n = uni(pl.n), m = uni(pl.m), k = uni(pl.k);
   const int nnzP = uni(pl.nnzP), nnzA = uni(pl.nnzA);  // (nnzA: what the kernel works on, the kept entries of a pruned plan)
@@ -1027,7 +1046,14 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
 #endif
     if (pl.Aorig != nullptr) it.Ax = w.Axc;
   } else {
-  if (pl.Aorig != nullptr) {
+  // reuse_factor (sfb.h): the caller vouches that P and A of this item are what the previous call on this workspace
+  // solved.  What the workspace holds from that call -- the compacted A, the scaling (it depends on P, A and, through
+  // c, on |q|), the factor (on the scaling, sigma and rho, i.e. on which rows are equalities) -- is re-used as far as
+  // it is PROVABLY what this call would compute: c and rho are recomputed and compared bit for bit.
+  const bool keep = allow_reuse && kp.reuse != 0 && (unsigned long long)__double_as_longlong(w.hdr[kHdrStamp]) == kFactorStamp &&
+                    w.hdr[kHdrSigma] == kp.sigma && w.hdr[kHdrScaling] == (double)kp.scaling;
+  if (pl.Aorig != nullptr && keep) it.Ax = w.Axc;
+  else if (pl.Aorig != nullptr) {
     // Pruned plan (its guard has passed, see the kernel): the kept entries of A are compacted into the workspace;
     // everything below works on the compressed pattern.  (Aorig is padded: branch-free batches.)
     constexpr int UB = 8;
@@ -1046,11 +1072,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     wave_sync();
   }
 
-  // ---- analyze(): :306-308 ----
-  for (int j = lane; j < n; j += kWave) w.sx[j] = 1.0;
-  for (int i = lane; i < m; i += kWave) w.sy[i] = 1.0;
-  wave_sync();
-
+  bool keep_scaling = keep && !kp.scaling;  // (no scaling: sx = sy = 1, c = 1 are there already)
   // ---- scale :673-730 ----
   if (kp.scaling) {
     // :681-693: column inf-norms of P as stored, then c
@@ -1066,6 +1088,15 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     const double qn = lane_max_abs(it.q, n, lane);
     c               = 1.0 / fmax(fmax(1e-6, sum / (double)n), qn);
     wave_sync();
+    keep_scaling = keep && c == w.hdr[kHdrC];  // same P, A and c: the Ruiz iteration below would reproduce sx, sy
+  }
+  if (!keep_scaling) {
+    // ---- analyze(): :306-308 ----
+    for (int j = lane; j < n; j += kWave) w.sx[j] = 1.0;
+    for (int i = lane; i < m; i += kWave) w.sy[i] = 1.0;
+    wave_sync();
+  }
+  if (kp.scaling && !keep_scaling) {
     int pass = 0;
     double crit;
     do {
@@ -1140,8 +1171,9 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
   }
 
   // ---- pre-check, rho and loop constants :361-374, :450, :473-474 ----
+  bool keep_factor = keep_scaling;
   {
-    bool bad = false;
+    bool bad = false, rho_changed = false;
     for (int i = lane; i < m; i += kWave) {
       const double li = it.l[i], ui = it.u[i], syi = w.sy[i];
       bad = bad || (li == inf) || (ui == -inf) || (ui - li < 0.0);
@@ -1149,6 +1181,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
       if (li == -inf && ui == inf) rho = 1e-6;
       else if (syi * fabs(li - ui) < 1e-5) rho = 1e3 * kp.rho_bar;
       else rho = kp.rho_bar;
+      if (keep_scaling) rho_changed = rho_changed || !(w.rho[i] == rho);
       w.rho[i]  = rho;
       w.rinv[i] = 1.0 / rho;
       w.lo[i]   = syi * li;
@@ -1156,13 +1189,22 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     }
     for (int j = lane; j < n; j += kWave) w.qc[j] = c * w.sx[j] * it.q[j];
     if (wave_ballot(bad)) ret_code = SFB_QP_PRIMAL_INFEASIBLE;
+    if (keep_scaling && wave_ballot(rho_changed)) keep_factor = false;
   }
   wave_sync();
 
   // ---- KKT fill + numeric factorisation :379-433 ----
-  if (!ldl_numeric_dev<8>(pl, it, w, t, 0, c, kp.sigma, kp.delta, lane)) {
-    ret_code = SFB_QP_UNKNOWN;
-    // Dinv of the remaining columns is never used: the loop below does not run
+  if (!keep_factor) {
+    if (lane == 0) w.hdr[kHdrStamp] = 0.0;  // until the new factor is complete
+    if (!ldl_numeric_dev<8>(pl, it, w, t, 0, c, kp.sigma, kp.delta, lane)) {
+      ret_code = SFB_QP_UNKNOWN;
+      // Dinv of the remaining columns is never used: the loop below does not run
+    } else if (lane == 0) {
+      w.hdr[kHdrStamp]   = __longlong_as_double((long long)kFactorStamp);
+      w.hdr[kHdrC]       = c;
+      w.hdr[kHdrSigma]   = kp.sigma;
+      w.hdr[kHdrScaling] = (double)kp.scaling;
+    }
   }
 
 #ifdef SFB_SP_TIMELINE
@@ -1368,7 +1410,17 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
   tl2 = wall_clock64();
 #endif
   // ---- polish :515-539 ----
-  if (ret_code == SFB_QP_OPTIMAL && kp.polish) sp_polish(pl, it, w, kp, t, c, lane, lean);
+  if (ret_code == SFB_QP_OPTIMAL && kp.polish) {
+    if (kp.reuse != 0 && allow_reuse) {  // keep the ADMM factor for the next call: the polish system goes to the second block
+      const Ws wp = polish_ws(w, gws + slot * ws_doubles,
+                              qp_sparse_polish_offset(n, m, uni(pl.nnzL), uni(pl.funits), uni(pl.bunits), pl.Aorig ? nnzA : 0), n, m,
+                              uni(pl.nnzL), uni(pl.funits), uni(pl.bunits));
+      sp_polish(pl, it, w, wp, kp, t, c, lane, lean);
+    } else {
+      if (lane == 0) w.hdr[kHdrStamp] = 0.0;  // the polish factorisation overwrites the ADMM factor
+      sp_polish(pl, it, w, w, kp, t, c, lane, lean);
+    }
+  }
 
   // ---- un-scale and report :544-548 ----
   double *ox = gx + b * (size_t)n, *oy = gy + b * (size_t)m;
@@ -1482,7 +1534,8 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev *_
     if (lane == 0) seen = atomicAdd(&g_sparse_active, 1);
     const bool lean = ((queue == nullptr ? (int)gridDim.x : batch) > lean_waves) || __builtin_amdgcn_readfirstlane(seen) >= lean_waves;
     const int st = sp_solve_item(*use, kp, gPx, gq, gAx, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode, wsb, wsd, lean_waves,
-                                 lean, (size_t)item, slot, t, lane, resume != 0, fbslot >= 0 ? nullptr : queue, batch, slice);
+                                 lean, (size_t)item, slot, t, lane, resume != 0, fbslot >= 0 ? nullptr : queue, batch, slice,
+                                 /*allow_reuse: the item's own slot of the main workspace*/ fbslot < 0 && slot == (size_t)item);
     wave_sync();
     if (lane == 0) {
       atomicSub(&g_sparse_active, 1);

@@ -40,14 +40,33 @@ struct SparsePlanDev {
 
 // per-item workspace, in doubles
 constexpr int kSweepPadDev = 16;  // == SparsePlanHost::kSweepPad
+#ifdef __HIPCC__
+#define SFB_HD __host__ __device__
+#else
+#define SFB_HD
+#endif
+// doubles of one copy of the numeric factor: [L values | D | scratch | zero | forward-sweep copy | backward-sweep copy | 1/D]
+SFB_HD inline size_t qp_sparse_factor_doubles(int n, int m, int nnzL, int funits, int bunits)
+{
+  return (size_t)nnzL + 2 * ((size_t)n + m) + 2 + (size_t)(funits + bunits + 2 * kSweepPadDev) * 128;
+}
+// offset of the second factor block (even, like the first one's)
+SFB_HD inline size_t qp_sparse_polish_offset(int n, int m, int nnzL, int funits, int bunits, int nnzA_compact)
+{
+  const size_t k   = (size_t)n + m;
+  const size_t off = qp_sparse_factor_doubles(n, m, nnzL, funits, bunits) + k + 6 * (size_t)n + 11 * (size_t)m + 16 +
+                     (((size_t)nnzA_compact + 1) & ~(size_t)1);
+  return (off + 1) & ~(size_t)1;
+}
 inline size_t qp_sparse_ws_doubles(int n, int m, int nnzL, int funits, int bunits, int nnzA_compact = 0)
 {
-  const size_t k = (size_t)n + m;
   // nnzA_compact: kept entries of A of a pruned plan (the kernel compacts the item's values into its workspace)
-  return (size_t)nnzL + (size_t)(funits + bunits + 2 * kSweepPadDev) * 128 + 3 * k + 6 * (size_t)n + 12 * (size_t)m + 16 +
-         (((size_t)nnzA_compact + 1) & ~(size_t)1);
-  // (accumulator layout of the factorisation: [L values | D | scratch | zero] is contiguous at the start of the block,
-  //  followed by the forward- and backward-sweep copies of the factor)
+  // Layout: factor of the ADMM matrix, iterate / scaling / constants, header (16 doubles), compacted A, and a SECOND
+  // factor block for the polish system -- used by calls with reuse_factor set (sfb.h), which keep the ADMM factor
+  // for the next call.
+  const size_t tot = qp_sparse_polish_offset(n, m, nnzL, funits, bunits, nnzA_compact) +
+                     qp_sparse_factor_doubles(n, m, nnzL, funits, bunits) + m + 4;
+  return (tot + 1) & ~(size_t)1;  // (even: the 16-byte loads of the sweep copies keep their alignment from item to item)
 }
 
 inline size_t qp_sparse_ws_doubles(const SparsePlanDev &pl)

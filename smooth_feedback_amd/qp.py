@@ -40,16 +40,18 @@ class QPSolverParams:
     eps_primal_inf: float = 1e-4
     eps_dual_inf: float = 1e-4
     max_iter: Optional[int] = None
-    max_time: Optional[float] = None  # seconds; rejected by the device path when set
+    max_time: Optional[float] = None  # seconds, on the device clock per item (include/sfb.h)
     stop_check_iter: int = 25
     polish: bool = True
     polish_iter: int = 5
     delta: float = 1e-6
+    reuse_factor: bool = False  # extension (include/sfb.h): P and A unchanged since the previous call on the workspace
 
     def to_c(self):
         p = _capi.SfbQPParams()
         _capi.lib.sfb_qp_params_default(C.byref(p))
         p.verbose = int(self.verbose)
+        p.reuse_factor = int(self.reuse_factor)
         p.alpha, p.rho, p.sigma = self.alpha, self.rho, self.sigma
         p.scaling = int(self.scaling)
         p.eps_abs, p.eps_rel = self.eps_abs, self.eps_rel

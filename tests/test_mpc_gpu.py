@@ -242,3 +242,115 @@ def test_launch_order_does_not_change_results(sfb):
         for a, b in zip(out[0], o):
             assert np.array_equal(a, b)
     assert (out[0][3] == 0).all()
+
+
+class _DeviceSolver:
+    """sfb_sparse_qp_solve_batch on a workspace that lives across calls (what the MPC swarm does every tick)."""
+
+    def __init__(self, sfb, plan, B, poison=None):
+        import torch
+        self.sfb, self.plan, self.B, self.torch = sfb, plan, B, torch
+        self.dev = torch.device("cuda:0")
+        self.ws = torch.empty((plan.workspace_bytes(B) + 7) // 8, dtype=torch.float64, device=self.dev)
+        if poison is not None:
+            self.ws.fill_(poison)
+
+    def __call__(self, Px, q, Ax, l, u, prm, warm=None):
+        torch, B, plan = self.torch, self.B, self.plan
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.dev)
+        d = [T(a) for a in (Px, q, Ax, l, u)]
+        w = [T(a) for a in warm] if warm is not None else None
+        x = torch.full((B, plan.n), np.nan, dtype=torch.float64, device=self.dev)
+        y = torch.full((B, plan.m), np.nan, dtype=torch.float64, device=self.dev)
+        obj = torch.full((B,), np.nan, dtype=torch.float64, device=self.dev)
+        it = torch.zeros(B, dtype=torch.int32, device=self.dev)
+        code = torch.full((B,), -1, dtype=torch.int32, device=self.dev)
+        plan.solve_batch_device(B, *[a.data_ptr() for a in d], x.data_ptr(), y.data_ptr(), obj.data_ptr(), it.data_ptr(),
+                                code.data_ptr(), self.ws.data_ptr(), prm, dwarm_x=w[0].data_ptr() if w else 0,
+                                dwarm_y=w[1].data_ptr() if w else 0, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return tuple(a.cpu().numpy() for a in (code, it, x, y, obj))
+
+
+@pytest.mark.parametrize("pruned", [False, True])
+@pytest.mark.parametrize("polish", [True, False])
+def test_factor_reuse_gives_the_same_bits(sfb, pruned, polish, monkeypatch):
+    """sfb_qp_params::reuse_factor (f3, the exact case): the caller vouches that P and A are unchanged since the
+    previous call on the workspace; the kernel keeps the compacted A, the scaling and the LDL' factor wherever they
+    are provably what it would recompute (c and the rho vector are re-derived and compared) and recomputes otherwise.
+    A sequence of ticks on ONE workspace with the flag set is compared, bit for bit, with the same problems solved
+    without the flag on a fresh workspace: q, l, u moving (everything kept), |q| large enough to change c (scaling
+    redone), an inequality row turning into an equality (rho changes: factor redone on the kept scaling), a tick
+    with a new A and no flag, and a flagged tick after it.  With polish the ADMM factor has to survive the polish
+    factorisation (second factor block of the workspace).  Small grid: the launches are time-sliced, items are
+    suspended and resumed by other blocks in between."""
+    monkeypatch.setenv("SFB_SP_GRID", "16")
+    variant, K, B = 6, 20, 48
+    d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
+    Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=21)
+    Av2, _, _ = M.mpc_assemble_batch(variant, K, B, seed=22)
+    keep = np.any(np.concatenate([Av, Av2]) != 0.0, axis=0) if pruned else None
+    plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K), keep=keep)
+    rng = np.random.default_rng(3)
+    Px = np.tile(Pv, (B, 1))
+    n, m = d["n"], d["m"]
+    ineq = l < u
+    q_small = 1e-3 * rng.uniform(-1, 1, (B, n))
+    q_big = q_small * 1e4                                        # |q| beyond the mean column norm of P: c changes
+    l_eq, u_eq = l.copy(), u.copy()
+    row = np.nonzero(ineq[0])[0][:3]
+    l_eq[::2, row] = u_eq[::2, row] = 0.1                        # inequality rows of every other agent become equalities
+    ticks = [                                                    # (A, q, l, u, flag)
+        (Av, q_small, l, u, True),                               # first call: nothing to keep (workspace is garbage)
+        (Av, -q_small, l - 0.01 * ineq, u + 0.02 * ineq, True),  # everything kept
+        (Av, q_big, l, u, True),                                 # c changes
+        (Av, q_big, l_eq, u_eq, True),                           # rho changes for half of the agents
+        (Av2, q_small, l, u, False),                             # new A: the caller does not set the flag
+        (Av2, q_small * 0.5, l, u + 0.01 * ineq, True),          # and may set it again afterwards
+    ]
+    run = _DeviceSolver(sfb, plan, B, poison=float("nan"))
+    warm = None
+    for t, (A_, q_, l_, u_, flag) in enumerate(ticks):
+        prm = sfb.QPSolverParams(max_iter=4000, polish=polish, reuse_factor=flag)
+        got = run(Px, q_, A_, l_, u_, prm, warm)
+        fresh = _DeviceSolver(sfb, plan, B, poison=0.0)
+        ref = fresh(Px, q_, A_, l_, u_, sfb.QPSolverParams(max_iter=4000, polish=polish), warm)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b, equal_nan=True), "tick %d" % t
+        assert (got[0] == 0).mean() > 0.9
+        warm = (got[2], got[3])
+
+
+def test_factor_reuse_really_skips_the_work(sfb):
+    """White box: with a pruned plan the kernel works on its own compacted copy of A.  A flagged call that is handed
+    GARBAGE in the kept entries of A (against the contract: the masked entries stay zero for the guard) must still
+    return the true problem's solution -- everything that depends on A (compaction, scaling, factor, residuals) came
+    from the workspace.  The same call without the flag solves the garbage problem instead."""
+    variant, K, B = 6, 20, 16
+    d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
+    Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=21)
+    keep = np.any(Av != 0.0, axis=0)
+    plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K), keep=keep)
+    Px, q = np.tile(Pv, (B, 1)), np.zeros((B, d["n"]))
+    run = _DeviceSolver(sfb, plan, B)
+    prm = sfb.QPSolverParams(max_iter=4000, reuse_factor=True)
+    first = run(Px, q, Av, l, u, prm)
+    garbage = Av * keep * 1.5 + 0.25 * keep
+    again = run(Px, q, garbage, l, u, prm)
+    for a, b in zip(first, again):
+        assert np.array_equal(a, b)
+    other = run(Px, q, garbage, l, u, sfb.QPSolverParams(max_iter=4000))
+    assert not np.array_equal(other[2], first[2])
+
+
+def test_double_integrator_mpc_reuses_its_factor(sfb):
+    """examples/mpc_doubleintegrator.cpp (x = (p, v), |u| <= 0.5, K = 20, tf = 5, 50 ms ticks) in closed loop: a linear
+    system, so the QP matrices of consecutive ticks are identical; the C++ solver front (QPSolver::solve) recognises
+    that and flags reuse_factor from the second tick on.  Inputs and iteration counts equal those of the same loop
+    with the reuse switched off, bit for bit; the loop converges to the desired trajectory within the input limit."""
+    r = M.mpc_doubleintegrator(40)
+    assert r["reuse_count"] == 39
+    assert np.array_equal(r["u"], r["u_ref"]) and np.array_equal(r["iter"], r["iter_ref"])
+    assert (r["code"] == 0).all()
+    assert np.abs(r["u"]).max() <= 0.5 + 1e-3 and np.abs(r["u"][0]) > 0.4    # starts 0.6 off: saturated input
+    print("double integrator closed loop, 40 ticks: %.1f ms with factor reuse, %.1f ms without" % tuple(1e3 * r["seconds"]))
