@@ -32,6 +32,7 @@ class OracleQPParams(C.Structure):
         ("polish_iter", C.c_uint32),
         ("delta", C.c_float),
         ("verbose", C.c_int32),
+        ("reuse_factor", C.c_int32),
     ]
 
 

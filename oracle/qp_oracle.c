@@ -43,6 +43,7 @@ void oracle_qp_params_default(oracle_qp_params *p)
   p->polish_iter     = 5;
   p->delta           = 1e-6f;
   p->verbose         = 0;
+  p->reuse_factor    = 0;
 }
 
 /* ------------------------------------------------------------------------------------------

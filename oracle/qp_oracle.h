@@ -43,6 +43,8 @@ typedef struct oracle_qp_params {
   uint32_t polish_iter;   /* :65 */
   float delta;            /* :67 */
   int32_t verbose;        /* :32 (ignored by the oracle) */
+  int32_t reuse_factor;   /* product extension (include/sfb.h): results never depend on it; ignored by the oracle,
+                             which like the reference scales and factorises on every solve */
 } oracle_qp_params;
 
 void oracle_qp_params_default(oracle_qp_params *p);
