@@ -298,6 +298,7 @@ int sfbx_mpc_swarm_step(int variant, int K, double tf, int64_t batch, uint64_t s
 
 }  // extern "C"
 
+#include <smooth/feedback/ocp_to_qp.hpp>
 #include <smooth/feedback/qp_solver.hpp>  // the reference's include path and namespace (forwarding header)
 
 namespace {
@@ -381,6 +382,70 @@ int sfbx_test_qp_solver_api(double * primal_dense, double * primal_sparse, doubl
       return 203;
     return 0;
   } catch (const std::exception &) {
+    return -1;
+  }
+}
+
+int sfbx_test_ocp_to_qp_basic(double * out, int solve)
+{
+  // tests/test_ocp_to_qp.cpp:41-107 (OcpToQp.Basic) with the generic front, through the reference's include path:
+  // theta = |xf|^2 + 2 q, f = (v, u), g = u^2, cr = u in [-1, 1], ce = xf in [-5, 5]^2, Mesh<5,5> refined to two
+  // intervals of 5 nodes, tf = 2, linearised around xl(t) = (0.05 t^2, 0.1 t), ul = 0.1.
+  namespace sf = smooth::feedback;
+  using X2 = sf::Rn<2>;
+  using U1 = sf::Rn<1>;
+  try {
+    const auto theta = [](double, const X2 &, const X2 & xf, const sf::Vec<1> & q) { return xf.v[0] * xf.v[0] + xf.v[1] * xf.v[1] + 2 * q[0]; };
+    const auto f     = [](double, const X2 & x, const U1 & u) { return sf::Vec<2>{x.v[1], u.v[0]}; };
+    const auto g     = [](double, const X2 &, const U1 & u) { return sf::Vec<1>{u.v[0] * u.v[0]}; };
+    const auto cr    = [](double, const X2 &, const U1 & u) { return sf::Vec<1>{u.v[0]}; };
+    const auto ce    = [](double, const X2 &, const X2 & xf, const sf::Vec<1> &) { return sf::Vec<2>{xf.v[0], xf.v[1]}; };
+    const auto ocp   = sf::make_ocp<X2, U1>(theta, f, g, cr, {-1.0}, {1.0}, ce, {-5.0, -5.0}, {5.0, 5.0});
+    const sf::Mesh mesh(2, 5);  // Mesh<5,5> + refine_ph(0, 10)
+    constexpr double tf = 2.;
+    const auto xl_fun = [](double t) { X2 x; x.v = {0.05 * t * t, 0.1 * t}; return x; };
+    const auto ul_fun = [](double) { U1 u; u.v = {0.1}; return u; };
+    const auto qp = sf::ocp_to_qp(ocp, mesh, tf, xl_fun, ul_fun);
+    const int N = mesh.N_colloc();
+    // :81-86 sizes
+    out[0] = qp.n; out[1] = qp.m; out[2] = (double)qp.q.size(); out[3] = (double)qp.l.size(); out[4] = (double)qp.u.size();
+    out[5] = (double)(qp.P_colptr.size() - 1); out[6] = (double)(qp.A_rowptr.size() - 1);
+    // :90-106 the exact trajectory satisfies the constraints
+    const double x0 = 3, v0 = -0.3, u0 = 0.1;
+    std::vector<double> var(qp.n);
+    for (int i = 0; i <= N; ++i) {
+      const double t = tf * mesh.node(i);
+      var[2 * i] = x0 + v0 * t + u0 * t * t / 2; var[2 * i + 1] = v0 + u0 * t;
+    }
+    for (int i = 0; i < N; ++i) var[2 * (N + 1) + i] = u0;
+    double lo = 1e300, hi = 1e300;
+    for (int r = 0; r < qp.m; ++r) {
+      double s = 0.0;
+      for (int q = qp.A_rowptr[r]; q < qp.A_rowptr[r + 1]; ++q) s += qp.A_val[q] * var[qp.A_colind[q]];
+      lo = std::min(lo, s - qp.l[r]);
+      hi = std::min(hi, qp.u[r] - s);
+    }
+    out[7] = lo; out[8] = hi;
+    // cost entries: d2(theta)/dxf^2 / 2 = I on the x_N block, qo_q w_i tf d2g/du^2 = 2 * w_i tf * 2 on u_i
+    out[9]  = qp.P_val[qp.P_colptr[2 * N + 1] - 1];                    // P(x_N[0], x_N[0])
+    out[10] = qp.P_val[qp.P_colptr[2 * (N + 1) + 1] - 1] / (mesh.weight(0) * tf);  // P(u_0, u_0) / (w_0 tf) = 4
+    out[11] = qp.q[2 * (N + 1)] / (mesh.weight(0) * tf);               // qo_q dg/du = 2 * 2 ul = 0.4
+    if (solve) {  // examples/ocp_se2_qp.cpp:33-41: solve_qp + qpsol_to_ocpsol
+      sf::QPSolverParams prm;
+      prm.max_iter = 4000;
+      const auto sol  = sf::solve_qp(qp, prm);
+      const auto osol = sf::qpsol_to_ocpsol(ocp, mesh, sol, tf, xl_fun, ul_fun);
+      out[12] = (double)(int)sol.code;
+      out[13] = osol.u(0.5).v[0];
+      out[14] = osol.x(tf).v[0];
+      out[15] = osol.x(tf).v[1];
+      out[16] = osol.x(0.0).v[0];
+      // the interpolated state equals linearisation + node value at a node
+      out[17] = osol.x(tf * mesh.node(3)).v[1] - (xl_fun(tf * mesh.node(3)).v[1] + sol.primal[2 * 3 + 1]);
+    }
+    return 0;
+  } catch (const std::exception & e) {
+    std::fprintf(stderr, "sfbx_test_ocp_to_qp_basic: %s\n", e.what());
     return -1;
   }
 }

@@ -29,6 +29,11 @@ int sfbx_test_mpc_se2(double *u_out, int32_t *codes, int32_t *traj_sizes);
  * seconds[2] = wall time of the two loops.  Needs a GPU. */
 int sfbx_test_mpc_doubleintegrator(int ticks, double *u_out, uint32_t *iters, int32_t *codes, double *u_ref, uint32_t *iters_ref,
                                    int64_t *reuse_count, double *seconds);
+/* tests/test_ocp_to_qp.cpp:41-107 with the GENERIC front ocp_to_qp() (include/smooth_feedback_amd/ocp_to_qp.hpp):
+ * out[0..6] sizes (n, m, |q|, |l|, |u|, cols of P, rows of A), out[7..8] = min(A var - l), min(u - A var) for the exact
+ * trajectory (:105-106), out[9..11] cost entries; solve != 0 (needs a GPU): out[12] status of solve_qp, out[13..17]
+ * values of the qpsol_to_ocpsol() trajectory. */
+int sfbx_test_ocp_to_qp_basic(double *out, int solve);
 /* tests/test_ocp_to_qp.cpp:41-107 through the MPC transcription (double integrator, two intervals of 5 LGR nodes, tf = 2):
  * out = {min(A var - l), min(u - A var), N, n, m, intervals} for the exact parabola trajectory.  Host only (no GPU). */
 int sfbx_test_ocp_to_qp_parabola(double *out);

@@ -133,3 +133,12 @@ def mpc_doubleintegrator(ticks):
     rc = lib().sfbx_test_mpc_doubleintegrator(ticks, _p(u), _p(it), _p(codes), _p(ur), _p(itr), C.byref(cnt), _p(sec))
     assert rc == 0, rc
     return dict(u=u, iter=it, code=codes, u_ref=ur, iter_ref=itr, reuse_count=cnt.value, seconds=sec)
+
+
+def ocp_to_qp_basic(solve=False):
+    """tests/test_ocp_to_qp.cpp:41-107 with the generic ocp_to_qp() front; solve=True also runs solve_qp and
+    qpsol_to_ocpsol (needs a GPU)."""
+    out = np.full(18, np.nan)
+    rc = lib().sfbx_test_ocp_to_qp_basic(_p(out), int(solve))
+    assert rc == 0, rc
+    return out

@@ -354,3 +354,17 @@ def test_double_integrator_mpc_reuses_its_factor(sfb):
     assert (r["code"] == 0).all()
     assert np.abs(r["u"]).max() <= 0.5 + 1e-3 and np.abs(r["u"][0]) > 0.4    # starts 0.6 off: saturated input
     print("double integrator closed loop, 40 ticks: %.1f ms with factor reuse, %.1f ms without" % tuple(1e3 * r["seconds"]))
+
+
+def test_generic_ocp_to_qp_solves_and_maps_back(sfb):
+    """examples/ocp_se2_qp.cpp:33-48 flow on the problem of tests/test_ocp_to_qp.cpp: ocp_to_qp() -> solve_qp (sparse
+    kernel) -> qpsol_to_ocpsol().  The QP is in deviations from (xl, ul) and nothing pins x_0, so the end-point cost
+    decides dx_N: the reference enters HALF the Hessian of theta into P (ocp_to_qp.hpp:191-193, block_add(..., 0.5))
+    next to the full gradient in q (:195-196), i.e. it minimises 1/2 dx' (1/2 H) dx + g' dx with H = 2 I,
+    g = 2 xl(tf): dx_N = -2 xl(tf) and x(tf) = -xl(tf) = (-0.2, -0.2) -- reproduced as is.  Optimal, input within
+    |u| <= 1; the returned trajectories are the linearisation plus the interpolated deviations (exact at nodes)."""
+    o = M.ocp_to_qp_basic(solve=True)
+    assert o[12] == 0                        # Optimal
+    assert abs(o[13]) <= 1.0 + 1e-3          # input within the running constraint
+    assert abs(o[14] + 0.2) < 1e-2 and abs(o[15] + 0.2) < 1e-2
+    assert abs(o[17]) < 1e-12

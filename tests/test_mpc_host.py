@@ -137,3 +137,18 @@ def test_exact_parabola_satisfies_the_transcription():
     lo, hi, N, n, m, nivals = out
     assert (N, nivals) == (10, 2) and n == 2 * 11 + 10 and m == 2 * 10 + 10 + 2
     assert lo >= -1e-8 and hi >= -1e-8, (lo, hi)
+
+
+def test_generic_ocp_to_qp_reproduces_the_reference_test():
+    """tests/test_ocp_to_qp.cpp:41-107 (OcpToQp.Basic) as written there, through the generic front ocp_to_qp()
+    (include/smooth_feedback_amd/ocp_to_qp.hpp, reached by the reference's include path <smooth/feedback/ocp_to_qp.hpp>):
+    sizes of P, q, A, l, u agree (:81-86) and the exact trajectory, stacked as [x_0 .. x_N | u_0 .. u_{N-1}], satisfies
+    l <= A var <= u to 1e-8 (:105-106).  Cost entries: theta = |xf|^2 + 2 q, g = u^2 give P(x_N, x_N) = 1/2 d2theta = 1,
+    P(u_i, u_i) = dtheta/dq * w_i tf * d2g = 4 w_i tf and q(u_i) = dtheta/dq * w_i tf * dg/du = 0.4 w_i tf at ul = 0.1
+    (ocp_to_qp.hpp:172-194); derivatives by finite differences here."""
+    o = M.ocp_to_qp_basic()
+    N = 10
+    n, m = 2 * (N + 1) + N, 2 * N + N + 2
+    assert tuple(o[:7]) == (n, m, n, m, m, n, m)
+    assert o[7] >= -1e-8 and o[8] >= -1e-8, (o[7], o[8])
+    assert abs(o[9] - 1.0) < 1e-4 and abs(o[10] - 4.0) < 1e-4 and abs(o[11] - 0.4) < 1e-6
