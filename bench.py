@@ -55,13 +55,14 @@ class DenseQPWorkload:
         self.out = torch.empty((2, batch), dtype=torch.int32, device=device)  # [iter; code]
         self.units_per_step = batch
         self.bytes_per_unit = qp_dense_algorithmic_bytes(n, m)
+        self.ws = sfb.Workspace.for_dense(batch, n, m, self.prm)   # created once: no allocation inside a step
 
     def step(self, stream):
         P, q, A, l, u = self.dev
-        self.sfb.solve_qp_batch_device(self.B, self.n, self.m, P.data_ptr(), q.data_ptr(), A.data_ptr(),
-                                       l.data_ptr(), u.data_ptr(), self.x.data_ptr(), self.y.data_ptr(),
-                                       self.obj.data_ptr(), self.out[0].data_ptr(), self.out[1].data_ptr(),
-                                       self.prm, stream=stream.cuda_stream)
+        self.sfb.solve_qp_batch_device_ws(self.B, self.n, self.m, P.data_ptr(), q.data_ptr(), A.data_ptr(),
+                                          l.data_ptr(), u.data_ptr(), self.x.data_ptr(), self.y.data_ptr(),
+                                          self.obj.data_ptr(), self.out[0].data_ptr(), self.out[1].data_ptr(),
+                                          self.ws, self.prm, stream=stream.cuda_stream)
 
     def small_outputs(self):
         return self.out

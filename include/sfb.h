@@ -138,12 +138,38 @@ void sfb_qp_params_default(sfb_qp_params *prm);
  *   x [batch][n] primal, y [batch][m] dual, obj [batch] (nullable), iter [batch] (nullable),
  *   code [batch] (sfb_qp_status values).
  * Requires 1 <= n, 1 <= m (n+m > SFB_QP_DENSE_MAX_K: see there; n+m <= 19 198).
- * Stream-ordered working memory (hipMallocAsync) is taken per call for n+m > 16.
+ * Working memory: sizes with n+m <= 32 (the four-per-wave kernel's records and queue) and n+m > SFB_QP_DENSE_MAX_K
+ * (the factor in HBM) need device memory beyond the arguments.  This entry point takes it stream-ordered
+ * (hipMallocAsync / hipFreeAsync) per call; sfb_qp_dense_solve_batch_ws below takes it from the caller instead.
  */
 sfb_status sfb_qp_dense_solve_batch(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P,
                                     const double *q, const double *A, const double *l, const double *u,
                                     const double *warm_x, const double *warm_y, double *x, double *y,
                                     double *obj, uint32_t *iter, int32_t *code, void *stream);
+
+/*
+ * Explicit workspaces.  The reference's QPSolver owns its work memory, allocated once by analyze()
+ * (qp_solver.hpp:297-338) and re-used by every solve(); the equivalent here is an opaque device buffer the caller
+ * creates once and hands to every call, so that no call allocates:
+ *   sfb_qp_dense_workspace_bytes   device bytes a dense call of this shape needs (0 for 32 < n+m <= 64)
+ *   sfb_workspace_create/destroy   device memory on the CURRENT device (bytes = 0 is allowed)
+ *   sfb_workspace_info             its device pointer and size -- the pointer is also what the shared-pattern sparse
+ *                                  entry points take as `workspace` (sfb_sparse_qp_plan_workspace_bytes)
+ *   sfb_qp_dense_solve_batch_ws    sfb_qp_dense_solve_batch on that memory; asynchronous on `stream`.  One call at
+ *                                  a time per workspace (calls on the same stream are ordered; use one workspace
+ *                                  per stream otherwise).  SFB_ERR_INVALID_ARG if the workspace is too small or of
+ *                                  another device.
+ */
+typedef struct sfb_workspace sfb_workspace;
+sfb_status sfb_qp_dense_workspace_bytes(const sfb_qp_params *prm, int64_t batch, int n, int m, int64_t *bytes);
+sfb_status sfb_workspace_create(int64_t bytes, sfb_workspace **out);
+void sfb_workspace_destroy(sfb_workspace *workspace);
+sfb_status sfb_workspace_info(const sfb_workspace *workspace, void **device_ptr, int64_t *bytes);
+sfb_status sfb_qp_dense_solve_batch_ws(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P,
+                                       const double *q, const double *A, const double *l, const double *u,
+                                       const double *warm_x, const double *warm_y, double *x, double *y,
+                                       double *obj, uint32_t *iter, int32_t *code, sfb_workspace *workspace,
+                                       void *stream);
 
 /* Same with host pointers (H2D copy, solve, D2H copy, synchronous) on the current device. */
 sfb_status sfb_qp_dense_solve_batch_host(const sfb_qp_params *prm, int64_t batch, int n, int m,

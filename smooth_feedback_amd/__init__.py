@@ -5,7 +5,7 @@ is the thin host-side mirror of the reference interface used by tests and bench.
 """
 from . import _capi  # noqa: F401  (fails loudly if libsfb.so is missing)
 from .qp import (QPBatchSolution, QPSolution, QPSolutionStatus, QPSolver, QPSolverParams,  # noqa: F401
-                 QuadraticProgram, pack_colmajor, random_qp_batch, solve_qp, solve_qp_batch_device,
+                 QuadraticProgram, pack_colmajor, random_qp_batch, solve_qp, solve_qp_batch_device, solve_qp_batch_device_ws, Workspace,
                  solve_qp_batch_host, QuadraticProgramSparse, SparseQPPlan, solve_qp_sparse)
 
 from .ekf import (ekf_predict_batch_device, ekf_predict_batch_host, ekf_predict_stepper_batch_device,  # noqa: F401

@@ -71,6 +71,12 @@ def _load():
     L.sfb_qp_params_default.restype = None
     L.sfb_qp_dense_solve_batch.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12 + [vp]
     L.sfb_qp_dense_solve_batch_host.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12
+    L.sfb_qp_dense_solve_batch_ws.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12 + [vp, vp]
+    L.sfb_qp_dense_workspace_bytes.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32, C.POINTER(C.c_int64)]
+    L.sfb_workspace_create.argtypes = [i64, C.POINTER(C.c_void_p)]
+    L.sfb_workspace_destroy.argtypes = [C.c_void_p]
+    L.sfb_workspace_destroy.restype = None
+    L.sfb_workspace_info.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     i32p = C.c_void_p
     L.sfb_sparse_qp_plan_create.argtypes = [i32, i32, i32p, i32p, i32p, i32p, i32, i32p, C.POINTER(C.c_void_p)]
     L.sfb_sparse_qp_plan_create_staged.argtypes = [i32, i32, i32p, i32p, i32p, i32p, i32, i32p, i32p, C.POINTER(C.c_void_p)]

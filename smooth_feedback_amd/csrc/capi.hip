@@ -121,22 +121,26 @@ sfb_status check_qp_args(const sfb_qp_params *prm, int64_t batch, int n, int m, 
 // (bit-identical to the dense oracle, i.e. to the reference's dense branch as far as that is pinned)
 sfb_status dense_big(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P, const double *q, const double *A,
                      const double *l, const double *u, const double *wx, const double *wy, double *x, double *y, double *obj,
-                     uint32_t *iter, int32_t *code, hipStream_t stream)
+                     uint32_t *iter, int32_t *code, hipStream_t stream, void *workspace)
 {
   const size_t bytes = (size_t)batch * sfb::qp_dense_big_ws_doubles(n, m) * sizeof(double);
-  char *buf          = nullptr;
+  char *buf          = static_cast<char *>(workspace);  // the caller's (sfb_workspace), or per call below
   bool async_alloc   = true;
-  hipError_t e       = hipMallocAsync(reinterpret_cast<void **>(&buf), bytes, stream);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    async_alloc = false;
-    e           = hipMalloc(reinterpret_cast<void **>(&buf), bytes);
-    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+  hipError_t e       = hipSuccess;
+  if (!workspace) {
+    e = hipMallocAsync(reinterpret_cast<void **>(&buf), bytes, stream);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      async_alloc = false;
+      e           = hipMalloc(reinterpret_cast<void **>(&buf), bytes);
+      if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    }
   }
   const sfb::DenseKernelParams kp = make_kernel_params(prm, n, m);
   const sfb::QpBatch g{P, q, A, l, u, wx, wy, x, y, obj, iter, code};
   e = sfb::qp_dense_big_launch(kp, batch, g, reinterpret_cast<double *>(buf), stream);
-  if (async_alloc) {
+  if (workspace) {
+  } else if (async_alloc) {
     (void)hipFreeAsync(buf, stream);
   } else {
     (void)hipStreamSynchronize(stream);
@@ -161,9 +165,7 @@ __global__ void __launch_bounds__(64) dense_A_to_rows_kernel(const double *__res
   }
 }
 
-sfb_status dense_via_sparse(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P, const double *q,
-                            const double *A, const double *l, const double *u, const double *wx, const double *wy,
-                            double *x, double *y, double *obj, uint32_t *iter, int32_t *code, hipStream_t stream)
+sfb_status dense_full_pattern_plan(int n, int m, sfb_sparse_qp_plan **out)
 {
   static std::mutex mu;
   static std::map<std::pair<int, int>, sfb_sparse_qp_plan *> plans;  // one symbolic analysis per shape, kept
@@ -186,29 +188,55 @@ sfb_status dense_via_sparse(const sfb_qp_params *prm, int64_t batch, int n, int 
       plan = it->second;
     }
   }
-  int64_t wsb = 0;
-  sfb_status st = sfb_sparse_qp_plan_info(plan, nullptr, nullptr, &wsb);
+  *out = plan;
+  return SFB_OK;
+}
+
+// bytes of one dense_via_sparse call: A by rows, then the sparse kernel's workspace
+sfb_status dense_via_sparse_bytes(sfb_sparse_qp_plan *plan, int64_t batch, int n, int m, size_t *abytes, size_t *bytes)
+{
+  int64_t wsb   = 0;
+  sfb_status st = sfb_sparse_qp_plan_workspace_bytes(plan, batch, &wsb);
   if (st != SFB_OK) return st;
-  const size_t abytes = (size_t)batch * (size_t)m * n * sizeof(double);
-  const size_t bytes  = abytes + (size_t)batch * (size_t)wsb;
-  char *buf           = nullptr;
-  bool async_alloc    = true;
-  hipError_t e        = hipMallocAsync(reinterpret_cast<void **>(&buf), bytes, stream);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    async_alloc = false;
-    e           = hipMalloc(reinterpret_cast<void **>(&buf), bytes);
-    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+  *abytes = ((size_t)batch * (size_t)m * n * sizeof(double) + 255) / 256 * 256;
+  *bytes  = *abytes + (size_t)wsb;
+  return SFB_OK;
+}
+
+sfb_status dense_via_sparse(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P, const double *q,
+                            const double *A, const double *l, const double *u, const double *wx, const double *wy,
+                            double *x, double *y, double *obj, uint32_t *iter, int32_t *code, hipStream_t stream,
+                            void *workspace)
+{
+  sfb_sparse_qp_plan *plan = nullptr;
+  sfb_status st            = dense_full_pattern_plan(n, m, &plan);
+  if (st != SFB_OK) return st;
+  size_t abytes = 0, bytes = 0;
+  st = dense_via_sparse_bytes(plan, batch, n, m, &abytes, &bytes);
+  if (st != SFB_OK) return st;
+  char *buf        = static_cast<char *>(workspace);
+  bool async_alloc = true;
+  hipError_t e     = hipSuccess;
+  if (!workspace) {
+    e = hipMallocAsync(reinterpret_cast<void **>(&buf), bytes, stream);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      async_alloc = false;
+      e           = hipMalloc(reinterpret_cast<void **>(&buf), bytes);
+      if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    }
   }
   double *Ax = reinterpret_cast<double *>(buf);
   hipLaunchKernelGGL(dense_A_to_rows_kernel, dim3((unsigned)batch), dim3(64), 0, stream, A, Ax, n, m);
   if ((e = hipGetLastError()) != hipSuccess) {
-    if (async_alloc) (void)hipFreeAsync(buf, stream);
+    if (workspace) {
+    } else if (async_alloc) (void)hipFreeAsync(buf, stream);
     else (void)hipFree(buf);
     return hip_fail(e, "dense_A_to_rows_kernel launch");
   }
   st = sfb_sparse_qp_solve_batch(plan, prm, batch, P, q, Ax, l, u, wx, wy, x, y, obj, iter, code, buf + abytes, stream);
-  if (async_alloc) {
+  if (workspace) {
+  } else if (async_alloc) {
     (void)hipFreeAsync(buf, stream);
   } else {
     (void)hipStreamSynchronize(stream);
@@ -259,28 +287,129 @@ void sfb_qp_params_default(sfb_qp_params *p)
   p->reuse_factor    = 0;
 }
 
+struct sfb_workspace {
+  void *mem    = nullptr;
+  size_t bytes = 0;
+  int device   = -1;
+};
+
+// device workspace one dense call needs beyond its arguments (0: the LDS-resident one-QP-per-wave kernels)
+static sfb_status dense_workspace_need(const sfb_qp_params *prm, int64_t batch, int n, int m, size_t *need)
+{
+  const int k = n + m;
+  *need       = 0;
+  if (k > SFB_QP_DENSE_MAX_K) {
+    static const bool big_off = [] { const char *v = getenv("SFB_QP_DENSE_BIG"); return v && v[0] == '0'; }();
+    if (k <= sfb::kDenseBigMaxK && !big_off) {
+      *need = (size_t)batch * sfb::qp_dense_big_ws_doubles(n, m) * sizeof(double);
+      return SFB_OK;
+    }
+    sfb_sparse_qp_plan *plan = nullptr;
+    sfb_status st            = dense_full_pattern_plan(n, m, &plan);
+    if (st != SFB_OK) return st;
+    size_t abytes = 0;
+    return dense_via_sparse_bytes(plan, batch, n, m, &abytes, need);
+  }
+  (void)prm;  // (a time limit sends k <= 32 to the one-per-wave kernels, which need none: the bound below still holds)
+  if (k <= 32) *need = sfb::qp_dense4_ws_bytes(n, m, batch);
+  return SFB_OK;
+}
+
+static sfb_status dense_solve_impl(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P, const double *q,
+                                   const double *A, const double *l, const double *u, const double *warm_x,
+                                   const double *warm_y, double *x, double *y, double *obj, uint32_t *iter, int32_t *code,
+                                   sfb_workspace *ws, bool ws_given, void *stream)
+{
+  sfb_status st = check_qp_args(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, code);
+  if (st != SFB_OK) return st;
+  if (ws_given && !ws) return fail(SFB_ERR_INVALID_ARG, "workspace is NULL");
+  st = require_device();
+  if (st != SFB_OK) return st;
+  if (batch == 0) return SFB_OK;
+  void *wsmem = nullptr;
+  if (ws) {
+    size_t need = 0;
+    st          = dense_workspace_need(prm, batch, n, m, &need);
+    if (st != SFB_OK) return st;
+    if (ws->bytes < need) return fail(SFB_ERR_INVALID_ARG, "workspace too small (sfb_qp_dense_workspace_bytes)");
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != ws->device)
+      return fail(SFB_ERR_INVALID_ARG, "workspace belongs to another device than the current one");
+    wsmem = need ? ws->mem : nullptr;
+  }
+  if (n + m > SFB_QP_DENSE_MAX_K) {
+    // SFB_QP_DENSE_BIG=0 (A/B, tests): route these sizes to the un-pivoted sparse kernel as well
+    static const bool big_off = [] { const char *v = getenv("SFB_QP_DENSE_BIG"); return v && v[0] == '0'; }();
+    if (n + m <= sfb::kDenseBigMaxK && !big_off)
+      return dense_big(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code, static_cast<hipStream_t>(stream),
+                       wsmem);
+    return dense_via_sparse(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code,
+                            static_cast<hipStream_t>(stream), wsmem);
+  }
+  const sfb::DenseKernelParams kp = make_kernel_params(prm, n, m);
+  hipError_t e = sfb::qp_dense_launch(kp, batch, P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code,
+                                      static_cast<hipStream_t>(stream), wsmem);
+  if (e != hipSuccess) return hip_fail(e, "qp_dense_kernel launch");
+  return SFB_OK;
+}
+
 sfb_status sfb_qp_dense_solve_batch(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P,
                                     const double *q, const double *A, const double *l, const double *u,
                                     const double *warm_x, const double *warm_y, double *x, double *y, double *obj,
                                     uint32_t *iter, int32_t *code, void *stream)
 {
-  sfb_status st = check_qp_args(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, code);
+  return dense_solve_impl(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code, nullptr, false, stream);
+}
+
+sfb_status sfb_qp_dense_solve_batch_ws(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P,
+                                       const double *q, const double *A, const double *l, const double *u,
+                                       const double *warm_x, const double *warm_y, double *x, double *y, double *obj,
+                                       uint32_t *iter, int32_t *code, sfb_workspace *workspace, void *stream)
+{
+  return dense_solve_impl(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code, workspace, true, stream);
+}
+
+sfb_status sfb_qp_dense_workspace_bytes(const sfb_qp_params *prm, int64_t batch, int n, int m, int64_t *bytes)
+{
+  if (!prm || !bytes) return fail(SFB_ERR_INVALID_ARG, "NULL argument");
+  if (batch < 0 || n < 1 || m < 1) return fail(SFB_ERR_INVALID_ARG, "batch < 0 or n, m < 1");
+  size_t need   = 0;
+  sfb_status st = dense_workspace_need(prm, batch, n, m, &need);
   if (st != SFB_OK) return st;
-  st = require_device();
+  *bytes = (int64_t)need;
+  return SFB_OK;
+}
+
+sfb_status sfb_workspace_create(int64_t bytes, sfb_workspace **out)
+{
+  if (!out || bytes < 0) return fail(SFB_ERR_INVALID_ARG, "out is NULL or bytes < 0");
+  *out          = nullptr;
+  sfb_status st = require_device();
   if (st != SFB_OK) return st;
-  if (batch == 0) return SFB_OK;
-  if (n + m > SFB_QP_DENSE_MAX_K) {
-    // SFB_QP_DENSE_BIG=0 (A/B, tests): route these sizes to the un-pivoted sparse kernel as well
-    static const bool big_off = [] { const char *v = getenv("SFB_QP_DENSE_BIG"); return v && v[0] == '0'; }();
-    if (n + m <= sfb::kDenseBigMaxK && !big_off)
-      return dense_big(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code, static_cast<hipStream_t>(stream));
-    return dense_via_sparse(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code,
-                            static_cast<hipStream_t>(stream));
+  auto *w       = new sfb_workspace();
+  hipError_t e  = hipGetDevice(&w->device);
+  if (e == hipSuccess && bytes > 0) e = hipMalloc(&w->mem, (size_t)bytes);
+  if (e != hipSuccess) {
+    delete w;
+    return hip_fail(e, "hipMalloc(workspace)");
   }
-  const sfb::DenseKernelParams kp = make_kernel_params(prm, n, m);
-  hipError_t e = sfb::qp_dense_launch(kp, batch, P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code,
-                                      static_cast<hipStream_t>(stream));
-  if (e != hipSuccess) return hip_fail(e, "qp_dense_kernel launch");
+  w->bytes = (size_t)bytes;
+  *out     = w;
+  return SFB_OK;
+}
+
+void sfb_workspace_destroy(sfb_workspace *ws)
+{
+  if (!ws) return;
+  if (ws->mem) (void)hipFree(ws->mem);
+  delete ws;
+}
+
+sfb_status sfb_workspace_info(const sfb_workspace *ws, void **device_ptr, int64_t *bytes)
+{
+  if (!ws) return fail(SFB_ERR_INVALID_ARG, "workspace is NULL");
+  if (device_ptr) *device_ptr = ws->mem;
+  if (bytes) *bytes = (int64_t)ws->bytes;
   return SFB_OK;
 }
 

@@ -281,14 +281,15 @@ size_t qp_dense_lds_bytes(int n, int m)
 
 hipError_t qp_dense_launch(const DenseKernelParams &kp, int64_t batch, const double *P, const double *q,
                            const double *A, const double *l, const double *u, const double *wx, const double *wy,
-                           double *x, double *y, double *obj, uint32_t *iter, int32_t *code, hipStream_t stream)
+                           double *x, double *y, double *obj, uint32_t *iter, int32_t *code, hipStream_t stream,
+                           void *workspace)
 {
   const int k        = kp.n + kp.m;
   const char *env4 = getenv("SFB_QP_DENSE4");  // A/B and tests: 0 selects the one-QP-per-wave kernels
   const int dense4 = env4 ? atoi(env4) : 1;
   if (k <= 32 && dense4 && kp.max_time_ns < 0) {  // (a time limit is implemented by the one-QP-per-wave kernels)
     const QpBatch g{P, q, A, l, u, wx, wy, x, y, obj, iter, code};
-    return qp_dense4_launch(kp, batch, g, stream);
+    return qp_dense4_launch(kp, batch, g, stream, workspace);
   }
   size_t lds         = qp_dense_lds_bytes(kp.n, kp.m);
   if (const char *pad = getenv("SFB_QP_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments only

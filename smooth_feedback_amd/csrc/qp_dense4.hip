@@ -866,7 +866,7 @@ __global__ void __launch_bounds__(64) qp_dense4_finish_kernel(const DenseKernelP
 size_t qp_dense4_lds_bytes(int n, int m) { return (size_t)kSlots * slot4_doubles(n, m) * sizeof(double); }
 
 template<int NB>
-static hipError_t launch4(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, int ncu, hipStream_t stream)
+static hipError_t launch4(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, int ncu, hipStream_t stream, void *workspace)
 {
   // per-launch workspace: QP records, then the queue (4 counters on their own cache lines + ring of `batch`
   // 8-byte entries); stream-ordered allocation (no device synchronisation in the steady state)
@@ -874,18 +874,23 @@ static hipError_t launch4(const DenseKernelParams &kp, int64_t batch, const QpBa
   const size_t rbytes = (size_t)batch * (size_t)R.size * sizeof(double);
   const size_t qbytes = 64 * sizeof(unsigned) + 2 * (size_t)batch * sizeof(unsigned long long);
   const size_t bytes  = rbytes + qbytes;
-  double *wsp        = nullptr;
+  double *wsp        = static_cast<double *>(workspace);  // the caller's (sfb_workspace), or per-launch below
+  const bool owned   = workspace == nullptr;
   bool async_alloc   = true;
-  hipError_t e       = hipMallocAsync(reinterpret_cast<void **>(&wsp), bytes, stream);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    async_alloc = false;
-    e           = hipMalloc(reinterpret_cast<void **>(&wsp), bytes);
-    if (e != hipSuccess) return e;
+  hipError_t e       = hipSuccess;
+  if (owned) {
+    e = hipMallocAsync(reinterpret_cast<void **>(&wsp), bytes, stream);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      async_alloc = false;
+      e           = hipMalloc(reinterpret_cast<void **>(&wsp), bytes);
+      if (e != hipSuccess) return e;
+    }
   }
   unsigned *queue = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(wsp) + rbytes);
   e               = hipMemsetAsync(queue, 0, qbytes, stream);
   if (e != hipSuccess) {
+    if (!owned) return e;
     if (async_alloc) (void)hipFreeAsync(wsp, stream);
     else (void)hipFree(wsp);
     return e;
@@ -913,6 +918,7 @@ static hipError_t launch4(const DenseKernelParams &kp, int64_t batch, const QpBa
                        slice_checks);
   hipLaunchKernelGGL((qp_dense4_finish_kernel<NB>), full, block, lds1, stream, kp, g, wsp);
   e = hipGetLastError();
+  if (!owned) return e;
   if (async_alloc) {
     const hipError_t e2 = hipFreeAsync(wsp, stream);
     if (e == hipSuccess) e = e2;
@@ -923,7 +929,13 @@ static hipError_t launch4(const DenseKernelParams &kp, int64_t batch, const QpBa
   return e;
 }
 
-hipError_t qp_dense4_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream)
+size_t qp_dense4_ws_bytes(int n, int m, int64_t batch)
+{
+  const size_t rsize = (n + m <= 16) ? (size_t)rec4_layout<1>(n, m).size : (size_t)rec4_layout<2>(n, m).size;
+  return (size_t)batch * rsize * sizeof(double) + 64 * sizeof(unsigned) + 2 * (size_t)batch * sizeof(unsigned long long);
+}
+
+hipError_t qp_dense4_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream, void *workspace)
 {
   static int cus[64] = {};
   int dev = 0;
@@ -934,7 +946,7 @@ hipError_t qp_dense4_launch(const DenseKernelParams &kp, int64_t batch, const Qp
     if (e != hipSuccess) return e;
   }
   const int ncu = (dev >= 0 && dev < 64 && cus[dev] > 0) ? cus[dev] : 256;
-  return (kp.n + kp.m <= 16) ? launch4<1>(kp, batch, g, ncu, stream) : launch4<2>(kp, batch, g, ncu, stream);
+  return (kp.n + kp.m <= 16) ? launch4<1>(kp, batch, g, ncu, stream, workspace) : launch4<2>(kp, batch, g, ncu, stream, workspace);
 }
 
 }  // namespace sfb

@@ -32,7 +32,10 @@ size_t qp_dense_lds_bytes(int n, int m);
 size_t qp_dense4_lds_bytes(int n, int m);
 
 // k = n+m <= 32: four QPs per wavefront, persistent grid with a device-side queue (qp_dense4.hip)
-hipError_t qp_dense4_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream);
+// workspace: qp_dense4_ws_bytes(n, m, batch) bytes of device memory, or nullptr = stream-ordered allocation per launch
+hipError_t qp_dense4_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream,
+                            void *workspace = nullptr);
+size_t qp_dense4_ws_bytes(int n, int m, int64_t batch);
 
 // 64 < n+m <= 1024: one QP per wavefront, KKT matrix and pivoted LDL' in the QP's HBM workspace (qp_dense_big.hip);
 // workspace: batch * qp_dense_big_ws_doubles(n, m) doubles
@@ -42,6 +45,7 @@ constexpr int kDenseBigMaxK = 1024;
 
 hipError_t qp_dense_launch(const DenseKernelParams &kp, int64_t batch, const double *P, const double *q,
                            const double *A, const double *l, const double *u, const double *wx, const double *wy,
-                           double *x, double *y, double *obj, uint32_t *iter, int32_t *code, hipStream_t stream);
+                           double *x, double *y, double *obj, uint32_t *iter, int32_t *code, hipStream_t stream,
+                           void *workspace = nullptr);  // (workspace: see qp_dense4_launch; unused by the one-per-wave kernels)
 
 }  // namespace sfb

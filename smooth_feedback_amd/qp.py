@@ -150,6 +150,49 @@ def solve_qp_batch_device(B, n, m, dP, dq, dA, dl, du, dx, dy, dobj, diter, dcod
         dobj or None, diter or None, dcode, stream or None))
 
 
+class Workspace:
+    """sfb_workspace: device memory the caller creates once and hands to every call (no allocation per call).
+    Workspace.for_dense(batch, n, m, prm) sizes it with sfb_qp_dense_workspace_bytes."""
+
+    def __init__(self, nbytes):
+        self._h = C.c_void_p()
+        _capi.check(_capi.lib.sfb_workspace_create(int(nbytes), C.byref(self._h)))
+        p, b = C.c_void_p(), C.c_int64()
+        _capi.check(_capi.lib.sfb_workspace_info(self._h, C.byref(p), C.byref(b)))
+        self.device_ptr, self.nbytes = p.value or 0, b.value
+
+    @staticmethod
+    def dense_bytes(batch, n, m, prm=None):
+        v = C.c_int64()
+        cp = (prm or QPSolverParams()).to_c()
+        _capi.check(_capi.lib.sfb_qp_dense_workspace_bytes(C.byref(cp), int(batch), int(n), int(m), C.byref(v)))
+        return v.value
+
+    @classmethod
+    def for_dense(cls, batch, n, m, prm=None):
+        return cls(cls.dense_bytes(batch, n, m, prm))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _capi.lib.sfb_workspace_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def solve_qp_batch_device_ws(B, n, m, dP, dq, dA, dl, du, dx, dy, dobj, diter, dcode, workspace: "Workspace", prm=None,
+                             dwarm_x=0, dwarm_y=0, stream=0):
+    """sfb_qp_dense_solve_batch_ws: like solve_qp_batch_device on the caller's Workspace."""
+    cp = (prm or QPSolverParams()).to_c()
+    _capi.check(_capi.lib.sfb_qp_dense_solve_batch_ws(
+        C.byref(cp), B, n, m, dP, dq, dA, dl, du, dwarm_x or None, dwarm_y or None, dx, dy,
+        dobj or None, diter or None, dcode, workspace._h, stream or None))
+
+
 class QPSolver:
     """QPSolver<QuadraticProgram<M,N,double>>, qp_solver.hpp:242-757 (dense problems, n+m <= 64)."""
 

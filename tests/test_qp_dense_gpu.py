@@ -395,3 +395,36 @@ def test_verbose_prints_a_summary_of_the_call(sfb, capfd):
     assert "[sfb] dense QP batch: 32 problem(s), n = 10, m = 20" in out and "status:" in out and "iterations: min" in out
     sfb.solve_qp_batch_host(P, q, A, l, u, sfb.QPSolverParams(max_iter=500))
     assert "[sfb]" not in capfd.readouterr().out
+
+
+@pytest.mark.parametrize("n,m", [(3, 5), (10, 20), (20, 30), (40, 60), (3, 203)])
+def test_explicit_workspace_gives_the_same_results(sfb, n, m):
+    """sfb_workspace_create / sfb_qp_dense_solve_batch_ws: the caller's device workspace instead of stream-ordered
+    allocations inside the call -- every dense path (four-per-wave, one-per-wave, big dense), same results bit for
+    bit, twice on the same workspace; a workspace that is too small is refused."""
+    import torch
+    B = 96
+    P, q, A, l, u = sfb.random_qp_batch(11, B, m, n, 0.6)
+    prm = sfb.QPSolverParams(max_iter=600)
+    ref = sfb.solve_qp_batch_host(P, q, A, l, u, prm)
+    need = sfb.Workspace.dense_bytes(B, n, m, prm)
+    assert (need == 0) == (32 < n + m <= 64)
+    ws = sfb.Workspace(need)
+    dev = torch.device("cuda:0")
+    d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (P, q, A, l, u)]
+    for _ in range(2):
+        x = torch.full((B, n), np.nan, dtype=torch.float64, device=dev); y = torch.full((B, m), np.nan, dtype=torch.float64, device=dev)
+        obj = torch.full((B,), np.nan, dtype=torch.float64, device=dev)
+        it = torch.zeros(B, dtype=torch.int32, device=dev); code = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        sfb.solve_qp_batch_device_ws(B, n, m, *[a.data_ptr() for a in d], x.data_ptr(), y.data_ptr(), obj.data_ptr(),
+                                     it.data_ptr(), code.data_ptr(), ws, prm, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(code.cpu().numpy(), ref.code) and np.array_equal(it.cpu().numpy().astype(np.uint32), ref.iter)
+        assert np.array_equal(x.cpu().numpy(), ref.primal, equal_nan=True) and np.array_equal(y.cpu().numpy(), ref.dual, equal_nan=True)
+        assert np.array_equal(obj.cpu().numpy(), ref.objective, equal_nan=True)
+    if need:
+        small = sfb.Workspace(need - 8)
+        with pytest.raises(sfb._capi.SfbError) as ei:
+            sfb.solve_qp_batch_device_ws(B, n, m, *[a.data_ptr() for a in d], x.data_ptr(), y.data_ptr(), obj.data_ptr(),
+                                         it.data_ptr(), code.data_ptr(), small, prm)
+        assert ei.value.status == sfb._capi.SFB_ERR_INVALID_ARG
