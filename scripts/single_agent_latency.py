@@ -7,11 +7,13 @@ import smooth_feedback_amd as sfb
 from examples import models_lib as M
 variant = int(os.environ.get("VARIANT", 12)); K = int(os.environ.get("K", 50)); B = int(os.environ.get("B", 1))
 d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
-plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K))
 prm = sfb.QPSolverParams(max_iter=4000)
 Px = np.tile(Pv, (B, 1)); q = np.zeros((B, d["n"]))
 Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=3)
 Av2, l2, u2 = M.mpc_assemble_batch(variant, K, B, seed=4)
+# like the MPC front: the explicit zeros of the transcription are declared (probed on a sample) unless NO_PRUNE=1
+keep = None if os.environ.get("NO_PRUNE") == "1" else np.any(M.mpc_assemble_batch(variant, K, 64, seed=5)[0] != 0.0, axis=0)
+plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K), keep=keep)
 r = plan.solve_batch_host(Px, q, Av, l, u, prm)
 def wall(fn, reps=20):
     ts = []
