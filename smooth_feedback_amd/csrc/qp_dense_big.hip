@@ -32,6 +32,7 @@ namespace sfb {
 namespace {
 
 constexpr int kBigMaxK = 1024;
+constexpr int64_t kRoomyBatch = 512;  // launches with fewer QPs get the large on-chip row pool (see big_row_cap)
 constexpr int kRB      = kBigMaxK / kWave;  // row blocks per lane at the largest size
 
 // The sweeps and the factorisation are real (outlined) device functions: a plain `double *` parameter is a GENERIC
@@ -52,16 +53,17 @@ __device__ __forceinline__ int wave_min_index(const int cand)
   return (int)(-wave_max(-(double)cand));  // exact: indices are far below 2^53
 }
 
-// Eigen 3.4 LDLT<., Upper> == oracle_ldlt_factor (oracle/qp_oracle.c:67-151) on the lower triangle W (K x K, leading
-// dimension ld) in global memory, stored COLUMN-major: element (i, j), i >= j, at W[j * ld + i] -- the update of column
-// kk reads, for every earlier column j, the entries of rows kk.. (lane = row): contiguous in this layout.  perm[K] (LDS): composed transpositions, (P b)[i] = b[perm[i]].
+// Eigen 3.4 LDLT<., Upper> == oracle_ldlt_factor (oracle/qp_oracle.c:67-151) on the row-major lower triangle W
+// (leading dimension ld, K x K), in global memory.  (Measured: a column-major layout -- coalesced reads in the column
+// update, strided ones in the row swaps of the pivoting -- is no faster for one QP and mixed for batches: +30 % for the
+// safety-filter shape (3, 203), -5 % for (100, 156).)  perm[K] (LDS): composed transpositions, (P b)[i] = b[perm[i]].
 // temp[K] (LDS) scratch.  Returns 1 on success, 0 on failure (info() == NumericalIssue).  Wave-uniform.
 __device__ inline int big_ldlt_factor(const int K, double *__restrict__ W, const int ld, int *perm_, double *temp_,
                                       const int lane)
 {
   LDS_I(perm, perm_);
   LDS_D(temp, temp_);
-#define WB(i, j) W[(size_t)(j) * (size_t)ld + (size_t)(i)]
+#define WB(i, j) W[(size_t)(i) * (size_t)ld + (size_t)(j)]
   for (int i = lane; i < K; i += kWave) perm[i] = i;
   wave_sync();
   if (K <= 1) return 1;
@@ -96,8 +98,9 @@ __device__ inline int big_ldlt_factor(const int K, double *__restrict__ W, const
     wave_sync();
     if (kk > 0) {
       for (int i = kk + lane; i < K; i += kWave) {  // rows kk (the diagonal) .. K-1: dot, then subtract
-        double s = 0.0;
-        for (int j = 0; j < kk; ++j) s = fma(WB(i, j), temp[j], s);
+        const double *row = &WB(i, 0);
+        double s          = 0.0;
+        for (int j = 0; j < kk; ++j) s = fma(row[j], temp[j], s);
         WB(i, kk) -= s;
       }
       wave_sync();
@@ -125,22 +128,45 @@ __device__ inline int big_ldlt_factor(const int K, double *__restrict__ W, const
 }
 
 constexpr int kBW = 16;  // column block of the triangular sweeps
+constexpr int kBP     = 17;  // row stride of the 16-wide tiles kept in LDS (odd: lane = row reads hit distinct banks)
 constexpr int kDiagCacheK = 384;  // up to this size the diagonal blocks of L are kept in LDS (k * 16 doubles)
 // Compact on-chip copy of the OFF-diagonal part of L for factors that are almost empty (a safety filter: n = 3
 // variables, hundreds of barrier rows with a diagonal (2,2) block): per 16-column block the rows that have a
-// non-zero entry in it, each with its 16 values.  big_row_cap(k) rows in all (forward and backward lists share the
+// non-zero entry in it, each with its 16 values.  big_row_cap(n, m) rows in all (forward and backward lists share the
 // pool); a factor with more keeps streaming its non-zero tiles from the workspace.
-__host__ __device__ constexpr int big_row_cap(const int k) { return (k <= kDiagCacheK) ? k + 128 : 192; }
-constexpr int kBP     = 17;  // row stride of the 16-wide tiles kept in LDS (odd: lane = row reads hit distinct banks)
+// Pool size: what is left of the 160 KB of a CU after everything else the kernel keeps in LDS (one wave per CU then --
+// a lone QP is what this matters for; batches of such QPs are served by fewer, faster waves), at most 2 k + 64 rows
+// (a safety filter needs n rows per block forward and, for the blocks holding the variables, all rows backward).
+__host__ __device__ constexpr size_t big_lds_fixed_bytes(const int n, const int m)
+{
+  const size_t k = (size_t)n + (size_t)m;
+  const size_t rb = (k + 63) / 64 <= 2 ? 2 : ((k + 63) / 64 <= 4 ? 4 : ((k + 63) / 64 <= 8 ? 8 : 16));
+  const size_t tiles = ((k + 15) / 16) * rb;  // non-zero maps of the sweep tiles, forward and backward
+  const size_t dcache = (k <= (size_t)kDiagCacheK) ? ((k + 15) / 16) * 16 * kBP : 0;
+  return (4 * k + 2 * (size_t)n + 6 * (size_t)m + 8 + dcache) * sizeof(double) +
+         ((k + 1) / 2 * 2 + 2 * tiles + 3 * ((k + 15) / 16 + 1) + 4) * sizeof(int);
+}
+// `roomy`: few QPs in the launch (at most one wave per CU anyway): take what the lists of such a factor can need;
+// otherwise k + 64 rows, which keeps two or three waves per CU for batches (measured at (40, 60): 3 waves per CU with
+// k + 64, 2 with k + 128: 90 vs 118 ms for 4 096 QPs) (the lists are an optimisation: a factor
+// they do not hold is streamed tile by tile, same results).
+__host__ __device__ constexpr int big_row_cap(const int n, const int m, const bool roomy)
+{
+  const size_t budget = 158 * 1024, fixed = big_lds_fixed_bytes(n, m), per_row = kBP * sizeof(double) + sizeof(int);
+  const size_t k = (size_t)n + m, fit = budget > fixed ? (budget - fixed) / per_row : 0;
+  const size_t want = roomy ? 2 * k + 64 : (k <= (size_t)kDiagCacheK ? k + 64 : 192);
+  const size_t cap  = fit < want ? fit : want;
+  return cap < 64 ? 64 : (int)cap;
+}
 
-// W(i, j) = LT(j, i) for i >= j (row i of L contiguous), Dg[i] = W(i, i), and the non-zero maps of the tiles the
+// LT(j, i) = W(i, j) for i > j (column j of L contiguous), Dg[i] = W(i, i), and the non-zero maps of the tiles the
 // blocked sweeps work on: fnz[jb * RB + r] != 0 iff L has a non-zero entry in rows 64 r .. 64 r + 63, columns
 // 16 jb .. 16 jb + 15 (forward sweep); bnz[jb * RB + r] the same for rows 16 jb .. + 15, columns 64 r .. + 63
 // (backward sweep).  An all-zero tile contributes exact zeros to every chain it takes part in and is skipped --
 // the KKT matrix of a safety filter (n = 3 variables, hundreds of barrier rows, a diagonal (2,2) block) leaves L
 // almost empty.
 template<int RB>
-__device__ inline void big_transpose(const int K, double *__restrict__ W, const int ld, const double *__restrict__ LT,
+__device__ inline void big_transpose(const int K, const double *__restrict__ W, const int ld, double *__restrict__ LT,
                                      double *__restrict__ Dg, int *fnz_, int *bnz_, double *dblk_, double *LDg_, int *cidx_,
                                      double *cval_, int *cflag_, const int cap, const int lane)
 {
@@ -151,13 +177,11 @@ __device__ inline void big_transpose(const int K, double *__restrict__ W, const 
   LDS_I(cidx, cidx_);
   LDS_D(cval, cval_);
   LDS_I(cflag, cflag_);
-  // the factor arrives column-major in LT (column j of L contiguous: the forward sweep's layout); W gets the row-major
-  // copy with the diagonal (row i of L contiguous: the backward sweep's layout)
-  for (int j = 0; j < K; ++j)
-    for (int i = j + lane; i < K; i += kWave) W[(size_t)i * ld + j] = LT[(size_t)j * ld + i];
-  wave_sync();
+  // LT: the column-major copy of the strictly lower triangle (column j of L contiguous: the forward sweep's layout)
+  for (int i = 0; i < K; ++i)
+    for (int j = lane; j < i; j += kWave) LT[(size_t)j * ld + i] = W[(size_t)i * ld + j];
   // cidx: [0, nb] forward block offsets, [nb + 1, 2 nb + 1] backward block offsets, nb flags "the diagonal block has
-  // entries below its diagonal", then the rows of the lists (forward lists first, one pool of big_row_cap(K) rows);
+  // entries below its diagonal", then the rows of the lists (forward lists first, one pool of `cap` rows);
   // cval: the rows' 16 values (stride kBP); cflag[0]: the lists are complete
   {
     const int nbk = (K + kBW - 1) / kBW;
@@ -489,19 +513,14 @@ size_t qp_dense_big_ws_doubles(int n, int m)
   const size_t k = (size_t)n + m;
   return 3 * k * k + k + 6 * (size_t)n + 11 * (size_t)m + 8;
 }
-size_t qp_dense_big_lds_bytes(int n, int m)
+size_t qp_dense_big_lds_bytes(int n, int m, int64_t batch)
 {
-  const size_t k = (size_t)n + m;
-  const size_t rb = (k + 63) / 64 <= 2 ? 2 : ((k + 63) / 64 <= 4 ? 4 : ((k + 63) / 64 <= 8 ? 8 : 16));
-  const size_t tiles = ((k + 15) / 16) * rb;  // non-zero maps of the sweep tiles, forward and backward
-  const size_t dcache = (k <= (size_t)kDiagCacheK) ? ((k + 15) / 16) * 16 * kBP : 0;
-  return (4 * k + 2 * (size_t)n + 6 * (size_t)m + 8 + dcache + (size_t)big_row_cap((int)k) * kBP) * sizeof(double) +
-         ((k + 1) / 2 * 2 + 2 * tiles + 3 * ((k + 15) / 16 + 1) + (size_t)big_row_cap((int)k) + 4) * sizeof(int);
+  return big_lds_fixed_bytes(n, m) + (size_t)big_row_cap(n, m, batch < kRoomyBatch) * (kBP * sizeof(double) + sizeof(int));
 }
 
 template<int RB>
 __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParams kp, const QpBatch g, double *__restrict__ gws,
-                                                         const size_t wsd)
+                                                         const size_t wsd, const int rcap)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int lane = threadIdx.x;
@@ -518,7 +537,6 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
   double *dblk = Lqc + n;
   double *LDg  = dblk + ((k <= kDiagCacheK) ? (size_t)((k + kBW - 1) / kBW) * kBW * kBP : 0);  // diagonal of the factor
   double *cval = LDg + k;                                                                        // compact off-diagonal rows
-  const int rcap = big_row_cap(k);
   int *perm = reinterpret_cast<int *>(cval + rcap * kBP);
   int *fnz = perm + (k + 1) / 2 * 2, *bnz = fnz + ((k + kBW - 1) / kBW) * RB;
   int *cidx = bnz + ((k + kBW - 1) / kBW) * RB, *cflag = cidx + 3 * ((k + kBW - 1) / kBW + 1) + rcap;
@@ -615,23 +633,23 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
   wave_sync();
 
   const unsigned long long t0_ticks = wall_clock64();  // :376
-  // ---- dense KKT fill :399-404 (lower triangle of the k x k array LT, column-major: (i, j) at LT[j k + i]) ----
-  for (int cc = 0; cc < n; ++cc)
-    for (int r = cc + lane; r < n; r += kWave) {
+  // ---- dense KKT fill :399-404 (row-major lower triangle of the k x k array H) ----
+  for (int r = 0; r < n; ++r)
+    for (int cc = lane; cc <= r; cc += kWave) {
       double v = c * w.sx[cc] * PM(cc, r) * w.sx[r];
       if (cc == r) v += kp.sigma;
-      w.LT[(size_t)cc * k + r] = v;
+      w.H[(size_t)r * k + cc] = v;
     }
   for (int e = lane; e < m * n; e += kWave) {
     const int i = e % m, j = e / m;
-    w.LT[(size_t)j * k + (n + i)] = w.sy[i] * A[e] * w.sx[j];
+    w.H[(size_t)(n + i) * k + j] = w.sy[i] * A[e] * w.sx[j];
   }
-  for (int i2 = 0; i2 < m; ++i2) {
-    for (int i = i2 + 1 + lane; i < m; i += kWave) w.LT[(size_t)(n + i2) * k + (n + i)] = 0.0;
-    if (lane == 0) w.LT[(size_t)(n + i2) * k + (n + i2)] = 1.0 / (-w.rho[i2]);
+  for (int i = 0; i < m; ++i) {
+    for (int i2 = lane; i2 < i; i2 += kWave) w.H[(size_t)(n + i) * k + (n + i2)] = 0.0;
+    if (lane == 0) w.H[(size_t)(n + i) * k + (n + i)] = 1.0 / (-w.rho[i]);
   }
   wave_sync();
-  if (!big_ldlt_factor(k, w.LT, k, perm, temp, lane)) ret_code = SFB_QP_UNKNOWN;  // :428-433
+  if (!big_ldlt_factor(k, w.H, k, perm, temp, lane)) ret_code = SFB_QP_UNKNOWN;  // :428-433
   const bool dcache = k <= kDiagCacheK;
   big_transpose<RB>(k, w.H, k, w.LT, w.Dg, fnz, bnz, dcache ? dblk : nullptr, LDg, cidx, cval, cflag, rcap, lane);
 
@@ -808,17 +826,16 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
     }
     wave_sync();
     const int na = nl + nu, K = n + na;
-    // Hs: the symmetric K x K matrix of the residual; Hp = Hs + diag(delta, -delta), lower triangle column-major in LT
-    // for the LDLT (:159-177); its factor's row-major copy goes to H
-    double *Hs = w.Hs, *Hp = w.H, *Hc = w.LT;
-    for (int e = lane; e < K * K; e += kWave) { Hs[e] = 0.0; Hc[e] = 0.0; }
+    // Hs: the symmetric K x K matrix of the residual; Hp = Hs + diag(delta, -delta) lower row-major for the LDLT (:159-177)
+    double *Hs = w.Hs, *Hp = w.H;
+    for (int e = lane; e < K * K; e += kWave) { Hs[e] = 0.0; Hp[e] = 0.0; }
     wave_sync();
     for (int i = 0; i < n; ++i)
       for (int j = i + lane; j < n; j += kWave) {
         const double v           = c * w.sx[i] * PM(i, j) * w.sx[j];  // :161 upper entry (i, j)
         Hs[(size_t)i * K + j]    = v;
         Hs[(size_t)j * K + i]    = v;
-        Hc[(size_t)i * K + j]    = v;
+        Hp[(size_t)j * K + i]    = v;
       }
     for (int e = lane; e < m * n; e += kWave) {
       const int row = e % m, j = e / m;
@@ -828,12 +845,12 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
         const double v = w.sy[row] * A[e] * w.sx[j];  // :163
         Hs[(size_t)j * K + col] = v;
         Hs[(size_t)col * K + j] = v;
-        Hc[(size_t)j * K + col] = v;
+        Hp[(size_t)col * K + j] = v;
       }
     }
     wave_sync();
-    for (int i = lane; i < n; i += kWave) Hc[(size_t)i * K + i] += kp.delta;
-    for (int a = lane; a < na; a += kWave) Hc[(size_t)(n + a) * K + (n + a)] -= kp.delta;
+    for (int i = lane; i < n; i += kWave) Hp[(size_t)i * K + i] += kp.delta;
+    for (int a = lane; a < na; a += kWave) Hp[(size_t)(n + a) * K + (n + a)] -= kp.delta;
     // h (:179-182) and t = 0
     for (int j = lane; j < n; j += kWave) w.hx[j] = -c * (w.sx[j] * q[j]);
     for (int i = lane; i < m; i += kWave) {
@@ -843,7 +860,7 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
     }
     for (int e = lane; e < K; e += kWave) aux[e] = 0.0;  // aux = t of the refinement
     wave_sync();
-    if (big_ldlt_factor(K, Hc, K, perm, temp, lane)) {
+    if (big_ldlt_factor(K, Hp, K, perm, temp, lane)) {
       big_transpose<RB>(K, Hp, K, w.LT, w.Dg, fnz, bnz, dcache ? dblk : nullptr, LDg, cidx, cval, cflag, rcap, lane);
       for (uint32_t it = 0; it != kp.polish_iter; ++it) {  // :193-195  t += Hp^-1 (h - Hs t)
         for (int i = lane; i < K; i += kWave) {
@@ -900,14 +917,15 @@ hipError_t qp_dense_big_launch(const DenseKernelParams &kp, int64_t batch, const
 {
   const int k = kp.n + kp.m;
   if (k > kBigMaxK) return hipErrorInvalidValue;
-  const size_t lds = qp_dense_big_lds_bytes(kp.n, kp.m);
+  const size_t lds = qp_dense_big_lds_bytes(kp.n, kp.m, batch);
+  const int rcap   = big_row_cap(kp.n, kp.m, batch < kRoomyBatch);
   const size_t wsd = qp_dense_big_ws_doubles(kp.n, kp.m);
   const dim3 grid((unsigned)batch), block(kWave);
   const int rb = (k + kWave - 1) / kWave;
-  if (rb <= 2) hipLaunchKernelGGL((qp_dense_big_kernel<2>), grid, block, lds, stream, kp, g, workspace, wsd);
-  else if (rb <= 4) hipLaunchKernelGGL((qp_dense_big_kernel<4>), grid, block, lds, stream, kp, g, workspace, wsd);
-  else if (rb <= 8) hipLaunchKernelGGL((qp_dense_big_kernel<8>), grid, block, lds, stream, kp, g, workspace, wsd);
-  else hipLaunchKernelGGL((qp_dense_big_kernel<kRB>), grid, block, lds, stream, kp, g, workspace, wsd);
+  if (rb <= 2) hipLaunchKernelGGL((qp_dense_big_kernel<2>), grid, block, lds, stream, kp, g, workspace, wsd, rcap);
+  else if (rb <= 4) hipLaunchKernelGGL((qp_dense_big_kernel<4>), grid, block, lds, stream, kp, g, workspace, wsd, rcap);
+  else if (rb <= 8) hipLaunchKernelGGL((qp_dense_big_kernel<8>), grid, block, lds, stream, kp, g, workspace, wsd, rcap);
+  else hipLaunchKernelGGL((qp_dense_big_kernel<kRB>), grid, block, lds, stream, kp, g, workspace, wsd, rcap);
   return hipGetLastError();
 }
 
