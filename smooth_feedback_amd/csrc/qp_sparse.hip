@@ -1199,7 +1199,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     if (!ldl_numeric_dev<8>(pl, it, w, t, 0, c, kp.sigma, kp.delta, lane)) {
       ret_code = SFB_QP_UNKNOWN;
       // Dinv of the remaining columns is never used: the loop below does not run
-    } else if (lane == 0) {
+    } else if (lane == 0 && allow_reuse) {  // (a slot that is not the item's own -- ordered launch, pool -- stays unstamped)
       w.hdr[kHdrStamp]   = __longlong_as_double((long long)kFactorStamp);
       w.hdr[kHdrC]       = c;
       w.hdr[kHdrSigma]   = kp.sigma;

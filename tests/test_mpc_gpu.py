@@ -368,3 +368,30 @@ def test_generic_ocp_to_qp_solves_and_maps_back(sfb):
     assert abs(o[13]) <= 1.0 + 1e-3          # input within the running constraint
     assert abs(o[14] + 0.2) < 1e-2 and abs(o[15] + 0.2) < 1e-2
     assert abs(o[17]) < 1e-12
+
+
+def test_factor_reuse_after_an_ordered_launch_is_safe(sfb):
+    """A launch with an explicit order uses workspace slot = launch position, not item: it must not leave anything a
+    later natural-order call with reuse_factor could mistake for the items' own factors."""
+    import torch
+    variant, K, B = 6, 20, 40
+    d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
+    Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=31)
+    plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K))
+    Px, q = np.tile(Pv, (B, 1)), np.zeros((B, d["n"]))
+    run = _DeviceSolver(sfb, plan, B)
+    prm = sfb.QPSolverParams(max_iter=4000, reuse_factor=True)
+    dev = torch.device("cuda:0")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    order = T(np.arange(B, dtype=np.int32)[::-1].copy())
+    dd = [T(a) for a in (Px, q, Av, l, u)]
+    x = torch.empty((B, d["n"]), dtype=torch.float64, device=dev); y = torch.empty((B, d["m"]), dtype=torch.float64, device=dev)
+    it = torch.zeros(B, dtype=torch.int32, device=dev); code = torch.zeros(B, dtype=torch.int32, device=dev)
+    plan.solve_batch_device(B, *[a.data_ptr() for a in dd], x.data_ptr(), y.data_ptr(), 0, it.data_ptr(), code.data_ptr(),
+                            run.ws.data_ptr(), prm, stream=torch.cuda.current_stream().cuda_stream, dorder=order.data_ptr())
+    torch.cuda.synchronize()
+    got = run(Px, q, Av, l, u, prm)                       # natural order, flagged: slot b now holds item B-1-b's leftovers
+    ref = _DeviceSolver(sfb, plan, B)(Px, q, Av, l, u, sfb.QPSolverParams(max_iter=4000))
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+    assert np.array_equal(x.cpu().numpy(), ref[2])
