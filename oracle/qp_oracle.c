@@ -594,7 +594,7 @@ int oracle_qp_dense_solve(const oracle_qp_params *prm, int n, int m, const doubl
 
 typedef struct {
   const oracle_qp_params *prm;
-  int64_t b0, b1;
+  int64_t batch, *next; /* items are handed out in chunks (iteration counts are heavy-tailed) */
   int n, m;
   const double *P, *q, *A, *l, *u, *wx, *wy;
   double *x, *y, *obj;
@@ -607,7 +607,8 @@ static void *batch_worker(void *arg)
 {
   batch_job *j = (batch_job *)arg;
   const size_t n = (size_t)j->n, m = (size_t)j->m;
-  for (int64_t b = j->b0; b < j->b1; ++b) {
+  for (int64_t b0; (b0 = __atomic_fetch_add(j->next, 16, __ATOMIC_RELAXED)) < j->batch;)
+  for (int64_t b = b0; b < b0 + 16 && b < j->batch; ++b) {
     const size_t sb = (size_t)b;
     int rc = oracle_qp_dense_solve(j->prm, j->n, j->m, j->P + sb * n * n, j->q + sb * n, j->A + sb * m * n,
                                    j->l + sb * m, j->u + sb * m, j->wx ? j->wx + sb * n : NULL,
@@ -629,11 +630,11 @@ int oracle_qp_dense_solve_batch(const oracle_qp_params *prm, int64_t batch, int 
   batch_job *jobs = (batch_job *)calloc((size_t)nthreads, sizeof(batch_job));
   pthread_t *th   = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
   if (!jobs || !th) { free(jobs); free(th); return -1; }
+  int64_t next_item = 0;
   for (int t = 0; t < nthreads; ++t) {
     batch_job *j = &jobs[t];
     j->prm = prm; j->n = n; j->m = m;
-    j->b0 = batch * t / nthreads;
-    j->b1 = batch * (t + 1) / nthreads;
+    j->batch = batch; j->next = &next_item;
     j->P = P; j->q = q; j->A = A; j->l = l; j->u = u; j->wx = warm_x; j->wy = warm_y;
     j->x = x; j->y = y; j->obj = obj; j->iter = iter; j->code = code;
   }

@@ -618,7 +618,7 @@ static int sp_solve_one(const sp_shared *sh, const sp_aux *aux, const oracle_qp_
 /* ---------------- batch driver ---------------- */
 typedef struct {
   const sp_shared *sh; const sp_aux *aux; const oracle_qp_params *prm;
-  int64_t b0, b1; int nnzP, nnzA;
+  int64_t batch; int64_t *next; int nnzP, nnzA; /* items are handed out one at a time (iteration counts are heavy-tailed) */
   const double *Px, *q, *Ax, *l, *u, *wx, *wy;
   double *x, *y, *obj; uint32_t *iter; int32_t *code; int rc;
 } sp_job;
@@ -627,7 +627,7 @@ static void *sp_worker(void *arg)
 {
   sp_job *j = (sp_job *)arg;
   const size_t n = (size_t)j->sh->n, m = (size_t)j->sh->m;
-  for (int64_t b = j->b0; b < j->b1; ++b) {
+  for (int64_t b; (b = __atomic_fetch_add(j->next, 1, __ATOMIC_RELAXED)) < j->batch;) {
     const size_t sb = (size_t)b;
     int rc = sp_solve_one(j->sh, j->aux, j->prm, j->Px + sb * (size_t)j->nnzP, j->q + sb * n,
                           j->Ax + sb * (size_t)j->nnzA, j->l + sb * m, j->u + sb * m,
@@ -705,10 +705,11 @@ int oracle_qp_sparse_solve_batch_ordered(const oracle_qp_params *prm, int64_t ba
   if ((int64_t)nthreads > batch) nthreads = (int)(batch > 0 ? batch : 1);
   sp_job *jobs  = (sp_job *)calloc((size_t)nthreads, sizeof(sp_job));
   pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+  int64_t next_item = 0;
   for (int t = 0; t < nthreads; ++t) {
     sp_job *j = &jobs[t];
     j->sh = &sh; j->aux = &aux; j->prm = prm; j->nnzP = Pp[n]; j->nnzA = Ap[m];
-    j->b0 = batch * t / nthreads; j->b1 = batch * (t + 1) / nthreads;
+    j->batch = batch; j->next = &next_item;
     j->Px = Px; j->q = q; j->Ax = Ax; j->l = l; j->u = u; j->wx = warm_x; j->wy = warm_y;
     j->x = x; j->y = y; j->obj = obj; j->iter = iter; j->code = code;
   }
