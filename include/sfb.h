@@ -350,6 +350,15 @@ sfb_status sfb_mpc_swarm_reset_warmstart(sfb_mpc_swarm *swarm);
 sfb_status sfb_mpc_swarm_step_host(sfb_mpc_swarm *swarm, const sfb_qp_params *prm, const double *records,
                                    const double *shared_jac, int warmstart, double *du0, uint32_t *iter,
                                    int32_t *code, double *primal, double *dual);
+
+/* Pipelined upload (optional).  sfb_mpc_swarm_host_records returns a PINNED host buffer [agents][record_doubles
+ * (shared_jac = 0)] owned by the swarm; the host threads that linearise write their agents' records straight into it
+ * and announce finished ranges with sfb_mpc_swarm_upload(first, count), which starts an asynchronous copy on the
+ * swarm's copy stream and returns at once -- the DMA of one chunk overlaps with the linearisation of the next.
+ * sfb_mpc_swarm_step_host called with records == that buffer (and shared_jac == NULL) waits for those copies, uploads
+ * whatever was not announced, and proceeds as above.  A range must not be rewritten between its upload and the step. */
+sfb_status sfb_mpc_swarm_host_records(sfb_mpc_swarm *swarm, double **records);
+sfb_status sfb_mpc_swarm_upload(sfb_mpc_swarm *swarm, int64_t first, int64_t count);
 /* Device buffers of the last tick (Ax [agents][nnzA], l, u [agents][m]) for inspection; valid until the next call. */
 sfb_status sfb_mpc_swarm_debug_buffers(sfb_mpc_swarm *swarm, const double **Ax, const double **l, const double **u);
 

@@ -13,6 +13,10 @@
 // construction (in reference v1 set_weights() never reaches the QP: cost is transcribed only in
 // the constructor, mpc.hpp:423 vs :593-598).
 #pragma once
+#include <cstdlib>
+#include <cstdio>
+#include <chrono>
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 #include <functional>
@@ -610,12 +614,12 @@ public:
     }
     layout_ = mpc_.device_layout();
     recd_   = MPCT::record_doubles(mpc_.N());
-    rec_.resize((size_t)B_ * recd_);
     du0_.resize((size_t)B_ * MPCT::Nu);
     iter_.resize(B_);
     code_.resize(B_);
     const auto & qp = mpc_.qp();
     sfb_check(sfb_mpc_swarm_create(mpc_.solver().plan(), &layout_->c, qp.P_val.data(), qp.q.data(), B_, &swarm_));
+    sfb_check(sfb_mpc_swarm_host_records(swarm_, &rec_));  // pinned, owned by the swarm
   }
   MPCSwarmDevice(const MPCSwarmDevice &)             = delete;
   MPCSwarmDevice & operator=(const MPCSwarmDevice &) = delete;
@@ -630,11 +634,34 @@ public:
             std::vector<double> * dual = nullptr)
   {
     const auto & qp = mpc_.qp();
-    parallel_for([&](int64_t b) { mpc_.fill_record(t[b], xs[b], &rec_[(size_t)b * recd_]); });
+    // the records are written straight into the swarm's pinned buffer, chunk by chunk; the DMA of a finished chunk
+    // (sfb_mpc_swarm_upload) overlaps with the linearisation of the next one
+    const int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(kUploadChunks, B_ / std::max(1, threads_)));
+    const auto tfill0 = std::chrono::steady_clock::now();
+    {
+      const int T = (int)std::min<int64_t>(threads_, B_ / chunks);
+      std::vector<std::atomic<int>> done(chunks);
+      for (auto & d : done) d.store(0);
+      std::atomic<int> failed{0};
+      std::vector<std::thread> th;
+      for (int k = 0; k < T; ++k)
+        th.emplace_back([&, k] {
+          for (int64_t c0 = 0; c0 < chunks; ++c0) {  // every thread takes its share of chunk after chunk
+            const int64_t b0 = B_ * c0 / chunks, b1 = B_ * (c0 + 1) / chunks, cnt = b1 - b0;
+            for (int64_t b = b0 + cnt * k / T; b < b0 + cnt * (k + 1) / T; ++b) mpc_.fill_record(t[b], xs[b], rec_ + (size_t)b * recd_);
+            if (done[c0].fetch_add(1) + 1 == T && sfb_mpc_swarm_upload(swarm_, b0, cnt) != SFB_OK) failed.store(1);  // last one in
+          }
+        });
+      for (auto & x : th) x.join();
+      if (failed.load()) sfb_check(SFB_ERR_HIP);
+    }
+    if (const char * tv = std::getenv("SFB_MPC_TIMING"); tv && tv[0] == '1')
+      std::fprintf(stderr, "[MPCSwarmDevice] linearise  %8.3f ms (uploads of finished chunks in flight)\n",
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tfill0).count());
     if (primal) primal->resize((size_t)B_ * qp.n);
     if (dual) dual->resize((size_t)B_ * qp.m);
     const sfb_qp_params c = mpc_.solver().params().to_c();
-    sfb_check(sfb_mpc_swarm_step_host(swarm_, &c, rec_.data(), nullptr, mpc_.params().warmstart ? 1 : 0, du0_.data(),
+    sfb_check(sfb_mpc_swarm_step_host(swarm_, &c, rec_, nullptr, mpc_.params().warmstart ? 1 : 0, du0_.data(),
                                       iter_.data(), code_.data(), primal ? primal->data() : nullptr,
                                       dual ? dual->data() : nullptr));
     us.resize(B_);
@@ -645,18 +672,22 @@ public:
     }
   }
   const std::vector<uint32_t> & iterations() const { return iter_; }
-  const std::vector<double> & records() const { return rec_; }
+  /// the linearisation records of the last tick ([agents][record_doubles], in the swarm's pinned buffer)
+  const double * records() const { return rec_; }
+  int64_t record_doubles() const { return recd_; }
   sfb_mpc_swarm * handle() { return swarm_; }
 
 private:
+  static constexpr int64_t kUploadChunks = 8;
   template<class Fn>
-  void parallel_for(Fn && fn)
+  void parallel_for(int64_t b0, int64_t b1, Fn && fn)
   {
-    const int T = (int)std::min<int64_t>(threads_, B_);
+    const int64_t cnt = b1 - b0;
+    const int T       = (int)std::min<int64_t>(threads_, cnt);
     std::vector<std::thread> th;
     for (int k = 0; k < T; ++k)
       th.emplace_back([&, k] {
-        for (int64_t b = B_ * k / T; b < B_ * (k + 1) / T; ++b) fn(b);
+        for (int64_t b = b0 + cnt * k / T; b < b0 + cnt * (k + 1) / T; ++b) fn(b);
       });
     for (auto & t : th) t.join();
   }
@@ -665,7 +696,8 @@ private:
   int threads_;
   std::unique_ptr<typename MPCT::DeviceLayout> layout_;
   sfb_mpc_swarm * swarm_ = nullptr;
-  std::vector<double> rec_, du0_;
+  double * rec_ = nullptr;  // the swarm's pinned record buffer
+  std::vector<double> du0_;
   std::vector<uint32_t> iter_;
   std::vector<int32_t> code_;
 };

@@ -125,6 +125,11 @@ struct sfb_mpc_swarm {
   std::vector<uint32_t> h_iter;   // iteration counts of the last tick (host), for the launch order of the next
   std::vector<int32_t> h_order;
   bool have_order = false;
+  // pipelined upload (sfb_mpc_swarm_host_records / _upload): pinned host records, a copy stream, and which agents'
+  // records of the CURRENT tick are already on their way
+  double *pinned = nullptr;
+  hipStream_t up_stream = nullptr;
+  std::vector<uint8_t> uploaded;
   std::mutex mu;
 };
 
@@ -272,6 +277,8 @@ sfb_status sfb_mpc_swarm_create(sfb_sparse_qp_plan *plan, const sfb_mpc_layout *
 void sfb_mpc_swarm_destroy(sfb_mpc_swarm *swarm)
 {
   if (!swarm) return;
+  if (swarm->up_stream) { (void)hipStreamSynchronize(swarm->up_stream); (void)hipStreamDestroy(swarm->up_stream); }
+  if (swarm->pinned) (void)hipHostFree(swarm->pinned);
   if (swarm->mem) (void)hipFree(swarm->mem);
   delete swarm;
 }
@@ -287,6 +294,42 @@ sfb_status check_swarm_device(const sfb_mpc_swarm *S)
   return SFB_OK;
 }
 }  // namespace
+
+sfb_status sfb_mpc_swarm_host_records(sfb_mpc_swarm *S, double **records)
+{
+  if (!S || !records) return sfb::fail(SFB_ERR_INVALID_ARG, "swarm / records is NULL");
+  if (sfb_status sd = check_swarm_device(S); sd != SFB_OK) return sd;
+  std::lock_guard<std::mutex> lk(S->mu);
+  if (!S->pinned) {
+    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&S->pinned), (size_t)S->agents * (size_t)S->rec_own.rec_doubles * 8, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&S->up_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      if (S->pinned) (void)hipHostFree(S->pinned);
+      S->pinned = nullptr;
+      return sfb::hip_fail(e, "hipHostMalloc(swarm records)");
+    }
+    S->uploaded.assign((size_t)S->agents, 0);
+  }
+  *records = S->pinned;
+  return SFB_OK;
+}
+
+sfb_status sfb_mpc_swarm_upload(sfb_mpc_swarm *S, int64_t first, int64_t count)
+{
+  if (!S) return sfb::fail(SFB_ERR_INVALID_ARG, "swarm is NULL");
+  if (!S->pinned) return sfb::fail(SFB_ERR_INVALID_ARG, "sfb_mpc_swarm_host_records first");
+  if (first < 0 || count < 0 || first + count > S->agents) return sfb::fail(SFB_ERR_INVALID_ARG, "range outside the swarm");
+  if (sfb_status sd = check_swarm_device(S); sd != SFB_OK) return sd;
+  if (count == 0) return SFB_OK;
+  std::lock_guard<std::mutex> lk(S->mu);
+  const size_t rd = (size_t)S->rec_own.rec_doubles;
+  hipError_t e = hipMemcpyAsync(S->rec + (size_t)first * rd, S->pinned + (size_t)first * rd, (size_t)count * rd * 8, hipMemcpyHostToDevice,
+                                S->up_stream);
+  if (e != hipSuccess) return sfb::hip_fail(e, "hipMemcpyAsync(swarm records)");
+  (void)hipStreamQuery(S->up_stream);  // flush: the copy must start now, not at the next synchronisation
+  std::fill(S->uploaded.begin() + first, S->uploaded.begin() + first + count, (uint8_t)1);
+  return SFB_OK;
+}
 
 sfb_status sfb_mpc_swarm_reset_warmstart(sfb_mpc_swarm *S)
 {
@@ -324,7 +367,20 @@ sfb_status sfb_mpc_swarm_step_host(sfb_mpc_swarm *S, const sfb_qp_params *prm, c
     t0 = t1;
   };
   do {
-    if ((e = hipMemcpy(S->rec, records, B * (size_t)p.rec_doubles * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
+    if (records == S->pinned && !shared_jac) {
+      // pipelined upload: ranges announced with sfb_mpc_swarm_upload are in flight on the copy stream; the rest go now
+      const size_t rd = (size_t)p.rec_doubles;
+      for (size_t b = 0; b < B && e == hipSuccess;) {
+        if (S->uploaded[b]) { ++b; continue; }
+        size_t b1 = b;
+        while (b1 < B && !S->uploaded[b1]) ++b1;
+        e = hipMemcpyAsync(S->rec + b * rd, S->pinned + b * rd, (b1 - b) * rd * 8, hipMemcpyHostToDevice, S->up_stream);
+        b = b1;
+      }
+      if (e != hipSuccess) break;
+      if ((e = hipStreamSynchronize(S->up_stream)) != hipSuccess) break;
+      std::fill(S->uploaded.begin(), S->uploaded.end(), (uint8_t)0);
+    } else if ((e = hipMemcpy(S->rec, records, B * (size_t)p.rec_doubles * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
     if (shared_jac && (e = hipMemcpy(S->shared, shared_jac, (size_t)S->shared_doubles * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
     lap("H2D");
     if ((e = sfb::mpc_assemble_launch(p, S->agents, S->rec, shared_jac ? S->shared : nullptr, S->Ax, S->l, S->u, nullptr)) != hipSuccess) break;
