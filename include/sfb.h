@@ -294,6 +294,8 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
  *   f, dfdx, dfdu: dynamics and right-Jacobians at (xdes(t+t_i), udes(t+t_i)); dxdes: body velocity of the
  *   desired trajectory; c, dcdx, dcdu: running constraint and Jacobians; e = xdes(t) (-) x and
  *   J = d^r exp^{-1}(e) (MPCCE, mpc.hpp:288-301).
+ * With layout->jac_keep the Jacobian blocks are packed: [ f | dxdes | dfdx kept (N * n_fx) | dfdu kept | c | dcdx kept |
+ * dcdu kept | e | J kept ].
  * If shared_jac is given (time-invariant linearisation: group-linear model on a fixed trajectory), the
  * Jacobians [dfdx | dfdu | dcdx | dcdu] are read from that ONE record and the per-agent record shrinks to
  *   [ f | dxdes | c | e | J ].
@@ -310,6 +312,12 @@ typedef struct sfb_mpc_layout {
   const int32_t *part_kind; /* [nparts] sfb_lie_kind */
   const int32_t *part_dof;  /* [nparts] sums to nx (SE2 and SO3: 3) */
   const double *crl, *cru;  /* [ncr] bounds of the running constraint (OCP::crl / cru as set by the MPC constructor) */
+  const uint8_t *jac_keep;  /* nullable.  Packed per-agent Jacobians: one flag per entry of the blocks
+                               [dfdx nx*nx | dfdu nx*nu | dcdx ncr*nx | dcdu ncr*nu | J nx*nx], row-major (d, c);
+                               the record then holds, per node (J: once), only the entries whose flag is set, in
+                               that order -- the others are 0.0 by the CALLER's guarantee (the dense Jacobian blocks
+                               of a bundle state are mostly structural zeros: two thirds of the headline model's
+                               record).  Ignored for records that share their Jacobians.  nu <= 32. */
 } sfb_mpc_layout;
 
 /* doubles in one per-agent record (shared_jac == 0: with the Jacobians) and in the shared Jacobian record */
@@ -359,6 +367,12 @@ sfb_status sfb_mpc_swarm_step_host(sfb_mpc_swarm *swarm, const sfb_qp_params *pr
  * whatever was not announced, and proceeds as above.  A range must not be rewritten between its upload and the step. */
 sfb_status sfb_mpc_swarm_host_records(sfb_mpc_swarm *swarm, double **records);
 sfb_status sfb_mpc_swarm_upload(sfb_mpc_swarm *swarm, int64_t first, int64_t count);
+
+/* Switch the packing of the per-agent records (layout->jac_keep semantics; NULL = unpacked) of an existing swarm --
+ * e.g. back to full records when a linearisation turns out to have a non-zero where the flags said zero.  The swarm's
+ * buffers are sized for unpacked records, warm starts and solver memory are untouched.  record_doubles (nullable)
+ * receives the new record length.  Pending uploads are waited for and forgotten. */
+sfb_status sfb_mpc_swarm_set_jac_keep(sfb_mpc_swarm *swarm, const uint8_t *jac_keep, int64_t *record_doubles);
 /* Device buffers of the last tick (Ax [agents][nnzA], l, u [agents][m]) for inspection; valid until the next call. */
 sfb_status sfb_mpc_swarm_debug_buffers(sfb_mpc_swarm *swarm, const double **Ax, const double **l, const double **u);
 

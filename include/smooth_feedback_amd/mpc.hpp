@@ -263,11 +263,14 @@ public:
   struct DeviceLayout {
     std::vector<double> alpha, D, crl, cru;
     std::vector<int32_t> kind, dof;
+    std::vector<uint8_t> jac_keep;  // empty: unpacked records
     sfb_mpc_layout c{};
   };
-  std::unique_ptr<DeviceLayout> device_layout() const
+  /// jac_keep (nullable): flags of the Jacobian entries the records carry (RecordPacking::keep)
+  std::unique_ptr<DeviceLayout> device_layout(const std::vector<uint8_t> * jac_keep = nullptr) const
   {
     auto L = std::make_unique<DeviceLayout>();
+    if (jac_keep) L->jac_keep = *jac_keep;
     for (int s = 0; s < mesh_.N_ivals(); ++s) L->alpha.push_back(mesh_.alpha(s));
     L->D.resize((size_t)(Kmesh + 1) * Kmesh);
     for (int j = 0; j <= Kmesh; ++j)
@@ -275,8 +278,83 @@ public:
     for (int d = 0; d < Ncr; ++d) { L->crl.push_back(crl_[d]); L->cru.push_back(cru_[d]); }
     if constexpr (!X::IsCommutative) LieParts<X>::append(L->kind, L->dof);
     L->c = sfb_mpc_layout{Nx, Nu, Ncr, Kmesh, mesh_.N_ivals(), prm_.tf, L->alpha.data(), L->D.data(),
-                          (int32_t)L->kind.size(), L->kind.data(), L->dof.data(), L->crl.data(), L->cru.data()};
+                          (int32_t)L->kind.size(), L->kind.data(), L->dof.data(), L->crl.data(), L->cru.data(),
+                          L->jac_keep.empty() ? nullptr : L->jac_keep.data()};
     return L;
+  }
+
+  /// Packed records (sfb_mpc_layout::jac_keep): the dense Jacobian blocks of a bundle state are mostly structural
+  /// zeros, and the record is what a device-resident swarm moves through PCIe every tick.  keep: one flag per entry of
+  /// [dfdx Nx*Nx | dfdu Nx*Nu | dcdx Ncr*Nx | dcdu Ncr*Nu | J Nx*Nx], row-major.
+  struct RecordPacking {
+    static constexpr int kFlags = 2 * Nx * Nx + Nx * Nu + Ncr * Nx + Ncr * Nu;
+    std::vector<uint8_t> keep = std::vector<uint8_t>(kFlags, 0);
+    int n_fx = 0, n_fu = 0, n_cx = 0, n_cu = 0, n_J = 0;
+    void count()
+    {
+      auto cnt = [&](int off, int len) { int c = 0; for (int e = 0; e < len; ++e) c += keep[off + e] != 0; return c; };
+      n_fx = cnt(0, Nx * Nx); n_fu = cnt(Nx * Nx, Nx * Nu); n_cx = cnt(Nx * Nx + Nx * Nu, Ncr * Nx);
+      n_cu = cnt(Nx * Nx + Nx * Nu + Ncr * Nx, Ncr * Nu); n_J = cnt(Nx * Nx + Nx * Nu + Ncr * Nx + Ncr * Nu, Nx * Nx);
+    }
+    int64_t doubles(int Nn) const { return (int64_t)Nn * (2 * Nx + n_fx + n_fu + Ncr + n_cx + n_cu) + Nx + n_J; }
+  };
+  /// marks the Jacobian entries that are non-zero in the full record `rec`
+  void probe_record(const double * rec, RecordPacking & pk) const
+  {
+    const int Nn = N();
+    const double *dfx = rec + 2 * Nn * Nx, *dfu = dfx + Nn * Nx * Nx, *dcx = dfu + Nn * Nx * Nu + Nn * Ncr,
+                 *dcu = dcx + Nn * Ncr * Nx, *Jm = dcu + Nn * Ncr * Nu + Nx;
+    uint8_t * k = pk.keep.data();
+    auto mark = [&](const double * blk, int blocks, int len) {
+      for (int b = 0; b < blocks; ++b)
+        for (int e = 0; e < len; ++e) k[e] |= !(blk[(size_t)b * len + e] == 0.0);
+      k += len;
+    };
+    mark(dfx, Nn, Nx * Nx); mark(dfu, Nn, Nx * Nu); mark(dcx, Nn, Ncr * Nx); mark(dcu, Nn, Ncr * Nu); mark(Jm, 1, Nx * Nx);
+    pk.count();
+  }
+  /// like probe_default: a few ticks after t, perturbed states on the desired trajectory (deterministic)
+  RecordPacking probe_record_default(double t) const
+  {
+    RecordPacking pk;
+    std::vector<double> rec((size_t)record_doubles(N()));
+    uint64_t lcg = 0x9E3779B97F4A7C15ull;
+    for (int s = 0; s < 6; ++s) {
+      const double ts = t + s * prm_.tf / double(N());
+      TangentX xi{};
+      for (auto & v : xi) {
+        lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+        v   = (double(lcg >> 11) / 9007199254740992.0 - 0.5);
+      }
+      fill_record(ts, rplus(xdes_(ts), xi), rec.data());
+      probe_record(rec.data(), pk);
+    }
+    return pk;
+  }
+  /// full record -> packed record; false if an entry outside the flags is not zero (the packing does not fit this
+  /// linearisation: the caller falls back to unpacked records)
+  bool pack_record(const double * rec, double * out, const RecordPacking & pk) const
+  {
+    const int Nn = N();
+    bool ok = true;
+    const double * src = rec;
+    const uint8_t * k  = pk.keep.data();
+    auto copy = [&](int len) { for (int e = 0; e < len; ++e) *out++ = *src++; };
+    auto pack = [&](int blocks, int len) {
+      for (int b = 0; b < blocks; ++b)
+        for (int e = 0; e < len; ++e, ++src) {
+          if (k[e]) *out++ = *src;
+          else ok = ok && (*src == 0.0);
+        }
+      k += len;
+    };
+    copy(2 * Nn * Nx);                                   // f, dxdes
+    pack(Nn, Nx * Nx); pack(Nn, Nx * Nu);                // dfdx, dfdu
+    copy(Nn * Ncr);                                      // c
+    pack(Nn, Ncr * Nx); pack(Nn, Ncr * Nu);              // dcdx, dcdu
+    copy(Nx);                                            // e
+    pack(1, Nx * Nx);                                    // J
+    return ok;
   }
   static constexpr int64_t record_doubles(int Nn)
   {
@@ -612,8 +690,15 @@ public:
       mpc_.probe_default(t_probe, keep);
       mpc_.analyze_solver(&keep);
     }
-    layout_ = mpc_.device_layout();
-    recd_   = MPCT::record_doubles(mpc_.N());
+    // packed records: structure of the Jacobians probed like the structure of A, checked per record when packing
+    pack_ = mpc_.probe_record_default(t_probe);
+    if (const char * v = std::getenv("SFB_MPC_PACK_PROBE_EMPTY"); v && v[0] == '1') {  // tests: a probe that saw nothing
+      pack_ = typename MPCT::RecordPacking{};
+      pack_.count();
+    }
+    packed_ = mpc_.params().prune_explicit_zeros && pack_.doubles(mpc_.N()) < MPCT::record_doubles(mpc_.N());
+    layout_ = mpc_.device_layout(packed_ ? &pack_.keep : nullptr);
+    recd_   = packed_ ? pack_.doubles(mpc_.N()) : MPCT::record_doubles(mpc_.N());
     du0_.resize((size_t)B_ * MPCT::Nu);
     iter_.resize(B_);
     code_.resize(B_);
@@ -642,18 +727,35 @@ public:
       const int T = (int)std::min<int64_t>(threads_, B_ / chunks);
       std::vector<std::atomic<int>> done(chunks);
       for (auto & d : done) d.store(0);
-      std::atomic<int> failed{0};
+      std::atomic<int> failed{0}, misfit{0};
+      const bool packed = packed_;
       std::vector<std::thread> th;
       for (int k = 0; k < T; ++k)
         th.emplace_back([&, k] {
+          std::vector<double> scratch(packed ? (size_t)MPCT::record_doubles(mpc_.N()) : 0);
           for (int64_t c0 = 0; c0 < chunks; ++c0) {  // every thread takes its share of chunk after chunk
             const int64_t b0 = B_ * c0 / chunks, b1 = B_ * (c0 + 1) / chunks, cnt = b1 - b0;
-            for (int64_t b = b0 + cnt * k / T; b < b0 + cnt * (k + 1) / T; ++b) mpc_.fill_record(t[b], xs[b], rec_ + (size_t)b * recd_);
+            for (int64_t b = b0 + cnt * k / T; b < b0 + cnt * (k + 1) / T; ++b) {
+              if (!packed) {
+                mpc_.fill_record(t[b], xs[b], rec_ + (size_t)b * recd_);
+              } else {
+                mpc_.fill_record(t[b], xs[b], scratch.data());
+                if (!mpc_.pack_record(scratch.data(), rec_ + (size_t)b * recd_, pack_)) misfit.store(1);
+              }
+            }
             if (done[c0].fetch_add(1) + 1 == T && sfb_mpc_swarm_upload(swarm_, b0, cnt) != SFB_OK) failed.store(1);  // last one in
           }
         });
       for (auto & x : th) x.join();
       if (failed.load()) sfb_check(SFB_ERR_HIP);
+      if (misfit.load()) {
+        // a linearisation has a non-zero where the probe saw none: unpacked records from now on (same results; warm
+        // starts and solver memory of the swarm are untouched), and this tick's records once more
+        packed_ = false;
+        recd_   = MPCT::record_doubles(mpc_.N());
+        sfb_check(sfb_mpc_swarm_set_jac_keep(swarm_, nullptr, nullptr));
+        step_fill_unpacked(t, xs);
+      }
     }
     if (const char * tv = std::getenv("SFB_MPC_TIMING"); tv && tv[0] == '1')
       std::fprintf(stderr, "[MPCSwarmDevice] linearise  %8.3f ms (uploads of finished chunks in flight)\n",
@@ -675,10 +777,16 @@ public:
   /// the linearisation records of the last tick ([agents][record_doubles], in the swarm's pinned buffer)
   const double * records() const { return rec_; }
   int64_t record_doubles() const { return recd_; }
+  bool packed_records() const { return packed_; }
   sfb_mpc_swarm * handle() { return swarm_; }
 
 private:
   static constexpr int64_t kUploadChunks = 8;
+  template<class XT>
+  void step_fill_unpacked(const std::vector<double> & t, const std::vector<XT> & xs)
+  {
+    parallel_for(0, B_, [&](int64_t b) { mpc_.fill_record(t[b], xs[b], rec_ + (size_t)b * recd_); });
+  }
   template<class Fn>
   void parallel_for(int64_t b0, int64_t b1, Fn && fn)
   {
@@ -697,6 +805,8 @@ private:
   std::unique_ptr<typename MPCT::DeviceLayout> layout_;
   sfb_mpc_swarm * swarm_ = nullptr;
   double * rec_ = nullptr;  // the swarm's pinned record buffer
+  typename MPCT::RecordPacking pack_;
+  bool packed_ = false;
   std::vector<double> du0_;
   std::vector<uint32_t> iter_;
   std::vector<int32_t> code_;

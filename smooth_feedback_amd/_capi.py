@@ -48,6 +48,7 @@ class SfbMPCLayout(C.Structure):
         ("nx", C.c_int32), ("nu", C.c_int32), ("ncr", C.c_int32), ("kmesh", C.c_int32), ("nivals", C.c_int32),
         ("tf", C.c_double), ("alpha", C.c_void_p), ("D", C.c_void_p), ("nparts", C.c_int32),
         ("part_kind", C.c_void_p), ("part_dof", C.c_void_p), ("crl", C.c_void_p), ("cru", C.c_void_p),
+        ("jac_keep", C.c_void_p),
     ]
 
 
@@ -112,6 +113,9 @@ def _load():
     L.sfb_mpc_swarm_destroy.argtypes = [vp]
     L.sfb_mpc_swarm_destroy.restype = None
     L.sfb_mpc_swarm_reset_warmstart.argtypes = [vp]
+    L.sfb_mpc_swarm_set_jac_keep.argtypes = [vp, vp, C.POINTER(C.c_int64)]
+    L.sfb_mpc_swarm_host_records.argtypes = [vp, C.POINTER(C.c_void_p)]
+    L.sfb_mpc_swarm_upload.argtypes = [vp, i64, i64]
     L.sfb_mpc_swarm_step_host.argtypes = [vp, C.POINTER(SfbQPParams), dp, dp, i32, dp, dp, dp, dp, dp]
     L.sfb_mpc_swarm_debug_buffers.argtypes = [vp] + [C.POINTER(C.c_void_p)] * 3
     L.sfb_random_qp_batch.argtypes = [C.c_uint32, i64, i32, i32, C.c_double] + [dp] * 5

@@ -47,6 +47,7 @@ sfb_status check_layout(const sfb_mpc_layout *L)
     return sfb::fail(SFB_ERR_INVALID_ARG, "layout: part_kind / part_dof missing");
   if (L->nivals > sfb::kMpcMaxIvals || L->kmesh > sfb::kMpcMaxKmesh || L->nx > sfb::kMpcMaxNx || L->ncr > sfb::kMpcMaxNcr)
     return sfb::fail(SFB_ERR_UNSUPPORTED, "layout: supported up to 128 intervals, 8 nodes per interval, nx 24, ncr 16");
+  if (L->jac_keep && L->nu > 32) return sfb::fail(SFB_ERR_UNSUPPORTED, "layout: jac_keep needs nu <= 32");
   int dof = 0;
   for (int g = 0; g < L->nparts; ++g) {
     const int k = L->part_kind[g], d = L->part_dof[g];
@@ -56,6 +57,50 @@ sfb_status check_layout(const sfb_mpc_layout *L)
   }
   if (L->nparts > 0 && dof != L->nx) return sfb::fail(SFB_ERR_INVALID_ARG, "layout: part dofs do not sum to nx");
   return SFB_OK;
+}
+
+// offsets of the record's fields; keep != nullptr: per-agent Jacobians packed by the flags (sfb.h, jac_keep)
+void set_packing(sfb::MpcAsmParams &p, bool shared, const uint8_t *keep)
+{
+  const int64_t N = p.N, nx = p.nx, nu = p.nu, ncr = p.ncr;
+  int64_t njx = N * nx * nx, nju = N * nx * nu, ncx = N * ncr * nx, ncu = N * ncr * nu, nJ = nx * nx;
+  p.packed = 0;
+  if (keep && !shared) {
+    p.packed = 1;
+    auto masks = [&](const uint8_t *f, int rows, int cols, uint32_t *km, uint16_t *kp) {
+      int cnt = 0;
+      for (int d = 0; d < rows; ++d) {
+        kp[d] = (uint16_t)cnt;
+        uint32_t mk = 0;
+        for (int c = 0; c < cols; ++c)
+          if (f[d * cols + c]) { mk |= 1u << c; ++cnt; }
+        km[d] = mk;
+      }
+      return cnt;
+    };
+    const uint8_t *f = keep;
+    p.n_fx = masks(f, (int)nx, (int)nx, p.km_fx, p.kp_fx); f += nx * nx;
+    p.n_fu = masks(f, (int)nx, (int)nu, p.km_fu, p.kp_fu); f += nx * nu;
+    p.n_cx = masks(f, (int)ncr, (int)nx, p.km_cx, p.kp_cx); f += ncr * nx;
+    p.n_cu = masks(f, (int)ncr, (int)nu, p.km_cu, p.kp_cu); f += ncr * nu;
+    p.n_J  = masks(f, (int)nx, (int)nx, p.km_J, p.kp_J);
+    njx = N * p.n_fx; nju = N * p.n_fu; ncx = N * p.n_cx; ncu = N * p.n_cu; nJ = p.n_J;
+  }
+  int64_t o = 0;
+  p.o_f = (int)o; o += N * nx;
+  p.o_dx = (int)o; o += N * nx;
+  if (!shared) {
+    p.o_dfdx = (int)o; o += njx;
+    p.o_dfdu = (int)o; o += nju;
+  }
+  p.o_c = (int)o; o += N * ncr;
+  if (!shared) {
+    p.o_dcdx = (int)o; o += ncx;
+    p.o_dcdu = (int)o; o += ncu;
+  }
+  p.o_e = (int)o; o += nx;
+  p.o_J = (int)o; o += nJ;
+  p.rec_doubles = o;
 }
 
 // ad(a) of the bundle as a sign/index table (lie.hpp: SE2::ad, SO3::ad = hat)
@@ -70,21 +115,7 @@ void fill_params(const sfb_mpc_layout *L, bool shared, sfb::MpcAsmParams &p)
   p.nnzA       = p.nnz_dyn + p.nnz_cr + L->nx * L->nx;
   p.m          = (int)(s.dyn_f + s.cr_c + L->nx);
   p.tf         = L->tf;
-  int64_t o = 0;
-  p.o_f = (int)o; o += s.dyn_f;
-  p.o_dx = (int)o; o += s.dyn_f;
-  if (!shared) {
-    p.o_dfdx = (int)o; o += s.dyn_jx;
-    p.o_dfdu = (int)o; o += s.dyn_ju;
-  }
-  p.o_c = (int)o; o += s.cr_c;
-  if (!shared) {
-    p.o_dcdx = (int)o; o += s.cr_jx;
-    p.o_dcdu = (int)o; o += s.cr_ju;
-  }
-  p.o_e = (int)o; o += s.ce_e;
-  p.o_J = (int)o; o += s.ce_J;
-  p.rec_doubles = o;
+  set_packing(p, shared, shared ? nullptr : L->jac_keep);
   if (shared) {
     p.o_dfdx = 0;
     p.o_dfdu = (int)s.dyn_jx;
@@ -114,6 +145,7 @@ void fill_params(const sfb_mpc_layout *L, bool shared, sfb::MpcAsmParams &p)
 struct sfb_mpc_swarm {
   sfb_sparse_qp_plan *plan = nullptr;
   sfb::MpcAsmParams rec_own{}, rec_shared{};
+  int64_t rec_full_doubles = 0;  // per-agent record without packing: what the record buffers are sized for
   int64_t agents = 0, shared_doubles = 0;
   int n = 0, m = 0, nnzP = 0, nnzA = 0, nu = 0, uoff = 0, devid = 0;
   size_t wsd = 0;  // solver workspace of the whole swarm, in doubles
@@ -185,9 +217,11 @@ sfb_status sfb_mpc_swarm_create(sfb_sparse_qp_plan *plan, const sfb_mpc_layout *
   if (st != SFB_OK) return st;
   if (agents < 1 || agents > 0x7FFFFFFFll) return sfb::fail(SFB_ERR_INVALID_ARG, "agents must be in [1, 2^31-1]");
   const sfb::SparsePlanHost &h = sfb::plan_io(plan);
-  sfb::MpcAsmParams p, ps;
+  sfb::MpcAsmParams p, ps, pfull;
   fill_params(layout, false, p);
   fill_params(layout, true, ps);
+  pfull = p;
+  set_packing(pfull, false, nullptr);  // buffers are sized for unpacked records: the packing may be switched later
   const int n = layout->nx * (p.N + 1) + layout->nu * p.N;
   if (h.n != n || h.m != p.m || h.nnzA != p.nnzA) return sfb::fail(SFB_ERR_INVALID_ARG, "plan does not have the sizes of the layout's QP");
   {  // the pattern of A must be the one the kernel writes (ocp_to_qp_allocate :56-69)
@@ -219,7 +253,7 @@ sfb_status sfb_mpc_swarm_create(sfb_sparse_qp_plan *plan, const sfb_mpc_layout *
   st = sfb::require_device();
   if (st != SFB_OK) return st;
   auto *S = new sfb_mpc_swarm;
-  S->plan = plan; S->rec_own = p; S->rec_shared = ps; S->agents = agents;
+  S->plan = plan; S->rec_own = p; S->rec_shared = ps; S->agents = agents; S->rec_full_doubles = pfull.rec_doubles;
   S->n = n; S->m = p.m; S->nnzP = h.nnzP; S->nnzA = p.nnzA; S->nu = layout->nu; S->uoff = layout->nx * (p.N + 1);
   S->shared_doubles = sfb_mpc_shared_jac_doubles(layout);
   {
@@ -230,7 +264,7 @@ sfb_status sfb_mpc_swarm_create(sfb_sparse_qp_plan *plan, const sfb_mpc_layout *
   }
   hipError_t e = hipGetDevice(&S->devid);
   const size_t B = (size_t)agents, N = (size_t)n, M = (size_t)p.m;
-  const size_t doubles = B * ((size_t)h.nnzP + N + (size_t)p.nnzA + 2 * M + 2 * (N + M) + (size_t)p.rec_doubles + (size_t)layout->nu) + S->wsd +
+  const size_t doubles = B * ((size_t)h.nnzP + N + (size_t)p.nnzA + 2 * M + 2 * (N + M) + (size_t)pfull.rec_doubles + (size_t)layout->nu) + S->wsd +
                          (size_t)S->shared_doubles + (size_t)h.nnzP + N;
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&S->mem), doubles * sizeof(double) + B * 12);
   if (e != hipSuccess) {
@@ -247,7 +281,7 @@ sfb_status sfb_mpc_swarm_create(sfb_sparse_qp_plan *plan, const sfb_mpc_layout *
   S->y = d; d += B * M;
   S->wx = d; d += B * N;
   S->wy = d; d += B * M;
-  S->rec = d; d += B * p.rec_doubles;
+  S->rec = d; d += B * pfull.rec_doubles;
   S->shared = d; d += S->shared_doubles;
   S->du0 = d; d += B * layout->nu;
   double *stage = d; d += h.nnzP + N;  // one copy of Px and q, replicated below
@@ -301,7 +335,7 @@ sfb_status sfb_mpc_swarm_host_records(sfb_mpc_swarm *S, double **records)
   if (sfb_status sd = check_swarm_device(S); sd != SFB_OK) return sd;
   std::lock_guard<std::mutex> lk(S->mu);
   if (!S->pinned) {
-    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&S->pinned), (size_t)S->agents * (size_t)S->rec_own.rec_doubles * 8, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&S->pinned), (size_t)S->agents * (size_t)S->rec_full_doubles * 8, hipHostMallocDefault);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&S->up_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
       if (S->pinned) (void)hipHostFree(S->pinned);
@@ -328,6 +362,21 @@ sfb_status sfb_mpc_swarm_upload(sfb_mpc_swarm *S, int64_t first, int64_t count)
   if (e != hipSuccess) return sfb::hip_fail(e, "hipMemcpyAsync(swarm records)");
   (void)hipStreamQuery(S->up_stream);  // flush: the copy must start now, not at the next synchronisation
   std::fill(S->uploaded.begin() + first, S->uploaded.begin() + first + count, (uint8_t)1);
+  return SFB_OK;
+}
+
+sfb_status sfb_mpc_swarm_set_jac_keep(sfb_mpc_swarm *S, const uint8_t *jac_keep, int64_t *record_doubles)
+{
+  if (!S) return sfb::fail(SFB_ERR_INVALID_ARG, "swarm is NULL");
+  if (jac_keep && S->rec_own.nu > 32) return sfb::fail(SFB_ERR_UNSUPPORTED, "jac_keep needs nu <= 32");
+  std::lock_guard<std::mutex> lk(S->mu);
+  if (S->up_stream) {  // nothing of the old layout may be in flight
+    hipError_t e = hipStreamSynchronize(S->up_stream);
+    if (e != hipSuccess) return sfb::hip_fail(e, "hipStreamSynchronize");
+    std::fill(S->uploaded.begin(), S->uploaded.end(), (uint8_t)0);
+  }
+  set_packing(S->rec_own, false, jac_keep);
+  if (record_doubles) *record_doubles = S->rec_own.rec_doubles;
   return SFB_OK;
 }
 

@@ -11,6 +11,15 @@
 
 namespace sfb {
 
+// entry (d, c) of block number `block` of a PACKED Jacobian array (`kept` entries per block, see MpcAsmParams)
+__device__ __forceinline__ double jac_entry(const double *__restrict__ blk, const int kept, const uint32_t *km, const uint16_t *kp,
+                                            const int block, const int d, const int c)
+{
+  const uint32_t mk = km[d];
+  if (((mk >> c) & 1u) == 0u) return 0.0;
+  return blk[(size_t)block * kept + kp[d] + __popc(mk & ((1u << c) - 1u))];
+}
+
 __global__ void __launch_bounds__(256) mpc_assemble_kernel(const MpcAsmParams p, const double *__restrict__ records,
                                                            const double *__restrict__ shared_jac,
                                                            double *__restrict__ gAx, double *__restrict__ gl,
@@ -22,6 +31,7 @@ __global__ void __launch_bounds__(256) mpc_assemble_kernel(const MpcAsmParams p,
   const double *jac = shared_jac ? shared_jac : rec;
   const int nx = p.nx, nu = p.nu, ncr = p.ncr, kmesh = p.kmesh;
   const double tf = p.tf;
+  const bool pk   = p.packed != 0 && shared_jac == nullptr;
   if (idx < p.nnzA) {
     double v;
     if (idx < p.nnz_dyn) {  // ocp_to_qp_update_dyn :240-275
@@ -31,11 +41,14 @@ __global__ void __launch_bounds__(256) mpc_assemble_kernel(const MpcAsmParams p,
       const double alpha = p.alpha[s];
       if (pos >= kmesh + nx) {  // u block :259
         const int c = pos - (kmesh + nx);
-        v           = 0.0 + tf * jac[p.o_dfdu + (node * nx + d) * nu + c];
+        const double ju = pk ? jac_entry(jac + p.o_dfdu, p.n_fu, p.km_fu, p.kp_fu, node, d, c)
+                             : jac[p.o_dfdu + (node * nx + d) * nu + c];
+        v               = 0.0 + tf * ju;
       } else if (pos >= i && pos < i + nx) {  // x block of the node itself
         const int c = pos - i;
         v           = 0.0;
-        v += tf * jac[p.o_dfdx + (node * nx + d) * nx + c];  // :258
+        v += tf * (pk ? jac_entry(jac + p.o_dfdx, p.n_fx, p.km_fx, p.kp_fx, node, d, c)
+                      : jac[p.o_dfdx + (node * nx + d) * nx + c]);  // :258
         if (p.has_ad) {                                      // :262-264   -tf/2 ad(f + dxdes)
           const int code = p.adsrc[d * nx + c];
           double a       = 0.0;
@@ -54,9 +67,16 @@ __global__ void __launch_bounds__(256) mpc_assemble_kernel(const MpcAsmParams p,
       }
     } else if (idx < p.nnz_dyn + p.nnz_cr) {  // ocp_to_qp_update_cr :279-323
       const int q = idx - p.nnz_dyn, row = q / (nx + nu), pos = q - row * (nx + nu);
-      v           = (pos < nx) ? jac[p.o_dcdx + row * nx + pos] : jac[p.o_dcdu + row * nu + (pos - nx)];
+      if (pk) {
+        const int cnode = row / ncr, cd = row - cnode * ncr;
+        v = (pos < nx) ? jac_entry(jac + p.o_dcdx, p.n_cx, p.km_cx, p.kp_cx, cnode, cd, pos)
+                       : jac_entry(jac + p.o_dcdu, p.n_cu, p.km_cu, p.kp_cu, cnode, cd, pos - nx);
+      } else {
+        v = (pos < nx) ? jac[p.o_dcdx + row * nx + pos] : jac[p.o_dcdu + row * nu + (pos - nx)];
+      }
     } else {  // ocp_to_qp_update_ce :326-373
-      v = rec[p.o_J + (idx - p.nnz_dyn - p.nnz_cr)];
+      const int e = idx - p.nnz_dyn - p.nnz_cr;
+      v           = pk ? jac_entry(rec + p.o_J, p.n_J, p.km_J, p.kp_J, 0, e / nx, e % nx) : rec[p.o_J + e];
     }
     gAx[b * p.nnzA + idx] = v;
   } else if (idx < p.nnzA + p.m) {

@@ -23,6 +23,13 @@ struct MpcAsmParams {
   double crl[kMpcMaxNcr], cru[kMpcMaxNcr];
   // ad(s) of the state group as a table over (d, c): 0 -> 0.0, +(k+1) -> s[k], -(k+1) -> -s[k]
   int8_t adsrc[kMpcMaxNx * kMpcMaxNx];
+  // Packed per-agent Jacobians (sfb_mpc_layout::jac_keep): the record holds only the entries whose flag is set, row by
+  // row; an entry (d, c) of a block is at [kept entries of the rows before d] + popcount(row mask below bit c), the
+  // others are 0.0.  km_*: one 32-bit column mask per row, kp_*: kept entries in the rows before, n_*: kept per block.
+  int packed;
+  int n_fx, n_fu, n_cx, n_cu, n_J;
+  uint32_t km_fx[kMpcMaxNx], km_fu[kMpcMaxNx], km_cx[kMpcMaxNcr], km_cu[kMpcMaxNcr], km_J[kMpcMaxNx];
+  uint16_t kp_fx[kMpcMaxNx], kp_fu[kMpcMaxNx], kp_cx[kMpcMaxNcr], kp_cu[kMpcMaxNcr], kp_J[kMpcMaxNx];
 };
 
 hipError_t mpc_assemble_launch(const MpcAsmParams &p, int64_t batch, const double *records, const double *shared_jac,

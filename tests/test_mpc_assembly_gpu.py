@@ -94,3 +94,62 @@ def test_device_swarm_front_matches_host_swarm_front(sfb, variant, K, B):
     u_d, c_d, i_d = M.mpc_swarm_step(variant, K, B, 3, device=True)
     assert np.array_equal(c_h, c_d) and np.array_equal(i_h, i_d) and np.array_equal(u_h, u_d)
     assert (c_d == 0).all() and np.all(np.abs(u_d) <= 0.5 + 1e-6)
+
+
+def _packed_layout(sfb, L, rec):
+    keep = L.jac_keep_of(rec)
+    parts = [(int(k), int(d)) for k, d in zip(L.kind, L.dof)]
+    return sfb.MPCLayout(L.nx, L.nu, L.ncr, L.kmesh, L.nivals, L.tf, L.alpha, L.D, parts=parts, crl=L.crl, cru=L.cru, jac_keep=keep)
+
+
+@pytest.mark.parametrize("variant,K,batch", [(6, 10, 7), (12, 50, 120)])
+def test_packed_records_assemble_to_the_same_bits(sfb, variant, K, batch):
+    """sfb_mpc_layout::jac_keep: records that carry only the Jacobian entries flagged non-zero (the dense blocks of a
+    bundle state are mostly structural zeros) assemble to the same A, l, u as the full records, which equal the host
+    transcription bit for bit."""
+    Av, l, u = M.mpc_assemble_batch(variant, K, batch, seed=9)
+    L, rec = M.mpc_records(variant, K, batch, seed=9)
+    Lp = _packed_layout(sfb, L, rec)
+    packed = Lp.pack_records(rec)
+    assert packed.shape[1] == Lp.record_doubles() < L.record_doubles() * 0.6
+    A2, l2, u2 = _assemble_on_device(Lp, packed)
+    assert np.array_equal(A2, Av) and np.array_equal(l2, l) and np.array_equal(u2, u)
+    print("record doubles", L.record_doubles(), "->", Lp.record_doubles())
+
+
+def test_swarm_switches_record_packing_in_place(sfb):
+    """sfb_mpc_swarm_set_jac_keep: a swarm created for packed records takes a packed tick, is switched to unpacked
+    records (what a front does when a linearisation does not fit the flags) and back; warm starts survive the switches
+    -- every tick equals the same tick of a swarm that always used full records."""
+    variant, K, B = 12, 50, 48
+    d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
+    plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K))
+    prm = sfb.QPSolverParams(max_iter=4000)
+    L, rec1 = M.mpc_records(variant, K, B, seed=21)
+    _, rec2 = M.mpc_records(variant, K, B, seed=22)
+    _, rec3 = M.mpc_records(variant, K, B, seed=23)
+    Lp = _packed_layout(sfb, L, np.concatenate([rec1, rec2, rec3]))
+    ref = sfb.MPCSwarm(plan, L, Pv, np.zeros(d["n"]), B)
+    sw = sfb.MPCSwarm(plan, Lp, Pv, np.zeros(d["n"]), B)
+    sw._rec_doubles = Lp.record_doubles()
+    for t, rec in enumerate((rec1, rec2, rec3)):
+        want = ref.step_host(rec, prm)
+        if t == 1:
+            assert sw.set_jac_keep(None) == L.record_doubles()
+            got = sw.step_host(rec, prm)
+            assert sw.set_jac_keep(Lp.jac_keep) == Lp.record_doubles()
+        else:
+            got = sw.step_host(Lp.pack_records(rec), prm)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b), "tick %d" % t
+    ref.close(); sw.close()
+
+
+def test_device_swarm_front_falls_back_to_full_records(sfb, monkeypatch):
+    """MPCSwarmDevice packs its records with flags probed at construction and checks every record while packing; with
+    a probe that saw nothing (test knob) the first tick does not fit, the front switches the swarm to full records and
+    carries on: same closed loop as the host front."""
+    u_h, c_h, i_h = M.mpc_swarm_step(6, 30, 64, 3)
+    monkeypatch.setenv("SFB_MPC_PACK_PROBE_EMPTY", "1")
+    u_d, c_d, i_d = M.mpc_swarm_step(6, 30, 64, 3, device=True)
+    assert np.array_equal(c_h, c_d) and np.array_equal(i_h, i_d) and np.array_equal(u_h, u_d)
