@@ -507,7 +507,7 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
   // the final values straight into the copies from the panels (scattered 8-byte writes) is quicker for a lone
   // wave but costs the batch more HBM traffic than this gather + coalesced write -- measured.
   // (branch-free, DEPTH gathers in flight per lane: padding slots read the always-zero accumulator; the copies'
-  //  lengths are multiples of kSweepPadDev * 128 >= DEPTH * 64)
+  //  lengths are multiples of 8 * 128 >= DEPTH * 64)
   auto gather_copy = [&](const int32_t *__restrict__ map, double *__restrict__ dst, const int total) {
     for (int q0 = lane; q0 < total; q0 += kWave * DEPTH) {
       int src[DEPTH];
@@ -594,7 +594,7 @@ __device__ __forceinline__ void stream_wait(vdouble2 &a, vint2 &b)
 // fetched with one 16-byte and one 8-byte load; the LDS reads of both slots are issued together (one
 // LDS round trip per unit on the dependent chain of a lone wave).  Branch-free; DEPTH units
 // (= 2 x DEPTH slots per lane) are in flight ahead of their use so the ~1.7 us HBM latency of a lone
-// wave is covered; t has k+1 entries, t[k] is the padding slot; `units` is a multiple of kSweepPadDev.
+// wave is covered; t has k+1 entries, t[k] is the padding slot; `units` is a multiple of the prefetch block (8).
 template<int DEPTH, bool BYTEOFF, bool LEAN>
 __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const int units, const double *vals, double *t,
                                  const int lane, const int32_t *__restrict__ mask32, const int full0, const int full1)

@@ -630,7 +630,7 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
       fprintf(stderr, "\n");
     }
     units           = steps;
-    units = ((units + SparsePlanHost::kSweepPad - 1) / SparsePlanHost::kSweepPad) * SparsePlanHost::kSweepPad;
+    units = ((units + 7) / 8) * 8;  // whole prefetch blocks of the kernel (8 units); an empty unit still costs a lone wave 80 ns
     const size_t total = (size_t)(units + SparsePlanHost::kSweepPad) * 128;
     xmap.assign(total, -1);
     // indices are stored as BYTE offsets into the work vector when they fit 16 bits (saves the kernel four
