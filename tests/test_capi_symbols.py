@@ -77,3 +77,25 @@ def test_random_qp_generator_properties(sfb):
     assert 0.15 < np.mean(A != 0) < 0.45
     P2, *_ = sfb.random_qp_batch(5, 8, 20, 10, 0.3)
     assert np.array_equal(P, P2)
+
+
+def test_header_is_plain_c_and_fronts_compile_standalone(tmp_path):
+    """include/sfb.h is the C-ABI: it must compile as C99 on its own; the C++ front -- under the reference's include
+    paths and namespace -- must compile without anything else of this repo (header-only, like the reference)."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None or shutil.which("g++") is None:
+        import pytest
+        pytest.skip("no host compiler")
+    c = tmp_path / "abi.c"
+    c.write_text('#include <sfb.h>\nint main(void) { sfb_qp_params p; sfb_mpc_layout l; sfb_workspace *w = 0; (void)p; (void)l; (void)w; return 0; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), "-c", str(c),
+                    "-o", str(tmp_path / "abi.o")], check=True)
+    cpp = tmp_path / "front.cpp"
+    cpp.write_text("#include <smooth/feedback/qp.hpp>\n#include <smooth/feedback/qp_solver.hpp>\n#include <smooth/feedback/ocp.hpp>\n"
+                   "#include <smooth/feedback/ocp_to_qp.hpp>\n#include <smooth/feedback/mpc.hpp>\n#include <smooth/feedback/ekf.hpp>\n"
+                   "#include <smooth/feedback/asif.hpp>\n#include <smooth/feedback/mesh.hpp>\n"
+                   "int main() { smooth::feedback::QPSolverParams p; smooth::feedback::QuadraticProgram<2, 3> q; (void)p; (void)q; return 0; }\n")
+    subprocess.run(["g++", "-std=c++20", "-Wall", "-fsyntax-only", "-I", os.path.join(root, "include"), str(cpp)], check=True)
