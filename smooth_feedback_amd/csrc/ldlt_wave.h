@@ -35,8 +35,11 @@ __device__ inline int ldlt_factor_lds(const int k, double *W, int *perm, double 
     const double a  = cand ? fabs(dg) : -1.0;
     const double mx = wave_max(a);
     unsigned long long bal = wave_ballot(cand && a == mx);
-    // all-NaN diagonal: nothing compares equal; keep kk (the oracle's strict '>' does the same)
-    const int p = bal ? (int)__builtin_ctzll(bal) : kk;
+    // Eigen's maxCoeff visitor starts from the first candidate and replaces it only by a strictly greater value: NaNs
+    // further down are skipped (fmax / the equality test above do the same), but a NaN AT kk stays the "maximum" --
+    // the pivot is then kk itself (and, being invalid, fails the factorisation unless the column below it is zero)
+    const double dkk = lane_bcast(dg, kk);
+    const int p      = (bal && !(dkk != dkk)) ? (int)__builtin_ctzll(bal) : kk;
 
     if (p != kk) {
       if (lane == 0) {

@@ -221,3 +221,34 @@ def test_cpp_front_predict_linear_with_rk4(sfb):
     rc = M.lib().sfbx_test_ekf_predict_linear9(*[b.ctypes.data_as(C.c_void_p) for b in bufs], err.ctypes.data_as(C.c_void_p))
     assert rc == 0
     assert err[0] < 1e-6 and err[1] < 1e-6, err
+
+
+@pytest.mark.parametrize("dof,ny", [(6, 3), (3, 2), (9, 3), (3, 10)])
+def test_non_finite_inputs_follow_the_reference_semantics(sfb, oracle, dof, ny):
+    """NaN / inf / singular innovation covariances: the reference's EKF does not validate anything -- the values go
+    through Eigen's LDLT (a NaN on the diagonal stays the pivot, an invalid pivot over a non-zero column is
+    info() != Success, a zero pivot divides to 0) and the products.  Per-lane and generic kernels both give the
+    oracle's P, delta and info, bit for bit (NaN payloads aside); the other filters of the batch are unaffected."""
+    B = 16
+    rng = np.random.default_rng(dof * 31 + ny)
+    P = _flat(_spd(rng, B, dof)); A = _flat(rng.uniform(-1, 1, (B, dof, dof)))
+    Q = _flat(0.1 * np.tile(np.eye(dof), (B, 1, 1))); dt = np.full(B, 0.02)
+    H = _flat(rng.uniform(-1, 1, (B, ny, dof))); R = _flat(0.1 * np.tile(np.eye(ny), (B, 1, 1)) + 0.01 * _spd(rng, B, ny))
+    r = rng.uniform(-1, 1, (B, ny))
+    clean = (P.copy(), A.copy(), Q.copy(), H.copy(), R.copy(), r.copy())
+    P[1, 0] = np.nan              # NaN on the covariance diagonal
+    A[2, 1] = np.nan
+    H[3, :] = 0.0; R[3, :] = 0.0  # S = 0: the all-zero branch of the factorisation
+    R[4, 0] = np.nan              # NaN at the first pivot of S
+    R[5, -1] = np.nan             # NaN at the last diagonal entry of S
+    r[6, 0] = np.inf
+    H[7, 0] = np.inf
+    R[8, :] = 0.0; H[8, :] = 0.0; H[8, 0] = 1e-200   # S tiny: |d| <= DBL_MIN divides to 0
+    P1, d1, i1 = sfb.ekf_step_batch_host(P, dof, A=A, Q=Q, dt=dt, H=H, R=R, r=r)
+    refp = oracle.ekf_predict_batch(A, Q, dt, P)
+    ref, dref, iref = oracle.ekf_update_batch(H, R, r, refp, dof)
+    assert np.array_equal(i1, iref), (i1, iref)
+    assert np.array_equal(P1, ref, equal_nan=True) and np.array_equal(d1, dref, equal_nan=True)
+    Pc, dc, ic = sfb.ekf_step_batch_host(clean[0], dof, A=clean[1], Q=clean[2], dt=dt, H=clean[3], R=clean[4], r=clean[5])
+    for b in (0, 9, 15):
+        assert np.array_equal(Pc[b], P1[b]) and np.array_equal(dc[b], d1[b])

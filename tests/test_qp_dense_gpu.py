@@ -428,3 +428,32 @@ def test_explicit_workspace_gives_the_same_results(sfb, n, m):
             sfb.solve_qp_batch_device_ws(B, n, m, *[a.data_ptr() for a in d], x.data_ptr(), y.data_ptr(), obj.data_ptr(),
                                          it.data_ptr(), code.data_ptr(), small, prm)
         assert ei.value.status == sfb._capi.SFB_ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("n,m", [(10, 20), (20, 30), (40, 60)])
+def test_non_finite_inputs_follow_the_reference_semantics(sfb, oracle, n, m):
+    """NaN / inf in the problem data: the reference has no input validation -- a NaN in q, P or A simply propagates
+    through the IEEE arithmetic (std::max-style norms ignore it, comparisons with it are false), l = +inf or u = -inf
+    is the pre-check's PrimalInfeasible (qp_solver.hpp:361-374).  Every dense kernel (four-per-wave, one-per-wave, big)
+    must give what the oracle gives: same codes and iteration counts, same primal / dual bit patterns up to NaN
+    payloads; the clean items of the batch are unaffected."""
+    B = 12
+    P, q, A, l, u = sfb.random_qp_batch(3, B, m, n, 0.8)
+    q[1, 0] = np.nan
+    P[2, 0] = np.nan
+    A[3, 1] = np.inf
+    l[4, 2] = np.inf
+    u[5, 3] = -np.inf
+    l[6, 0] = np.nan
+    q[7, :] = np.inf
+    A[8, :] = 0.0
+    prm = sfb.QPSolverParams(max_iter=300)
+    r = sfb.solve_qp_batch_host(P, q, A, l, u, prm)
+    ref = oracle.qp_dense_solve_batch(P, q, A, l, u, params=_oracle_params(oracle, prm))
+    assert np.array_equal(r.code, ref["code"]) and np.array_equal(r.iter, ref["iter"]), (r.code, ref["code"], r.iter, ref["iter"])
+    assert np.array_equal(r.primal, ref["x"], equal_nan=True) and np.array_equal(r.dual, ref["y"], equal_nan=True)
+    assert r.code[4] == 2 and r.code[5] == 2 and r.iter[4] == 0
+    clean = sfb.random_qp_batch(3, B, m, n, 0.8)
+    rc = sfb.solve_qp_batch_host(*clean, prm)
+    for b in (0, 9, 10, 11):
+        assert np.array_equal(rc.primal[b], r.primal[b]) and rc.iter[b] == r.iter[b]

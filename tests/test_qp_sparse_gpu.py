@@ -83,3 +83,32 @@ def test_large_banded_problem_uses_element_indices(sfb, oracle, sweep_mode):
                                        Am.indptr.astype(np.int32), Am.indices.astype(np.int32), Ax, l, u, perm=plan.perm, forder=plan.factor_order(),
                                        params=_oracle_params(oracle, prm), nthreads=3)
     assert _compare(r, ref)
+
+
+def test_non_finite_inputs_follow_the_reference_semantics_sparse(sfb, oracle):
+    """NaN / inf in the values of a shared-pattern batch: no input validation in the reference -- the values propagate
+    through the IEEE arithmetic; l = +inf / u = -inf is the pre-check's PrimalInfeasible.  Codes, iteration counts and
+    the bit patterns of primal / dual (up to NaN payloads) equal the sparse oracle's; clean items are unaffected."""
+    n, m, B = 30, 50, 12
+    P, q, A, l, u = sfb.random_qp_batch(7, B, m, n, 0.15)
+    Pp, Pi, Px, Ap, Aj, Ax = dense_batch_to_sparse(P, A, n, m)
+    clean = (Px.copy(), q.copy(), Ax.copy(), l.copy(), u.copy())
+    q[1, 0] = np.nan
+    Px[2, 0] = np.nan
+    Ax[3, 1] = np.inf
+    l[4, 2] = np.inf
+    u[5, 3] = -np.inf
+    l[6, 0] = np.nan
+    q[7, :] = np.inf
+    Ax[8, :] = 0.0
+    plan = sfb.SparseQPPlan(n, m, Pp, Pi, Ap, Aj)
+    prm = sfb.QPSolverParams(max_iter=300)
+    r = plan.solve_batch_host(Px, q, Ax, l, u, prm)
+    ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Ax, l, u, perm=plan.perm, forder=plan.factor_order(),
+                                       params=_oracle_params(oracle, prm))
+    assert np.array_equal(r.code, ref["code"]) and np.array_equal(r.iter, ref["iter"]), (r.code, ref["code"], r.iter, ref["iter"])
+    assert np.array_equal(r.primal, ref["x"], equal_nan=True) and np.array_equal(r.dual, ref["y"], equal_nan=True)
+    assert r.code[4] == 2 and r.code[5] == 2 and r.iter[4] == 0
+    rc = plan.solve_batch_host(*clean, prm)
+    for b in (0, 9, 10, 11):
+        assert np.array_equal(rc.primal[b], r.primal[b]) and rc.iter[b] == r.iter[b]
