@@ -1,4 +1,4 @@
-"""Randomised parity sweeps (scripts/fuzz_dense.py, scripts/fuzz_sparse.py) as part of the GPU suite: a few hundred random
+"""Randomised parity sweeps (scripts/fuzz_dense.py, fuzz_sparse.py, fuzz_ekf.py) as part of the GPU suite: a few hundred random
 configurations each -- sizes across all dense kernels, random patterns and pruned plans with violating items, solver
 parameters incl. max_iter 0 / 1, stop_check_iter 0 / 1, infinite and equal bounds, warm starts -- every one bit-identical
 to the CPU oracle (codes, iteration counts, primal, dual, objective).  Needs an MI355X."""
@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("script,n", [("fuzz_dense.py", 400), ("fuzz_sparse.py", 150)])
+@pytest.mark.parametrize("script,n", [("fuzz_dense.py", 400), ("fuzz_sparse.py", 150), ("fuzz_ekf.py", 300)])
 def test_randomised_parity_sweep(script, n):
     env = dict(os.environ, N=str(n), SEED="424242")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script)], env=env, cwd=os.path.join(ROOT, "scripts"),
