@@ -14,7 +14,7 @@ if __name__ == "__main__":
     bad = 0
     for it in range(N):
         rng = np.random.default_rng(10**6 + seed0 + it)
-        n = int(rng.integers(2, 40)); m = int(rng.integers(2, 60)); B = int(rng.integers(1, 24))
+        n = int(rng.integers(2, 40)); m = int(rng.integers(2, 60)); B = int(rng.integers(1, int(os.environ.get("BMAX", 24))))
         P, q, A, l, u = sfb.random_qp_batch(int(rng.integers(1, 10**6)), B, m, n, float(rng.choice([0.05, 0.2, 0.6])))
         Pp, Pi, Px, Ap, Aj, Ax = dense_batch_to_sparse(P, A, n, m, upper_only=bool(rng.random() < 0.5))
         mask = rng.random((B, m))
