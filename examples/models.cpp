@@ -700,18 +700,44 @@ int sfbx_mesh(int n_ivals, int K, double * nodes, double * weights, double * Dus
 namespace {
 // safe set and backup controller of examples/mpc_asif_vehicle.cpp:95-104: stay 0.7 away from (0, -2.3); the
 // direction is evaluated at the query point and treated as constant by the differentiation, as in the example
-Vec<1> vehicle_h(double, const X6 & x)
-{
-  const double dx = x.part<0>().x - 0.0, dy = x.part<0>().y - (-2.3);
-  const double nrm = std::sqrt(dx * dx + dy * dy);
-  return {(dx * dx + dy * dy) / nrm - 0.7};
-}
-U2 vehicle_bu(double, const X6 & x)
-{
-  U2 u;
-  u.v = {0.2 * x.part<1>().v[0], -0.5};
-  return u;
-}
+// barrier and backup controller of examples/mpc_asif_vehicle.cpp:95-129 as functors with analytic right-Jacobians (the
+// reference differentiates its lambdas with autodiff; without the members the front falls back to forward differences)
+struct VehicleH {
+  Vec<1> operator()(double, const X6 & x) const
+  {
+    const double dx = x.part<0>().x - 0.0, dy = x.part<0>().y - (-2.3);
+    const double nrm = std::sqrt(dx * dx + dy * dy);
+    return {(dx * dx + dy * dy) / nrm - 0.7};
+  }
+  // h = |p - c| - 0.7 and p (+) a = p + R (a_0, a_1) + O(a^2): dh/da = (p - c)' R / |p - c| on the SE2 translation part
+  void jacobian(double, const X6 & x, Mat<1, 6> & J) const
+  {
+    const auto & g  = x.part<0>();
+    const double dx = g.x - 0.0, dy = g.y - (-2.3), nrm = std::sqrt(dx * dx + dy * dy);
+    J       = Mat<1, 6>::Zero();
+    J(0, 0) = (dx * g.c + dy * g.s) / nrm;
+    J(0, 1) = (-dx * g.s + dy * g.c) / nrm;
+  }
+  Vec<1> operator()(size_t, double t, const X6 & x) const { return (*this)(t, x); }              // swarm callbacks
+  void jacobian(size_t, double t, const X6 & x, Mat<1, 6> & J) const { jacobian(t, x, J); }
+};
+struct VehicleBU {
+  U2 operator()(double, const X6 & x) const
+  {
+    U2 u;
+    u.v = {0.2 * x.part<1>().v[0], -0.5};
+    return u;
+  }
+  void jacobian(double, const X6 &, Mat<2, 6> & J) const
+  {
+    J       = Mat<2, 6>::Zero();
+    J(0, 3) = 0.2;
+  }
+  U2 operator()(size_t, double t, const X6 & x) const { return (*this)(t, x); }
+  void jacobian(size_t, double t, const X6 & x, Mat<2, 6> & J) const { jacobian(t, x, J); }
+};
+Vec<1> vehicle_h(double t, const X6 & x) { return VehicleH{}(t, x); }
+U2 vehicle_bu(double t, const X6 & x) { return VehicleBU{}(t, x); }
 ASIFilterParams<U2> vehicle_asif_params(int K)
 {
   ASIFilterParams<U2> p;
@@ -789,7 +815,7 @@ int sfbx_test_asif(int which, double * u_out, int32_t * code, uint32_t * iter, i
       X6 xx = xdes6(3.7);
       xx.part<0>() = SE2::FromAngle(-2.0, 0.9, -1.9);  // heading towards the obstacle, 1 m away
       U2 ud; ud.v = {0.4, 0.1};
-      const auto [ua, c] = asif(xx, ud, vehicle_h, vehicle_bu);
+      const auto [ua, c] = asif(xx, ud, VehicleH{}, VehicleBU{});
       u_out[0] = ua.v[0]; u_out[1] = ua.v[1]; u_out[2] = 0.0;
       report(asif.qp(), asif.last_solution(), c);
     }
@@ -816,8 +842,8 @@ int sfbx_asif_swarm_step(int64_t batch, uint64_t seed, int K, int ticks, double 
       std::uniform_real_distribution<double> d(-0.5, 0.5);
       ud[b].v = {d(rng), d(rng)};
     }
-    auto hb  = [](size_t, double t, const X6 & xx) { return vehicle_h(t, xx); };
-    auto bub = [](size_t, double t, const X6 & xx) { return vehicle_bu(t, xx); };
+    const VehicleH hb{};    // (SFB_ASIF_FD=1: plain lambdas instead -- forward differences, as before)
+    const VehicleBU bub{};
     std::vector<U2> out;
     for (int tick = 0; tick < ticks; ++tick) {
       if (tick > 0) {  // move every vehicle 25 ms along its filtered input (explicit Euler)
@@ -828,7 +854,12 @@ int sfbx_asif_swarm_step(int64_t batch, uint64_t seed, int K, int ticks, double 
         }
       }
       if (tick == ticks - 1) swarm.copy_warm_start(wx, wy);
-      out = swarm(g, ud, hb, bub);
+      static const bool fd = [] { const char * v = std::getenv("SFB_ASIF_FD"); return v && v[0] == '1'; }();
+      if (fd)
+        out = swarm(g, ud, [](size_t, double t, const X6 & xx) { return vehicle_h(t, xx); },
+                    [](size_t, double t, const X6 & xx) { return vehicle_bu(t, xx); });
+      else
+        out = swarm(g, ud, hb, bub);
     }
     for (int64_t b = 0; b < batch; ++b) { u_out[2 * b] = out[b].v[0]; u_out[2 * b + 1] = out[b].v[1]; }
     std::copy(swarm.codes().begin(), swarm.codes().end(), codes);

@@ -99,6 +99,18 @@ Mat<NO, G::Dof> dr_fd(Fun && fun, const G & g, const Vec<NO> & f0)
   }
   return J;
 }
+// fn(agent, t, x) seen as fn(t, x) for one agent; forwards fn.jacobian(agent, t, x, J) when the callable has one
+template<class Fn, class G>
+struct AgentFn {
+  const Fn & fn;
+  std::size_t agent;
+  auto operator()(double t, const G & x) const { return fn(agent, t, x); }
+  template<class M, class F2 = Fn>  // (F2: keeps the member lookup dependent, so a callable without one is no error)
+  auto jacobian(double t, const G & x, M & J) const -> decltype(std::declval<const F2 &>().jacobian(agent, t, x, J))
+  {
+    return fn.jacobian(agent, t, x, J);
+  }
+};
 }  // namespace detail
 
 /// asif_func.hpp:104-199.  f(x, u) -> Tangent<X>, h(t, x) -> Vec<nh>, bu(t, x) -> U
@@ -122,16 +134,27 @@ void asif_to_qp_update(QuadraticProgram<> & qp, const ASIFProblem<X, U> & pbm, c
   Mat<nx, nx> S    = Mat<nx, nx>::Identity();  // dx/dx0
 
   // value of the dynamics at call time and its derivative w.r.t. u :155-157
+  // Derivatives: the reference differentiates f, h and bu with smooth::diff (autodiff when available).  Here a functor
+  // may carry analytic right-Jacobians -- f.jacobian(x, u, dfdx, dfdu) (the MPC front's convention), h.jacobian(t, x,
+  // dhdx), bu.jacobian(t, x, dbudx) --; whatever is missing is replaced by forward differences (step sqrt(eps)).
+  constexpr bool f_an = requires(Mat<nx, nx> & a, Mat<nx, nu> & b) { f.jacobian(pbm.x0, pbm.u_des, a, b); };
   const Vec<nx> f0 = f(x, pbm.u_des);
-  const Mat<nx, nu> d_f0_du =
-    detail::dr_fd<nx>([&](const U & vu) { return f(x, vu); }, pbm.u_des, f0);
+  Mat<nx, nu> d_f0_du{};
+  if constexpr (f_an) {
+    Mat<nx, nx> unused{};
+    f.jacobian(x, pbm.u_des, unused, d_f0_du);
+  } else {
+    d_f0_du = detail::dr_fd<nx>([&](const U & vu) { return f(x, vu); }, pbm.u_des, f0);
+  }
 
   for (std::size_t k = 0; k != prm.K; ++k) {
     // barrier function and its derivatives w.r.t. (t, x) :161-166
     const HVal hval = h(t, x);
     const double e  = detail::fd_step();
     const HVal ht   = h(t + e, x);
-    const Mat<nh, nx> dh_dx = detail::dr_fd<nh>([&](const X & vx) { return h(t, vx); }, x, hval);
+    Mat<nh, nx> dh_dx{};
+    if constexpr (requires { h.jacobian(t, x, dh_dx); }) h.jacobian(t, x, dh_dx);
+    else dh_dx = detail::dr_fd<nh>([&](const X & vx) { return h(t, vx); }, x, hval);
     // barrier constraint :168-172
     const Mat<nh, nx> dh_dx0 = dh_dx * S;
     const Mat<nh, nu> Ak     = dh_dx0 * d_f0_du;
@@ -152,9 +175,31 @@ void asif_to_qp_update(QuadraticProgram<> & qp, const ASIFProblem<X, U> & pbm, c
         x = rplus(x, dx);
       }
       {
-        auto fcl_fun       = [&](const X & vx) { return f(vx, bu(t, vx)); };
-        const Vec<nx> fcl  = fcl_fun(x);
-        Mat<nx, nx> dS     = detail::dr_fd<nx>(fcl_fun, x, fcl);
+        auto fcl_fun = [&](const X & vx) { return f(vx, bu(t, vx)); };
+        Vec<nx> fcl{};
+        Mat<nx, nx> dS{};
+        if constexpr (f_an) {  // d/dx f(x, bu(x)) = df/dx + df/du dbu/dx
+          const U ucl = bu(t, x);
+          fcl         = f(x, ucl);
+          Mat<nx, nu> dfu{};
+          f.jacobian(x, ucl, dS, dfu);
+          Mat<nu, nx> dbx{};
+          if constexpr (requires { bu.jacobian(t, x, dbx); }) {
+            bu.jacobian(t, x, dbx);
+          } else {
+            const double hh = detail::fd_step();
+            for (int c = 0; c < nx; ++c) {
+              typename X::Tangent e{};
+              e[c]          = hh;
+              const auto du = rminus(bu(t, rplus(x, e)), ucl);
+              for (int r = 0; r < nu; ++r) dbx(r, c) = du[r] / hh;
+            }
+          }
+          dS = dS + dfu * dbx;
+        } else {
+          fcl = fcl_fun(x);
+          dS  = detail::dr_fd<nx>(fcl_fun, x, fcl);
+        }
         const Mat<nx, nx> adf = X::ad(fcl);
         for (size_t i = 0; i < dS.a.size(); ++i) dS.a[i] -= adf.a[i];
         S = S + dt_act * (dS * S);
@@ -313,9 +358,8 @@ public:
           QuadraticProgram<> qp = qp_;  // same layout, private values
           for (std::size_t b = B_ * k / T; b < B_ * (k + 1) / T; ++b) {
             ASIFProblem<G, U> pbm{prm_.T, g[b], u_des[b], prm_.u_weight, prm_.ulim};
-            asif_to_qp_update<G, U>(
-              qp, pbm, prm_.asif, f_, [&](double t, const G & x) { return h(b, t, x); },
-              [&](double t, const G & x) { return bu(b, t, x); });
+            asif_to_qp_update<G, U>(qp, pbm, prm_.asif, f_, detail::AgentFn<std::remove_reference_t<H>, G>{h, b},
+                                    detail::AgentFn<std::remove_reference_t<BU>, G>{bu, b});
             std::copy(qp.P.begin(), qp.P.end(), P_.begin() + b * n_ * n_);
             std::copy(qp.q.begin(), qp.q.end(), q_.begin() + b * n_);
             std::copy(qp.A.begin(), qp.A.end(), A_.begin() + b * m_ * n_);
