@@ -3,7 +3,7 @@ sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 import smooth_feedback_amd as sfb
 dev = torch.device("cuda:0"); rng = np.random.default_rng(0)
-for dof, ny in ((9, 3), (15, 6), (3, 10)):
+for dof, ny in ((7, 3), (8, 3), (9, 3), (10, 3), (15, 6), (3, 10)):
     B = 1 << 18
     def spd(n):
         M = rng.standard_normal((n, n)); return M @ M.T + n * np.eye(n)
