@@ -5,7 +5,7 @@ import numpy as np, torch
 import smooth_feedback_amd as sfb
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
-for dof, ny in ((6, 3), (7, 3), (8, 3), (9, 3), (10, 3), (3, 10), (12, 6), (16, 16)):
+for dof, ny in ((6, 3), (6, 6), (4, 4), (7, 3), (8, 3), (9, 3), (10, 3), (3, 10), (12, 6), (16, 16)):
     B = 1 << 18
     def spd(n):
         M = rng.standard_normal((n, n)); return M @ M.T + n * np.eye(n)

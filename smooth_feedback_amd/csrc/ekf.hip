@@ -750,6 +750,7 @@ static bool ekf_fast(int dof, int ny, bool update)
 {
   const bool nok = dof == 2 || dof == 3 || dof == 4 || dof == 6 || dof == 7;  // (7: the last size whose fused step fits the registers)
   if (dof == 8 && !update) return true;  // predict alone still fits at dof 8 (0.11 ms for 262 144 filters; generic: 0.2); at 9 and 10 it spills and loses
+  if (update && ((dof == 6 && ny == 6) || (dof == 4 && ny == 4))) return true;  // full-state measurements
   return update ? (nok && ny >= 1 && ny <= 3) : nok;
 }
 
@@ -805,7 +806,7 @@ hipError_t ekf_launch(const EkfArgs &a, int dof, int ny, bool predict, bool upda
   SFB_EKF_CASE(2, 1) SFB_EKF_CASE(2, 2) SFB_EKF_CASE(2, 3)
   SFB_EKF_CASE(3, 1) SFB_EKF_CASE(3, 2) SFB_EKF_CASE(3, 3)
   SFB_EKF_CASE(4, 1) SFB_EKF_CASE(4, 2) SFB_EKF_CASE(4, 3)
-  SFB_EKF_CASE(6, 1) SFB_EKF_CASE(6, 2) SFB_EKF_CASE(6, 3)
+  SFB_EKF_CASE(6, 1) SFB_EKF_CASE(6, 2) SFB_EKF_CASE(6, 3) SFB_EKF_CASE(6, 6) SFB_EKF_CASE(4, 4)
   SFB_EKF_CASE(7, 1) SFB_EKF_CASE(7, 2) SFB_EKF_CASE(7, 3) SFB_EKF_CASE(8, 1)
 #undef SFB_EKF_CASE
   return hipErrorInvalidValue;

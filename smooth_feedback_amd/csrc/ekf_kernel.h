@@ -23,7 +23,7 @@ struct EkfArgs {
 };
 
 // largest dof / ny of the generic kernel (one filter per wavefront, matrices in LDS); the register-resident
-// one-filter-per-lane kernels cover dof in {2,3,4,6} x ny in {1,2,3}
+// one-filter-per-lane kernels cover dof in {2,3,4,6,7} x ny in {1,2,3}, (4,4), (6,6), and the update for dof 8..10
 constexpr int kEkfMaxDim = 16;
 bool ekf_supported(int dof, int ny, bool update);
 hipError_t ekf_launch(const EkfArgs &a, int dof, int ny, bool predict, bool update, hipStream_t stream);

@@ -62,7 +62,7 @@ def test_unsupported_sizes_fail_loudly(sfb):
 
 
 @pytest.mark.parametrize("dof,ny", [(10, 3), (3, 10), (9, 1), (5, 5), (1, 1), (16, 16), (7, 2), (6, 4), (8, 3), (9, 3), (10, 1), (10, 2),
-                                    (7, 1), (9, 4), (11, 3)])
+                                    (7, 1), (9, 4), (11, 3), (6, 6), (4, 4), (6, 5)])
 @pytest.mark.parametrize("B", [1, 130])
 def test_generic_sizes_match_oracle(sfb, oracle, dof, ny, B):
     """The sizes outside the register-resident kernels run one filter per wavefront with the matrices in LDS --
