@@ -389,9 +389,10 @@ sfb_status sfb_mpc_swarm_debug_buffers(sfb_mpc_swarm *swarm, const double **Ax, 
  * H [batch][ny*dof], R [batch][ny*ny], r [batch][ny], delta [batch][dof].  Only the upper triangles
  * of Q and R are read (ekf.hpp:77,:114).  q_shared / r_shared / dt_shared != 0: Q / R / dt point to
  * ONE matrix / scalar used by every item.  info[batch] (nullable): 0 ok, 1 = LDLT of S failed.
- * Supported sizes: dof, ny <= 16.  dof in {2,3,4,6} with ny in {1,2,3} run one filter per lane, register-resident
- * (the streaming kernels of the benchmark configuration); every other size (the reference's own tests use
- * (dof, ny) = (10,3), (3,10) and dof = 9) runs one filter per wavefront with its matrices in LDS.
+ * Supported sizes: dof, ny <= 16.  dof in {2,3,4,6,7} with ny in {1,2,3}, and (4,4), (6,6), run one filter per lane,
+ * register-resident (the streaming kernels of the benchmark configuration); dof in {8,9,10} with ny <= 3 use a
+ * per-lane update behind a separate predict launch; every other size (the reference's own tests also use (3,10))
+ * runs one filter per wavefront with its matrices in LDS.  Same results in every case.
  * Device pointers, asynchronous on `stream`; P is updated in place.
  * ---------------------------------------------------------------------------------------- */
 sfb_status sfb_ekf_predict_batch(int64_t batch, int dof, const double *A, const double *Q, int q_shared,
