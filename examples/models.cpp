@@ -14,28 +14,20 @@
 #include <smooth_feedback_amd/ekf.hpp>
 #include <smooth_feedback_amd/mpc.hpp>
 
+#include "vehicle_model.h"
+
 using namespace smooth_feedback_amd;
+using sfbx::U2;
+using sfbx::VehicleBU;
+using sfbx::VehicleDyn6;
+using sfbx::VehicleH;
+using sfbx::X6;
 
 namespace {
 
-// ---- vehicle of examples/mpc_asif_vehicle.cpp:42-55 ----
-using X6 = Bundle<SE2, Rn<3>>;
+// ---- vehicle of examples/mpc_asif_vehicle.cpp:42-55: X6, U2, VehicleDyn6, VehicleH, VehicleBU in vehicle_model.h ----
 using X12 = Bundle<SE2, Rn<3>, SE2, Rn<3>>;
-using U2 = Rn<2>;
 
-struct VehicleDyn6 {
-  Vec<6> operator()(const X6 & x, const U2 & u) const
-  {
-    const auto & v = x.part<1>().v;
-    return {v[0], v[1], v[2], -0.2 * v[0] + u.v[0], 0.0, -0.4 * v[2] + u.v[1]};
-  }
-  void jacobian(const X6 &, const U2 &, Mat<6, 6> & dx, Mat<6, 2> & du) const
-  {
-    dx = Mat<6, 6>::Zero(); du = Mat<6, 2>::Zero();
-    dx(0, 3) = 1; dx(1, 4) = 1; dx(2, 5) = 1; dx(3, 3) = -0.2; dx(5, 5) = -0.4;
-    du(3, 0) = 1; du(5, 1) = 1;
-  }
-};
 struct VehicleDyn12 {
   Vec<12> operator()(const X12 & x, const U2 & u) const
   {
@@ -700,61 +692,9 @@ int sfbx_mesh(int n_ivals, int K, double * nodes, double * weights, double * Dus
 namespace {
 // safe set and backup controller of examples/mpc_asif_vehicle.cpp:95-104: stay 0.7 away from (0, -2.3); the
 // direction is evaluated at the query point and treated as constant by the differentiation, as in the example
-// barrier and backup controller of examples/mpc_asif_vehicle.cpp:95-129 as functors with analytic right-Jacobians (the
-// reference differentiates its lambdas with autodiff; without the members the front falls back to forward differences)
-struct VehicleH {
-  Vec<1> operator()(double, const X6 & x) const
-  {
-    const double dx = x.part<0>().x - 0.0, dy = x.part<0>().y - (-2.3);
-    const double nrm = std::sqrt(dx * dx + dy * dy);
-    return {(dx * dx + dy * dy) / nrm - 0.7};
-  }
-  // h = |p - c| - 0.7 and p (+) a = p + R (a_0, a_1) + O(a^2): dh/da = (p - c)' R / |p - c| on the SE2 translation part
-  void jacobian(double, const X6 & x, Mat<1, 6> & J) const
-  {
-    const auto & g  = x.part<0>();
-    const double dx = g.x - 0.0, dy = g.y - (-2.3), nrm = std::sqrt(dx * dx + dy * dy);
-    J       = Mat<1, 6>::Zero();
-    J(0, 0) = (dx * g.c + dy * g.s) / nrm;
-    J(0, 1) = (-dx * g.s + dy * g.c) / nrm;
-  }
-  Vec<1> operator()(size_t, double t, const X6 & x) const { return (*this)(t, x); }              // swarm callbacks
-  void jacobian(size_t, double t, const X6 & x, Mat<1, 6> & J) const { jacobian(t, x, J); }
-};
-struct VehicleBU {
-  U2 operator()(double, const X6 & x) const
-  {
-    U2 u;
-    u.v = {0.2 * x.part<1>().v[0], -0.5};
-    return u;
-  }
-  void jacobian(double, const X6 &, Mat<2, 6> & J) const
-  {
-    J       = Mat<2, 6>::Zero();
-    J(0, 3) = 0.2;
-  }
-  U2 operator()(size_t, double t, const X6 & x) const { return (*this)(t, x); }
-  void jacobian(size_t, double t, const X6 & x, Mat<2, 6> & J) const { jacobian(t, x, J); }
-};
 Vec<1> vehicle_h(double t, const X6 & x) { return VehicleH{}(t, x); }
 U2 vehicle_bu(double t, const X6 & x) { return VehicleBU{}(t, x); }
-ASIFilterParams<U2> vehicle_asif_params(int K)
-{
-  ASIFilterParams<U2> p;
-  p.T        = 2.5;
-  p.nh       = 1;
-  p.u_weight = {20.0, 1.0};
-  p.ulim.rows = 2;
-  p.ulim.A    = {1, 0, 0, 1};
-  p.ulim.l    = {-0.2, -0.5};
-  p.ulim.u    = {0.5, 0.5};
-  p.asif.K          = (size_t)K;
-  p.asif.alpha      = 5;
-  p.asif.dt         = 0.01;
-  p.asif.relax_cost = 100;
-  p.qp.polish       = false;
-  return p;
-}
+ASIFilterParams<U2> vehicle_asif_params(int K) { return sfbx::vehicle_asif_params(K); }
 void copy_qp(const QuadraticProgram<> & qp, double * P, double * q, double * A, double * l, double * u)
 {
   std::copy(qp.P.begin(), qp.P.end(), P);
@@ -823,6 +763,22 @@ int sfbx_test_asif(int which, double * u_out, int32_t * code, uint32_t * iter, i
   } catch (const std::exception &) {
     return 1;
   }
+}
+
+int sfbx_asif_swarm_states(int64_t batch, uint64_t seed, double * states, double * udes)
+{
+  for (int64_t b = 0; b < batch; ++b) {
+    const X6 g = perturbed(xdes6(0.025 * double(b % 400)), seed + (uint64_t)b);
+    std::mt19937_64 rng(seed + 7919u * (uint64_t)b);
+    std::uniform_real_distribution<double> d(-0.5, 0.5);
+    const auto & p = g.part<0>();
+    const auto & v = g.part<1>().v;
+    double * s = states + 7 * b;
+    s[0] = p.x; s[1] = p.y; s[2] = p.c; s[3] = p.s; s[4] = v[0]; s[5] = v[1]; s[6] = v[2];
+    udes[2 * b] = d(rng);
+    udes[2 * b + 1] = d(rng);
+  }
+  return 0;
 }
 
 int sfbx_asif_swarm_step(int64_t batch, uint64_t seed, int K, int ticks, double * u_out, int32_t * codes, uint32_t * iters,

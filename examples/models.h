@@ -84,6 +84,8 @@ int sfbx_test_asif(int which, double *u_out, int32_t *code, uint32_t *iter, int3
 int sfbx_asif_swarm_step(int64_t batch, uint64_t seed, int K, int ticks, double *u_out, int32_t *codes, uint32_t *iters,
                          double *P, double *q, double *A, double *l, double *u, double *x, double *y, double *wx,
                          double *wy);
+/* the states (x, y, cos, sin, v0, v1, v2) [batch][7] and desired inputs [batch][2] sfbx_asif_swarm_step starts from */
+int sfbx_asif_swarm_states(int64_t batch, uint64_t seed, double *states, double *udes);
 /* mesh: nodes (N+1), weights (N+1), Dus ((K+1)*K col-major) for `n` intervals of K points */
 int sfbx_mesh(int n_ivals, int K, double *nodes, double *weights, double *Dus);
 

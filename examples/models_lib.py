@@ -142,3 +142,36 @@ def ocp_to_qp_basic(solve=False):
     rc = lib().sfbx_test_ocp_to_qp_basic(_p(out), int(solve))
     assert rc == 0, rc
     return out
+
+
+_dev = None
+
+
+def dev_lib():
+    """libsfb_models_dev.so: the device-side fronts (examples/models_device.hip, compiled by hipcc)."""
+    global _dev
+    if _dev is None:
+        lib()  # libsfb.so / the host harness first
+        _dev = C.CDLL(os.path.join(ROOT, "smooth_feedback_amd", "libsfb_models_dev.so"))
+    return _dev
+
+
+def asif_swarm_states(batch, seed=0):
+    st = np.zeros((batch, 7)); ud = np.zeros((batch, 2))
+    assert lib().sfbx_asif_swarm_states(C.c_int64(batch), C.c_uint64(seed), _p(st), _p(ud)) == 0
+    return st, ud
+
+
+def asif_swarm_device_step(states, udes, K, ticks=1):
+    """ASIFSwarmDevice (assembly and solve on the GPU) from the states of asif_swarm_states; outputs like asif_swarm_step."""
+    batch = len(states)
+    n, m = 3, K + 3
+    out = dict(u=np.zeros((batch, 2)), code=np.zeros(batch, np.int32), iter=np.zeros(batch, np.uint32), P=np.zeros((batch, n * n)),
+               q=np.zeros((batch, n)), A=np.zeros((batch, m * n)), l=np.zeros((batch, m)), ub=np.zeros((batch, m)),
+               x=np.zeros((batch, n)), y=np.zeros((batch, m)), wx=np.zeros((batch, n)), wy=np.zeros((batch, m)), seconds=np.zeros(ticks))
+    st = np.ascontiguousarray(states, dtype=np.float64); ud = np.ascontiguousarray(udes, dtype=np.float64)
+    rc = dev_lib().sfbx_asif_swarm_device_step(C.c_int64(batch), K, ticks, _p(st), _p(ud), _p(out["u"]), _p(out["code"]), _p(out["iter"]),
+                                               _p(out["P"]), _p(out["q"]), _p(out["A"]), _p(out["l"]), _p(out["ub"]), _p(out["x"]),
+                                               _p(out["y"]), _p(out["wx"]), _p(out["wy"]), _p(out["seconds"]))
+    assert rc == 0, rc
+    return out

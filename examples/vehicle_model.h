@@ -1,0 +1,87 @@
+// The vehicle of examples/mpc_asif_vehicle.cpp (:42-55 dynamics, :95-129 safety filter) as functors usable on the host and
+// in HIP device code: state X6 = SE2 x R^3 (pose, body velocities), input U2 = R^2.  With analytic right-Jacobians (the
+// reference differentiates its lambdas with autodiff; without the members the fronts fall back to forward differences).
+#pragma once
+#include <cmath>
+#include <cstddef>
+
+#include <smooth_feedback_amd/asif.hpp>
+#include <smooth_feedback_amd/lie.hpp>
+
+namespace sfbx {
+using namespace smooth_feedback_amd;
+
+using X6 = Bundle<SE2, Rn<3>>;
+using U2 = Rn<2>;
+
+struct VehicleDyn6 {
+  SFB_LIE_HD Vec<6> operator()(const X6 & x, const U2 & u) const
+  {
+    const auto & v = x.part<1>().v;
+    return {v[0], v[1], v[2], -0.2 * v[0] + u.v[0], 0.0, -0.4 * v[2] + u.v[1]};
+  }
+  SFB_LIE_HD void jacobian(const X6 &, const U2 &, Mat<6, 6> & dx, Mat<6, 2> & du) const
+  {
+    dx = Mat<6, 6>::Zero(); du = Mat<6, 2>::Zero();
+    dx(0, 3) = 1; dx(1, 4) = 1; dx(2, 5) = 1; dx(3, 3) = -0.2; dx(5, 5) = -0.4;
+    du(3, 0) = 1; du(5, 1) = 1;
+  }
+};
+
+// barrier: stay 0.7 away from the obstacle at (0, -2.3)
+struct VehicleH {
+  SFB_LIE_HD Vec<1> operator()(double, const X6 & x) const
+  {
+    const double dx = x.part<0>().x - 0.0, dy = x.part<0>().y - (-2.3);
+    const double nrm = std::sqrt(dx * dx + dy * dy);
+    return {(dx * dx + dy * dy) / nrm - 0.7};
+  }
+  // h = |p - c| - 0.7 and p (+) a = p + R (a_0, a_1) + O(a^2): dh/da = (p - c)' R / |p - c| on the SE2 translation part
+  SFB_LIE_HD void jacobian(double, const X6 & x, Mat<1, 6> & J) const
+  {
+    const auto & g  = x.part<0>();
+    const double dx = g.x - 0.0, dy = g.y - (-2.3), nrm = std::sqrt(dx * dx + dy * dy);
+    J       = Mat<1, 6>::Zero();
+    J(0, 0) = (dx * g.c + dy * g.s) / nrm;
+    J(0, 1) = (-dx * g.s + dy * g.c) / nrm;
+  }
+  SFB_LIE_HD Vec<1> operator()(std::size_t, double t, const X6 & x) const { return (*this)(t, x); }  // swarm callbacks
+  SFB_LIE_HD void jacobian(std::size_t, double t, const X6 & x, Mat<1, 6> & J) const { jacobian(t, x, J); }
+};
+
+// backup controller: brake and turn
+struct VehicleBU {
+  SFB_LIE_HD U2 operator()(double, const X6 & x) const
+  {
+    U2 u;
+    u.v = {0.2 * x.part<1>().v[0], -0.5};
+    return u;
+  }
+  SFB_LIE_HD void jacobian(double, const X6 &, Mat<2, 6> & J) const
+  {
+    J       = Mat<2, 6>::Zero();
+    J(0, 3) = 0.2;
+  }
+  SFB_LIE_HD U2 operator()(std::size_t, double t, const X6 & x) const { return (*this)(t, x); }
+  SFB_LIE_HD void jacobian(std::size_t, double t, const X6 & x, Mat<2, 6> & J) const { jacobian(t, x, J); }
+};
+
+inline ASIFilterParams<U2> vehicle_asif_params(int K)
+{
+  ASIFilterParams<U2> p;
+  p.T        = 2.5;
+  p.nh       = 1;
+  p.u_weight = {20.0, 1.0};
+  p.ulim.rows = 2;
+  p.ulim.A    = {1, 0, 0, 1};
+  p.ulim.l    = {-0.2, -0.5};
+  p.ulim.u    = {0.5, 0.5};
+  p.asif.K          = (size_t)K;
+  p.asif.alpha      = 5;
+  p.asif.dt         = 0.01;
+  p.asif.relax_cost = 100;
+  p.qp.polish       = false;
+  return p;
+}
+
+}  // namespace sfbx

@@ -42,7 +42,7 @@ struct ManifoldBounds {
 
 namespace detail {
 template<int N>
-Vec<N> ones()
+SFB_LIE_HD Vec<N> ones()
 {
   Vec<N> v{};
   for (int i = 0; i < N; ++i) v[i] = 1.0;
@@ -83,11 +83,11 @@ void asif_to_qp_allocate(QuadraticProgram<> & qp, std::size_t K, std::size_t nu_
 }
 
 namespace detail {
-inline double fd_step() { return std::sqrt(std::numeric_limits<double>::epsilon()); }
+SFB_LIE_HD inline double fd_step() { return 1.4901161193847656e-08; }  // sqrt(DBL_EPSILON) = 2^-26, exactly
 
 // right derivative of g -> fun(g) (values in R^NO) at g, by forward differences
 template<int NO, class G, class Fun>
-Mat<NO, G::Dof> dr_fd(Fun && fun, const G & g, const Vec<NO> & f0)
+SFB_LIE_HD Mat<NO, G::Dof> dr_fd(Fun && fun, const G & g, const Vec<NO> & f0)
 {
   Mat<NO, G::Dof> J{};
   const double h = fd_step();
@@ -104,31 +104,49 @@ template<class Fn, class G>
 struct AgentFn {
   const Fn & fn;
   std::size_t agent;
-  auto operator()(double t, const G & x) const { return fn(agent, t, x); }
+  SFB_LIE_HD auto operator()(double t, const G & x) const { return fn(agent, t, x); }
   template<class M, class F2 = Fn>  // (F2: keeps the member lookup dependent, so a callable without one is no error)
-  auto jacobian(double t, const G & x, M & J) const -> decltype(std::declval<const F2 &>().jacobian(agent, t, x, J))
+  SFB_LIE_HD auto jacobian(double t, const G & x, M & J) const -> decltype(std::declval<const F2 &>().jacobian(agent, t, x, J))
   {
     return fn.jacobian(agent, t, x, J);
   }
 };
 }  // namespace detail
 
-/// asif_func.hpp:104-199.  f(x, u) -> Tangent<X>, h(t, x) -> Vec<nh>, bu(t, x) -> U
+/// The problem of asif_to_qp_update as plain data (usable in device code): ASIFProblem with the input bounds as
+/// pointers, and the parameters of ASIFtoQPParams.
+template<class X, class U>
+struct ASIFProblemView {
+  double T;
+  X x0;
+  U u_des;
+  Vec<U::Dof> W_u;
+  int ulim_rows;
+  const double *ulim_A, *ulim_l, *ulim_u;  // ManifoldBounds: A rows x Dof<U> column-major, l, u [rows]
+  U ulim_c;
+  int K;
+  double alpha, dt, relax_cost;
+};
+
+/// asif_func.hpp:104-199 on raw arrays: P [N*N], q [N], A [M*N] column-major, l, u [M] with N = nu + 1,
+/// M = K nh + nu_ineq + 1, all-zero on entry as asif_to_qp_allocate leaves them (only the entries the reference writes
+/// are written).  f(x, u) -> Tangent<X>, h(t, x) -> Vec<nh>, bu(t, x) -> U.  Host and device (asif_device.hpp) run
+/// this very function, so their QPs differ only by what sin / cos / atan2 of the two maths libraries differ.
 template<class X, class U, class F, class H, class BU>
-void asif_to_qp_update(QuadraticProgram<> & qp, const ASIFProblem<X, U> & pbm, const ASIFtoQPParams & prm, F && f, H && h,
-                       BU && bu)
+SFB_LIE_HD void asif_fill(double * qP, double * qq, double * qA, double * ql, double * qu, const ASIFProblemView<X, U> & pbm,
+                          const F & f, const H & h, const BU & bu)
 {
   constexpr int nx = X::Dof, nu = U::Dof;
   using HVal       = std::decay_t<decltype(h(0.0, pbm.x0))>;
   constexpr int nh = int(std::tuple_size<HVal>::value);
-  const int nu_ineq = pbm.ulim.rows;
-  const int M = int(prm.K) * nh + nu_ineq + 1;
+  const int nu_ineq = pbm.ulim_rows;
+  const int K = pbm.K, M = K * nh + nu_ineq + 1;
   const double inf = std::numeric_limits<double>::infinity();
-  auto A = [&](int r, int c) -> double & { return qp.A[(size_t)r + (size_t)c * M]; };
+  auto A = [&](int r, int c) -> double & { return qA[(size_t)r + (size_t)c * M]; };
 
   // iteration variables :139-143
-  const double tau = pbm.T / static_cast<double>(prm.K);
-  const double dt  = std::min<double>(prm.dt, tau);
+  const double tau = pbm.T / static_cast<double>(K);
+  const double dt  = (pbm.dt < tau) ? pbm.dt : tau;
   double t         = 0;
   X x              = pbm.x0;
   Mat<nx, nx> S    = Mat<nx, nx>::Identity();  // dx/dx0
@@ -147,7 +165,7 @@ void asif_to_qp_update(QuadraticProgram<> & qp, const ASIFProblem<X, U> & pbm, c
     d_f0_du = detail::dr_fd<nx>([&](const U & vu) { return f(x, vu); }, pbm.u_des, f0);
   }
 
-  for (std::size_t k = 0; k != prm.K; ++k) {
+  for (int k = 0; k != K; ++k) {
     // barrier function and its derivatives w.r.t. (t, x) :161-166
     const HVal hval = h(t, x);
     const double e  = detail::fd_step();
@@ -160,18 +178,18 @@ void asif_to_qp_update(QuadraticProgram<> & qp, const ASIFProblem<X, U> & pbm, c
     const Mat<nh, nu> Ak     = dh_dx0 * d_f0_du;
     const Vec<nh> dhf        = dh_dx0 * f0;
     for (int r = 0; r < nh; ++r) {
-      for (int c = 0; c < nu; ++c) A(int(k) * nh + r, c) = Ak(r, c);
-      qp.l[k * nh + r] = -((ht[r] - hval[r]) / e) - prm.alpha * hval[r] - dhf[r];
-      qp.u[k * nh + r] = inf;
+      for (int c = 0; c < nu; ++c) A(k * nh + r, c) = Ak(r, c);
+      ql[k * nh + r] = -((ht[r] - hval[r]) / e) - pbm.alpha * hval[r] - dhf[r];
+      qu[k * nh + r] = inf;
     }
     // integrate system and sensitivity until the next constraint :175-180.  As in the reference the
     // step is fixed per interval, the state is stepped first and the sensitivity ODE is evaluated at
     // the stepped state with the old time.
-    const double dt_act = std::min(dt, tau * double(k + 1) - t);
+    const double rest = tau * double(k + 1) - t, dt_act = (rest < dt) ? rest : dt;
     while (t < tau * double(k + 1)) {
       {
         auto dx = f(x, bu(t, x));
-        for (auto & v : dx) v *= dt_act;
+        for (int i = 0; i < nx; ++i) dx[i] *= dt_act;
         x = rplus(x, dx);
       }
       {
@@ -201,7 +219,7 @@ void asif_to_qp_update(QuadraticProgram<> & qp, const ASIFProblem<X, U> & pbm, c
           dS  = detail::dr_fd<nx>(fcl_fun, x, fcl);
         }
         const Mat<nx, nx> adf = X::ad(fcl);
-        for (size_t i = 0; i < dS.a.size(); ++i) dS.a[i] -= adf.a[i];
+        for (int i = 0; i < nx * nx; ++i) dS.a[i] -= adf.a[i];
         S = S + dt_act * (dS * S);
       }
       t += dt_act;
@@ -209,31 +227,42 @@ void asif_to_qp_update(QuadraticProgram<> & qp, const ASIFProblem<X, U> & pbm, c
   }
 
   // relaxation of the barrier constraints :183
-  for (int r = 0; r < int(prm.K) * nh; ++r) A(r, nu) = 1.0;
+  for (int r = 0; r < K * nh; ++r) A(r, nu) = 1.0;
   // input bounds :186-188
   {
-    const auto d = rminus(pbm.u_des, pbm.ulim.c);
+    const auto d = rminus(pbm.u_des, pbm.ulim_c);
     for (int r = 0; r < nu_ineq; ++r) {
       double Ad = 0.0;
       for (int c = 0; c < nu; ++c) {
-        const double a             = pbm.ulim.A[(size_t)r + (size_t)c * nu_ineq];
-        A(int(prm.K) * nh + r, c) = a;
+        const double a     = pbm.ulim_A[(size_t)r + (size_t)c * nu_ineq];
+        A(K * nh + r, c) = a;
         Ad += a * d[c];
       }
-      qp.l[prm.K * nh + r] = pbm.ulim.l[r] - Ad;
-      qp.u[prm.K * nh + r] = pbm.ulim.u[r] - Ad;
+      ql[K * nh + r] = pbm.ulim_l[r] - Ad;
+      qu[K * nh + r] = pbm.ulim_u[r] - Ad;
     }
   }
   // bounds on the relaxation delta :191-193
-  A(int(prm.K) * nh + nu_ineq, nu) = 1.0;
-  qp.l[prm.K * nh + nu_ineq]        = 0.0;
-  qp.u[prm.K * nh + nu_ineq]        = inf;
+  A(K * nh + nu_ineq, nu) = 1.0;
+  ql[K * nh + nu_ineq]     = 0.0;
+  qu[K * nh + nu_ineq]     = inf;
   // cost :195-198
   const int N = nu + 1;
-  for (int i = 0; i < nu; ++i) qp.P[(size_t)i + (size_t)i * N] = pbm.W_u[i];
-  qp.P[(size_t)nu + (size_t)nu * N] = prm.relax_cost;
-  qp.q[nu]                          = 0.0;
+  for (int i = 0; i < nu; ++i) qP[(size_t)i + (size_t)i * N] = pbm.W_u[i];
+  qP[(size_t)nu + (size_t)nu * N] = pbm.relax_cost;
+  qq[nu]                          = 0.0;
 }
+
+/// asif_func.hpp:104-199.  f(x, u) -> Tangent<X>, h(t, x) -> Vec<nh>, bu(t, x) -> U
+template<class X, class U, class F, class H, class BU>
+void asif_to_qp_update(QuadraticProgram<> & qp, const ASIFProblem<X, U> & pbm, const ASIFtoQPParams & prm, F && f, H && h,
+                       BU && bu)
+{
+  const ASIFProblemView<X, U> v{pbm.T, pbm.x0, pbm.u_des, pbm.W_u, pbm.ulim.rows, pbm.ulim.A.data(), pbm.ulim.l.data(),
+                                pbm.ulim.u.data(), pbm.ulim.c, int(prm.K), prm.alpha, prm.dt, prm.relax_cost};
+  asif_fill<X, U>(qp.P.data(), qp.q.data(), qp.A.data(), qp.l.data(), qp.u.data(), v, f, h, bu);
+}
+
 
 /// asif_func.hpp:245-260
 template<class X, class U, class F, class H, class BU>

@@ -16,6 +16,14 @@
 #include <utility>
 #include <vector>
 
+// Everything here is usable in HIP device code as well (a model written against these types can be linearised or
+// integrated on the GPU, asif_device.hpp): the functions are __host__ __device__ when compiled by hipcc.
+#if defined(__HIPCC__)
+#define SFB_LIE_HD __host__ __device__
+#else
+#define SFB_LIE_HD
+#endif
+
 namespace smooth_feedback_amd {
 
 // ---- tiny fixed-size column-major matrix ----
@@ -23,10 +31,10 @@ template<int R, int C>
 struct Mat {
   std::array<double, (R * C > 0 ? R * C : 1)> a{};
   static constexpr int rows = R, cols = C;
-  double &operator()(int r, int c) { return a[(size_t)r + (size_t)c * R]; }
-  double operator()(int r, int c) const { return a[(size_t)r + (size_t)c * R]; }
-  static Mat Zero() { return Mat{}; }
-  static Mat Identity()
+  SFB_LIE_HD double &operator()(int r, int c) { return a[(size_t)r + (size_t)c * R]; }
+  SFB_LIE_HD double operator()(int r, int c) const { return a[(size_t)r + (size_t)c * R]; }
+  SFB_LIE_HD static Mat Zero() { return Mat{}; }
+  SFB_LIE_HD static Mat Identity()
   {
     Mat m{};
     for (int i = 0; i < (R < C ? R : C); ++i) m(i, i) = 1.0;
@@ -37,7 +45,7 @@ template<int N>
 using Vec = std::array<double, (N > 0 ? N : 1)>;
 
 template<int R, int K, int C>
-Mat<R, C> operator*(const Mat<R, K> &A, const Mat<K, C> &B)
+SFB_LIE_HD Mat<R, C> operator*(const Mat<R, K> &A, const Mat<K, C> &B)
 {
   Mat<R, C> out{};
   for (int c = 0; c < C; ++c)
@@ -46,19 +54,19 @@ Mat<R, C> operator*(const Mat<R, K> &A, const Mat<K, C> &B)
   return out;
 }
 template<int R, int C>
-Mat<R, C> operator+(Mat<R, C> A, const Mat<R, C> &B)
+SFB_LIE_HD Mat<R, C> operator+(Mat<R, C> A, const Mat<R, C> &B)
 {
   for (size_t i = 0; i < A.a.size(); ++i) A.a[i] += B.a[i];
   return A;
 }
 template<int R, int C>
-Mat<R, C> operator*(double s, Mat<R, C> A)
+SFB_LIE_HD Mat<R, C> operator*(double s, Mat<R, C> A)
 {
   for (auto &v : A.a) v *= s;
   return A;
 }
 template<int R, int C>
-Vec<R> operator*(const Mat<R, C> &A, const Vec<C> &x)
+SFB_LIE_HD Vec<R> operator*(const Mat<R, C> &A, const Vec<C> &x)
 {
   Vec<R> y{};
   for (int c = 0; c < C; ++c)
@@ -73,21 +81,21 @@ struct Rn {
   static constexpr bool IsCommutative = true;
   using Tangent                      = Vec<N>;
   Vec<N> v{};
-  static Rn Identity() { return Rn{}; }
-  friend Rn rplus(const Rn &g, const Tangent &a)
+  SFB_LIE_HD static Rn Identity() { return Rn{}; }
+  SFB_LIE_HD friend Rn rplus(const Rn &g, const Tangent &a)
   {
     Rn r = g;
     for (int i = 0; i < N; ++i) r.v[i] += a[i];
     return r;
   }
-  friend Tangent rminus(const Rn &a, const Rn &b)
+  SFB_LIE_HD friend Tangent rminus(const Rn &a, const Rn &b)
   {
     Tangent t{};
     for (int i = 0; i < N; ++i) t[i] = a.v[i] - b.v[i];
     return t;
   }
-  static Mat<N, N> ad(const Tangent &) { return Mat<N, N>::Zero(); }
-  static Mat<N, N> dr_expinv(const Tangent &) { return Mat<N, N>::Identity(); }
+  SFB_LIE_HD static Mat<N, N> ad(const Tangent &) { return Mat<N, N>::Zero(); }
+  SFB_LIE_HD static Mat<N, N> dr_expinv(const Tangent &) { return Mat<N, N>::Identity(); }
 };
 
 // ---- SE(2): tangent order (v_x, v_y, omega) ----
@@ -97,11 +105,11 @@ struct SE2 {
   using Tangent                      = Vec<3>;
   double x = 0, y = 0, c = 1, s = 0;  // translation, cos/sin of the heading
 
-  static SE2 Identity() { return SE2{}; }
-  static SE2 FromAngle(double th, double px, double py) { return SE2{px, py, std::cos(th), std::sin(th)}; }
-  double angle() const { return std::atan2(s, c); }
+  SFB_LIE_HD static SE2 Identity() { return SE2{}; }
+  SFB_LIE_HD static SE2 FromAngle(double th, double px, double py) { return SE2{px, py, std::cos(th), std::sin(th)}; }
+  SFB_LIE_HD double angle() const { return std::atan2(s, c); }
 
-  static SE2 exp(const Tangent &a)
+  SFB_LIE_HD static SE2 exp(const Tangent &a)
   {
     const double th = a[2], th2 = th * th;
     double A, B;  // A = sin(th)/th, B = (1-cos(th))/th
@@ -114,7 +122,7 @@ struct SE2 {
     }
     return SE2{A * a[0] - B * a[1], B * a[0] + A * a[1], std::cos(th), std::sin(th)};
   }
-  Tangent log() const
+  SFB_LIE_HD Tangent log() const
   {
     const double th = angle(), th2 = th * th;
     double A, B;
@@ -128,15 +136,15 @@ struct SE2 {
     const double den = A * A + B * B;
     return {(A * x + B * y) / den, (-B * x + A * y) / den, th};
   }
-  SE2 inverse() const { return SE2{-(c * x + s * y), -(-s * x + c * y), c, -s}; }
-  friend SE2 operator*(const SE2 &g, const SE2 &h)
+  SFB_LIE_HD SE2 inverse() const { return SE2{-(c * x + s * y), -(-s * x + c * y), c, -s}; }
+  SFB_LIE_HD friend SE2 operator*(const SE2 &g, const SE2 &h)
   {
     return SE2{g.x + g.c * h.x - g.s * h.y, g.y + g.s * h.x + g.c * h.y, g.c * h.c - g.s * h.s, g.s * h.c + g.c * h.s};
   }
-  friend SE2 rplus(const SE2 &g, const Tangent &a) { return g * exp(a); }
-  friend Tangent rminus(const SE2 &a, const SE2 &b) { return (b.inverse() * a).log(); }
+  SFB_LIE_HD friend SE2 rplus(const SE2 &g, const Tangent &a) { return g * exp(a); }
+  SFB_LIE_HD friend Tangent rminus(const SE2 &a, const SE2 &b) { return (b.inverse() * a).log(); }
 
-  static Mat<3, 3> ad(const Tangent &a)
+  SFB_LIE_HD static Mat<3, 3> ad(const Tangent &a)
   {
     Mat<3, 3> m{};
     m(0, 1) = -a[2]; m(0, 2) = a[1];
@@ -144,7 +152,7 @@ struct SE2 {
     return m;
   }
   // inverse of the right Jacobian of exp:  I + ad/2 + (1/th^2 - (1+cos th)/(2 th sin th)) ad^2
-  static Mat<3, 3> dr_expinv(const Tangent &a)
+  SFB_LIE_HD static Mat<3, 3> dr_expinv(const Tangent &a)
   {
     const double th = a[2], th2 = th * th;
     const double k  = (th2 < 1e-8) ? (1.0 / 12.0 + th2 / 720.0) : (1.0 / th2 - (1.0 + std::cos(th)) / (2.0 * th * std::sin(th)));
@@ -160,8 +168,8 @@ struct SO3 {
   using Tangent                      = Vec<3>;
   double w = 1, x = 0, y = 0, z = 0;
 
-  static SO3 Identity() { return SO3{}; }
-  static SO3 exp(const Tangent &a)
+  SFB_LIE_HD static SO3 Identity() { return SO3{}; }
+  SFB_LIE_HD static SO3 exp(const Tangent &a)
   {
     const double th2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
     double A, B;  // A = sin(th/2)/th, B = cos(th/2)
@@ -175,7 +183,7 @@ struct SO3 {
     }
     return SO3{B, A * a[0], A * a[1], A * a[2]};
   }
-  Tangent log() const
+  SFB_LIE_HD Tangent log() const
   {
     const double s2 = x * x + y * y + z * z;
     double k;  // angle / sin(angle/2), with the shortest rotation (w >= 0 branch)
@@ -188,8 +196,8 @@ struct SO3 {
     }
     return {sgn * k * x, sgn * k * y, sgn * k * z};
   }
-  SO3 inverse() const { return SO3{w, -x, -y, -z}; }
-  friend SO3 operator*(const SO3 &a, const SO3 &b)
+  SFB_LIE_HD SO3 inverse() const { return SO3{w, -x, -y, -z}; }
+  SFB_LIE_HD friend SO3 operator*(const SO3 &a, const SO3 &b)
   {
     SO3 r{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
           a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
@@ -197,10 +205,10 @@ struct SO3 {
     r.w /= nrm; r.x /= nrm; r.y /= nrm; r.z /= nrm;
     return r;
   }
-  friend SO3 rplus(const SO3 &g, const Tangent &a) { return g * exp(a); }
-  friend Tangent rminus(const SO3 &a, const SO3 &b) { return (b.inverse() * a).log(); }
+  SFB_LIE_HD friend SO3 rplus(const SO3 &g, const Tangent &a) { return g * exp(a); }
+  SFB_LIE_HD friend Tangent rminus(const SO3 &a, const SO3 &b) { return (b.inverse() * a).log(); }
 
-  static Mat<3, 3> ad(const Tangent &a)  // = hat(a)
+  SFB_LIE_HD static Mat<3, 3> ad(const Tangent &a)  // = hat(a)
   {
     Mat<3, 3> m{};
     m(0, 1) = -a[2]; m(0, 2) = a[1];
@@ -208,7 +216,7 @@ struct SO3 {
     m(2, 0) = -a[1]; m(2, 1) = a[0];
     return m;
   }
-  static Mat<3, 3> dr_expinv(const Tangent &a)
+  SFB_LIE_HD static Mat<3, 3> dr_expinv(const Tangent &a)
   {
     const double th2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], th = std::sqrt(th2);
     const double k   = (th2 < 1e-8) ? (1.0 / 12.0 + th2 / 720.0) : (1.0 / th2 - (1.0 + std::cos(th)) / (2.0 * th * std::sin(th)));
@@ -225,25 +233,25 @@ struct Bundle {
   using Tangent                      = Vec<Dof>;
   std::tuple<Gs...> parts{};
 
-  static Bundle Identity() { return Bundle{}; }
+  SFB_LIE_HD static Bundle Identity() { return Bundle{}; }
   template<size_t I>
-  auto &part() { return std::get<I>(parts); }
+  SFB_LIE_HD auto &part() { return std::get<I>(parts); }
   template<size_t I>
-  const auto &part() const { return std::get<I>(parts); }
+  SFB_LIE_HD const auto &part() const { return std::get<I>(parts); }
 
   template<class F>
-  static void for_parts(F &&f)
+  SFB_LIE_HD static void for_parts(F &&f)
   {
     for_parts_impl(std::forward<F>(f), std::index_sequence_for<Gs...>{});
   }
   template<class F, size_t... I>
-  static void for_parts_impl(F &&f, std::index_sequence<I...>)
+  SFB_LIE_HD static void for_parts_impl(F &&f, std::index_sequence<I...>)
   {
     int off = 0;
     ((f(std::integral_constant<size_t, I>{}, off), off += std::tuple_element_t<I, std::tuple<Gs...>>::Dof), ...);
   }
   template<int N, int O>
-  static Vec<N> seg(const Tangent &a, int off)
+  SFB_LIE_HD static Vec<N> seg(const Tangent &a, int off)
   {
     (void)O;
     Vec<N> r{};
@@ -251,7 +259,7 @@ struct Bundle {
     return r;
   }
 
-  friend Bundle rplus(const Bundle &g, const Tangent &a)
+  SFB_LIE_HD friend Bundle rplus(const Bundle &g, const Tangent &a)
   {
     Bundle r = g;
     for_parts([&](auto I, int off) {
@@ -260,7 +268,7 @@ struct Bundle {
     });
     return r;
   }
-  friend Tangent rminus(const Bundle &a, const Bundle &b)
+  SFB_LIE_HD friend Tangent rminus(const Bundle &a, const Bundle &b)
   {
     Tangent t{};
     for_parts([&](auto I, int off) {
@@ -270,15 +278,15 @@ struct Bundle {
     });
     return t;
   }
-  static Mat<Dof, Dof> ad(const Tangent &a) { return blockdiag(a, [](auto g, const auto &ai) { return decltype(g)::ad(ai); }); }
-  static Mat<Dof, Dof> dr_expinv(const Tangent &a)
+  SFB_LIE_HD static Mat<Dof, Dof> ad(const Tangent &a) { return blockdiag(a, [](auto g, const auto &ai) { return decltype(g)::ad(ai); }); }
+  SFB_LIE_HD static Mat<Dof, Dof> dr_expinv(const Tangent &a)
   {
     return blockdiag(a, [](auto g, const auto &ai) { return decltype(g)::dr_expinv(ai); });
   }
 
 private:
   template<class F>
-  static Mat<Dof, Dof> blockdiag(const Tangent &a, F &&f)
+  SFB_LIE_HD static Mat<Dof, Dof> blockdiag(const Tangent &a, F &&f)
   {
     Mat<Dof, Dof> m{};
     for_parts([&](auto I, int off) {
