@@ -25,76 +25,20 @@ using sfbx::X6;
 
 namespace {
 
-// ---- vehicle of examples/mpc_asif_vehicle.cpp:42-55: X6, U2, VehicleDyn6, VehicleH, VehicleBU in vehicle_model.h ----
-using X12 = Bundle<SE2, Rn<3>, SE2, Rn<3>>;
+// ---- the vehicle models (states, dynamics, running constraint, desired trajectories, barrier, backup controller):
+// vehicle_model.h, shared with the device-side harness ----
+using sfbx::InputBox;
+using sfbx::MPC12;
+using sfbx::MPC6;
+using sfbx::VehicleDyn12;
+using sfbx::X12;
+X6 xdes6(double t) { return sfbx::VehicleModel6{}.xdes(t); }
+X12 xdes12(double t) { return sfbx::VehicleModel12{}.xdes(t); }
+MPC6 make6(int K, double tf) { return sfbx::make_vehicle_mpc<MPC6, sfbx::VehicleModel6>(K, tf); }
+MPC12 make12(int K, double tf) { return sfbx::make_vehicle_mpc<MPC12, sfbx::VehicleModel12>(K, tf); }
 
-struct VehicleDyn12 {
-  Vec<12> operator()(const X12 & x, const U2 & u) const
-  {
-    const auto & v = x.part<1>().v;
-    const auto & w = x.part<3>().v;
-    return {v[0], v[1], v[2], -0.2 * v[0] + u.v[0], 0.0, -0.4 * v[2] + u.v[1],
-            w[0], w[1], w[2], -0.3 * w[0] + u.v[0], 0.0, -0.5 * w[2] + u.v[1]};
-  }
-  void jacobian(const X12 &, const U2 &, Mat<12, 12> & dx, Mat<12, 2> & du) const
-  {
-    dx = Mat<12, 12>::Zero(); du = Mat<12, 2>::Zero();
-    dx(0, 3) = 1; dx(1, 4) = 1; dx(2, 5) = 1; dx(3, 3) = -0.2; dx(5, 5) = -0.4;
-    dx(6, 9) = 1; dx(7, 10) = 1; dx(8, 11) = 1; dx(9, 9) = -0.3; dx(11, 11) = -0.5;
-    du(3, 0) = 1; du(5, 1) = 1; du(9, 0) = 1; du(11, 1) = 1;
-  }
-};
-template<class X>
-struct InputBox {
-  Vec<2> operator()(const X &, const U2 & u) const { return {u.v[0], u.v[1]}; }
-  void jacobian(const X &, const U2 &, Mat<2, X::Dof> & dx, Mat<2, 2> & du) const
-  {
-    dx = Mat<2, X::Dof>::Zero();
-    du = Mat<2, 2>::Identity();
-  }
-};
-
-// desired trajectories, examples/mpc_asif_vehicle.cpp:73-79
-X6 xdes6(double t)
-{
-  X6 x;
-  x.part<0>() = rplus(SE2::FromAngle(M_PI_2, 2.5, 0.0), SE2::Tangent{t * 1.0, 0.0, t * 0.4});
-  x.part<1>().v = {1.0, 0.0, 0.4};
-  return x;
-}
-Vec<6> dxdes6(double) { return {1.0, 0.0, 0.4, 0.0, 0.0, 0.0}; }
-X12 xdes12(double t)
-{
-  X12 x;
-  x.part<0>() = rplus(SE2::FromAngle(M_PI_2, 2.5, 0.0), SE2::Tangent{t * 1.0, 0.0, t * 0.4});
-  x.part<1>().v = {1.0, 0.0, 0.4};
-  x.part<2>() = rplus(SE2::FromAngle(M_PI_2, 2.5, -1.0), SE2::Tangent{t * 0.8, 0.0, t * 0.3});
-  x.part<3>().v = {0.8, 0.0, 0.3};
-  return x;
-}
-Vec<12> dxdes12(double) { return {1.0, 0.0, 0.4, 0, 0, 0, 0.8, 0.0, 0.3, 0, 0, 0}; }
-
-using MPC6  = MPC<X6, U2, 2, VehicleDyn6, InputBox<X6>>;
-using MPC12 = MPC<X12, U2, 2, VehicleDyn12, InputBox<X12>>;
-
-MPC6 make6(int K, double tf)
-{
-  MPCParams p;
-  p.K = (size_t)K; p.tf = tf;
-  MPC6 m(VehicleDyn6{}, InputBox<X6>{}, {-0.5, -0.5}, {0.5, 0.5}, p);
-  m.set_xdes(xdes6, dxdes6);
-  m.set_udes([](double) { return U2{}; });
-  return m;
-}
-MPC12 make12(int K, double tf)
-{
-  MPCParams p;
-  p.K = (size_t)K; p.tf = tf;
-  MPC12 m(VehicleDyn12{}, InputBox<X12>{}, {-0.5, -0.5}, {0.5, 0.5}, p);
-  m.set_xdes(xdes12, dxdes12);
-  m.set_udes([](double) { return U2{}; });
-  return m;
-}
+Vec<6> mpc_dyn(MPC6 &, const X6 & x, const U2 & u) { return VehicleDyn6{}(x, u); }
+Vec<12> mpc_dyn(MPC12 &, const X12 & x, const U2 & u) { return VehicleDyn12{}(x, u); }
 
 template<class X>
 X perturbed(const X & x0, uint64_t seed)
@@ -185,9 +129,6 @@ int records_batch(M & mpc, XF xdes, int64_t batch, uint64_t seed, double * rec, 
   for (auto & t : th) t.join();
   return 0;
 }
-
-Vec<6> mpc_dyn(MPC6 &, const X6 & x, const U2 & u) { return VehicleDyn6{}(x, u); }
-Vec<12> mpc_dyn(MPC12 &, const X12 & x, const U2 & u) { return VehicleDyn12{}(x, u); }
 
 }  // namespace
 

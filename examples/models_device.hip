@@ -1,10 +1,15 @@
 // Example / test harness of the device-side fronts (compiled by hipcc into libsfb_models_dev.so): the vehicle safety
-// filter of examples/mpc_asif_vehicle.cpp for a swarm, assembled AND solved on the GPU (ASIFSwarmDevice).
+// filter of examples/mpc_asif_vehicle.cpp for a swarm, assembled AND solved on the GPU (ASIFSwarmDevice), and the vehicle
+// MPC swarm linearised on the GPU (MPCSwarmDeviceLin).
 #include <cstdint>
 #include <cstdio>
 #include <vector>
 
+#include <chrono>
+#include <random>
+
 #include <smooth_feedback_amd/asif_device.hpp>
+#include <smooth_feedback_amd/mpc_device.hpp>
 
 #include "vehicle_model.h"
 
@@ -12,7 +17,81 @@ using namespace smooth_feedback_amd;
 using sfbx::U2;
 using sfbx::X6;
 
+namespace {
+// the swarm of sfbx_mpc_swarm_step (models.cpp): agent b at time 0.025 (b mod 400), its state off the desired one
+template<class X>
+X perturbed(const X & x0, uint64_t seed)
+{
+  std::mt19937_64 rng(seed);
+  std::uniform_real_distribution<double> d(-0.5, 0.5);
+  typename X::Tangent xi{};
+  for (auto & v : xi) v = d(rng);
+  return rplus(x0, xi);
+}
+
+template<class MPCT, class Model>
+int devlin_step(int K, double tf, int64_t batch, uint64_t seed, int ticks, int probe_empty, double * u0, int32_t * codes, uint32_t * iters,
+                double * records, int64_t * record_doubles, int32_t * packed, double * seconds)
+{
+  using X = decltype(std::declval<const Model &>().xdes(0.0));
+  const Model mdl{};
+  auto mpc = sfbx::make_vehicle_mpc<MPCT, Model>(K, tf);
+  MPCSwarmDeviceLin<MPCT, Model> swarm(mpc, mdl, batch, 0.0, probe_empty != 0);
+  std::vector<double> t((size_t)batch);
+  std::vector<X> xs((size_t)batch);
+  for (int64_t b = 0; b < batch; ++b) {
+    t[b]  = 0.025 * double(b % 400);
+    xs[b] = perturbed(mdl.xdes(t[b]), seed + (uint64_t)b);
+  }
+  std::vector<sfbx::U2> us;
+  std::vector<QPSolutionStatus> cs;
+  for (int k = 0; k < ticks; ++k) {
+    if (k > 0)
+      for (int64_t b = 0; b < batch; ++b) {  // crude closed loop, as in models.cpp
+        auto f = mdl.f(xs[b], us[b]);
+        for (auto & v : f) v *= 0.025;
+        xs[b] = rplus(xs[b], f);
+        t[b] += 0.025;
+      }
+    const auto t0 = std::chrono::steady_clock::now();
+    swarm.step(t, xs, us, cs);
+    if (seconds) seconds[k] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  for (int64_t b = 0; b < batch; ++b) {
+    u0[2 * b] = us[b].v[0]; u0[2 * b + 1] = us[b].v[1];
+    codes[b] = (int32_t)cs[b];
+    iters[b] = swarm.iterations()[b];
+  }
+  if (record_doubles) *record_doubles = swarm.record_doubles();
+  if (packed) *packed = swarm.packed_records() ? 1 : 0;
+  if (records) swarm.copy_records(records);
+  return 0;
+}
+}  // namespace
+
 extern "C" {
+
+/* sfbx_mpc_swarm_device_step (models.h) with the linearisation on the GPU as well (MPCSwarmDeviceLin): same agents, same
+ * closed loop.  Also out: the records of the LAST tick as the device wrote them ([batch][*record_doubles], room for the
+ * unpacked size; NULL to skip), whether they are packed, seconds[ticks].  probe_empty != 0: start from an empty packing
+ * (every non-zero Jacobian entry is then a misfit -> the unpacked fallback runs). */
+int sfbx_mpc_swarm_devlin_step(int variant, int K, double tf, int64_t batch, uint64_t seed, int ticks, int probe_empty, double * u0,
+                               int32_t * codes, uint32_t * iters, double * records, int64_t * record_doubles, int32_t * packed,
+                               double * seconds)
+{
+  try {
+    if (variant == 6)
+      return devlin_step<sfbx::MPC6, sfbx::VehicleModel6>(K, tf, batch, seed, ticks, probe_empty, u0, codes, iters, records, record_doubles,
+                                                          packed, seconds);
+    if (variant == 12)
+      return devlin_step<sfbx::MPC12, sfbx::VehicleModel12>(K, tf, batch, seed, ticks, probe_empty, u0, codes, iters, records,
+                                                            record_doubles, packed, seconds);
+  } catch (const std::exception & e) {
+    std::fprintf(stderr, "sfbx_mpc_swarm_devlin_step: %s\n", e.what());
+    return -2;
+  }
+  return -1;
+}
 
 /* Like sfbx_asif_swarm_step (models.h) from given states [batch][7] = (x, y, cos, sin, v0, v1, v2) and desired inputs
  * [batch][2]: `ticks` consecutive filter calls, the vehicles moved 25 ms along their filtered inputs in between.  Out for

@@ -126,6 +126,13 @@ def mpc_swarm_step(variant, K, batch, ticks, seed=1, tf=5.0, device=False):
     return u0, codes, iters
 
 
+def last_tick_seconds(n):
+    """wall seconds of every swarm.step() of the last mpc_swarm_step call"""
+    out = np.zeros(n)
+    k = lib().sfbx_last_tick_seconds(_p(out), n)
+    return out[:k]
+
+
 def mpc_doubleintegrator(ticks):
     """examples/mpc_doubleintegrator.cpp in closed loop, with the factor reuse of the solver front and without."""
     u = np.zeros(ticks); it = np.zeros(ticks, np.uint32); codes = np.zeros(ticks, np.int32)
@@ -174,4 +181,24 @@ def asif_swarm_device_step(states, udes, K, ticks=1):
                                                _p(out["P"]), _p(out["q"]), _p(out["A"]), _p(out["l"]), _p(out["ub"]), _p(out["x"]),
                                                _p(out["y"]), _p(out["wx"]), _p(out["wy"]), _p(out["seconds"]))
     assert rc == 0, rc
+    return out
+
+
+def mpc_swarm_devlin_step(variant, K, batch, ticks, seed=1, tf=5.0, probe_empty=False, want_records=True):
+    """MPCSwarmDeviceLin (linearisation, assembly and solve on the GPU): the agents and closed loop of mpc_swarm_step;
+    also the records of the last tick as the device wrote them."""
+    dims = mpc_dims(variant, K)
+    Nx, Nu, N = dims["Nx"], dims["Nu"], dims["N"]
+    full = N * (2 * Nx + Nx * Nx + Nx * Nu + 2 + 2 * Nx + 2 * Nu) + Nx + Nx * Nx
+    out = dict(u0=np.zeros((batch, 2)), code=np.zeros(batch, np.int32), iter=np.zeros(batch, np.uint32), seconds=np.zeros(ticks))
+    rec = np.zeros((batch, full)) if want_records else None
+    rd = C.c_int64(0); packed = C.c_int32(0)
+    rc = dev_lib().sfbx_mpc_swarm_devlin_step(variant, K, C.c_double(tf), C.c_int64(batch), C.c_uint64(seed), ticks, int(probe_empty),
+                                              _p(out["u0"]), _p(out["code"]), _p(out["iter"]), _p(rec) if want_records else None,
+                                              C.byref(rd), C.byref(packed), _p(out["seconds"]))
+    assert rc == 0, rc
+    out["record_doubles"] = rd.value
+    out["packed"] = bool(packed.value)
+    if want_records:
+        out["records"] = rec.reshape(-1)[: batch * rd.value].reshape(batch, rd.value).copy()
     return out

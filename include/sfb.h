@@ -368,6 +368,15 @@ sfb_status sfb_mpc_swarm_step_host(sfb_mpc_swarm *swarm, const sfb_qp_params *pr
 sfb_status sfb_mpc_swarm_host_records(sfb_mpc_swarm *swarm, double **records);
 sfb_status sfb_mpc_swarm_upload(sfb_mpc_swarm *swarm, int64_t first, int64_t count);
 
+/* Records produced ON the device.  sfb_mpc_swarm_device_records returns the swarm's device record buffer
+ * ([agents][record_doubles], the current packing); a caller whose model is device-callable fills it with its own kernel
+ * (include/smooth_feedback_amd/mpc_device.hpp does, one thread per agent and node) on the null stream, and
+ * sfb_mpc_swarm_step_resident runs the tick from there: assemble, solve, warm starts, small outputs -- nothing but the
+ * agents' times and states goes up. */
+sfb_status sfb_mpc_swarm_device_records(sfb_mpc_swarm *swarm, double **records, int64_t *record_doubles);
+sfb_status sfb_mpc_swarm_step_resident(sfb_mpc_swarm *swarm, const sfb_qp_params *prm, int warmstart, double *du0,
+                                       uint32_t *iter, int32_t *code, double *primal, double *dual);
+
 /* Switch the packing of the per-agent records (layout->jac_keep semantics; NULL = unpacked) of an existing swarm --
  * e.g. back to full records when a linearisation turns out to have a non-zero where the flags said zero.  The swarm's
  * buffers are sized for unpacked records, warm starts and solver memory are untouched.  record_doubles (nullable)

@@ -33,6 +33,33 @@
 
 namespace smooth_feedback_amd {
 
+namespace detail {
+/// value and right-Jacobians of fn(x, u) -> Vec<NO>: the functor's `jacobian(x, u, dx, du)` when it has one, else forward
+/// differences with step sqrt(eps) (the reference's default without the autodiff header).  Host and device.
+template<int NO, class Fn, class X, class U>
+SFB_LIE_HD void xu_jacobian(const Fn & fn, const X & x, const U & u, Vec<NO> & val, Mat<NO, X::Dof> & dx, Mat<NO, U::Dof> & du)
+{
+  val = fn(x, u);
+  if constexpr (requires { fn.jacobian(x, u, dx, du); }) {
+    fn.jacobian(x, u, dx, du);
+  } else {
+    const double h = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON) = 2^-26
+    for (int c = 0; c < X::Dof; ++c) {
+      typename X::Tangent e{};
+      e[c]          = h;
+      const auto v2 = fn(rplus(x, e), u);
+      for (int r = 0; r < NO; ++r) dx(r, c) = (v2[r] - val[r]) / h;
+    }
+    for (int c = 0; c < U::Dof; ++c) {
+      typename U::Tangent e{};
+      e[c]          = h;
+      const auto v2 = fn(x, rplus(u, e));
+      for (int r = 0; r < NO; ++r) du(r, c) = (v2[r] - val[r]) / h;
+    }
+  }
+}
+}  // namespace detail
+
 /// mpc.hpp:309-333
 struct MPCParams {
   std::size_t K{10};
@@ -538,45 +565,11 @@ private:
   // f and its right-Jacobians at (x, u)
   void dyn_jacobian(const X & x, const U & u, Vec<Nx> & fv, Mat<Nx, Nx> & dfdx, Mat<Nx, Nu> & dfdu) const
   {
-    fv = f_(x, u);
-    if constexpr (requires(const F & ff) { ff.jacobian(x, u, dfdx, dfdu); }) {
-      f_.jacobian(x, u, dfdx, dfdu);
-    } else {
-      const double h = std::sqrt(std::numeric_limits<double>::epsilon());
-      for (int c = 0; c < Nx; ++c) {
-        TangentX e{};
-        e[c]          = h;
-        const auto f2 = f_(rplus(x, e), u);
-        for (int r = 0; r < Nx; ++r) dfdx(r, c) = (f2[r] - fv[r]) / h;
-      }
-      for (int c = 0; c < Nu; ++c) {
-        typename U::Tangent e{};
-        e[c]          = h;
-        const auto f2 = f_(x, rplus(u, e));
-        for (int r = 0; r < Nx; ++r) dfdu(r, c) = (f2[r] - fv[r]) / h;
-      }
-    }
+    detail::xu_jacobian<Nx>(f_, x, u, fv, dfdx, dfdu);
   }
   void cr_jacobian(const X & x, const U & u, Vec<Ncr> & cv, Mat<Ncr, Nx> & dcdx, Mat<Ncr, Nu> & dcdu) const
   {
-    cv = cr_(x, u);
-    if constexpr (requires(const CR & cc) { cc.jacobian(x, u, dcdx, dcdu); }) {
-      cr_.jacobian(x, u, dcdx, dcdu);
-    } else {
-      const double h = std::sqrt(std::numeric_limits<double>::epsilon());
-      for (int c = 0; c < Nx; ++c) {
-        TangentX e{};
-        e[c]          = h;
-        const auto c2 = cr_(rplus(x, e), u);
-        for (int r = 0; r < Ncr; ++r) dcdx(r, c) = (c2[r] - cv[r]) / h;
-      }
-      for (int c = 0; c < Nu; ++c) {
-        typename U::Tangent e{};
-        e[c]          = h;
-        const auto c2 = cr_(x, rplus(u, e));
-        for (int r = 0; r < Ncr; ++r) dcdu(r, c) = (c2[r] - cv[r]) / h;
-      }
-    }
+    detail::xu_jacobian<Ncr>(cr_, x, u, cv, dcdx, dcdu);
   }
 
   F f_;

@@ -117,6 +117,8 @@ def _load():
     L.sfb_mpc_swarm_host_records.argtypes = [vp, C.POINTER(C.c_void_p)]
     L.sfb_mpc_swarm_upload.argtypes = [vp, i64, i64]
     L.sfb_mpc_swarm_step_host.argtypes = [vp, C.POINTER(SfbQPParams), dp, dp, i32, dp, dp, dp, dp, dp]
+    L.sfb_mpc_swarm_device_records.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.sfb_mpc_swarm_step_resident.argtypes = [vp, C.POINTER(SfbQPParams), i32, dp, dp, dp, dp, dp]
     L.sfb_mpc_swarm_debug_buffers.argtypes = [vp] + [C.POINTER(C.c_void_p)] * 3
     L.sfb_random_qp_batch.argtypes = [C.c_uint32, i64, i32, i32, C.c_double] + [dp] * 5
     return L

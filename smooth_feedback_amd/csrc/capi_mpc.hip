@@ -392,12 +392,12 @@ sfb_status sfb_mpc_swarm_reset_warmstart(sfb_mpc_swarm *S)
   return SFB_OK;
 }
 
-sfb_status sfb_mpc_swarm_step_host(sfb_mpc_swarm *S, const sfb_qp_params *prm, const double *records,
-                                   const double *shared_jac, int warmstart, double *du0, uint32_t *iter,
-                                   int32_t *code, double *primal, double *dual)
+static sfb_status swarm_step_impl(sfb_mpc_swarm *S, const sfb_qp_params *prm, const double *records, const double *shared_jac,
+                                  int warmstart, double *du0, uint32_t *iter, int32_t *code, double *primal, double *dual,
+                                  const bool resident)
 {
   if (!S) return sfb::fail(SFB_ERR_INVALID_ARG, "swarm is NULL");
-  if (!prm || !records || !du0 || !code) return sfb::fail(SFB_ERR_INVALID_ARG, "NULL params / records / output pointer");
+  if (!prm || (!records && !resident) || !du0 || !code) return sfb::fail(SFB_ERR_INVALID_ARG, "NULL params / records / output pointer");
   if (sfb_status sd = check_swarm_device(S); sd != SFB_OK) return sd;
   std::lock_guard<std::mutex> lk(S->mu);
   const size_t B = (size_t)S->agents;
@@ -416,7 +416,10 @@ sfb_status sfb_mpc_swarm_step_host(sfb_mpc_swarm *S, const sfb_qp_params *prm, c
     t0 = t1;
   };
   do {
-    if (records == S->pinned && !shared_jac) {
+    if (resident) {
+      // the records are in the swarm's device buffer already (written there by the caller's kernel, on the null stream
+      // or synchronised with it)
+    } else if (records == S->pinned && !shared_jac) {
       // pipelined upload: ranges announced with sfb_mpc_swarm_upload are in flight on the copy stream; the rest go now
       const size_t rd = (size_t)p.rec_doubles;
       for (size_t b = 0; b < B && e == hipSuccess;) {
@@ -462,6 +465,27 @@ sfb_status sfb_mpc_swarm_step_host(sfb_mpc_swarm *S, const sfb_qp_params *prm, c
   } while (false);
   if (e != hipSuccess) st = sfb::hip_fail(e, "sfb_mpc_swarm_step_host");
   return st;
+}
+
+sfb_status sfb_mpc_swarm_step_host(sfb_mpc_swarm *S, const sfb_qp_params *prm, const double *records,
+                                   const double *shared_jac, int warmstart, double *du0, uint32_t *iter,
+                                   int32_t *code, double *primal, double *dual)
+{
+  return swarm_step_impl(S, prm, records, shared_jac, warmstart, du0, iter, code, primal, dual, false);
+}
+
+sfb_status sfb_mpc_swarm_step_resident(sfb_mpc_swarm *S, const sfb_qp_params *prm, int warmstart, double *du0, uint32_t *iter,
+                                       int32_t *code, double *primal, double *dual)
+{
+  return swarm_step_impl(S, prm, nullptr, nullptr, warmstart, du0, iter, code, primal, dual, true);
+}
+
+sfb_status sfb_mpc_swarm_device_records(sfb_mpc_swarm *S, double **records, int64_t *record_doubles)
+{
+  if (!S || !records) return sfb::fail(SFB_ERR_INVALID_ARG, "swarm / records is NULL");
+  *records = S->rec;
+  if (record_doubles) *record_doubles = S->rec_own.rec_doubles;
+  return SFB_OK;
 }
 
 sfb_status sfb_mpc_swarm_debug_buffers(sfb_mpc_swarm *S, const double **Ax, const double **l, const double **u)
