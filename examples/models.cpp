@@ -706,6 +706,37 @@ int sfbx_test_asif(int which, double * u_out, int32_t * code, uint32_t * iter, i
   }
 }
 
+/* one host EKF<> object per filter (every predict substep and update is a batch-of-one GPU call): the reference semantics
+ * sfbx_ekf_swarm_device (models_device.hip) is checked against */
+int sfbx_ekf_swarm_host(int64_t batch, int steps, int rk4, double tau, double dt, const double * states, const double * P0,
+                        const double * y, double * states_out, double * P_out)
+{
+  try {
+    const auto Q = sfbx::vehicle_ekf_Q();
+    const auto R = sfbx::vehicle_ekf_R();
+    auto run = [&](auto & ekf, int64_t b) {
+      Mat<6, 6> P;
+      std::copy(P0 + 36 * b, P0 + 36 * (b + 1), P.a.begin());
+      ekf.reset(sfbx::vehicle_state(states + 7 * b), P);
+      for (int k = 0; k < steps; ++k) {
+        ekf.predict(sfbx::VehicleEkfDyn{}, Q, tau, dt > 0 ? std::optional<double>(dt) : std::nullopt);
+        const double * yk = y + ((size_t)k * batch + b) * 3;
+        ekf.template update<3>(sfbx::VehicleEkfMeas{}, Vec<3>{yk[0], yk[1], yk[2]}, R);
+      }
+      sfbx::vehicle_state_out(ekf.estimate(), states_out + 7 * b);
+      const auto Pn = ekf.covariance();
+      std::copy(Pn.a.begin(), Pn.a.end(), P_out + 36 * b);
+    };
+    for (int64_t b = 0; b < batch; ++b) {
+      if (rk4) { EKF<X6, EKFStepper::RK4> e; run(e, b); }
+      else { EKF<X6> e; run(e, b); }
+    }
+    return 0;
+  } catch (const std::exception &) {
+    return -2;
+  }
+}
+
 int sfbx_asif_swarm_states(int64_t batch, uint64_t seed, double * states, double * udes)
 {
   for (int64_t b = 0; b < batch; ++b) {

@@ -86,6 +86,10 @@ int sfbx_asif_swarm_step(int64_t batch, uint64_t seed, int K, int ticks, double 
                          double *wy);
 /* the states (x, y, cos, sin, v0, v1, v2) [batch][7] and desired inputs [batch][2] sfbx_asif_swarm_step starts from */
 int sfbx_asif_swarm_states(int64_t batch, uint64_t seed, double *states, double *udes);
+/* vehicle EKFs, one host EKF<> object per filter: `steps` x (predict(Q, tau, dt) + update(y[step], R)); the host twin of
+ * sfbx_ekf_swarm_device (models_device.hip) */
+int sfbx_ekf_swarm_host(int64_t batch, int steps, int rk4, double tau, double dt, const double *states, const double *P0,
+                        const double *y, double *states_out, double *P_out);
 /* mesh: nodes (N+1), weights (N+1), Dus ((K+1)*K col-major) for `n` intervals of K points */
 int sfbx_mesh(int n_ivals, int K, double *nodes, double *weights, double *Dus);
 

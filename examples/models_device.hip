@@ -9,6 +9,7 @@
 #include <random>
 
 #include <smooth_feedback_amd/asif_device.hpp>
+#include <smooth_feedback_amd/ekf_device.hpp>
 #include <smooth_feedback_amd/mpc_device.hpp>
 
 #include "vehicle_model.h"
@@ -67,9 +68,63 @@ int devlin_step(int K, double tf, int64_t batch, uint64_t seed, int ticks, int p
   if (records) swarm.copy_records(records);
   return 0;
 }
+
+template<EKFStepper Stp>
+int ekf_swarm(int64_t batch, int steps, int fused, double tau, double dt, const double * states, const double * P0, const double * y,
+              double * states_out, double * P_out, int32_t * info, double * seconds)
+{
+  EKFSwarmDevice<X6, sfbx::VehicleEkfDyn, sfbx::VehicleEkfMeas, 3, Stp> swarm(sfbx::VehicleEkfDyn{}, sfbx::VehicleEkfMeas{}, batch);
+  std::vector<X6> g((size_t)batch);
+  std::vector<Mat<6, 6>> P((size_t)batch);
+  for (int64_t b = 0; b < batch; ++b) {
+    g[b] = sfbx::vehicle_state(states + 7 * b);
+    std::copy(P0 + 36 * b, P0 + 36 * (b + 1), P[b].a.begin());
+  }
+  swarm.reset(g, P);
+  const auto Q = sfbx::vehicle_ekf_Q();
+  const auto R = sfbx::vehicle_ekf_R();
+  std::vector<Vec<3>> ys((size_t)batch);
+  for (int k = 0; k < steps; ++k) {
+    for (int64_t b = 0; b < batch; ++b) ys[b] = {y[((size_t)k * batch + b) * 3], y[((size_t)k * batch + b) * 3 + 1], y[((size_t)k * batch + b) * 3 + 2]};
+    const auto t0 = std::chrono::steady_clock::now();
+    if (fused) {
+      swarm.step(Q, tau, ys, R);
+    } else {
+      swarm.predict(Q, tau, dt > 0 ? std::optional<double>(dt) : std::nullopt);
+      swarm.update(ys, R);
+    }
+    (void)hipDeviceSynchronize();
+    if (seconds) seconds[k] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  g = swarm.estimates();
+  P = swarm.covariances();
+  const auto inf = swarm.update_info();
+  for (int64_t b = 0; b < batch; ++b) {
+    sfbx::vehicle_state_out(g[b], states_out + 7 * b);
+    std::copy(P[b].a.begin(), P[b].a.end(), P_out + 36 * b);
+    info[b] = inf[b];
+  }
+  return 0;
+}
 }  // namespace
 
 extern "C" {
+
+/* A swarm of vehicle EKFs on the GPU (EKFSwarmDevice; model: vehicle_model.h VehicleEkfDyn / VehicleEkfMeas): `steps` times
+ * predict(Q, tau, dt) + update(y[step], R) -- or the fused step() (fused != 0, Euler, one substep) -- from states [batch][7]
+ * and covariances P0 [batch][36]; y [steps][batch][3].  dt <= 0: the default single substep.  Out: states, covariances, the
+ * last update's info, seconds[steps].  sfbx_ekf_swarm_host (models.h) does the same with one host EKF<> object per filter. */
+int sfbx_ekf_swarm_device(int64_t batch, int steps, int rk4, int fused, double tau, double dt, const double * states, const double * P0,
+                          const double * y, double * states_out, double * P_out, int32_t * info, double * seconds)
+{
+  try {
+    return rk4 ? ekf_swarm<EKFStepper::RK4>(batch, steps, fused, tau, dt, states, P0, y, states_out, P_out, info, seconds)
+               : ekf_swarm<EKFStepper::Euler>(batch, steps, fused, tau, dt, states, P0, y, states_out, P_out, info, seconds);
+  } catch (const std::exception & e) {
+    std::fprintf(stderr, "sfbx_ekf_swarm_device: %s\n", e.what());
+    return -2;
+  }
+}
 
 /* sfbx_mpc_swarm_device_step (models.h) with the linearisation on the GPU as well (MPCSwarmDeviceLin): same agents, same
  * closed loop.  Also out: the records of the LAST tick as the device wrote them ([batch][*record_doubles], room for the

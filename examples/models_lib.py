@@ -202,3 +202,35 @@ def mpc_swarm_devlin_step(variant, K, batch, ticks, seed=1, tf=5.0, probe_empty=
     if want_records:
         out["records"] = rec.reshape(-1)[: batch * rd.value].reshape(batch, rd.value).copy()
     return out
+
+
+def ekf_swarm_inputs(batch, steps, seed=0):
+    """states [batch][7] of asif_swarm_states, SPD covariances, measurements near the states' (x, y, v0)"""
+    st, _ = asif_swarm_states(batch, seed)
+    rng = np.random.default_rng(seed)
+    G = rng.uniform(-1, 1, (batch, 6, 6))
+    P0 = (np.eye(6)[None] * 0.5 + G @ G.transpose(0, 2, 1) / 12).reshape(batch, 36)
+    y = st[None, :, [0, 1, 4]] + rng.normal(0, 0.2, (steps, batch, 3))
+    return st, np.ascontiguousarray(P0), np.ascontiguousarray(y)
+
+
+def ekf_swarm_device(states, P0, y, tau=0.1, dt=0.0, rk4=False, fused=False):
+    """EKFSwarmDevice (ekf_device.hpp): len(y) predict+update rounds of every filter on the GPU."""
+    batch, steps = len(states), len(y)
+    out = dict(states=np.zeros((batch, 7)), P=np.zeros((batch, 36)), info=np.zeros(batch, np.int32), seconds=np.zeros(steps))
+    st = np.ascontiguousarray(states, dtype=np.float64); P0 = np.ascontiguousarray(P0, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
+    rc = dev_lib().sfbx_ekf_swarm_device(C.c_int64(batch), steps, int(rk4), int(fused), C.c_double(tau), C.c_double(dt), _p(st), _p(P0),
+                                         _p(y), _p(out["states"]), _p(out["P"]), _p(out["info"]), _p(out["seconds"]))
+    assert rc == 0, rc
+    return out
+
+
+def ekf_swarm_host(states, P0, y, tau=0.1, dt=0.0, rk4=False):
+    """the same through one host EKF<> object per filter"""
+    batch, steps = len(states), len(y)
+    out = dict(states=np.zeros((batch, 7)), P=np.zeros((batch, 36)))
+    st = np.ascontiguousarray(states, dtype=np.float64); P0 = np.ascontiguousarray(P0, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
+    rc = lib().sfbx_ekf_swarm_host(C.c_int64(batch), steps, int(rk4), C.c_double(tau), C.c_double(dt), _p(st), _p(P0), _p(y),
+                                   _p(out["states"]), _p(out["P"]))
+    assert rc == 0, rc
+    return out

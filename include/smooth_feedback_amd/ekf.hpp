@@ -1,5 +1,5 @@
 // Host side of the EKF path: same interface as smooth::feedback::EKF<G> (reference ekf.hpp:39-149)
-// for one filter, plus EKFBatch for swarms.  The Lie-group work that needs the user's callbacks
+// for one filter; ekf_device.hpp (hipcc) runs a swarm of filters with device-callable models entirely on the GPU.  The Lie-group work that needs the user's callbacks
 // (linearisation of f and h at the estimate, state propagation, g (+) delta) stays here on the host;
 // the covariance algebra runs on the GPU through sfb_ekf_*_batch (include/sfb.h).
 //
@@ -29,14 +29,17 @@ inline void ekf_check(sfb_status st)
   if (st != SFB_OK) throw std::runtime_error(std::string("sfb: ") + sfb_last_error());
 }
 
+// forward-difference step of the host and device fronts: sqrt(DBL_EPSILON)
+SFB_LIE_HD constexpr double ekf_fd_step() { return 1.4901161193847656e-08; }
+
 // A = -ad(f(g)) + d^r f/dg  (ekf.hpp:86-87), right-derivative by forward differences
 template<class G, class F>
-Mat<G::Dof, G::Dof> ekf_linearise_dyn(F && f, const G & g, typename G::Tangent & fv)
+SFB_LIE_HD Mat<G::Dof, G::Dof> ekf_linearise_dyn(F && f, const G & g, typename G::Tangent & fv)
 {
   constexpr int N = G::Dof;
   fv = f(g);
   Mat<N, N> dr{};
-  const double h = std::sqrt(std::numeric_limits<double>::epsilon());
+  const double h = ekf_fd_step();
   for (int c = 0; c < N; ++c) {
     typename G::Tangent e{};
     e[c]          = h;
@@ -47,6 +50,35 @@ Mat<G::Dof, G::Dof> ekf_linearise_dyn(F && f, const G & g, typename G::Tangent &
   Mat<N, N> A{};
   for (int i = 0; i < N * N; ++i) A.a[i] = -adf.a[i] + dr.a[i];
   return A;
+}
+
+// H = d^r h/dg by forward differences and the innovation r = y - h(g)  (ekf.hpp:119-121, measurements in R^Ny)
+template<int Ny, class G, class HF>
+SFB_LIE_HD void ekf_linearise_meas(HF && h, const G & g, const Vec<Ny> & y, Mat<Ny, G::Dof> & Hm, Vec<Ny> & r)
+{
+  constexpr int N    = G::Dof;
+  const Vec<Ny> hval = h(g);
+  const double eps   = ekf_fd_step();
+  for (int c = 0; c < N; ++c) {
+    typename G::Tangent e{};
+    e[c]          = eps;
+    const auto h2 = h(rplus(g, e));
+    for (int rr = 0; rr < Ny; ++rr) Hm(rr, c) = (h2[rr] - hval[rr]) / eps;
+  }
+  for (int i = 0; i < Ny; ++i) r[i] = y[i] - hval[i];
+}
+
+// runge_kutta4 on the group: stage states g (+) dt a_ij k_j, result g (+) dt sum b_i k_i; k1 = f(t, g) given
+template<class G, class F>
+SFB_LIE_HD G ekf_rk4_state(F && f, double t, double h, const G & g, const typename G::Tangent & k1)
+{
+  auto scaled = [](typename G::Tangent k, double c) { for (auto & v : k) v *= c; return k; };
+  const auto k2 = f(t + 0.5 * h, rplus(g, scaled(k1, 0.5 * h)));
+  const auto k3 = f(t + 0.5 * h, rplus(g, scaled(k2, 0.5 * h)));
+  const auto k4 = f(t + h, rplus(g, scaled(k3, h)));
+  typename G::Tangent d{};
+  for (int i = 0; i < G::Dof; ++i) d[i] = h * (1.0 / 6.0) * k1[i] + h * (1.0 / 3.0) * k2[i] + h * (1.0 / 3.0) * k3[i] + h * (1.0 / 6.0) * k4[i];
+  return rplus(g, d);
 }
 }  // namespace detail
 
@@ -88,14 +120,7 @@ public:
         for (auto & v : fv) v *= h;
         g_hat_ = rplus(g_hat_, fv);  // euler on the group: g <- g (+) dt f (:97)
       } else {
-        auto scaled = [](typename G::Tangent k, double c) { for (auto & v : k) v *= c; return k; };
-        const auto k1 = fv;
-        const auto k2 = f(t + 0.5 * h, rplus(g_hat_, scaled(k1, 0.5 * h)));
-        const auto k3 = f(t + 0.5 * h, rplus(g_hat_, scaled(k2, 0.5 * h)));
-        const auto k4 = f(t + h, rplus(g_hat_, scaled(k3, h)));
-        typename G::Tangent d{};
-        for (int i = 0; i < N; ++i) d[i] = h * (1.0 / 6.0) * k1[i] + h * (1.0 / 3.0) * k2[i] + h * (1.0 / 3.0) * k3[i] + h * (1.0 / 6.0) * k4[i];
-        g_hat_ = rplus(g_hat_, d);
+        g_hat_ = detail::ekf_rk4_state(f, t, h, g_hat_, fv);
       }
     };
     while (t + dt_v < tau) {
@@ -109,17 +134,9 @@ public:
   template<int Ny, class H>
   void update(H && h, const Vec<Ny> & y, const Mat<Ny, Ny> & R)
   {
-    const Vec<Ny> hval = h(g_hat_);
     Mat<Ny, N> Hm{};
-    const double eps = std::sqrt(std::numeric_limits<double>::epsilon());
-    for (int c = 0; c < N; ++c) {
-      typename G::Tangent e{};
-      e[c]          = eps;
-      const auto h2 = h(rplus(g_hat_, e));
-      for (int r = 0; r < Ny; ++r) Hm(r, c) = (h2[r] - hval[r]) / eps;
-    }
     Vec<Ny> r{};
-    for (int i = 0; i < Ny; ++i) r[i] = y[i] - hval[i];
+    detail::ekf_linearise_meas<Ny>(h, g_hat_, y, Hm, r);
     typename G::Tangent delta{};
     int32_t info = 0;
     detail::ekf_check(sfb_ekf_step_batch_host(1, N, Ny, nullptr, nullptr, 0, nullptr, 0, Hm.a.data(), R.a.data(), 1,
