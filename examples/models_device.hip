@@ -126,6 +126,63 @@ int sfbx_ekf_swarm_device(int64_t batch, int steps, int rk4, int fused, double t
   }
 }
 
+/* examples/mpc_asif_vehicle.cpp:151-175 for a swarm, both controllers on the GPU: per 25 ms tick the MPC input of every vehicle
+ * (MPCSwarmDeviceLin, K_mpc), filtered by the ASI filter (ASIFSwarmDevice, K_asif), then one runge_kutta4 step of the
+ * closed loop.  Vehicle 0 starts at the identity like the example, the others off it by xi ~ U(-0.3, 0.3)^6 (mt19937_64(seed + b)).
+ * Out per tick: positions xy [ticks][batch][2], u_mpc / u_asif [ticks][batch][2], the number of non-Optimal MPC / ASIF
+ * solves, the smallest barrier value h(x) over the swarm, seconds [ticks][2] (MPC, ASIF). */
+int sfbx_vehicle_swarm_sim(int64_t batch, int K_mpc, int K_asif, int ticks, uint64_t seed, double * xy, double * u_mpc, double * u_asif,
+                           int32_t * mpc_bad, int32_t * asif_bad, double * hmin, double * seconds)
+{
+  try {
+    const sfbx::VehicleModel6 mdl{};
+    auto mpc = sfbx::make_vehicle_mpc<sfbx::MPC6, sfbx::VehicleModel6>(K_mpc, 5.0);
+    MPCSwarmDeviceLin<sfbx::MPC6, sfbx::VehicleModel6> ctrl(mpc, mdl, batch);
+    ASIFSwarmDevice<X6, U2, sfbx::VehicleDyn6, sfbx::VehicleH, sfbx::VehicleBU> filt(sfbx::VehicleDyn6{}, sfbx::VehicleH{}, sfbx::VehicleBU{},
+                                                                                    (size_t)batch, sfbx::vehicle_asif_params(K_asif));
+    std::vector<X6> x((size_t)batch);
+    for (int64_t b = 1; b < batch; ++b) {
+      std::mt19937_64 rng(seed + (uint64_t)b);
+      std::uniform_real_distribution<double> d(-0.3, 0.3);
+      X6::Tangent xi{};
+      for (auto & v : xi) v = d(rng);
+      x[b] = rplus(X6::Identity(), xi);
+    }
+    std::vector<double> t((size_t)batch, 0.0);
+    std::vector<U2> um, ua;
+    std::vector<QPSolutionStatus> cs;
+    const double dt = 0.025;
+    for (int k = 0; k < ticks; ++k) {
+      auto t0 = std::chrono::steady_clock::now();
+      ctrl.step(t, x, um, cs);
+      auto t1 = std::chrono::steady_clock::now();
+      ua = filt(x, um);
+      auto t2 = std::chrono::steady_clock::now();
+      seconds[2 * k]     = std::chrono::duration<double>(t1 - t0).count();
+      seconds[2 * k + 1] = std::chrono::duration<double>(t2 - t1).count();
+      mpc_bad[k] = asif_bad[k] = 0;
+      hmin[k]    = 1e300;
+      for (int64_t b = 0; b < batch; ++b) {
+        mpc_bad[k] += cs[b] != QPSolutionStatus::Optimal;
+        asif_bad[k] += filt.codes()[b] != 0;
+        double * o = xy + ((size_t)k * batch + b) * 2;
+        o[0] = x[b].part<0>().x; o[1] = x[b].part<0>().y;
+        double * pm = u_mpc + ((size_t)k * batch + b) * 2, *pa = u_asif + ((size_t)k * batch + b) * 2;
+        pm[0] = um[b].v[0]; pm[1] = um[b].v[1]; pa[0] = ua[b].v[0]; pa[1] = ua[b].v[1];
+        hmin[k] = std::min(hmin[k], sfbx::VehicleH{}(0.0, x[b])[0]);
+        const U2 u = ua[b];
+        auto f     = [&](double, const X6 & g) { return sfbx::VehicleDyn6{}(g, u); };
+        x[b]       = detail::ekf_rk4_state(f, 0.0, dt, x[b], f(0.0, x[b]));  // runge_kutta4 on the group (:146-147)
+        t[b] += dt;
+      }
+    }
+    return 0;
+  } catch (const std::exception & e) {
+    std::fprintf(stderr, "sfbx_vehicle_swarm_sim: %s\n", e.what());
+    return -2;
+  }
+}
+
 /* sfbx_mpc_swarm_device_step (models.h) with the linearisation on the GPU as well (MPCSwarmDeviceLin): same agents, same
  * closed loop.  Also out: the records of the LAST tick as the device wrote them ([batch][*record_doubles], room for the
  * unpacked size; NULL to skip), whether they are packed, seconds[ticks].  probe_empty != 0: start from an empty packing

@@ -234,3 +234,13 @@ def ekf_swarm_host(states, P0, y, tau=0.1, dt=0.0, rk4=False):
                                    _p(out["states"]), _p(out["P"]))
     assert rc == 0, rc
     return out
+
+
+def vehicle_swarm_sim(batch, ticks, K_mpc=30, K_asif=200, seed=0):
+    """examples/mpc_asif_vehicle.cpp's closed loop for a swarm, MPC and ASI filter on the GPU (models_device.hip)."""
+    out = dict(xy=np.zeros((ticks, batch, 2)), u_mpc=np.zeros((ticks, batch, 2)), u_asif=np.zeros((ticks, batch, 2)),
+               mpc_bad=np.zeros(ticks, np.int32), asif_bad=np.zeros(ticks, np.int32), hmin=np.zeros(ticks), seconds=np.zeros((ticks, 2)))
+    rc = dev_lib().sfbx_vehicle_swarm_sim(C.c_int64(batch), K_mpc, K_asif, ticks, C.c_uint64(seed), _p(out["xy"]), _p(out["u_mpc"]),
+                                          _p(out["u_asif"]), _p(out["mpc_bad"]), _p(out["asif_bad"]), _p(out["hmin"]), _p(out["seconds"]))
+    assert rc == 0, rc
+    return out
