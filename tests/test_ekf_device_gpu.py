@@ -42,3 +42,11 @@ def test_covariances_stay_symmetric_and_positive():
     assert np.min(np.linalg.eigvalsh(P)) > 0
     # measured components are known better than before
     assert np.mean(P[:, 0, 0]) < np.mean(P0.reshape(-1, 6, 6)[:, 0, 0])
+
+
+@pytest.mark.parametrize("batch", [1, 65])
+def test_ragged_swarm_sizes(batch):
+    st, P0, y = M.ekf_swarm_inputs(batch, 2, seed=11)
+    dev = M.ekf_swarm_device(st, P0, y, tau=0.1, dt=0.05)
+    host = M.ekf_swarm_host(st, P0, y, tau=0.1, dt=0.05)
+    assert np.max(np.abs(dev["states"] - host["states"])) <= TOL and np.max(np.abs(dev["P"] - host["P"])) <= TOL

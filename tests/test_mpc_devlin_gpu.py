@@ -34,7 +34,7 @@ def test_device_records_equal_fill_record(variant, K):
     assert np.array_equal(pk["u0"], full["u0"])
 
 
-@pytest.mark.parametrize("variant,K,batch", [(6, 20, 200), (12, 20, 500), (12, 50, 64)])
+@pytest.mark.parametrize("variant,K,batch", [(6, 20, 200), (12, 20, 500), (12, 50, 64), (12, 20, 1), (6, 20, 65)])
 def test_closed_loop_equals_host_linearised_swarm(variant, K, batch):
     ticks = 3
     u_ref, c_ref, it_ref = M.mpc_swarm_step(variant, K, batch, ticks, seed=1, device=True)
@@ -43,7 +43,7 @@ def test_closed_loop_equals_host_linearised_swarm(variant, K, batch):
     assert np.all(r["code"] == 0)
     assert np.max(np.abs(r["u0"] - u_ref)) <= U_TOL
     # iteration counts may move by a check interval where a residual sits on the tolerance
-    assert np.mean(r["iter"] == it_ref) >= 0.95
+    assert np.mean(r["iter"] == it_ref) >= (0.95 if batch >= 64 else 0.0)
 
 
 def test_misfit_falls_back_to_unpacked_records():
