@@ -32,7 +32,7 @@ namespace sfb {
 namespace {
 
 constexpr int kBigMaxK = 1024;
-constexpr int64_t kRoomyBatch = 512;  // launches with fewer QPs get the large on-chip row pool (see big_row_cap)
+constexpr int64_t kRoomyBatch = 257;  // launches with fewer QPs (at most one per CU) get the large on-chip row pool (see big_row_cap)
 constexpr int kRB      = kBigMaxK / kWave;  // row blocks per lane at the largest size
 
 // The sweeps and the factorisation are real (outlined) device functions: a plain `double *` parameter is a GENERIC
@@ -137,12 +137,12 @@ constexpr int kDiagCacheK = 384;  // up to this size the diagonal blocks of L ar
 // Pool size: what is left of the 160 KB of a CU after everything else the kernel keeps in LDS (one wave per CU then --
 // a lone QP is what this matters for; batches of such QPs are served by fewer, faster waves), at most 2 k + 64 rows
 // (a safety filter needs n rows per block forward and, for the blocks holding the variables, all rows backward).
-__host__ __device__ constexpr size_t big_lds_fixed_bytes(const int n, const int m)
+__host__ __device__ constexpr size_t big_lds_fixed_bytes(const int n, const int m, const bool diag_cache = true)
 {
   const size_t k = (size_t)n + (size_t)m;
   const size_t rb = (k + 63) / 64 <= 2 ? 2 : ((k + 63) / 64 <= 4 ? 4 : ((k + 63) / 64 <= 8 ? 8 : 16));
   const size_t tiles = ((k + 15) / 16) * rb;  // non-zero maps of the sweep tiles, forward and backward
-  const size_t dcache = (k <= (size_t)kDiagCacheK) ? ((k + 15) / 16) * 16 * kBP : 0;
+  const size_t dcache = (diag_cache && k <= (size_t)kDiagCacheK) ? ((k + 15) / 16) * 16 * kBP : 0;
   return (4 * k + 2 * (size_t)n + 6 * (size_t)m + 8 + dcache) * sizeof(double) +
          ((k + 1) / 2 * 2 + 2 * tiles + 3 * ((k + 15) / 16 + 1) + 4) * sizeof(int);
 }
@@ -150,13 +150,25 @@ __host__ __device__ constexpr size_t big_lds_fixed_bytes(const int n, const int 
 // otherwise k + 64 rows, which keeps two or three waves per CU for batches (measured at (40, 60): 3 waves per CU with
 // k + 64, 2 with k + 128: 90 vs 118 ms for 4 096 QPs) (the lists are an optimisation: a factor
 // they do not hold is streamed tile by tile, same results).
-__host__ __device__ constexpr int big_row_cap(const int n, const int m, const bool roomy)
+__host__ __device__ constexpr int big_row_cap(const int n, const int m, const bool roomy, const bool diag_cache = true)
 {
-  const size_t budget = 158 * 1024, fixed = big_lds_fixed_bytes(n, m), per_row = kBP * sizeof(double) + sizeof(int);
+  const size_t budget = 158 * 1024, fixed = big_lds_fixed_bytes(n, m, diag_cache), per_row = kBP * sizeof(double) + sizeof(int);
   const size_t k = (size_t)n + m, fit = budget > fixed ? (budget - fixed) / per_row : 0;
   const size_t want = roomy ? 2 * k + 64 : (k <= (size_t)kDiagCacheK ? k + 64 : 192);
-  const size_t cap  = fit < want ? fit : want;
-  return cap < 64 ? 64 : (int)cap;
+  size_t cap        = fit < want ? fit : want;
+  if (cap < 64) cap = 64;
+  if (!roomy) {
+    // batches: resident blocks per CU come in steps of the LDS request, and several sizes sit just above a step
+    // ((3, 203): 84 KB = one block per CU, 255 rows instead of 270 make it two).  Give up to 40 % of the pool for one
+    // more resident wave -- occupancy is what batches are short of, the lists are an optimisation.
+    const size_t cu = 160 * 1024, total = fixed + cap * per_row, blocks = total ? cu / total : 1;
+    const size_t share = (cu / (blocks + 1)) & ~(size_t)1023;  // per-block LDS for one more block, below any allocation granule
+    if (share > fixed + 1024) {
+      const size_t cap2 = (share - 1024 - fixed) / per_row;
+      if (cap2 >= 64 && 10 * cap2 >= 6 * cap && cap2 < cap) cap = cap2;
+    }
+  }
+  return (int)cap;
 }
 
 // LT(j, i) = W(i, j) for i > j (column j of L contiguous), Dg[i] = W(i, i), and the non-zero maps of the tiles the
@@ -513,14 +525,28 @@ size_t qp_dense_big_ws_doubles(int n, int m)
   const size_t k = (size_t)n + m;
   return 3 * k * k + k + 6 * (size_t)n + 11 * (size_t)m + 8;
 }
-size_t qp_dense_big_lds_bytes(int n, int m, int64_t batch)
+// LDS configuration of a launch: the row pool (big_row_cap) and whether the diagonal blocks are cached.  A lone QP wants
+// both; a batch must not be left with ONE wave per CU -- (4, 301) with the diagonal cache is 122 KB, without it 79 KB.
+struct BigLds { bool diag_cache; int rcap; size_t bytes; };
+static BigLds big_lds_config(int n, int m, int64_t batch)
 {
-  return big_lds_fixed_bytes(n, m) + (size_t)big_row_cap(n, m, batch < kRoomyBatch) * (kBP * sizeof(double) + sizeof(int));
+  const size_t per_row = kBP * sizeof(double) + sizeof(int), cu = 160 * 1024;
+  auto make = [&](bool dc) {
+    const int rc = big_row_cap(n, m, batch < kRoomyBatch, dc);
+    return BigLds{dc, rc, big_lds_fixed_bytes(n, m, dc) + (size_t)rc * per_row};
+  };
+  const BigLds with = make(true);
+  if (batch < kRoomyBatch || n + m > kDiagCacheK) return with;
+  const BigLds without = make(false);
+  // measured (scripts/dense_big_time.py): a second resident block is worth the cache ((4, 301): 2.8 -> 3.7 k QP/s), a third
+  // or later one is not ((3, 203): 23.9 k QP/s with the cache and 2 blocks, 13.7 k without it and 3)
+  return (cu / with.bytes <= 1 && cu / without.bytes >= 2) ? without : with;
 }
+size_t qp_dense_big_lds_bytes(int n, int m, int64_t batch) { return big_lds_config(n, m, batch).bytes; }
 
 template<int RB>
 __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParams kp, const QpBatch g, double *__restrict__ gws,
-                                                         const size_t wsd, const int rcap)
+                                                         const size_t wsd, const int rcap, const int dck)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int lane = threadIdx.x;
@@ -533,9 +559,10 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
   double *t = sm, *temp = t + k, *aux = temp + k + 8, *xs = aux + k, *ys = xs + n, *zs = ys + m;
   // the per-iteration constants of the ADMM loop (a lone wave pays a memory round trip per phase otherwise)
   double *Lrho = zs + m, *Lrinv = Lrho + m, *Llo = Lrinv + m, *Lhi = Llo + m, *Lqc = Lhi + m;
-  // diagonal 16 x 16 blocks of L for the blocked sweeps, cached in LDS while they fit (k <= kDiagCacheK)
+  // diagonal 16 x 16 blocks of L for the blocked sweeps, cached in LDS while they fit (k <= dck: kDiagCacheK, or 0 for
+  // batches that gain a resident block per CU without the cache)
   double *dblk = Lqc + n;
-  double *LDg  = dblk + ((k <= kDiagCacheK) ? (size_t)((k + kBW - 1) / kBW) * kBW * kBP : 0);  // diagonal of the factor
+  double *LDg  = dblk + ((k <= dck) ? (size_t)((k + kBW - 1) / kBW) * kBW * kBP : 0);  // diagonal of the factor
   double *cval = LDg + k;                                                                        // compact off-diagonal rows
   int *perm = reinterpret_cast<int *>(cval + rcap * kBP);
   int *fnz = perm + (k + 1) / 2 * 2, *bnz = fnz + ((k + kBW - 1) / kBW) * RB;
@@ -650,7 +677,7 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
   }
   wave_sync();
   if (!big_ldlt_factor(k, w.H, k, perm, temp, lane)) ret_code = SFB_QP_UNKNOWN;  // :428-433
-  const bool dcache = k <= kDiagCacheK;
+  const bool dcache = k <= dck;
   big_transpose<RB>(k, w.H, k, w.LT, w.Dg, fnz, bnz, dcache ? dblk : nullptr, LDg, cidx, cval, cflag, rcap, lane);
 
   // ---- initial iterate :436-445 ----
@@ -917,15 +944,16 @@ hipError_t qp_dense_big_launch(const DenseKernelParams &kp, int64_t batch, const
 {
   const int k = kp.n + kp.m;
   if (k > kBigMaxK) return hipErrorInvalidValue;
-  const size_t lds = qp_dense_big_lds_bytes(kp.n, kp.m, batch);
-  const int rcap   = big_row_cap(kp.n, kp.m, batch < kRoomyBatch);
+  const BigLds cfg = big_lds_config(kp.n, kp.m, batch);
+  const size_t lds = cfg.bytes;
+  const int rcap = cfg.rcap, dck = cfg.diag_cache ? kDiagCacheK : 0;
   const size_t wsd = qp_dense_big_ws_doubles(kp.n, kp.m);
   const dim3 grid((unsigned)batch), block(kWave);
   const int rb = (k + kWave - 1) / kWave;
-  if (rb <= 2) hipLaunchKernelGGL((qp_dense_big_kernel<2>), grid, block, lds, stream, kp, g, workspace, wsd, rcap);
-  else if (rb <= 4) hipLaunchKernelGGL((qp_dense_big_kernel<4>), grid, block, lds, stream, kp, g, workspace, wsd, rcap);
-  else if (rb <= 8) hipLaunchKernelGGL((qp_dense_big_kernel<8>), grid, block, lds, stream, kp, g, workspace, wsd, rcap);
-  else hipLaunchKernelGGL((qp_dense_big_kernel<kRB>), grid, block, lds, stream, kp, g, workspace, wsd, rcap);
+  if (rb <= 2) hipLaunchKernelGGL((qp_dense_big_kernel<2>), grid, block, lds, stream, kp, g, workspace, wsd, rcap, dck);
+  else if (rb <= 4) hipLaunchKernelGGL((qp_dense_big_kernel<4>), grid, block, lds, stream, kp, g, workspace, wsd, rcap, dck);
+  else if (rb <= 8) hipLaunchKernelGGL((qp_dense_big_kernel<8>), grid, block, lds, stream, kp, g, workspace, wsd, rcap, dck);
+  else hipLaunchKernelGGL((qp_dense_big_kernel<kRB>), grid, block, lds, stream, kp, g, workspace, wsd, rcap, dck);
   return hipGetLastError();
 }
 
