@@ -153,6 +153,7 @@ public:
   /// one control tick for all agents
   void step(const std::vector<double> & t, const std::vector<X> & xs, std::vector<U> & us, std::vector<QPSolutionStatus> & codes)
   {
+    if ((int64_t)t.size() != B_ || (int64_t)xs.size() != B_) throw std::invalid_argument("MPCSwarmDeviceLin: one time and state per agent");
     detail::mpc_hip_check(hipMemcpy(dt_, t.data(), (size_t)B_ * 8, hipMemcpyHostToDevice), "hipMemcpy(t)");
     detail::mpc_hip_check(hipMemcpy(dx_, xs.data(), (size_t)B_ * sizeof(X), hipMemcpyHostToDevice), "hipMemcpy(x)");
     linearise();
