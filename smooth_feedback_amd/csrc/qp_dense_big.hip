@@ -144,7 +144,7 @@ __host__ __device__ constexpr size_t big_lds_fixed_bytes(const int n, const int 
   const size_t tiles = ((k + 15) / 16) * rb;  // non-zero maps of the sweep tiles, forward and backward
   const size_t dcache = (diag_cache && k <= (size_t)kDiagCacheK) ? ((k + 15) / 16) * 16 * kBP : 0;
   return (4 * k + 2 * (size_t)n + 6 * (size_t)m + 8 + dcache) * sizeof(double) +
-         ((k + 1) / 2 * 2 + 2 * tiles + 3 * ((k + 15) / 16 + 1) + 4) * sizeof(int);
+         ((k + 1) / 2 * 2 + 2 * tiles + 4 * ((k + 15) / 16 + 1) + 4) * sizeof(int);
 }
 // `roomy`: few QPs in the launch (at most one wave per CU anyway): take what the lists of such a factor can need;
 // otherwise k + 64 rows, which keeps two or three waves per CU for batches (measured at (40, 60): 3 waves per CU with
@@ -193,11 +193,12 @@ __device__ inline void big_transpose(const int K, const double *__restrict__ W, 
   for (int i = 0; i < K; ++i)
     for (int j = lane; j < i; j += kWave) LT[(size_t)j * ld + i] = W[(size_t)i * ld + j];
   // cidx: [0, nb] forward block offsets, [nb + 1, 2 nb + 1] backward block offsets, nb flags "the diagonal block has
-  // entries below its diagonal", then the rows of the lists (forward lists first, one pool of `cap` rows);
-  // cval: the rows' 16 values (stride kBP); cflag[0]: the lists are complete
+  // entries below its diagonal", nb run lengths of the forward sweep (below), then the rows of the lists (forward lists
+  // first, one pool of `cap` rows); cval: the rows' 16 values (stride kBP); cflag[0]: the lists are complete
   {
     const int nbk = (K + kBW - 1) / kBW;
-    lds_i *const foff = cidx, *const boff = cidx + nbk + 1, *const dflag = boff + nbk + 1, *const rows = dflag + nbk;
+    lds_i *const foff = cidx, *const boff = cidx + nbk + 1, *const dflag = boff + nbk + 1, *const frun = dflag + nbk,
+                 *const rows = frun + nbk;
     int np = 0;
     for (int dir = 0; dir < 2; ++dir) {
       lds_i *const off = dir ? boff : foff;
@@ -235,6 +236,35 @@ __device__ inline void big_transpose(const int K, const double *__restrict__ W, 
       if (lane == 0) off[nbk] = np;
     }
     if (lane == 0) cflag[0] = (np <= cap) ? 1 : 0;
+    wave_sync();
+    // frun[jb] > 0: blocks jb .. jb + frun[jb] - 1 have no entries below the diagonal inside their diagonal blocks, the
+    // SAME (at most 64) rows below them, and all of those rows lie beyond the run's columns -- the constraint columns
+    // of a safety filter, whose only dependants are the variables' rows.  The forward sweep then carries those rows in
+    // registers through the whole run (big_solve).  0: the block takes the general path.
+    if (np <= cap) {
+      int end_same = nbk;  // wave-uniform: end of the run of identical lists the block after jb belongs to
+      for (int jb = nbk - 1; jb >= 0; --jb) {
+        const int e0 = ubig(foff[jb]), c = ubig(foff[jb + 1]) - e0;
+        const bool plain = ubig(dflag[jb]) == 0 && c > 0 && c <= kWave;
+        bool same = false;
+        if (plain && jb + 1 < nbk && ubig(frun[jb + 1]) > 0 && ubig(foff[jb + 2]) - ubig(foff[jb + 1]) == c) {
+          const int e1 = ubig(foff[jb + 1]);
+          same = wave_ballot(lane < c && rows[e0 + (lane < c ? lane : 0)] != rows[e1 + (lane < c ? lane : 0)]) == 0ull;
+        }
+        if (!same) end_same = jb + 1;
+        int len = 0;
+        if (plain) {
+          const int lim = ubig(rows[e0]) / kBW;  // the smallest dependent row must lie beyond the run
+          len = (end_same < lim ? end_same : lim) - jb;
+          if (len < 1) len = 0;
+        }
+        if (!plain) end_same = jb;  // nothing continues through a general block
+        if (lane == 0) frun[jb] = len;
+        wave_sync();
+      }
+    } else {
+      for (int jb = lane; jb < nbk; jb += kWave) frun[jb] = 0;
+    }
   }
   for (int i = lane; i < K; i += kWave) LDg[i] = W[(size_t)i * ld + i];
   if (dblk_ != nullptr) {  // dblk[jb][r][c] = L(16 jb + r, 16 jb + c), r > c (other entries 0)
@@ -292,8 +322,8 @@ __device__ inline void big_solve(const int K, const double *__restrict__ W, cons
   LDS_D(temp, temp_);
   const int nbk0    = (K + kBW - 1) / kBW;
   const bool compact = cflag[0] != 0;  // wave-uniform (LDS)
-  const lds_i *const foff = cidx, *const boff = cidx + nbk0 + 1, *const dflag = boff + nbk0 + 1, *const frow = dflag + nbk0,
-                     *const brow = frow;
+  const lds_i *const foff = cidx, *const boff = cidx + nbk0 + 1, *const dflag = boff + nbk0 + 1, *const frun = dflag + nbk0,
+                     *const frow = frun + nbk0, *const brow = frow;
   const lds_d *const fval = cval, *const bval = cval;
   BP_T(p0);
   for (int i = lane; i < K; i += kWave) temp[i] = t[perm[i]];
@@ -318,6 +348,33 @@ __device__ inline void big_solve(const int K, const double *__restrict__ W, cons
     const int e0 = compact ? ubig(foff[jb]) : 0, e1 = compact ? ubig(foff[jb + 1]) : 0;
     const bool chain = !compact || ubig(dflag[jb]) != 0;
     if (compact && !chain && e0 == e1) continue;
+    if (const int run = compact ? ubig(frun[jb]) : 0; run > 0) {
+      // a run of blocks without chains whose only dependants are the same few rows beyond the run (big_transpose): one
+      // lane per dependent row keeps its entry in a register through the whole run; the columns' values are final and
+      // read straight from LDS (broadcast reads) -- no cross-lane traffic, no store / fence between the blocks.  The
+      // updates of a row happen in the same order as block by block.
+      const bool eon = lane < e1 - e0;
+      const int erow = frow[e0 + (eon ? lane : 0)];
+      double esv     = t[erow];
+      for (int b = jb; b < jb + run; ++b) {
+        const int eb = ubig(foff[b]) + (eon ? lane : 0), c0 = b * kBW;
+        double fv[kBW], tt[kBW];
+#pragma unroll
+        for (int jj = 0; jj < kBW; ++jj) {
+          fv[jj] = fval[eb * kBP + jj];
+          tt[jj] = t[c0 + jj];  // (past K in the last block: whatever follows t in LDS, its fv is an exact zero and skipped)
+        }
+#pragma unroll
+        for (int jj = 0; jj < kBW; ++jj) {
+          const double nv = fma(-fv[jj], tt[jj], esv);
+          esv             = (eon && fv[jj] != 0.0) ? nv : esv;
+        }
+      }
+      if (eon) t[erow] = esv;
+      wave_lds_fence();
+      jb += run - 1;
+      continue;
+    }
     // everything the block needs is requested up front (one LDS / memory latency, not one per column): the diagonal
     // block, and the first 64 of the rows below it that have entries in the block
     if (!chain) {
@@ -566,7 +623,7 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
   double *cval = LDg + k;                                                                        // compact off-diagonal rows
   int *perm = reinterpret_cast<int *>(cval + rcap * kBP);
   int *fnz = perm + (k + 1) / 2 * 2, *bnz = fnz + ((k + kBW - 1) / kBW) * RB;
-  int *cidx = bnz + ((k + kBW - 1) / kBW) * RB, *cflag = cidx + 3 * ((k + kBW - 1) / kBW + 1) + rcap;
+  int *cidx = bnz + ((k + kBW - 1) / kBW) * RB, *cflag = cidx + 4 * ((k + kBW - 1) / kBW + 1) + rcap;
   BigWs w;
   {
     double *p = gws + b * wsd;
