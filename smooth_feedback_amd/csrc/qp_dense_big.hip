@@ -144,7 +144,7 @@ __host__ __device__ constexpr size_t big_lds_fixed_bytes(const int n, const int 
   const size_t tiles = ((k + 15) / 16) * rb;  // non-zero maps of the sweep tiles, forward and backward
   const size_t dcache = (diag_cache && k <= (size_t)kDiagCacheK) ? ((k + 15) / 16) * 16 * kBP : 0;
   return (4 * k + 2 * (size_t)n + 6 * (size_t)m + 8 + dcache) * sizeof(double) +
-         ((k + 1) / 2 * 2 + 2 * tiles + 4 * ((k + 15) / 16 + 1) + 4) * sizeof(int);
+         ((k + 1) / 2 * 2 + 2 * tiles + 5 * ((k + 15) / 16 + 1) + 4) * sizeof(int);
 }
 // `roomy`: few QPs in the launch (at most one wave per CU anyway): take what the lists of such a factor can need;
 // otherwise k + 64 rows, which keeps two or three waves per CU for batches (measured at (40, 60): 3 waves per CU with
@@ -193,12 +193,12 @@ __device__ inline void big_transpose(const int K, const double *__restrict__ W, 
   for (int i = 0; i < K; ++i)
     for (int j = lane; j < i; j += kWave) LT[(size_t)j * ld + i] = W[(size_t)i * ld + j];
   // cidx: [0, nb] forward block offsets, [nb + 1, 2 nb + 1] backward block offsets, nb flags "the diagonal block has
-  // entries below its diagonal", nb run lengths of the forward sweep (below), then the rows of the lists (forward lists
+  // entries below its diagonal", nb run lengths of the forward sweep and nb skip counts of the backward sweep (below), then the rows of the lists (forward lists
   // first, one pool of `cap` rows); cval: the rows' 16 values (stride kBP); cflag[0]: the lists are complete
   {
     const int nbk = (K + kBW - 1) / kBW;
     lds_i *const foff = cidx, *const boff = cidx + nbk + 1, *const dflag = boff + nbk + 1, *const frun = dflag + nbk,
-                 *const rows = frun + nbk;
+                 *const bskip = frun + nbk, *const rows = bskip + nbk;
     int np = 0;
     for (int dir = 0; dir < 2; ++dir) {
       lds_i *const off = dir ? boff : foff;
@@ -265,6 +265,16 @@ __device__ inline void big_transpose(const int K, const double *__restrict__ W, 
     } else {
       for (int jb = lane; jb < nbk; jb += kWave) frun[jb] = 0;
     }
+    // bskip[jb]: how many blocks jb, jb - 1, ... in a row the backward sweep has nothing to do for (no chain, nothing
+    // depends on them: the constraint columns of a safety filter) -- it jumps over them with one LDS read
+    {
+      int cnt = 0;
+      for (int jb = 0; jb < nbk; ++jb) {
+        const bool idle = np <= cap && ubig(dflag[jb]) == 0 && ubig(boff[jb]) == ubig(boff[jb + 1]);
+        cnt = idle ? cnt + 1 : 0;
+        if (lane == 0) bskip[jb] = cnt;
+      }
+    }
   }
   for (int i = lane; i < K; i += kWave) LDg[i] = W[(size_t)i * ld + i];
   if (dblk_ != nullptr) {  // dblk[jb][r][c] = L(16 jb + r, 16 jb + c), r > c (other entries 0)
@@ -297,7 +307,7 @@ __device__ inline void big_transpose(const int K, const double *__restrict__ W, 
 // the pivot travels by v_readlane), then every other row takes the block's 16 updates in the same ascending
 // (descending) order -- ONE memory round trip per block instead of one per column.  |d| <= DBL_MIN -> 0, true division.
 #ifdef SFB_BIG_PROF
-__device__ unsigned long long g_bigprof[8];
+__device__ unsigned long long g_bigprof[12];
 #define BP_T(x) const unsigned long long x = wall_clock64()
 #define BP_ADD(i, a, b) if (lane == 0 && blockIdx.x == 0) g_bigprof[i] += (b) - (a)
 #else
@@ -323,7 +333,7 @@ __device__ inline void big_solve(const int K, const double *__restrict__ W, cons
   const int nbk0    = (K + kBW - 1) / kBW;
   const bool compact = cflag[0] != 0;  // wave-uniform (LDS)
   const lds_i *const foff = cidx, *const boff = cidx + nbk0 + 1, *const dflag = boff + nbk0 + 1, *const frun = dflag + nbk0,
-                     *const frow = frun + nbk0, *const brow = frow;
+                     *const bskip = frun + nbk0, *const frow = bskip + nbk0, *const brow = frow;
   const lds_d *const fval = cval, *const bval = cval;
   BP_T(p0);
   for (int i = lane; i < K; i += kWave) temp[i] = t[perm[i]];
@@ -356,8 +366,9 @@ __device__ inline void big_solve(const int K, const double *__restrict__ W, cons
       const bool eon = lane < e1 - e0;
       const int erow = frow[e0 + (eon ? lane : 0)];
       double esv     = t[erow];
-      for (int b = jb; b < jb + run; ++b) {
-        const int eb = ubig(foff[b]) + (eon ? lane : 0), c0 = b * kBW;
+      const int cnt = e1 - e0;  // the lists of a run have the same length and follow each other in the pool
+      for (int b = jb, eb = e0 + (eon ? lane : 0); b < jb + run; ++b, eb += cnt) {
+        const int c0 = b * kBW;
         double fv[kBW], tt[kBW];
 #pragma unroll
         for (int jj = 0; jj < kBW; ++jj) {
@@ -367,7 +378,7 @@ __device__ inline void big_solve(const int K, const double *__restrict__ W, cons
 #pragma unroll
         for (int jj = 0; jj < kBW; ++jj) {
           const double nv = fma(-fv[jj], tt[jj], esv);
-          esv             = (eon && fv[jj] != 0.0) ? nv : esv;
+          esv             = (fv[jj] != 0.0) ? nv : esv;  // (lanes without a row compute on lane 0's data and store nothing)
         }
       }
       if (eon) t[erow] = esv;
@@ -468,15 +479,21 @@ __device__ inline void big_solve(const int K, const double *__restrict__ W, cons
     t[i]           = (fabs(d) > DBL_MIN) ? t[i] / d : 0.0;
   }
   wave_lds_fence();
+  BP_T(p3);
+  BP_ADD(4, p2, p3);
   // ---- backward ----
   for (int jb = nb - 1; jb >= 0; --jb) {
     const int j0 = jb * kBW, l0 = j0 % kWave, rb = j0 / kWave, nbw = (K - j0 < kBW) ? K - j0 : kBW;
     const bool inblk = lane >= l0 && lane < l0 + nbw;
     const int lrow   = inblk ? lane - l0 : 0, iblk = j0 + lrow, lcol = inblk ? lane - l0 : kBW - 1;
     double dv[kBW], tb[kBW];
+    if (const int idle = compact ? ubig(bskip[jb]) : 0; idle > 0) {
+      jb -= idle - 1;
+      continue;
+    }
     const int e0 = compact ? ubig(boff[jb]) : 0, e1 = compact ? ubig(boff[jb + 1]) : 0;
     const bool chain = !compact || ubig(dflag[jb]) != 0;
-    if (compact && !chain && e0 == e1) continue;
+    BP_T(r0);
     if (!chain) {
     } else if (dblk_ != nullptr) {  // (lanes outside the block read its last column: empty)
 #pragma unroll
@@ -555,7 +572,12 @@ __device__ inline void big_solve(const int K, const double *__restrict__ W, cons
       }
     }
     wave_lds_fence();
+    BP_T(r1);
+    BP_ADD(6, r0, r1);
+    BP_ADD(11, 0ull, 1ull);
   }
+  BP_T(p4);
+  BP_ADD(7, p3, p4);
   for (int i = lane; i < K; i += kWave) temp[perm[i]] = t[i];
   wave_sync();
   for (int i = lane; i < K; i += kWave) t[i] = temp[i];
@@ -623,7 +645,7 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
   double *cval = LDg + k;                                                                        // compact off-diagonal rows
   int *perm = reinterpret_cast<int *>(cval + rcap * kBP);
   int *fnz = perm + (k + 1) / 2 * 2, *bnz = fnz + ((k + kBW - 1) / kBW) * RB;
-  int *cidx = bnz + ((k + kBW - 1) / kBW) * RB, *cflag = cidx + 4 * ((k + kBW - 1) / kBW + 1) + rcap;
+  int *cidx = bnz + ((k + kBW - 1) / kBW) * RB, *cflag = cidx + 5 * ((k + kBW - 1) / kBW + 1) + rcap;
   BigWs w;
   {
     double *p = gws + b * wsd;
@@ -717,6 +739,7 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
   wave_sync();
 
   const unsigned long long t0_ticks = wall_clock64();  // :376
+  BP_T(u0);
   // ---- dense KKT fill :399-404 (row-major lower triangle of the k x k array H) ----
   for (int r = 0; r < n; ++r)
     for (int cc = lane; cc <= r; cc += kWave) {
@@ -733,9 +756,15 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
     if (lane == 0) w.H[(size_t)(n + i) * k + (n + i)] = 1.0 / (-w.rho[i]);
   }
   wave_sync();
+  BP_T(u1);
   if (!big_ldlt_factor(k, w.H, k, perm, temp, lane)) ret_code = SFB_QP_UNKNOWN;  // :428-433
+  BP_T(u2);
   const bool dcache = k <= dck;
   big_transpose<RB>(k, w.H, k, w.LT, w.Dg, fnz, bnz, dcache ? dblk : nullptr, LDg, cidx, cval, cflag, rcap, lane);
+  BP_T(u3);
+  BP_ADD(8, u0, u1);
+  BP_ADD(9, u1, u2);
+  BP_ADD(10, u2, u3);
 
   // ---- initial iterate :436-445 ----
   if (g.wx != nullptr) {
@@ -882,9 +911,9 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
 
 #ifdef SFB_BIG_PROF
   if (lane == 0 && blockIdx.x == 0) {
-    printf("bigprof iters %u compact %d | x10ns: perm-in %llu forward %llu (chains %llu rest %llu) solve %llu loop %llu\n", iter, cflag[0],
-           g_bigprof[0], g_bigprof[1], g_bigprof[2], g_bigprof[3], g_bigprof[5], wall_clock64() - t0_ticks);
-    for (int i = 0; i < 8; ++i) g_bigprof[i] = 0;
+    printf("bigprof iters %u compact %d | x10ns: perm-in %llu forward %llu (chains %llu rest %llu) solve %llu loop %llu | kkt fill %llu ldlt %llu transpose+lists %llu | D %llu backward %llu (executed blocks %llu: %llu)\n", iter, cflag[0],
+           g_bigprof[0], g_bigprof[1], g_bigprof[2], g_bigprof[3], g_bigprof[5], wall_clock64() - t0_ticks, g_bigprof[8], g_bigprof[9], g_bigprof[10], g_bigprof[4], g_bigprof[7], g_bigprof[11], g_bigprof[6]);
+    for (int i = 0; i < 12; ++i) g_bigprof[i] = 0;
   }
 #endif
   // ---- polish :92-204, :515-539 (on the scaled iterate; a failed factorisation leaves the ADMM solution) ----
