@@ -58,11 +58,18 @@ __device__ __forceinline__ int wave_min_index(const int cand)
 // update, strided ones in the row swaps of the pivoting -- is no faster for one QP and mixed for batches: +30 % for the
 // safety-filter shape (3, 203), -5 % for (100, 156).)  perm[K] (LDS): composed transpositions, (P b)[i] = b[perm[i]].
 // temp[K] (LDS) scratch.  Returns 1 on success, 0 on failure (info() == NumericalIssue).  Wave-uniform.
-__device__ inline int big_ldlt_factor(const int K, double *__restrict__ W, const int ld, int *perm_, double *temp_,
+// nzj[K] (LDS, ints) scratch: per column the indices j with temp(j) != 0.  A zero temp(j) adds row(j) * 0 = +-0 to the
+// dot product of every row, which leaves it unchanged as long as row(j) is finite (the running sum is never -0: it
+// starts at +0) -- so while every entry of L computed so far is finite (checked as the entries are written), the dot
+// products run over the non-zero terms only, in the same order.  A safety filter's constraint columns have no non-zero
+// term at all: their update vanishes.  Once a non-finite entry appears the full loops run again.
+__device__ inline int big_ldlt_factor(const int K, double *__restrict__ W, const int ld, int *perm_, double *temp_, int *nzj_,
                                       const int lane)
 {
   LDS_I(perm, perm_);
   LDS_D(temp, temp_);
+  LDS_I(nzj, nzj_);
+  bool all_finite = true;  // wave-uniform: every entry of columns < kk (rows below the diagonal) and their pivots
 #define WB(i, j) W[(size_t)(i) * (size_t)ld + (size_t)(j)]
   for (int i = lane; i < K; i += kWave) perm[i] = i;
   wave_sync();
@@ -93,14 +100,33 @@ __device__ inline int big_ldlt_factor(const int K, double *__restrict__ W, const
       }
       wave_sync();
     }
-    // temp(j) = D(j) * L(kk, j), j < kk
-    for (int j = lane; j < kk; j += kWave) temp[j] = WB(j, j) * WB(kk, j);
+    // temp(j) = D(j) * L(kk, j), j < kk (and the list of its non-zero entries)
+    int nn = 0;
+    for (int j0 = 0; j0 < kk; j0 += kWave) {
+      const int j    = j0 + lane;
+      const double v = (j < kk) ? WB(j, j) * WB(kk, j) : 0.0;
+      if (j < kk) temp[j] = v;
+      const unsigned long long mk = wave_ballot(j < kk && v != 0.0);
+      if (j < kk && v != 0.0) nzj[nn + __popcll(mk & lanemask_lt(lane))] = j;
+      nn += __popcll(mk);
+    }
     wave_sync();
-    if (kk > 0) {
+    if (kk > 0 && (!all_finite || 2 * nn > kk)) {  // (mostly non-zero terms: the plain loop streams better than the indexed one)
       for (int i = kk + lane; i < K; i += kWave) {  // rows kk (the diagonal) .. K-1: dot, then subtract
         const double *row = &WB(i, 0);
         double s          = 0.0;
         for (int j = 0; j < kk; ++j) s = fma(row[j], temp[j], s);
+        WB(i, kk) -= s;
+      }
+      wave_sync();
+    } else if (nn > 0) {
+      for (int i = kk + lane; i < K; i += kWave) {
+        const double *row = &WB(i, 0);
+        double s          = 0.0;
+        for (int q = 0; q < nn; ++q) {
+          const int j = nzj[q];
+          s           = fma(row[j], temp[j], s);
+        }
         WB(i, kk) -= s;
       }
       wave_sync();
@@ -113,11 +139,18 @@ __device__ inline int big_ldlt_factor(const int K, double *__restrict__ W, const
         for (int j = 0; j < i; ++j) nz = nz || !(WB(i, j) == 0.0);
       return wave_ballot(nz) ? 0 : 1;
     }
-    bool nzcol = false;
+    bool nzcol = false, fin = fabs(akk) < INFINITY;
     for (int i = kk + 1 + lane; i < K; i += kWave) {
-      if (valid) WB(i, kk) /= akk;
-      else nzcol = nzcol || !(WB(i, kk) == 0.0);
+      double v = WB(i, kk);
+      if (valid) {
+        v /= akk;
+        WB(i, kk) = v;
+      } else {
+        nzcol = nzcol || !(v == 0.0);
+      }
+      fin = fin && fabs(v) < INFINITY;
     }
+    if (all_finite && wave_ballot(!fin)) all_finite = false;
     if (!valid && wave_ballot(nzcol)) ret = 0;
     if (found_zero && valid) ret = 0;
     else if (!valid) found_zero = 1;
@@ -757,7 +790,7 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
   }
   wave_sync();
   BP_T(u1);
-  if (!big_ldlt_factor(k, w.H, k, perm, temp, lane)) ret_code = SFB_QP_UNKNOWN;  // :428-433
+  if (!big_ldlt_factor(k, w.H, k, perm, temp, reinterpret_cast<int *>(t), lane)) ret_code = SFB_QP_UNKNOWN;  // :428-433
   BP_T(u2);
   const bool dcache = k <= dck;
   big_transpose<RB>(k, w.H, k, w.LT, w.Dg, fnz, bnz, dcache ? dblk : nullptr, LDg, cidx, cval, cflag, rcap, lane);
@@ -973,7 +1006,7 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
     }
     for (int e = lane; e < K; e += kWave) aux[e] = 0.0;  // aux = t of the refinement
     wave_sync();
-    if (big_ldlt_factor(K, Hp, K, perm, temp, lane)) {
+    if (big_ldlt_factor(K, Hp, K, perm, temp, reinterpret_cast<int *>(t), lane)) {
       big_transpose<RB>(K, Hp, K, w.LT, w.Dg, fnz, bnz, dcache ? dblk : nullptr, LDg, cidx, cval, cflag, rcap, lane);
       for (uint32_t it = 0; it != kp.polish_iter; ++it) {  // :193-195  t += Hp^-1 (h - Hs t)
         for (int i = lane; i < K; i += kWave) {
