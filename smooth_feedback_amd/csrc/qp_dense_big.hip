@@ -334,7 +334,8 @@ __device__ inline void big_transpose(const int K, const double *__restrict__ W, 
   wave_sync();
 }
 
-// LDLT::_solve_impl == oracle_ldlt_solve: t (LDS, K entries, original order) <- P^T L^-T D^-1 L^-1 P t.
+// LDLT::_solve_impl == oracle_ldlt_solve: temp (LDS, K entries, original order) <- P^T L^-T D^-1 L^-1 P temp; t (LDS, K
+// entries) is the permuted work vector -- the two permutations are the copies between them.
 // Per row the oracle subtracts L(i, j) t_j for j ascending (forward) / L(j, i) t_j for j descending (backward); here
 // the columns come in BLOCKS of 16: the 16 rows of the diagonal block are finished first (in registers: lane = row,
 // the pivot travels by v_readlane), then every other row takes the block's 16 updates in the same ascending
@@ -369,9 +370,7 @@ __device__ inline void big_solve(const int K, const double *__restrict__ W, cons
                      *const bskip = frun + nbk0, *const frow = bskip + nbk0, *const brow = frow;
   const lds_d *const fval = cval, *const bval = cval;
   BP_T(p0);
-  for (int i = lane; i < K; i += kWave) temp[i] = t[perm[i]];
-  wave_sync();
-  for (int i = lane; i < K; i += kWave) t[i] = temp[i];
+  for (int i = lane; i < K; i += kWave) t[i] = temp[perm[i]];  // the right-hand side comes in temp (natural order)
   wave_sync();
   const int nb = (K + kBW - 1) / kBW;
   BP_T(p1);
@@ -611,9 +610,7 @@ __device__ inline void big_solve(const int K, const double *__restrict__ W, cons
   }
   BP_T(p4);
   BP_ADD(7, p3, p4);
-  for (int i = lane; i < K; i += kWave) temp[perm[i]] = t[i];
-  wave_sync();
-  for (int i = lane; i < K; i += kWave) t[i] = temp[i];
+  for (int i = lane; i < K; i += kWave) temp[perm[i]] = t[i];  // ... and the solution leaves in temp (natural order)
   wave_sync();
 }
 
@@ -843,8 +840,8 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
   const uint32_t sci   = kp.stop_check_iter;
   const uint32_t maxit = kp.max_iter;
   for (; iter != maxit && ret_code < 0; ++iter) {
-    for (int j = lane; j < n; j += kWave) t[j] = kp.sigma * xs[j] - Lqc[j];                  // :450
-    for (int i = lane; i < m; i += kWave) t[n + i] = zs[i] - Lrinv[i] * ys[i];              // :451
+    for (int j = lane; j < n; j += kWave) temp[j] = kp.sigma * xs[j] - Lqc[j];               // :450
+    for (int i = lane; i < m; i += kWave) temp[n + i] = zs[i] - Lrinv[i] * ys[i];           // :451
     wave_sync();
     BP_T(s0);
     big_solve<RB>(k, w.H, w.LT, w.Dg, k, perm, fnz, bnz, dcache ? dblk : nullptr, LDg, cidx, cval, cflag, t, temp, lane);  // :462
@@ -852,7 +849,7 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
     BP_ADD(5, s0, s1);
     const bool chk = (sci != 0) && (iter % sci == 1);                                       // :465
     for (int j = lane; j < n; j += kWave) {                                                 // :470
-      const double xo = xs[j], xn = kp.alpha * t[j] + kp.alpha_comp * xo;
+      const double xo = xs[j], xn = kp.alpha * temp[j] + kp.alpha_comp * xo;
       xs[j] = xn;
       if (chk) {
         w.xus[j]  = w.sx[j] * xn;
@@ -860,7 +857,7 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
       }
     }
     for (int i = lane; i < m; i += kWave) {                                                 // :471-477
-      const double ri = Lrinv[i], rh = Lrho[i], yo = ys[i], zo = zs[i], nu = t[n + i];
+      const double ri = Lrinv[i], rh = Lrho[i], yo = ys[i], zo = zs[i], nu = temp[n + i];
       double zn = kp.alpha * (ri * nu) + kp.alpha_comp * (ri * yo) + zo;
       zn        = (zn < Llo[i]) ? Llo[i] : zn;
       zn        = (Lhi[i] < zn) ? Lhi[i] : zn;
@@ -1012,11 +1009,11 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
         for (int i = lane; i < K; i += kWave) {
           double s = 0.0;
           for (int j = 0; j < K; ++j) s = fma(Hs[(size_t)j * K + i], aux[j], s);  // (Hs is symmetric: column i == row i)
-          t[i] = ((i < n) ? w.hx[i] : w.Ax[i - n]) - s;
+          temp[i] = ((i < n) ? w.hx[i] : w.Ax[i - n]) - s;
         }
         wave_sync();
         big_solve<RB>(K, Hp, w.LT, w.Dg, K, perm, fnz, bnz, dcache ? dblk : nullptr, LDg, cidx, cval, cflag, t, temp, lane);
-        for (int i = lane; i < K; i += kWave) aux[i] += t[i];
+        for (int i = lane; i < K; i += kWave) aux[i] += temp[i];
         wave_sync();
       }
       for (int j = lane; j < n; j += kWave) xs[j] = aux[j];  // :199
