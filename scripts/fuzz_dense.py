@@ -20,8 +20,16 @@ def main():
       n = int(rng.integers(1, 14)); m = int(rng.integers(1, 24))
       if rng.random() < 0.15: n, m = int(rng.integers(20, 30)), int(rng.integers(20, 36))      # one-per-wave sizes
       if rng.random() < 0.05: n, m = int(rng.integers(3, 40)), int(rng.integers(62, 90))       # big kernel
-      B = int(rng.integers(1, 40))
+      if os.environ.get("BIG") == "1":                                                           # big kernel only: filter shapes, block-structured A
+          n, m = int(rng.integers(1, 6)), int(rng.integers(64, 330))
+          if rng.random() < 0.3: n, m = int(rng.integers(6, 60)), int(rng.integers(60, 200))
+      B = int(rng.integers(1, 40 if os.environ.get("BIG") != "1" else 6))
       P, q, A, l, u = sfb.random_qp_batch(int(rng.integers(1, 10**6)), B, m, n, float(rng.choice([0.1, 0.5, 1.0])))
+      if os.environ.get("BIG") == "1" and rng.random() < 0.5:   # rows that touch one variable only / empty rows: long chain-free runs
+          Am = A.reshape(B, n, m).copy()
+          keepv = rng.integers(0, n, m)
+          for j in range(n): Am[:, j, :] *= (keepv == j) | (rng.random(m) < 0.2)
+          A = np.ascontiguousarray(Am.reshape(B, -1))
       mask = rng.random((B, m))
       l = np.where(mask < 0.15, -np.inf, l); u = np.where((mask > 0.15) & (mask < 0.3), np.inf, u)
       l = np.where(mask > 0.9, u, l)                       # equalities
