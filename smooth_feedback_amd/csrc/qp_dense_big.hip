@@ -22,6 +22,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 #include "../../include/sfb.h"
 #include "qp_dense_kernel.h"
@@ -187,7 +188,13 @@ __host__ __device__ constexpr int big_row_cap(const int n, const int m, const bo
 {
   const size_t budget = 158 * 1024, fixed = big_lds_fixed_bytes(n, m, diag_cache), per_row = kBP * sizeof(double) + sizeof(int);
   const size_t k = (size_t)n + m, fit = budget > fixed ? (budget - fixed) / per_row : 0;
-  const size_t want = roomy ? 2 * k + 64 : (k <= (size_t)kDiagCacheK ? k + 64 : 192);
+  // rows a completely dense factor puts into the lists (every row below / left of each 16-column block, both sweeps):
+  // a lone QP of up to k = 128 keeps even that on chip
+  const size_t nb = (k + 15) / 16;
+  size_t dense_rows = 0;
+  for (size_t jb = 0; jb < nb; ++jb) dense_rows += (k > 16 * (jb + 1) ? k - 16 * (jb + 1) : 0) + 16 * jb;
+  const size_t roomy_want = dense_rows > 2 * k + 64 ? dense_rows : 2 * k + 64;
+  const size_t want = roomy ? roomy_want : (k <= (size_t)kDiagCacheK ? k + 64 : 192);
   size_t cap        = fit < want ? fit : want;
   if (cap < 64) cap = 64;
   if (!roomy) {
@@ -640,12 +647,14 @@ struct BigLds { bool diag_cache; int rcap; size_t bytes; };
 static BigLds big_lds_config(int n, int m, int64_t batch)
 {
   const size_t per_row = kBP * sizeof(double) + sizeof(int), cu = 160 * 1024;
+  static const bool force_roomy = [] { const char *v = getenv("SFB_BIG_ROOMY"); return v && v[0] == '1'; }();  // A/B knob
+  const bool roomy = batch < kRoomyBatch || force_roomy;
   auto make = [&](bool dc) {
-    const int rc = big_row_cap(n, m, batch < kRoomyBatch, dc);
+    const int rc = big_row_cap(n, m, roomy, dc);
     return BigLds{dc, rc, big_lds_fixed_bytes(n, m, dc) + (size_t)rc * per_row};
   };
   const BigLds with = make(true);
-  if (batch < kRoomyBatch || n + m > kDiagCacheK) return with;
+  if (roomy || n + m > kDiagCacheK) return with;
   const BigLds without = make(false);
   // measured (scripts/dense_big_time.py): a second resident block is worth the cache ((4, 301): 2.8 -> 3.7 k QP/s), a third
   // or later one is not ((3, 203): 23.9 k QP/s with the cache and 2 blocks, 13.7 k without it and 3)
