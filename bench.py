@@ -32,6 +32,32 @@ import torch  # noqa: E402
 HBM_PEAK_BYTES_PER_S = 8.0e12  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def host_cpus():
+    """What this process may really use of the host: the scheduler affinity mask and the cgroup CPU quota, not the
+    number of CPUs the machine has (os.cpu_count()).  Returns (threads to use, description for the bench line)."""
+    logical = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = logical
+    quota = None
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),                       # cgroup v2: "max 100000" / "800000 100000"
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), None])):  # cgroup v1
+        try:
+            with open(path) as f:
+                a, b = parse(f.read())
+            if b is None:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    b = f.read().strip()
+            if a not in ("max", "-1"):
+                quota = float(a) / float(b)
+            break
+        except (OSError, ValueError):
+            continue
+    usable = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
+    return usable, {"os_cpu_count": logical, "sched_affinity": affinity, "cgroup_cpu_quota": quota, "threads_used": usable}
+
+
 def qp_dense_algorithmic_bytes(n, m):
     """P,q,A,l,u in; x,y,obj,iter,code out."""
     return 8 * (n * n + n + m * n + 2 * m) + 8 * (n + m + 1) + 8
@@ -139,7 +165,9 @@ class MPCWorkload:
         self.d, self.pat = d, (Pp, Pi, Pv, Ap, Aj)
         self.name = "mpc_qp_nx%d_nu%d_K%d_b%d_default_qp_params" % (d["Nx"], d["Nu"], K, batch)
         t0 = time.perf_counter()
-        Av, l, u = M.mpc_assemble_batch(variant, K, batch, seed=1000003 * rank + 3, threads=os.cpu_count() or 8)
+        # host assembly threads: this rank's share of the CPUs the job may use (N ranks on one node share them)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        Av, l, u = M.mpc_assemble_batch(variant, K, batch, seed=1000003 * rank + 3, threads=max(1, host_cpus()[0] // max(1, local_world)))
         self.host_assembly_s = time.perf_counter() - t0
         # Structure probe, as the C++ front does (MPCSwarm::step): stored entries of A that are zero in a sample of the
         # batch are declared explicit zeros (ocp_to_qp writes dense Jacobian blocks) and left out of the analysis;
@@ -413,7 +441,9 @@ def secondary_line(sfb, workload, device, steps=3):
         rec["workload_stats"] = wl.extra()
     if hasattr(wl, "roofline_alt"):
         rec["roofline_alt"] = wl.roofline_alt(kern_ms)
-    rec["cpu_baseline"], rec["parity_vs_oracle"] = wl.cpu_baseline(os.cpu_count() or 1, budget_s=4.0)
+    cores, cpuinfo = host_cpus()
+    rec["cpu_baseline"], rec["parity_vs_oracle"] = wl.cpu_baseline(cores, budget_s=4.0)
+    rec["cpu_baseline"]["host"] = cpuinfo
     return rec
 
 
@@ -489,10 +519,22 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     gather_check = None
-    if world > 1:  # the gathered rows: this rank's own came back unchanged, every peer sent something
+    if world > 1:
+        # What came out of the gather, checked against an independent path: every rank puts an exact (integer,
+        # wrap-around) checksum of ITS rows into its slot of a vector that is summed over the ranks with an all_reduce;
+        # the rows received from rank r must reproduce rank r's checksum.  Shards come from different seeds, so a
+        # peer's rows must also differ from this rank's own.
+        def checksum(tns):
+            return tns.contiguous().view(torch.int32).to(torch.int64).sum()
         own = wl.small_outputs()
+        cs = torch.zeros(world, dtype=torch.int64, device=device)
+        cs[rank] = checksum(own)
+        dist.all_reduce(cs, op=dist.ReduceOp.SUM)
+        peers = [r for r in range(world) if r != rank]
         gather_check = {"own_rows_intact": bool(torch.equal(gathered[rank], own)),
-                        "peer_rows_received": all(bool((gathered[r] != 0).any()) for r in range(world) if r != rank)}
+                        "peer_rows_received": all(bool(checksum(gathered[r]) == cs[r]) for r in peers),
+                        "peer_rows_differ_from_own": all(not bool(torch.equal(gathered[r], own)) for r in peers),
+                        "ranks_checked": world}
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -532,8 +574,14 @@ def main():
         if world == 1 and hasattr(wl, "pipelined") and not args.no_pipelined:
             rec["pipelined"] = wl.pipelined(max(4, 2 * args.steps))
         if not args.no_cpu_baseline and world == 1:
-            cores = os.cpu_count() or 1
+            cores, cpuinfo = host_cpus()
             rec["cpu_baseline"], rec["parity_vs_oracle"] = wl.cpu_baseline(cores)
+            # `cores` = threads the oracle was run with = CPUs this process may use (affinity mask, cgroup quota), which
+            # can be far fewer than the machine's logical CPUs; single_core next to it shows the scaling that was real
+            rec["cpu_baseline"]["host"] = cpuinfo
+            sc = rec["cpu_baseline"].get("single_core")
+            if sc and sc.get("value"):
+                rec["cpu_baseline"]["speedup_over_single_core"] = rec["cpu_baseline"]["value"] / sc["value"]
         if world == 1 and not args.no_secondary and not args.no_cpu_baseline and args.batch is None:
             del wl  # free the headline workload's device memory first
             torch.cuda.empty_cache()

@@ -319,6 +319,42 @@ int sfbx_test_qp_solver_api(double * primal_dense, double * primal_sparse, doubl
   }
 }
 
+int sfbx_test_solve_after_solve_batch(double * out)
+{
+  // solve(A1) -> solve_batch(B = 1, A2) -> solve(A1): the batch call shares the plan's device workspace with solve(), so
+  // the third call must NOT vouch for the factor of the first (reuse_factor) although it sees the same matrices again.
+  // Scaling off: c = 1 for both problems, i.e. the kernel's own re-check of c cannot tell them apart.
+  try {
+    QuadraticProgramSparse<> sp;
+    sp.n = 2; sp.m = 2;
+    sp.P_colptr = {0, 1, 2}; sp.P_rowind = {0, 1}; sp.P_val = {1.0, 2.0};
+    sp.A_rowptr = {0, 2, 3}; sp.A_colind = {0, 1, 0}; sp.A_val = {1.0, 1.0, 1.0};
+    sp.q = {-1.0, -1.0}; sp.l = {-0.5, -0.25}; sp.u = {0.5, 0.25};
+    QPSolverParams prm;
+    prm.scaling = false; prm.polish = false;
+    SparseQPSolver solver(sp, prm);
+    const auto first = solver.solve(sp);
+    const int64_t reuse0 = solver.factor_reuse_count();
+    auto other = sp;
+    other.A_val = {3.0, -2.0, 0.5};
+    double x[2], y[2], obj;
+    uint32_t it;
+    int32_t code;
+    solver.solve_batch(1, other.P_val.data(), other.q.data(), other.A_val.data(), other.l.data(), other.u.data(), nullptr, nullptr,
+                       x, y, &obj, &it, &code);
+    const auto third = solver.solve(sp);
+    out[0] = (third.primal == first.primal && third.dual == first.dual && third.iter == first.iter && third.code == first.code) ? 1.0 : 0.0;
+    out[1] = double(solver.factor_reuse_count() - reuse0);  // 0: the third call was not flagged
+    const auto fourth = solver.solve(sp);                    // now the previous call on the workspace WAS solve(sp)
+    out[2] = double(solver.factor_reuse_count() - reuse0);  // 1
+    out[3] = (fourth.primal == first.primal && fourth.iter == first.iter) ? 1.0 : 0.0;
+    out[4] = first.primal[0]; out[5] = first.primal[1]; out[6] = x[0]; out[7] = x[1];
+    return 0;
+  } catch (const std::exception &) {
+    return -1;
+  }
+}
+
 int sfbx_test_ocp_to_qp_basic(double * out, int solve)
 {
   // tests/test_ocp_to_qp.cpp:41-107 (OcpToQp.Basic) with the generic front, through the reference's include path:
@@ -474,6 +510,77 @@ int sfbx_test_mpc_doubleintegrator(int ticks, double * u_out, uint32_t * iters, 
     std::fprintf(stderr, "sfbx_test_mpc_doubleintegrator: %s\n", e.what());
     return -1;
   }
+}
+
+int sfbx_test_mpc_time_and_setters(double * out)
+{
+  // (1) set_xdes_rel / set_udes_rel (mpc.hpp:539-586) against the absolute-time setters, Time = double
+  using sfbx::VehicleModel6;
+  const VehicleModel6 mdl{};
+  MPCParams p;
+  p.K = 10; p.tf = 2.5;
+  const double t0 = 0.75, t = 1.3;
+  MPC6 a(mdl.f, mdl.cr, {-0.5, -0.5}, {0.5, 0.5}, p), b(mdl.f, mdl.cr, {-0.5, -0.5}, {0.5, 0.5}, p);
+  a.set_xdes([mdl, t0](double ta) { return mdl.xdes(ta - t0); }, [mdl, t0](double ta) { return mdl.dxdes(ta - t0); });
+  a.set_udes([mdl, t0](double ta) { return mdl.udes(ta - t0); });
+  b.set_xdes_rel([mdl](double tr) { return mdl.xdes(tr); }, t0);  // velocity by central differences
+  b.set_udes_rel([mdl](double tr) { return mdl.udes(tr); }, t0);
+  const X6 x = perturbed(mdl.xdes(t - t0), 17);
+  const int nA = (int)a.qp().A_val.size(), m = a.qp().m;
+  std::vector<double> Aa(nA), la(m), ua(m), Ab(nA), lb(m), ub(m);
+  a.assemble(t, x, Aa.data(), la.data(), ua.data());
+  b.assemble(t, x, Ab.data(), lb.data(), ub.data());
+  double d = 0;
+  for (int e = 0; e < nA; ++e) d = std::max(d, std::fabs(Aa[e] - Ab[e]));
+  for (int e = 0; e < m; ++e) d = std::max({d, std::fabs(la[e] - lb[e]), std::fabs(ua[e] - ub[e])});
+  out[0] = d;  // finite-difference velocity vs the analytic one: ~1e-9
+  // (2) the Time concept (time.hpp:25-89): the same controller on a std::chrono clock
+  using Clock = std::chrono::steady_clock;
+  using TP    = Clock::time_point;
+  using MPC6c = MPC<X6, U2, 2, VehicleDyn6, sfbx::InputBox<X6>, 4, TP>;
+  static_assert(Time<TP> && Time<std::chrono::nanoseconds> && Time<double>);
+  const TP epoch = TP{} + std::chrono::hours(1000);
+  MPC6c c(mdl.f, mdl.cr, {-0.5, -0.5}, {0.5, 0.5}, p);
+  c.set_xdes_rel([mdl](double tr) { return mdl.xdes(tr); }, time_trait<TP>::plus(epoch, t0));
+  c.set_udes_rel([mdl](double tr) { return mdl.udes(tr); }, time_trait<TP>::plus(epoch, t0));
+  std::vector<double> Ac(nA), lc(m), uc(m);
+  c.assemble(time_trait<TP>::plus(epoch, t), x, Ac.data(), lc.data(), uc.data());
+  d = 0;
+  for (int e = 0; e < nA; ++e) d = std::max(d, std::fabs(Ac[e] - Ab[e]));
+  for (int e = 0; e < m; ++e) d = std::max({d, std::fabs(lc[e] - lb[e]), std::fabs(uc[e] - ub[e])});
+  out[1] = d;  // nanosecond clock resolution against double seconds: ~1e-8
+  // (3) set_weights (mpc.hpp:593-598): stored, and -- as in the reference at v1 -- not transcribed into P
+  const std::vector<double> P0 = a.qp().P_val;
+  MPCWeights<X6, U2> w;
+  w.Q(0, 0) = 7.0; w.R(1, 1) = 3.0; w.Qtf(2, 2) = 5.0;
+  a.set_weights(w);
+  out[2] = (a.qp().P_val == P0) ? 1.0 : 0.0;
+  out[3] = (a.weights().Q(0, 0) == 7.0 && a.weights().R(1, 1) == 3.0 && a.weights().Qtf(2, 2) == 5.0) ? 1.0 : 0.0;
+  MPC6 wctor(mdl.f, mdl.cr, {-0.5, -0.5}, {0.5, 0.5}, p, w);  // the constructor is what transcribes weights
+  out[4] = (wctor.qp().P_val != P0) ? 1.0 : 0.0;
+  // (4) a new desired trajectory after the analysis: looked at lazily, re-analysed only when it leaves the analysed
+  //     structure, never while a device-resident swarm pins the plan (the symbolic analysis is host code: no GPU)
+  std::vector<uint8_t> keep;
+  b.probe_default(t, keep);
+  b.analyze_solver(&keep);
+  const sfb_sparse_qp_plan * plan0 = b.solver().plan();
+  b.set_udes_rel([mdl](double tr) { return mdl.udes(tr); }, t0 + 0.1);  // same structure
+  b.refresh_structure(t);
+  out[5] = (b.solver().plan() == plan0) ? 1.0 : 0.0;
+  // a trajectory with another structure: a straight line along x leaves the SE2 adjoint block emptier / other entries
+  b.set_xdes([](double ta) { X6 g; g.part<0>() = SE2{0.3 * ta, 1.0, 1.0, 0.0}; g.part<1>().v = {0.3, 0.0, 0.0}; return g; },
+             [](double) { return Vec<6>{0.3, 0, 0, 0, 0, 0}; });
+  b.solver().pin_plan();
+  b.refresh_structure(t);
+  out[6] = (b.solver().plan() == plan0) ? 1.0 : 0.0;  // pinned: untouched
+  bool threw = false;
+  try { b.solver().reset(); } catch (const std::logic_error &) { threw = true; }
+  out[7] = threw ? 1.0 : 0.0;
+  b.solver().unpin_plan();
+  b.set_udes_rel([mdl](double tr) { return mdl.udes(tr); }, t0);  // marks the structure dirty again
+  b.refresh_structure(t);
+  out[8] = b.solver().analyzed() ? 1.0 : 0.0;  // still analysed (same plan or a new one that covers both structures)
+  return 0;
 }
 
 int sfbx_test_mpc_se2(double * u_out, int32_t * codes, int32_t * traj_sizes)

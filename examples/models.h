@@ -23,6 +23,11 @@ int sfbx_mpc_assemble_batch(int variant, int K, double tf, int64_t batch, uint64
 /* Closed loop of tests/test_mpc.cpp:34-117 (SE2 state, R2 input, f = (u0, 0, u1), -1 <= u <= 1):
  * three consecutive MPC calls with warm start, then three without. u_out[6][2], codes[6]. Needs a GPU. */
 int sfbx_test_mpc_se2(double *u_out, int32_t *codes, int32_t *traj_sizes);
+/* MPC API beyond operator(): out[0] set_xdes_rel / set_udes_rel (mpc.hpp:539-586) vs the absolute-time setters (max abs
+ * difference of A, l, u), out[1] the same controller with Time = std::chrono::steady_clock::time_point (time.hpp:25-89),
+ * out[2..4] set_weights (mpc.hpp:593-598: stored, not transcribed; the constructor transcribes), out[5..8] lazy structure
+ * refresh after set_xdes / set_udes and plan pinning (1.0 = as specified).  Host only (no GPU). */
+int sfbx_test_mpc_time_and_setters(double *out);
 /* examples/mpc_doubleintegrator.cpp:31-101 in closed loop for `ticks` ticks of 50 ms (time-invariant QP matrices: the
  * solver front flags every tick after the first as reuse_factor), then the same loop with the reuse switched off:
  * u_out / iters / codes [ticks] and u_ref / iters_ref [ticks]; reuse_count = flagged solves of the first loop;
@@ -42,6 +47,10 @@ int sfbx_test_ocp_to_qp_parabola(double *out);
  * namespace: primal_dense / primal_sparse [5][2] = the five solvers' primal (original, copy, copy-assigned, moved,
  * move-assigned); primal_partial = {x0, x1, objective, hot-start x0, x1}.  Returns 0 on success.  Needs a GPU. */
 int sfbx_test_qp_solver_api(double *primal_dense, double *primal_sparse, double *primal_partial);
+/* QPSolver<sparse>: solve(A1), solve_batch(A2), solve(A1), solve(A1) on one solver (shared device workspace): out[0] third
+ * == first bit for bit, out[1] / out[2] solves flagged reuse_factor after the third / fourth call (0 / 1), out[3] fourth
+ * == first, out[4..7] primal of first and of the batch call.  Needs a GPU. */
+int sfbx_test_solve_after_solve_batch(double *out);
 /* Swarm tick through MPCSwarm (host assembly + one batched GPU solve): returns u0 [batch][2], codes. */
 int sfbx_mpc_swarm_step(int variant, int K, double tf, int64_t batch, uint64_t seed, int ticks, double *u0,
                         int32_t *codes, uint32_t *iters);

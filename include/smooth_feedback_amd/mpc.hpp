@@ -7,11 +7,12 @@
 //   ocp_to_qp_update_dyn      :198-276
 //   ocp_to_qp_update_cr       :279-323
 //   ocp_to_qp_update_ce       :326-373 with MPCCE (mpc.hpp:275-302)
-// Deviations, all on the host: time is a double (seconds) instead of a chrono-like T; Jacobians of
-// user functions are analytic when the functor has `jacobian(...)`, else forward differences with
-// step sqrt(eps) (the reference's default without the autodiff header); weights are taken at
-// construction (in reference v1 set_weights() never reaches the QP: cost is transcribed only in
-// the constructor, mpc.hpp:423 vs :593-598).
+// Deviations, all on the host: Jacobians of user functions are analytic when the functor has
+// `jacobian(...)`, else forward differences with step sqrt(eps) (the reference's default without the
+// autodiff header).  Time is the trailing template parameter T (any type with a time_trait, time.hpp:
+// double seconds by default, std::chrono time points / durations as in the reference's time.hpp:25-89).
+// set_weights() stores the weights like the reference does and, like the reference at v1, does NOT
+// re-transcribe the cost: P is built once in the constructor (mpc.hpp:423 vs :593-598).
 #pragma once
 #include <cstdlib>
 #include <cstdio>
@@ -30,6 +31,7 @@
 #include "lie.hpp"
 #include "mesh.hpp"
 #include "qp.hpp"
+#include "time.hpp"
 
 namespace smooth_feedback_amd {
 
@@ -80,47 +82,83 @@ struct MPCWeights {
   Mat<U::Dof, U::Dof> R   = Mat<U::Dof, U::Dof>::Identity();
 };
 
-template<class X, class U, int Ncr_, class F, class CR, int Kmesh = 4>
+template<class X, class U, int Ncr_, class F, class CR, int Kmesh = 4, Time T = double>
 class MPC {
 public:
   static constexpr int Nx = X::Dof, Nu = U::Dof, Ncr = Ncr_;
   using TangentX = Vec<Nx>;
+  using TimeT    = T;
+  /// absolute time t plus a horizon offset in seconds
+  static T tplus(const T & t, double s) { return time_trait<T>::plus(t, s); }
 
   MPC(F f, CR cr, Vec<Ncr> crl, Vec<Ncr> cru, MPCParams prm = {}, MPCWeights<X, U> w = {})
       : f_(std::move(f)), cr_(std::move(cr)), crl_(crl), cru_(cru), prm_(std::move(prm)),
-        mesh_(int((prm_.K + Kmesh - 1) / Kmesh), Kmesh), solver_(std::make_shared<SparseQPSolver>(prm_.qp))
+        mesh_(int((prm_.K + Kmesh - 1) / Kmesh), Kmesh), solver_(std::make_shared<SparseQPSolver>(prm_.qp)), weights_(w)
   {
-    xdes_ = [](double) { return X::Identity(); };
-    dxdes_ = [](double) { return TangentX{}; };
-    udes_ = [](double) { return U::Identity(); };
+    xdes_ = [](T) { return X::Identity(); };
+    dxdes_ = [](T) { return TangentX{}; };
+    udes_ = [](T) { return U::Identity(); };
     allocate(w);
   }
 
-  // ---- desired trajectories (absolute time), mpc.hpp:524-586 ----
-  void set_xdes(std::function<X(double)> x_des, std::function<TangentX(double)> dx_des)
+  // ---- desired trajectories, mpc.hpp:520-586 ----
+  /// absolute time: x_des(t) and its body velocity dx_des(t)
+  void set_xdes(std::function<X(T)> x_des, std::function<TangentX(T)> dx_des)
   {
     xdes_ = std::move(x_des);
     dxdes_ = std::move(dx_des);
     structure_changed();
   }
-  /// derivative by central differences of x(t) (the reference autodiffs / finite-differences x(t))
-  void set_xdes(std::function<X(double)> x_des)
+  /// absolute time, derivative by central differences of x(t) (the reference autodiffs / finite-differences x(t))
+  void set_xdes(std::function<X(T)> x_des)
   {
     auto xd = x_des;
-    dxdes_  = [xd](double t) {
+    dxdes_  = [xd](T t) {
       const double h = 1e-6;
-      TangentX d     = rminus(xd(t + h), xd(t - h));
+      TangentX d     = rminus(xd(tplus(t, h)), xd(tplus(t, -h)));
       for (auto & v : d) v /= (2 * h);
       return d;
     };
     xdes_ = std::move(x_des);
     structure_changed();
   }
-  void set_udes(std::function<U(double)> u_des)
+  void set_udes(std::function<U(T)> u_des)
   {
     udes_ = std::move(u_des);
     structure_changed();
   }
+  /// relative time, mpc.hpp:539-545: u_des(t) = f(t - t0) with f: double (seconds) -> U
+  template<class Fun>
+    requires std::is_same_v<std::invoke_result_t<Fun, double>, U>
+  void set_udes_rel(Fun && f, T t0 = T{})
+  {
+    set_udes([t0, f = std::forward<Fun>(f)](T t_abs) -> U { return f(time_trait<T>::minus(t_abs, t0)); });
+  }
+  /// relative time, mpc.hpp:572-586: x_des(t) = f(t - t0); the body velocity is the derivative of f (here: central
+  /// differences with step 1e-6 s, or f.velocity(t_rel) when the functor provides it)
+  template<class Fun>
+    requires std::is_same_v<std::invoke_result_t<Fun, double>, X>
+  void set_xdes_rel(Fun && f, T t0 = T{})
+  {
+    std::function<X(T)> xd = [t0, f](T t_abs) -> X { return f(time_trait<T>::minus(t_abs, t0)); };
+    std::function<TangentX(T)> dxd = [t0, f](T t_abs) -> TangentX {
+      const double tr = time_trait<T>::minus(t_abs, t0);
+      if constexpr (requires { { f.velocity(tr) } -> std::convertible_to<TangentX>; }) {
+        return f.velocity(tr);
+      } else {
+        const double h = 1e-6;
+        TangentX d     = rminus(f(tr + h), f(tr - h));
+        for (auto & v : d) v /= (2 * h);
+        return d;
+      }
+    };
+    set_xdes(std::move(xd), std::move(dxd));
+  }
+  /// mpc.hpp:593-598.  As in the reference at v1 the new weights are stored but never reach the QP: the cost block P is
+  /// transcribed once, in the constructor (mpc.hpp:423), and operator() only updates the dynamics / constraint rows.
+  /// Construct a new MPC (or pass the weights to the constructor) to control with other weights.
+  void set_weights(const MPCWeights<X, U> & w) { weights_ = w; }
+  const MPCWeights<X, U> & weights() const { return weights_; }
   void reset_warmstart() { warm_.reset(); }
 
   // ---- sizes / pattern ----
@@ -163,7 +201,7 @@ public:
     return st;
   }
   /// OR the non-zero entries of A at (t, x) into keep (one byte per stored entry of A).
-  void probe_structure(double t, const X & x, std::vector<uint8_t> & keep) const
+  void probe_structure(const T & t, const X & x, std::vector<uint8_t> & keep) const
   {
     std::vector<double> Av(qp_.A_val.size()), lv(qp_.m), uv(qp_.m);
     assemble(t, x, Av.data(), lv.data(), uv.data());
@@ -171,11 +209,11 @@ public:
     for (size_t e = 0; e < Av.size(); ++e) keep[e] |= !(Av[e] == 0.0);
   }
   /// probe at a few ticks after t from perturbed states on the desired trajectory (deterministic)
-  void probe_default(double t, std::vector<uint8_t> & keep) const
+  void probe_default(const T & t, std::vector<uint8_t> & keep) const
   {
     uint64_t lcg = 0x9E3779B97F4A7C15ull;
     for (int s = 0; s < 6; ++s) {
-      const double ts = t + s * prm_.tf / double(N());
+      const T ts = tplus(t, s * prm_.tf / double(N()));
       TangentX xi{};
       for (auto & v : xi) {
         lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
@@ -198,12 +236,35 @@ public:
     if (!solver_->analyzed()) {
       const auto st = elimination_stage();
       solver_->analyze(qp_, nullptr, st.data(), (keep && prm_.prune_explicit_zeros) ? keep->data() : nullptr);
+      if (keep && prm_.prune_explicit_zeros) keep_analysed_ = *keep;
+      else keep_analysed_.clear();
+      structure_dirty_ = false;
     }
+  }
+  /// After set_xdes / set_udes the linearisations may have non-zeros where the analysed ones had explicit zeros.  The
+  /// device checks the declaration for every solve anyway (a violating problem is solved on the whole pattern: slower,
+  /// never wrong), so nothing HAS to happen; this looks at the new trajectory once, at the next solve, and analyses
+  /// again only if it really leaves the analysed structure -- and never while a device-resident swarm holds the plan
+  /// (QPSolver::pin_plan: the swarm keeps the raw plan pointer, sfb.h).  Aval (nullable): values of A to probe as well.
+  void refresh_structure(const T & t, const double * Aval = nullptr)
+  {
+    if (!structure_dirty_ || !solver_->analyzed()) return;
+    structure_dirty_ = false;
+    if (!prm_.prune_explicit_zeros || keep_analysed_.empty() || solver_->plan_pinned()) return;
+    std::vector<uint8_t> keep;
+    if (Aval) probe_values(Aval, keep);
+    probe_default(t, keep);
+    bool inside = true;
+    for (size_t e = 0; e < keep.size() && inside; ++e) inside = !keep[e] || keep_analysed_[e];
+    if (inside) return;
+    for (size_t e = 0; e < keep.size(); ++e) keep[e] |= keep_analysed_[e];
+    solver_->reset();
+    analyze_solver(&keep);
   }
 
   /// Numeric part of MPC::operator() before the solve (mpc.hpp:473-486): writes the values of A (in
   /// the pattern of qp().A_*), l and u for current time t and state x.  Thread-safe (const).
-  void assemble(double t, const X & x, double * Aval, double * l, double * u) const
+  void assemble(const T & t, const X & x, double * Aval, double * l, double * u) const
   {
     const int Nn = N();
     const double tf = prm_.tf;
@@ -214,9 +275,9 @@ public:
       for (int i = 0; i < Kmesh; ++i) {
         const int node   = M + i;
         const double t_i = tf * mesh_.node(node);
-        const X xl       = xdes_(t + t_i);
-        const TangentX dxl = dxdes_(t + t_i);
-        const U ul       = udes_(t + t_i);
+        const X xl       = xdes_(tplus(t, t_i));
+        const TangentX dxl = dxdes_(tplus(t, t_i));
+        const U ul       = udes_(tplus(t, t_i));
         Vec<Nx> fv;
         Mat<Nx, Nx> dfdx;
         Mat<Nx, Nu> dfdu;
@@ -256,8 +317,8 @@ public:
     //     set_time, which leaves the constructor-time values -- identical for time-invariant cr) ---
     for (int node = 0; node < Nn; ++node) {
       const double t_i = tf * mesh_.node(node);
-      const X xl       = xdes_(t + t_i);
-      const U ul       = udes_(t + t_i);
+      const X xl       = xdes_(tplus(t, t_i));
+      const U ul       = udes_(tplus(t, t_i));
       Vec<Ncr> cv;
       Mat<Ncr, Nx> dcdx;
       Mat<Ncr, Nu> dcdu;
@@ -341,13 +402,13 @@ public:
     pk.count();
   }
   /// like probe_default: a few ticks after t, perturbed states on the desired trajectory (deterministic)
-  RecordPacking probe_record_default(double t) const
+  RecordPacking probe_record_default(const T & t) const
   {
     RecordPacking pk;
     std::vector<double> rec((size_t)record_doubles(N()));
     uint64_t lcg = 0x9E3779B97F4A7C15ull;
     for (int s = 0; s < 6; ++s) {
-      const double ts = t + s * prm_.tf / double(N());
+      const T ts = tplus(t, s * prm_.tf / double(N()));
       TangentX xi{};
       for (auto & v : xi) {
         lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
@@ -390,7 +451,7 @@ public:
   /// The part of assemble() that needs the user's callbacks: linearisation of dynamics, running constraint
   /// and initial-state constraint at (xdes, udes) for time t and state x, as one record of
   /// sfb_mpc_assemble_batch (layout in sfb.h; matrices row-major).  Thread-safe (const).
-  void fill_record(double t, const X & x, double * rec) const
+  void fill_record(const T & t, const X & x, double * rec) const
   {
     const int Nn = N();
     const double tf = prm_.tf;
@@ -398,9 +459,9 @@ public:
            *dcx = cc + Nn * Ncr, *dcu = dcx + Nn * Ncr * Nx, *e0 = dcu + Nn * Ncr * Nu, *Jm = e0 + Nx;
     for (int node = 0; node < Nn; ++node) {
       const double t_i   = tf * mesh_.node(node);
-      const X xl         = xdes_(t + t_i);
-      const TangentX dxl = dxdes_(t + t_i);
-      const U ul         = udes_(t + t_i);
+      const X xl         = xdes_(tplus(t, t_i));
+      const TangentX dxl = dxdes_(tplus(t, t_i));
+      const U ul         = udes_(tplus(t, t_i));
       Vec<Nx> fv;
       Mat<Nx, Nx> dfdx;
       Mat<Nx, Nu> dfdu;
@@ -431,14 +492,14 @@ public:
   }
 
   /// mpc.hpp:518   udes(0) (+) primal[uvar_B : +Nu]
-  U input_from_primal(double t, const double * primal) const
+  U input_from_primal(const T & t, const double * primal) const
   {
     typename U::Tangent du{};
     for (int c = 0; c < Nu; ++c) du[c] = primal[uvar_B() + c];
     return rplus(udes_(t), du);
   }
 
-  U input_from_du0(double t, const double * du0) const
+  U input_from_du0(const T & t, const double * du0) const
   {
     typename U::Tangent du{};
     for (int c = 0; c < Nu; ++c) du[c] = du0[c];
@@ -446,10 +507,11 @@ public:
   }
 
   /// MPC::operator(), mpc.hpp:458-519
-  std::pair<U, QPSolutionStatus> operator()(double t, const X & x, std::vector<U> * u_traj = nullptr,
+  std::pair<U, QPSolutionStatus> operator()(const T & t, const X & x, std::vector<U> * u_traj = nullptr,
                                             std::vector<X> * x_traj = nullptr)
   {
     assemble(t, x, qp_.A_val.data(), qp_.l.data(), qp_.u.data());
+    refresh_structure(t, qp_.A_val.data());
     if (!solver_->analyzed()) {
       std::vector<uint8_t> keep;
       probe_values(qp_.A_val.data(), keep);
@@ -463,7 +525,7 @@ public:
       for (int i = 0; i < Nn; ++i) {
         typename U::Tangent du{};
         for (int c = 0; c < Nu; ++c) du[c] = sol.primal[uvar_B() + i * Nu + c];
-        (*u_traj)[i] = rplus(udes_(t + prm_.tf * mesh_.node(i)), du);
+        (*u_traj)[i] = rplus(udes_(tplus(t, prm_.tf * mesh_.node(i))), du);
       }
     }
     if (x_traj) {  // :501-507
@@ -471,7 +533,7 @@ public:
       for (int i = 0; i <= Nn; ++i) {
         TangentX dx{};
         for (int c = 0; c < Nx; ++c) dx[c] = sol.primal[i * Nx + c];
-        (*x_traj)[i] = rplus(xdes_(t + prm_.tf * mesh_.node(i)), dx);
+        (*x_traj)[i] = rplus(xdes_(tplus(t, prm_.tf * mesh_.node(i))), dx);
       }
     }
     if (prm_.warmstart &&
@@ -482,11 +544,8 @@ public:
   }
 
 private:
-  // a new linearisation trajectory may have other explicit zeros: probe and analyse again at the next solve
-  void structure_changed()
-  {
-    if (prm_.prune_explicit_zeros && solver_->analyzed()) solver_->reset();
-  }
+  // a new linearisation trajectory may have other explicit zeros: looked at by refresh_structure() at the next solve
+  void structure_changed() { structure_dirty_ = true; }
   int dcon_B() const { return 0; }
   int crcon_B() const { return Nx * N(); }
   int cecon_B() const { return Nx * N() + Ncr * N(); }
@@ -577,11 +636,14 @@ private:
   Vec<Ncr> crl_, cru_;
   MPCParams prm_;
   Mesh mesh_;
-  std::function<X(double)> xdes_;
-  std::function<TangentX(double)> dxdes_;
-  std::function<U(double)> udes_;
+  std::function<X(T)> xdes_;
+  std::function<TangentX(T)> dxdes_;
+  std::function<U(T)> udes_;
   QuadraticProgramSparse<> qp_;
   std::shared_ptr<SparseQPSolver> solver_;
+  MPCWeights<X, U> weights_;
+  std::vector<uint8_t> keep_analysed_;  // the A_keep mask of the current analysis (empty: whole pattern)
+  bool structure_dirty_ = false;
   std::optional<QPSolution<>> warm_;
 };
 
@@ -610,10 +672,11 @@ public:
 
   /// one control tick for all agents: returns inputs and per-agent status codes
   template<class XT, class UT>
-  void step(const std::vector<double> & t, const std::vector<XT> & xs, std::vector<UT> & us,
+  void step(const std::vector<typename MPCT::TimeT> & t, const std::vector<XT> & xs, std::vector<UT> & us,
             std::vector<QPSolutionStatus> & codes)
   {
     const auto & qp = mpc_.qp();
+    if (B_ > 0) mpc_.refresh_structure(t[0]);  // after set_xdes / set_udes on the prototype
     parallel_for([&](int64_t b) {
       mpc_.assemble(t[b], xs[b], &Ax_[(size_t)b * nA_], &l_[(size_t)b * qp.m], &u_[(size_t)b * qp.m]);
     });
@@ -675,7 +738,7 @@ template<class MPCT>
 class MPCSwarmDevice {
 public:
   /// t_probe: a time in the range the agents will run at (the structure of the linearisation is probed there)
-  explicit MPCSwarmDevice(MPCT & proto, int64_t agents, int threads = 0, double t_probe = 0.0)
+  explicit MPCSwarmDevice(MPCT & proto, int64_t agents, int threads = 0, typename MPCT::TimeT t_probe = {})
       : mpc_(proto), B_(agents), threads_(threads > 0 ? threads : (int)std::max(1u, std::thread::hardware_concurrency()))
   {
     if (!mpc_.solver().analyzed()) {
@@ -697,17 +760,22 @@ public:
     code_.resize(B_);
     const auto & qp = mpc_.qp();
     sfb_check(sfb_mpc_swarm_create(mpc_.solver().plan(), &layout_->c, qp.P_val.data(), qp.q.data(), B_, &swarm_));
+    mpc_.solver().pin_plan();  // the swarm holds the raw plan pointer (sfb.h: the plan must outlive the swarm)
     sfb_check(sfb_mpc_swarm_host_records(swarm_, &rec_));  // pinned, owned by the swarm
   }
   MPCSwarmDevice(const MPCSwarmDevice &)             = delete;
   MPCSwarmDevice & operator=(const MPCSwarmDevice &) = delete;
-  ~MPCSwarmDevice() { sfb_mpc_swarm_destroy(swarm_); }
+  ~MPCSwarmDevice()
+  {
+    sfb_mpc_swarm_destroy(swarm_);
+    mpc_.solver().unpin_plan();
+  }
 
   void reset_warmstart() { sfb_check(sfb_mpc_swarm_reset_warmstart(swarm_)); }
 
   /// one control tick for all agents; primal / dual (nullable) receive the full solutions
   template<class XT, class UT>
-  void step(const std::vector<double> & t, const std::vector<XT> & xs, std::vector<UT> & us,
+  void step(const std::vector<typename MPCT::TimeT> & t, const std::vector<XT> & xs, std::vector<UT> & us,
             std::vector<QPSolutionStatus> & codes, std::vector<double> * primal = nullptr,
             std::vector<double> * dual = nullptr)
   {
@@ -776,7 +844,7 @@ public:
 private:
   static constexpr int64_t kUploadChunks = 8;
   template<class XT>
-  void step_fill_unpacked(const std::vector<double> & t, const std::vector<XT> & xs)
+  void step_fill_unpacked(const std::vector<typename MPCT::TimeT> & t, const std::vector<XT> & xs)
   {
     parallel_for(0, B_, [&](int64_t b) { mpc_.fill_record(t[b], xs[b], rec_ + (size_t)b * recd_); });
   }

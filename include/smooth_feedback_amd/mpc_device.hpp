@@ -124,7 +124,9 @@ public:
     packed_ = mpc_.params().prune_explicit_zeros && pack_.doubles(mpc_.N()) < MPCT::record_doubles(mpc_.N());
     layout_ = mpc_.device_layout(packed_ ? &pack_.keep : nullptr);
     const auto & qp = mpc_.qp();
+    static_assert(std::is_same_v<typename MPCT::TimeT, double>, "the device-side linearisation takes time as double seconds");
     sfb_check(sfb_mpc_swarm_create(mpc_.solver().plan(), &layout_->c, qp.P_val.data(), qp.q.data(), B_, &swarm_));
+    mpc_.solver().pin_plan();  // the swarm holds the raw plan pointer
     sfb_check(sfb_mpc_swarm_device_records(swarm_, &drec_, nullptr));
     const int Nn = mpc_.N();
     std::vector<double> tau((size_t)Nn + 1);
@@ -145,6 +147,7 @@ public:
   ~MPCSwarmDeviceLin()
   {
     sfb_mpc_swarm_destroy(swarm_);
+    mpc_.solver().unpin_plan();
     if (dmem_) (void)hipFree(dmem_);
   }
 

@@ -130,6 +130,15 @@ struct PlanHolder {
     plan = nullptr;
   }
 };
+/// pins travel with the analysis: a copy starts unpinned (it has no analysis), a move takes them over
+struct PinCount {
+  int v = 0;
+  PinCount() = default;
+  PinCount(const PinCount &) {}
+  PinCount(PinCount && o) noexcept : v(o.v) { o.v = 0; }
+  PinCount & operator=(const PinCount &) { return *this; }
+  PinCount & operator=(PinCount && o) noexcept { if (this != &o) { v = o.v; o.v = 0; } return *this; }
+};
 }  // namespace detail
 
 /// QPSolver<Pbm>, qp_solver.hpp:242-757.  Pbm = QuadraticProgram<M, N> (dense kernels) or QuadraticProgramSparse<>
@@ -162,6 +171,7 @@ public:
     sol_.primal.assign(n_, 0.0);
     sol_.dual.assign(m_, 0.0);
     if constexpr (sparse) {
+      if (pins_.v > 0) throw std::logic_error("QPSolver::analyze: the analysis is in use by a device-resident swarm");
       holder_.reset();
       last_P_.clear(); last_A_.clear();
       sfb_check(sfb_sparse_qp_plan_create_pruned(pbm.n, pbm.m, pbm.P_colptr.data(), pbm.P_rowind.data(), pbm.A_rowptr.data(),
@@ -182,6 +192,7 @@ public:
   /// forget the analysis (the next solve analyses again)
   void reset()
   {
+    if (pins_.v > 0) throw std::logic_error("QPSolver::reset: the analysis is in use by a device-resident swarm");
     holder_.reset();
     analyzed_ = false;
   }
@@ -230,6 +241,9 @@ public:
     const sfb_qp_params c = prm_.to_c();
     if constexpr (sparse) {
       if (!holder_.plan) throw std::logic_error("QPSolver::solve_batch: analyze() first");
+      // the batch call shares the plan's host-side device workspace with solve(): whatever factor solve() left there is
+      // gone, so the next solve() must not vouch for it (reuse_factor) even if it sees its old matrices again
+      last_P_.clear(); last_A_.clear();
       sfb_check(sfb_sparse_qp_solve_batch_host(holder_.plan, &c, B, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code));
     } else {
       sfb_check(sfb_qp_dense_solve_batch_host(&c, B, n_, m_, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code));
@@ -247,6 +261,11 @@ public:
   }
   const QPSolverParams & params() const { return prm_; }
   sfb_sparse_qp_plan * plan() { return holder_.plan; }
+  /// Objects that keep the raw plan pointer beyond a call (device-resident swarms: sfb_mpc_swarm holds it, sfb.h) pin
+  /// the analysis for their lifetime; while pinned, reset() and analyze() refuse to destroy it.
+  void pin_plan() { ++pins_.v; }
+  void unpin_plan() { if (pins_.v > 0) --pins_.v; }
+  bool plan_pinned() const { return pins_.v > 0; }
 
 private:
   QPSolverParams prm_{};
@@ -254,6 +273,7 @@ private:
   bool analyzed_ = false;
   std::vector<double> last_P_, last_A_;  // sparse: the matrices of the previous solve() (factor reuse)
   int64_t reuse_count_ = 0;
+  detail::PinCount pins_;
   int n_ = 0, m_ = 0;
   Solution sol_;
 };

@@ -11,6 +11,12 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "build", "liboracle.so")
+# Variants of the same sources (oracle/Makefile), for tests/test_parity_robustness.py only:
+#   "strict" (default, what everything else uses): -ffp-contract=off, fma only where spelled -- the arithmetic the HIP
+#   kernels reproduce bit for bit;  "fast": the reference's own benchmark flags;  "san": ASan + UBSan.
+# SFB_ORACLE_VARIANT selects the variant a fresh process starts with (the sanitizer build needs libasan preloaded).
+_VARIANT_LIBS = {"strict": ("liboracle.so", None), "fast": ("liboracle_fast.so", "fast"), "san": ("liboracle_san.so", "san")}
+_variant = os.environ.get("SFB_ORACLE_VARIANT", "strict")
 
 
 class OracleQPParams(C.Structure):
@@ -36,21 +42,41 @@ class OracleQPParams(C.Structure):
     ]
 
 
-def build(force=False):
+def build(force=False, variant="strict"):
     """Compile the oracle with the committed Makefile (gcc only)."""
-    if force or not os.path.exists(_LIB_PATH):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
-    return _LIB_PATH
+    name, target = _VARIANT_LIBS[variant]
+    path = os.path.join(_HERE, "build", name)
+    if force or not os.path.exists(path):
+        if force and os.path.exists(path) and target is not None:
+            os.remove(path)
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + ([target] if target else []))
+    return path
 
 
-_lib = None
+_libs = {}
+
+
+class variant:
+    """`with loader.variant("fast"): ...` -- every call inside goes to that build of the oracle."""
+
+    def __init__(self, name):
+        assert name in _VARIANT_LIBS, name
+        self.name = name
+
+    def __enter__(self):
+        global _variant
+        self.prev, _variant = _variant, self.name
+        return self
+
+    def __exit__(self, *exc):
+        global _variant
+        _variant = self.prev
+        return False
 
 
 def lib():
-    global _lib
-    if _lib is None:
-        build()
-        L = C.CDLL(_LIB_PATH)
+    if _variant not in _libs:
+        L = C.CDLL(build(variant=_variant))
         dp = C.POINTER(C.c_double)
         L.oracle_qp_params_default.argtypes = [C.POINTER(OracleQPParams)]
         L.oracle_qp_params_default.restype = None
@@ -84,8 +110,8 @@ def lib():
         L.oracle_ldlt_factor.restype = C.c_int
         L.oracle_ldlt_solve.argtypes = [C.c_int, dp, C.c_int, C.POINTER(C.c_int), dp]
         L.oracle_ldlt_solve.restype = None
-        _lib = L
-    return _lib
+        _libs[_variant] = L
+    return _libs[_variant]
 
 
 def default_params(**kw):

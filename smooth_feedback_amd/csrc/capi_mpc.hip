@@ -353,7 +353,15 @@ sfb_status sfb_mpc_swarm_upload(sfb_mpc_swarm *S, int64_t first, int64_t count)
   if (!S) return sfb::fail(SFB_ERR_INVALID_ARG, "swarm is NULL");
   if (!S->pinned) return sfb::fail(SFB_ERR_INVALID_ARG, "sfb_mpc_swarm_host_records first");
   if (first < 0 || count < 0 || first + count > S->agents) return sfb::fail(SFB_ERR_INVALID_ARG, "range outside the swarm");
-  if (sfb_status sd = check_swarm_device(S); sd != SFB_OK) return sd;
+  {
+    // This entry point is meant to be called from the caller's linearisation threads, and a new host thread starts on
+    // device 0 whatever the thread that created the swarm had selected: make the swarm's device current here instead of
+    // rejecting the call (the copy below goes to the swarm's own stream and memory).
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess && dev != S->devid) e = hipSetDevice(S->devid);
+    if (e != hipSuccess) return sfb::hip_fail(e, "hipSetDevice(swarm device)");
+  }
   if (count == 0) return SFB_OK;
   std::lock_guard<std::mutex> lk(S->mu);
   const size_t rd = (size_t)S->rec_own.rec_doubles;

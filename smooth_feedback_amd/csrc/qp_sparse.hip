@@ -52,6 +52,12 @@ struct Ws {
 };
 // reuse_factor: the header of an item whose workspace holds a successful ADMM factorisation
 constexpr int kHdrStamp = 6, kHdrC = 7, kHdrSigma = 8, kHdrScaling = 9;
+// phased launches (see qp_sparse_launch): [10] status after the setup / ADMM phase (-1 = open), [11] 1.0 = the item was
+// solved completely in the fallback pool during the setup phase (the later phases skip it), [12] timeline stamp
+constexpr int kHdrCode = 10, kHdrComplete = 11;
+[[maybe_unused]] constexpr int kHdrTl2 = 12;
+// what one launch does with an item
+enum { PH_ALL = 0, PH_SETUP = 1, PH_ADMM = 2, PH_FINISH = 3 };
 constexpr unsigned long long kFactorStamp = 0x5FB0FAC7A11CE5EDull;
 
 __device__ __forceinline__ Ws carve_ws(double *base, int n, int m, int nnzL, int funits, int bunits)
@@ -1015,8 +1021,8 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
                                              uint32_t *__restrict__ giter, int32_t *__restrict__ gcode,
                                              double *__restrict__ gws, const size_t ws_doubles, const int lean_waves,
                                              bool lean, const size_t b, const size_t slot, double *t, const int lane,
-                                             const bool resume, const int32_t *queue, const int batch,
-                                             const uint32_t slice, const bool allow_reuse)
+                                             bool resume, const int32_t *queue, const int batch,
+                                             const uint32_t slice, const bool allow_reuse, const int phase)
 {
   const int n = uni(pl.n), m = uni(pl.m), k = uni(pl.k);
   const int nnzP = uni(pl.nnzP), nnzA = uni(pl.nnzA);  // (nnzA: what the kernel works on, the kept entries of a pruned plan)
@@ -1035,6 +1041,11 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
   if (lane == 0) t[k] = 0.0;  // padding slot of the packed sweeps
   const double inf = INFINITY;
   unsigned long long t0_ticks = wall_clock64();  // start of the item's solve (:376), kept across suspensions
+  if (phase >= PH_ADMM) {  // phased launch: every item continues from the state the previous phase left in its workspace
+    if (w.hdr[kHdrComplete] == 1.0) return SP_DONE;
+    if (!resume) ret_code = (int)w.hdr[kHdrCode];  // (an item suspended inside this phase is open by construction)
+    resume = true;
+  }
   if (resume) {
     c        = w.hdr[0];
     iter     = (uint32_t)w.hdr[1];
@@ -1244,10 +1255,26 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
   wave_sync();
   }  // !resume
 
+  if (phase == PH_SETUP) {  // phased launch: the ADMM phase continues from here
+    if (lane == 0) {
+      w.hdr[0] = c;
+      w.hdr[1] = 0.0;
+      w.hdr[2] = (double)next_chk;
+      w.hdr[3] = (double)t0_ticks;
+#ifdef SFB_SP_TIMELINE
+      w.hdr[4] = (double)tl0;
+      w.hdr[5] = (double)tl1;
+#endif
+      w.hdr[kHdrCode]     = (double)ret_code;
+      w.hdr[kHdrComplete] = 0.0;
+    }
+    return SP_DONE;
+  }
+
   // ---- ADMM loop :447-510 ----
   const uint32_t iter0 = iter;  // start of this slice
   bool need_rhs        = true;
-  for (; iter != maxit && ret_code < 0; ++iter) {
+  for (; phase != PH_FINISH && iter != maxit && ret_code < 0; ++iter) {
     // element-wise phases: the loads of UNR strided elements are issued together (one memory round
     // trip per UNR elements instead of one per element -- matters for a wave that runs alone)
     // (the batch sizes are what the 168-VGPR budget of three waves per SIMD allows)
@@ -1409,6 +1436,20 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
 #ifdef SFB_SP_TIMELINE
   tl2 = wall_clock64();
 #endif
+  if (phase == PH_ADMM) {  // phased launch: polish and report belong to the next phase
+    if (lane == 0) {
+      w.hdr[0] = c;
+      w.hdr[1] = (double)iter;
+      w.hdr[kHdrCode] = (double)ret_code;
+#ifdef SFB_SP_TIMELINE
+      w.hdr[kHdrTl2] = (double)tl2;
+#endif
+    }
+    return SP_DONE;
+  }
+#ifdef SFB_SP_TIMELINE
+  if (phase == PH_FINISH) tl2 = (unsigned long long)w.hdr[kHdrTl2];
+#endif
   // ---- polish :515-539 ----
   if (ret_code == SFB_QP_OPTIMAL && kp.polish) {
     if (kp.reuse != 0 && allow_reuse) {  // keep the ADMM factor for the next call: the polish system goes to the second block
@@ -1471,7 +1512,7 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev *_
                                                        const int lean_waves, const int32_t *__restrict__ order,
                                                        int32_t *__restrict__ queue, const int batch, const uint32_t slice,
                                                        const SparsePlanDev *__restrict__ plf, double *__restrict__ gwsf,
-                                                       const size_t wsf_doubles, int32_t *__restrict__ fbflags)
+                                                       const size_t wsf_doubles, int32_t *__restrict__ fbflags, const int phase)
 {
   extern __shared__ __attribute__((aligned(16))) double t[];  // work / solution vector, factorisation scratch
   // The plan (some forty pointers) is read from device memory where it is used: as a by-value kernel argument it
@@ -1515,7 +1556,7 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev *_
     double *wsb              = gws;
     size_t wsd = ws_doubles, slot = (queue == nullptr) ? (size_t)blockIdx.x : (size_t)item;
     int fbslot = -1;
-    if (plf != nullptr && !resume && !sp_guard_ok(*plp, gAx + (size_t)item * (size_t)uni(plp->nnzA_io), lane)) {
+    if (plf != nullptr && !resume && phase <= PH_SETUP && !sp_guard_ok(*plp, gAx + (size_t)item * (size_t)uni(plp->nnzA_io), lane)) {
       if (lane == 0) {
         for (int probe = blockIdx.x % kFbSlots;; probe = (probe + 1) % kFbSlots) {
           if (atomicCAS(&fbflags[probe], 0, 1) == 0) { fbslot = probe; break; }
@@ -1533,9 +1574,13 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev *_
     int seen = 0;
     if (lane == 0) seen = atomicAdd(&g_sparse_active, 1);
     const bool lean = ((queue == nullptr ? (int)gridDim.x : batch) > lean_waves) || __builtin_amdgcn_readfirstlane(seen) >= lean_waves;
+    // (phased launches: an item of the fallback pool runs all phases at once, in the setup launch)
     const int st = sp_solve_item(*use, kp, gPx, gq, gAx, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode, wsb, wsd, lean_waves,
                                  lean, (size_t)item, slot, t, lane, resume != 0, fbslot >= 0 ? nullptr : queue, batch, slice,
-                                 /*allow_reuse: the item's own slot of the main workspace*/ fbslot < 0 && slot == (size_t)item);
+                                 /*allow_reuse: the item's own slot of the main workspace*/ fbslot < 0 && slot == (size_t)item,
+                                 fbslot >= 0 ? PH_ALL : phase);
+    if (fbslot >= 0 && phase == PH_SETUP && lane == 0)  // tell the later phases (the item's own slot is otherwise unused)
+      carve_ws(gws + (size_t)item * ws_doubles, uni(plp->n), uni(plp->m), uni(plp->nnzL), uni(plp->funits), uni(plp->bunits)).hdr[kHdrComplete] = 1.0;
     wave_sync();
     if (lane == 0) {
       atomicSub(&g_sparse_active, 1);
@@ -1600,15 +1645,44 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
       sliced = true;
     }
   }
-  if (sliced || pruned) {
-    hipError_t e = hipMemsetAsync(aux, 0, qp_sparse_aux_bytes(batch), stream);
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL(qp_sparse_kernel, dim3(grid), dim3(kWave), lds, stream, pl.self, kp, Px, q, Ax, l, u, wx, wy, x, y, obj, iter,
-                     code, workspace, wsd, lean_waves, order, qarg, (int)batch, (uint32_t)std::max(1, slice),
-                     pruned ? fallback->self : nullptr, fallback_ws, pruned ? qp_sparse_ws_doubles(*fallback) : 0,
-                     aux ? aux + batch + kQRing : nullptr);
-  return hipGetLastError();
+  // PHASED LAUNCH (time-sliced launches only, SFB_SP_PHASED=1): three kernels on the stream instead of one -- setup
+  // (scaling, factorisation, initial iterate), the ADMM loop, polish + report -- each with its own grid; the item's
+  // state travels through its workspace header, exactly like a suspended item of a time-sliced launch, and the results
+  // are bit-identical (tests/test_mpc_gpu.py).  The idea: setup and polish are latency-bound per item and want every
+  // wave the chip holds, while the ADMM loop streams the factor twice per iteration and is fastest with only as many
+  // items in flight as the 256 MB Infinity Cache (MALL) holds factor copies of (loop alone, headline plan: 21.3
+  // item-iterations/us with 768 waves and plain loads against 16.8 with 3 072 waves and non-temporal loads).
+  // Measured on the headline batch (scripts/r3/phased_sweep.py): 78 ms against 76 ms for the single kernel -- what the
+  // ADMM phase gains, the lost overlap of setup / polish (7.6 + 10 ms on their own) with it costs again, and the tail of
+  // long-running items is the same.  So the phased launch is OFF by default; it stays as the instrument that separates
+  // the three phases for the profiler (profiles/r3_mpc_phases).
+  const char *ph    = getenv("SFB_SP_PHASED");
+  const bool phased = sliced && ph && atoi(ph) == 1;
+  auto launch = [&](unsigned g, int32_t *qa, int lw, int phase) -> hipError_t {
+    if (qa != nullptr || pruned) {
+      hipError_t e = hipMemsetAsync(aux, 0, qp_sparse_aux_bytes(batch), stream);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(qp_sparse_kernel, dim3(g), dim3(kWave), lds, stream, pl.self, kp, Px, q, Ax, l, u, wx, wy, x, y, obj, iter,
+                       code, workspace, wsd, lw, order, qa, (int)batch, (uint32_t)std::max(1, slice),
+                       pruned ? fallback->self : nullptr, fallback_ws, pruned ? qp_sparse_ws_doubles(*fallback) : 0,
+                       aux ? aux + batch + kQRing : nullptr, phase);
+    return hipGetLastError();
+  };
+  if (!phased) return launch(grid, qarg, lean_waves, PH_ALL);
+  // grid of the ADMM phase: items whose two schedule-ordered factor copies fit ~70 % of the MALL
+  const double stream_bytes = (double)(pl.funits + pl.bunits) * 128.0 * sizeof(double);
+  unsigned grid2 = (unsigned)std::max(256.0, 0.70 * 256.0 * 1024.0 * 1024.0 / stream_bytes);
+  if (const char *g2 = getenv("SFB_SP_GRID2"); g2 && atoi(g2) > 0) grid2 = (unsigned)atoi(g2);
+  grid2 = std::min(grid2, grid);
+  // plain (cache-allocating) loads in the ADMM phase unless the grid is too large for the MALL anyway
+  const char *lw2       = getenv("SFB_SP_LEAN_WAVES2");
+  const int lean_waves2 = lw2 ? atoi(lw2) : (grid2 < grid ? 0x7FFFFFFF : lean_waves);
+  hipError_t e = launch(grid, qarg, lean_waves, PH_SETUP);
+  if (e != hipSuccess) return e;
+  e = launch(grid2, qarg, lean_waves2, PH_ADMM);
+  if (e != hipSuccess) return e;
+  return launch(grid, qarg, lean_waves, PH_FINISH);
 }
 
 }  // namespace sfb

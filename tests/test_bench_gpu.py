@@ -37,7 +37,7 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline():
 def test_two_ranks_code_path(workload, batch, port):
     """Every workload through the N > 1 path: per-rank shard, barrier, ONE gather of the small per-item outputs per
     step (for mpc: u_0, code, iter sliced out of the solution), max-over-ranks timing; rank 0 checks that its own
-    rows come back from the gather unchanged and that the other rank's rows differ from a zero fill."""
+    rows come back from the gather unchanged and that the other rank's rows reproduce that rank's checksum."""
     env = dict(os.environ, SFB_BENCH_SHARE_DEVICE="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
@@ -49,7 +49,24 @@ def test_two_ranks_code_path(workload, batch, port):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["config"]["global_batch"] == 2 * batch and d["config"]["per_gpu_batch"] == batch
     assert d["value"] > 0 and "cpu_baseline" not in d and "secondary" not in d
-    assert d["gather_check"] == {"own_rows_intact": True, "peer_rows_received": True}
+    assert d["gather_check"] == {"own_rows_intact": True, "peer_rows_received": True, "peer_rows_differ_from_own": True,
+                                 "ranks_checked": 2}
+
+
+def test_eight_ranks_mpc_code_path():
+    """The shape of BASELINE configs[3] (8 ranks, one shard of MPC agents each, ONE gather of u_0 / code / iter per
+    step) with all ranks on cuda:0 over gloo: sharding by rank-derived seeds, host assembly threads divided among the
+    ranks, the gather checked against per-rank checksums that travel by a separate all_reduce."""
+    env = dict(os.environ, SFB_BENCH_SHARE_DEVICE="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                          "--master-addr", "127.0.0.1", "--master-port", "29557", "bench.py", "--gpus", "8",
+                          "--workload", "mpc", "--batch", "64", "--steps", "2", "--warmup", "1"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8 * 64
+    assert d["gather_check"] == {"own_rows_intact": True, "peer_rows_received": True, "peer_rows_differ_from_own": True,
+                                 "ranks_checked": 8}
 
 
 def test_default_line_carries_the_secondary_workloads():

@@ -169,6 +169,42 @@ def test_time_sliced_launch_equals_one_block_per_item(sfb, oracle, grid, slice_i
         assert np.array_equal(r.iter[5:6], ref5["iter"]) and np.array_equal(r.primal[5:6], ref5["x"])
 
 
+@pytest.mark.parametrize("grid,grid2,slice_iters", [(16, 5, 25), (48, 48, 50), (32, 9, 1000000)])
+def test_phased_launch_equals_the_single_kernel(sfb, oracle, grid, grid2, slice_iters, monkeypatch):
+    """SFB_SP_PHASED=1 splits a time-sliced launch into three kernels (setup / ADMM loop / polish + report, each with
+    its own grid; the item's state travels through its workspace header like a suspended item's).  Same bits as the
+    single kernel: plain and pruned plans, cold and warm start, an item on the fallback path (solved completely in the
+    setup phase and skipped by the later ones), items that fail the pre-check (iter == 0) and a max_iter cut-off."""
+    variant, K, B = 6, 10, 150
+    d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
+    Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=23)
+    keep = np.any(Av != 0.0, axis=0)
+    Av[7, np.nonzero(~keep)[0][2]] = -0.25       # violates the mask: fallback pool
+    l[11, 3], u[11, 3] = 1.0, -1.0                 # u < l: PrimalInfeasible at the pre-check, no iteration
+    Px, q = np.tile(Pv, (B, 1)), np.zeros((B, d["n"]))
+    for prm in (sfb.QPSolverParams(max_iter=4000), sfb.QPSolverParams(max_iter=60, polish=False)):
+        for kp in (None, keep):
+            plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K), keep=kp)
+            monkeypatch.setenv("SFB_SP_SLICE", str(slice_iters))
+            monkeypatch.setenv("SFB_SP_GRID", str(grid))
+            monkeypatch.setenv("SFB_SP_PHASED", "0")
+            base = plan.solve_batch_host(Px, q, Av, l, u, prm)
+            base2 = plan.solve_batch_host(Px, q, Av, l, u, prm, warm_x=0.5 * base.primal, warm_y=0.5 * base.dual)
+            monkeypatch.setenv("SFB_SP_PHASED", "1")
+            monkeypatch.setenv("SFB_SP_GRID2", str(grid2))
+            r = plan.solve_batch_host(Px, q, Av, l, u, prm)
+            r2 = plan.solve_batch_host(Px, q, Av, l, u, prm, warm_x=0.5 * base.primal, warm_y=0.5 * base.dual)
+            for a, b in ((r, base), (r2, base2)):
+                assert np.array_equal(a.code, b.code) and np.array_equal(a.iter, b.iter)
+                assert np.array_equal(a.primal, b.primal, equal_nan=True) and np.array_equal(a.dual, b.dual, equal_nan=True)
+                assert np.array_equal(a.objective, b.objective, equal_nan=True)
+            assert r.code[11] == 2 and r.iter[11] == 0
+            if prm.max_iter == 60:
+                assert (r.code == 4).any() and r.iter.max() == 60
+    for k in ("SFB_SP_SLICE", "SFB_SP_GRID", "SFB_SP_PHASED", "SFB_SP_GRID2"):
+        monkeypatch.delenv(k)
+
+
 def test_max_time_on_the_sparse_path(sfb, oracle):
     """max_time (qp_solver.hpp:504-507) on the sparse kernel: 1 ns ends every agent at its first stopping check;
     deterministic and equal to the oracle with the same limit.  Also through a time-sliced launch."""

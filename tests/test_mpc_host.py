@@ -152,3 +152,18 @@ def test_generic_ocp_to_qp_reproduces_the_reference_test():
     assert tuple(o[:7]) == (n, m, n, m, m, n, m)
     assert o[7] >= -1e-8 and o[8] >= -1e-8, (o[7], o[8])
     assert abs(o[9] - 1.0) < 1e-4 and abs(o[10] - 4.0) < 1e-4 and abs(o[11] - 0.4) < 1e-6
+
+
+def test_time_concept_relative_setters_weights_and_structure_refresh():
+    """MPC API beyond operator() (reference mpc.hpp:520-603, time.hpp:25-89), through the C++ front:
+    set_xdes_rel / set_udes_rel reproduce the absolute-time setters (the relative version differentiates x(t) by central
+    differences: agreement to 1e-6); the controller on a std::chrono clock assembles the same QP as with double seconds;
+    set_weights stores the weights without re-transcribing P (the reference's v1 behaviour) while the constructor does
+    transcribe them; a new desired trajectory after the analysis is looked at lazily and never destroys a plan that a
+    device-resident swarm has pinned."""
+    import ctypes as C
+    out = np.full(9, -1.0)
+    assert M.lib().sfbx_test_mpc_time_and_setters(out.ctypes.data_as(C.c_void_p)) == 0
+    assert 0 <= out[0] <= 1e-6, out[0]
+    assert 0 <= out[1] <= 1e-6, out[1]
+    assert list(out[2:]) == [1.0] * 7, out

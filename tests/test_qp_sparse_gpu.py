@@ -112,3 +112,16 @@ def test_non_finite_inputs_follow_the_reference_semantics_sparse(sfb, oracle):
     rc = plan.solve_batch_host(*clean, prm)
     for b in (0, 9, 10, 11):
         assert np.array_equal(rc.primal[b], r.primal[b]) and rc.iter[b] == r.iter[b]
+
+
+def test_solve_after_solve_batch_does_not_reuse_a_foreign_factor(sfb):
+    """QPSolver<QuadraticProgramSparse>::solve() flags reuse_factor when it is handed the previous solve()'s matrices
+    again; solve_batch() on the same solver shares the device workspace, so it must end that claim (round-2 advisor
+    finding): solve(A1), solve_batch(A2), solve(A1) -- scaling off, so the kernel's own re-check of c cannot tell the two
+    problems apart -- gives the first call's bits again and is not flagged; one more solve(A1) is flagged, same bits."""
+    import ctypes as C
+    from examples import models_lib as M
+    out = np.full(8, -1.0)
+    assert M.lib().sfbx_test_solve_after_solve_batch(out.ctypes.data_as(C.c_void_p)) == 0
+    assert out[0] == 1.0 and out[1] == 0.0 and out[2] == 1.0 and out[3] == 1.0, out
+    assert not np.allclose(out[4:6], out[6:8])          # the batch call really solved another problem
