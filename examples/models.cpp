@@ -81,10 +81,13 @@ int fill_pattern(const M & mpc, int32_t * Pp, int32_t * Pi, double * Pval, int32
 
 std::vector<double> g_tick_seconds;  // wall time of every swarm.step() of the last swarm_step call
 
+bool g_swarm_multi_device = false;  // sfbx_mpc_swarm_step_multi: shard the swarm's solves over the device list
+
 template<class M, class XF, class X, class Swarm = MPCSwarm<M>>
 int swarm_step(M & mpc, XF xdes, int64_t batch, uint64_t seed, int ticks, double * u0, int32_t * codes, uint32_t * iters)
 {
   Swarm swarm(mpc, batch);
+  mpc.solver().shard_over_devices(g_swarm_multi_device);
   std::vector<double> t(batch);
   std::vector<X> xs(batch);
   for (int64_t b = 0; b < batch; ++b) {
@@ -227,6 +230,19 @@ int sfbx_mpc_swarm_step(int variant, int K, double tf, int64_t batch, uint64_t s
     return -2;
   }
   return -1;
+}
+
+int sfbx_mpc_swarm_step_multi(int variant, int K, double tf, int64_t batch, uint64_t seed, int ticks, const int * devices,
+                              int ndev, double * u0, int32_t * codes, uint32_t * iters)
+{
+  // MPCSwarm with its batched solves sharded over `devices` from this one process (sfb_set_devices +
+  // QPSolver::shard_over_devices): SURVEY.md section 8(b) / 8(e) for the caller the reference actually has, C++.
+  if (sfb_set_devices(devices, ndev) != SFB_OK) return -3;
+  g_swarm_multi_device = true;
+  const int rc = sfbx_mpc_swarm_step(variant, K, tf, batch, seed, ticks, u0, codes, iters);
+  g_swarm_multi_device = false;
+  (void)sfb_set_devices(nullptr, 0);
+  return rc;
 }
 
 }  // extern "C"

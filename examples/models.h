@@ -54,6 +54,10 @@ int sfbx_test_solve_after_solve_batch(double *out);
 /* Swarm tick through MPCSwarm (host assembly + one batched GPU solve): returns u0 [batch][2], codes. */
 int sfbx_mpc_swarm_step(int variant, int K, double tf, int64_t batch, uint64_t seed, int ticks, double *u0,
                         int32_t *codes, uint32_t *iters);
+/* The same swarm with every batched solve sharded over `devices` (sfb_set_devices; an ordinal may repeat) from this
+ * one process: one host thread, plan upload and workspace per device.  Same outputs as sfbx_mpc_swarm_step. */
+int sfbx_mpc_swarm_step_multi(int variant, int K, double tf, int64_t batch, uint64_t seed, int ticks, const int *devices,
+                              int ndev, double *u0, int32_t *codes, uint32_t *iters);
 /* Device-side assembly (sfb_mpc_assemble_batch / sfb_mpc_swarm, include/sfb.h): the layout of the variant's
  * transcription -- dims = {nx, nu, ncr, kmesh, nivals, nparts}, alpha [nivals], D [(kmesh+1)*kmesh], kind / dof
  * [nparts], crl / cru [ncr] --, the linearisation records of the agents of sfbx_mpc_assemble_batch

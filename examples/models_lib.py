@@ -126,6 +126,17 @@ def mpc_swarm_step(variant, K, batch, ticks, seed=1, tf=5.0, device=False):
     return u0, codes, iters
 
 
+def mpc_swarm_step_multi(variant, K, batch, ticks, devices, seed=1, tf=5.0):
+    """mpc_swarm_step with every batched solve sharded over `devices` from this one process (MPCSwarm +
+    QPSolver::shard_over_devices + sfb_set_devices)."""
+    u0 = np.zeros((batch, 2)); codes = np.zeros(batch, np.int32); iters = np.zeros(batch, np.uint32)
+    dev = (C.c_int * len(devices))(*devices)
+    rc = lib().sfbx_mpc_swarm_step_multi(variant, K, C.c_double(tf), C.c_int64(batch), C.c_uint64(seed), ticks, dev, len(devices),
+                                         _p(u0), _p(codes), _p(iters))
+    assert rc == 0, rc
+    return u0, codes, iters
+
+
 def last_tick_seconds(n):
     """wall seconds of every swarm.step() of the last mpc_swarm_step call"""
     out = np.zeros(n)

@@ -117,6 +117,22 @@ const char *sfb_last_error(void);
 /* Number of visible HIP devices (0 if none / runtime unusable). */
 sfb_status sfb_device_count(int *count);
 
+/*
+ * Several devices from ONE process.  The reference has no parallelism (its benchmark "batch"
+ * is a sequential for loop, benchmarks/bench_types.hpp:93); the items of a batch are independent, so a batch shards
+ * trivially.  Two ways to use more than one GPU:
+ *   - one process per GPU (torchrun / MPI): every entry point of this header works on the process's current device;
+ *     the launcher shards the batch (bench.py, smooth_feedback_amd/sharding.py);
+ *   - one process, the *_multi host-pointer entry points below: the batch is cut into one contiguous shard per entry
+ *     of the device list, every shard runs on its own host thread with its device current (own plan upload, own
+ *     workspace, own stream) and writes its slice of the caller's output arrays -- host memory is the gathering
+ *     point, there is no device-to-device exchange on this path.  Results are identical to the single-device call.
+ * sfb_set_devices: the device list of the *_multi entry points (default / count == 0: every visible device).  An
+ * ordinal may appear more than once (its shards are then serialised on that device; used by the tests on 1-GPU boxes).
+ */
+sfb_status sfb_set_devices(const int *devices, int count);
+sfb_status sfb_get_devices(int *devices, int capacity, int *count);
+
 /* Defaults of QPSolverParams (qp_solver.hpp:29-68). */
 void sfb_qp_params_default(sfb_qp_params *prm);
 
@@ -171,11 +187,19 @@ sfb_status sfb_qp_dense_solve_batch_ws(const sfb_qp_params *prm, int64_t batch, 
                                        double *obj, uint32_t *iter, int32_t *code, sfb_workspace *workspace,
                                        void *stream);
 
-/* Same with host pointers (H2D copy, solve, D2H copy, synchronous) on the current device. */
+/* Same with host pointers (H2D copy, solve, D2H copy, synchronous) on the current device.  One device staging buffer
+ * per device is kept between calls (the analogue of the working memory a reference QPSolver object keeps,
+ * qp_solver.hpp:297-338); concurrent callers are not serialised.  sfb_host_staging_trim() frees what is kept. */
 sfb_status sfb_qp_dense_solve_batch_host(const sfb_qp_params *prm, int64_t batch, int n, int m,
                                          const double *P, const double *q, const double *A, const double *l,
                                          const double *u, const double *warm_x, const double *warm_y,
                                          double *x, double *y, double *obj, uint32_t *iter, int32_t *code);
+void sfb_host_staging_trim(void);
+/* ... and sharded over the device list (sfb_set_devices); same arguments, same results. */
+sfb_status sfb_qp_dense_solve_batch_host_multi(const sfb_qp_params *prm, int64_t batch, int n, int m,
+                                               const double *P, const double *q, const double *A, const double *l,
+                                               const double *u, const double *warm_x, const double *warm_y,
+                                               double *x, double *y, double *obj, uint32_t *iter, int32_t *code);
 
 /* ------------------------------------------------------------------------------------------
  * Sparse QPs sharing ONE sparsity pattern (a swarm of MPC problems from the same transcription).
@@ -265,11 +289,17 @@ sfb_status sfb_sparse_qp_solve_batch_ordered(sfb_sparse_qp_plan *plan, const sfb
                                              const int32_t *order, void *stream);
 /* Same with host pointers (synchronous).  The device buffers are owned by the plan and kept between calls
  * (grow-only, freed by sfb_sparse_qp_plan_destroy) -- the analogue of the working memory a QPSolver object
- * keeps between solves (qp_solver.hpp:242-338); host-pointer calls on ONE plan are serialised. */
+ * keeps between solves (qp_solver.hpp:242-338); host-pointer calls on ONE plan and ONE device are serialised. */
 sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
                                           const double *Px, const double *q, const double *Ax, const double *l,
                                           const double *u, const double *warm_x, const double *warm_y,
                                           double *x, double *y, double *obj, uint32_t *iter, int32_t *code);
+/* ... and sharded over the device list (sfb_set_devices): one contiguous shard, host thread, plan upload and workspace
+ * per device; same arguments, same results (calls on different devices are not serialised). */
+sfb_status sfb_sparse_qp_solve_batch_host_multi(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
+                                                const double *Px, const double *q, const double *Ax, const double *l,
+                                                const double *u, const double *warm_x, const double *warm_y,
+                                                double *x, double *y, double *obj, uint32_t *iter, int32_t *code);
 
 /* ------------------------------------------------------------------------------------------
  * Device-side MPC assembly and the device-resident swarm.

@@ -244,11 +244,18 @@ public:
       // the batch call shares the plan's host-side device workspace with solve(): whatever factor solve() left there is
       // gone, so the next solve() must not vouch for it (reuse_factor) even if it sees its old matrices again
       last_P_.clear(); last_A_.clear();
-      sfb_check(sfb_sparse_qp_solve_batch_host(holder_.plan, &c, B, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code));
+      sfb_check((multi_device_ ? sfb_sparse_qp_solve_batch_host_multi : sfb_sparse_qp_solve_batch_host)(
+        holder_.plan, &c, B, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code));
     } else {
-      sfb_check(sfb_qp_dense_solve_batch_host(&c, B, n_, m_, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code));
+      sfb_check((multi_device_ ? sfb_qp_dense_solve_batch_host_multi : sfb_qp_dense_solve_batch_host)(
+        &c, B, n_, m_, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code));
     }
   }
+  /// solve_batch() on every device of the process (sfb_set_devices, sfb.h): the batch is cut into contiguous shards,
+  /// one per device, each solved by its own host thread; same results as on one device.  The reference has no
+  /// counterpart (its batches are a sequential loop, benchmarks/bench_types.hpp:93).
+  void shard_over_devices(bool on) { multi_device_ = on; }
+  bool sharded_over_devices() const { return multi_device_; }
 
   /// solves that found the previous solve's matrices again and were flagged reuse_factor
   int64_t factor_reuse_count() const { return reuse_count_; }
@@ -274,6 +281,7 @@ private:
   std::vector<double> last_P_, last_A_;  // sparse: the matrices of the previous solve() (factor reuse)
   int64_t reuse_count_ = 0;
   detail::PinCount pins_;
+  bool multi_device_ = false;
   int n_ = 0, m_ = 0;
   Solution sol_;
 };

@@ -72,6 +72,7 @@ def _load():
     L.sfb_qp_params_default.restype = None
     L.sfb_qp_dense_solve_batch.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12 + [vp]
     L.sfb_qp_dense_solve_batch_host.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12
+    L.sfb_qp_dense_solve_batch_host_multi.argtypes = L.sfb_qp_dense_solve_batch_host.argtypes
     L.sfb_qp_dense_solve_batch_ws.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12 + [vp, vp]
     L.sfb_qp_dense_workspace_bytes.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32, C.POINTER(C.c_int64)]
     L.sfb_workspace_create.argtypes = [i64, C.POINTER(C.c_void_p)]
@@ -93,6 +94,7 @@ def _load():
     L.sfb_sparse_qp_solve_batch.argtypes = [C.c_void_p, C.POINTER(SfbQPParams), i64] + [dp] * 12 + [vp, vp]
     L.sfb_sparse_qp_solve_batch_ordered.argtypes = [C.c_void_p, C.POINTER(SfbQPParams), i64] + [dp] * 12 + [vp, vp, vp]
     L.sfb_sparse_qp_solve_batch_host.argtypes = [C.c_void_p, C.POINTER(SfbQPParams), i64] + [dp] * 12
+    L.sfb_sparse_qp_solve_batch_host_multi.argtypes = L.sfb_sparse_qp_solve_batch_host.argtypes
     L.sfb_ekf_predict_batch.argtypes = [i64, i32, dp, dp, i32, dp, i32, dp, vp]
     L.sfb_ekf_predict_stepper_batch.argtypes = [i32, i64, i32, dp, dp, i32, dp, i32, dp, vp]
     L.sfb_ekf_predict_stepper_batch_host.argtypes = [i32, i64, i32, dp, dp, i32, dp, i32, dp]
@@ -120,6 +122,9 @@ def _load():
     L.sfb_mpc_swarm_device_records.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     L.sfb_mpc_swarm_step_resident.argtypes = [vp, C.POINTER(SfbQPParams), i32, dp, dp, dp, dp, dp]
     L.sfb_mpc_swarm_debug_buffers.argtypes = [vp] + [C.POINTER(C.c_void_p)] * 3
+    L.sfb_set_devices.argtypes = [C.POINTER(C.c_int), i32]
+    L.sfb_get_devices.argtypes = [C.POINTER(C.c_int), i32, C.POINTER(C.c_int)]
+    L.sfb_host_staging_trim.restype = None
     L.sfb_random_qp_batch.argtypes = [C.c_uint32, i64, i32, i32, C.c_double] + [dp] * 5
     return L
 
@@ -136,3 +141,17 @@ def device_count():
     n = C.c_int(0)
     check(lib.sfb_device_count(C.byref(n)))
     return n.value
+
+
+def set_devices(devices=None):
+    """Device list of the *_multi entry points (None / empty: every visible device)."""
+    devices = list(devices or [])
+    arr = (C.c_int * max(1, len(devices)))(*devices)
+    check(lib.sfb_set_devices(arr if devices else None, len(devices)))
+
+
+def get_devices():
+    n = C.c_int(0)
+    arr = (C.c_int * 64)()
+    check(lib.sfb_get_devices(arr, 64, C.byref(n)))
+    return [arr[i] for i in range(min(n.value, 64))]

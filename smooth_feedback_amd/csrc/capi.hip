@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -247,9 +248,80 @@ sfb_status dense_via_sparse(const sfb_qp_params *prm, int64_t batch, int n, int 
 
 }  // namespace
 
+namespace sfb {
+namespace {
+std::mutex g_devices_mu;
+std::vector<int> g_devices;  // empty: all visible devices
+}  // namespace
+
+std::vector<int> device_list()
+{
+  {
+    std::lock_guard<std::mutex> lk(g_devices_mu);
+    if (!g_devices.empty()) return g_devices;
+  }
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess) {
+    (void)hipGetLastError();
+    cnt = 0;
+  }
+  std::vector<int> all((size_t)std::max(cnt, 0));
+  for (int d = 0; d < cnt; ++d) all[(size_t)d] = d;
+  return all;
+}
+
+sfb_status run_sharded(int64_t batch, const std::function<sfb_status(int, int64_t, int64_t)> &fn)
+{
+  const std::vector<int> devs = device_list();
+  if (devs.empty()) return fail(SFB_ERR_NO_DEVICE, "no HIP device (the sfb library has no CPU fallback)");
+  const int64_t G = (int64_t)devs.size();
+  std::vector<sfb_status> st((size_t)G, SFB_OK);
+  std::vector<std::string> msg((size_t)G);
+  std::vector<std::thread> th;
+  for (int64_t g = 0; g < G; ++g) {
+    const int64_t b0 = batch * g / G, b1 = batch * (g + 1) / G;  // contiguous shards
+    if (b1 == b0) continue;
+    th.emplace_back([&, g, b0, b1] {
+      hipError_t e = hipSetDevice(devs[(size_t)g]);
+      if (e != hipSuccess) st[(size_t)g] = hip_fail(e, "hipSetDevice");
+      else st[(size_t)g] = fn(devs[(size_t)g], b0, b1 - b0);
+      if (st[(size_t)g] != SFB_OK) msg[(size_t)g] = sfb_last_error();  // (thread-local: carried over by hand)
+    });
+  }
+  for (auto &t : th) t.join();
+  for (int64_t g = 0; g < G; ++g)
+    if (st[(size_t)g] != SFB_OK) return fail(st[(size_t)g], "device " + std::to_string(devs[(size_t)g]) + ": " + msg[(size_t)g]);
+  return SFB_OK;
+}
+}  // namespace sfb
+
 extern "C" {
 
 const char *sfb_version(void) { return "smooth_feedback_amd 0.1.0 (gfx950)"; }
+
+sfb_status sfb_set_devices(const int *devices, int count)
+{
+  if (count < 0 || (count > 0 && !devices)) return fail(SFB_ERR_INVALID_ARG, "bad device list");
+  int visible = 0;
+  if (hipGetDeviceCount(&visible) != hipSuccess) {
+    (void)hipGetLastError();
+    visible = 0;
+  }
+  for (int i = 0; i < count; ++i)
+    if (devices[i] < 0 || devices[i] >= visible) return fail(SFB_ERR_INVALID_ARG, "device ordinal out of range");
+  std::lock_guard<std::mutex> lk(sfb::g_devices_mu);
+  sfb::g_devices.assign(devices, devices + count);
+  return SFB_OK;
+}
+
+sfb_status sfb_get_devices(int *devices, int capacity, int *count)
+{
+  if (!count) return fail(SFB_ERR_INVALID_ARG, "count is NULL");
+  const std::vector<int> d = sfb::device_list();
+  *count = (int)d.size();
+  for (int i = 0; devices && i < capacity && i < (int)d.size(); ++i) devices[i] = d[(size_t)i];
+  return SFB_OK;
+}
 
 const char *sfb_last_error(void) { return sfb::g_last_error.c_str(); }
 
@@ -413,6 +485,68 @@ sfb_status sfb_workspace_info(const sfb_workspace *ws, void **device_ptr, int64_
   return SFB_OK;
 }
 
+}  // extern "C"
+
+namespace {
+struct HostStage {
+  char *mem;
+  size_t bytes;
+};
+std::mutex g_stage_mu;
+std::map<int, HostStage> g_stage;  // per device: the staging buffer kept between host-pointer calls
+HostStage host_stage_take(int dev)
+{
+  std::lock_guard<std::mutex> lk(g_stage_mu);
+  HostStage s = {nullptr, 0};
+  auto it = g_stage.find(dev);
+  if (it != g_stage.end()) { s = it->second; g_stage.erase(it); }
+  return s;
+}
+void host_stage_give(int dev, HostStage s)
+{
+  if (!s.mem) return;
+  HostStage drop = {nullptr, 0};
+  {
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    auto it = g_stage.find(dev);
+    if (it == g_stage.end()) g_stage[dev] = s;
+    else if (it->second.bytes < s.bytes) { drop = it->second; it->second = s; }  // keep the larger one
+    else drop = s;
+  }
+  if (drop.mem) (void)hipFree(drop.mem);
+}
+}  // namespace
+
+extern "C" {
+
+sfb_status sfb_qp_dense_solve_batch_host_multi(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P,
+                                               const double *q, const double *A, const double *l, const double *u,
+                                               const double *warm_x, const double *warm_y, double *x, double *y,
+                                               double *obj, uint32_t *iter, int32_t *code)
+{
+  sfb_status st = check_qp_args(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, code);
+  if (st != SFB_OK) return st;
+  if (batch == 0) return require_device();
+  const size_t N = (size_t)n, M = (size_t)m;
+  return sfb::run_sharded(batch, [&](int, int64_t b0, int64_t cnt) {
+    const size_t o = (size_t)b0;
+    return sfb_qp_dense_solve_batch_host(prm, cnt, n, m, P + o * N * N, q + o * N, A + o * M * N, l + o * M, u + o * M,
+                                         warm_x ? warm_x + o * N : nullptr, warm_y ? warm_y + o * M : nullptr, x + o * N,
+                                         y + o * M, obj ? obj + o : nullptr, iter ? iter + o : nullptr, code + o);
+  });
+}
+
+void sfb_host_staging_trim(void)
+{
+  std::map<int, HostStage> old;
+  {
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    old.swap(g_stage);
+  }
+  for (auto &kv : old)
+    if (kv.second.mem) (void)hipFree(kv.second.mem);
+}
+
 sfb_status sfb_qp_dense_solve_batch_host(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P,
                                          const double *q, const double *A, const double *l, const double *u,
                                          const double *warm_x, const double *warm_y, double *x, double *y,
@@ -427,28 +561,28 @@ sfb_status sfb_qp_dense_solve_batch_host(const sfb_qp_params *prm, int64_t batch
   const size_t B = (size_t)batch, N = (size_t)n, M = (size_t)m;
   const size_t in_d  = B * (N * N + N + M * N + 2 * M) + (warm_x ? B * (N + M) : 0);
   const size_t out_d = B * (N + M + 1);
-  // Staging memory of the host-pointer entry point, kept per device between calls (grow-only): ASIFilter solves ONE
-  // small QP per tick through here, and a hipMalloc / hipFree pair per call would dominate its latency.  Host-pointer
-  // calls are serialised by the lock (they are synchronous anyway).
-  static std::mutex stage_mu;
-  static std::map<int, std::pair<char *, size_t>> stage;
+  // Staging memory of the host-pointer entry point: ONE buffer per device is kept between calls (ASIFilter solves one
+  // small QP per tick through here, and a hipMalloc / hipFree pair per call would dominate its latency).  The lock is
+  // held only while the buffer is taken or handed back: concurrent callers do not serialise -- one of them gets the
+  // kept buffer, the others allocate their own for the call.  sfb_host_staging_trim() frees what is kept.
   const size_t bytes = (in_d + out_d) * sizeof(double) + B * (sizeof(uint32_t) + sizeof(int32_t));
   int devid          = 0;
   hipError_t e       = hipGetDevice(&devid);
   if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
-  std::lock_guard<std::mutex> stage_lock(stage_mu);
-  auto &cache = stage[devid];
-  if (cache.second < bytes) {
-    if (cache.first) (void)hipFree(cache.first);
-    cache = {nullptr, 0};
-    e     = hipMalloc(reinterpret_cast<void **>(&cache.first), bytes);
-    if (e != hipSuccess) {
-      cache = {nullptr, 0};
-      return hip_fail(e, "hipMalloc");
-    }
-    cache.second = bytes;
+  HostStage mine = host_stage_take(devid);
+  if (mine.bytes < bytes) {
+    if (mine.mem) (void)hipFree(mine.mem);
+    mine = {nullptr, 0};
+    e    = hipMalloc(reinterpret_cast<void **>(&mine.mem), bytes);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    mine.bytes = bytes;
   }
-  char *dev = cache.first;
+  struct Return {  // hand the buffer back on every exit path
+    int dev;
+    HostStage &s;
+    ~Return() { host_stage_give(dev, s); }
+  } ret{devid, mine};
+  char *dev = mine.mem;
 
   double *dP = reinterpret_cast<double *>(dev);
   double *dq = dP + B * N * N;

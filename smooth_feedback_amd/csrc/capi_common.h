@@ -2,7 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <functional>
 #include <string>
+#include <vector>
 
 #include "../../include/sfb.h"
 #include "qp_dense_kernel.h"
@@ -17,6 +19,12 @@ DenseKernelParams make_kernel_params(const sfb_qp_params *prm, int n, int m);
 // breakdown and the outcome): one summary of the call -- phase times, status histogram, iteration statistics.
 void verbose_report(const char *what, int64_t batch, int n, int m, double h2d_ms, double solve_ms, double d2h_ms,
                     const int32_t *code, const uint32_t *iter);
+// Multi-device entry points (sfb_*_multi): the device list of sfb_set_devices (default: every visible device), and a
+// helper that cuts [0, batch) into one contiguous shard per list entry and runs `fn(device, first, count)` for every
+// non-empty shard on its own host thread with that device current.  Returns the first failure (its message becomes
+// this thread's sfb_last_error).
+std::vector<int> device_list();
+sfb_status run_sharded(int64_t batch, const std::function<sfb_status(int device, int64_t first, int64_t count)> &fn);
 struct SparsePlanHost;
 const SparsePlanHost &plan_host(const sfb_sparse_qp_plan *plan);  // capi_sparse.hip: the pattern the kernel works on
 const SparsePlanHost &plan_io(const sfb_sparse_qp_plan *plan);    // the caller's pattern (== plan_host unless pruned)

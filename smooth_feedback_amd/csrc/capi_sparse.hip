@@ -30,10 +30,14 @@ struct sfb_sparse_qp_plan {
   // Device memory of the host-pointer entry point, kept between calls like the working memory a
   // smooth::feedback::QPSolver object keeps between solves (qp_solver.hpp:242-338): a swarm that ticks at
   // a fixed batch size allocates its ~1.3 MB per agent once, not every tick.  Guarded by host_mu (calls
-  // with host pointers on one plan are serialised; device-pointer calls bring their own workspace).
-  std::mutex host_mu;
-  std::map<int, std::pair<char *, size_t>> host_ws;  // device ordinal -> (buffer, bytes)
-  std::map<int, int64_t> host_batch;  // device ordinal -> batch of the last call whose workspace content is still in the buffer
+  // with host pointers on one plan AND one device are serialised; calls on different devices -- the shards of
+  // sfb_sparse_qp_solve_batch_host_multi -- run side by side; device-pointer calls bring their own workspace).
+  struct HostDev {
+    std::mutex mu;
+    std::pair<char *, size_t> ws{nullptr, 0};  // (buffer, bytes)
+    int64_t batch = -1;                        // batch of the last call whose workspace content is still in the buffer
+  };
+  std::map<int, HostDev> host_dev;  // device ordinal -> state; entries are created under `mu` and never move
 };
 
 namespace sfb {
@@ -138,6 +142,7 @@ WsLayout ws_layout(const sfb_sparse_qp_plan *plan, int64_t batch)
   size_t pool  = 0;
   if (plan->pruned) {
     const sfb::SparsePlanHost &f = plan->full;
+    // pool of whole-pattern slots: min(batch, 64); the kernel is told the same count and probes the flags modulo it
     pool = (size_t)std::min<int64_t>(batch, sfb::qp_sparse_fallback_slots()) *
            sfb::qp_sparse_ws_doubles(f.n, f.m, f.nnzL, f.funits, f.bunits, 0) * sizeof(double);
   }
@@ -196,8 +201,11 @@ sfb_status sfb_sparse_qp_plan_create_pruned(int n, int m, const int32_t *P_colpt
   if (!p) return sfb::fail(SFB_ERR_INVALID_ARG, "out of memory");
   const char *msg = "";
   bool any_masked = false;
-  if (A_keep && n >= 1 && m >= 1 && A_rowptr && A_rowptr[0] == 0 && A_rowptr[m] >= 0)
-    for (int e = 0; e < A_rowptr[m] && !any_masked; ++e) any_masked = A_keep[e] == 0;
+  if (A_keep && n >= 1 && m >= 1 && A_rowptr && A_rowptr[0] == 0 && A_rowptr[m] >= 0) {
+    bool monotone = true;  // A_keep has A_rowptr[m] entries only if the row pointers are what they claim to be
+    for (int r = 0; r < m && monotone; ++r) monotone = A_rowptr[r + 1] >= A_rowptr[r] && A_rowptr[r + 1] <= A_rowptr[m];
+    for (int e = 0; monotone && e < A_rowptr[m] && !any_masked; ++e) any_masked = A_keep[e] == 0;
+  }
   if (!any_masked) {
     if (!sfb::build_sparse_plan(n, m, P_colptr, P_rowind, A_rowptr, A_colind, ordering, user_perm, stage, p->host, &msg)) {
       delete p;
@@ -206,8 +214,13 @@ sfb_status sfb_sparse_qp_plan_create_pruned(int n, int m, const int32_t *P_colpt
     *plan = p;
     return SFB_OK;
   }
-  // compressed pattern of A: the kept entries, in storage order
+  // compressed pattern of A: the kept entries, in storage order.  (The pattern is read here BEFORE build_sparse_plan
+  // validates it, so the checks the loop below relies on come first.)
   const int nnzA = A_rowptr[m];
+  if (nnzA > 0 && !A_colind) {
+    delete p;
+    return sfb::fail(SFB_ERR_INVALID_ARG, "A_colind is NULL");
+  }
   std::vector<int32_t> Ap(m + 1, 0), Aj;
   Aj.reserve(nnzA);
   for (int r = 0; r < m; ++r) {
@@ -216,7 +229,10 @@ sfb_status sfb_sparse_qp_plan_create_pruned(int n, int m, const int32_t *P_colpt
       return sfb::fail(SFB_ERR_INVALID_ARG, "A row pointers not monotone");
     }
     for (int e = A_rowptr[r]; e < A_rowptr[r + 1]; ++e)
-      if (A_keep[e]) {
+      if (A_colind[e] < 0 || A_colind[e] >= n) {
+        delete p;
+        return sfb::fail(SFB_ERR_INVALID_ARG, "A column index out of range");
+      } else if (A_keep[e]) {
         Aj.push_back(A_colind[e]);
         p->Aorig.push_back(e);
       } else {
@@ -248,8 +264,8 @@ void sfb_sparse_qp_plan_destroy(sfb_sparse_qp_plan *plan)
     if (kv.second.blob) (void)hipFree(kv.second.blob);
     if (kv.second.blob_full) (void)hipFree(kv.second.blob_full);
   }
-  for (auto &kv : plan->host_ws)
-    if (kv.second.first) (void)hipFree(kv.second.first);
+  for (auto &kv : plan->host_dev)
+    if (kv.second.ws.first) (void)hipFree(kv.second.ws.first);
   delete plan;
 }
 
@@ -353,8 +369,13 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
   int devid    = 0;
   hipError_t e = hipGetDevice(&devid);
   if (e != hipSuccess) return sfb::hip_fail(e, "hipGetDevice");
-  std::lock_guard<std::mutex> host_lock(plan->host_mu);
-  auto &cache = plan->host_ws[devid];
+  sfb_sparse_qp_plan::HostDev *hd = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(plan->mu);
+    hd = &plan->host_dev[devid];
+  }
+  std::lock_guard<std::mutex> host_lock(hd->mu);
+  auto &cache = hd->ws;
   if (cache.second < bytes) {  // grow-only
     if (cache.first) (void)hipFree(cache.first);
     cache = {nullptr, 0};
@@ -364,13 +385,13 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
       return sfb::hip_fail(e, "hipMalloc");
     }
     cache.second = bytes;
-    plan->host_batch[devid] = -1;
+    hd->batch    = -1;
   }
   // reuse_factor refers to "the previous call on this workspace": the workspace sits at the start of the cached
   // buffer, so it is the same memory, item for item, exactly when the batch size is that of the previous call
   sfb_qp_params prm_call = *prm;
-  if (plan->host_batch[devid] != batch) prm_call.reuse_factor = 0;
-  plan->host_batch[devid] = batch;
+  if (hd->batch != batch) prm_call.reuse_factor = 0;
+  hd->batch = batch;
   prm = &prm_call;
   char *devmem = cache.first;
   double *dws = reinterpret_cast<double *>(devmem);
@@ -422,6 +443,35 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
                         iter ? iter : (itv.empty() ? nullptr : itv.data()));
   }
   return st;
+}
+
+
+sfb_status sfb_sparse_qp_solve_batch_host_multi(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
+                                                const double *Px, const double *q, const double *Ax, const double *l,
+                                                const double *u, const double *warm_x, const double *warm_y, double *x,
+                                                double *y, double *obj, uint32_t *iter, int32_t *code)
+{
+  sfb_status st = check_sparse_args(plan, prm, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, code);
+  if (st != SFB_OK) return st;
+  if (batch == 0) return sfb::require_device();
+  const sfb::SparsePlanHost &h = sfb::plan_io(plan);
+  const size_t N = (size_t)h.n, M = (size_t)h.m, NP = (size_t)h.nnzP, NA = (size_t)h.nnzA;
+  // reuse_factor refers to "the previous call on this device's workspace": with a device listed twice two shards
+  // share one workspace, and the claim cannot be kept
+  sfb_qp_params prm_call = *prm;
+  {
+    std::vector<int> d = sfb::device_list();
+    std::sort(d.begin(), d.end());
+    if (std::adjacent_find(d.begin(), d.end()) != d.end()) prm_call.reuse_factor = 0;
+  }
+  prm = &prm_call;
+  return sfb::run_sharded(batch, [&](int, int64_t b0, int64_t cnt) {
+    const size_t o = (size_t)b0;  // the plan uploads its tables to a device on first use; each device has its own workspace
+    return sfb_sparse_qp_solve_batch_host(plan, prm, cnt, Px ? Px + o * NP : nullptr, q + o * N, Ax ? Ax + o * NA : nullptr,
+                                          l + o * M, u + o * M, warm_x ? warm_x + o * N : nullptr,
+                                          warm_y ? warm_y + o * M : nullptr, x + o * N, y + o * M, obj ? obj + o : nullptr,
+                                          iter ? iter + o : nullptr, code + o);
+  });
 }
 
 }  // extern "C"

@@ -1512,7 +1512,7 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev *_
                                                        const int lean_waves, const int32_t *__restrict__ order,
                                                        int32_t *__restrict__ queue, const int batch, const uint32_t slice,
                                                        const SparsePlanDev *__restrict__ plf, double *__restrict__ gwsf,
-                                                       const size_t wsf_doubles, int32_t *__restrict__ fbflags, const int phase)
+                                                       const size_t wsf_doubles, int32_t *__restrict__ fbflags, const int phase, const int nfb)
 {
   extern __shared__ __attribute__((aligned(16))) double t[];  // work / solution vector, factorisation scratch
   // The plan (some forty pointers) is read from device memory where it is used: as a by-value kernel argument it
@@ -1558,7 +1558,7 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev *_
     int fbslot = -1;
     if (plf != nullptr && !resume && phase <= PH_SETUP && !sp_guard_ok(*plp, gAx + (size_t)item * (size_t)uni(plp->nnzA_io), lane)) {
       if (lane == 0) {
-        for (int probe = blockIdx.x % kFbSlots;; probe = (probe + 1) % kFbSlots) {
+        for (int probe = blockIdx.x % nfb;; probe = (probe + 1) % nfb) {  // nfb = slots the pool really has
           if (atomicCAS(&fbflags[probe], 0, 1) == 0) { fbslot = probe; break; }
           __builtin_amdgcn_s_sleep(8);
         }
@@ -1666,7 +1666,7 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     hipLaunchKernelGGL(qp_sparse_kernel, dim3(g), dim3(kWave), lds, stream, pl.self, kp, Px, q, Ax, l, u, wx, wy, x, y, obj, iter,
                        code, workspace, wsd, lw, order, qa, (int)batch, (uint32_t)std::max(1, slice),
                        pruned ? fallback->self : nullptr, fallback_ws, pruned ? qp_sparse_ws_doubles(*fallback) : 0,
-                       aux ? aux + batch + kQRing : nullptr, phase);
+                       aux ? aux + batch + kQRing : nullptr, phase, (int)std::min<int64_t>(batch, kFbSlots));
     return hipGetLastError();
   };
   if (!phased) return launch(grid, qarg, lean_waves, PH_ALL);

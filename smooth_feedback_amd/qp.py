@@ -111,9 +111,10 @@ def pack_colmajor(M):
     return np.ascontiguousarray(np.transpose(M, (0, 2, 1)).reshape(M.shape[0], -1))
 
 
-def solve_qp_batch_host(P, q, A, l, u, prm: Optional[QPSolverParams] = None, warm_x=None, warm_y=None):
+def solve_qp_batch_host(P, q, A, l, u, prm: Optional[QPSolverParams] = None, warm_x=None, warm_y=None, multi_device=False):
     """Batched solve_qp on host numpy buffers.  P (B, n*n) and A (B, m*n) are COLUMN-major flat
-    buffers (see pack_colmajor), q (B,n), l,u (B,m).  Calls sfb_qp_dense_solve_batch_host."""
+    buffers (see pack_colmajor), q (B,n), l,u (B,m).  Calls sfb_qp_dense_solve_batch_host, or with multi_device the
+    variant that shards the batch over the device list (_capi.set_devices)."""
     q = np.ascontiguousarray(q, dtype=np.float64)
     l = np.ascontiguousarray(l, dtype=np.float64)
     if q.ndim != 2 or l.ndim != 2:
@@ -134,7 +135,8 @@ def solve_qp_batch_host(P, q, A, l, u, prm: Optional[QPSolverParams] = None, war
     it = np.empty(B, dtype=np.uint32)
     code = np.empty(B, dtype=np.int32)
     cp = (prm or QPSolverParams()).to_c()
-    _capi.check(_capi.lib.sfb_qp_dense_solve_batch_host(
+    fn = _capi.lib.sfb_qp_dense_solve_batch_host_multi if multi_device else _capi.lib.sfb_qp_dense_solve_batch_host
+    _capi.check(fn(
         C.byref(cp), B, n, m, _ptr(P), _ptr(q), _ptr(A), _ptr(l), _ptr(u), _ptr(warm_x), _ptr(warm_y),
         _ptr(x), _ptr(y), _ptr(obj), _ptr(it), _ptr(code)))
     return QPBatchSolution(code=code, iter=it, primal=x, dual=y, objective=obj)
@@ -333,8 +335,9 @@ class SparseQPPlan:
         except Exception:
             pass
 
-    def solve_batch_host(self, Px, q, Ax, l, u, prm: Optional[QPSolverParams] = None, warm_x=None, warm_y=None):
-        """sfb_sparse_qp_solve_batch_host: Px (B, nnzP), q (B, n), Ax (B, nnzA), l,u (B, m)."""
+    def solve_batch_host(self, Px, q, Ax, l, u, prm: Optional[QPSolverParams] = None, warm_x=None, warm_y=None,
+                         multi_device=False):
+        """sfb_sparse_qp_solve_batch_host[_multi]: Px (B, nnzP), q (B, n), Ax (B, nnzA), l,u (B, m)."""
         q = np.ascontiguousarray(q, dtype=np.float64)
         B = q.shape[0]
         Px = _f64(np.reshape(Px, (B, self.nnzP)), (B, self.nnzP))
@@ -347,7 +350,8 @@ class SparseQPPlan:
         x = np.empty((B, self.n)); y = np.empty((B, self.m)); obj = np.empty(B)
         it = np.empty(B, dtype=np.uint32); code = np.empty(B, dtype=np.int32)
         cp = (prm or QPSolverParams()).to_c()
-        _capi.check(_capi.lib.sfb_sparse_qp_solve_batch_host(
+        fn = _capi.lib.sfb_sparse_qp_solve_batch_host_multi if multi_device else _capi.lib.sfb_sparse_qp_solve_batch_host
+        _capi.check(fn(
             self._h, C.byref(cp), B, _ptr(Px), _ptr(q), _ptr(Ax), _ptr(l), _ptr(u), _ptr(warm_x), _ptr(warm_y),
             _ptr(x), _ptr(y), _ptr(obj), _ptr(it), _ptr(code)))
         return QPBatchSolution(code=code, iter=it, primal=x, dual=y, objective=obj)
