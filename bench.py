@@ -447,6 +447,58 @@ def secondary_line(sfb, workload, device, steps=3):
     return rec
 
 
+DENSE_SIZES = [(10, 20), (16, 32), (20, 40), (32, 32), (32, 64), (40, 60), (64, 64)]
+
+
+def dense_sizes_table(sfb, device, cores):
+    """The north star's size class (dense QPs with n <= 64) beyond the one size of BASELINE configs[1]: random QPs of
+    benchmarks/bench_types.hpp:19-41 at several (n, m), under the reference benchmark's parameters (bench.cpp:148-153)
+    and under the library defaults (max_iter 10 000 in both).  Device-resident, HIP-event timed.  QP-iterations/s is
+    quoted next to QP/s because iteration counts differ by orders of magnitude between sizes and parameter sets (and
+    a single QP that runs into max_iter on its own wave sets the time of a batch of fast ones).  Kernels: n + m <= 32
+    four QPs per wave (qp_dense4), <= 64 one per wave with the factor in registers / LDS (qp_dense), <= 128 one per
+    wave with the packed factor in LDS and the iterate in registers (qp_dense_big, packed engine)."""
+    from oracle import loader as O
+    rows = []
+    for n, m in DENSE_SIZES:
+        k = n + m
+        B = 8192 if k <= 32 else (4096 if k <= 64 else 2048)
+        P, q, A, l, u = sfb.random_qp_batch(5, B, m, n, 1.0)
+        d = [torch.from_numpy(a).to(device) for a in (P, q, A, l, u)]
+        f64 = dict(dtype=torch.float64, device=device)
+        x, y, obj = torch.empty((B, n), **f64), torch.empty((B, m), **f64), torch.empty(B, **f64)
+        out = torch.empty((2, B), dtype=torch.int32, device=device)
+        stream = torch.cuda.current_stream()
+        for name, prm, okw in (("reference_benchmark", sfb.QPSolverParams(eps_abs=1e-6, eps_rel=1e-6, polish=True, max_iter=10000, scaling=False),
+                                dict(eps_abs=1e-6, eps_rel=1e-6, polish=1, max_iter=10000, scaling=0)),
+                               ("library_defaults", sfb.QPSolverParams(max_iter=10000), dict(max_iter=10000))):
+            def go():
+                sfb.solve_qp_batch_device(B, n, m, *[a.data_ptr() for a in d], x.data_ptr(), y.data_ptr(), obj.data_ptr(),
+                                          out[0].data_ptr(), out[1].data_ptr(), prm, stream=stream.cuda_stream)
+            go(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream); go(); e1.record(stream); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            it = out[0].cpu().numpy().astype(np.int64); code = out[1].cpu().numpy()
+            S = min(B, 128)
+            ref = O.qp_dense_solve_batch(P[:S], q[:S], A[:S], l[:S], u[:S], params=O.default_params(**okw), nthreads=cores)
+            fin = np.isfinite(ref["x"]).all(axis=1)
+            opt = code == 0
+            na = n + m / 2.0
+            flops = (k ** 3 / 3.0 + it * (2 * k * k + 10 * m + 3 * n) + np.ceil(it / 25.0) * (4 * n * n + 8 * m * n)
+                     + opt * (na ** 3 / 3.0 + 15 * na * na)).sum()
+            rows.append({"n": n, "m": m, "params": name, "batch": B, "ms": ms, "qp_per_s": B / ms * 1e3,
+                         "qp_iterations_per_s": float(it.sum()) / ms * 1e3, "iterations": {"mean": float(it.mean()), "max": int(it.max())},
+                         "codes": np.bincount(code, minlength=7).tolist(),
+                         "roofline_alt": {"bound": "fp64_valu", "achieved": flops / (ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK / 1e12,
+                                          "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / FP64_VALU_PEAK},
+                         "parity_vs_oracle": {"sample": S, "code_mismatches": int((code[:S] != ref["code"]).sum()),
+                                              "iter_mismatches": int((it[:S] != ref["iter"]).sum()),
+                                              "max_abs_dx": float(np.abs(x[:S].cpu().numpy() - ref["x"])[fin].max(initial=0.0))}})
+        del d, x, y, obj, out
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -586,6 +638,7 @@ def main():
             del wl  # free the headline workload's device memory first
             torch.cuda.empty_cache()
             rec["secondary"] = {w: secondary_line(sfb, w, device) for w in sorted(WORKLOADS) if w != args.workload}
+            rec["secondary"]["qp_dense_sizes"] = dense_sizes_table(sfb, device, host_cpus()[0])
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.barrier()

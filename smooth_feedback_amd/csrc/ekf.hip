@@ -17,6 +17,7 @@
 #include <cmath>
 
 #include "../../include/sfb.h"
+#include "../../include/smooth_feedback_amd/detail/ekf_lane.hpp"
 #include "ekf_kernel.h"
 #include "ldlt_wave.h"
 #include "wave_util.h"
@@ -25,202 +26,7 @@ namespace sfb {
 
 namespace {
 
-typedef double vd2 __attribute__((ext_vector_type(2)));
-
-// ---- coalesced tile I/O: 64 items x W doubles, contiguous in HBM, one item per lane in LDS ----
-template<int W>
-__device__ __forceinline__ void tile_load(const double *__restrict__ g, int64_t item0, int64_t nitems, double *lds,
-                                          int lane)
-{
-  constexpr int WP = W | 1;  // odd stride: conflict-free per-lane walks
-  const int total  = (int)(nitems - item0 < kWave ? nitems - item0 : kWave) * W;
-  const double *src = g + item0 * W;
-  // all global loads first (independent, one wait), then the LDS scatter
-  if constexpr (W % 2 == 0) {
-    constexpr int W2 = W / 2;  // 16-byte loads; a pair never straddles two items
-    // (non-temporal: every byte of the batch is touched exactly once per launch)
-    const vd2 *src2 = reinterpret_cast<const vd2 *>(src);
-    vd2 v[W2];
-#pragma unroll
-    for (int c = 0; c < W2; ++c) {
-      const int idx = c * kWave + lane;
-      v[c]          = (2 * idx < total) ? __builtin_nontemporal_load(&src2[idx]) : vd2{0.0, 0.0};
-    }
-#pragma unroll
-    for (int c = 0; c < W2; ++c) {
-      const int idx = 2 * (c * kWave + lane);
-      const int o   = (idx / W) * WP + (idx % W);
-      lds[o]        = v[c].x;
-      lds[o + 1]    = v[c].y;
-    }
-  } else {
-    double v[W];
-#pragma unroll
-    for (int c = 0; c < W; ++c) {
-      const int idx = c * kWave + lane;
-      v[c]          = (idx < total) ? __builtin_nontemporal_load(&src[idx]) : 0.0;
-    }
-#pragma unroll
-    for (int c = 0; c < W; ++c) {
-      const int idx = c * kWave + lane;
-      lds[(idx / W) * WP + (idx % W)] = v[c];
-    }
-  }
-}
-template<int W>
-__device__ __forceinline__ void tile_store(double *__restrict__ g, int64_t item0, int64_t nitems, const double *lds,
-                                           int lane)
-{
-  constexpr int WP = W | 1;
-  const int total  = (int)(nitems - item0 < kWave ? nitems - item0 : kWave) * W;
-  double *dst      = g + item0 * W;
-  if constexpr (W % 2 == 0) {
-    constexpr int W2 = W / 2;
-    vd2 *dst2        = reinterpret_cast<vd2 *>(dst);
-#pragma unroll
-    for (int c = 0; c < W2; ++c) {
-      const int i2  = c * kWave + lane;
-      const int idx = 2 * i2;
-      const int o   = (idx / W) * WP + (idx % W);
-      if (idx < total) __builtin_nontemporal_store(vd2{lds[o], lds[o + 1]}, &dst2[i2]);
-    }
-  } else {
-#pragma unroll
-    for (int c = 0; c < W; ++c) {
-      const int idx = c * kWave + lane;
-      if (idx < total) __builtin_nontemporal_store(lds[(idx / W) * WP + (idx % W)], &dst[idx]);
-    }
-  }
-}
-
-// ---- pivoted LDL' of a tiny symmetric matrix, fully unrolled (static register indices) ----
-// W lower (row-major W[i][j], j <= i).  Same algorithm/ordering as oracle_ldlt_factor.
-template<int M>
-struct SmallLdlt {
-  double W[M][M];
-  int tr[M];
-  bool ok;
-
-  __device__ __forceinline__ void swap_rc(int kk, int p)  // symmetric swap kk <-> p (p > kk), static loops
-  {
-#pragma unroll
-    for (int pc = 1; pc < M; ++pc) {
-      if (pc == p) {
-#pragma unroll
-        for (int kc = 0; kc < M - 1; ++kc) {
-          if (kc == kk && kc < pc) {
-#pragma unroll
-            for (int t = 0; t < M; ++t)
-              if (t < kc) { const double a = W[kc][t]; W[kc][t] = W[pc][t]; W[pc][t] = a; }
-#pragma unroll
-            for (int i = 0; i < M; ++i)
-              if (i > pc) { const double a = W[i][kc]; W[i][kc] = W[i][pc]; W[i][pc] = a; }
-            { const double a = W[kc][kc]; W[kc][kc] = W[pc][pc]; W[pc][pc] = a; }
-#pragma unroll
-            for (int i = 0; i < M; ++i)
-              if (i > kc && i < pc) { const double a = W[i][kc]; W[i][kc] = W[pc][i]; W[pc][i] = a; }
-          }
-        }
-      }
-    }
-  }
-
-  __device__ __forceinline__ void factor()
-  {
-    ok = true;
-    if constexpr (M == 1) {
-      tr[0] = 0;
-      return;
-    }
-    bool found_zero = false, finished = false;
-    double temp[M];
-#pragma unroll
-    for (int kk = 0; kk < M; ++kk) {
-      if (!finished) {
-        int p       = kk;
-        double best = fabs(W[kk][kk]);
-#pragma unroll
-        for (int i = kk + 1; i < M; ++i) {
-          const double a = fabs(W[i][i]);
-          if (a > best) { best = a; p = i; }
-        }
-        tr[kk] = p;
-        if (p != kk) swap_rc(kk, p);
-        if (kk > 0) {
-#pragma unroll
-          for (int j = 0; j < kk; ++j) temp[j] = W[j][j] * W[kk][j];
-          double s = 0.0;
-#pragma unroll
-          for (int j = 0; j < kk; ++j) s = fma(W[kk][j], temp[j], s);
-          W[kk][kk] -= s;
-#pragma unroll
-          for (int i = kk + 1; i < M; ++i) {
-            double t = 0.0;
-#pragma unroll
-            for (int j = 0; j < kk; ++j) t = fma(W[i][j], temp[j], t);
-            W[i][kk] -= t;
-          }
-        }
-        const double akk = W[kk][kk];
-        const bool valid = fabs(akk) > 0.0;
-        if (kk == 0 && !valid) {
-#pragma unroll
-          for (int j = 0; j < M; ++j) {
-            tr[j] = j;
-#pragma unroll
-            for (int i = j + 1; i < M; ++i) ok = ok && (W[i][j] == 0.0);
-          }
-          finished = true;
-        } else {
-          if (valid) {
-#pragma unroll
-            for (int i = kk + 1; i < M; ++i) W[i][kk] /= akk;
-          } else {
-#pragma unroll
-            for (int i = kk + 1; i < M; ++i) ok = ok && (W[i][kk] == 0.0);
-          }
-          if (found_zero && valid) ok = false;
-          else if (!valid) found_zero = true;
-        }
-      }
-    }
-  }
-
-  __device__ __forceinline__ void solve(double (&b)[M]) const  // P b, L^-1, D^-1 (|d|<=DBL_MIN -> 0), L^-T, P^T
-  {
-#pragma unroll
-    for (int i = 0; i < M; ++i) {
-#pragma unroll
-      for (int pc = 0; pc < M; ++pc)
-        if (pc > i && tr[i] == pc) { const double a = b[i]; b[i] = b[pc]; b[pc] = a; }
-    }
-#pragma unroll
-    for (int i = 0; i < M; ++i) {
-      double s = b[i];
-#pragma unroll
-      for (int j = 0; j < i; ++j) s = fma(-W[i][j], b[j], s);
-      b[i] = s;
-    }
-#pragma unroll
-    for (int i = 0; i < M; ++i) {
-      const double d = W[i][i];
-      b[i]           = (fabs(d) > DBL_MIN) ? b[i] / d : 0.0;
-    }
-#pragma unroll
-    for (int i = M - 1; i >= 0; --i) {
-      double s = b[i];
-#pragma unroll
-      for (int j = M - 1; j > i; --j) s = fma(-W[j][i], b[j], s);
-      b[i] = s;
-    }
-#pragma unroll
-    for (int i = M - 1; i >= 0; --i) {
-#pragma unroll
-      for (int pc = 0; pc < M; ++pc)
-        if (pc > i && tr[i] == pc) { const double a = b[i]; b[i] = b[pc]; b[pc] = a; }
-    }
-  }
-};
+using namespace ekf_lane;  // tile I/O, SmallLdlt and the per-lane predict / update (include/smooth_feedback_amd/detail/ekf_lane.hpp)
 
 }  // namespace
 
@@ -256,24 +62,9 @@ __global__ void __launch_bounds__(64) ekf_kernel(const EkfArgs a)
       wave_sync();
     }
     const double dt = live ? (a.dt_shared ? a.dt[0] : a.dt[item]) : 0.0;
-    double Pn[NN];
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-#pragma unroll
-      for (int i = 0; i <= j; ++i) {
-        double m1 = 0.0, m2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < N; ++k) m1 = fma(A[i + k * N], P[k + j * N], m1);
-#pragma unroll
-        for (int k = 0; k < N; ++k) m2 = fma(P[i + k * N], A[j + k * N], m2);
-        const double q = a.q_shared ? a.Q[i + j * N] : (live ? lds[lane * NP + i + j * N] : 0.0);
-        const double s = (m1 + m2) + q;  // ekf.hpp:88, upper triangle mirrored
-        Pn[i + j * N]  = P[i + j * N] + dt * s;
-        if (i != j) Pn[j + i * N] = P[j + i * N] + dt * s;
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < NN; ++e) P[e] = Pn[e];
+    ekf_lane_predict<N>(P, A, [&](const int i, const int j) {
+      return a.q_shared ? a.Q[i + j * N] : (live ? lds[lane * NP + i + j * N] : 0.0);
+    }, dt);
     wave_sync();
   }
 
@@ -286,93 +77,29 @@ __global__ void __launch_bounds__(64) ekf_kernel(const EkfArgs a)
     for (int e = 0; e < MN; ++e) H[e] = live ? lds[lane * MNP + e] : 0.0;
     wave_sync();
 
-    double T[MN], HP[MN];  // H * symU(P), H * P   (ekf.hpp:129, :134)
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-#pragma unroll
-      for (int aa = 0; aa < M; ++aa) {
-        double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < N; ++k) s1 = fma(H[aa + k * M], (k <= j) ? P[k + j * N] : P[j + k * N], s1);
-#pragma unroll
-        for (int k = 0; k < N; ++k) s2 = fma(H[aa + k * M], P[k + j * N], s2);
-        T[aa + j * M]  = s1;
-        HP[aa + j * M] = s2;
-      }
-    }
-    SmallLdlt<M> F;
-    {
-      constexpr int MM = M * M, MMP = MM | 1;
-      if (!a.r_shared) {
-        tile_load<MM>(a.R, item0, a.batch, lds, lane);
-        wave_sync();
-      }
-#pragma unroll
-      for (int b = 0; b < M; ++b) {
-#pragma unroll
-        for (int aa = 0; aa < M; ++aa) {
-          if (aa <= b) {
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < N; ++k) s = fma(T[aa + k * M], H[b + k * M], s);
-            const double rr = a.r_shared ? a.R[aa + b * M] : (live ? lds[lane * MMP + aa + b * M] : ((aa == b) ? 1.0 : 0.0));
-            F.W[b][aa]      = s + rr;
-          } else {
-            F.W[b][aa] = 0.0;
-          }
-        }
-      }
+    // R of this item in registers (upper part), then the per-lane update
+    constexpr int MM = M * M, MMP = MM | 1;
+    if (!a.r_shared) {
+      tile_load<MM>(a.R, item0, a.batch, lds, lane);
       wave_sync();
     }
-    F.factor();
-    double X[MN];  // S^-1 (H P), column by column
+    double Rv[MM];
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-      double col[M];
+    for (int b = 0; b < M; ++b) {
 #pragma unroll
-      for (int aa = 0; aa < M; ++aa) col[aa] = HP[aa + j * M];
-      F.solve(col);
-#pragma unroll
-      for (int aa = 0; aa < M; ++aa) X[aa + j * M] = col[aa];
+      for (int aa = 0; aa < M; ++aa)
+        Rv[aa + b * M] = (aa <= b) ? (a.r_shared ? a.R[aa + b * M] : (live ? lds[lane * MMP + aa + b * M] : ((aa == b) ? 1.0 : 0.0))) : 0.0;
     }
-    // delta = K r, K = X'   (:137)
-    double rv[M];
+    wave_sync();
+    double rv[M], delta[N];
 #pragma unroll
     for (int aa = 0; aa < M; ++aa) rv[aa] = live ? a.r[item * M + aa] : 0.0;
+    const bool ok = ekf_lane_update<N, M>(P, H, [&](const int aa, const int b) { return Rv[aa + b * M]; }, rv, delta);
+    if (live) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      double s = 0.0;
-#pragma unroll
-      for (int aa = 0; aa < M; ++aa) s = fma(X[aa + i * M], rv[aa], s);
-      if (live) a.delta[item * N + i] = s;
+      for (int i = 0; i < N; ++i) a.delta[item * N + i] = delta[i];
     }
-    if (a.info != nullptr && live) a.info[item] = F.ok ? 0 : 1;
-    // P = symU((I - K H) P)   (:138)
-    double IK[NN];
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        double s = 0.0;
-#pragma unroll
-        for (int aa = 0; aa < M; ++aa) s = fma(X[aa + i * M], H[aa + k * M], s);
-        IK[i + k * N] = ((i == k) ? 1.0 : 0.0) - s;
-      }
-    }
-    double Pn[NN];
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-#pragma unroll
-      for (int i = 0; i <= j; ++i) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < N; ++k) s = fma(IK[i + k * N], P[k + j * N], s);
-        Pn[i + j * N] = s;
-        Pn[j + i * N] = s;
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < NN; ++e) P[e] = Pn[e];
+    if (a.info != nullptr && live) a.info[item] = ok ? 0 : 1;
   }
 
   // ---- write P back (coalesced through LDS) ----

@@ -182,6 +182,11 @@ __global__ void __launch_bounds__(64, SFB_QP_WAVES_PER_EU) qp_dense_kernel(const
     wave_lds_fence();
   }
 
+  if constexpr (MODE == SWEEP_READLANE_LDS) {  // the zero slot of the pipelined backward sweep (nothing in the loop writes s.temp)
+    if (lane == 0) s.temp[k - 1] = 0.0;
+    wave_lds_fence();
+  }
+
   // ---- ADMM loop :447-510 ----
   uint32_t iter        = 0;
   const uint32_t sci   = kp.stop_check_iter;
@@ -226,9 +231,22 @@ __global__ void __launch_bounds__(64, SFB_QP_WAVES_PER_EU) qp_dense_kernel(const
         t               = fma(-Lc[j], tj, t);
       }
     } else {
-      for (int j = k - 1; j > 0; --j) {
-        const double tj = lane_bcast(t, j);
-        const double lj = (lane < j) ? s.W[tri(j, lane)] : 0.0;
+      // L' from LDS (row j of the packed factor, one entry per lane).  The loads do not depend on the chain: they are
+      // issued PF steps ahead of their use, so that only [v_readlane -> v_fma] is left on the dependent path (a rolled
+      // loop waits for every load: one LDS latency per step, measured 4 x slower at k = 60).  Steps j >= k and lanes
+      // >= j read the zero slot: exact no-ops on finite data, like the zero-padded registers of the forward sweep.
+      constexpr int PF = 6;
+      const int zidx = (int)(s.temp - s.W) + k - 1;  // s.temp[k-1]: kept at 0.0 for the whole loop (see below)
+      auto lidx = [&](const int J) { return (lane < J && J < k) ? tri(J, lane) : zidx; };
+      double pf[PF];
+#pragma unroll
+      for (int e = 0; e < PF; ++e) pf[e] = s.W[lidx(KP - 1 - e)];
+#pragma unroll
+      for (int J = KP - 1; J > 0; --J) {
+        const int slot  = (KP - 1 - J) % PF;
+        const double lj = pf[slot];
+        if (J - PF > 0) pf[slot] = s.W[lidx(J - PF)];
+        const double tj = (J < k) ? lane_bcast(t, J < k ? J : 0) : 0.0;
         t               = fma(-lj, tj, t);
       }
     }

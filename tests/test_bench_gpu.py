@@ -77,7 +77,12 @@ def test_default_line_carries_the_secondary_workloads():
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
     assert d["config"]["workload"].startswith("mpc_qp_nx12_nu2_K50_b8192")
-    assert set(d["secondary"]) == {"qp_dense", "ekf"}
+    assert set(d["secondary"]) == {"qp_dense", "ekf", "qp_dense_sizes"}
+    sizes = d["secondary"].pop("qp_dense_sizes")
+    assert {(r["n"], r["m"]) for r in sizes} == {(10, 20), (16, 32), (20, 40), (32, 32), (32, 64), (40, 60), (64, 64)}
+    for r in sizes:   # every size of the north star's class: measured, and bit-identical to the oracle on its sample
+        assert r["qp_per_s"] > 0 and r["parity_vs_oracle"] == {"sample": r["parity_vs_oracle"]["sample"], "code_mismatches": 0,
+                                                                "iter_mismatches": 0, "max_abs_dx": 0.0}
     for k, v in d["secondary"].items():
         assert v["value"] > 0 and {"bound", "achieved", "peak", "frac", "traffic", "kernel_ms"} <= set(v["roofline"])
         assert "cpu_baseline" in v and "parity_vs_oracle" in v
