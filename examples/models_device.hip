@@ -81,13 +81,22 @@ int ekf_swarm(int64_t batch, int steps, int fused, double tau, double dt, const 
     std::copy(P0 + 36 * b, P0 + 36 * (b + 1), P[b].a.begin());
   }
   swarm.reset(g, P);
+  swarm.one_launch(fused != 2);  // fused: 1 = step() in one launch, 2 = step() as separate launches, 3 = 1 with resident measurements
+  double * dy = nullptr;
+  if (fused == 3) {
+    if (hipMalloc(reinterpret_cast<void **>(&dy), (size_t)steps * batch * 24) != hipSuccess) return -3;
+    (void)hipMemcpy(dy, y, (size_t)steps * batch * 24, hipMemcpyHostToDevice);
+  }
   const auto Q = sfbx::vehicle_ekf_Q();
   const auto R = sfbx::vehicle_ekf_R();
   std::vector<Vec<3>> ys((size_t)batch);
   for (int k = 0; k < steps; ++k) {
     for (int64_t b = 0; b < batch; ++b) ys[b] = {y[((size_t)k * batch + b) * 3], y[((size_t)k * batch + b) * 3 + 1], y[((size_t)k * batch + b) * 3 + 2]};
     const auto t0 = std::chrono::steady_clock::now();
-    if (fused) {
+    if (fused == 3) {  // measurements already on the device: copied device-to-device into the swarm's buffer
+      (void)hipMemcpy(swarm.device_measurements(), dy + (size_t)k * batch * 3, (size_t)batch * 24, hipMemcpyDeviceToDevice);
+      swarm.step_resident(Q, tau, R);
+    } else if (fused) {
       swarm.step(Q, tau, ys, R);
     } else {
       swarm.predict(Q, tau, dt > 0 ? std::optional<double>(dt) : std::nullopt);
@@ -96,6 +105,7 @@ int ekf_swarm(int64_t batch, int steps, int fused, double tau, double dt, const 
     (void)hipDeviceSynchronize();
     if (seconds) seconds[k] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
+  if (dy) (void)hipFree(dy);
   g = swarm.estimates();
   P = swarm.covariances();
   const auto inf = swarm.update_info();

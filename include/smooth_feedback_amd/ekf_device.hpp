@@ -22,6 +22,7 @@
 #include <string>
 #include <vector>
 
+#include "detail/ekf_lane.hpp"
 #include "ekf.hpp"
 
 namespace smooth_feedback_amd {
@@ -75,6 +76,66 @@ __global__ void __launch_bounds__(64) ekf_apply_kernel(const int64_t B, G * __re
   typename G::Tangent d;
   for (int i = 0; i < G::Dof; ++i) d[i] = delta[b * G::Dof + i];
   g[b] = rplus(g[b], d);  // ekf.hpp:137
+}
+
+// One predict substep (Euler, ekf.hpp:84-97) followed by the update (:116-139) of every filter in ONE launch: a lane
+// linearises the dynamics at its estimate, steps its covariance (registers), steps the estimate, linearises the
+// measurement at the new estimate, runs the Kalman update and applies g (+) delta -- the covariance crosses HBM once in
+// each direction, A / H / r / delta never leave the registers.  Same helper functions and the same per-lane covariance
+// arithmetic (detail/ekf_lane.hpp) as the separate launches: identical results.
+template<class G, class Dyn, class Meas, int Ny>
+__global__ void __launch_bounds__(64) ekf_step_fused_kernel(const int64_t B, const Dyn f, const Meas hfn, const double t, const double h,
+                                                            const Mat<G::Dof, G::Dof> Q, const Mat<Ny, Ny> R, G * __restrict__ g,
+                                                            const double * __restrict__ y, double * __restrict__ Pg,
+                                                            int32_t * __restrict__ info)
+{
+  namespace L = sfb::ekf_lane;
+  constexpr int N = G::Dof, NN = N * N, NP = NN | 1;
+  __shared__ double lds[NP * L::kLanes];
+  const int lane      = threadIdx.x;
+  const int64_t item0 = (int64_t)blockIdx.x * L::kLanes, b = item0 + lane;
+  const bool live     = b < B;
+  double P[NN];
+  L::tile_load<NN>(Pg, item0, B, lds, lane);
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < NN; ++e) P[e] = live ? lds[lane * NP + e] : 0.0;
+  __syncthreads();
+  G x = live ? g[b] : G::Identity();
+  bool ok = true;
+  {
+    typename G::Tangent fv;
+    const Mat<N, N> A0 = ekf_linearise_dyn<G>([&](const G & xx) { return f(t, xx); }, x, fv);
+    double A[NN];
+#pragma unroll
+    for (int e = 0; e < NN; ++e) A[e] = A0.a[e];
+    L::ekf_lane_predict<N>(P, A, [&](const int i, const int j) { return Q.a[i + j * N]; }, live ? h : 0.0);
+    for (auto & v : fv) v *= h;
+    x = rplus(x, fv);  // ekf.hpp:97
+  }
+  {
+    Vec<Ny> yb, rb;
+    for (int i = 0; i < Ny; ++i) yb[i] = live ? y[b * Ny + i] : 0.0;
+    Mat<Ny, N> Hm{};
+    ekf_linearise_meas<Ny>(hfn, x, yb, Hm, rb);
+    double H[Ny * N], rv[Ny], delta[N];
+#pragma unroll
+    for (int e = 0; e < Ny * N; ++e) H[e] = Hm.a[e];
+#pragma unroll
+    for (int i = 0; i < Ny; ++i) rv[i] = rb[i];
+    ok = L::ekf_lane_update<N, Ny>(P, H, [&](const int a, const int c) { return (a <= c) ? R.a[a + c * Ny] : 0.0; }, rv, delta);
+    typename G::Tangent d;
+    for (int i = 0; i < N; ++i) d[i] = delta[i];
+    x = rplus(x, d);  // ekf.hpp:137
+  }
+  if (live) {
+    g[b]    = x;
+    info[b] = ok ? 0 : 1;
+#pragma unroll
+    for (int e = 0; e < NN; ++e) lds[lane * NP + e] = P[e];
+  }
+  __syncthreads();
+  L::tile_store<NN>(Pg, item0, B, lds, lane);
 }
 
 inline void ekf_hip_check(hipError_t e, const char * what)
@@ -176,6 +237,9 @@ public:
     apply();
   }
 
+  /// step(): everything of a round in ONE launch (default), or linearisation / covariance / state launches one after
+  /// the other on resident buffers (the path predict() and update() take); same results
+  void one_launch(bool on) { one_launch_ = on; }
   /// predict(Q, tau) with ONE substep followed by update(y, R): same results, the covariance is read and written once
   void step(const CovT & Q, double tau, const std::vector<Vec<Ny>> & y, const Mat<Ny, Ny> & R)
   {
@@ -187,6 +251,10 @@ public:
     if constexpr (Stp != EKFStepper::Euler) {
       predict(Q, tau);
       update_resident(R);
+    } else if (one_launch_) {
+      hipLaunchKernelGGL((detail::ekf_step_fused_kernel<G, Dyn, Meas, Ny>), grid(), dim3(64), 0, nullptr, B_, f_, h_, 0.0, tau, Q, R, g_, y_, P_,
+                         info_);
+      detail::ekf_hip_check(hipGetLastError(), "ekf_step_fused_kernel");
     } else {
       upload_small(Q_, Q.a.data(), (size_t)N * N);
       upload_small(R_, R.a.data(), (size_t)Ny * Ny);
@@ -239,6 +307,7 @@ private:
   Dyn f_;
   Meas h_;
   int64_t B_;
+  bool one_launch_ = true;
   double * mem_ = nullptr;
   double *P_ = nullptr, *A_ = nullptr, *Am_ = nullptr, *Ae_ = nullptr, *H_ = nullptr, *y_ = nullptr, *r_ = nullptr, *delta_ = nullptr;
   double *Q_ = nullptr, *R_ = nullptr, *dt_ = nullptr;

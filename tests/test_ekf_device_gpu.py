@@ -34,6 +34,21 @@ def test_fused_step_equals_predict_then_update():
     assert np.array_equal(a["states"], b["states"]) and np.array_equal(a["P"], b["P"])
 
 
+def test_one_launch_round_equals_the_separate_launches():
+    """step() runs linearisation, covariance step, state step, Kalman update and g (+) delta of a round in ONE kernel
+    (P crosses HBM once each way; A, H, r, delta stay in registers); the same round as four launches on resident
+    buffers, or with the measurements already on the device, gives the same bits."""
+    st, P0, y = M.ekf_swarm_inputs(3000, 5, seed=4)
+    one = M.ekf_swarm_device(st, P0, y, tau=0.05, fused=1)
+    four = M.ekf_swarm_device(st, P0, y, tau=0.05, fused=2)
+    res = M.ekf_swarm_device(st, P0, y, tau=0.05, fused=3)
+    plain = M.ekf_swarm_device(st, P0, y, tau=0.05, fused=0)
+    for other in (four, res, plain):
+        assert np.array_equal(one["states"], other["states"]) and np.array_equal(one["P"], other["P"])
+        assert np.array_equal(one["info"], other["info"])
+    assert np.max(np.abs(one["states"] - st)) > 1e-3
+
+
 def test_covariances_stay_symmetric_and_positive():
     st, P0, y = M.ekf_swarm_inputs(512, 6, seed=9)
     r = M.ekf_swarm_device(st, P0, y, tau=0.1, dt=0.025)
