@@ -11,8 +11,9 @@ st, P0, y = M.ekf_swarm_inputs(batch, steps, seed=1)
 for name, kw in (("one-launch round, measurements resident", dict(fused=3)), ("one-launch round (Euler, 1 substep)", dict(fused=1)), ("round as 4 launches", dict(fused=2)), ("predict + update (Euler)", dict()),
                  ("predict(dt = tau/4) + update (Euler)", dict(dt=0.025)), ("predict + update (RK4)", dict(rk4=True))):
     r = M.ekf_swarm_device(st, P0, y, tau=0.1, **kw)
-    s = np.median(r["seconds"][1:])
-    print(f"{name:40s} {1e3 * s:8.3f} ms per round of {batch} filters ({"measurements already on the device" if kw.get("fused") == 3 else "measurement upload included"}) = {batch / s / 1e6:8.1f} M filter-rounds/s")
+    s_ = np.median(r["seconds"][1:])
+    where = "measurements already on the device" if kw.get("fused") == 3 else "measurement upload included"
+    print(f"{name:40s} {1e3 * s_:8.3f} ms per round of {batch} filters ({where}) = {batch / s_ / 1e6:8.1f} M filter-rounds/s")
 nb = 64
 t0 = time.perf_counter()
 M.ekf_swarm_host(st[:nb], P0[:nb], y[:, :nb], tau=0.1)
