@@ -358,7 +358,7 @@ WORKLOADS = {"mpc": MPCWorkload, "qp_dense": DenseQPWorkload, "ekf": EKFWorkload
 # The sparse kernel mixes 16-byte streams (factor, vectors) with 8-byte gathers (factorisation, checks): x2 is exact
 # for the former (~85 % of its reads) and over-counts the latter, so its traffic figure is an upper bound (~ +10 %).
 FETCH_CORRECTION = {"mpc": 2.0, "ekf": 2.0, "qp_dense": 1.0 / 0.58}
-PROFILE_TAG = "r2"
+PROFILE_TAG = "r3"
 FP64_VALU_PEAK = 78.6e12  # MI355X vector FP64 (half the 157.3 TFLOP/s FP32 vector rate of MI355X_MICROARCH.md)
 
 
