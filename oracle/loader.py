@@ -173,7 +173,7 @@ def _ip(a):
 
 
 def qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Ax, l, u, perm=None, params=None, warm_x=None, warm_y=None,
-                          nthreads=1, forder=None):
+                          nthreads=1, forder=None, trace_rows=0):
     """Sparse branch.  P CSC (Pp, Pi) with values Px (B, nnzP); A CSR (Ap, Aj) with values Ax (B, nnzA).
     perm: elimination order of the (n+m) KKT unknowns (new -> old) or None (natural).
     forder: accumulation order of the numeric factorisation (rank of every permuted column) or None (postorder of
@@ -200,14 +200,22 @@ def qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Ax, l, u, perm=None, params=Non
     if forder is not None:
         forder = np.ascontiguousarray(forder, dtype=np.int32)
         assert sorted(forder.tolist()) == list(range(n + m))
+    trace = None
+    if trace_rows:  # the verbose table of qp_solver.hpp:490-501 as data: (ITER, OBJ, PRI_RES, DUA_RES) per check
+        trace = np.full((B, int(trace_rows), 4), -1.0)
+        lib().oracle_qp_sparse_set_trace.argtypes = [C.POINTER(C.c_double), C.c_int]
+        lib().oracle_qp_sparse_set_trace.restype = None
+        lib().oracle_qp_sparse_set_trace(_dp(trace), int(trace_rows))
     rc = lib().oracle_qp_sparse_solve_batch_ordered(
         C.byref(p), B, n, m, _ip(Pp), _ip(Pi), _dp(Px), _dp(q), _ip(Ap), _ip(Aj), _dp(Ax), _dp(l), _dp(u),
         _ip(perm), _ip(forder), _dp(warm_x), _dp(warm_y), _dp(x), _dp(y), _dp(obj),
         it.ctypes.data_as(C.POINTER(C.c_uint32)), code.ctypes.data_as(C.POINTER(C.c_int32)), int(nthreads),
         C.byref(nnzL))
+    if trace_rows:
+        lib().oracle_qp_sparse_set_trace(None, 0)
     if rc != 0:
         raise RuntimeError("oracle_qp_sparse_solve_batch failed rc=%d" % rc)
-    return dict(x=x, y=y, obj=obj, iter=it, code=code, nnzL=nnzL.value)
+    return dict(x=x, y=y, obj=obj, iter=it, code=code, nnzL=nnzL.value, trace=trace)
 
 
 def ekf_predict_batch(A, Q, dt, P, stepper="euler", A_mid=None, A_end=None):

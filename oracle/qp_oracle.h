@@ -106,6 +106,13 @@ int oracle_qp_sparse_solve_batch_ordered(const oracle_qp_params *prm, int64_t ba
                                          int32_t *code, int nthreads, int64_t *nnzL_out);
 
 /*
+ * The reference's verbose table (qp_solver.hpp:409-420, :490-501) as data instead of text: while a trace buffer is
+ * set, the sparse batch calls record one row (ITER, OBJ, PRI_RES, DUA_RES) per stopping check of every item into
+ * trace[batch][cap][4]; unused rows have ITER = -1.  Process-global; clear with (NULL, 0).
+ */
+void oracle_qp_sparse_set_trace(double *trace, int cap);
+
+/*
  * Restatement of Eigen 3.4 LDLT (unblocked, diagonal pivoting) exposed for unit tests.
  * W: k*k row-major work matrix, lower triangle (incl. diagonal) holds the symmetric input on
  * entry and L (unit, strictly lower) + D (diagonal) on exit.  tr[k]: transpositions.

@@ -279,7 +279,16 @@ typedef struct {
   double *x_us, *dx_us, *Pxv, *Aty, *Axv, *y_us, *z_us, *dy_us;
   double *Kval, *Lx, *D, *Dinv, *work;
   double *primal, *dual;
+  double *trace; /* verbose table (qp_solver.hpp:490-501), one row (iter, obj, pri_res, dua_res) per stopping check */
+  int trace_cap, trace_rows;
 } sp_work;
+
+/* The rows of the reference's verbose table (qp_solver.hpp:409-420 header, :490-501 rows) instead of printing them:
+ * trace[batch][cap][4] = (ITER, OBJ, PRI_RES, DUA_RES) of every stopping check, rows beyond the last check hold
+ * ITER = -1.  Process-global switch (test infrastructure; set before a batch call, cleared with NULL). */
+static double *g_trace   = NULL;
+static int g_trace_cap   = 0;
+void oracle_qp_sparse_set_trace(double *trace, int cap) { g_trace = trace; g_trace_cap = cap; }
 
 static double norm_inf(const double *v, int len)
 {
@@ -505,7 +514,8 @@ static int sp_polish(sp_work *w, const sp_aux *aux) /* qp_solver.hpp:92-204, spa
 
 static int sp_solve_one(const sp_shared *sh, const sp_aux *aux, const oracle_qp_params *prm, const double *Px,
                         const double *q, const double *Ax, const double *l, const double *u, const double *warm_x,
-                        const double *warm_y, double *x, double *y, double *obj, uint32_t *iter_out, int32_t *code_out)
+                        const double *warm_y, double *x, double *y, double *obj, uint32_t *iter_out, int32_t *code_out,
+                        double *trace, int trace_cap)
 {
   const ksym *s = sh->s;
   const int n = sh->n, m = sh->m, k = s->k;
@@ -513,6 +523,8 @@ static int sp_solve_one(const sp_shared *sh, const sp_aux *aux, const oracle_qp_
   sp_work *w = &W;
   memset(w, 0, sizeof(*w));
   w->sh = sh; w->prm = *prm; w->Px = Px; w->q = q; w->Ax = Ax; w->l = l; w->u = u;
+  w->trace = trace; w->trace_cap = trace_cap;
+  for (int r = 0; trace && r < trace_cap; ++r) trace[4 * r] = -1.0;
   const size_t nd = (size_t)(6 * n + 10 * m + 5 * k) + (size_t)s->nnzK + (size_t)s->nnzL + 16;
   double *mem     = (double *)calloc(nd, sizeof(double));
   if (!mem) return -1;
@@ -588,6 +600,17 @@ static int sp_solve_one(const sp_shared *sh, const sp_aux *aux, const oracle_qp_
       for (int j = 0; j < n; ++j) w->dx_us[j] = w->sx[j] * (w->primal[j] - w->dx_us[j]);
       for (int i = 0; i < m; ++i) w->dy_us[i] = w->sy[i] * (w->dual[i] - w->dy_us[i]) / w->c;
       ret_code = sp_check_stopping(w);
+      if (w->trace && w->trace_rows < w->trace_cap) { /* :490-501, the three columns in the reference's expressions */
+        double *row = w->trace + 4 * (size_t)w->trace_rows++;
+        double o = 0.0, pri = 0.0, dua = 0.0;
+        sp_mv_P(w, w->x_us, w->Pxv);
+        for (int j = 0; j < n; ++j) o += (0.5 * w->Pxv[j] + q[j]) * w->x_us[j];
+        sp_mv_A(w, w->x_us, w->Axv);
+        for (int i = 0; i < m; ++i) pri = dmax(pri, fabs(w->Axv[i] - w->z_us[i]));
+        sp_mv_At(w, w->y_us, w->Aty);
+        for (int j = 0; j < n; ++j) dua = dmax(dua, fabs(w->Pxv[j] + q[j] + w->Aty[j]));
+        row[0] = (double)iter; row[1] = o; row[2] = pri; row[3] = dua;
+      }
       if (ret_code < 0 && prm->max_time_ns >= 0) { /* :504-507 */
         struct timespec t1;
         clock_gettime(CLOCK_MONOTONIC, &t1);
@@ -632,7 +655,8 @@ static void *sp_worker(void *arg)
     int rc = sp_solve_one(j->sh, j->aux, j->prm, j->Px + sb * (size_t)j->nnzP, j->q + sb * n,
                           j->Ax + sb * (size_t)j->nnzA, j->l + sb * m, j->u + sb * m,
                           j->wx ? j->wx + sb * n : NULL, j->wy ? j->wy + sb * m : NULL, j->x + sb * n,
-                          j->y + sb * m, j->obj ? j->obj + sb : NULL, j->iter ? j->iter + sb : NULL, j->code + sb);
+                          j->y + sb * m, j->obj ? j->obj + sb : NULL, j->iter ? j->iter + sb : NULL, j->code + sb,
+                          g_trace ? g_trace + 4 * sb * (size_t)g_trace_cap : NULL, g_trace_cap);
     if (rc) j->rc = rc;
   }
   return NULL;

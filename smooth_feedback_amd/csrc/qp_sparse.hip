@@ -57,7 +57,11 @@ constexpr int kHdrStamp = 6, kHdrC = 7, kHdrSigma = 8, kHdrScaling = 9;
 constexpr int kHdrCode = 10, kHdrComplete = 11;
 [[maybe_unused]] constexpr int kHdrTl2 = 12;
 // what one launch does with an item
-enum { PH_ALL = 0, PH_SETUP = 1, PH_ADMM = 2, PH_FINISH = 3 };
+enum { PH_SETUP = 1, PH_ADMM = 2, PH_FINISH = 3 };
+// A launch performs the phases ph0 .. ph1 of every item it visits (packed into one kernel argument together with the
+// pause point, see qp_sparse_launch): [SETUP, FINISH] = everything.
+constexpr int phases_pack(int ph0, int ph1, unsigned pause_at = 0) { return ph0 | (ph1 << 4) | (int)(pause_at << 8); }
+constexpr int PH_EVERYTHING = phases_pack(PH_SETUP, PH_FINISH);
 constexpr unsigned long long kFactorStamp = 0x5FB0FAC7A11CE5EDull;
 
 __device__ __forceinline__ Ws carve_ws(double *base, int n, int m, int nnzL, int funits, int bunits)
@@ -608,12 +612,15 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
   // lean == false (few waves left on the chip: latency matters, HBM traffic does not): every block issues plain loads
   static_assert(DEPTH <= kSweepPadDev && kSweepPadDev % DEPTH == 0, "schedule padding must cover the prefetch distance");
   static_assert(2 * DEPTH <= 62, "vmcnt is a 6-bit counter");
-  static_assert(DEPTH <= 8, "two value pointers cover 8 units of 1 KB with 12-bit offsets");
-  // per-lane stream pointers (VGPRs): values of units d < 4 / d >= 4 of a block, indices of all units
-  const vdouble2 *vp0 = reinterpret_cast<const vdouble2 *>(vals) + lane;
-  const vdouble2 *vp1 = vp0 + 4 * kWave;
-  const vint2 *ip     = reinterpret_cast<const vint2 *>(idx) + lane;
-  static_assert(DEPTH == 8, "one scalar load fetches the lane-mask shifts of a block of 8 units");
+  static_assert(DEPTH == 8 || (DEPTH == 16 && !LEAN), "one scalar load fetches the lane-mask shifts of a block of 8 units");
+  // per-lane stream pointers (VGPRs): one per 4 units of values (1 KB each) and per 8 units of indices (12-bit offsets)
+  constexpr int NVP = DEPTH / 4, NIP = DEPTH / 8;
+  const vdouble2 *vp[NVP];
+  const vint2 *ip[NIP];
+#pragma unroll
+  for (int e = 0; e < NVP; ++e) vp[e] = reinterpret_cast<const vdouble2 *>(vals) + lane + e * 4 * kWave;
+#pragma unroll
+  for (int e = 0; e < NIP; ++e) ip[e] = reinterpret_cast<const vint2 *>(idx) + lane + e * 8 * kWave;
   vdouble2 lx[DEPTH];
   vint2 ix[DEPTH];
 #pragma unroll
@@ -623,20 +630,16 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
   // MODE 0: plain cached loads (latency mode); 1: non-temporal loads (full units, bandwidth mode); 2: non-temporal
   // loads masked to the lanes that carry slots (partially filled units, bandwidth mode)
   auto issue = [&]<int D, int MODE>(std::integral_constant<int, D>, std::integral_constant<int, MODE>, const sint8 &mk) {
-    if constexpr (MODE == 2) {
-      if constexpr (D < 4) stream_load_masked<D * kWave * 16>(lx[D], vp0, mk[D]);
-      else stream_load_masked<(D - 4) * kWave * 16>(lx[D], vp1, mk[D]);
-    } else {
-      if constexpr (D < 4) stream_load<D * kWave * 16, MODE == 1>(lx[D], vp0);
-      else stream_load<(D - 4) * kWave * 16, MODE == 1>(lx[D], vp1);
-    }
-    stream_load<D * kWave * 8>(ix[D], ip);
+    if constexpr (MODE == 2) stream_load_masked<(D % 4) * kWave * 16>(lx[D], vp[D / 4], mk[D % 8]);
+    else stream_load<(D % 4) * kWave * 16, MODE == 1>(lx[D], vp[D / 4]);
+    stream_load<(D % 8) * kWave * 8>(ix[D], ip[D / 8]);
   };
   auto for_units = [&]<int... D>(std::integer_sequence<int, D...>, auto &&fn) { (fn(std::integral_constant<int, D>{}), ...); };
-  auto advance = [&] {
-    vp0 += DEPTH * kWave;
-    vp1 += DEPTH * kWave;
-    ip += DEPTH * kWave;
+  auto advance = [&](const int by) {
+#pragma unroll
+    for (int e = 0; e < NVP; ++e) vp[e] += by * kWave;
+#pragma unroll
+    for (int e = 0; e < NIP; ++e) ip[e] += by * kWave;
   };
   sint8 mk;  // mask shifts of the units the current block issues
   {  // the table pointer as a scalar (it may live in a VGPR lane after register spilling)
@@ -654,7 +657,7 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
     for_units(std::make_integer_sequence<int, DEPTH>{},
               [&]<int D>(std::integral_constant<int, D> dd) { issue(dd, std::integral_constant<int, 0>{}, mk); });
   }
-  advance();
+  advance(DEPTH);
   // (tgt, piv) of the two slots of a unit as byte offsets (BYTEOFF, plan.idx_scale == 8) or element indices
   struct Addr { unsigned t0, p0, t1, p1; };
   auto extract = [](const vint2 &v) { const unsigned a = (unsigned)v.x, b = (unsigned)v.y; return Addr{a & 0xFFFFu, a >> 16, b & 0xFFFFu, b >> 16}; };
@@ -682,7 +685,7 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
       issue(dd, msk, mk);  // unit u0 + D + DEPTH (always inside the padded arrays)
       cur = nxt;
     });
-    advance();
+    advance(DEPTH);
   };
   // blocks whose TARGETS [u0 + DEPTH, u0 + 2 DEPTH) lie inside the full run issue unmasked loads
   const int r0 = max(0, min(units, full0 - DEPTH)), r1 = max(r0, min(units, full1 - DEPTH));
@@ -692,7 +695,12 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
     for (; u0 < r1; u0 += DEPTH) block(std::integral_constant<int, 1>{}, u0);
     for (; u0 < units; u0 += DEPTH) block(std::integral_constant<int, 2>{}, u0);
   } else {
-    for (; u0 < units; u0 += DEPTH) block(std::integral_constant<int, 0>{}, u0);
+    for (; u0 < units; u0 += DEPTH) {
+      // `units` is a multiple of 8 and the arrays carry 16 units of padding: the last block of a 16-deep pipeline may
+      // start 8 units before the end -- its prefetches (never consumed) are pulled back into the padding
+      if (DEPTH == 16 && u0 + DEPTH > units) advance(-8);
+      block(std::integral_constant<int, 0>{}, u0);
+    }
   }
   // the trailing prefetches (padding) are never consumed: retire them before their registers are reused
 #pragma unroll
@@ -701,6 +709,8 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
 }
 
 // t (LDS, permuted order) <- K^-1 t   (qp_solver.hpp:457-459)
+// SD: prefetch distance of the cacheable (latency) form of the sweeps, 8 or 16 units
+template<int SD>
 __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, double *t, const int lane, const bool lean)
 {
   const int k = uni(pl.k);
@@ -710,8 +720,8 @@ __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, doubl
       if (bo) sweep_dev<SFB_SWEEP_DEPTH, true, true>(idx, units, vals, t, lane, mask, f0, f1);
       else sweep_dev<SFB_SWEEP_DEPTH, false, true>(idx, units, vals, t, lane, mask, f0, f1);
     } else {
-      if (bo) sweep_dev<SFB_SWEEP_DEPTH, true, false>(idx, units, vals, t, lane, mask, f0, f1);
-      else sweep_dev<SFB_SWEEP_DEPTH, false, false>(idx, units, vals, t, lane, mask, f0, f1);
+      if (bo) sweep_dev<SD, true, false>(idx, units, vals, t, lane, mask, f0, f1);
+      else sweep_dev<SD, false, false>(idx, units, vals, t, lane, mask, f0, f1);
     }
   };
   sweep(pl.fidx, uni(pl.funits), w.LxF, pl.fmask, uni(pl.ffull0), uni(pl.ffull1));  // forward (column oriented order)
@@ -783,8 +793,10 @@ __device__ __forceinline__ double sp_row_P(const SparsePlanDev &pl, const Item &
 // t: LDS scratch (the work vector is free between the update phase of one iteration and the right-hand side of
 // the next).  The two order-dependent scalar sums of the test (:607-621, :633) are fed from LDS: their inputs
 // are fetched by all lanes in parallel, chunk by chunk, and only the dependent add / fma chain is sequential.
+// score (nullable): how far the item is from its tolerances at this check -- residual / tolerance of the primal test,
+// or of the dual test when the primal one passes -- the launcher's predictor of the iterations that are left.
 __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it, const Ws &w,
-                                        const DenseKernelParams &kp, double *t, const int lane)
+                                        const DenseKernelParams &kp, double *t, const int lane, float *score = nullptr)
 {
   const int n = uni(pl.n), m = uni(pl.m);
   const double inf = INFINITY;
@@ -798,6 +810,7 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
       z = fmax(z, fabs(zi));
     }
     const double Ax_norm = wave_max(a), r_norm = wave_max(r), z_norm = wave_max(z);
+    if (score != nullptr && lane == 0) *score = (float)(r_norm / (kp.eps_abs + kp.eps_rel * fmax(Ax_norm, z_norm)));
     if (r_norm <= kp.eps_abs + kp.eps_rel * fmax(Ax_norm, z_norm)) {
       double pn = 0.0, qn = 0.0, an = 0.0, rn = 0.0;
       for (int j = lane; j < n; j += kWave) {
@@ -807,8 +820,9 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
         an = fmax(an, fabs(Aty));
         rn = fmax(rn, fabs(Px + (qj + Aty)));
       }
-      const double dual_scale = fmax(fmax(wave_max(pn), wave_max(qn)), wave_max(an));
-      if (wave_max(rn) <= kp.eps_abs + kp.eps_rel * dual_scale) return SFB_QP_OPTIMAL;
+      const double dual_scale = fmax(fmax(wave_max(pn), wave_max(qn)), wave_max(an)), rn_norm = wave_max(rn);
+      if (rn_norm <= kp.eps_abs + kp.eps_rel * dual_scale) return SFB_QP_OPTIMAL;
+      if (score != nullptr && lane == 0) *score = (float)(rn_norm / (kp.eps_abs + kp.eps_rel * dual_scale));
     }
   }
   {  // PRIMAL INFEASIBILITY: max(|A'dy|, certificate sum) < thr.  The cheap certificate sum is formed first and
@@ -876,6 +890,7 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
 
 // detail::polish_qp (sparse), embedded in the full pattern.  In/out: scaled xs / ys in the workspace.
 // wf: the workspace view whose factor fields the polish factorisation may overwrite (w itself, or polish_ws(w))
+template<int SD>
 __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const Ws &w, const Ws &wf, const DenseKernelParams &kp,
                                  double *t, const double c, const int lane, const bool lean)
 {
@@ -969,7 +984,7 @@ __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const 
       t[pl.pinv[n + rr]] = h - acc;
     }
     wave_sync();
-    ldl_solve_dev(pl, wf, t, lane, lean);
+    ldl_solve_dev<SD>(pl, wf, t, lane, lean);
     for (int e = lane; e < k; e += kWave) w.tv[e] += t[pl.pinv[e]];
     wave_sync();
   }
@@ -987,7 +1002,7 @@ __device__ int g_sparse_active = 0;  // resident waves of qp_sparse_kernel (all 
 //   q[kQRing + i]  ring entries (item + 1, 0 = empty), capacity = batch
 constexpr int kQFresh = 0, kQHead = 16, kQTail = 32, kQRing = 48;
 
-enum { SP_DONE = 0, SP_SUSPENDED = 2 };
+enum { SP_DONE = 0, SP_SUSPENDED = 2, SP_PAUSED = 3 };
 
 // GUARD of a pruned plan: the entries of A the plan's creator declared zero must be zero in this item (NaN counts
 // as non-zero).  Amasked is padded: branch-free batches.
@@ -1013,6 +1028,7 @@ __device__ __forceinline__ bool sp_guard_ok(const SparsePlanDev &pl, const doubl
 // resume == true: continue an item another block has suspended (its state is in its workspace).
 // Runs until the item is finished (SP_DONE), or -- time-sliced launches only, queue != nullptr -- until the item
 // has used its slice while others are waiting for a wave (SP_SUSPENDED: state saved, the caller queues the item).
+template<int SD>
 __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const DenseKernelParams &kp, const double *__restrict__ gPx,
                                              const double *__restrict__ gq, const double *__restrict__ gAx,
                                              const double *__restrict__ gl, const double *__restrict__ gu,
@@ -1022,8 +1038,10 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
                                              double *__restrict__ gws, const size_t ws_doubles, const int lean_waves,
                                              bool lean, const size_t b, const size_t slot, double *t, const int lane,
                                              bool resume, const int32_t *queue, const int batch,
-                                             const uint32_t slice, const bool allow_reuse, const int phase)
+                                             const uint32_t slice, const bool allow_reuse, const int phases, float *score)
 {
+  const int ph0 = phases & 15, ph1 = (phases >> 4) & 15;  // the phases this launch performs
+  const uint32_t pause_at = (uint32_t)phases >> 8;        // != 0: leave the ADMM loop open at the first check from here on
   const int n = uni(pl.n), m = uni(pl.m), k = uni(pl.k);
   const int nnzP = uni(pl.nnzP), nnzA = uni(pl.nnzA);  // (nnzA: what the kernel works on, the kept entries of a pruned plan)
   Item it{gPx + b * (size_t)nnzP, gq + b * (size_t)n, gAx + b * (size_t)uni(pl.nnzA_io), gl + b * (size_t)m,
@@ -1041,7 +1059,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
   if (lane == 0) t[k] = 0.0;  // padding slot of the packed sweeps
   const double inf = INFINITY;
   unsigned long long t0_ticks = wall_clock64();  // start of the item's solve (:376), kept across suspensions
-  if (phase >= PH_ADMM) {  // phased launch: every item continues from the state the previous phase left in its workspace
+  if (ph0 >= PH_ADMM) {  // phased launch: every item continues from the state the previous phase left in its workspace
     if (w.hdr[kHdrComplete] == 1.0) return SP_DONE;
     if (!resume) ret_code = (int)w.hdr[kHdrCode];  // (an item suspended inside this phase is open by construction)
     resume = true;
@@ -1255,7 +1273,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
   wave_sync();
   }  // !resume
 
-  if (phase == PH_SETUP) {  // phased launch: the ADMM phase continues from here
+  if (ph1 == PH_SETUP) {  // phased launch: the ADMM phase continues from here
     if (lane == 0) {
       w.hdr[0] = c;
       w.hdr[1] = 0.0;
@@ -1274,7 +1292,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
   // ---- ADMM loop :447-510 ----
   const uint32_t iter0 = iter;  // start of this slice
   bool need_rhs        = true;
-  for (; phase != PH_FINISH && iter != maxit && ret_code < 0; ++iter) {
+  for (; ph0 <= PH_ADMM && iter != maxit && ret_code < 0; ++iter) {
     // element-wise phases: the loads of UNR strided elements are issued together (one memory round
     // trip per UNR elements instead of one per element -- matters for a wave that runs alone)
     // (the batch sizes are what the 168-VGPR budget of three waves per SIMD allows)
@@ -1317,7 +1335,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     }
     }
     wave_sync();
-    ldl_solve_dev(pl, w, t, lane, lean);                                                        // :456-460
+    ldl_solve_dev<SD>(pl, w, t, lane, lean);                                                        // :456-460
     const bool chk = (iter == next_chk);
     if (chk) next_chk += sci;
     need_rhs = chk;
@@ -1391,7 +1409,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     }
     wave_sync();
     if (chk) {
-      ret_code = sp_check_stopping(pl, it, w, kp, t, lane);
+      ret_code = sp_check_stopping(pl, it, w, kp, t, lane, pause_at != 0 ? score : nullptr);
       if (ret_code < 0 && max_time_exceeded(kp.max_time_ns, t0_ticks)) ret_code = SFB_QP_MAX_TIME;  // :504-507
       wave_sync();
       lean = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_sparse_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >
@@ -1401,6 +1419,24 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
       if (iter > 600) __builtin_amdgcn_s_setprio(3);
       else if (iter > 300) __builtin_amdgcn_s_setprio(2);
       else if (iter > 100) __builtin_amdgcn_s_setprio(1);
+      // Pause (launches in predicted order, see qp_sparse_launch): the item has iterated long enough for its residual
+      // to tell how long it will go on; it waits in its workspace for the launch that orders the survivors.
+      if (pause_at != 0 && ret_code < 0 && iter + 1 >= pause_at && iter + 1 != maxit) {
+        if (lane == 0) {
+          w.hdr[0] = c;
+          w.hdr[1] = (double)(iter + 1);
+          w.hdr[2] = (double)next_chk;
+          w.hdr[3] = (double)t0_ticks;
+#ifdef SFB_SP_TIMELINE
+          w.hdr[4] = (double)tl0;
+          w.hdr[5] = (double)tl1;
+#endif
+          w.hdr[kHdrCode]     = -1.0;
+          w.hdr[kHdrComplete] = 0.0;
+        }
+        __builtin_amdgcn_s_setprio(0);
+        return SP_PAUSED;
+      }
       // Time slicing: an item that has used its slice gives its wave back when fresh items are left or suspended
       // ones are waiting -- the long runners then share the waves round-robin and finish together, instead of
       // the ones that happened to start late running alone at the end of the launch.  Everything an item needs
@@ -1436,7 +1472,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
 #ifdef SFB_SP_TIMELINE
   tl2 = wall_clock64();
 #endif
-  if (phase == PH_ADMM) {  // phased launch: polish and report belong to the next phase
+  if (ph1 == PH_ADMM) {  // phased launch: polish and report belong to the next phase
     if (lane == 0) {
       w.hdr[0] = c;
       w.hdr[1] = (double)iter;
@@ -1448,7 +1484,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     return SP_DONE;
   }
 #ifdef SFB_SP_TIMELINE
-  if (phase == PH_FINISH) tl2 = (unsigned long long)w.hdr[kHdrTl2];
+  if (ph0 == PH_FINISH) tl2 = (unsigned long long)w.hdr[kHdrTl2];
 #endif
   // ---- polish :515-539 ----
   if (ret_code == SFB_QP_OPTIMAL && kp.polish) {
@@ -1456,10 +1492,10 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
       const Ws wp = polish_ws(w, gws + slot * ws_doubles,
                               qp_sparse_polish_offset(n, m, uni(pl.nnzL), uni(pl.funits), uni(pl.bunits), pl.Aorig ? nnzA : 0), n, m,
                               uni(pl.nnzL), uni(pl.funits), uni(pl.bunits));
-      sp_polish(pl, it, w, wp, kp, t, c, lane, lean);
+      sp_polish<SD>(pl, it, w, wp, kp, t, c, lane, lean);
     } else {
       if (lane == 0) w.hdr[kHdrStamp] = 0.0;  // the polish factorisation overwrites the ADMM factor
-      sp_polish(pl, it, w, w, kp, t, c, lane, lean);
+      sp_polish<SD>(pl, it, w, w, kp, t, c, lane, lean);
     }
   }
 
@@ -1501,7 +1537,8 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
 // fallback pool of a pruned plan (kFbSlots ints, 0 = free).
 constexpr int kFbSlots = 64;
 
-__global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev *__restrict__ plp, const DenseKernelParams kp,
+template<int SD>
+__global__ void __launch_bounds__(64, SD == 16 ? 2 : 3) qp_sparse_kernel(const SparsePlanDev *__restrict__ plp, const DenseKernelParams kp,
                                                        const double *__restrict__ gPx, const double *__restrict__ gq,
                                                        const double *__restrict__ gAx, const double *__restrict__ gl,
                                                        const double *__restrict__ gu, const double *__restrict__ gwx,
@@ -1512,8 +1549,14 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev *_
                                                        const int lean_waves, const int32_t *__restrict__ order,
                                                        int32_t *__restrict__ queue, const int batch, const uint32_t slice,
                                                        const SparsePlanDev *__restrict__ plf, double *__restrict__ gwsf,
-                                                       const size_t wsf_doubles, int32_t *__restrict__ fbflags, const int phase, const int nfb)
+                                                       const size_t wsf_doubles, int32_t *__restrict__ fbflags, const int phases, const int nfb,
+                                                       float *__restrict__ keys, const int32_t *__restrict__ nfresh_dev, const int ncrit)
 {
+  // ncrit: the first ncrit fresh items of this launch (the longest of a launch in predicted order) always use cacheable loads
+  // keys (nullable): per item, the predictor score of a paused item (SP_PAUSED) or -1 (nothing left to do for the next launch)
+  // nfresh_dev (nullable): the fresh items of this launch are order[0 .. *nfresh_dev - 1] (the survivors of the previous one)
+  const int ph0    = phases & 15;
+  const int nfresh = nfresh_dev ? __builtin_amdgcn_readfirstlane(*nfresh_dev) : batch;
   extern __shared__ __attribute__((aligned(16))) double t[];  // work / solution vector, factorisation scratch
   // The plan (some forty pointers) is read from device memory where it is used: as a by-value kernel argument it
   // would sit in SGPRs for the whole life of the loop below and push the kernel into register spills.
@@ -1523,13 +1566,14 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev *_
   // batch.  Fresh items first, in launch order; an item that has used its slice while others wait goes to the back
   // of a ring and is continued later by whichever block is free (its state lives in ITS workspace slot = item).
   for (bool first = true;; first = false) {
-    int item = -1, resume = 0;
+    int item = -1, resume = 0, crit = 0;
     if (queue == nullptr) {
       if (first) item = order ? order[blockIdx.x] : (int)blockIdx.x;
     } else if (lane == 0) {
-      if (__hip_atomic_load(&queue[kQFresh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < batch) {
+      if (__hip_atomic_load(&queue[kQFresh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nfresh) {
         const int tk = atomicAdd(&queue[kQFresh], 1);
-        if (tk < batch) item = order ? order[tk] : tk;
+        if (tk < nfresh) item = order ? order[tk] : tk;
+        crit = tk < ncrit;
       }
       while (item < 0) {
         const int head = __hip_atomic_load(&queue[kQHead], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1546,6 +1590,7 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev *_
     }
     item   = __builtin_amdgcn_readfirstlane(item);
     resume = __builtin_amdgcn_readfirstlane(resume);
+    const int lean_waves_item = __builtin_amdgcn_readfirstlane(crit) ? 0x7FFFFFFF : lean_waves;
     if (item < 0) break;
     if (resume) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the suspending block's stores (other CU / XCD)
     wave_sync();
@@ -1556,7 +1601,7 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev *_
     double *wsb              = gws;
     size_t wsd = ws_doubles, slot = (queue == nullptr) ? (size_t)blockIdx.x : (size_t)item;
     int fbslot = -1;
-    if (plf != nullptr && !resume && phase <= PH_SETUP && !sp_guard_ok(*plp, gAx + (size_t)item * (size_t)uni(plp->nnzA_io), lane)) {
+    if (plf != nullptr && !resume && ph0 <= PH_SETUP && !sp_guard_ok(*plp, gAx + (size_t)item * (size_t)uni(plp->nnzA_io), lane)) {
       if (lane == 0) {
         for (int probe = blockIdx.x % nfb;; probe = (probe + 1) % nfb) {  // nfb = slots the pool really has
           if (atomicCAS(&fbflags[probe], 0, 1) == 0) { fbslot = probe; break; }
@@ -1573,13 +1618,14 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev *_
     // launches on purpose -- independent batches on other streams fill the chip just the same.)
     int seen = 0;
     if (lane == 0) seen = atomicAdd(&g_sparse_active, 1);
-    const bool lean = ((queue == nullptr ? (int)gridDim.x : batch) > lean_waves) || __builtin_amdgcn_readfirstlane(seen) >= lean_waves;
+    const bool lean = ((queue == nullptr ? (int)gridDim.x : batch) > lean_waves_item) || __builtin_amdgcn_readfirstlane(seen) >= lean_waves_item;
     // (phased launches: an item of the fallback pool runs all phases at once, in the setup launch)
-    const int st = sp_solve_item(*use, kp, gPx, gq, gAx, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode, wsb, wsd, lean_waves,
-                                 lean, (size_t)item, slot, t, lane, resume != 0, fbslot >= 0 ? nullptr : queue, batch, slice,
+    const int st = sp_solve_item<SD>(*use, kp, gPx, gq, gAx, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode, wsb, wsd, lean_waves_item,
+                                 lean, (size_t)item, slot, t, lane, resume != 0, fbslot >= 0 ? nullptr : queue, nfresh, slice,
                                  /*allow_reuse: the item's own slot of the main workspace*/ fbslot < 0 && slot == (size_t)item,
-                                 fbslot >= 0 ? PH_ALL : phase);
-    if (fbslot >= 0 && phase == PH_SETUP && lane == 0)  // tell the later phases (the item's own slot is otherwise unused)
+                                 fbslot >= 0 ? PH_EVERYTHING : phases, keys ? keys + item : nullptr);
+    if (keys != nullptr && st != SP_PAUSED && lane == 0) keys[item] = -1.0f;
+    if (fbslot >= 0 && phases != PH_EVERYTHING && lane == 0)  // tell the later launches (the item's own slot is otherwise unused)
       carve_ws(gws + (size_t)item * ws_doubles, uni(plp->n), uni(plp->m), uni(plp->nnzL), uni(plp->funits), uni(plp->bunits)).hdr[kHdrComplete] = 1.0;
     wave_sync();
     if (lane == 0) {
@@ -1600,17 +1646,59 @@ __global__ void __launch_bounds__(64, 3) qp_sparse_kernel(const SparsePlanDev *_
   }
 }
 
+// ORDER OF THE SURVIVORS (launches in predicted order): items with a score (>= 0 or NaN) sorted by descending score
+// into order2[0 .. *count - 1].  Counting sort on the leading 12 bits of the float (16 bins per octave -- the score
+// predicts the iterations left to a few percent at best); one workgroup, the batch is small next to the solves.
+constexpr int kRankBins = 4096, kRankThreads = 1024;
+__global__ __launch_bounds__(kRankThreads) void sp_rank_kernel(const float *__restrict__ keys, const int batch,
+                                                               int32_t *__restrict__ order2, int32_t *__restrict__ count)
+{
+  __shared__ int hist[kRankBins];
+  __shared__ int psum[kRankThreads];
+  const int tid = threadIdx.x;
+  auto bin_of = [](float k) { return (kRankBins - 1) - (int)(__float_as_uint(k) >> 19); };  // (sign bit clear: < 4096)
+  for (int b = tid; b < kRankBins; b += kRankThreads) hist[b] = 0;
+  __syncthreads();
+  for (int i = tid; i < batch; i += kRankThreads) {
+    const float k = keys[i];
+    if (!(k < 0.0f)) atomicAdd(&hist[bin_of(fabsf(k))], 1);
+  }
+  __syncthreads();
+  constexpr int per = kRankBins / kRankThreads;
+  int mine[per], tot = 0;
+  for (int e = 0; e < per; ++e) { mine[e] = hist[tid * per + e]; tot += mine[e]; }
+  psum[tid] = tot;
+  __syncthreads();
+  for (int d = 1; d < kRankThreads; d <<= 1) {  // inclusive scan of the per-thread totals
+    const int v = (tid >= d) ? psum[tid - d] : 0;
+    __syncthreads();
+    psum[tid] += v;
+    __syncthreads();
+  }
+  int start = psum[tid] - tot;
+  for (int e = 0; e < per; ++e) { hist[tid * per + e] = start; start += mine[e]; }
+  if (tid == kRankThreads - 1) *count = psum[tid];
+  __syncthreads();
+  for (int i = tid; i < batch; i += kRankThreads) {
+    const float k = keys[i];
+    if (!(k < 0.0f)) order2[atomicAdd(&hist[bin_of(fabsf(k))], 1)] = i;
+  }
+}
+
 // blocks of qp_sparse_kernel the device holds at once with `lds` bytes of dynamic LDS each
 static int sparse_resident_blocks(size_t lds)
 {
   int dev = 0, per_cu = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qp_sparse_kernel, kWave, lds) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qp_sparse_kernel<SFB_SWEEP_DEPTH>, kWave, lds) != hipSuccess) return 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
   return per_cu * cus;
 }
 
-size_t qp_sparse_aux_bytes(int64_t batch) { return ((size_t)batch + kQRing + kFbSlots) * sizeof(int32_t); }
+// auxiliary memory of a launch: [queue: kQRing + batch][flags of the fallback pool: kFbSlots] (zeroed per kernel) and,
+// for launches in predicted order, [scores: batch floats][order of the survivors: batch][their count: 16]
+static size_t sparse_aux_queue_ints(int64_t batch) { return (size_t)batch + kQRing + kFbSlots; }
+size_t qp_sparse_aux_bytes(int64_t batch) { return (sparse_aux_queue_ints(batch) + 2 * (size_t)batch + 16) * sizeof(int32_t); }
 int qp_sparse_fallback_slots() { return kFbSlots; }
 
 hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp, int64_t batch, const double *Px,
@@ -1658,18 +1746,55 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
   // the three phases for the profiler (profiles/r3_mpc_phases).
   const char *ph    = getenv("SFB_SP_PHASED");
   const bool phased = sliced && ph && atoi(ph) == 1;
-  auto launch = [&](unsigned g, int32_t *qa, int lw, int phase) -> hipError_t {
+  auto launch = [&](unsigned g, int32_t *qa, int lw, int phases, const int32_t *ord = nullptr, uint32_t slc = 0, float *keys = nullptr,
+                    const int32_t *nfresh = nullptr, int ncrit = 0, bool deep = false) -> hipError_t {
     if (qa != nullptr || pruned) {
-      hipError_t e = hipMemsetAsync(aux, 0, qp_sparse_aux_bytes(batch), stream);
+      hipError_t e = hipMemsetAsync(aux, 0, sparse_aux_queue_ints(batch) * sizeof(int32_t), stream);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(qp_sparse_kernel, dim3(g), dim3(kWave), lds, stream, pl.self, kp, Px, q, Ax, l, u, wx, wy, x, y, obj, iter,
-                       code, workspace, wsd, lw, order, qa, (int)batch, (uint32_t)std::max(1, slice),
+    auto *kern = deep ? qp_sparse_kernel<16> : qp_sparse_kernel<SFB_SWEEP_DEPTH>;
+    hipLaunchKernelGGL(kern, dim3(g), dim3(kWave), lds, stream, pl.self, kp, Px, q, Ax, l, u, wx, wy, x, y, obj, iter,
+                       code, workspace, wsd, lw, ord, qa, (int)batch, slc ? slc : (uint32_t)std::max(1, slice),
                        pruned ? fallback->self : nullptr, fallback_ws, pruned ? qp_sparse_ws_doubles(*fallback) : 0,
-                       aux ? aux + batch + kQRing : nullptr, phase, (int)std::min<int64_t>(batch, kFbSlots));
+                       aux ? aux + batch + kQRing : nullptr, phases, (int)std::min<int64_t>(batch, kFbSlots), keys, nfresh, ncrit);
     return hipGetLastError();
   };
-  if (!phased) return launch(grid, qarg, lean_waves, PH_ALL);
+  // LAUNCH IN PREDICTED ORDER (time-sliced launches, default; SFB_SP_PREDICT=0 turns it off).  ADMM iteration counts are
+  // heavy-tailed (headline batch: mean 88, p99 627, max 1 152) and a wave alone needs 22-27 us per iteration, so the
+  // longest items set the time of a launch unless they START first -- and what identifies them is cheap: the ratio of
+  // the primal (or dual) residual to its tolerance at the first stopping check after ~26 iterations orders the items
+  // almost like their final iteration counts (rank correlation 0.97 on the headline batch; the ten longest items are
+  // among the first fifteen).  So: (1) one launch takes every item through setup and its first `pause` iterations --
+  // items that are done by then are polished and reported right there, the others leave their score and wait in their
+  // workspace (same state as a suspended item); (2) a one-block counting sort orders the survivors by score; (3) a second
+  // launch runs them longest-first, first come first served, on a grid small enough that a wave iterates at nearly the
+  // speed of a lone wave (its factor stays in the 256 MB Infinity Cache).  The order is a schedule only: the results are
+  // bit-identical (tests/test_mpc_gpu.py).
+  const char *pr       = getenv("SFB_SP_PREDICT");
+  const char *pa       = getenv("SFB_SP_PAUSE");
+  const unsigned pause = pa ? (unsigned)std::max(0, atoi(pa)) : 27u;
+  const bool predicted = sliced && !phased && !(pr && atoi(pr) == 0) && pause > 0 && kp.stop_check_iter >= 2 && kp.max_iter > 2 * pause;
+  if (predicted) {
+    int32_t *xtra   = aux + sparse_aux_queue_ints(batch);
+    float *keys     = reinterpret_cast<float *>(xtra);
+    int32_t *order2 = xtra + batch, *count = xtra + 2 * batch;
+    hipError_t e = launch(grid, qarg, lean_waves, phases_pack(PH_SETUP, PH_FINISH, pause), order, 0, keys);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sp_rank_kernel, dim3(1), dim3(kRankThreads), 0, stream, keys, (int)batch, order2, count);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    const double stream_bytes = (double)(pl.funits + pl.bunits) * 128.0 * sizeof(double);
+    // grid of the second launch: as many items as keep their two schedule-ordered factor copies in ~70 % of the 256 MB
+    // Infinity Cache (headline plan: 640 -- measured 512: 70.5 ms, 576: 66.7, 640: 64.0, 768: 65.2, 1 024: 72.1)
+    unsigned grid3 = ((unsigned)std::max(256.0, 0.70 * 256.0 * 1024.0 * 1024.0 / stream_bytes) + 32u) / 64u * 64u;
+    if (const char *g3 = getenv("SFB_SP_GRID3"); g3 && atoi(g3) > 0) grid3 = (unsigned)atoi(g3);
+    grid3 = std::min(grid3, grid);
+    const char *lw3 = getenv("SFB_SP_LEAN_WAVES3");
+    const char *sl3 = getenv("SFB_SP_SLICE3");
+    return launch(grid3, qarg, lw3 ? atoi(lw3) : (grid3 < grid ? 0x7FFFFFFF : lean_waves), phases_pack(PH_ADMM, PH_FINISH), order2,
+                  sl3 ? (uint32_t)std::max(1, atoi(sl3)) : 0x40000000u, nullptr, count, getenv("SFB_SP_CRIT") ? atoi(getenv("SFB_SP_CRIT")) : 0,
+                  getenv("SFB_SP_DEEP3") && atoi(getenv("SFB_SP_DEEP3")) == 1);
+  }
+  if (!phased) return launch(grid, qarg, lean_waves, PH_EVERYTHING, order);
   // grid of the ADMM phase: items whose two schedule-ordered factor copies fit ~70 % of the MALL
   const double stream_bytes = (double)(pl.funits + pl.bunits) * 128.0 * sizeof(double);
   unsigned grid2 = (unsigned)std::max(256.0, 0.70 * 256.0 * 1024.0 * 1024.0 / stream_bytes);
@@ -1678,11 +1803,11 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
   // plain (cache-allocating) loads in the ADMM phase unless the grid is too large for the MALL anyway
   const char *lw2       = getenv("SFB_SP_LEAN_WAVES2");
   const int lean_waves2 = lw2 ? atoi(lw2) : (grid2 < grid ? 0x7FFFFFFF : lean_waves);
-  hipError_t e = launch(grid, qarg, lean_waves, PH_SETUP);
+  hipError_t e = launch(grid, qarg, lean_waves, phases_pack(PH_SETUP, PH_SETUP), order);
   if (e != hipSuccess) return e;
-  e = launch(grid2, qarg, lean_waves2, PH_ADMM);
+  e = launch(grid2, qarg, lean_waves2, phases_pack(PH_ADMM, PH_ADMM), order);
   if (e != hipSuccess) return e;
-  return launch(grid, qarg, lean_waves, PH_FINISH);
+  return launch(grid, qarg, lean_waves, phases_pack(PH_FINISH, PH_FINISH), order);
 }
 
 }  // namespace sfb

@@ -205,6 +205,54 @@ def test_phased_launch_equals_the_single_kernel(sfb, oracle, grid, grid2, slice_
         monkeypatch.delenv(k)
 
 
+@pytest.mark.parametrize("grid,grid3,pause,deep", [(16, 5, 27, 0), (48, 48, 2, 1), (32, 9, 60, 0), (24, 3, 27, 1)])
+def test_launch_in_predicted_order_equals_the_single_kernel(sfb, oracle, grid, grid3, pause, deep, monkeypatch):
+    """Default for time-sliced launches: a first launch takes every item through setup and its first `pause` iterations
+    (items done by then are polished and reported there), the survivors leave a score -- residual over tolerance at
+    their last stopping check -- and wait in their workspace; a counting sort orders them by descending score and a second
+    launch finishes them longest-first.  A schedule only: same bits as the single kernel (SFB_SP_PREDICT=0) and as the
+    oracle, for plain and pruned plans, cold and warm start, an item on the fallback path, a pre-check failure, a
+    max_iter cut-off and another stop_check_iter; also with the 16-unit prefetch form of the second launch."""
+    variant, K, B = 6, 10, 150
+    d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
+    Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=29)
+    keep = np.any(Av != 0.0, axis=0)
+    Av[9, np.nonzero(~keep)[0][1]] = 0.5          # violates the mask: fallback pool, solved completely in the first launch
+    l[13, 2], u[13, 2] = 1.0, -1.0                 # u < l: PrimalInfeasible at the pre-check, no iteration
+    Px, q = np.tile(Pv, (B, 1)), np.zeros((B, d["n"]))
+    knobs = ("SFB_SP_GRID", "SFB_SP_PREDICT", "SFB_SP_GRID3", "SFB_SP_PAUSE", "SFB_SP_DEEP3")
+    for prm in (sfb.QPSolverParams(max_iter=4000), sfb.QPSolverParams(max_iter=150, polish=False),
+                sfb.QPSolverParams(max_iter=4000, stop_check_iter=7)):
+        for kp in (None, keep):
+            plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K), keep=kp)
+            monkeypatch.setenv("SFB_SP_GRID", str(grid))
+            monkeypatch.setenv("SFB_SP_PREDICT", "0")
+            base = plan.solve_batch_host(Px, q, Av, l, u, prm)
+            base2 = plan.solve_batch_host(Px, q, Av, l, u, prm, warm_x=0.5 * base.primal, warm_y=0.5 * base.dual)
+            monkeypatch.delenv("SFB_SP_PREDICT")
+            monkeypatch.setenv("SFB_SP_GRID3", str(grid3))
+            monkeypatch.setenv("SFB_SP_PAUSE", str(pause))
+            monkeypatch.setenv("SFB_SP_DEEP3", str(deep))
+            r = plan.solve_batch_host(Px, q, Av, l, u, prm)
+            r2 = plan.solve_batch_host(Px, q, Av, l, u, prm, warm_x=0.5 * base.primal, warm_y=0.5 * base.dual)
+            for a, b in ((r, base), (r2, base2)):
+                assert np.array_equal(a.code, b.code) and np.array_equal(a.iter, b.iter)
+                assert np.array_equal(a.primal, b.primal, equal_nan=True) and np.array_equal(a.dual, b.dual, equal_nan=True)
+                assert np.array_equal(a.objective, b.objective, equal_nan=True)
+            assert r.code[13] == 2 and r.iter[13] == 0
+            assert (r.iter > pause + 25).any()                                   # the second launch had work ...
+            assert pause < 27 or (r.iter[r.iter > 0] <= pause + 25).any()        # ... and some items were done in the first
+            if prm.max_iter == 150:
+                assert (r.code == 4).any() and r.iter.max() == 150
+            if kp is None:
+                ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l, u, perm=plan.perm, forder=plan.factor_order(),
+                                                   params=_oracle_params(oracle, prm), nthreads=8)
+                assert np.array_equal(r.iter, ref["iter"]) and np.array_equal(r.code, ref["code"]) and np.array_equal(r.primal, ref["x"])
+            for k in knobs[1:]:
+                monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("SFB_SP_GRID")
+
+
 def test_max_time_on_the_sparse_path(sfb, oracle):
     """max_time (qp_solver.hpp:504-507) on the sparse kernel: 1 ns ends every agent at its first stopping check;
     deterministic and equal to the oracle with the same limit.  Also through a time-sliced launch."""
