@@ -201,8 +201,8 @@ def qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Ax, l, u, perm=None, params=Non
         forder = np.ascontiguousarray(forder, dtype=np.int32)
         assert sorted(forder.tolist()) == list(range(n + m))
     trace = None
-    if trace_rows:  # the verbose table of qp_solver.hpp:490-501 as data: (ITER, OBJ, PRI_RES, DUA_RES) per check
-        trace = np.full((B, int(trace_rows), 4), -1.0)
+    if trace_rows:  # the verbose table of qp_solver.hpp:490-501 as data: (ITER, OBJ, PRI_RES, DUA_RES, PRI_TOL, DUA_TOL) per check
+        trace = np.full((B, int(trace_rows), 6), -1.0)
         lib().oracle_qp_sparse_set_trace.argtypes = [C.POINTER(C.c_double), C.c_int]
         lib().oracle_qp_sparse_set_trace.restype = None
         lib().oracle_qp_sparse_set_trace(_dp(trace), int(trace_rows))

@@ -107,8 +107,8 @@ int oracle_qp_sparse_solve_batch_ordered(const oracle_qp_params *prm, int64_t ba
 
 /*
  * The reference's verbose table (qp_solver.hpp:409-420, :490-501) as data instead of text: while a trace buffer is
- * set, the sparse batch calls record one row (ITER, OBJ, PRI_RES, DUA_RES) per stopping check of every item into
- * trace[batch][cap][4]; unused rows have ITER = -1.  Process-global; clear with (NULL, 0).
+ * set, the sparse batch calls record one row (ITER, OBJ, PRI_RES, DUA_RES, tolerance of PRI_RES, tolerance of DUA_RES
+ * -- qp_solver.hpp:580-590) per stopping check of every item into trace[batch][cap][6]; unused rows have ITER = -1.  Process-global; clear with (NULL, 0).
  */
 void oracle_qp_sparse_set_trace(double *trace, int cap);
 

@@ -284,8 +284,8 @@ typedef struct {
 } sp_work;
 
 /* The rows of the reference's verbose table (qp_solver.hpp:409-420 header, :490-501 rows) instead of printing them:
- * trace[batch][cap][4] = (ITER, OBJ, PRI_RES, DUA_RES) of every stopping check, rows beyond the last check hold
- * ITER = -1.  Process-global switch (test infrastructure; set before a batch call, cleared with NULL). */
+ * trace[batch][cap][6] = (ITER, OBJ, PRI_RES, DUA_RES, tolerance of PRI_RES, tolerance of DUA_RES) of every stopping
+ * check, rows beyond the last check hold ITER = -1.  Process-global switch (test infrastructure; set before a batch call, cleared with NULL). */
 static double *g_trace   = NULL;
 static int g_trace_cap   = 0;
 void oracle_qp_sparse_set_trace(double *trace, int cap) { g_trace = trace; g_trace_cap = cap; }
@@ -524,7 +524,7 @@ static int sp_solve_one(const sp_shared *sh, const sp_aux *aux, const oracle_qp_
   memset(w, 0, sizeof(*w));
   w->sh = sh; w->prm = *prm; w->Px = Px; w->q = q; w->Ax = Ax; w->l = l; w->u = u;
   w->trace = trace; w->trace_cap = trace_cap;
-  for (int r = 0; trace && r < trace_cap; ++r) trace[4 * r] = -1.0;
+  for (int r = 0; trace && r < trace_cap; ++r) trace[6 * r] = -1.0;
   const size_t nd = (size_t)(6 * n + 10 * m + 5 * k) + (size_t)s->nnzK + (size_t)s->nnzL + 16;
   double *mem     = (double *)calloc(nd, sizeof(double));
   if (!mem) return -1;
@@ -601,7 +601,7 @@ static int sp_solve_one(const sp_shared *sh, const sp_aux *aux, const oracle_qp_
       for (int i = 0; i < m; ++i) w->dy_us[i] = w->sy[i] * (w->dual[i] - w->dy_us[i]) / w->c;
       ret_code = sp_check_stopping(w);
       if (w->trace && w->trace_rows < w->trace_cap) { /* :490-501, the three columns in the reference's expressions */
-        double *row = w->trace + 4 * (size_t)w->trace_rows++;
+        double *row = w->trace + 6 * (size_t)w->trace_rows++;
         double o = 0.0, pri = 0.0, dua = 0.0;
         sp_mv_P(w, w->x_us, w->Pxv);
         for (int j = 0; j < n; ++j) o += (0.5 * w->Pxv[j] + q[j]) * w->x_us[j];
@@ -610,6 +610,9 @@ static int sp_solve_one(const sp_shared *sh, const sp_aux *aux, const oracle_qp_
         sp_mv_At(w, w->y_us, w->Aty);
         for (int j = 0; j < n; ++j) dua = dmax(dua, fabs(w->Pxv[j] + q[j] + w->Aty[j]));
         row[0] = (double)iter; row[1] = o; row[2] = pri; row[3] = dua;
+        /* ... and the tolerances the two residuals are tested against (:580-590) */
+        row[4] = (double)prm->eps_abs + (double)prm->eps_rel * dmax(norm_inf(w->Axv, m), norm_inf(w->z_us, m));
+        row[5] = (double)prm->eps_abs + (double)prm->eps_rel * dmax(dmax(norm_inf(w->Pxv, n), norm_inf(q, n)), norm_inf(w->Aty, n));
       }
       if (ret_code < 0 && prm->max_time_ns >= 0) { /* :504-507 */
         struct timespec t1;
@@ -656,7 +659,7 @@ static void *sp_worker(void *arg)
                           j->Ax + sb * (size_t)j->nnzA, j->l + sb * m, j->u + sb * m,
                           j->wx ? j->wx + sb * n : NULL, j->wy ? j->wy + sb * m : NULL, j->x + sb * n,
                           j->y + sb * m, j->obj ? j->obj + sb : NULL, j->iter ? j->iter + sb : NULL, j->code + sb,
-                          g_trace ? g_trace + 4 * sb * (size_t)g_trace_cap : NULL, g_trace_cap);
+                          g_trace ? g_trace + 6 * sb * (size_t)g_trace_cap : NULL, g_trace_cap);
     if (rc) j->rc = rc;
   }
   return NULL;

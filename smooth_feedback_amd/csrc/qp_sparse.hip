@@ -1556,7 +1556,10 @@ __global__ void __launch_bounds__(64, SD == 16 ? 2 : 3) qp_sparse_kernel(const S
   // keys (nullable): per item, the predictor score of a paused item (SP_PAUSED) or -1 (nothing left to do for the next launch)
   // nfresh_dev (nullable): the fresh items of this launch are order[0 .. *nfresh_dev - 1] (the survivors of the previous one)
   const int ph0    = phases & 15;
-  const int nfresh = nfresh_dev ? __builtin_amdgcn_readfirstlane(*nfresh_dev) : batch;
+  const int nfresh = nfresh_dev ? __builtin_amdgcn_readfirstlane(nfresh_dev[0]) : batch;
+  // ... worked on by the first nfresh_dev[1] blocks of the grid only (the rank kernel sizes the launch, see there)
+  const int nwaves = nfresh_dev ? __builtin_amdgcn_readfirstlane(nfresh_dev[1]) : (queue == nullptr ? (int)gridDim.x : batch);
+  if (nfresh_dev != nullptr && (int)blockIdx.x >= nwaves) return;
   extern __shared__ __attribute__((aligned(16))) double t[];  // work / solution vector, factorisation scratch
   // The plan (some forty pointers) is read from device memory where it is used: as a by-value kernel argument it
   // would sit in SGPRs for the whole life of the loop below and push the kernel into register spills.
@@ -1618,7 +1621,7 @@ __global__ void __launch_bounds__(64, SD == 16 ? 2 : 3) qp_sparse_kernel(const S
     // launches on purpose -- independent batches on other streams fill the chip just the same.)
     int seen = 0;
     if (lane == 0) seen = atomicAdd(&g_sparse_active, 1);
-    const bool lean = ((queue == nullptr ? (int)gridDim.x : batch) > lean_waves_item) || __builtin_amdgcn_readfirstlane(seen) >= lean_waves_item;
+    const bool lean = (nwaves > lean_waves_item) || __builtin_amdgcn_readfirstlane(seen) >= lean_waves_item;
     // (phased launches: an item of the fallback pool runs all phases at once, in the setup launch)
     const int st = sp_solve_item<SD>(*use, kp, gPx, gq, gAx, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode, wsb, wsd, lean_waves_item,
                                  lean, (size_t)item, slot, t, lane, resume != 0, fbslot >= 0 ? nullptr : queue, nfresh, slice,
@@ -1647,11 +1650,18 @@ __global__ void __launch_bounds__(64, SD == 16 ? 2 : 3) qp_sparse_kernel(const S
 }
 
 // ORDER OF THE SURVIVORS (launches in predicted order): items with a score (>= 0 or NaN) sorted by descending score
-// into order2[0 .. *count - 1].  Counting sort on the leading 12 bits of the float (16 bins per octave -- the score
+// into order2[0 .. count[0] - 1].  Counting sort on the leading 12 bits of the float (16 bins per octave -- the score
 // predicts the iterations left to a few percent at best); one workgroup, the batch is small next to the solves.
+// count[1] = WAVES of the second launch.  The launch is shortest when the longest item, iterating all the time, ends
+// together with the rest of the work: waves = (sum of the survivors' remaining iterations) / (those of the longest).
+// Before the active set settles ADMM's residuals fall like 1 / iteration, so the remaining iterations go like the score
+// itself (headline batch: 25, 30, 50, 77, 127, 327, 968 iterations on average for scores in [2, 4), [4, 8), ... --
+// sum / max of the scores 493, of the true counts 443): waves = sum_k score_k / score_max, clamped to [g_lo, g_hi] --
+// g_lo: the items whose factors fit the Infinity Cache (fewer waves do not saturate it), g_hi: what the chip holds.
 constexpr int kRankBins = 4096, kRankThreads = 1024;
 __global__ __launch_bounds__(kRankThreads) void sp_rank_kernel(const float *__restrict__ keys, const int batch,
-                                                               int32_t *__restrict__ order2, int32_t *__restrict__ count)
+                                                               int32_t *__restrict__ order2, int32_t *__restrict__ count,
+                                                               const int g_lo, const int g_hi)
 {
   __shared__ int hist[kRankBins];
   __shared__ int psum[kRankThreads];
@@ -1677,7 +1687,34 @@ __global__ __launch_bounds__(kRankThreads) void sp_rank_kernel(const float *__re
   }
   int start = psum[tid] - tot;
   for (int e = 0; e < per; ++e) { hist[tid * per + e] = start; start += mine[e]; }
-  if (tid == kRankThreads - 1) *count = psum[tid];
+  const int total = psum[kRankThreads - 1];
+  __syncthreads();
+  {  // score of a bin, from its exponent and leading mantissa bits: log2 = (bits >> 19) / 16 - 127; scores beyond 2^40
+     // (and infinities / NaNs) count as 2^40, scores below 1 as 1
+    auto lg = [](int b) { return exp2f(fminf(40.0f, fmaxf(0.0f, (float)((kRankBins - 1) - b) * (1.0f / 16.0f) - 127.0f))); };
+    float part = 0.0f;
+    int first  = kRankBins;
+    for (int e = 0; e < per; ++e) {
+      part += (float)mine[e] * lg(tid * per + e);
+      if (mine[e] > 0 && first == kRankBins) first = tid * per + e;
+    }
+    __shared__ float fsum[kRankThreads];
+    fsum[tid] = part;
+    psum[tid] = first;
+    __syncthreads();
+    for (int d = kRankThreads / 2; d > 0; d >>= 1) {
+      if (tid < d) {
+        fsum[tid] += fsum[tid + d];
+        psum[tid] = min(psum[tid], psum[tid + d]);
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const float want = (psum[0] < kRankBins) ? fsum[0] / lg(psum[0]) : 0.0f;
+      count[0] = total;
+      count[1] = max(g_lo, min(g_hi, ((int)want + 32) / 64 * 64));
+    }
+  }
   __syncthreads();
   for (int i = tid; i < batch; i += kRankThreads) {
     const float k = keys[i];
@@ -1780,17 +1817,19 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     int32_t *order2 = xtra + batch, *count = xtra + 2 * batch;
     hipError_t e = launch(grid, qarg, lean_waves, phases_pack(PH_SETUP, PH_FINISH, pause), order, 0, keys);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sp_rank_kernel, dim3(1), dim3(kRankThreads), 0, stream, keys, (int)batch, order2, count);
+    // Waves of the second launch: at least as many items as keep their two schedule-ordered factor copies in ~70 % of the
+    // 256 MB Infinity Cache (headline plan: 640 -- measured 512: 70.5 ms, 576: 66.7, 640: 64.0, 768: 65.2, 1 024: 72.1), more
+    // when the survivors' work is large against the longest item (the rank kernel decides: 16 384 agents 896, 32 768 agents
+    // 1 792); the grid is the chip's, the blocks beyond the chosen number leave at once.  Cacheable loads while the active
+    // waves' factors fit the Infinity Cache, non-temporal masked ones beyond (as in the single launch).
+    const double stream_bytes = (double)(pl.funits + pl.bunits) * 128.0 * sizeof(double), mall = 256.0 * 1024.0 * 1024.0;
+    unsigned g_lo = std::min(grid, ((unsigned)std::max(256.0, 0.70 * mall / stream_bytes) + 32u) / 64u * 64u), g_hi = grid;
+    if (const char *g3 = getenv("SFB_SP_GRID3"); g3 && atoi(g3) > 0) g_lo = g_hi = std::min(grid, (unsigned)atoi(g3));
+    hipLaunchKernelGGL(sp_rank_kernel, dim3(1), dim3(kRankThreads), 0, stream, keys, (int)batch, order2, count, (int)g_lo, (int)g_hi);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    const double stream_bytes = (double)(pl.funits + pl.bunits) * 128.0 * sizeof(double);
-    // grid of the second launch: as many items as keep their two schedule-ordered factor copies in ~70 % of the 256 MB
-    // Infinity Cache (headline plan: 640 -- measured 512: 70.5 ms, 576: 66.7, 640: 64.0, 768: 65.2, 1 024: 72.1)
-    unsigned grid3 = ((unsigned)std::max(256.0, 0.70 * 256.0 * 1024.0 * 1024.0 / stream_bytes) + 32u) / 64u * 64u;
-    if (const char *g3 = getenv("SFB_SP_GRID3"); g3 && atoi(g3) > 0) grid3 = (unsigned)atoi(g3);
-    grid3 = std::min(grid3, grid);
     const char *lw3 = getenv("SFB_SP_LEAN_WAVES3");
     const char *sl3 = getenv("SFB_SP_SLICE3");
-    return launch(grid3, qarg, lw3 ? atoi(lw3) : (grid3 < grid ? 0x7FFFFFFF : lean_waves), phases_pack(PH_ADMM, PH_FINISH), order2,
+    return launch(g_hi, qarg, lw3 ? atoi(lw3) : (int)std::max(512.0, mall / stream_bytes), phases_pack(PH_ADMM, PH_FINISH), order2,
                   sl3 ? (uint32_t)std::max(1, atoi(sl3)) : 0x40000000u, nullptr, count, getenv("SFB_SP_CRIT") ? atoi(getenv("SFB_SP_CRIT")) : 0,
                   getenv("SFB_SP_DEEP3") && atoi(getenv("SFB_SP_DEEP3")) == 1);
   }
