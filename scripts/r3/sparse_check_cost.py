@@ -30,7 +30,7 @@ for B in (1, 8192):
             e0.record(s); go(); e1.record(s); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
         return min(ts)
     tiny = dict(eps_abs=1e-30, eps_rel=1e-30, eps_primal_inf=1e-30, eps_dual_inf=1e-30, polish=False)
-    os.environ["SFB_SP_SLICE"] = "1000000"
+    os.environ["SFB_SP_SLICE"] = "1000000"; os.environ["SFB_SP_PREDICT"] = "0"
     a = timed(sfb.QPSolverParams(max_iter=101, stop_check_iter=0, **tiny)); b = timed(sfb.QPSolverParams(max_iter=401, stop_check_iter=0, **tiny))
     c = timed(sfb.QPSolverParams(max_iter=101, stop_check_iter=25, **tiny)); e = timed(sfb.QPSolverParams(max_iter=401, stop_check_iter=25, **tiny))
     it0 = (b - a) / 300; it1 = (e - c) / 300

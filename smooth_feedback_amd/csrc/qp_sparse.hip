@@ -774,6 +774,71 @@ __device__ __forceinline__ double sp_row_dot(const int p0, const int p1, const d
   }
   return s;
 }
+// The same for RB rows of a lane at once (rows i0, i0 + 64, ...), CE entries per row and memory round trip: a lone wave
+// pays two round trips per CHUNK, and a lane's rows one after the other made a stopping check cost four ADMM iterations.
+// Every row's fma chain is the sequential one (storage order).  s[r] = the product of row i0 + r * 64 (0 beyond nrows).
+template<int RB, int CE, class PtrF, class PosF, class IdxF>
+__device__ __forceinline__ void sp_rows_dot(double (&s)[RB], const int i0, const int nrows, PtrF ptr, const double *vals, PosF pos,
+                                            IdxF idx, const double *v)
+{
+  int p[RB], pe[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int i = i0 + r * kWave;
+    const bool on = i < nrows;
+    p[r]  = on ? ptr(i) : 0;
+    pe[r] = on ? ptr(i + 1) : 0;
+    s[r]  = 0.0;
+  }
+  for (;;) {
+    bool more = false;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) more = more || p[r] < pe[r];
+    if (!more) break;
+    int ps[RB][CE], ix[RB][CE];
+    double a[RB][CE], x[RB][CE];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int e = 0; e < CE; ++e) {
+        const bool on = p[r] + e < pe[r];
+        ps[r][e] = on ? pos(p[r] + e) : 0;
+        ix[r][e] = on ? idx(p[r] + e) : 0;
+      }
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int e = 0; e < CE; ++e) {
+        a[r][e] = vals[ps[r][e]];
+        x[r][e] = v[ix[r][e]];
+      }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+#pragma unroll
+      for (int e = 0; e < CE; ++e)
+        if (p[r] + e < pe[r]) s[r] = fma(a[r][e], x[r][e], s[r]);
+      p[r] += CE;
+    }
+  }
+}
+template<int RB, int CE>
+__device__ __forceinline__ void sp_rows_A(double (&s)[RB], const SparsePlanDev &pl, const Item &it, int i0, const double *v)
+{
+  sp_rows_dot<RB, CE>(s, i0, uni(pl.m), [&](int i) { return pl.Ap[i]; }, it.Ax, [](int p) { return p; },
+                      [&](int p) { return pl.Aj[p]; }, v);
+}
+template<int RB, int CE>
+__device__ __forceinline__ void sp_rows_P(double (&s)[RB], const SparsePlanDev &pl, const Item &it, int i0, const double *v)
+{
+  sp_rows_dot<RB, CE>(s, i0, uni(pl.n), [&](int i) { return pl.Prp[i]; }, it.Px, [&](int p) { return pl.Prpos[p]; },
+                      [&](int p) { return pl.Prj[p]; }, v);
+}
+template<int RB, int CE>
+__device__ __forceinline__ void sp_rows_At(double (&s)[RB], const SparsePlanDev &pl, const Item &it, int j0, const double *v)
+{
+  sp_rows_dot<RB, CE>(s, j0, uni(pl.n), [&](int j) { return pl.Acp[j]; }, it.Ax, [&](int p) { return pl.Acpos[p]; },
+                      [&](int p) { return pl.Aci[p]; }, v);
+}
 __device__ __forceinline__ double sp_row_A(const SparsePlanDev &pl, const Item &it, int i, const double *v)
 {
   return sp_row_dot(pl.Ap[i], pl.Ap[i + 1], it.Ax, [](int p) { return p; }, [&](int p) { return pl.Aj[p]; }, v);
@@ -803,11 +868,21 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
   const int chunk  = (uni(pl.k) + 1) / 2;  // pairs of doubles that fit the work vector
   {  // OPTIMALITY
     double a = 0.0, r = 0.0, z = 0.0;
-    for (int i = lane; i < m; i += kWave) {
-      const double Ax = sp_row_A(pl, it, i, w.xus), zi = w.zus[i];
-      a = fmax(a, fabs(Ax));
-      r = fmax(r, fabs(Ax - zi));
-      z = fmax(z, fabs(zi));
+    constexpr int RB = 4, CE = 2;  // (8 entries in flight per lane: what the register budget of three waves per SIMD leaves)
+#ifndef SFB_CHK_EXP
+#define SFB_CHK_EXP 0  // timing experiments only (scripts/r3/check_parts.sh): leave parts of the check out
+#endif
+    for (int i0 = lane; i0 < ((SFB_CHK_EXP & 1) ? 0 : m); i0 += kWave * RB) {
+      double Ax[RB], zi[RB];
+#pragma unroll
+      for (int rr = 0; rr < RB; ++rr) zi[rr] = (i0 + rr * kWave < m) ? w.zus[i0 + rr * kWave] : 0.0;
+      sp_rows_A<RB, CE>(Ax, pl, it, i0, w.xus);
+#pragma unroll
+      for (int rr = 0; rr < RB; ++rr) {  // (rows beyond m contribute |0|: the norms are >= 0 anyway)
+        a = fmax(a, fabs(Ax[rr]));
+        r = fmax(r, fabs(Ax[rr] - zi[rr]));
+        z = fmax(z, fabs(zi[rr]));
+      }
     }
     const double Ax_norm = wave_max(a), r_norm = wave_max(r), z_norm = wave_max(z);
     if (score != nullptr && lane == 0) *score = (float)(r_norm / (kp.eps_abs + kp.eps_rel * fmax(Ax_norm, z_norm)));
@@ -835,7 +910,7 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
     // the running sum starts at +0.0 and therefore is never -0.0).
     double acc = 0.0;
     bool brk   = false;
-    for (int c0 = 0; c0 < m; c0 += chunk) {
+    for (int c0 = 0; c0 < ((SFB_CHK_EXP & 2) ? 0 : m); c0 += chunk) {
       const int c1 = min(m, c0 + chunk);
       for (int i = c0 + lane; i < c1; i += kWave) {
         const double ui = it.u[i], li = it.l[i], dyi = w.dyus[i];
@@ -844,7 +919,22 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
         brk = brk || (ui == inf && dyi > thr) || (li == -inf && dyi < -thr);
       }
       wave_sync();
-      for (int e = 0; e < 2 * (c1 - c0); ++e) acc += t[e];
+      {  // the sequential sum: 16 terms per LDS round trip (one read per add exposed the LDS latency 1 480 times per check:
+         // 49 of the 90 us a check cost a lone wave)
+        const int cnt = 2 * (c1 - c0);
+        int e = 0;
+        for (; e + 16 <= cnt; e += 16) {
+          vdouble2 v[8];
+#pragma unroll
+          for (int qq = 0; qq < 8; ++qq) v[qq] = *reinterpret_cast<const vdouble2 *>(t + e + 2 * qq);
+#pragma unroll
+          for (int qq = 0; qq < 8; ++qq) {
+            acc += v[qq].x;
+            acc += v[qq].y;
+          }
+        }
+        for (; e < cnt; ++e) acc += t[e];
+      }
       wave_sync();
     }
     if (wave_ballot(brk)) acc = inf;
@@ -861,7 +951,12 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
     const double dx_norm = lane_max_abs(w.dxus, n, lane);
     const double thr     = kp.eps_dinf * dx_norm;
     double pn            = 0.0;
-    for (int j = lane; j < n; j += kWave) pn = fmax(pn, fabs(sp_row_P(pl, it, j, w.dxus)));
+    for (int j0 = lane; j0 < ((SFB_CHK_EXP & 4) ? 0 : n); j0 += kWave * 8) {
+      double Pdx[8];
+      sp_rows_P<8, 1>(Pdx, pl, it, j0, w.dxus);
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) pn = fmax(pn, fabs(Pdx[rr]));
+    }
     const double Pdx_n = wave_max(pn);
     if (!(Pdx_n <= thr)) return -1;
     double qdx = 0.0;  // q' dx, sequential fma chain (:633) fed from LDS
@@ -872,7 +967,18 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
         t[2 * (j - c0) + 1] = w.dxus[j];
       }
       wave_sync();
-      for (int e = 0; e < c1 - c0; ++e) qdx = fma(t[2 * e], t[2 * e + 1], qdx);
+      {
+        const int cnt = c1 - c0;
+        int e = 0;
+        for (; e + 8 <= cnt; e += 8) {
+          vdouble2 v[8];
+#pragma unroll
+          for (int qq = 0; qq < 8; ++qq) v[qq] = *reinterpret_cast<const vdouble2 *>(t + 2 * (e + qq));
+#pragma unroll
+          for (int qq = 0; qq < 8; ++qq) qdx = fma(v[qq].x, v[qq].y, qdx);
+        }
+        for (; e < cnt; ++e) qdx = fma(t[2 * e], t[2 * e + 1], qdx);
+      }
       wave_sync();
     }
     if (!(qdx <= thr)) return -1;
@@ -1113,7 +1219,17 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     }
     wave_sync();
     double sum = t[0];
-    for (int j = 1; j < n; ++j) sum += t[j];
+    {  // sequential sum (:687), 16 terms per LDS round trip
+      int j = 1;
+      for (; j + 16 <= n; j += 16) {
+        double v[16];
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) v[qq] = t[j + qq];
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) sum += v[qq];
+      }
+      for (; j < n; ++j) sum += t[j];
+    }
     const double qn = lane_max_abs(it.q, n, lane);
     c               = 1.0 / fmax(fmax(1e-6, sum / (double)n), qn);
     wave_sync();
@@ -1509,17 +1625,32 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
   for (int i = lane; i < m; i += kWave) oy[i] = w.sy[i] * w.ys[i] / c;
   wave_sync();
   if (gobj != nullptr) {
-    for (int i = lane; i < n; i += kWave) {
-      double acc = 0.0;
-      for (int p = pl.Prp[i]; p < pl.Prp[i + 1]; ++p) acc = fma(0.5 * it.Px[pl.Prpos[p]], w.xus[pl.Prj[p]], acc);
-      t[i] = acc + it.q[i];
+    // primal . (0.5 P primal + q): the rows in parallel, the dot product as the sequential fma chain it is -- fed from
+    // LDS in chunks of pairs (x_i, row_i), 8 pairs per LDS round trip (one global load per term cost a lone wave ~0.1 ms)
+    const int chunk = (k + 1) / 2;
+    double o        = 0.0;
+    for (int c0 = 0; c0 < n; c0 += chunk) {
+      const int c1 = min(n, c0 + chunk);
+      for (int i = c0 + lane; i < c1; i += kWave) {
+        double acc = 0.0;
+        for (int p = pl.Prp[i]; p < pl.Prp[i + 1]; ++p) acc = fma(0.5 * it.Px[pl.Prpos[p]], w.xus[pl.Prj[p]], acc);
+        t[2 * (i - c0)]     = w.xus[i];
+        t[2 * (i - c0) + 1] = acc + it.q[i];
+      }
+      wave_sync();
+      const int cnt = c1 - c0;
+      int e = 0;
+      for (; e + 8 <= cnt; e += 8) {
+        vdouble2 v[8];
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) v[qq] = *reinterpret_cast<const vdouble2 *>(t + 2 * (e + qq));
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) o = fma(v[qq].x, v[qq].y, o);
+      }
+      for (; e < cnt; ++e) o = fma(t[2 * e], t[2 * e + 1], o);
+      wave_sync();
     }
-    wave_sync();
-    if (lane == 0) {
-      double o = 0.0;
-      for (int i = 0; i < n; ++i) o = fma(w.xus[i], t[i], o);
-      gobj[b] = o;
-    }
+    if (lane == 0) gobj[b] = o;
   }
   if (lane == 0) {
     gcode[b] = (ret_code >= 0) ? ret_code : SFB_QP_MAX_ITERATIONS;
