@@ -33,7 +33,7 @@ def timed(order=None, reps=3):
     return best
 def env(**kw):
     for k in ("SFB_SP_SLICE", "SFB_SP_GRID", "SFB_SP_PHASED", "SFB_SP_GRID2", "SFB_SP_LEAN_WAVES", "SFB_SP_LEAN_WAVES2", "SFB_SP_PREDICT",
-              "SFB_SP_GRID3", "SFB_SP_LEAN_WAVES3", "SFB_SP_SLICE3", "SFB_SP_PAUSE", "SFB_SP_CRIT", "SFB_SP_DEEP3"): os.environ.pop(k, None)
+              "SFB_SP_GRID3", "SFB_SP_LEAN_WAVES3", "SFB_SP_SLICE3", "SFB_SP_PAUSE", "SFB_SP_CRIT", "SFB_SP_DEEP3", "SFB_SP_NAP"): os.environ.pop(k, None)
     for k, v in kw.items(): os.environ[k] = str(v)
 env(SFB_SP_PREDICT=0)
 t_nat = timed()
@@ -48,6 +48,14 @@ for sig in (0.3, 0.6, 1.0):  # a predictor with log-normal error of that sigma
     noisy[sig] = torch.from_numpy(np.argsort(-(itc * np.exp(sig * rng.standard_normal(B))), kind="stable").astype(np.int32)).to(dev)
 def check():
     assert torch.equal(code, c0) and np.array_equal(it.cpu().numpy(), itc) and torch.equal(x, x0), "results depend on the order!"
+if os.environ.get("PART", "predict") == "nap":
+    for g in (640, 768, 1024):
+        for crit in (64, 128, 256):
+            for nap in (0, 4, 8, 16, 32):
+                env(SFB_SP_GRID3=g, SFB_SP_CRIT=crit, SFB_SP_NAP=nap)
+                a = timed(reps=2); check()
+                print("grid3 %4d, first %3d items unpaced, the others nap %2d x 0.43 us per iteration: %.2f ms (%.0f QP/s)" % (g, crit, nap, a, B / a * 1e3), flush=True)
+    sys.exit(0)
 if os.environ.get("PART", "predict") == "deep":
     for deep in (1, 0):
         for g in (256, 320, 384, 448, 512, 576, 640, 768):

@@ -30,6 +30,9 @@
 #include "qp_sparse_kernel.h"
 #include "wave_util.h"
 
+#ifndef SFB_ITER_EXP
+#define SFB_ITER_EXP 0  // timing experiments only (scripts/r3/iter_parts.sh): 1 = no update phases, 2 = no sweeps
+#endif
 #ifndef SFB_SWEEP_DEPTH
 #define SFB_SWEEP_DEPTH 8  // units (2 slots per lane each) in flight per sweep
 #endif
@@ -1134,7 +1137,9 @@ __device__ __forceinline__ bool sp_guard_ok(const SparsePlanDev &pl, const doubl
 // resume == true: continue an item another block has suspended (its state is in its workspace).
 // Runs until the item is finished (SP_DONE), or -- time-sliced launches only, queue != nullptr -- until the item
 // has used its slice while others are waiting for a wave (SP_SUSPENDED: state saved, the caller queues the item).
-template<int SD>
+// LAT: the form for launches with few waves, each nearly alone on its SIMD (second launch of the predicted order): one
+// wave per SIMD pair of registers more (256 VGPRs) and the ADMM vectors of the loop in LDS, see the loop
+template<bool LAT>
 __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const DenseKernelParams &kp, const double *__restrict__ gPx,
                                              const double *__restrict__ gq, const double *__restrict__ gAx,
                                              const double *__restrict__ gl, const double *__restrict__ gu,
@@ -1144,7 +1149,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
                                              double *__restrict__ gws, const size_t ws_doubles, const int lean_waves,
                                              bool lean, const size_t b, const size_t slot, double *t, const int lane,
                                              bool resume, const int32_t *queue, const int batch,
-                                             const uint32_t slice, const bool allow_reuse, const int phases, float *score)
+                                             const uint32_t slice, const bool allow_reuse, const int phases, float *score, const int nap = 0)
 {
   const int ph0 = phases & 15, ph1 = (phases >> 4) & 15;  // the phases this launch performs
   const uint32_t pause_at = (uint32_t)phases >> 8;        // != 0: leave the ADMM loop open at the first check from here on
@@ -1167,8 +1172,15 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
   unsigned long long t0_ticks = wall_clock64();  // start of the item's solve (:376), kept across suspensions
   if (ph0 >= PH_ADMM) {  // phased launch: every item continues from the state the previous phase left in its workspace
     if (w.hdr[kHdrComplete] == 1.0) return SP_DONE;
+#ifdef SFB_SP_TIMELINE
+    const bool tl_continued = !resume;  // first visit of this launch: tl1 = when the launch took the item up
+#endif
     if (!resume) ret_code = (int)w.hdr[kHdrCode];  // (an item suspended inside this phase is open by construction)
     resume = true;
+#ifdef SFB_SP_TIMELINE
+    if (tl_continued && lane == 0) w.hdr[5] = (double)wall_clock64();
+    wave_sync();
+#endif
   }
   if (resume) {
     c        = w.hdr[0];
@@ -1408,11 +1420,40 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
   // ---- ADMM loop :447-510 ----
   const uint32_t iter0 = iter;  // start of this slice
   bool need_rhs        = true;
+  // The vectors of the loop: in the item's workspace -- or, LAT, in LDS behind the work vector for as long as this wave
+  // iterates on the item (x, z, y copied in here and back when the wave lets go of the item; c q, 1/rho, rho, the scaled
+  // bounds and the permutation are constants of the loop).  A lone wave spent 6 of its 23.5 us per iteration waiting for
+  // the five global round trips of the update phases, and the vectors are a quarter of the loop's traffic.
+  double *vxs = w.xs, *vqc = w.qc, *vys = w.ys, *vzs = w.zs, *vrinv = w.rinv, *vrho = w.rho, *vlo = w.lo, *vhi = w.hi;
+  const int32_t *vpinv = pl.pinv;
+  const bool iterates  = ph0 <= PH_ADMM && iter != maxit && ret_code < 0;
+  if constexpr (LAT) {
+    vxs = t + ((k + 2) & ~1); vqc = vxs + n; vys = vqc + n; vzs = vys + m; vrinv = vzs + m; vrho = vrinv + m; vlo = vrho + m;
+    vhi = vlo + m;
+    int32_t *lp = reinterpret_cast<int32_t *>(vhi + m);
+    vpinv       = lp;
+    if (iterates) {
+      for (int j = lane; j < n; j += kWave) { vxs[j] = w.xs[j]; vqc[j] = w.qc[j]; }
+      for (int i = lane; i < m; i += kWave) {
+        vys[i] = w.ys[i]; vzs[i] = w.zs[i]; vrinv[i] = w.rinv[i]; vrho[i] = w.rho[i]; vlo[i] = w.lo[i]; vhi[i] = w.hi[i];
+      }
+      for (int e = lane; e < k; e += kWave) lp[e] = pl.pinv[e];
+      wave_sync();
+    }
+  }
+  auto vectors_home = [&] {  // LAT: x, z, y back to the workspace (polish, report, or the next wave that takes the item up)
+    if constexpr (LAT) {
+      if (iterates) {
+        for (int j = lane; j < n; j += kWave) w.xs[j] = vxs[j];
+        for (int i = lane; i < m; i += kWave) { w.ys[i] = vys[i]; w.zs[i] = vzs[i]; }
+      }
+    }
+  };
   for (; ph0 <= PH_ADMM && iter != maxit && ret_code < 0; ++iter) {
     // element-wise phases: the loads of UNR strided elements are issued together (one memory round
     // trip per UNR elements instead of one per element -- matters for a wave that runs alone)
     // (the batch sizes are what the 168-VGPR budget of three waves per SIMD allows)
-    constexpr int UNR_A = 8, UNR_B = 4;
+    constexpr int UNR_A = LAT ? 8 : 4, UNR_B = 4;
     // The right-hand side of the NEXT solve is written by the update phase below from the values it has just
     // computed (same expressions, no re-read of x, z, y, 1/rho); only the first iteration and the one after a
     // stopping check (which uses t as scratch) build it here.
@@ -1425,9 +1466,9 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
       for (int e = 0; e < UNR; ++e) {
         const int j = j0 + e * kWave;
         const bool on = j < n;
-        xv[e] = on ? w.xs[j] : 0.0;
-        qv[e] = on ? w.qc[j] : 0.0;
-        pv[e] = on ? pl.pinv[j] : k;
+        xv[e] = on ? vxs[j] : 0.0;
+        qv[e] = on ? vqc[j] : 0.0;
+        pv[e] = on ? vpinv[j] : k;
       }
 #pragma unroll
       for (int e = 0; e < UNR; ++e)
@@ -1440,10 +1481,10 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
       for (int e = 0; e < UNR; ++e) {
         const int i = i0 + e * kWave;
         const bool on = i < m;
-        zv[e] = on ? w.zs[i] : 0.0;
-        rv[e] = on ? w.rinv[i] : 0.0;
-        yv[e] = on ? w.ys[i] : 0.0;
-        pv[e] = on ? pl.pinv[n + i] : k;
+        zv[e] = on ? vzs[i] : 0.0;
+        rv[e] = on ? vrinv[i] : 0.0;
+        yv[e] = on ? vys[i] : 0.0;
+        pv[e] = on ? vpinv[n + i] : k;
       }
 #pragma unroll
       for (int e = 0; e < UNR; ++e)
@@ -1451,77 +1492,96 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     }
     }
     wave_sync();
-    ldl_solve_dev<SD>(pl, w, t, lane, lean);                                                        // :456-460
+    if (!(SFB_ITER_EXP & 2)) ldl_solve_dev<SFB_SWEEP_DEPTH>(pl, w, t, lane, lean);                               // :456-460
+    for (int q = 0; q < nap; ++q) __builtin_amdgcn_s_sleep(16);  // pacing of the items that are not critical (see the kernel)
     const bool chk = (iter == next_chk);
     if (chk) next_chk += sci;
     need_rhs = chk;
-    {
-    constexpr int UNR = UNR_A;
-    for (int j0 = lane; j0 < n; j0 += kWave * UNR) {  // :470
-      double xo[UNR], sxj[UNR], qv[UNR];
-      int pv[UNR];
+    // UPDATE PHASES :470-477.  Whole rows of 64 elements run without predicates, U rows per batch (their loads are issued
+    // together: one round trip per batch); only the last, partial row is predicated.  Nothing of the stopping check is in
+    // here: per element it cost a lone wave more instructions than the update itself (the check's pointers and divisions,
+    // reloaded from spilled SGPRs).  At a check the old iterate is parked in dx_us / dy_us first (the oracle's memcpy,
+    // qp_solver.hpp:466-467) and the unscaled vectors are formed by a pass of their own below -- same expressions, same bits.
+    if (chk) {
+      for (int j = lane; j < n; j += kWave) w.dxus[j] = vxs[j];
+      for (int i = lane; i < m; i += kWave) w.dyus[i] = vys[i];
+    }
+    auto xrows = [&]<int U, bool PRED>(std::integral_constant<int, U>, std::bool_constant<PRED>, const int r0) {
+      double xo[U], qv[U];
+      int pv[U];
 #pragma unroll
-      for (int e = 0; e < UNR; ++e) {
-        const int j = j0 + e * kWave;
-        const bool on = j < n;
-        xo[e]  = on ? w.xs[j] : 0.0;
-        qv[e]  = on ? w.qc[j] : 0.0;
-        pv[e]  = on ? pl.pinv[j] : k;
-        sxj[e] = (on && chk) ? w.sx[j] : 0.0;
+      for (int e = 0; e < U; ++e) {
+        const int j   = lane + (r0 + e) * kWave;
+        const bool on = !PRED || j < n;
+        xo[e] = on ? vxs[j] : 0.0;
+        qv[e] = on ? vqc[j] : 0.0;
+        pv[e] = on ? vpinv[j] : k;
       }
 #pragma unroll
-      for (int e = 0; e < UNR; ++e) {
-        const int j = j0 + e * kWave;
-        if (j < n) {
+      for (int e = 0; e < U; ++e) {
+        const int j = lane + (r0 + e) * kWave;
+        if (!PRED || j < n) {
           const double xn = kp.alpha * t[pv[e]] + kp.alpha_comp * xo[e];
-          w.xs[j]  = xn;
+          vxs[j]   = xn;
           t[pv[e]] = kp.sigma * xn - qv[e];  // rhs of the next solve (:450)
-          if (chk) {
-            w.xus[j]  = sxj[e] * xn;
-            w.dxus[j] = sxj[e] * (xn - xo[e]);
-          }
         }
       }
-    }
-    }
-    {
-    constexpr int UNR = UNR_B;
-    for (int i0 = lane; i0 < m; i0 += kWave * UNR) {  // :471-477
-      double yo[UNR], zo[UNR], ri[UNR], rh[UNR], lo[UNR], hi[UNR], syi[UNR];
-      int pv[UNR];
+    };
+    auto yrows = [&]<int U, bool PRED>(std::integral_constant<int, U>, std::bool_constant<PRED>, const int r0) {
+      double yo[U], zo[U], ri[U], rh[U], lo[U], hi[U];
+      int pv[U];
 #pragma unroll
-      for (int e = 0; e < UNR; ++e) {
-        const int i = i0 + e * kWave;
-        const bool on = i < m;
-        yo[e] = on ? w.ys[i] : 0.0;
-        zo[e] = on ? w.zs[i] : 0.0;
-        ri[e] = on ? w.rinv[i] : 0.0;
-        rh[e] = on ? w.rho[i] : 0.0;
-        lo[e] = on ? w.lo[i] : 0.0;
-        hi[e] = on ? w.hi[i] : 0.0;
-        pv[e] = on ? pl.pinv[n + i] : k;
-        syi[e] = (on && chk) ? w.sy[i] : 1.0;
+      for (int e = 0; e < U; ++e) {
+        const int i   = lane + (r0 + e) * kWave;
+        const bool on = !PRED || i < m;
+        yo[e] = on ? vys[i] : 0.0;
+        zo[e] = on ? vzs[i] : 0.0;
+        ri[e] = on ? vrinv[i] : 0.0;
+        rh[e] = on ? vrho[i] : 0.0;
+        lo[e] = on ? vlo[i] : 0.0;
+        hi[e] = on ? vhi[i] : 0.0;
+        pv[e] = on ? vpinv[n + i] : k;
       }
 #pragma unroll
-      for (int e = 0; e < UNR; ++e) {
-        const int i = i0 + e * kWave;
-        if (i < m) {
+      for (int e = 0; e < U; ++e) {
+        const int i = lane + (r0 + e) * kWave;
+        if (!PRED || i < m) {
           const double nu = t[pv[e]];
           double zn = kp.alpha * (ri[e] * nu) + kp.alpha_comp * (ri[e] * yo[e]) + zo[e];
           zn = (zn < lo[e]) ? lo[e] : zn;
           zn = (hi[e] < zn) ? hi[e] : zn;
           const double yn = kp.alpha_comp * yo[e] + kp.alpha * nu + rh[e] * zo[e] - rh[e] * zn;
-          w.ys[i]  = yn;
-          w.zs[i]  = zn;
+          vys[i]   = yn;
+          vzs[i]   = zn;
           t[pv[e]] = zn - ri[e] * yn;  // rhs of the next solve (:451)
-          if (chk) {
-            w.yus[i]  = syi[e] * yn / c;
-            w.zus[i]  = (1.0 / syi[e]) * zn;
-            w.dyus[i] = syi[e] * (yn - yo[e]) / c;
-          }
         }
       }
+    };
+    auto all_rows = [&]<int U>(std::integral_constant<int, U> uu, const int len, auto &&rows) {
+      const int full = len / kWave;  // rows in which every lane has an element
+      int r = 0;
+      for (; r + U <= full; r += U) rows(uu, std::false_type{}, r);
+      if constexpr (U > 4) if (r + 4 <= full) { rows(std::integral_constant<int, 4>{}, std::false_type{}, r); r += 4; }
+      if constexpr (U > 2) if (r + 2 <= full) { rows(std::integral_constant<int, 2>{}, std::false_type{}, r); r += 2; }
+      if constexpr (U > 1) if (r + 1 <= full) { rows(std::integral_constant<int, 1>{}, std::false_type{}, r); r += 1; }
+      if (full * kWave < len) rows(std::integral_constant<int, 1>{}, std::true_type{}, r);
+    };
+    if (!(SFB_ITER_EXP & 1)) {
+      all_rows(std::integral_constant<int, UNR_A>{}, n, xrows);
+      all_rows(std::integral_constant<int, UNR_B>{}, m, yrows);
     }
+    if (chk) {  // :481-488 unscaled iterate and differences for the check
+      for (int j = lane; j < n; j += kWave) {
+        const double xn = vxs[j], sxj = w.sx[j], xo = w.dxus[j];
+        w.xus[j]  = sxj * xn;
+        w.dxus[j] = sxj * (xn - xo);
+      }
+      for (int i = lane; i < m; i += kWave) {
+        const double yn = vys[i], zn = vzs[i], syi = w.sy[i], yo = w.dyus[i];
+        w.yus[i]  = syi * yn / c;
+        w.zus[i]  = (1.0 / syi) * zn;
+        w.dyus[i] = syi * (yn - yo) / c;
+      }
     }
     wave_sync();
     if (chk) {
@@ -1551,6 +1611,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
           w.hdr[kHdrComplete] = 0.0;
         }
         __builtin_amdgcn_s_setprio(0);
+        vectors_home();
         return SP_PAUSED;
       }
       // Time slicing: an item that has used its slice gives its wave back when fresh items are left or suspended
@@ -1578,12 +1639,14 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
 #endif
           }
           __builtin_amdgcn_s_setprio(0);
+          vectors_home();
           return SP_SUSPENDED;
         }
       }
     }
   }
   __builtin_amdgcn_s_setprio(0);
+  vectors_home();
 
 #ifdef SFB_SP_TIMELINE
   tl2 = wall_clock64();
@@ -1608,10 +1671,10 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
       const Ws wp = polish_ws(w, gws + slot * ws_doubles,
                               qp_sparse_polish_offset(n, m, uni(pl.nnzL), uni(pl.funits), uni(pl.bunits), pl.Aorig ? nnzA : 0), n, m,
                               uni(pl.nnzL), uni(pl.funits), uni(pl.bunits));
-      sp_polish<SD>(pl, it, w, wp, kp, t, c, lane, lean);
+      sp_polish<SFB_SWEEP_DEPTH>(pl, it, w, wp, kp, t, c, lane, lean);
     } else {
       if (lane == 0) w.hdr[kHdrStamp] = 0.0;  // the polish factorisation overwrites the ADMM factor
-      sp_polish<SD>(pl, it, w, w, kp, t, c, lane, lean);
+      sp_polish<SFB_SWEEP_DEPTH>(pl, it, w, w, kp, t, c, lane, lean);
     }
   }
 
@@ -1668,8 +1731,8 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
 // fallback pool of a pruned plan (kFbSlots ints, 0 = free).
 constexpr int kFbSlots = 64;
 
-template<int SD>
-__global__ void __launch_bounds__(64, SD == 16 ? 2 : 3) qp_sparse_kernel(const SparsePlanDev *__restrict__ plp, const DenseKernelParams kp,
+template<bool LAT>
+__global__ void __launch_bounds__(64, LAT ? 2 : 3) qp_sparse_kernel(const SparsePlanDev *__restrict__ plp, const DenseKernelParams kp,
                                                        const double *__restrict__ gPx, const double *__restrict__ gq,
                                                        const double *__restrict__ gAx, const double *__restrict__ gl,
                                                        const double *__restrict__ gu, const double *__restrict__ gwx,
@@ -1681,7 +1744,8 @@ __global__ void __launch_bounds__(64, SD == 16 ? 2 : 3) qp_sparse_kernel(const S
                                                        int32_t *__restrict__ queue, const int batch, const uint32_t slice,
                                                        const SparsePlanDev *__restrict__ plf, double *__restrict__ gwsf,
                                                        const size_t wsf_doubles, int32_t *__restrict__ fbflags, const int phases, const int nfb,
-                                                       float *__restrict__ keys, const int32_t *__restrict__ nfresh_dev, const int ncrit)
+                                                       float *__restrict__ keys, const int32_t *__restrict__ nfresh_dev, const int ncrit, const int nap,
+                                                       const int mode_sel)
 {
   // ncrit: the first ncrit fresh items of this launch (the longest of a launch in predicted order) always use cacheable loads
   // keys (nullable): per item, the predictor score of a paused item (SP_PAUSED) or -1 (nothing left to do for the next launch)
@@ -1691,6 +1755,8 @@ __global__ void __launch_bounds__(64, SD == 16 ? 2 : 3) qp_sparse_kernel(const S
   // ... worked on by the first nfresh_dev[1] blocks of the grid only (the rank kernel sizes the launch, see there)
   const int nwaves = nfresh_dev ? __builtin_amdgcn_readfirstlane(nfresh_dev[1]) : (queue == nullptr ? (int)gridDim.x : batch);
   if (nfresh_dev != nullptr && (int)blockIdx.x >= nwaves) return;
+  // ... and only if the rank kernel chose this launch's form (nfresh_dev[2]; mode_sel < 0: unconditional)
+  if (nfresh_dev != nullptr && mode_sel >= 0 && __builtin_amdgcn_readfirstlane(nfresh_dev[2]) != mode_sel) return;
   extern __shared__ __attribute__((aligned(16))) double t[];  // work / solution vector, factorisation scratch
   // The plan (some forty pointers) is read from device memory where it is used: as a by-value kernel argument it
   // would sit in SGPRs for the whole life of the loop below and push the kernel into register spills.
@@ -1754,10 +1820,11 @@ __global__ void __launch_bounds__(64, SD == 16 ? 2 : 3) qp_sparse_kernel(const S
     if (lane == 0) seen = atomicAdd(&g_sparse_active, 1);
     const bool lean = (nwaves > lean_waves_item) || __builtin_amdgcn_readfirstlane(seen) >= lean_waves_item;
     // (phased launches: an item of the fallback pool runs all phases at once, in the setup launch)
-    const int st = sp_solve_item<SD>(*use, kp, gPx, gq, gAx, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode, wsb, wsd, lean_waves_item,
+    const int st = sp_solve_item<LAT>(*use, kp, gPx, gq, gAx, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode, wsb, wsd, lean_waves_item,
                                  lean, (size_t)item, slot, t, lane, resume != 0, fbslot >= 0 ? nullptr : queue, nfresh, slice,
                                  /*allow_reuse: the item's own slot of the main workspace*/ fbslot < 0 && slot == (size_t)item,
-                                 fbslot >= 0 ? PH_EVERYTHING : phases, keys ? keys + item : nullptr);
+                                 fbslot >= 0 ? PH_EVERYTHING : phases, keys ? keys + item : nullptr,
+                                 __builtin_amdgcn_readfirstlane(crit) ? 0 : nap);
     if (keys != nullptr && st != SP_PAUSED && lane == 0) keys[item] = -1.0f;
     if (fbslot >= 0 && phases != PH_EVERYTHING && lane == 0)  // tell the later launches (the item's own slot is otherwise unused)
       carve_ws(gws + (size_t)item * ws_doubles, uni(plp->n), uni(plp->m), uni(plp->nnzL), uni(plp->funits), uni(plp->bunits)).hdr[kHdrComplete] = 1.0;
@@ -1792,7 +1859,7 @@ __global__ void __launch_bounds__(64, SD == 16 ? 2 : 3) qp_sparse_kernel(const S
 constexpr int kRankBins = 4096, kRankThreads = 1024;
 __global__ __launch_bounds__(kRankThreads) void sp_rank_kernel(const float *__restrict__ keys, const int batch,
                                                                int32_t *__restrict__ order2, int32_t *__restrict__ count,
-                                                               const int g_lo, const int g_hi)
+                                                               const int g_lo, const int g_hi, const int lat_lo, const int lat_hi)
 {
   __shared__ int hist[kRankBins];
   __shared__ int psum[kRankThreads];
@@ -1842,8 +1909,16 @@ __global__ __launch_bounds__(kRankThreads) void sp_rank_kernel(const float *__re
     }
     if (tid == 0) {
       const float want = (psum[0] < kRankBins) ? fsum[0] / lg(psum[0]) : 0.0f;
+      // count[0..2]: survivors, waves, form of the second launch (1 = the LAT kernel on at most lat_hi waves, chosen when
+      // that is enough for the work; 0 = the standard kernel); count[4..6]: the same for a launch on the whole chip
+      const int w64 = ((int)fminf(want, 1e9f) + 32) / 64 * 64;
+      const int lat = lat_hi > 0 && w64 <= lat_hi + lat_hi / 4;
       count[0] = total;
-      count[1] = max(g_lo, min(g_hi, ((int)want + 32) / 64 * 64));
+      count[1] = lat ? max(lat_lo, min(lat_hi, w64)) : max(g_lo, min(g_hi, w64));
+      count[2] = lat;
+      count[4] = total;
+      count[5] = g_hi;
+      count[6] = lat;
     }
   }
   __syncthreads();
@@ -1858,7 +1933,7 @@ static int sparse_resident_blocks(size_t lds)
 {
   int dev = 0, per_cu = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qp_sparse_kernel<SFB_SWEEP_DEPTH>, kWave, lds) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qp_sparse_kernel<false>, kWave, lds) != hipSuccess) return 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
   return per_cu * cus;
 }
@@ -1915,16 +1990,17 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
   const char *ph    = getenv("SFB_SP_PHASED");
   const bool phased = sliced && ph && atoi(ph) == 1;
   auto launch = [&](unsigned g, int32_t *qa, int lw, int phases, const int32_t *ord = nullptr, uint32_t slc = 0, float *keys = nullptr,
-                    const int32_t *nfresh = nullptr, int ncrit = 0, bool deep = false) -> hipError_t {
+                    const int32_t *nfresh = nullptr, int mode_sel = -1, bool lat = false, size_t lds_lat = 0) -> hipError_t {
+    const int ncrit = 0, nap = getenv("SFB_SP_NAP") ? atoi(getenv("SFB_SP_NAP")) : 0;  // (experiments, see scripts/r3/experiments)
     if (qa != nullptr || pruned) {
       hipError_t e = hipMemsetAsync(aux, 0, sparse_aux_queue_ints(batch) * sizeof(int32_t), stream);
       if (e != hipSuccess) return e;
     }
-    auto *kern = deep ? qp_sparse_kernel<16> : qp_sparse_kernel<SFB_SWEEP_DEPTH>;
-    hipLaunchKernelGGL(kern, dim3(g), dim3(kWave), lds, stream, pl.self, kp, Px, q, Ax, l, u, wx, wy, x, y, obj, iter,
+    auto *kern = lat ? qp_sparse_kernel<true> : qp_sparse_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3(g), dim3(kWave), lat ? lds_lat : lds, stream, pl.self, kp, Px, q, Ax, l, u, wx, wy, x, y, obj, iter,
                        code, workspace, wsd, lw, ord, qa, (int)batch, slc ? slc : (uint32_t)std::max(1, slice),
                        pruned ? fallback->self : nullptr, fallback_ws, pruned ? qp_sparse_ws_doubles(*fallback) : 0,
-                       aux ? aux + batch + kQRing : nullptr, phases, (int)std::min<int64_t>(batch, kFbSlots), keys, nfresh, ncrit);
+                       aux ? aux + batch + kQRing : nullptr, phases, (int)std::min<int64_t>(batch, kFbSlots), keys, nfresh, ncrit, nap, mode_sel);
     return hipGetLastError();
   };
   // LAUNCH IN PREDICTED ORDER (time-sliced launches, default; SFB_SP_PREDICT=0 turns it off).  ADMM iteration counts are
@@ -1956,13 +2032,49 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     const double stream_bytes = (double)(pl.funits + pl.bunits) * 128.0 * sizeof(double), mall = 256.0 * 1024.0 * 1024.0;
     unsigned g_lo = std::min(grid, ((unsigned)std::max(256.0, 0.70 * mall / stream_bytes) + 32u) / 64u * 64u), g_hi = grid;
     if (const char *g3 = getenv("SFB_SP_GRID3"); g3 && atoi(g3) > 0) g_lo = g_hi = std::min(grid, (unsigned)atoi(g3));
-    hipLaunchKernelGGL(sp_rank_kernel, dim3(1), dim3(kRankThreads), 0, stream, keys, (int)batch, order2, count, (int)g_lo, (int)g_hi);
+    // LAT form of the second launch (see sp_solve_item): the loop's vectors in LDS, two waves per CU -- when that many waves
+    // are enough for the survivors' work (the rank kernel decides; headline batch: yes) and the vectors fit; polish and
+    // report of the survivors then follow as a launch of their own on the whole chip (they are latency-bound and want every
+    // wave; inside the few waves of the loop they took 40 % of the wave time).  Otherwise: the standard kernel, loop and
+    // polish in one launch.  Both are enqueued, the blocks of the form that was not chosen leave at once.
+    const int kk = pl.n + pl.m;
+    const size_t lds_lat = std::max(lds, (size_t)(((kk + 2) & ~1) + 2 * pl.n + 6 * pl.m + (kk + 1) / 2 + 2) * sizeof(double));
+    int lat_hi = 0, lat_lo = 0;
+    if (const char *lt = getenv("SFB_SP_LAT"); !(lt && atoi(lt) == 0) && lds_lat <= 80 * 1024) {
+      static bool attr_set = false;  // (idempotent; racing callers set the same value)
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(qp_sparse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_set = true;
+      }
+      int dev = 0, per_cu = 0, cus = 0;
+      if (hipGetDevice(&dev) == hipSuccess &&
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qp_sparse_kernel<true>, kWave, lds_lat) == hipSuccess &&
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+        lat_hi = std::min<int>(per_cu * cus, (int)grid);
+      const char *ll = getenv("SFB_SP_LAT_LO");
+      lat_lo = std::min(lat_hi, ll ? atoi(ll) : 448);
+      if (const char *g3 = getenv("SFB_SP_GRID3"); g3 && atoi(g3) > 0) lat_lo = lat_hi = std::min(lat_hi, atoi(g3));
+    }
+    hipLaunchKernelGGL(sp_rank_kernel, dim3(1), dim3(kRankThreads), 0, stream, keys, (int)batch, order2, count, (int)g_lo, (int)g_hi,
+                       lat_lo, lat_hi);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const char *lw3 = getenv("SFB_SP_LEAN_WAVES3");
     const char *sl3 = getenv("SFB_SP_SLICE3");
-    return launch(g_hi, qarg, lw3 ? atoi(lw3) : (int)std::max(512.0, mall / stream_bytes), phases_pack(PH_ADMM, PH_FINISH), order2,
-                  sl3 ? (uint32_t)std::max(1, atoi(sl3)) : 0x40000000u, nullptr, count, getenv("SFB_SP_CRIT") ? atoi(getenv("SFB_SP_CRIT")) : 0,
-                  getenv("SFB_SP_DEEP3") && atoi(getenv("SFB_SP_DEEP3")) == 1);
+    const uint32_t slice3 = sl3 ? (uint32_t)std::max(1, atoi(sl3)) : 0x40000000u;
+    if (lat_hi > 0) {
+      e = launch((unsigned)lat_hi, qarg, 0x7FFFFFFF, phases_pack(PH_ADMM, PH_ADMM), order2, slice3, nullptr, count, 1, true, lds_lat);
+      if (e != hipSuccess) return e;
+      e = launch(grid, qarg, lean_waves, phases_pack(PH_FINISH, PH_FINISH), order2, slice3, nullptr, count + 4, 1);
+      if (e != hipSuccess) return e;
+    }
+    return launch(g_hi, qarg, lw3 ? atoi(lw3) : (int)std::max(512.0, mall / stream_bytes), phases_pack(PH_ADMM, PH_FINISH), order2, slice3,
+                  nullptr, count, lat_hi > 0 ? 0 : -1);
+  }
+  if (const char *fl = getenv("SFB_SP_FORCE_LAT"); !phased && fl && atoi(fl) == 1) {  // measurements: the LAT form for a whole launch
+    const int kk = pl.n + pl.m;
+    const size_t lds_lat = std::max(lds, (size_t)(((kk + 2) & ~1) + 2 * pl.n + 6 * pl.m + (kk + 1) / 2 + 2) * sizeof(double));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(qp_sparse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return launch(grid, qarg, lean_waves, PH_EVERYTHING, order, 0, nullptr, nullptr, -1, true, lds_lat);
   }
   if (!phased) return launch(grid, qarg, lean_waves, PH_EVERYTHING, order);
   // grid of the ADMM phase: items whose two schedule-ordered factor copies fit ~70 % of the MALL
