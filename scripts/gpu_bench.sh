@@ -12,6 +12,8 @@ def show(name, d):
     print("   cpu", {k: (v if not isinstance(v, dict) else v) for k, v in d.get("cpu_baseline", {}).items() if k != "sample"})
     print("   parity", d.get("parity_vs_oracle"))
 show("headline", r)
-for k, v in r.get("secondary", {}).items(): show(k, v)
+for k, v in r.get("secondary", {}).items():
+    if isinstance(v, dict) and "roofline" in v: show(k, v)
+    else: print(k, json.dumps(v)[:1500])
 print("pipelined", r.get("pipelined", {}).get("value"))
 PY

@@ -42,6 +42,7 @@ def main():
             out["kernels"].setdefault(k, {})["duration_ms_per_dispatch"] = [round(d, 4) for _, d in v]
         launch_tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
         launch_n = {"FETCH_SIZE": set(), "WRITE_SIZE": set()}
+        rank_n = {"FETCH_SIZE": set(), "WRITE_SIZE": set()}
         for i in range(1, 10):
             path = os.path.join(src, "pmc%d" % i, "p_counter_collection.csv")
             if not os.path.exists(path):
@@ -64,6 +65,8 @@ def main():
                         launch_tot[r["Counter_Name"]] += float(r["Counter_Value"])
                         if DOMINANT[wl] in r["Kernel_Name"]:
                             launch_n[r["Counter_Name"]].add(r["Dispatch_Id"])
+                        if "sp_rank_kernel" in r["Kernel_Name"]:
+                            rank_n[r["Counter_Name"]].add(r["Dispatch_Id"])
             for k, cs in per.items():
                 for c, vals in cs.items():
                     vals.sort()
@@ -77,6 +80,8 @@ def main():
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if launch_n[c]:
                 n = len(launch_n[c]) // (3 if wl == "mpc_phases" else 1)
+                if wl == "mpc" and rank_n[c]:  # launch in predicted order: several sparse dispatches and ONE rank kernel per launch
+                    n = len(rank_n[c])
                 out[c] = {"dispatches": n, "mean_per_dispatch_KB": launch_tot[c] / max(1, n)}
         for k, e in out["kernels"].items():  # derived ratios
             c = {n: v["mean_per_dispatch"] for n, v in e.get("counters", {}).items()}
