@@ -490,7 +490,7 @@ def dense_sizes_table(sfb, device, cores):
     rows = []
     for n, m in DENSE_SIZES:
         k = n + m
-        B = 8192 if k <= 32 else (4096 if k <= 64 else 2048)
+        B = 65536  # the batch of BASELINE configs[1]: one QP that runs into max_iter sets the time of a small batch
         P, q, A, l, u = sfb.random_qp_batch(5, B, m, n, 1.0)
         d = [torch.from_numpy(a).to(device) for a in (P, q, A, l, u)]
         f64 = dict(dtype=torch.float64, device=device)

@@ -36,6 +36,9 @@
 #ifndef SFB_SWEEP_DEPTH
 #define SFB_SWEEP_DEPTH 8  // units (2 slots per lane each) in flight per sweep
 #endif
+#ifndef SFB_LAT_SWEEP_DEPTH
+#define SFB_LAT_SWEEP_DEPTH 8  // ... in the loop of the LAT form (8 or 16)
+#endif
 
 namespace sfb {
 
@@ -1492,7 +1495,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     }
     }
     wave_sync();
-    if (!(SFB_ITER_EXP & 2)) ldl_solve_dev<SFB_SWEEP_DEPTH>(pl, w, t, lane, lean);                               // :456-460
+    if (!(SFB_ITER_EXP & 2)) ldl_solve_dev<LAT ? SFB_LAT_SWEEP_DEPTH : SFB_SWEEP_DEPTH>(pl, w, t, lane, lean);  // :456-460
     for (int q = 0; q < nap; ++q) __builtin_amdgcn_s_sleep(16);  // pacing of the items that are not critical (see the kernel)
     const bool chk = (iter == next_chk);
     if (chk) next_chk += sci;
