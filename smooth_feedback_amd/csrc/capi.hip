@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+#include "knobs.h"
 #include "../../include/sfb.h"
 #include "capi_common.h"
 #include "qp_dense_kernel.h"
@@ -89,7 +90,7 @@ DenseKernelParams make_kernel_params(const sfb_qp_params *prm, int n, int m)
   kp.scaling         = prm->scaling ? 1 : 0;
   kp.polish          = prm->polish ? 1 : 0;
   kp.reuse           = prm->reuse_factor ? 1 : 0;
-  if (const char *nr = std::getenv("SFB_QP_NO_REUSE"); nr && nr[0] == '1') kp.reuse = 0;  // A/B knob (tests, timing)
+  if (const char *nr = sfb::knob("SFB_QP_NO_REUSE"); nr && nr[0] == '1') kp.reuse = 0;  // A/B knob (tests, timing)
   return kp;
 }
 
@@ -371,7 +372,7 @@ static sfb_status dense_workspace_need(const sfb_qp_params *prm, int64_t batch, 
   const int k = n + m;
   *need       = 0;
   if (k > SFB_QP_DENSE_MAX_K) {
-    static const bool big_off = [] { const char *v = getenv("SFB_QP_DENSE_BIG"); return v && v[0] == '0'; }();
+    static const bool big_off = [] { const char *v = sfb::knob("SFB_QP_DENSE_BIG"); return v && v[0] == '0'; }();
     if (k <= sfb::kDenseBigMaxK && !big_off) {
       *need = (size_t)batch * sfb::qp_dense_big_ws_doubles(n, m) * sizeof(double);
       return SFB_OK;
@@ -411,7 +412,7 @@ static sfb_status dense_solve_impl(const sfb_qp_params *prm, int64_t batch, int 
   }
   if (n + m > SFB_QP_DENSE_MAX_K) {
     // SFB_QP_DENSE_BIG=0 (A/B, tests): route these sizes to the un-pivoted sparse kernel as well
-    static const bool big_off = [] { const char *v = getenv("SFB_QP_DENSE_BIG"); return v && v[0] == '0'; }();
+    static const bool big_off = [] { const char *v = sfb::knob("SFB_QP_DENSE_BIG"); return v && v[0] == '0'; }();
     if (n + m <= sfb::kDenseBigMaxK && !big_off)
       return dense_big(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code, static_cast<hipStream_t>(stream),
                        wsmem);

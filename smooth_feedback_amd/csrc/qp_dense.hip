@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstdlib>
 
+#include "knobs.h"
 #include "../../include/sfb.h"
 #include "qp_dense_common.h"
 
@@ -303,19 +304,19 @@ hipError_t qp_dense_launch(const DenseKernelParams &kp, int64_t batch, const dou
                            void *workspace)
 {
   const int k        = kp.n + kp.m;
-  const char *env4 = getenv("SFB_QP_DENSE4");  // A/B and tests: 0 selects the one-QP-per-wave kernels
+  const char *env4 = sfb::knob("SFB_QP_DENSE4");  // A/B and tests: 0 selects the one-QP-per-wave kernels
   const int dense4 = env4 ? atoi(env4) : 1;
   if (k <= 32 && dense4 && kp.max_time_ns < 0) {  // (a time limit is implemented by the one-QP-per-wave kernels)
     const QpBatch g{P, q, A, l, u, wx, wy, x, y, obj, iter, code};
     return qp_dense4_launch(kp, batch, g, stream, workspace);
   }
   size_t lds         = qp_dense_lds_bytes(kp.n, kp.m);
-  if (const char *pad = getenv("SFB_QP_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments only
+  if (const char *pad = sfb::knob("SFB_QP_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments only
   const dim3 grid((unsigned)batch), block(kWave);
 #define SFB_LAUNCH(KPV, MODE)                                                                                   \
   hipLaunchKernelGGL((qp_dense_kernel<KPV, MODE>), grid, block, lds, stream, kp, P, q, A, l, u, wx, wy, x, y, \
                      obj, iter, code)
-  static const int force_mode = getenv("SFB_QP_SWEEP") ? atoi(getenv("SFB_QP_SWEEP")) : -1;  // A/B only
+  static const int force_mode = sfb::knob("SFB_QP_SWEEP") ? atoi(sfb::knob("SFB_QP_SWEEP")) : -1;  // A/B only
   if (k <= 32 && force_mode != SWEEP_READLANE) {
     SFB_LAUNCH(32, SWEEP_DPP32);
   } else if (k <= 16) {

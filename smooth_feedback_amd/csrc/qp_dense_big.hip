@@ -26,6 +26,7 @@
 #include <type_traits>
 #include <utility>
 
+#include "knobs.h"
 #include "../../include/sfb.h"
 #include "qp_dense_kernel.h"
 #include "wave_util.h"
@@ -862,12 +863,12 @@ static BigLds big_lds_config(int n, int m, int64_t batch)
   const size_t per_row = kBP * sizeof(double) + sizeof(int), cu = 160 * 1024;
   // k <= 128: the packed engine -- the whole factor in LDS (it takes the place of the row pool), no diagonal cache.
   // SFB_QP_BIG_PACKED=0 (A/B knob) keeps the tile / list engine.
-  static const bool packed_off = [] { const char *v = getenv("SFB_QP_BIG_PACKED"); return v && v[0] == '0'; }();
+  static const bool packed_off = [] { const char *v = sfb::knob("SFB_QP_BIG_PACKED"); return v && v[0] == '0'; }();
   if (n + m <= kMidMaxK && !packed_off) {
     const int rc = (int)((mid_lds_doubles(n + m) + kBP - 1) / kBP);
     return BigLds{false, rc, big_lds_fixed_bytes(n, m, false) + (size_t)rc * per_row, true};
   }
-  static const bool force_roomy = [] { const char *v = getenv("SFB_BIG_ROOMY"); return v && v[0] == '1'; }();  // A/B knob
+  static const bool force_roomy = [] { const char *v = sfb::knob("SFB_BIG_ROOMY"); return v && v[0] == '1'; }();  // A/B knob
   const bool roomy = batch < kRoomyBatch || force_roomy;
   auto make = [&](bool dc) {
     const int rc = big_row_cap(n, m, roomy, dc);

@@ -26,6 +26,7 @@
 #include <cfloat>
 #include <cmath>
 
+#include "knobs.h"
 #include "../../include/sfb.h"
 #include "qp_sparse_kernel.h"
 #include "wave_util.h"
@@ -1957,22 +1958,22 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
   const bool pruned = pl.Aorig != nullptr;
   size_t lds = (size_t)std::max(pl.lds_doubles, pruned ? fallback->lds_doubles : 0) * sizeof(double);
   // SFB_SP_WAVES_PER_CU (tuning): cap the resident workgroups per CU by padding the LDS request
-  if (const char *wpc = getenv("SFB_SP_WAVES_PER_CU"); wpc && atoi(wpc) > 0)
+  if (const char *wpc = sfb::knob("SFB_SP_WAVES_PER_CU"); wpc && atoi(wpc) > 0)
     lds = std::max(lds, std::min<size_t>(160 * 1024, (size_t)(160 * 1024 / atoi(wpc)) & ~(size_t)15));
   const size_t wsd = qp_sparse_ws_doubles(pl);
   // below this many busy waves the sweeps use plain loads (see the kernel); SFB_SP_LEAN_WAVES overrides (tuning)
-  const char *lw        = getenv("SFB_SP_LEAN_WAVES");
+  const char *lw        = sfb::knob("SFB_SP_LEAN_WAVES");
   const int lean_waves  = lw ? atoi(lw) : 512;
   // Time slicing (see the kernel): only when the batch does not fit the chip at once.  SFB_SP_SLICE = iterations
   // per slice (0 = off: one block per item, the hardware dispatcher is the queue).
-  const char *sl   = getenv("SFB_SP_SLICE");
+  const char *sl   = sfb::knob("SFB_SP_SLICE");
   const int slice  = sl ? atoi(sl) : 50;
   unsigned grid    = (unsigned)batch;
   int32_t *qarg    = nullptr;
   bool sliced      = false;
   if (aux != nullptr && slice > 0) {
     int resident = sparse_resident_blocks(lds);
-    if (const char *g = getenv("SFB_SP_GRID"); g && atoi(g) > 0) resident = std::min(resident, atoi(g));  // tests: force slicing
+    if (const char *g = sfb::knob("SFB_SP_GRID"); g && atoi(g) > 0) resident = std::min(resident, atoi(g));  // tests: force slicing
     if (resident > 0 && batch > resident) {
       grid   = (unsigned)resident;
       qarg   = aux;
@@ -1990,11 +1991,11 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
   // ADMM phase gains, the lost overlap of setup / polish (7.6 + 10 ms on their own) with it costs again, and the tail of
   // long-running items is the same.  So the phased launch is OFF by default; it stays as the instrument that separates
   // the three phases for the profiler (profiles/r3_mpc_phases).
-  const char *ph    = getenv("SFB_SP_PHASED");
+  const char *ph    = sfb::knob("SFB_SP_PHASED");
   const bool phased = sliced && ph && atoi(ph) == 1;
   auto launch = [&](unsigned g, int32_t *qa, int lw, int phases, const int32_t *ord = nullptr, uint32_t slc = 0, float *keys = nullptr,
                     const int32_t *nfresh = nullptr, int mode_sel = -1, bool lat = false, size_t lds_lat = 0) -> hipError_t {
-    const int ncrit = 0, nap = getenv("SFB_SP_NAP") ? atoi(getenv("SFB_SP_NAP")) : 0;  // (experiments, see scripts/r3/experiments)
+    const int ncrit = 0, nap = sfb::knob("SFB_SP_NAP") ? atoi(sfb::knob("SFB_SP_NAP")) : 0;  // (experiments, see scripts/r3/experiments)
     if (qa != nullptr || pruned) {
       hipError_t e = hipMemsetAsync(aux, 0, sparse_aux_queue_ints(batch) * sizeof(int32_t), stream);
       if (e != hipSuccess) return e;
@@ -2017,8 +2018,8 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
   // launch runs them longest-first, first come first served, on a grid small enough that a wave iterates at nearly the
   // speed of a lone wave (its factor stays in the 256 MB Infinity Cache).  The order is a schedule only: the results are
   // bit-identical (tests/test_mpc_gpu.py).
-  const char *pr       = getenv("SFB_SP_PREDICT");
-  const char *pa       = getenv("SFB_SP_PAUSE");
+  const char *pr       = sfb::knob("SFB_SP_PREDICT");
+  const char *pa       = sfb::knob("SFB_SP_PAUSE");
   const unsigned pause = pa ? (unsigned)std::max(0, atoi(pa)) : 27u;
   const bool predicted = sliced && !phased && !(pr && atoi(pr) == 0) && pause > 0 && kp.stop_check_iter >= 2 && kp.max_iter > 2 * pause;
   if (predicted) {
@@ -2034,7 +2035,7 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     // waves' factors fit the Infinity Cache, non-temporal masked ones beyond (as in the single launch).
     const double stream_bytes = (double)(pl.funits + pl.bunits) * 128.0 * sizeof(double), mall = 256.0 * 1024.0 * 1024.0;
     unsigned g_lo = std::min(grid, ((unsigned)std::max(256.0, 0.70 * mall / stream_bytes) + 32u) / 64u * 64u), g_hi = grid;
-    if (const char *g3 = getenv("SFB_SP_GRID3"); g3 && atoi(g3) > 0) g_lo = g_hi = std::min(grid, (unsigned)atoi(g3));
+    if (const char *g3 = sfb::knob("SFB_SP_GRID3"); g3 && atoi(g3) > 0) g_lo = g_hi = std::min(grid, (unsigned)atoi(g3));
     // LAT form of the second launch (see sp_solve_item): the loop's vectors in LDS, two waves per CU -- when that many waves
     // are enough for the survivors' work (the rank kernel decides; headline batch: yes) and the vectors fit; polish and
     // report of the survivors then follow as a launch of their own on the whole chip (they are latency-bound and want every
@@ -2043,7 +2044,7 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     const int kk = pl.n + pl.m;
     const size_t lds_lat = std::max(lds, (size_t)(((kk + 2) & ~1) + 2 * pl.n + 6 * pl.m + (kk + 1) / 2 + 2) * sizeof(double));
     int lat_hi = 0, lat_lo = 0;
-    if (const char *lt = getenv("SFB_SP_LAT"); !(lt && atoi(lt) == 0) && lds_lat <= 80 * 1024) {
+    if (const char *lt = sfb::knob("SFB_SP_LAT"); !(lt && atoi(lt) == 0) && lds_lat <= 80 * 1024) {
       static bool attr_set = false;  // (idempotent; racing callers set the same value)
       if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(qp_sparse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
@@ -2054,15 +2055,15 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
           hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qp_sparse_kernel<true>, kWave, lds_lat) == hipSuccess &&
           hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
         lat_hi = std::min<int>(per_cu * cus, (int)grid);
-      const char *ll = getenv("SFB_SP_LAT_LO");
+      const char *ll = sfb::knob("SFB_SP_LAT_LO");
       lat_lo = std::min(lat_hi, ll ? atoi(ll) : 448);
-      if (const char *g3 = getenv("SFB_SP_GRID3"); g3 && atoi(g3) > 0) lat_lo = lat_hi = std::min(lat_hi, atoi(g3));
+      if (const char *g3 = sfb::knob("SFB_SP_GRID3"); g3 && atoi(g3) > 0) lat_lo = lat_hi = std::min(lat_hi, atoi(g3));
     }
     hipLaunchKernelGGL(sp_rank_kernel, dim3(1), dim3(kRankThreads), 0, stream, keys, (int)batch, order2, count, (int)g_lo, (int)g_hi,
                        lat_lo, lat_hi);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    const char *lw3 = getenv("SFB_SP_LEAN_WAVES3");
-    const char *sl3 = getenv("SFB_SP_SLICE3");
+    const char *lw3 = sfb::knob("SFB_SP_LEAN_WAVES3");
+    const char *sl3 = sfb::knob("SFB_SP_SLICE3");
     const uint32_t slice3 = sl3 ? (uint32_t)std::max(1, atoi(sl3)) : 0x40000000u;
     if (lat_hi > 0) {
       e = launch((unsigned)lat_hi, qarg, 0x7FFFFFFF, phases_pack(PH_ADMM, PH_ADMM), order2, slice3, nullptr, count, 1, true, lds_lat);
@@ -2073,7 +2074,7 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     return launch(g_hi, qarg, lw3 ? atoi(lw3) : (int)std::max(512.0, mall / stream_bytes), phases_pack(PH_ADMM, PH_FINISH), order2, slice3,
                   nullptr, count, lat_hi > 0 ? 0 : -1);
   }
-  if (const char *fl = getenv("SFB_SP_FORCE_LAT"); !phased && fl && atoi(fl) == 1) {  // measurements: the LAT form for a whole launch
+  if (const char *fl = sfb::knob("SFB_SP_FORCE_LAT"); !phased && fl && atoi(fl) == 1) {  // measurements: the LAT form for a whole launch
     const int kk = pl.n + pl.m;
     const size_t lds_lat = std::max(lds, (size_t)(((kk + 2) & ~1) + 2 * pl.n + 6 * pl.m + (kk + 1) / 2 + 2) * sizeof(double));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(qp_sparse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2083,10 +2084,10 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
   // grid of the ADMM phase: items whose two schedule-ordered factor copies fit ~70 % of the MALL
   const double stream_bytes = (double)(pl.funits + pl.bunits) * 128.0 * sizeof(double);
   unsigned grid2 = (unsigned)std::max(256.0, 0.70 * 256.0 * 1024.0 * 1024.0 / stream_bytes);
-  if (const char *g2 = getenv("SFB_SP_GRID2"); g2 && atoi(g2) > 0) grid2 = (unsigned)atoi(g2);
+  if (const char *g2 = sfb::knob("SFB_SP_GRID2"); g2 && atoi(g2) > 0) grid2 = (unsigned)atoi(g2);
   grid2 = std::min(grid2, grid);
   // plain (cache-allocating) loads in the ADMM phase unless the grid is too large for the MALL anyway
-  const char *lw2       = getenv("SFB_SP_LEAN_WAVES2");
+  const char *lw2       = sfb::knob("SFB_SP_LEAN_WAVES2");
   const int lean_waves2 = lw2 ? atoi(lw2) : (grid2 < grid ? 0x7FFFFFFF : lean_waves);
   hipError_t e = launch(grid, qarg, lean_waves, phases_pack(PH_SETUP, PH_SETUP), order);
   if (e != hipSuccess) return e;

@@ -1,3 +1,4 @@
+#include "knobs.h"
 #include "sparse_plan.h"
 
 #include <algorithm>
@@ -343,7 +344,7 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
     {
       constexpr int kMinCols = 8;
       std::vector<char> in_lds(k, 0);
-      const char *no_lds = getenv("SFB_PLAN_NO_LDS");  // A/B knob: every column a top column (accumulators in HBM)
+      const char *no_lds = sfb::knob("SFB_PLAN_NO_LDS");  // A/B knob: every column a top column (accumulators in HBM)
       for (int j = (no_lds && no_lds[0] == '1') ? -1 : k - 1; j >= 0;) {
         const int c0 = fdesc[j], nc = j - c0 + 1, nL = FLp[j + 1] - FLp[c0];
         const int reserve = std::max(2 * maxR1[j], 384);  // panel + multipliers of the supernodes formed below
@@ -520,7 +521,7 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
       }
     o.ztop.push_back(SCRATCH); o.ztop.push_back(2);
     o.nztop = (int)o.ztop.size() / 2;
-    if (const char *dbg = getenv("SFB_PLAN_DEBUG"); dbg && dbg[0] == '1') {  // diagnostics: segments and supernodes
+    if (const char *dbg = sfb::knob("SFB_PLAN_DEBUG"); dbg && dbg[0] == '1') {  // diagnostics: segments and supernodes
       int maxR = 0, over64 = 0, nlds = 0, cols_lds = 0;
       long long panel = 0, acc_lds = 0, ext = 0, internal = 0;
       for (const Seg &sg : segs) {
@@ -624,7 +625,7 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
       }
     }
     const int steps = (int)slots.size();
-    if (const char *dbg = getenv("SFB_PLAN_DEBUG"); dbg && dbg[0] == '1') {  // diagnostics: fill of the sweep units
+    if (const char *dbg = sfb::knob("SFB_PLAN_DEBUG"); dbg && dbg[0] == '1') {  // diagnostics: fill of the sweep units
       fprintf(stderr, "[sfb plan] %s sweep: %d units, slots per unit:", forward ? "forward" : "backward", steps);
       for (int s = 0; s < steps; ++s) fprintf(stderr, " %d", (int)slots[s].size());
       fprintf(stderr, "\n");
