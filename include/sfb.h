@@ -287,6 +287,17 @@ sfb_status sfb_sparse_qp_solve_batch_ordered(sfb_sparse_qp_plan *plan, const sfb
                                              const double *u, const double *warm_x, const double *warm_y, double *x,
                                              double *y, double *obj, uint32_t *iter, int32_t *code, void *workspace,
                                              const int32_t *order, void *stream);
+/* Same with the reference's verbose table (qp_solver.hpp:409-420, :490-501) as DATA: trace [batch][trace_rows][5] (device)
+ * receives, per item and stopping check, one row (ITER, OBJ = (0.5 P x + q).x, PRI_RES = |A x - z|_inf,
+ * DUA_RES = |P x + q + A'y|_inf on the unscaled iterate -- the reference's expressions -- and TIME in microseconds of
+ * the device clock since the item's solve began); checks beyond trace_rows are dropped, the caller presets ITER = -1 to
+ * recognise unused rows.  One wave per item without time slicing, same arithmetic and results as the plain call
+ * (a launch of a separate instance of the kernel: diagnostics, not the fast path). */
+sfb_status sfb_sparse_qp_solve_batch_trace(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
+                                           const double *Px, const double *q, const double *Ax, const double *l,
+                                           const double *u, const double *warm_x, const double *warm_y, double *x,
+                                           double *y, double *obj, uint32_t *iter, int32_t *code, void *workspace,
+                                           double *trace, int32_t trace_rows, void *stream);
 /* Same with host pointers (synchronous).  The device buffers are owned by the plan and kept between calls
  * (grow-only, freed by sfb_sparse_qp_plan_destroy) -- the analogue of the working memory a QPSolver object
  * keeps between solves (qp_solver.hpp:242-338); host-pointer calls on ONE plan and ONE device are serialised. */
@@ -294,6 +305,15 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
                                           const double *Px, const double *q, const double *Ax, const double *l,
                                           const double *u, const double *warm_x, const double *warm_y,
                                           double *x, double *y, double *obj, uint32_t *iter, int32_t *code);
+/* ... with the verbose table as data (trace [batch][trace_rows][5], HOST memory, nullable; see
+ * sfb_sparse_qp_solve_batch_trace).  sfb_sparse_qp_solve_batch_host with prm->verbose set and batch == 1 -- the
+ * reference's use of the flag, one QPSolver object -- collects the table this way and prints it in the reference's
+ * format (header, one line per stopping check, summary). */
+sfb_status sfb_sparse_qp_solve_batch_host_trace(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
+                                                const double *Px, const double *q, const double *Ax, const double *l,
+                                                const double *u, const double *warm_x, const double *warm_y, double *x,
+                                                double *y, double *obj, uint32_t *iter, int32_t *code, double *trace,
+                                                int32_t trace_rows);
 /* ... and sharded over the device list (sfb_set_devices): one contiguous shard, host thread, plan upload and workspace
  * per device; same arguments, same results (calls on different devices are not serialised). */
 sfb_status sfb_sparse_qp_solve_batch_host_multi(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,

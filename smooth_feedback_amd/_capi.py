@@ -95,6 +95,8 @@ def _load():
     L.sfb_sparse_qp_solve_batch_ordered.argtypes = [C.c_void_p, C.POINTER(SfbQPParams), i64] + [dp] * 12 + [vp, vp, vp]
     L.sfb_sparse_qp_solve_batch_host.argtypes = [C.c_void_p, C.POINTER(SfbQPParams), i64] + [dp] * 12
     L.sfb_sparse_qp_solve_batch_host_multi.argtypes = L.sfb_sparse_qp_solve_batch_host.argtypes
+    L.sfb_sparse_qp_solve_batch_host_trace.argtypes = [C.c_void_p, C.POINTER(SfbQPParams), i64] + [dp] * 12 + [dp, i32]
+    L.sfb_sparse_qp_solve_batch_trace.argtypes = [C.c_void_p, C.POINTER(SfbQPParams), i64] + [dp] * 12 + [vp, dp, i32, vp]
     L.sfb_ekf_predict_batch.argtypes = [i64, i32, dp, dp, i32, dp, i32, dp, vp]
     L.sfb_ekf_predict_stepper_batch.argtypes = [i32, i64, i32, dp, dp, i32, dp, i32, dp, vp]
     L.sfb_ekf_predict_stepper_batch_host.argtypes = [i32, i64, i32, dp, dp, i32, dp, i32, dp]

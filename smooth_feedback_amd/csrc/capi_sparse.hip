@@ -315,11 +315,12 @@ sfb_status sfb_sparse_qp_plan_get_factor_order(const sfb_sparse_qp_plan *plan, i
   return SFB_OK;
 }
 
-sfb_status sfb_sparse_qp_solve_batch_ordered(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
+namespace {
+sfb_status solve_batch_impl(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
                                      const double *Px, const double *q, const double *Ax, const double *l,
                                      const double *u, const double *warm_x, const double *warm_y, double *x,
                                      double *y, double *obj, uint32_t *iter, int32_t *code, void *workspace,
-                                             const int32_t *order, void *stream)
+                                             const int32_t *order, void *stream, double *trace, int32_t trace_rows)
 {
   sfb_status st = check_sparse_args(plan, prm, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, code);
   if (st != SFB_OK) return st;
@@ -336,9 +337,32 @@ sfb_status sfb_sparse_qp_solve_batch_ordered(sfb_sparse_qp_plan *plan, const sfb
   char *wsc        = static_cast<char *>(workspace);
   hipError_t e     = sfb::qp_sparse_launch(dc->dev, kp, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code,
                                            reinterpret_cast<double *>(wsc), hs, order, reinterpret_cast<int32_t *>(wsc + L.aux_off),
-                                           plan->pruned ? &dc->dev_full : nullptr, reinterpret_cast<double *>(wsc + L.pool_off));
+                                           plan->pruned ? &dc->dev_full : nullptr, reinterpret_cast<double *>(wsc + L.pool_off),
+                                           trace, (int)trace_rows);
   if (e != hipSuccess) return sfb::hip_fail(e, "qp_sparse_kernel launch");
   return SFB_OK;
+}
+}  // namespace
+
+sfb_status sfb_sparse_qp_solve_batch_ordered(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
+                                             const double *Px, const double *q, const double *Ax, const double *l,
+                                             const double *u, const double *warm_x, const double *warm_y, double *x,
+                                             double *y, double *obj, uint32_t *iter, int32_t *code, void *workspace,
+                                             const int32_t *order, void *stream)
+{
+  return solve_batch_impl(plan, prm, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code, workspace, order, stream,
+                          nullptr, 0);
+}
+
+sfb_status sfb_sparse_qp_solve_batch_trace(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
+                                           const double *Px, const double *q, const double *Ax, const double *l,
+                                           const double *u, const double *warm_x, const double *warm_y, double *x,
+                                           double *y, double *obj, uint32_t *iter, int32_t *code, void *workspace,
+                                           double *trace, int32_t trace_rows, void *stream)
+{
+  if (!trace || trace_rows <= 0) return sfb::fail(SFB_ERR_INVALID_ARG, "trace is NULL or trace_rows <= 0");
+  return solve_batch_impl(plan, prm, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code, workspace, nullptr, stream,
+                          trace, trace_rows);
 }
 
 sfb_status sfb_sparse_qp_solve_batch(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
@@ -356,7 +380,27 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
                                           const double *u, const double *warm_x, const double *warm_y, double *x,
                                           double *y, double *obj, uint32_t *iter, int32_t *code)
 {
+  return sfb_sparse_qp_solve_batch_host_trace(plan, prm, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code, nullptr, 0);
+}
+
+sfb_status sfb_sparse_qp_solve_batch_host_trace(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
+                                                const double *Px, const double *q, const double *Ax, const double *l,
+                                                const double *u, const double *warm_x, const double *warm_y, double *x,
+                                                double *y, double *obj, uint32_t *iter, int32_t *code, double *trace,
+                                                int32_t trace_rows)
+{
   sfb_status st = check_sparse_args(plan, prm, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, code);
+  if (st == SFB_OK && trace != nullptr && trace_rows <= 0) st = sfb::fail(SFB_ERR_INVALID_ARG, "trace_rows <= 0");
+  // verbose for ONE problem (the reference's use of the flag: one QPSolver object, qp_solver.hpp:409-420, :490-501): the
+  // per-iteration table is collected on the device and printed below
+  std::vector<double> vtrace;
+  if (st == SFB_OK && prm->verbose && batch == 1 && trace == nullptr) {
+    const uint64_t sci = prm->stop_check_iter > 0 ? (uint64_t)prm->stop_check_iter : 1u, cap = 4096;
+    const uint64_t mi  = prm->max_iter >= 0 ? (uint64_t)prm->max_iter : cap * sci;  // (negative: no limit)
+    trace_rows = (int32_t)std::min<uint64_t>(cap, mi / sci + 2);
+    vtrace.assign((size_t)trace_rows * 5, 0.0);
+    trace = vtrace.data();
+  }
   if (st != SFB_OK) return st;
   st = sfb::require_device();
   if (st != SFB_OK) return st;
@@ -364,7 +408,8 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
   const sfb::SparsePlanHost &h = sfb::plan_io(plan);  // the caller's pattern (strides of the value arrays)
   const size_t B = (size_t)batch, N = (size_t)h.n, M = (size_t)h.m, NP = (size_t)h.nnzP, NA = (size_t)h.nnzA;
   const size_t wsb  = ws_layout(plan, batch).total;  // multiple of 8
-  const size_t in_d = B * (NP + N + NA + 2 * M) + (warm_x ? B * (N + M) : 0), out_d = B * (N + M + 1);
+  const size_t TR = trace ? B * (size_t)trace_rows * 5 : 0;
+  const size_t in_d = B * (NP + N + NA + 2 * M) + (warm_x ? B * (N + M) : 0), out_d = B * (N + M + 1) + TR;
   const size_t bytes = (in_d + out_d) * sizeof(double) + wsb + B * 8;
   int devid    = 0;
   hipError_t e = hipGetDevice(&devid);
@@ -399,8 +444,8 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
   double *dq = dPx + B * NP, *dAx = dq + B * N, *dl = dAx + B * NA, *du = dl + B * M;
   double *dwx = nullptr, *dwy = nullptr, *dx = du + B * M;
   if (warm_x) { dwx = dx; dwy = dwx + B * N; dx = dwy + B * M; }
-  double *dy = dx + B * N, *dobj = dy + B * M;
-  uint32_t *dit  = reinterpret_cast<uint32_t *>(dobj + B);
+  double *dy = dx + B * N, *dobj = dy + B * M, *dtrace = dobj + B;
+  uint32_t *dit  = reinterpret_cast<uint32_t *>(dtrace + TR);
   int32_t *dcode = reinterpret_cast<int32_t *>(dit + B);
   auto H2D = [&](void *d, const void *hh, size_t nb) { return nb ? hipMemcpy(d, hh, nb, hipMemcpyHostToDevice) : hipSuccess; };
   auto D2H = [&](void *hh, const void *d, size_t nb) { return nb ? hipMemcpy(hh, d, nb, hipMemcpyDeviceToHost) : hipSuccess; };
@@ -418,9 +463,13 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
       if ((e = H2D(dwx, warm_x, B * N * 8)) != hipSuccess) break;
       if ((e = H2D(dwy, warm_y, B * M * 8)) != hipSuccess) break;
     }
+    if (trace) {  // unused rows keep ITER = -1
+      for (size_t r = 0; r < TR; ++r) trace[r] = (r % 5 == 0) ? -1.0 : 0.0;
+      if ((e = H2D(dtrace, trace, TR * 8)) != hipSuccess) break;
+    }
     tv1 = clk::now();
-    st = sfb_sparse_qp_solve_batch(plan, prm, batch, dPx, dq, dAx, dl, du, dwx, dwy, dx, dy, dobj, dit, dcode, dws,
-                                   nullptr);
+    st = solve_batch_impl(plan, prm, batch, dPx, dq, dAx, dl, du, dwx, dwy, dx, dy, dobj, dit, dcode, dws, nullptr, nullptr,
+                          trace ? dtrace : nullptr, trace_rows);
     if (st != SFB_OK) break;
     if ((e = hipDeviceSynchronize()) != hipSuccess) break;
     tv2 = clk::now();
@@ -429,8 +478,17 @@ sfb_status sfb_sparse_qp_solve_batch_host(sfb_sparse_qp_plan *plan, const sfb_qp
     if (obj && (e = D2H(obj, dobj, B * 8)) != hipSuccess) break;
     if (iter && (e = D2H(iter, dit, B * 4)) != hipSuccess) break;
     if ((e = D2H(code, dcode, B * 4)) != hipSuccess) break;
+    if (trace && (e = D2H(trace, dtrace, TR * 8)) != hipSuccess) break;
   } while (false);
   if (e != hipSuccess) st = sfb::hip_fail(e, "sfb_sparse_qp_solve_batch_host");
+  if (st == SFB_OK && !vtrace.empty()) {  // the table of qp_solver.hpp:409-420, :490-501 (TIME: device clock, microseconds)
+    std::printf("========================= QP Solver =========================\n");
+    std::printf("Solving sparse QP with n=%d, m=%d\n", h.n, h.m);
+    std::printf("%8s%14s%14s%14s%10s\n", "ITER", "OBJ", "PRI_RES", "DUA_RES", "TIME");
+    for (int32_t r = 0; r < trace_rows && vtrace[(size_t)r * 5] >= 0.0; ++r)
+      std::printf("%7.0f:%14.6e%14.6e%14.6e%10.0f\n", vtrace[(size_t)r * 5], vtrace[(size_t)r * 5 + 1], vtrace[(size_t)r * 5 + 2],
+                  vtrace[(size_t)r * 5 + 3], vtrace[(size_t)r * 5 + 4]);
+  }
   if (st == SFB_OK && prm->verbose) {
     std::vector<uint32_t> itv;
     if (!iter) {

@@ -1001,6 +1001,41 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
   return -1;
 }
 
+// One row of the reference's verbose table (qp_solver.hpp:490-501) after a stopping check: ITER, OBJ = (0.5 P x + q) . x,
+// PRI_RES = |A x - z|_inf, DUA_RES = |P x + q + A' y|_inf on the unscaled iterate, TIME in microseconds of the device clock
+// since the item's solve began -- the three columns in the reference's expressions and the order of
+// oracle/qp_sparse_oracle.c's trace (products row by row like the check's, the dot product a sequential mul + add chain).
+// Only the TRACE instance of the kernel calls this (sfb_sparse_qp_solve_batch_trace); t is scratch like in the check.
+__device__ __noinline__ void sp_trace_row(const SparsePlanDev &pl, const Item &it, const Ws &w, double *t, const int lane,
+                                          const uint32_t iter, const unsigned long long t0_ticks, double *row)
+{
+  const int n = uni(pl.n), m = uni(pl.m);
+  const int chunk = (uni(pl.k) + 1) / 2;
+  double pri = 0.0, dua = 0.0, o = 0.0;
+  for (int i = lane; i < m; i += kWave) pri = fmax(pri, fabs(sp_row_A(pl, it, i, w.xus) - w.zus[i]));
+  for (int c0 = 0; c0 < n; c0 += chunk) {
+    const int c1 = min(n, c0 + chunk);
+    for (int j = c0 + lane; j < c1; j += kWave) {
+      const double Px = sp_row_P(pl, it, j, w.xus), qj = it.q[j];
+      dua = fmax(dua, fabs(Px + qj + sp_row_At(pl, it, j, w.yus)));
+      t[2 * (j - c0)]     = 0.5 * Px + qj;
+      t[2 * (j - c0) + 1] = w.xus[j];
+    }
+    wave_sync();
+    for (int e = 0; e < c1 - c0; ++e) o += t[2 * e] * t[2 * e + 1];
+    wave_sync();
+  }
+  pri = wave_max(pri);
+  dua = wave_max(dua);
+  if (lane == 0) {
+    row[0] = (double)iter;
+    row[1] = o;
+    row[2] = pri;
+    row[3] = dua;
+    row[4] = (double)(wall_clock64() - t0_ticks) * 0.01;
+  }
+}
+
 // detail::polish_qp (sparse), embedded in the full pattern.  In/out: scaled xs / ys in the workspace.
 // wf: the workspace view whose factor fields the polish factorisation may overwrite (w itself, or polish_ws(w))
 template<int SD>
@@ -1143,7 +1178,7 @@ __device__ __forceinline__ bool sp_guard_ok(const SparsePlanDev &pl, const doubl
 // has used its slice while others are waiting for a wave (SP_SUSPENDED: state saved, the caller queues the item).
 // LAT: the form for launches with few waves, each nearly alone on its SIMD (second launch of the predicted order): one
 // wave per SIMD pair of registers more (256 VGPRs) and the ADMM vectors of the loop in LDS, see the loop
-template<bool LAT>
+template<bool LAT, bool TRACE = false>
 __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const DenseKernelParams &kp, const double *__restrict__ gPx,
                                              const double *__restrict__ gq, const double *__restrict__ gAx,
                                              const double *__restrict__ gl, const double *__restrict__ gu,
@@ -1153,7 +1188,8 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
                                              double *__restrict__ gws, const size_t ws_doubles, const int lean_waves,
                                              bool lean, const size_t b, const size_t slot, double *t, const int lane,
                                              bool resume, const int32_t *queue, const int batch,
-                                             const uint32_t slice, const bool allow_reuse, const int phases, float *score, const int nap = 0)
+                                             const uint32_t slice, const bool allow_reuse, const int phases, float *score, const int nap = 0,
+                                             double *trace = nullptr, const int trace_cap = 0)
 {
   const int ph0 = phases & 15, ph1 = (phases >> 4) & 15;  // the phases this launch performs
   const uint32_t pause_at = (uint32_t)phases >> 8;        // != 0: leave the ADMM loop open at the first check from here on
@@ -1171,6 +1207,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
   const uint32_t sci   = kp.stop_check_iter;
   const uint32_t maxit = kp.max_iter;
   uint32_t next_chk    = (sci >= 2) ? 1u : 0xFFFFFFFFu;
+  [[maybe_unused]] int trace_rows = 0;  // TRACE: rows of the verbose table written so far (one block per item: never suspended)
   if (lane == 0) t[k] = 0.0;  // padding slot of the packed sweeps
   const double inf = INFINITY;
   unsigned long long t0_ticks = wall_clock64();  // start of the item's solve (:376), kept across suspensions
@@ -1590,6 +1627,10 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     wave_sync();
     if (chk) {
       ret_code = sp_check_stopping(pl, it, w, kp, t, lane, pause_at != 0 ? score : nullptr);
+      if constexpr (TRACE) {  // the reference's verbose table as data (:490-501)
+        if (trace != nullptr && trace_rows < trace_cap) sp_trace_row(pl, it, w, t, lane, iter, t0_ticks, trace + ((size_t)b * (size_t)trace_cap + (size_t)trace_rows) * 5);
+        ++trace_rows;
+      }
       if (ret_code < 0 && max_time_exceeded(kp.max_time_ns, t0_ticks)) ret_code = SFB_QP_MAX_TIME;  // :504-507
       wave_sync();
       lean = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_sparse_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >
@@ -1735,7 +1776,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
 // fallback pool of a pruned plan (kFbSlots ints, 0 = free).
 constexpr int kFbSlots = 64;
 
-template<bool LAT>
+template<bool LAT, bool TRACE = false>
 __global__ void __launch_bounds__(64, LAT ? 2 : 3) qp_sparse_kernel(const SparsePlanDev *__restrict__ plp, const DenseKernelParams kp,
                                                        const double *__restrict__ gPx, const double *__restrict__ gq,
                                                        const double *__restrict__ gAx, const double *__restrict__ gl,
@@ -1749,7 +1790,7 @@ __global__ void __launch_bounds__(64, LAT ? 2 : 3) qp_sparse_kernel(const Sparse
                                                        const SparsePlanDev *__restrict__ plf, double *__restrict__ gwsf,
                                                        const size_t wsf_doubles, int32_t *__restrict__ fbflags, const int phases, const int nfb,
                                                        float *__restrict__ keys, const int32_t *__restrict__ nfresh_dev, const int ncrit, const int nap,
-                                                       const int mode_sel)
+                                                       const int mode_sel, double *__restrict__ trace, const int trace_cap)
 {
   // ncrit: the first ncrit fresh items of this launch (the longest of a launch in predicted order) always use cacheable loads
   // keys (nullable): per item, the predictor score of a paused item (SP_PAUSED) or -1 (nothing left to do for the next launch)
@@ -1824,11 +1865,11 @@ __global__ void __launch_bounds__(64, LAT ? 2 : 3) qp_sparse_kernel(const Sparse
     if (lane == 0) seen = atomicAdd(&g_sparse_active, 1);
     const bool lean = (nwaves > lean_waves_item) || __builtin_amdgcn_readfirstlane(seen) >= lean_waves_item;
     // (phased launches: an item of the fallback pool runs all phases at once, in the setup launch)
-    const int st = sp_solve_item<LAT>(*use, kp, gPx, gq, gAx, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode, wsb, wsd, lean_waves_item,
+    const int st = sp_solve_item<LAT, TRACE>(*use, kp, gPx, gq, gAx, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode, wsb, wsd, lean_waves_item,
                                  lean, (size_t)item, slot, t, lane, resume != 0, fbslot >= 0 ? nullptr : queue, nfresh, slice,
                                  /*allow_reuse: the item's own slot of the main workspace*/ fbslot < 0 && slot == (size_t)item,
                                  fbslot >= 0 ? PH_EVERYTHING : phases, keys ? keys + item : nullptr,
-                                 __builtin_amdgcn_readfirstlane(crit) ? 0 : nap);
+                                 __builtin_amdgcn_readfirstlane(crit) ? 0 : nap, trace, trace_cap);
     if (keys != nullptr && st != SP_PAUSED && lane == 0) keys[item] = -1.0f;
     if (fbslot >= 0 && phases != PH_EVERYTHING && lane == 0)  // tell the later launches (the item's own slot is otherwise unused)
       carve_ws(gws + (size_t)item * ws_doubles, uni(plp->n), uni(plp->m), uni(plp->nnzL), uni(plp->funits), uni(plp->bunits)).hdr[kHdrComplete] = 1.0;
@@ -1952,7 +1993,7 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
                             const double *q, const double *Ax, const double *l, const double *u, const double *wx,
                             const double *wy, double *x, double *y, double *obj, uint32_t *iter, int32_t *code,
                             double *workspace, hipStream_t stream, const int32_t *order, int32_t *aux,
-                            const SparsePlanDev *fallback, double *fallback_ws)
+                            const SparsePlanDev *fallback, double *fallback_ws, double *trace, int trace_cap)
 {
   if (pl.Aorig != nullptr && (fallback == nullptr || fallback_ws == nullptr || aux == nullptr)) return hipErrorInvalidValue;
   const bool pruned = pl.Aorig != nullptr;
@@ -2000,13 +2041,17 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
       hipError_t e = hipMemsetAsync(aux, 0, sparse_aux_queue_ints(batch) * sizeof(int32_t), stream);
       if (e != hipSuccess) return e;
     }
-    auto *kern = lat ? qp_sparse_kernel<true> : qp_sparse_kernel<false>;
+    auto *kern = trace ? qp_sparse_kernel<false, true> : (lat ? qp_sparse_kernel<true> : qp_sparse_kernel<false>);
     hipLaunchKernelGGL(kern, dim3(g), dim3(kWave), lat ? lds_lat : lds, stream, pl.self, kp, Px, q, Ax, l, u, wx, wy, x, y, obj, iter,
                        code, workspace, wsd, lw, ord, qa, (int)batch, slc ? slc : (uint32_t)std::max(1, slice),
                        pruned ? fallback->self : nullptr, fallback_ws, pruned ? qp_sparse_ws_doubles(*fallback) : 0,
-                       aux ? aux + batch + kQRing : nullptr, phases, (int)std::min<int64_t>(batch, kFbSlots), keys, nfresh, ncrit, nap, mode_sel);
+                       aux ? aux + batch + kQRing : nullptr, phases, (int)std::min<int64_t>(batch, kFbSlots), keys, nfresh, ncrit, nap, mode_sel,
+                       trace, trace_cap);
     return hipGetLastError();
   };
+  // TRACE (sfb_sparse_qp_solve_batch_trace): one block per item whatever the batch size -- the row count of an item's table
+  // lives in its wave -- through the TRACE instance of the kernel; same arithmetic, same results.
+  if (trace != nullptr) return launch((unsigned)batch, nullptr, lean_waves, PH_EVERYTHING, order);
   // LAUNCH IN PREDICTED ORDER (time-sliced launches, default; SFB_SP_PREDICT=0 turns it off).  ADMM iteration counts are
   // heavy-tailed (headline batch: mean 88, p99 627, max 1 152) and a wave alone needs 22-27 us per iteration, so the
   // longest items set the time of a launch unless they START first -- and what identifies them is cheap: the ratio of

@@ -80,11 +80,15 @@ inline size_t qp_sparse_ws_doubles(const SparsePlanDev &pl)
 //   fallback / fallback_ws: pruned plans only -- the whole-pattern plan and a pool of qp_sparse_fallback_slots()
 //   workspace slots of ITS per-item size: an item whose masked entries are not all zero is solved there, inside
 //   the same launch.
+//   trace (device, batch x trace_cap x 5 doubles, nullable): the reference's verbose table as data -- per item one row
+//   (ITER, OBJ, PRI_RES, DUA_RES, TIME us) per stopping check, rows beyond trace_cap are dropped; the caller presets
+//   ITER = -1.  Forces one block per item (no time slicing).
 hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp, int64_t batch, const double *Px,
                             const double *q, const double *Ax, const double *l, const double *u, const double *wx,
                             const double *wy, double *x, double *y, double *obj, uint32_t *iter, int32_t *code,
                             double *workspace, hipStream_t stream, const int32_t *order = nullptr, int32_t *aux = nullptr,
-                            const SparsePlanDev *fallback = nullptr, double *fallback_ws = nullptr);
+                            const SparsePlanDev *fallback = nullptr, double *fallback_ws = nullptr,
+                            double *trace = nullptr, int trace_cap = 0);
 size_t qp_sparse_aux_bytes(int64_t batch);
 int qp_sparse_fallback_slots();
 

@@ -92,6 +92,7 @@ class QPBatchSolution:
     primal: np.ndarray
     dual: np.ndarray
     objective: np.ndarray
+    trace: Optional[np.ndarray] = None  # (B, rows, 5): ITER, OBJ, PRI_RES, DUA_RES, TIME [us] per stopping check (ITER -1: unused)
 
 
 def _f64(a, shape):
@@ -336,8 +337,9 @@ class SparseQPPlan:
             pass
 
     def solve_batch_host(self, Px, q, Ax, l, u, prm: Optional[QPSolverParams] = None, warm_x=None, warm_y=None,
-                         multi_device=False):
-        """sfb_sparse_qp_solve_batch_host[_multi]: Px (B, nnzP), q (B, n), Ax (B, nnzA), l,u (B, m)."""
+                         multi_device=False, trace_rows=0):
+        """sfb_sparse_qp_solve_batch_host[_multi | _trace]: Px (B, nnzP), q (B, n), Ax (B, nnzA), l,u (B, m).
+        trace_rows > 0: the reference's verbose table (qp_solver.hpp:490-501) as data in `.trace`."""
         q = np.ascontiguousarray(q, dtype=np.float64)
         B = q.shape[0]
         Px = _f64(np.reshape(Px, (B, self.nnzP)), (B, self.nnzP))
@@ -350,6 +352,14 @@ class SparseQPPlan:
         x = np.empty((B, self.n)); y = np.empty((B, self.m)); obj = np.empty(B)
         it = np.empty(B, dtype=np.uint32); code = np.empty(B, dtype=np.int32)
         cp = (prm or QPSolverParams()).to_c()
+        if trace_rows:
+            if multi_device:
+                raise ValueError("trace_rows and multi_device exclude each other")
+            trace = np.empty((B, int(trace_rows), 5))
+            _capi.check(_capi.lib.sfb_sparse_qp_solve_batch_host_trace(
+                self._h, C.byref(cp), B, _ptr(Px), _ptr(q), _ptr(Ax), _ptr(l), _ptr(u), _ptr(warm_x), _ptr(warm_y),
+                _ptr(x), _ptr(y), _ptr(obj), _ptr(it), _ptr(code), _ptr(trace), int(trace_rows)))
+            return QPBatchSolution(code=code, iter=it, primal=x, dual=y, objective=obj, trace=trace)
         fn = _capi.lib.sfb_sparse_qp_solve_batch_host_multi if multi_device else _capi.lib.sfb_sparse_qp_solve_batch_host
         _capi.check(fn(
             self._h, C.byref(cp), B, _ptr(Px), _ptr(q), _ptr(Ax), _ptr(l), _ptr(u), _ptr(warm_x), _ptr(warm_y),

@@ -125,3 +125,51 @@ def test_solve_after_solve_batch_does_not_reuse_a_foreign_factor(sfb):
     assert M.lib().sfbx_test_solve_after_solve_batch(out.ctypes.data_as(C.c_void_p)) == 0
     assert out[0] == 1.0 and out[1] == 0.0 and out[2] == 1.0 and out[3] == 1.0, out
     assert not np.allclose(out[4:6], out[6:8])          # the batch call really solved another problem
+
+
+@pytest.mark.parametrize("n,m,density", [(10, 20, 0.5), (30, 50, 0.15)])
+def test_verbose_table_as_data_matches_the_oracle_trace(sfb, oracle, n, m, density):
+    """qp_solver.hpp:490-501: ITER, OBJ, PRI_RES, DUA_RES per stopping check -- the device trace against the oracle's,
+    and the results of the traced call against the plain one (bit for bit)."""
+    B, rows = 96, 12
+    P, q, A, l, u = sfb.random_qp_batch(17, B, m, n, density)
+    Pp, Pi, Px, Ap, Aj, Ax = dense_batch_to_sparse(P, A, n, m, upper_only=True)
+    plan = sfb.SparseQPPlan(n, m, Pp, Pi, Ap, Aj)
+    prm = sfb.QPSolverParams(max_iter=252)
+    plain = plan.solve_batch_host(Px, q, Ax, l, u, prm)
+    r = plan.solve_batch_host(Px, q, Ax, l, u, prm, trace_rows=rows)
+    assert np.array_equal(r.code, plain.code) and np.array_equal(r.iter, plain.iter)
+    assert np.array_equal(r.primal, plain.primal, equal_nan=True) and np.array_equal(r.dual, plain.dual, equal_nan=True)
+    ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Ax, l, u, perm=plan.perm, forder=plan.factor_order(),
+                                       params=_oracle_params(oracle, prm), nthreads=8, trace_rows=rows)
+    assert np.array_equal(r.iter, ref["iter"])
+    tr, tref = r.trace, ref["trace"]
+    assert np.array_equal(tr[:, :, 0], tref[:, :, 0]), "check iterations differ"
+    used = tref[:, :, 0] >= 0
+    assert used.sum() > B  # more than one check per item on average
+    assert (tr[:, :, 0][used] % 25 == 1).all()  # checks at iter % 25 == 1 (:479)
+    for col, name in ((1, "OBJ"), (2, "PRI_RES"), (3, "DUA_RES")):
+        a, b = tr[:, :, col][used], tref[:, :, col][used]
+        fin = np.isfinite(b)
+        assert np.array_equal(a[fin], b[fin]), (name, np.abs(a[fin] - b[fin]).max())
+    both = used[:, 1:] & used[:, :-1]
+    assert (tr[:, :, 4][used] >= 0).all() and (tr[:, 1:, 4][both] >= tr[:, :-1, 4][both]).all()  # TIME (device clock, us) grows
+    # a table shorter than the number of checks: the leading rows, nothing written behind them
+    short = plan.solve_batch_host(Px, q, Ax, l, u, prm, trace_rows=2)
+    assert short.trace.shape == (B, 2, 5) and np.array_equal(short.trace[:, :, :4], tr[:, :2, :4], equal_nan=True)
+
+
+def test_verbose_single_problem_prints_the_reference_table(sfb, capfd):
+    """QPSolverParams::verbose on one sparse problem: the header and one line per stopping check (qp_solver.hpp:409-420,
+    :490-501), then the summary."""
+    case = KNOWN_ANSWERS["PortfolioOptimization"] if "PortfolioOptimization" in KNOWN_ANSWERS else KNOWN_ANSWERS[sorted(KNOWN_ANSWERS)[0]]
+    P, q, A, l, u = (np.asarray(t, dtype=np.float64) for t in case[:5])
+    Pc = sp.csc_matrix(P); Pc.eliminate_zeros(); Pc.sort_indices()
+    Ac = sp.csr_matrix(A); Ac.sort_indices()
+    plan = sfb.SparseQPPlan(len(q), len(l), Pc.indptr, Pc.indices, Ac.indptr, Ac.indices)
+    r = plan.solve_batch_host(Pc.data[None], q[None], Ac.data[None], l[None], u[None], sfb.QPSolverParams(verbose=True))
+    out = capfd.readouterr().out
+    assert "========================= QP Solver" in out and "Solving sparse QP with n=%d, m=%d" % (len(q), len(l)) in out
+    assert "ITER" in out and "PRI_RES" in out and "DUA_RES" in out
+    lines = [ln for ln in out.splitlines() if ln.strip().split(":")[0].strip().isdigit() and ":" in ln]
+    assert len(lines) == (int(r.iter[0]) - 2) // 25 + 1 and lines[0].strip().startswith("1:")
