@@ -40,6 +40,9 @@
 #ifndef SFB_LAT_SWEEP_DEPTH
 #define SFB_LAT_SWEEP_DEPTH 8  // ... in the loop of the LAT form (8 or 16)
 #endif
+#ifndef SFB_LAT_NT
+#define SFB_LAT_NT 0  // 1: the loop of the LAT form streams the factor VALUES with non-temporal loads (the index arrays keep the L2)
+#endif
 
 namespace sfb {
 
@@ -612,7 +615,7 @@ __device__ __forceinline__ void stream_wait(vdouble2 &a, vint2 &b)
 // LDS round trip per unit on the dependent chain of a lone wave).  Branch-free; DEPTH units
 // (= 2 x DEPTH slots per lane) are in flight ahead of their use so the ~1.7 us HBM latency of a lone
 // wave is covered; t has k+1 entries, t[k] is the padding slot; `units` is a multiple of the prefetch block (8).
-template<int DEPTH, bool BYTEOFF, bool LEAN>
+template<int DEPTH, bool BYTEOFF, bool LEAN, bool NTP = false>
 __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const int units, const double *vals, double *t,
                                  const int lane, const int32_t *__restrict__ mask32, const int full0, const int full1)
 {
@@ -662,7 +665,7 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
               [&]<int D>(std::integral_constant<int, D> dd) { issue(dd, std::integral_constant<int, 2>{}, mk); });
   } else {
     for_units(std::make_integer_sequence<int, DEPTH>{},
-              [&]<int D>(std::integral_constant<int, D> dd) { issue(dd, std::integral_constant<int, 0>{}, mk); });
+              [&]<int D>(std::integral_constant<int, D> dd) { issue(dd, std::integral_constant<int, NTP ? 1 : 0>{}, mk); });
   }
   advance(DEPTH);
   // (tgt, piv) of the two slots of a unit as byte offsets (BYTEOFF, plan.idx_scale == 8) or element indices
@@ -706,7 +709,7 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
       // `units` is a multiple of 8 and the arrays carry 16 units of padding: the last block of a 16-deep pipeline may
       // start 8 units before the end -- its prefetches (never consumed) are pulled back into the padding
       if (DEPTH == 16 && u0 + DEPTH > units) advance(-8);
-      block(std::integral_constant<int, 0>{}, u0);
+      block(std::integral_constant<int, NTP ? 1 : 0>{}, u0);
     }
   }
   // the trailing prefetches (padding) are never consumed: retire them before their registers are reused
@@ -717,7 +720,7 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
 
 // t (LDS, permuted order) <- K^-1 t   (qp_solver.hpp:457-459)
 // SD: prefetch distance of the cacheable (latency) form of the sweeps, 8 or 16 units
-template<int SD>
+template<int SD, bool NTP = false>
 __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, double *t, const int lane, const bool lean)
 {
   const int k = uni(pl.k);
@@ -727,8 +730,8 @@ __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, doubl
       if (bo) sweep_dev<SFB_SWEEP_DEPTH, true, true>(idx, units, vals, t, lane, mask, f0, f1);
       else sweep_dev<SFB_SWEEP_DEPTH, false, true>(idx, units, vals, t, lane, mask, f0, f1);
     } else {
-      if (bo) sweep_dev<SD, true, false>(idx, units, vals, t, lane, mask, f0, f1);
-      else sweep_dev<SD, false, false>(idx, units, vals, t, lane, mask, f0, f1);
+      if (bo) sweep_dev<SD, true, false, NTP>(idx, units, vals, t, lane, mask, f0, f1);
+      else sweep_dev<SD, false, false, NTP>(idx, units, vals, t, lane, mask, f0, f1);
     }
   };
   sweep(pl.fidx, uni(pl.funits), w.LxF, pl.fmask, uni(pl.ffull0), uni(pl.ffull1));  // forward (column oriented order)
@@ -1533,7 +1536,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     }
     }
     wave_sync();
-    if (!(SFB_ITER_EXP & 2)) ldl_solve_dev<LAT ? SFB_LAT_SWEEP_DEPTH : SFB_SWEEP_DEPTH>(pl, w, t, lane, lean);  // :456-460
+    if (!(SFB_ITER_EXP & 2)) ldl_solve_dev<LAT ? SFB_LAT_SWEEP_DEPTH : SFB_SWEEP_DEPTH, LAT && SFB_LAT_NT>(pl, w, t, lane, lean);  // :456-460
     for (int q = 0; q < nap; ++q) __builtin_amdgcn_s_sleep(16);  // pacing of the items that are not critical (see the kernel)
     const bool chk = (iter == next_chk);
     if (chk) next_chk += sci;
