@@ -77,7 +77,9 @@ typedef struct sfb_qp_params {
   uint32_t polish_iter;     /* :65                                      (5)     */
   float delta;              /* :67                                      (1e-6f) */
   int32_t verbose;          /* :32  host-pointer entry points print a summary of the call (phase times,
-                                    status histogram, iteration statistics); ignored by the asynchronous
+                                    status histogram, iteration statistics) and, when the call is ONE problem,
+                                    the reference's per-iteration table before it (:409-420, :490-501; as data
+                                    for any batch: sfb_sparse_qp_solve_batch_trace); ignored by the asynchronous
                                     device-pointer entry points                 (0)     */
   int32_t reuse_factor;     /* NOT in the reference (which re-scales and re-factorises on every solve(), reusing
                                     only the symbolic analysis, :424-426).  Shared-pattern sparse entry points only;

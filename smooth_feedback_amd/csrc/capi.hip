@@ -69,6 +69,25 @@ void verbose_report(const char *what, int64_t batch, int n, int m, double h2d_ms
   std::fflush(stdout);
 }
 
+void verbose_table(const char *kind, int n, int m, const double *trace, int rows, const char *note)
+{
+  std::printf("========================= QP Solver =========================\n");
+  std::printf("Solving %s QP with n=%d, m=%d\n", kind, n, m);
+  if (note) std::printf("%s\n", note);
+  std::printf("%8s%14s%14s%14s%10s\n", "ITER", "OBJ", "PRI_RES", "DUA_RES", "TIME");
+  for (int r = 0; r < rows && trace[(size_t)r * 5] >= 0.0; ++r)
+    std::printf("%7.0f:%14.6e%14.6e%14.6e%10.0f\n", trace[(size_t)r * 5], trace[(size_t)r * 5 + 1], trace[(size_t)r * 5 + 2],
+                trace[(size_t)r * 5 + 3], trace[(size_t)r * 5 + 4]);
+  std::fflush(stdout);
+}
+
+int verbose_table_rows(const sfb_qp_params *prm)
+{
+  const uint64_t sci = prm->stop_check_iter > 0 ? (uint64_t)prm->stop_check_iter : 1u, cap = 4096;
+  const uint64_t mi  = prm->max_iter >= 0 ? (uint64_t)prm->max_iter : cap * sci;  // (negative: no limit)
+  return (int)std::min<uint64_t>(cap, mi / sci + 2);
+}
+
 DenseKernelParams make_kernel_params(const sfb_qp_params *prm, int n, int m)
 {
   DenseKernelParams kp;
@@ -245,6 +264,43 @@ sfb_status dense_via_sparse(const sfb_qp_params *prm, int64_t batch, int n, int 
     (void)hipFree(buf);
   }
   return st;
+}
+
+// verbose, ONE dense problem (device pointers of the call): the per-iteration table of qp_solver.hpp:490-501.  The dense
+// kernels carry no trace; the table is produced by a second, diagnostic solve of the same problem through the sparse
+// kernel's TRACE instance on the full pattern -- no pivoting there, so its iterates equal the dense kernel's up to rounding
+// (the header says so); the results the caller receives are the dense kernel's.
+void dense_verbose_table(const sfb_qp_params *prm, int n, int m, const double *P, const double *q, const double *A, const double *l,
+                         const double *u, const double *wx, const double *wy)
+{
+  sfb_sparse_qp_plan *plan = nullptr;
+  if (dense_full_pattern_plan(n, m, &plan) != SFB_OK) return;
+  size_t abytes = 0, bytes = 0;
+  if (dense_via_sparse_bytes(plan, 1, n, m, &abytes, &bytes) != SFB_OK) return;
+  const int rows     = sfb::verbose_table_rows(prm);
+  const size_t extra = ((size_t)n + m + 2 + (size_t)rows * 5) * sizeof(double) + 16;
+  char *buf          = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&buf), bytes + extra) != hipSuccess) { (void)hipGetLastError(); return; }
+  double *Ax = reinterpret_cast<double *>(buf), *tx = reinterpret_cast<double *>(buf + bytes), *ty = tx + n, *tobj = ty + m,
+         *dtrace = tobj + 1;
+  uint32_t *titer = reinterpret_cast<uint32_t *>(dtrace + (size_t)rows * 5);
+  int32_t *tcode  = reinterpret_cast<int32_t *>(titer + 1);
+  std::vector<double> tr((size_t)rows * 5, 0.0);
+  for (int r = 0; r < rows; ++r) tr[(size_t)r * 5] = -1.0;
+  sfb_qp_params p2 = *prm;
+  p2.verbose       = 0;
+  bool ok = hipMemcpy(dtrace, tr.data(), tr.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(dense_A_to_rows_kernel, dim3(1), dim3(64), 0, nullptr, A, Ax, n, m);
+    ok = hipGetLastError() == hipSuccess &&
+         sfb_sparse_qp_solve_batch_trace(plan, &p2, 1, P, q, Ax, l, u, wx, wy, tx, ty, tobj, titer, tcode, buf + abytes, dtrace, rows,
+                                         nullptr) == SFB_OK &&
+         hipDeviceSynchronize() == hipSuccess && hipMemcpy(tr.data(), dtrace, tr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  (void)hipFree(buf);
+  if (ok)
+    sfb::verbose_table("dense", n, m, tr.data(), rows,
+                       "(table: diagnostic solve without pivoting, equal to the solve's iterates up to rounding)");
 }
 
 }  // namespace
@@ -632,13 +688,15 @@ sfb_status sfb_qp_dense_solve_batch_host(const sfb_qp_params *prm, int64_t batch
     if ((e = D2H(code, dcode, B * 4)) != hipSuccess) break;
   } while (false);
   if (e != hipSuccess) st = hip_fail(e, "sfb_qp_dense_solve_batch_host");
+  const auto tv3 = clk::now();
+  if (st == SFB_OK && prm->verbose && batch == 1) dense_verbose_table(prm, n, m, dP, dq, dA, dl, du, dwx, dwy);  // (inputs still on the device)
   if (st == SFB_OK && prm->verbose) {
     std::vector<uint32_t> itv;
     if (!iter) {
       itv.resize(B);
       if (hipMemcpy(itv.data(), dit, B * 4, hipMemcpyDeviceToHost) != hipSuccess) itv.clear();
     }
-    sfb::verbose_report("dense QP batch", batch, n, m, ms(tv0, tv1), ms(tv1, tv2), ms(tv2, clk::now()), code,
+    sfb::verbose_report("dense QP batch", batch, n, m, ms(tv0, tv1), ms(tv1, tv2), ms(tv2, tv3), code,
                         iter ? iter : (itv.empty() ? nullptr : itv.data()));
   }
   return st;

@@ -19,6 +19,11 @@ DenseKernelParams make_kernel_params(const sfb_qp_params *prm, int n, int m);
 // breakdown and the outcome): one summary of the call -- phase times, status histogram, iteration statistics.
 void verbose_report(const char *what, int64_t batch, int n, int m, double h2d_ms, double solve_ms, double d2h_ms,
                     const int32_t *code, const uint32_t *iter);
+// ... and, for ONE problem, the per-iteration table itself in the reference's format (:409-420, :490-501): trace = rows x 5
+// (ITER, OBJ, PRI_RES, DUA_RES, TIME us; ITER < 0 ends the table), as written by sfb_sparse_qp_solve_batch_trace.
+void verbose_table(const char *kind, int n, int m, const double *trace, int rows, const char *note = nullptr);
+// rows a table needs for these parameters (capped)
+int verbose_table_rows(const sfb_qp_params *prm);
 // Multi-device entry points (sfb_*_multi): the device list of sfb_set_devices (default: every visible device), and a
 // helper that cuts [0, batch) into one contiguous shard per list entry and runs `fn(device, first, count)` for every
 // non-empty shard on its own host thread with that device current.  Returns the first failure (its message becomes

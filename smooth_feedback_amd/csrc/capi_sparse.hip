@@ -395,9 +395,7 @@ sfb_status sfb_sparse_qp_solve_batch_host_trace(sfb_sparse_qp_plan *plan, const 
   // per-iteration table is collected on the device and printed below
   std::vector<double> vtrace;
   if (st == SFB_OK && prm->verbose && batch == 1 && trace == nullptr) {
-    const uint64_t sci = prm->stop_check_iter > 0 ? (uint64_t)prm->stop_check_iter : 1u, cap = 4096;
-    const uint64_t mi  = prm->max_iter >= 0 ? (uint64_t)prm->max_iter : cap * sci;  // (negative: no limit)
-    trace_rows = (int32_t)std::min<uint64_t>(cap, mi / sci + 2);
+    trace_rows = sfb::verbose_table_rows(prm);
     vtrace.assign((size_t)trace_rows * 5, 0.0);
     trace = vtrace.data();
   }
@@ -482,12 +480,7 @@ sfb_status sfb_sparse_qp_solve_batch_host_trace(sfb_sparse_qp_plan *plan, const 
   } while (false);
   if (e != hipSuccess) st = sfb::hip_fail(e, "sfb_sparse_qp_solve_batch_host");
   if (st == SFB_OK && !vtrace.empty()) {  // the table of qp_solver.hpp:409-420, :490-501 (TIME: device clock, microseconds)
-    std::printf("========================= QP Solver =========================\n");
-    std::printf("Solving sparse QP with n=%d, m=%d\n", h.n, h.m);
-    std::printf("%8s%14s%14s%14s%10s\n", "ITER", "OBJ", "PRI_RES", "DUA_RES", "TIME");
-    for (int32_t r = 0; r < trace_rows && vtrace[(size_t)r * 5] >= 0.0; ++r)
-      std::printf("%7.0f:%14.6e%14.6e%14.6e%10.0f\n", vtrace[(size_t)r * 5], vtrace[(size_t)r * 5 + 1], vtrace[(size_t)r * 5 + 2],
-                  vtrace[(size_t)r * 5 + 3], vtrace[(size_t)r * 5 + 4]);
+    sfb::verbose_table("sparse", h.n, h.m, vtrace.data(), trace_rows);
   }
   if (st == SFB_OK && prm->verbose) {
     std::vector<uint32_t> itv;

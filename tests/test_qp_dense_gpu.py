@@ -457,3 +457,26 @@ def test_non_finite_inputs_follow_the_reference_semantics(sfb, oracle, n, m):
     rc = sfb.solve_qp_batch_host(*clean, prm)
     for b in (0, 9, 10, 11):
         assert np.array_equal(rc.primal[b], r.primal[b]) and rc.iter[b] == r.iter[b]
+
+
+def test_verbose_single_dense_problem_prints_the_reference_table(sfb, capfd):
+    """QPSolverParams::verbose on ONE dense problem (the reference's use: solve_qp / one QPSolver, qp_solver.hpp:409-420,
+    :490-501): header, one line per stopping check with the residuals falling to the tolerances, then the summary; the
+    results are those of the plain call."""
+    P, q, A, l, u = sfb.random_qp_batch(3, 1, 20, 10, 1.0)
+    plain = sfb.solve_qp_batch_host(P, q, A, l, u, sfb.QPSolverParams(max_iter=4000))
+    capfd.readouterr()
+    r = sfb.solve_qp_batch_host(P, q, A, l, u, sfb.QPSolverParams(max_iter=4000, verbose=True))
+    out = capfd.readouterr().out
+    assert np.array_equal(r.primal, plain.primal) and np.array_equal(r.iter, plain.iter) and np.array_equal(r.code, plain.code)
+    assert "========================= QP Solver" in out and "Solving dense QP with n=10, m=20" in out
+    rows = [ln.split(":")[1].split() for ln in out.splitlines() if ":" in ln and ln.split(":")[0].strip().isdigit()]
+    its = [int(ln.split(":")[0]) for ln in out.splitlines() if ":" in ln and ln.split(":")[0].strip().isdigit()]
+    assert its[0] == 1 and all(b - a == 25 for a, b in zip(its, its[1:]))
+    if int(r.code[0]) == 0:  # Optimal: as many checks as the solve's own count says, the last row within the tolerances' range
+        assert len(its) == (int(r.iter[0]) - 2) // 25 + 1
+        assert float(rows[-1][1]) < float(rows[0][1]) or float(rows[-1][2]) < float(rows[0][2])
+    # batches keep the summary only
+    sfb.solve_qp_batch_host(*sfb.random_qp_batch(3, 4, 20, 10, 1.0), sfb.QPSolverParams(max_iter=100, verbose=True))
+    out = capfd.readouterr().out
+    assert "QP Solver ====" not in out and "[sfb] dense QP batch: 4 problem(s)" in out
