@@ -424,7 +424,7 @@ def pmc_traffic(workload, workload_name):
         return None, "no PMC summary"
 
 
-KERNEL_NAME = {"mpc": "qp_sparse_kernel", "qp_dense": "qp_dense4_iterate_kernel (+ setup and finish kernels of the same launch)",
+KERNEL_NAME = {"mpc": "qp_sparse_kernel (launch in predicted order: first launch, rank kernel, LAT loop launch, finish launch)", "qp_dense": "qp_dense4_iterate_kernel (+ setup and finish kernels of the same launch)",
                "ekf": "ekf_kernel"}
 
 
@@ -442,6 +442,10 @@ def roofline_of(workload, wl, kern_ms, with_traffic):
         if r["traffic"]:  # what the kernel actually moves through HBM, as a rate and a fraction of peak
             r["traffic_GBps"] = r["traffic"] / (kern_ms * 1e-3) / 1e9
             r["traffic_frac"] = r["traffic"] / (kern_ms * 1e-3) / HBM_PEAK_BYTES_PER_S
+            if workload == "mpc":
+                r["traffic_note"] = ("FETCH_SIZE / WRITE_SIZE count the L2's traffic with the fabric: more than half of it (the loop "
+                                     "launch's factor streams, profiles/r3_mpc/summary.json: qp_sparse_kernel<true>) is served by the "
+                                     "256 MB Infinity Cache, not by HBM -- an upper bound of the HBM bytes")
     return r
 
 
