@@ -721,8 +721,11 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
 // t (LDS, permuted order) <- K^-1 t   (qp_solver.hpp:457-459)
 // SD: prefetch distance of the cacheable (latency) form of the sweeps, 8 or 16 units
 template<int SD, bool NTP = false>
-__device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, double *t, const int lane, const bool lean)
+__device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, double *t, const int lane, const bool lean,
+                                     const double *dinv_lds = nullptr)
 {
+  // dinv_lds (LAT form): 1 / D in LDS -- the global copy costs a lone wave one memory round trip per iteration
+  const double *const Dinv = dinv_lds ? dinv_lds : w.Dinv;
   const int k = uni(pl.k);
   const bool bo = uni(pl.idx_scale) == 8;
   auto sweep = [&](const int32_t *idx, const int units, const double *vals, const int32_t *mask, const int f0, const int f1) {
@@ -738,7 +741,7 @@ __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, doubl
   for (int j0 = lane; j0 < k; j0 += kWave * 8) {  // D^-1 (:458), loads batched
     double dv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dv[e] = (j0 + e * kWave < k) ? w.Dinv[j0 + e * kWave] : 0.0;
+    for (int e = 0; e < 8; ++e) dv[e] = (j0 + e * kWave < k) ? Dinv[j0 + e * kWave] : 0.0;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
       if (j0 + e * kWave < k) t[j0 + e * kWave] = dv[e] * t[j0 + e * kWave];
@@ -1470,18 +1473,21 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
   // the five global round trips of the update phases, and the vectors are a quarter of the loop's traffic.
   double *vxs = w.xs, *vqc = w.qc, *vys = w.ys, *vzs = w.zs, *vrinv = w.rinv, *vrho = w.rho, *vlo = w.lo, *vhi = w.hi;
   const int32_t *vpinv = pl.pinv;
+  [[maybe_unused]] double *vdinv = nullptr;  // LAT: 1 / D of the ADMM factor in LDS
   const bool iterates  = ph0 <= PH_ADMM && iter != maxit && ret_code < 0;
   if constexpr (LAT) {
     vxs = t + ((k + 2) & ~1); vqc = vxs + n; vys = vqc + n; vzs = vys + m; vrinv = vzs + m; vrho = vrinv + m; vlo = vrho + m;
     vhi = vlo + m;
     int32_t *lp = reinterpret_cast<int32_t *>(vhi + m);
     vpinv       = lp;
+    vdinv       = reinterpret_cast<double *>(lp + ((k + 2) & ~1));
     if (iterates) {
       for (int j = lane; j < n; j += kWave) { vxs[j] = w.xs[j]; vqc[j] = w.qc[j]; }
       for (int i = lane; i < m; i += kWave) {
         vys[i] = w.ys[i]; vzs[i] = w.zs[i]; vrinv[i] = w.rinv[i]; vrho[i] = w.rho[i]; vlo[i] = w.lo[i]; vhi[i] = w.hi[i];
       }
       for (int e = lane; e < k; e += kWave) lp[e] = pl.pinv[e];
+      for (int e = lane; e < k; e += kWave) vdinv[e] = w.Dinv[e];
       wave_sync();
     }
   }
@@ -1536,7 +1542,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     }
     }
     wave_sync();
-    if (!(SFB_ITER_EXP & 2)) ldl_solve_dev<LAT ? SFB_LAT_SWEEP_DEPTH : SFB_SWEEP_DEPTH, LAT && SFB_LAT_NT>(pl, w, t, lane, lean);  // :456-460
+    if (!(SFB_ITER_EXP & 2)) ldl_solve_dev<LAT ? SFB_LAT_SWEEP_DEPTH : SFB_SWEEP_DEPTH, LAT && SFB_LAT_NT>(pl, w, t, lane, lean, LAT ? vdinv : nullptr);  // :456-460
     for (int q = 0; q < nap; ++q) __builtin_amdgcn_s_sleep(16);  // pacing of the items that are not critical (see the kernel)
     const bool chk = (iter == next_chk);
     if (chk) next_chk += sci;
@@ -2090,7 +2096,7 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     // wave; inside the few waves of the loop they took 40 % of the wave time).  Otherwise: the standard kernel, loop and
     // polish in one launch.  Both are enqueued, the blocks of the form that was not chosen leave at once.
     const int kk = pl.n + pl.m;
-    const size_t lds_lat = std::max(lds, (size_t)(((kk + 2) & ~1) + 2 * pl.n + 6 * pl.m + (kk + 1) / 2 + 2) * sizeof(double));
+    const size_t lds_lat = std::max(lds, (size_t)(((kk + 2) & ~1) + 2 * pl.n + 6 * pl.m + ((kk + 2) & ~1) / 2 + kk + 2) * sizeof(double));
     int lat_hi = 0, lat_lo = 0;
     if (const char *lt = sfb::knob("SFB_SP_LAT"); !(lt && atoi(lt) == 0) && lds_lat <= 80 * 1024) {
       static bool attr_set = false;  // (idempotent; racing callers set the same value)
@@ -2124,7 +2130,7 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
   }
   if (const char *fl = sfb::knob("SFB_SP_FORCE_LAT"); !phased && fl && atoi(fl) == 1) {  // measurements: the LAT form for a whole launch
     const int kk = pl.n + pl.m;
-    const size_t lds_lat = std::max(lds, (size_t)(((kk + 2) & ~1) + 2 * pl.n + 6 * pl.m + (kk + 1) / 2 + 2) * sizeof(double));
+    const size_t lds_lat = std::max(lds, (size_t)(((kk + 2) & ~1) + 2 * pl.n + 6 * pl.m + ((kk + 2) & ~1) / 2 + kk + 2) * sizeof(double));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(qp_sparse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return launch(grid, qarg, lean_waves, PH_EVERYTHING, order, 0, nullptr, nullptr, -1, true, lds_lat);
   }
