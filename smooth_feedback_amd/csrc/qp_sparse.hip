@@ -615,10 +615,18 @@ __device__ __forceinline__ void stream_wait(vdouble2 &a, vint2 &b)
 // LDS round trip per unit on the dependent chain of a lone wave).  Branch-free; DEPTH units
 // (= 2 x DEPTH slots per lane) are in flight ahead of their use so the ~1.7 us HBM latency of a lone
 // wave is covered; t has k+1 entries, t[k] is the padding slot; `units` is a multiple of the prefetch block (8).
-template<int DEPTH, bool BYTEOFF, bool LEAN, bool NTP = false>
+// CHAINED SWEEPS (cacheable form only): sweeps that follow each other share their prefetch registers so that the stream
+// never drains between them.  NEXT: the last block fetches the first DEPTH units of the NEXT stream (idx_next / vals_next)
+// instead of padding and leaves them in flight in lx / ix; PRE: no prologue, lx / ix hold this sweep's first DEPTH units
+// already (issued by the sweep before).  A lone wave otherwise waits one full memory latency at the head of every sweep.
+// (Between chained sweeps nothing else may touch memory: the counted waits assume the stream's loads only.)
+template<int DEPTH, bool BYTEOFF, bool LEAN, bool NTP = false, bool PRE = false, bool NEXT = false>
 __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const int units, const double *vals, double *t,
-                                 const int lane, const int32_t *__restrict__ mask32, const int full0, const int full1)
+                                 const int lane, const int32_t *__restrict__ mask32, const int full0, const int full1,
+                                 vdouble2 (&lx)[DEPTH], vint2 (&ix)[DEPTH], const int32_t *__restrict__ idx_next = nullptr,
+                                 const double *vals_next = nullptr)
 {
+  static_assert(!(PRE || NEXT) || (!LEAN && DEPTH == 8), "chained sweeps: cacheable form, prefetch distance 8");
   // lean == false (few waves left on the chip: latency matters, HBM traffic does not): every block issues plain loads
   static_assert(DEPTH <= kSweepPadDev && kSweepPadDev % DEPTH == 0, "schedule padding must cover the prefetch distance");
   static_assert(2 * DEPTH <= 62, "vmcnt is a 6-bit counter");
@@ -631,10 +639,10 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
   for (int e = 0; e < NVP; ++e) vp[e] = reinterpret_cast<const vdouble2 *>(vals) + lane + e * 4 * kWave;
 #pragma unroll
   for (int e = 0; e < NIP; ++e) ip[e] = reinterpret_cast<const vint2 *>(idx) + lane + e * 8 * kWave;
-  vdouble2 lx[DEPTH];
-  vint2 ix[DEPTH];
+  if constexpr (!PRE) {
 #pragma unroll
-  for (int d = 0; d < DEPTH; ++d) lx[d] = vdouble2{0.0, 0.0};  // masked lanes keep what the register holds
+    for (int d = 0; d < DEPTH; ++d) lx[d] = vdouble2{0.0, 0.0};  // masked lanes keep what the register holds
+  }
   // Value loads of partially filled units are masked to the lanes that carry slots (sparse_plan.h): the padding
   // of the schedule then costs no HBM traffic.  Units in [full0, full1) are full: plain loads, no mask fetch.
   // MODE 0: plain cached loads (latency mode); 1: non-temporal loads (full units, bandwidth mode); 2: non-temporal
@@ -663,7 +671,7 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
     mask_wait(mk);
     for_units(std::make_integer_sequence<int, DEPTH>{},
               [&]<int D>(std::integral_constant<int, D> dd) { issue(dd, std::integral_constant<int, 2>{}, mk); });
-  } else {
+  } else if constexpr (!PRE) {
     for_units(std::make_integer_sequence<int, DEPTH>{},
               [&]<int D>(std::integral_constant<int, D> dd) { issue(dd, std::integral_constant<int, NTP ? 1 : 0>{}, mk); });
   }
@@ -705,17 +713,28 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
     for (; u0 < r1; u0 += DEPTH) block(std::integral_constant<int, 1>{}, u0);
     for (; u0 < units; u0 += DEPTH) block(std::integral_constant<int, 2>{}, u0);
   } else {
-    for (; u0 < units; u0 += DEPTH) {
+    for (; u0 + (NEXT ? DEPTH : 0) < units; u0 += DEPTH) {
       // `units` is a multiple of 8 and the arrays carry 16 units of padding: the last block of a 16-deep pipeline may
       // start 8 units before the end -- its prefetches (never consumed) are pulled back into the padding
       if (DEPTH == 16 && u0 + DEPTH > units) advance(-8);
       block(std::integral_constant<int, NTP ? 1 : 0>{}, u0);
     }
-  }
-  // the trailing prefetches (padding) are never consumed: retire them before their registers are reused
+    if constexpr (NEXT) {  // the last block (units >= DEPTH, the caller's condition): its loads are the next stream's first units
 #pragma unroll
-  for (int d = 0; d < DEPTH; ++d) stream_wait<0>(lx[d], ix[d]);
-  wave_sync();
+      for (int e = 0; e < NVP; ++e) vp[e] = reinterpret_cast<const vdouble2 *>(vals_next) + lane + e * 4 * kWave;
+#pragma unroll
+      for (int e = 0; e < NIP; ++e) ip[e] = reinterpret_cast<const vint2 *>(idx_next) + lane + e * 8 * kWave;
+      block(std::integral_constant<int, NTP ? 1 : 0>{}, u0);
+    }
+  }
+  if constexpr (NEXT) {
+    wave_lds_fence();  // (no s_waitcnt vmcnt(0) here: the next sweep's first units stay in flight)
+  } else {
+    // the trailing prefetches (padding) are never consumed: retire them before their registers are reused
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) stream_wait<0>(lx[d], ix[d]);
+    wave_sync();
+  }
 }
 
 // t (LDS, permuted order) <- K^-1 t   (qp_solver.hpp:457-459)
@@ -730,11 +749,15 @@ __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, doubl
   const bool bo = uni(pl.idx_scale) == 8;
   auto sweep = [&](const int32_t *idx, const int units, const double *vals, const int32_t *mask, const int f0, const int f1) {
     if (lean) {
-      if (bo) sweep_dev<SFB_SWEEP_DEPTH, true, true>(idx, units, vals, t, lane, mask, f0, f1);
-      else sweep_dev<SFB_SWEEP_DEPTH, false, true>(idx, units, vals, t, lane, mask, f0, f1);
+      vdouble2 lx[SFB_SWEEP_DEPTH];
+      vint2 ix[SFB_SWEEP_DEPTH];
+      if (bo) sweep_dev<SFB_SWEEP_DEPTH, true, true>(idx, units, vals, t, lane, mask, f0, f1, lx, ix);
+      else sweep_dev<SFB_SWEEP_DEPTH, false, true>(idx, units, vals, t, lane, mask, f0, f1, lx, ix);
     } else {
-      if (bo) sweep_dev<SD, true, false, NTP>(idx, units, vals, t, lane, mask, f0, f1);
-      else sweep_dev<SD, false, false, NTP>(idx, units, vals, t, lane, mask, f0, f1);
+      vdouble2 lx[SD];
+      vint2 ix[SD];
+      if (bo) sweep_dev<SD, true, false, NTP>(idx, units, vals, t, lane, mask, f0, f1, lx, ix);
+      else sweep_dev<SD, false, false, NTP>(idx, units, vals, t, lane, mask, f0, f1, lx, ix);
     }
   };
   sweep(pl.fidx, uni(pl.funits), w.LxF, pl.fmask, uni(pl.ffull0), uni(pl.ffull1));  // forward (column oriented order)
@@ -748,6 +771,31 @@ __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, doubl
   }
   wave_sync();
   sweep(pl.bidx, uni(pl.bunits), w.LxB, pl.bmask, uni(pl.bfull0), uni(pl.bfull1));  // backward (rows pushing, descending)
+}
+
+// The same for the LAT form of the loop (1 / D and every loop vector in LDS: between the sweeps, and between the backward
+// sweep of one iteration and the forward sweep of the next, nothing touches memory): the sweeps are CHAINED -- the forward
+// sweep's last block fetches the head of the backward stream, the backward sweep's last block the head of the forward
+// stream for the next iteration when the caller says there is one without a stopping check in between (`next`); `pre`:
+// lx / ix hold the forward stream's head from the previous call.  Requires byte offsets and funits, bunits >= 8.
+template<bool NTP>
+__device__ __forceinline__ void ldl_solve_lat(const SparsePlanDev &pl, const Ws &w, double *t, const int lane, const double *Dinv,
+                                              vdouble2 (&lx)[8], vint2 (&ix)[8], const bool pre, const bool next)
+{
+  const int k = uni(pl.k);
+  if (pre) sweep_dev<8, true, false, NTP, true, true>(pl.fidx, uni(pl.funits), w.LxF, t, lane, pl.fmask, 0, 0, lx, ix, pl.bidx, w.LxB);
+  else sweep_dev<8, true, false, NTP, false, true>(pl.fidx, uni(pl.funits), w.LxF, t, lane, pl.fmask, 0, 0, lx, ix, pl.bidx, w.LxB);
+  for (int j0 = lane; j0 < k; j0 += kWave * 8) {  // D^-1 (:458) from LDS
+    double dv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dv[e] = (j0 + e * kWave < k) ? Dinv[j0 + e * kWave] : 0.0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (j0 + e * kWave < k) t[j0 + e * kWave] = dv[e] * t[j0 + e * kWave];
+  }
+  wave_lds_fence();
+  if (next) sweep_dev<8, true, false, NTP, true, true>(pl.bidx, uni(pl.bunits), w.LxB, t, lane, pl.bmask, 0, 0, lx, ix, pl.fidx, w.LxF);
+  else sweep_dev<8, true, false, NTP, true, false>(pl.bidx, uni(pl.bunits), w.LxB, t, lane, pl.bmask, 0, 0, lx, ix);
 }
 
 __device__ __forceinline__ double lane_max_abs(const double *v, int len, int lane)
@@ -1499,6 +1547,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
       }
     }
   };
+  [[maybe_unused]] const bool lat_chain = LAT && uni(pl.idx_scale) == 8 && uni(pl.funits) >= 8 && uni(pl.bunits) >= 8;
   for (; ph0 <= PH_ADMM && iter != maxit && ret_code < 0; ++iter) {
     // element-wise phases: the loads of UNR strided elements are issued together (one memory round
     // trip per UNR elements instead of one per element -- matters for a wave that runs alone)
@@ -1541,10 +1590,23 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
         if (i0 + e * kWave < m) t[pv[e]] = zv[e] - rv[e] * yv[e];
     }
     }
-    wave_sync();
-    if (!(SFB_ITER_EXP & 2)) ldl_solve_dev<LAT ? SFB_LAT_SWEEP_DEPTH : SFB_SWEEP_DEPTH, LAT && SFB_LAT_NT>(pl, w, t, lane, lean, LAT ? vdinv : nullptr);  // :456-460
-    for (int q = 0; q < nap; ++q) __builtin_amdgcn_s_sleep(16);  // pacing of the items that are not critical (see the kernel)
     const bool chk = (iter == next_chk);
+    wave_sync();
+    if constexpr (LAT && SFB_LAT_SWEEP_DEPTH == 8) {
+      if (lat_chain && !lean) {
+        // chained sweeps (ldl_solve_lat): the backward stream's head is fetched by the forward sweep's last block.  Carrying the
+        // chain on into the next iteration's forward sweep (prefetch registers live across the update phases) was built and
+        // is NOT done: the compiler is free to copy loop-carried registers while their loads are in flight (wrong results).
+        vdouble2 lat_lx[8];
+        vint2 lat_ix[8];
+        ldl_solve_lat<SFB_LAT_NT != 0>(pl, w, t, lane, vdinv, lat_lx, lat_ix, false, false);
+      } else {
+        ldl_solve_dev<SFB_LAT_SWEEP_DEPTH, SFB_LAT_NT != 0>(pl, w, t, lane, lean, vdinv);
+      }
+    } else {
+    if (!(SFB_ITER_EXP & 2)) ldl_solve_dev<LAT ? SFB_LAT_SWEEP_DEPTH : SFB_SWEEP_DEPTH, LAT && SFB_LAT_NT>(pl, w, t, lane, lean, LAT ? vdinv : nullptr);  // :456-460
+    }
+    for (int q = 0; q < nap; ++q) __builtin_amdgcn_s_sleep(16);  // pacing of the items that are not critical (see the kernel)
     if (chk) next_chk += sci;
     need_rhs = chk;
     // UPDATE PHASES :470-477.  Whole rows of 64 elements run without predicates, U rows per batch (their loads are issued
