@@ -921,6 +921,10 @@ __device__ __forceinline__ double sp_row_P(const SparsePlanDev &pl, const Item &
 // are fetched by all lanes in parallel, chunk by chunk, and only the dependent add / fma chain is sequential.
 // score (nullable): how far the item is from its tolerances at this check -- residual / tolerance of the primal test,
 // or of the dual test when the primal one passes -- the launcher's predictor of the iterations that are left.
+// RBX: rows per lane whose products are formed together (their loads share the memory round trips): 4 is what the
+// register budget of three waves per SIMD leaves; the LAT form (one wave per SIMD pair of registers more, the loop's state in
+// LDS) takes all rows of a lane at once -- a check cost a lone wave 46 us = two iterations, most of it these round trips.
+template<int RBX = 4>
 __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it, const Ws &w,
                                         const DenseKernelParams &kp, double *t, const int lane, float *score = nullptr)
 {
@@ -929,7 +933,7 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
   const int chunk  = (uni(pl.k) + 1) / 2;  // pairs of doubles that fit the work vector
   {  // OPTIMALITY
     double a = 0.0, r = 0.0, z = 0.0;
-    constexpr int RB = 4, CE = 2;  // (8 entries in flight per lane: what the register budget of three waves per SIMD leaves)
+    constexpr int RB = RBX, CE = 2;  // (RB = 4: 8 entries in flight per lane)
 #ifndef SFB_CHK_EXP
 #define SFB_CHK_EXP 0  // timing experiments only (scripts/r3/check_parts.sh): leave parts of the check out
 #endif
@@ -949,12 +953,28 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
     if (score != nullptr && lane == 0) *score = (float)(r_norm / (kp.eps_abs + kp.eps_rel * fmax(Ax_norm, z_norm)));
     if (r_norm <= kp.eps_abs + kp.eps_rel * fmax(Ax_norm, z_norm)) {
       double pn = 0.0, qn = 0.0, an = 0.0, rn = 0.0;
+      if constexpr (RBX <= 4) {  // (three waves per SIMD: one row at a time, 8 entries in flight)
       for (int j = lane; j < n; j += kWave) {
         const double Px = sp_row_P(pl, it, j, w.xus), Aty = sp_row_At(pl, it, j, w.yus), qj = it.q[j];
         pn = fmax(pn, fabs(Px));
         qn = fmax(qn, fabs(qj));
         an = fmax(an, fabs(Aty));
         rn = fmax(rn, fabs(Px + (qj + Aty)));
+      }
+      } else
+      for (int j0 = lane; j0 < n; j0 += kWave * RB) {  // rows of P x and A'y, RB per lane at a time (each row's chain as before)
+        double Px[RB], Aty[RB], qj[RB];
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) qj[rr] = (j0 + rr * kWave < n) ? it.q[j0 + rr * kWave] : 0.0;
+        sp_rows_P<RB, CE>(Px, pl, it, j0, w.xus);
+        sp_rows_At<RB, CE>(Aty, pl, it, j0, w.yus);
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {  // (rows beyond n contribute |0|)
+          pn = fmax(pn, fabs(Px[rr]));
+          qn = fmax(qn, fabs(qj[rr]));
+          an = fmax(an, fabs(Aty[rr]));
+          rn = fmax(rn, fabs(Px[rr] + (qj[rr] + Aty[rr])));
+        }
       }
       const double dual_scale = fmax(fmax(wave_max(pn), wave_max(qn)), wave_max(an)), rn_norm = wave_max(rn);
       if (rn_norm <= kp.eps_abs + kp.eps_rel * dual_scale) return SFB_QP_OPTIMAL;
@@ -1001,7 +1021,15 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
     if (wave_ballot(brk)) acc = inf;
     if (!(acc >= thr)) {
       double an = 0.0;
-      for (int j = lane; j < n; j += kWave) an = fmax(an, fabs(sp_row_At(pl, it, j, w.dyus)));
+      if constexpr (RBX <= 4) {
+        for (int j = lane; j < n; j += kWave) an = fmax(an, fabs(sp_row_At(pl, it, j, w.dyus)));
+      } else
+      for (int j0 = lane; j0 < n; j0 += kWave * RBX) {
+        double Atdy[RBX];
+        sp_rows_At<RBX, 2>(Atdy, pl, it, j0, w.dyus);
+#pragma unroll
+        for (int rr = 0; rr < RBX; ++rr) an = fmax(an, fabs(Atdy[rr]));
+      }
       const double Aty_norm = wave_max(an);
       const double mxv      = (Aty_norm < acc) ? acc : Aty_norm;
       if (mxv < thr) return SFB_QP_PRIMAL_INFEASIBLE;
@@ -1697,7 +1725,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     }
     wave_sync();
     if (chk) {
-      ret_code = sp_check_stopping(pl, it, w, kp, t, lane, pause_at != 0 ? score : nullptr);
+      ret_code = sp_check_stopping<LAT ? 6 : 4>(pl, it, w, kp, t, lane, pause_at != 0 ? score : nullptr);
       if constexpr (TRACE) {  // the reference's verbose table as data (:490-501)
         if (trace != nullptr && trace_rows < trace_cap) sp_trace_row(pl, it, w, t, lane, iter, t0_ticks, trace + ((size_t)b * (size_t)trace_cap + (size_t)trace_rows) * 5);
         ++trace_rows;
@@ -1848,7 +1876,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
 constexpr int kFbSlots = 64;
 
 template<bool LAT, bool TRACE = false>
-__global__ void __launch_bounds__(64, LAT ? 2 : 3) qp_sparse_kernel(const SparsePlanDev *__restrict__ plp, const DenseKernelParams kp,
+__global__ void __launch_bounds__(64, (LAT || TRACE) ? 2 : 3) qp_sparse_kernel(const SparsePlanDev *__restrict__ plp, const DenseKernelParams kp,
                                                        const double *__restrict__ gPx, const double *__restrict__ gq,
                                                        const double *__restrict__ gAx, const double *__restrict__ gl,
                                                        const double *__restrict__ gu, const double *__restrict__ gwx,
