@@ -2003,7 +2003,8 @@ __global__ void __launch_bounds__(64, (LAT || TRACE) ? 2 : 3) qp_sparse_kernel(c
 constexpr int kRankBins = 4096, kRankThreads = 1024;
 __global__ __launch_bounds__(kRankThreads) void sp_rank_kernel(const float *__restrict__ keys, const int batch,
                                                                int32_t *__restrict__ order2, int32_t *__restrict__ count,
-                                                               const int g_lo, const int g_hi, const int lat_lo, const int lat_hi)
+                                                               const int g_lo, const int g_hi, const int lat_lo, const int lat_hi,
+                                                               const int lat_max)
 {
   __shared__ int hist[kRankBins];
   __shared__ int psum[kRankThreads];
@@ -2056,7 +2057,7 @@ __global__ __launch_bounds__(kRankThreads) void sp_rank_kernel(const float *__re
       // count[0..2]: survivors, waves, form of the second launch (1 = the LAT kernel on at most lat_hi waves, chosen when
       // that is enough for the work; 0 = the standard kernel); count[4..6]: the same for a launch on the whole chip
       const int w64 = ((int)fminf(want, 1e9f) + 32) / 64 * 64;
-      const int lat = lat_hi > 0 && w64 <= lat_hi + lat_hi / 4;
+      const int lat = lat_hi > 0 && w64 <= lat_max;  // lat_max: the wanted waves up to which the LAT form is chosen
       count[0] = total;
       count[1] = lat ? max(lat_lo, min(lat_hi, w64)) : max(g_lo, min(g_hi, w64));
       count[2] = lat;
@@ -2180,8 +2181,8 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     const double stream_bytes = (double)(pl.funits + pl.bunits) * 128.0 * sizeof(double), mall = 256.0 * 1024.0 * 1024.0;
     unsigned g_lo = std::min(grid, ((unsigned)std::max(256.0, 0.70 * mall / stream_bytes) + 32u) / 64u * 64u), g_hi = grid;
     if (const char *g3 = sfb::knob("SFB_SP_GRID3"); g3 && atoi(g3) > 0) g_lo = g_hi = std::min(grid, (unsigned)atoi(g3));
-    // LAT form of the second launch (see sp_solve_item): the loop's vectors in LDS, two waves per CU -- when that many waves
-    // are enough for the survivors' work (the rank kernel decides; headline batch: yes) and the vectors fit; polish and
+    // LAT form of the second launch (see sp_solve_item): the loop's vectors in LDS, two waves per CU -- when the vectors fit
+    // (the rank kernel sizes the launch; SFB_SP_LAT_MAXW restores a threshold on the wanted waves); polish and
     // report of the survivors then follow as a launch of their own on the whole chip (they are latency-bound and want every
     // wave; inside the few waves of the loop they took 40 % of the wave time).  Otherwise: the standard kernel, loop and
     // polish in one launch.  Both are enqueued, the blocks of the form that was not chosen leave at once.
@@ -2203,8 +2204,13 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
       lat_lo = std::min(lat_hi, ll ? atoi(ll) : 448);
       if (const char *g3 = sfb::knob("SFB_SP_GRID3"); g3 && atoi(g3) > 0) lat_lo = lat_hi = std::min(lat_hi, atoi(g3));
     }
+    const char *lm    = sfb::knob("SFB_SP_LAT_MAXW");
+    // ... for any amount of work: two LAT waves per CU (loop vectors in LDS, factors from the Infinity Cache) also move more
+    // item-iterations per microsecond (21) than the standard form on the whole chip (17-18.5): 12 288 agents 90.7 -> 80.9 ms,
+    // 16 384: 120.6 -> 106.4, 32 768: 218.6 -> 205.3 (scripts/r3/batch_sweep.sh)
+    const int lat_max = lm ? atoi(lm) : 0x7FFFFFFF;
     hipLaunchKernelGGL(sp_rank_kernel, dim3(1), dim3(kRankThreads), 0, stream, keys, (int)batch, order2, count, (int)g_lo, (int)g_hi,
-                       lat_lo, lat_hi);
+                       lat_lo, lat_hi, lat_max);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const char *lw3 = sfb::knob("SFB_SP_LEAN_WAVES3");
     const char *sl3 = sfb::knob("SFB_SP_SLICE3");
