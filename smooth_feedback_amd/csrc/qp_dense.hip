@@ -90,7 +90,10 @@ struct DppSweep {
   }
 };
 
-template<int KP, int MODE>
+// GPA: P and A stay in global memory (qp_dense_common.h, pa_run) -- for k > 32 their LDS copies are a third to a half of
+// the block's LDS and the kernel's throughput is proportional to the blocks a CU holds (measured with padded LDS requests:
+// (20, 40) 5 -> 4 -> 3 blocks per CU = 3.6 -> 2.9 -> 2.2 x 10^8 QP-iterations/s).
+template<int KP, int MODE, bool GPA = false>
 __global__ void __launch_bounds__(64, SFB_QP_WAVES_PER_EU) qp_dense_kernel(const DenseKernelParams kp, const double *__restrict__ gP,
                                                       const double *__restrict__ gq, const double *__restrict__ gA,
                                                       const double *__restrict__ gl, const double *__restrict__ gu,
@@ -103,12 +106,12 @@ __global__ void __launch_bounds__(64, SFB_QP_WAVES_PER_EU) qp_dense_kernel(const
   const int lane   = threadIdx.x;
   const int n      = kp.n, m = kp.m, k = n + m;
   const size_t b   = blockIdx.x;
-  const Lds s      = carve(smem, n, m, k);
+  Lds s            = carve(smem, n, m, k, GPA);
 
   const QpBatch g{gP, gq, gA, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode};
   double c     = 1.0;
   const unsigned long long t0_ticks = wall_clock64();  // (:376 takes it after scaling; setup is microseconds here)
-  int ret_code = qp_setup(s, kp, n, m, b, g, lane, c);
+  int ret_code = qp_setup<GPA>(s, kp, n, m, b, g, lane, c);
 
   // ---- register-resident factor: Lr[j] = L(i,j) (j<i), Lc[j] = L(j,i) (j>i), d = D(i) ----
   constexpr bool LC_REGS = (MODE == SWEEP_READLANE);
@@ -177,7 +180,7 @@ __global__ void __launch_bounds__(64, SFB_QP_WAVES_PER_EU) qp_dense_kernel(const
     if (isc) {
       ys       = c * ((1.0 / syv) * s.yv[ci]);
       double t = 0.0;
-      for (int j = 0; j < n; ++j) t = fma(syv * s.A[ci + j * m], s.xv[j], t);
+      pa_run<GPA>(s.A + ci, m, n, [&](int j, double a) { t = fma(syv * a, s.xv[j], t); });
       zs = t;
     }
     wave_lds_fence();
@@ -276,7 +279,7 @@ __global__ void __launch_bounds__(64, SFB_QP_WAVES_PER_EU) qp_dense_kernel(const
         s.dyus[ci] = syv * (ys - yold) / c;
       }
       wave_lds_fence();
-      ret_code = qp_check_stopping(s, kp, n, m, lane);
+      ret_code = qp_check_stopping<GPA>(s, kp, n, m, lane);
       if (ret_code < 0 && max_time_exceeded(kp.max_time_ns, t0_ticks)) ret_code = SFB_QP_MAX_TIME;  // :504-507
       wave_lds_fence();
     }
@@ -287,13 +290,24 @@ __global__ void __launch_bounds__(64, SFB_QP_WAVES_PER_EU) qp_dense_kernel(const
   if (isc) s.yv[ci] = ys;
   wave_lds_fence();
 
-  qp_finish(s, kp, n, m, c, b, g, lane, ret_code, iter);
+  qp_finish<GPA>(s, kp, n, m, c, b, g, lane, ret_code, iter);
+}
+
+// 48 < k <= 64: the GPA kernel (no LDS copies of P and A): (20, 40) 5 -> 8 blocks per CU, 68 k -> 97 k QP/s under the reference
+// benchmark's parameters, (32, 32) 4 -> 7 blocks, 0.80 -> 0.98 M QP/s.  Not for 32 < k <= 48: that kernel's 209 VGPRs allow 8
+// blocks per CU, which its LDS request with the copies already reaches -- (16, 32) 155 k -> 145 k QP/s with the stopping checks'
+// global reads.  SFB_QP_DENSE_PA_LDS=1 (A/B, tests): the kernel with the copies at every size.
+static bool dense_pa_global(int k)
+{
+  static const bool off = [] { const char *v = sfb::knob("SFB_QP_DENSE_PA_LDS"); return v && v[0] == '1'; }();
+  return k > 48 && !off;
 }
 
 size_t qp_dense_lds_bytes(int n, int m)
 {
   const int k = n + m;
-  const size_t doubles = ((size_t)k * (k + 1)) / 2 + (size_t)n * n + (size_t)m * n + 5 * (size_t)n + 8 * (size_t)m + (size_t)k;
+  const size_t pa = dense_pa_global(k) ? 0 : (size_t)n * n + (size_t)m * n;
+  const size_t doubles = ((size_t)k * (k + 1)) / 2 + pa + 5 * (size_t)n + 8 * (size_t)m + (size_t)k;
   const size_t ints    = (size_t)k + (size_t)m;
   return doubles * sizeof(double) + ((ints * sizeof(int) + 15) / 16) * 16;
 }
@@ -326,7 +340,9 @@ hipError_t qp_dense_launch(const DenseKernelParams &kp, int64_t batch, const dou
   } else if (k <= 48) {
     SFB_LAUNCH(48, SWEEP_READLANE_LDS);
   } else {
-    SFB_LAUNCH(64, SWEEP_READLANE_LDS);
+    if (dense_pa_global(k)) hipLaunchKernelGGL((qp_dense_kernel<64, SWEEP_READLANE_LDS, true>), grid, block, lds, stream, kp, P, q, A, l, u, wx, wy,
+                                               x, y, obj, iter, code);
+    else SFB_LAUNCH(64, SWEEP_READLANE_LDS);
   }
 #undef SFB_LAUNCH
   return hipGetLastError();

@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(64) qp_dense4_setup_kernel(const DenseKernelPa
   const int lane = threadIdx.x;
   const int n = kp.n, m = kp.m, k = n + m;
   const size_t b = blockIdx.x;
-  const Lds S    = carve(smem, n, m, k);
+  Lds S          = carve(smem, n, m, k);
   const Rec4 R   = rec4_layout<NB>(n, m);
   double *rec    = wsp + b * (size_t)R.size;
   double c;
@@ -665,8 +665,8 @@ __global__ void __launch_bounds__(64, 2) qp_dense4_iterate_kernel(const DenseKer
             const Lds S     = slot_view(smem, n, m, row, cval);
             const size_t nb = (size_t)mine;
             const double *P = g.P + nb * (size_t)(n * n), *A = g.A + nb * (size_t)(m * n);
-            for (int e = cc; e < n * n; e += 16) S.P[e] = P[e];
-            for (int e = cc; e < m * n; e += 16) S.A[e] = A[e];
+            for (int e = cc; e < n * n; e += 16) const_cast<double *>(S.P)[e] = P[e];
+            for (int e = cc; e < m * n; e += 16) const_cast<double *>(S.A)[e] = A[e];
             for (int e = cc; e < n; e += 16) {
               S.q[e]  = g.q[nb * n + e];
               S.sx[e] = rec[R.off_sx + e];
@@ -843,8 +843,8 @@ __global__ void __launch_bounds__(64) qp_dense4_finish_kernel(const DenseKernelP
   const double *rec = wsp + b * (size_t)R.size;
   {
     const double *P = g.P + b * (size_t)(n * n), *A = g.A + b * (size_t)(m * n);
-    for (int e = lane; e < n * n; e += kWave) S.P[e] = P[e];
-    for (int e = lane; e < m * n; e += kWave) S.A[e] = A[e];
+    for (int e = lane; e < n * n; e += kWave) const_cast<double *>(S.P)[e] = P[e];
+    for (int e = lane; e < m * n; e += kWave) const_cast<double *>(S.A)[e] = A[e];
     if (lane < n) {
       S.q[lane]  = g.q[b * n + lane];
       S.sx[lane] = rec[R.off_sx + lane];

@@ -16,17 +16,41 @@
 namespace sfb {
 
 struct Lds {
-  double *W, *P, *A, *q, *l, *u, *sx, *sy, *rho, *xv, *yv, *zus, *dxus, *dyus, *temp;
+  double *W;
+  const double *P, *A;  // the problem's P and A: LDS copies, or (GPA kernels) the caller's arrays in global memory
+  double *q, *l, *u, *sx, *sy, *rho, *xv, *yv, *zus, *dxus, *dyus, *temp;
   int *perm, *LU;
 };
 
-__device__ __forceinline__ Lds carve(double *base, int n, int m, int k)
+// f(e, base[e * stride]) for e = 0 .. count-1 IN ORDER.  GPA == false: the plain loop (P / A in LDS).  GPA == true: P / A
+// are read from global memory -- the loads of eight elements are issued together and the calls follow in order, so a
+// sequential chain over a row costs count / 8 memory round trips instead of count.
+template<bool GPA, class F>
+__device__ __forceinline__ void pa_run(const double *base, const int stride, const int count, F &&f)
+{
+  if constexpr (!GPA) {
+    for (int e = 0; e < count; ++e) f(e, base[e * stride]);
+  } else {
+    constexpr int U = 8;
+    for (int e0 = 0; e0 < count; e0 += U) {
+      double a[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) a[u] = (e0 + u < count) ? base[(e0 + u) * stride] : 0.0;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (e0 + u < count) f(e0 + u, a[u]);
+    }
+  }
+}
+
+// pa_global: the layout without LDS copies of P and A (s.P / s.A are set by qp_setup<true> to the caller's arrays)
+__device__ __forceinline__ Lds carve(double *base, int n, int m, int k, const bool pa_global = false)
 {
   Lds s;
   double *p = base;
   s.W    = p; p += (k * (k + 1)) >> 1;
-  s.P    = p; p += n * n;
-  s.A    = p; p += m * n;
+  s.P    = p; p += pa_global ? 0 : n * n;
+  s.A    = p; p += pa_global ? 0 : m * n;
   s.q    = p; p += n;
   s.l    = p; p += m;
   s.u    = p; p += m;
@@ -45,6 +69,7 @@ __device__ __forceinline__ Lds carve(double *base, int n, int m, int k)
 }
 
 // QPSolver::scale, qp_solver.hpp:673-730.  Lane j<n owns column j (sx_j), lane n+i owns row i (sy_i).
+template<bool GPA = false>
 __device__ inline double qp_scale(const Lds &s, const int n, const int m, const int lane)
 {
   const int k     = n + m;
@@ -56,7 +81,7 @@ __device__ inline double qp_scale(const Lds &s, const int n, const int m, const 
   if (isc) s.sy[ci] = 1.0;
   if (isx) {
     double t = 0.0;
-    for (int row = 0; row < n; ++row) t = fmax(t, fabs(s.P[row + lane * n]));
+    pa_run<GPA>(s.P + lane * n, 1, n, [&](int, double p) { t = fmax(t, fabs(p)); });
     if (t == 0.0) t = 1.0;
     s.temp[lane] = t;
   }
@@ -76,11 +101,11 @@ __device__ inline double qp_scale(const Lds &s, const int n, const int m, const 
     double inc = 0.0;
     if (isx) {
       const double sxc = s.sx[lane];
-      for (int row = 0; row < n; ++row) inc = fmax(inc, fabs(c * s.sx[row] * sxc * s.P[row + lane * n]));
-      for (int row = 0; row < m; ++row) inc = fmax(inc, fabs(s.sy[row] * sxc * s.A[row + lane * m]));
+      pa_run<GPA>(s.P + lane * n, 1, n, [&](int row, double p) { inc = fmax(inc, fabs(c * s.sx[row] * sxc * p)); });
+      pa_run<GPA>(s.A + lane * m, 1, m, [&](int row, double a) { inc = fmax(inc, fabs(s.sy[row] * sxc * a)); });
     } else if (isc) {
       const double syr = s.sy[ci];
-      for (int col = 0; col < n; ++col) inc = fmax(inc, fabs(syr * s.sx[col] * s.A[ci + col * m]));
+      pa_run<GPA>(s.A + ci, m, n, [&](int col, double a) { inc = fmax(inc, fabs(syr * s.sx[col] * a)); });
     }
     if (inc == 0.0) inc = 1.0;
     wave_lds_fence();  // every lane has read the old sx/sy
@@ -94,28 +119,32 @@ __device__ inline double qp_scale(const Lds &s, const int n, const int m, const 
 }
 
 // rows of the original-order mat-vecs, fixed accumulation order (ascending inner index, fma)
+template<bool GPA = false>
 __device__ __forceinline__ double row_A(const Lds &s, int n, int m, int i, const double *v)
 {
   double r = 0.0;
-  for (int j = 0; j < n; ++j) r = fma(s.A[i + j * m], v[j], r);
+  pa_run<GPA>(s.A + i, m, n, [&](int j, double a) { r = fma(a, v[j], r); });
   return r;
 }
+template<bool GPA = false>
 __device__ __forceinline__ double row_At(const Lds &s, int n, int m, int j, const double *v)
 {
   (void)n;
   double r = 0.0;
-  for (int i = 0; i < m; ++i) r = fma(s.A[i + j * m], v[i], r);
+  pa_run<GPA>(s.A + j * m, 1, m, [&](int i, double a) { r = fma(a, v[i], r); });
   return r;
 }
+template<bool GPA = false>
 __device__ __forceinline__ double row_P(const Lds &s, int n, int i, const double *v)
 {
   double r = 0.0;
-  for (int j = 0; j < n; ++j) r = fma(s.P[i + j * n], v[j], r);
+  pa_run<GPA>(s.P + i, n, n, [&](int j, double p) { r = fma(p, v[j], r); });
   return r;
 }
 
 // QPSolver::check_stopping, qp_solver.hpp:574-644 on xv(=x_us), yv(=y_us), zus, dxus, dyus in LDS.
 // Returns a QPSolutionStatus or -1 (std::nullopt).  Wave-uniform.
+template<bool GPA = false>
 __device__ inline int qp_check_stopping(const Lds &s, const DenseKernelParams &kp, const int n, const int m,
                                         const int lane)
 {
@@ -123,14 +152,14 @@ __device__ inline int qp_check_stopping(const Lds &s, const DenseKernelParams &k
   const double inf = INFINITY;
 
   // OPTIMALITY :584-594
-  const double Ax      = lm ? row_A(s, n, m, lane, s.xv) : 0.0;
+  const double Ax      = lm ? row_A<GPA>(s, n, m, lane, s.xv) : 0.0;
   const double Ax_norm = wave_max(fabs(Ax));
   const double zi      = lm ? s.zus[lane] : 0.0;
   const double r_norm  = wave_max(lm ? fabs(Ax - zi) : 0.0);
   const double z_norm  = wave_max(fabs(zi));
   if (r_norm <= kp.eps_abs + kp.eps_rel * fmax(Ax_norm, z_norm)) {
-    const double Px  = ln ? row_P(s, n, lane, s.xv) : 0.0;
-    const double Aty = ln ? row_At(s, n, m, lane, s.yv) : 0.0;
+    const double Px  = ln ? row_P<GPA>(s, n, lane, s.xv) : 0.0;
+    const double Aty = ln ? row_At<GPA>(s, n, m, lane, s.yv) : 0.0;
     const double qi  = ln ? s.q[lane] : 0.0;
     const double dual_scale = fmax(fmax(wave_max(fabs(Px)), wave_max(fabs(qi))), wave_max(fabs(Aty)));
     const double res        = ln ? Px + (qi + Aty) : 0.0;
@@ -139,7 +168,7 @@ __device__ inline int qp_check_stopping(const Lds &s, const DenseKernelParams &k
 
   // PRIMAL INFEASIBILITY :598-621
   {
-    const double Aty      = ln ? row_At(s, n, m, lane, s.dyus) : 0.0;
+    const double Aty      = ln ? row_At<GPA>(s, n, m, lane, s.dyus) : 0.0;
     const double Aty_norm = wave_max(fabs(Aty));
     const double Edy_norm = wave_max(lm ? fabs(s.dyus[lane]) : 0.0);
     const double thr      = kp.eps_pinf * Edy_norm;
@@ -166,9 +195,9 @@ __device__ inline int qp_check_stopping(const Lds &s, const DenseKernelParams &k
 
   // DUAL INFEASIBILITY :625-641
   {
-    const double Adx     = lm ? row_A(s, n, m, lane, s.dxus) : 0.0;
+    const double Adx     = lm ? row_A<GPA>(s, n, m, lane, s.dxus) : 0.0;
     const double dx_norm = wave_max(ln ? fabs(s.dxus[lane]) : 0.0);
-    const double Pdx     = ln ? row_P(s, n, lane, s.dxus) : 0.0;
+    const double Pdx     = ln ? row_P<GPA>(s, n, lane, s.dxus) : 0.0;
     const double Pdx_n   = wave_max(fabs(Pdx));
     double qdx           = 0.0;
     for (int j = 0; j < n; ++j) qdx = fma(s.q[j], s.dxus[j], qdx);
@@ -192,6 +221,7 @@ __device__ inline int qp_check_stopping(const Lds &s, const DenseKernelParams &k
 
 // detail::polish_qp, qp_solver.hpp:92-204 (dense branch).  In: scaled primal in xv[n], scaled dual in
 // yv[m] (LDS, original order).  Out: the same arrays updated on success.  Reuses W/perm/temp.
+template<bool GPA = false>
 __device__ inline void qp_polish(const Lds &s, const DenseKernelParams &kp, const int n, const int m,
                                  const double c, const int lane)
 {
@@ -215,16 +245,16 @@ __device__ inline void qp_polish(const Lds &s, const DenseKernelParams &kp, cons
   if (lane < n) {
     const int r      = lane;
     const double sxr = s.sx[r];
-    for (int cc = 0; cc <= r; ++cc) {
-      double v = c * s.sx[cc] * s.P[cc + r * n] * sxr;
+    pa_run<GPA>(s.P + r * n, 1, r + 1, [&](int cc, double p) {
+      double v = c * s.sx[cc] * p * sxr;
       if (cc == r) v += kp.delta;
       s.W[tri(r, cc)] = v;
-    }
+    });
     h = -c * (sxr * s.q[r]);
   } else if (lane < K) {
     const int a = lane - n, row = s.LU[a];
     const double syr = s.sy[row];
-    for (int j = 0; j < n; ++j) s.W[tri(lane, j)] = syr * s.A[row + j * m] * s.sx[j];
+    pa_run<GPA>(s.A + row, m, n, [&](int j, double av) { s.W[tri(lane, j)] = syr * av * s.sx[j]; });
     for (int j = n; j < lane; ++j) s.W[tri(lane, j)] = 0.0;
     s.W[tri(lane, lane)] = 0.0 - kp.delta;
     h                     = (a < nl) ? syr * s.l[row] : syr * s.u[row];
@@ -245,20 +275,34 @@ __device__ inline void qp_polish(const Lds &s, const DenseKernelParams &kp, cons
       const int r      = lane;
       const double sxr = s.sx[r];
       double acc       = 0.0;
-      for (int j = 0; j < n; ++j) {
-        const int a = (j < r) ? j : r, b = (j < r) ? r : j;  // upper entry (a,b)
-        acc         = fma(c * s.sx[a] * s.P[a + b * n] * s.sx[b], tv[j], acc);
-      }
-      for (int a = 0; a < na; ++a) {
-        const int row = s.LU[a];
-        acc           = fma(s.sy[row] * s.A[row + r * m] * sxr, tv[n + a], acc);
+      // upper entry (a, b) of P: (j, r) for j < r -- column r, contiguous -- then (r, j) for j >= r -- row r, stride n
+      pa_run<GPA>(s.P + r * n, 1, r, [&](int j, double p) { acc = fma(c * s.sx[j] * p * s.sx[r], tv[j], acc); });
+      pa_run<GPA>(s.P + r + r * n, n, n - r, [&](int e, double p) { acc = fma(c * s.sx[r] * p * s.sx[r + e], tv[r + e], acc); });
+      if constexpr (!GPA) {
+        for (int a = 0; a < na; ++a) {
+          const int row = s.LU[a];
+          acc           = fma(s.sy[row] * s.A[row + r * m] * sxr, tv[n + a], acc);
+        }
+      } else {
+        constexpr int U = 8;
+        for (int a0 = 0; a0 < na; a0 += U) {  // gather of the active rows' entries of column r, eight at a time
+          int row[U];
+          double av[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) row[u] = (a0 + u < na) ? s.LU[a0 + u] : 0;
+#pragma unroll
+          for (int u = 0; u < U; ++u) av[u] = s.A[row[u] + r * m];
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (a0 + u < na) acc = fma(s.sy[row[u]] * av[u] * sxr, tv[n + a0 + u], acc);
+        }
       }
       res = h - acc;
     } else if (lane < K) {
       const int row    = s.LU[lane - n];
       const double syr = s.sy[row];
       double acc       = 0.0;
-      for (int j = 0; j < n; ++j) acc = fma(syr * s.A[row + j * m] * s.sx[j], tv[j], acc);
+      pa_run<GPA>(s.A + row, m, n, [&](int j, double av) { acc = fma(syr * av * s.sx[j], tv[j], acc); });
       res = h - acc;
     }
     wave_lds_fence();
@@ -275,7 +319,8 @@ __device__ inline void qp_polish(const Lds &s, const DenseKernelParams &kp, cons
 // Problem b -> LDS, Ruiz scaling (:347), feasibility pre-check and rho (:361-374), KKT matrix
 // (:399-404), pivoted LDL' (:428-433).  Returns the status if the solve ends before the first
 // iteration (PrimalInfeasible / Unknown), else -1.  c = cost scaling.
-__device__ inline int qp_setup(const Lds &s, const DenseKernelParams &kp, const int n, const int m, const size_t b,
+template<bool GPA = false>
+__device__ inline int qp_setup(Lds &s, const DenseKernelParams &kp, const int n, const int m, const size_t b,
                                const QpBatch &g, const int lane, double &c)
 {
   const int k      = n + m;
@@ -284,8 +329,14 @@ __device__ inline int qp_setup(const Lds &s, const DenseKernelParams &kp, const 
   {
     const double *P = g.P + b * (size_t)(n * n);
     const double *A = g.A + b * (size_t)(m * n);
-    for (int i = lane; i < n * n; i += kWave) s.P[i] = P[i];
-    for (int i = lane; i < m * n; i += kWave) s.A[i] = A[i];
+    if constexpr (GPA) {  // no LDS copies: the routines below read the caller's arrays (pa_run)
+      s.P = P;
+      s.A = A;
+    } else {
+      double *Pl = const_cast<double *>(s.P), *Al = const_cast<double *>(s.A);  // (carve() gave them LDS room)
+      for (int i = lane; i < n * n; i += kWave) Pl[i] = P[i];
+      for (int i = lane; i < m * n; i += kWave) Al[i] = A[i];
+    }
     if (lane < n) s.q[lane] = g.q[b * n + lane];
     if (lane < m) {
       s.l[lane] = g.l[b * m + lane];
@@ -298,7 +349,7 @@ __device__ inline int qp_setup(const Lds &s, const DenseKernelParams &kp, const 
 
   // ---- scaling :347 ----
   c = 1.0;
-  if (kp.scaling) c = qp_scale(s, n, m, lane);
+  if (kp.scaling) c = qp_scale<GPA>(s, n, m, lane);
 
   // ---- feasibility pre-check and rho :361-374 (lane i < m owns constraint i) ----
   int ret_code = -1;
@@ -325,15 +376,15 @@ __device__ inline int qp_setup(const Lds &s, const DenseKernelParams &kp, const 
   if (lane < n) {
     const int r      = lane;
     const double sxr = s.sx[r];
-    for (int cc = 0; cc <= r; ++cc) {
-      double v = c * s.sx[cc] * s.P[cc + r * n] * sxr;
+    pa_run<GPA>(s.P + r * n, 1, r + 1, [&](int cc, double p) {
+      double v = c * s.sx[cc] * p * sxr;
       if (cc == r) v += kp.sigma;
       s.W[tri(r, cc)] = v;
-    }
+    });
   } else if (lane < k) {
     const int i      = lane - n;
     const double syi = s.sy[i];
-    for (int j = 0; j < n; ++j) s.W[tri(lane, j)] = syi * s.A[i + j * m] * s.sx[j];
+    pa_run<GPA>(s.A + i, m, n, [&](int j, double av) { s.W[tri(lane, j)] = syi * av * s.sx[j]; });
     for (int j = n; j < lane; ++j) s.W[tri(lane, j)] = 0.0;
     s.W[tri(lane, lane)] = 1.0 / (-s.rho[i]);
   }
@@ -345,12 +396,13 @@ __device__ inline int qp_setup(const Lds &s, const DenseKernelParams &kp, const 
 }
 
 // End of QPSolver::solve (:515-548).  In: the scaled iterate in s.xv / s.yv (original order).
+template<bool GPA = false>
 __device__ inline void qp_finish(const Lds &s, const DenseKernelParams &kp, const int n, const int m, const double c,
                                  const size_t b, const QpBatch &g, const int lane, const int ret_code,
                                  const uint32_t iter)
 {
   // ---- polish :515-539 (a failed polish leaves Optimal, cf. :537 vs :544) ----
-  if (ret_code == SFB_QP_OPTIMAL && kp.polish) qp_polish(s, kp, n, m, c, lane);
+  if (ret_code == SFB_QP_OPTIMAL && kp.polish) qp_polish<GPA>(s, kp, n, m, c, lane);
 
   // ---- un-scale and report :544-548 ----
   double xo = 0.0;
@@ -364,7 +416,7 @@ __device__ inline void qp_finish(const Lds &s, const DenseKernelParams &kp, cons
   if (g.obj != nullptr) {
     if (lane < n) {
       double acc = 0.0;
-      for (int j = 0; j < n; ++j) acc = fma(0.5 * s.P[lane + j * n], s.dxus[j], acc);
+      pa_run<GPA>(s.P + lane, n, n, [&](int j, double p) { acc = fma(0.5 * p, s.dxus[j], acc); });
       s.temp[lane] = acc + s.q[lane];
     }
     wave_lds_fence();
