@@ -30,6 +30,7 @@
 #include "../../include/sfb.h"
 #include "qp_dense_kernel.h"
 #include "wave_util.h"
+#include "sweep_rows.h"
 
 namespace sfb {
 
@@ -666,7 +667,10 @@ __device__ inline void mid_finish_factor(const int K_, double *Lpk_, double *LDg
   LDS_D(Lpk, Lpk_);
   LDS_D(LDg, LDg_);
   if (lane < kMidZ) Lpk[lane] = 0.0;
-  for (int i = lane; i < K; i += kWave) LDg[i] = Lpk[kMidZ + ((i * (i + 1)) >> 1) + i];
+  for (int i = lane; i < K; i += kWave) {
+    LDg[i] = Lpk[kMidZ + ((i * (i + 1)) >> 1) + i];
+    Lpk[kMidZ + ((i * (i + 1)) >> 1) + i] = -0.0;  // what the pivot lane of a block-sweep chain step multiplies by (sweep_rows.h)
+  }
   wave_sync();
 }
 
@@ -828,7 +832,8 @@ __device__ __attribute__((noinline)) MidPair mid_sweeps(const int K_, const doub
 }
 
 // temp (LDS, K entries, original order) <- P^T L^-T D^-1 L^-1 P temp  (oracle_ldlt_solve)
-__device__ inline void mid_solve(const int K_, const double *Lpk_, const double *LDg_, const int *perm_, double *temp_, const int lane)
+__device__ inline void mid_solve(const int K_, const double *Lpk_, const double *LDg_, const int *perm_, double *temp_, const int lane,
+                                 const bool rows_engine)
 {
   const int K = ubig(K_);
   LDS_CI(perm, perm_);
@@ -836,7 +841,12 @@ __device__ inline void mid_solve(const int K_, const double *Lpk_, const double 
   const bool vlo = lane < K, vhi = lane + kWave < K;
   MidPair t{vlo ? temp[perm[vlo ? lane : 0]] : 0.0, vhi ? temp[perm[vhi ? lane + kWave : 0]] : 0.0};
   wave_sync();  // (every lane has read its right-hand side entries)
-  t = mid_sweeps(K, Lpk_, LDg_, t, lane);
+  if (rows_engine) {
+    const rows::Pair r = rows::row_sweeps_any(K, Lpk_ + kMidZ, LDg_, rows::Pair{t.lo, t.hi}, lane);
+    t = MidPair{r.lo, r.hi};
+  } else {
+    t = mid_sweeps(K, Lpk_, LDg_, t, lane);
+  }
   if (vlo) temp[perm[lane]] = t.lo;
   if (vhi) temp[perm[lane + kWave]] = t.hi;
   wave_sync();
@@ -1195,7 +1205,13 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
       }
     };
     for (; iter != maxit && ret_code < 0; ++iter) {
-      const MidPair t = mid_sweeps(k, cval, LDg, MidPair{rhs(ha), rhs(hb)}, lane);  // :462
+      MidPair t;                                                                       // :462
+      if (packed == 2) {
+        const rows::Pair r = rows::row_sweeps_any(k, cval + kMidZ, LDg, rows::Pair{rhs(ha), rhs(hb)}, lane);
+        t = MidPair{r.lo, r.hi};
+      } else {
+        t = mid_sweeps(k, cval, LDg, MidPair{rhs(ha), rhs(hb)}, lane);
+      }
       const bool chk  = (iter == next_chk);                                          // :465
       if (chk) next_chk += sci;
       upd(ha, t.lo, chk);
@@ -1334,7 +1350,7 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
           temp[i] = ((i < n) ? w.hx[i] : w.Ax[i - n]) - s;
         }
         wave_sync();
-        if (packed) mid_solve(K, cval, LDg, perm, temp, lane);
+        if (packed) mid_solve(K, cval, LDg, perm, temp, lane, packed == 2);
         else big_solve<RB>(K, Hp, w.LT, w.Dg, K, perm, fnz, bnz, dcache ? dblk : nullptr, LDg, cidx, cval, cflag, t, temp, lane);
         for (int i = lane; i < K; i += kWave) aux[i] += temp[i];
         wave_sync();
@@ -1389,7 +1405,9 @@ hipError_t qp_dense_big_launch(const DenseKernelParams &kp, int64_t batch, const
   const size_t wsd = qp_dense_big_ws_doubles(kp.n, kp.m);
   const dim3 grid((unsigned)batch), block(kWave);
   const int rb = (k + kWave - 1) / kWave;
-  const int packed = cfg.packed ? 1 : 0;
+  // packed engine: 2 = block sweeps with DPP pivot broadcast (sweep_rows.h), 1 = v_readlane sweeps (SFB_QP_MID_ROWS=0, A/B)
+  static const bool rows_off = [] { const char *v = sfb::knob("SFB_QP_MID_ROWS"); return v && v[0] == '0'; }();
+  const int packed = cfg.packed ? (rows_off ? 1 : 2) : 0;
   if (rb <= 2) hipLaunchKernelGGL((qp_dense_big_kernel<2>), grid, block, lds, stream, kp, g, workspace, wsd, rcap, dck, packed);
   else if (rb <= 4) hipLaunchKernelGGL((qp_dense_big_kernel<4>), grid, block, lds, stream, kp, g, workspace, wsd, rcap, dck, 0);
   else if (rb <= 8) hipLaunchKernelGGL((qp_dense_big_kernel<8>), grid, block, lds, stream, kp, g, workspace, wsd, rcap, dck, 0);
