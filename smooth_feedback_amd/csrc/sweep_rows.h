@@ -115,6 +115,50 @@ __device__ __forceinline__ void rider(double &t, const double &tp, const double 
   asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:%4 bank_mask:0xf" : "+v"(t) : "v"(tp), "v"(l), "n"(J), "n"(RM));
 }
 
+// One half block (8 steps) as ONE asm statement: [lane mask; chain step; full mask; riders] x 8 -- nothing of the
+// compiler's between the steps (it pads consecutive asm statements with s_nop and waits for every LDS operand
+// separately: a lone wave pays ~5.5 cycles for every instruction of any kind), one s_waitcnt in front for all operands.
+// Forward: step U is J = 8 C + U, lanes cc >= J (s_mov_b64 exec, mask_ge(J)); backward: J = 15 - 8 C - U, lanes
+// cc <= J (s_not_b64 exec, mask_ge(J + 1); 0 for J = 15).  The last step of the second half has no chain operation
+// (forward J = 15, backward J = 0: only the pivot lane would be left).  RM0 / RM1: row masks of the riders on tlo / thi, 0 = none.
+#define SFB_RS_CHF(U) "s_mov_b64 exec, %[m" #U "]\n\tv_fmac_f64_dpp %[tp], %[tp], -%[c" #U "] row_newbcast:%[j" #U "] row_mask:0xf bank_mask:0xf\n\ts_mov_b64 exec, -1\n\t"
+#define SFB_RS_CHB(U) "s_not_b64 exec, %[m" #U "]\n\tv_fmac_f64_dpp %[tp], %[tp], -%[c" #U "] row_newbcast:%[j" #U "] row_mask:0xf bank_mask:0xf\n\ts_mov_b64 exec, -1\n\t"
+#define SFB_RS_NOC(U) ""
+#define SFB_RS_R0(U) "v_fmac_f64_dpp %[t0], %[tp], -%[a" #U "] row_newbcast:%[j" #U "] row_mask:%[r0] bank_mask:0xf\n\t"
+#define SFB_RS_R1(U) "v_fmac_f64_dpp %[t1], %[tp], -%[b" #U "] row_newbcast:%[j" #U "] row_mask:%[r1] bank_mask:0xf\n\t"
+#define SFB_RS_NOR(U) ""
+#define SFB_RS_STAGE(CH, CH7, RA, RB)                                                                                      \
+  CH(0) RA(0) RB(0) CH(1) RA(1) RB(1) CH(2) RA(2) RB(2) CH(3) RA(3) RB(3) CH(4) RA(4) RB(4) CH(5) RA(5) RB(5) CH(6) RA(6) \
+      RB(6) CH7(7) RA(7) RB(7)
+#define SFB_RS_V8(p, a) [p##0] "v"(a[0]), [p##1] "v"(a[1]), [p##2] "v"(a[2]), [p##3] "v"(a[3]), [p##4] "v"(a[4]), [p##5] "v"(a[5]), [p##6] "v"(a[6]), [p##7] "v"(a[7])
+#define SFB_RS_S8(m) [m0] "s"(m[0]), [m1] "s"(m[1]), [m2] "s"(m[2]), [m3] "s"(m[3]), [m4] "s"(m[4]), [m5] "s"(m[5]), [m6] "s"(m[6]), [m7] "s"(m[7])
+#define SFB_RS_J8(J0, D) [j0] "n"(J0), [j1] "n"(J0 + D), [j2] "n"(J0 + 2 * D), [j3] "n"(J0 + 3 * D), [j4] "n"(J0 + 4 * D), [j5] "n"(J0 + 5 * D), [j6] "n"(J0 + 6 * D), [j7] "n"(J0 + 7 * D)
+template<bool FWD, int C, int RM0, int RM1>
+__device__ __forceinline__ void stage8(double &tp, double &tlo, double &thi, const double (&ch)[8], const double (&f0)[8],
+                                       const double (&f1)[8], const unsigned long long (&m)[8])
+{
+  constexpr int J0 = FWD ? 8 * C : 15 - 8 * C, D = FWD ? 1 : -1;
+  const double c[8] = {ch[0], ch[1], ch[2], ch[3], ch[4], ch[5], ch[6], C == 1 ? ch[6] : ch[7]};  // (no chain operand at the last step of C = 1)
+  const double(&A)[8] = RM0 != 0 ? f0 : c;  // (absent riders: operands that cost no register)
+  const double(&B)[8] = RM1 != 0 ? f1 : c;
+#define SFB_RS_EMIT(CH, CH7, RA, RB)                                                                                            \
+  asm volatile(SFB_RS_STAGE(CH, CH7, RA, RB)                                                                                    \
+               : [tp] "+v"(tp), [t0] "+v"(tlo), [t1] "+v"(thi)                                                                  \
+               : SFB_RS_V8(c, c), SFB_RS_V8(a, A), SFB_RS_V8(b, B), SFB_RS_S8(m), SFB_RS_J8(J0, D), [r0] "n"(RM0), [r1] "n"(RM1) \
+               : "scc")
+#define SFB_RS_PICK(CH, CH7)                                                                \
+  if constexpr (RM0 != 0 && RM1 != 0) SFB_RS_EMIT(CH, CH7, SFB_RS_R0, SFB_RS_R1);           \
+  else if constexpr (RM0 != 0) SFB_RS_EMIT(CH, CH7, SFB_RS_R0, SFB_RS_NOR);                 \
+  else if constexpr (RM1 != 0) SFB_RS_EMIT(CH, CH7, SFB_RS_NOR, SFB_RS_R1);                 \
+  else SFB_RS_EMIT(CH, CH7, SFB_RS_NOR, SFB_RS_NOR)
+  if constexpr (FWD && C == 0) { SFB_RS_PICK(SFB_RS_CHF, SFB_RS_CHF); }
+  else if constexpr (FWD) { SFB_RS_PICK(SFB_RS_CHF, SFB_RS_NOC); }
+  else if constexpr (C == 0) { SFB_RS_PICK(SFB_RS_CHB, SFB_RS_CHB); }
+  else { SFB_RS_PICK(SFB_RS_CHB, SFB_RS_NOC); }
+#undef SFB_RS_PICK
+#undef SFB_RS_EMIT
+}
+
 // (L D L')^-1 applied to the PERMUTED vector t held in registers (rows lane, lane + 64): L^-1, D^-1, L^-T -- the middle
 // of oracle_ldlt_solve.  T: the packed lower triangle in LDS, entry (i, j), j < i, at T[i (i + 1) / 2 + j], its diagonal
 // slots at -0.0 (chain_ge); Dg: the diagonal D.  NB = ceil(K / 16) blocks, compile time; everything is unrolled over compile-time block and step numbers
@@ -148,6 +192,8 @@ __device__ __attribute__((noinline)) Pair row_sweeps(const int K_, const double 
   // the lane masks of the chain steps, resident in SGPR pairs for the whole call
   unsigned long long mk[16];  // mk[J] = lanes cc >= J, J = 1 .. 15
   mk[0] = ~0ull;
+  unsigned long long mzero = 0ull;
+  asm volatile("" : "+s"(mk[0]), "+s"(mzero));
   static_for<15>([&]<int J>(ic<J>) {
     mk[J + 1] = mask_ge(J + 1);
     asm volatile("" : "+s"(mk[J + 1]));
@@ -170,13 +216,9 @@ __device__ __attribute__((noinline)) Pair row_sweeps(const int K_, const double 
     constexpr int JB = S >> 1, C = S & 1, RP = JB & 3, QP = JB >> 2;
     constexpr int RM0 = fwd_rows<NB>(JB, 0), RM1 = NQ > 1 ? fwd_rows<NB>(JB, 1) : 0;
     if constexpr (C == 0) tp = row_to_all<RP>(QP ? thi : tlo);
-    if (JB < NB - 1 || 16 * JB + 8 * C < K) {  // (the last block beyond K: rows that do not exist)
-      static_for<8>([&]<int U>(ic<U>) {
-        constexpr int J = 8 * C + U;
-        if constexpr (J < 15) chain_ge<J>(tp, ch[C][U], mk[J]);
-        if constexpr (RM0 != 0) rider<J, RM0>(tlo, tp, f0[C][U]);
-        if constexpr (RM1 != 0) rider<J, RM1>(thi, tp, f1[C][U]);
-      });
+    if (JB < NB - 1 || 16 * JB + 8 * C < K) {  // (the last block beyond K: rows that do not exist -- pivots there only reach such rows)
+      const unsigned long long m8[8] = {mk[8 * C], mk[8 * C + 1], mk[8 * C + 2], mk[8 * C + 3], mk[8 * C + 4], mk[8 * C + 5], mk[8 * C + 6], mk[8 * C + 7]};
+      stage8<true, C, RM0, RM1>(tp, tlo, thi, ch[C], f0[C], f1[C], m8);
     }
     if constexpr (C == 1) {  // the finished segment back to its owner row
       if constexpr (QP) thi = (owner == (unsigned)RP) ? tp : thi;
@@ -213,14 +255,20 @@ __device__ __attribute__((noinline)) Pair row_sweeps(const int K_, const double 
     constexpr int JB = NB - 1 - (S >> 1), C = S & 1, RP = JB & 3, QP = JB >> 2;
     constexpr int RM0 = bwd_rows(JB, 0), RM1 = NQ > 1 ? bwd_rows(JB, 1) : 0;
     if constexpr (C == 0) tp = row_to_all<RP>(QP ? thi : tlo);
-    static_for<8>([&]<int U>(ic<U>) {
-      constexpr int J = 15 - 8 * C - U;
-      if (JB < NB - 1 || 16 * JB + J < K) {  // (the last block: pivots beyond K do not exist)
-        if constexpr (J >= 1) chain_le<J>(tp, ch[C][U], mk[J < 15 ? J + 1 : 0]);
-        if constexpr (RM0 != 0) rider<J, RM0>(tlo, tp, f0[C][U]);
-        if constexpr (RM1 != 0) rider<J, RM1>(thi, tp, f1[C][U]);
-      }
-    });
+    if (JB < NB - 1 || K == 16 * NB) {
+      // step U is J = 15 - 8 C - U: s_not_b64 of mask_ge(J + 1) (of nothing at J = 15: every lane)
+      const unsigned long long m8[8] = {C == 0 ? mzero : mk[8], mk[15 - 8 * C], mk[14 - 8 * C], mk[13 - 8 * C], mk[12 - 8 * C], mk[11 - 8 * C], mk[10 - 8 * C], mk[9 - 8 * C]};
+      stage8<false, C, RM0, RM1>(tp, tlo, thi, ch[C], f0[C], f1[C], m8);
+    } else {  // the last block of a system that does not fill it: pivots beyond K do not exist, step by step
+      static_for<8>([&]<int U>(ic<U>) {
+        constexpr int J = 15 - 8 * C - U;
+        if (16 * JB + J < K) {
+          if constexpr (J >= 1) chain_le<J>(tp, ch[C][U], mk[J < 15 ? J + 1 : 0]);
+          if constexpr (RM0 != 0) rider<J, RM0>(tlo, tp, f0[C][U]);
+          if constexpr (RM1 != 0) rider<J, RM1>(thi, tp, f1[C][U]);
+        }
+      });
+    }
     if constexpr (C == 1) {
       if constexpr (QP) thi = (owner == (unsigned)RP) ? tp : thi;
       else tlo = (owner == (unsigned)RP) ? tp : tlo;
