@@ -23,6 +23,9 @@ def main():
       if os.environ.get("BIG") == "1":                                                           # big kernel only: filter shapes, block-structured A
           n, m = int(rng.integers(1, 6)), int(rng.integers(64, 330))
           if rng.random() < 0.3: n, m = int(rng.integers(6, 60)), int(rng.integers(60, 200))
+      if os.environ.get("MID") == "1":                                                           # the on-chip block-sweep kernel: 32 < n + m <= 128, every shape
+          kk = int(rng.integers(33, 129)); n = int(rng.integers(1, kk)); m = kk - n
+          if rng.random() < 0.3: n, m = int(rng.integers(8, 50)), int(rng.integers(25, 79))
       B = int(rng.integers(1, 40 if os.environ.get("BIG") != "1" else 6))
       P, q, A, l, u = sfb.random_qp_batch(int(rng.integers(1, 10**6)), B, m, n, float(rng.choice([0.1, 0.5, 1.0])))
       if os.environ.get("BIG") == "1" and rng.random() < 0.5:   # rows that touch one variable only / empty rows: long chain-free runs

@@ -144,6 +144,13 @@ sfb_status dense_big(const sfb_qp_params *prm, int64_t batch, int n, int m, cons
                      const double *l, const double *u, const double *wx, const double *wy, double *x, double *y, double *obj,
                      uint32_t *iter, int32_t *code, hipStream_t stream, void *workspace)
 {
+  if (n + m <= sfb::kDenseMidMaxK && sfb::qp_dense_mid_enabled()) {  // up to 128: everything on chip, no workspace (qp_dense_mid.hip)
+    const sfb::DenseKernelParams kpm = make_kernel_params(prm, n, m);
+    const sfb::QpBatch gm{P, q, A, l, u, wx, wy, x, y, obj, iter, code};
+    const hipError_t em = sfb::qp_dense_mid_launch(kpm, batch, gm, stream);
+    if (em != hipSuccess) return hip_fail(em, "qp_dense_mid_kernel launch");
+    return SFB_OK;
+  }
   const size_t bytes = (size_t)batch * sfb::qp_dense_big_ws_doubles(n, m) * sizeof(double);
   char *buf          = static_cast<char *>(workspace);  // the caller's (sfb_workspace), or per call below
   bool async_alloc   = true;
@@ -430,7 +437,7 @@ static sfb_status dense_workspace_need(const sfb_qp_params *prm, int64_t batch, 
   if (k > SFB_QP_DENSE_MAX_K) {
     static const bool big_off = [] { const char *v = sfb::knob("SFB_QP_DENSE_BIG"); return v && v[0] == '0'; }();
     if (k <= sfb::kDenseBigMaxK && !big_off) {
-      *need = (size_t)batch * sfb::qp_dense_big_ws_doubles(n, m) * sizeof(double);
+      *need = (k <= sfb::kDenseMidMaxK && sfb::qp_dense_mid_enabled()) ? 0 : (size_t)batch * sfb::qp_dense_big_ws_doubles(n, m) * sizeof(double);
       return SFB_OK;
     }
     sfb_sparse_qp_plan *plan = nullptr;

@@ -43,6 +43,13 @@ size_t qp_dense_big_ws_doubles(int n, int m);
 hipError_t qp_dense_big_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, double *workspace, hipStream_t stream);
 constexpr int kDenseBigMaxK = 1024;
 
+// 32 < n+m <= 128: one QP per wavefront, everything on chip (qp_dense_mid.hip): packed factor in LDS, block sweeps with
+// the pivot broadcast fused into the FP64 FMA, the matrix written in Eigen's pivot order before an unpivoted factorisation
+constexpr int kDenseMidMaxK = 128;
+size_t qp_dense_mid_lds_bytes(int n, int m);
+hipError_t qp_dense_mid_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream);
+bool qp_dense_mid_enabled();  // SFB_QP_MID=0 (A/B, tests): the kernels these sizes had before
+
 hipError_t qp_dense_launch(const DenseKernelParams &kp, int64_t batch, const double *P, const double *q,
                            const double *A, const double *l, const double *u, const double *wx, const double *wy,
                            double *x, double *y, double *obj, uint32_t *iter, int32_t *code, hipStream_t stream,

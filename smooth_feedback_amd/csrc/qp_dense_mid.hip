@@ -1,0 +1,919 @@
+// Batched dense ADMM QP solver for gfx950, 32 < n+m <= 128: ONE QP PER WAVEFRONT, everything on chip.
+//
+// Replaces, per batch item, smooth::feedback::solve_qp for QuadraticProgram<M,N,double> (reference
+// qp_solver.hpp:343-568 solve, :574-644 check_stopping, :673-730 scale, :92-204 polish_qp; Eigen 3.4 LDLT<Upper> at
+// :259,428,462 and :187-195).  Arithmetic -- association of every element-wise expression, accumulation order of every
+// dot product and triangular solve, true divisions, sqrt -- is that of oracle/qp_oracle.c: the two agree bit for bit.
+// Compiled with -ffp-contract=off; fma() only where the oracle spells it.
+//
+// What is where
+//   LDS (per wave = per QP): the KKT matrix / its factor L as a PACKED lower triangle T (entry (i, j), j <= i, at
+//     i (i + 1) / 2 + j), the diagonal D, one scratch vector, the permutation, and ONE shared area V that holds in turn
+//     the scaling vectors (setup), the un-scaled iterates of a stopping check (loop), and scaling vectors + iterate +
+//     active sets (polish): 40.2 KB at (32, 64) -- four QPs per CU --, 17 KB at (20, 40) -- nine.
+//   Global memory: P, q, A, l, u of the QP are read where they lie (coalesced; batches of loads in flight, pa_run).
+//   Registers: lane l carries rows l and l + 64 of the PERMUTED system through the whole ADMM loop (variable, iterate,
+//     constants): an iteration is right-hand side -> block sweeps (sweep_rows.h) -> update, no LDS vector traffic.
+//
+// Pivoting without row swaps.  Eigen's LDLT picks, at step kk, the first largest |diagonal| among rows kk.. of the NOT
+// yet updated trailing matrix (oracle_ldlt_factor): the diagonal entries it compares are the ORIGINAL ones, so the whole
+// sequence of transpositions follows from the original diagonal alone.  It is simulated on the diagonal held in
+// registers (k wave-wide argmax steps), the KKT matrix is written into T in its final order, and the factorisation runs
+// without a single swap: same entries, same operations, same order -- the arithmetic of a row never depended on where
+// the row was stored.
+//
+// Factorisation.  Left-looking like Eigen's: column kk = W(., kk) - sum_j L(., j) temp(j), s = 0, j ascending,
+// s = fma(L(i, j), temp(j), s), one row (two for k > 64) per lane.  The dot products run in chunks of 8 terms with the
+// loads of the next chunk in flight; a chunk reaches up to 7 terms beyond kk, where temp is 0 and the row holds entries
+// not yet eliminated: fma(finite, 0, s) == s (the running sum is never -0) -- exact as long as every value in T is
+// finite, which is tracked as values are written; from the first non-finite value on the plain loops run.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdlib>
+
+#include "../../include/sfb.h"
+#include "knobs.h"
+#include "qp_dense_kernel.h"
+#include "sweep_rows.h"
+#include "wave_util.h"
+
+namespace sfb {
+namespace {
+
+using rows::lds_d;
+using lds_i = __attribute__((address_space(3))) int;
+using lds_b = __attribute__((address_space(3))) unsigned char;
+
+__device__ __forceinline__ int mtri(const int i) { return (i * (i + 1)) >> 1; }
+__device__ __forceinline__ int muni(const int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ bool mfinite(const double v) { return fabs(v) < INFINITY; }
+
+constexpr int kMidPadT = 8;  // zeros behind the packed triangle (the chunked dot products read up to 7 entries past a row)
+
+// LDS layout in doubles (host and device)
+struct MidLayout {
+  int T, Dg, tmp, V, perm, total;
+};
+__host__ __device__ inline MidLayout mid_layout(const int n, const int m)
+{
+  const int k = n + m;
+  MidLayout L;
+  int p   = 0;
+  L.T     = p;  p += (k * (k + 1)) / 2 + kMidPadT;  p = (p + 1) & ~1;
+  L.Dg    = p;  p += k;                             p = (p + 1) & ~1;
+  L.tmp   = p;  p += k + 8;                         p = (p + 1) & ~1;  // temp of the factorisation (padded to 8), iperm (ints), dy of a stopping check, exchange vector
+  L.V     = p;  p += 2 * k + (m + 3) / 4;           p = (p + 1) & ~1;  // [sx sy | x y | active-set lists (bytes)] or [x dx y z] of a stopping check
+  L.perm  = p;  p += (k + 7) / 8;                   p = (p + 1) & ~1;  // k bytes
+  L.total = p;
+  return L;
+}
+
+// f(e, base[e * stride]) for e = 0 .. count-1 IN ORDER; the loads of U elements are issued together (P and A are read
+// from global memory: a sequential chain over a row costs count / U memory round trips).
+template<int U = 16, class F>
+__device__ __forceinline__ void mrun(const double *base, const int stride, const int count, F &&f)
+{
+  for (int e0 = 0; e0 < count; e0 += U) {
+    double a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] = (e0 + u < count) ? base[(size_t)(e0 + u) * stride] : 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (e0 + u < count) f(e0 + u, a[u]);
+  }
+}
+// ---------------------------------------------------------------------------------------------------------------
+// Eigen's pivot order from the diagonal alone (see the header).  d[r] / id[r]: value and index held at position
+// lane + 64 r; on return position p holds the entry Eigen's transpositions bring there (id = its original index).
+template<int R>
+__device__ inline void mid_pivot_order(const int K, double (&d)[R], int (&id)[R], const int lane)
+{
+  for (int kk = 0; kk + 1 < K; ++kk) {
+    double a[R];
+    double am = -1.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int pos = lane + kWave * r;
+      a[r]          = (pos >= kk && pos < K) ? fabs(d[r]) : -1.0;
+      am            = fmax(am, a[r]);
+    }
+    const double mx = wave_max(am);
+    int p           = kk;
+    const int hk = kk >> 6, lk = kk & 63;
+    const double dkk = lane_bcast((R > 1 && hk) ? d[R - 1] : d[0], lk);
+    if (!(dkk != dkk)) {  // (a NaN AT kk stays the maximum of Eigen's strict '>' scan; NaNs further down are skipped)
+      bool found = false;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const unsigned long long bal = wave_ballot(a[r] == mx && a[r] >= 0.0);
+        if (!found && bal) {
+          p     = kWave * r + (int)__builtin_ctzll(bal);
+          found = true;
+        }
+      }
+    }
+    if (p != kk) {
+      const int hp = p >> 6, lp = p & 63;
+      const double dp = lane_bcast((R > 1 && hp) ? d[R - 1] : d[0], lp);
+      const int ip    = __builtin_amdgcn_readlane((R > 1 && hp) ? id[R - 1] : id[0], lp);
+      const int ik    = __builtin_amdgcn_readlane((R > 1 && hk) ? id[R - 1] : id[0], lk);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int pos = lane + kWave * r;
+        if (pos == kk) { d[r] = dp; id[r] = ip; }
+        else if (pos == p) { d[r] = dkk; id[r] = ik; }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Unpivoted LDL' (Eigen 3.4's unblocked algorithm = oracle_ldlt_factor without its swaps) of the K x K matrix in the
+// packed triangle T, in place; D goes to Dg and the diagonal slots of T end at -0.0 (sweep_rows.h).  tmp: K + 8 doubles.
+// Returns 1 on success, 0 on failure (info() == NumericalIssue).  Wave-uniform.  `fin`: every value in T (pad included) is finite.
+template<int R>
+__device__ inline int mid_ldlt(const int K_, lds_d *const T, lds_d *const Dg, lds_d *const tmp, const int lane, bool fin)
+{
+  const int K = muni(K_);
+  int ret = 1, found_zero = 0;
+  int ri[R];
+  const lds_d *rp[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    ri[r] = lane + kWave * r;
+    rp[r] = T + mtri(ri[r] < K ? ri[r] : 0);
+  }
+  auto finish = [&]() {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (ri[r] < K) T[mtri(ri[r]) + ri[r]] = -0.0;
+    wave_lds_fence();
+  };
+  if (K <= 1) {
+    if (K == 1 && lane == 0) Dg[0] = T[0];
+    finish();
+    return 1;
+  }
+  for (int kk = 0; kk < K; ++kk) {
+    // temp(j) = D(j) * L(kk, j), j < kk; zeros up to the next multiple of 8
+    const int kk8      = (kk + 7) & ~7;
+    const lds_d *const rk = T + mtri(kk);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int j = lane + kWave * r;
+      if (j < kk) tmp[j] = Dg[j] * rk[j];
+      else if (j < kk8) tmp[j] = 0.0;
+    }
+    wave_lds_fence();
+    double s[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) s[r] = 0.0;
+    if (kk > 0) {
+      if (fin) {
+        // chunks of 8 terms, the next chunk's operands in flight.  Rows below kk (already final) ride along: their sums are not used.
+        const bool lo_on = (R == 1) || kk < kWave;  // (rows < 64 are all final once kk >= 64)
+        const int nch    = kk8 >> 3;
+        double ta[8], tb[8], va[R][8], vb[R][8];
+        auto load = [&](double (&tv)[8], double (&vv)[R][8], const int c) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) tv[e] = tmp[8 * c + e];
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            if (r > 0 || lo_on) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) vv[r][e] = rp[r][8 * c + e];
+            }
+        };
+        auto fmas = [&](const double (&tv)[8], const double (&vv)[R][8]) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+              if (r > 0 || lo_on) s[r] = fma(vv[r][e], tv[e], s[r]);
+          }
+        };
+        load(ta, va, 0);
+        int c = 0;
+        for (; c + 1 < nch; c += 2) {
+          load(tb, vb, c + 1);
+          fmas(ta, va);
+          if (c + 2 < nch) load(ta, va, c + 2);
+          fmas(tb, vb);
+        }
+        if (c < nch) fmas(ta, va);
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (ri[r] >= kk && ri[r] < K) {
+            double t = 0.0;
+            for (int j = 0; j < kk; ++j) t = fma(rp[r][j], tmp[j], t);
+            s[r] = t;
+          }
+      }
+    }
+    double val[R];
+    bool cand[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      cand[r] = ri[r] >= kk && ri[r] < K;
+      val[r]  = cand[r] ? rp[r][kk] : 0.0;
+      if (kk > 0 && cand[r]) val[r] -= s[r];
+    }
+    const double akk = lane_bcast((R > 1 && (kk >> 6)) ? val[R - 1] : val[0], kk & 63);
+    const bool valid = fabs(akk) > 0.0;
+    if (kk == 0 && !valid) {  // whole diagonal zero: success iff the strictly lower triangle is zero
+      bool nz = false;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (ri[r] < K)
+          for (int j = 0; j < ri[r]; ++j) nz = nz || !(rp[r][j] == 0.0);
+      const int ok = wave_ballot(nz) ? 0 : 1;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (ri[r] < K) Dg[ri[r]] = rp[r][ri[r]];
+      wave_lds_fence();
+      finish();
+      return ok;
+    }
+    bool nzcol = false, f2 = mfinite(akk);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (ri[r] == kk) Dg[kk] = akk;
+      if (cand[r] && ri[r] > kk) {
+        double v = val[r];
+        if (valid) {
+          v = v / akk;
+        } else {
+          nzcol = nzcol || !(v == 0.0);
+        }
+        const_cast<lds_d *>(rp[r])[kk] = v;
+        f2 = f2 && mfinite(v);
+      }
+    }
+    if (fin && wave_ballot(!f2)) fin = false;
+    if (!valid && wave_ballot(nzcol)) ret = 0;
+    if (found_zero && valid) ret = 0;
+    else if (!valid) found_zero = 1;
+    wave_lds_fence();
+  }
+  finish();
+  return ret;
+}
+
+// one row of the loop's state: the variable perm[row] of the KKT system, its iterate and constants
+struct MidRow {
+  bool isx, isc;
+  int xi, ci;
+  double qc, sxv, syv, rho, rinv, lo, hi, x, y, z;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+template<int NB, int WPE>
+__global__ void __launch_bounds__(64, WPE) qp_dense_mid_kernel(const DenseKernelParams kp, const QpBatch g)
+{
+  constexpr int R = NB > 4 ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int lane = threadIdx.x;
+  const int n = kp.n, m = kp.m, k = n + m;
+  const size_t b = blockIdx.x;
+  const MidLayout L = mid_layout(n, m);
+  lds_d *const T = (lds_d *)(sm + L.T), *const Dg = (lds_d *)(sm + L.Dg), *const tmp = (lds_d *)(sm + L.tmp), *const V = (lds_d *)(sm + L.V);
+  lds_b *const perm = (lds_b *)(sm + L.perm);
+  lds_i *const iperm = (lds_i *)(sm + L.tmp);
+  const double *const P = g.P + b * (size_t)n * n, *const q = g.q + b * (size_t)n, *const A = g.A + b * (size_t)m * n;
+  const double *const l = g.l + b * (size_t)m, *const u = g.u + b * (size_t)m;
+  const double inf = INFINITY;
+  const int tsz    = (k * (k + 1)) / 2 + kMidPadT;
+
+  // ================= setup: natural order, unit e = lane + 64 r: e < n variable e, else constraint e - n =================
+  lds_d *const SX = V, *const SY = V + n;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {  // analyze(): :306-308
+    const int e = lane + kWave * r;
+    if (e < k) V[e] = 1.0;
+  }
+  wave_lds_fence();
+  double c = 1.0;
+  if (kp.scaling) {  // :673-730
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int e = lane + kWave * r;
+      if (e < n) {  // :681-690 column inf-norms of P
+        double t = 0.0;
+        mrun(P + (size_t)e * n, 1, n, [&](int, double p) { t = fmax(t, fabs(p)); });
+        if (t == 0.0) t = 1.0;
+        tmp[e] = t;
+      }
+    }
+    wave_lds_fence();
+    double sum = tmp[0];  // :693 mean(): sequential sum
+    for (int j = 1; j < n; ++j) sum += tmp[j];
+    double qv = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int e = lane + kWave * r;
+      if (e < n) qv = fmax(qv, fabs(q[e]));
+    }
+    const double qn = wave_max(qv);
+    c               = 1.0 / fmax(fmax(1e-6, sum / (double)n), qn);
+    wave_lds_fence();
+    int pass = 0;
+    double crit;
+    do {  // :698-729
+      double inc[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int e = lane + kWave * r;
+        double v    = 0.0;
+        if (e < n) {
+          const double sxc = SX[e];
+          mrun(P + (size_t)e * n, 1, n, [&](int row, double p) { v = fmax(v, fabs(c * SX[row] * sxc * p)); });  // :704-707
+          mrun(A + (size_t)e * m, 1, m, [&](int row, double a) { v = fmax(v, fabs(SY[row] * sxc * a)); });      // :712-714
+        } else if (e < k) {
+          const double syr = SY[e - n];
+          mrun(A + (e - n), m, n, [&](int col, double a) { v = fmax(v, fabs(syr * SX[col] * a)); });
+        }
+        if (v == 0.0) v = 1.0;
+        inc[r] = v;
+      }
+      wave_lds_fence();  // every lane has read the old sx / sy
+      double cm = 0.0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int e = lane + kWave * r;
+        if (e < k) {
+          V[e] = sqrt(1.0 / fmax(inc[r], 1e-8)) * V[e];
+          cm   = fmax(cm, fabs(inc[r] - 1.0));
+        }
+      }
+      crit = wave_max(cm);
+      wave_lds_fence();
+    } while (pass++ < 10 && crit > 0.1);
+  }
+
+  // ---- pre-check and rho :361-374, the diagonal of the KKT matrix :399-404 ----
+  int ret_code = -1;
+  double dgn[R];
+  int idn[R];
+  {
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int e = lane + kWave * r;
+      idn[r]      = e;
+      dgn[r]      = 0.0;
+      if (e < n) {
+        const double sxe = SX[e];
+        dgn[r]           = c * sxe * P[(size_t)e * n + e] * sxe + kp.sigma;
+      } else if (e < k) {
+        const double li = l[e - n], ui = u[e - n];
+        bad = bad || (li == inf) || (ui == -inf) || (ui - li < 0.0);
+        double rho;
+        if (li == -inf && ui == inf) rho = 1e-6;
+        else if (SY[e - n] * fabs(li - ui) < 1e-5) rho = 1e3 * kp.rho_bar;
+        else rho = kp.rho_bar;
+        dgn[r] = 1.0 / (-rho);
+      }
+    }
+    if (wave_ballot(bad)) ret_code = SFB_QP_PRIMAL_INFEASIBLE;
+  }
+  const unsigned long long t0_ticks = wall_clock64();  // :376
+
+  // ---- Eigen's pivot order (from the diagonal), then the KKT matrix straight into its final positions ----
+  mid_pivot_order<R>(k, dgn, idn, lane);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int pos = lane + kWave * r;
+    if (pos < k) {
+      perm[pos]      = (unsigned char)idn[r];
+      iperm[idn[r]] = pos;
+    }
+  }
+  for (int e = lane; e < tsz; e += kWave) T[e] = 0.0;
+  wave_lds_fence();
+  bool fin = true;
+  {
+    const float rn = 1.0f / (float)n, rm = 1.0f / (float)m;
+    for (int e = lane; e < n * n; e += kWave) {  // upper entries (a, bb), a < bb, of P: ((c sx_a) P_ab) sx_b
+      const int bb = (int)(((float)e + 0.5f) * rn), a = e - bb * n;
+      if (a < bb) {
+        const double v = c * SX[a] * P[e] * SX[bb];
+        const int ra = iperm[a], rb = iperm[bb];
+        T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
+        fin = fin && mfinite(v);
+      }
+    }
+    for (int e = lane; e < m * n; e += kWave) {  // (sy_i A_ij) sx_j
+      const int j = (int)(((float)e + 0.5f) * rm), i = e - j * m;
+      const double v = SY[i] * A[e] * SX[j];
+      const int ra = iperm[n + i], rb = iperm[j];
+      T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
+      fin = fin && mfinite(v);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int pos = lane + kWave * r;
+      if (pos < k) {
+        T[mtri(pos) + pos] = dgn[r];
+        fin = fin && mfinite(dgn[r]);
+      }
+    }
+    fin = !wave_ballot(!fin);
+  }
+  wave_lds_fence();
+
+  // ---- LDL' :428-433 ----
+  if (!mid_ldlt<R>(k, T, Dg, tmp, lane, fin)) ret_code = SFB_QP_UNKNOWN;
+
+  // ================= lane roles for the loop: rows lane, lane + 64 of the PERMUTED system =================
+  MidRow h[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = lane + kWave * r;
+    const bool in = row < k;
+    const int v   = in ? perm[row] : 0;
+    MidRow &w = h[r];
+    w.isx = in && v < n;
+    w.isc = in && v >= n;
+    w.xi  = w.isx ? v : 0;
+    w.ci  = w.isc ? v - n : 0;
+    w.sxv = w.isx ? SX[w.xi] : 1.0;
+    w.syv = w.isc ? SY[w.ci] : 1.0;
+    w.qc  = w.isx ? c * w.sxv * q[w.xi] : 0.0;  // (c sx_j) q_j of the right-hand side :450
+    const double li = w.isc ? l[w.ci] : 0.0, ui = w.isc ? u[w.ci] : 0.0;
+    double rho = 1.0;
+    if (w.isc) {
+      if (li == -inf && ui == inf) rho = 1e-6;
+      else if (w.syv * fabs(li - ui) < 1e-5) rho = 1e3 * kp.rho_bar;
+      else rho = kp.rho_bar;
+    }
+    w.rho  = rho;
+    w.rinv = 1.0 / rho;
+    w.lo   = w.isc ? w.syv * li : 0.0;
+    w.hi   = w.isc ? w.syv * ui : 0.0;
+    w.x = w.y = w.z = 0.0;
+  }
+  // ---- initial iterate :436-445 ----
+  if (g.wx != nullptr) {
+    const double *const wx = g.wx + b * (size_t)n, *const wy = g.wy + b * (size_t)m;
+    lds_d *const WX = tmp;  // the warm primal, broadcast operand of z = (Sy A) x_ws
+    for (int j = lane; j < n; j += kWave) WX[j] = wx[j];
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      MidRow &w = h[r];
+      if (w.isx) w.x = (1.0 / w.sxv) * wx[w.xi];
+      if (w.isc) {
+        w.y      = c * ((1.0 / w.syv) * wy[w.ci]);
+        double s = 0.0;
+        const double syv = w.syv;
+        mrun(A + w.ci, m, n, [&](int j, double a) { s = fma(syv * a, WX[j], s); });
+        w.z = s;
+      }
+    }
+    wave_lds_fence();
+  }
+
+  // ================= stopping check :574-644 on the un-scaled iterates in V =================
+  lds_d *const xus = V, *const dxus = V + n, *const yus = V + 2 * n, *const zus = yus + m, *const dyus = tmp;
+  auto stop_check = [&]() -> int {
+    // rows of the mat-vecs: constraint i = lane + 64 r (< m), variable j = lane + 64 r (< n); s = 0, inner index ascending, fma
+    int ci_[R], vj_[R];
+    bool con[R], var[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      ci_[r] = lane + kWave * r;  con[r] = ci_[r] < m;
+      vj_[r] = lane + kWave * r;  var[r] = vj_[r] < n;
+    }
+    auto mv_A2 = [&](const lds_d *v0, double (&o0)[R], const lds_d *v1, double (&o1)[R], const bool two) {  // A v0 (and A v1)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        double s0 = 0.0, s1 = 0.0;
+        if (con[r]) {
+          if (two) mrun<16>(A + ci_[r], m, n, [&](int j, double a) { s0 = fma(a, v0[j], s0); s1 = fma(a, v1[j], s1); });
+          else mrun<16>(A + ci_[r], m, n, [&](int j, double a) { s0 = fma(a, v0[j], s0); });
+        }
+        o0[r] = s0;
+        o1[r] = s1;
+      }
+    };
+    auto mv_At = [&](const lds_d *v, double (&o)[R]) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        double s = 0.0;
+        if (var[r]) mrun<16>(A + (size_t)vj_[r] * m, 1, m, [&](int i, double a) { s = fma(a, v[i], s); });
+        o[r] = s;
+      }
+    };
+    auto mv_P = [&](const lds_d *v, double (&o)[R]) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        double s = 0.0;
+        if (var[r]) mrun<16>(P + vj_[r], n, n, [&](int j, double p) { s = fma(p, v[j], s); });
+        o[r] = s;
+      }
+    };
+    auto nrm = [&](const double (&v)[R], const bool (&on)[R]) {
+      double a = 0.0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) a = fmax(a, on[r] ? fabs(v[r]) : 0.0);
+      return wave_max(a);
+    };
+    auto nrm_lds = [&](const lds_d *v, const int len) {
+      double a = 0.0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int e = lane + kWave * r;
+        if (e < len) a = fmax(a, fabs(v[e]));
+      }
+      return wave_max(a);
+    };
+    double Ax[R], Adx[R];
+    mv_A2(xus, Ax, dxus, Adx, true);  // (A dx is needed by every check that does not end in Optimal / PrimalInfeasible: one pass over A for both)
+    // OPTIMALITY :584-594
+    {
+      const double Ax_norm = nrm(Ax, con);
+      double rs[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) rs[r] = con[r] ? Ax[r] - zus[ci_[r]] : 0.0;
+      if (nrm(rs, con) <= kp.eps_abs + kp.eps_rel * fmax(Ax_norm, nrm_lds(zus, m))) {
+        double Px[R], Aty[R], qv[R], res[R];
+        mv_P(xus, Px);
+        mv_At(yus, Aty);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          qv[r]  = var[r] ? q[vj_[r]] : 0.0;
+          res[r] = var[r] ? Px[r] + (qv[r] + Aty[r]) : 0.0;  // :592
+        }
+        const double dual_scale = fmax(fmax(nrm(Px, var), nrm(qv, var)), nrm(Aty, var));
+        if (nrm(res, var) <= kp.eps_abs + kp.eps_rel * dual_scale) return SFB_QP_OPTIMAL;
+      }
+    }
+    // PRIMAL INFEASIBILITY :598-621
+    {
+      double Aty[R];
+      mv_At(dyus, Aty);
+      const double Edy = nrm_lds(dyus, m);
+      const double thr = kp.eps_pinf * Edy;
+      // the ordered sum with its early exit to +inf: the oracle breaks at the first row with an unbounded side beyond the
+      // threshold and the sum becomes +inf, so only "any such row" matters; otherwise the sum is the ordered one (a skipped
+      // term adds +0.0, exact: the sum is never -0.0).  Terms go through xus / yus (dead after the optimality test).
+      lds_d *const tu = yus, *const tl = zus;
+      bool brk = false;
+      double ul_[R][2];
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (con[r]) {
+          const double ui = u[ci_[r]], li = l[ci_[r]], dyi = dyus[ci_[r]];
+          ul_[r][0] = (ui != inf) ? ui * fmax(0.0, dyi) : 0.0;
+          ul_[r][1] = (li != -inf) ? li * fmin(0.0, dyi) : 0.0;
+          brk = brk || (ui == inf && dyi > thr) || (li == -inf && dyi < -thr);
+        }
+      wave_lds_fence();
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (con[r]) {
+          tu[ci_[r]] = ul_[r][0];
+          tl[ci_[r]] = ul_[r][1];
+        }
+      wave_lds_fence();
+      double s = 0.0;
+      for (int i = 0; i < m; ++i) { s += tu[i]; s += tl[i]; }
+      if (wave_ballot(brk)) s = inf;
+      const double an = nrm(Aty, var);
+      if (((an < s) ? s : an) < thr) return SFB_QP_PRIMAL_INFEASIBLE;
+    }
+    // DUAL INFEASIBILITY :625-641
+    {
+      double Pdx[R];
+      mv_P(dxus, Pdx);
+      const double dxn = nrm_lds(dxus, n);
+      const double thr = kp.eps_dinf * dxn;
+      lds_d *const qs = xus;  // q next to dx for the ordered dot product
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (var[r]) qs[vj_[r]] = q[vj_[r]];
+      wave_lds_fence();
+      double qdx = 0.0;
+      for (int j = 0; j < n; ++j) qdx = fma(qs[j], dxus[j], qdx);
+      const bool ok = (nrm(Pdx, var) <= thr) && (qdx <= thr);
+      bool rowok    = true;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (con[r]) {
+          const double ui = u[ci_[r]], li = l[ci_[r]];
+          if (ui == inf) rowok = rowok && (Adx[r] >= -thr);
+          else if (li == -inf) rowok = rowok && (Adx[r] <= thr);
+          else rowok = rowok && (fabs(Adx[r]) < thr);
+        }
+      if (ok && !wave_ballot(!rowok)) return SFB_QP_DUAL_INFEASIBLE;
+    }
+    return -1;
+  };
+
+  // ================= ADMM loop :447-510 =================
+  uint32_t iter        = 0;
+  const uint32_t sci   = kp.stop_check_iter;
+  const uint32_t maxit = kp.max_iter;
+  uint32_t next_chk    = (sci >= 2) ? 1u : 0xFFFFFFFFu;  // iter % sci == 1 (:465) without a division per iteration
+  auto rhs = [&](const MidRow &w) { return w.isx ? (kp.sigma * w.x - w.qc) : (w.isc ? (w.z - w.rinv * w.y) : 0.0); };  // :450-451
+  auto upd = [&](MidRow &w, const double t, const bool chk) {                                                              // :470-477
+    const double xo = w.x, yo = w.y;
+    w.x       = kp.alpha * t + kp.alpha_comp * w.x;
+    double zn = kp.alpha * (w.rinv * t) + kp.alpha_comp * (w.rinv * w.y) + w.z;
+    zn        = (zn < w.lo) ? w.lo : zn;
+    zn        = (w.hi < zn) ? w.hi : zn;
+    w.y       = kp.alpha_comp * w.y + kp.alpha * t + w.rho * w.z - w.rho * zn;
+    w.z       = zn;
+    if (chk) {  // :481-485
+      if (w.isx) {
+        xus[w.xi]  = w.sxv * w.x;
+        dxus[w.xi] = w.sxv * (w.x - xo);
+      }
+      if (w.isc) {
+        yus[w.ci]  = w.syv * w.y / c;
+        zus[w.ci]  = (1.0 / w.syv) * w.z;
+        dyus[w.ci] = w.syv * (w.y - yo) / c;
+      }
+    }
+  };
+  for (; iter != maxit && ret_code < 0; ++iter) {
+    rows::Pair t{rhs(h[0]), R > 1 ? rhs(h[R - 1]) : 0.0};
+#ifdef SFB_MID_SWEEP_NOINLINE
+    t = rows::row_sweeps<NB, false>(k, (const double *)T, (const double *)Dg, t, lane);  // :462
+#else
+    t = rows::row_sweeps_inl<NB, false>(k, (const double *)T, (const double *)Dg, t, lane);  // :462
+#endif
+    const bool chk = (iter == next_chk);                                              // :465
+    if (chk) next_chk += sci;
+    upd(h[0], t.lo, chk);
+    if constexpr (R > 1) upd(h[R - 1], t.hi, chk);
+    if (chk) {
+      wave_lds_fence();
+      ret_code = stop_check();
+      if (ret_code < 0 && max_time_exceeded(kp.max_time_ns, t0_ticks)) ret_code = SFB_QP_MAX_TIME;  // :504-507
+      wave_lds_fence();
+    }
+  }
+
+  // ================= the end of solve() :515-548: V = [sx | sy | x | y | lists] in natural order =================
+  lds_d *const XS = V + k, *const YS = V + k + n;
+  wave_lds_fence();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const MidRow &w = h[r];
+    if (w.isx) { SX[w.xi] = w.sxv; XS[w.xi] = w.x; }
+    if (w.isc) { SY[w.ci] = w.syv; YS[w.ci] = w.y; }
+  }
+  wave_lds_fence();
+
+  // ---- polish :92-204 (on the scaled iterate; a failed factorisation leaves the ADMM solution) ----
+  if (ret_code == SFB_QP_OPTIMAL && kp.polish) {
+    const double eps = DBL_EPSILON;
+    lds_b *const colof = (lds_b *)(V + 2 * k);  // per constraint: its row n + a of the polish system, or 255
+    lds_b *const LU    = colof + m;             // row n + a -> constraint
+    // active sets: lower indices first, then upper, each ascending (:113-123)
+    int nl = 0, nu = 0;
+    int act[R], pos[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = lane + kWave * r;
+      int a       = 0;
+      if (i < m) {
+        const double yi = YS[i];
+        if (yi < -100 * eps && l[i] != -inf) a = 1;
+        if (yi > 100 * eps && u[i] != inf) a = 2;
+      }
+      const unsigned long long bl = wave_ballot(a == 1), bu = wave_ballot(a == 2);
+      act[r] = a;
+      pos[r] = (a == 1) ? nl + __popcll(bl & lanemask_lt(lane)) : nu + __popcll(bu & lanemask_lt(lane));
+      nl += __popcll(bl);
+      nu += __popcll(bu);
+    }
+    const int na = nl + nu, K = n + na;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = lane + kWave * r;
+      if (i < m) {
+        const int a = act[r] == 0 ? -1 : pos[r] + (act[r] == 2 ? nl : 0);
+        colof[i]    = (unsigned char)(a < 0 ? 255 : n + a);
+        if (a >= 0) LU[a] = (unsigned char)i;
+      }
+    }
+    wave_lds_fence();
+    // rows of the polish system: e = lane + 64 r < K: variable e, or active constraint LU[e - n]; h :179-182; diagonal of Hp :174-177
+    double hh[R], dgp[R];
+    int idp[R], prow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int e = lane + kWave * r;
+      idp[r] = e;  hh[r] = 0.0;  dgp[r] = 0.0;  prow[r] = 0;
+      if (e < n) {
+        const double sxe = SX[e];
+        dgp[r] = c * sxe * P[(size_t)e * n + e] * sxe + kp.delta;
+        hh[r]  = -c * (sxe * q[e]);
+      } else if (e < K) {
+        const int row = LU[e - n];
+        prow[r]       = row;
+        dgp[r]        = 0.0 - kp.delta;
+        hh[r]         = (e - n < nl) ? SY[row] * l[row] : SY[row] * u[row];
+      }
+    }
+    mid_pivot_order<R>(K, dgp, idp, lane);
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int p = lane + kWave * r;
+      if (p < K) {
+        perm[p]        = (unsigned char)idp[r];
+        iperm[idp[r]] = p;
+      }
+    }
+    const int tszp = (K * (K + 1)) / 2 + kMidPadT;
+    for (int e = lane; e < tszp; e += kWave) T[e] = 0.0;
+    wave_lds_fence();
+    bool finp = true;
+    {
+      const float rn = 1.0f / (float)n, rm = 1.0f / (float)m;
+      for (int e = lane; e < n * n; e += kWave) {
+        const int bb = (int)(((float)e + 0.5f) * rn), a = e - bb * n;
+        if (a < bb) {
+          const double v = c * SX[a] * P[e] * SX[bb];  // :161
+          const int ra = iperm[a], rb = iperm[bb];
+          T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
+          finp = finp && mfinite(v);
+        }
+      }
+      for (int e = lane; e < m * n; e += kWave) {
+        const int j = (int)(((float)e + 0.5f) * rm), i = e - j * m;
+        const int col = colof[i];
+        if (col != 255) {
+          const double v = SY[i] * A[e] * SX[j];  // :163
+          const int ra = iperm[col], rb = iperm[j];
+          T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
+          finp = finp && mfinite(v);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int p = lane + kWave * r;
+        if (p < K) {
+          T[mtri(p) + p] = dgp[r];
+          finp = finp && mfinite(dgp[r]);
+        }
+      }
+      finp = !wave_ballot(!finp);
+    }
+    wave_lds_fence();
+    if (mid_ldlt<R>(K, T, Dg, tmp, lane, finp)) {  // :187-190
+      double tt[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) tt[r] = 0.0;
+      lds_d *const tv = tmp;
+      for (uint32_t it = 0; it != kp.polish_iter; ++it) {  // :193-195  t += Hp^-1 (h - H t); the entries of H are recomputed (same products)
+        bool tfin = true;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int e = lane + kWave * r;
+          if (e < K) tv[e] = tt[r];
+          tfin = tfin && mfinite(tt[r]);
+        }
+        tfin = !wave_ballot(!tfin);
+        wave_lds_fence();
+        double res[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int e = lane + kWave * r;
+          double acc  = 0.0;
+          if (e < n) {
+            const double sxr = SX[e];
+            // upper entry (a, bb) of P: (j, e) for j < e -- column e, contiguous -- then (e, j) for j >= e -- row e, stride n
+            mrun(P + (size_t)e * n, 1, e, [&](int j, double p) { acc = fma(c * SX[j] * p * sxr, tv[j], acc); });
+            mrun(P + e + (size_t)e * n, n, n - e, [&](int d, double p) { acc = fma(c * sxr * p * SX[e + d], tv[e + d], acc); });
+            for (int a0 = 0; a0 < na; a0 += 8) {  // the active rows' entries of column e, eight at a time
+              int row[8];
+              double av[8];
+#pragma unroll
+              for (int uu = 0; uu < 8; ++uu) row[uu] = (a0 + uu < na) ? LU[a0 + uu] : 0;
+#pragma unroll
+              for (int uu = 0; uu < 8; ++uu) av[uu] = A[row[uu] + (size_t)e * m];
+#pragma unroll
+              for (int uu = 0; uu < 8; ++uu)
+                if (a0 + uu < na) acc = fma(SY[row[uu]] * av[uu] * sxr, tv[n + a0 + uu], acc);
+            }
+          } else if (e < K) {
+            const double syr = SY[prow[r]];
+            mrun(A + prow[r], m, n, [&](int j, double av) { acc = fma(syr * av * SX[j], tv[j], acc); });
+            // the zero (2,2) block of H: fma(0, t_j, acc) leaves acc unchanged for finite t_j (acc is never -0)
+            if (!tfin)
+              for (int j = n; j < K; ++j) acc = fma(0.0, tv[j], acc);
+          }
+          res[r] = hh[r] - acc;
+        }
+        wave_lds_fence();
+        // oracle_ldlt_solve: P b -> sweeps -> P^T, through the exchange vector
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int e = lane + kWave * r;
+          if (e < K) tv[e] = res[r];
+        }
+        wave_lds_fence();
+        rows::Pair pr{0.0, 0.0};
+        {
+          const int p0 = lane, p1 = lane + kWave;
+          if (p0 < K) pr.lo = tv[perm[p0]];
+          if (R > 1 && p1 < K) pr.hi = tv[perm[p1]];
+        }
+        wave_lds_fence();
+        pr = rows::row_sweeps<NB>(K, (const double *)T, (const double *)Dg, pr, lane);
+        {
+          const int p0 = lane, p1 = lane + kWave;
+          if (p0 < K) tv[perm[p0]] = pr.lo;
+          if (R > 1 && p1 < K) tv[perm[p1]] = pr.hi;
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int e = lane + kWave * r;
+          if (e < K) tt[r] += tv[e];
+        }
+        wave_lds_fence();
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {  // :199-201
+        const int e = lane + kWave * r;
+        if (e < n) XS[e] = tt[r];
+        else if (e < K) YS[prow[r]] = tt[r];
+      }
+    }
+    wave_lds_fence();
+  }
+
+  // ---- un-scale and report :544-548 ----
+  double *const ox = g.x + b * (size_t)n, *const oy = g.y + b * (size_t)m;
+  lds_d *const xo = tmp, *const pv = Dg;  // (both dead by now)
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int e = lane + kWave * r;
+    if (e < n) {
+      const double v = SX[e] * XS[e];
+      ox[e] = v;
+      xo[e] = v;
+    }
+    if (e < m) oy[e] = SY[e] * YS[e] / c;
+  }
+  wave_lds_fence();
+  if (g.obj != nullptr) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int e = lane + kWave * r;
+      if (e < n) {
+        double s = 0.0;
+        mrun(P + e, n, n, [&](int j, double p) { s = fma(0.5 * p, xo[j], s); });
+        pv[e] = s + q[e];
+      }
+    }
+    wave_lds_fence();
+    if (lane == 0) {
+      double o = 0.0;
+      for (int i = 0; i < n; ++i) o = fma(xo[i], pv[i], o);
+      g.obj[b] = o;
+    }
+  }
+  if (lane == 0) {
+    g.code[b] = (ret_code >= 0) ? ret_code : SFB_QP_MAX_ITERATIONS;
+    if (g.iter != nullptr) g.iter[b] = iter;
+  }
+}
+
+}  // namespace
+
+bool qp_dense_mid_enabled()
+{
+  static const bool off = [] { const char *v = sfb::knob("SFB_QP_MID"); return v && v[0] == '0'; }();
+  return !off;
+}
+
+size_t qp_dense_mid_lds_bytes(int n, int m) { return (size_t)mid_layout(n, m).total * sizeof(double); }
+
+hipError_t qp_dense_mid_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream)
+{
+  const int k = kp.n + kp.m;
+  if (k > kDenseMidMaxK || k < 1) return hipErrorInvalidValue;
+  const size_t lds = qp_dense_mid_lds_bytes(kp.n, kp.m);
+  const dim3 grid((unsigned)batch), block(kWave);
+  const int nb = (k + 15) / 16;
+#define SFB_MID(NBV, W) hipLaunchKernelGGL((qp_dense_mid_kernel<NBV, W>), grid, block, lds, stream, kp, g)
+  if (nb <= 3) SFB_MID(3, 4);
+  else if (nb == 4) SFB_MID(4, 3);
+  else if (nb == 5) SFB_MID(5, 2);
+  else if (nb == 6) SFB_MID(6, 1);
+  else if (nb == 7) SFB_MID(7, 1);
+  else SFB_MID(8, 1);
+#undef SFB_MID
+  return hipGetLastError();
+}
+
+}  // namespace sfb

@@ -40,6 +40,19 @@ __device__ __forceinline__ void static_for(F &&f)
   [&]<int... I>(std::integer_sequence<int, I...>) { (f(ic<I>{}), ...); }(std::make_integer_sequence<int, N>{});
 }
 
+// One operand of a sweep step from LDS as ONE ds_read_b64.  The load is volatile so that the compiler does not pair
+// neighbours into ds_read2_b64: that instruction occupies the LDS for 8 cycles per wave (two passes of four 16-lane
+// groups) against 2 for ds_read_b64 -- and with every resident wave sweeping, the LDS pipe of the CU is what the
+// batch rate hangs on (measured: (16, 32) at 95 % of the ds_read2_b64 bound).
+#ifndef SFB_ROWS_LD_PAIRED
+__device__ __forceinline__ double ld1(const __attribute__((address_space(3))) double *p)
+{
+  return *(const volatile __attribute__((address_space(3))) double *)p;
+}
+#else
+__device__ __forceinline__ double ld1(const __attribute__((address_space(3))) double *p) { return *p; }
+#endif
+
 struct Pair { double lo, hi; };  // rows lane and lane + 64 of a vector in the permuted order of the factorisation
 
 // lanes cc >= J of every 16-lane row
@@ -163,9 +176,10 @@ __device__ __forceinline__ void stage8(double &tp, double &tlo, double &thi, con
 // of oracle_ldlt_solve.  T: the packed lower triangle in LDS, entry (i, j), j < i, at T[i (i + 1) / 2 + j], its diagonal
 // slots at -0.0 (chain_ge); Dg: the diagonal D.  NB = ceil(K / 16) blocks, compile time; everything is unrolled over compile-time block and step numbers
 // (pivot lane, LDS offsets, lane and row masks are immediates).  The operands of a half block (8 steps) are fetched
-// from LDS while the previous half block runs.
-template<int NB>
-__device__ __attribute__((noinline)) Pair row_sweeps(const int K_, const double *T_, const double *Dg_, Pair t, const int lane)
+// from LDS while the previous half block runs.  An instance serves every K <= 16 NB (half blocks beyond K are skipped
+// by one wave-uniform test each): the polish system of a QP goes through the instance of its ADMM loop.
+template<int NB, bool ANYK = true>  // ANYK: any K <= 16 NB; otherwise 16 (NB - 1) < K <= 16 NB (only the last block can be partial: no tests on the others)
+__device__ __forceinline__ Pair row_sweeps_inl(const int K_, const double *T_, const double *Dg_, Pair t, const int lane)
 {
   static_assert(NB >= 1 && NB <= 8, "k <= 128");
   constexpr int NQ = NB > 4 ? 2 : 1;
@@ -207,16 +221,18 @@ __device__ __attribute__((noinline)) Pair row_sweeps(const int K_, const double 
     constexpr int JB = S >> 1, C = S & 1;
     static_for<8>([&]<int U>(ic<U>) {
       constexpr int J = 8 * C + U;
-      if constexpr (J < 15) ch[C][U] = pch[JB][J];
-      if constexpr (fwd_rows<NB>(JB, 0) != 0) f0[C][U] = plo[16 * JB + J];
-      if constexpr (NQ > 1 && fwd_rows<NB>(JB, 1) != 0) f1[C][U] = phi[16 * JB + J];
+      if constexpr (J < 15) ch[C][U] = ld1(pch[JB] + J);
+      if constexpr (fwd_rows<NB>(JB, 0) != 0) f0[C][U] = ld1(plo + 16 * JB + J);
+      if constexpr (NQ > 1 && fwd_rows<NB>(JB, 1) != 0) f1[C][U] = ld1(phi + 16 * JB + J);
     });
   };
   auto frun = [&]<int S>(ic<S>) {
     constexpr int JB = S >> 1, C = S & 1, RP = JB & 3, QP = JB >> 2;
     constexpr int RM0 = fwd_rows<NB>(JB, 0), RM1 = NQ > 1 ? fwd_rows<NB>(JB, 1) : 0;
+    if constexpr (ANYK)
+      if (16 * JB >= K) return;  // (blocks beyond K: rows that do not exist)
     if constexpr (C == 0) tp = row_to_all<RP>(QP ? thi : tlo);
-    if (JB < NB - 1 || 16 * JB + 8 * C < K) {  // (the last block beyond K: rows that do not exist -- pivots there only reach such rows)
+    if ((!ANYK && JB < NB - 1) || 16 * JB + 8 * C < K) {  // (a half block beyond K: pivots there only reach rows that do not exist)
       const unsigned long long m8[8] = {mk[8 * C], mk[8 * C + 1], mk[8 * C + 2], mk[8 * C + 3], mk[8 * C + 4], mk[8 * C + 5], mk[8 * C + 6], mk[8 * C + 7]};
       stage8<true, C, RM0, RM1>(tp, tlo, thi, ch[C], f0[C], f1[C], m8);
     }
@@ -236,9 +252,9 @@ __device__ __attribute__((noinline)) Pair row_sweeps(const int K_, const double 
     constexpr int JB = NB - 1 - (S >> 1), C = S & 1;
     static_for<8>([&]<int U>(ic<U>) {
       constexpr int J = 15 - 8 * C - U, RW = 16 * JB + J, RO = (RW * (RW + 1)) / 2;
-      if constexpr (J >= 1) ch[C][U] = pcc[RO + 16 * JB];
-      if constexpr (bwd_rows(JB, 0) != 0) f0[C][U] = cl0[RO];
-      if constexpr (NQ > 1 && bwd_rows(JB, 1) != 0) f1[C][U] = cl1[RO];
+      if constexpr (J >= 1) ch[C][U] = ld1(pcc + RO + 16 * JB);
+      if constexpr (bwd_rows(JB, 0) != 0) f0[C][U] = ld1(cl0 + RO);
+      if constexpr (NQ > 1 && bwd_rows(JB, 1) != 0) f1[C][U] = ld1(cl1 + RO);
     });
   };
   bload(ic<0>{});
@@ -254,12 +270,14 @@ __device__ __attribute__((noinline)) Pair row_sweeps(const int K_, const double 
   auto brun = [&]<int S>(ic<S>) {
     constexpr int JB = NB - 1 - (S >> 1), C = S & 1, RP = JB & 3, QP = JB >> 2;
     constexpr int RM0 = bwd_rows(JB, 0), RM1 = NQ > 1 ? bwd_rows(JB, 1) : 0;
+    if constexpr (ANYK)
+      if (16 * JB >= K) return;
     if constexpr (C == 0) tp = row_to_all<RP>(QP ? thi : tlo);
-    if (JB < NB - 1 || K == 16 * NB) {
+    if ((!ANYK && JB < NB - 1) || 16 * JB + 15 - 8 * C < K) {  // every pivot of this half block exists
       // step U is J = 15 - 8 C - U: s_not_b64 of mask_ge(J + 1) (of nothing at J = 15: every lane)
       const unsigned long long m8[8] = {C == 0 ? mzero : mk[8], mk[15 - 8 * C], mk[14 - 8 * C], mk[13 - 8 * C], mk[12 - 8 * C], mk[11 - 8 * C], mk[10 - 8 * C], mk[9 - 8 * C]};
       stage8<false, C, RM0, RM1>(tp, tlo, thi, ch[C], f0[C], f1[C], m8);
-    } else {  // the last block of a system that does not fill it: pivots beyond K do not exist, step by step
+    } else if ((!ANYK && JB < NB - 1) || 16 * JB + 8 - 8 * C < K) {  // the block that holds row K - 1 without being full: pivots beyond K do not exist, step by step
       static_for<8>([&]<int U>(ic<U>) {
         constexpr int J = 15 - 8 * C - U;
         if (16 * JB + J < K) {
@@ -281,19 +299,26 @@ __device__ __attribute__((noinline)) Pair row_sweeps(const int K_, const double 
   return Pair{tlo, thi};
 }
 
+// outlined instance (call sites off the hot loop); any K <= 16 NB
+template<int NB, bool ANYK = true>
+__device__ __attribute__((noinline)) Pair row_sweeps(const int K_, const double *T_, const double *Dg_, Pair t, const int lane)
+{
+  return row_sweeps_inl<NB, ANYK>(K_, T_, Dg_, t, lane);
+}
+
 // NB = ceil(K / 16) is wave-uniform at run time: one instance per block count
 __device__ __forceinline__ Pair row_sweeps_any(const int K, const double *T, const double *Dg, const Pair t, const int lane)
 {
   switch ((__builtin_amdgcn_readfirstlane(K) + 15) >> 4) {
     case 0:
-    case 1: return row_sweeps<1>(K, T, Dg, t, lane);
-    case 2: return row_sweeps<2>(K, T, Dg, t, lane);
-    case 3: return row_sweeps<3>(K, T, Dg, t, lane);
-    case 4: return row_sweeps<4>(K, T, Dg, t, lane);
-    case 5: return row_sweeps<5>(K, T, Dg, t, lane);
-    case 6: return row_sweeps<6>(K, T, Dg, t, lane);
-    case 7: return row_sweeps<7>(K, T, Dg, t, lane);
-    default: return row_sweeps<8>(K, T, Dg, t, lane);
+    case 1: return row_sweeps<1, false>(K, T, Dg, t, lane);
+    case 2: return row_sweeps<2, false>(K, T, Dg, t, lane);
+    case 3: return row_sweeps<3, false>(K, T, Dg, t, lane);
+    case 4: return row_sweeps<4, false>(K, T, Dg, t, lane);
+    case 5: return row_sweeps<5, false>(K, T, Dg, t, lane);
+    case 6: return row_sweeps<6, false>(K, T, Dg, t, lane);
+    case 7: return row_sweeps<7, false>(K, T, Dg, t, lane);
+    default: return row_sweeps<8, false>(K, T, Dg, t, lane);
   }
 }
 
