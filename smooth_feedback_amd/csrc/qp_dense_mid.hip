@@ -50,6 +50,13 @@ __device__ __forceinline__ int mtri(const int i) { return (i * (i + 1)) >> 1; }
 __device__ __forceinline__ int muni(const int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ bool mfinite(const double v) { return fabs(v) < INFINITY; }
 
+// profiling build (scripts/r4/build_variant.sh prof qp_dense_mid.hip -DSFB_MID_PROF): block 0 prints where its time went
+#ifdef SFB_MID_PROF
+#define MP_T(i) mp_t[i] = wall_clock64()
+#else
+#define MP_T(i)
+#endif
+
 constexpr int kMidPadT = 8;  // zeros behind the packed triangle (the chunked dot products read up to 7 entries past a row)
 
 // LDS layout in doubles (host and device)
@@ -84,34 +91,64 @@ __device__ __forceinline__ void mrun(const double *base, const int stride, const
       if (e0 + u < count) f(e0 + u, a[u]);
   }
 }
+// f(e, base[e]) for the elements e = lane, lane + 64, ... < count of a contiguous array (coalesced), U loads in flight per lane
+template<int U = 8, class F>
+__device__ __forceinline__ void mstream(const double *base, const int count, const int lane, F &&f)
+{
+  for (int b0 = 0; b0 < count; b0 += kWave * U) {
+    double a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = b0 + lane + kWave * u;
+      a[u]        = (e < count) ? base[e] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = b0 + lane + kWave * u;
+      if (e < count) f(e, a[u]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Eigen's pivot order from the diagonal alone (see the header).  d[r] / id[r]: value and index held at position
 // lane + 64 r; on return position p holds the entry Eigen's transpositions bring there (id = its original index).
 template<int R>
-__device__ inline void mid_pivot_order(const int K, double (&d)[R], int (&id)[R], const int lane)
+__device__ inline void mid_pivot_order(const int K_, double (&d)[R], int (&id)[R], const int lane)
 {
+  const int K = muni(K_);
+  // mx: the largest |d| among the positions >= kk (NaNs skipped).  It only changes when the positions holding it are used
+  // up, so the wave-wide maximum is recomputed when the search for it comes back empty, not at every step.
+  double mx   = 0.0;
+  bool mx_set = false;
   for (int kk = 0; kk + 1 < K; ++kk) {
-    double a[R];
-    double am = -1.0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int pos = lane + kWave * r;
-      a[r]          = (pos >= kk && pos < K) ? fabs(d[r]) : -1.0;
-      am            = fmax(am, a[r]);
-    }
-    const double mx = wave_max(am);
-    int p           = kk;
     const int hk = kk >> 6, lk = kk & 63;
     const double dkk = lane_bcast((R > 1 && hk) ? d[R - 1] : d[0], lk);
+    int p = kk;
     if (!(dkk != dkk)) {  // (a NaN AT kk stays the maximum of Eigen's strict '>' scan; NaNs further down are skipped)
-      bool found = false;
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        if (!mx_set) {
+          double am = -1.0;
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const unsigned long long bal = wave_ballot(a[r] == mx && a[r] >= 0.0);
-        if (!found && bal) {
-          p     = kWave * r + (int)__builtin_ctzll(bal);
-          found = true;
+          for (int r = 0; r < R; ++r) {
+            const int pos = lane + kWave * r;
+            am            = fmax(am, (pos >= kk && pos < K) ? fabs(d[r]) : -1.0);
+          }
+          mx     = wave_max(am);
+          mx_set = true;
         }
+        bool found = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int pos = lane + kWave * r;
+          const unsigned long long bal = wave_ballot(pos >= kk && pos < K && fabs(d[r]) == mx);
+          if (!found && bal) {
+            p     = kWave * r + (int)__builtin_ctzll(bal);
+            found = true;
+          }
+        }
+        if (found) break;
+        mx_set = false;  // the positions that held mx are all in front of kk now: next value
       }
     }
     if (p != kk) {
@@ -130,8 +167,44 @@ __device__ inline void mid_pivot_order(const int K, double (&d)[R], int (&id)[R]
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Dot products of one factorisation step: s[r] = sum_{j < 8 nch} fma(row_r[j], tmp[j], s[r]), j ascending, for the rows
+// R0 .. R-1 of the lane (R0 = 1: only rows >= 64 are still being eliminated).  Chunks of 8 terms, two chunks per trip
+// with the operands of the following chunk requested before the FMAs of the current one (the request past the last
+// chunk is clamped to it: a harmless re-read instead of a conditional the compiler would turn into register copies).
+template<int R, int R0>
+__device__ __forceinline__ void mid_dots(const lds_d *const tmp, const lds_d *const (&rp)[R], const int nch, double (&s)[R])
+{
+  double ta[8], tb[8], va[R][8], vb[R][8];
+  auto load = [&](double (&tv)[8], double (&vv)[R][8], const int c) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tv[e] = tmp[8 * c + e];
+#pragma unroll
+    for (int r = R0; r < R; ++r) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vv[r][e] = rp[r][8 * c + e];
+    }
+  };
+  auto fmas = [&](const double (&tv)[8], const double (&vv)[R][8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int r = R0; r < R; ++r) s[r] = fma(vv[r][e], tv[e], s[r]);
+    }
+  };
+  const int last = nch - 1;
+  load(ta, va, 0);
+  int c = 0;
+  for (; c + 1 < nch; c += 2) {
+    load(tb, vb, c + 1);
+    fmas(ta, va);
+    load(ta, va, (c + 2 < last) ? c + 2 : last);
+    fmas(tb, vb);
+  }
+  if (c < nch) fmas(ta, va);
+}
+
 // Unpivoted LDL' (Eigen 3.4's unblocked algorithm = oracle_ldlt_factor without its swaps) of the K x K matrix in the
-// packed triangle T, in place; D goes to Dg and the diagonal slots of T end at -0.0 (sweep_rows.h).  tmp: K + 8 doubles.
+// packed triangle T, in place; D goes to Dg and the diagonal slots of T end at -0.0 (sweep_rows.h).  tmp: K + 16 doubles.
 // Returns 1 on success, 0 on failure (info() == NumericalIssue).  Wave-uniform.  `fin`: every value in T (pad included) is finite.
 template<int R>
 __device__ inline int mid_ldlt(const int K_, lds_d *const T, lds_d *const Dg, lds_d *const tmp, const int lane, bool fin)
@@ -171,38 +244,9 @@ __device__ inline int mid_ldlt(const int K_, lds_d *const T, lds_d *const Dg, ld
 #pragma unroll
     for (int r = 0; r < R; ++r) s[r] = 0.0;
     if (kk > 0) {
-      if (fin) {
-        // chunks of 8 terms, the next chunk's operands in flight.  Rows below kk (already final) ride along: their sums are not used.
-        const bool lo_on = (R == 1) || kk < kWave;  // (rows < 64 are all final once kk >= 64)
-        const int nch    = kk8 >> 3;
-        double ta[8], tb[8], va[R][8], vb[R][8];
-        auto load = [&](double (&tv)[8], double (&vv)[R][8], const int c) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) tv[e] = tmp[8 * c + e];
-#pragma unroll
-          for (int r = 0; r < R; ++r)
-            if (r > 0 || lo_on) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) vv[r][e] = rp[r][8 * c + e];
-            }
-        };
-        auto fmas = [&](const double (&tv)[8], const double (&vv)[R][8]) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-              if (r > 0 || lo_on) s[r] = fma(vv[r][e], tv[e], s[r]);
-          }
-        };
-        load(ta, va, 0);
-        int c = 0;
-        for (; c + 1 < nch; c += 2) {
-          load(tb, vb, c + 1);
-          fmas(ta, va);
-          if (c + 2 < nch) load(ta, va, c + 2);
-          fmas(tb, vb);
-        }
-        if (c < nch) fmas(ta, va);
+      if (fin) {  // (rows below kk -- already final -- ride along: their sums are not used)
+        if (R > 1 && kk >= kWave) mid_dots<R, R - 1>(tmp, rp, kk8 >> 3, s);  // rows < 64 are all final
+        else mid_dots<R, 0>(tmp, rp, kk8 >> 3, s);
       } else {
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -274,6 +318,7 @@ template<int NB, int WPE>
 __global__ void __launch_bounds__(64, WPE) qp_dense_mid_kernel(const DenseKernelParams kp, const QpBatch g)
 {
   constexpr int R = NB > 4 ? 2 : 1;
+  constexpr int kFillU = NB > 4 ? 16 : 8;     // loads in flight per lane while P and A are streamed into the KKT matrix
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int lane = threadIdx.x;
   const int n = kp.n, m = kp.m, k = n + m;
@@ -287,6 +332,10 @@ __global__ void __launch_bounds__(64, WPE) qp_dense_mid_kernel(const DenseKernel
   const double inf = INFINITY;
   const int tsz    = (k * (k + 1)) / 2 + kMidPadT;
 
+#ifdef SFB_MID_PROF
+  unsigned long long mp_t[12] = {};
+#endif
+  MP_T(0);
   // ================= setup: natural order, unit e = lane + 64 r: e < n variable e, else constraint e - n =================
   lds_d *const SX = V, *const SY = V + n;
 #pragma unroll
@@ -353,6 +402,7 @@ __global__ void __launch_bounds__(64, WPE) qp_dense_mid_kernel(const DenseKernel
     } while (pass++ < 10 && crit > 0.1);
   }
 
+  MP_T(1);
   // ---- pre-check and rho :361-374, the diagonal of the KKT matrix :399-404 ----
   int ret_code = -1;
   double dgn[R];
@@ -382,7 +432,9 @@ __global__ void __launch_bounds__(64, WPE) qp_dense_mid_kernel(const DenseKernel
   const unsigned long long t0_ticks = wall_clock64();  // :376
 
   // ---- Eigen's pivot order (from the diagonal), then the KKT matrix straight into its final positions ----
+  MP_T(2);
   mid_pivot_order<R>(k, dgn, idn, lane);
+  MP_T(3);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int pos = lane + kWave * r;
@@ -396,22 +448,22 @@ __global__ void __launch_bounds__(64, WPE) qp_dense_mid_kernel(const DenseKernel
   bool fin = true;
   {
     const float rn = 1.0f / (float)n, rm = 1.0f / (float)m;
-    for (int e = lane; e < n * n; e += kWave) {  // upper entries (a, bb), a < bb, of P: ((c sx_a) P_ab) sx_b
+    mstream<kFillU>(P, n * n, lane, [&](const int e, const double pv) {  // upper entries (a, bb), a < bb, of P: ((c sx_a) P_ab) sx_b
       const int bb = (int)(((float)e + 0.5f) * rn), a = e - bb * n;
       if (a < bb) {
-        const double v = c * SX[a] * P[e] * SX[bb];
+        const double v = c * SX[a] * pv * SX[bb];
         const int ra = iperm[a], rb = iperm[bb];
         T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
         fin = fin && mfinite(v);
       }
-    }
-    for (int e = lane; e < m * n; e += kWave) {  // (sy_i A_ij) sx_j
+    });
+    mstream<kFillU>(A, m * n, lane, [&](const int e, const double av) {  // (sy_i A_ij) sx_j
       const int j = (int)(((float)e + 0.5f) * rm), i = e - j * m;
-      const double v = SY[i] * A[e] * SX[j];
+      const double v = SY[i] * av * SX[j];
       const int ra = iperm[n + i], rb = iperm[j];
       T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
       fin = fin && mfinite(v);
-    }
+    });
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int pos = lane + kWave * r;
@@ -424,8 +476,10 @@ __global__ void __launch_bounds__(64, WPE) qp_dense_mid_kernel(const DenseKernel
   }
   wave_lds_fence();
 
+  MP_T(4);
   // ---- LDL' :428-433 ----
   if (!mid_ldlt<R>(k, T, Dg, tmp, lane, fin)) ret_code = SFB_QP_UNKNOWN;
+  MP_T(5);
 
   // ================= lane roles for the loop: rows lane, lane + 64 of the PERMUTED system =================
   MidRow h[R];
@@ -613,6 +667,7 @@ __global__ void __launch_bounds__(64, WPE) qp_dense_mid_kernel(const DenseKernel
     return -1;
   };
 
+  MP_T(6);
   // ================= ADMM loop :447-510 =================
   uint32_t iter        = 0;
   const uint32_t sci   = kp.stop_check_iter;
@@ -641,11 +696,7 @@ __global__ void __launch_bounds__(64, WPE) qp_dense_mid_kernel(const DenseKernel
   };
   for (; iter != maxit && ret_code < 0; ++iter) {
     rows::Pair t{rhs(h[0]), R > 1 ? rhs(h[R - 1]) : 0.0};
-#ifdef SFB_MID_SWEEP_NOINLINE
-    t = rows::row_sweeps<NB, false>(k, (const double *)T, (const double *)Dg, t, lane);  // :462
-#else
     t = rows::row_sweeps_inl<NB, false>(k, (const double *)T, (const double *)Dg, t, lane);  // :462
-#endif
     const bool chk = (iter == next_chk);                                              // :465
     if (chk) next_chk += sci;
     upd(h[0], t.lo, chk);
@@ -658,6 +709,7 @@ __global__ void __launch_bounds__(64, WPE) qp_dense_mid_kernel(const DenseKernel
     }
   }
 
+  MP_T(7);
   // ================= the end of solve() :515-548: V = [sx | sy | x | y | lists] in natural order =================
   lds_d *const XS = V + k, *const YS = V + k + n;
   wave_lds_fence();
@@ -737,25 +789,25 @@ __global__ void __launch_bounds__(64, WPE) qp_dense_mid_kernel(const DenseKernel
     bool finp = true;
     {
       const float rn = 1.0f / (float)n, rm = 1.0f / (float)m;
-      for (int e = lane; e < n * n; e += kWave) {
+      mstream<kFillU>(P, n * n, lane, [&](const int e, const double pv) {
         const int bb = (int)(((float)e + 0.5f) * rn), a = e - bb * n;
         if (a < bb) {
-          const double v = c * SX[a] * P[e] * SX[bb];  // :161
+          const double v = c * SX[a] * pv * SX[bb];  // :161
           const int ra = iperm[a], rb = iperm[bb];
           T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
           finp = finp && mfinite(v);
         }
-      }
-      for (int e = lane; e < m * n; e += kWave) {
+      });
+      mstream<kFillU>(A, m * n, lane, [&](const int e, const double av) {
         const int j = (int)(((float)e + 0.5f) * rm), i = e - j * m;
         const int col = colof[i];
         if (col != 255) {
-          const double v = SY[i] * A[e] * SX[j];  // :163
+          const double v = SY[i] * av * SX[j];  // :163
           const int ra = iperm[col], rb = iperm[j];
           T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
           finp = finp && mfinite(v);
         }
-      }
+      });
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int p = lane + kWave * r;
@@ -851,6 +903,7 @@ __global__ void __launch_bounds__(64, WPE) qp_dense_mid_kernel(const DenseKernel
     wave_lds_fence();
   }
 
+  MP_T(8);
   // ---- un-scale and report :544-548 ----
   double *const ox = g.x + b * (size_t)n, *const oy = g.y + b * (size_t)m;
   lds_d *const xo = tmp, *const pv = Dg;  // (both dead by now)
@@ -886,6 +939,13 @@ __global__ void __launch_bounds__(64, WPE) qp_dense_mid_kernel(const DenseKernel
     g.code[b] = (ret_code >= 0) ? ret_code : SFB_QP_MAX_ITERATIONS;
     if (g.iter != nullptr) g.iter[b] = iter;
   }
+#ifdef SFB_MID_PROF
+  MP_T(9);
+  if (lane == 0 && blockIdx.x == 0)
+    printf("midprof (%d,%d) x10ns: scale %llu | rho+diag %llu | pivot order %llu | zero+fill %llu | ldlt %llu | roles+warm %llu | loop %llu (%u iterations) | polish %llu | report %llu\n",
+           n, m, mp_t[1] - mp_t[0], mp_t[2] - mp_t[1], mp_t[3] - mp_t[2], mp_t[4] - mp_t[3], mp_t[5] - mp_t[4], mp_t[6] - mp_t[5], mp_t[7] - mp_t[6], iter,
+           mp_t[8] - mp_t[7], mp_t[9] - mp_t[8]);
+#endif
 }
 
 }  // namespace
