@@ -147,7 +147,7 @@ sfb_status dense_big(const sfb_qp_params *prm, int64_t batch, int n, int m, cons
   if (n + m <= sfb::kDenseMidMaxK && sfb::qp_dense_mid_enabled()) {  // up to 128: everything on chip, no workspace (qp_dense_mid.hip)
     const sfb::DenseKernelParams kpm = make_kernel_params(prm, n, m);
     const sfb::QpBatch gm{P, q, A, l, u, wx, wy, x, y, obj, iter, code};
-    const hipError_t em = sfb::qp_dense_mid_launch(kpm, batch, gm, stream);
+    const hipError_t em = sfb::qp_dense_mid_launch(kpm, batch, gm, stream, workspace);
     if (em != hipSuccess) return hip_fail(em, "qp_dense_mid_kernel launch");
     return SFB_OK;
   }
@@ -437,7 +437,8 @@ static sfb_status dense_workspace_need(const sfb_qp_params *prm, int64_t batch, 
   if (k > SFB_QP_DENSE_MAX_K) {
     static const bool big_off = [] { const char *v = sfb::knob("SFB_QP_DENSE_BIG"); return v && v[0] == '0'; }();
     if (k <= sfb::kDenseBigMaxK && !big_off) {
-      *need = (k <= sfb::kDenseMidMaxK && sfb::qp_dense_mid_enabled()) ? 0 : (size_t)batch * sfb::qp_dense_big_ws_doubles(n, m) * sizeof(double);
+      *need = (k <= sfb::kDenseMidMaxK && sfb::qp_dense_mid_enabled()) ? sfb::qp_dense_mid_ws_bytes(make_kernel_params(prm, n, m), batch)
+                                                                       : (size_t)batch * sfb::qp_dense_big_ws_doubles(n, m) * sizeof(double);
       return SFB_OK;
     }
     sfb_sparse_qp_plan *plan = nullptr;
@@ -446,8 +447,9 @@ static sfb_status dense_workspace_need(const sfb_qp_params *prm, int64_t batch, 
     size_t abytes = 0;
     return dense_via_sparse_bytes(plan, batch, n, m, &abytes, need);
   }
-  (void)prm;  // (a time limit sends k <= 32 to the one-per-wave kernels, which need none: the bound below still holds)
+  // (a time limit sends k <= 32 to the one-per-wave kernels, which need none: the bound below still holds)
   if (k <= 32) *need = sfb::qp_dense4_ws_bytes(n, m, batch);
+  else if (sfb::qp_dense_mid_enabled()) *need = sfb::qp_dense_mid_ws_bytes(make_kernel_params(prm, n, m), batch);
   return SFB_OK;
 }
 

@@ -326,7 +326,7 @@ hipError_t qp_dense_launch(const DenseKernelParams &kp, int64_t batch, const dou
   }
   if (k > 32 && qp_dense_mid_enabled() && !sfb::knob("SFB_QP_SWEEP")) {  // 32 < k <= 64: the on-chip block-sweep kernel (qp_dense_mid.hip)
     const QpBatch g{P, q, A, l, u, wx, wy, x, y, obj, iter, code};
-    return qp_dense_mid_launch(kp, batch, g, stream);
+    return qp_dense_mid_launch(kp, batch, g, stream, workspace);
   }
   size_t lds         = qp_dense_lds_bytes(kp.n, kp.m);
   if (const char *pad = sfb::knob("SFB_QP_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments only

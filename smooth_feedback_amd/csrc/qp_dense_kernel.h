@@ -47,7 +47,9 @@ constexpr int kDenseBigMaxK = 1024;
 // the pivot broadcast fused into the FP64 FMA, the matrix written in Eigen's pivot order before an unpivoted factorisation
 constexpr int kDenseMidMaxK = 128;
 size_t qp_dense_mid_lds_bytes(int n, int m);
-hipError_t qp_dense_mid_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream);
+// workspace: qp_dense_mid_ws_bytes bytes of device memory (0 for batches the chip holds at once), or nullptr = stream-ordered allocation
+size_t qp_dense_mid_ws_bytes(const DenseKernelParams &kp, int64_t batch);
+hipError_t qp_dense_mid_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream, void *workspace = nullptr);
 bool qp_dense_mid_enabled();  // SFB_QP_MID=0 (A/B, tests): the kernels these sizes had before
 
 hipError_t qp_dense_launch(const DenseKernelParams &kp, int64_t batch, const double *P, const double *q,

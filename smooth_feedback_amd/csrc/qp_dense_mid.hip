@@ -57,6 +57,14 @@ __device__ __forceinline__ bool mfinite(const double v) { return fabs(v) < INFIN
 #define MP_T(i)
 #endif
 
+// waves per SIMD the k <= 48 / k <= 64 instances are compiled for (VGPR budget 168 at 3, 256 at 2)
+#ifndef SFB_MID_W3
+#define SFB_MID_W3 3
+#endif
+#ifndef SFB_MID_W4
+#define SFB_MID_W4 2
+#endif
+
 constexpr int kMidPadT = 8;  // zeros behind the packed triangle (the chunked dot products read up to 7 entries past a row)
 
 // LDS layout in doubles (host and device)
@@ -314,638 +322,847 @@ struct MidRow {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
+// Ordered dot products against a matrix in global memory: f(j, base[j * stride], v0[j], v1[j]) for j = 0 .. count-1 IN
+// ORDER, the matrix entries and the LDS vector entries of a batch requested together (no wait, no branch per element);
+// batches of U, the remainder in batches of U/2, U/4, ... 1.
+template<int U, class F>
+__device__ __forceinline__ void mvec_batch(const double *const base, const size_t stride, const lds_d *const v0, const lds_d *const v1, const int j0, F &&f)
+{
+  double a[U], x0[U], x1[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) a[u] = base[(size_t)(j0 + u) * stride];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    x0[u] = v0[j0 + u];
+    x1[u] = v1[j0 + u];
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) f(j0 + u, a[u], x0[u], x1[u]);
+}
+template<int U = 16, class F>
+__device__ __forceinline__ void mvec(const double *const base, const size_t stride, const lds_d *const v0, const lds_d *const v1, const int count, F &&f)
+{
+  int j = 0;
+  for (; j + U <= count; j += U) mvec_batch<U>(base, stride, v0, v1, j, f);
+  if constexpr (U >= 16) if (count - j >= 8) { mvec_batch<8>(base, stride, v0, v1, j, f); j += 8; }
+  if constexpr (U >= 8) if (count - j >= 4) { mvec_batch<4>(base, stride, v0, v1, j, f); j += 4; }
+  if constexpr (U >= 4) if (count - j >= 2) { mvec_batch<2>(base, stride, v0, v1, j, f); j += 2; }
+  if (count - j >= 1) mvec_batch<1>(base, stride, v0, v1, j, f);
+}
+
+// QPSolver::check_stopping, qp_solver.hpp:574-644 (oracle qp_check_stopping) on the un-scaled iterates
+// V = [x (n) | dx (n) | y (m) | z (m)], dy in tmp.  Returns a QPSolutionStatus or -1 (std::nullopt).  Wave-uniform.
+// Outlined: it runs once per stop_check_iter iterations and its registers stay out of the ADMM loop's budget.
+// Rows of the mat-vecs: constraint i = lane + 64 r (< m), variable j = lane + 64 r (< n); s = 0, inner index ascending, fma.
+template<int R>
+__device__ __attribute__((noinline)) int mid_stop_check(const int n_, const int m_, const int lane, const double *const P, const double *const q,
+                                                        const double *const A, const double *const l, const double *const u, lds_d *const V,
+                                                        lds_d *const tmp, const double eps_abs, const double eps_rel, const double eps_pinf,
+                                                        const double eps_dinf)
+{
+  const int n = muni(n_), m = muni(m_);
+  const double inf = INFINITY;
+  lds_d *const xus = V, *const dxus = V + n, *const yus = V + 2 * n, *const zus = yus + m, *const dyus = tmp;
+  int ci_[R], vj_[R];
+  bool con[R], var[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    ci_[r] = lane + kWave * r;  con[r] = ci_[r] < m;
+    vj_[r] = lane + kWave * r;  var[r] = vj_[r] < n;
+  }
+  // rows that do not exist read row 0 (valid memory) and drop the result: no divergent control flow around the batches
+  auto mv_A2 = [&](const lds_d *v0, double (&o0)[R], const lds_d *v1, double (&o1)[R]) {  // A v0 and A v1, one pass over A
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      double s0 = 0.0, s1 = 0.0;
+      mvec<16>(A + (con[r] ? ci_[r] : 0), (size_t)m, v0, v1, n, [&](int, double a, double x0, double x1) { s0 = fma(a, x0, s0); s1 = fma(a, x1, s1); });
+      o0[r] = con[r] ? s0 : 0.0;
+      o1[r] = con[r] ? s1 : 0.0;
+    }
+  };
+  auto mv_At = [&](const lds_d *v, double (&o)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      double s = 0.0;
+      mvec<16>(A + (size_t)(var[r] ? vj_[r] : 0) * m, 1, v, v, m, [&](int, double a, double x0, double) { s = fma(a, x0, s); });
+      o[r] = var[r] ? s : 0.0;
+    }
+  };
+  auto mv_P = [&](const lds_d *v, double (&o)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      double s = 0.0;
+      mvec<16>(P + (var[r] ? vj_[r] : 0), (size_t)n, v, v, n, [&](int, double p, double x0, double) { s = fma(p, x0, s); });
+      o[r] = var[r] ? s : 0.0;
+    }
+  };
+  auto nrm = [&](const double (&v)[R], const bool (&on)[R]) {
+    double a = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) a = fmax(a, on[r] ? fabs(v[r]) : 0.0);
+    return wave_max(a);
+  };
+  auto nrm_lds = [&](const lds_d *v, const int len) {
+    double a = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int e = lane + kWave * r;
+      if (e < len) a = fmax(a, fabs(v[e]));
+    }
+    return wave_max(a);
+  };
+  double Ax[R], Adx[R];
+  mv_A2(xus, Ax, dxus, Adx);  // (A dx is needed by every check that does not end in Optimal / PrimalInfeasible: one pass over A for both)
+  // OPTIMALITY :584-594
+  {
+    const double Ax_norm = nrm(Ax, con);
+    double rs[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) rs[r] = con[r] ? Ax[r] - zus[ci_[r]] : 0.0;
+    if (nrm(rs, con) <= eps_abs + eps_rel * fmax(Ax_norm, nrm_lds(zus, m))) {
+      double Px[R], Aty[R], qv[R], res[R];
+      mv_P(xus, Px);
+      mv_At(yus, Aty);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        qv[r]  = var[r] ? q[vj_[r]] : 0.0;
+        res[r] = var[r] ? Px[r] + (qv[r] + Aty[r]) : 0.0;  // :592
+      }
+      const double dual_scale = fmax(fmax(nrm(Px, var), nrm(qv, var)), nrm(Aty, var));
+      if (nrm(res, var) <= eps_abs + eps_rel * dual_scale) return SFB_QP_OPTIMAL;
+    }
+  }
+  // PRIMAL INFEASIBILITY :598-621
+  {
+    double Aty[R];
+    mv_At(dyus, Aty);
+    const double Edy = nrm_lds(dyus, m);
+    const double thr = eps_pinf * Edy;
+    // the ordered sum with its early exit to +inf: the oracle breaks at the first row with an unbounded side beyond the
+    // threshold and the sum becomes +inf, so only "any such row" matters; otherwise the sum is the ordered one (a skipped
+    // term adds +0.0, exact: the sum is never -0.0).  The terms go through y / z (dead after the optimality test).
+    lds_d *const tu = yus, *const tl = zus;
+    bool brk = false;
+    double ul_[R][2];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (con[r]) {
+        const double ui = u[ci_[r]], li = l[ci_[r]], dyi = dyus[ci_[r]];
+        ul_[r][0] = (ui != inf) ? ui * fmax(0.0, dyi) : 0.0;
+        ul_[r][1] = (li != -inf) ? li * fmin(0.0, dyi) : 0.0;
+        brk = brk || (ui == inf && dyi > thr) || (li == -inf && dyi < -thr);
+      }
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (con[r]) {
+        tu[ci_[r]] = ul_[r][0];
+        tl[ci_[r]] = ul_[r][1];
+      }
+    wave_lds_fence();
+    double s = 0.0;
+    {
+      int i = 0;
+      for (; i + 8 <= m; i += 8) {  // (eight terms of each side requested together; same order of additions)
+        double a[8], b[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] = tu[i + e]; b[e] = tl[i + e]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s += a[e]; s += b[e]; }
+      }
+      for (; i < m; ++i) { s += tu[i]; s += tl[i]; }
+    }
+    if (wave_ballot(brk)) s = inf;
+    const double an = nrm(Aty, var);
+    if (((an < s) ? s : an) < thr) return SFB_QP_PRIMAL_INFEASIBLE;
+  }
+  // DUAL INFEASIBILITY :625-641
+  {
+    double Pdx[R];
+    mv_P(dxus, Pdx);
+    const double dxn = nrm_lds(dxus, n);
+    const double thr = eps_dinf * dxn;
+    lds_d *const qs = xus;  // q next to dx for the ordered dot product
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (var[r]) qs[vj_[r]] = q[vj_[r]];
+    wave_lds_fence();
+    double qdx = 0.0;
+    {
+      int j = 0;
+      for (; j + 8 <= n; j += 8) {
+        double a[8], b[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] = qs[j + e]; b[e] = dxus[j + e]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qdx = fma(a[e], b[e], qdx);
+      }
+      for (; j < n; ++j) qdx = fma(qs[j], dxus[j], qdx);
+    }
+    const bool ok = (nrm(Pdx, var) <= thr) && (qdx <= thr);
+    bool rowok    = true;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (con[r]) {
+        const double ui = u[ci_[r]], li = l[ci_[r]];
+        if (ui == inf) rowok = rowok && (Adx[r] >= -thr);
+        else if (li == -inf) rowok = rowok && (Adx[r] <= thr);
+        else rowok = rowok && (fabs(Adx[r]) < thr);
+      }
+    if (ok && !wave_ballot(!rowok)) return SFB_QP_DUAL_INFEASIBLE;
+  }
+  return -1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 template<int NB, int WPE>
-__global__ void __launch_bounds__(64, WPE) qp_dense_mid_kernel(const DenseKernelParams kp, const QpBatch g)
+__global__ void __launch_bounds__(64, WPE) qp_dense_mid_kernel(const DenseKernelParams kp, const QpBatch g, double *__restrict__ gws, const size_t wsd,
+                                                               unsigned *__restrict__ queue, const unsigned batch, const uint32_t slice)
 {
   constexpr int R = NB > 4 ? 2 : 1;
   constexpr int kFillU = NB > 4 ? 16 : 8;     // loads in flight per lane while P and A are streamed into the KKT matrix
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int lane = threadIdx.x;
   const int n = kp.n, m = kp.m, k = n + m;
-  const size_t b = blockIdx.x;
   const MidLayout L = mid_layout(n, m);
   lds_d *const T = (lds_d *)(sm + L.T), *const Dg = (lds_d *)(sm + L.Dg), *const tmp = (lds_d *)(sm + L.tmp), *const V = (lds_d *)(sm + L.V);
   lds_b *const perm = (lds_b *)(sm + L.perm);
   lds_i *const iperm = (lds_i *)(sm + L.tmp);
-  const double *const P = g.P + b * (size_t)n * n, *const q = g.q + b * (size_t)n, *const A = g.A + b * (size_t)m * n;
-  const double *const l = g.l + b * (size_t)m, *const u = g.u + b * (size_t)m;
+  lds_d *const SX = V, *const SY = V + n;
   const double inf = INFINITY;
   const int tsz    = (k * (k + 1)) / 2 + kMidPadT;
-
-#ifdef SFB_MID_PROF
-  unsigned long long mp_t[12] = {};
-#endif
-  MP_T(0);
-  // ================= setup: natural order, unit e = lane + 64 r: e < n variable e, else constraint e - n =================
-  lds_d *const SX = V, *const SY = V + n;
-#pragma unroll
-  for (int r = 0; r < R; ++r) {  // analyze(): :306-308
-    const int e = lane + kWave * r;
-    if (e < k) V[e] = 1.0;
-  }
-  wave_lds_fence();
-  double c = 1.0;
-  if (kp.scaling) {  // :673-730
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int e = lane + kWave * r;
-      if (e < n) {  // :681-690 column inf-norms of P
-        double t = 0.0;
-        mrun(P + (size_t)e * n, 1, n, [&](int, double p) { t = fmax(t, fabs(p)); });
-        if (t == 0.0) t = 1.0;
-        tmp[e] = t;
-      }
-    }
-    wave_lds_fence();
-    double sum = tmp[0];  // :693 mean(): sequential sum
-    for (int j = 1; j < n; ++j) sum += tmp[j];
-    double qv = 0.0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int e = lane + kWave * r;
-      if (e < n) qv = fmax(qv, fabs(q[e]));
-    }
-    const double qn = wave_max(qv);
-    c               = 1.0 / fmax(fmax(1e-6, sum / (double)n), qn);
-    wave_lds_fence();
-    int pass = 0;
-    double crit;
-    do {  // :698-729
-      double inc[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int e = lane + kWave * r;
-        double v    = 0.0;
-        if (e < n) {
-          const double sxc = SX[e];
-          mrun(P + (size_t)e * n, 1, n, [&](int row, double p) { v = fmax(v, fabs(c * SX[row] * sxc * p)); });  // :704-707
-          mrun(A + (size_t)e * m, 1, m, [&](int row, double a) { v = fmax(v, fabs(SY[row] * sxc * a)); });      // :712-714
-        } else if (e < k) {
-          const double syr = SY[e - n];
-          mrun(A + (e - n), m, n, [&](int col, double a) { v = fmax(v, fabs(syr * SX[col] * a)); });
-        }
-        if (v == 0.0) v = 1.0;
-        inc[r] = v;
-      }
-      wave_lds_fence();  // every lane has read the old sx / sy
-      double cm = 0.0;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int e = lane + kWave * r;
-        if (e < k) {
-          V[e] = sqrt(1.0 / fmax(inc[r], 1e-8)) * V[e];
-          cm   = fmax(cm, fabs(inc[r] - 1.0));
-        }
-      }
-      crit = wave_max(cm);
-      wave_lds_fence();
-    } while (pass++ < 10 && crit > 0.1);
-  }
-
-  MP_T(1);
-  // ---- pre-check and rho :361-374, the diagonal of the KKT matrix :399-404 ----
-  int ret_code = -1;
-  double dgn[R];
-  int idn[R];
-  {
-    bool bad = false;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int e = lane + kWave * r;
-      idn[r]      = e;
-      dgn[r]      = 0.0;
-      if (e < n) {
-        const double sxe = SX[e];
-        dgn[r]           = c * sxe * P[(size_t)e * n + e] * sxe + kp.sigma;
-      } else if (e < k) {
-        const double li = l[e - n], ui = u[e - n];
-        bad = bad || (li == inf) || (ui == -inf) || (ui - li < 0.0);
-        double rho;
-        if (li == -inf && ui == inf) rho = 1e-6;
-        else if (SY[e - n] * fabs(li - ui) < 1e-5) rho = 1e3 * kp.rho_bar;
-        else rho = kp.rho_bar;
-        dgn[r] = 1.0 / (-rho);
-      }
-    }
-    if (wave_ballot(bad)) ret_code = SFB_QP_PRIMAL_INFEASIBLE;
-  }
-  const unsigned long long t0_ticks = wall_clock64();  // :376
-
-  // ---- Eigen's pivot order (from the diagonal), then the KKT matrix straight into its final positions ----
-  MP_T(2);
-  mid_pivot_order<R>(k, dgn, idn, lane);
-  MP_T(3);
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int pos = lane + kWave * r;
-    if (pos < k) {
-      perm[pos]      = (unsigned char)idn[r];
-      iperm[idn[r]] = pos;
-    }
-  }
-  for (int e = lane; e < tsz; e += kWave) T[e] = 0.0;
-  wave_lds_fence();
-  bool fin = true;
-  {
-    const float rn = 1.0f / (float)n, rm = 1.0f / (float)m;
-    mstream<kFillU>(P, n * n, lane, [&](const int e, const double pv) {  // upper entries (a, bb), a < bb, of P: ((c sx_a) P_ab) sx_b
-      const int bb = (int)(((float)e + 0.5f) * rn), a = e - bb * n;
-      if (a < bb) {
-        const double v = c * SX[a] * pv * SX[bb];
-        const int ra = iperm[a], rb = iperm[bb];
-        T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
-        fin = fin && mfinite(v);
-      }
-    });
-    mstream<kFillU>(A, m * n, lane, [&](const int e, const double av) {  // (sy_i A_ij) sx_j
-      const int j = (int)(((float)e + 0.5f) * rm), i = e - j * m;
-      const double v = SY[i] * av * SX[j];
-      const int ra = iperm[n + i], rb = iperm[j];
-      T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
-      fin = fin && mfinite(v);
-    });
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int pos = lane + kWave * r;
-      if (pos < k) {
-        T[mtri(pos) + pos] = dgn[r];
-        fin = fin && mfinite(dgn[r]);
-      }
-    }
-    fin = !wave_ballot(!fin);
-  }
-  wave_lds_fence();
-
-  MP_T(4);
-  // ---- LDL' :428-433 ----
-  if (!mid_ldlt<R>(k, T, Dg, tmp, lane, fin)) ret_code = SFB_QP_UNKNOWN;
-  MP_T(5);
-
-  // ================= lane roles for the loop: rows lane, lane + 64 of the PERMUTED system =================
-  MidRow h[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int row = lane + kWave * r;
-    const bool in = row < k;
-    const int v   = in ? perm[row] : 0;
-    MidRow &w = h[r];
-    w.isx = in && v < n;
-    w.isc = in && v >= n;
-    w.xi  = w.isx ? v : 0;
-    w.ci  = w.isc ? v - n : 0;
-    w.sxv = w.isx ? SX[w.xi] : 1.0;
-    w.syv = w.isc ? SY[w.ci] : 1.0;
-    w.qc  = w.isx ? c * w.sxv * q[w.xi] : 0.0;  // (c sx_j) q_j of the right-hand side :450
-    const double li = w.isc ? l[w.ci] : 0.0, ui = w.isc ? u[w.ci] : 0.0;
-    double rho = 1.0;
-    if (w.isc) {
-      if (li == -inf && ui == inf) rho = 1e-6;
-      else if (w.syv * fabs(li - ui) < 1e-5) rho = 1e3 * kp.rho_bar;
-      else rho = kp.rho_bar;
-    }
-    w.rho  = rho;
-    w.rinv = 1.0 / rho;
-    w.lo   = w.isc ? w.syv * li : 0.0;
-    w.hi   = w.isc ? w.syv * ui : 0.0;
-    w.x = w.y = w.z = 0.0;
-  }
-  // ---- initial iterate :436-445 ----
-  if (g.wx != nullptr) {
-    const double *const wx = g.wx + b * (size_t)n, *const wy = g.wy + b * (size_t)m;
-    lds_d *const WX = tmp;  // the warm primal, broadcast operand of z = (Sy A) x_ws
-    for (int j = lane; j < n; j += kWave) WX[j] = wx[j];
-    wave_lds_fence();
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      MidRow &w = h[r];
-      if (w.isx) w.x = (1.0 / w.sxv) * wx[w.xi];
-      if (w.isc) {
-        w.y      = c * ((1.0 / w.syv) * wy[w.ci]);
-        double s = 0.0;
-        const double syv = w.syv;
-        mrun(A + w.ci, m, n, [&](int j, double a) { s = fma(syv * a, WX[j], s); });
-        w.z = s;
-      }
-    }
-    wave_lds_fence();
-  }
-
-  // ================= stopping check :574-644 on the un-scaled iterates in V =================
-  lds_d *const xus = V, *const dxus = V + n, *const yus = V + 2 * n, *const zus = yus + m, *const dyus = tmp;
-  auto stop_check = [&]() -> int {
-    // rows of the mat-vecs: constraint i = lane + 64 r (< m), variable j = lane + 64 r (< n); s = 0, inner index ascending, fma
-    int ci_[R], vj_[R];
-    bool con[R], var[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      ci_[r] = lane + kWave * r;  con[r] = ci_[r] < m;
-      vj_[r] = lane + kWave * r;  var[r] = vj_[r] < n;
-    }
-    auto mv_A2 = [&](const lds_d *v0, double (&o0)[R], const lds_d *v1, double (&o1)[R], const bool two) {  // A v0 (and A v1)
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        double s0 = 0.0, s1 = 0.0;
-        if (con[r]) {
-          if (two) mrun<16>(A + ci_[r], m, n, [&](int j, double a) { s0 = fma(a, v0[j], s0); s1 = fma(a, v1[j], s1); });
-          else mrun<16>(A + ci_[r], m, n, [&](int j, double a) { s0 = fma(a, v0[j], s0); });
-        }
-        o0[r] = s0;
-        o1[r] = s1;
-      }
-    };
-    auto mv_At = [&](const lds_d *v, double (&o)[R]) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        double s = 0.0;
-        if (var[r]) mrun<16>(A + (size_t)vj_[r] * m, 1, m, [&](int i, double a) { s = fma(a, v[i], s); });
-        o[r] = s;
-      }
-    };
-    auto mv_P = [&](const lds_d *v, double (&o)[R]) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        double s = 0.0;
-        if (var[r]) mrun<16>(P + vj_[r], n, n, [&](int j, double p) { s = fma(p, v[j], s); });
-        o[r] = s;
-      }
-    };
-    auto nrm = [&](const double (&v)[R], const bool (&on)[R]) {
-      double a = 0.0;
-#pragma unroll
-      for (int r = 0; r < R; ++r) a = fmax(a, on[r] ? fabs(v[r]) : 0.0);
-      return wave_max(a);
-    };
-    auto nrm_lds = [&](const lds_d *v, const int len) {
-      double a = 0.0;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int e = lane + kWave * r;
-        if (e < len) a = fmax(a, fabs(v[e]));
-      }
-      return wave_max(a);
-    };
-    double Ax[R], Adx[R];
-    mv_A2(xus, Ax, dxus, Adx, true);  // (A dx is needed by every check that does not end in Optimal / PrimalInfeasible: one pass over A for both)
-    // OPTIMALITY :584-594
-    {
-      const double Ax_norm = nrm(Ax, con);
-      double rs[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) rs[r] = con[r] ? Ax[r] - zus[ci_[r]] : 0.0;
-      if (nrm(rs, con) <= kp.eps_abs + kp.eps_rel * fmax(Ax_norm, nrm_lds(zus, m))) {
-        double Px[R], Aty[R], qv[R], res[R];
-        mv_P(xus, Px);
-        mv_At(yus, Aty);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          qv[r]  = var[r] ? q[vj_[r]] : 0.0;
-          res[r] = var[r] ? Px[r] + (qv[r] + Aty[r]) : 0.0;  // :592
-        }
-        const double dual_scale = fmax(fmax(nrm(Px, var), nrm(qv, var)), nrm(Aty, var));
-        if (nrm(res, var) <= kp.eps_abs + kp.eps_rel * dual_scale) return SFB_QP_OPTIMAL;
-      }
-    }
-    // PRIMAL INFEASIBILITY :598-621
-    {
-      double Aty[R];
-      mv_At(dyus, Aty);
-      const double Edy = nrm_lds(dyus, m);
-      const double thr = kp.eps_pinf * Edy;
-      // the ordered sum with its early exit to +inf: the oracle breaks at the first row with an unbounded side beyond the
-      // threshold and the sum becomes +inf, so only "any such row" matters; otherwise the sum is the ordered one (a skipped
-      // term adds +0.0, exact: the sum is never -0.0).  Terms go through xus / yus (dead after the optimality test).
-      lds_d *const tu = yus, *const tl = zus;
-      bool brk = false;
-      double ul_[R][2];
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        if (con[r]) {
-          const double ui = u[ci_[r]], li = l[ci_[r]], dyi = dyus[ci_[r]];
-          ul_[r][0] = (ui != inf) ? ui * fmax(0.0, dyi) : 0.0;
-          ul_[r][1] = (li != -inf) ? li * fmin(0.0, dyi) : 0.0;
-          brk = brk || (ui == inf && dyi > thr) || (li == -inf && dyi < -thr);
-        }
-      wave_lds_fence();
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        if (con[r]) {
-          tu[ci_[r]] = ul_[r][0];
-          tl[ci_[r]] = ul_[r][1];
-        }
-      wave_lds_fence();
-      double s = 0.0;
-      for (int i = 0; i < m; ++i) { s += tu[i]; s += tl[i]; }
-      if (wave_ballot(brk)) s = inf;
-      const double an = nrm(Aty, var);
-      if (((an < s) ? s : an) < thr) return SFB_QP_PRIMAL_INFEASIBLE;
-    }
-    // DUAL INFEASIBILITY :625-641
-    {
-      double Pdx[R];
-      mv_P(dxus, Pdx);
-      const double dxn = nrm_lds(dxus, n);
-      const double thr = kp.eps_dinf * dxn;
-      lds_d *const qs = xus;  // q next to dx for the ordered dot product
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        if (var[r]) qs[vj_[r]] = q[vj_[r]];
-      wave_lds_fence();
-      double qdx = 0.0;
-      for (int j = 0; j < n; ++j) qdx = fma(qs[j], dxus[j], qdx);
-      const bool ok = (nrm(Pdx, var) <= thr) && (qdx <= thr);
-      bool rowok    = true;
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        if (con[r]) {
-          const double ui = u[ci_[r]], li = l[ci_[r]];
-          if (ui == inf) rowok = rowok && (Adx[r] >= -thr);
-          else if (li == -inf) rowok = rowok && (Adx[r] <= thr);
-          else rowok = rowok && (fabs(Adx[r]) < thr);
-        }
-      if (ok && !wave_ballot(!rowok)) return SFB_QP_DUAL_INFEASIBLE;
-    }
-    return -1;
-  };
-
-  MP_T(6);
-  // ================= ADMM loop :447-510 =================
-  uint32_t iter        = 0;
   const uint32_t sci   = kp.stop_check_iter;
   const uint32_t maxit = kp.max_iter;
-  uint32_t next_chk    = (sci >= 2) ? 1u : 0xFFFFFFFFu;  // iter % sci == 1 (:465) without a division per iteration
-  auto rhs = [&](const MidRow &w) { return w.isx ? (kp.sigma * w.x - w.qc) : (w.isc ? (w.z - w.rinv * w.y) : 0.0); };  // :450-451
-  auto upd = [&](MidRow &w, const double t, const bool chk) {                                                              // :470-477
-    const double xo = w.x, yo = w.y;
-    w.x       = kp.alpha * t + kp.alpha_comp * w.x;
-    double zn = kp.alpha * (w.rinv * t) + kp.alpha_comp * (w.rinv * w.y) + w.z;
-    zn        = (zn < w.lo) ? w.lo : zn;
-    zn        = (w.hi < zn) ? w.hi : zn;
-    w.y       = kp.alpha_comp * w.y + kp.alpha * t + w.rho * w.z - w.rho * zn;
-    w.z       = zn;
-    if (chk) {  // :481-485
-      if (w.isx) {
-        xus[w.xi]  = w.sxv * w.x;
-        dxus[w.xi] = w.sxv * (w.x - xo);
-      }
-      if (w.isc) {
-        yus[w.ci]  = w.syv * w.y / c;
-        zus[w.ci]  = (1.0 / w.syv) * w.z;
-        dyus[w.ci] = w.syv * (w.y - yo) / c;
-      }
-    }
-  };
-  for (; iter != maxit && ret_code < 0; ++iter) {
-    rows::Pair t{rhs(h[0]), R > 1 ? rhs(h[R - 1]) : 0.0};
-    t = rows::row_sweeps_inl<NB, false>(k, (const double *)T, (const double *)Dg, t, lane);  // :462
-    const bool chk = (iter == next_chk);                                              // :465
-    if (chk) next_chk += sci;
-    upd(h[0], t.lo, chk);
-    if constexpr (R > 1) upd(h[R - 1], t.hi, chk);
-    if (chk) {
-      wave_lds_fence();
-      ret_code = stop_check();
-      if (ret_code < 0 && max_time_exceeded(kp.max_time_ns, t0_ticks)) ret_code = SFB_QP_MAX_TIME;  // :504-507
-      wave_lds_fence();
-    }
-  }
 
-  MP_T(7);
-  // ================= the end of solve() :515-548: V = [sx | sy | x | y | lists] in natural order =================
-  lds_d *const XS = V + k, *const YS = V + k + n;
-  wave_lds_fence();
+  // Launch shape.  queue == nullptr: one QP per workgroup, the hardware dispatcher is the work queue (batches that fit the
+  // chip at once).  Otherwise a PERSISTENT grid with a device-side queue, time-sliced like the k <= 32 kernel's: fresh QPs
+  // are handed out by a ticket counter; a QP that has held its wave for `slice` iterations while others are waiting
+  // saves its state (factor, permutation, iterate: MidSave) in its workspace and goes to the back of a ring of
+  // 2 * batch tagged entries, from where any wave resumes it -- the QPs that run into max_iter advance together
+  // instead of the last-started one running alone at the end.  Results do not depend on the launch shape.
+  unsigned *const q_fresh = queue, *const q_rhead = queue ? queue + 16 : nullptr, *const q_tail = queue ? queue + 32 : nullptr,
+                 *const q_done = queue ? queue + 48 : nullptr;
+  unsigned long long *const ring = queue ? reinterpret_cast<unsigned long long *>(queue + 64) : nullptr;
+  const unsigned ring_n = 2u * batch;
+  constexpr unsigned kNone = 0xFFFFFFFFu;
+  unsigned pend   = kNone;  // ring ticket this wave is waiting for
+  bool fresh_left = true;
+  for (;;) {
+    size_t b     = blockIdx.x;
+    bool resumed = false;
+    if (queue != nullptr) {
+      int item = -1;
+      if (pend == kNone) {
+        if (fresh_left) {
+          unsigned t = 0;
+          if (lane == 0) t = atomicAdd(q_fresh, 1u);
+          t = (unsigned)muni((int)t);
+          if (t < batch) item = (int)t;
+          else fresh_left = false;
+        }
+        if (item < 0) {
+          unsigned t = 0;
+          if (lane == 0) t = atomicAdd(q_rhead, 1u);
+          pend = (unsigned)muni((int)t);
+        }
+      }
+      if (item < 0) {
+        unsigned long long e = 0;
+        if (lane == 0) e = __hip_atomic_load(ring + (pend % ring_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned lo32 = (unsigned)muni((int)(unsigned)e), hi32 = (unsigned)muni((int)(unsigned)(e >> 32));
+        if (hi32 == pend + 1u) {  // my entry has arrived
+          if (lane == 0) __hip_atomic_store(ring + (pend % ring_n), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          item    = (int)(lo32 - 1u);
+          pend    = kNone;
+          resumed = true;
+          __threadfence();  // the state was written by another wave
+        } else {
+          unsigned d = 0;
+          if (lane == 0) d = __hip_atomic_load(q_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((unsigned)muni((int)d) >= batch) break;  // every QP has been reported
+          __builtin_amdgcn_s_sleep(16);
+          continue;
+        }
+      }
+      b = (size_t)item;
+    }
+    const double *const P = g.P + b * (size_t)n * n, *const q = g.q + b * (size_t)n, *const A = g.A + b * (size_t)m * n;
+    const double *const l = g.l + b * (size_t)m, *const u = g.u + b * (size_t)m;
+    double *const sv = gws ? gws + b * wsd : nullptr;  // MidSave of this QP: [T | D | per row: scale, x or y, z | perm (bytes) | header]
+    double *const sv_rows = sv ? sv + tsz + k : nullptr, *const sv_perm = sv ? sv_rows + 3 * k : nullptr, *const sv_hdr = sv ? sv_perm + (k + 7) / 8 : nullptr;
+    double c     = 1.0;
+    int ret_code = -1;
+    unsigned long long t0_ticks = 0;
+    MidRow h[R];
+    uint32_t iter     = 0;
+    uint32_t next_chk = (sci >= 2) ? 1u : 0xFFFFFFFFu;  // iter % sci == 1 (:465) without a division per iteration
+#ifdef SFB_MID_PROF
+    unsigned long long mp_t[12] = {};
+#endif
+    MP_T(0);
+    if (!resumed) {
+      // ================= setup: natural order, unit e = lane + 64 r: e < n variable e, else constraint e - n =================
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const MidRow &w = h[r];
-    if (w.isx) { SX[w.xi] = w.sxv; XS[w.xi] = w.x; }
-    if (w.isc) { SY[w.ci] = w.syv; YS[w.ci] = w.y; }
-  }
-  wave_lds_fence();
+      for (int r = 0; r < R; ++r) {  // analyze(): :306-308
+        const int e = lane + kWave * r;
+        if (e < k) V[e] = 1.0;
+      }
+      wave_lds_fence();
+      if (kp.scaling) {  // :673-730
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int e = lane + kWave * r;
+          if (e < n) {  // :681-690 column inf-norms of P
+            double t = 0.0;
+            mrun(P + (size_t)e * n, 1, n, [&](int, double p) { t = fmax(t, fabs(p)); });
+            if (t == 0.0) t = 1.0;
+            tmp[e] = t;
+          }
+        }
+        wave_lds_fence();
+        double sum = tmp[0];  // :693 mean(): sequential sum
+        for (int j = 1; j < n; ++j) sum += tmp[j];
+        double qv = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int e = lane + kWave * r;
+          if (e < n) qv = fmax(qv, fabs(q[e]));
+        }
+        const double qn = wave_max(qv);
+        c               = 1.0 / fmax(fmax(1e-6, sum / (double)n), qn);
+        wave_lds_fence();
+        int pass = 0;
+        double crit;
+        do {  // :698-729
+          double inc[R];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int e = lane + kWave * r;
+            double v    = 0.0;
+            if (e < n) {
+              const double sxc = SX[e];
+              mrun(P + (size_t)e * n, 1, n, [&](int row, double p) { v = fmax(v, fabs(c * SX[row] * sxc * p)); });  // :704-707
+              mrun(A + (size_t)e * m, 1, m, [&](int row, double a) { v = fmax(v, fabs(SY[row] * sxc * a)); });      // :712-714
+            } else if (e < k) {
+              const double syr = SY[e - n];
+              mrun(A + (e - n), m, n, [&](int col, double a) { v = fmax(v, fabs(syr * SX[col] * a)); });
+            }
+            if (v == 0.0) v = 1.0;
+            inc[r] = v;
+          }
+          wave_lds_fence();  // every lane has read the old sx / sy
+          double cm = 0.0;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int e = lane + kWave * r;
+            if (e < k) {
+              V[e] = sqrt(1.0 / fmax(inc[r], 1e-8)) * V[e];
+              cm   = fmax(cm, fabs(inc[r] - 1.0));
+            }
+          }
+          crit = wave_max(cm);
+          wave_lds_fence();
+        } while (pass++ < 10 && crit > 0.1);
+      }
 
-  // ---- polish :92-204 (on the scaled iterate; a failed factorisation leaves the ADMM solution) ----
-  if (ret_code == SFB_QP_OPTIMAL && kp.polish) {
-    const double eps = DBL_EPSILON;
-    lds_b *const colof = (lds_b *)(V + 2 * k);  // per constraint: its row n + a of the polish system, or 255
-    lds_b *const LU    = colof + m;             // row n + a -> constraint
-    // active sets: lower indices first, then upper, each ascending (:113-123)
-    int nl = 0, nu = 0;
-    int act[R], pos[R];
+      MP_T(1);
+      // ---- pre-check and rho :361-374, the diagonal of the KKT matrix :399-404 ----
+      double dgn[R];
+      int idn[R];
+      {
+        bool bad = false;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = lane + kWave * r;
-      int a       = 0;
-      if (i < m) {
-        const double yi = YS[i];
-        if (yi < -100 * eps && l[i] != -inf) a = 1;
-        if (yi > 100 * eps && u[i] != inf) a = 2;
-      }
-      const unsigned long long bl = wave_ballot(a == 1), bu = wave_ballot(a == 2);
-      act[r] = a;
-      pos[r] = (a == 1) ? nl + __popcll(bl & lanemask_lt(lane)) : nu + __popcll(bu & lanemask_lt(lane));
-      nl += __popcll(bl);
-      nu += __popcll(bu);
-    }
-    const int na = nl + nu, K = n + na;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = lane + kWave * r;
-      if (i < m) {
-        const int a = act[r] == 0 ? -1 : pos[r] + (act[r] == 2 ? nl : 0);
-        colof[i]    = (unsigned char)(a < 0 ? 255 : n + a);
-        if (a >= 0) LU[a] = (unsigned char)i;
-      }
-    }
-    wave_lds_fence();
-    // rows of the polish system: e = lane + 64 r < K: variable e, or active constraint LU[e - n]; h :179-182; diagonal of Hp :174-177
-    double hh[R], dgp[R];
-    int idp[R], prow[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int e = lane + kWave * r;
-      idp[r] = e;  hh[r] = 0.0;  dgp[r] = 0.0;  prow[r] = 0;
-      if (e < n) {
-        const double sxe = SX[e];
-        dgp[r] = c * sxe * P[(size_t)e * n + e] * sxe + kp.delta;
-        hh[r]  = -c * (sxe * q[e]);
-      } else if (e < K) {
-        const int row = LU[e - n];
-        prow[r]       = row;
-        dgp[r]        = 0.0 - kp.delta;
-        hh[r]         = (e - n < nl) ? SY[row] * l[row] : SY[row] * u[row];
-      }
-    }
-    mid_pivot_order<R>(K, dgp, idp, lane);
-    wave_lds_fence();
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int p = lane + kWave * r;
-      if (p < K) {
-        perm[p]        = (unsigned char)idp[r];
-        iperm[idp[r]] = p;
-      }
-    }
-    const int tszp = (K * (K + 1)) / 2 + kMidPadT;
-    for (int e = lane; e < tszp; e += kWave) T[e] = 0.0;
-    wave_lds_fence();
-    bool finp = true;
-    {
-      const float rn = 1.0f / (float)n, rm = 1.0f / (float)m;
-      mstream<kFillU>(P, n * n, lane, [&](const int e, const double pv) {
-        const int bb = (int)(((float)e + 0.5f) * rn), a = e - bb * n;
-        if (a < bb) {
-          const double v = c * SX[a] * pv * SX[bb];  // :161
-          const int ra = iperm[a], rb = iperm[bb];
-          T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
-          finp = finp && mfinite(v);
+        for (int r = 0; r < R; ++r) {
+          const int e = lane + kWave * r;
+          idn[r]      = e;
+          dgn[r]      = 0.0;
+          if (e < n) {
+            const double sxe = SX[e];
+            dgn[r]           = c * sxe * P[(size_t)e * n + e] * sxe + kp.sigma;
+          } else if (e < k) {
+            const double li = l[e - n], ui = u[e - n];
+            bad = bad || (li == inf) || (ui == -inf) || (ui - li < 0.0);
+            double rho;
+            if (li == -inf && ui == inf) rho = 1e-6;
+            else if (SY[e - n] * fabs(li - ui) < 1e-5) rho = 1e3 * kp.rho_bar;
+            else rho = kp.rho_bar;
+            dgn[r] = 1.0 / (-rho);
+          }
         }
-      });
-      mstream<kFillU>(A, m * n, lane, [&](const int e, const double av) {
-        const int j = (int)(((float)e + 0.5f) * rm), i = e - j * m;
-        const int col = colof[i];
-        if (col != 255) {
-          const double v = SY[i] * av * SX[j];  // :163
-          const int ra = iperm[col], rb = iperm[j];
-          T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
-          finp = finp && mfinite(v);
+        if (wave_ballot(bad)) ret_code = SFB_QP_PRIMAL_INFEASIBLE;
+      }
+      t0_ticks = wall_clock64();  // :376
+
+      // ---- Eigen's pivot order (from the diagonal), then the KKT matrix straight into its final positions ----
+      MP_T(2);
+      mid_pivot_order<R>(k, dgn, idn, lane);
+      MP_T(3);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int pos = lane + kWave * r;
+        if (pos < k) {
+          perm[pos]      = (unsigned char)idn[r];
+          iperm[idn[r]] = pos;
         }
-      });
+      }
+      for (int e = lane; e < tsz; e += kWave) T[e] = 0.0;
+      wave_lds_fence();
+      bool fin = true;
+      {
+        const float rn = 1.0f / (float)n, rm = 1.0f / (float)m;
+        mstream<kFillU>(P, n * n, lane, [&](const int e, const double pv) {  // upper entries (a, bb), a < bb, of P: ((c sx_a) P_ab) sx_b
+          const int bb = (int)(((float)e + 0.5f) * rn), a = e - bb * n;
+          if (a < bb) {
+            const double v = c * SX[a] * pv * SX[bb];
+            const int ra = iperm[a], rb = iperm[bb];
+            T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
+            fin = fin && mfinite(v);
+          }
+        });
+        mstream<kFillU>(A, m * n, lane, [&](const int e, const double av) {  // (sy_i A_ij) sx_j
+          const int j = (int)(((float)e + 0.5f) * rm), i = e - j * m;
+          const double v = SY[i] * av * SX[j];
+          const int ra = iperm[n + i], rb = iperm[j];
+          T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
+          fin = fin && mfinite(v);
+        });
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int pos = lane + kWave * r;
+          if (pos < k) {
+            T[mtri(pos) + pos] = dgn[r];
+            fin = fin && mfinite(dgn[r]);
+          }
+        }
+        fin = !wave_ballot(!fin);
+      }
+      wave_lds_fence();
+
+      MP_T(4);
+      // ---- LDL' :428-433 ----
+      if (!mid_ldlt<R>(k, T, Dg, tmp, lane, fin)) ret_code = SFB_QP_UNKNOWN;
+      MP_T(5);
+
+      // ================= lane roles for the loop: rows lane, lane + 64 of the PERMUTED system =================
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int row = lane + kWave * r;
+        const bool in = row < k;
+        const int v   = in ? perm[row] : 0;
+        MidRow &w = h[r];
+        w.isx = in && v < n;
+        w.isc = in && v >= n;
+        w.xi  = w.isx ? v : 0;
+        w.ci  = w.isc ? v - n : 0;
+        w.sxv = w.isx ? SX[w.xi] : 1.0;
+        w.syv = w.isc ? SY[w.ci] : 1.0;
+        w.qc  = w.isx ? c * w.sxv * q[w.xi] : 0.0;  // (c sx_j) q_j of the right-hand side :450
+        const double li = w.isc ? l[w.ci] : 0.0, ui = w.isc ? u[w.ci] : 0.0;
+        double rho = 1.0;
+        if (w.isc) {
+          if (li == -inf && ui == inf) rho = 1e-6;
+          else if (w.syv * fabs(li - ui) < 1e-5) rho = 1e3 * kp.rho_bar;
+          else rho = kp.rho_bar;
+        }
+        w.rho  = rho;
+        w.rinv = 1.0 / rho;
+        w.lo   = w.isc ? w.syv * li : 0.0;
+        w.hi   = w.isc ? w.syv * ui : 0.0;
+        w.x = w.y = w.z = 0.0;
+      }
+      // ---- initial iterate :436-445 ----
+      if (g.wx != nullptr) {
+        const double *const wx = g.wx + b * (size_t)n, *const wy = g.wy + b * (size_t)m;
+        lds_d *const WX = tmp;  // the warm primal, broadcast operand of z = (Sy A) x_ws
+        for (int j = lane; j < n; j += kWave) WX[j] = wx[j];
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          MidRow &w = h[r];
+          if (w.isx) w.x = (1.0 / w.sxv) * wx[w.xi];
+          if (w.isc) {
+            w.y      = c * ((1.0 / w.syv) * wy[w.ci]);
+            double s = 0.0;
+            const double syv = w.syv;
+            mrun(A + w.ci, m, n, [&](int j, double a) { s = fma(syv * a, WX[j], s); });
+            w.z = s;
+          }
+        }
+        wave_lds_fence();
+      }
+
+    } else {
+      // ---- resume: factor, permutation and the rows' state come back from the workspace; the rows' constants are
+      //      recomputed from the same expressions (they are functions of the saved scale factors and the problem data) ----
+      for (int e = lane; e < tsz; e += kWave) T[e] = sv[e];
+      for (int e = lane; e < k; e += kWave) Dg[e] = sv[tsz + e];
+      const unsigned char *const pb = reinterpret_cast<const unsigned char *>(sv_perm);
+      for (int e = lane; e < k; e += kWave) perm[e] = pb[e];
+      c        = sv_hdr[0];
+      iter     = (uint32_t)sv_hdr[1];
+      next_chk = (uint32_t)sv_hdr[2];
+      t0_ticks = (unsigned long long)__double_as_longlong(sv_hdr[3]);
+      wave_lds_fence();
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int row = lane + kWave * r;
+        const bool in = row < k;
+        const int v   = in ? perm[row] : 0;
+        MidRow &w = h[r];
+        w.isx = in && v < n;
+        w.isc = in && v >= n;
+        w.xi  = w.isx ? v : 0;
+        w.ci  = w.isc ? v - n : 0;
+        const double sc = in ? sv_rows[3 * row] : 1.0, a0 = in ? sv_rows[3 * row + 1] : 0.0, a1 = in ? sv_rows[3 * row + 2] : 0.0;
+        w.sxv = w.isx ? sc : 1.0;
+        w.syv = w.isc ? sc : 1.0;
+        w.qc  = w.isx ? c * w.sxv * q[w.xi] : 0.0;
+        const double li = w.isc ? l[w.ci] : 0.0, ui = w.isc ? u[w.ci] : 0.0;
+        double rho = 1.0;
+        if (w.isc) {
+          if (li == -inf && ui == inf) rho = 1e-6;
+          else if (w.syv * fabs(li - ui) < 1e-5) rho = 1e3 * kp.rho_bar;
+          else rho = kp.rho_bar;
+        }
+        w.rho  = rho;
+        w.rinv = 1.0 / rho;
+        w.lo   = w.isc ? w.syv * li : 0.0;
+        w.hi   = w.isc ? w.syv * ui : 0.0;
+        w.x = w.isx ? a0 : 0.0;
+        w.y = w.isc ? a0 : 0.0;
+        w.z = w.isc ? a1 : 0.0;
+      }
+    }
+    // ================= stopping check :574-644 on the un-scaled iterates in V =================
+    lds_d *const xus = V, *const dxus = V + n, *const yus = V + 2 * n, *const zus = yus + m, *const dyus = tmp;
+
+    MP_T(6);
+    // ================= ADMM loop :447-510 =================
+    auto rhs = [&](const MidRow &w) { return w.isx ? (kp.sigma * w.x - w.qc) : (w.isc ? (w.z - w.rinv * w.y) : 0.0); };  // :450-451
+    auto upd = [&](MidRow &w, const double t, const bool chk) {                                                              // :470-477
+      const double xo = w.x, yo = w.y;
+      w.x       = kp.alpha * t + kp.alpha_comp * w.x;
+      double zn = kp.alpha * (w.rinv * t) + kp.alpha_comp * (w.rinv * w.y) + w.z;
+      zn        = (zn < w.lo) ? w.lo : zn;
+      zn        = (w.hi < zn) ? w.hi : zn;
+      w.y       = kp.alpha_comp * w.y + kp.alpha * t + w.rho * w.z - w.rho * zn;
+      w.z       = zn;
+      if (chk) {  // :481-485
+        if (w.isx) {
+          xus[w.xi]  = w.sxv * w.x;
+          dxus[w.xi] = w.sxv * (w.x - xo);
+        }
+        if (w.isc) {
+          yus[w.ci]  = w.syv * w.y / c;
+          zus[w.ci]  = (1.0 / w.syv) * w.z;
+          dyus[w.ci] = w.syv * (w.y - yo) / c;
+        }
+      }
+    };
+    const rows::Masks masks = rows::make_masks();  // (once, in front of the loop: see sweep_rows.h)
+    uint32_t it0   = iter;  // iteration at which this wave took the QP
+    bool suspended = false;
+    for (; iter != maxit && ret_code < 0; ++iter) {
+      if (queue != nullptr && iter - it0 >= slice) {  // the slice is used up: hand the QP back if others are waiting
+        unsigned waiting = 0;
+        if (lane == 0) {
+          const unsigned fr = __hip_atomic_load(q_fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned hd = __hip_atomic_load(q_rhead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned tl = __hip_atomic_load(q_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          waiting = (fr < batch || (int)(tl - hd) > 0) ? 1u : 0u;
+        }
+        if (muni((int)waiting)) {
+          suspended = true;
+          break;
+        }
+        it0 = iter;  // nobody waits: a fresh slice
+      }
+      rows::Pair t{rhs(h[0]), R > 1 ? rhs(h[R - 1]) : 0.0};
+      t = rows::row_sweeps_inl<NB, false>(k, (const double *)T, (const double *)Dg, t, lane, masks);  // :462
+      const bool chk = (iter == next_chk);                                              // :465
+      if (chk) next_chk += sci;
+      upd(h[0], t.lo, chk);
+      if constexpr (R > 1) upd(h[R - 1], t.hi, chk);
+      if (chk) {
+        wave_lds_fence();
+        ret_code = mid_stop_check<R>(n, m, lane, P, q, A, l, u, V, tmp, kp.eps_abs, kp.eps_rel, kp.eps_pinf, kp.eps_dinf);
+        if (ret_code < 0 && max_time_exceeded(kp.max_time_ns, t0_ticks)) ret_code = SFB_QP_MAX_TIME;  // :504-507
+        wave_lds_fence();
+      }
+    }
+
+    if (suspended) {
+      wave_lds_fence();
+      for (int e = lane; e < tsz; e += kWave) sv[e] = T[e];
+      for (int e = lane; e < k; e += kWave) sv[tsz + e] = Dg[e];
+      unsigned char *const pb = reinterpret_cast<unsigned char *>(sv_perm);
+      for (int e = lane; e < k; e += kWave) pb[e] = perm[e];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int row = lane + kWave * r;
+        if (row < k) {
+          const MidRow &w = h[r];
+          sv_rows[3 * row]     = w.isx ? w.sxv : w.syv;
+          sv_rows[3 * row + 1] = w.isx ? w.x : w.y;
+          sv_rows[3 * row + 2] = w.z;
+        }
+      }
+      if (lane == 0) {
+        sv_hdr[0] = c;
+        sv_hdr[1] = (double)iter;
+        sv_hdr[2] = (double)next_chk;
+        sv_hdr[3] = __longlong_as_double((long long)t0_ticks);
+      }
+      __threadfence();  // the state is complete (device scope) before the id can be popped
+      if (lane == 0) {
+        const unsigned j           = atomicAdd(q_tail, 1u);
+        unsigned long long *slot   = ring + (j % ring_n);
+        const unsigned long long v = ((unsigned long long)(j + 1u) << 32) | ((unsigned)b + 1u);
+        while (atomicCAS(slot, 0ull, v) != 0ull) __builtin_amdgcn_s_sleep(1);
+      }
+      continue;
+    }
+
+    MP_T(7);
+    // ================= the end of solve() :515-548: V = [sx | sy | x | y | lists] in natural order =================
+    lds_d *const XS = V + k, *const YS = V + k + n;
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const MidRow &w = h[r];
+      if (w.isx) { SX[w.xi] = w.sxv; XS[w.xi] = w.x; }
+      if (w.isc) { SY[w.ci] = w.syv; YS[w.ci] = w.y; }
+    }
+    wave_lds_fence();
+
+    // ---- polish :92-204 (on the scaled iterate; a failed factorisation leaves the ADMM solution) ----
+    if (ret_code == SFB_QP_OPTIMAL && kp.polish) {
+      const double eps = DBL_EPSILON;
+      lds_b *const colof = (lds_b *)(V + 2 * k);  // per constraint: its row n + a of the polish system, or 255
+      lds_b *const LU    = colof + m;             // row n + a -> constraint
+      // active sets: lower indices first, then upper, each ascending (:113-123)
+      int nl = 0, nu = 0;
+      int act[R], pos[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int i = lane + kWave * r;
+        int a       = 0;
+        if (i < m) {
+          const double yi = YS[i];
+          if (yi < -100 * eps && l[i] != -inf) a = 1;
+          if (yi > 100 * eps && u[i] != inf) a = 2;
+        }
+        const unsigned long long bl = wave_ballot(a == 1), bu = wave_ballot(a == 2);
+        act[r] = a;
+        pos[r] = (a == 1) ? nl + __popcll(bl & lanemask_lt(lane)) : nu + __popcll(bu & lanemask_lt(lane));
+        nl += __popcll(bl);
+        nu += __popcll(bu);
+      }
+      const int na = nl + nu, K = n + na;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int i = lane + kWave * r;
+        if (i < m) {
+          const int a = act[r] == 0 ? -1 : pos[r] + (act[r] == 2 ? nl : 0);
+          colof[i]    = (unsigned char)(a < 0 ? 255 : n + a);
+          if (a >= 0) LU[a] = (unsigned char)i;
+        }
+      }
+      wave_lds_fence();
+      // rows of the polish system: e = lane + 64 r < K: variable e, or active constraint LU[e - n]; h :179-182; diagonal of Hp :174-177
+      double hh[R], dgp[R];
+      int idp[R], prow[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int e = lane + kWave * r;
+        idp[r] = e;  hh[r] = 0.0;  dgp[r] = 0.0;  prow[r] = 0;
+        if (e < n) {
+          const double sxe = SX[e];
+          dgp[r] = c * sxe * P[(size_t)e * n + e] * sxe + kp.delta;
+          hh[r]  = -c * (sxe * q[e]);
+        } else if (e < K) {
+          const int row = LU[e - n];
+          prow[r]       = row;
+          dgp[r]        = 0.0 - kp.delta;
+          hh[r]         = (e - n < nl) ? SY[row] * l[row] : SY[row] * u[row];
+        }
+      }
+      mid_pivot_order<R>(K, dgp, idp, lane);
+      wave_lds_fence();
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int p = lane + kWave * r;
         if (p < K) {
-          T[mtri(p) + p] = dgp[r];
-          finp = finp && mfinite(dgp[r]);
+          perm[p]        = (unsigned char)idp[r];
+          iperm[idp[r]] = p;
         }
       }
-      finp = !wave_ballot(!finp);
-    }
-    wave_lds_fence();
-    if (mid_ldlt<R>(K, T, Dg, tmp, lane, finp)) {  // :187-190
-      double tt[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) tt[r] = 0.0;
-      lds_d *const tv = tmp;
-      for (uint32_t it = 0; it != kp.polish_iter; ++it) {  // :193-195  t += Hp^-1 (h - H t); the entries of H are recomputed (same products)
-        bool tfin = true;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int e = lane + kWave * r;
-          if (e < K) tv[e] = tt[r];
-          tfin = tfin && mfinite(tt[r]);
-        }
-        tfin = !wave_ballot(!tfin);
-        wave_lds_fence();
-        double res[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int e = lane + kWave * r;
-          double acc  = 0.0;
-          if (e < n) {
-            const double sxr = SX[e];
-            // upper entry (a, bb) of P: (j, e) for j < e -- column e, contiguous -- then (e, j) for j >= e -- row e, stride n
-            mrun(P + (size_t)e * n, 1, e, [&](int j, double p) { acc = fma(c * SX[j] * p * sxr, tv[j], acc); });
-            mrun(P + e + (size_t)e * n, n, n - e, [&](int d, double p) { acc = fma(c * sxr * p * SX[e + d], tv[e + d], acc); });
-            for (int a0 = 0; a0 < na; a0 += 8) {  // the active rows' entries of column e, eight at a time
-              int row[8];
-              double av[8];
-#pragma unroll
-              for (int uu = 0; uu < 8; ++uu) row[uu] = (a0 + uu < na) ? LU[a0 + uu] : 0;
-#pragma unroll
-              for (int uu = 0; uu < 8; ++uu) av[uu] = A[row[uu] + (size_t)e * m];
-#pragma unroll
-              for (int uu = 0; uu < 8; ++uu)
-                if (a0 + uu < na) acc = fma(SY[row[uu]] * av[uu] * sxr, tv[n + a0 + uu], acc);
-            }
-          } else if (e < K) {
-            const double syr = SY[prow[r]];
-            mrun(A + prow[r], m, n, [&](int j, double av) { acc = fma(syr * av * SX[j], tv[j], acc); });
-            // the zero (2,2) block of H: fma(0, t_j, acc) leaves acc unchanged for finite t_j (acc is never -0)
-            if (!tfin)
-              for (int j = n; j < K; ++j) acc = fma(0.0, tv[j], acc);
+      const int tszp = (K * (K + 1)) / 2 + kMidPadT;
+      for (int e = lane; e < tszp; e += kWave) T[e] = 0.0;
+      wave_lds_fence();
+      bool finp = true;
+      {
+        const float rn = 1.0f / (float)n, rm = 1.0f / (float)m;
+        mstream<kFillU>(P, n * n, lane, [&](const int e, const double pv) {
+          const int bb = (int)(((float)e + 0.5f) * rn), a = e - bb * n;
+          if (a < bb) {
+            const double v = c * SX[a] * pv * SX[bb];  // :161
+            const int ra = iperm[a], rb = iperm[bb];
+            T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
+            finp = finp && mfinite(v);
           }
-          res[r] = hh[r] - acc;
-        }
-        wave_lds_fence();
-        // oracle_ldlt_solve: P b -> sweeps -> P^T, through the exchange vector
+        });
+        mstream<kFillU>(A, m * n, lane, [&](const int e, const double av) {
+          const int j = (int)(((float)e + 0.5f) * rm), i = e - j * m;
+          const int col = colof[i];
+          if (col != 255) {
+            const double v = SY[i] * av * SX[j];  // :163
+            const int ra = iperm[col], rb = iperm[j];
+            T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
+            finp = finp && mfinite(v);
+          }
+        });
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const int e = lane + kWave * r;
-          if (e < K) tv[e] = res[r];
+          const int p = lane + kWave * r;
+          if (p < K) {
+            T[mtri(p) + p] = dgp[r];
+            finp = finp && mfinite(dgp[r]);
+          }
         }
-        wave_lds_fence();
-        rows::Pair pr{0.0, 0.0};
-        {
-          const int p0 = lane, p1 = lane + kWave;
-          if (p0 < K) pr.lo = tv[perm[p0]];
-          if (R > 1 && p1 < K) pr.hi = tv[perm[p1]];
-        }
-        wave_lds_fence();
-        pr = rows::row_sweeps<NB>(K, (const double *)T, (const double *)Dg, pr, lane);
-        {
-          const int p0 = lane, p1 = lane + kWave;
-          if (p0 < K) tv[perm[p0]] = pr.lo;
-          if (R > 1 && p1 < K) tv[perm[p1]] = pr.hi;
-        }
-        wave_lds_fence();
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int e = lane + kWave * r;
-          if (e < K) tt[r] += tv[e];
-        }
-        wave_lds_fence();
+        finp = !wave_ballot(!finp);
       }
+      wave_lds_fence();
+      if (mid_ldlt<R>(K, T, Dg, tmp, lane, finp)) {  // :187-190
+        double tt[R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {  // :199-201
-        const int e = lane + kWave * r;
-        if (e < n) XS[e] = tt[r];
-        else if (e < K) YS[prow[r]] = tt[r];
+        for (int r = 0; r < R; ++r) tt[r] = 0.0;
+        lds_d *const tv = tmp;
+        for (uint32_t it = 0; it != kp.polish_iter; ++it) {  // :193-195  t += Hp^-1 (h - H t); the entries of H are recomputed (same products)
+          bool tfin = true;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int e = lane + kWave * r;
+            if (e < K) tv[e] = tt[r];
+            tfin = tfin && mfinite(tt[r]);
+          }
+          tfin = !wave_ballot(!tfin);
+          wave_lds_fence();
+          double res[R];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int e = lane + kWave * r;
+            double acc  = 0.0;
+            if (e < n) {
+              const double sxr = SX[e];
+              // upper entry (a, bb) of P: (j, e) for j < e -- column e, contiguous -- then (e, j) for j >= e -- row e, stride n
+              mrun(P + (size_t)e * n, 1, e, [&](int j, double p) { acc = fma(c * SX[j] * p * sxr, tv[j], acc); });
+              mrun(P + e + (size_t)e * n, n, n - e, [&](int d, double p) { acc = fma(c * sxr * p * SX[e + d], tv[e + d], acc); });
+              for (int a0 = 0; a0 < na; a0 += 8) {  // the active rows' entries of column e, eight at a time
+                int row[8];
+                double av[8];
+#pragma unroll
+                for (int uu = 0; uu < 8; ++uu) row[uu] = (a0 + uu < na) ? LU[a0 + uu] : 0;
+#pragma unroll
+                for (int uu = 0; uu < 8; ++uu) av[uu] = A[row[uu] + (size_t)e * m];
+#pragma unroll
+                for (int uu = 0; uu < 8; ++uu)
+                  if (a0 + uu < na) acc = fma(SY[row[uu]] * av[uu] * sxr, tv[n + a0 + uu], acc);
+              }
+            } else if (e < K) {
+              const double syr = SY[prow[r]];
+              mrun(A + prow[r], m, n, [&](int j, double av) { acc = fma(syr * av * SX[j], tv[j], acc); });
+              // the zero (2,2) block of H: fma(0, t_j, acc) leaves acc unchanged for finite t_j (acc is never -0)
+              if (!tfin)
+                for (int j = n; j < K; ++j) acc = fma(0.0, tv[j], acc);
+            }
+            res[r] = hh[r] - acc;
+          }
+          wave_lds_fence();
+          // oracle_ldlt_solve: P b -> sweeps -> P^T, through the exchange vector
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int e = lane + kWave * r;
+            if (e < K) tv[e] = res[r];
+          }
+          wave_lds_fence();
+          rows::Pair pr{0.0, 0.0};
+          {
+            const int p0 = lane, p1 = lane + kWave;
+            if (p0 < K) pr.lo = tv[perm[p0]];
+            if (R > 1 && p1 < K) pr.hi = tv[perm[p1]];
+          }
+          wave_lds_fence();
+          pr = rows::row_sweeps<NB>(K, (const double *)T, (const double *)Dg, pr, lane);
+          {
+            const int p0 = lane, p1 = lane + kWave;
+            if (p0 < K) tv[perm[p0]] = pr.lo;
+            if (R > 1 && p1 < K) tv[perm[p1]] = pr.hi;
+          }
+          wave_lds_fence();
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int e = lane + kWave * r;
+            if (e < K) tt[r] += tv[e];
+          }
+          wave_lds_fence();
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {  // :199-201
+          const int e = lane + kWave * r;
+          if (e < n) XS[e] = tt[r];
+          else if (e < K) YS[prow[r]] = tt[r];
+        }
       }
+      wave_lds_fence();
     }
-    wave_lds_fence();
-  }
 
-  MP_T(8);
-  // ---- un-scale and report :544-548 ----
-  double *const ox = g.x + b * (size_t)n, *const oy = g.y + b * (size_t)m;
-  lds_d *const xo = tmp, *const pv = Dg;  // (both dead by now)
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int e = lane + kWave * r;
-    if (e < n) {
-      const double v = SX[e] * XS[e];
-      ox[e] = v;
-      xo[e] = v;
-    }
-    if (e < m) oy[e] = SY[e] * YS[e] / c;
-  }
-  wave_lds_fence();
-  if (g.obj != nullptr) {
+    MP_T(8);
+    // ---- un-scale and report :544-548 ----
+    double *const ox = g.x + b * (size_t)n, *const oy = g.y + b * (size_t)m;
+    lds_d *const xo = tmp, *const pv = Dg;  // (both dead by now)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int e = lane + kWave * r;
       if (e < n) {
-        double s = 0.0;
-        mrun(P + e, n, n, [&](int j, double p) { s = fma(0.5 * p, xo[j], s); });
-        pv[e] = s + q[e];
+        const double v = SX[e] * XS[e];
+        ox[e] = v;
+        xo[e] = v;
       }
+      if (e < m) oy[e] = SY[e] * YS[e] / c;
     }
     wave_lds_fence();
-    if (lane == 0) {
-      double o = 0.0;
-      for (int i = 0; i < n; ++i) o = fma(xo[i], pv[i], o);
-      g.obj[b] = o;
+    if (g.obj != nullptr) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int e = lane + kWave * r;
+        if (e < n) {
+          double s = 0.0;
+          mrun(P + e, n, n, [&](int j, double p) { s = fma(0.5 * p, xo[j], s); });
+          pv[e] = s + q[e];
+        }
+      }
+      wave_lds_fence();
+      if (lane == 0) {
+        double o = 0.0;
+        for (int i = 0; i < n; ++i) o = fma(xo[i], pv[i], o);
+        g.obj[b] = o;
+      }
     }
-  }
-  if (lane == 0) {
-    g.code[b] = (ret_code >= 0) ? ret_code : SFB_QP_MAX_ITERATIONS;
-    if (g.iter != nullptr) g.iter[b] = iter;
-  }
+    if (lane == 0) {
+      g.code[b] = (ret_code >= 0) ? ret_code : SFB_QP_MAX_ITERATIONS;
+      if (g.iter != nullptr) g.iter[b] = iter;
+    }
 #ifdef SFB_MID_PROF
-  MP_T(9);
-  if (lane == 0 && blockIdx.x == 0)
-    printf("midprof (%d,%d) x10ns: scale %llu | rho+diag %llu | pivot order %llu | zero+fill %llu | ldlt %llu | roles+warm %llu | loop %llu (%u iterations) | polish %llu | report %llu\n",
-           n, m, mp_t[1] - mp_t[0], mp_t[2] - mp_t[1], mp_t[3] - mp_t[2], mp_t[4] - mp_t[3], mp_t[5] - mp_t[4], mp_t[6] - mp_t[5], mp_t[7] - mp_t[6], iter,
-           mp_t[8] - mp_t[7], mp_t[9] - mp_t[8]);
+    MP_T(9);
+    if (lane == 0 && blockIdx.x == 0)
+      printf("midprof (%d,%d) x10ns: scale %llu | rho+diag %llu | pivot order %llu | zero+fill %llu | ldlt %llu | roles+warm %llu | loop %llu (%u iterations) | polish %llu | report %llu\n",
+             n, m, mp_t[1] - mp_t[0], mp_t[2] - mp_t[1], mp_t[3] - mp_t[2], mp_t[4] - mp_t[3], mp_t[5] - mp_t[4], mp_t[6] - mp_t[5], mp_t[7] - mp_t[6], iter,
+             mp_t[8] - mp_t[7], mp_t[9] - mp_t[8]);
 #endif
+    if (queue == nullptr) break;
+    if (lane == 0) atomicAdd(q_done, 1u);
+  }
 }
 
 }  // namespace
@@ -958,22 +1175,111 @@ bool qp_dense_mid_enabled()
 
 size_t qp_dense_mid_lds_bytes(int n, int m) { return (size_t)mid_layout(n, m).total * sizeof(double); }
 
-hipError_t qp_dense_mid_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream)
+namespace {
+template<int NBV, int W>
+hipError_t mid_resident_one(const size_t lds, int *resident)  // waves of this instance the device holds at once (LDS / VGPR limits)
 {
-  const int k = kp.n + kp.m;
-  if (k > kDenseMidMaxK || k < 1) return hipErrorInvalidValue;
+  int per_cu = 0, dev = 0;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qp_dense_mid_kernel<NBV, W>, kWave, lds);
+  if (e != hipSuccess) return e;
+  hipDeviceProp_t prop;
+  e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+  if (e != hipSuccess) return e;
+  *resident = per_cu * prop.multiProcessorCount;
+  return hipSuccess;
+}
+// grid = number of workgroups; batch_q = items behind the queue (0: one per workgroup)
+hipError_t mid_dispatch(const DenseKernelParams &kp, const QpBatch &g, const unsigned grid, const unsigned batch_q, double *ws, const size_t wsd,
+                        unsigned *queue, const uint32_t slice, int *resident, hipStream_t stream)
+{
+  const int k = kp.n + kp.m, nb = (k + 15) / 16;
   const size_t lds = qp_dense_mid_lds_bytes(kp.n, kp.m);
-  const dim3 grid((unsigned)batch), block(kWave);
-  const int nb = (k + 15) / 16;
-#define SFB_MID(NBV, W) hipLaunchKernelGGL((qp_dense_mid_kernel<NBV, W>), grid, block, lds, stream, kp, g)
-  if (nb <= 3) SFB_MID(3, 4);
-  else if (nb == 4) SFB_MID(4, 3);
+#define SFB_MID(NBV, W)                                                                                                               \
+  do {                                                                                                                                \
+    if (resident != nullptr) return mid_resident_one<NBV, W>(lds, resident);                                                          \
+    hipLaunchKernelGGL((qp_dense_mid_kernel<NBV, W>), dim3(grid), dim3(kWave), lds, stream, kp, g, ws, wsd, queue, batch_q, slice); \
+    return hipGetLastError();                                                                                                         \
+  } while (0)
+  if (nb <= 3) SFB_MID(3, SFB_MID_W3);
+  else if (nb == 4) SFB_MID(4, SFB_MID_W4);
   else if (nb == 5) SFB_MID(5, 2);
   else if (nb == 6) SFB_MID(6, 1);
   else if (nb == 7) SFB_MID(7, 1);
   else SFB_MID(8, 1);
 #undef SFB_MID
-  return hipGetLastError();
+}
+size_t mid_save_doubles(int n, int m)
+{
+  const size_t k = (size_t)n + m;
+  return (k * (k + 1)) / 2 + kMidPadT + k + 3 * k + (k + 7) / 8 + 4;  // MidSave: [T | D | rows | perm | header]
+}
+// iterations a QP may hold its wave while others wait (SFB_MID_SLICE, in stopping-check intervals; 0 = never time-sliced)
+uint32_t mid_slice(const DenseKernelParams &kp)
+{
+  const char *const v = sfb::knob("SFB_MID_SLICE");  // (read per call: the tests change it)
+  const int checks    = v ? atoi(v) : 40;
+  if (checks <= 0) return 0;
+  return (uint32_t)checks * (kp.stop_check_iter >= 2 ? kp.stop_check_iter : 25u);
+}
+// waves of the kernel the current device holds at once (cached per device and shape class)
+int mid_resident(const DenseKernelParams &kp)
+{
+  const char *const v = sfb::knob("SFB_MID_GRID");  // tests: a tiny grid forces time slicing
+  const int forced    = v ? atoi(v) : 0;
+  if (forced > 0) return forced;
+  int r = 0;
+  if (mid_dispatch(kp, QpBatch{}, 0, 0, nullptr, 0, nullptr, 0, &r, nullptr) != hipSuccess) return 0;
+  return r;
+}
+}  // namespace
+
+// Device memory a launch needs beyond its arguments: nothing for a batch the chip holds at once (or with time slicing off);
+// otherwise one MidSave per QP and the queue.
+size_t qp_dense_mid_ws_bytes(const DenseKernelParams &kp, int64_t batch)
+{
+  if (mid_slice(kp) == 0) return 0;
+  const int res = mid_resident(kp);
+  if (res <= 0 || batch <= (int64_t)res) return 0;
+  return (size_t)batch * mid_save_doubles(kp.n, kp.m) * sizeof(double) + 256 + 2 * (size_t)batch * sizeof(unsigned long long);
+}
+
+hipError_t qp_dense_mid_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream, void *workspace)
+{
+  const int k = kp.n + kp.m;
+  if (k > kDenseMidMaxK || k < 1) return hipErrorInvalidValue;
+  const size_t need = qp_dense_mid_ws_bytes(kp, batch);
+  if (need == 0) return mid_dispatch(kp, g, (unsigned)batch, 0, nullptr, 0, nullptr, 0, nullptr, stream);
+  // persistent, time-sliced launch
+  char *buf        = static_cast<char *>(workspace);
+  bool async_alloc = true;
+  hipError_t e     = hipSuccess;
+  if (buf == nullptr) {
+    e = hipMallocAsync(reinterpret_cast<void **>(&buf), need, stream);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      async_alloc = false;
+      e           = hipMalloc(reinterpret_cast<void **>(&buf), need);
+      if (e != hipSuccess) return e;
+    }
+  }
+  const size_t wsd   = mid_save_doubles(kp.n, kp.m);
+  const size_t qoff  = (size_t)batch * wsd * sizeof(double);
+  unsigned *queue    = reinterpret_cast<unsigned *>(buf + qoff);
+  e = hipMemsetAsync(queue, 0, need - qoff, stream);
+  if (e == hipSuccess) {
+    const int res = mid_resident(kp);
+    e = mid_dispatch(kp, g, (unsigned)res, (unsigned)batch, reinterpret_cast<double *>(buf), wsd, queue, mid_slice(kp), nullptr, stream);
+  }
+  if (workspace == nullptr) {
+    if (async_alloc) {
+      (void)hipFreeAsync(buf, stream);
+    } else {
+      (void)hipStreamSynchronize(stream);
+      (void)hipFree(buf);
+    }
+  }
+  return e;
 }
 
 }  // namespace sfb

@@ -178,8 +178,28 @@ __device__ __forceinline__ void stage8(double &tp, double &tlo, double &thi, con
 // (pivot lane, LDS offsets, lane and row masks are immediates).  The operands of a half block (8 steps) are fetched
 // from LDS while the previous half block runs.  An instance serves every K <= 16 NB (half blocks beyond K are skipped
 // by one wave-uniform test each): the polish system of a QP goes through the instance of its ADMM loop.
+// The lane masks of the chain steps as opaque SGPR pairs (a 64-bit mask is no literal of s_mov_b64: the compiler would
+// otherwise build it from two 32-bit moves at every use).  A caller with a loop around the sweeps makes them ONCE in
+// front of it -- made inside, they are re-built and the registers they displace spilled and reloaded every iteration.
+struct Masks {
+  unsigned long long mk[16];  // mk[J] = lanes cc >= J of every 16-lane row, J = 1 .. 15; mk[0] = all
+  unsigned long long zero;
+};
+__device__ __forceinline__ Masks make_masks()
+{
+  Masks M;
+  M.mk[0] = ~0ull;
+  M.zero  = 0ull;
+  asm volatile("" : "+s"(M.mk[0]), "+s"(M.zero));
+  static_for<15>([&]<int J>(ic<J>) {
+    M.mk[J + 1] = mask_ge(J + 1);
+    asm volatile("" : "+s"(M.mk[J + 1]));
+  });
+  return M;
+}
+
 template<int NB, bool ANYK = true>  // ANYK: any K <= 16 NB; otherwise 16 (NB - 1) < K <= 16 NB (only the last block can be partial: no tests on the others)
-__device__ __forceinline__ Pair row_sweeps_inl(const int K_, const double *T_, const double *Dg_, Pair t, const int lane)
+__device__ __forceinline__ Pair row_sweeps_inl(const int K_, const double *T_, const double *Dg_, Pair t, const int lane, const Masks &M)
 {
   static_assert(NB >= 1 && NB <= 8, "k <= 128");
   constexpr int NQ = NB > 4 ? 2 : 1;
@@ -203,15 +223,8 @@ __device__ __forceinline__ Pair row_sweeps_inl(const int K_, const double *T_, c
     pch[JB]       = T + ((row < K) ? ((row * (row + 1)) >> 1) + 16 * JB : 0);
   });
   const lds_d *const pcc = T + cc;
-  // the lane masks of the chain steps, resident in SGPR pairs for the whole call
-  unsigned long long mk[16];  // mk[J] = lanes cc >= J, J = 1 .. 15
-  mk[0] = ~0ull;
-  unsigned long long mzero = 0ull;
-  asm volatile("" : "+s"(mk[0]), "+s"(mzero));
-  static_for<15>([&]<int J>(ic<J>) {
-    mk[J + 1] = mask_ge(J + 1);
-    asm volatile("" : "+s"(mk[J + 1]));
-  });
+  const unsigned long long(&mk)[16] = M.mk;  // the lane masks of the chain steps, resident in SGPR pairs
+  const unsigned long long mzero    = M.zero;
   const unsigned owner = (unsigned)r;
   double tp = 0.0;
   double ch[2][8], f0[2][8], f1[2][8];
@@ -303,7 +316,7 @@ __device__ __forceinline__ Pair row_sweeps_inl(const int K_, const double *T_, c
 template<int NB, bool ANYK = true>
 __device__ __attribute__((noinline)) Pair row_sweeps(const int K_, const double *T_, const double *Dg_, Pair t, const int lane)
 {
-  return row_sweeps_inl<NB, ANYK>(K_, T_, Dg_, t, lane);
+  return row_sweeps_inl<NB, ANYK>(K_, T_, Dg_, t, lane, make_masks());
 }
 
 // NB = ceil(K / 16) is wave-uniform at run time: one instance per block count

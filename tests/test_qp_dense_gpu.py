@@ -256,6 +256,37 @@ def test_four_per_wave_slot_refill(sfb, oracle, env_knob, waves, n, m):
     _compare(r, ref2)
 
 
+@pytest.mark.parametrize("waves,slice_checks", [(1, 1), (5, 2), (16, 40)])
+@pytest.mark.parametrize("n,m", [(16, 32), (20, 44), (40, 60), (64, 64), (100, 20)])
+def test_mid_kernel_time_sliced_launch(sfb, oracle, env_knob, waves, slice_checks, n, m):
+    """qp_dense_mid_kernel (32 < n+m <= 128) as a persistent grid of 1 / 5 / 16 waves with a slice of 1 / 2 / 40 check
+    intervals: QPs are suspended (factor, permutation and iterate to the workspace) and resumed by other waves many
+    times; results equal the oracle's bit for bit, as with one QP per workgroup -- cold and warm starts, infeasible
+    items, max_iter on and off a check iteration, no checks at all."""
+    env_knob(SFB_MID_GRID=waves, SFB_MID_SLICE=slice_checks)
+    for B, prm in ((37, sfb.QPSolverParams(max_iter=700)),
+                   (23, sfb.QPSolverParams(eps_abs=1e-6, eps_rel=1e-6, max_iter=403, scaling=False)),
+                   (19, sfb.QPSolverParams(max_iter=77, stop_check_iter=3, polish=False)),
+                   (18, sfb.QPSolverParams(max_iter=130, stop_check_iter=0))):
+        P, q, A, l, u = sfb.random_qp_batch(300 + B, B, m, n, 0.8)
+        l[::7] = -np.inf
+        l[3::11] = u[3::11]
+        l[5], u[5] = 1.0, -1.0             # u < l: PrimalInfeasible before the first iteration (:361-364)
+        r = sfb.solve_qp_batch_host(P, q, A, l, u, prm)
+        ref = oracle.qp_dense_solve_batch(P, q, A, l, u, params=_oracle_params(oracle, prm), nthreads=8)
+        _compare(r, ref)
+    B = 29
+    P, q, A, l, u = sfb.random_qp_batch(12, B, m, n, 1.0)
+    prm = sfb.QPSolverParams(max_iter=900)
+    op = _oracle_params(oracle, prm)
+    ref = oracle.qp_dense_solve_batch(P, q, A, l, u, params=op, nthreads=8)
+    wx = np.where(np.isfinite(ref["x"]), ref["x"], 0.0)
+    wy = np.where(np.isfinite(ref["y"]), ref["y"], 0.0)
+    r = sfb.solve_qp_batch_host(P, q + 0.02, A, l, u, prm, warm_x=wx, warm_y=wy)
+    ref2 = oracle.qp_dense_solve_batch(P, q + 0.02, A, l, u, params=op, warm_x=wx, warm_y=wy, nthreads=8)
+    _compare(r, ref2)
+
+
 @pytest.mark.parametrize("n,m", [(10, 20), (5, 11), (16, 16)])
 def test_one_per_wave_kernels_still_agree(sfb, oracle, env_knob, n, m):
     """k <= 32 through the one-QP-per-wavefront kernels (SFB_QP_DENSE4=0): same bits as the four-per-wave
