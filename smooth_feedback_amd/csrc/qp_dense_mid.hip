@@ -52,7 +52,8 @@ __device__ __forceinline__ bool mfinite(const double v) { return fabs(v) < INFIN
 
 // profiling build (scripts/r4/build_variant.sh prof qp_dense_mid.hip -DSFB_MID_PROF): block 0 prints where its time went
 #ifdef SFB_MID_PROF
-#define MP_T(i) mp_t[i] = wall_clock64()
+__device__ unsigned long long g_midprof[12];
+#define MP_T(i) g_midprof[i] = wall_clock64()
 #else
 #define MP_T(i)
 #endif
@@ -515,355 +516,639 @@ __device__ __attribute__((noinline)) int mid_stop_check(const int n_, const int 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template<int NB, int WPE>
-__global__ void __launch_bounds__(64, WPE) qp_dense_mid_kernel(const DenseKernelParams kp, const QpBatch g, double *__restrict__ gws, const size_t wsd,
-                                                               unsigned *__restrict__ queue, const unsigned batch, const uint32_t slice)
+// One QP as seen by the phases below: its LDS regions, its arrays in global memory, where its results go.
+struct MidC {
+  int n, m, k, lane, tsz;
+  lds_d *T, *Dg, *tmp, *V;
+  lds_b *perm;
+  lds_i *iperm;
+  const double *P, *q, *A, *l, *u, *wx, *wy;
+  double *ox, *oy, *oobj;
+  uint32_t *oiter;
+  int32_t *ocode;
+};
+__device__ __forceinline__ MidC mid_context(double *sm, const DenseKernelParams &kp, const QpBatch &g, const size_t b, const int lane)
 {
-  constexpr int R = NB > 4 ? 2 : 1;
-  constexpr int kFillU = NB > 4 ? 16 : 8;     // loads in flight per lane while P and A are streamed into the KKT matrix
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int lane = threadIdx.x;
   const int n = kp.n, m = kp.m, k = n + m;
   const MidLayout L = mid_layout(n, m);
-  lds_d *const T = (lds_d *)(sm + L.T), *const Dg = (lds_d *)(sm + L.Dg), *const tmp = (lds_d *)(sm + L.tmp), *const V = (lds_d *)(sm + L.V);
-  lds_b *const perm = (lds_b *)(sm + L.perm);
-  lds_i *const iperm = (lds_i *)(sm + L.tmp);
+  MidC C;
+  C.n = n;  C.m = m;  C.k = k;  C.lane = lane;  C.tsz = (k * (k + 1)) / 2 + kMidPadT;
+  C.T = (lds_d *)(sm + L.T);  C.Dg = (lds_d *)(sm + L.Dg);  C.tmp = (lds_d *)(sm + L.tmp);  C.V = (lds_d *)(sm + L.V);
+  C.perm  = (lds_b *)(sm + L.perm);
+  C.iperm = (lds_i *)(sm + L.tmp);
+  C.P = g.P + b * (size_t)n * n;  C.q = g.q + b * (size_t)n;  C.A = g.A + b * (size_t)m * n;
+  C.l = g.l + b * (size_t)m;      C.u = g.u + b * (size_t)m;
+  C.wx = g.wx ? g.wx + b * (size_t)n : nullptr;
+  C.wy = g.wy ? g.wy + b * (size_t)m : nullptr;
+  C.ox = g.x + b * (size_t)n;  C.oy = g.y + b * (size_t)m;
+  C.oobj  = g.obj ? g.obj + b : nullptr;
+  C.oiter = g.iter ? g.iter + b : nullptr;
+  C.ocode = g.code + b;
+  return C;
+}
+
+// Setup of QPSolver::solve (:347-445): scaling, pre-check and rho, KKT matrix in pivot order, LDL', the lanes' rows of the
+// permuted system with their constants and the initial iterate.  Returns the status if the solve ends before the first
+// iteration (PrimalInfeasible / Unknown), else -1.
+template<int R, int kFillU>
+__device__ __forceinline__ int mid_setup(const MidC &C, const DenseKernelParams &kp, MidRow (&h)[R], double &c, unsigned long long &t0_ticks)
+{
+  const int n = C.n, m = C.m, k = C.k, lane = C.lane, tsz = C.tsz;
+  lds_d *const T = C.T, *const Dg = C.Dg, *const tmp = C.tmp, *const V = C.V;
+  lds_b *const perm = C.perm;
+  lds_i *const iperm = C.iperm;
   lds_d *const SX = V, *const SY = V + n;
+  const double *const P = C.P, *const q = C.q, *const A = C.A, *const l = C.l, *const u = C.u;
   const double inf = INFINITY;
-  const int tsz    = (k * (k + 1)) / 2 + kMidPadT;
-  const uint32_t sci   = kp.stop_check_iter;
-  const uint32_t maxit = kp.max_iter;
-
-  // Launch shape.  queue == nullptr: one QP per workgroup, the hardware dispatcher is the work queue (batches that fit the
-  // chip at once).  Otherwise a PERSISTENT grid with a device-side queue, time-sliced like the k <= 32 kernel's: fresh QPs
-  // are handed out by a ticket counter; a QP that has held its wave for `slice` iterations while others are waiting
-  // saves its state (factor, permutation, iterate: MidSave) in its workspace and goes to the back of a ring of
-  // 2 * batch tagged entries, from where any wave resumes it -- the QPs that run into max_iter advance together
-  // instead of the last-started one running alone at the end.  Results do not depend on the launch shape.
-  unsigned *const q_fresh = queue, *const q_rhead = queue ? queue + 16 : nullptr, *const q_tail = queue ? queue + 32 : nullptr,
-                 *const q_done = queue ? queue + 48 : nullptr;
-  unsigned long long *const ring = queue ? reinterpret_cast<unsigned long long *>(queue + 64) : nullptr;
-  const unsigned ring_n = 2u * batch;
-  constexpr unsigned kNone = 0xFFFFFFFFu;
-  unsigned pend   = kNone;  // ring ticket this wave is waiting for
-  bool fresh_left = true;
-  for (;;) {
-    size_t b     = blockIdx.x;
-    bool resumed = false;
-    if (queue != nullptr) {
-      int item = -1;
-      if (pend == kNone) {
-        if (fresh_left) {
-          unsigned t = 0;
-          if (lane == 0) t = atomicAdd(q_fresh, 1u);
-          t = (unsigned)muni((int)t);
-          if (t < batch) item = (int)t;
-          else fresh_left = false;
-        }
-        if (item < 0) {
-          unsigned t = 0;
-          if (lane == 0) t = atomicAdd(q_rhead, 1u);
-          pend = (unsigned)muni((int)t);
-        }
-      }
-      if (item < 0) {
-        unsigned long long e = 0;
-        if (lane == 0) e = __hip_atomic_load(ring + (pend % ring_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned lo32 = (unsigned)muni((int)(unsigned)e), hi32 = (unsigned)muni((int)(unsigned)(e >> 32));
-        if (hi32 == pend + 1u) {  // my entry has arrived
-          if (lane == 0) __hip_atomic_store(ring + (pend % ring_n), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          item    = (int)(lo32 - 1u);
-          pend    = kNone;
-          resumed = true;
-          __threadfence();  // the state was written by another wave
-        } else {
-          unsigned d = 0;
-          if (lane == 0) d = __hip_atomic_load(q_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((unsigned)muni((int)d) >= batch) break;  // every QP has been reported
-          __builtin_amdgcn_s_sleep(16);
-          continue;
-        }
-      }
-      b = (size_t)item;
-    }
-    const double *const P = g.P + b * (size_t)n * n, *const q = g.q + b * (size_t)n, *const A = g.A + b * (size_t)m * n;
-    const double *const l = g.l + b * (size_t)m, *const u = g.u + b * (size_t)m;
-    double *const sv = gws ? gws + b * wsd : nullptr;  // MidSave of this QP: [T | D | per row: scale, x or y, z | perm (bytes) | header]
-    double *const sv_rows = sv ? sv + tsz + k : nullptr, *const sv_perm = sv ? sv_rows + 3 * k : nullptr, *const sv_hdr = sv ? sv_perm + (k + 7) / 8 : nullptr;
-    double c     = 1.0;
-    int ret_code = -1;
-    unsigned long long t0_ticks = 0;
-    MidRow h[R];
-    uint32_t iter     = 0;
-    uint32_t next_chk = (sci >= 2) ? 1u : 0xFFFFFFFFu;  // iter % sci == 1 (:465) without a division per iteration
-#ifdef SFB_MID_PROF
-    unsigned long long mp_t[12] = {};
-#endif
-    MP_T(0);
-    if (!resumed) {
-      // ================= setup: natural order, unit e = lane + 64 r: e < n variable e, else constraint e - n =================
+  (void)tsz; (void)T; (void)Dg; (void)tmp; (void)perm; (void)iperm; (void)SX; (void)SY; (void)P; (void)q; (void)A; (void)l; (void)u; (void)inf; (void)k; (void)m; (void)lane;
+  int ret_code = -1;
+  c            = 1.0;
+  // ================= setup: natural order, unit e = lane + 64 r: e < n variable e, else constraint e - n =================
 #pragma unroll
-      for (int r = 0; r < R; ++r) {  // analyze(): :306-308
+  for (int r = 0; r < R; ++r) {  // analyze(): :306-308
+    const int e = lane + kWave * r;
+    if (e < k) V[e] = 1.0;
+  }
+  wave_lds_fence();
+  if (kp.scaling) {  // :673-730
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int e = lane + kWave * r;
+      if (e < n) {  // :681-690 column inf-norms of P
+        double t = 0.0;
+        mrun(P + (size_t)e * n, 1, n, [&](int, double p) { t = fmax(t, fabs(p)); });
+        if (t == 0.0) t = 1.0;
+        tmp[e] = t;
+      }
+    }
+    wave_lds_fence();
+    double sum = tmp[0];  // :693 mean(): sequential sum
+    for (int j = 1; j < n; ++j) sum += tmp[j];
+    double qv = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int e = lane + kWave * r;
+      if (e < n) qv = fmax(qv, fabs(q[e]));
+    }
+    const double qn = wave_max(qv);
+    c               = 1.0 / fmax(fmax(1e-6, sum / (double)n), qn);
+    wave_lds_fence();
+    int pass = 0;
+    double crit;
+    do {  // :698-729
+      double inc[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
         const int e = lane + kWave * r;
-        if (e < k) V[e] = 1.0;
-      }
-      wave_lds_fence();
-      if (kp.scaling) {  // :673-730
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int e = lane + kWave * r;
-          if (e < n) {  // :681-690 column inf-norms of P
-            double t = 0.0;
-            mrun(P + (size_t)e * n, 1, n, [&](int, double p) { t = fmax(t, fabs(p)); });
-            if (t == 0.0) t = 1.0;
-            tmp[e] = t;
-          }
+        double v    = 0.0;
+        if (e < n) {
+          const double sxc = SX[e];
+          mrun(P + (size_t)e * n, 1, n, [&](int row, double p) { v = fmax(v, fabs(c * SX[row] * sxc * p)); });  // :704-707
+          mrun(A + (size_t)e * m, 1, m, [&](int row, double a) { v = fmax(v, fabs(SY[row] * sxc * a)); });      // :712-714
+        } else if (e < k) {
+          const double syr = SY[e - n];
+          mrun(A + (e - n), m, n, [&](int col, double a) { v = fmax(v, fabs(syr * SX[col] * a)); });
         }
-        wave_lds_fence();
-        double sum = tmp[0];  // :693 mean(): sequential sum
-        for (int j = 1; j < n; ++j) sum += tmp[j];
-        double qv = 0.0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int e = lane + kWave * r;
-          if (e < n) qv = fmax(qv, fabs(q[e]));
-        }
-        const double qn = wave_max(qv);
-        c               = 1.0 / fmax(fmax(1e-6, sum / (double)n), qn);
-        wave_lds_fence();
-        int pass = 0;
-        double crit;
-        do {  // :698-729
-          double inc[R];
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const int e = lane + kWave * r;
-            double v    = 0.0;
-            if (e < n) {
-              const double sxc = SX[e];
-              mrun(P + (size_t)e * n, 1, n, [&](int row, double p) { v = fmax(v, fabs(c * SX[row] * sxc * p)); });  // :704-707
-              mrun(A + (size_t)e * m, 1, m, [&](int row, double a) { v = fmax(v, fabs(SY[row] * sxc * a)); });      // :712-714
-            } else if (e < k) {
-              const double syr = SY[e - n];
-              mrun(A + (e - n), m, n, [&](int col, double a) { v = fmax(v, fabs(syr * SX[col] * a)); });
-            }
-            if (v == 0.0) v = 1.0;
-            inc[r] = v;
-          }
-          wave_lds_fence();  // every lane has read the old sx / sy
-          double cm = 0.0;
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const int e = lane + kWave * r;
-            if (e < k) {
-              V[e] = sqrt(1.0 / fmax(inc[r], 1e-8)) * V[e];
-              cm   = fmax(cm, fabs(inc[r] - 1.0));
-            }
-          }
-          crit = wave_max(cm);
-          wave_lds_fence();
-        } while (pass++ < 10 && crit > 0.1);
+        if (v == 0.0) v = 1.0;
+        inc[r] = v;
       }
-
-      MP_T(1);
-      // ---- pre-check and rho :361-374, the diagonal of the KKT matrix :399-404 ----
-      double dgn[R];
-      int idn[R];
-      {
-        bool bad = false;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int e = lane + kWave * r;
-          idn[r]      = e;
-          dgn[r]      = 0.0;
-          if (e < n) {
-            const double sxe = SX[e];
-            dgn[r]           = c * sxe * P[(size_t)e * n + e] * sxe + kp.sigma;
-          } else if (e < k) {
-            const double li = l[e - n], ui = u[e - n];
-            bad = bad || (li == inf) || (ui == -inf) || (ui - li < 0.0);
-            double rho;
-            if (li == -inf && ui == inf) rho = 1e-6;
-            else if (SY[e - n] * fabs(li - ui) < 1e-5) rho = 1e3 * kp.rho_bar;
-            else rho = kp.rho_bar;
-            dgn[r] = 1.0 / (-rho);
-          }
-        }
-        if (wave_ballot(bad)) ret_code = SFB_QP_PRIMAL_INFEASIBLE;
-      }
-      t0_ticks = wall_clock64();  // :376
-
-      // ---- Eigen's pivot order (from the diagonal), then the KKT matrix straight into its final positions ----
-      MP_T(2);
-      mid_pivot_order<R>(k, dgn, idn, lane);
-      MP_T(3);
+      wave_lds_fence();  // every lane has read the old sx / sy
+      double cm = 0.0;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const int pos = lane + kWave * r;
-        if (pos < k) {
-          perm[pos]      = (unsigned char)idn[r];
-          iperm[idn[r]] = pos;
+        const int e = lane + kWave * r;
+        if (e < k) {
+          V[e] = sqrt(1.0 / fmax(inc[r], 1e-8)) * V[e];
+          cm   = fmax(cm, fabs(inc[r] - 1.0));
         }
       }
-      for (int e = lane; e < tsz; e += kWave) T[e] = 0.0;
+      crit = wave_max(cm);
       wave_lds_fence();
-      bool fin = true;
-      {
-        const float rn = 1.0f / (float)n, rm = 1.0f / (float)m;
-        mstream<kFillU>(P, n * n, lane, [&](const int e, const double pv) {  // upper entries (a, bb), a < bb, of P: ((c sx_a) P_ab) sx_b
-          const int bb = (int)(((float)e + 0.5f) * rn), a = e - bb * n;
-          if (a < bb) {
-            const double v = c * SX[a] * pv * SX[bb];
-            const int ra = iperm[a], rb = iperm[bb];
-            T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
-            fin = fin && mfinite(v);
-          }
-        });
-        mstream<kFillU>(A, m * n, lane, [&](const int e, const double av) {  // (sy_i A_ij) sx_j
-          const int j = (int)(((float)e + 0.5f) * rm), i = e - j * m;
-          const double v = SY[i] * av * SX[j];
-          const int ra = iperm[n + i], rb = iperm[j];
-          T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
-          fin = fin && mfinite(v);
-        });
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int pos = lane + kWave * r;
-          if (pos < k) {
-            T[mtri(pos) + pos] = dgn[r];
-            fin = fin && mfinite(dgn[r]);
-          }
-        }
-        fin = !wave_ballot(!fin);
-      }
-      wave_lds_fence();
+    } while (pass++ < 10 && crit > 0.1);
+  }
 
-      MP_T(4);
-      // ---- LDL' :428-433 ----
-      if (!mid_ldlt<R>(k, T, Dg, tmp, lane, fin)) ret_code = SFB_QP_UNKNOWN;
-      MP_T(5);
-
-      // ================= lane roles for the loop: rows lane, lane + 64 of the PERMUTED system =================
+  MP_T(1);
+  // ---- pre-check and rho :361-374, the diagonal of the KKT matrix :399-404 ----
+  double dgn[R];
+  int idn[R];
+  {
+    bool bad = false;
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int row = lane + kWave * r;
-        const bool in = row < k;
-        const int v   = in ? perm[row] : 0;
-        MidRow &w = h[r];
-        w.isx = in && v < n;
-        w.isc = in && v >= n;
-        w.xi  = w.isx ? v : 0;
-        w.ci  = w.isc ? v - n : 0;
-        w.sxv = w.isx ? SX[w.xi] : 1.0;
-        w.syv = w.isc ? SY[w.ci] : 1.0;
-        w.qc  = w.isx ? c * w.sxv * q[w.xi] : 0.0;  // (c sx_j) q_j of the right-hand side :450
-        const double li = w.isc ? l[w.ci] : 0.0, ui = w.isc ? u[w.ci] : 0.0;
-        double rho = 1.0;
-        if (w.isc) {
-          if (li == -inf && ui == inf) rho = 1e-6;
-          else if (w.syv * fabs(li - ui) < 1e-5) rho = 1e3 * kp.rho_bar;
-          else rho = kp.rho_bar;
-        }
-        w.rho  = rho;
-        w.rinv = 1.0 / rho;
-        w.lo   = w.isc ? w.syv * li : 0.0;
-        w.hi   = w.isc ? w.syv * ui : 0.0;
-        w.x = w.y = w.z = 0.0;
-      }
-      // ---- initial iterate :436-445 ----
-      if (g.wx != nullptr) {
-        const double *const wx = g.wx + b * (size_t)n, *const wy = g.wy + b * (size_t)m;
-        lds_d *const WX = tmp;  // the warm primal, broadcast operand of z = (Sy A) x_ws
-        for (int j = lane; j < n; j += kWave) WX[j] = wx[j];
-        wave_lds_fence();
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          MidRow &w = h[r];
-          if (w.isx) w.x = (1.0 / w.sxv) * wx[w.xi];
-          if (w.isc) {
-            w.y      = c * ((1.0 / w.syv) * wy[w.ci]);
-            double s = 0.0;
-            const double syv = w.syv;
-            mrun(A + w.ci, m, n, [&](int j, double a) { s = fma(syv * a, WX[j], s); });
-            w.z = s;
-          }
-        }
-        wave_lds_fence();
-      }
-
-    } else {
-      // ---- resume: factor, permutation and the rows' state come back from the workspace; the rows' constants are
-      //      recomputed from the same expressions (they are functions of the saved scale factors and the problem data) ----
-      for (int e = lane; e < tsz; e += kWave) T[e] = sv[e];
-      for (int e = lane; e < k; e += kWave) Dg[e] = sv[tsz + e];
-      const unsigned char *const pb = reinterpret_cast<const unsigned char *>(sv_perm);
-      for (int e = lane; e < k; e += kWave) perm[e] = pb[e];
-      c        = sv_hdr[0];
-      iter     = (uint32_t)sv_hdr[1];
-      next_chk = (uint32_t)sv_hdr[2];
-      t0_ticks = (unsigned long long)__double_as_longlong(sv_hdr[3]);
-      wave_lds_fence();
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int row = lane + kWave * r;
-        const bool in = row < k;
-        const int v   = in ? perm[row] : 0;
-        MidRow &w = h[r];
-        w.isx = in && v < n;
-        w.isc = in && v >= n;
-        w.xi  = w.isx ? v : 0;
-        w.ci  = w.isc ? v - n : 0;
-        const double sc = in ? sv_rows[3 * row] : 1.0, a0 = in ? sv_rows[3 * row + 1] : 0.0, a1 = in ? sv_rows[3 * row + 2] : 0.0;
-        w.sxv = w.isx ? sc : 1.0;
-        w.syv = w.isc ? sc : 1.0;
-        w.qc  = w.isx ? c * w.sxv * q[w.xi] : 0.0;
-        const double li = w.isc ? l[w.ci] : 0.0, ui = w.isc ? u[w.ci] : 0.0;
-        double rho = 1.0;
-        if (w.isc) {
-          if (li == -inf && ui == inf) rho = 1e-6;
-          else if (w.syv * fabs(li - ui) < 1e-5) rho = 1e3 * kp.rho_bar;
-          else rho = kp.rho_bar;
-        }
-        w.rho  = rho;
-        w.rinv = 1.0 / rho;
-        w.lo   = w.isc ? w.syv * li : 0.0;
-        w.hi   = w.isc ? w.syv * ui : 0.0;
-        w.x = w.isx ? a0 : 0.0;
-        w.y = w.isc ? a0 : 0.0;
-        w.z = w.isc ? a1 : 0.0;
+    for (int r = 0; r < R; ++r) {
+      const int e = lane + kWave * r;
+      idn[r]      = e;
+      dgn[r]      = 0.0;
+      if (e < n) {
+        const double sxe = SX[e];
+        dgn[r]           = c * sxe * P[(size_t)e * n + e] * sxe + kp.sigma;
+      } else if (e < k) {
+        const double li = l[e - n], ui = u[e - n];
+        bad = bad || (li == inf) || (ui == -inf) || (ui - li < 0.0);
+        double rho;
+        if (li == -inf && ui == inf) rho = 1e-6;
+        else if (SY[e - n] * fabs(li - ui) < 1e-5) rho = 1e3 * kp.rho_bar;
+        else rho = kp.rho_bar;
+        dgn[r] = 1.0 / (-rho);
       }
     }
-    // ================= stopping check :574-644 on the un-scaled iterates in V =================
-    lds_d *const xus = V, *const dxus = V + n, *const yus = V + 2 * n, *const zus = yus + m, *const dyus = tmp;
+    if (wave_ballot(bad)) ret_code = SFB_QP_PRIMAL_INFEASIBLE;
+  }
+  t0_ticks = wall_clock64();  // :376
 
-    MP_T(6);
-    // ================= ADMM loop :447-510 =================
-    auto rhs = [&](const MidRow &w) { return w.isx ? (kp.sigma * w.x - w.qc) : (w.isc ? (w.z - w.rinv * w.y) : 0.0); };  // :450-451
-    auto upd = [&](MidRow &w, const double t, const bool chk) {                                                              // :470-477
-      const double xo = w.x, yo = w.y;
-      w.x       = kp.alpha * t + kp.alpha_comp * w.x;
-      double zn = kp.alpha * (w.rinv * t) + kp.alpha_comp * (w.rinv * w.y) + w.z;
-      zn        = (zn < w.lo) ? w.lo : zn;
-      zn        = (w.hi < zn) ? w.hi : zn;
-      w.y       = kp.alpha_comp * w.y + kp.alpha * t + w.rho * w.z - w.rho * zn;
-      w.z       = zn;
-      if (chk) {  // :481-485
-        if (w.isx) {
-          xus[w.xi]  = w.sxv * w.x;
-          dxus[w.xi] = w.sxv * (w.x - xo);
+  // ---- Eigen's pivot order (from the diagonal), then the KKT matrix straight into its final positions ----
+  MP_T(2);
+  mid_pivot_order<R>(k, dgn, idn, lane);
+  MP_T(3);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int pos = lane + kWave * r;
+    if (pos < k) {
+      perm[pos]      = (unsigned char)idn[r];
+      iperm[idn[r]] = pos;
+    }
+  }
+  for (int e = lane; e < tsz; e += kWave) T[e] = 0.0;
+  wave_lds_fence();
+  bool fin = true;
+  {
+    const float rn = 1.0f / (float)n, rm = 1.0f / (float)m;
+    mstream<kFillU>(P, n * n, lane, [&](const int e, const double pv) {  // upper entries (a, bb), a < bb, of P: ((c sx_a) P_ab) sx_b
+      const int bb = (int)(((float)e + 0.5f) * rn), a = e - bb * n;
+      if (a < bb) {
+        const double v = c * SX[a] * pv * SX[bb];
+        const int ra = iperm[a], rb = iperm[bb];
+        T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
+        fin = fin && mfinite(v);
+      }
+    });
+    mstream<kFillU>(A, m * n, lane, [&](const int e, const double av) {  // (sy_i A_ij) sx_j
+      const int j = (int)(((float)e + 0.5f) * rm), i = e - j * m;
+      const double v = SY[i] * av * SX[j];
+      const int ra = iperm[n + i], rb = iperm[j];
+      T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
+      fin = fin && mfinite(v);
+    });
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int pos = lane + kWave * r;
+      if (pos < k) {
+        T[mtri(pos) + pos] = dgn[r];
+        fin = fin && mfinite(dgn[r]);
+      }
+    }
+    fin = !wave_ballot(!fin);
+  }
+  wave_lds_fence();
+
+  MP_T(4);
+  // ---- LDL' :428-433 ----
+  if (!mid_ldlt<R>(k, T, Dg, tmp, lane, fin)) ret_code = SFB_QP_UNKNOWN;
+  MP_T(5);
+
+  // ================= lane roles for the loop: rows lane, lane + 64 of the PERMUTED system =================
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = lane + kWave * r;
+    const bool in = row < k;
+    const int v   = in ? perm[row] : 0;
+    MidRow &w = h[r];
+    w.isx = in && v < n;
+    w.isc = in && v >= n;
+    w.xi  = w.isx ? v : 0;
+    w.ci  = w.isc ? v - n : 0;
+    w.sxv = w.isx ? SX[w.xi] : 1.0;
+    w.syv = w.isc ? SY[w.ci] : 1.0;
+    w.qc  = w.isx ? c * w.sxv * q[w.xi] : 0.0;  // (c sx_j) q_j of the right-hand side :450
+    const double li = w.isc ? l[w.ci] : 0.0, ui = w.isc ? u[w.ci] : 0.0;
+    double rho = 1.0;
+    if (w.isc) {
+      if (li == -inf && ui == inf) rho = 1e-6;
+      else if (w.syv * fabs(li - ui) < 1e-5) rho = 1e3 * kp.rho_bar;
+      else rho = kp.rho_bar;
+    }
+    w.rho  = rho;
+    w.rinv = 1.0 / rho;
+    w.lo   = w.isc ? w.syv * li : 0.0;
+    w.hi   = w.isc ? w.syv * ui : 0.0;
+    w.x = w.y = w.z = 0.0;
+  }
+  // ---- initial iterate :436-445 ----
+  if (C.wx != nullptr) {
+    const double *const wx = C.wx, *const wy = C.wy;
+    lds_d *const WX = tmp;  // the warm primal, broadcast operand of z = (Sy A) x_ws
+    for (int j = lane; j < n; j += kWave) WX[j] = wx[j];
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      MidRow &w = h[r];
+      if (w.isx) w.x = (1.0 / w.sxv) * wx[w.xi];
+      if (w.isc) {
+        w.y      = c * ((1.0 / w.syv) * wy[w.ci]);
+        double s = 0.0;
+        const double syv = w.syv;
+        mrun(A + w.ci, m, n, [&](int j, double a) { s = fma(syv * a, WX[j], s); });
+        w.z = s;
+      }
+    }
+    wave_lds_fence();
+  }
+  return ret_code;
+}
+
+// The record of a QP in the workspace (doubles): [T (tsz) | D (k) | per row of the permuted system: scale factor, x or y, z
+// (3 k) | permutation (k bytes) | header: c, iter, next check, start ticks, status].  A QP travels through it between the
+// setup, loop and finish launches and when it is suspended by a time-sliced loop launch.
+constexpr int kMidHdr = 8;
+__host__ __device__ inline size_t mid_save_doubles(const int n, const int m)
+{
+  const size_t k = (size_t)n + m;
+  return (k * (k + 1)) / 2 + kMidPadT + k + 3 * k + (k + 7) / 8 + kMidHdr;
+}
+struct MidRec {
+  double *T, *Dg, *rows, *perm, *hdr;
+};
+__device__ __forceinline__ MidRec mid_record(double *const sv, const int k, const int tsz)
+{
+  MidRec r;
+  r.T = sv;  r.Dg = sv + tsz;  r.rows = r.Dg + k;  r.perm = r.rows + 3 * k;  r.hdr = r.perm + (k + 7) / 8;
+  return r;
+}
+template<int R>
+__device__ __forceinline__ void mid_save_state(const MidC &C, const MidRec rec, const MidRow (&h)[R], const double c, const uint32_t iter,
+                                               const uint32_t next_chk, const unsigned long long t0_ticks, const int code, const bool with_factor)
+{
+  const int k = C.k, lane = C.lane, tsz = C.tsz;
+  wave_lds_fence();
+  if (with_factor) {
+    for (int e = lane; e < tsz; e += kWave) rec.T[e] = C.T[e];
+    for (int e = lane; e < k; e += kWave) rec.Dg[e] = C.Dg[e];
+    unsigned char *const pb = reinterpret_cast<unsigned char *>(rec.perm);
+    for (int e = lane; e < k; e += kWave) pb[e] = C.perm[e];
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = lane + kWave * r;
+    if (row < k) {
+      const MidRow &w = h[r];
+      rec.rows[3 * row]     = w.isx ? w.sxv : w.syv;
+      rec.rows[3 * row + 1] = w.isx ? w.x : w.y;
+      rec.rows[3 * row + 2] = w.z;
+    }
+  }
+  if (lane == 0) {
+    rec.hdr[0] = c;
+    rec.hdr[1] = (double)iter;
+    rec.hdr[2] = (double)next_chk;
+    rec.hdr[3] = __longlong_as_double((long long)t0_ticks);
+    rec.hdr[4] = (double)code;
+  }
+}
+// with_factor: the factor and D come back to LDS (loop launch); otherwise only what the finish phase reads
+template<int R>
+__device__ __forceinline__ void mid_load_state(const MidC &C, const DenseKernelParams &kp, const MidRec rec, MidRow (&h)[R], double &c, uint32_t &iter,
+                                               uint32_t &next_chk, unsigned long long &t0_ticks, int &code, const bool with_factor)
+{
+  const int n = C.n, m = C.m, k = C.k, lane = C.lane, tsz = C.tsz;
+  lds_d *const T = C.T, *const Dg = C.Dg, *const tmp = C.tmp, *const V = C.V;
+  lds_b *const perm = C.perm;
+  lds_i *const iperm = C.iperm;
+  lds_d *const SX = V, *const SY = V + n;
+  const double *const P = C.P, *const q = C.q, *const A = C.A, *const l = C.l, *const u = C.u;
+  const double inf = INFINITY;
+  (void)tsz; (void)T; (void)Dg; (void)tmp; (void)perm; (void)iperm; (void)SX; (void)SY; (void)P; (void)q; (void)A; (void)l; (void)u; (void)inf; (void)k; (void)m; (void)lane;
+  const double *const sv_rows = rec.rows, *const sv_hdr = rec.hdr;
+  if (with_factor) {
+    for (int e = lane; e < tsz; e += kWave) T[e] = rec.T[e];
+    for (int e = lane; e < k; e += kWave) Dg[e] = rec.Dg[e];
+  }
+  {
+    const unsigned char *const pb = reinterpret_cast<const unsigned char *>(rec.perm);
+    for (int e = lane; e < k; e += kWave) perm[e] = pb[e];
+  }
+  c        = sv_hdr[0];
+  iter     = (uint32_t)sv_hdr[1];
+  next_chk = (uint32_t)sv_hdr[2];
+  t0_ticks = (unsigned long long)__double_as_longlong(sv_hdr[3]);
+  code     = (int)sv_hdr[4];
+  wave_lds_fence();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = lane + kWave * r;
+    const bool in = row < k;
+    const int v   = in ? perm[row] : 0;
+    MidRow &w = h[r];
+    w.isx = in && v < n;
+    w.isc = in && v >= n;
+    w.xi  = w.isx ? v : 0;
+    w.ci  = w.isc ? v - n : 0;
+    const double sc = in ? sv_rows[3 * row] : 1.0, a0 = in ? sv_rows[3 * row + 1] : 0.0, a1 = in ? sv_rows[3 * row + 2] : 0.0;
+    w.sxv = w.isx ? sc : 1.0;
+    w.syv = w.isc ? sc : 1.0;
+    w.qc  = w.isx ? c * w.sxv * q[w.xi] : 0.0;
+    const double li = w.isc ? l[w.ci] : 0.0, ui = w.isc ? u[w.ci] : 0.0;
+    double rho = 1.0;
+    if (w.isc) {
+      if (li == -inf && ui == inf) rho = 1e-6;
+      else if (w.syv * fabs(li - ui) < 1e-5) rho = 1e3 * kp.rho_bar;
+      else rho = kp.rho_bar;
+    }
+    w.rho  = rho;
+    w.rinv = 1.0 / rho;
+    w.lo   = w.isc ? w.syv * li : 0.0;
+    w.hi   = w.isc ? w.syv * ui : 0.0;
+    w.x = w.isx ? a0 : 0.0;
+    w.y = w.isc ? a0 : 0.0;
+    w.z = w.isc ? a1 : 0.0;
+  }
+}
+
+// The end of QPSolver::solve (:515-548): polish, un-scale, report.
+template<int R, int NB, int kFillU>
+__device__ __forceinline__ void mid_finish(const MidC &C, const DenseKernelParams &kp, const MidRow (&h)[R], const double c, const int ret_code,
+                                           const uint32_t iter)
+{
+  const int n = C.n, m = C.m, k = C.k, lane = C.lane, tsz = C.tsz;
+  lds_d *const T = C.T, *const Dg = C.Dg, *const tmp = C.tmp, *const V = C.V;
+  lds_b *const perm = C.perm;
+  lds_i *const iperm = C.iperm;
+  lds_d *const SX = V, *const SY = V + n;
+  const double *const P = C.P, *const q = C.q, *const A = C.A, *const l = C.l, *const u = C.u;
+  const double inf = INFINITY;
+  (void)tsz; (void)T; (void)Dg; (void)tmp; (void)perm; (void)iperm; (void)SX; (void)SY; (void)P; (void)q; (void)A; (void)l; (void)u; (void)inf; (void)k; (void)m; (void)lane;
+  // ================= the end of solve() :515-548: V = [sx | sy | x | y | lists] in natural order =================
+  lds_d *const XS = V + k, *const YS = V + k + n;
+  wave_lds_fence();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const MidRow &w = h[r];
+    if (w.isx) { SX[w.xi] = w.sxv; XS[w.xi] = w.x; }
+    if (w.isc) { SY[w.ci] = w.syv; YS[w.ci] = w.y; }
+  }
+  wave_lds_fence();
+
+  // ---- polish :92-204 (on the scaled iterate; a failed factorisation leaves the ADMM solution) ----
+  if (ret_code == SFB_QP_OPTIMAL && kp.polish) {
+    const double eps = DBL_EPSILON;
+    lds_b *const colof = (lds_b *)(V + 2 * k);  // per constraint: its row n + a of the polish system, or 255
+    lds_b *const LU    = colof + m;             // row n + a -> constraint
+    // active sets: lower indices first, then upper, each ascending (:113-123)
+    int nl = 0, nu = 0;
+    int act[R], pos[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = lane + kWave * r;
+      int a       = 0;
+      if (i < m) {
+        const double yi = YS[i];
+        if (yi < -100 * eps && l[i] != -inf) a = 1;
+        if (yi > 100 * eps && u[i] != inf) a = 2;
+      }
+      const unsigned long long bl = wave_ballot(a == 1), bu = wave_ballot(a == 2);
+      act[r] = a;
+      pos[r] = (a == 1) ? nl + __popcll(bl & lanemask_lt(lane)) : nu + __popcll(bu & lanemask_lt(lane));
+      nl += __popcll(bl);
+      nu += __popcll(bu);
+    }
+    const int na = nl + nu, K = n + na;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = lane + kWave * r;
+      if (i < m) {
+        const int a = act[r] == 0 ? -1 : pos[r] + (act[r] == 2 ? nl : 0);
+        colof[i]    = (unsigned char)(a < 0 ? 255 : n + a);
+        if (a >= 0) LU[a] = (unsigned char)i;
+      }
+    }
+    wave_lds_fence();
+    // rows of the polish system: e = lane + 64 r < K: variable e, or active constraint LU[e - n]; h :179-182; diagonal of Hp :174-177
+    double hh[R], dgp[R];
+    int idp[R], prow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int e = lane + kWave * r;
+      idp[r] = e;  hh[r] = 0.0;  dgp[r] = 0.0;  prow[r] = 0;
+      if (e < n) {
+        const double sxe = SX[e];
+        dgp[r] = c * sxe * P[(size_t)e * n + e] * sxe + kp.delta;
+        hh[r]  = -c * (sxe * q[e]);
+      } else if (e < K) {
+        const int row = LU[e - n];
+        prow[r]       = row;
+        dgp[r]        = 0.0 - kp.delta;
+        hh[r]         = (e - n < nl) ? SY[row] * l[row] : SY[row] * u[row];
+      }
+    }
+    mid_pivot_order<R>(K, dgp, idp, lane);
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int p = lane + kWave * r;
+      if (p < K) {
+        perm[p]        = (unsigned char)idp[r];
+        iperm[idp[r]] = p;
+      }
+    }
+    const int tszp = (K * (K + 1)) / 2 + kMidPadT;
+    for (int e = lane; e < tszp; e += kWave) T[e] = 0.0;
+    wave_lds_fence();
+    bool finp = true;
+    {
+      const float rn = 1.0f / (float)n, rm = 1.0f / (float)m;
+      mstream<kFillU>(P, n * n, lane, [&](const int e, const double pv) {
+        const int bb = (int)(((float)e + 0.5f) * rn), a = e - bb * n;
+        if (a < bb) {
+          const double v = c * SX[a] * pv * SX[bb];  // :161
+          const int ra = iperm[a], rb = iperm[bb];
+          T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
+          finp = finp && mfinite(v);
         }
-        if (w.isc) {
-          yus[w.ci]  = w.syv * w.y / c;
-          zus[w.ci]  = (1.0 / w.syv) * w.z;
-          dyus[w.ci] = w.syv * (w.y - yo) / c;
+      });
+      mstream<kFillU>(A, m * n, lane, [&](const int e, const double av) {
+        const int j = (int)(((float)e + 0.5f) * rm), i = e - j * m;
+        const int col = colof[i];
+        if (col != 255) {
+          const double v = SY[i] * av * SX[j];  // :163
+          const int ra = iperm[col], rb = iperm[j];
+          T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
+          finp = finp && mfinite(v);
+        }
+      });
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int p = lane + kWave * r;
+        if (p < K) {
+          T[mtri(p) + p] = dgp[r];
+          finp = finp && mfinite(dgp[r]);
         }
       }
-    };
-    const rows::Masks masks = rows::make_masks();  // (once, in front of the loop: see sweep_rows.h)
-    uint32_t it0   = iter;  // iteration at which this wave took the QP
-    bool suspended = false;
-    for (; iter != maxit && ret_code < 0; ++iter) {
-      if (queue != nullptr && iter - it0 >= slice) {  // the slice is used up: hand the QP back if others are waiting
+      finp = !wave_ballot(!finp);
+    }
+    wave_lds_fence();
+    if (mid_ldlt<R>(K, T, Dg, tmp, lane, finp)) {  // :187-190
+      double tt[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) tt[r] = 0.0;
+      lds_d *const tv = tmp;
+      for (uint32_t it = 0; it != kp.polish_iter; ++it) {  // :193-195  t += Hp^-1 (h - H t); the entries of H are recomputed (same products)
+        bool tfin = true;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int e = lane + kWave * r;
+          if (e < K) tv[e] = tt[r];
+          tfin = tfin && mfinite(tt[r]);
+        }
+        tfin = !wave_ballot(!tfin);
+        wave_lds_fence();
+        double res[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int e = lane + kWave * r;
+          double acc  = 0.0;
+          if (e < n) {
+            const double sxr = SX[e];
+            // upper entry (a, bb) of P: (j, e) for j < e -- column e, contiguous -- then (e, j) for j >= e -- row e, stride n
+            mrun(P + (size_t)e * n, 1, e, [&](int j, double p) { acc = fma(c * SX[j] * p * sxr, tv[j], acc); });
+            mrun(P + e + (size_t)e * n, n, n - e, [&](int d, double p) { acc = fma(c * sxr * p * SX[e + d], tv[e + d], acc); });
+            for (int a0 = 0; a0 < na; a0 += 8) {  // the active rows' entries of column e, eight at a time
+              int row[8];
+              double av[8];
+#pragma unroll
+              for (int uu = 0; uu < 8; ++uu) row[uu] = (a0 + uu < na) ? LU[a0 + uu] : 0;
+#pragma unroll
+              for (int uu = 0; uu < 8; ++uu) av[uu] = A[row[uu] + (size_t)e * m];
+#pragma unroll
+              for (int uu = 0; uu < 8; ++uu)
+                if (a0 + uu < na) acc = fma(SY[row[uu]] * av[uu] * sxr, tv[n + a0 + uu], acc);
+            }
+          } else if (e < K) {
+            const double syr = SY[prow[r]];
+            mrun(A + prow[r], m, n, [&](int j, double av) { acc = fma(syr * av * SX[j], tv[j], acc); });
+            // the zero (2,2) block of H: fma(0, t_j, acc) leaves acc unchanged for finite t_j (acc is never -0)
+            if (!tfin)
+              for (int j = n; j < K; ++j) acc = fma(0.0, tv[j], acc);
+          }
+          res[r] = hh[r] - acc;
+        }
+        wave_lds_fence();
+        // oracle_ldlt_solve: P b -> sweeps -> P^T, through the exchange vector
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int e = lane + kWave * r;
+          if (e < K) tv[e] = res[r];
+        }
+        wave_lds_fence();
+        rows::Pair pr{0.0, 0.0};
+        {
+          const int p0 = lane, p1 = lane + kWave;
+          if (p0 < K) pr.lo = tv[perm[p0]];
+          if (R > 1 && p1 < K) pr.hi = tv[perm[p1]];
+        }
+        wave_lds_fence();
+        pr = rows::row_sweeps<NB>(K, (const double *)T, (const double *)Dg, pr, lane);
+        {
+          const int p0 = lane, p1 = lane + kWave;
+          if (p0 < K) tv[perm[p0]] = pr.lo;
+          if (R > 1 && p1 < K) tv[perm[p1]] = pr.hi;
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int e = lane + kWave * r;
+          if (e < K) tt[r] += tv[e];
+        }
+        wave_lds_fence();
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {  // :199-201
+        const int e = lane + kWave * r;
+        if (e < n) XS[e] = tt[r];
+        else if (e < K) YS[prow[r]] = tt[r];
+      }
+    }
+    wave_lds_fence();
+  }
+
+  MP_T(8);
+  // ---- un-scale and report :544-548 ----
+  double *const ox = C.ox, *const oy = C.oy;
+  lds_d *const xo = tmp, *const pv = Dg;  // (both dead by now)
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int e = lane + kWave * r;
+    if (e < n) {
+      const double v = SX[e] * XS[e];
+      ox[e] = v;
+      xo[e] = v;
+    }
+    if (e < m) oy[e] = SY[e] * YS[e] / c;
+  }
+  wave_lds_fence();
+  if (C.oobj != nullptr) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int e = lane + kWave * r;
+      if (e < n) {
+        double s = 0.0;
+        mrun(P + e, n, n, [&](int j, double p) { s = fma(0.5 * p, xo[j], s); });
+        pv[e] = s + q[e];
+      }
+    }
+    wave_lds_fence();
+    if (lane == 0) {
+      double o = 0.0;
+      for (int i = 0; i < n; ++i) o = fma(xo[i], pv[i], o);
+      *C.oobj = o;
+    }
+  }
+  if (lane == 0) {
+    *C.ocode = (ret_code >= 0) ? ret_code : SFB_QP_MAX_ITERATIONS;
+    if (C.oiter != nullptr) *C.oiter = iter;
+  }
+}
+
+// One ADMM iteration state machine (:447-510) on the rows in registers.  QUEUE: time-sliced -- returns true when the QP
+// has used its slice while others are waiting (the caller suspends it), false when the loop has ended.
+template<int NB, int R, bool QUEUE>
+__device__ __forceinline__ bool mid_admm(const MidC &C, const DenseKernelParams &kp, MidRow (&h)[R], const double c, uint32_t &iter, uint32_t &next_chk,
+                                         int &ret_code, const unsigned long long t0_ticks, const uint32_t slice, const unsigned *const q_fresh,
+                                         const unsigned *const q_rhead, const unsigned *const q_tail, const unsigned batch)
+{
+  const int n = C.n, m = C.m, k = C.k, lane = C.lane, tsz = C.tsz;
+  lds_d *const T = C.T, *const Dg = C.Dg, *const tmp = C.tmp, *const V = C.V;
+  lds_b *const perm = C.perm;
+  lds_i *const iperm = C.iperm;
+  lds_d *const SX = V, *const SY = V + n;
+  const double *const P = C.P, *const q = C.q, *const A = C.A, *const l = C.l, *const u = C.u;
+  const double inf = INFINITY;
+  (void)tsz; (void)T; (void)Dg; (void)tmp; (void)perm; (void)iperm; (void)SX; (void)SY; (void)P; (void)q; (void)A; (void)l; (void)u; (void)inf; (void)k; (void)m; (void)lane;
+  const uint32_t sci = kp.stop_check_iter, maxit = kp.max_iter;
+  lds_d *const xus = V, *const dxus = V + n, *const yus = V + 2 * n, *const zus = yus + m, *const dyus = tmp;  // the un-scaled iterates of a stopping check
+  auto rhs = [&](const MidRow &w) { return w.isx ? (kp.sigma * w.x - w.qc) : (w.isc ? (w.z - w.rinv * w.y) : 0.0); };  // :450-451
+  auto upd = [&](MidRow &w, const double t, const bool chk) {                                                              // :470-477
+    const double xo = w.x, yo = w.y;
+    w.x       = kp.alpha * t + kp.alpha_comp * w.x;
+    double zn = kp.alpha * (w.rinv * t) + kp.alpha_comp * (w.rinv * w.y) + w.z;
+    zn        = (zn < w.lo) ? w.lo : zn;
+    zn        = (w.hi < zn) ? w.hi : zn;
+    w.y       = kp.alpha_comp * w.y + kp.alpha * t + w.rho * w.z - w.rho * zn;
+    w.z       = zn;
+    if (chk) {  // :481-485
+      if (w.isx) {
+        xus[w.xi]  = w.sxv * w.x;
+        dxus[w.xi] = w.sxv * (w.x - xo);
+      }
+      if (w.isc) {
+        yus[w.ci]  = w.syv * w.y / c;
+        zus[w.ci]  = (1.0 / w.syv) * w.z;
+        dyus[w.ci] = w.syv * (w.y - yo) / c;
+      }
+    }
+  };
+  const rows::Masks masks = rows::make_masks();  // (once, in front of the loop: see sweep_rows.h)
+  uint32_t it0 = iter;  // iteration at which this wave took the QP
+  for (; iter != maxit && ret_code < 0; ++iter) {
+    if constexpr (QUEUE) {
+      if (iter - it0 >= slice) {  // the slice is used up: hand the QP back if others are waiting
         unsigned waiting = 0;
         if (lane == 0) {
           const unsigned fr = __hip_atomic_load(q_fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -871,297 +1156,165 @@ __global__ void __launch_bounds__(64, WPE) qp_dense_mid_kernel(const DenseKernel
           const unsigned tl = __hip_atomic_load(q_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           waiting = (fr < batch || (int)(tl - hd) > 0) ? 1u : 0u;
         }
-        if (muni((int)waiting)) {
-          suspended = true;
-          break;
-        }
+        if (muni((int)waiting)) return true;
         it0 = iter;  // nobody waits: a fresh slice
       }
-      rows::Pair t{rhs(h[0]), R > 1 ? rhs(h[R - 1]) : 0.0};
-      t = rows::row_sweeps_inl<NB, false>(k, (const double *)T, (const double *)Dg, t, lane, masks);  // :462
-      const bool chk = (iter == next_chk);                                              // :465
-      if (chk) next_chk += sci;
-      upd(h[0], t.lo, chk);
-      if constexpr (R > 1) upd(h[R - 1], t.hi, chk);
-      if (chk) {
-        wave_lds_fence();
-        ret_code = mid_stop_check<R>(n, m, lane, P, q, A, l, u, V, tmp, kp.eps_abs, kp.eps_rel, kp.eps_pinf, kp.eps_dinf);
-        if (ret_code < 0 && max_time_exceeded(kp.max_time_ns, t0_ticks)) ret_code = SFB_QP_MAX_TIME;  // :504-507
-        wave_lds_fence();
+    }
+    rows::Pair t{rhs(h[0]), R > 1 ? rhs(h[R - 1]) : 0.0};
+    t = rows::row_sweeps_inl<NB, false>(k, (const double *)T, (const double *)Dg, t, lane, masks);  // :462
+    const bool chk = (iter == next_chk);                                                            // :465
+    if (chk) next_chk += sci;
+    upd(h[0], t.lo, chk);
+    if constexpr (R > 1) upd(h[R - 1], t.hi, chk);
+    if (chk) {
+      wave_lds_fence();
+      ret_code = mid_stop_check<R>(n, m, lane, P, q, A, l, u, V, tmp, kp.eps_abs, kp.eps_rel, kp.eps_pinf, kp.eps_dinf);
+      if (ret_code < 0 && max_time_exceeded(kp.max_time_ns, t0_ticks)) ret_code = SFB_QP_MAX_TIME;  // :504-507
+      wave_lds_fence();
+    }
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// FUSED launch: one QP per workgroup from setup to report, the hardware dispatcher is the work queue, no workspace --
+// batches the chip holds at once (and single QPs: one launch).
+template<int NB, int WPE>
+__global__ void __launch_bounds__(64, WPE) qp_dense_mid_kernel(const DenseKernelParams kp, const QpBatch g)
+{
+  constexpr int R = NB > 4 ? 2 : 1;
+  constexpr int kFillU = NB > 4 ? 16 : 8;  // loads in flight per lane while P and A are streamed into the KKT matrix
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int lane = threadIdx.x;
+  const MidC C   = mid_context(sm, kp, g, blockIdx.x, lane);
+  MidRow h[R];
+  double c = 1.0;
+  unsigned long long t0_ticks = 0;
+  MP_T(0);
+  int ret_code      = mid_setup<R, kFillU>(C, kp, h, c, t0_ticks);
+  uint32_t iter     = 0;
+  uint32_t next_chk = (kp.stop_check_iter >= 2) ? 1u : 0xFFFFFFFFu;  // iter % sci == 1 (:465) without a division per iteration
+  MP_T(6);
+  mid_admm<NB, R, false>(C, kp, h, c, iter, next_chk, ret_code, t0_ticks, 0, nullptr, nullptr, nullptr, 0);
+  MP_T(7);
+  mid_finish<R, NB, kFillU>(C, kp, h, c, ret_code, iter);
+#ifdef SFB_MID_PROF
+  MP_T(9);
+  if (lane == 0 && blockIdx.x == 0)
+    printf("midprof (%d,%d) x10ns: scale %llu | rho+diag %llu | pivot order %llu | zero+fill %llu | ldlt %llu | roles+warm %llu | loop %llu (%u iterations) | polish %llu | report %llu\n",
+           C.n, C.m, g_midprof[1] - g_midprof[0], g_midprof[2] - g_midprof[1], g_midprof[3] - g_midprof[2], g_midprof[4] - g_midprof[3],
+           g_midprof[5] - g_midprof[4], g_midprof[6] - g_midprof[5], g_midprof[7] - g_midprof[6], iter, g_midprof[8] - g_midprof[7], g_midprof[9] - g_midprof[8]);
+#endif
+}
+
+// SPLIT launch for batches larger than the chip: setup (one QP per workgroup) -> records; loop (persistent, time-sliced);
+// finish (one QP per workgroup).  The ADMM loop, where a batch spends its time, then runs in a kernel that carries
+// nothing else: no scaling / fill / factorisation / polish code competing for its registers, and a QP that runs into
+// max_iter does not hold a wave from setup to report.
+template<int NB, int WPE>
+__global__ void __launch_bounds__(64, WPE) qp_dense_mid_setup_kernel(const DenseKernelParams kp, const QpBatch g, double *__restrict__ gws, const size_t wsd)
+{
+  constexpr int R = NB > 4 ? 2 : 1;
+  constexpr int kFillU = NB > 4 ? 16 : 8;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int lane = threadIdx.x;
+  const MidC C   = mid_context(sm, kp, g, blockIdx.x, lane);
+  MidRow h[R];
+  double c = 1.0;
+  unsigned long long t0_ticks = 0;
+  const int ret_code = mid_setup<R, kFillU>(C, kp, h, c, t0_ticks);
+  mid_save_state<R>(C, mid_record(gws + (size_t)blockIdx.x * wsd, C.k, C.tsz), h, c, 0u, (kp.stop_check_iter >= 2) ? 1u : 0xFFFFFFFFu, t0_ticks, ret_code, true);
+}
+
+template<int NB, int WPE>
+__global__ void __launch_bounds__(64, WPE) qp_dense_mid_finish_kernel(const DenseKernelParams kp, const QpBatch g, double *__restrict__ gws, const size_t wsd)
+{
+  constexpr int R = NB > 4 ? 2 : 1;
+  constexpr int kFillU = NB > 4 ? 16 : 8;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int lane = threadIdx.x;
+  const MidC C   = mid_context(sm, kp, g, blockIdx.x, lane);
+  MidRow h[R];
+  double c = 1.0;
+  unsigned long long t0_ticks = 0;
+  uint32_t iter = 0, next_chk = 0;
+  int ret_code = -1;
+  mid_load_state<R>(C, kp, mid_record(gws + (size_t)blockIdx.x * wsd, C.k, C.tsz), h, c, iter, next_chk, t0_ticks, ret_code, false);
+  mid_finish<R, NB, kFillU>(C, kp, h, c, ret_code, iter);
+}
+
+// The loop launch: a PERSISTENT grid with a device-side queue, time-sliced like the k <= 32 kernel's.  QPs are handed
+// out by a ticket counter; a QP that has held its wave for `slice` iterations while others are waiting goes back into
+// its record and to the back of a ring of 2 * batch tagged entries, from where any wave resumes it -- the QPs that run
+// into max_iter advance together instead of the last-started one running alone at the end.  Results do not depend on
+// grid, slice or order.
+template<int NB, int WPE>
+__global__ void __launch_bounds__(64, WPE) qp_dense_mid_loop_kernel(const DenseKernelParams kp, const QpBatch g, double *__restrict__ gws, const size_t wsd,
+                                                                    unsigned *__restrict__ queue, const unsigned batch, const uint32_t slice)
+{
+  constexpr int R = NB > 4 ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int lane = threadIdx.x;
+  unsigned *const q_fresh = queue, *const q_rhead = queue + 16, *const q_tail = queue + 32, *const q_done = queue + 48;
+  unsigned long long *const ring = reinterpret_cast<unsigned long long *>(queue + 64);
+  const unsigned ring_n = 2u * batch;
+  constexpr unsigned kNone = 0xFFFFFFFFu;
+  unsigned pend   = kNone;  // ring ticket this wave is waiting for
+  bool fresh_left = true;
+  for (;;) {
+    int item = -1;
+    if (pend == kNone) {
+      if (fresh_left) {
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(q_fresh, 1u);
+        t = (unsigned)muni((int)t);
+        if (t < batch) item = (int)t;
+        else fresh_left = false;
+      }
+      if (item < 0) {
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(q_rhead, 1u);
+        pend = (unsigned)muni((int)t);
       }
     }
-
+    if (item < 0) {
+      unsigned long long e = 0;
+      if (lane == 0) e = __hip_atomic_load(ring + (pend % ring_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned lo32 = (unsigned)muni((int)(unsigned)e), hi32 = (unsigned)muni((int)(unsigned)(e >> 32));
+      if (hi32 == pend + 1u) {  // my entry has arrived
+        if (lane == 0) __hip_atomic_store(ring + (pend % ring_n), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        item = (int)(lo32 - 1u);
+        pend = kNone;
+        __threadfence();  // the record was written by another wave
+      } else {
+        unsigned d = 0;
+        if (lane == 0) d = __hip_atomic_load(q_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)muni((int)d) >= batch) break;  // every QP has left the loop
+        __builtin_amdgcn_s_sleep(16);
+        continue;
+      }
+    }
+    const MidC C     = mid_context(sm, kp, g, (size_t)item, lane);
+    const MidRec rec = mid_record(gws + (size_t)item * wsd, C.k, C.tsz);
+    MidRow h[R];
+    double c = 1.0;
+    unsigned long long t0_ticks = 0;
+    uint32_t iter = 0, next_chk = 0;
+    int ret_code = -1;
+    mid_load_state<R>(C, kp, rec, h, c, iter, next_chk, t0_ticks, ret_code, true);
+    const bool suspended = mid_admm<NB, R, true>(C, kp, h, c, iter, next_chk, ret_code, t0_ticks, slice, q_fresh, q_rhead, q_tail, batch);
+    mid_save_state<R>(C, rec, h, c, iter, next_chk, t0_ticks, ret_code, suspended);
     if (suspended) {
-      wave_lds_fence();
-      for (int e = lane; e < tsz; e += kWave) sv[e] = T[e];
-      for (int e = lane; e < k; e += kWave) sv[tsz + e] = Dg[e];
-      unsigned char *const pb = reinterpret_cast<unsigned char *>(sv_perm);
-      for (int e = lane; e < k; e += kWave) pb[e] = perm[e];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int row = lane + kWave * r;
-        if (row < k) {
-          const MidRow &w = h[r];
-          sv_rows[3 * row]     = w.isx ? w.sxv : w.syv;
-          sv_rows[3 * row + 1] = w.isx ? w.x : w.y;
-          sv_rows[3 * row + 2] = w.z;
-        }
-      }
-      if (lane == 0) {
-        sv_hdr[0] = c;
-        sv_hdr[1] = (double)iter;
-        sv_hdr[2] = (double)next_chk;
-        sv_hdr[3] = __longlong_as_double((long long)t0_ticks);
-      }
-      __threadfence();  // the state is complete (device scope) before the id can be popped
+      __threadfence();  // the record is complete (device scope) before the id can be popped
       if (lane == 0) {
         const unsigned j           = atomicAdd(q_tail, 1u);
         unsigned long long *slot   = ring + (j % ring_n);
-        const unsigned long long v = ((unsigned long long)(j + 1u) << 32) | ((unsigned)b + 1u);
+        const unsigned long long v = ((unsigned long long)(j + 1u) << 32) | ((unsigned)item + 1u);
         while (atomicCAS(slot, 0ull, v) != 0ull) __builtin_amdgcn_s_sleep(1);
       }
-      continue;
+    } else if (lane == 0) {
+      atomicAdd(q_done, 1u);
     }
-
-    MP_T(7);
-    // ================= the end of solve() :515-548: V = [sx | sy | x | y | lists] in natural order =================
-    lds_d *const XS = V + k, *const YS = V + k + n;
-    wave_lds_fence();
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const MidRow &w = h[r];
-      if (w.isx) { SX[w.xi] = w.sxv; XS[w.xi] = w.x; }
-      if (w.isc) { SY[w.ci] = w.syv; YS[w.ci] = w.y; }
-    }
-    wave_lds_fence();
-
-    // ---- polish :92-204 (on the scaled iterate; a failed factorisation leaves the ADMM solution) ----
-    if (ret_code == SFB_QP_OPTIMAL && kp.polish) {
-      const double eps = DBL_EPSILON;
-      lds_b *const colof = (lds_b *)(V + 2 * k);  // per constraint: its row n + a of the polish system, or 255
-      lds_b *const LU    = colof + m;             // row n + a -> constraint
-      // active sets: lower indices first, then upper, each ascending (:113-123)
-      int nl = 0, nu = 0;
-      int act[R], pos[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int i = lane + kWave * r;
-        int a       = 0;
-        if (i < m) {
-          const double yi = YS[i];
-          if (yi < -100 * eps && l[i] != -inf) a = 1;
-          if (yi > 100 * eps && u[i] != inf) a = 2;
-        }
-        const unsigned long long bl = wave_ballot(a == 1), bu = wave_ballot(a == 2);
-        act[r] = a;
-        pos[r] = (a == 1) ? nl + __popcll(bl & lanemask_lt(lane)) : nu + __popcll(bu & lanemask_lt(lane));
-        nl += __popcll(bl);
-        nu += __popcll(bu);
-      }
-      const int na = nl + nu, K = n + na;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int i = lane + kWave * r;
-        if (i < m) {
-          const int a = act[r] == 0 ? -1 : pos[r] + (act[r] == 2 ? nl : 0);
-          colof[i]    = (unsigned char)(a < 0 ? 255 : n + a);
-          if (a >= 0) LU[a] = (unsigned char)i;
-        }
-      }
-      wave_lds_fence();
-      // rows of the polish system: e = lane + 64 r < K: variable e, or active constraint LU[e - n]; h :179-182; diagonal of Hp :174-177
-      double hh[R], dgp[R];
-      int idp[R], prow[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int e = lane + kWave * r;
-        idp[r] = e;  hh[r] = 0.0;  dgp[r] = 0.0;  prow[r] = 0;
-        if (e < n) {
-          const double sxe = SX[e];
-          dgp[r] = c * sxe * P[(size_t)e * n + e] * sxe + kp.delta;
-          hh[r]  = -c * (sxe * q[e]);
-        } else if (e < K) {
-          const int row = LU[e - n];
-          prow[r]       = row;
-          dgp[r]        = 0.0 - kp.delta;
-          hh[r]         = (e - n < nl) ? SY[row] * l[row] : SY[row] * u[row];
-        }
-      }
-      mid_pivot_order<R>(K, dgp, idp, lane);
-      wave_lds_fence();
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int p = lane + kWave * r;
-        if (p < K) {
-          perm[p]        = (unsigned char)idp[r];
-          iperm[idp[r]] = p;
-        }
-      }
-      const int tszp = (K * (K + 1)) / 2 + kMidPadT;
-      for (int e = lane; e < tszp; e += kWave) T[e] = 0.0;
-      wave_lds_fence();
-      bool finp = true;
-      {
-        const float rn = 1.0f / (float)n, rm = 1.0f / (float)m;
-        mstream<kFillU>(P, n * n, lane, [&](const int e, const double pv) {
-          const int bb = (int)(((float)e + 0.5f) * rn), a = e - bb * n;
-          if (a < bb) {
-            const double v = c * SX[a] * pv * SX[bb];  // :161
-            const int ra = iperm[a], rb = iperm[bb];
-            T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
-            finp = finp && mfinite(v);
-          }
-        });
-        mstream<kFillU>(A, m * n, lane, [&](const int e, const double av) {
-          const int j = (int)(((float)e + 0.5f) * rm), i = e - j * m;
-          const int col = colof[i];
-          if (col != 255) {
-            const double v = SY[i] * av * SX[j];  // :163
-            const int ra = iperm[col], rb = iperm[j];
-            T[mtri(ra > rb ? ra : rb) + (ra > rb ? rb : ra)] = v;
-            finp = finp && mfinite(v);
-          }
-        });
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int p = lane + kWave * r;
-          if (p < K) {
-            T[mtri(p) + p] = dgp[r];
-            finp = finp && mfinite(dgp[r]);
-          }
-        }
-        finp = !wave_ballot(!finp);
-      }
-      wave_lds_fence();
-      if (mid_ldlt<R>(K, T, Dg, tmp, lane, finp)) {  // :187-190
-        double tt[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) tt[r] = 0.0;
-        lds_d *const tv = tmp;
-        for (uint32_t it = 0; it != kp.polish_iter; ++it) {  // :193-195  t += Hp^-1 (h - H t); the entries of H are recomputed (same products)
-          bool tfin = true;
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const int e = lane + kWave * r;
-            if (e < K) tv[e] = tt[r];
-            tfin = tfin && mfinite(tt[r]);
-          }
-          tfin = !wave_ballot(!tfin);
-          wave_lds_fence();
-          double res[R];
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const int e = lane + kWave * r;
-            double acc  = 0.0;
-            if (e < n) {
-              const double sxr = SX[e];
-              // upper entry (a, bb) of P: (j, e) for j < e -- column e, contiguous -- then (e, j) for j >= e -- row e, stride n
-              mrun(P + (size_t)e * n, 1, e, [&](int j, double p) { acc = fma(c * SX[j] * p * sxr, tv[j], acc); });
-              mrun(P + e + (size_t)e * n, n, n - e, [&](int d, double p) { acc = fma(c * sxr * p * SX[e + d], tv[e + d], acc); });
-              for (int a0 = 0; a0 < na; a0 += 8) {  // the active rows' entries of column e, eight at a time
-                int row[8];
-                double av[8];
-#pragma unroll
-                for (int uu = 0; uu < 8; ++uu) row[uu] = (a0 + uu < na) ? LU[a0 + uu] : 0;
-#pragma unroll
-                for (int uu = 0; uu < 8; ++uu) av[uu] = A[row[uu] + (size_t)e * m];
-#pragma unroll
-                for (int uu = 0; uu < 8; ++uu)
-                  if (a0 + uu < na) acc = fma(SY[row[uu]] * av[uu] * sxr, tv[n + a0 + uu], acc);
-              }
-            } else if (e < K) {
-              const double syr = SY[prow[r]];
-              mrun(A + prow[r], m, n, [&](int j, double av) { acc = fma(syr * av * SX[j], tv[j], acc); });
-              // the zero (2,2) block of H: fma(0, t_j, acc) leaves acc unchanged for finite t_j (acc is never -0)
-              if (!tfin)
-                for (int j = n; j < K; ++j) acc = fma(0.0, tv[j], acc);
-            }
-            res[r] = hh[r] - acc;
-          }
-          wave_lds_fence();
-          // oracle_ldlt_solve: P b -> sweeps -> P^T, through the exchange vector
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const int e = lane + kWave * r;
-            if (e < K) tv[e] = res[r];
-          }
-          wave_lds_fence();
-          rows::Pair pr{0.0, 0.0};
-          {
-            const int p0 = lane, p1 = lane + kWave;
-            if (p0 < K) pr.lo = tv[perm[p0]];
-            if (R > 1 && p1 < K) pr.hi = tv[perm[p1]];
-          }
-          wave_lds_fence();
-          pr = rows::row_sweeps<NB>(K, (const double *)T, (const double *)Dg, pr, lane);
-          {
-            const int p0 = lane, p1 = lane + kWave;
-            if (p0 < K) tv[perm[p0]] = pr.lo;
-            if (R > 1 && p1 < K) tv[perm[p1]] = pr.hi;
-          }
-          wave_lds_fence();
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const int e = lane + kWave * r;
-            if (e < K) tt[r] += tv[e];
-          }
-          wave_lds_fence();
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {  // :199-201
-          const int e = lane + kWave * r;
-          if (e < n) XS[e] = tt[r];
-          else if (e < K) YS[prow[r]] = tt[r];
-        }
-      }
-      wave_lds_fence();
-    }
-
-    MP_T(8);
-    // ---- un-scale and report :544-548 ----
-    double *const ox = g.x + b * (size_t)n, *const oy = g.y + b * (size_t)m;
-    lds_d *const xo = tmp, *const pv = Dg;  // (both dead by now)
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int e = lane + kWave * r;
-      if (e < n) {
-        const double v = SX[e] * XS[e];
-        ox[e] = v;
-        xo[e] = v;
-      }
-      if (e < m) oy[e] = SY[e] * YS[e] / c;
-    }
-    wave_lds_fence();
-    if (g.obj != nullptr) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int e = lane + kWave * r;
-        if (e < n) {
-          double s = 0.0;
-          mrun(P + e, n, n, [&](int j, double p) { s = fma(0.5 * p, xo[j], s); });
-          pv[e] = s + q[e];
-        }
-      }
-      wave_lds_fence();
-      if (lane == 0) {
-        double o = 0.0;
-        for (int i = 0; i < n; ++i) o = fma(xo[i], pv[i], o);
-        g.obj[b] = o;
-      }
-    }
-    if (lane == 0) {
-      g.code[b] = (ret_code >= 0) ? ret_code : SFB_QP_MAX_ITERATIONS;
-      if (g.iter != nullptr) g.iter[b] = iter;
-    }
-#ifdef SFB_MID_PROF
-    MP_T(9);
-    if (lane == 0 && blockIdx.x == 0)
-      printf("midprof (%d,%d) x10ns: scale %llu | rho+diag %llu | pivot order %llu | zero+fill %llu | ldlt %llu | roles+warm %llu | loop %llu (%u iterations) | polish %llu | report %llu\n",
-             n, m, mp_t[1] - mp_t[0], mp_t[2] - mp_t[1], mp_t[3] - mp_t[2], mp_t[4] - mp_t[3], mp_t[5] - mp_t[4], mp_t[6] - mp_t[5], mp_t[7] - mp_t[6], iter,
-             mp_t[8] - mp_t[7], mp_t[9] - mp_t[8]);
-#endif
-    if (queue == nullptr) break;
-    if (lane == 0) atomicAdd(q_done, 1u);
   }
 }
 
@@ -1176,45 +1329,60 @@ bool qp_dense_mid_enabled()
 size_t qp_dense_mid_lds_bytes(int n, int m) { return (size_t)mid_layout(n, m).total * sizeof(double); }
 
 namespace {
-template<int NBV, int W>
-hipError_t mid_resident_one(const size_t lds, int *resident)  // waves of this instance the device holds at once (LDS / VGPR limits)
+// compile-time shape classes: NB = ceil(k / 16) blocks; waves per SIMD the LOOP kernels are compiled for (VGPR budget);
+// the setup / finish kernels and the fused kernel take what the LDS leaves them anyway
+template<int NBV> struct MidW { static constexpr int loop = NBV <= 3 ? SFB_MID_W3 : (NBV == 4 ? SFB_MID_W4 : (NBV == 5 ? 2 : 1)), other = NBV <= 5 ? 2 : 1; };
+
+enum MidOp { MID_RESIDENT, MID_FUSED, MID_SETUP, MID_LOOP, MID_FINISH };
+struct MidLaunch {
+  MidOp op;
+  unsigned grid, batch;
+  double *ws;
+  size_t wsd;
+  unsigned *queue;
+  uint32_t slice;
+  int *resident;
+  hipStream_t stream;
+};
+template<int NBV>
+hipError_t mid_launch_nb(const DenseKernelParams &kp, const QpBatch &g, const size_t lds, const MidLaunch &a)
 {
-  int per_cu = 0, dev = 0;
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qp_dense_mid_kernel<NBV, W>, kWave, lds);
-  if (e != hipSuccess) return e;
-  hipDeviceProp_t prop;
-  e = hipGetDevice(&dev);
-  if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
-  if (e != hipSuccess) return e;
-  *resident = per_cu * prop.multiProcessorCount;
-  return hipSuccess;
+  constexpr int WL = MidW<NBV>::loop, WO = MidW<NBV>::other;
+  switch (a.op) {
+    case MID_RESIDENT: {  // waves of the loop kernel the device holds at once (LDS / VGPR limits)
+      int per_cu = 0, dev = 0;
+      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qp_dense_mid_loop_kernel<NBV, WL>, kWave, lds);
+      if (e != hipSuccess) return e;
+      hipDeviceProp_t prop;
+      e = hipGetDevice(&dev);
+      if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+      if (e != hipSuccess) return e;
+      *a.resident = per_cu * prop.multiProcessorCount;
+      return hipSuccess;
+    }
+    case MID_FUSED: hipLaunchKernelGGL((qp_dense_mid_kernel<NBV, WO>), dim3(a.grid), dim3(kWave), lds, a.stream, kp, g); break;
+    case MID_SETUP: hipLaunchKernelGGL((qp_dense_mid_setup_kernel<NBV, WO>), dim3(a.grid), dim3(kWave), lds, a.stream, kp, g, a.ws, a.wsd); break;
+    case MID_LOOP:
+      hipLaunchKernelGGL((qp_dense_mid_loop_kernel<NBV, WL>), dim3(a.grid), dim3(kWave), lds, a.stream, kp, g, a.ws, a.wsd, a.queue, a.batch, a.slice);
+      break;
+    case MID_FINISH: hipLaunchKernelGGL((qp_dense_mid_finish_kernel<NBV, WO>), dim3(a.grid), dim3(kWave), lds, a.stream, kp, g, a.ws, a.wsd); break;
+  }
+  return hipGetLastError();
 }
-// grid = number of workgroups; batch_q = items behind the queue (0: one per workgroup)
-hipError_t mid_dispatch(const DenseKernelParams &kp, const QpBatch &g, const unsigned grid, const unsigned batch_q, double *ws, const size_t wsd,
-                        unsigned *queue, const uint32_t slice, int *resident, hipStream_t stream)
+hipError_t mid_launch(const DenseKernelParams &kp, const QpBatch &g, const MidLaunch &a)
 {
   const int k = kp.n + kp.m, nb = (k + 15) / 16;
   const size_t lds = qp_dense_mid_lds_bytes(kp.n, kp.m);
-#define SFB_MID(NBV, W)                                                                                                               \
-  do {                                                                                                                                \
-    if (resident != nullptr) return mid_resident_one<NBV, W>(lds, resident);                                                          \
-    hipLaunchKernelGGL((qp_dense_mid_kernel<NBV, W>), dim3(grid), dim3(kWave), lds, stream, kp, g, ws, wsd, queue, batch_q, slice); \
-    return hipGetLastError();                                                                                                         \
-  } while (0)
-  if (nb <= 3) SFB_MID(3, SFB_MID_W3);
-  else if (nb == 4) SFB_MID(4, SFB_MID_W4);
-  else if (nb == 5) SFB_MID(5, 2);
-  else if (nb == 6) SFB_MID(6, 1);
-  else if (nb == 7) SFB_MID(7, 1);
-  else SFB_MID(8, 1);
-#undef SFB_MID
+  switch (nb) {
+    case 0: case 1: case 2: case 3: return mid_launch_nb<3>(kp, g, lds, a);
+    case 4: return mid_launch_nb<4>(kp, g, lds, a);
+    case 5: return mid_launch_nb<5>(kp, g, lds, a);
+    case 6: return mid_launch_nb<6>(kp, g, lds, a);
+    case 7: return mid_launch_nb<7>(kp, g, lds, a);
+    default: return mid_launch_nb<8>(kp, g, lds, a);
+  }
 }
-size_t mid_save_doubles(int n, int m)
-{
-  const size_t k = (size_t)n + m;
-  return (k * (k + 1)) / 2 + kMidPadT + k + 3 * k + (k + 7) / 8 + 4;  // MidSave: [T | D | rows | perm | header]
-}
-// iterations a QP may hold its wave while others wait (SFB_MID_SLICE, in stopping-check intervals; 0 = never time-sliced)
+// iterations a QP may hold its wave while others wait (SFB_MID_SLICE, in stopping-check intervals; 0 = the fused launch for every batch)
 uint32_t mid_slice(const DenseKernelParams &kp)
 {
   const char *const v = sfb::knob("SFB_MID_SLICE");  // (read per call: the tests change it)
@@ -1222,20 +1390,21 @@ uint32_t mid_slice(const DenseKernelParams &kp)
   if (checks <= 0) return 0;
   return (uint32_t)checks * (kp.stop_check_iter >= 2 ? kp.stop_check_iter : 25u);
 }
-// waves of the kernel the current device holds at once (cached per device and shape class)
+// waves of the loop kernel the current device holds at once
 int mid_resident(const DenseKernelParams &kp)
 {
-  const char *const v = sfb::knob("SFB_MID_GRID");  // tests: a tiny grid forces time slicing
+  const char *const v = sfb::knob("SFB_MID_GRID");  // tests: a tiny grid forces the split, time-sliced launch
   const int forced    = v ? atoi(v) : 0;
   if (forced > 0) return forced;
   int r = 0;
-  if (mid_dispatch(kp, QpBatch{}, 0, 0, nullptr, 0, nullptr, 0, &r, nullptr) != hipSuccess) return 0;
+  MidLaunch a{MID_RESIDENT, 0, 0, nullptr, 0, nullptr, 0, &r, nullptr};
+  if (mid_launch(kp, QpBatch{}, a) != hipSuccess) return 0;
   return r;
 }
 }  // namespace
 
-// Device memory a launch needs beyond its arguments: nothing for a batch the chip holds at once (or with time slicing off);
-// otherwise one MidSave per QP and the queue.
+// Device memory a launch needs beyond its arguments: nothing for a batch the chip holds at once (the fused kernel);
+// otherwise one record per QP and the queue of the loop launch.
 size_t qp_dense_mid_ws_bytes(const DenseKernelParams &kp, int64_t batch)
 {
   if (mid_slice(kp) == 0) return 0;
@@ -1249,8 +1418,8 @@ hipError_t qp_dense_mid_launch(const DenseKernelParams &kp, int64_t batch, const
   const int k = kp.n + kp.m;
   if (k > kDenseMidMaxK || k < 1) return hipErrorInvalidValue;
   const size_t need = qp_dense_mid_ws_bytes(kp, batch);
-  if (need == 0) return mid_dispatch(kp, g, (unsigned)batch, 0, nullptr, 0, nullptr, 0, nullptr, stream);
-  // persistent, time-sliced launch
+  if (need == 0) return mid_launch(kp, g, MidLaunch{MID_FUSED, (unsigned)batch, (unsigned)batch, nullptr, 0, nullptr, 0, nullptr, stream});
+  // split launch: setup -> loop (persistent, time-sliced) -> finish
   char *buf        = static_cast<char *>(workspace);
   bool async_alloc = true;
   hipError_t e     = hipSuccess;
@@ -1263,14 +1432,18 @@ hipError_t qp_dense_mid_launch(const DenseKernelParams &kp, int64_t batch, const
       if (e != hipSuccess) return e;
     }
   }
-  const size_t wsd   = mid_save_doubles(kp.n, kp.m);
-  const size_t qoff  = (size_t)batch * wsd * sizeof(double);
-  unsigned *queue    = reinterpret_cast<unsigned *>(buf + qoff);
+  const size_t wsd  = mid_save_doubles(kp.n, kp.m);
+  const size_t qoff = (size_t)batch * wsd * sizeof(double);
+  unsigned *queue   = reinterpret_cast<unsigned *>(buf + qoff);
+  double *ws        = reinterpret_cast<double *>(buf);
   e = hipMemsetAsync(queue, 0, need - qoff, stream);
+  if (e == hipSuccess) e = mid_launch(kp, g, MidLaunch{MID_SETUP, (unsigned)batch, (unsigned)batch, ws, wsd, nullptr, 0, nullptr, stream});
   if (e == hipSuccess) {
     const int res = mid_resident(kp);
-    e = mid_dispatch(kp, g, (unsigned)res, (unsigned)batch, reinterpret_cast<double *>(buf), wsd, queue, mid_slice(kp), nullptr, stream);
+    const unsigned grid = (unsigned)((int64_t)res < batch ? res : batch);
+    e = mid_launch(kp, g, MidLaunch{MID_LOOP, grid, (unsigned)batch, ws, wsd, queue, mid_slice(kp), nullptr, stream});
   }
+  if (e == hipSuccess) e = mid_launch(kp, g, MidLaunch{MID_FINISH, (unsigned)batch, (unsigned)batch, ws, wsd, nullptr, 0, nullptr, stream});
   if (workspace == nullptr) {
     if (async_alloc) {
       (void)hipFreeAsync(buf, stream);
