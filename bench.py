@@ -488,8 +488,9 @@ def dense_sizes_table(sfb, device, cores):
     and under the library defaults (max_iter 10 000 in both).  Device-resident, HIP-event timed.  QP-iterations/s is
     quoted next to QP/s because iteration counts differ by orders of magnitude between sizes and parameter sets (and
     a single QP that runs into max_iter on its own wave sets the time of a batch of fast ones).  Kernels: n + m <= 32
-    four QPs per wave (qp_dense4), <= 64 one per wave with the factor in registers / LDS (qp_dense), <= 128 one per
-    wave with the packed factor in LDS and the iterate in registers (qp_dense_big, packed engine)."""
+    four QPs per wave (qp_dense4); 32 < n + m <= 128 one per wave, packed factor in LDS, iterate in registers, block
+    sweeps, as setup / time-sliced loop / finish launches over per-QP records in the caller's workspace (qp_dense_mid).
+    Parity: the first 2 048 QPs of every batch against the dense oracle."""
     from oracle import loader as O
     rows = []
     for n, m in DENSE_SIZES:
@@ -501,18 +502,22 @@ def dense_sizes_table(sfb, device, cores):
         x, y, obj = torch.empty((B, n), **f64), torch.empty((B, m), **f64), torch.empty(B, **f64)
         out = torch.empty((2, B), dtype=torch.int32, device=device)
         stream = torch.cuda.current_stream()
+        ws = None
         for name, prm, okw in (("reference_benchmark", sfb.QPSolverParams(eps_abs=1e-6, eps_rel=1e-6, polish=True, max_iter=10000, scaling=False),
                                 dict(eps_abs=1e-6, eps_rel=1e-6, polish=1, max_iter=10000, scaling=0)),
                                ("library_defaults", sfb.QPSolverParams(max_iter=10000), dict(max_iter=10000))):
+            need = sfb.Workspace.dense_bytes(B, n, m, prm)   # the caller's workspace: no allocation inside the timed call
+            if ws is None or ws.nbytes < need:
+                ws = sfb.Workspace(need)  # (a re-created one frees the old through __del__)
             def go():
-                sfb.solve_qp_batch_device(B, n, m, *[a.data_ptr() for a in d], x.data_ptr(), y.data_ptr(), obj.data_ptr(),
-                                          out[0].data_ptr(), out[1].data_ptr(), prm, stream=stream.cuda_stream)
+                sfb.solve_qp_batch_device_ws(B, n, m, *[a.data_ptr() for a in d], x.data_ptr(), y.data_ptr(), obj.data_ptr(),
+                                             out[0].data_ptr(), out[1].data_ptr(), ws, prm, stream=stream.cuda_stream)
             go(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream); go(); e1.record(stream); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1)
             it = out[0].cpu().numpy().astype(np.int64); code = out[1].cpu().numpy()
-            S = min(B, 128)
+            S = min(B, 2048)
             ref = O.qp_dense_solve_batch(P[:S], q[:S], A[:S], l[:S], u[:S], params=O.default_params(**okw), nthreads=cores)
             fin = np.isfinite(ref["x"]).all(axis=1)
             opt = code == 0
@@ -527,7 +532,7 @@ def dense_sizes_table(sfb, device, cores):
                          "parity_vs_oracle": {"sample": S, "code_mismatches": int((code[:S] != ref["code"]).sum()),
                                               "iter_mismatches": int((it[:S] != ref["iter"]).sum()),
                                               "max_abs_dx": float(np.abs(x[:S].cpu().numpy() - ref["x"])[fin].max(initial=0.0))}})
-        del d, x, y, obj, out
+        del d, x, y, obj, out, ws
     return rows
 
 

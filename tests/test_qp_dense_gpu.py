@@ -336,6 +336,26 @@ def test_larger_dense_problems_are_bit_identical_to_the_dense_oracle(sfb, oracle
         assert np.array_equal(a, b, equal_nan=True)
 
 
+@pytest.mark.parametrize("n,m,B", [(20, 40, 4096), (40, 60, 4096), (64, 64, 4096), (3, 203, 4096)])
+def test_bench_batch_parity_of_the_mid_and_big_routes(sfb, oracle, n, m, B):
+    """The dense routes beyond the four-per-wave kernel at a batch larger than the chip, on the benchmark's generator
+    (benchmarks/bench_types.hpp:19-41) under the reference benchmark's parameters (bench.cpp:148-153) and under the
+    library defaults: the split, time-sliced launch of qp_dense_mid (k = 60: one block per wave and two waves per SIMD;
+    k = 100, 128: two rows per lane) and the pivoted big kernel ((3, 203)) against the oracle on EVERY QP of the batch --
+    codes, iteration counts, primal, dual, objective bit for bit.  The suite's other tests use 24-96 QPs per route."""
+    import os
+    P, q, A, l, u = sfb.random_qp_batch(5, B, m, n, 1.0)
+    if m > 128:   # a safety filter's shape: bands around the generator's point, few active rows
+        u = u + 5.0
+    for prm in (sfb.QPSolverParams(eps_abs=1e-6, eps_rel=1e-6, polish=True, max_iter=10000 if n + m <= 128 else 1500, scaling=False),
+                sfb.QPSolverParams(max_iter=10000 if n + m <= 128 else 1500)):
+        r = sfb.solve_qp_batch_host(P, q, A, l, u, prm)
+        ref = oracle.qp_dense_solve_batch(P, q, A, l, u, params=_oracle_params(oracle, prm), nthreads=min(64, os.cpu_count() or 8))
+        assert int((r.code != ref["code"]).sum()) == 0 and int((r.iter != ref["iter"]).sum()) == 0
+        for a, b in ((r.primal, ref["x"]), (r.dual, ref["y"]), (r.objective, ref["obj"])):
+            assert np.array_equal(a, b, equal_nan=True)
+
+
 def test_known_answers_padded_beyond_64(sfb, oracle):
     """The reference's known answers (tests/test_qp.cpp) embedded in larger problems (extra free rows and
     decoupled variables push n + m past 64): the big dense kernel reproduces codes and solutions."""
