@@ -260,6 +260,49 @@ class MPCWorkload:
                 "note": "launch order = descending iteration count of the previous solve of the same batch (what MPCSwarmDevice does "
                         "between ticks); `value` above is the cold launch in natural order"}
 
+    def closed_loop(self, ticks=8, reps=3):
+        """What a user of MPC::operator() (mpc.hpp:458-519) sees, next to the device-resident `value` (BASELINE.md section 3):
+        end_to_end   -- the host-pointer entry point on the SAME batch: H2D of the QP data + solve + D2H of x, y, obj, iter, code;
+        swarm_tick   -- MPCSwarmDeviceLin (include/smooth_feedback_amd/mpc_device.hpp): states up, linearisation + assembly +
+                        warm-started solve on the GPU, u0 / code / iter down; closed loop of the bench's vehicle model at the
+                        reference example's 25 ms control period (examples/mpc_asif_vehicle.cpp:58,161-169);
+        single_agent -- ONE controller through the host entry point (the reference's own use), cold and warm."""
+        from examples import models_lib as M
+        Px, q, Av, l, u = self.host
+        r = self.plan.solve_batch_host(Px, q, Av, l, u, self.prm)  # (first call: staging buffers, workspace)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = self.plan.solve_batch_host(Px, q, Av, l, u, self.prm)
+            ts.append(time.perf_counter() - t0)
+        it = self.out[0].cpu().numpy().astype(np.uint32)
+        moved = sum(a.nbytes for a in self.host) + r.primal.nbytes + r.dual.nbytes + r.objective.nbytes + r.iter.nbytes + r.code.nbytes
+        e2e = {"value": self.B / float(np.median(ts)), "unit": "QP solves/s", "ms_per_step": 1e3 * float(np.median(ts)), "reps": reps,
+               "bytes_over_pcie_per_step": int(moved), "results_identical_to_device_resident": bool(np.array_equal(r.iter, it)),
+               "entry": "sfb_sparse_qp_solve_batch_host (pageable numpy buffers in, numpy buffers out)"}
+        variant, K = 12, 50
+        sw = M.mpc_swarm_devlin_step(variant, K, self.B, ticks, seed=1, want_records=False)
+        warm = sw["seconds"][2:]  # tick 0: cold start + structure probe + plan; tick 1: first warm start
+        tick = {"ms_per_tick": 1e3 * float(np.mean(warm)), "ms_per_tick_all": [round(1e3 * float(s), 3) for s in sw["seconds"]],
+                "agents": self.B, "ticks": ticks, "warm_ticks_averaged": len(warm), "control_period_ms": 25.0,
+                "mean_iterations_last_tick": float(sw["iter"].mean()), "optimal_fraction_last_tick": float(np.mean(sw["code"] == 0)),
+                "value": self.B / float(np.mean(warm)), "unit": "MPC ticks/s",
+                "path": "MPCSwarmDeviceLin::step: states H2D, device linearisation + assembly + warm-started sparse solve, u0/code/iter D2H"}
+        P1, q1 = Px[:1], q[:1]
+        cold, warm1 = [], []
+        r1 = self.plan.solve_batch_host(P1, q1, Av[:1], l[:1], u[:1], self.prm)
+        for _ in range(10):
+            t0 = time.perf_counter()
+            r1 = self.plan.solve_batch_host(P1, q1, Av[:1], l[:1], u[:1], self.prm)
+            cold.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            r2 = self.plan.solve_batch_host(P1, q1, Av[:1], l[:1], u[:1], self.prm, warm_x=r1.primal, warm_y=r1.dual)
+            warm1.append(time.perf_counter() - t0)
+        single = {"cold_ms": 1e3 * float(np.median(cold)), "cold_iterations": int(r1.iter[0]), "warm_ms": 1e3 * float(np.median(warm1)),
+                  "warm_iterations": int(r2.iter[0]), "warm_note": "the same QP warm-started from its own solution: scaling + factorisation + polish + PCIe, "
+                  "the floor of a warm tick", "entry": "sfb_sparse_qp_solve_batch_host, batch 1 (n = m = %d)" % self.d["n"]}
+        return {"end_to_end": e2e, "swarm_tick": tick, "single_agent": single}
+
     def extra(self):
         it = self.out[0].cpu().numpy().astype(np.int64)
         code = self.out[1].cpu().numpy()
@@ -372,9 +415,34 @@ class EKFWorkload:
                   "delta_bit_identical": bool(np.array_equal(delta, dref)),
                   "max_abs_dP": float(np.abs(Pg - P).max()), "max_abs_ddelta": float(np.abs(delta - dref).max()),
                   "max_abs_P": float(np.abs(Pg).max())}
-        return {"value": S * self.launches / dt, "unit": "EKF steps/s", "cores": 1, "kind": "port",
+        single = {"value": S * self.launches / dt, "cores": 1, "sample": "first %d filters x %d ticks, 1 thread, %.1f s" % (S, self.launches, dt)}
+        if cores <= 1:
+            return {"value": single["value"], "unit": "EKF steps/s", "cores": 1, "kind": "port",
+                    "sample": "first %d filters of rank 0's batch x %d ticks, oracle/ekf_oracle.c (scalar C restatement of "
+                              "ekf.hpp:84-96,119-138), 1 thread, %.1f s" % (S, self.launches, dt), "single_core": single}, parity
+        # all cores: static partition of a `cores` times larger sample, one thread per part
+        # (the oracle's C loops run without the GIL)
+        from concurrent.futures import ThreadPoolExecutor
+        SA = int(min(self.B, S * cores))
+        parts = [(i * SA // cores, (i + 1) * SA // cores) for i in range(cores)]
+
+        def ticks_of(part):
+            a, b = part
+            Pc = h["P"][a:b].copy()
+            for _ in range(self.launches):
+                Pq = O.ekf_predict_batch(h["A"][a:b], h["Q"][a:b], h["dt"][a:b], Pc)
+                Pc, _, _ = O.ekf_update_batch(h["H"][a:b], h["R"][a:b], h["r"][a:b], Pq, self.n)
+            return Pc
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            res = list(ex.map(ticks_of, parts))
+        dta = time.perf_counter() - t0
+        parity["all_cores_sample"] = SA
+        parity["all_cores_P_bit_identical"] = bool(np.array_equal(self.dev["P"][:SA].cpu().numpy(), np.concatenate(res)))
+        return {"value": SA * self.launches / dta, "unit": "EKF steps/s", "cores": cores, "kind": "port",
                 "sample": "first %d filters of rank 0's batch x %d ticks, oracle/ekf_oracle.c (scalar C restatement of "
-                          "ekf.hpp:84-96,119-138), 1 thread, %.1f s" % (S, self.launches, dt)}, parity
+                          "ekf.hpp:84-96,119-138), static partition over %d threads, %.1f s" % (SA, self.launches, cores, dta),
+                "single_core": single}, parity
 
 
 WORKLOADS = {"mpc": MPCWorkload, "qp_dense": DenseQPWorkload, "ekf": EKFWorkload}
@@ -386,7 +454,7 @@ WORKLOADS = {"mpc": MPCWorkload, "qp_dense": DenseQPWorkload, "ekf": EKFWorkload
 # The sparse kernel mixes 16-byte streams (factor, vectors) with 8-byte gathers (factorisation, checks): x2 is exact
 # for the former (~85 % of its reads) and over-counts the latter, so its traffic figure is an upper bound (~ +10 %).
 FETCH_CORRECTION = {"mpc": 2.0, "ekf": 2.0, "qp_dense": 1.0 / 0.58}
-PROFILE_TAG = "r3"
+PROFILE_TAG = "r4"
 FP64_VALU_PEAK = 78.6e12  # MI355X vector FP64 (half the 157.3 TFLOP/s FP32 vector rate of MI355X_MICROARCH.md)
 
 
@@ -444,8 +512,8 @@ def roofline_of(workload, wl, kern_ms, with_traffic):
             r["traffic_frac"] = r["traffic"] / (kern_ms * 1e-3) / HBM_PEAK_BYTES_PER_S
             if workload == "mpc":
                 r["traffic_note"] = ("FETCH_SIZE / WRITE_SIZE count the L2's traffic with the fabric: more than half of it (the loop "
-                                     "launch's factor streams, profiles/r3_mpc/summary.json: qp_sparse_kernel<true>) is served by the "
-                                     "256 MB Infinity Cache, not by HBM -- an upper bound of the HBM bytes")
+                                     "launch's factor streams, profiles/%s_mpc/summary.json: qp_sparse_kernel<true>) is served by the "
+                                     "256 MB Infinity Cache, not by HBM -- an upper bound of the HBM bytes") % PROFILE_TAG
     return r
 
 
@@ -546,6 +614,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the multi-stream throughput measurement (mpc)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads reported next to the headline")
+    ap.add_argument("--no-closed-loop", action="store_true", help="skip the end-to-end / swarm-tick / single-agent figures (mpc)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -663,6 +732,8 @@ def main():
         if world == 1 and hasattr(wl, "pipelined") and not args.no_pipelined:
             rec["ordered_like_a_swarm_tick"] = wl.ordered_like_a_swarm_tick()
             rec["pipelined"] = wl.pipelined(max(4, 2 * args.steps))
+            if args.batch is None and not args.no_closed_loop:
+                rec["closed_loop"] = wl.closed_loop()
         if not args.no_cpu_baseline and world == 1:
             cores, cpuinfo = host_cpus()
             rec["cpu_baseline"], rec["parity_vs_oracle"] = wl.cpu_baseline(cores)

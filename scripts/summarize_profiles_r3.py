@@ -1,4 +1,5 @@
-"""gpurun_out/prof_r3_<name>/ (written by scripts/profile_r3.sh on the GPU box) -> profiles/r3_<name>/:
+"""gpurun_out/prof_<tag>_<name>/ (written by scripts/profile_r3.sh / profile_r4.sh on the GPU box) -> profiles/<tag>_<name>/
+(python scripts/summarize_profiles_r3.py [tag], default r3):
 kernel_stats.csv (rocprofv3's own --stats summary) and summary.json: per product kernel the per-dispatch means of its
 duration, of FETCH_SIZE / WRITE_SIZE and of the SQ / TCC counters (every counter group from its own pass), the
 launch resources rocprofv3 reports (VGPRs, LDS, grid) and a few derived ratios.  The keys bench.py reads for
@@ -12,17 +13,18 @@ DOMINANT = {"mpc": "qp_sparse_kernel", "mpc_phases": "qp_sparse_kernel", "qp_den
 
 
 def short(name):
-    n = name.replace("void ", "").replace("sfb::", "")
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("sfb::", "")
     return n.split("(")[0]
 
 
 def main():
     from bench import source_hash
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
     for wl in ("mpc", "mpc_phases", "qp_dense", "dense_mid", "ekf"):
-        src = os.path.join(ROOT, "gpurun_out", "prof_r3_%s" % wl)
+        src = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, wl))
         if not os.path.isdir(src):
             continue
-        dst = os.path.join(ROOT, "profiles", "r3_%s" % wl)
+        dst = os.path.join(ROOT, "profiles", "%s_%s" % (tag, wl))
         os.makedirs(dst, exist_ok=True)
         shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(dst, "kernel_stats.csv"))
         out = {"source_hash": source_hash(), "kernel_stats": [], "kernels": {}}

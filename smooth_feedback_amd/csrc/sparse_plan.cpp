@@ -35,6 +35,187 @@ void transpose_pattern(int nouter, int ninner, const std::vector<int32_t> &outer
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// BANK-AWARE PLACEMENT of the slots of one sweep unit.  The slots of a unit are independent (two of them never share a
+// target, and no pivot is a target of the same unit), so any slot may sit in any of the unit's 2 x lanes positions
+// (lane, half) without changing a bit.  What the position does change is which LDS accesses are served together: per
+// half the kernel issues ds_read_b64 t[piv], ds_read_b64 t[tgt] and ds_write_b64 t[tgt] for all lanes.  gfx950 serves
+// an 8-byte read in two groups of 32 lanes with 64 four-byte banks -- two doubles whose indices agree mod 32 collide
+// unless they are the same double (broadcast) -- and an 8-byte write in four groups of 16 lanes with 32 banks (indices
+// mod 16).  Every extra distinct address on a bank costs the group one more LDS cycle, on the dependent chain of a lone
+// wave.  Modelled cost of a unit = sum over the read groups of [max bank load of the targets + max bank load of the
+// distinct pivots] + sum over the write groups of [max bank load of the targets].
+struct UnitPlacer {
+  struct S { int32_t tgt, piv; };
+  int lanes = 0;
+  std::vector<S> sl;
+  std::vector<int> where;  // slot -> position (lane * 2 + half)
+
+  static int wgroup(int pos) { return (pos & 1) * 4 + ((pos >> 1) >> 4); }  // half * 4 + lane / 16
+  static int rgroup(int pos) { return (pos & 1) * 2 + ((pos >> 1) >> 5); }  // half * 2 + lane / 32
+  int capacity(int wg) const
+  {
+    const int l0 = (wg & 3) * 16;
+    return std::max(0, std::min(lanes, l0 + 16) - l0);
+  }
+  // exact modelled cycles of the slot set `members` as read group / write group
+  int read_cost(const std::vector<int> &members) const
+  {
+    int tl[32] = {0}, pl[32] = {0}, mt = 0, mp = 0;
+    int32_t seen[128];
+    int ns = 0;
+    for (int e : members) {
+      mt = std::max(mt, ++tl[sl[e].tgt & 31]);
+      bool dup = false;
+      for (int i = 0; i < ns; ++i) dup = dup || seen[i] == sl[e].piv;
+      if (!dup) {
+        seen[ns++] = sl[e].piv;
+        mp = std::max(mp, ++pl[sl[e].piv & 31]);
+      }
+    }
+    return mt + mp;
+  }
+  int write_cost(const std::vector<int> &members) const
+  {
+    int tl[16] = {0}, mt = 0;
+    for (int e : members) mt = std::max(mt, ++tl[sl[e].tgt & 15]);
+    return mt;
+  }
+  int total_cost(const std::vector<int> (&wg)[8]) const
+  {
+    int c = 0;
+    for (int g = 0; g < 8; ++g) c += write_cost(wg[g]);
+    for (int r = 0; r < 4; ++r) {
+      std::vector<int> m(wg[2 * r]);
+      m.insert(m.end(), wg[2 * r + 1].begin(), wg[2 * r + 1].end());
+      c += read_cost(m);
+    }
+    return c;
+  }
+  // cost of the natural placement (slot e at lane e % lanes, half e / lanes) -- what the schedule used before
+  int natural(std::vector<int> (&wg)[8]) const
+  {
+    for (auto &g : wg) g.clear();
+    for (int e = 0; e < (int)sl.size(); ++e) wg[wgroup((e % lanes) * 2 + e / lanes)].push_back(e);
+    return total_cost(wg);
+  }
+  // returns {modelled cycles before, after}; `where` filled
+  std::pair<int, int> place()
+  {
+    const int c = (int)sl.size();
+    std::vector<int> wg[8];
+    const int before = natural(wg);
+    std::vector<int> best[8];
+    for (int g = 0; g < 8; ++g) best[g] = wg[g];
+    int best_cost = before;
+    // greedy: slots of the same pivot together (largest columns first), each into the write group where it adds the
+    // fewest collisions; ties go to the group that already reads the pivot, then to the emptier group
+    std::vector<int> order(c);
+    std::iota(order.begin(), order.end(), 0);
+    std::vector<int> pcount(c, 0);
+    for (int e = 0; e < c; ++e)
+      for (int f = 0; f < c; ++f) pcount[e] += sl[f].piv == sl[e].piv;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      if (pcount[a] != pcount[b]) return pcount[a] > pcount[b];
+      if (sl[a].piv != sl[b].piv) return sl[a].piv < sl[b].piv;
+      return sl[a].tgt < sl[b].tgt;
+    });
+    std::vector<int> g2[8];
+    for (int e : order) {
+      int bg = -1;
+      long bscore = 0;
+      for (int g = 0; g < 8; ++g) {
+        if ((int)g2[g].size() >= capacity(g)) continue;
+        const int r = g >> 1;
+        int tcol = 0, pcol = 0, wcol = 0;
+        bool has_piv = false;
+        int32_t pv[64];
+        int npv = 0;
+        for (int gg = 2 * r; gg < 2 * r + 2; ++gg)
+          for (int f : g2[gg]) {
+            tcol += (sl[f].tgt & 31) == (sl[e].tgt & 31);
+            if (sl[f].piv == sl[e].piv) has_piv = true;
+            else if ((sl[f].piv & 31) == (sl[e].piv & 31)) {
+              bool dup = false;
+              for (int i = 0; i < npv; ++i) dup = dup || pv[i] == sl[f].piv;
+              if (!dup && npv < 64) pv[npv++] = sl[f].piv;
+            }
+          }
+        pcol = has_piv ? 0 : npv;
+        for (int f : g2[g]) wcol += (sl[f].tgt & 15) == (sl[e].tgt & 15);
+        const long score = 1000L * (tcol + pcol + wcol) + (has_piv ? 0 : 100) + (long)g2[g].size();
+        if (bg < 0 || score < bscore) { bg = g; bscore = score; }
+      }
+      g2[bg].push_back(e);
+    }
+    int cost = total_cost(g2);
+    // local search over the slots that sit on an over-subscribed bank: swap with a slot of another write group (or
+    // move into its free capacity) whenever the modelled cost of the groups involved drops
+    auto rcost = [&](int r) {
+      std::vector<int> m(g2[2 * r]);
+      m.insert(m.end(), g2[2 * r + 1].begin(), g2[2 * r + 1].end());
+      return read_cost(m);
+    };
+    auto pair_cost = [&](int g, int h) {  // read + write cost of everything the write groups g and h take part in
+      int cst = write_cost(g2[g]) + write_cost(g2[h]) + rcost(g >> 1);
+      if ((h >> 1) != (g >> 1)) cst += rcost(h >> 1);
+      return cst;
+    };
+    auto is_bad = [&](int g, size_t ia) {
+      const int e = g2[g][ia], r = g >> 1;
+      int tl = 0, wl = 0;
+      bool pconf = false;
+      for (int gg = 2 * r; gg < 2 * r + 2; ++gg)
+        for (int f : g2[gg]) {
+          tl += (sl[f].tgt & 31) == (sl[e].tgt & 31);
+          pconf = pconf || (sl[f].piv != sl[e].piv && (sl[f].piv & 31) == (sl[e].piv & 31));
+        }
+      for (int f : g2[g]) wl += (sl[f].tgt & 15) == (sl[e].tgt & 15);
+      return tl > 1 || wl > 1 || pconf;
+    };
+    for (int pass = 0; pass < 3 && cost > 16; ++pass) {
+      bool improved = false;
+      for (int g = 0; g < 8; ++g)
+        for (size_t ia = 0; ia < g2[g].size(); ++ia) {
+          if (!is_bad(g, ia)) continue;
+          bool moved = false;
+          for (int h = 0; h < 8 && !moved; ++h) {
+            if (h == g) continue;
+            const int c0 = pair_cost(g, h);
+            for (size_t ib = 0; ib < g2[h].size() && !moved; ++ib) {
+              std::swap(g2[g][ia], g2[h][ib]);
+              if (pair_cost(g, h) < c0) moved = true;
+              else std::swap(g2[g][ia], g2[h][ib]);
+            }
+            if (!moved && (int)g2[h].size() < capacity(h)) {
+              const std::vector<int> sg(g2[g]), sh(g2[h]);
+              g2[h].push_back(g2[g][ia]);
+              g2[g].erase(g2[g].begin() + (long)ia);
+              if (pair_cost(g, h) < c0) moved = true;
+              else { g2[g] = sg; g2[h] = sh; }
+            }
+          }
+          if (moved) {
+            improved = true;
+            if (ia >= g2[g].size()) break;
+          }
+        }
+      cost = total_cost(g2);
+      if (!improved) break;
+    }
+    if (cost < best_cost) {
+      best_cost = cost;
+      for (int g = 0; g < 8; ++g) best[g] = g2[g];
+    }
+    where.assign(c, -1);
+    for (int g = 0; g < 8; ++g) {
+      const int half = g >> 2, l0 = (g & 3) * 16;
+      for (size_t i = 0; i < best[g].size(); ++i) where[best[g][i]] = (l0 + (int)i) * 2 + half;
+    }
+    return {before, best_cost};
+  }
+};
+
 // Minimum-degree ordering on the symmetric KKT graph with explicit fill (bitset adjacency).
 // k is at most a few thousand for the problems of this path; O(k^2 * k/64) is fine on the host.
 std::vector<int32_t> min_degree_order(int k, const std::vector<std::pair<int, int>> &edges, const int32_t *stage)
@@ -644,18 +825,30 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
     // the scratch entry k, whatever value the register holds).  full0/full1: the longest run of completely filled
     // units, cut to multiples of 8; the kernel uses unmasked loads there.
     xmask.assign((size_t)units + 2 * SparsePlanHost::kSweepPad, 63);  // padding units: lane 0 only
+    // SFB_PLAN_BANKS=0: the natural placement (slot e at lane e % lanes, half e / lanes) instead of the bank-aware one
+    const bool bank_aware = [] { const char *v = sfb::knob("SFB_PLAN_BANKS"); return !(v && v[0] == '0'); }();
+    long cyc_before = 0, cyc_after = 0;
+    UnitPlacer up;
     for (int s = 0; s < steps; ++s) {
       const int lanes = std::max(1, ((int)slots[s].size() + 1) / 2);
       xmask[s]        = 64 - lanes;  // exec = all ones >> (64 - lanes)
+      // step s -> unit s; the leading `lanes` lanes carry everything, two slots per lane (UnitPlacer: which slot where)
+      up.lanes = lanes;
+      up.sl.clear();
+      for (const auto &e : slots[s]) up.sl.push_back({e[1], e[2]});
+      const auto cyc = up.place();
+      cyc_before += cyc.first;
+      cyc_after += bank_aware ? cyc.second : cyc.first;
       for (size_t e = 0; e < slots[s].size(); ++e) {
-        // step s -> unit s, lane e % lanes, slot e / lanes: the leading `lanes` lanes carry everything, and slots
-        // that follow each other in the sweep order (neighbouring rows of one column) sit in neighbouring lanes
-        // (LDS banks); a full unit is lane e % 64, slot e / 64
-        const size_t q = ((size_t)s * 64 + (e % (size_t)lanes)) * 2 + (e / (size_t)lanes);
+        const int pos  = bank_aware ? up.where[e] : (int)((e % (size_t)lanes) * 2 + e / (size_t)lanes);
+        const size_t q = (size_t)s * 128 + (size_t)pos;
         xmap[q] = acc_of(slots[s][e][0]);
         xidx[q] = (slots[s][e][1] * sc) | ((slots[s][e][2] * sc) << 16);
       }
     }
+    if (const char *dbg = sfb::knob("SFB_PLAN_DEBUG"); dbg && dbg[0] == '1')
+      fprintf(stderr, "[sfb plan] %s sweep: modelled LDS cycles of the slot accesses per sweep: natural placement %ld, bank-aware %ld (floor %d)\n",
+              forward ? "forward" : "backward", cyc_before, cyc_after, 16 * steps);
     full0 = full1 = 0;
     for (int s = 0; s < steps;) {
       if ((int)slots[s].size() != cap) { ++s; continue; }
