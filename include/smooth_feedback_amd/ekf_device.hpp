@@ -180,28 +180,43 @@ public:
   void reset(const std::vector<G> & g, const std::vector<CovT> & P)
   {
     if ((int64_t)g.size() != B_ || (int64_t)P.size() != B_) throw std::invalid_argument("EKFSwarmDevice: one state and covariance per filter");
-    detail::ekf_hip_check(hipMemcpy(g_, g.data(), (size_t)B_ * sizeof(G), hipMemcpyHostToDevice), "hipMemcpy(states)");
-    detail::ekf_hip_check(hipMemcpy(P_, P.data(), (size_t)B_ * sizeof(CovT), hipMemcpyHostToDevice), "hipMemcpy(covariances)");
+    reset(g.data(), P.data());
   }
   /// ekf.hpp:61 / :66 (device -> host)
   std::vector<G> estimates() const
   {
     std::vector<G> out((size_t)B_);
-    detail::ekf_hip_check(hipMemcpy(out.data(), g_, (size_t)B_ * sizeof(G), hipMemcpyDeviceToHost), "hipMemcpy(states)");
+    estimates(out.data());
     return out;
   }
   std::vector<CovT> covariances() const
   {
     std::vector<CovT> out((size_t)B_);
-    detail::ekf_hip_check(hipMemcpy(out.data(), P_, (size_t)B_ * sizeof(CovT), hipMemcpyDeviceToHost), "hipMemcpy(covariances)");
+    covariances(out.data());
     return out;
   }
   /// 1 where the LDL' of the innovation covariance failed in the last update (the reference does not check)
   std::vector<int32_t> update_info() const
   {
     std::vector<int32_t> out((size_t)B_);
-    detail::ekf_hip_check(hipMemcpy(out.data(), info_, (size_t)B_ * 4, hipMemcpyDeviceToHost), "hipMemcpy(info)");
+    update_info(out.data());
     return out;
+  }
+  /// the same on arrays of size() entries (a shard of a larger swarm: multi_device.hpp)
+  void reset(const G * g, const CovT * P)
+  {
+    detail::ekf_hip_check(hipMemcpy(g_, g, (size_t)B_ * sizeof(G), hipMemcpyHostToDevice), "hipMemcpy(states)");
+    detail::ekf_hip_check(hipMemcpy(P_, P, (size_t)B_ * sizeof(CovT), hipMemcpyHostToDevice), "hipMemcpy(covariances)");
+  }
+  void estimates(G * out) const { detail::ekf_hip_check(hipMemcpy(out, g_, (size_t)B_ * sizeof(G), hipMemcpyDeviceToHost), "hipMemcpy(states)"); }
+  void covariances(CovT * out) const
+  {
+    detail::ekf_hip_check(hipMemcpy(out, P_, (size_t)B_ * sizeof(CovT), hipMemcpyDeviceToHost), "hipMemcpy(covariances)");
+  }
+  void update_info(int32_t * out) const { detail::ekf_hip_check(hipMemcpy(out, info_, (size_t)B_ * 4, hipMemcpyDeviceToHost), "hipMemcpy(info)"); }
+  void upload_measurements(const Vec<Ny> * y)
+  {
+    detail::ekf_hip_check(hipMemcpy(y_, y, (size_t)B_ * sizeof(Vec<Ny>), hipMemcpyHostToDevice), "hipMemcpy(measurements)");
   }
   /// resident buffers, for callers that produce measurements or consume estimates on the device
   G * device_estimates() { return g_; }
@@ -275,7 +290,7 @@ private:
   void upload_measurements(const std::vector<Vec<Ny>> & y)
   {
     if ((int64_t)y.size() != B_) throw std::invalid_argument("EKFSwarmDevice: one measurement per filter");
-    detail::ekf_hip_check(hipMemcpy(y_, y.data(), (size_t)B_ * sizeof(Vec<Ny>), hipMemcpyHostToDevice), "hipMemcpy(measurements)");
+    upload_measurements(y.data());
   }
   dim3 grid() const { return dim3((unsigned)((B_ + 63) / 64)); }
   void linearise_dyn(double t, double h)

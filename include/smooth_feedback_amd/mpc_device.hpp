@@ -157,8 +157,15 @@ public:
   void step(const std::vector<double> & t, const std::vector<X> & xs, std::vector<U> & us, std::vector<QPSolutionStatus> & codes)
   {
     if ((int64_t)t.size() != B_ || (int64_t)xs.size() != B_) throw std::invalid_argument("MPCSwarmDeviceLin: one time and state per agent");
-    detail::mpc_hip_check(hipMemcpy(dt_, t.data(), (size_t)B_ * 8, hipMemcpyHostToDevice), "hipMemcpy(t)");
-    detail::mpc_hip_check(hipMemcpy(dx_, xs.data(), (size_t)B_ * sizeof(X), hipMemcpyHostToDevice), "hipMemcpy(x)");
+    us.resize((size_t)B_);
+    codes.resize((size_t)B_);
+    step(t.data(), xs.data(), us.data(), codes.data());
+  }
+  /// the same on arrays of size() entries (a shard of a larger swarm: multi_device.hpp)
+  void step(const double * t, const X * xs, U * us, QPSolutionStatus * codes)
+  {
+    detail::mpc_hip_check(hipMemcpy(dt_, t, (size_t)B_ * 8, hipMemcpyHostToDevice), "hipMemcpy(t)");
+    detail::mpc_hip_check(hipMemcpy(dx_, xs, (size_t)B_ * sizeof(X), hipMemcpyHostToDevice), "hipMemcpy(x)");
     linearise();
     int misfit = 0;
     detail::mpc_hip_check(hipMemcpy(&misfit, dmisfit_, sizeof(int), hipMemcpyDeviceToHost), "hipMemcpy(flag)");
@@ -173,13 +180,12 @@ public:
     const sfb_qp_params c = mpc_.solver().params().to_c();
     sfb_check(sfb_mpc_swarm_step_resident(swarm_, &c, mpc_.params().warmstart ? 1 : 0, du0_.data(), iter_.data(), code_.data(), nullptr,
                                           nullptr));
-    us.resize((size_t)B_);
-    codes.resize((size_t)B_);
     for (int64_t b = 0; b < B_; ++b) {
       us[(size_t)b]    = mpc_.input_from_du0(t[(size_t)b], &du0_[(size_t)b * Nu]);
       codes[(size_t)b] = static_cast<QPSolutionStatus>(code_[(size_t)b]);
     }
   }
+  int64_t size() const { return B_; }
   const std::vector<uint32_t> & iterations() const { return iter_; }
   bool packed_records() const { return packed_; }
   int64_t record_doubles() const { return map_.rec_doubles; }

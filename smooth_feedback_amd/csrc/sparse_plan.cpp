@@ -51,168 +51,165 @@ struct UnitPlacer {
   std::vector<S> sl;
   std::vector<int> where;  // slot -> position (lane * 2 + half)
 
-  static int wgroup(int pos) { return (pos & 1) * 4 + ((pos >> 1) >> 4); }  // half * 4 + lane / 16
-  static int rgroup(int pos) { return (pos & 1) * 2 + ((pos >> 1) >> 5); }  // half * 2 + lane / 32
+  // write group g = half * 4 + lane / 16 (8 of them), read group r = g / 2 = half * 2 + lane / 32
   int capacity(int wg) const
   {
     const int l0 = (wg & 3) * 16;
     return std::max(0, std::min(lanes, l0 + 16) - l0);
   }
-  // exact modelled cycles of the slot set `members` as read group / write group
-  int read_cost(const std::vector<int> &members) const
+  // bank occupancy of a placement, kept incrementally
+  std::vector<int> pid;      // slot -> index of its pivot among the unit's distinct pivots
+  std::vector<int> pbank;    // distinct pivot -> bank
+  int np = 0;
+  // bank loads with their maximum kept up to date in O(1) (histogram of the loads)
+  template<int NBANK>
+  struct Banks {
+    int n[NBANK], hist[130], mx;
+    void clear() { std::fill(n, n + NBANK, 0); std::fill(hist, hist + 130, 0); hist[0] = NBANK; mx = 0; }
+    void inc(int b) { hist[n[b]]--; hist[++n[b]]++; if (n[b] > mx) mx = n[b]; }
+    void dec(int b) { hist[n[b]]--; hist[--n[b]]++; while (mx > 0 && hist[mx] == 0) --mx; }
+  };
+  Banks<32> tc[4], pb[4];
+  Banks<16> wc[8];
+  std::vector<int> pc[4];    // per read group: slots per distinct pivot
+  void reset()
   {
-    int tl[32] = {0}, pl[32] = {0}, mt = 0, mp = 0;
-    int32_t seen[128];
-    int ns = 0;
-    for (int e : members) {
-      mt = std::max(mt, ++tl[sl[e].tgt & 31]);
-      bool dup = false;
-      for (int i = 0; i < ns; ++i) dup = dup || seen[i] == sl[e].piv;
-      if (!dup) {
-        seen[ns++] = sl[e].piv;
-        mp = std::max(mp, ++pl[sl[e].piv & 31]);
-      }
-    }
-    return mt + mp;
+    for (auto &b : tc) b.clear();
+    for (auto &b : pb) b.clear();
+    for (auto &b : wc) b.clear();
+    for (auto &v : pc) v.assign((size_t)np, 0);
   }
-  int write_cost(const std::vector<int> &members) const
+  void add(int e, int g, int d)  // d = +1 / -1
   {
-    int tl[16] = {0}, mt = 0;
-    for (int e : members) mt = std::max(mt, ++tl[sl[e].tgt & 15]);
-    return mt;
-  }
-  int total_cost(const std::vector<int> (&wg)[8]) const
-  {
-    int c = 0;
-    for (int g = 0; g < 8; ++g) c += write_cost(wg[g]);
-    for (int r = 0; r < 4; ++r) {
-      std::vector<int> m(wg[2 * r]);
-      m.insert(m.end(), wg[2 * r + 1].begin(), wg[2 * r + 1].end());
-      c += read_cost(m);
+    const int r = g >> 1;
+    int &n = pc[r][pid[e]];
+    if (d > 0) {
+      tc[r].inc(sl[e].tgt & 31);
+      wc[g].inc(sl[e].tgt & 15);
+      if (n++ == 0) pb[r].inc(pbank[pid[e]]);
+    } else {
+      tc[r].dec(sl[e].tgt & 31);
+      wc[g].dec(sl[e].tgt & 15);
+      if (--n == 0) pb[r].dec(pbank[pid[e]]);
     }
+  }
+  int rcost(int r) const { return tc[r].mx + pb[r].mx; }
+  int wcost(int g) const { return wc[g].mx; }
+  int cost_of(int g, int h) const  // everything the write groups g and h take part in
+  {
+    int c = wcost(g) + wcost(h) + rcost(g >> 1);
+    if ((h >> 1) != (g >> 1)) c += rcost(h >> 1);
     return c;
   }
-  // cost of the natural placement (slot e at lane e % lanes, half e / lanes) -- what the schedule used before
-  int natural(std::vector<int> (&wg)[8]) const
+  int total() const
   {
-    for (auto &g : wg) g.clear();
-    for (int e = 0; e < (int)sl.size(); ++e) wg[wgroup((e % lanes) * 2 + e / lanes)].push_back(e);
-    return total_cost(wg);
+    int c = 0;
+    for (int g = 0; g < 8; ++g) c += wcost(g);
+    for (int r = 0; r < 4; ++r) c += rcost(r);
+    return c;
   }
-  // returns {modelled cycles before, after}; `where` filled
-  std::pair<int, int> place()
+  bool bad(int e, int g) const  // on a bank that sets the cost of its group
+  {
+    const int r = g >> 1;
+    const int t = tc[r].n[sl[e].tgt & 31], w = wc[g].n[sl[e].tgt & 15], p = pb[r].n[pbank[pid[e]]];
+    return (t > 1 && t == tc[r].mx) || (w > 1 && w == wc[g].mx) || (p > 1 && p == pb[r].mx);
+  }
+  // returns {modelled cycles of the natural placement, of the chosen one}; `where` filled.  search: local search passes
+  std::pair<int, int> place(const int search)
   {
     const int c = (int)sl.size();
-    std::vector<int> wg[8];
-    const int before = natural(wg);
-    std::vector<int> best[8];
-    for (int g = 0; g < 8; ++g) best[g] = wg[g];
-    int best_cost = before;
-    // greedy: slots of the same pivot together (largest columns first), each into the write group where it adds the
-    // fewest collisions; ties go to the group that already reads the pivot, then to the emptier group
-    std::vector<int> order(c);
+    // distinct pivots
+    pid.assign((size_t)c, 0);
+    pbank.clear();
+    {
+      std::vector<std::pair<int32_t, int>> pv;
+      for (int e = 0; e < c; ++e) pv.emplace_back(sl[e].piv, e);
+      std::sort(pv.begin(), pv.end());
+      np = 0;
+      for (int i = 0; i < c; ++i) {
+        if (i == 0 || pv[i].first != pv[i - 1].first) { pbank.push_back(pv[i].first & 31); ++np; }
+        pid[pv[i].second] = np - 1;
+      }
+    }
+    std::vector<int> grp((size_t)c);
+    // natural placement: slot e at lane e % lanes, half e / lanes
+    reset();
+    for (int e = 0; e < c; ++e) {
+      const int lane = e % lanes, half = e / lanes;
+      grp[e] = half * 4 + (lane >> 4);
+      add(e, grp[e], +1);
+    }
+    const int before = total();
+    std::vector<int> natural(grp);
+    // greedy: the slots of a pivot together (largest columns first), each into the write group where it adds the fewest
+    // collisions; ties go to a group that already reads the pivot, then to the emptier one
+    std::vector<int> cnt((size_t)np, 0), order((size_t)c), fill(8, 0);
+    for (int e = 0; e < c; ++e) cnt[pid[e]]++;
     std::iota(order.begin(), order.end(), 0);
-    std::vector<int> pcount(c, 0);
-    for (int e = 0; e < c; ++e)
-      for (int f = 0; f < c; ++f) pcount[e] += sl[f].piv == sl[e].piv;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-      if (pcount[a] != pcount[b]) return pcount[a] > pcount[b];
-      if (sl[a].piv != sl[b].piv) return sl[a].piv < sl[b].piv;
-      return sl[a].tgt < sl[b].tgt;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+      if (cnt[pid[x]] != cnt[pid[y]]) return cnt[pid[x]] > cnt[pid[y]];
+      if (pid[x] != pid[y]) return pid[x] < pid[y];
+      return sl[x].tgt < sl[y].tgt;
     });
-    std::vector<int> g2[8];
+    reset();
     for (int e : order) {
       int bg = -1;
-      long bscore = 0;
+      long bs = 0;
       for (int g = 0; g < 8; ++g) {
-        if ((int)g2[g].size() >= capacity(g)) continue;
+        if (fill[g] >= capacity(g)) continue;
         const int r = g >> 1;
-        int tcol = 0, pcol = 0, wcol = 0;
-        bool has_piv = false;
-        int32_t pv[64];
-        int npv = 0;
-        for (int gg = 2 * r; gg < 2 * r + 2; ++gg)
-          for (int f : g2[gg]) {
-            tcol += (sl[f].tgt & 31) == (sl[e].tgt & 31);
-            if (sl[f].piv == sl[e].piv) has_piv = true;
-            else if ((sl[f].piv & 31) == (sl[e].piv & 31)) {
-              bool dup = false;
-              for (int i = 0; i < npv; ++i) dup = dup || pv[i] == sl[f].piv;
-              if (!dup && npv < 64) pv[npv++] = sl[f].piv;
-            }
-          }
-        pcol = has_piv ? 0 : npv;
-        for (int f : g2[g]) wcol += (sl[f].tgt & 15) == (sl[e].tgt & 15);
-        const long score = 1000L * (tcol + pcol + wcol) + (has_piv ? 0 : 100) + (long)g2[g].size();
-        if (bg < 0 || score < bscore) { bg = g; bscore = score; }
+        const bool has = pc[r][pid[e]] > 0;
+        const int col = tc[r].n[sl[e].tgt & 31] + wc[g].n[sl[e].tgt & 15] + (has ? 0 : pb[r].n[pbank[pid[e]]]);
+        const long score = 1000L * col + (has ? 0 : 100) + fill[g];
+        if (bg < 0 || score < bs) { bg = g; bs = score; }
       }
-      g2[bg].push_back(e);
+      grp[e] = bg;
+      fill[bg]++;
+      add(e, bg, +1);
     }
-    int cost = total_cost(g2);
-    // local search over the slots that sit on an over-subscribed bank: swap with a slot of another write group (or
-    // move into its free capacity) whenever the modelled cost of the groups involved drops
-    auto rcost = [&](int r) {
-      std::vector<int> m(g2[2 * r]);
-      m.insert(m.end(), g2[2 * r + 1].begin(), g2[2 * r + 1].end());
-      return read_cost(m);
-    };
-    auto pair_cost = [&](int g, int h) {  // read + write cost of everything the write groups g and h take part in
-      int cst = write_cost(g2[g]) + write_cost(g2[h]) + rcost(g >> 1);
-      if ((h >> 1) != (g >> 1)) cst += rcost(h >> 1);
-      return cst;
-    };
-    auto is_bad = [&](int g, size_t ia) {
-      const int e = g2[g][ia], r = g >> 1;
-      int tl = 0, wl = 0;
-      bool pconf = false;
-      for (int gg = 2 * r; gg < 2 * r + 2; ++gg)
-        for (int f : g2[gg]) {
-          tl += (sl[f].tgt & 31) == (sl[e].tgt & 31);
-          pconf = pconf || (sl[f].piv != sl[e].piv && (sl[f].piv & 31) == (sl[e].piv & 31));
-        }
-      for (int f : g2[g]) wl += (sl[f].tgt & 15) == (sl[e].tgt & 15);
-      return tl > 1 || wl > 1 || pconf;
-    };
-    for (int pass = 0; pass < 3 && cost > 16; ++pass) {
+    // local search: a slot on an over-subscribed bank swaps with a slot of another write group (or moves into free
+    // capacity there) whenever that lowers the modelled cycles of the groups involved
+    int nrg = 0, nwg = 0;  // groups in use: their count is the floor of the model
+    for (int g = 0; g < 8; ++g) nwg += capacity(g) > 0;
+    for (int r = 0; r < 4; ++r) nrg += capacity(2 * r) > 0;
+    for (int pass = 0; pass < search && total() > 2 * nrg + nwg; ++pass) {
       bool improved = false;
-      for (int g = 0; g < 8; ++g)
-        for (size_t ia = 0; ia < g2[g].size(); ++ia) {
-          if (!is_bad(g, ia)) continue;
-          bool moved = false;
-          for (int h = 0; h < 8 && !moved; ++h) {
-            if (h == g) continue;
-            const int c0 = pair_cost(g, h);
-            for (size_t ib = 0; ib < g2[h].size() && !moved; ++ib) {
-              std::swap(g2[g][ia], g2[h][ib]);
-              if (pair_cost(g, h) < c0) moved = true;
-              else std::swap(g2[g][ia], g2[h][ib]);
-            }
-            if (!moved && (int)g2[h].size() < capacity(h)) {
-              const std::vector<int> sg(g2[g]), sh(g2[h]);
-              g2[h].push_back(g2[g][ia]);
-              g2[g].erase(g2[g].begin() + (long)ia);
-              if (pair_cost(g, h) < c0) moved = true;
-              else { g2[g] = sg; g2[h] = sh; }
-            }
-          }
-          if (moved) {
-            improved = true;
-            if (ia >= g2[g].size()) break;
-          }
+      for (int a = 0; a < c; ++a) {
+        if (!bad(a, grp[a])) continue;
+        const int g = grp[a];
+        bool moved = false;
+        for (int h = 0; h < 8 && !moved; ++h) {  // free capacity first
+          if (h == g || fill[h] >= capacity(h)) continue;
+          const int c0 = cost_of(g, h);
+          add(a, g, -1); add(a, h, +1);
+          if (cost_of(g, h) < c0) { grp[a] = h; fill[g]--; fill[h]++; moved = true; }
+          else { add(a, h, -1); add(a, g, +1); }
         }
-      cost = total_cost(g2);
+        for (int b = 0; b < c && !moved; ++b) {
+          const int h = grp[b];
+          if (h == g) continue;
+          const int c0 = cost_of(g, h);
+          add(a, g, -1); add(b, h, -1); add(a, h, +1); add(b, g, +1);
+          if (cost_of(g, h) < c0) { grp[a] = h; grp[b] = g; moved = true; }
+          else { add(a, h, -1); add(b, g, -1); add(a, g, +1); add(b, h, +1); }
+        }
+        improved = improved || moved;
+      }
       if (!improved) break;
     }
-    if (cost < best_cost) {
-      best_cost = cost;
-      for (int g = 0; g < 8; ++g) best[g] = g2[g];
+    int after = total();
+    if (after >= before) { grp = natural; after = before; }
+    where.assign((size_t)c, -1);
+    if (grp == natural) {
+      for (int e = 0; e < c; ++e) where[e] = (e % lanes) * 2 + e / lanes;
+    } else {
+      int nxt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int e = 0; e < c; ++e) {
+        const int g = grp[e], half = g >> 2, l0 = (g & 3) * 16;
+        where[e] = (l0 + nxt[g]++) * 2 + half;
+      }
     }
-    where.assign(c, -1);
-    for (int g = 0; g < 8; ++g) {
-      const int half = g >> 2, l0 = (g & 3) * 16;
-      for (size_t i = 0; i < best[g].size(); ++i) where[best[g][i]] = (l0 + (int)i) * 2 + half;
-    }
-    return {before, best_cost};
+    return {before, after};
   }
 };
 
@@ -829,6 +826,7 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
     const bool bank_aware = [] { const char *v = sfb::knob("SFB_PLAN_BANKS"); return !(v && v[0] == '0'); }();
     long cyc_before = 0, cyc_after = 0;
     UnitPlacer up;
+    const int search_passes = ns <= 20000 ? 1 : 0;  // (one pass does nearly everything; the large whole-pattern fallback plans get the greedy placement only)
     for (int s = 0; s < steps; ++s) {
       const int lanes = std::max(1, ((int)slots[s].size() + 1) / 2);
       xmask[s]        = 64 - lanes;  // exec = all ones >> (64 - lanes)
@@ -836,7 +834,7 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
       up.lanes = lanes;
       up.sl.clear();
       for (const auto &e : slots[s]) up.sl.push_back({e[1], e[2]});
-      const auto cyc = up.place();
+      const auto cyc = up.place(search_passes);
       cyc_before += cyc.first;
       cyc_after += bank_aware ? cyc.second : cyc.first;
       for (size_t e = 0; e < slots[s].size(); ++e) {
