@@ -641,19 +641,24 @@ def main():
 
     import smooth_feedback_amd as sfb
 
-    kw = {} if args.batch is None else {"batch": args.batch}
-    wl = WORKLOADS[args.workload](sfb, rank, device, **kw)
+    # Sharding (smooth_feedback_amd/sharding.py, the module the gloo tests cover): the job's batch is `world` times the
+    # per-GPU batch, rank r owns the contiguous range shard_range(total, r, world) of it -- weak scaling, so every range
+    # has the per-GPU size -- and the only exchange is gather_small_outputs of the per-item (u0, code, iter) rows.
+    from smooth_feedback_amd.sharding import gather_small_outputs, shard_range
+    per_gpu = args.batch if args.batch is not None else WORKLOADS[args.workload].__init__.__defaults__[0]
+    total = per_gpu * world
+    lo, hi = shard_range(total, rank, world)
+    wl = WORKLOADS[args.workload](sfb, rank, device, batch=hi - lo)
     stream = torch.cuda.current_stream()
     gathered = None
-    if world > 1:
-        gathered = [torch.empty_like(wl.small_outputs()) for _ in range(world)]
 
     def one_step():
+        nonlocal gathered
         if hasattr(wl, "pre_step"):
             wl.pre_step()
         wl.step(stream)
         if world > 1:  # the only exchange on this path: final gather of the small outputs (RCCL/xGMI)
-            dist.all_gather(gathered, wl.small_outputs())
+            gathered = gather_small_outputs(wl.small_outputs(), total)
 
     def barrier():
         if world > 1:
@@ -672,7 +677,7 @@ def main():
         wl.step(stream)
         ev[k][1].record(stream)
         if world > 1:
-            dist.all_gather(gathered, wl.small_outputs())
+            gathered = gather_small_outputs(wl.small_outputs(), total)
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -689,10 +694,11 @@ def main():
         cs[rank] = checksum(own)
         dist.all_reduce(cs, op=dist.ReduceOp.SUM)
         peers = [r for r in range(world) if r != rank]
-        gather_check = {"own_rows_intact": bool(torch.equal(gathered[rank], own)),
-                        "peer_rows_received": all(bool(checksum(gathered[r]) == cs[r]) for r in peers),
-                        "peer_rows_differ_from_own": all(not bool(torch.equal(gathered[r], own)) for r in peers),
-                        "ranks_checked": world}
+        rows = {r: gathered[slice(*shard_range(total, r, world))] for r in range(world)}  # rank r's rows of the gathered tensor
+        gather_check = {"own_rows_intact": bool(torch.equal(rows[rank], own)),
+                        "peer_rows_received": all(bool(checksum(rows[r]) == cs[r]) for r in peers),
+                        "peer_rows_differ_from_own": all(not bool(torch.equal(rows[r], own)) for r in peers),
+                        "gathered_rows": int(gathered.shape[0]), "ranks_checked": world}
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:

@@ -11,6 +11,7 @@
 #include <smooth_feedback_amd/asif_device.hpp>
 #include <smooth_feedback_amd/ekf_device.hpp>
 #include <smooth_feedback_amd/mpc_device.hpp>
+#include <smooth_feedback_amd/multi_device.hpp>
 
 #include "vehicle_model.h"
 
@@ -30,14 +31,12 @@ X perturbed(const X & x0, uint64_t seed)
   return rplus(x0, xi);
 }
 
-template<class MPCT, class Model>
-int devlin_step(int K, double tf, int64_t batch, uint64_t seed, int ticks, int probe_empty, double * u0, int32_t * codes, uint32_t * iters,
-                double * records, int64_t * record_doubles, int32_t * packed, double * seconds)
+// `ticks` closed-loop ticks of the swarm of sfbx_mpc_swarm_step through any swarm type with MPCSwarmDeviceLin's step()
+template<class Model, class Swarm>
+void devlin_loop(Swarm & swarm, const Model & mdl, int64_t batch, uint64_t seed, int ticks, double * u0, int32_t * codes, uint32_t * iters,
+                 double * seconds)
 {
   using X = decltype(std::declval<const Model &>().xdes(0.0));
-  const Model mdl{};
-  auto mpc = sfbx::make_vehicle_mpc<MPCT, Model>(K, tf);
-  MPCSwarmDeviceLin<MPCT, Model> swarm(mpc, mdl, batch, 0.0, probe_empty != 0);
   std::vector<double> t((size_t)batch);
   std::vector<X> xs((size_t)batch);
   for (int64_t b = 0; b < batch; ++b) {
@@ -63,9 +62,69 @@ int devlin_step(int K, double tf, int64_t batch, uint64_t seed, int ticks, int p
     codes[b] = (int32_t)cs[b];
     iters[b] = swarm.iterations()[b];
   }
+}
+
+template<class MPCT, class Model>
+int devlin_step(int K, double tf, int64_t batch, uint64_t seed, int ticks, int probe_empty, double * u0, int32_t * codes, uint32_t * iters,
+                double * records, int64_t * record_doubles, int32_t * packed, double * seconds)
+{
+  const Model mdl{};
+  auto mpc = sfbx::make_vehicle_mpc<MPCT, Model>(K, tf);
+  MPCSwarmDeviceLin<MPCT, Model> swarm(mpc, mdl, batch, 0.0, probe_empty != 0);
+  devlin_loop(swarm, mdl, batch, seed, ticks, u0, codes, iters, seconds);
   if (record_doubles) *record_doubles = swarm.record_doubles();
   if (packed) *packed = swarm.packed_records() ? 1 : 0;
   if (records) swarm.copy_records(records);
+  return 0;
+}
+
+template<class MPCT, class Model>
+int devlin_step_multi(int K, double tf, int64_t batch, uint64_t seed, int ticks, const int * devices, int ndev, int thread_per_shard, double * u0,
+                      int32_t * codes, uint32_t * iters, double * seconds)
+{
+  const Model mdl{};
+  auto mpc = sfbx::make_vehicle_mpc<MPCT, Model>(K, tf);
+  MPCSwarmMultiDeviceLin<MPCT, Model> swarm(mpc, mdl, batch, std::vector<int>(devices, devices + ndev));
+  swarm.shards().thread_per_shard(thread_per_shard != 0);
+  devlin_loop(swarm, mdl, batch, seed, ticks, u0, codes, iters, seconds);
+  return 0;
+}
+
+// the same rounds through EKFSwarmMultiDevice (fused: 0 = predict + update, 1 = step())
+template<EKFStepper Stp>
+int ekf_swarm_multi(int64_t batch, int steps, int fused, double tau, double dt, const int * devices, int ndev, int thread_per_shard,
+                    const double * states, const double * P0, const double * y, double * states_out, double * P_out, int32_t * info)
+{
+  EKFSwarmMultiDevice<X6, sfbx::VehicleEkfDyn, sfbx::VehicleEkfMeas, 3, Stp> swarm(sfbx::VehicleEkfDyn{}, sfbx::VehicleEkfMeas{}, batch,
+                                                                                  std::vector<int>(devices, devices + ndev));
+  swarm.shards().thread_per_shard(thread_per_shard != 0);
+  std::vector<X6> g((size_t)batch);
+  std::vector<Mat<6, 6>> P((size_t)batch);
+  for (int64_t b = 0; b < batch; ++b) {
+    g[b] = sfbx::vehicle_state(states + 7 * b);
+    std::copy(P0 + 36 * b, P0 + 36 * (b + 1), P[b].a.begin());
+  }
+  swarm.reset(g, P);
+  const auto Q = sfbx::vehicle_ekf_Q();
+  const auto R = sfbx::vehicle_ekf_R();
+  std::vector<Vec<3>> ys((size_t)batch);
+  for (int k = 0; k < steps; ++k) {
+    for (int64_t b = 0; b < batch; ++b) ys[b] = {y[((size_t)k * batch + b) * 3], y[((size_t)k * batch + b) * 3 + 1], y[((size_t)k * batch + b) * 3 + 2]};
+    if (fused) {
+      swarm.step(Q, tau, ys, R);
+    } else {
+      swarm.predict(Q, tau, dt > 0 ? std::optional<double>(dt) : std::nullopt);
+      swarm.update(ys, R);
+    }
+  }
+  g = swarm.estimates();
+  P = swarm.covariances();
+  const auto inf = swarm.update_info();
+  for (int64_t b = 0; b < batch; ++b) {
+    sfbx::vehicle_state_out(g[b], states_out + 7 * b);
+    std::copy(P[b].a.begin(), P[b].a.end(), P_out + 36 * b);
+    info[b] = inf[b];
+  }
   return 0;
 }
 
@@ -134,6 +193,38 @@ int sfbx_ekf_swarm_device(int64_t batch, int steps, int rk4, int fused, double t
     std::fprintf(stderr, "sfbx_ekf_swarm_device: %s\n", e.what());
     return -2;
   }
+}
+
+/* sfbx_ekf_swarm_device through EKFSwarmMultiDevice (multi_device.hpp): the filters sharded over `devices` (an ordinal may repeat),
+ * one resident swarm per shard.  thread_per_shard != 0: a host thread per shard even on one device (test hook). */
+int sfbx_ekf_swarm_device_multi(int64_t batch, int steps, int rk4, int fused, double tau, double dt, const int * devices, int ndev,
+                                int thread_per_shard, const double * states, const double * P0, const double * y, double * states_out,
+                                double * P_out, int32_t * info)
+{
+  try {
+    return rk4 ? ekf_swarm_multi<EKFStepper::RK4>(batch, steps, fused, tau, dt, devices, ndev, thread_per_shard, states, P0, y, states_out, P_out, info)
+               : ekf_swarm_multi<EKFStepper::Euler>(batch, steps, fused, tau, dt, devices, ndev, thread_per_shard, states, P0, y, states_out, P_out,
+                                                    info);
+  } catch (const std::exception & e) {
+    std::fprintf(stderr, "sfbx_ekf_swarm_device_multi: %s\n", e.what());
+    return -2;
+  }
+}
+
+/* sfbx_mpc_swarm_devlin_step through MPCSwarmMultiDeviceLin (multi_device.hpp): the agents sharded over `devices`. */
+int sfbx_mpc_swarm_devlin_step_multi(int variant, int K, double tf, int64_t batch, uint64_t seed, int ticks, const int * devices, int ndev,
+                                     int thread_per_shard, double * u0, int32_t * codes, uint32_t * iters, double * seconds)
+{
+  try {
+    if (variant == 6)
+      return devlin_step_multi<sfbx::MPC6, sfbx::VehicleModel6>(K, tf, batch, seed, ticks, devices, ndev, thread_per_shard, u0, codes, iters, seconds);
+    if (variant == 12)
+      return devlin_step_multi<sfbx::MPC12, sfbx::VehicleModel12>(K, tf, batch, seed, ticks, devices, ndev, thread_per_shard, u0, codes, iters, seconds);
+  } catch (const std::exception & e) {
+    std::fprintf(stderr, "sfbx_mpc_swarm_devlin_step_multi: %s\n", e.what());
+    return -2;
+  }
+  return -1;
 }
 
 /* examples/mpc_asif_vehicle.cpp:151-175 for a swarm, both controllers on the GPU: per 25 ms tick the MPC input of every vehicle

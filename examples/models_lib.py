@@ -215,6 +215,29 @@ def mpc_swarm_devlin_step(variant, K, batch, ticks, seed=1, tf=5.0, probe_empty=
     return out
 
 
+def mpc_swarm_devlin_step_multi(variant, K, batch, ticks, devices, seed=1, tf=5.0, thread_per_shard=False):
+    """MPCSwarmMultiDeviceLin (multi_device.hpp): mpc_swarm_devlin_step with the agents sharded over `devices` from this one
+    process, one resident swarm per shard."""
+    out = dict(u0=np.zeros((batch, 2)), code=np.zeros(batch, np.int32), iter=np.zeros(batch, np.uint32), seconds=np.zeros(ticks))
+    dev = (C.c_int * len(devices))(*devices)
+    rc = dev_lib().sfbx_mpc_swarm_devlin_step_multi(variant, K, C.c_double(tf), C.c_int64(batch), C.c_uint64(seed), ticks, dev, len(devices),
+                                                    int(thread_per_shard), _p(out["u0"]), _p(out["code"]), _p(out["iter"]), _p(out["seconds"]))
+    assert rc == 0, rc
+    return out
+
+
+def ekf_swarm_device_multi(states, P0, y, devices, tau=0.1, dt=0.0, rk4=False, fused=False, thread_per_shard=False):
+    """EKFSwarmMultiDevice (multi_device.hpp): ekf_swarm_device with the filters sharded over `devices`."""
+    batch, steps = len(states), len(y)
+    out = dict(states=np.zeros((batch, 7)), P=np.zeros((batch, 36)), info=np.zeros(batch, np.int32))
+    st = np.ascontiguousarray(states, dtype=np.float64); P0 = np.ascontiguousarray(P0, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
+    dev = (C.c_int * len(devices))(*devices)
+    rc = dev_lib().sfbx_ekf_swarm_device_multi(C.c_int64(batch), steps, int(rk4), int(fused), C.c_double(tau), C.c_double(dt), dev, len(devices),
+                                               int(thread_per_shard), _p(st), _p(P0), _p(y), _p(out["states"]), _p(out["P"]), _p(out["info"]))
+    assert rc == 0, rc
+    return out
+
+
 def ekf_swarm_inputs(batch, steps, seed=0):
     """states [batch][7] of asif_swarm_states, SPD covariances, measurements near the states' (x, y, v0)"""
     st, _ = asif_swarm_states(batch, seed)

@@ -74,3 +74,35 @@ def test_cpp_swarm_sharded_over_devices_equals_single_device(sfb):
     for a, b in zip(one, many):
         assert np.array_equal(a, b)
     assert (one[1] == 0).all() and one[2].max() > 25
+
+
+@pytest.mark.parametrize("devices,threads", [([0, 0, 0], False), ([0, 0], True), ([0] * 7, True)])
+def test_resident_mpc_swarm_sharded_over_devices_equals_single_device(sfb, devices, threads):
+    """MPCSwarmMultiDeviceLin (multi_device.hpp): one resident swarm per shard (own device memory, plan upload, workspace),
+    states up and u0 / code / iter down per tick.  Three closed-loop ticks (cold start, two warm starts) of 151 vehicles --
+    not divisible by the shard counts -- equal the single-device MPCSwarmDeviceLin bit for bit; with a host thread per
+    shard the shards use the device concurrently, as the threads of several devices would."""
+    one = M.mpc_swarm_devlin_step(6, 10, 151, 3, seed=5, want_records=False)
+    many = M.mpc_swarm_devlin_step_multi(6, 10, 151, 3, devices, seed=5, thread_per_shard=threads)
+    for key in ("u0", "code", "iter"):
+        assert np.array_equal(one[key], many[key]), key
+    assert (one["code"] == 0).all() and one["iter"].max() >= 2
+
+
+def test_resident_mpc_swarm_with_fewer_agents_than_devices(sfb):
+    one = M.mpc_swarm_devlin_step(6, 10, 2, 2, seed=3, want_records=False)
+    many = M.mpc_swarm_devlin_step_multi(6, 10, 2, 2, [0, 0, 0, 0, 0], seed=3)
+    for key in ("u0", "code", "iter"):
+        assert np.array_equal(one[key], many[key]), key
+
+
+@pytest.mark.parametrize("rk4,fused,threads", [(False, False, False), (False, True, True), (True, False, True)])
+def test_resident_ekf_swarm_sharded_over_devices_equals_single_device(sfb, rk4, fused, threads):
+    """EKFSwarmMultiDevice: 1 003 vehicle filters over {0, 0, 0}, three predict + update rounds (Euler substeps / one-launch
+    step() / RK4): estimates, covariances and the update info of the single-device EKFSwarmDevice, bit for bit."""
+    st, P0, y = M.ekf_swarm_inputs(1003, 3, seed=2)
+    kw = dict(tau=0.1, dt=0.0 if fused else 0.04, rk4=rk4, fused=fused)
+    one = M.ekf_swarm_device(st, P0, y, **kw)
+    many = M.ekf_swarm_device_multi(st, P0, y, [0, 0, 0], thread_per_shard=threads, **kw)
+    for key in ("states", "P", "info"):
+        assert np.array_equal(one[key], many[key]), key
