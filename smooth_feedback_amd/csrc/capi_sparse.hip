@@ -36,6 +36,7 @@ struct sfb_sparse_qp_plan {
     std::mutex mu;
     std::pair<char *, size_t> ws{nullptr, 0};  // (buffer, bytes)
     int64_t batch = -1;                        // batch of the last call whose workspace content is still in the buffer
+    uint64_t origin = 0;                       // who made that call: 0 = a direct host call, else the signature of a *_multi call
   };
   std::map<int, HostDev> host_dev;  // device ordinal -> state; entries are created under `mu` and never move
 };
@@ -46,6 +47,9 @@ const SparsePlanHost &plan_io(const sfb_sparse_qp_plan *plan) { return plan->pru
 }  // namespace sfb
 
 namespace {
+
+// set by sfb_sparse_qp_solve_batch_host_multi around its per-shard calls: signature of (device list, total batch)
+thread_local uint64_t tl_multi_origin = 0;
 
 // upload all index arrays of one host plan as one blob
 sfb_status upload_plan(const sfb::SparsePlanHost &h, const std::vector<int32_t> *Aorig, const std::vector<int32_t> *Amasked,
@@ -432,9 +436,13 @@ sfb_status sfb_sparse_qp_solve_batch_host_trace(sfb_sparse_qp_plan *plan, const 
   }
   // reuse_factor refers to "the previous call on this workspace": the workspace sits at the start of the cached
   // buffer, so it is the same memory, item for item, exactly when the batch size is that of the previous call
+  // -- and the call comes from where the previous one came from: a shard of a *_multi call holds the items its device
+  // list and total batch assign to this device, a direct call the caller's; equal shard SIZES alone do not make the
+  // items the same (the kernel re-checks c and rho only, which agree across the agents of an MPC swarm).
   sfb_qp_params prm_call = *prm;
-  if (hd->batch != batch) prm_call.reuse_factor = 0;
-  hd->batch = batch;
+  if (hd->batch != batch || hd->origin != tl_multi_origin) prm_call.reuse_factor = 0;
+  hd->batch  = batch;
+  hd->origin = tl_multi_origin;
   prm = &prm_call;
   char *devmem = cache.first;
   double *dws = reinterpret_cast<double *>(devmem);
@@ -510,19 +518,30 @@ sfb_status sfb_sparse_qp_solve_batch_host_multi(sfb_sparse_qp_plan *plan, const 
   // reuse_factor refers to "the previous call on this device's workspace": with a device listed twice two shards
   // share one workspace, and the claim cannot be kept
   sfb_qp_params prm_call = *prm;
+  uint64_t origin = 1469598103934665603ull;  // FNV-1a over (device list, batch): which items a device's shard holds
   {
     std::vector<int> d = sfb::device_list();
+    for (int v : d) origin = (origin ^ (uint64_t)(uint32_t)v) * 1099511628211ull;
+    origin = (origin ^ (uint64_t)batch) * 1099511628211ull;
+    if (origin == 0) origin = 1;
     std::sort(d.begin(), d.end());
     if (std::adjacent_find(d.begin(), d.end()) != d.end()) prm_call.reuse_factor = 0;
   }
-  prm = &prm_call;
-  return sfb::run_sharded(batch, [&](int, int64_t b0, int64_t cnt) {
+  prm_call.verbose = 0;  // (reported once for the whole call below, not once per shard)
+  const sfb_qp_params *const prm_shard = &prm_call;
+  const sfb_status rs = sfb::run_sharded(batch, [&](int, int64_t b0, int64_t cnt) {
     const size_t o = (size_t)b0;  // the plan uploads its tables to a device on first use; each device has its own workspace
-    return sfb_sparse_qp_solve_batch_host(plan, prm, cnt, Px ? Px + o * NP : nullptr, q + o * N, Ax ? Ax + o * NA : nullptr,
+    tl_multi_origin = origin;
+    const sfb_status s1 = sfb_sparse_qp_solve_batch_host(plan, prm_shard, cnt, Px ? Px + o * NP : nullptr, q + o * N, Ax ? Ax + o * NA : nullptr,
                                           l + o * M, u + o * M, warm_x ? warm_x + o * N : nullptr,
                                           warm_y ? warm_y + o * M : nullptr, x + o * N, y + o * M, obj ? obj + o : nullptr,
                                           iter ? iter + o : nullptr, code + o);
+    tl_multi_origin = 0;
+    return s1;
   });
+  if (rs == SFB_OK && prm->verbose)
+    sfb::verbose_report("sparse QP batch (sharded over the device list)", batch, h.n, h.m, 0.0, 0.0, 0.0, code, iter);
+  return rs;
 }
 
 }  // extern "C"

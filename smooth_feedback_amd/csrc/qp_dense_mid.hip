@@ -66,6 +66,11 @@ __device__ unsigned long long g_midprof[12];
 #define SFB_MID_W4 2
 #endif
 
+// registers-only sweeps for k <= 64 (0: the LDS block engine for every size; A/B builds)
+#ifndef SFB_MID_REGS
+#define SFB_MID_REGS 1
+#endif
+
 constexpr int kMidPadT = 8;  // zeros behind the packed triangle (the chunked dot products read up to 7 entries past a row)
 
 // LDS layout in doubles (host and device)
@@ -356,7 +361,7 @@ __device__ __forceinline__ void mvec(const double *const base, const size_t stri
 // Outlined: it runs once per stop_check_iter iterations and its registers stay out of the ADMM loop's budget.
 // Rows of the mat-vecs: constraint i = lane + 64 r (< m), variable j = lane + 64 r (< n); s = 0, inner index ascending, fma.
 template<int R>
-__device__ __attribute__((noinline)) int mid_stop_check(const int n_, const int m_, const int lane, const double *const P, const double *const q,
+__device__ __forceinline__ int mid_stop_check_body(const int n_, const int m_, const int lane, const double *const P, const double *const q,
                                                         const double *const A, const double *const l, const double *const u, lds_d *const V,
                                                         lds_d *const tmp, const double eps_abs, const double eps_rel, const double eps_pinf,
                                                         const double eps_dinf)
@@ -513,6 +518,16 @@ __device__ __attribute__((noinline)) int mid_stop_check(const int n_, const int 
     if (ok && !wave_ballot(!rowok)) return SFB_QP_DUAL_INFEASIBLE;
   }
   return -1;
+}
+
+// outlined instance (the LDS block engine: the check's registers stay out of the ADMM loop's budget)
+template<int R>
+__device__ __attribute__((noinline)) int mid_stop_check(const int n, const int m, const int lane, const double *const P, const double *const q,
+                                                        const double *const A, const double *const l, const double *const u, lds_d *const V,
+                                                        lds_d *const tmp, const double eps_abs, const double eps_rel, const double eps_pinf,
+                                                        const double eps_dinf)
+{
+  return mid_stop_check_body<R>(n, m, lane, P, q, A, l, u, V, tmp, eps_abs, eps_rel, eps_pinf, eps_dinf);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1144,7 +1159,15 @@ __device__ __forceinline__ bool mid_admm(const MidC &C, const DenseKernelParams 
       }
     }
   };
-  const rows::Masks masks = rows::make_masks();  // (once, in front of the loop: see sweep_rows.h)
+  // k <= 64: the factor moves into registers for the duration of the loop (sweep_rows.h, registers-only engine)
+  constexpr bool kRegs = NB <= 4 && SFB_MID_REGS != 0;
+  rows::Masks masks{};
+  if constexpr (!kRegs) masks = rows::make_masks();  // (once, in front of the loop: see sweep_rows.h)
+  rows::RegFactor<kRegs ? NB : 2> F;
+  if constexpr (kRegs) {
+    wave_lds_fence();
+    rows::reg_factor_load<NB>(F, k, (const double *)T, (const double *)Dg, lane);
+  }
   uint32_t it0 = iter;  // iteration at which this wave took the QP
   for (; iter != maxit && ret_code < 0; ++iter) {
     if constexpr (QUEUE) {
@@ -1161,16 +1184,23 @@ __device__ __forceinline__ bool mid_admm(const MidC &C, const DenseKernelParams 
       }
     }
     rows::Pair t{rhs(h[0]), R > 1 ? rhs(h[R - 1]) : 0.0};
-    t = rows::row_sweeps_inl<NB, false>(k, (const double *)T, (const double *)Dg, t, lane, masks);  // :462
+    if constexpr (kRegs) t.lo = rows::row_sweeps_reg<NB>(k, F, t.lo, lane);                              // :462
+    else t = rows::row_sweeps_inl<NB, false>(k, (const double *)T, (const double *)Dg, t, lane, masks);
     const bool chk = (iter == next_chk);                                                            // :465
     if (chk) next_chk += sci;
     upd(h[0], t.lo, chk);
     if constexpr (R > 1) upd(h[R - 1], t.hi, chk);
     if (chk) {
       wave_lds_fence();
-      ret_code = mid_stop_check<R>(n, m, lane, P, q, A, l, u, V, tmp, kp.eps_abs, kp.eps_rel, kp.eps_pinf, kp.eps_dinf);
+      // registers-only engine: the check is INLINED -- the factor registers are dead across it (re-filled from LDS behind
+      // it), so it works in them; an outlined call would save and restore the live registers through scratch memory
+      if constexpr (kRegs) ret_code = mid_stop_check_body<R>(n, m, lane, P, q, A, l, u, V, tmp, kp.eps_abs, kp.eps_rel, kp.eps_pinf, kp.eps_dinf);
+      else ret_code = mid_stop_check<R>(n, m, lane, P, q, A, l, u, V, tmp, kp.eps_abs, kp.eps_rel, kp.eps_pinf, kp.eps_dinf);
       if (ret_code < 0 && max_time_exceeded(kp.max_time_ns, t0_ticks)) ret_code = SFB_QP_MAX_TIME;  // :504-507
       wave_lds_fence();
+      // the factor registers are re-filled from LDS behind the outlined check instead of living across the call (the
+      // compiler would save and restore all of them through scratch memory at the call site)
+      if constexpr (kRegs) rows::reg_factor_load<NB>(F, k, (const double *)T, (const double *)Dg, lane);
     }
   }
   return false;

@@ -312,6 +312,183 @@ __device__ __forceinline__ Pair row_sweeps_inl(const int K_, const double *T_, c
   return Pair{tlo, thi};
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// REGISTERS-ONLY engine, K <= 64 (NB <= 4 blocks, one row per lane): the whole factor of the QP lives in VGPRs for
+// the duration of the ADMM loop and a sweep touches no LDS at all.
+//
+// The block engine above keeps the pivot block's chain replicated in all four 16-lane rows so that the riders can read
+// x_J while the chain is still running -- which makes every lane need the chain operands of EVERY block (16 NB doubles
+// if they were kept in registers).  Here the two are separated per pivot block JB:
+//   1. chain: the in-block substitution runs in row JB only, in place on the lanes' own values
+//      (v_fmac_f64_dpp t, t, -ch[J] row_newbcast:J row_mask:1<<JB, lanes cc >= J / cc <= J through EXEC) -- a lane needs the
+//      operands of ITS OWN block only: ch[J] = Lsym(cc, J), the symmetric 16 x 16 diagonal block (row form for the
+//      forward sweep where cc > J, column form for the backward sweep where cc < J, the factorisation's -0.0 at cc == J:
+//      the triangles are complementary, one array serves both sweeps like in qp_dense4.hip);
+//   2. the finished segment goes to all rows (row_to_all: v_permlane16_swap / v_permlane32_swap, no LDS);
+//   3. riders: every row beyond (forward) / before (backward) the pivot block takes the block's 16 updates,
+//      v_fmac_f64_dpp t, xb, -ro[.][J] row_newbcast:J, J ascending / descending -- 16 (NB - 1) operands per lane, the same
+//      array for both sweeps (rows beyond block o hold L(row, 16 o + J), rows up to block o hold L(16 (o + 1) + J, row)).
+// 16 NB doubles per lane in all (96 VGPRs at K <= 48, 128 at K <= 64) against 16 (2 NB - 1) for a replicated chain.
+// Per row the operations and their order are the oracle's, exactly as in the block engine: row i subtracts L(i, j) x_j
+// for j ascending (riders of the earlier blocks in block order, then its own block's chain), L(j, i) x_j for j
+// descending on the way back; lanes a step does not concern are switched off (EXEC / row_mask): no 0 * pivot products.
+// A lone wave pays the chain's dependent latency un-hidden (18-20 cycles per step) but issues 4 instructions per step
+// instead of 6-8 and waits for no operand; with 2-3 waves per SIMD the VALU is the only shared resource left.
+template<int NB>
+struct RegFactor {
+  static_assert(NB >= 2 && NB <= 4, "32 < K <= 64");
+  double ch[16];
+  double ro[NB - 1][16];
+  double d;
+};
+
+// F <- the packed factor T (LDS), for the lane's row = lane.  16 (NB - 1) < K <= 16 NB.  Entries of rows / columns that do not
+// exist are exact zeros.
+template<int NB>
+__device__ __forceinline__ void reg_factor_load(RegFactor<NB> &F, const int K_, const double *T_, const double *Dg_, const int lane)
+{
+  const int K           = __builtin_amdgcn_readfirstlane(K_);
+  const lds_d *const T  = (const lds_d *)T_;
+  const lds_d *const Dg = (const lds_d *)Dg_;
+  // (the addresses below depend on the lane and K only: inside a persistent loop over QPs the compiler would hoist all
+  // 16 NB of them out of the loop and keep them in scratch memory -- the opaque copy of the lane number ties them to the call)
+  int ln = lane;
+  asm volatile("" : "+v"(ln));
+  const int cc = ln & 15, r = ln >> 4, i = ln;
+  const bool vi = i < K;
+  // Addresses as [per-lane base] + [J x per-lane stride] + [compile-time offset]; an entry that does not exist reads T[0]
+  // (valid LDS) and is replaced by an exact zero.  Diagonal block of row block r, entry (a, b) = (max, min)(cc, J) at
+  // tri(16 r + a) + 16 r + b:  J < cc: tri(i) + 16 r + J;  J >= cc: tri(16 r + J) + i = [tri(16 r) + i] + J 16 r + tri(J).
+  const int rowA = vi ? ((i * (i + 1)) >> 1) : 0;            // tri(i)
+  const int baseA = rowA + 16 * r;                            // + J
+  const int r16   = 16 * r;
+  const int baseB = ((r16 * (r16 + 1)) >> 1) + i;             // + J r16 + tri(J)
+  static_for<16>([&]<int J>(ic<J>) {
+    const bool lower = J < cc;  // the lane's own row holds the entry
+    const bool ok    = lower ? vi : (r16 + J < K);
+    const int idx    = lower ? baseA + J : baseB + J * r16 + (J * (J + 1)) / 2;
+    const double v   = T[ok ? idx : 0];
+    F.ch[J] = ok ? v : 0.0;
+  });
+  static_for<NB - 1>([&]<int O>(ic<O>) {
+    const bool fwd = r > O;  // rows beyond block O: forward operands L(i, 16 O + J); rows up to it: backward operands L(16 (O + 1) + J, i)
+    static_for<16>([&]<int J>(ic<J>) {
+      constexpr int p = 16 * (O + 1) + J;
+      const bool ok   = vi && (fwd || O + 1 < NB - 1 || p < K);  // (only the last block can be partial)
+      const int idx   = fwd ? rowA + (16 * O + J) : i + (p * (p + 1)) / 2;
+      const double v  = T[ok ? idx : 0];
+      F.ro[O][J] = ok ? v : 0.0;
+    });
+  });
+  F.d = Dg[vi ? i : 0];
+}
+
+// chain steps of one half block (8 steps; the last step of the second half has no operation) as ONE asm statement.  The
+// lane mask of a step is the same 32-bit pattern in both halves of EXEC (four 16-lane rows): two s_mov_b32 with a literal --
+// no SGPRs for the masks -- which are also the two wait states the DPP read of t needs after the VALU write before it;
+// nothing rides between the chain steps here, so EXEC stays narrowed from step to step and is restored once at the end.
+__host__ __device__ constexpr unsigned mask32_ge(const int J) { return (unsigned)(mask_ge(J) & 0xFFFFFFFFull); }
+#define SFB_RG_CH(U) "s_mov_b32 exec_lo, %[m" #U "]\n\ts_mov_b32 exec_hi, %[m" #U "]\n\tv_fmac_f64_dpp %[t], %[t], -%[c" #U "] row_newbcast:%[j" #U "] row_mask:%[rm] bank_mask:0xf\n\t"
+#define SFB_RG_RID(U) "v_fmac_f64_dpp %[t], %[x], -%[c" #U "] row_newbcast:%[j" #U "] row_mask:%[rm] bank_mask:0xf\n\t"
+#define SFB_RG_M8(M) [m0] "n"(M(0)), [m1] "n"(M(1)), [m2] "n"(M(2)), [m3] "n"(M(3)), [m4] "n"(M(4)), [m5] "n"(M(5)), [m6] "n"(M(6)), [m7] "n"(M(7))
+template<bool FWD, int C, int RP>
+__device__ __forceinline__ void reg_chain8(double &t, const double (&ch)[16])
+{
+  constexpr int J0 = FWD ? 8 * C : 15 - 8 * C, D = FWD ? 1 : -1;
+  const double c[8] = {ch[J0], ch[J0 + D], ch[J0 + 2 * D], ch[J0 + 3 * D], ch[J0 + 4 * D], ch[J0 + 5 * D], ch[J0 + 6 * D], ch[C == 1 ? J0 + 6 * D : J0 + 7 * D]};
+  // forward step J: lanes cc >= J; backward step J: lanes cc <= J
+#define SFB_RG_MASK(U) (FWD ? mask32_ge(J0 + (U) * D) : (~mask32_ge(J0 + (U) * D + 1) & 0xFFFFFFFFu))
+  if constexpr (C == 0)
+    asm volatile(SFB_RG_CH(0) SFB_RG_CH(1) SFB_RG_CH(2) SFB_RG_CH(3) SFB_RG_CH(4) SFB_RG_CH(5) SFB_RG_CH(6) SFB_RG_CH(7) "s_mov_b64 exec, -1"
+                 : [t] "+v"(t)
+                 : SFB_RS_V8(c, c), SFB_RG_M8(SFB_RG_MASK), SFB_RS_J8(J0, D), [rm] "n"(1 << RP));
+  else
+    asm volatile(SFB_RG_CH(0) SFB_RG_CH(1) SFB_RG_CH(2) SFB_RG_CH(3) SFB_RG_CH(4) SFB_RG_CH(5) SFB_RG_CH(6) "s_mov_b64 exec, -1"
+                 : [t] "+v"(t)
+                 : SFB_RS_V8(c, c), SFB_RG_M8(SFB_RG_MASK), SFB_RS_J8(J0, D), [rm] "n"(1 << RP));
+#undef SFB_RG_MASK
+}
+// the riders of one half block: t(cc) = fma(-ro[J], xb(J), t(cc)) on the rows of RM, J = J0, J0 + D, ...
+template<bool FWD, int C, int RM>
+__device__ __forceinline__ void reg_riders8(double &t, const double &xb, const double (&ro)[16])
+{
+  constexpr int J0 = FWD ? 8 * C : 15 - 8 * C, D = FWD ? 1 : -1;
+  const double c[8] = {ro[J0], ro[J0 + D], ro[J0 + 2 * D], ro[J0 + 3 * D], ro[J0 + 4 * D], ro[J0 + 5 * D], ro[J0 + 6 * D], ro[J0 + 7 * D]};
+  asm volatile("s_nop 1\n\t" SFB_RG_RID(0) SFB_RG_RID(1) SFB_RG_RID(2) SFB_RG_RID(3) SFB_RG_RID(4) SFB_RG_RID(5) SFB_RG_RID(6) SFB_RG_RID(7)
+               : [t] "+v"(t)
+               : [x] "v"(xb), SFB_RS_V8(c, c), SFB_RS_J8(J0, D), [rm] "n"(RM));
+}
+// single steps (the half block that holds row K - 1 without being full, backward sweep)
+template<int J, int RP>
+__device__ __forceinline__ void reg_chain_le(double &t, const double l)
+{
+  asm volatile("s_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, %2\n\t"
+               "v_fmac_f64_dpp %0, %0, -%1 row_newbcast:%3 row_mask:%4 bank_mask:0xf\n\t"
+               "s_mov_b64 exec, -1"
+               : "+v"(t)
+               : "v"(l), "n"(~mask32_ge(J + 1) & 0xFFFFFFFFu), "n"(J), "n"(1 << RP));
+}
+
+// (L D L')^-1 applied to the permuted vector t (row = lane) from the factor in registers.  16 (NB - 1) < K <= 16 NB.
+template<int NB>
+__device__ __forceinline__ double row_sweeps_reg(const int K_, const RegFactor<NB> &F, const double t, const int lane)
+{
+  const int K   = __builtin_amdgcn_readfirstlane(K_);
+  const bool vi = lane < K;
+  double tl     = vi ? t : 0.0;
+  // ---------------- forward: blocks 0 .. NB-1 ----------------
+  static_for<NB>([&]<int JB>(ic<JB>) {
+    constexpr bool LAST = JB == NB - 1;
+    static_for<2>([&]<int C>(ic<C>) {
+      if (!LAST || 16 * JB + 8 * C < K) reg_chain8<true, C, JB>(tl, F.ch);  // (a half block beyond K: pivots there only reach rows that do not exist)
+    });
+    if constexpr (!LAST) {
+      constexpr int RM = fwd_rows<NB>(JB, 0);
+      const double xb  = row_to_all<JB>(tl);
+      reg_riders8<true, 0, RM>(tl, xb, F.ro[JB]);
+      reg_riders8<true, 1, RM>(tl, xb, F.ro[JB]);
+    }
+  });
+  // ---------------- D^-1 (|d| <= DBL_MIN -> 0, true division) ----------------
+  tl = (fabs(F.d) > DBL_MIN) ? tl / F.d : 0.0;
+  if (!vi) tl = 0.0;
+  // ---------------- backward: blocks NB-1 .. 0 ----------------
+  static_for<NB>([&]<int S>(ic<S>) {
+    constexpr int JB    = NB - 1 - S;
+    constexpr bool LAST = JB == NB - 1;
+    static_for<2>([&]<int C>(ic<C>) {
+      if (!LAST || 16 * JB + 15 - 8 * C < K) {  // every pivot of this half block exists
+        reg_chain8<false, C, JB>(tl, F.ch);
+      } else if (16 * JB + 8 - 8 * C < K) {  // the half block that holds row K - 1 without being full: step by step
+        static_for<8>([&]<int U>(ic<U>) {
+          constexpr int J = 15 - 8 * C - U;
+          if constexpr (J >= 1)
+            if (16 * JB + J < K) reg_chain_le<J, JB>(tl, F.ch[J]);
+        });
+      }
+    });
+    if constexpr (JB > 0) {
+      constexpr int RM = bwd_rows(JB, 0);
+      const double xb  = row_to_all<JB>(tl);
+      static_for<2>([&]<int C>(ic<C>) {
+        if (!LAST || 16 * JB + 15 - 8 * C < K) {
+          reg_riders8<false, C, RM>(tl, xb, F.ro[JB - 1]);
+        } else if (16 * JB + 8 - 8 * C < K) {
+          static_for<8>([&]<int U>(ic<U>) {
+            constexpr int J = 15 - 8 * C - U;
+            if (16 * JB + J < K) {
+              double tt = tl;
+              asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:%4 bank_mask:0xf" : "+v"(tt) : "v"(xb), "v"(F.ro[JB - 1][J]), "n"(J), "n"(RM));
+              tl = tt;
+            }
+          });
+        }
+      });
+    }
+  });
+  return tl;
+}
+
 // outlined instance (call sites off the hot loop); any K <= 16 NB
 template<int NB, bool ANYK = true>
 __device__ __attribute__((noinline)) Pair row_sweeps(const int K_, const double *T_, const double *Dg_, Pair t, const int lane)
