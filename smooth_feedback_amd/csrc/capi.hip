@@ -342,17 +342,29 @@ sfb_status run_sharded(int64_t batch, const std::function<sfb_status(int, int64_
   std::vector<sfb_status> st((size_t)G, SFB_OK);
   std::vector<std::string> msg((size_t)G);
   std::vector<std::thread> th;
-  for (int64_t g = 0; g < G; ++g) {
+  bool spawn_failed = false;
+  for (int64_t g = 0; g < G && !spawn_failed; ++g) {
     const int64_t b0 = batch * g / G, b1 = batch * (g + 1) / G;  // contiguous shards
     if (b1 == b0) continue;
-    th.emplace_back([&, g, b0, b1] {
-      hipError_t e = hipSetDevice(devs[(size_t)g]);
-      if (e != hipSuccess) st[(size_t)g] = hip_fail(e, "hipSetDevice");
-      else st[(size_t)g] = fn(devs[(size_t)g], b0, b1 - b0);
-      if (st[(size_t)g] != SFB_OK) msg[(size_t)g] = sfb_last_error();  // (thread-local: carried over by hand)
-    });
+    try {
+      th.emplace_back([&, g, b0, b1] {
+        try {
+          hipError_t e = hipSetDevice(devs[(size_t)g]);
+          if (e != hipSuccess) st[(size_t)g] = hip_fail(e, "hipSetDevice");
+          else st[(size_t)g] = fn(devs[(size_t)g], b0, b1 - b0);
+        } catch (const std::exception &ex) {  // (nothing may leave a thread of an extern "C" entry point)
+          st[(size_t)g] = fail(SFB_ERR_HIP, std::string("exception in a shard: ") + ex.what());
+        } catch (...) {
+          st[(size_t)g] = fail(SFB_ERR_HIP, "exception in a shard");
+        }
+        if (st[(size_t)g] != SFB_OK) msg[(size_t)g] = sfb_last_error();  // (thread-local: carried over by hand)
+      });
+    } catch (const std::exception &) {  // std::system_error of the thread constructor: finish what was started, then report
+      spawn_failed = true;
+    }
   }
   for (auto &t : th) t.join();
+  if (spawn_failed) return fail(SFB_ERR_HIP, "could not start a host thread for a device shard");
   for (int64_t g = 0; g < G; ++g)
     if (st[(size_t)g] != SFB_OK) return fail(st[(size_t)g], "device " + std::to_string(devs[(size_t)g]) + ": " + msg[(size_t)g]);
   return SFB_OK;

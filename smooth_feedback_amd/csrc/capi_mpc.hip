@@ -354,13 +354,20 @@ sfb_status sfb_mpc_swarm_upload(sfb_mpc_swarm *S, int64_t first, int64_t count)
   if (!S) return sfb::fail(SFB_ERR_INVALID_ARG, "swarm is NULL");
   if (!S->pinned) return sfb::fail(SFB_ERR_INVALID_ARG, "sfb_mpc_swarm_host_records first");
   if (first < 0 || count < 0 || first + count > S->agents) return sfb::fail(SFB_ERR_INVALID_ARG, "range outside the swarm");
+  // This entry point is meant to be called from the caller's linearisation threads, and a new host thread starts on
+  // device 0 whatever the thread that created the swarm had selected: the swarm's device is made current for the copy
+  // (it goes to the swarm's own stream and memory) and the caller's device is restored on the way out.
+  struct DeviceGuard {
+    int prev = -1;
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  } guard;
   {
-    // This entry point is meant to be called from the caller's linearisation threads, and a new host thread starts on
-    // device 0 whatever the thread that created the swarm had selected: make the swarm's device current here instead of
-    // rejecting the call (the copy below goes to the swarm's own stream and memory).
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess && dev != S->devid) e = hipSetDevice(S->devid);
+    if (e == hipSuccess && dev != S->devid) {
+      e = hipSetDevice(S->devid);
+      if (e == hipSuccess) guard.prev = dev;
+    }
     if (e != hipSuccess) return sfb::hip_fail(e, "hipSetDevice(swarm device)");
   }
   if (count == 0) return SFB_OK;

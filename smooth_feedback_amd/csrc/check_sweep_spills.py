@@ -3,7 +3,13 @@
 loads + `s_waitcnt vmcnt(N)`), so scratch (spill) traffic INSIDE a sweep would corrupt the counts.  Spills elsewhere
 are merely slow.  Usage: check_sweep_spills.py <device assembly>.  A sweep region = a maximal run of the hand-issued
 `global_load_dwordx4 ... off offset:N` stream loads (gaps of fewer than 400 lines); fails if a scratch instruction
-lies inside one."""
+lies inside one.
+
+Second check (the sweeps keep stream loads IN FLIGHT across compiler-generated code: the prefetch registers lx / ix are
+written asynchronously, which the compiler does not know): inside every sweep region the outstanding loads are replayed
+in program order -- a load enters a FIFO with its destination registers, `s_waitcnt vmcnt(N)` retires all but the N
+youngest -- and any other instruction that names a register of a load still in flight (a copy, a rename, a read before
+the counted wait) fails the build."""
 import re
 import sys
 
@@ -22,5 +28,48 @@ bad = [i for i, l in enumerate(lines) if re.search(r"\bscratch_(load|store)", l)
 if bad:
     sys.exit("check_sweep_spills: register spill inside a sweep (line %d of %s): hand-counted s_waitcnt would be wrong"
              % (bad[0] + 1, sys.argv[1]))
+
+
+def regs_of(text):
+    out = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
+        out.update(range(int(a), int(b) + 1))
+    out.update(int(a) for a in re.findall(r"\bv(\d+)\b", text))
+    return out
+
+
+hazards = 0
+for a, b in regions:
+    fifo = []  # destination register sets of the loads in flight, oldest first
+    for i in range(a, b + 1):
+        t = lines[i].split(";")[0].strip()
+        if not t or t.startswith(".") or t.endswith(":"):
+            continue
+        op = t.split()[0]
+        if op.startswith(("global_load", "flat_load", "buffer_load")):
+            dst = regs_of(t.split(",")[0])
+            busy = set().union(*fifo) if fifo else set()
+            src = regs_of(",".join(t.split(",")[1:]))
+            if src & busy:
+                sys.exit("check_sweep_spills: line %d of %s: address of a load is a register of a load still in flight: %s" % (i + 1, sys.argv[1], t))
+            fifo.append(dst)
+            continue
+        if op.startswith(("global_store", "flat_store", "buffer_store")):
+            fifo.append(set())  # stores count in vmcnt on gfx9
+        if op == "s_waitcnt":
+            m = re.search(r"vmcnt\((\d+)\)", t)
+            if m:
+                n = int(m.group(1))
+                while len(fifo) > n:
+                    fifo.pop(0)
+            elif re.fullmatch(r"s_waitcnt\s+0(x0+)?", t):
+                fifo = []
+            continue
+        busy = set().union(*fifo) if fifo else set()
+        if busy and (regs_of(t) & busy):
+            hazards += 1
+            sys.exit("check_sweep_spills: line %d of %s touches a register of a stream load that is still in flight "
+                     "(before its counted s_waitcnt): %s" % (i + 1, sys.argv[1], t))
 nspill = sum(1 for l in lines if re.search(r"\bscratch_(load|store)", l))
-print("check_sweep_spills: %d sweep regions, %d scratch instructions, none inside a sweep" % (len(regions), nspill))
+print("check_sweep_spills: %d sweep regions, %d scratch instructions, none inside a sweep; no instruction touches a register of a "
+      "load in flight" % (len(regions), nspill))

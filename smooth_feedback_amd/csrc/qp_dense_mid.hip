@@ -71,6 +71,10 @@ __device__ unsigned long long g_midprof[12];
 #define SFB_MID_REGS 1
 #endif
 
+#ifndef SFB_MID_CHK_KEEP
+#define SFB_MID_CHK_KEEP 1
+#endif
+
 constexpr int kMidPadT = 8;  // zeros behind the packed triangle (the chunked dot products read up to 7 entries past a row)
 
 // LDS layout in doubles (host and device)
@@ -360,7 +364,7 @@ __device__ __forceinline__ void mvec(const double *const base, const size_t stri
 // V = [x (n) | dx (n) | y (m) | z (m)], dy in tmp.  Returns a QPSolutionStatus or -1 (std::nullopt).  Wave-uniform.
 // Outlined: it runs once per stop_check_iter iterations and its registers stay out of the ADMM loop's budget.
 // Rows of the mat-vecs: constraint i = lane + 64 r (< m), variable j = lane + 64 r (< n); s = 0, inner index ascending, fma.
-template<int R>
+template<int R, int MU = 16>  // MU: matrix entries requested together per row (16 when the check has the registers to itself)
 __device__ __forceinline__ int mid_stop_check_body(const int n_, const int m_, const int lane, const double *const P, const double *const q,
                                                         const double *const A, const double *const l, const double *const u, lds_d *const V,
                                                         lds_d *const tmp, const double eps_abs, const double eps_rel, const double eps_pinf,
@@ -381,7 +385,7 @@ __device__ __forceinline__ int mid_stop_check_body(const int n_, const int m_, c
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       double s0 = 0.0, s1 = 0.0;
-      mvec<16>(A + (con[r] ? ci_[r] : 0), (size_t)m, v0, v1, n, [&](int, double a, double x0, double x1) { s0 = fma(a, x0, s0); s1 = fma(a, x1, s1); });
+      mvec<MU>(A + (con[r] ? ci_[r] : 0), (size_t)m, v0, v1, n, [&](int, double a, double x0, double x1) { s0 = fma(a, x0, s0); s1 = fma(a, x1, s1); });
       o0[r] = con[r] ? s0 : 0.0;
       o1[r] = con[r] ? s1 : 0.0;
     }
@@ -390,7 +394,7 @@ __device__ __forceinline__ int mid_stop_check_body(const int n_, const int m_, c
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       double s = 0.0;
-      mvec<16>(A + (size_t)(var[r] ? vj_[r] : 0) * m, 1, v, v, m, [&](int, double a, double x0, double) { s = fma(a, x0, s); });
+      mvec<MU>(A + (size_t)(var[r] ? vj_[r] : 0) * m, 1, v, v, m, [&](int, double a, double x0, double) { s = fma(a, x0, s); });
       o[r] = var[r] ? s : 0.0;
     }
   };
@@ -398,7 +402,7 @@ __device__ __forceinline__ int mid_stop_check_body(const int n_, const int m_, c
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       double s = 0.0;
-      mvec<16>(P + (var[r] ? vj_[r] : 0), (size_t)n, v, v, n, [&](int, double p, double x0, double) { s = fma(p, x0, s); });
+      mvec<MU>(P + (var[r] ? vj_[r] : 0), (size_t)n, v, v, n, [&](int, double p, double x0, double) { s = fma(p, x0, s); });
       o[r] = var[r] ? s : 0.0;
     }
   };
@@ -1161,6 +1165,7 @@ __device__ __forceinline__ bool mid_admm(const MidC &C, const DenseKernelParams 
   };
   // k <= 64: the factor moves into registers for the duration of the loop (sweep_rows.h, registers-only engine)
   constexpr bool kRegs = NB <= 4 && SFB_MID_REGS != 0;
+  constexpr bool kChkKeep = SFB_MID_CHK_KEEP != 0;
   rows::Masks masks{};
   if constexpr (!kRegs) masks = rows::make_masks();  // (once, in front of the loop: see sweep_rows.h)
   rows::RegFactor<kRegs ? NB : 2> F;
@@ -1192,15 +1197,16 @@ __device__ __forceinline__ bool mid_admm(const MidC &C, const DenseKernelParams 
     if constexpr (R > 1) upd(h[R - 1], t.hi, chk);
     if (chk) {
       wave_lds_fence();
-      // registers-only engine: the check is INLINED -- the factor registers are dead across it (re-filled from LDS behind
-      // it), so it works in them; an outlined call would save and restore the live registers through scratch memory
-      if constexpr (kRegs) ret_code = mid_stop_check_body<R>(n, m, lane, P, q, A, l, u, V, tmp, kp.eps_abs, kp.eps_rel, kp.eps_pinf, kp.eps_dinf);
+      // registers-only engine: the check is INLINED (an outlined call would save and restore the live factor registers
+      // through scratch memory); SFB_MID_CHK_KEEP: the factor registers stay live across it and the check requests the
+      // matrix entries in short batches that fit next to them, otherwise they are dead across it and re-filled from LDS behind it
+      if constexpr (kRegs) ret_code = mid_stop_check_body<R, kChkKeep ? (NB <= 3 ? 4 : 8) : 16>(n, m, lane, P, q, A, l, u, V, tmp, kp.eps_abs, kp.eps_rel, kp.eps_pinf, kp.eps_dinf);
       else ret_code = mid_stop_check<R>(n, m, lane, P, q, A, l, u, V, tmp, kp.eps_abs, kp.eps_rel, kp.eps_pinf, kp.eps_dinf);
       if (ret_code < 0 && max_time_exceeded(kp.max_time_ns, t0_ticks)) ret_code = SFB_QP_MAX_TIME;  // :504-507
       wave_lds_fence();
       // the factor registers are re-filled from LDS behind the outlined check instead of living across the call (the
       // compiler would save and restore all of them through scratch memory at the call site)
-      if constexpr (kRegs) rows::reg_factor_load<NB>(F, k, (const double *)T, (const double *)Dg, lane);
+      if constexpr (kRegs && !kChkKeep) rows::reg_factor_load<NB>(F, k, (const double *)T, (const double *)Dg, lane);
     }
   }
   return false;

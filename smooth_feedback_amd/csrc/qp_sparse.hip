@@ -2190,13 +2190,13 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     const size_t lds_lat = std::max(lds, (size_t)(((kk + 2) & ~1) + 2 * pl.n + 6 * pl.m + ((kk + 2) & ~1) / 2 + kk + 2) * sizeof(double));
     int lat_hi = 0, lat_lo = 0;
     if (const char *lt = sfb::knob("SFB_SP_LAT"); !(lt && atoi(lt) == 0) && lds_lat <= 80 * 1024) {
-      static bool attr_set = false;  // (idempotent; racing callers set the same value)
-      if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(qp_sparse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_set = true;
-      }
+      // (per call: the attribute belongs to the CURRENT device and the shards of a *_multi call run on several; cheap and idempotent.
+      // A runtime that refuses the opt-in leaves lat_hi = 0: the standard form runs.)
+      const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(qp_sparse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              80 * 1024) == hipSuccess;
+      if (!lds_ok) (void)hipGetLastError();
       int dev = 0, per_cu = 0, cus = 0;
-      if (hipGetDevice(&dev) == hipSuccess &&
+      if (lds_ok && hipGetDevice(&dev) == hipSuccess &&
           hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qp_sparse_kernel<true>, kWave, lds_lat) == hipSuccess &&
           hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
         lat_hi = std::min<int>(per_cu * cus, (int)grid);

@@ -50,12 +50,12 @@ def test_two_ranks_code_path(workload, batch, port):
     assert d["config"]["global_batch"] == 2 * batch and d["config"]["per_gpu_batch"] == batch
     assert d["value"] > 0 and "cpu_baseline" not in d and "secondary" not in d
     assert d["gather_check"] == {"own_rows_intact": True, "peer_rows_received": True, "peer_rows_differ_from_own": True,
-                                 "ranks_checked": 2}
+                                 "gathered_rows": 2 * batch, "ranks_checked": 2}
 
 
 def test_eight_ranks_mpc_code_path():
     """The shape of BASELINE configs[3] (8 ranks, one shard of MPC agents each, ONE gather of u_0 / code / iter per
-    step) with all ranks on cuda:0 over gloo: sharding by rank-derived seeds, host assembly threads divided among the
+    step) with all ranks on cuda:0 over gloo: sharding.shard_range over the job's batch, rank-derived seeds, host assembly threads divided among the
     ranks, the gather checked against per-rank checksums that travel by a separate all_reduce."""
     env = dict(os.environ, SFB_BENCH_SHARE_DEVICE="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
@@ -66,7 +66,7 @@ def test_eight_ranks_mpc_code_path():
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8 * 64
     assert d["gather_check"] == {"own_rows_intact": True, "peer_rows_received": True, "peer_rows_differ_from_own": True,
-                                 "ranks_checked": 8}
+                                 "gathered_rows": 8 * 64, "ranks_checked": 8}
 
 
 def test_default_line_carries_the_secondary_workloads():
@@ -90,3 +90,10 @@ def test_default_line_carries_the_secondary_workloads():
     assert d["secondary"]["ekf"]["parity_vs_oracle"]["P_bit_identical"]
     assert d["parity_vs_oracle"]["iter_mismatches"] == 0 and d["parity_vs_oracle"]["max_abs_dx"] == 0.0
     assert d["cpu_baseline"]["single_core"]["cores"] == 1
+    # what a user of MPC::operator() sees (end-to-end incl. H2D), driver-timed in the same run
+    cl = d["closed_loop"]
+    assert cl["end_to_end"]["results_identical_to_device_resident"] and cl["end_to_end"]["value"] > 0
+    assert cl["swarm_tick"]["agents"] == 8192 and cl["swarm_tick"]["ms_per_tick"] > 0 and cl["swarm_tick"]["optimal_fraction_last_tick"] == 1.0
+    assert cl["single_agent"]["cold_ms"] > 0 and cl["single_agent"]["warm_iterations"] <= cl["single_agent"]["cold_iterations"]
+    ekf_cpu = d["secondary"]["ekf"]["cpu_baseline"]
+    assert ekf_cpu["single_core"]["cores"] == 1 and d["secondary"]["ekf"]["parity_vs_oracle"].get("all_cores_P_bit_identical", True)
