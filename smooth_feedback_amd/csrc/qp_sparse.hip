@@ -31,17 +31,8 @@
 #include "qp_sparse_kernel.h"
 #include "wave_util.h"
 
-#ifndef SFB_ITER_EXP
-#define SFB_ITER_EXP 0  // timing experiments only (scripts/r3/iter_parts.sh): 1 = no update phases, 2 = no sweeps
-#endif
 #ifndef SFB_SWEEP_DEPTH
 #define SFB_SWEEP_DEPTH 8  // units (2 slots per lane each) in flight per sweep
-#endif
-#ifndef SFB_LAT_SWEEP_DEPTH
-#define SFB_LAT_SWEEP_DEPTH 8  // ... in the loop of the LAT form (8 or 16)
-#endif
-#ifndef SFB_LAT_NT
-#define SFB_LAT_NT 0  // 1: the loop of the LAT form streams the factor VALUES with non-temporal loads (the index arrays keep the L2)
 #endif
 
 namespace sfb {
@@ -620,7 +611,7 @@ __device__ __forceinline__ void stream_wait(vdouble2 &a, vint2 &b)
 // instead of padding and leaves them in flight in lx / ix; PRE: no prologue, lx / ix hold this sweep's first DEPTH units
 // already (issued by the sweep before).  A lone wave otherwise waits one full memory latency at the head of every sweep.
 // (Between chained sweeps nothing else may touch memory: the counted waits assume the stream's loads only.)
-template<int DEPTH, bool BYTEOFF, bool LEAN, bool NTP = false, bool PRE = false, bool NEXT = false>
+template<int DEPTH, bool BYTEOFF, bool LEAN, bool PRE = false, bool NEXT = false>
 __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const int units, const double *vals, double *t,
                                  const int lane, const int32_t *__restrict__ mask32, const int full0, const int full1,
                                  vdouble2 (&lx)[DEPTH], vint2 (&ix)[DEPTH], const int32_t *__restrict__ idx_next = nullptr,
@@ -630,7 +621,7 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
   // lean == false (few waves left on the chip: latency matters, HBM traffic does not): every block issues plain loads
   static_assert(DEPTH <= kSweepPadDev && kSweepPadDev % DEPTH == 0, "schedule padding must cover the prefetch distance");
   static_assert(2 * DEPTH <= 62, "vmcnt is a 6-bit counter");
-  static_assert(DEPTH == 8 || (DEPTH == 16 && !LEAN), "one scalar load fetches the lane-mask shifts of a block of 8 units");
+  static_assert(DEPTH == 8, "one scalar load fetches the lane-mask shifts of a block of 8 units");
   // per-lane stream pointers (VGPRs): one per 4 units of values (1 KB each) and per 8 units of indices (12-bit offsets)
   constexpr int NVP = DEPTH / 4, NIP = DEPTH / 8;
   const vdouble2 *vp[NVP];
@@ -673,7 +664,7 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
               [&]<int D>(std::integral_constant<int, D> dd) { issue(dd, std::integral_constant<int, 2>{}, mk); });
   } else if constexpr (!PRE) {
     for_units(std::make_integer_sequence<int, DEPTH>{},
-              [&]<int D>(std::integral_constant<int, D> dd) { issue(dd, std::integral_constant<int, NTP ? 1 : 0>{}, mk); });
+              [&]<int D>(std::integral_constant<int, D> dd) { issue(dd, std::integral_constant<int, 0>{}, mk); });
   }
   advance(DEPTH);
   // (tgt, piv) of the two slots of a unit as byte offsets (BYTEOFF, plan.idx_scale == 8) or element indices
@@ -714,17 +705,14 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
     for (; u0 < units; u0 += DEPTH) block(std::integral_constant<int, 2>{}, u0);
   } else {
     for (; u0 + (NEXT ? DEPTH : 0) < units; u0 += DEPTH) {
-      // `units` is a multiple of 8 and the arrays carry 16 units of padding: the last block of a 16-deep pipeline may
-      // start 8 units before the end -- its prefetches (never consumed) are pulled back into the padding
-      if (DEPTH == 16 && u0 + DEPTH > units) advance(-8);
-      block(std::integral_constant<int, NTP ? 1 : 0>{}, u0);
+      block(std::integral_constant<int, 0>{}, u0);
     }
     if constexpr (NEXT) {  // the last block (units >= DEPTH, the caller's condition): its loads are the next stream's first units
 #pragma unroll
       for (int e = 0; e < NVP; ++e) vp[e] = reinterpret_cast<const vdouble2 *>(vals_next) + lane + e * 4 * kWave;
 #pragma unroll
       for (int e = 0; e < NIP; ++e) ip[e] = reinterpret_cast<const vint2 *>(idx_next) + lane + e * 8 * kWave;
-      block(std::integral_constant<int, NTP ? 1 : 0>{}, u0);
+      block(std::integral_constant<int, 0>{}, u0);
     }
   }
   if constexpr (NEXT) {
@@ -738,8 +726,8 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
 }
 
 // t (LDS, permuted order) <- K^-1 t   (qp_solver.hpp:457-459)
-// SD: prefetch distance of the cacheable (latency) form of the sweeps, 8 or 16 units
-template<int SD, bool NTP = false>
+// SD: prefetch distance of the cacheable (latency) form of the sweeps (8 units)
+template<int SD>
 __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, double *t, const int lane, const bool lean,
                                      const double *dinv_lds = nullptr)
 {
@@ -756,8 +744,8 @@ __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, doubl
     } else {
       vdouble2 lx[SD];
       vint2 ix[SD];
-      if (bo) sweep_dev<SD, true, false, NTP>(idx, units, vals, t, lane, mask, f0, f1, lx, ix);
-      else sweep_dev<SD, false, false, NTP>(idx, units, vals, t, lane, mask, f0, f1, lx, ix);
+      if (bo) sweep_dev<SD, true, false>(idx, units, vals, t, lane, mask, f0, f1, lx, ix);
+      else sweep_dev<SD, false, false>(idx, units, vals, t, lane, mask, f0, f1, lx, ix);
     }
   };
   sweep(pl.fidx, uni(pl.funits), w.LxF, pl.fmask, uni(pl.ffull0), uni(pl.ffull1));  // forward (column oriented order)
@@ -778,13 +766,12 @@ __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, doubl
 // sweep's last block fetches the head of the backward stream, the backward sweep's last block the head of the forward
 // stream for the next iteration when the caller says there is one without a stopping check in between (`next`); `pre`:
 // lx / ix hold the forward stream's head from the previous call.  Requires byte offsets and funits, bunits >= 8.
-template<bool NTP>
 __device__ __forceinline__ void ldl_solve_lat(const SparsePlanDev &pl, const Ws &w, double *t, const int lane, const double *Dinv,
                                               vdouble2 (&lx)[8], vint2 (&ix)[8], const bool pre, const bool next)
 {
   const int k = uni(pl.k);
-  if (pre) sweep_dev<8, true, false, NTP, true, true>(pl.fidx, uni(pl.funits), w.LxF, t, lane, pl.fmask, 0, 0, lx, ix, pl.bidx, w.LxB);
-  else sweep_dev<8, true, false, NTP, false, true>(pl.fidx, uni(pl.funits), w.LxF, t, lane, pl.fmask, 0, 0, lx, ix, pl.bidx, w.LxB);
+  if (pre) sweep_dev<8, true, false, true, true>(pl.fidx, uni(pl.funits), w.LxF, t, lane, pl.fmask, 0, 0, lx, ix, pl.bidx, w.LxB);
+  else sweep_dev<8, true, false, false, true>(pl.fidx, uni(pl.funits), w.LxF, t, lane, pl.fmask, 0, 0, lx, ix, pl.bidx, w.LxB);
   for (int j0 = lane; j0 < k; j0 += kWave * 8) {  // D^-1 (:458) from LDS
     double dv[8];
 #pragma unroll
@@ -794,8 +781,8 @@ __device__ __forceinline__ void ldl_solve_lat(const SparsePlanDev &pl, const Ws 
       if (j0 + e * kWave < k) t[j0 + e * kWave] = dv[e] * t[j0 + e * kWave];
   }
   wave_lds_fence();
-  if (next) sweep_dev<8, true, false, NTP, true, true>(pl.bidx, uni(pl.bunits), w.LxB, t, lane, pl.bmask, 0, 0, lx, ix, pl.fidx, w.LxF);
-  else sweep_dev<8, true, false, NTP, true, false>(pl.bidx, uni(pl.bunits), w.LxB, t, lane, pl.bmask, 0, 0, lx, ix);
+  if (next) sweep_dev<8, true, false, true, true>(pl.bidx, uni(pl.bunits), w.LxB, t, lane, pl.bmask, 0, 0, lx, ix, pl.fidx, w.LxF);
+  else sweep_dev<8, true, false, true, false>(pl.bidx, uni(pl.bunits), w.LxB, t, lane, pl.bmask, 0, 0, lx, ix);
 }
 
 __device__ __forceinline__ double lane_max_abs(const double *v, int len, int lane)
@@ -934,10 +921,7 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
   {  // OPTIMALITY
     double a = 0.0, r = 0.0, z = 0.0;
     constexpr int RB = RBX, CE = 2;  // (RB = 4: 8 entries in flight per lane)
-#ifndef SFB_CHK_EXP
-#define SFB_CHK_EXP 0  // timing experiments only (scripts/r3/check_parts.sh): leave parts of the check out
-#endif
-    for (int i0 = lane; i0 < ((SFB_CHK_EXP & 1) ? 0 : m); i0 += kWave * RB) {
+    for (int i0 = lane; i0 < m; i0 += kWave * RB) {
       double Ax[RB], zi[RB];
 #pragma unroll
       for (int rr = 0; rr < RB; ++rr) zi[rr] = (i0 + rr * kWave < m) ? w.zus[i0 + rr * kWave] : 0.0;
@@ -991,7 +975,7 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
     // the running sum starts at +0.0 and therefore is never -0.0).
     double acc = 0.0;
     bool brk   = false;
-    for (int c0 = 0; c0 < ((SFB_CHK_EXP & 2) ? 0 : m); c0 += chunk) {
+    for (int c0 = 0; c0 < m; c0 += chunk) {
       const int c1 = min(m, c0 + chunk);
       for (int i = c0 + lane; i < c1; i += kWave) {
         const double ui = it.u[i], li = it.l[i], dyi = w.dyus[i];
@@ -1040,7 +1024,7 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
     const double dx_norm = lane_max_abs(w.dxus, n, lane);
     const double thr     = kp.eps_dinf * dx_norm;
     double pn            = 0.0;
-    for (int j0 = lane; j0 < ((SFB_CHK_EXP & 4) ? 0 : n); j0 += kWave * 8) {
+    for (int j0 = lane; j0 < n; j0 += kWave * 8) {
       double Pdx[8];
       sp_rows_P<8, 1>(Pdx, pl, it, j0, w.dxus);
 #pragma unroll
@@ -1270,7 +1254,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
                                              double *__restrict__ gws, const size_t ws_doubles, const int lean_waves,
                                              bool lean, const size_t b, const size_t slot, double *t, const int lane,
                                              bool resume, const int32_t *queue, const int batch,
-                                             const uint32_t slice, const bool allow_reuse, const int phases, float *score, const int nap = 0,
+                                             const uint32_t slice, const bool allow_reuse, const int phases, float *score,
                                              double *trace = nullptr, const int trace_cap = 0)
 {
   const int ph0 = phases & 15, ph1 = (phases >> 4) & 15;  // the phases this launch performs
@@ -1620,21 +1604,20 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     }
     const bool chk = (iter == next_chk);
     wave_sync();
-    if constexpr (LAT && SFB_LAT_SWEEP_DEPTH == 8) {
+    if constexpr (LAT) {
       if (lat_chain && !lean) {
         // chained sweeps (ldl_solve_lat): the backward stream's head is fetched by the forward sweep's last block.  Carrying the
         // chain on into the next iteration's forward sweep (prefetch registers live across the update phases) was built and
         // is NOT done: the compiler is free to copy loop-carried registers while their loads are in flight (wrong results).
         vdouble2 lat_lx[8];
         vint2 lat_ix[8];
-        ldl_solve_lat<SFB_LAT_NT != 0>(pl, w, t, lane, vdinv, lat_lx, lat_ix, false, false);
+        ldl_solve_lat(pl, w, t, lane, vdinv, lat_lx, lat_ix, false, false);
       } else {
-        ldl_solve_dev<SFB_LAT_SWEEP_DEPTH, SFB_LAT_NT != 0>(pl, w, t, lane, lean, vdinv);
+        ldl_solve_dev<8>(pl, w, t, lane, lean, vdinv);
       }
     } else {
-    if (!(SFB_ITER_EXP & 2)) ldl_solve_dev<LAT ? SFB_LAT_SWEEP_DEPTH : SFB_SWEEP_DEPTH, LAT && SFB_LAT_NT>(pl, w, t, lane, lean, LAT ? vdinv : nullptr);  // :456-460
+      ldl_solve_dev<SFB_SWEEP_DEPTH>(pl, w, t, lane, lean, nullptr);  // :456-460
     }
-    for (int q = 0; q < nap; ++q) __builtin_amdgcn_s_sleep(16);  // pacing of the items that are not critical (see the kernel)
     if (chk) next_chk += sci;
     need_rhs = chk;
     // UPDATE PHASES :470-477.  Whole rows of 64 elements run without predicates, U rows per batch (their loads are issued
@@ -1706,10 +1689,8 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
       if constexpr (U > 1) if (r + 1 <= full) { rows(std::integral_constant<int, 1>{}, std::false_type{}, r); r += 1; }
       if (full * kWave < len) rows(std::integral_constant<int, 1>{}, std::true_type{}, r);
     };
-    if (!(SFB_ITER_EXP & 1)) {
-      all_rows(std::integral_constant<int, UNR_A>{}, n, xrows);
-      all_rows(std::integral_constant<int, UNR_B>{}, m, yrows);
-    }
+    all_rows(std::integral_constant<int, UNR_A>{}, n, xrows);
+    all_rows(std::integral_constant<int, UNR_B>{}, m, yrows);
     if (chk) {  // :481-488 unscaled iterate and differences for the check
       for (int j = lane; j < n; j += kWave) {
         const double xn = vxs[j], sxj = w.sx[j], xo = w.dxus[j];
@@ -1888,10 +1869,9 @@ __global__ void __launch_bounds__(64, (LAT || TRACE) ? 2 : 3) qp_sparse_kernel(c
                                                        int32_t *__restrict__ queue, const int batch, const uint32_t slice,
                                                        const SparsePlanDev *__restrict__ plf, double *__restrict__ gwsf,
                                                        const size_t wsf_doubles, int32_t *__restrict__ fbflags, const int phases, const int nfb,
-                                                       float *__restrict__ keys, const int32_t *__restrict__ nfresh_dev, const int ncrit, const int nap,
+                                                       float *__restrict__ keys, const int32_t *__restrict__ nfresh_dev,
                                                        const int mode_sel, double *__restrict__ trace, const int trace_cap)
 {
-  // ncrit: the first ncrit fresh items of this launch (the longest of a launch in predicted order) always use cacheable loads
   // keys (nullable): per item, the predictor score of a paused item (SP_PAUSED) or -1 (nothing left to do for the next launch)
   // nfresh_dev (nullable): the fresh items of this launch are order[0 .. *nfresh_dev - 1] (the survivors of the previous one)
   const int ph0    = phases & 15;
@@ -1910,14 +1890,13 @@ __global__ void __launch_bounds__(64, (LAT || TRACE) ? 2 : 3) qp_sparse_kernel(c
   // batch.  Fresh items first, in launch order; an item that has used its slice while others wait goes to the back
   // of a ring and is continued later by whichever block is free (its state lives in ITS workspace slot = item).
   for (bool first = true;; first = false) {
-    int item = -1, resume = 0, crit = 0;
+    int item = -1, resume = 0;
     if (queue == nullptr) {
       if (first) item = order ? order[blockIdx.x] : (int)blockIdx.x;
     } else if (lane == 0) {
       if (__hip_atomic_load(&queue[kQFresh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nfresh) {
         const int tk = atomicAdd(&queue[kQFresh], 1);
         if (tk < nfresh) item = order ? order[tk] : tk;
-        crit = tk < ncrit;
       }
       while (item < 0) {
         const int head = __hip_atomic_load(&queue[kQHead], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1934,7 +1913,7 @@ __global__ void __launch_bounds__(64, (LAT || TRACE) ? 2 : 3) qp_sparse_kernel(c
     }
     item   = __builtin_amdgcn_readfirstlane(item);
     resume = __builtin_amdgcn_readfirstlane(resume);
-    const int lean_waves_item = __builtin_amdgcn_readfirstlane(crit) ? 0x7FFFFFFF : lean_waves;
+    const int lean_waves_item = lean_waves;
     if (item < 0) break;
     if (resume) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the suspending block's stores (other CU / XCD)
     wave_sync();
@@ -1967,8 +1946,7 @@ __global__ void __launch_bounds__(64, (LAT || TRACE) ? 2 : 3) qp_sparse_kernel(c
     const int st = sp_solve_item<LAT, TRACE>(*use, kp, gPx, gq, gAx, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode, wsb, wsd, lean_waves_item,
                                  lean, (size_t)item, slot, t, lane, resume != 0, fbslot >= 0 ? nullptr : queue, nfresh, slice,
                                  /*allow_reuse: the item's own slot of the main workspace*/ fbslot < 0 && slot == (size_t)item,
-                                 fbslot >= 0 ? PH_EVERYTHING : phases, keys ? keys + item : nullptr,
-                                 __builtin_amdgcn_readfirstlane(crit) ? 0 : nap, trace, trace_cap);
+                                 fbslot >= 0 ? PH_EVERYTHING : phases, keys ? keys + item : nullptr, trace, trace_cap);
     if (keys != nullptr && st != SP_PAUSED && lane == 0) keys[item] = -1.0f;
     if (fbslot >= 0 && phases != PH_EVERYTHING && lane == 0)  // tell the later launches (the item's own slot is otherwise unused)
       carve_ws(gws + (size_t)item * ws_doubles, uni(plp->n), uni(plp->m), uni(plp->nnzL), uni(plp->funits), uni(plp->bunits)).hdr[kHdrComplete] = 1.0;
@@ -2136,7 +2114,6 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
   const bool phased = sliced && ph && atoi(ph) == 1;
   auto launch = [&](unsigned g, int32_t *qa, int lw, int phases, const int32_t *ord = nullptr, uint32_t slc = 0, float *keys = nullptr,
                     const int32_t *nfresh = nullptr, int mode_sel = -1, bool lat = false, size_t lds_lat = 0) -> hipError_t {
-    const int ncrit = 0, nap = sfb::knob("SFB_SP_NAP") ? atoi(sfb::knob("SFB_SP_NAP")) : 0;  // (experiments, see scripts/r3/experiments)
     if (qa != nullptr || pruned) {
       hipError_t e = hipMemsetAsync(aux, 0, sparse_aux_queue_ints(batch) * sizeof(int32_t), stream);
       if (e != hipSuccess) return e;
@@ -2145,7 +2122,7 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     hipLaunchKernelGGL(kern, dim3(g), dim3(kWave), lat ? lds_lat : lds, stream, pl.self, kp, Px, q, Ax, l, u, wx, wy, x, y, obj, iter,
                        code, workspace, wsd, lw, ord, qa, (int)batch, slc ? slc : (uint32_t)std::max(1, slice),
                        pruned ? fallback->self : nullptr, fallback_ws, pruned ? qp_sparse_ws_doubles(*fallback) : 0,
-                       aux ? aux + batch + kQRing : nullptr, phases, (int)std::min<int64_t>(batch, kFbSlots), keys, nfresh, ncrit, nap, mode_sel,
+                       aux ? aux + batch + kQRing : nullptr, phases, (int)std::min<int64_t>(batch, kFbSlots), keys, nfresh, mode_sel,
                        trace, trace_cap);
     return hipGetLastError();
   };

@@ -205,14 +205,15 @@ def test_phased_launch_equals_the_single_kernel(sfb, oracle, grid, grid2, slice_
         monkeypatch.delenv(k)
 
 
-@pytest.mark.parametrize("grid,grid3,pause,deep", [(16, 5, 27, 0), (48, 48, 2, 1), (32, 9, 60, 0), (24, 3, 27, 1)])
-def test_launch_in_predicted_order_equals_the_single_kernel(sfb, oracle, grid, grid3, pause, deep, monkeypatch):
+@pytest.mark.parametrize("grid,grid3,pause,lat", [(16, 5, 27, 1), (48, 48, 2, 0), (32, 9, 60, 1), (24, 3, 27, 0)])
+def test_launch_in_predicted_order_equals_the_single_kernel(sfb, oracle, grid, grid3, pause, lat, monkeypatch):
     """Default for time-sliced launches: a first launch takes every item through setup and its first `pause` iterations
     (items done by then are polished and reported there), the survivors leave a score -- residual over tolerance at
     their last stopping check -- and wait in their workspace; a counting sort orders them by descending score and a second
     launch finishes them longest-first.  A schedule only: same bits as the single kernel (SFB_SP_PREDICT=0) and as the
     oracle, for plain and pruned plans, cold and warm start, an item on the fallback path, a pre-check failure, a
-    max_iter cut-off and another stop_check_iter; also with the 16-unit prefetch form of the second launch."""
+    max_iter cut-off and another stop_check_iter; with the loop launch in the LAT form (loop vectors in LDS, chained sweeps:
+    the default) and in the standard form (SFB_SP_LAT=0)."""
     variant, K, B = 6, 10, 150
     d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
     Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=29)
@@ -220,7 +221,7 @@ def test_launch_in_predicted_order_equals_the_single_kernel(sfb, oracle, grid, g
     Av[9, np.nonzero(~keep)[0][1]] = 0.5          # violates the mask: fallback pool, solved completely in the first launch
     l[13, 2], u[13, 2] = 1.0, -1.0                 # u < l: PrimalInfeasible at the pre-check, no iteration
     Px, q = np.tile(Pv, (B, 1)), np.zeros((B, d["n"]))
-    knobs = ("SFB_SP_GRID", "SFB_SP_PREDICT", "SFB_SP_GRID3", "SFB_SP_PAUSE", "SFB_SP_DEEP3")
+    knobs = ("SFB_SP_GRID", "SFB_SP_PREDICT", "SFB_SP_GRID3", "SFB_SP_PAUSE", "SFB_SP_LAT")
     for prm in (sfb.QPSolverParams(max_iter=4000), sfb.QPSolverParams(max_iter=150, polish=False),
                 sfb.QPSolverParams(max_iter=4000, stop_check_iter=7)):
         for kp in (None, keep):
@@ -232,7 +233,7 @@ def test_launch_in_predicted_order_equals_the_single_kernel(sfb, oracle, grid, g
             monkeypatch.delenv("SFB_SP_PREDICT")
             monkeypatch.setenv("SFB_SP_GRID3", str(grid3))
             monkeypatch.setenv("SFB_SP_PAUSE", str(pause))
-            monkeypatch.setenv("SFB_SP_DEEP3", str(deep))
+            monkeypatch.setenv("SFB_SP_LAT", str(lat))
             r = plan.solve_batch_host(Px, q, Av, l, u, prm)
             r2 = plan.solve_batch_host(Px, q, Av, l, u, prm, warm_x=0.5 * base.primal, warm_y=0.5 * base.dual)
             for a, b in ((r, base), (r2, base2)):
