@@ -91,7 +91,10 @@ class DenseQPWorkload:
                                           self.ws, self.prm, stream=stream.cuda_stream)
 
     def small_outputs(self):
-        return self.out
+        if not hasattr(self, "small"):
+            self.small = torch.empty((self.B, 2), dtype=torch.int32, device=self.out.device)
+        self.small.copy_(self.out.T)  # one row per QP: (iter, code)
+        return self.small
 
     def extra(self):
         it = self.out[0].cpu().numpy().astype(np.int64)
@@ -288,6 +291,10 @@ class MPCWorkload:
                 "mean_iterations_last_tick": float(sw["iter"].mean()), "optimal_fraction_last_tick": float(np.mean(sw["code"] == 0)),
                 "value": self.B / float(np.mean(warm)), "unit": "MPC ticks/s",
                 "path": "MPCSwarmDeviceLin::step: states H2D, device linearisation + assembly + warm-started sparse solve, u0/code/iter D2H"}
+        # the same closed loop with half the agents: what fits the reference example's 25 ms control period on one GPU
+        sw2 = M.mpc_swarm_devlin_step(variant, K, self.B // 2, 6, seed=1, want_records=False)
+        tick["half_swarm"] = {"agents": self.B // 2, "ms_per_tick": 1e3 * float(np.mean(sw2["seconds"][2:])),
+                              "mean_iterations_last_tick": float(sw2["iter"].mean())}
         P1, q1 = Px[:1], q[:1]
         cold, warm1 = [], []
         r1 = self.plan.solve_batch_host(P1, q1, Av[:1], l[:1], u[:1], self.prm)

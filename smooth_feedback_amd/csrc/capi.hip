@@ -278,7 +278,7 @@ sfb_status dense_via_sparse(const sfb_qp_params *prm, int64_t batch, int n, int 
 // kernel's TRACE instance on the full pattern -- no pivoting there, so its iterates equal the dense kernel's up to rounding
 // (the header says so); the results the caller receives are the dense kernel's.
 void dense_verbose_table(const sfb_qp_params *prm, int n, int m, const double *P, const double *q, const double *A, const double *l,
-                         const double *u, const double *wx, const double *wy)
+                         const double *u, const double *wx, const double *wy, const uint32_t *real_iter, const int32_t *real_code)
 {
   sfb_sparse_qp_plan *plan = nullptr;
   if (dense_full_pattern_plan(n, m, &plan) != SFB_OK) return;
@@ -304,10 +304,21 @@ void dense_verbose_table(const sfb_qp_params *prm, int n, int m, const double *P
                                          nullptr) == SFB_OK &&
          hipDeviceSynchronize() == hipSuccess && hipMemcpy(tr.data(), dtrace, tr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess;
   }
+  uint32_t titer_h = 0;
+  int32_t tcode_h  = -1;
+  if (ok) ok = hipMemcpy(&titer_h, titer, 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(&tcode_h, tcode, 4, hipMemcpyDeviceToHost) == hipSuccess;
   (void)hipFree(buf);
-  if (ok)
-    sfb::verbose_table("dense", n, m, tr.data(), rows,
-                       "(table: diagnostic solve without pivoting, equal to the solve's iterates up to rounding)");
+  if (!ok) {
+    (void)hipGetLastError();
+    std::printf("[sfb] verbose: the diagnostic solve behind the per-iteration table failed (%s); no table\n", sfb_last_error());
+    return;
+  }
+  sfb::verbose_table("dense", n, m, tr.data(), rows,
+                     "(table: diagnostic solve without pivoting, equal to the solve's iterates up to rounding)");
+  // the solve whose results the caller receives is the pivoted dense kernel's: say so when the two ended differently
+  if (real_iter != nullptr && real_code != nullptr && (titer_h != *real_iter || tcode_h != *real_code))
+    std::printf("[sfb] verbose: NOTE the table's diagnostic solve ended after %u iterations with code %d, the returned (pivoted) solve after "
+                "%u iterations with code %d\n", titer_h, (int)tcode_h, *real_iter, (int)*real_code);
 }
 
 }  // namespace
@@ -710,7 +721,11 @@ sfb_status sfb_qp_dense_solve_batch_host(const sfb_qp_params *prm, int64_t batch
   } while (false);
   if (e != hipSuccess) st = hip_fail(e, "sfb_qp_dense_solve_batch_host");
   const auto tv3 = clk::now();
-  if (st == SFB_OK && prm->verbose && batch == 1) dense_verbose_table(prm, n, m, dP, dq, dA, dl, du, dwx, dwy);  // (inputs still on the device)
+  if (st == SFB_OK && prm->verbose && batch == 1) {  // (inputs still on the device)
+    uint32_t it1 = 0;
+    const bool have_it = iter ? (it1 = iter[0], true) : hipMemcpy(&it1, dit, 4, hipMemcpyDeviceToHost) == hipSuccess;
+    dense_verbose_table(prm, n, m, dP, dq, dA, dl, du, dwx, dwy, have_it ? &it1 : nullptr, code);
+  }
   if (st == SFB_OK && prm->verbose) {
     std::vector<uint32_t> itv;
     if (!iter) {
