@@ -443,9 +443,8 @@ __device__ __forceinline__ int mid_stop_check_body(const int n_, const int m_, c
     }
   }
   // PRIMAL INFEASIBILITY :598-621
+  // (the certificate's cheap parts first, the mat-vec A' dy only while the verdict is still open: below)
   {
-    double Aty[R];
-    mv_At(dyus, Aty);
     const double Edy = nrm_lds(dyus, m);
     const double thr = eps_pinf * Edy;
     // the ordered sum with its early exit to +inf: the oracle breaks at the first row with an unbounded side beyond the
@@ -483,13 +482,18 @@ __device__ __forceinline__ int mid_stop_check_body(const int n_, const int m_, c
       for (; i < m; ++i) { s += tu[i]; s += tl[i]; }
     }
     if (wave_ballot(brk)) s = inf;
-    const double an = nrm(Aty, var);
-    if (((an < s) ? s : an) < thr) return SFB_QP_PRIMAL_INFEASIBLE;
+    // :616-620 is max(||A' dy||, s) < thr with max(a, s) = (a < s) ? s : a.  With s >= thr (a true comparison: s is no NaN) the
+    // maximum is s or an a >= s or a NaN, never below thr -- whatever A' dy is, so it is not formed.
+    if (!(s >= thr)) {
+      double Aty[R];
+      mv_At(dyus, Aty);
+      const double an = nrm(Aty, var);
+      if (((an < s) ? s : an) < thr) return SFB_QP_PRIMAL_INFEASIBLE;
+    }
   }
   // DUAL INFEASIBILITY :625-641
+  // (q' dx and the row conditions on A dx first; P dx only when they hold)
   {
-    double Pdx[R];
-    mv_P(dxus, Pdx);
     const double dxn = nrm_lds(dxus, n);
     const double thr = eps_dinf * dxn;
     lds_d *const qs = xus;  // q next to dx for the ordered dot product
@@ -509,8 +513,7 @@ __device__ __forceinline__ int mid_stop_check_body(const int n_, const int m_, c
       }
       for (; j < n; ++j) qdx = fma(qs[j], dxus[j], qdx);
     }
-    const bool ok = (nrm(Pdx, var) <= thr) && (qdx <= thr);
-    bool rowok    = true;
+    bool rowok = true;
 #pragma unroll
     for (int r = 0; r < R; ++r)
       if (con[r]) {
@@ -519,7 +522,11 @@ __device__ __forceinline__ int mid_stop_check_body(const int n_, const int m_, c
         else if (li == -inf) rowok = rowok && (Adx[r] <= thr);
         else rowok = rowok && (fabs(Adx[r]) < thr);
       }
-    if (ok && !wave_ballot(!rowok)) return SFB_QP_DUAL_INFEASIBLE;
+    if ((qdx <= thr) && !wave_ballot(!rowok)) {
+      double Pdx[R];
+      mv_P(dxus, Pdx);
+      if (nrm(Pdx, var) <= thr) return SFB_QP_DUAL_INFEASIBLE;
+    }
   }
   return -1;
 }
