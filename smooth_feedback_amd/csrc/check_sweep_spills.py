@@ -41,6 +41,7 @@ def regs_of(text):
 hazards = 0
 for a, b in regions:
     fifo = []  # destination register sets of the loads in flight, oldest first
+    lds = []   # the same for the LDS reads of the hand-scheduled units (retired by s_waitcnt lgkmcnt(N), in order)
     for i in range(a, b + 1):
         t = lines[i].split(";")[0].strip()
         if not t or t.startswith(".") or t.endswith(":"):
@@ -56,16 +57,33 @@ for a, b in regions:
             continue
         if op.startswith(("global_store", "flat_store", "buffer_store")):
             fifo.append(set())  # stores count in vmcnt on gfx9
+        if op.startswith("ds_read"):
+            busy_l = set().union(*lds) if lds else set()
+            if regs_of(",".join(t.split(",")[1:])) & (busy_l | (set().union(*fifo) if fifo else set())):
+                sys.exit("check_sweep_spills: line %d of %s: address of an LDS read is a register still in flight: %s" % (i + 1, sys.argv[1], t))
+            lds.append(regs_of(t.split(",")[0]))
+            continue
+        if op.startswith("ds_write"):
+            busy_l = set().union(*lds) if lds else set()
+            if regs_of(t) & (busy_l | (set().union(*fifo) if fifo else set())):
+                sys.exit("check_sweep_spills: line %d of %s: an LDS write names a register still in flight: %s" % (i + 1, sys.argv[1], t))
+            lds.append(set())  # writes count in lgkmcnt as well
+            continue
         if op == "s_waitcnt":
             m = re.search(r"vmcnt\((\d+)\)", t)
             if m:
                 n = int(m.group(1))
                 while len(fifo) > n:
                     fifo.pop(0)
-            elif re.fullmatch(r"s_waitcnt\s+0(x0+)?", t):
-                fifo = []
+            m = re.search(r"lgkmcnt\((\d+)\)", t)
+            if m:
+                n = int(m.group(1))
+                while len(lds) > n:
+                    lds.pop(0)
+            if re.fullmatch(r"s_waitcnt\s+0(x0+)?", t):
+                fifo, lds = [], []
             continue
-        busy = set().union(*fifo) if fifo else set()
+        busy = (set().union(*fifo) if fifo else set()) | (set().union(*lds) if lds else set())
         if busy and (regs_of(t) & busy):
             hazards += 1
             sys.exit("check_sweep_spills: line %d of %s touches a register of a stream load that is still in flight "

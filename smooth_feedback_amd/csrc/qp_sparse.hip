@@ -31,6 +31,9 @@
 #include "qp_sparse_kernel.h"
 #include "wave_util.h"
 
+#ifndef SFB_SWEEP_ASM
+#define SFB_SWEEP_ASM 1  // 0: the compiler-scheduled units for every form of the sweeps (A/B builds)
+#endif
 #ifndef SFB_SWEEP_DEPTH
 #define SFB_SWEEP_DEPTH 8  // units (2 slots per lane each) in flight per sweep
 #endif
@@ -673,6 +676,78 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
   auto at = [&](unsigned v) -> double & {
     return BYTEOFF ? *reinterpret_cast<double *>(reinterpret_cast<char *>(t) + v) : t[v];
   };
+  // HAND-SCHEDULED UNITS (the cacheable / latency form with byte offsets: the loop launch's lone waves).  The compiler
+  // sinks the unpacking of the next unit's addresses and the issue of the stream loads onto the dependent chain
+  // [reads -> fma -> writes -> reads]; here a unit is ONE asm statement in the order
+  //   wait for unit u+1's stream data | unpack its four LDS addresses (in the shadow of unit u's reads) | wait for the reads |
+  //   two FMAs | two writes | the four reads of unit u+1 right behind them (the LDS serves a wave in order) | the stream loads
+  //   of unit u+8 (in the shadow of those reads).
+  // The reads' results travel from one statement to the next in (a0, b0, a1, b1) while in flight, like the stream loads do in
+  // lx / ix (check_sweep_spills.py replays both).  Same operations on the same operands: bit-identical.
+  constexpr bool kAsmUnits = SFB_SWEEP_ASM != 0 && !LEAN && BYTEOFF && DEPTH == 8;
+  if constexpr (kAsmUnits) {
+#define SFB_SDWA_HI(d, s) "v_add_u32_sdwa " d ", %[tb], " s " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+#define SFB_SDWA_LO(d, s) "v_add_u32_sdwa " d ", %[tb], " s " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+    const unsigned tb = (unsigned)reinterpret_cast<unsigned long long>(t);  // LDS byte address of the work vector (low half of its flat address)
+    stream_wait<2 * (DEPTH - 1)>(lx[0], ix[0]);
+    unsigned ct0, cp0, ct1, cp1;  // LDS addresses of the current unit's targets / pivots
+    double a0, b0, a1, b1;        // what its reads return (in flight between the statements)
+    asm volatile(SFB_SDWA_HI("%[p0]", "%[ixx]") SFB_SDWA_LO("%[t0]", "%[ixx]") SFB_SDWA_HI("%[p1]", "%[ixy]") SFB_SDWA_LO("%[t1]", "%[ixy]")
+                 "ds_read_b64 %[a0], %[p0]\n\tds_read_b64 %[b0], %[t0]\n\tds_read_b64 %[a1], %[p1]\n\tds_read_b64 %[b1], %[t1]"
+                 : [p0] "=&v"(cp0), [t0] "=&v"(ct0), [p1] "=&v"(cp1), [t1] "=&v"(ct1), [a0] "=&v"(a0), [b0] "=&v"(b0), [a1] "=&v"(a1), [b1] "=&v"(b1)
+                 : [tb] "v"(tb), [ixx] "v"(ix[0].x), [ixy] "v"(ix[0].y));
+    (void)cp0; (void)cp1;
+    auto unit = [&]<int D>(std::integral_constant<int, D>) {
+      constexpr int N = (D + 1) % DEPTH;
+      const double vx = lx[D].x, vy = lx[D].y;
+      unsigned nt0, np0, nt1, np1;
+      asm volatile("s_waitcnt vmcnt(12)\n\t"  // unit N's stream data (six younger units stay in flight)
+                   SFB_SDWA_HI("%[np0]", "%[ixx]") SFB_SDWA_LO("%[nt0]", "%[ixx]") SFB_SDWA_HI("%[np1]", "%[ixy]") SFB_SDWA_LO("%[nt1]", "%[ixy]")
+                   "s_waitcnt lgkmcnt(2)\n\t"
+                   "v_fma_f64 %[a0], -%[vx], %[a0], %[b0]\n\t"
+                   "s_waitcnt lgkmcnt(0)\n\t"
+                   "v_fma_f64 %[a1], -%[vy], %[a1], %[b1]\n\t"
+                   "ds_write_b64 %[ct0], %[a0]\n\t"
+                   "ds_write_b64 %[ct1], %[a1]\n\t"
+                   "ds_read_b64 %[a0], %[np0]\n\t"
+                   "ds_read_b64 %[b0], %[nt0]\n\t"
+                   "ds_read_b64 %[a1], %[np1]\n\t"
+                   "ds_read_b64 %[b1], %[nt1]\n\t"
+                   "global_load_dwordx4 %[lxo], %[vp], off offset:%[vo]\n\t"
+                   "global_load_dwordx2 %[ixo], %[ip], off offset:%[io]"
+                   : [a0] "+v"(a0), [b0] "+v"(b0), [a1] "+v"(a1), [b1] "+v"(b1), [np0] "=&v"(np0), [nt0] "=&v"(nt0), [np1] "=&v"(np1),
+                     [nt1] "=&v"(nt1), [lxo] "=v"(lx[D]), [ixo] "=v"(ix[D])
+                   : [vx] "v"(vx), [vy] "v"(vy), [ct0] "v"(ct0), [ct1] "v"(ct1), [tb] "v"(tb), [ixx] "v"(ix[N].x), [ixy] "v"(ix[N].y),
+                     [vp] "v"(vp[D / 4]), [ip] "v"(ip[D / 8]), [vo] "n"((D % 4) * kWave * 16), [io] "n"((D % 8) * kWave * 8));
+      ct0 = nt0;
+      ct1 = nt1;
+      (void)np0; (void)np1;
+    };
+    for (int u0 = 0; u0 + (NEXT ? DEPTH : 0) < units; u0 += DEPTH) {
+      for_units(std::make_integer_sequence<int, DEPTH>{}, unit);
+      advance(DEPTH);
+    }
+    if constexpr (NEXT) {  // the last block (units >= DEPTH, the caller's condition): its loads are the next stream's first units
+#pragma unroll
+      for (int e = 0; e < NVP; ++e) vp[e] = reinterpret_cast<const vdouble2 *>(vals_next) + lane + e * 4 * kWave;
+#pragma unroll
+      for (int e = 0; e < NIP; ++e) ip[e] = reinterpret_cast<const vint2 *>(idx_next) + lane + e * 8 * kWave;
+      for_units(std::make_integer_sequence<int, DEPTH>{}, unit);
+    }
+    // the reads issued behind the last unit (a padding unit's scratch entry, or the next stream's first unit before its
+    // D^-1 step: never used) are retired before their registers are
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
+    if constexpr (NEXT) {
+      wave_lds_fence();  // (no s_waitcnt vmcnt(0) here: the next sweep's first units stay in flight)
+    } else {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) stream_wait<0>(lx[d], ix[d]);
+      wave_sync();
+    }
+    return;
+#undef SFB_SDWA_HI
+#undef SFB_SDWA_LO
+  }
   // Software pipeline over the units: the addresses of unit u+1 are unpacked (and its stream loads awaited) while
   // the LDS reads of unit u are in flight, so that only [reads -> fma -> writes] is left on the dependent chain.
   stream_wait<2 * (DEPTH - 1)>(lx[0], ix[0]);
