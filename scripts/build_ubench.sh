@@ -1,4 +1,4 @@
 #!/bin/bash
 # builds the micro-benchmarks under scripts/ubench/ into scripts/ubench/bin/ (git-ignored); run them on the GPU box
 cd "$(dirname "$0")/ubench" && mkdir -p bin
-for s in lat thr ldschain issue; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -w $s.hip -o bin/$s || exit 1; done
+for s in lat thr ldschain issue mix; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -w $s.hip -o bin/$s || exit 1; done
