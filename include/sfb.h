@@ -165,6 +165,16 @@ sfb_status sfb_qp_dense_solve_batch(const sfb_qp_params *prm, int64_t batch, int
                                     const double *warm_x, const double *warm_y, double *x, double *y,
                                     double *obj, uint32_t *iter, int32_t *code, void *stream);
 
+/* Same (n+m <= 128) with the reference's verbose table (qp_solver.hpp:409-420, :490-501) as DATA: trace [batch][trace_rows][5]
+ * (device) receives one row (ITER, OBJ, PRI_RES, DUA_RES, TIME in microseconds of the device clock since the solve began) per
+ * stopping check of every problem, computed on the iterates of the solve itself; checks beyond trace_rows are dropped, the caller
+ * presets ITER = -1 to tell used rows from unused ones.  One wave per problem whatever the batch size (a diagnostic path);
+ * results are those of sfb_qp_dense_solve_batch, bit for bit.  SFB_ERR_UNSUPPORTED for n+m > 128. */
+sfb_status sfb_qp_dense_solve_batch_trace(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P,
+                                          const double *q, const double *A, const double *l, const double *u,
+                                          const double *warm_x, const double *warm_y, double *x, double *y, double *obj,
+                                          uint32_t *iter, int32_t *code, double *trace, int32_t trace_rows, void *stream);
+
 /*
  * Explicit workspaces.  The reference's QPSolver owns its work memory, allocated once by analyze()
  * (qp_solver.hpp:297-338) and re-used by every solve(); the equivalent here is an opaque device buffer the caller
@@ -197,6 +207,12 @@ sfb_status sfb_qp_dense_solve_batch_host(const sfb_qp_params *prm, int64_t batch
                                          const double *u, const double *warm_x, const double *warm_y,
                                          double *x, double *y, double *obj, uint32_t *iter, int32_t *code);
 void sfb_host_staging_trim(void);
+/* ... with the verbose table as data (trace [batch][trace_rows][5], HOST memory; see sfb_qp_dense_solve_batch_trace; n+m <= 128).
+ * With prm->verbose on ONE problem of that size class the host entry point above prints this table itself. */
+sfb_status sfb_qp_dense_solve_batch_host_trace(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P,
+                                               const double *q, const double *A, const double *l, const double *u,
+                                               const double *warm_x, const double *warm_y, double *x, double *y, double *obj,
+                                               uint32_t *iter, int32_t *code, double *trace, int32_t trace_rows);
 /* ... and sharded over the device list (sfb_set_devices); same arguments, same results. */
 sfb_status sfb_qp_dense_solve_batch_host_multi(const sfb_qp_params *prm, int64_t batch, int n, int m,
                                                const double *P, const double *q, const double *A, const double *l,

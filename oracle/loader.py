@@ -128,7 +128,7 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
 
 
-def qp_dense_solve_batch(P, q, A, l, u, params=None, warm_x=None, warm_y=None, nthreads=1):
+def qp_dense_solve_batch(P, q, A, l, u, params=None, warm_x=None, warm_y=None, nthreads=1, trace_rows=0):
     """Batch-major inputs: P (B,n,n) with P[b] stored COLUMN-major, i.e. P[b].ravel() is the
     col-major buffer (pass np.asfortranarray-style data flattened); same for A (B, m*n).
 
@@ -154,13 +154,23 @@ def qp_dense_solve_batch(P, q, A, l, u, params=None, warm_x=None, warm_y=None, n
     it = np.zeros(B, dtype=np.uint32)
     code = np.zeros(B, dtype=np.int32)
     p = params if params is not None else default_params()
-    rc = lib().oracle_qp_dense_solve_batch(
-        C.byref(p), B, n, m, _dp(P), _dp(q), _dp(A), _dp(l), _dp(u), _dp(warm_x), _dp(warm_y),
-        _dp(x), _dp(y), _dp(obj), it.ctypes.data_as(C.POINTER(C.c_uint32)),
-        code.ctypes.data_as(C.POINTER(C.c_int32)), int(nthreads))
+    trace = None
+    if trace_rows:  # the verbose table of qp_solver.hpp:490-501 as data: (ITER, OBJ, PRI_RES, DUA_RES, PRI_TOL, DUA_TOL) per check
+        trace = np.full((B, int(trace_rows), 6), -1.0)
+        lib().oracle_qp_dense_set_trace.argtypes = [C.POINTER(C.c_double), C.c_int]
+        lib().oracle_qp_dense_set_trace.restype = None
+        lib().oracle_qp_dense_set_trace(_dp(trace), int(trace_rows))
+    try:
+        rc = lib().oracle_qp_dense_solve_batch(
+            C.byref(p), B, n, m, _dp(P), _dp(q), _dp(A), _dp(l), _dp(u), _dp(warm_x), _dp(warm_y),
+            _dp(x), _dp(y), _dp(obj), it.ctypes.data_as(C.POINTER(C.c_uint32)),
+            code.ctypes.data_as(C.POINTER(C.c_int32)), int(nthreads))
+    finally:
+        if trace_rows:
+            lib().oracle_qp_dense_set_trace(None, 0)
     if rc != 0:
         raise RuntimeError("oracle_qp_dense_solve_batch failed rc=%d" % rc)
-    return dict(x=x, y=y, obj=obj, iter=it, code=code)
+    return dict(x=x, y=y, obj=obj, iter=it, code=code, trace=trace)
 
 
 def colmajor(M):

@@ -297,6 +297,15 @@ static void mv_P(const qp_work *w, const double *v, double *out) /* out = P v (P
 }
 
 /* QPSolver::check_stopping, qp_solver.hpp:574-644.  Returns -1 for std::nullopt. */
+/* The reference's verbose table (qp_solver.hpp:490-501) as data, like oracle_qp_sparse_set_trace: while a trace buffer is set,
+ * every stopping check of every item appends (ITER, OBJ, PRI_RES, DUA_RES, tolerance of PRI_RES, tolerance of DUA_RES) to
+ * trace[item][cap][6]; unused rows keep ITER = -1.  Process-global; clear with (NULL, 0). */
+static double *g_dense_trace            = NULL;
+static int g_dense_trace_cap            = 0;
+static __thread double *tl_dense_trace  = NULL; /* the rows of the item the calling thread is solving */
+static __thread int tl_dense_trace_rows = 0;
+void oracle_qp_dense_set_trace(double *trace, int cap) { g_dense_trace = trace; g_dense_trace_cap = cap; }
+
 static int qp_check_stopping(qp_work *w)
 {
   const int n = w->n, m = w->m;
@@ -557,6 +566,19 @@ int oracle_qp_dense_solve(const oracle_qp_params *prm, int n, int m, const doubl
       for (int j = 0; j < n; ++j) w->dx_us[j] = w->sx[j] * (w->primal[j] - w->dx_us[j]);
       for (int i = 0; i < m; ++i) w->dy_us[i] = w->sy[i] * (w->dual[i] - w->dy_us[i]) / w->c;
       ret_code = qp_check_stopping(w);
+      if (tl_dense_trace && tl_dense_trace_rows < g_dense_trace_cap) { /* :490-501, the three columns in the reference's expressions */
+        double *row = tl_dense_trace + 6 * (size_t)tl_dense_trace_rows++;
+        double o = 0.0, pri = 0.0, dua = 0.0;
+        mv_P(w, w->x_us, w->Px);
+        for (int j = 0; j < n; ++j) o += (0.5 * w->Px[j] + q[j]) * w->x_us[j];
+        mv_A(w, w->x_us, w->Ax);
+        for (int i = 0; i < m; ++i) pri = dmax(pri, fabs(w->Ax[i] - w->z_us[i]));
+        mv_At(w, w->y_us, w->Aty);
+        for (int j = 0; j < n; ++j) dua = dmax(dua, fabs(w->Px[j] + q[j] + w->Aty[j]));
+        row[0] = (double)iter; row[1] = o; row[2] = pri; row[3] = dua;
+        row[4] = (double)prm->eps_abs + (double)prm->eps_rel * dmax(norm_inf(w->Ax, m), norm_inf(w->z_us, m));
+        row[5] = (double)prm->eps_abs + (double)prm->eps_rel * dmax(dmax(norm_inf(w->Px, n), norm_inf(q, n)), norm_inf(w->Aty, n));
+      }
       if (ret_code < 0 && prm->max_time_ns >= 0) { /* :504-507 */
         struct timespec t1;
         clock_gettime(CLOCK_MONOTONIC, &t1);
@@ -610,6 +632,9 @@ static void *batch_worker(void *arg)
   for (int64_t b0; (b0 = __atomic_fetch_add(j->next, 16, __ATOMIC_RELAXED)) < j->batch;)
   for (int64_t b = b0; b < b0 + 16 && b < j->batch; ++b) {
     const size_t sb = (size_t)b;
+    tl_dense_trace      = g_dense_trace ? g_dense_trace + 6 * sb * (size_t)g_dense_trace_cap : NULL;
+    tl_dense_trace_rows = 0;
+    for (int r = 0; tl_dense_trace && r < g_dense_trace_cap; ++r) tl_dense_trace[6 * r] = -1.0;
     int rc = oracle_qp_dense_solve(j->prm, j->n, j->m, j->P + sb * n * n, j->q + sb * n, j->A + sb * m * n,
                                    j->l + sb * m, j->u + sb * m, j->wx ? j->wx + sb * n : NULL,
                                    j->wy ? j->wy + sb * m : NULL, j->x + sb * n, j->y + sb * m,

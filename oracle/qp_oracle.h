@@ -111,6 +111,8 @@ int oracle_qp_sparse_solve_batch_ordered(const oracle_qp_params *prm, int64_t ba
  * -- qp_solver.hpp:580-590) per stopping check of every item into trace[batch][cap][6]; unused rows have ITER = -1.  Process-global; clear with (NULL, 0).
  */
 void oracle_qp_sparse_set_trace(double *trace, int cap);
+/* the same for oracle_qp_dense_solve_batch: trace[batch][cap][6] */
+void oracle_qp_dense_set_trace(double *trace, int cap);
 
 /*
  * Restatement of Eigen 3.4 LDLT (unblocked, diagonal pivoting) exposed for unit tests.

@@ -73,6 +73,8 @@ def _load():
     L.sfb_qp_dense_solve_batch.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12 + [vp]
     L.sfb_qp_dense_solve_batch_host.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12
     L.sfb_qp_dense_solve_batch_host_multi.argtypes = L.sfb_qp_dense_solve_batch_host.argtypes
+    L.sfb_qp_dense_solve_batch_host_trace.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12 + [dp, i32]
+    L.sfb_qp_dense_solve_batch_trace.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12 + [dp, i32, vp]
     L.sfb_qp_dense_solve_batch_ws.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12 + [vp, vp]
     L.sfb_qp_dense_workspace_bytes.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32, C.POINTER(C.c_int64)]
     L.sfb_workspace_create.argtypes = [i64, C.POINTER(C.c_void_p)]

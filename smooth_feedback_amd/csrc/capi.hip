@@ -273,6 +273,32 @@ sfb_status dense_via_sparse(const sfb_qp_params *prm, int64_t batch, int n, int 
   return st;
 }
 
+// verbose, ONE dense problem with n + m <= 128 (device pointers of the call): the per-iteration table of qp_solver.hpp:490-501
+// from the TRACE instance of the on-chip dense kernel (qp_dense_mid.hip) -- the same pivoted arithmetic as the solve whose
+// results the caller receives (every dense route is bit-identical to the dense oracle), so the rows ARE that solve's iterates.
+void dense_native_table(const sfb_qp_params *prm, int n, int m, const double *P, const double *q, const double *A, const double *l,
+                        const double *u, const double *wx, const double *wy)
+{
+  const int rows = sfb::verbose_table_rows(prm);
+  std::vector<double> tr((size_t)rows * 5, 0.0);
+  for (int r = 0; r < rows; ++r) tr[(size_t)r * 5] = -1.0;
+  char *buf = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&buf), ((size_t)n + m + 2 + tr.size()) * 8 + 16) != hipSuccess) { (void)hipGetLastError(); return; }
+  double *tx = reinterpret_cast<double *>(buf), *ty = tx + n, *tobj = ty + m, *dtr = tobj + 1;
+  uint32_t *titer = reinterpret_cast<uint32_t *>(dtr + tr.size());
+  int32_t *tcode  = reinterpret_cast<int32_t *>(titer + 1);
+  sfb_qp_params p2 = *prm;
+  p2.verbose       = 0;
+  const sfb::DenseKernelParams kp = make_kernel_params(&p2, n, m);
+  const sfb::QpBatch g{P, q, A, l, u, wx, wy, tx, ty, tobj, titer, tcode};
+  const bool ok = hipMemcpy(dtr, tr.data(), tr.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+                  sfb::qp_dense_mid_trace_launch(kp, 1, g, nullptr, dtr, rows) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+                  hipMemcpy(tr.data(), dtr, tr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(buf);
+  if (ok) sfb::verbose_table("dense", n, m, tr.data(), rows, nullptr);
+  else (void)hipGetLastError();
+}
+
 // verbose, ONE dense problem (device pointers of the call): the per-iteration table of qp_solver.hpp:490-501.  The dense
 // kernels carry no trace; the table is produced by a second, diagnostic solve of the same problem through the sparse
 // kernel's TRACE instance on the full pattern -- no pivoting there, so its iterates equal the dense kernel's up to rounding
@@ -522,6 +548,25 @@ sfb_status sfb_qp_dense_solve_batch(const sfb_qp_params *prm, int64_t batch, int
   return dense_solve_impl(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code, nullptr, false, stream);
 }
 
+sfb_status sfb_qp_dense_solve_batch_trace(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P, const double *q,
+                                          const double *A, const double *l, const double *u, const double *warm_x, const double *warm_y,
+                                          double *x, double *y, double *obj, uint32_t *iter, int32_t *code, double *trace,
+                                          int32_t trace_rows, void *stream)
+{
+  sfb_status st = check_qp_args(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, code);
+  if (st != SFB_OK) return st;
+  if (trace_rows < 0 || (trace_rows > 0 && !trace)) return fail(SFB_ERR_INVALID_ARG, "trace is NULL or trace_rows < 0");
+  if (n + m > sfb::kDenseMidMaxK) return fail(SFB_ERR_UNSUPPORTED, "the per-iteration table of a dense problem needs n + m <= 128");
+  st = require_device();
+  if (st != SFB_OK) return st;
+  if (batch == 0) return SFB_OK;
+  const sfb::DenseKernelParams kp = make_kernel_params(prm, n, m);
+  const sfb::QpBatch g{P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code};
+  const hipError_t e = sfb::qp_dense_mid_trace_launch(kp, batch, g, static_cast<hipStream_t>(stream), trace_rows > 0 ? trace : nullptr, trace_rows);
+  if (e != hipSuccess) return hip_fail(e, "qp_dense_mid_trace_kernel launch");
+  return SFB_OK;
+}
+
 sfb_status sfb_qp_dense_solve_batch_ws(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P,
                                        const double *q, const double *A, const double *l, const double *u,
                                        const double *warm_x, const double *warm_y, double *x, double *y, double *obj,
@@ -724,7 +769,8 @@ sfb_status sfb_qp_dense_solve_batch_host(const sfb_qp_params *prm, int64_t batch
   if (st == SFB_OK && prm->verbose && batch == 1) {  // (inputs still on the device)
     uint32_t it1 = 0;
     const bool have_it = iter ? (it1 = iter[0], true) : hipMemcpy(&it1, dit, 4, hipMemcpyDeviceToHost) == hipSuccess;
-    dense_verbose_table(prm, n, m, dP, dq, dA, dl, du, dwx, dwy, have_it ? &it1 : nullptr, code);
+    if (n + m <= sfb::kDenseMidMaxK) dense_native_table(prm, n, m, dP, dq, dA, dl, du, dwx, dwy);  // the solve's own iterates
+    else dense_verbose_table(prm, n, m, dP, dq, dA, dl, du, dwx, dwy, have_it ? &it1 : nullptr, code);
   }
   if (st == SFB_OK && prm->verbose) {
     std::vector<uint32_t> itv;
@@ -735,6 +781,58 @@ sfb_status sfb_qp_dense_solve_batch_host(const sfb_qp_params *prm, int64_t batch
     sfb::verbose_report("dense QP batch", batch, n, m, ms(tv0, tv1), ms(tv1, tv2), ms(tv2, tv3), code,
                         iter ? iter : (itv.empty() ? nullptr : itv.data()));
   }
+  return st;
+}
+
+sfb_status sfb_qp_dense_solve_batch_host_trace(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P, const double *q,
+                                               const double *A, const double *l, const double *u, const double *warm_x, const double *warm_y,
+                                               double *x, double *y, double *obj, uint32_t *iter, int32_t *code, double *trace,
+                                               int32_t trace_rows)
+{
+  sfb_status st = check_qp_args(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, code);
+  if (st != SFB_OK) return st;
+  if (trace_rows < 0 || (trace_rows > 0 && !trace)) return fail(SFB_ERR_INVALID_ARG, "trace is NULL or trace_rows < 0");
+  if (n + m > sfb::kDenseMidMaxK) return fail(SFB_ERR_UNSUPPORTED, "the per-iteration table of a dense problem needs n + m <= 128");
+  st = require_device();
+  if (st != SFB_OK) return st;
+  if (batch == 0) return SFB_OK;
+  const size_t B = (size_t)batch, N = (size_t)n, M = (size_t)m, TR = B * (size_t)trace_rows * 5;
+  const size_t doubles = B * (N * N + N + M * N + 2 * M) + (warm_x ? B * (N + M) : 0) + B * (N + M + 1) + TR;
+  char *mem    = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&mem), doubles * 8 + B * 8);
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+  double *dP = reinterpret_cast<double *>(mem), *dq = dP + B * N * N, *dA = dq + B * N, *dl = dA + B * M * N, *du = dl + B * M, *nx = du + B * M;
+  double *dwx = nullptr, *dwy = nullptr;
+  if (warm_x) { dwx = nx; dwy = dwx + B * N; nx = dwy + B * M; }
+  double *dx = nx, *dy = dx + B * N, *dobj = dy + B * M, *dtr = dobj + B;
+  uint32_t *dit  = reinterpret_cast<uint32_t *>(dtr + TR);
+  int32_t *dcode = reinterpret_cast<int32_t *>(dit + B);
+  auto H2D = [&](void *d, const void *h, size_t nb) { return hipMemcpy(d, h, nb, hipMemcpyHostToDevice); };
+  auto D2H = [&](void *h, const void *d, size_t nb) { return hipMemcpy(h, d, nb, hipMemcpyDeviceToHost); };
+  do {
+    if ((e = H2D(dP, P, B * N * N * 8)) != hipSuccess) break;
+    if ((e = H2D(dq, q, B * N * 8)) != hipSuccess) break;
+    if ((e = H2D(dA, A, B * M * N * 8)) != hipSuccess) break;
+    if ((e = H2D(dl, l, B * M * 8)) != hipSuccess) break;
+    if ((e = H2D(du, u, B * M * 8)) != hipSuccess) break;
+    if (warm_x && ((e = H2D(dwx, warm_x, B * N * 8)) != hipSuccess || (e = H2D(dwy, warm_y, B * M * 8)) != hipSuccess)) break;
+    if (TR) {  // unused rows keep ITER = -1
+      std::vector<double> init(TR, 0.0);
+      for (size_t r = 0; r < TR; r += 5) init[r] = -1.0;
+      if ((e = H2D(dtr, init.data(), TR * 8)) != hipSuccess) break;
+    }
+    st = sfb_qp_dense_solve_batch_trace(prm, batch, n, m, dP, dq, dA, dl, du, dwx, dwy, dx, dy, dobj, dit, dcode, TR ? dtr : nullptr, trace_rows, nullptr);
+    if (st != SFB_OK) break;
+    if ((e = hipDeviceSynchronize()) != hipSuccess) break;
+    if ((e = D2H(x, dx, B * N * 8)) != hipSuccess) break;
+    if ((e = D2H(y, dy, B * M * 8)) != hipSuccess) break;
+    if (obj && (e = D2H(obj, dobj, B * 8)) != hipSuccess) break;
+    if (iter && (e = D2H(iter, dit, B * 4)) != hipSuccess) break;
+    if ((e = D2H(code, dcode, B * 4)) != hipSuccess) break;
+    if (TR && (e = D2H(trace, dtr, TR * 8)) != hipSuccess) break;
+  } while (false);
+  (void)hipFree(mem);
+  if (e != hipSuccess) return hip_fail(e, "sfb_qp_dense_solve_batch_host_trace");
   return st;
 }
 

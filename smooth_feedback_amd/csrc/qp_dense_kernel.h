@@ -50,6 +50,9 @@ size_t qp_dense_mid_lds_bytes(int n, int m);
 // workspace: qp_dense_mid_ws_bytes bytes of device memory (0 for batches the chip holds at once), or nullptr = stream-ordered allocation
 size_t qp_dense_mid_ws_bytes(const DenseKernelParams &kp, int64_t batch);
 hipError_t qp_dense_mid_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream, void *workspace = nullptr);
+// the same solve through the TRACE instance (one block per QP, any n + m <= 128): a row (ITER, OBJ, PRI_RES, DUA_RES, TIME us) of the
+// reference's verbose table per stopping check into trace [batch][trace_cap][5] (device memory, rows preset by the caller)
+hipError_t qp_dense_mid_trace_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream, double *trace, int trace_cap);
 bool qp_dense_mid_enabled();  // SFB_QP_MID=0 (A/B, tests): the kernels these sizes had before
 
 hipError_t qp_dense_launch(const DenseKernelParams &kp, int64_t batch, const double *P, const double *q,

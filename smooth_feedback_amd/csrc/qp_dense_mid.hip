@@ -531,6 +531,49 @@ __device__ __forceinline__ int mid_stop_check_body(const int n_, const int m_, c
   return -1;
 }
 
+// One row of the reference's verbose table (qp_solver.hpp:490-501) at a stopping check: ITER, OBJ = (0.5 P x + q) . x,
+// PRI_RES = |A x - z|_inf, DUA_RES = |P x + q + A' y|_inf on the un-scaled iterate (V = [x | dx | y | z], still intact:
+// called in FRONT of the check, which re-uses y, z and x as scratch), TIME in microseconds of the device clock since the
+// solve began.  The three products row by row like the check's (k ascending fma chains), the dot product a sequential
+// mul + add chain: the columns of oracle/qp_oracle.c's trace, bit for bit.  Only the TRACE instance calls this.
+// sc: n doubles of LDS scratch behind the kernel's regular areas.
+template<int R>
+__device__ __attribute__((noinline)) void mid_trace_row(const int n_, const int m_, const int lane, const double *const P, const double *const q,
+                                                       const double *const A, lds_d *const V, lds_d *const sc, const uint32_t iter,
+                                                       const unsigned long long t0_ticks, double *const row)
+{
+  const int n = muni(n_), m = muni(m_);
+  lds_d *const xus = V, *const yus = V + 2 * n, *const zus = yus + m;
+  double Px[R], Aty[R], Ax[R], qv[R];
+  double pri = 0.0, dua = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int e = lane + kWave * r;
+    const bool var = e < n, con = e < m;
+    double sp = 0.0, sa = 0.0, st = 0.0;
+    mvec<8>(P + (var ? e : 0), (size_t)n, xus, xus, n, [&](int, double p, double x0, double) { sp = fma(p, x0, sp); });
+    mvec<8>(A + (size_t)(var ? e : 0) * m, 1, yus, yus, m, [&](int, double a, double y0, double) { st = fma(a, y0, st); });
+    mvec<8>(A + (con ? e : 0), (size_t)m, xus, xus, n, [&](int, double a, double x0, double) { sa = fma(a, x0, sa); });
+    Px[r] = var ? sp : 0.0;  Aty[r] = var ? st : 0.0;  Ax[r] = con ? sa : 0.0;
+    qv[r] = var ? q[e] : 0.0;
+    if (var) {
+      sc[e] = (0.5 * Px[r] + qv[r]) * xus[e];
+      dua   = fmax(dua, fabs(Px[r] + qv[r] + Aty[r]));
+    }
+    if (con) pri = fmax(pri, fabs(Ax[r] - zus[e]));
+  }
+  wave_lds_fence();
+  double o = 0.0;
+  for (int j = 0; j < n; ++j) o += sc[j];
+  pri = wave_max(pri);
+  dua = wave_max(dua);
+  if (lane == 0) {
+    row[0] = (double)iter;  row[1] = o;  row[2] = pri;  row[3] = dua;
+    row[4] = (double)((wall_clock64() - t0_ticks) / 100ull);
+  }
+  wave_lds_fence();
+}
+
 // outlined instance (the LDS block engine: the check's registers stay out of the ADMM loop's budget)
 template<int R>
 __device__ __attribute__((noinline)) int mid_stop_check(const int n, const int m, const int lane, const double *const P, const double *const q,
@@ -1134,11 +1177,13 @@ __device__ __forceinline__ void mid_finish(const MidC &C, const DenseKernelParam
 
 // One ADMM iteration state machine (:447-510) on the rows in registers.  QUEUE: time-sliced -- returns true when the QP
 // has used its slice while others are waiting (the caller suspends it), false when the loop has ended.
-template<int NB, int R, bool QUEUE>
+template<int NB, int R, bool QUEUE, bool TRACE = false>
 __device__ __forceinline__ bool mid_admm(const MidC &C, const DenseKernelParams &kp, MidRow (&h)[R], const double c, uint32_t &iter, uint32_t &next_chk,
                                          int &ret_code, const unsigned long long t0_ticks, const uint32_t slice, const unsigned *const q_fresh,
-                                         const unsigned *const q_rhead, const unsigned *const q_tail, const unsigned batch)
+                                         const unsigned *const q_rhead, const unsigned *const q_tail, const unsigned batch,
+                                         double *const trace = nullptr, const int trace_cap = 0, lds_d *const trace_sc = nullptr)
 {
+  [[maybe_unused]] int trace_rows = 0;
   const int n = C.n, m = C.m, k = C.k, lane = C.lane, tsz = C.tsz;
   lds_d *const T = C.T, *const Dg = C.Dg, *const tmp = C.tmp, *const V = C.V;
   lds_b *const perm = C.perm;
@@ -1171,7 +1216,8 @@ __device__ __forceinline__ bool mid_admm(const MidC &C, const DenseKernelParams 
     }
   };
   // k <= 64: the factor moves into registers for the duration of the loop (sweep_rows.h, registers-only engine)
-  constexpr bool kRegs = NB <= 4 && SFB_MID_REGS != 0;
+  // (the TRACE instance serves every k <= 16 NB, also below the class of its block count: the LDS engine in its any-K form)
+  constexpr bool kRegs = NB <= 4 && SFB_MID_REGS != 0 && !TRACE;
   constexpr bool kChkKeep = SFB_MID_CHK_KEEP != 0;
   rows::Masks masks{};
   if constexpr (!kRegs) masks = rows::make_masks();  // (once, in front of the loop: see sweep_rows.h)
@@ -1197,13 +1243,17 @@ __device__ __forceinline__ bool mid_admm(const MidC &C, const DenseKernelParams 
     }
     rows::Pair t{rhs(h[0]), R > 1 ? rhs(h[R - 1]) : 0.0};
     if constexpr (kRegs) t.lo = rows::row_sweeps_reg<NB>(k, F, t.lo, lane);                              // :462
-    else t = rows::row_sweeps_inl<NB, false>(k, (const double *)T, (const double *)Dg, t, lane, masks);
+    else t = rows::row_sweeps_inl<NB, TRACE>(k, (const double *)T, (const double *)Dg, t, lane, masks);
     const bool chk = (iter == next_chk);                                                            // :465
     if (chk) next_chk += sci;
     upd(h[0], t.lo, chk);
     if constexpr (R > 1) upd(h[R - 1], t.hi, chk);
     if (chk) {
       wave_lds_fence();
+      if constexpr (TRACE) {  // the reference's verbose table as data (:490-501)
+        if (trace != nullptr && trace_rows < trace_cap) mid_trace_row<R>(n, m, lane, P, q, A, V, trace_sc, iter, t0_ticks, trace + 5 * (size_t)trace_rows);
+        ++trace_rows;
+      }
       // registers-only engine: the check is INLINED (an outlined call would save and restore the live factor registers
       // through scratch memory); SFB_MID_CHK_KEEP: the factor registers stay live across it and the check requests the
       // matrix entries in short batches that fit next to them, otherwise they are dead across it and re-filled from LDS behind it
@@ -1248,6 +1298,29 @@ __global__ void __launch_bounds__(64, WPE) qp_dense_mid_kernel(const DenseKernel
            C.n, C.m, g_midprof[1] - g_midprof[0], g_midprof[2] - g_midprof[1], g_midprof[3] - g_midprof[2], g_midprof[4] - g_midprof[3],
            g_midprof[5] - g_midprof[4], g_midprof[6] - g_midprof[5], g_midprof[7] - g_midprof[6], iter, g_midprof[8] - g_midprof[7], g_midprof[9] - g_midprof[8]);
 #endif
+}
+
+// TRACE instance of the fused launch (sfb_qp_dense_solve_batch_trace; verbose on one problem): the same solve, one block per QP
+// whatever the batch size, with a row of the reference's verbose table written per stopping check (trace [batch][cap][5], rows
+// beyond cap dropped).  Serves every n + m <= 16 NB (the NB = 3 instance also the sizes the four-per-wave kernel normally takes).
+template<int NB, int WPE>
+__global__ void __launch_bounds__(64, WPE) qp_dense_mid_trace_kernel(const DenseKernelParams kp, const QpBatch g, double *__restrict__ trace,
+                                                                     const int trace_cap)
+{
+  constexpr int R = NB > 4 ? 2 : 1;
+  constexpr int kFillU = NB > 4 ? 16 : 8;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int lane = threadIdx.x;
+  const MidC C   = mid_context(sm, kp, g, blockIdx.x, lane);
+  MidRow h[R];
+  double c = 1.0;
+  unsigned long long t0_ticks = 0;
+  int ret_code      = mid_setup<R, kFillU>(C, kp, h, c, t0_ticks);
+  uint32_t iter     = 0;
+  uint32_t next_chk = (kp.stop_check_iter >= 2) ? 1u : 0xFFFFFFFFu;
+  mid_admm<NB, R, false, true>(C, kp, h, c, iter, next_chk, ret_code, t0_ticks, 0, nullptr, nullptr, nullptr, 0,
+                               trace ? trace + (size_t)blockIdx.x * (size_t)trace_cap * 5 : nullptr, trace_cap, (lds_d *)(sm + mid_layout(kp.n, kp.m).total));
+  mid_finish<R, NB, kFillU>(C, kp, h, c, ret_code, iter);
 }
 
 // SPLIT launch for batches larger than the chip: setup (one QP per workgroup) -> records; loop (persistent, time-sliced);
@@ -1376,7 +1449,7 @@ namespace {
 // the setup / finish kernels and the fused kernel take what the LDS leaves them anyway
 template<int NBV> struct MidW { static constexpr int loop = NBV <= 3 ? SFB_MID_W3 : (NBV == 4 ? SFB_MID_W4 : (NBV == 5 ? 2 : 1)), other = NBV <= 5 ? 2 : 1; };
 
-enum MidOp { MID_RESIDENT, MID_FUSED, MID_SETUP, MID_LOOP, MID_FINISH };
+enum MidOp { MID_RESIDENT, MID_FUSED, MID_SETUP, MID_LOOP, MID_FINISH, MID_TRACE };
 struct MidLaunch {
   MidOp op;
   unsigned grid, batch;
@@ -1386,6 +1459,8 @@ struct MidLaunch {
   uint32_t slice;
   int *resident;
   hipStream_t stream;
+  double *trace = nullptr;
+  int trace_cap = 0;
 };
 template<int NBV>
 hipError_t mid_launch_nb(const DenseKernelParams &kp, const QpBatch &g, const size_t lds, const MidLaunch &a)
@@ -1409,6 +1484,10 @@ hipError_t mid_launch_nb(const DenseKernelParams &kp, const QpBatch &g, const si
       hipLaunchKernelGGL((qp_dense_mid_loop_kernel<NBV, WL>), dim3(a.grid), dim3(kWave), lds, a.stream, kp, g, a.ws, a.wsd, a.queue, a.batch, a.slice);
       break;
     case MID_FINISH: hipLaunchKernelGGL((qp_dense_mid_finish_kernel<NBV, WO>), dim3(a.grid), dim3(kWave), lds, a.stream, kp, g, a.ws, a.wsd); break;
+    case MID_TRACE:
+      hipLaunchKernelGGL((qp_dense_mid_trace_kernel<NBV, WO>), dim3(a.grid), dim3(kWave), lds + (size_t)kp.n * sizeof(double), a.stream, kp, g, a.trace,
+                         a.trace_cap);
+      break;
   }
   return hipGetLastError();
 }
@@ -1454,6 +1533,16 @@ size_t qp_dense_mid_ws_bytes(const DenseKernelParams &kp, int64_t batch)
   const int res = mid_resident(kp);
   if (res <= 0 || batch <= (int64_t)res) return 0;
   return (size_t)batch * mid_save_doubles(kp.n, kp.m) * sizeof(double) + 256 + 2 * (size_t)batch * sizeof(unsigned long long);
+}
+
+hipError_t qp_dense_mid_trace_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream, double *trace, int trace_cap)
+{
+  const int k = kp.n + kp.m;
+  if (k > kDenseMidMaxK || k < 1) return hipErrorInvalidValue;
+  MidLaunch a{MID_TRACE, (unsigned)batch, (unsigned)batch, nullptr, 0, nullptr, 0, nullptr, stream};
+  a.trace     = trace;
+  a.trace_cap = trace_cap;
+  return mid_launch(kp, g, a);
 }
 
 hipError_t qp_dense_mid_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream, void *workspace)

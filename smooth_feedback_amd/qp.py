@@ -112,10 +112,12 @@ def pack_colmajor(M):
     return np.ascontiguousarray(np.transpose(M, (0, 2, 1)).reshape(M.shape[0], -1))
 
 
-def solve_qp_batch_host(P, q, A, l, u, prm: Optional[QPSolverParams] = None, warm_x=None, warm_y=None, multi_device=False):
+def solve_qp_batch_host(P, q, A, l, u, prm: Optional[QPSolverParams] = None, warm_x=None, warm_y=None, multi_device=False,
+                        trace_rows=0):
     """Batched solve_qp on host numpy buffers.  P (B, n*n) and A (B, m*n) are COLUMN-major flat
     buffers (see pack_colmajor), q (B,n), l,u (B,m).  Calls sfb_qp_dense_solve_batch_host, or with multi_device the
-    variant that shards the batch over the device list (_capi.set_devices)."""
+    variant that shards the batch over the device list (_capi.set_devices).  trace_rows > 0 (n + m <= 128): the
+    reference's verbose table (qp_solver.hpp:490-501) as data in `.trace` (sfb_qp_dense_solve_batch_host_trace)."""
     q = np.ascontiguousarray(q, dtype=np.float64)
     l = np.ascontiguousarray(l, dtype=np.float64)
     if q.ndim != 2 or l.ndim != 2:
@@ -136,6 +138,14 @@ def solve_qp_batch_host(P, q, A, l, u, prm: Optional[QPSolverParams] = None, war
     it = np.empty(B, dtype=np.uint32)
     code = np.empty(B, dtype=np.int32)
     cp = (prm or QPSolverParams()).to_c()
+    if trace_rows:
+        if multi_device:
+            raise ValueError("trace_rows and multi_device exclude each other")
+        trace = np.empty((B, int(trace_rows), 5))
+        _capi.check(_capi.lib.sfb_qp_dense_solve_batch_host_trace(
+            C.byref(cp), B, n, m, _ptr(P), _ptr(q), _ptr(A), _ptr(l), _ptr(u), _ptr(warm_x), _ptr(warm_y),
+            _ptr(x), _ptr(y), _ptr(obj), _ptr(it), _ptr(code), _ptr(trace), int(trace_rows)))
+        return QPBatchSolution(code=code, iter=it, primal=x, dual=y, objective=obj, trace=trace)
     fn = _capi.lib.sfb_qp_dense_solve_batch_host_multi if multi_device else _capi.lib.sfb_qp_dense_solve_batch_host
     _capi.check(fn(
         C.byref(cp), B, n, m, _ptr(P), _ptr(q), _ptr(A), _ptr(l), _ptr(u), _ptr(warm_x), _ptr(warm_y),

@@ -531,3 +531,63 @@ def test_verbose_single_dense_problem_prints_the_reference_table(sfb, capfd):
     sfb.solve_qp_batch_host(*sfb.random_qp_batch(3, 4, 20, 10, 1.0), sfb.QPSolverParams(max_iter=100, verbose=True))
     out = capfd.readouterr().out
     assert "QP Solver ====" not in out and "[sfb] dense QP batch: 4 problem(s)" in out
+
+
+@pytest.mark.parametrize("n,m,B", [(3, 5, 40), (10, 20, 64), (16, 32, 48), (20, 40, 48), (32, 64, 24), (40, 60, 24), (64, 64, 12)])
+def test_verbose_table_as_data_matches_the_dense_oracle_trace(sfb, oracle, n, m, B):
+    """qp_solver.hpp:490-501 for dense problems, natively: ITER, OBJ, PRI_RES, DUA_RES per stopping check from the TRACE
+    instance of the on-chip dense kernel (n + m <= 128, every block count incl. the sizes the four-per-wave kernel
+    normally takes) against the dense oracle's trace bit for bit, and the results of the traced call against the plain
+    one -- the table is made of the iterates of the very solve whose results are returned."""
+    rows = 10
+    P, q, A, l, u = sfb.random_qp_batch(23, B, m, n, 0.9)
+    prm = sfb.QPSolverParams(max_iter=202)
+    plain = sfb.solve_qp_batch_host(P, q, A, l, u, prm)
+    r = sfb.solve_qp_batch_host(P, q, A, l, u, prm, trace_rows=rows)
+    assert np.array_equal(r.code, plain.code) and np.array_equal(r.iter, plain.iter)
+    assert np.array_equal(r.primal, plain.primal, equal_nan=True) and np.array_equal(r.dual, plain.dual, equal_nan=True)
+    assert np.array_equal(r.objective, plain.objective, equal_nan=True)
+    ref = oracle.qp_dense_solve_batch(P, q, A, l, u, params=_oracle_params(oracle, prm), nthreads=8, trace_rows=rows)
+    assert np.array_equal(r.iter, ref["iter"]) and np.array_equal(r.code, ref["code"])
+    tr, tref = r.trace, ref["trace"]
+    assert np.array_equal(tr[:, :, 0], tref[:, :, 0]), "check iterations differ"
+    used = tref[:, :, 0] >= 0
+    assert used.sum() > B and (tr[:, :, 0][used] % 25 == 1).all()
+    for col, name in ((1, "OBJ"), (2, "PRI_RES"), (3, "DUA_RES")):
+        a, b = tr[:, :, col][used], tref[:, :, col][used]
+        fin = np.isfinite(b)
+        assert np.array_equal(a[fin], b[fin]), (name, np.abs(a[fin] - b[fin]).max())
+    both = used[:, 1:] & used[:, :-1]
+    assert (tr[:, :, 4][used] >= 0).all() and (tr[:, 1:, 4][both] >= tr[:, :-1, 4][both]).all()  # TIME grows
+    # warm start and a table shorter than the number of checks
+    w = sfb.solve_qp_batch_host(P, q, A, l, u, prm, warm_x=0.5 * plain.primal, warm_y=0.5 * plain.dual, trace_rows=2)
+    wp = sfb.solve_qp_batch_host(P, q, A, l, u, prm, warm_x=0.5 * plain.primal, warm_y=0.5 * plain.dual)
+    assert w.trace.shape == (B, 2, 5) and np.array_equal(w.iter, wp.iter) and np.array_equal(w.primal, wp.primal, equal_nan=True)
+
+
+def test_dense_trace_is_refused_beyond_the_on_chip_sizes(sfb):
+    P, q, A, l, u = sfb.random_qp_batch(1, 2, 100, 40, 0.5)
+    with pytest.raises(sfb._capi.SfbError) as ei:
+        sfb.solve_qp_batch_host(P, q, A, l, u, sfb.QPSolverParams(max_iter=50), trace_rows=4)
+    assert "128" in str(ei.value)
+
+
+def test_verbose_single_dense_problem_table_is_the_solves_own(sfb, oracle, capfd):
+    """verbose on ONE dense problem with n + m <= 128 prints the native table: its rows are the oracle's trace of the same
+    solve (to the printed digits), no diagnostic-solve note."""
+    P, q, A, l, u = sfb.random_qp_batch(4, 1, 40, 20, 1.0)
+    prm = sfb.QPSolverParams(max_iter=3000, verbose=True)
+    capfd.readouterr()
+    r = sfb.solve_qp_batch_host(P, q, A, l, u, prm)
+    out = capfd.readouterr().out
+    assert "Solving dense QP with n=20, m=40" in out and "diagnostic solve" not in out
+    lines = [ln for ln in out.splitlines() if ":" in ln and ln.split(":")[0].strip().isdigit()]
+    ref = oracle.qp_dense_solve_batch(P, q, A, l, u, params=_oracle_params(oracle, sfb.QPSolverParams(max_iter=3000)), trace_rows=len(lines) + 2)
+    used = ref["trace"][0][ref["trace"][0][:, 0] >= 0]
+    assert len(lines) == len(used) and int(r.iter[0]) == int(ref["iter"][0])
+    for ln, row in zip(lines, used):
+        it, rest = ln.split(":")
+        vals = [float(v) for v in rest.split()[:3]]
+        assert int(it) == int(row[0])
+        for v, e in zip(vals, row[1:4]):
+            assert v == float("%.6e" % e)
