@@ -31,8 +31,11 @@ using namespace ekf_lane;  // tile I/O, SmallLdlt and the per-lane predict / upd
 }  // namespace
 
 // One launch = optional predict (Euler substep) followed by optional update, fused per item.
+#ifndef SFB_EKF_WPE
+#define SFB_EKF_WPE 1  // waves per SIMD the fused kernel is compiled for (2: 256 registers in all, measured slower -- scripts/r4/experiments)
+#endif
 template<int N, int M, bool PREDICT, bool UPDATE>
-__global__ void __launch_bounds__(64) ekf_kernel(const EkfArgs a)
+__global__ void __launch_bounds__(64, SFB_EKF_WPE) ekf_kernel(const EkfArgs a)
 {
   constexpr int NN = N * N, NP = NN | 1;
   constexpr int WMAX = (NN > M * N ? NN : M * N) > M * M ? (NN > M * N ? NN : M * N) : M * M;
