@@ -993,6 +993,9 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
   const int n = uni(pl.n), m = uni(pl.m);
   const double inf = INFINITY;
   const int chunk  = (uni(pl.k) + 1) / 2;  // pairs of doubles that fit the work vector
+  // x and y of the check as the caller left them in the work vector (t[0, n) and t[n, n + m): LDS gathers instead of global ones,
+  // the same values); the later parts use t as scratch
+  const double *const xl = t, *const yl = t + n;
   {  // OPTIMALITY
     double a = 0.0, r = 0.0, z = 0.0;
     constexpr int RB = RBX, CE = 2;  // (RB = 4: 8 entries in flight per lane)
@@ -1000,7 +1003,7 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
       double Ax[RB], zi[RB];
 #pragma unroll
       for (int rr = 0; rr < RB; ++rr) zi[rr] = (i0 + rr * kWave < m) ? w.zus[i0 + rr * kWave] : 0.0;
-      sp_rows_A<RB, CE>(Ax, pl, it, i0, w.xus);
+      sp_rows_A<RB, CE>(Ax, pl, it, i0, xl);
 #pragma unroll
       for (int rr = 0; rr < RB; ++rr) {  // (rows beyond m contribute |0|: the norms are >= 0 anyway)
         a = fmax(a, fabs(Ax[rr]));
@@ -1014,7 +1017,7 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
       double pn = 0.0, qn = 0.0, an = 0.0, rn = 0.0;
       if constexpr (RBX <= 4) {  // (three waves per SIMD: one row at a time, 8 entries in flight)
       for (int j = lane; j < n; j += kWave) {
-        const double Px = sp_row_P(pl, it, j, w.xus), Aty = sp_row_At(pl, it, j, w.yus), qj = it.q[j];
+        const double Px = sp_row_P(pl, it, j, xl), Aty = sp_row_At(pl, it, j, yl), qj = it.q[j];
         pn = fmax(pn, fabs(Px));
         qn = fmax(qn, fabs(qj));
         an = fmax(an, fabs(Aty));
@@ -1025,8 +1028,8 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
         double Px[RB], Aty[RB], qj[RB];
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) qj[rr] = (j0 + rr * kWave < n) ? it.q[j0 + rr * kWave] : 0.0;
-        sp_rows_P<RB, CE>(Px, pl, it, j0, w.xus);
-        sp_rows_At<RB, CE>(Aty, pl, it, j0, w.yus);
+        sp_rows_P<RB, CE>(Px, pl, it, j0, xl);
+        sp_rows_At<RB, CE>(Aty, pl, it, j0, yl);
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) {  // (rows beyond n contribute |0|)
           pn = fmax(pn, fabs(Px[rr]));
@@ -1770,11 +1773,13 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
       for (int j = lane; j < n; j += kWave) {
         const double xn = vxs[j], sxj = w.sx[j], xo = w.dxus[j];
         w.xus[j]  = sxj * xn;
+        t[j]      = sxj * xn;  // (the check's mat-vecs gather x and y from the work vector, free until the next right-hand side)
         w.dxus[j] = sxj * (xn - xo);
       }
       for (int i = lane; i < m; i += kWave) {
         const double yn = vys[i], zn = vzs[i], syi = w.sy[i], yo = w.dyus[i];
         w.yus[i]  = syi * yn / c;
+        t[n + i]  = syi * yn / c;
         w.zus[i]  = (1.0 / syi) * zn;
         w.dyus[i] = syi * (yn - yo) / c;
       }
