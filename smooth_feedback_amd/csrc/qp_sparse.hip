@@ -1047,12 +1047,41 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
      // A'dy only when the sum leaves the verdict open (same result, NaN included).
     const double Edy_norm = lane_max_abs(w.dyus, m, lane);
     const double thr      = kp.eps_pinf * Edy_norm;
+    // FAST PATH.  What the verdict needs of the ordered sum is the side of thr it lies on, and its terms summed in ANY order
+    // (per lane, then across the wave) differ from the ordered sum by at most 2 gamma_N S, S = the sum of the |terms|, N = 2 m
+    // (both are within gamma_(N-1) S of the exact sum: Higham, Accuracy and Stability of Numerical Algorithms, eq. 4.4).
+    // With err = 4 N eps S, four times that bound:  sum - err >= thr  =>  acc >= thr, the test is over;
+    // sum + err < thr  =>  acc < thr, and then max(|A'dy|, acc) < thr  <=>  |A'dy| < thr (either acc is the larger one, which
+    // is < thr and the smaller |A'dy| with it, or |A'dy| is).  The ordered sum itself -- 2 m dependent additions fed from LDS,
+    // a quarter of a check for a lone wave -- is formed only when the bound does not decide, when a row breaks to +inf, or
+    // when a term is not finite.
+    int side = 2;  // 0: acc >= thr, 1: acc < thr, 2: undecided
+    {
+      double ps = 0.0, pa = 0.0;
+      bool brk0 = false;
+      for (int i = lane; i < m; i += kWave) {
+        const double ui = it.u[i], li = it.l[i], dyi = w.dyus[i];
+        const double ta = (ui != inf) ? ui * fmax(0.0, dyi) : 0.0, tb = (li != -inf) ? li * fmin(0.0, dyi) : 0.0;
+        ps += ta;
+        ps += tb;
+        pa += fabs(ta);
+        pa += fabs(tb);
+        brk0 = brk0 || (ui == inf && dyi > thr) || (li == -inf && dyi < -thr);
+      }
+      const double sum = wave_sum(ps), S = wave_sum(pa);
+      const double err = 4.0 * (2.0 * (double)m) * DBL_EPSILON * S;
+      if (!wave_ballot(brk0) && S < inf) {  // (S is NaN or +inf as soon as one term is not finite)
+        if (sum - err >= thr) side = 0;
+        else if (sum + err < thr) side = 1;
+      }
+    }
+    double acc = 0.0;
+    bool brk   = false;
+    if (side == 2) {
     // Certificate sum, sequential over the rows with an early exit to +inf (:607-621).  Equivalent form: the
     // result is +inf iff SOME row has an unbounded side with dy beyond the threshold; otherwise it is the
     // ordered sum of u_i max(0,dy_i) then l_i min(0,dy_i) over the rows, where a skipped term adds +0.0 (exact:
     // the running sum starts at +0.0 and therefore is never -0.0).
-    double acc = 0.0;
-    bool brk   = false;
     for (int c0 = 0; c0 < m; c0 += chunk) {
       const int c1 = min(m, c0 + chunk);
       for (int i = c0 + lane; i < c1; i += kWave) {
@@ -1081,35 +1110,47 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
       wave_sync();
     }
     if (wave_ballot(brk)) acc = inf;
-    if (!(acc >= thr)) {
+    }
+    if (side == 1 || (side == 2 && !(acc >= thr))) {
+      for (int e = lane; e < m; e += kWave) t[e] = w.dyus[e];  // dy into the work vector: the gathers of A'dy stay on chip
+      wave_sync();
       double an = 0.0;
       if constexpr (RBX <= 4) {
-        for (int j = lane; j < n; j += kWave) an = fmax(an, fabs(sp_row_At(pl, it, j, w.dyus)));
+        for (int j = lane; j < n; j += kWave) an = fmax(an, fabs(sp_row_At(pl, it, j, t)));
       } else
       for (int j0 = lane; j0 < n; j0 += kWave * RBX) {
         double Atdy[RBX];
-        sp_rows_At<RBX, 2>(Atdy, pl, it, j0, w.dyus);
+        sp_rows_At<RBX, 2>(Atdy, pl, it, j0, t);
 #pragma unroll
         for (int rr = 0; rr < RBX; ++rr) an = fmax(an, fabs(Atdy[rr]));
       }
       const double Aty_norm = wave_max(an);
-      const double mxv      = (Aty_norm < acc) ? acc : Aty_norm;
+      wave_sync();
+      const double mxv      = (side == 1 || !(Aty_norm < acc)) ? Aty_norm : acc;  // (side 1: acc < thr is known, see above)
       if (mxv < thr) return SFB_QP_PRIMAL_INFEASIBLE;
     }
   }
   {  // DUAL INFEASIBILITY: |P dx| <= thr, q'dx <= thr and the row conditions on A dx, each evaluated only while
      // the verdict is still open.
-    const double dx_norm = lane_max_abs(w.dxus, n, lane);
+    double dmx = 0.0;  // |dx|_inf, and dx into the work vector for the gathers of P dx (LDS instead of global round trips)
+    for (int e = lane; e < n; e += kWave) {
+      const double v = w.dxus[e];
+      t[e] = v;
+      dmx  = fmax(dmx, fabs(v));
+    }
+    const double dx_norm = wave_max(dmx);
     const double thr     = kp.eps_dinf * dx_norm;
+    wave_sync();
     double pn            = 0.0;
     for (int j0 = lane; j0 < n; j0 += kWave * 8) {
       double Pdx[8];
-      sp_rows_P<8, 1>(Pdx, pl, it, j0, w.dxus);
+      sp_rows_P<8, 1>(Pdx, pl, it, j0, t);
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) pn = fmax(pn, fabs(Pdx[rr]));
     }
     const double Pdx_n = wave_max(pn);
     if (!(Pdx_n <= thr)) return -1;
+    wave_sync();  // (every lane is done with dx in t: the chain below stages its operands there)
     double qdx = 0.0;  // q' dx, sequential fma chain (:633) fed from LDS
     for (int c0 = 0; c0 < n; c0 += chunk) {
       const int c1 = min(n, c0 + chunk);

@@ -35,6 +35,17 @@ __device__ __forceinline__ double wave_max(double v)
   return fmax(fmax(a, b), fmax(c, d));
 }
 
+// sum over all 64 lanes in a fixed tree order, result uniform (for quantities whose summation order is free)
+__device__ __forceinline__ double wave_sum(double v)
+{
+  v = v + dpp_mov<0x128>(v);  // row_ror:8
+  v = v + dpp_mov<0x124>(v);  // row_ror:4
+  v = v + dpp_mov<0x122>(v);  // row_ror:2
+  v = v + dpp_mov<0x121>(v);  // row_ror:1  -> every lane of a 16-lane row holds the row sum
+  const double a = lane_bcast(v, 0), b = lane_bcast(v, 16), c = lane_bcast(v, 32), d = lane_bcast(v, 48);
+  return (a + b) + (c + d);
+}
+
 // ---- 16-lane-row primitives (DPP on DP-ALU ops supports row_newbcast only, gfx90a+) ----
 // t += bcast_row(t, J) * negl on the rows selected by ROWMASK (other rows keep t).  The pivot of
 // an elimination step never leaves the VALU: no v_readlane -> SGPR -> VALU round trip.
