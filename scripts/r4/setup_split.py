@@ -25,6 +25,8 @@ def timed(label, **kw):
 
 timed("defaults")
 timed("polish off", polish=False)
+timed("polish_iter 0 (second factorisation, no refinement)", polish_iter=0)
+timed("polish_iter 1", polish_iter=1)
 timed("max_iter 1 (setup + 1 iteration + report)", max_iter=1)
 timed("max_iter 1, scaling off", max_iter=1, scaling=False)
 timed("max_iter 2", max_iter=2)

@@ -120,13 +120,26 @@ __device__ __forceinline__ void kkt_fill(const int32_t *__restrict__ desc4, cons
                                          const double c, const double sigma, const double delta, const int lane)
 {
   const vint4k *desc = reinterpret_cast<const vint4k *>(desc4);
+  // (the descriptors of batch b + 1 are requested before the entries batch b points to are gathered: one memory round trip per
+  //  batch on the dependent path instead of two)
+  vint4k dn[U];
+  int mn[U];
+  auto fetch = [&](const int p0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool on = p0 + u * kWave < p_end;
+      dn[u] = desc[on ? p0 + u * kWave : p_begin];
+      mn[u] = map[on ? p0 + u * kWave : p_begin];
+    }
+  };
+  if (p_begin + lane < p_end) fetch(p_begin + lane);
   for (int p0 = p_begin + lane; p0 < p_end; p0 += kWave * U) {
     vint4k d[U];
     int mp[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      d[u]  = desc[p0 + u * kWave];
-      mp[u] = map[p0 + u * kWave];
+      d[u]  = dn[u];
+      mp[u] = mn[u];
     }
     double s1[U], s2[U], val[U], ac[U];
 #pragma unroll
@@ -140,6 +153,7 @@ __device__ __forceinline__ void kkt_fill(const int32_t *__restrict__ desc4, cons
       val[u] = isP ? it.Px[idx] : (isA ? it.Ax[idx] : (kind == K_RHO ? w.rho[idx] : 0.0));
       ac[u]  = (isA && mode != 0) ? w.act[r] : 1.0;
     }
+    if (p0 + kWave * U < p_end) fetch(p0 + kWave * U);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int kind = d[u].x, r = d[u].z, cc = d[u].w;
@@ -1223,6 +1237,61 @@ __device__ __noinline__ void sp_trace_row(const SparsePlanDev &pl, const Item &i
 
 // detail::polish_qp (sparse), embedded in the full pattern.  In/out: scaled xs / ys in the workspace.
 // wf: the workspace view whose factor fields the polish factorisation may overwrite (w itself, or polish_ws(w))
+// acc[r] <- the sequential chain fm(r, position, values, acc[r]) over the entries [ptr(i).a, ptr(i).b) of the rows i = i0 + 64 r,
+// RB rows of a lane together, CE entries per row and step: idx(q) = the positions / indices of entry q (shared arrays), load(.) =
+// what they point to (item data, vectors).  The idx loads of step s + 1 are issued before the products of step s are formed:
+// one memory round trip per step on the dependent path.  Rows beyond nrows and entries beyond a row's end are not applied.
+template<int RB, int CE, class PtrF, class IdxF, class LoadF, class FmaF>
+__device__ __forceinline__ void sp_rows_chain(double (&acc)[RB], const int i0, const int nrows, PtrF ptr, IdxF idx, LoadF load, FmaF fm)
+{
+  using IdxT = decltype(idx(0));
+  using ValT = decltype(load(idx(0)));
+  int p[RB], pe[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int i = i0 + r * kWave;
+    p[r] = pe[r] = 0;
+    if (i < nrows) {
+      const auto pp = ptr(i);
+      p[r]  = pp.a;
+      pe[r] = pp.b;
+    }
+  }
+  IdxT ix[RB][CE];
+  auto fetch = [&] {
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int e = 0; e < CE; ++e) ix[r][e] = idx((p[r] + e < pe[r]) ? p[r] + e : 0);
+  };
+  fetch();
+  for (;;) {
+    bool more = false;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) more = more || p[r] < pe[r];
+    if (!more) break;
+    ValT v[RB][CE];
+    IdxT ic[RB][CE];
+    bool on[RB][CE];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int e = 0; e < CE; ++e) {
+        ic[r][e] = ix[r][e];
+        v[r][e]  = load(ic[r][e]);
+        on[r][e] = p[r] + e < pe[r];
+      }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) p[r] += CE;
+    fetch();
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int e = 0; e < CE; ++e)
+        if (on[r][e]) acc[r] = fm(r, ic[r][e], v[r][e], acc[r]);
+  }
+}
+
 template<int SD>
 __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const Ws &w, const Ws &wf, const DenseKernelParams &kp,
                                  double *t, const double c, const int lane, const bool lean)
@@ -1243,78 +1312,73 @@ __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const 
     // residual rows h - K tv (:193-195), entries in storage order as in the oracle.  Like sp_row_dot the entries of
     // a row are fetched in chunks: positions / indices first, then everything they point to, then the fma chain
     // (two memory round trips per chunk of 8 entries instead of three per entry).
-    constexpr int U = kRowChunk;
-    for (int i = lane; i < n; i += kWave) {
-      double acc = 0.0;
-      const double sxi = w.sx[i];
-      for (int q = pl.Sp[i], q1 = pl.Sp[i + 1]; q < q1; q += U) {  // P as selfadjointView<Upper>: entry (min, max)
-        int e[U], j[U];
-        double pv[U], sj[U], xv[U];
+    // RB rows of a lane advance together, CE entries each per step (sp_rows_chain: the positions of the next step are on
+    // their way while the products of this one are formed); every row's chain is the sequential one of the oracle.
+#ifndef SFB_POLISH_RB
+#define SFB_POLISH_RB 2
+#define SFB_POLISH_CE 2
+#endif
+    constexpr int RB = SFB_POLISH_RB, CE = SFB_POLISH_CE;
+    struct Ix { int a, b; };
+    struct V3 { double a, b, c; };
+    struct V4 { double a, b, c, d; };
+    for (int i0 = lane; i0 < n; i0 += kWave * RB) {
+      double acc[RB], sxi[RB], qi[RB];
+      int pv[RB];
 #pragma unroll
-        for (int a = 0; a < U; ++a) {
-          const bool on = q + a < q1;
-          e[a] = on ? pl.Spos[q + a] : 0;
-          j[a] = on ? pl.Sj[q + a] : 0;
-        }
-#pragma unroll
-        for (int a = 0; a < U; ++a) {
-          pv[a] = it.Px[e[a]];
-          sj[a] = w.sx[j[a]];
-          xv[a] = w.tv[j[a]];
-        }
-#pragma unroll
-        for (int a = 0; a < U; ++a)
-          if (q + a < q1) {
-            const double s_ec = (j[a] > i) ? sj[a] : sxi, s_er = (j[a] > i) ? sxi : sj[a];  // row er <= column ec
-            acc = fma(c * s_ec * s_er * pv[a], xv[a], acc);
-          }
+      for (int r = 0; r < RB; ++r) {
+        const int i = i0 + r * kWave;
+        const bool on = i < n;
+        acc[r] = 0.0;
+        sxi[r] = on ? w.sx[i] : 0.0;
+        qi[r]  = on ? it.q[i] : 0.0;
+        pv[r]  = on ? pl.pinv[i] : k;
       }
-      for (int q = pl.Acp[i], q1 = pl.Acp[i + 1]; q < q1; q += U) {  // column i of A, active rows only
-        int rr[U], e[U];
-        double av[U], sr[U], xv[U], ac[U];
+      // P as selfadjointView<Upper>: entry (min, max)
+      sp_rows_chain<RB, CE>(acc, i0, n, [&](int i) { return Ix{pl.Sp[i], pl.Sp[i + 1]}; },
+                            [&](int q) { return Ix{pl.Spos[q], pl.Sj[q]}; },
+                            [&](const Ix &x) { return V3{it.Px[x.a], w.sx[x.b], w.tv[x.b]}; },
+                            [&](int r, const Ix &x, const V3 &v, double a) {
+                              const int i = i0 + r * kWave;
+                              const double s_ec = (x.b > i) ? v.b : sxi[r], s_er = (x.b > i) ? sxi[r] : v.b;  // row er <= column ec
+                              return fma(c * s_ec * s_er * v.a, v.c, a);
+                            });
+      // column i of A, active rows only
+      sp_rows_chain<RB, CE>(acc, i0, n, [&](int i) { return Ix{pl.Acp[i], pl.Acp[i + 1]}; },
+                            [&](int q) { return Ix{pl.Acpos[q], pl.Aci[q]}; },
+                            [&](const Ix &x) { return V4{w.act[x.b], w.sy[x.b], it.Ax[x.a], w.tv[n + x.b]}; },
+                            [&](int r, const Ix &, const V4 &v, double a) { return (v.a != 0.0) ? fma(v.b * sxi[r] * v.c, v.d, a) : a; });
 #pragma unroll
-        for (int a = 0; a < U; ++a) {
-          const bool on = q + a < q1;
-          rr[a] = on ? pl.Aci[q + a] : 0;
-          e[a]  = on ? pl.Acpos[q + a] : 0;
-        }
-#pragma unroll
-        for (int a = 0; a < U; ++a) {
-          ac[a] = w.act[rr[a]];
-          sr[a] = w.sy[rr[a]];
-          av[a] = it.Ax[e[a]];
-          xv[a] = w.tv[n + rr[a]];
-        }
-#pragma unroll
-        for (int a = 0; a < U; ++a)
-          if (q + a < q1 && ac[a] != 0.0) acc = fma(sr[a] * sxi * av[a], xv[a], acc);
+      for (int r = 0; r < RB; ++r) {
+        const double h = -c * (sxi[r] * qi[r]);  // :180
+        if (i0 + r * kWave < n) t[pv[r]] = h - acc[r];
       }
-      const double h = -c * (sxi * it.q[i]);  // :180
-      t[pl.pinv[i]]  = h - acc;
     }
-    for (int rr = lane; rr < m; rr += kWave) {
-      const double a_ = w.act[rr];
-      double acc = 0.0, h = 0.0;
-      if (a_ != 0.0) {
-        const double syr = w.sy[rr];
-        for (int q = pl.Ap[rr], q1 = pl.Ap[rr + 1]; q < q1; q += U) {
-          int j[U];
-          double av[U], sj[U], xv[U];
+    for (int r0 = lane; r0 < m; r0 += kWave * RB) {
+      double acc[RB], a_[RB], syr[RB], lb[RB], ub[RB];
+      int pv[RB];
 #pragma unroll
-          for (int a = 0; a < U; ++a) j[a] = (q + a < q1) ? pl.Aj[q + a] : 0;
-#pragma unroll
-          for (int a = 0; a < U; ++a) {
-            av[a] = (q + a < q1) ? it.Ax[q + a] : 0.0;
-            sj[a] = w.sx[j[a]];
-            xv[a] = w.tv[j[a]];
-          }
-#pragma unroll
-          for (int a = 0; a < U; ++a)
-            if (q + a < q1) acc = fma(syr * sj[a] * av[a], xv[a], acc);
-        }
-        h = (a_ == 1.0) ? syr * it.l[rr] : syr * it.u[rr];  // :181-182
+      for (int r = 0; r < RB; ++r) {
+        const int rr = r0 + r * kWave;
+        const bool on = rr < m;
+        acc[r] = 0.0;
+        a_[r]  = on ? w.act[rr] : 0.0;
+        syr[r] = on ? w.sy[rr] : 0.0;
+        lb[r]  = on ? it.l[rr] : 0.0;
+        ub[r]  = on ? it.u[rr] : 0.0;
+        pv[r]  = on ? pl.pinv[n + rr] : k;
       }
-      t[pl.pinv[n + rr]] = h - acc;
+      sp_rows_chain<RB, CE>(acc, r0, m,
+                            [&](int rr) { return (w.act[rr] != 0.0) ? Ix{pl.Ap[rr], pl.Ap[rr + 1]} : Ix{0, 0}; },  // inactive rows: h - acc = 0
+                            [&](int q) { return Ix{q, pl.Aj[q]}; },
+                            [&](const Ix &x) { return V3{it.Ax[x.a], w.sx[x.b], w.tv[x.b]}; },
+                            [&](int r, const Ix &, const V3 &v, double a) { return fma(syr[r] * v.b * v.a, v.c, a); });
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        double h = 0.0;
+        if (a_[r] != 0.0) h = (a_[r] == 1.0) ? syr[r] * lb[r] : syr[r] * ub[r];  // :181-182
+        if (r0 + r * kWave < m) t[pv[r]] = h - acc[r];
+      }
     }
     wave_sync();
     ldl_solve_dev<SD>(pl, wf, t, lane, lean);
@@ -1490,50 +1554,73 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
       // |sy sx A| is the same product for the column and the row an entry belongs to.
       for (int e = lane; e < k; e += kWave) t[e] = 0.0;
       wave_sync();
+      // The entries are streamed in batches of UB per lane; the pattern and the values of batch b + 1 are requested before the
+      // scaling factors batch b points to are gathered (one memory round trip per batch on the dependent path, not two).
       constexpr int UB = 8;
-      for (int p0 = lane; p0 < nnzP; p0 += kWave * UB) {
+      {
         int rr[UB], cc[UB];
-        double pv[UB], sr[UB], sc[UB];
+        double pv[UB];
+        auto fetchP = [&](const int p0) {
 #pragma unroll
-        for (int e = 0; e < UB; ++e) {
-          const int p = p0 + e * kWave;
-          const bool on = p < nnzP;
-          rr[e] = on ? pl.Pi[p] : 0;
-          cc[e] = on ? pl.Pcol[p] : 0;
-          pv[e] = on ? it.Px[p] : 0.0;
+          for (int e = 0; e < UB; ++e) {
+            const int p = p0 + e * kWave;
+            const bool on = p < nnzP;
+            rr[e] = on ? pl.Pi[p] : 0;
+            cc[e] = on ? pl.Pcol[p] : 0;
+            pv[e] = on ? it.Px[p] : 0.0;
+          }
+        };
+        fetchP(lane);
+        for (int p0 = lane; p0 < nnzP; p0 += kWave * UB) {
+          int c0[UB];
+          double v0[UB], sr[UB], sc[UB];
+#pragma unroll
+          for (int e = 0; e < UB; ++e) {
+            sr[e] = w.sx[rr[e]];
+            sc[e] = w.sx[cc[e]];
+            c0[e] = cc[e];
+            v0[e] = pv[e];
+          }
+          fetchP(p0 + kWave * UB);
+#pragma unroll
+          for (int e = 0; e < UB; ++e)
+            if (p0 + e * kWave < nnzP)
+              __hip_atomic_fetch_max(&t[c0[e]], fabs(c * sr[e] * sc[e] * v0[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-#pragma unroll
-        for (int e = 0; e < UB; ++e) {
-          sr[e] = w.sx[rr[e]];
-          sc[e] = w.sx[cc[e]];
-        }
-#pragma unroll
-        for (int e = 0; e < UB; ++e)
-          if (p0 + e * kWave < nnzP)
-            __hip_atomic_fetch_max(&t[cc[e]], fabs(c * sr[e] * sc[e] * pv[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      for (int p0 = lane; p0 < nnzA; p0 += kWave * UB) {
+      {
         int rr[UB], cc[UB];
-        double av[UB], sr[UB], sc[UB];
+        double av[UB];
+        auto fetchA = [&](const int p0) {
 #pragma unroll
-        for (int e = 0; e < UB; ++e) {
-          const int p = p0 + e * kWave;
-          const bool on = p < nnzA;
-          rr[e] = on ? pl.Arow[p] : 0;
-          cc[e] = on ? pl.Aj[p] : 0;
-          av[e] = on ? it.Ax[p] : 0.0;
-        }
+          for (int e = 0; e < UB; ++e) {
+            const int p = p0 + e * kWave;
+            const bool on = p < nnzA;
+            rr[e] = on ? pl.Arow[p] : 0;
+            cc[e] = on ? pl.Aj[p] : 0;
+            av[e] = on ? it.Ax[p] : 0.0;
+          }
+        };
+        fetchA(lane);
+        for (int p0 = lane; p0 < nnzA; p0 += kWave * UB) {
+          int r0[UB], c0[UB];
+          double v0[UB], sr[UB], sc[UB];
 #pragma unroll
-        for (int e = 0; e < UB; ++e) {
-          sr[e] = w.sy[rr[e]];
-          sc[e] = w.sx[cc[e]];
-        }
+          for (int e = 0; e < UB; ++e) {
+            sr[e] = w.sy[rr[e]];
+            sc[e] = w.sx[cc[e]];
+            r0[e] = rr[e];
+            c0[e] = cc[e];
+            v0[e] = av[e];
+          }
+          fetchA(p0 + kWave * UB);
 #pragma unroll
-        for (int e = 0; e < UB; ++e) {
-          if (p0 + e * kWave < nnzA) {
-            const double v = fabs(sr[e] * sc[e] * av[e]);
-            __hip_atomic_fetch_max(&t[cc[e]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_max(&t[n + rr[e]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          for (int e = 0; e < UB; ++e) {
+            if (p0 + e * kWave < nnzA) {
+              const double v = fabs(sr[e] * sc[e] * v0[e]);
+              __hip_atomic_fetch_max(&t[c0[e]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_fetch_max(&t[n + r0[e]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
           }
         }
       }
