@@ -537,13 +537,20 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
   // (branch-free, DEPTH gathers in flight per lane: padding slots read the always-zero accumulator; the copies'
   //  lengths are multiples of 8 * 128 >= DEPTH * 64)
   auto gather_copy = [&](const int32_t *__restrict__ map, double *__restrict__ dst, const int total) {
+    int srcn[DEPTH];  // (the map of block b + 1 is requested before the values of block b are gathered)
+#pragma unroll
+    for (int dd = 0; dd < DEPTH; ++dd) srcn[dd] = map[lane + dd * kWave];
     for (int q0 = lane; q0 < total; q0 += kWave * DEPTH) {
       int src[DEPTH];
       double v[DEPTH];
 #pragma unroll
-      for (int dd = 0; dd < DEPTH; ++dd) src[dd] = map[q0 + dd * kWave];
+      for (int dd = 0; dd < DEPTH; ++dd) src[dd] = srcn[dd];
 #pragma unroll
       for (int dd = 0; dd < DEPTH; ++dd) v[dd] = ACC[src[dd] >= 0 ? src[dd] : nnzL + k + 1];
+      if (q0 + kWave * DEPTH < total) {
+#pragma unroll
+        for (int dd = 0; dd < DEPTH; ++dd) srcn[dd] = map[q0 + kWave * DEPTH + dd * kWave];
+      }
 #pragma unroll
       for (int dd = 0; dd < DEPTH; ++dd) __builtin_nontemporal_store(v[dd], &dst[q0 + dd * kWave]);  // read again only by the sweeps
     }
@@ -1408,13 +1415,20 @@ __device__ __forceinline__ bool sp_guard_ok(const SparsePlanDev &pl, const doubl
   constexpr int UB = 8;
   const int nmasked = uni(pl.nmasked);
   bool bad = false;
+  int srcn[UB];  // (the positions of batch b + 1 are requested before the entries of batch b; Amasked is padded by a batch)
+#pragma unroll
+  for (int e = 0; e < UB; ++e) srcn[e] = pl.Amasked[lane + e * kWave];
   for (int p0 = lane; p0 < nmasked; p0 += kWave * UB) {
     int src[UB];
     double v[UB];
 #pragma unroll
-    for (int e = 0; e < UB; ++e) src[e] = pl.Amasked[p0 + e * kWave];
+    for (int e = 0; e < UB; ++e) src[e] = srcn[e];
 #pragma unroll
     for (int e = 0; e < UB; ++e) v[e] = Ax[src[e]];
+    if (p0 + kWave * UB < nmasked) {
+#pragma unroll
+      for (int e = 0; e < UB; ++e) srcn[e] = pl.Amasked[p0 + kWave * UB + e * kWave];
+    }
 #pragma unroll
     for (int e = 0; e < UB; ++e) bad = bad || !(v[e] == 0.0);
   }
@@ -1494,13 +1508,20 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     // Pruned plan (its guard has passed, see the kernel): the kept entries of A are compacted into the workspace;
     // everything below works on the compressed pattern.  (Aorig is padded: branch-free batches.)
     constexpr int UB = 8;
+    int srcn[UB];  // (the positions of batch b + 1 are requested before the entries of batch b are gathered)
+#pragma unroll
+    for (int e = 0; e < UB; ++e) srcn[e] = pl.Aorig[lane + e * kWave];
     for (int p0 = lane; p0 < nnzA; p0 += kWave * UB) {
       int src[UB];
       double v[UB];
 #pragma unroll
-      for (int e = 0; e < UB; ++e) src[e] = pl.Aorig[p0 + e * kWave];
+      for (int e = 0; e < UB; ++e) src[e] = srcn[e];
 #pragma unroll
       for (int e = 0; e < UB; ++e) v[e] = it.Ax[src[e]];
+      if (p0 + kWave * UB < nnzA) {
+#pragma unroll
+        for (int e = 0; e < UB; ++e) srcn[e] = pl.Aorig[p0 + kWave * UB + e * kWave];
+      }
 #pragma unroll
       for (int e = 0; e < UB; ++e)
         if (p0 + e * kWave < nnzA) w.Axc[p0 + e * kWave] = v[e];
@@ -2027,11 +2048,30 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     double o        = 0.0;
     for (int c0 = 0; c0 < n; c0 += chunk) {
       const int c1 = min(n, c0 + chunk);
-      for (int i = c0 + lane; i < c1; i += kWave) {
-        double acc = 0.0;
-        for (int p = pl.Prp[i]; p < pl.Prp[i + 1]; ++p) acc = fma(0.5 * it.Px[pl.Prpos[p]], w.xus[pl.Prj[p]], acc);
-        t[2 * (i - c0)]     = w.xus[i];
-        t[2 * (i - c0) + 1] = acc + it.q[i];
+      struct Ix { int a, b; };
+      struct V2 { double a, b; };
+      constexpr int RB = 4, CE = 2;  // rows of 0.5 P x, RB per lane together (one entry at a time cost two round trips per ENTRY)
+      for (int i0 = c0 + lane; i0 < c1; i0 += kWave * RB) {
+        double acc[RB], xi[RB], qi[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const int i = i0 + r * kWave;
+          acc[r] = 0.0;
+          xi[r]  = (i < c1) ? w.xus[i] : 0.0;
+          qi[r]  = (i < c1) ? it.q[i] : 0.0;
+        }
+        sp_rows_chain<RB, CE>(acc, i0, c1, [&](int i) { return Ix{pl.Prp[i], pl.Prp[i + 1]}; },
+                              [&](int q) { return Ix{pl.Prpos[q], pl.Prj[q]}; },
+                              [&](const Ix &x) { return V2{it.Px[x.a], w.xus[x.b]}; },
+                              [&](int, const Ix &, const V2 &v, double a) { return fma(0.5 * v.a, v.b, a); });
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const int i = i0 + r * kWave;
+          if (i < c1) {
+            t[2 * (i - c0)]     = xi[r];
+            t[2 * (i - c0) + 1] = acc[r] + qi[r];
+          }
+        }
       }
       wave_sync();
       const int cnt = c1 - c0;
