@@ -63,6 +63,30 @@ def test_random_sparse_batches(sfb, oracle, n, m, density, ordering, sweep_mode)
     _compare(r2, ref2)
 
 
+@pytest.mark.parametrize("n,m,sci", [(10, 20, 2), (10, 20, 5), (24, 60, 3)])
+def test_infeasibility_verdicts_with_a_check_every_few_iterations(sfb, oracle, n, m, sci):
+    """The primal-infeasibility test decides from a bound on the ordered certificate sum wherever the bound allows
+    (sp_check_stopping, FAST PATH; tests/test_check_bound.py): many checks per solve on batches in which every verdict occurs,
+    codes / iteration counts / iterates identical to the oracle, which always forms the ordered sum."""
+    B = 256
+    P, q, A, l, u = sfb.random_qp_batch(20261301 + n, B, m, n, 0.5)
+    rng = np.random.default_rng(n * m + sci)
+    mask = rng.random((B, m))
+    l = np.where(mask < 0.15, -np.inf, l); u = np.where((mask > 0.15) & (mask < 0.3), np.inf, u)
+    l = np.where(mask > 0.85, u, l)              # equality rows (dense: mostly infeasible systems when m > n)
+    P[B // 2:] *= 1e-3                           # weakly convex half: dual-infeasibility candidates with free rows
+    Pp, Pi, Px, Ap, Aj, Ax = dense_batch_to_sparse(P, A, n, m, upper_only=True)
+    plan = sfb.SparseQPPlan(n, m, Pp, Pi, Ap, Aj)
+    for prm in (sfb.QPSolverParams(max_iter=1500, stop_check_iter=sci), sfb.QPSolverParams(max_iter=400, stop_check_iter=sci, scaling=False, eps_abs=1e-6, eps_rel=1e-6)):
+        r = plan.solve_batch_host(Px, q, Ax, l, u, prm)
+        ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Ax, l, u, perm=plan.perm, forder=plan.factor_order(),
+                                           params=_oracle_params(oracle, prm), nthreads=8)
+        _compare(r, ref)
+        codes = np.bincount(r.code, minlength=7)
+        print(n, m, sci, "codes", codes)
+    assert codes[2] > 0  # SFB_QP_PRIMAL_INFEASIBLE verdicts (by certificate) occurred
+
+
 def test_large_banded_problem_uses_element_indices(sfb, oracle, sweep_mode):
     """n + m = 9 000 > 8 190: the sweep schedules store element indices instead of 16-bit byte offsets and the
     work vector takes 72 KB of LDS per wave.  Tridiagonal P, three entries per row of A; bit-identical to the oracle."""
