@@ -60,7 +60,7 @@ sfb_status upload_plan(const sfb::SparsePlanHost &h, const std::vector<int32_t> 
                                         &h.Prp, &h.Prj, &h.Prpos, &h.Sp, &h.Sj, &h.Spos, &h.perm, &h.pinv,
                                         &h.Kp, &h.Ki, &h.Kdesc, &h.Lp, &h.Li, &h.Rp, &h.Rk, &h.Rpos, &h.Rlen,
                                         &h.fmap, &h.fidx, &h.bmap, &h.bidx, &h.Kmap, &h.rptr, &h.rtgt, &h.rab, &h.snptr, &h.snR, &h.poff, &h.pmap, &h.fmask, &h.bmask,
-                                        &h.f2s, &h.seg, &h.pmapL, &h.rsplit, &h.KmapL, &h.KdescT, &h.KmapT, &h.ztop,
+                                        &h.f2s, &h.seg, &h.pmapL, &h.rsplit, &h.KmapL, &h.KdescT, &h.KmapT, &h.ztop, &h.ustream, &h.utype, &h.uomap,
                                         Aorig ? Aorig : &none, Amasked ? Amasked : &none};
   constexpr int NA = sizeof(arrs) / sizeof(arrs[0]);
   size_t off[NA + 1];
@@ -82,9 +82,9 @@ sfb_status upload_plan(const sfb::SparsePlanHost &h, const std::vector<int32_t> 
                             &d.Prp, &d.Prj, &d.Prpos, &d.Sp, &d.Sj, &d.Spos, &d.perm, &d.pinv,
                             &d.Kp, &d.Ki, &d.Kdesc, &d.Lp, &d.Li, &d.Rp, &d.Rk, &d.Rpos, &d.Rlen,
                             &d.fmap, &d.fidx, &d.bmap, &d.bidx, &d.Kmap, &d.rptr, &d.rtgt, &d.rab, &d.snptr, &d.snR, &d.poff, &d.pmap, &d.fmask, &d.bmask,
-                            &d.f2s, &d.seg, &d.pmapL, &d.rsplit, &d.KmapL, &d.KdescT, &d.KmapT, &d.ztop,
+                            &d.f2s, &d.seg, &d.pmapL, &d.rsplit, &d.KmapL, &d.KdescT, &d.KmapT, &d.ztop, &d.ustream, &d.utype, &d.uomap,
                             &d.Aorig, &d.Amasked};
-  d.funits = h.funits; d.bunits = h.bunits; d.ffull0 = h.ffull0; d.ffull1 = h.ffull1; d.bfull0 = h.bfull0; d.bfull1 = h.bfull1; d.idx_scale = h.idx_scale; d.rsteps = h.rsteps; d.maxcol = h.maxcol; d.nsn = h.nsn; d.lds_doubles = h.lds_doubles; d.nseg = h.nseg; d.nnzKT = h.nnzKT; d.nztop = h.nztop;
+  d.funits = h.funits; d.bunits = h.bunits; d.ffull0 = h.ffull0; d.ffull1 = h.ffull1; d.bfull0 = h.bfull0; d.bfull1 = h.bfull1; d.idx_scale = h.idx_scale; d.rsteps = h.rsteps; d.maxcol = h.maxcol; d.nsn = h.nsn; d.lds_doubles = h.lds_doubles; d.nseg = h.nseg; d.nnzKT = h.nnzKT; d.nztop = h.nztop; d.units = h.units; d.nunits = h.nunits;
   for (int a = 0; a < NA; ++a) *ptrs[a] = dblob + off[a];
   d.nnzA_io = nnzA_io;
   d.nmasked = Amasked ? (int)Amasked->size() - 512 : 0;  // without the padding
@@ -247,7 +247,7 @@ sfb_status sfb_sparse_qp_plan_create_pruned(int n, int m, const int32_t *P_colpt
   // kernel plan on the kept entries; fallback plan on the whole pattern with the SAME elimination order, so that
   // an item's result does not depend on which of the two solved it (up to the sign of zeros)
   bool ok = sfb::build_sparse_plan(n, m, P_colptr, P_rowind, Ap.data(), Aj.data(), ordering, user_perm, stage, p->host, &msg);
-  if (ok) ok = sfb::build_sparse_plan(n, m, P_colptr, P_rowind, A_rowptr, A_colind, ordering, p->host.perm.data(), nullptr, p->full, &msg);
+  if (ok) ok = sfb::build_sparse_plan(n, m, P_colptr, P_rowind, A_rowptr, A_colind, ordering, p->host.perm.data(), nullptr, p->full, &msg, p->host.lds_doubles);
   if (!ok) {
     delete p;
     return sfb::fail(SFB_ERR_INVALID_ARG, msg);

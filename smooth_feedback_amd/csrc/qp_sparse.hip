@@ -268,6 +268,194 @@ __device__ __forceinline__ bool panel_eliminate(double (&reg)[kPanelCols], const
   return panel_eliminate_w<kPanelCols>(reg, wd, R, pan, mul, lane);
 }
 
+// Schedule-ordered copies of the factor for the two sweeps (padding slots carry 0).  A streaming pass: writing
+// the final values straight into the copies from the panels (scattered 8-byte writes) is quicker for a lone
+// wave but costs the batch more HBM traffic than this gather + coalesced write -- measured.
+// (branch-free, DEPTH gathers in flight per lane: padding slots read the always-zero accumulator; the copies'
+//  lengths are multiples of 8 * 128 >= DEPTH * 64)
+template<int DEPTH>
+__device__ __forceinline__ void ldl_sweep_copies(const SparsePlanDev &pl, const Ws &w, const int lane)
+{
+  const int k = uni(pl.k), nnzL = uni(pl.nnzL);
+  const double *ACC = w.Lx;
+  auto gather_copy = [&](const int32_t *__restrict__ map, double *__restrict__ dst, const int total) {
+    int srcn[DEPTH];  // (the map of block b + 1 is requested before the values of block b are gathered)
+#pragma unroll
+    for (int dd = 0; dd < DEPTH; ++dd) srcn[dd] = map[lane + dd * kWave];
+    for (int q0 = lane; q0 < total; q0 += kWave * DEPTH) {
+      int src[DEPTH];
+      double v[DEPTH];
+#pragma unroll
+      for (int dd = 0; dd < DEPTH; ++dd) src[dd] = srcn[dd];
+#pragma unroll
+      for (int dd = 0; dd < DEPTH; ++dd) v[dd] = ACC[src[dd] >= 0 ? src[dd] : nnzL + k + 1];
+      if (q0 + kWave * DEPTH < total) {
+#pragma unroll
+        for (int dd = 0; dd < DEPTH; ++dd) srcn[dd] = map[q0 + kWave * DEPTH + dd * kWave];
+      }
+#pragma unroll
+      for (int dd = 0; dd < DEPTH; ++dd) __builtin_nontemporal_store(v[dd], &dst[q0 + dd * kWave]);  // read again only by the sweeps
+    }
+  };
+  static_assert(kSweepPadDev * 2 >= DEPTH, "copy loop assumes whole blocks");
+  wave_sync();
+  gather_copy(pl.fmap, w.LxF, (uni(pl.funits) + kSweepPadDev) * 2 * kWave);
+  gather_copy(pl.bmap, w.LxB, (uni(pl.bunits) + kSweepPadDev) * 2 * kWave);
+  wave_sync();
+}
+
+// UNIT ENGINE of the numeric factorisation (sparse_plan.h; round 5).  Same accumulators, same arithmetic per accumulator
+// and in the same order as the supernodal engine below (and the oracle's left-looking loop) -- executed like the sweeps: a
+// static schedule of units of 128 independent slots on operands in LDS,
+//   F  slot:  t[tgt] = fma(-t[a], t[b] * t[d], t[tgt])      L(a, j), L(b, j), D(j) of the source column j
+//   DM slot:  t[tgt] = t[tgt] / t[d]                         the column becomes final
+// streamed as 16 bytes per lane and unit from the shared plan (L2).  Per segment of columns: its accumulators (a closed
+// segment = a subtree: filled on chip; an open one: fetched from the workspace, where the fill and the earlier segments
+// left them) and the accumulators of later columns it updates are brought into LDS, the units run, everything goes back.
+// A lone wave needed 1.06 ms for the headline plan's factorisation in the supernodal form (105 panels eliminated by
+// v_readlane broadcasts, one IEEE division chain per column, two dependent global round trips per supernode, 150 k VALU
+// instructions at 2-3 % lane utilisation); here it is ~1 600 units of ~60-100 ns.
+// t = LDS of pl.lds_doubles doubles.  Returns 1 / 0 (zero pivot).
+typedef int vint4u __attribute__((ext_vector_type(4)));
+template<int DEPTH>
+__device__ inline int ldl_numeric_units(const SparsePlanDev &pl, const Item &it, const Ws &w, double *t, const int mode,
+                                        const double c, const double sigma, const double delta, const int lane)
+{
+  const int nnzL = uni(pl.nnzL);
+#ifdef SFB_PROF_LDL
+  unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, pc = __builtin_amdgcn_s_memtime();
+#define SFB_ULAP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[i] += now_ - pc; pc = now_; }
+#else
+#define SFB_ULAP(i)
+#endif
+  double *ACC = w.Lx;  // [0, nnzL): L entries, [nnzL, nnzL+k): D, [nnzL+k]: sink, [nnzL+k+1]: always zero
+  for (int z = 0, nz = uni(pl.nztop); z < nz; ++z) {  // accumulators of the open segments (the others never live in HBM)
+    const int z0 = uni(pl.ztop[2 * z]), zn = uni(pl.ztop[2 * z + 1]);
+    for (int p = lane; p < zn; p += kWave) ACC[z0 + p] = 0.0;
+  }
+  wave_sync();
+  kkt_fill<4>(pl.KdescT, pl.KmapT, 0, uni(pl.nnzKT), it, w, ACC, mode, c, sigma, delta, lane);
+  wave_sync();
+  SFB_ULAP(0)
+  const vint4u *__restrict__ stream = reinterpret_cast<const vint4u *>(pl.ustream);
+  auto at = [&](const unsigned off) -> double & { return *reinterpret_cast<double *>(reinterpret_cast<char *>(t) + off); };
+  bool zero_pivot = false;
+  constexpr int UB = 8;  // loads in flight per lane in the copy loops
+  for (int sg = 0, nseg = uni(pl.nseg); sg < nseg; ++sg) {
+    const int32_t *sgp = pl.seg + 12 * sg;
+    const int u0 = uni(sgp[0]), u1 = uni(sgp[1]), c0 = uni(sgp[2]), c1 = uni(sgp[3]), closed = uni(sgp[4]), nLs = uni(sgp[5]);
+    const int accN = uni(sgp[6]), kp0 = uni(sgp[7]), kp1 = uni(sgp[8]), gL = uni(sgp[9]), nout = uni(sgp[10]);
+    const int32_t *__restrict__ omap = pl.uomap + uni(sgp[11]);  // (padded by a batch: branch-free index loads)
+    const int sink = accN + nout;
+    // ---- working set -> LDS ----
+    if (closed) {
+      for (int e = lane; e < accN; e += kWave) t[e] = 0.0;
+      wave_lds_fence();
+      kkt_fill<4>(pl.Kdesc, pl.KmapL, kp0, kp1, it, w, t, mode, c, sigma, delta, lane);
+    } else {
+      for (int e0 = lane; e0 < accN; e0 += kWave * UB) {  // own L entries and diagonals: two contiguous ranges of the workspace
+        double v[UB];
+#pragma unroll
+        for (int e = 0; e < UB; ++e) {
+          const int x = e0 + e * kWave;
+          v[e] = (x < accN) ? ACC[x < nLs ? gL + x : nnzL + c0 + (x - nLs)] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < UB; ++e)
+          if (e0 + e * kWave < accN) t[e0 + e * kWave] = v[e];
+      }
+    }
+    for (int e0 = lane; e0 < nout; e0 += kWave * UB) {  // outside accumulators
+      int src[UB];
+      double v[UB];
+#pragma unroll
+      for (int e = 0; e < UB; ++e) src[e] = omap[e0 + e * kWave];
+#pragma unroll
+      for (int e = 0; e < UB; ++e) v[e] = ACC[src[e]];
+#pragma unroll
+      for (int e = 0; e < UB; ++e)
+        if (e0 + e * kWave < nout) t[accN + e0 + e * kWave] = v[e];
+    }
+    if (lane < 3) t[sink + lane] = (lane == 2) ? 1.0 : 0.0;  // sink, zero, one: operands of the padding slots
+    wave_lds_fence();
+    SFB_ULAP(1)
+    // ---- units ----
+    // The stream is fetched in BLOCKS of DEPTH units, two register sets taking turns: all loads of block b + 1 are requested
+    // when block b begins, so that they have a whole block's time (DEPTH dependent LDS round trips) to arrive -- the
+    // compiler waits for everything in flight at the loop's head, which then costs nothing.  (Requested one per unit,
+    // the same wait drained the queue every DEPTH units: 390 cycles per unit of a lone wave instead of ~200.  Hand-issued
+    // loads with counted waits as in the sweeps do not survive the branch between the two kinds of units: the register
+    // allocator copies loop-carried registers whose loads are in flight.)  A unit's kind travels in the stream itself
+    // (second word of a slot: all ones = division), read from lane 0.
+    {
+      typedef const __attribute__((address_space(1))) vint4u *gstream_t;
+      gstream_t sp = (gstream_t)(stream + (size_t)u0 * kWave + lane);
+      auto fetch = [&](vint4u (&q)[DEPTH]) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) q[d] = sp[d * kWave];
+        sp += DEPTH * kWave;
+      };
+      auto run = [&](const vint4u (&q)[DEPTH], const int ub) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+          const unsigned x0 = (unsigned)q[d].x, y0 = (unsigned)q[d].y, x1 = (unsigned)q[d].z, y1 = (unsigned)q[d].w;
+          const bool dm = __builtin_amdgcn_readfirstlane((int)y0) == -1;
+          if (ub + d < u1) {
+            if (dm) {
+              const double T0 = at(x0 & 0xFFFFu), D0 = at(x0 >> 16), T1 = at(x1 & 0xFFFFu), D1 = at(x1 >> 16);
+              at(x0 & 0xFFFFu) = T0 / D0;
+              at(x1 & 0xFFFFu) = T1 / D1;
+            } else {
+              const double T0 = at(x0 & 0xFFFFu), A0 = at(x0 >> 16), B0 = at(y0 & 0xFFFFu), D0 = at(y0 >> 16);
+              const double T1 = at(x1 & 0xFFFFu), A1 = at(x1 >> 16), B1 = at(y1 & 0xFFFFu), D1 = at(y1 >> 16);
+              at(x0 & 0xFFFFu) = fma(-A0, B0 * D0, T0);
+              at(x1 & 0xFFFFu) = fma(-A1, B1 * D1, T1);
+            }
+          }
+        }
+      };
+      vint4u qa[DEPTH], qb[DEPTH];
+      fetch(qa);
+      for (int u = u0; u < u1; u += 2 * DEPTH) {  // (the stream is padded by two blocks: the fetches stay inside)
+        fetch(qb);
+        run(qa, u);
+        fetch(qa);
+        if (u + DEPTH < u1) run(qb, u + DEPTH);
+      }
+    }
+    wave_lds_fence();
+    SFB_ULAP(2)
+    // ---- final L and D of the segment, the updated outside accumulators -> workspace; 1 / D (the sweeps multiply by the
+    // reciprocal, qp_solver.hpp:458), in S numbering; a zero pivot anywhere = NumericalIssue ----
+    for (int e = lane; e < nLs; e += kWave) ACC[gL + e] = t[e];
+    for (int j = c0 + lane; j < c1; j += kWave) {
+      const double d = t[nLs + (j - c0)];
+      zero_pivot = zero_pivot || d == 0.0;
+      ACC[nnzL + j]      = d;
+      w.Dinv[pl.f2s[j]] = 1.0 / d;
+    }
+    for (int e0 = lane; e0 < nout; e0 += kWave * UB) {
+      int dst[UB];
+#pragma unroll
+      for (int e = 0; e < UB; ++e) dst[e] = omap[e0 + e * kWave];
+#pragma unroll
+      for (int e = 0; e < UB; ++e)
+        if (e0 + e * kWave < nout) ACC[dst[e]] = t[accN + e0 + e * kWave];
+    }
+    wave_sync();  // the workspace is up to date before a later segment fetches from it (and t is free again)
+    SFB_ULAP(3)
+  }
+  if (wave_ballot(zero_pivot)) return 0;
+  ldl_sweep_copies<DEPTH>(pl, w, lane);
+  SFB_ULAP(4)
+#ifdef SFB_PROF_LDL
+  if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
+    printf("[ldl units block %u mode %d] zero+open fill %llu  segments: working set in %llu  units %llu  out %llu | copies %llu  (cycles of s_memtime)\n",
+           blockIdx.x, mode, pt[0], pt[1], pt[2], pt[3], pt[4]);
+#endif
+  return 1;
+}
+
 // Numeric LDL' on the shared pattern, RIGHT-LOOKING over RELAXED SUPERNODES with a static schedule
 // (sparse_plan.h), in the factorisation numbering F (a postorder of the elimination tree).  Accumulators
 // [L values | D | sink | zero]: every accumulator sees its sources in ascending column order,
@@ -291,6 +479,7 @@ template<int DEPTH>
 __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, const Ws &w, double *t, const int mode,
                                       const double c, const double sigma, const double delta, const int lane)
 {
+  if (uni(pl.units)) return ldl_numeric_units<DEPTH>(pl, it, w, t, mode, c, sigma, delta, lane);
   const int k = uni(pl.k), nnzL = uni(pl.nnzL);
 #ifdef SFB_PROF_LDL
   unsigned long long pt[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pc = __builtin_amdgcn_s_memtime();
@@ -309,7 +498,7 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
   wave_sync();
   SFB_LAP(0)
   for (int sg = 0, nseg = uni(pl.nseg); sg < nseg; ++sg) {
-    const int32_t *sgp = pl.seg + 10 * sg;
+    const int32_t *sgp = pl.seg + 12 * sg;
     const int sn0 = uni(sgp[0]), sn1 = uni(sgp[1]), on_chip = uni(sgp[4]);
     if (on_chip) {
       // ---------------- LDS segment ----------------
@@ -531,35 +720,7 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
     SFB_LAP(6)
     }
   }
-  // Schedule-ordered copies of the factor for the two sweeps (padding slots carry 0).  A streaming pass: writing
-  // the final values straight into the copies from the panels (scattered 8-byte writes) is quicker for a lone
-  // wave but costs the batch more HBM traffic than this gather + coalesced write -- measured.
-  // (branch-free, DEPTH gathers in flight per lane: padding slots read the always-zero accumulator; the copies'
-  //  lengths are multiples of 8 * 128 >= DEPTH * 64)
-  auto gather_copy = [&](const int32_t *__restrict__ map, double *__restrict__ dst, const int total) {
-    int srcn[DEPTH];  // (the map of block b + 1 is requested before the values of block b are gathered)
-#pragma unroll
-    for (int dd = 0; dd < DEPTH; ++dd) srcn[dd] = map[lane + dd * kWave];
-    for (int q0 = lane; q0 < total; q0 += kWave * DEPTH) {
-      int src[DEPTH];
-      double v[DEPTH];
-#pragma unroll
-      for (int dd = 0; dd < DEPTH; ++dd) src[dd] = srcn[dd];
-#pragma unroll
-      for (int dd = 0; dd < DEPTH; ++dd) v[dd] = ACC[src[dd] >= 0 ? src[dd] : nnzL + k + 1];
-      if (q0 + kWave * DEPTH < total) {
-#pragma unroll
-        for (int dd = 0; dd < DEPTH; ++dd) srcn[dd] = map[q0 + kWave * DEPTH + dd * kWave];
-      }
-#pragma unroll
-      for (int dd = 0; dd < DEPTH; ++dd) __builtin_nontemporal_store(v[dd], &dst[q0 + dd * kWave]);  // read again only by the sweeps
-    }
-  };
-  static_assert(kSweepPadDev * 2 >= DEPTH, "copy loop assumes whole blocks");
-  wave_sync();
-  gather_copy(pl.fmap, w.LxF, (uni(pl.funits) + kSweepPadDev) * 2 * kWave);
-  gather_copy(pl.bmap, w.LxB, (uni(pl.bunits) + kSweepPadDev) * 2 * kWave);
-  wave_sync();
+  ldl_sweep_copies<DEPTH>(pl, w, lane);
   SFB_LAP(7)
 #ifdef SFB_PROF_LDL
   if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))

@@ -33,6 +33,8 @@ struct SparsePlanDev {
   // factorisation numbering and LDS-resident subtrees (sparse_plan.h)
   const int32_t *f2s, *seg, *pmapL, *rsplit, *KmapL, *KdescT, *KmapT, *ztop;
   int nseg, nnzKT, nztop;
+  const int32_t *ustream, *utype, *uomap;  // unit engine of the factorisation (sparse_plan.h); units == 0: supernodal engine
+  int units, nunits;
   int nnzA_io, nmasked;
   const int32_t *Aorig, *Amasked;
   const SparsePlanDev *self;  // device copy of this struct (what the kernel is handed)

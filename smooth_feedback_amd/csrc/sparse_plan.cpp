@@ -269,7 +269,7 @@ std::vector<int32_t> min_degree_order(int k, const std::vector<std::pair<int, in
 
 bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const int32_t *Ap, const int32_t *Aj,
                        int ordering, const int32_t *user_perm, const int32_t *stage, SparsePlanHost &o,
-                       const char **msg)
+                       const char **msg, int lds_hint)
 {
   static const char *ok = "";
   *msg = ok;
@@ -497,8 +497,17 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
     if (o.maxcol >= (1 << 16)) { *msg = "column of L too long for the update encoding"; return false; }
     // LDS per item: the work vector of the sweeps (k + 1), the panel scratch of the widest column, and room for the
     // accumulators of a subtree (below)
-    constexpr int kLdsTarget = 2048;
-    o.lds_doubles = std::max(std::max(k + 2, 2 * o.maxcol + 4), kLdsTarget);
+    // Unit engine (below): as little as holds the whole factor -- or, when that is more than kLdsSmall doubles, the work
+    // vector and kLdsSmall (twelve waves per CU instead of ten for the MPC-sized plans; the segments shrink with it).
+    // When some column does not fit that on its own, kLdsTarget is tried, then the supernodal engine with kLdsTarget.
+    // lds_hint > 0 (the whole-pattern fallback of a pruned plan): the LDS of the plan it accompanies -- the kernel is
+    // launched with the larger of the two, and the fallback solves a handful of items.
+    constexpr int kLdsTarget = 2048, kLdsSmall = 1536;
+    const int lds_floor = std::max(k + 2, 2 * o.maxcol + 4);
+    const int lds_small = lds_hint > 0 ? std::max(lds_floor, lds_hint)
+                                       : (std::max(lds_floor, std::min(o.nnzL + k + 3, kLdsSmall)) + 63) / 64 * 64;
+    const int lds_large = std::max(lds_small, lds_hint > 0 ? lds_hint : kLdsTarget);
+    o.lds_doubles = lds_small;
 
     // ---- LDS-resident subtrees ----
     // A subtree of the elimination tree (a contiguous column range [c0, c1) in F) whose accumulators -- its
@@ -517,16 +526,22 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
     for (int j = 0; j < k; ++j) maxR1[j] = 1 + FLp[j + 1] - FLp[j];
     for (int j = 0; j < k; ++j)
       if (parF[j] >= 0) maxR1[parF[j]] = std::max(maxR1[parF[j]], maxR1[j]);
-    struct Seg { int c0, c1, lds, nL, accN, sn0, sn1; };
+    struct Seg { int c0, c1, lds, nL, accN, sn0, sn1, nout, omap0; };
     std::vector<Seg> segs;
-    {
+    // `units`: segments for the unit engine (below) -- a subtree fits when its accumulators and the accumulators of
+    // its ancestors that it updates (at most all pairs of the root column's structure) do
+    auto choose_segments = [&](const bool units) {
+      segs.clear();
       constexpr int kMinCols = 8;
       std::vector<char> in_lds(k, 0);
       const char *no_lds = sfb::knob("SFB_PLAN_NO_LDS");  // A/B knob: every column a top column (accumulators in HBM)
       for (int j = (no_lds && no_lds[0] == '1') ? -1 : k - 1; j >= 0;) {
         const int c0 = fdesc[j], nc = j - c0 + 1, nL = FLp[j + 1] - FLp[c0];
         const int reserve = std::max(2 * maxR1[j], 384);  // panel + multipliers of the supernodes formed below
-        if (nc >= kMinCols && maxR1[j] <= 64 && nL + nc + 2 + reserve <= o.lds_doubles) {
+        const int ccj = FLp[j + 1] - FLp[j];
+        const bool fits = units ? nL + nc + ccj * (ccj + 1) / 2 + 3 <= o.lds_doubles
+                                : (maxR1[j] <= 64 && nL + nc + 2 + reserve <= o.lds_doubles);
+        if (nc >= kMinCols && fits) {
           for (int c = c0; c <= j; ++c) in_lds[c] = 1;
           j = c0 - 1;
         } else {
@@ -542,12 +557,187 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
           int root = e - 1;
           while (fdesc[root] != c) --root;
           e = root + 1;
-          segs.push_back({c, e, 1, FLp[e] - FLp[c], FLp[e] - FLp[c] + (e - c), 0, 0});
+          segs.push_back({c, e, 1, FLp[e] - FLp[c], FLp[e] - FLp[c] + (e - c), 0, 0, 0, 0});
         } else {
           while (e < k && !in_lds[e]) ++e;
-          segs.push_back({c, e, 0, 0, 0, 0, 0});
+          segs.push_back({c, e, 0, 0, 0, 0, 0, 0, 0});
         }
         c = e;
+      }
+    };
+
+    // ---- UNIT ENGINE of the numeric factorisation (see sparse_plan.h) ----
+    // Every segment's work -- the divisions L(r, j) = acc(r, j) / D(j) ("DM" slots) and the updates
+    // acc(a, b) = fma(-L(a, j), L(b, j) D(j), acc(a, b)) ("F" slots) of its columns -- is list-scheduled into units of
+    // 128 independent slots of ONE kind, executed on accumulators that all live in LDS: the segment's own ones and the
+    // ("outside") accumulators of later columns that it updates, fetched from the workspace when the segment starts
+    // and returned when it ends.  A slot waits for the previous writer of its target (the updates of one accumulator
+    // keep the ascending order of their source columns: the oracle's order) and for the slots that finalise what it
+    // reads.  Applicable when every column fits the LDS on its own; otherwise the supernodal engine below runs.
+    o.units = 0;
+    o.ustream.clear(); o.utype.clear(); o.uomap.clear();
+    {
+      const char *uk = sfb::knob("SFB_PLAN_UNITS");  // A/B knob: 0 = the supernodal engine for every plan
+      bool ok = false;
+      for (int attempt = 0; attempt < 2 && !ok; ++attempt) {
+      if (attempt == 1 && lds_large == lds_small) break;
+      o.lds_doubles = attempt == 0 ? lds_small : lds_large;
+      ok = !(uk && uk[0] == '0') && (size_t)o.lds_doubles * 8 < (1u << 16);
+      if (ok) {
+        choose_segments(true);
+        // top runs are cut greedily into ranges whose own + outside accumulators fit
+        std::vector<Seg> cut;
+        std::vector<int32_t> seen(o.nnzL + k, -1), percol(k + 1, 0);
+        for (const Seg &sg : segs) {
+          if (sg.lds) { cut.push_back(sg); continue; }
+          int c0 = sg.c0;
+          while (c0 < sg.c1 && ok) {
+            // grow [c0, c1): own = entries + diagonals of the columns, outside = distinct accumulators (a, b), b >= c1
+            int own = 0, nout = 0, best = -1;
+            std::vector<int32_t> touched;
+            for (int j = c0; j < sg.c1; ++j) {
+              own += FLp[j + 1] - FLp[j] + 1;
+              nout -= percol[j];  // accumulators of column j itself are own from now on
+              for (int bp = FLp[j]; bp < FLp[j + 1]; ++bp)
+                for (int ap = bp; ap < FLp[j + 1]; ++ap) {
+                  const int b = FLi[bp], a = FLi[ap];
+                  const int g = (a == b) ? o.nnzL + b : pos_in_col(b, a);
+                  if (g < 0) { *msg = "internal: update outside the pattern of L"; return false; }
+                  if (seen[g] != c0) { seen[g] = c0; touched.push_back(g); percol[b]++; ++nout; }
+                }
+              if (own + nout + 3 <= o.lds_doubles) best = j + 1;
+              else if (best >= 0) break;
+              else if (j == c0) break;
+            }
+            for (int g : touched) seen[g] = -1;
+            std::fill(percol.begin(), percol.end(), 0);
+            if (best < 0) { ok = false; break; }
+            cut.push_back({c0, best, 0, 0, 0, 0, 0, 0, 0});
+            c0 = best;
+          }
+        }
+        if (ok) segs.swap(cut);
+      }
+      }
+      if (ok) {
+        struct Op { int32_t t, a, b, d; };  // LDS offsets (DM: a = b = -1)
+        std::vector<int32_t> outidx(o.nnzL + k, -1);
+        for (Seg &sg : segs) {
+          const int c0 = sg.c0, c1 = sg.c1;
+          sg.nL   = FLp[c1] - FLp[c0];
+          sg.accN = sg.nL + (c1 - c0);
+          sg.omap0 = (int)o.uomap.size();
+          sg.sn0   = (int)o.utype.size();
+          // outside accumulators, in order of first touch
+          int nout = 0;
+          auto off_of = [&](int g) {
+            if (g < o.nnzL) { if (g >= FLp[c0] && g < FLp[c1]) return g - FLp[c0]; }
+            else if (g - o.nnzL >= c0 && g - o.nnzL < c1) return sg.nL + (g - o.nnzL - c0);
+            if (outidx[g] < 0) { outidx[g] = nout++; o.uomap.push_back(g); }
+            return sg.accN + outidx[g];
+          };
+          std::vector<Op> ops;
+          std::vector<std::array<int32_t, 3>> deps;  // up to three predecessors (-1 = none)
+          std::vector<int32_t> dm_of(sg.nL, -1);
+          std::vector<int32_t> writer;               // LDS offset -> last op that wrote it
+          for (int j = c0; j < c1; ++j) {
+            const int dOff = sg.nL + (j - c0);
+            if ((int)writer.size() < sg.accN) writer.resize(sg.accN, -1);
+            for (int p = FLp[j]; p < FLp[j + 1]; ++p) {
+              const int tOff = p - FLp[c0];
+              deps.push_back({writer[tOff], writer[dOff], -1});
+              dm_of[tOff] = (int)ops.size();
+              writer[tOff] = (int)ops.size();
+              ops.push_back({tOff, -1, -1, dOff});
+            }
+            for (int bp = FLp[j]; bp < FLp[j + 1]; ++bp)
+              for (int ap = bp; ap < FLp[j + 1]; ++ap) {
+                const int b = FLi[bp], a = FLi[ap];
+                const int g = (a == b) ? o.nnzL + b : pos_in_col(b, a);
+                if (g < 0) { *msg = "internal: update outside the pattern of L"; return false; }
+                const int T = off_of(g);
+                if ((int)writer.size() <= T) writer.resize(T + 1, -1);
+                deps.push_back({dm_of[ap - FLp[c0]], dm_of[bp - FLp[c0]], writer[T]});
+                writer[T] = (int)ops.size();
+                ops.push_back({T, ap - FLp[c0], bp - FLp[c0], dOff});
+              }
+          }
+          for (int e = sg.omap0; e < (int)o.uomap.size(); ++e) outidx[o.uomap[e]] = -1;
+          sg.nout = nout;
+          if (sg.accN + nout + 3 > o.lds_doubles) { *msg = "internal: segment does not fit the LDS"; return false; }
+          const int SINK = sg.accN + nout, ZEROL = SINK + 1, ONE = SINK + 2;
+          // list scheduling on the critical path, units of one kind
+          const int nops = (int)ops.size();
+          std::vector<int32_t> nsucc(nops + 1, 0), succ, height(nops, 1), npred(nops, 0);
+          for (int i = 0; i < nops; ++i)
+            for (int d : deps[i])
+              if (d >= 0) { nsucc[d + 1]++; npred[i]++; }
+          for (int i = 0; i < nops; ++i) nsucc[i + 1] += nsucc[i];
+          succ.resize(nsucc[nops]);
+          {
+            std::vector<int32_t> fill(nops, 0);
+            for (int i = 0; i < nops; ++i)
+              for (int d : deps[i])
+                if (d >= 0) succ[nsucc[d] + fill[d]++] = i;
+          }
+          for (int i = nops - 1; i >= 0; --i)
+            for (int d : deps[i])
+              if (d >= 0) height[d] = std::max(height[d], height[i] + 1);
+          std::vector<std::pair<int32_t, int32_t>> ready[2];  // heaps of (height, -op): [0] F, [1] DM
+          for (int i = 0; i < nops; ++i)
+            if (npred[i] == 0) ready[ops[i].a < 0].emplace_back(height[i], -i);
+          for (auto &h : ready) std::make_heap(h.begin(), h.end());
+          int done = 0;
+          std::vector<int32_t> cur, arriving;
+          while (done < nops) {
+            // the kind whose best ready slot has the longer chain of dependants; ties: divisions (they release updates)
+            int kind;
+            if (ready[0].empty()) kind = 1;
+            else if (ready[1].empty()) kind = 0;
+            else kind = ready[1].front().first >= ready[0].front().first;
+            cur.clear();
+            arriving.clear();
+            while ((int)cur.size() < 128 && !ready[kind].empty()) {
+              std::pop_heap(ready[kind].begin(), ready[kind].end());
+              cur.push_back(-ready[kind].back().second);
+              ready[kind].pop_back();
+            }
+            done += (int)cur.size();
+            const size_t base = o.ustream.size();
+            o.ustream.resize(base + 256);
+            o.utype.push_back(kind);
+            for (int e = 0; e < 128; ++e) {
+              const int lane = e % 64, half = e / 64;
+              int32_t w0, w1;
+              if (e < (int)cur.size()) {
+                const Op &op = ops[cur[e]];
+                if (kind) { w0 = (op.t * 8) | ((op.d * 8) << 16); w1 = -1; }
+                else { w0 = (op.t * 8) | ((op.a * 8) << 16); w1 = (op.b * 8) | ((op.d * 8) << 16); }
+              } else if (kind) { w0 = (SINK * 8) | ((ONE * 8) << 16); w1 = -1; }
+              else { w0 = (SINK * 8) | ((ZEROL * 8) << 16); w1 = (ZEROL * 8) | ((ZEROL * 8) << 16); }
+              o.ustream[base + (size_t)lane * 4 + 2 * half]     = w0;
+              o.ustream[base + (size_t)lane * 4 + 2 * half + 1] = w1;
+            }
+            for (int i : cur)
+              for (int q = nsucc[i]; q < nsucc[i + 1]; ++q)
+                if (--npred[succ[q]] == 0) arriving.push_back(succ[q]);
+            for (int i : arriving) {
+              auto &h = ready[ops[i].a < 0];
+              h.emplace_back(height[i], -i);
+              std::push_heap(h.begin(), h.end());
+            }
+          }
+          sg.sn1 = (int)o.utype.size();
+        }
+        o.units  = 1;
+        o.nunits = (int)o.utype.size();
+        o.ustream.resize(o.ustream.size() + (size_t)256 * 2 * SparsePlanHost::kSweepPad, 0);  // prefetched past the end (two blocks), never executed
+        o.utype.resize(o.utype.size() + SparsePlanHost::kSweepPad + 32, 0);
+        o.uomap.resize(o.uomap.size() + 64 * 8, o.nnzL + k);  // padding: the scratch accumulator
+      } else {
+        o.ustream.clear(); o.utype.clear(); o.uomap.clear();
+        o.lds_doubles = lds_large;
+        choose_segments(false);
       }
     }
 
@@ -562,6 +752,7 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
     o.rtgt.clear(); o.rab.clear();
     o.rptr.push_back(0);
     for (Seg &sg : segs) {
+      if (o.units) break;
       sg.sn0 = (int)o.snptr.size();
       const int scratch = sg.lds ? o.lds_doubles - ((sg.accN + 2 + 1) & ~1) : o.lds_doubles;
       // accumulator -> LDS offset inside an LDS segment: [L entries | D | sink | zero]
@@ -646,11 +837,14 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
       sg.sn1 = (int)o.snptr.size();
     }
     o.nsn = (int)o.snptr.size();
-    // segment table {sn0, sn1, c0, c1, lds, nL, accN, first K entry, last K entry + 1, first L entry}
+    // segment table {sn0, sn1, c0, c1, lds, nL, accN, first K entry, last K entry + 1, first L entry, outside accumulators,
+    // start of their map} (unit engine: sn0, sn1 = the segment's units)
     o.nseg = (int)segs.size();
     o.seg.clear();
     for (const Seg &sg : segs)
-      for (int v : {sg.sn0, sg.sn1, sg.c0, sg.c1, sg.lds, sg.nL, sg.accN, (int)FKp[sg.c0], (int)FKp[sg.c1], (int)FLp[sg.c0]}) o.seg.push_back(v);
+      for (int v : {sg.sn0, sg.sn1, sg.c0, sg.c1, sg.lds, sg.nL, sg.accN, (int)FKp[sg.c0], (int)FKp[sg.c1], (int)FLp[sg.c0], sg.nout, sg.omap0})
+        o.seg.push_back(v);
+    static_assert(SparsePlanHost::kSegStride == 12, "segment table layout");
     // KKT fill.  Kdesc: {kind, idx, r, c} of every entry in F order (row / column of the source entry resolved
     // here), Kmap its accumulator, KmapL its LDS offset inside an LDS segment; KdescT / KmapT: the entries of the
     // TOP columns only (their accumulators live in HBM), padded for branch-free batches.
@@ -714,6 +908,13 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
         panel += (long long)w * R;
         internal += o.rsplit[sn] - o.rptr[sn];
         ext += o.rptr[sn + 1] - o.rsplit[sn];
+      }
+      if (o.units) {
+        int nf = 0, nd = 0, maxw = 0;
+        for (int u = 0; u < o.nunits; ++u) (o.utype[u] ? nd : nf)++;
+        for (const Seg &sg : segs) maxw = std::max(maxw, sg.accN + sg.nout + 3);
+        fprintf(stderr, "[sfb plan] unit engine: %d units (%d update + %d division), %d segments, largest working set %d of %d doubles\n",
+                o.nunits, nf, nd, (int)segs.size(), maxw, o.lds_doubles);
       }
       fprintf(stderr, "[sfb plan] %d supernodes, max R %d, %d with R > 64, panel entries %lld, trailing steps %d on chip + %d in HBM; "
               "%d segments, %d on chip with %d columns and %lld accumulators of %d; lds_doubles %d\n", o.nsn, maxR, over64, panel,

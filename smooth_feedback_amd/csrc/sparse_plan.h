@@ -82,16 +82,34 @@ struct SparsePlanHost {
   //   rsplit[s] : first HBM step of supernode s's trailing schedule; steps [rptr[s], rsplit[s]) target LDS offsets
   //   KmapL  : LDS offset of every K entry of an LDS segment;  KdescT / KmapT (nnzKT entries, padded): the K
   //            entries of the top columns;  ztop: {start, length} accumulator ranges the kernel zeroes in HBM
+  static constexpr int kSegStride = 12;  // seg also carries {outside accumulators, start of their map} (unit engine)
   std::vector<int32_t> seg, pmapL, rsplit, KmapL, KdescT, KmapT, ztop;
   int nseg = 0, nnzKT = 0, nztop = 0;
+  // UNIT ENGINE of the numeric factorisation (round 5; sparse_plan.cpp).  Instead of supernodal panels, the work of a
+  // segment [c0, c1) of columns is a static schedule of UNITS of 128 independent slots of one kind,
+  //   DM  (division):  L(r, j) = acc(r, j) / D(j)                                  words {t | d << 16, all ones}
+  //   F   (update):    acc(a, b) = fma(-L(a, j), L(b, j) * D(j), acc(a, b))          words {t | a << 16, b | d << 16}
+  // all operands being byte offsets into the segment's LDS working set
+  //   [own L entries (nL) | own D (c1 - c0) | outside accumulators (nout) | sink | zero | one]:
+  // the accumulators of later columns that the segment updates are fetched from the workspace when it starts
+  // (uomap[omap0 + e] = accumulator index) and returned when it ends.  Every accumulator still receives its updates
+  // in ascending order of the source column, each one the oracle's fma -- bit for bit the left-looking loop.
+  // A closed segment (lds == 1: a whole subtree, nobody outside updates its accumulators) fills its KKT entries on
+  // chip; an open one (a run of top columns) finds its accumulators, filled and partly updated, in the workspace.
+  //   ustream : unit u, lane l, half h (slot h * 64 + l) at [(u * 64 + l) * 4 + 2 h ..+1]; padded by kSweepPad units
+  //   utype[u]: 1 = DM, 0 = F;  seg[..] = {u0, u1, ...} the units of a segment
+  // units == 0: some column does not fit the LDS on its own (or SFB_PLAN_UNITS=0): the supernodal engine runs.
+  std::vector<int32_t> ustream, utype, uomap;
+  int units = 0, nunits = 0;
 };
 
 // ordering: 0 = natural, 1 = minimum degree (default); user_perm (k entries, new->old) overrides.
 // stage (k entries, nullable): constrained minimum degree -- unknowns of a lower stage are
 // eliminated before any unknown of a higher stage (e.g. interval separators of an MPC horizon last:
 // shorter elimination tree, less fill).  Returns false on malformed input (msg set).
+// lds_hint > 0: the LDS (doubles) of the plan this one accompanies as the whole-pattern fallback (sparse_plan.cpp).
 bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const int32_t *Ap, const int32_t *Aj,
                        int ordering, const int32_t *user_perm, const int32_t *stage, SparsePlanHost &out,
-                       const char **msg);
+                       const char **msg, int lds_hint = 0);
 
 }  // namespace sfb
