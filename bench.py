@@ -310,6 +310,24 @@ class MPCWorkload:
                   "the floor of a warm tick", "entry": "sfb_sparse_qp_solve_batch_host, batch 1 (n = m = %d)" % self.d["n"]}
         return {"end_to_end": e2e, "swarm_tick": tick, "single_agent": single}
 
+    def phases_ms(self):
+        """The reference's verbose summary (qp_solver.hpp:550-565: Matrix filling / Factorization / Iteration / Polish) as DATA for
+        the headline batch: sfb_sparse_qp_solve_batch_phases = the same solves through the TRACE instance of the kernel (one wave
+        per agent, the whole batch resident in turn), per-agent device wall-clock per phase; batch means in ms.  NOT the timed
+        launch (that one is time-sliced and ordered): what an agent's solve consists of when the chip is full."""
+        Px, q, Ax, l, u = self.dev
+        ph = torch.zeros((self.B, 6), dtype=torch.float64, device=Px.device)
+        x2, y2, out2 = torch.empty_like(self.x), torch.empty_like(self.y), torch.empty_like(self.out)
+        self.plan.solve_batch_device_phases(self.B, Px.data_ptr(), q.data_ptr(), Ax.data_ptr(), l.data_ptr(), u.data_ptr(),
+                                            x2.data_ptr(), y2.data_ptr(), 0, out2[0].data_ptr(), out2[1].data_ptr(),
+                                            self.ws.data_ptr(), ph.data_ptr(), self.prm)
+        torch.cuda.synchronize()
+        m = (ph.mean(dim=0) * 1e-3).cpu().numpy()
+        names = ("scaling_and_precheck", "matrix_filling", "factorization", "iteration", "polish", "unscale_and_report")
+        return {**{k: float(v) for k, v in zip(names, m)}, "per_agent_total": float(m.sum()),
+                "results_identical_to_the_timed_launch": bool(torch.equal(x2, self.x) and torch.equal(out2, self.out)),
+                "unit": "ms per agent (batch mean, device wall clock)", "entry": "sfb_sparse_qp_solve_batch_phases (TRACE instance, one wave per agent)"}
+
     def extra(self):
         it = self.out[0].cpu().numpy().astype(np.int64)
         code = self.out[1].cpu().numpy()
@@ -745,6 +763,7 @@ def main():
         if world == 1 and hasattr(wl, "pipelined") and not args.no_pipelined:
             rec["ordered_like_a_swarm_tick"] = wl.ordered_like_a_swarm_tick()
             rec["pipelined"] = wl.pipelined(max(4, 2 * args.steps))
+            rec["phases_ms"] = wl.phases_ms()
             if args.batch is None and not args.no_closed_loop:
                 rec["closed_loop"] = wl.closed_loop()
         if not args.no_cpu_baseline and world == 1:

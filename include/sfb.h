@@ -174,6 +174,16 @@ sfb_status sfb_qp_dense_solve_batch_trace(const sfb_qp_params *prm, int64_t batc
                                           const double *q, const double *A, const double *l, const double *u,
                                           const double *warm_x, const double *warm_y, double *x, double *y, double *obj,
                                           uint32_t *iter, int32_t *code, double *trace, int32_t trace_rows, void *stream);
+/* Same, and the reference's closing summary (qp_solver.hpp:550-565) as DATA: phase_us (device, nullable) = batch x 16 doubles, of
+ * which the first batch x 6 receive per problem the microseconds of the device's wall clock spent in
+ *   [0] scaling and pre-check (before the reference's t0, :376)   [1] matrix filling (pivot order, zero, fill)
+ *   [2] factorization   [3] iteration   [4] polish   [5] un-scale and report
+ * (the remaining batch x 10 doubles are scratch for the kernel's stamps).  trace is nullable when trace_rows == 0. */
+sfb_status sfb_qp_dense_solve_batch_phases(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P,
+                                           const double *q, const double *A, const double *l, const double *u,
+                                           const double *warm_x, const double *warm_y, double *x, double *y, double *obj,
+                                           uint32_t *iter, int32_t *code, double *trace, int32_t trace_rows, double *phase_us,
+                                           void *stream);
 
 /*
  * Explicit workspaces.  The reference's QPSolver owns its work memory, allocated once by analyze()
@@ -213,6 +223,13 @@ sfb_status sfb_qp_dense_solve_batch_host_trace(const sfb_qp_params *prm, int64_t
                                                const double *q, const double *A, const double *l, const double *u,
                                                const double *warm_x, const double *warm_y, double *x, double *y, double *obj,
                                                uint32_t *iter, int32_t *code, double *trace, int32_t trace_rows);
+/* ... and the per-phase times (phase_us [batch][6], HOST memory, nullable; see sfb_qp_dense_solve_batch_phases).
+ * sfb_qp_dense_solve_batch_host with prm->verbose set and batch == 1 prints table and summary from the same data. */
+sfb_status sfb_qp_dense_solve_batch_host_phases(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P,
+                                                const double *q, const double *A, const double *l, const double *u,
+                                                const double *warm_x, const double *warm_y, double *x, double *y, double *obj,
+                                                uint32_t *iter, int32_t *code, double *trace, int32_t trace_rows,
+                                                double *phase_us);
 /* ... and sharded over the device list (sfb_set_devices); same arguments, same results. */
 sfb_status sfb_qp_dense_solve_batch_host_multi(const sfb_qp_params *prm, int64_t batch, int n, int m,
                                                const double *P, const double *q, const double *A, const double *l,
@@ -316,6 +333,17 @@ sfb_status sfb_sparse_qp_solve_batch_trace(sfb_sparse_qp_plan *plan, const sfb_q
                                            const double *u, const double *warm_x, const double *warm_y, double *x,
                                            double *y, double *obj, uint32_t *iter, int32_t *code, void *workspace,
                                            double *trace, int32_t trace_rows, void *stream);
+/* Same, and the reference's closing summary (qp_solver.hpp:550-565: Matrix filling / Factorization / Iteration / Polish) as
+ * DATA: phase_us [batch][6] (device, required) receives per item the microseconds of the device's wall clock spent in
+ *   [0] scaling and pre-check (before the reference's t0, :376)   [1] matrix filling   [2] factorization   [3] iteration
+ *   [4] polish   [5] un-scale and report
+ * -- their sum is the time the item held its wavefront, [1] + .. + [4] is the reference's "Total time".  trace is nullable here.
+ * Like the table: the TRACE instance of the kernel, one wave per item, same arithmetic and results as the plain call. */
+sfb_status sfb_sparse_qp_solve_batch_phases(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
+                                            const double *Px, const double *q, const double *Ax, const double *l,
+                                            const double *u, const double *warm_x, const double *warm_y, double *x,
+                                            double *y, double *obj, uint32_t *iter, int32_t *code, void *workspace,
+                                            double *trace, int32_t trace_rows, double *phase_us, void *stream);
 /* Same with host pointers (synchronous).  The device buffers are owned by the plan and kept between calls
  * (grow-only, freed by sfb_sparse_qp_plan_destroy) -- the analogue of the working memory a QPSolver object
  * keeps between solves (qp_solver.hpp:242-338); host-pointer calls on ONE plan and ONE device are serialised. */
@@ -332,6 +360,13 @@ sfb_status sfb_sparse_qp_solve_batch_host_trace(sfb_sparse_qp_plan *plan, const 
                                                 const double *u, const double *warm_x, const double *warm_y, double *x,
                                                 double *y, double *obj, uint32_t *iter, int32_t *code, double *trace,
                                                 int32_t trace_rows);
+/* ... and the per-phase times (phase_us [batch][6], HOST memory, nullable; see sfb_sparse_qp_solve_batch_phases).  With
+ * prm->verbose set and batch == 1 the summary of qp_solver.hpp:550-565 is printed from them. */
+sfb_status sfb_sparse_qp_solve_batch_host_phases(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
+                                                 const double *Px, const double *q, const double *Ax, const double *l,
+                                                 const double *u, const double *warm_x, const double *warm_y,
+                                                 double *x, double *y, double *obj, uint32_t *iter, int32_t *code,
+                                                 double *trace, int32_t trace_rows, double *phase_us);
 /* ... and sharded over the device list (sfb_set_devices): one contiguous shard, host thread, plan upload and workspace
  * per device; same arguments, same results (calls on different devices are not serialised). */
 sfb_status sfb_sparse_qp_solve_batch_host_multi(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,

@@ -75,6 +75,8 @@ def _load():
     L.sfb_qp_dense_solve_batch_host_multi.argtypes = L.sfb_qp_dense_solve_batch_host.argtypes
     L.sfb_qp_dense_solve_batch_host_trace.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12 + [dp, i32]
     L.sfb_qp_dense_solve_batch_trace.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12 + [dp, i32, vp]
+    L.sfb_qp_dense_solve_batch_host_phases.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12 + [dp, i32, dp]
+    L.sfb_qp_dense_solve_batch_phases.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12 + [dp, i32, dp, vp]
     L.sfb_qp_dense_solve_batch_ws.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32] + [dp] * 12 + [vp, vp]
     L.sfb_qp_dense_workspace_bytes.argtypes = [C.POINTER(SfbQPParams), i64, i32, i32, C.POINTER(C.c_int64)]
     L.sfb_workspace_create.argtypes = [i64, C.POINTER(C.c_void_p)]
@@ -99,6 +101,8 @@ def _load():
     L.sfb_sparse_qp_solve_batch_host_multi.argtypes = L.sfb_sparse_qp_solve_batch_host.argtypes
     L.sfb_sparse_qp_solve_batch_host_trace.argtypes = [C.c_void_p, C.POINTER(SfbQPParams), i64] + [dp] * 12 + [dp, i32]
     L.sfb_sparse_qp_solve_batch_trace.argtypes = [C.c_void_p, C.POINTER(SfbQPParams), i64] + [dp] * 12 + [vp, dp, i32, vp]
+    L.sfb_sparse_qp_solve_batch_host_phases.argtypes = [C.c_void_p, C.POINTER(SfbQPParams), i64] + [dp] * 12 + [dp, i32, dp]
+    L.sfb_sparse_qp_solve_batch_phases.argtypes = [C.c_void_p, C.POINTER(SfbQPParams), i64] + [dp] * 12 + [vp, dp, i32, dp, vp]
     L.sfb_ekf_predict_batch.argtypes = [i64, i32, dp, dp, i32, dp, i32, dp, vp]
     L.sfb_ekf_predict_stepper_batch.argtypes = [i32, i64, i32, dp, dp, i32, dp, i32, dp, vp]
     L.sfb_ekf_predict_stepper_batch_host.argtypes = [i32, i64, i32, dp, dp, i32, dp, i32, dp]

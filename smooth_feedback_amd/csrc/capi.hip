@@ -69,6 +69,25 @@ void verbose_report(const char *what, int64_t batch, int n, int m, double h2d_ms
   std::fflush(stdout);
 }
 
+// The reference's closing summary of a verbose solve (qp_solver.hpp:550-565), from the per-phase times of the device
+// (phase_us: scaling + pre-check | matrix filling | factorisation | iteration | polish | un-scale and report, microseconds).
+// Its "Total time" runs from t0 (:376, after the scaling) to the end of the polish; the two parts outside are added as lines.
+void verbose_summary(int32_t code, uint32_t iter, const double *phase_us)
+{
+  std::printf("QP solver summary:\n");
+  std::printf("Result %d\n", (int)code);
+  std::printf("%-25s%10lld\n", "Iterations", (long long)iter - 1);  // (the reference prints iter - 1, :556)
+  std::printf("%-26s%10.0f\n", "Total time (\xC2\xB5s)", phase_us[1] + phase_us[2] + phase_us[3] + phase_us[4]);
+  std::printf("%-25s%10.0f\n", "  Matrix filling", phase_us[1]);
+  std::printf("%-25s%10.0f\n", "  Factorization", phase_us[2]);
+  std::printf("%-25s%10.0f\n", "  Iteration", phase_us[3]);
+  std::printf("%-25s%10.0f\n", "  Polish", phase_us[4]);
+  std::printf("%-25s%10.0f\n", "(before t0: scaling)", phase_us[0]);
+  std::printf("%-25s%10.0f\n", "(after: un-scale, report)", phase_us[5]);
+  std::printf("=============================================================\n");
+  std::fflush(stdout);
+}
+
 void verbose_table(const char *kind, int n, int m, const double *trace, int rows, const char *note)
 {
   std::printf("========================= QP Solver =========================\n");
@@ -276,27 +295,42 @@ sfb_status dense_via_sparse(const sfb_qp_params *prm, int64_t batch, int n, int 
 // verbose, ONE dense problem with n + m <= 128 (device pointers of the call): the per-iteration table of qp_solver.hpp:490-501
 // from the TRACE instance of the on-chip dense kernel (qp_dense_mid.hip) -- the same pivoted arithmetic as the solve whose
 // results the caller receives (every dense route is bit-identical to the dense oracle), so the rows ARE that solve's iterates.
+// The closing summary (:550-565) follows from the same launch's phase stamps.  The re-solve runs WITHOUT the caller's time
+// limit and for at most the iterations the returned solve took (real_iter, nullable): a solve that ended with MaxTime has
+// its table end at the same iteration instead of wherever the second run's clock would cut it.
 void dense_native_table(const sfb_qp_params *prm, int n, int m, const double *P, const double *q, const double *A, const double *l,
-                        const double *u, const double *wx, const double *wy)
+                        const double *u, const double *wx, const double *wy, const uint32_t *real_iter, const int32_t *real_code)
 {
   const int rows = sfb::verbose_table_rows(prm);
   std::vector<double> tr((size_t)rows * 5, 0.0);
   for (int r = 0; r < rows; ++r) tr[(size_t)r * 5] = -1.0;
   char *buf = nullptr;
-  if (hipMalloc(reinterpret_cast<void **>(&buf), ((size_t)n + m + 2 + tr.size()) * 8 + 16) != hipSuccess) { (void)hipGetLastError(); return; }
-  double *tx = reinterpret_cast<double *>(buf), *ty = tx + n, *tobj = ty + m, *dtr = tobj + 1;
-  uint32_t *titer = reinterpret_cast<uint32_t *>(dtr + tr.size());
+  if (hipMalloc(reinterpret_cast<void **>(&buf), ((size_t)n + m + 2 + tr.size() + 16) * 8 + 16) != hipSuccess) { (void)hipGetLastError(); return; }
+  double *tx = reinterpret_cast<double *>(buf), *ty = tx + n, *tobj = ty + m, *dtr = tobj + 1, *dph = dtr + tr.size();
+  uint32_t *titer = reinterpret_cast<uint32_t *>(dph + 16);
   int32_t *tcode  = reinterpret_cast<int32_t *>(titer + 1);
   sfb_qp_params p2 = *prm;
   p2.verbose       = 0;
+  p2.max_time_ns   = -1;
+  if (real_iter != nullptr && (p2.max_iter < 0 || (int64_t)*real_iter < p2.max_iter)) p2.max_iter = (int64_t)*real_iter;
   const sfb::DenseKernelParams kp = make_kernel_params(&p2, n, m);
   const sfb::QpBatch g{P, q, A, l, u, wx, wy, tx, ty, tobj, titer, tcode};
+  double ph[6] = {0, 0, 0, 0, 0, 0};
+  uint32_t it2 = 0;
+  int32_t code2 = -1;
   const bool ok = hipMemcpy(dtr, tr.data(), tr.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
-                  sfb::qp_dense_mid_trace_launch(kp, 1, g, nullptr, dtr, rows) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
-                  hipMemcpy(tr.data(), dtr, tr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess;
+                  sfb::qp_dense_mid_trace_launch(kp, 1, g, nullptr, dtr, rows, dph) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+                  hipMemcpy(tr.data(), dtr, tr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+                  hipMemcpy(ph, dph, sizeof(ph), hipMemcpyDeviceToHost) == hipSuccess &&
+                  hipMemcpy(&it2, titer, 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(&code2, tcode, 4, hipMemcpyDeviceToHost) == hipSuccess;
   (void)hipFree(buf);
-  if (ok) sfb::verbose_table("dense", n, m, tr.data(), rows, nullptr);
-  else (void)hipGetLastError();
+  if (ok) {
+    sfb::verbose_table("dense", n, m, tr.data(), rows, nullptr);
+    sfb::verbose_summary(real_code ? *real_code : code2, real_iter ? *real_iter : it2, ph);
+    if (real_iter != nullptr && real_code != nullptr && (it2 != *real_iter || (code2 != *real_code && *real_code != SFB_QP_MAX_TIME)))
+      std::printf("[sfb] verbose: NOTE the table's solve ended after %u iterations with code %d, the returned solve after %u iterations with code %d\n",
+                  it2, (int)code2, *real_iter, (int)*real_code);
+  } else (void)hipGetLastError();
 }
 
 // verbose, ONE dense problem (device pointers of the call): the per-iteration table of qp_solver.hpp:490-501.  The dense
@@ -553,6 +587,14 @@ sfb_status sfb_qp_dense_solve_batch_trace(const sfb_qp_params *prm, int64_t batc
                                           double *x, double *y, double *obj, uint32_t *iter, int32_t *code, double *trace,
                                           int32_t trace_rows, void *stream)
 {
+  return sfb_qp_dense_solve_batch_phases(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code, trace, trace_rows, nullptr, stream);
+}
+
+sfb_status sfb_qp_dense_solve_batch_phases(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P, const double *q,
+                                           const double *A, const double *l, const double *u, const double *warm_x, const double *warm_y,
+                                           double *x, double *y, double *obj, uint32_t *iter, int32_t *code, double *trace,
+                                           int32_t trace_rows, double *phase_us, void *stream)
+{
   sfb_status st = check_qp_args(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, code);
   if (st != SFB_OK) return st;
   if (trace_rows < 0 || (trace_rows > 0 && !trace)) return fail(SFB_ERR_INVALID_ARG, "trace is NULL or trace_rows < 0");
@@ -562,7 +604,7 @@ sfb_status sfb_qp_dense_solve_batch_trace(const sfb_qp_params *prm, int64_t batc
   if (batch == 0) return SFB_OK;
   const sfb::DenseKernelParams kp = make_kernel_params(prm, n, m);
   const sfb::QpBatch g{P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code};
-  const hipError_t e = sfb::qp_dense_mid_trace_launch(kp, batch, g, static_cast<hipStream_t>(stream), trace_rows > 0 ? trace : nullptr, trace_rows);
+  const hipError_t e = sfb::qp_dense_mid_trace_launch(kp, batch, g, static_cast<hipStream_t>(stream), trace_rows > 0 ? trace : nullptr, trace_rows, phase_us);
   if (e != hipSuccess) return hip_fail(e, "qp_dense_mid_trace_kernel launch");
   return SFB_OK;
 }
@@ -769,7 +811,7 @@ sfb_status sfb_qp_dense_solve_batch_host(const sfb_qp_params *prm, int64_t batch
   if (st == SFB_OK && prm->verbose && batch == 1) {  // (inputs still on the device)
     uint32_t it1 = 0;
     const bool have_it = iter ? (it1 = iter[0], true) : hipMemcpy(&it1, dit, 4, hipMemcpyDeviceToHost) == hipSuccess;
-    if (n + m <= sfb::kDenseMidMaxK) dense_native_table(prm, n, m, dP, dq, dA, dl, du, dwx, dwy);  // the solve's own iterates
+    if (n + m <= sfb::kDenseMidMaxK) dense_native_table(prm, n, m, dP, dq, dA, dl, du, dwx, dwy, have_it ? &it1 : nullptr, code);  // the solve's own iterates
     else dense_verbose_table(prm, n, m, dP, dq, dA, dl, du, dwx, dwy, have_it ? &it1 : nullptr, code);
   }
   if (st == SFB_OK && prm->verbose) {
@@ -789,6 +831,14 @@ sfb_status sfb_qp_dense_solve_batch_host_trace(const sfb_qp_params *prm, int64_t
                                                double *x, double *y, double *obj, uint32_t *iter, int32_t *code, double *trace,
                                                int32_t trace_rows)
 {
+  return sfb_qp_dense_solve_batch_host_phases(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code, trace, trace_rows, nullptr);
+}
+
+sfb_status sfb_qp_dense_solve_batch_host_phases(const sfb_qp_params *prm, int64_t batch, int n, int m, const double *P, const double *q,
+                                                const double *A, const double *l, const double *u, const double *warm_x, const double *warm_y,
+                                                double *x, double *y, double *obj, uint32_t *iter, int32_t *code, double *trace,
+                                                int32_t trace_rows, double *phase_us)
+{
   sfb_status st = check_qp_args(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, code);
   if (st != SFB_OK) return st;
   if (trace_rows < 0 || (trace_rows > 0 && !trace)) return fail(SFB_ERR_INVALID_ARG, "trace is NULL or trace_rows < 0");
@@ -796,8 +846,8 @@ sfb_status sfb_qp_dense_solve_batch_host_trace(const sfb_qp_params *prm, int64_t
   st = require_device();
   if (st != SFB_OK) return st;
   if (batch == 0) return SFB_OK;
-  const size_t B = (size_t)batch, N = (size_t)n, M = (size_t)m, TR = B * (size_t)trace_rows * 5;
-  const size_t doubles = B * (N * N + N + M * N + 2 * M) + (warm_x ? B * (N + M) : 0) + B * (N + M + 1) + TR;
+  const size_t B = (size_t)batch, N = (size_t)n, M = (size_t)m, TR = B * (size_t)trace_rows * 5, PH = phase_us ? B * 16 : 0;
+  const size_t doubles = B * (N * N + N + M * N + 2 * M) + (warm_x ? B * (N + M) : 0) + B * (N + M + 1) + TR + PH;
   char *mem    = nullptr;
   hipError_t e = hipMalloc(reinterpret_cast<void **>(&mem), doubles * 8 + B * 8);
   if (e != hipSuccess) return hip_fail(e, "hipMalloc");
@@ -805,7 +855,8 @@ sfb_status sfb_qp_dense_solve_batch_host_trace(const sfb_qp_params *prm, int64_t
   double *dwx = nullptr, *dwy = nullptr;
   if (warm_x) { dwx = nx; dwy = dwx + B * N; nx = dwy + B * M; }
   double *dx = nx, *dy = dx + B * N, *dobj = dy + B * M, *dtr = dobj + B;
-  uint32_t *dit  = reinterpret_cast<uint32_t *>(dtr + TR);
+  double *dph    = dtr + TR;
+  uint32_t *dit  = reinterpret_cast<uint32_t *>(dph + PH);
   int32_t *dcode = reinterpret_cast<int32_t *>(dit + B);
   auto H2D = [&](void *d, const void *h, size_t nb) { return hipMemcpy(d, h, nb, hipMemcpyHostToDevice); };
   auto D2H = [&](void *h, const void *d, size_t nb) { return hipMemcpy(h, d, nb, hipMemcpyDeviceToHost); };
@@ -821,7 +872,8 @@ sfb_status sfb_qp_dense_solve_batch_host_trace(const sfb_qp_params *prm, int64_t
       for (size_t r = 0; r < TR; r += 5) init[r] = -1.0;
       if ((e = H2D(dtr, init.data(), TR * 8)) != hipSuccess) break;
     }
-    st = sfb_qp_dense_solve_batch_trace(prm, batch, n, m, dP, dq, dA, dl, du, dwx, dwy, dx, dy, dobj, dit, dcode, TR ? dtr : nullptr, trace_rows, nullptr);
+    st = sfb_qp_dense_solve_batch_phases(prm, batch, n, m, dP, dq, dA, dl, du, dwx, dwy, dx, dy, dobj, dit, dcode, TR ? dtr : nullptr, trace_rows,
+                                         PH ? dph : nullptr, nullptr);
     if (st != SFB_OK) break;
     if ((e = hipDeviceSynchronize()) != hipSuccess) break;
     if ((e = D2H(x, dx, B * N * 8)) != hipSuccess) break;
@@ -830,6 +882,7 @@ sfb_status sfb_qp_dense_solve_batch_host_trace(const sfb_qp_params *prm, int64_t
     if (iter && (e = D2H(iter, dit, B * 4)) != hipSuccess) break;
     if ((e = D2H(code, dcode, B * 4)) != hipSuccess) break;
     if (TR && (e = D2H(trace, dtr, TR * 8)) != hipSuccess) break;
+    if (PH && (e = D2H(phase_us, dph, B * 6 * 8)) != hipSuccess) break;
   } while (false);
   (void)hipFree(mem);
   if (e != hipSuccess) return hip_fail(e, "sfb_qp_dense_solve_batch_host_trace");

@@ -22,6 +22,8 @@ void verbose_report(const char *what, int64_t batch, int n, int m, double h2d_ms
 // ... and, for ONE problem, the per-iteration table itself in the reference's format (:409-420, :490-501): trace = rows x 5
 // (ITER, OBJ, PRI_RES, DUA_RES, TIME us; ITER < 0 ends the table), as written by sfb_sparse_qp_solve_batch_trace.
 void verbose_table(const char *kind, int n, int m, const double *trace, int rows, const char *note = nullptr);
+// ... and its closing summary (:550-565) from the six per-phase times of the *_phases entry points
+void verbose_summary(int32_t code, uint32_t iter, const double *phase_us);
 // rows a table needs for these parameters (capped)
 int verbose_table_rows(const sfb_qp_params *prm);
 // Multi-device entry points (sfb_*_multi): the device list of sfb_set_devices (default: every visible device), and a

@@ -324,7 +324,8 @@ sfb_status solve_batch_impl(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, 
                                      const double *Px, const double *q, const double *Ax, const double *l,
                                      const double *u, const double *warm_x, const double *warm_y, double *x,
                                      double *y, double *obj, uint32_t *iter, int32_t *code, void *workspace,
-                                             const int32_t *order, void *stream, double *trace, int32_t trace_rows)
+                                             const int32_t *order, void *stream, double *trace, int32_t trace_rows,
+                                             double *phase_us = nullptr)
 {
   sfb_status st = check_sparse_args(plan, prm, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, code);
   if (st != SFB_OK) return st;
@@ -342,7 +343,7 @@ sfb_status solve_batch_impl(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, 
   hipError_t e     = sfb::qp_sparse_launch(dc->dev, kp, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code,
                                            reinterpret_cast<double *>(wsc), hs, order, reinterpret_cast<int32_t *>(wsc + L.aux_off),
                                            plan->pruned ? &dc->dev_full : nullptr, reinterpret_cast<double *>(wsc + L.pool_off),
-                                           trace, (int)trace_rows);
+                                           trace, (int)trace_rows, phase_us);
   if (e != hipSuccess) return sfb::hip_fail(e, "qp_sparse_kernel launch");
   return SFB_OK;
 }
@@ -369,6 +370,18 @@ sfb_status sfb_sparse_qp_solve_batch_trace(sfb_sparse_qp_plan *plan, const sfb_q
                           trace, trace_rows);
 }
 
+sfb_status sfb_sparse_qp_solve_batch_phases(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
+                                            const double *Px, const double *q, const double *Ax, const double *l,
+                                            const double *u, const double *warm_x, const double *warm_y, double *x,
+                                            double *y, double *obj, uint32_t *iter, int32_t *code, void *workspace,
+                                            double *trace, int32_t trace_rows, double *phase_us, void *stream)
+{
+  if (!phase_us) return sfb::fail(SFB_ERR_INVALID_ARG, "phase_us is NULL");
+  if (trace != nullptr && trace_rows <= 0) return sfb::fail(SFB_ERR_INVALID_ARG, "trace_rows <= 0");
+  return solve_batch_impl(plan, prm, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code, workspace, nullptr, stream,
+                          trace, trace ? trace_rows : 0, phase_us);
+}
+
 sfb_status sfb_sparse_qp_solve_batch(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
                                      const double *Px, const double *q, const double *Ax, const double *l,
                                      const double *u, const double *warm_x, const double *warm_y, double *x,
@@ -393,15 +406,29 @@ sfb_status sfb_sparse_qp_solve_batch_host_trace(sfb_sparse_qp_plan *plan, const 
                                                 double *y, double *obj, uint32_t *iter, int32_t *code, double *trace,
                                                 int32_t trace_rows)
 {
+  return sfb_sparse_qp_solve_batch_host_phases(plan, prm, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, obj, iter, code, trace,
+                                               trace_rows, nullptr);
+}
+
+sfb_status sfb_sparse_qp_solve_batch_host_phases(sfb_sparse_qp_plan *plan, const sfb_qp_params *prm, int64_t batch,
+                                                 const double *Px, const double *q, const double *Ax, const double *l,
+                                                 const double *u, const double *warm_x, const double *warm_y, double *x,
+                                                 double *y, double *obj, uint32_t *iter, int32_t *code, double *trace,
+                                                 int32_t trace_rows, double *phase_us)
+{
   sfb_status st = check_sparse_args(plan, prm, batch, Px, q, Ax, l, u, warm_x, warm_y, x, y, code);
   if (st == SFB_OK && trace != nullptr && trace_rows <= 0) st = sfb::fail(SFB_ERR_INVALID_ARG, "trace_rows <= 0");
-  // verbose for ONE problem (the reference's use of the flag: one QPSolver object, qp_solver.hpp:409-420, :490-501): the
-  // per-iteration table is collected on the device and printed below
-  std::vector<double> vtrace;
+  // verbose for ONE problem (the reference's use of the flag: one QPSolver object, qp_solver.hpp:409-420, :490-501, :550-565):
+  // the per-iteration table and the per-phase times are collected on the device and printed below
+  std::vector<double> vtrace, vphase;
   if (st == SFB_OK && prm->verbose && batch == 1 && trace == nullptr) {
     trace_rows = sfb::verbose_table_rows(prm);
     vtrace.assign((size_t)trace_rows * 5, 0.0);
     trace = vtrace.data();
+  }
+  if (st == SFB_OK && prm->verbose && batch == 1 && phase_us == nullptr) {
+    vphase.assign(6, 0.0);
+    phase_us = vphase.data();
   }
   if (st != SFB_OK) return st;
   st = sfb::require_device();
@@ -410,7 +437,8 @@ sfb_status sfb_sparse_qp_solve_batch_host_trace(sfb_sparse_qp_plan *plan, const 
   const sfb::SparsePlanHost &h = sfb::plan_io(plan);  // the caller's pattern (strides of the value arrays)
   const size_t B = (size_t)batch, N = (size_t)h.n, M = (size_t)h.m, NP = (size_t)h.nnzP, NA = (size_t)h.nnzA;
   const size_t wsb  = ws_layout(plan, batch).total;  // multiple of 8
-  const size_t TR = trace ? B * (size_t)trace_rows * 5 : 0;
+  const size_t TR = (trace ? B * (size_t)trace_rows * 5 : 0) + (phase_us ? B * 6 : 0);  // the table, then the phase times
+  const size_t TR0 = trace ? B * (size_t)trace_rows * 5 : 0;
   const size_t in_d = B * (NP + N + NA + 2 * M) + (warm_x ? B * (N + M) : 0), out_d = B * (N + M + 1) + TR;
   const size_t bytes = (in_d + out_d) * sizeof(double) + wsb + B * 8;
   int devid    = 0;
@@ -470,12 +498,12 @@ sfb_status sfb_sparse_qp_solve_batch_host_trace(sfb_sparse_qp_plan *plan, const 
       if ((e = H2D(dwy, warm_y, B * M * 8)) != hipSuccess) break;
     }
     if (trace) {  // unused rows keep ITER = -1
-      for (size_t r = 0; r < TR; ++r) trace[r] = (r % 5 == 0) ? -1.0 : 0.0;
-      if ((e = H2D(dtrace, trace, TR * 8)) != hipSuccess) break;
+      for (size_t r = 0; r < TR0; ++r) trace[r] = (r % 5 == 0) ? -1.0 : 0.0;
+      if ((e = H2D(dtrace, trace, TR0 * 8)) != hipSuccess) break;
     }
     tv1 = clk::now();
     st = solve_batch_impl(plan, prm, batch, dPx, dq, dAx, dl, du, dwx, dwy, dx, dy, dobj, dit, dcode, dws, nullptr, nullptr,
-                          trace ? dtrace : nullptr, trace_rows);
+                          trace ? dtrace : nullptr, trace ? trace_rows : 0, phase_us ? dtrace + TR0 : nullptr);
     if (st != SFB_OK) break;
     if ((e = hipDeviceSynchronize()) != hipSuccess) break;
     tv2 = clk::now();
@@ -484,11 +512,18 @@ sfb_status sfb_sparse_qp_solve_batch_host_trace(sfb_sparse_qp_plan *plan, const 
     if (obj && (e = D2H(obj, dobj, B * 8)) != hipSuccess) break;
     if (iter && (e = D2H(iter, dit, B * 4)) != hipSuccess) break;
     if ((e = D2H(code, dcode, B * 4)) != hipSuccess) break;
-    if (trace && (e = D2H(trace, dtrace, TR * 8)) != hipSuccess) break;
+    if (trace && (e = D2H(trace, dtrace, TR0 * 8)) != hipSuccess) break;
+    if (phase_us && (e = D2H(phase_us, dtrace + TR0, B * 6 * 8)) != hipSuccess) break;
   } while (false);
   if (e != hipSuccess) st = sfb::hip_fail(e, "sfb_sparse_qp_solve_batch_host");
   if (st == SFB_OK && !vtrace.empty()) {  // the table of qp_solver.hpp:409-420, :490-501 (TIME: device clock, microseconds)
     sfb::verbose_table("sparse", h.n, h.m, vtrace.data(), trace_rows);
+  }
+  if (st == SFB_OK && !vphase.empty()) {  // the summary of qp_solver.hpp:550-565
+    uint32_t it1 = 0;
+    if (iter) it1 = iter[0];
+    else if (hipMemcpy(&it1, dit, 4, hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError();
+    sfb::verbose_summary(code[0], it1, vphase.data());
   }
   if (st == SFB_OK && prm->verbose) {
     std::vector<uint32_t> itv;

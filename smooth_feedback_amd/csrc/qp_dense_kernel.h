@@ -52,7 +52,10 @@ size_t qp_dense_mid_ws_bytes(const DenseKernelParams &kp, int64_t batch);
 hipError_t qp_dense_mid_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream, void *workspace = nullptr);
 // the same solve through the TRACE instance (one block per QP, any n + m <= 128): a row (ITER, OBJ, PRI_RES, DUA_RES, TIME us) of the
 // reference's verbose table per stopping check into trace [batch][trace_cap][5] (device memory, rows preset by the caller)
-hipError_t qp_dense_mid_trace_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream, double *trace, int trace_cap);
+// phase_us (device, nullable): batch x 6 per-phase microseconds (sfb.h, sfb_qp_dense_solve_batch_phases) FOLLOWED by batch x 10
+// doubles of scratch for the kernel's stamps -- the caller allocates batch x 16 doubles
+hipError_t qp_dense_mid_trace_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream, double *trace, int trace_cap,
+                                     double *phase_us = nullptr);
 bool qp_dense_mid_enabled();  // SFB_QP_MID=0 (A/B, tests): the kernels these sizes had before
 
 hipError_t qp_dense_launch(const DenseKernelParams &kp, int64_t batch, const double *P, const double *q,

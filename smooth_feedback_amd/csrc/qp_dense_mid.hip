@@ -51,11 +51,14 @@ __device__ __forceinline__ int muni(const int v) { return __builtin_amdgcn_readf
 __device__ __forceinline__ bool mfinite(const double v) { return fabs(v) < INFINITY; }
 
 // profiling build (scripts/r4/build_variant.sh prof qp_dense_mid.hip -DSFB_MID_PROF): block 0 prints where its time went
+// Stamps at the phase boundaries of a solve.  C.stamps (nullptr outside the TRACE instance: the branch folds away at compile
+// time, everything is inlined) receives the wall clock at points 0 .. 9 -- the per-phase times of the reference's verbose
+// summary as data (qp_solver.hpp:550-565; sfb_qp_dense_solve_batch_phases).
 #ifdef SFB_MID_PROF
 __device__ unsigned long long g_midprof[12];
-#define MP_T(i) g_midprof[i] = wall_clock64()
+#define MP_T(i) { g_midprof[i] = wall_clock64(); if (C.stamps != nullptr && C.lane == 0) C.stamps[i] = (double)wall_clock64(); }
 #else
-#define MP_T(i)
+#define MP_T(i) { if (C.stamps != nullptr && C.lane == 0) C.stamps[i] = (double)wall_clock64(); }
 #endif
 
 // waves per SIMD the k <= 48 / k <= 64 instances are compiled for (VGPR budget 168 at 3, 256 at 2)
@@ -595,6 +598,7 @@ struct MidC {
   double *ox, *oy, *oobj;
   uint32_t *oiter;
   int32_t *ocode;
+  double *stamps;  // TRACE instance: ten wall-clock stamps of this QP (see MP_T), else nullptr
 };
 __device__ __forceinline__ MidC mid_context(double *sm, const DenseKernelParams &kp, const QpBatch &g, const size_t b, const int lane)
 {
@@ -613,6 +617,7 @@ __device__ __forceinline__ MidC mid_context(double *sm, const DenseKernelParams 
   C.oobj  = g.obj ? g.obj + b : nullptr;
   C.oiter = g.iter ? g.iter + b : nullptr;
   C.ocode = g.code + b;
+  C.stamps = nullptr;
   return C;
 }
 
@@ -1303,24 +1308,45 @@ __global__ void __launch_bounds__(64, WPE) qp_dense_mid_kernel(const DenseKernel
 // TRACE instance of the fused launch (sfb_qp_dense_solve_batch_trace; verbose on one problem): the same solve, one block per QP
 // whatever the batch size, with a row of the reference's verbose table written per stopping check (trace [batch][cap][5], rows
 // beyond cap dropped).  Serves every n + m <= 16 NB (the NB = 3 instance also the sizes the four-per-wave kernel normally takes).
+// phase_us (nullable, [batch][6] + 10 doubles of scratch per QP behind them, see qp_dense_mid_trace_launch): the per-phase
+// microseconds of the reference's summary (:550-565) -- scaling and pre-check | matrix filling (pivot order, zero, fill) |
+// factorization | iteration | polish | un-scale and report.
 template<int NB, int WPE>
 __global__ void __launch_bounds__(64, WPE) qp_dense_mid_trace_kernel(const DenseKernelParams kp, const QpBatch g, double *__restrict__ trace,
-                                                                     const int trace_cap)
+                                                                     const int trace_cap, double *__restrict__ phase_us)
 {
   constexpr int R = NB > 4 ? 2 : 1;
   constexpr int kFillU = NB > 4 ? 16 : 8;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int lane = threadIdx.x;
-  const MidC C   = mid_context(sm, kp, g, blockIdx.x, lane);
+  MidC C   = mid_context(sm, kp, g, blockIdx.x, lane);
+  C.stamps = phase_us ? phase_us + (size_t)gridDim.x * 6 + (size_t)blockIdx.x * 10 : nullptr;
   MidRow h[R];
   double c = 1.0;
   unsigned long long t0_ticks = 0;
+  MP_T(0);
   int ret_code      = mid_setup<R, kFillU>(C, kp, h, c, t0_ticks);
   uint32_t iter     = 0;
   uint32_t next_chk = (kp.stop_check_iter >= 2) ? 1u : 0xFFFFFFFFu;
+  MP_T(6);
   mid_admm<NB, R, false, true>(C, kp, h, c, iter, next_chk, ret_code, t0_ticks, 0, nullptr, nullptr, nullptr, 0,
                                trace ? trace + (size_t)blockIdx.x * (size_t)trace_cap * 5 : nullptr, trace_cap, (lds_d *)(sm + mid_layout(kp.n, kp.m).total));
+  MP_T(7);
   mid_finish<R, NB, kFillU>(C, kp, h, c, ret_code, iter);
+  if (phase_us != nullptr) {
+    __syncthreads();
+    MP_T(9);
+    if (lane == 0) {  // (lane 0 wrote the stamps itself)
+      const double *st = C.stamps;
+      double *o = phase_us + (size_t)blockIdx.x * 6;
+      o[0] = (st[2] - st[0]) * 0.01;  // 100 MHz wall clock -> microseconds
+      o[1] = (st[4] - st[2]) * 0.01;
+      o[2] = (st[5] - st[4]) * 0.01;
+      o[3] = (st[7] - st[5]) * 0.01;
+      o[4] = (st[8] - st[7]) * 0.01;
+      o[5] = (st[9] - st[8]) * 0.01;
+    }
+  }
 }
 
 // SPLIT launch for batches larger than the chip: setup (one QP per workgroup) -> records; loop (persistent, time-sliced);
@@ -1461,6 +1487,7 @@ struct MidLaunch {
   hipStream_t stream;
   double *trace = nullptr;
   int trace_cap = 0;
+  double *phase_us = nullptr;
 };
 template<int NBV>
 hipError_t mid_launch_nb(const DenseKernelParams &kp, const QpBatch &g, const size_t lds, const MidLaunch &a)
@@ -1486,7 +1513,7 @@ hipError_t mid_launch_nb(const DenseKernelParams &kp, const QpBatch &g, const si
     case MID_FINISH: hipLaunchKernelGGL((qp_dense_mid_finish_kernel<NBV, WO>), dim3(a.grid), dim3(kWave), lds, a.stream, kp, g, a.ws, a.wsd); break;
     case MID_TRACE:
       hipLaunchKernelGGL((qp_dense_mid_trace_kernel<NBV, WO>), dim3(a.grid), dim3(kWave), lds + (size_t)kp.n * sizeof(double), a.stream, kp, g, a.trace,
-                         a.trace_cap);
+                         a.trace_cap, a.phase_us);
       break;
   }
   return hipGetLastError();
@@ -1535,13 +1562,15 @@ size_t qp_dense_mid_ws_bytes(const DenseKernelParams &kp, int64_t batch)
   return (size_t)batch * mid_save_doubles(kp.n, kp.m) * sizeof(double) + 256 + 2 * (size_t)batch * sizeof(unsigned long long);
 }
 
-hipError_t qp_dense_mid_trace_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream, double *trace, int trace_cap)
+hipError_t qp_dense_mid_trace_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream, double *trace, int trace_cap,
+                                     double *phase_us)
 {
   const int k = kp.n + kp.m;
   if (k > kDenseMidMaxK || k < 1) return hipErrorInvalidValue;
   MidLaunch a{MID_TRACE, (unsigned)batch, (unsigned)batch, nullptr, 0, nullptr, 0, nullptr, stream};
   a.trace     = trace;
   a.trace_cap = trace_cap;
+  a.phase_us  = phase_us;
   return mid_launch(kp, g, a);
 }
 

@@ -319,8 +319,19 @@ __device__ __forceinline__ void ldl_sweep_copies(const SparsePlanDev &pl, const 
 typedef int vint4u __attribute__((ext_vector_type(4)));
 template<int DEPTH>
 __device__ inline int ldl_numeric_units(const SparsePlanDev &pl, const Item &it, const Ws &w, double *t, const int mode,
-                                        const double c, const double sigma, const double delta, const int lane)
+                                        const double c, const double sigma, const double delta, const int lane,
+                                        unsigned long long *fill_ticks = nullptr)
 {
+  // fill_ticks (TRACE instance: "Matrix filling" of the reference's summary, qp_solver.hpp:560): wall-clock ticks spent
+  // bringing KKT entries and accumulators into place, as opposed to the units, the returns and the sweep copies
+  unsigned long long fclk = fill_ticks ? wall_clock64() : 0ull;
+  auto fill_lap = [&](const bool is_fill) {
+    if (fill_ticks) {
+      const unsigned long long now = wall_clock64();
+      if (is_fill) *fill_ticks += now - fclk;
+      fclk = now;
+    }
+  };
   const int nnzL = uni(pl.nnzL);
 #ifdef SFB_PROF_LDL
   unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, pc = __builtin_amdgcn_s_memtime();
@@ -337,6 +348,7 @@ __device__ inline int ldl_numeric_units(const SparsePlanDev &pl, const Item &it,
   kkt_fill<4>(pl.KdescT, pl.KmapT, 0, uni(pl.nnzKT), it, w, ACC, mode, c, sigma, delta, lane);
   wave_sync();
   SFB_ULAP(0)
+  fill_lap(true);
   const vint4u *__restrict__ stream = reinterpret_cast<const vint4u *>(pl.ustream);
   auto at = [&](const unsigned off) -> double & { return *reinterpret_cast<double *>(reinterpret_cast<char *>(t) + off); };
   bool zero_pivot = false;
@@ -379,6 +391,7 @@ __device__ inline int ldl_numeric_units(const SparsePlanDev &pl, const Item &it,
     if (lane < 3) t[sink + lane] = (lane == 2) ? 1.0 : 0.0;  // sink, zero, one: operands of the padding slots
     wave_lds_fence();
     SFB_ULAP(1)
+    fill_lap(true);
     // ---- units ----
     // The stream is fetched in BLOCKS of DEPTH units, two register sets taking turns: all loads of block b + 1 are requested
     // when block b begins, so that they have a whole block's time (DEPTH dependent LDS round trips) to arrive -- the
@@ -444,6 +457,7 @@ __device__ inline int ldl_numeric_units(const SparsePlanDev &pl, const Item &it,
     }
     wave_sync();  // the workspace is up to date before a later segment fetches from it (and t is free again)
     SFB_ULAP(3)
+    fill_lap(false);
   }
   if (wave_ballot(zero_pivot)) return 0;
   ldl_sweep_copies<DEPTH>(pl, w, lane);
@@ -477,9 +491,18 @@ __device__ inline int ldl_numeric_units(const SparsePlanDev &pl, const Item &it,
 // t = LDS of pl.lds_doubles doubles.  Returns 1 / 0 (zero pivot).
 template<int DEPTH>
 __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, const Ws &w, double *t, const int mode,
-                                      const double c, const double sigma, const double delta, const int lane)
+                                      const double c, const double sigma, const double delta, const int lane,
+                                      unsigned long long *fill_ticks = nullptr)
 {
-  if (uni(pl.units)) return ldl_numeric_units<DEPTH>(pl, it, w, t, mode, c, sigma, delta, lane);
+  if (uni(pl.units)) return ldl_numeric_units<DEPTH>(pl, it, w, t, mode, c, sigma, delta, lane, fill_ticks);
+  unsigned long long fclk = fill_ticks ? wall_clock64() : 0ull;  // (see ldl_numeric_units)
+  auto fill_lap = [&](const bool is_fill) {
+    if (fill_ticks) {
+      const unsigned long long now = wall_clock64();
+      if (is_fill) *fill_ticks += now - fclk;
+      fclk = now;
+    }
+  };
   const int k = uni(pl.k), nnzL = uni(pl.nnzL);
 #ifdef SFB_PROF_LDL
   unsigned long long pt[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pc = __builtin_amdgcn_s_memtime();
@@ -497,9 +520,11 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
   kkt_fill<4>(pl.KdescT, pl.KmapT, 0, uni(pl.nnzKT), it, w, ACC, mode, c, sigma, delta, lane);
   wave_sync();
   SFB_LAP(0)
+  fill_lap(true);
   for (int sg = 0, nseg = uni(pl.nseg); sg < nseg; ++sg) {
     const int32_t *sgp = pl.seg + 12 * sg;
     const int sn0 = uni(sgp[0]), sn1 = uni(sgp[1]), on_chip = uni(sgp[4]);
+    fill_lap(false);
     if (on_chip) {
       // ---------------- LDS segment ----------------
       const int accN = uni(sgp[6]), kp0 = uni(sgp[7]), kp1 = uni(sgp[8]), nLs = uni(sgp[5]);
@@ -511,6 +536,7 @@ __device__ inline int ldl_numeric_dev(const SparsePlanDev &pl, const Item &it, c
       kkt_fill<4>(pl.Kdesc, pl.KmapL, kp0, kp1, it, w, t, mode, c, sigma, delta, lane);
       wave_lds_fence();
       SFB_LAP(1)
+      fill_lap(true);
       // Supernodes of the segment.  Software pipeline over the supernodes: while one is being eliminated, the panel
       // map of the next is on its way from the L2, and the first block of accumulators OUTSIDE the subtree that
       // this supernode updates (they do not depend on its panel) is on its way from HBM.
@@ -1462,7 +1488,7 @@ __device__ __forceinline__ void sp_rows_chain(double (&acc)[RB], const int i0, c
 
 template<int SD>
 __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const Ws &w, const Ws &wf, const DenseKernelParams &kp,
-                                 double *t, const double c, const int lane, const bool lean)
+                                 double *t, const double c, const int lane, const bool lean)  // (its fill + factorisation count as "Polish", qp_solver.hpp:563)
 {
   const int n = uni(pl.n), m = uni(pl.m), k = uni(pl.k);
   const double inf = INFINITY, eps = DBL_EPSILON;
@@ -1613,8 +1639,21 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
                                              bool lean, const size_t b, const size_t slot, double *t, const int lane,
                                              bool resume, const int32_t *queue, const int batch,
                                              const uint32_t slice, const bool allow_reuse, const int phases, float *score,
-                                             double *trace = nullptr, const int trace_cap = 0)
+                                             double *trace = nullptr, const int trace_cap = 0, double *phase_us = nullptr)
 {
+  // phase_us (TRACE instance, nullable): six doubles per item, microseconds of the device's wall clock -- scaling and
+  // pre-check (before the reference's t0, qp_solver.hpp:376), then its summary (:559-563) "Matrix filling", "Factorization",
+  // "Iteration", "Polish", and un-scale / report.  Their sum is the time the item held its wave.
+  [[maybe_unused]] unsigned long long ph_clk = 0, ph_fill = 0;
+  [[maybe_unused]] unsigned long long ph_t[6] = {0, 0, 0, 0, 0, 0};
+  [[maybe_unused]] auto phase_lap = [&](const int i) {
+    if constexpr (TRACE) {
+      const unsigned long long now = wall_clock64();
+      ph_t[i] += now - ph_clk;
+      ph_clk = now;
+    }
+  };
+  if constexpr (TRACE) ph_clk = wall_clock64();
   const int ph0 = phases & 15, ph1 = (phases >> 4) & 15;  // the phases this launch performs
   const uint32_t pause_at = (uint32_t)phases >> 8;        // != 0: leave the ADMM loop open at the first check from here on
   const int n = uni(pl.n), m = uni(pl.m), k = uni(pl.k);
@@ -1846,9 +1885,10 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
   wave_sync();
 
   // ---- KKT fill + numeric factorisation :379-433 ----
+  phase_lap(0);
   if (!keep_factor) {
     if (lane == 0) w.hdr[kHdrStamp] = 0.0;  // until the new factor is complete
-    if (!ldl_numeric_dev<8>(pl, it, w, t, 0, c, kp.sigma, kp.delta, lane)) {
+    if (!ldl_numeric_dev<8>(pl, it, w, t, 0, c, kp.sigma, kp.delta, lane, TRACE ? &ph_fill : nullptr)) {
       ret_code = SFB_QP_UNKNOWN;
       // Dinv of the remaining columns is never used: the loop below does not run
     } else if (lane == 0 && allow_reuse) {  // (a slot that is not the item's own -- ordered launch, pool -- stays unstamped)
@@ -1859,6 +1899,11 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     }
   }
 
+  if constexpr (TRACE) {  // the factorisation's time, split into filling and the rest
+    phase_lap(2);
+    ph_t[1] = ph_fill;
+    ph_t[2] -= ph_fill;
+  }
 #ifdef SFB_SP_TIMELINE
   tl1 = wall_clock64();
 #endif
@@ -2180,6 +2225,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
 #ifdef SFB_SP_TIMELINE
   if (ph0 == PH_FINISH) tl2 = (unsigned long long)w.hdr[kHdrTl2];
 #endif
+  phase_lap(3);
   // ---- polish :515-539 ----
   if (ret_code == SFB_QP_OPTIMAL && kp.polish) {
     if (kp.reuse != 0 && allow_reuse) {  // keep the ADMM factor for the next call: the polish system goes to the second block
@@ -2193,6 +2239,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     }
   }
 
+  phase_lap(4);
   // ---- un-scale and report :544-548 ----
   double *ox = gx + b * (size_t)n, *oy = gy + b * (size_t)m;
   for (int j = lane; j < n; j += kWave) {
@@ -2256,6 +2303,12 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     oy[0] = (double)tl0; oy[1] = (double)tl1; oy[2] = (double)tl2; oy[3] = (double)wall_clock64();
 #endif
   }
+  if constexpr (TRACE) {
+    wave_sync();  // (the report's stores are on their way: the lap below ends the item's time in the wave)
+    phase_lap(5);
+    if (phase_us != nullptr && lane == 0)
+      for (int i = 0; i < 6; ++i) phase_us[b * 6 + i] = (double)ph_t[i] * 0.01;  // 100 MHz wall clock
+  }
   return SP_DONE;
 }
 
@@ -2279,7 +2332,8 @@ __global__ void __launch_bounds__(64, (LAT || TRACE) ? 2 : 3) qp_sparse_kernel(c
                                                        const SparsePlanDev *__restrict__ plf, double *__restrict__ gwsf,
                                                        const size_t wsf_doubles, int32_t *__restrict__ fbflags, const int phases, const int nfb,
                                                        float *__restrict__ keys, const int32_t *__restrict__ nfresh_dev,
-                                                       const int mode_sel, double *__restrict__ trace, const int trace_cap)
+                                                       const int mode_sel, double *__restrict__ trace, const int trace_cap,
+                                                       double *__restrict__ phase_us)
 {
   // keys (nullable): per item, the predictor score of a paused item (SP_PAUSED) or -1 (nothing left to do for the next launch)
   // nfresh_dev (nullable): the fresh items of this launch are order[0 .. *nfresh_dev - 1] (the survivors of the previous one)
@@ -2355,7 +2409,7 @@ __global__ void __launch_bounds__(64, (LAT || TRACE) ? 2 : 3) qp_sparse_kernel(c
     const int st = sp_solve_item<LAT, TRACE>(*use, kp, gPx, gq, gAx, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode, wsb, wsd, lean_waves_item,
                                  lean, (size_t)item, slot, t, lane, resume != 0, fbslot >= 0 ? nullptr : queue, nfresh, slice,
                                  /*allow_reuse: the item's own slot of the main workspace*/ fbslot < 0 && slot == (size_t)item,
-                                 fbslot >= 0 ? PH_EVERYTHING : phases, keys ? keys + item : nullptr, trace, trace_cap);
+                                 fbslot >= 0 ? PH_EVERYTHING : phases, keys ? keys + item : nullptr, trace, trace_cap, phase_us);
     if (keys != nullptr && st != SP_PAUSED && lane == 0) keys[item] = -1.0f;
     if (fbslot >= 0 && phases != PH_EVERYTHING && lane == 0)  // tell the later launches (the item's own slot is otherwise unused)
       carve_ws(gws + (size_t)item * ws_doubles, uni(plp->n), uni(plp->m), uni(plp->nnzL), uni(plp->funits), uni(plp->bunits)).hdr[kHdrComplete] = 1.0;
@@ -2480,7 +2534,7 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
                             const double *q, const double *Ax, const double *l, const double *u, const double *wx,
                             const double *wy, double *x, double *y, double *obj, uint32_t *iter, int32_t *code,
                             double *workspace, hipStream_t stream, const int32_t *order, int32_t *aux,
-                            const SparsePlanDev *fallback, double *fallback_ws, double *trace, int trace_cap)
+                            const SparsePlanDev *fallback, double *fallback_ws, double *trace, int trace_cap, double *phase_us)
 {
   if (pl.Aorig != nullptr && (fallback == nullptr || fallback_ws == nullptr || aux == nullptr)) return hipErrorInvalidValue;
   const bool pruned = pl.Aorig != nullptr;
@@ -2527,17 +2581,17 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
       hipError_t e = hipMemsetAsync(aux, 0, sparse_aux_queue_ints(batch) * sizeof(int32_t), stream);
       if (e != hipSuccess) return e;
     }
-    auto *kern = trace ? qp_sparse_kernel<false, true> : (lat ? qp_sparse_kernel<true> : qp_sparse_kernel<false>);
+    auto *kern = (trace || phase_us) ? qp_sparse_kernel<false, true> : (lat ? qp_sparse_kernel<true> : qp_sparse_kernel<false>);
     hipLaunchKernelGGL(kern, dim3(g), dim3(kWave), lat ? lds_lat : lds, stream, pl.self, kp, Px, q, Ax, l, u, wx, wy, x, y, obj, iter,
                        code, workspace, wsd, lw, ord, qa, (int)batch, slc ? slc : (uint32_t)std::max(1, slice),
                        pruned ? fallback->self : nullptr, fallback_ws, pruned ? qp_sparse_ws_doubles(*fallback) : 0,
                        aux ? aux + batch + kQRing : nullptr, phases, (int)std::min<int64_t>(batch, kFbSlots), keys, nfresh, mode_sel,
-                       trace, trace_cap);
+                       trace, trace_cap, phase_us);
     return hipGetLastError();
   };
   // TRACE (sfb_sparse_qp_solve_batch_trace): one block per item whatever the batch size -- the row count of an item's table
   // lives in its wave -- through the TRACE instance of the kernel; same arithmetic, same results.
-  if (trace != nullptr) return launch((unsigned)batch, nullptr, lean_waves, PH_EVERYTHING, order);
+  if (trace != nullptr || phase_us != nullptr) return launch((unsigned)batch, nullptr, lean_waves, PH_EVERYTHING, order);
   // LAUNCH IN PREDICTED ORDER (time-sliced launches, default; SFB_SP_PREDICT=0 turns it off).  ADMM iteration counts are
   // heavy-tailed (headline batch: mean 88, p99 627, max 1 152) and a wave alone needs 22-27 us per iteration, so the
   // longest items set the time of a launch unless they START first -- and what identifies them is cheap: the ratio of

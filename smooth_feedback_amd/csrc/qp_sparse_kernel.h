@@ -85,12 +85,15 @@ inline size_t qp_sparse_ws_doubles(const SparsePlanDev &pl)
 //   trace (device, batch x trace_cap x 5 doubles, nullable): the reference's verbose table as data -- per item one row
 //   (ITER, OBJ, PRI_RES, DUA_RES, TIME us) per stopping check, rows beyond trace_cap are dropped; the caller presets
 //   ITER = -1.  Forces one block per item (no time slicing).
+//   phase_us (device, batch x 6 doubles, nullable): per item the microseconds of scaling + pre-check | matrix filling |
+//   factorisation | iteration | polish | un-scale and report (the reference's summary, qp_solver.hpp:559-563, as data); also
+//   through the TRACE instance of the kernel.
 hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp, int64_t batch, const double *Px,
                             const double *q, const double *Ax, const double *l, const double *u, const double *wx,
                             const double *wy, double *x, double *y, double *obj, uint32_t *iter, int32_t *code,
                             double *workspace, hipStream_t stream, const int32_t *order = nullptr, int32_t *aux = nullptr,
                             const SparsePlanDev *fallback = nullptr, double *fallback_ws = nullptr,
-                            double *trace = nullptr, int trace_cap = 0);
+                            double *trace = nullptr, int trace_cap = 0, double *phase_us = nullptr);
 size_t qp_sparse_aux_bytes(int64_t batch);
 int qp_sparse_fallback_slots();
 

@@ -93,6 +93,7 @@ class QPBatchSolution:
     dual: np.ndarray
     objective: np.ndarray
     trace: Optional[np.ndarray] = None  # (B, rows, 5): ITER, OBJ, PRI_RES, DUA_RES, TIME [us] per stopping check (ITER -1: unused)
+    phase_us: Optional[np.ndarray] = None  # (B, 6): scaling | matrix filling | factorization | iteration | polish | report [us]
 
 
 def _f64(a, shape):
@@ -113,7 +114,7 @@ def pack_colmajor(M):
 
 
 def solve_qp_batch_host(P, q, A, l, u, prm: Optional[QPSolverParams] = None, warm_x=None, warm_y=None, multi_device=False,
-                        trace_rows=0):
+                        trace_rows=0, phases=False):
     """Batched solve_qp on host numpy buffers.  P (B, n*n) and A (B, m*n) are COLUMN-major flat
     buffers (see pack_colmajor), q (B,n), l,u (B,m).  Calls sfb_qp_dense_solve_batch_host, or with multi_device the
     variant that shards the batch over the device list (_capi.set_devices).  trace_rows > 0 (n + m <= 128): the
@@ -138,14 +139,15 @@ def solve_qp_batch_host(P, q, A, l, u, prm: Optional[QPSolverParams] = None, war
     it = np.empty(B, dtype=np.uint32)
     code = np.empty(B, dtype=np.int32)
     cp = (prm or QPSolverParams()).to_c()
-    if trace_rows:
+    if trace_rows or phases:  # phases: the per-phase times of qp_solver.hpp:550-565 as data in `.phase_us` (n + m <= 128)
         if multi_device:
-            raise ValueError("trace_rows and multi_device exclude each other")
-        trace = np.empty((B, int(trace_rows), 5))
-        _capi.check(_capi.lib.sfb_qp_dense_solve_batch_host_trace(
+            raise ValueError("trace_rows / phases and multi_device exclude each other")
+        trace = np.empty((B, int(trace_rows), 5)) if trace_rows else None
+        ph = np.zeros((B, 6)) if phases else None
+        _capi.check(_capi.lib.sfb_qp_dense_solve_batch_host_phases(
             C.byref(cp), B, n, m, _ptr(P), _ptr(q), _ptr(A), _ptr(l), _ptr(u), _ptr(warm_x), _ptr(warm_y),
-            _ptr(x), _ptr(y), _ptr(obj), _ptr(it), _ptr(code), _ptr(trace), int(trace_rows)))
-        return QPBatchSolution(code=code, iter=it, primal=x, dual=y, objective=obj, trace=trace)
+            _ptr(x), _ptr(y), _ptr(obj), _ptr(it), _ptr(code), _ptr(trace), int(trace_rows), _ptr(ph)))
+        return QPBatchSolution(code=code, iter=it, primal=x, dual=y, objective=obj, trace=trace, phase_us=ph)
     fn = _capi.lib.sfb_qp_dense_solve_batch_host_multi if multi_device else _capi.lib.sfb_qp_dense_solve_batch_host
     _capi.check(fn(
         C.byref(cp), B, n, m, _ptr(P), _ptr(q), _ptr(A), _ptr(l), _ptr(u), _ptr(warm_x), _ptr(warm_y),
@@ -347,7 +349,7 @@ class SparseQPPlan:
             pass
 
     def solve_batch_host(self, Px, q, Ax, l, u, prm: Optional[QPSolverParams] = None, warm_x=None, warm_y=None,
-                         multi_device=False, trace_rows=0):
+                         multi_device=False, trace_rows=0, phases=False):
         """sfb_sparse_qp_solve_batch_host[_multi | _trace]: Px (B, nnzP), q (B, n), Ax (B, nnzA), l,u (B, m).
         trace_rows > 0: the reference's verbose table (qp_solver.hpp:490-501) as data in `.trace`."""
         q = np.ascontiguousarray(q, dtype=np.float64)
@@ -362,14 +364,15 @@ class SparseQPPlan:
         x = np.empty((B, self.n)); y = np.empty((B, self.m)); obj = np.empty(B)
         it = np.empty(B, dtype=np.uint32); code = np.empty(B, dtype=np.int32)
         cp = (prm or QPSolverParams()).to_c()
-        if trace_rows:
+        if trace_rows or phases:  # phases: the per-phase times of qp_solver.hpp:550-565 as data in `.phase_us`
             if multi_device:
-                raise ValueError("trace_rows and multi_device exclude each other")
-            trace = np.empty((B, int(trace_rows), 5))
-            _capi.check(_capi.lib.sfb_sparse_qp_solve_batch_host_trace(
+                raise ValueError("trace_rows / phases and multi_device exclude each other")
+            trace = np.empty((B, int(trace_rows), 5)) if trace_rows else None
+            ph = np.zeros((B, 6)) if phases else None
+            _capi.check(_capi.lib.sfb_sparse_qp_solve_batch_host_phases(
                 self._h, C.byref(cp), B, _ptr(Px), _ptr(q), _ptr(Ax), _ptr(l), _ptr(u), _ptr(warm_x), _ptr(warm_y),
-                _ptr(x), _ptr(y), _ptr(obj), _ptr(it), _ptr(code), _ptr(trace), int(trace_rows)))
-            return QPBatchSolution(code=code, iter=it, primal=x, dual=y, objective=obj, trace=trace)
+                _ptr(x), _ptr(y), _ptr(obj), _ptr(it), _ptr(code), _ptr(trace), int(trace_rows), _ptr(ph)))
+            return QPBatchSolution(code=code, iter=it, primal=x, dual=y, objective=obj, trace=trace, phase_us=ph)
         fn = _capi.lib.sfb_sparse_qp_solve_batch_host_multi if multi_device else _capi.lib.sfb_sparse_qp_solve_batch_host
         _capi.check(fn(
             self._h, C.byref(cp), B, _ptr(Px), _ptr(q), _ptr(Ax), _ptr(l), _ptr(u), _ptr(warm_x), _ptr(warm_y),
@@ -384,6 +387,16 @@ class SparseQPPlan:
         _capi.check(_capi.lib.sfb_sparse_qp_solve_batch_ordered(
             self._h, C.byref(cp), B, dPx, dq, dAx, dl, du, dwarm_x or None, dwarm_y or None, dx, dy,
             dobj or None, diter or None, dcode, dworkspace, dorder or None, stream or None))
+
+
+    def solve_batch_device_phases(self, B, dPx, dq, dAx, dl, du, dx, dy, dobj, diter, dcode, dworkspace, dphase_us, prm=None,
+                                  dwarm_x=0, dwarm_y=0, stream=0, dtrace=0, trace_rows=0):
+        """sfb_sparse_qp_solve_batch_phases on device pointers: the same solve through the TRACE instance of the kernel (one
+        wave per item), with the per-phase microseconds of qp_solver.hpp:550-565 in dphase_us (B x 6 doubles)."""
+        cp = (prm or QPSolverParams()).to_c()
+        _capi.check(_capi.lib.sfb_sparse_qp_solve_batch_phases(
+            self._h, C.byref(cp), B, dPx, dq, dAx, dl, du, dwarm_x or None, dwarm_y or None, dx, dy,
+            dobj or None, diter or None, dcode, dworkspace, dtrace or None, int(trace_rows), dphase_us, stream or None))
 
 
 def solve_qp_sparse(pbm: QuadraticProgramSparse, prm: Optional[QPSolverParams] = None,

@@ -591,3 +591,38 @@ def test_verbose_single_dense_problem_table_is_the_solves_own(sfb, oracle, capfd
         assert int(it) == int(row[0])
         for v, e in zip(vals, row[1:4]):
             assert v == float("%.6e" % e)
+
+
+@pytest.mark.parametrize("n,m,B", [(10, 20, 96), (20, 40, 64), (40, 60, 32)])
+def test_dense_phase_times_as_data(sfb, n, m, B):
+    """qp_solver.hpp:550-565 as data for dense problems with n + m <= 128 (TRACE instance of the on-chip kernel): same results
+    as the plain call, six non-negative times per problem; with the table, their first four reach past its last TIME stamp."""
+    P, q, A, l, u = sfb.random_qp_batch(8, B, m, n, 1.0)
+    prm = sfb.QPSolverParams(max_iter=1000)
+    plain = sfb.solve_qp_batch_host(P, q, A, l, u, prm)
+    r = sfb.solve_qp_batch_host(P, q, A, l, u, prm, trace_rows=48, phases=True)
+    assert np.array_equal(r.code, plain.code) and np.array_equal(r.iter, plain.iter)
+    assert np.array_equal(r.primal, plain.primal, equal_nan=True) and np.array_equal(r.dual, plain.dual, equal_nan=True)
+    ph = r.phase_us
+    assert ph.shape == (B, 6) and (ph >= 0).all() and (ph[:, 1:4] > 0).all()
+    used = r.trace[:, :, 0] >= 0
+    last_time = np.where(used, r.trace[:, :, 4], 0.0).max(1)
+    # (the table's clock starts at the reference's t0, after the scaling: phases 1 .. 3 cover it)
+    assert (ph[:, 1:4].sum(1) + 0.02 >= last_time).all(), (ph[:4], last_time[:4])
+    only = sfb.solve_qp_batch_host(P, q, A, l, u, prm, phases=True)
+    assert only.trace is None and np.array_equal(only.primal, plain.primal, equal_nan=True) and (only.phase_us >= 0).all()
+
+
+def test_verbose_single_dense_problem_prints_the_reference_summary(sfb, capfd):
+    """... and the closing summary (:550-565) after the native table, its phase lines adding up to the total."""
+    P, q, A, l, u = sfb.random_qp_batch(4, 1, 40, 20, 1.0)
+    capfd.readouterr()
+    r = sfb.solve_qp_batch_host(P, q, A, l, u, sfb.QPSolverParams(max_iter=3000, verbose=True))
+    out = capfd.readouterr().out
+    tail = out[out.index("QP solver summary:"):]
+    assert "Result %d" % int(r.code[0]) in tail and "NOTE the table's solve" not in out
+    vals = {ln[:25].strip(): float(ln[25:]) for ln in tail.splitlines() if ln.startswith("  ")}
+    assert set(vals) == {"Matrix filling", "Factorization", "Iteration", "Polish"}
+    total = [float(ln.split()[-1]) for ln in tail.splitlines() if ln.startswith("Total time")][0]
+    assert abs(sum(vals.values()) - total) <= 2.0
+    assert int([ln for ln in tail.splitlines() if ln.startswith("Iterations")][0].split()[-1]) == int(r.iter[0]) - 1

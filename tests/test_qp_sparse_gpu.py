@@ -197,3 +197,75 @@ def test_verbose_single_problem_prints_the_reference_table(sfb, capfd):
     assert "ITER" in out and "PRI_RES" in out and "DUA_RES" in out
     lines = [ln for ln in out.splitlines() if ln.strip().split(":")[0].strip().isdigit() and ":" in ln]
     assert len(lines) == (int(r.iter[0]) - 2) // 25 + 1 and lines[0].strip().startswith("1:")
+
+
+def test_phase_times_as_data(sfb, oracle):
+    """qp_solver.hpp:550-565 (Matrix filling / Factorization / Iteration / Polish) as data: the *_phases entry point solves
+    through the TRACE instance -- same results as the plain call -- and returns six non-negative per-phase times per item whose
+    sum covers the table's last TIME stamp (taken inside the iteration phase); for ONE problem alone on the device the sum is
+    the kernel's duration as HIP events see it (2 % + launch latency)."""
+    import torch
+    B, n, m, rows = 64, 30, 50, 12
+    P, q, A, l, u = sfb.random_qp_batch(23, B, m, n, 0.15)
+    Pp, Pi, Px, Ap, Aj, Ax = dense_batch_to_sparse(P, A, n, m, upper_only=True)
+    plan = sfb.SparseQPPlan(n, m, Pp, Pi, Ap, Aj)
+    prm = sfb.QPSolverParams(max_iter=252)
+    plain = plan.solve_batch_host(Px, q, Ax, l, u, prm)
+    r = plan.solve_batch_host(Px, q, Ax, l, u, prm, trace_rows=rows, phases=True)
+    assert np.array_equal(r.code, plain.code) and np.array_equal(r.iter, plain.iter)
+    assert np.array_equal(r.primal, plain.primal, equal_nan=True) and np.array_equal(r.dual, plain.dual, equal_nan=True)
+    ph = r.phase_us
+    assert ph.shape == (B, 6) and (ph >= 0).all() and (ph.sum(1) > 0).all()
+    used = r.trace[:, :, 0] >= 0
+    last_time = np.where(used, r.trace[:, :, 4], 0.0).max(1)
+    assert (ph[:, :4].sum(1) + 0.02 >= last_time).all()  # scaling + fill + factor + iteration reach past the last check
+    assert (ph[:, 4][plain.code != 0] < 5.0).all()       # no polish unless Optimal (a few clock reads only)
+    only = plan.solve_batch_host(Px, q, Ax, l, u, prm, phases=True)  # without the table
+    assert only.trace is None and np.array_equal(only.primal, plain.primal, equal_nan=True) and only.phase_us.shape == (B, 6)
+    # one MPC-sized problem alone on the device: phase sum against HIP events around the launch
+    from examples import models_lib as M
+    d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(12, 50)
+    Av, l, u = M.mpc_assemble_batch(12, 50, 1, seed=5, threads=1)
+    plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(12, 50), keep=(Av[0] != 0.0))
+    dev = torch.device("cuda:0")
+    t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (Pv[None], np.zeros((1, d["n"])), Av, l, u)]
+    f64 = dict(dtype=torch.float64, device=dev)
+    x, y = torch.empty((1, d["n"]), **f64), torch.empty((1, d["m"]), **f64)
+    out = torch.empty((2, 1), dtype=torch.int32, device=dev)
+    ws = torch.empty((plan.workspace_bytes(1) + 7) // 8, **f64)
+    phd = torch.zeros((1, 6), **f64)
+    st = torch.cuda.Stream()
+    best = None
+    with torch.cuda.stream(st):
+        for rep in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            plan.solve_batch_device_phases(1, *(a.data_ptr() for a in t), x.data_ptr(), y.data_ptr(), 0, out[0].data_ptr(),
+                                           out[1].data_ptr(), ws.data_ptr(), phd.data_ptr(), sfb.QPSolverParams(), stream=st.cuda_stream)
+            e1.record(st)
+            st.synchronize()
+            ev_us, sum_us = 1e3 * e0.elapsed_time(e1), float(phd.sum())
+            if best is None or ev_us < best[0]:
+                best = (ev_us, sum_us)
+    ev_us, sum_us = best
+    print("one MPC QP: events %.1f us, phases %s us" % (ev_us, np.round(phd.cpu().numpy()[0], 1)))
+    assert int(out[1, 0]) == 0 and sum_us <= ev_us + 1.0 and sum_us >= 0.98 * ev_us - 40.0, (ev_us, sum_us)
+
+
+def test_verbose_single_problem_prints_the_reference_summary(sfb, capfd):
+    """... and the closing summary of qp_solver.hpp:550-565 with its four phase lines."""
+    case = KNOWN_ANSWERS[sorted(KNOWN_ANSWERS)[0]]
+    P, q, A, l, u = (np.asarray(t, dtype=np.float64) for t in case[:5])
+    Pc = sp.csc_matrix(P); Pc.eliminate_zeros(); Pc.sort_indices()
+    Ac = sp.csr_matrix(A); Ac.sort_indices()
+    plan = sfb.SparseQPPlan(len(q), len(l), Pc.indptr, Pc.indices, Ac.indptr, Ac.indices)
+    r = plan.solve_batch_host(Pc.data[None], q[None], Ac.data[None], l[None], u[None], sfb.QPSolverParams(verbose=True))
+    out = capfd.readouterr().out
+    tail = out[out.index("QP solver summary:"):]
+    assert "Result %d" % int(r.code[0]) in tail
+    for name in ("Iterations", "Total time", "  Matrix filling", "  Factorization", "  Iteration", "  Polish"):
+        assert name in tail, name
+    vals = {ln[:25].strip(): float(ln[25:]) for ln in tail.splitlines() if ln.startswith("  ")}
+    total = [float(ln.split()[-1]) for ln in tail.splitlines() if ln.startswith("Total time")][0]
+    assert abs(sum(vals.values()) - total) <= 2.0  # the four lines add up to the total (printed as whole microseconds)
+    assert int([ln for ln in tail.splitlines() if ln.startswith("Iterations")][0].split()[-1]) == int(r.iter[0]) - 1
