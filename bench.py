@@ -656,7 +656,11 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # SFB_BENCH_FORCE_COLLECTIVES=1 (test hook): a world of ONE rank still initialises the process group (RCCL unless the device
+    # is shared) and issues every collective of the N > 1 path -- the gather of the small outputs, the checksum all_reduce, the
+    # barrier, the max-over-ranks reduction -- so that the first 8-GPU run is not the first time RCCL sees these dtypes / shapes
+    collectives = world > 1 or os.environ.get("SFB_BENCH_FORCE_COLLECTIVES") == "1"
+    if collectives:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share:
@@ -682,11 +686,11 @@ def main():
         if hasattr(wl, "pre_step"):
             wl.pre_step()
         wl.step(stream)
-        if world > 1:  # the only exchange on this path: final gather of the small outputs (RCCL/xGMI)
-            gathered = gather_small_outputs(wl.small_outputs(), total)
+        if collectives:  # the only exchange on this path: final gather of the small outputs (RCCL/xGMI)
+            gathered = gather_small_outputs(wl.small_outputs(), total, force=True)
 
     def barrier():
-        if world > 1:
+        if collectives:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -701,13 +705,13 @@ def main():
         ev[k][0].record(stream)   # HIP events on the stream the kernel is launched on
         wl.step(stream)
         ev[k][1].record(stream)
-        if world > 1:
-            gathered = gather_small_outputs(wl.small_outputs(), total)
+        if collectives:
+            gathered = gather_small_outputs(wl.small_outputs(), total, force=True)
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     gather_check = None
-    if world > 1:
+    if collectives:
         # What came out of the gather, checked against an independent path: every rank puts an exact (integer,
         # wrap-around) checksum of ITS rows into its slot of a vector that is summed over the ranks with an all_reduce;
         # the rows received from rank r must reproduce rank r's checksum.  Shards come from different seeds, so a
@@ -724,9 +728,12 @@ def main():
                         "peer_rows_received": all(bool(checksum(rows[r]) == cs[r]) for r in peers),
                         "peer_rows_differ_from_own": all(not bool(torch.equal(rows[r], own)) for r in peers),
                         "gathered_rows": int(gathered.shape[0]), "ranks_checked": world}
+        if world == 1:  # (forced collectives) say which backend carried them and what went through it
+            gather_check.update({"backend": dist.get_backend(), "gathered_dtype": str(gathered.dtype).replace("torch.", ""),
+                                 "checksum_via_all_reduce_matches": bool(cs[0] == checksum(own))})
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if collectives:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
@@ -781,7 +788,7 @@ def main():
             rec["secondary"] = {w: secondary_line(sfb, w, device) for w in sorted(WORKLOADS) if w != args.workload}
             rec["secondary"]["qp_dense_sizes"] = dense_sizes_table(sfb, device, host_cpus()[0])
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if collectives:
         dist.barrier()
         dist.destroy_process_group()
 

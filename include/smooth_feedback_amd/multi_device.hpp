@@ -12,9 +12,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cstdint>
 #include <exception>
 #include <memory>
+#include <optional>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -185,7 +188,15 @@ public:
   EKFSwarmMultiDevice(Dyn f, Meas h, int64_t filters, std::vector<int> devices = {}) : cut_(filters, std::move(devices)), B_(filters)
   {
     part_.resize(cut_.size());
-    cut_.for_each([&](size_t i, const DeviceShards::Shard & s) { part_[i] = std::make_unique<One>(f, h, s.count); });
+    try {
+      cut_.for_each([&](size_t i, const DeviceShards::Shard & s) { part_[i] = std::make_unique<One>(f, h, s.count); });
+    } catch (...) {  // the shards built so far own memory of THEIR devices: released with those devices current
+      try {
+        cut_.for_each([&](size_t i, const DeviceShards::Shard &) { part_[i].reset(); });
+      } catch (...) {
+      }
+      throw;
+    }
   }
   EKFSwarmMultiDevice(const EKFSwarmMultiDevice &)             = delete;
   EKFSwarmMultiDevice & operator=(const EKFSwarmMultiDevice &) = delete;
@@ -247,7 +258,7 @@ public:
     cut_.for_each([&](size_t i, const DeviceShards::Shard & s) {
       part_[i]->upload_measurements(y.data() + s.first);
       part_[i]->step_resident(Q, tau, R);
-      (void)hipDeviceSynchronize();  // (the launch is asynchronous: the tick is over when every shard's is)
+      detail::ekf_hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");  // (asynchronous launch: the tick is over -- and its faults are reported -- when every shard's is)
     });
   }
 

@@ -7,5 +7,9 @@ cd "$(dirname "$0")/../smooth_feedback_amd/csrc"
 make -s
 mkdir -p build_prof
 cp build/*.o build_prof/
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -ffp-contract=off -fno-fast-math ${PROF_DEFS:--DSFB_PROF_LDL} -c qp_sparse.hip -o build_prof/qp_sparse.o
+FLAGS="--offload-arch=gfx950 -O3 -std=c++20 -fPIC -ffp-contract=off -fno-fast-math ${PROF_DEFS:--DSFB_PROF_LDL}"
+/opt/rocm/bin/hipcc $FLAGS -c qp_sparse.hip -o build_prof/qp_sparse.o
+# the same guard as the Makefile's: numbers from a build whose sweeps spill or touch in-flight registers mean nothing
+/opt/rocm/bin/hipcc $FLAGS -S --cuda-device-only qp_sparse.hip -o build_prof/qp_sparse.s 2> /dev/null
+python3 check_sweep_spills.py build_prof/qp_sparse.s > build_prof/qp_sparse.spills || (cat build_prof/qp_sparse.spills; rm -f build_prof/qp_sparse.o; false)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsfb_prof.so build_prof/*.o -Wl,-rpath,/opt/rocm/lib

@@ -9,5 +9,9 @@ mkdir -p build_x$NAME
 cp build/*.o build_x$NAME/
 for f in $FILES; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -ffp-contract=off -fno-fast-math $DEFS -c $f -o build_x$NAME/${f%.hip}.o
+  if [ "$f" = qp_sparse.hip ]; then  # the Makefile's guard: a variant whose sweeps spill or touch in-flight registers is refused
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -ffp-contract=off -fno-fast-math $DEFS -S --cuda-device-only $f -o build_x$NAME/qp_sparse.s 2> /dev/null
+    python3 check_sweep_spills.py build_x$NAME/qp_sparse.s > build_x$NAME/qp_sparse.spills || (cat build_x$NAME/qp_sparse.spills; rm -f build_x$NAME/qp_sparse.o; false)
+  fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsfb_$NAME.so build_x$NAME/*.o -Wl,-rpath,/opt/rocm/lib

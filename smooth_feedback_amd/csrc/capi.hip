@@ -59,8 +59,11 @@ void verbose_report(const char *what, int64_t batch, int n, int m, double h2d_ms
     if (iter) { imin = std::min(imin, iter[b]); imax = std::max(imax, iter[b]); isum += iter[b]; }
   }
   std::printf("[sfb] %s: %lld problem(s), n = %d, m = %d\n", what, (long long)batch, n, m);
-  std::printf("[sfb]   time: upload %.3f ms | solve on device (scaling, factorisation, ADMM, polish) %.3f ms | download %.3f ms\n",
-              h2d_ms, solve_ms, d2h_ms);
+  if (h2d_ms < 0.0)  // a sharded call: the shards' uploads, solves and downloads overlap -- one wall-clock figure for the call
+    std::printf("[sfb]   time: %.3f ms for the whole call (upload, solve on the devices, download; the shards run side by side)\n", solve_ms);
+  else
+    std::printf("[sfb]   time: upload %.3f ms | solve on device (scaling, factorisation, ADMM, polish) %.3f ms | download %.3f ms\n",
+                h2d_ms, solve_ms, d2h_ms);
   std::printf("[sfb]   status:");
   for (int c = 0; c < 7; ++c)
     if (hist[c]) std::printf(" %s %lld", names[c], hist[c]);

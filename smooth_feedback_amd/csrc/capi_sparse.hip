@@ -564,6 +564,7 @@ sfb_status sfb_sparse_qp_solve_batch_host_multi(sfb_sparse_qp_plan *plan, const 
   }
   prm_call.verbose = 0;  // (reported once for the whole call below, not once per shard)
   const sfb_qp_params *const prm_shard = &prm_call;
+  const auto t_call = std::chrono::steady_clock::now();
   const sfb_status rs = sfb::run_sharded(batch, [&](int, int64_t b0, int64_t cnt) {
     const size_t o = (size_t)b0;  // the plan uploads its tables to a device on first use; each device has its own workspace
     tl_multi_origin = origin;
@@ -575,7 +576,8 @@ sfb_status sfb_sparse_qp_solve_batch_host_multi(sfb_sparse_qp_plan *plan, const 
     return s1;
   });
   if (rs == SFB_OK && prm->verbose)
-    sfb::verbose_report("sparse QP batch (sharded over the device list)", batch, h.n, h.m, 0.0, 0.0, 0.0, code, iter);
+    sfb::verbose_report("sparse QP batch (sharded over the device list)", batch, h.n, h.m, -1.0,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), -1.0, code, iter);
   return rs;
 }
 

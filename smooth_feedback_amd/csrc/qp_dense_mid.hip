@@ -29,6 +29,9 @@
 // finite, which is tracked as values are written; from the first non-finite value on the plain loops run.
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <mutex>
+
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
@@ -1545,9 +1548,25 @@ int mid_resident(const DenseKernelParams &kp)
   const char *const v = sfb::knob("SFB_MID_GRID");  // tests: a tiny grid forces the split, time-sliced launch
   const int forced    = v ? atoi(v) : 0;
   if (forced > 0) return forced;
+  // The occupancy query and the device attributes behind it cost host time on every call (two to three per solve): cached per
+  // (device, kernel instance = block count, LDS bytes), which is all the answer depends on.
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  const int nb = (kp.n + kp.m + 15) / 16;
+  const unsigned long long key = ((unsigned long long)(unsigned)dev << 48) | ((unsigned long long)(unsigned)nb << 40) |
+                                 (unsigned long long)qp_dense_mid_lds_bytes(kp.n, kp.m);
+  static std::mutex mu;
+  static std::map<unsigned long long, int> cache;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    const auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+  }
   int r = 0;
   MidLaunch a{MID_RESIDENT, 0, 0, nullptr, 0, nullptr, 0, &r, nullptr};
   if (mid_launch(kp, QpBatch{}, a) != hipSuccess) return 0;
+  std::lock_guard<std::mutex> lk(mu);
+  cache[key] = r;
   return r;
 }
 }  // namespace

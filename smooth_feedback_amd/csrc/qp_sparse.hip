@@ -903,7 +903,8 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
     asm volatile(SFB_SDWA_HI("%[p0]", "%[ixx]") SFB_SDWA_LO("%[t0]", "%[ixx]") SFB_SDWA_HI("%[p1]", "%[ixy]") SFB_SDWA_LO("%[t1]", "%[ixy]")
                  "ds_read_b64 %[a0], %[p0]\n\tds_read_b64 %[b0], %[t0]\n\tds_read_b64 %[a1], %[p1]\n\tds_read_b64 %[b1], %[t1]"
                  : [p0] "=&v"(cp0), [t0] "=&v"(ct0), [p1] "=&v"(cp1), [t1] "=&v"(ct1), [a0] "=&v"(a0), [b0] "=&v"(b0), [a1] "=&v"(a1), [b1] "=&v"(b1)
-                 : [tb] "v"(tb), [ixx] "v"(ix[0].x), [ixy] "v"(ix[0].y));
+                 : [tb] "v"(tb), [ixx] "v"(ix[0].x), [ixy] "v"(ix[0].y)
+                 : "memory");  // (the units read and write t behind the compiler's back: no C-level LDS access moves across the sweep's ends)
     (void)cp0; (void)cp1;
     auto unit = [&]<int D>(std::integral_constant<int, D>) {
       constexpr int N = (D + 1) % DEPTH;
@@ -944,7 +945,7 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
     }
     // the reads issued behind the last unit (a padding unit's scratch entry, or the next stream's first unit before its
     // D^-1 step: never used) are retired before their registers are
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1) : : "memory");
     if constexpr (NEXT) {
       wave_lds_fence();  // (no s_waitcnt vmcnt(0) here: the next sweep's first units stay in flight)
     } else {

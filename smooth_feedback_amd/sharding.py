@@ -13,10 +13,11 @@ def shard_range(total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_small_outputs(local: torch.Tensor, total: int):
+def gather_small_outputs(local: torch.Tensor, total: int, force: bool = False):
     """All ranks contribute their shard's rows (dim 0); returns the (total, ...) tensor on every rank.
-    Shards may differ by one row, so pad to the largest shard for the collective."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    Shards may differ by one row, so pad to the largest shard for the collective.
+    force: issue the collective even in a world of one (tests: the RCCL path on a 1-GPU box)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     sizes = [shard_range(total, r, world) for r in range(world)]

@@ -97,3 +97,25 @@ def test_default_line_carries_the_secondary_workloads():
     assert cl["single_agent"]["cold_ms"] > 0 and cl["single_agent"]["warm_iterations"] <= cl["single_agent"]["cold_iterations"]
     ekf_cpu = d["secondary"]["ekf"]["cpu_baseline"]
     assert ekf_cpu["single_core"]["cores"] == 1 and d["secondary"]["ekf"]["parity_vs_oracle"].get("all_cores_P_bit_identical", True)
+
+
+@pytest.mark.parametrize("workload,batch,dtype,port", [("mpc", 96, "float64", 29565), ("qp_dense", 4096, "int32", 29573)])
+def test_rccl_carries_the_collectives_of_the_n_gpu_path(workload, batch, dtype, port):
+    """The `nccl` (= RCCL) branch of bench.py on the one GPU there is: one rank under torch.distributed.run, process group on
+    RCCL with the device bound, and every collective of the N > 1 path issued for real (SFB_BENCH_FORCE_COLLECTIVES=1: the
+    world-of-one shortcut of sharding.gather_small_outputs is bypassed) -- all_gather of the small per-item outputs (float64
+    (batch, 4) rows of u0 / code / iter for mpc, int32 (batch, 2) for the dense QPs), the int64 checksum all_reduce, the
+    barrier, the float64 MAX all_reduce of the elapsed time.  What an 8-GPU run adds is peers, not code."""
+    env = dict(os.environ, SFB_BENCH_FORCE_COLLECTIVES="1")
+    env.pop("SFB_BENCH_SHARE_DEVICE", None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "1",
+                          "--workload", workload, "--batch", str(batch), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-pipelined", "--no-secondary", "--no-closed-loop"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["gather_check"] == {"own_rows_intact": True, "peer_rows_received": True, "peer_rows_differ_from_own": True,
+                                 "gathered_rows": batch, "ranks_checked": 1, "backend": "nccl", "gathered_dtype": dtype,
+                                 "checksum_via_all_reduce_matches": True}
