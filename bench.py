@@ -640,6 +640,9 @@ def main():
     ap.add_argument("--no-pipelined", action="store_true", help="skip the multi-stream throughput measurement (mpc)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads reported next to the headline")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the end-to-end / swarm-tick / single-agent figures (mpc)")
+    ap.add_argument("--debug-knob", action="append", default=[], metavar="NAME=VALUE",
+                    help="a debug knob of the library (sfb_debug_set, csrc/knobs.h) for this run: measurements and profiling only; "
+                         "recorded in the line as `debug_knobs`")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -669,6 +672,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=device)  # RCCL over xGMI
 
     import smooth_feedback_amd as sfb
+    debug_knobs = sfb.debug_set_from(",".join(args.debug_knob)) if args.debug_knob else {}
 
     # Sharding (smooth_feedback_amd/sharding.py, the module the gloo tests cover): the job's batch is `world` times the
     # per-GPU batch, rank r owns the contiguous range shard_range(total, r, world) of it -- weak scaling, so every range
@@ -757,6 +761,8 @@ def main():
                        "parallelism": "batch-sharded x%d, one gather of the small per-item outputs (u0 / code / iter)" % world},
             "roofline": roofline_of(args.workload, wl, kern_ms, world == 1),
         }
+        if debug_knobs:  # NOT a production line: launch shapes / engines were steered through sfb_debug_set
+            rec["debug_knobs"] = debug_knobs
         if gather_check is not None:
             rec["gather_check"] = gather_check
         if hasattr(wl, "extra"):

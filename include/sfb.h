@@ -116,6 +116,12 @@ typedef struct sfb_qp_params {
 const char *sfb_version(void);
 /* Thread-local description of the last non-OK status returned on this thread. */
 const char *sfb_last_error(void);
+
+/* Debug knobs (tests, A/B measurements, diagnostics): launch shapes and engine choices, listed in
+ * smooth_feedback_amd/csrc/knobs.h -- e.g. "SFB_SP_GRID" = "4" forces the time-sliced launch of the sparse kernel on a tiny
+ * grid.  None changes a result.  value == NULL clears a knob; an unknown name is SFB_ERR_INVALID_ARG.  This call is the ONLY
+ * way to set them: the library reads no environment variable. */
+sfb_status sfb_debug_set(const char *name, const char *value);
 /* Number of visible HIP devices (0 if none / runtime unusable). */
 sfb_status sfb_device_count(int *count);
 

@@ -59,4 +59,6 @@ def main():
 
 
 if __name__ == "__main__":
+    if os.environ.get("KNOBS"):  # debug knobs of the library for this sweep: KNOBS="SFB_SP_GRID=4,SFB_SP_PAUSE=2" (sfb_debug_set)
+        print("debug knobs:", sfb.debug_set_from(os.environ["KNOBS"]))
     main()

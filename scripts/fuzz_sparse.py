@@ -10,6 +10,8 @@ from sparse_cases import dense_batch_to_sparse
 from fuzz_dense import oparams  # noqa: E402
 
 if __name__ == "__main__":
+    if os.environ.get("KNOBS"):  # debug knobs of the library for this sweep: KNOBS="SFB_SP_GRID=4,SFB_SP_PAUSE=2" (sfb_debug_set)
+        print("debug knobs:", sfb.debug_set_from(os.environ["KNOBS"]))
     N = int(os.environ.get("N", 200)); seed0 = int(os.environ.get("SEED", 1))
     bad = 0
     for it in range(N):

@@ -7,8 +7,9 @@ cd /tmp; export TMPDIR=/tmp
 for v in "$@"; do
   OUT=$ROOT/gpurun_out/launch_trace_$(echo $v | tr '= ' '__')
   rm -rf $OUT
-  (cd $ROOT && env $v timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python bench.py --steps 3 --warmup 1 \
-    --no-cpu-baseline --no-pipelined --no-secondary --no-closed-loop --workload mpc > $OUT.log 2>&1)
+  K=""; case $v in SFB_*) K="--debug-knob $v";; esac  # (debug knobs go through sfb_debug_set; anything else, e.g. A=1, is a plain label)
+  (cd $ROOT && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python bench.py --steps 3 --warmup 1 \
+    --no-cpu-baseline --no-pipelined --no-secondary --no-closed-loop --workload mpc $K > $OUT.log 2>&1)
   echo "== $v"
   python3 - <<PY
 import csv, glob

@@ -4,8 +4,7 @@
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/phase_counters
 rm -rf $OUT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --workload mpc --steps 2 --warmup 1 --no-cpu-baseline --no-pipelined --no-secondary --no-closed-loop"
-export SFB_SP_PHASED=1
+CMD="python $ROOT/bench.py --workload mpc --steps 2 --warmup 1 --no-cpu-baseline --no-pipelined --no-secondary --no-closed-loop --debug-knob SFB_SP_PHASED=1"
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_ANY" \

@@ -4,6 +4,7 @@ The compute path is libsfb.so (hand-written HIP for gfx950, C-ABI in include/sfb
 is the thin host-side mirror of the reference interface used by tests and bench.py.
 """
 from . import _capi  # noqa: F401  (fails loudly if libsfb.so is missing)
+from ._capi import debug_set, debug_set_from  # noqa: F401  (debug knobs of the library: tests, A/B measurements)
 from .qp import (QPBatchSolution, QPSolution, QPSolutionStatus, QPSolver, QPSolverParams,  # noqa: F401
                  QuadraticProgram, pack_colmajor, random_qp_batch, solve_qp, solve_qp_batch_device, solve_qp_batch_device_ws, Workspace,
                  solve_qp_batch_host, QuadraticProgramSparse, SparseQPPlan, solve_qp_sparse)

@@ -67,6 +67,7 @@ def _load():
     vp, dp, i64, i32 = C.c_void_p, C.c_void_p, C.c_int64, C.c_int
     L.sfb_version.restype = C.c_char_p
     L.sfb_last_error.restype = C.c_char_p
+    L.sfb_debug_set.argtypes = [C.c_char_p, C.c_char_p]
     L.sfb_device_count.argtypes = [C.POINTER(C.c_int)]
     L.sfb_qp_params_default.argtypes = [C.POINTER(SfbQPParams)]
     L.sfb_qp_params_default.restype = None
@@ -138,6 +139,20 @@ def _load():
 
 
 lib = _load()
+
+
+def debug_set(name, value=None):
+    """sfb_debug_set: a debug knob of the library (csrc/knobs.h) -- launch shapes / engine choices for tests and A/B
+    measurements; value None clears it.  The library reads no environment variable: this is the only way in."""
+    check(lib.sfb_debug_set(name.encode(), None if value is None else str(value).encode()))
+
+
+def debug_set_from(spec):
+    """"NAME=VALUE,NAME=VALUE" (the KNOBS variable of the scripts, bench.py --debug-knob): applies every pair, returns them."""
+    pairs = [kv.split("=", 1) for kv in spec.replace(";", ",").split(",") if kv.strip()]
+    for k, v in pairs:
+        debug_set(k.strip(), v.strip())
+    return {k.strip(): v.strip() for k, v in pairs}
 
 
 def check(status):

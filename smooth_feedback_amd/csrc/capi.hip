@@ -131,7 +131,6 @@ DenseKernelParams make_kernel_params(const sfb_qp_params *prm, int n, int m)
   kp.scaling         = prm->scaling ? 1 : 0;
   kp.polish          = prm->polish ? 1 : 0;
   kp.reuse           = prm->reuse_factor ? 1 : 0;
-  if (const char *nr = sfb::knob("SFB_QP_NO_REUSE"); nr && nr[0] == '1') kp.reuse = 0;  // A/B knob (tests, timing)
   return kp;
 }
 
@@ -166,7 +165,7 @@ sfb_status dense_big(const sfb_qp_params *prm, int64_t batch, int n, int m, cons
                      const double *l, const double *u, const double *wx, const double *wy, double *x, double *y, double *obj,
                      uint32_t *iter, int32_t *code, hipStream_t stream, void *workspace)
 {
-  if (n + m <= sfb::kDenseMidMaxK && sfb::qp_dense_mid_enabled()) {  // up to 128: everything on chip, no workspace (qp_dense_mid.hip)
+  if (n + m <= sfb::kDenseMidMaxK) {  // up to 128: everything on chip, no workspace (qp_dense_mid.hip)
     const sfb::DenseKernelParams kpm = make_kernel_params(prm, n, m);
     const sfb::QpBatch gm{P, q, A, l, u, wx, wy, x, y, obj, iter, code};
     const hipError_t em = sfb::qp_dense_mid_launch(kpm, batch, gm, stream, workspace);
@@ -475,6 +474,12 @@ sfb_status sfb_get_devices(int *devices, int capacity, int *count)
 
 const char *sfb_last_error(void) { return sfb::g_last_error.c_str(); }
 
+sfb_status sfb_debug_set(const char *name, const char *value)
+{
+  if (sfb::knob_set(name, value) != 0) return sfb::fail(SFB_ERR_INVALID_ARG, std::string("sfb_debug_set: unknown knob ") + (name ? name : "(null)"));
+  return SFB_OK;
+}
+
 sfb_status sfb_device_count(int *count)
 {
   if (!count) return fail(SFB_ERR_INVALID_ARG, "count is NULL");
@@ -521,10 +526,11 @@ static sfb_status dense_workspace_need(const sfb_qp_params *prm, int64_t batch, 
   const int k = n + m;
   *need       = 0;
   if (k > SFB_QP_DENSE_MAX_K) {
-    static const bool big_off = [] { const char *v = sfb::knob("SFB_QP_DENSE_BIG"); return v && v[0] == '0'; }();
-    if (k <= sfb::kDenseBigMaxK && !big_off) {
-      *need = (k <= sfb::kDenseMidMaxK && sfb::qp_dense_mid_enabled()) ? sfb::qp_dense_mid_ws_bytes(make_kernel_params(prm, n, m), batch)
-                                                                       : (size_t)batch * sfb::qp_dense_big_ws_doubles(n, m) * sizeof(double);
+    const char *const bv = sfb::knob("SFB_QP_DENSE_BIG");  // 0 (tests): sizes beyond 128 through the un-pivoted sparse kernel
+    const bool big_off   = bv && bv[0] == '0';
+    if (k <= sfb::kDenseMidMaxK || (k <= sfb::kDenseBigMaxK && !big_off)) {
+      *need = k <= sfb::kDenseMidMaxK ? sfb::qp_dense_mid_ws_bytes(make_kernel_params(prm, n, m), batch)
+                                      : (size_t)batch * sfb::qp_dense_big_ws_doubles(n, m) * sizeof(double);
       return SFB_OK;
     }
     sfb_sparse_qp_plan *plan = nullptr;
@@ -533,9 +539,9 @@ static sfb_status dense_workspace_need(const sfb_qp_params *prm, int64_t batch, 
     size_t abytes = 0;
     return dense_via_sparse_bytes(plan, batch, n, m, &abytes, need);
   }
-  // (a time limit sends k <= 32 to the one-per-wave kernels, which need none: the bound below still holds)
-  if (k <= 32) *need = sfb::qp_dense4_ws_bytes(n, m, batch);
-  else if (sfb::qp_dense_mid_enabled()) *need = sfb::qp_dense_mid_ws_bytes(make_kernel_params(prm, n, m), batch);
+  // (a time limit sends k <= 32 to the 32 < k <= 128 kernel, which implements it: the larger of the two needs covers both)
+  const size_t need_mid = sfb::qp_dense_mid_ws_bytes(make_kernel_params(prm, n, m), batch);
+  *need = k <= 32 ? std::max(sfb::qp_dense4_ws_bytes(n, m, batch), prm->max_time_ns >= 0 ? need_mid : (size_t)0) : need_mid;
   return SFB_OK;
 }
 
@@ -563,8 +569,9 @@ static sfb_status dense_solve_impl(const sfb_qp_params *prm, int64_t batch, int 
   }
   if (n + m > SFB_QP_DENSE_MAX_K) {
     // SFB_QP_DENSE_BIG=0 (A/B, tests): route these sizes to the un-pivoted sparse kernel as well
-    static const bool big_off = [] { const char *v = sfb::knob("SFB_QP_DENSE_BIG"); return v && v[0] == '0'; }();
-    if (n + m <= sfb::kDenseBigMaxK && !big_off)
+    const char *const bv = sfb::knob("SFB_QP_DENSE_BIG");
+    const bool big_off   = bv && bv[0] == '0';
+    if (n + m <= sfb::kDenseMidMaxK || (n + m <= sfb::kDenseBigMaxK && !big_off))
       return dense_big(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code, static_cast<hipStream_t>(stream),
                        wsmem);
     return dense_via_sparse(prm, batch, n, m, P, q, A, l, u, warm_x, warm_y, x, y, obj, iter, code,

@@ -421,7 +421,8 @@ static sfb_status swarm_step_impl(sfb_mpc_swarm *S, const sfb_qp_params *prm, co
   hipError_t e = hipSuccess;
   sfb_status st = SFB_OK;
   // SFB_MPC_TIMING=1: synchronise after every stage and print the wall time of each (diagnostics only)
-  static const bool timing = [] { const char *v = sfb::knob("SFB_MPC_TIMING"); return v && v[0] == '1'; }();
+  const char *const tk = sfb::knob("SFB_MPC_TIMING");
+  const bool timing    = tk && tk[0] == '1';
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto t0 = now();
   auto lap = [&](const char *what) {
@@ -455,8 +456,7 @@ static sfb_status swarm_step_impl(sfb_mpc_swarm *S, const sfb_qp_params *prm, co
     lap("assemble");
     // Warm-started ticks: the agents that iterated longest in the previous tick are launched first (their counts
     // change little from tick to tick), so the stragglers overlap with the bulk of the batch.
-    static const bool no_order = [] { const char *v = sfb::knob("SFB_MPC_NO_ORDER"); return v && v[0] == '1'; }();  // A/B knob
-    const bool ordered = warmstart && S->have_order && !no_order;
+    const bool ordered = warmstart && S->have_order;
     if (ordered && (e = hipMemcpy(S->order, S->h_order.data(), B * 4, hipMemcpyHostToDevice)) != hipSuccess) break;
     st = sfb_sparse_qp_solve_batch_ordered(S->plan, prm, S->agents, S->Px, S->q, S->Ax, S->l, S->u,
                                            warmstart ? S->wx : nullptr, warmstart ? S->wy : nullptr, S->x, S->y, nullptr,

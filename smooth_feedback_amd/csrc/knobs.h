@@ -1,27 +1,29 @@
-// Environment knobs of libsfb.so: A/B experiments, measurements and tests only -- none of them
-// changes a result (the parity tests run the variants against each other), several select another kernel or launch
-// shape.  Every read goes through knob(): the first time a knob is found SET, the library says so on stderr, so a
-// production run cannot be steered silently by a stale environment.
+// Debug knobs of libsfb.so: launch shapes and engine choices for tests, A/B measurements and diagnostics -- none of them
+// changes a result (the parity tests run the variants against each other).  They are set through ONE entry point,
+// sfb_debug_set(name, value) (include/sfb.h); the library reads NO environment variable, so a stale environment cannot
+// steer a production launch.  Every set is announced on stderr.
+//
+//   sparse kernel, launch shape   SFB_SP_GRID        cap on the resident workgroups (tests: a tiny grid forces time slicing)
+//                                 SFB_SP_SLICE       iterations per time slice (0: one workgroup per item)
+//                                 SFB_SP_PAUSE       iteration of the first launch's pause (launch in predicted order)
+//                                 SFB_SP_PREDICT     0: a single time-sliced launch instead of the launch in predicted order
+//                                 SFB_SP_LAT         0: the standard form of the kernel for the loop launch
+//                                 SFB_SP_FORCE_LAT   1: the LAT form of the kernel for a whole launch
+//                                 SFB_SP_PHASED      1: setup / ADMM loop / polish + report as three launches (profiling)
+//                                 SFB_SP_LEAN_WAVES  busy waves above which the sweeps use masked non-temporal loads
+//   dense kernels                 SFB_MID_GRID, SFB_MID_SLICE   32 < n + m <= 128: resident waves / checks per slice
+//                                 SFB_QP4_MAX_WAVES  n + m <= 32: cap on the persistent grid
+//                                 SFB_QP_DENSE_BIG   0: sizes beyond 128 through the sparse kernel
+//   plan                          SFB_PLAN_UNITS     0: the supernodal engine of the numeric factorisation for every plan
+//                                 SFB_PLAN_DEBUG     1: print segments, units and sweep schedules of a plan
+//   MPC swarm                     SFB_MPC_TIMING     1: synchronise after every stage of a tick and print its wall time
 #pragma once
-#include <cstdio>
-#include <cstdlib>
-#include <mutex>
-#include <set>
-#include <string>
 
 namespace sfb {
 
-inline const char *knob(const char *name)
-{
-  const char *v = std::getenv(name);
-  if (v != nullptr) {
-    static std::mutex mu;
-    static std::set<std::string> seen;
-    std::lock_guard<std::mutex> lk(mu);
-    if (seen.insert(name).second)
-      std::fprintf(stderr, "[sfb] tuning knob %s=%s is set (experiments and tests only; results do not depend on it)\n", name, v);
-  }
-  return v;
-}
+// value of a knob set through sfb_debug_set, or nullptr (knobs.cpp)
+const char *knob(const char *name);
+// 0 = ok, 1 = unknown name; value == nullptr clears the knob
+int knob_set(const char *name, const char *value);
 
 }  // namespace sfb

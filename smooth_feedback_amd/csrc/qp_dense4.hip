@@ -902,8 +902,7 @@ static hipError_t launch4(const DenseKernelParams &kp, int64_t batch, const QpBa
 
   const size_t lds = qp_dense4_lds_bytes(kp.n, kp.m);
   int per_cu       = (int)((160u * 1024u) / lds);
-  const char *occ  = sfb::knob("SFB_QP4_WAVES_PER_CU");  // A/B only
-  const int occ_cap = occ ? atoi(occ) : (NB > 1 ? 8 : 16);
+  const int occ_cap = NB > 1 ? 8 : 16;
   if (per_cu > occ_cap) per_cu = occ_cap;  // waves per SIMD the VGPR budget of the kernel allows: 2 (NB = 2) / 4
   if (per_cu < 1) per_cu = 1;
   int64_t max_waves = (int64_t)ncu * per_cu;
@@ -912,8 +911,7 @@ static hipError_t launch4(const DenseKernelParams &kp, int64_t batch, const QpBa
     if (c >= 1 && c < max_waves) max_waves = c;
   }
   const dim3 grid((unsigned)(batch < max_waves ? batch : max_waves));
-  unsigned slice_checks = 80;  // time slice in stopping-check intervals (2 000 iterations at the default 25)
-  if (const char *sl = sfb::knob("SFB_QP4_SLICE")) slice_checks = (unsigned)atoi(sl) > 0 ? (unsigned)atoi(sl) : 1u;  // A/B, tests
+  const unsigned slice_checks = 80;  // time slice in stopping-check intervals (2 000 iterations at the default 25)
   if (kp.max_iter != 0)  // nothing to iterate otherwise: the finish kernel reports the initial iterate
     hipLaunchKernelGGL((qp_dense4_iterate_kernel<NB>), grid, block, lds, stream, kp, g, wsp, queue, (unsigned)batch,
                        slice_checks);

@@ -30,7 +30,6 @@
 #include "../../include/sfb.h"
 #include "qp_dense_kernel.h"
 #include "wave_util.h"
-#include "sweep_rows.h"
 
 namespace sfb {
 
@@ -68,18 +67,12 @@ __device__ __forceinline__ int wave_min_index(const int cand)
 // starts at +0) -- so while every entry of L computed so far is finite (checked as the entries are written), the dot
 // products run over the non-zero terms only, in the same order.  A safety filter's constraint columns have no non-zero
 // term at all: their update vanishes.  Once a non-finite entry appears the full loops run again.
-// Where the matrix lives: the row-major square in the QP's workspace (global memory), or -- k <= 128, packed engine --
-// the packed lower triangle in LDS (entry (i, j), j <= i, at i (i + 1) / 2 + j), where the factor then stays.
+// Where the matrix lives: the row-major square in the QP's workspace (global memory).
 struct BigMatGlobal {
   double *W;
   size_t ld;
   __device__ __forceinline__ double &at(const int i, const int j) const { return W[(size_t)i * ld + (size_t)j]; }
   __device__ __forceinline__ const double *row(const int i) const { return W + (size_t)i * ld; }
-};
-struct BigMatPacked {
-  lds_d *T;
-  __device__ __forceinline__ lds_d &at(const int i, const int j) const { return T[((i * (i + 1)) >> 1) + j]; }
-  __device__ __forceinline__ const lds_d *row(const int i) const { return T + ((i * (i + 1)) >> 1); }
 };
 template<class Mat>
 __device__ inline int big_ldlt_factor(const int K_, const Mat W, int *perm_, double *temp_, int *nzj_, const int lane)
@@ -646,212 +639,6 @@ __device__ __forceinline__ double big_norm_inf(const double *v, const int len, c
   return wave_max(r);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// PACKED ENGINE, K <= 128: the whole factor on chip.  The strictly lower triangle of L sits in LDS as a packed
-// triangle (entry (i, j), j < i, at kMidZ + i (i + 1) / 2 + j, behind kMidZ zeros that the lanes a step does not
-// concern read instead; 66 KB at K = 128), D in LDg.  Lane l carries rows l and l + 64 of the work vector in REGISTERS
-// for the whole solve; a sweep is K - 1 dependent steps [pivot: v_readlane -> SGPR pair; one v_fma_f64 per half], the
-// entries of L coming from LDS a chunk of kMidU steps ahead of their use (the loads do not depend on the chain).
-// Same operations in the same order as oracle_ldlt_solve: every row subtracts L(i, j) t_j for j ascending (forward) /
-// L(j, i) t_j for j descending (backward); a lane a step does not concern multiplies a 0.0 entry, an exact no-op on
-// finite data (the convention of the k <= 64 kernels' zero-padded factor registers).
-constexpr int kMidMaxK = 128;
-constexpr int kMidU    = 8;   // steps per chunk (the LDS loads of a chunk are issued together, one chunk ahead)
-constexpr int kMidZ    = 16;  // zeros in front of the packed triangle (>= kMidU, even)
-__host__ __device__ constexpr size_t mid_lds_doubles(const int k) { return (size_t)kMidZ + (size_t)k * (size_t)(k + 1) / 2; }
-
-// after the in-place factorisation of the packed triangle: the zeros in front of it and the diagonal D
-__device__ inline void mid_finish_factor(const int K_, double *Lpk_, double *LDg_, const int lane)
-{
-  const int K = ubig(K_);
-  LDS_D(Lpk, Lpk_);
-  LDS_D(LDg, LDg_);
-  if (lane < kMidZ) Lpk[lane] = 0.0;
-  for (int i = lane; i < K; i += kWave) {
-    LDg[i] = Lpk[kMidZ + ((i * (i + 1)) >> 1) + i];
-    Lpk[kMidZ + ((i * (i + 1)) >> 1) + i] = -0.0;  // what the pivot lane of a block-sweep chain step multiplies by (sweep_rows.h)
-  }
-  wave_sync();
-}
-
-template<int I> using mid_ic = std::integral_constant<int, I>;
-template<int N, class F>
-__device__ __forceinline__ void mid_static_for(F &&f)
-{
-  [&]<int... I>(std::integer_sequence<int, I...>) { (f(mid_ic<I>{}), ...); }(std::make_integer_sequence<int, N>{});
-}
-// t = fma(-l, pj, t) on the lanes ABOVE / BELOW a compile-time lane only: EXEC is narrowed around the one instruction
-// (the compiler never sees EXEC change: one asm statement), so the other lanes keep their value bit for bit -- no
-// 0 * pivot products, non-finite pivots included.  pj is wave-uniform (an SGPR pair, from v_readlane).
-template<int LANE>  // lanes > LANE
-__device__ __forceinline__ void mid_fma_above(double &t, const double l, const double pj)
-{
-  static_assert(LANE >= 0 && LANE < kWave - 1, "at least one lane above");
-  asm volatile("s_lshl_b64 exec, -1, %3\n\tv_fma_f64 %0, -%1, %2, %0\n\ts_mov_b64 exec, -1" : "+v"(t) : "v"(l), "s"(pj), "n"(LANE + 1) : "scc");
-}
-template<int LANE>  // lanes < LANE
-__device__ __forceinline__ void mid_fma_below(double &t, const double l, const double pj)
-{
-  static_assert(LANE >= 1 && LANE < kWave, "at least one lane below, not all");
-  asm volatile("s_bfm_b64 exec, %3, 0\n\tv_fma_f64 %0, -%1, %2, %0\n\ts_mov_b64 exec, -1" : "+v"(t) : "v"(l), "s"(pj), "n"(LANE));
-}
-
-struct MidPair { double lo, hi; };  // rows lane and lane + 64 of a vector in the permuted order of the factorisation
-// (L D L')^-1 applied to the PERMUTED vector t held in registers: L^-1, D^-1, L^-T (the middle of oracle_ldlt_solve).
-// Fully unrolled over compile-time step numbers J (pivot lane, LDS offsets and lane masks are immediates; the only
-// run-time control flow is one wave-uniform test per chunk of kMidU steps, which ends the sweeps at K).
-__device__ __attribute__((noinline)) MidPair mid_sweeps(const int K_, const double *Lpk_, const double *LDg_, MidPair t, const int lane)
-{
-  const int K = ubig(K_);  // (an outlined function receives its arguments in VGPRs: without this every `J < K` is a per-lane test)
-  LDS_CD(Lpk, Lpk_);
-  LDS_CD(LDg, LDg_);
-  const lds_d *const T = Lpk + kMidZ;  // the packed triangle
-  const bool vlo = lane < K, vhi = lane + kWave < K;
-  const int ilo = lane, ihi = lane + kWave;
-  double tlo = vlo ? t.lo : 0.0, thi = vhi ? t.hi : 0.0;
-  // row pointers; a row that does not exist reads row 0's region (valid LDS; its value is never used: no pivot, no store)
-  const lds_d *const plo = T + (vlo ? (ilo * (ilo + 1)) >> 1 : 0);
-  const lds_d *const phi = T + (vhi ? (ihi * (ihi + 1)) >> 1 : 0);
-  const lds_d *const pln = T + lane;  // backward: L(J, lane) = pln[tri(J, 0)], L(J, lane + 64) = pln[tri(J, 0) + 64]
-  const int K1 = K - 1;
-  constexpr int NC = kWave / kMidU;  // chunks per half
-  double blo[2][kMidU], bhi[2][kMidU];
-
-  // ---------------- forward: steps J = 0 .. K - 2 ----------------
-  // phase 1, J < f1 = min(64, K - 1): pivot = row J (low half).  Low rows take part while lane > J, high rows always.
-  // (Steps of the last chunk beyond f1 only touch rows that do not exist.)
-  const int f1 = K1 < kWave ? K1 : kWave;
-  {
-    auto load = [&]<int C>(mid_ic<C>) {
-      mid_static_for<kMidU>([&]<int U>(mid_ic<U>) {
-        blo[C & 1][U] = plo[C * kMidU + U];
-        bhi[C & 1][U] = phi[C * kMidU + U];
-      });
-    };
-    load(mid_ic<0>{});
-    mid_static_for<NC>([&]<int C>(mid_ic<C>) {
-      if (C * kMidU < f1) {
-        if constexpr (C + 1 < NC) load(mid_ic<C + 1>{});
-        mid_static_for<kMidU>([&]<int U>(mid_ic<U>) {
-          constexpr int J = C * kMidU + U;
-          const double pj = lane_bcast(tlo, J);
-          if constexpr (J < kWave - 1) mid_fma_above<J>(tlo, blo[C & 1][U], pj);
-          thi = fma(-bhi[C & 1][U], pj, thi);
-        });
-      }
-    });
-  }
-  // phase 2, 64 <= J < K - 1: pivot = row J (high half, lane J - 64); high rows take part while lane + 64 > J
-  if (K1 > kWave) {
-    auto load = [&]<int C>(mid_ic<C>) {
-      mid_static_for<kMidU>([&]<int U>(mid_ic<U>) { bhi[C & 1][U] = phi[kWave + C * kMidU + U]; });
-    };
-    load(mid_ic<0>{});
-    mid_static_for<NC>([&]<int C>(mid_ic<C>) {
-      if (kWave + C * kMidU < K1) {
-        if constexpr (C + 1 < NC) load(mid_ic<C + 1>{});
-        mid_static_for<kMidU>([&]<int U>(mid_ic<U>) {
-          constexpr int JL = C * kMidU + U;  // pivot lane = J - 64
-          if constexpr (JL < kWave - 1) mid_fma_above<JL>(thi, bhi[C & 1][U], lane_bcast(thi, JL));
-        });
-      }
-    });
-  }
-  // ---------------- D^-1 (|d| <= DBL_MIN -> 0, true division) ----------------
-  {
-    const double dlo = LDg[vlo ? ilo : 0], dhi = LDg[vhi ? ihi : 0];
-    tlo = (fabs(dlo) > DBL_MIN) ? tlo / dlo : 0.0;
-    thi = (fabs(dhi) > DBL_MIN) ? thi / dhi : 0.0;
-    if (!vlo) tlo = 0.0;
-    if (!vhi) thi = 0.0;
-  }
-  // ---------------- backward: steps J = K - 1 .. 1; row J of L is contiguous: L(J, i) at tri(J, 0) + i ----------------
-  // Chunks are taken from the top; in the chunk that contains K - 1 the steps above it are skipped one by one (their
-  // pivots would be rows that do not exist), every other chunk runs without tests.
-  // phase A, J = K - 1 .. 64: pivot = row J (high half); low rows i = lane < 64 <= J always take part, high rows while
-  // lane + 64 < J
-  if (K > kWave) {
-    auto load = [&]<int C>(mid_ic<C>) {  // chunk C holds J = 64 + 8 C + 7 - U
-      mid_static_for<kMidU>([&]<int U>(mid_ic<U>) {
-        constexpr int J = kWave + C * kMidU + (kMidU - 1 - U), RB = (J * (J + 1)) / 2;
-        blo[C & 1][U] = pln[RB];
-        bhi[C & 1][U] = pln[RB + kWave];
-      });
-    };
-    auto run = [&]<int C, bool GUARD>(mid_ic<C>, std::bool_constant<GUARD>) {
-      mid_static_for<kMidU>([&]<int U>(mid_ic<U>) {
-        constexpr int J = kWave + C * kMidU + (kMidU - 1 - U), JL = J - kWave;
-        if (!GUARD || J <= K1) {
-          const double pj = lane_bcast(thi, JL);
-          tlo = fma(-blo[C & 1][U], pj, tlo);
-          if constexpr (JL >= 1) mid_fma_below<JL>(thi, bhi[C & 1][U], pj);
-        }
-      });
-    };
-    bool first = true;  // wave-uniform: the first chunk that runs fetches its own entries, the others were fetched ahead
-    mid_static_for<NC>([&]<int CR>(mid_ic<CR>) {
-      constexpr int C = NC - 1 - CR;
-      if (kWave + C * kMidU <= K1) {
-        if (first) load(mid_ic<C>{});
-        first = false;
-        if constexpr (C >= 1) load(mid_ic<C - 1>{});
-        if (kWave + C * kMidU + kMidU - 1 > K1) run(mid_ic<C>{}, std::true_type{});  // the chunk that contains K - 1
-        else run(mid_ic<C>{}, std::false_type{});
-      }
-    });
-  }
-  // phase B, J = min(63, K - 1) .. 1: pivot = row J (low half); low rows take part while lane < J
-  {
-    auto load = [&]<int C>(mid_ic<C>) {  // chunk C holds J = 8 C + 7 - U
-      mid_static_for<kMidU>([&]<int U>(mid_ic<U>) {
-        constexpr int J = C * kMidU + (kMidU - 1 - U), RB = (J * (J + 1)) / 2;
-        blo[C & 1][U] = pln[RB];
-      });
-    };
-    auto run = [&]<int C, bool GUARD>(mid_ic<C>, std::bool_constant<GUARD>) {
-      mid_static_for<kMidU>([&]<int U>(mid_ic<U>) {
-        constexpr int J = C * kMidU + (kMidU - 1 - U);
-        if constexpr (J >= 1) {
-          if (!GUARD || J <= K1) mid_fma_below<J>(tlo, blo[C & 1][U], lane_bcast(tlo, J));
-        }
-      });
-    };
-    bool first = true;
-    mid_static_for<NC>([&]<int CR>(mid_ic<CR>) {
-      constexpr int C = NC - 1 - CR;
-      if (C * kMidU <= K1) {
-        if (first) load(mid_ic<C>{});
-        first = false;
-        if constexpr (C >= 1) load(mid_ic<C - 1>{});
-        if (C * kMidU + kMidU - 1 > K1) run(mid_ic<C>{}, std::true_type{});  // the top chunk of a system smaller than 64
-        else run(mid_ic<C>{}, std::false_type{});
-      }
-    });
-  }
-  return MidPair{tlo, thi};
-}
-
-// temp (LDS, K entries, original order) <- P^T L^-T D^-1 L^-1 P temp  (oracle_ldlt_solve)
-__device__ inline void mid_solve(const int K_, const double *Lpk_, const double *LDg_, const int *perm_, double *temp_, const int lane,
-                                 const bool rows_engine)
-{
-  const int K = ubig(K_);
-  LDS_CI(perm, perm_);
-  LDS_D(temp, temp_);
-  const bool vlo = lane < K, vhi = lane + kWave < K;
-  MidPair t{vlo ? temp[perm[vlo ? lane : 0]] : 0.0, vhi ? temp[perm[vhi ? lane + kWave : 0]] : 0.0};
-  wave_sync();  // (every lane has read its right-hand side entries)
-  if (rows_engine) {
-    const rows::Pair r = rows::row_sweeps_any(K, Lpk_ + kMidZ, LDg_, rows::Pair{t.lo, t.hi}, lane);
-    t = MidPair{r.lo, r.hi};
-  } else {
-    t = mid_sweeps(K, Lpk_, LDg_, t, lane);
-  }
-  if (vlo) temp[perm[lane]] = t.lo;
-  if (vhi) temp[perm[lane + kWave]] = t.hi;
-  wave_sync();
-}
-
 struct BigWs {
   double *H, *LT, *Hs, *Dg;                                                // k*k each, k
   double *sx, *xus, *dxus, *Px, *Aty, *hx;                                 // n each
@@ -867,22 +654,14 @@ size_t qp_dense_big_ws_doubles(int n, int m)
 }
 // LDS configuration of a launch: the row pool (big_row_cap) and whether the diagonal blocks are cached.  A lone QP wants
 // both; a batch must not be left with ONE wave per CU -- (4, 301) with the diagonal cache is 122 KB, without it 79 KB.
-struct BigLds { bool diag_cache; int rcap; size_t bytes; bool packed; };
+struct BigLds { bool diag_cache; int rcap; size_t bytes; };
 static BigLds big_lds_config(int n, int m, int64_t batch)
 {
   const size_t per_row = kBP * sizeof(double) + sizeof(int), cu = 160 * 1024;
-  // k <= 128: the packed engine -- the whole factor in LDS (it takes the place of the row pool), no diagonal cache.
-  // SFB_QP_BIG_PACKED=0 (A/B knob) keeps the tile / list engine.
-  static const bool packed_off = [] { const char *v = sfb::knob("SFB_QP_BIG_PACKED"); return v && v[0] == '0'; }();
-  if (n + m <= kMidMaxK && !packed_off) {
-    const int rc = (int)((mid_lds_doubles(n + m) + kBP - 1) / kBP);
-    return BigLds{false, rc, big_lds_fixed_bytes(n, m, false) + (size_t)rc * per_row, true};
-  }
-  static const bool force_roomy = [] { const char *v = sfb::knob("SFB_BIG_ROOMY"); return v && v[0] == '1'; }();  // A/B knob
-  const bool roomy = batch < kRoomyBatch || force_roomy;
+  const bool roomy = batch < kRoomyBatch;
   auto make = [&](bool dc) {
     const int rc = big_row_cap(n, m, roomy, dc);
-    return BigLds{dc, rc, big_lds_fixed_bytes(n, m, dc) + (size_t)rc * per_row, false};
+    return BigLds{dc, rc, big_lds_fixed_bytes(n, m, dc) + (size_t)rc * per_row};
   };
   const BigLds with = make(true);
   if (roomy || n + m > kDiagCacheK) return with;
@@ -895,7 +674,7 @@ size_t qp_dense_big_lds_bytes(int n, int m, int64_t batch) { return big_lds_conf
 
 template<int RB>
 __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParams kp, const QpBatch g, double *__restrict__ gws,
-                                                         const size_t wsd, const int rcap, const int dck, const int packed)
+                                                         const size_t wsd, const int rcap, const int dck)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int lane = threadIdx.x;
@@ -1011,9 +790,6 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
   const unsigned long long t0_ticks = wall_clock64();  // :376
   BP_T(u0);
   // ---- dense KKT fill :399-404 (row-major lower triangle of the k x k array H) ----
-  // (packed engine: the matrix is built, factorised and kept in LDS -- the pool `cval` holds the packed triangle --
-  //  and never exists in the workspace; same entries, same operations)
-  const BigMatPacked Hl{(lds_d *)cval + kMidZ};
   const BigMatGlobal Hg{w.H, (size_t)k};
   auto kkt_fill = [&](const auto Hm) {
     for (int r = 0; r < n; ++r)
@@ -1031,17 +807,14 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
       if (lane == 0) Hm.at(n + i, n + i) = 1.0 / (-w.rho[i]);
     }
   };
-  if (packed) kkt_fill(Hl);
-  else kkt_fill(Hg);
+  kkt_fill(Hg);
   wave_sync();
   BP_T(u1);
-  const int fact_ok = packed ? big_ldlt_factor(k, Hl, perm, temp, reinterpret_cast<int *>(t), lane)
-                             : big_ldlt_factor(k, Hg, perm, temp, reinterpret_cast<int *>(t), lane);  // :428-433
+  const int fact_ok = big_ldlt_factor(k, Hg, perm, temp, reinterpret_cast<int *>(t), lane);  // :428-433
   if (!fact_ok) ret_code = SFB_QP_UNKNOWN;
   BP_T(u2);
   const bool dcache = k <= dck;
-  if (packed) mid_finish_factor(k, cval, LDg, lane);
-  else big_transpose<RB>(k, w.H, k, w.LT, w.Dg, fnz, bnz, dcache ? dblk : nullptr, LDg, cidx, cval, cflag, rcap, lane);
+  big_transpose<RB>(k, w.H, k, w.LT, w.Dg, fnz, bnz, dcache ? dblk : nullptr, LDg, cidx, cval, cflag, rcap, lane);
   BP_T(u3);
   BP_ADD(8, u0, u1);
   BP_ADD(9, u1, u2);
@@ -1156,79 +929,6 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
   uint32_t iter        = 0;
   const uint32_t sci   = kp.stop_check_iter;
   const uint32_t maxit = kp.max_iter;
-  if (packed) {
-    // PACKED MODE (k <= 128): the whole iteration in registers.  Lane l carries rows l and l + 64 of the PERMUTED system
-    // for the entire loop -- variable v = perm[row], its iterate (x, or y and z) and its constants -- so an iteration is
-    // right-hand side, the two sweeps over the LDS-resident factor (mid_sweeps) and the update, without touching LDS
-    // vectors or a barrier; only the iterations with a stopping check scatter the un-scaled iterates to the workspace.
-    // Same expressions as the LDS loop below (and as the k <= 64 kernels, which fold the permutation the same way).
-    struct Half { bool isx, isc; int xi, ci; double qc, sxv, syv, rho, rinv, lo, hi, x, y, z; };
-    auto mk = [&](const int row) {
-      Half h{};
-      const bool in = row < k;
-      const int v   = in ? perm[row] : 0;
-      h.isx = in && v < n;  h.isc = in && v >= n;
-      h.xi = h.isx ? v : 0; h.ci = h.isc ? v - n : 0;
-      h.qc   = h.isx ? Lqc[h.xi] : 0.0;
-      h.sxv  = h.isx ? w.sx[h.xi] : 1.0;
-      h.syv  = h.isc ? w.sy[h.ci] : 1.0;
-      h.rho  = h.isc ? Lrho[h.ci] : 1.0;
-      h.rinv = h.isc ? Lrinv[h.ci] : 1.0;
-      h.lo   = h.isc ? Llo[h.ci] : 0.0;
-      h.hi   = h.isc ? Lhi[h.ci] : 0.0;
-      h.x = h.isx ? xs[h.xi] : 0.0;
-      h.y = h.isc ? ys[h.ci] : 0.0;
-      h.z = h.isc ? zs[h.ci] : 0.0;
-      return h;
-    };
-    Half ha = mk(lane), hb = mk(lane + kWave);
-    uint32_t next_chk = (sci >= 2) ? 1u : 0xFFFFFFFFu;  // iter % sci == 1 (:465) without a division per iteration
-    auto rhs = [&](const Half &h) { return h.isx ? (kp.sigma * h.x - h.qc) : (h.isc ? (h.z - h.rinv * h.y) : 0.0); };  // :450-451
-    auto upd = [&](Half &h, const double t, const bool chk) {                                                          // :470-477
-      const double xo = h.x, yo = h.y;
-      h.x       = kp.alpha * t + kp.alpha_comp * h.x;
-      double zn = kp.alpha * (h.rinv * t) + kp.alpha_comp * (h.rinv * h.y) + h.z;
-      zn        = (zn < h.lo) ? h.lo : zn;
-      zn        = (h.hi < zn) ? h.hi : zn;
-      h.y       = kp.alpha_comp * h.y + kp.alpha * t + h.rho * h.z - h.rho * zn;
-      h.z       = zn;
-      if (chk) {  // :481-485
-        if (h.isx) {
-          w.xus[h.xi]  = h.sxv * h.x;
-          w.dxus[h.xi] = h.sxv * (h.x - xo);
-        }
-        if (h.isc) {
-          w.yus[h.ci]  = h.syv * h.y / c;
-          w.zus[h.ci]  = (1.0 / h.syv) * h.z;
-          w.dyus[h.ci] = h.syv * (h.y - yo) / c;
-        }
-      }
-    };
-    for (; iter != maxit && ret_code < 0; ++iter) {
-      MidPair t;                                                                       // :462
-      if (packed == 2) {
-        const rows::Pair r = rows::row_sweeps_any(k, cval + kMidZ, LDg, rows::Pair{rhs(ha), rhs(hb)}, lane);
-        t = MidPair{r.lo, r.hi};
-      } else {
-        t = mid_sweeps(k, cval, LDg, MidPair{rhs(ha), rhs(hb)}, lane);
-      }
-      const bool chk  = (iter == next_chk);                                          // :465
-      if (chk) next_chk += sci;
-      upd(ha, t.lo, chk);
-      upd(hb, t.hi, chk);
-      if (chk) {
-        wave_sync();
-        ret_code = stop_check();
-        if (ret_code < 0 && max_time_exceeded(kp.max_time_ns, t0_ticks)) ret_code = SFB_QP_MAX_TIME;  // :504-507
-      }
-    }
-    // the iterate back to the LDS arrays in natural order (polish and the report read them there)
-    if (ha.isx) xs[ha.xi] = ha.x;
-    if (hb.isx) xs[hb.xi] = hb.x;
-    if (ha.isc) { ys[ha.ci] = ha.y; zs[ha.ci] = ha.z; }
-    if (hb.isc) { ys[hb.ci] = hb.y; zs[hb.ci] = hb.z; }
-    wave_sync();
-  } else
   for (; iter != maxit && ret_code < 0; ++iter) {
     for (int j = lane; j < n; j += kWave) temp[j] = kp.sigma * xs[j] - Lqc[j];               // :450
     for (int i = lane; i < m; i += kWave) temp[n + i] = zs[i] - Lrinv[i] * ys[i];           // :451
@@ -1301,10 +1001,9 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
     // Hs: the symmetric K x K matrix of the residual; Hp = Hs + diag(delta, -delta) lower row-major for the LDLT (:159-177)
     double *Hs = w.Hs, *Hp = w.H;
     const BigMatGlobal Hpg{Hp, (size_t)K};
-    auto polish_fill = [&](const auto Hm, const bool lds) {
+    auto polish_fill = [&](const auto Hm) {
       for (int e = lane; e < K * K; e += kWave) Hs[e] = 0.0;
-      if (lds) { for (int e = lane; e < (K * (K + 1)) / 2; e += kWave) Hm.at(0, e) = 0.0; }  // (the packed triangle is contiguous)
-      else { for (int e = lane; e < K * K; e += kWave) Hp[e] = 0.0; }
+      for (int e = lane; e < K * K; e += kWave) Hp[e] = 0.0;
       wave_sync();
       for (int i = 0; i < n; ++i)
         for (int j = i + lane; j < n; j += kWave) {
@@ -1328,8 +1027,7 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
       for (int i = lane; i < n; i += kWave) Hm.at(i, i) += kp.delta;
       for (int a = lane; a < na; a += kWave) Hm.at(n + a, n + a) -= kp.delta;
     };
-    if (packed) polish_fill(Hl, true);
-    else polish_fill(Hpg, false);
+    polish_fill(Hpg);
     // h (:179-182) and t = 0
     for (int j = lane; j < n; j += kWave) w.hx[j] = -c * (w.sx[j] * q[j]);
     for (int i = lane; i < m; i += kWave) {
@@ -1339,10 +1037,8 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
     }
     for (int e = lane; e < K; e += kWave) aux[e] = 0.0;  // aux = t of the refinement
     wave_sync();
-    if (packed ? big_ldlt_factor(K, Hl, perm, temp, reinterpret_cast<int *>(t), lane)
-               : big_ldlt_factor(K, Hpg, perm, temp, reinterpret_cast<int *>(t), lane)) {
-      if (packed) mid_finish_factor(K, cval, LDg, lane);
-      else big_transpose<RB>(K, Hp, K, w.LT, w.Dg, fnz, bnz, dcache ? dblk : nullptr, LDg, cidx, cval, cflag, rcap, lane);
+    if (big_ldlt_factor(K, Hpg, perm, temp, reinterpret_cast<int *>(t), lane)) {
+      big_transpose<RB>(K, Hp, K, w.LT, w.Dg, fnz, bnz, dcache ? dblk : nullptr, LDg, cidx, cval, cflag, rcap, lane);
       for (uint32_t it = 0; it != kp.polish_iter; ++it) {  // :193-195  t += Hp^-1 (h - Hs t)
         for (int i = lane; i < K; i += kWave) {
           double s = 0.0;
@@ -1350,8 +1046,7 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
           temp[i] = ((i < n) ? w.hx[i] : w.Ax[i - n]) - s;
         }
         wave_sync();
-        if (packed) mid_solve(K, cval, LDg, perm, temp, lane, packed == 2);
-        else big_solve<RB>(K, Hp, w.LT, w.Dg, K, perm, fnz, bnz, dcache ? dblk : nullptr, LDg, cidx, cval, cflag, t, temp, lane);
+        big_solve<RB>(K, Hp, w.LT, w.Dg, K, perm, fnz, bnz, dcache ? dblk : nullptr, LDg, cidx, cval, cflag, t, temp, lane);
         for (int i = lane; i < K; i += kWave) aux[i] += temp[i];
         wave_sync();
       }
@@ -1398,20 +1093,16 @@ __global__ void __launch_bounds__(64) qp_dense_big_kernel(const DenseKernelParam
 hipError_t qp_dense_big_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, double *workspace, hipStream_t stream)
 {
   const int k = kp.n + kp.m;
-  if (k > kBigMaxK) return hipErrorInvalidValue;
+  if (k > kBigMaxK || k <= kDenseMidMaxK) return hipErrorInvalidValue;  // (up to 128: qp_dense_mid.hip, everything on chip)
   const BigLds cfg = big_lds_config(kp.n, kp.m, batch);
   const size_t lds = cfg.bytes;
   const int rcap = cfg.rcap, dck = cfg.diag_cache ? kDiagCacheK : 0;
   const size_t wsd = qp_dense_big_ws_doubles(kp.n, kp.m);
   const dim3 grid((unsigned)batch), block(kWave);
   const int rb = (k + kWave - 1) / kWave;
-  // packed engine: 2 = block sweeps with DPP pivot broadcast (sweep_rows.h), 1 = v_readlane sweeps (SFB_QP_MID_ROWS=0, A/B)
-  static const bool rows_off = [] { const char *v = sfb::knob("SFB_QP_MID_ROWS"); return v && v[0] == '0'; }();
-  const int packed = cfg.packed ? (rows_off ? 1 : 2) : 0;
-  if (rb <= 2) hipLaunchKernelGGL((qp_dense_big_kernel<2>), grid, block, lds, stream, kp, g, workspace, wsd, rcap, dck, packed);
-  else if (rb <= 4) hipLaunchKernelGGL((qp_dense_big_kernel<4>), grid, block, lds, stream, kp, g, workspace, wsd, rcap, dck, 0);
-  else if (rb <= 8) hipLaunchKernelGGL((qp_dense_big_kernel<8>), grid, block, lds, stream, kp, g, workspace, wsd, rcap, dck, 0);
-  else hipLaunchKernelGGL((qp_dense_big_kernel<kRB>), grid, block, lds, stream, kp, g, workspace, wsd, rcap, dck, 0);
+  if (rb <= 4) hipLaunchKernelGGL((qp_dense_big_kernel<4>), grid, block, lds, stream, kp, g, workspace, wsd, rcap, dck);
+  else if (rb <= 8) hipLaunchKernelGGL((qp_dense_big_kernel<8>), grid, block, lds, stream, kp, g, workspace, wsd, rcap, dck);
+  else hipLaunchKernelGGL((qp_dense_big_kernel<kRB>), grid, block, lds, stream, kp, g, workspace, wsd, rcap, dck);
   return hipGetLastError();
 }
 

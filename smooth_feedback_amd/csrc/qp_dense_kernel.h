@@ -56,7 +56,6 @@ hipError_t qp_dense_mid_launch(const DenseKernelParams &kp, int64_t batch, const
 // doubles of scratch for the kernel's stamps -- the caller allocates batch x 16 doubles
 hipError_t qp_dense_mid_trace_launch(const DenseKernelParams &kp, int64_t batch, const QpBatch &g, hipStream_t stream, double *trace, int trace_cap,
                                      double *phase_us = nullptr);
-bool qp_dense_mid_enabled();  // SFB_QP_MID=0 (A/B, tests): the kernels these sizes had before
 
 hipError_t qp_dense_launch(const DenseKernelParams &kp, int64_t batch, const double *P, const double *q,
                            const double *A, const double *l, const double *u, const double *wx, const double *wy,

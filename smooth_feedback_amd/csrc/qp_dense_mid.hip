@@ -1465,12 +1465,6 @@ __global__ void __launch_bounds__(64, WPE) qp_dense_mid_loop_kernel(const DenseK
 
 }  // namespace
 
-bool qp_dense_mid_enabled()
-{
-  static const bool off = [] { const char *v = sfb::knob("SFB_QP_MID"); return v && v[0] == '0'; }();
-  return !off;
-}
-
 size_t qp_dense_mid_lds_bytes(int n, int m) { return (size_t)mid_layout(n, m).total * sizeof(double); }
 
 namespace {

@@ -2539,10 +2539,7 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
 {
   if (pl.Aorig != nullptr && (fallback == nullptr || fallback_ws == nullptr || aux == nullptr)) return hipErrorInvalidValue;
   const bool pruned = pl.Aorig != nullptr;
-  size_t lds = (size_t)std::max(pl.lds_doubles, pruned ? fallback->lds_doubles : 0) * sizeof(double);
-  // SFB_SP_WAVES_PER_CU (tuning): cap the resident workgroups per CU by padding the LDS request
-  if (const char *wpc = sfb::knob("SFB_SP_WAVES_PER_CU"); wpc && atoi(wpc) > 0)
-    lds = std::max(lds, std::min<size_t>(160 * 1024, (size_t)(160 * 1024 / atoi(wpc)) & ~(size_t)15));
+  const size_t lds = (size_t)std::max(pl.lds_doubles, pruned ? fallback->lds_doubles : 0) * sizeof(double);
   const size_t wsd = qp_sparse_ws_doubles(pl);
   // below this many busy waves the sweeps use plain loads (see the kernel); SFB_SP_LEAN_WAVES overrides (tuning)
   const char *lw        = sfb::knob("SFB_SP_LEAN_WAVES");
@@ -2621,9 +2618,8 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     // waves' factors fit the Infinity Cache, non-temporal masked ones beyond (as in the single launch).
     const double stream_bytes = (double)(pl.funits + pl.bunits) * 128.0 * sizeof(double), mall = 256.0 * 1024.0 * 1024.0;
     unsigned g_lo = std::min(grid, ((unsigned)std::max(256.0, 0.70 * mall / stream_bytes) + 32u) / 64u * 64u), g_hi = grid;
-    if (const char *g3 = sfb::knob("SFB_SP_GRID3"); g3 && atoi(g3) > 0) g_lo = g_hi = std::min(grid, (unsigned)atoi(g3));
     // LAT form of the second launch (see sp_solve_item): the loop's vectors in LDS, two waves per CU -- when the vectors fit
-    // (the rank kernel sizes the launch; SFB_SP_LAT_MAXW restores a threshold on the wanted waves); polish and
+    // (the rank kernel sizes the launch); polish and
     // report of the survivors then follow as a launch of their own on the whole chip (they are latency-bound and want every
     // wave; inside the few waves of the loop they took 40 % of the wave time).  Otherwise: the standard kernel, loop and
     // polish in one launch.  Both are enqueued, the blocks of the form that was not chosen leave at once.
@@ -2641,28 +2637,23 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
           hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qp_sparse_kernel<true>, kWave, lds_lat) == hipSuccess &&
           hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
         lat_hi = std::min<int>(per_cu * cus, (int)grid);
-      const char *ll = sfb::knob("SFB_SP_LAT_LO");
-      lat_lo = std::min(lat_hi, ll ? atoi(ll) : 448);
-      if (const char *g3 = sfb::knob("SFB_SP_GRID3"); g3 && atoi(g3) > 0) lat_lo = lat_hi = std::min(lat_hi, atoi(g3));
+      lat_lo = std::min(lat_hi, 448);
     }
-    const char *lm    = sfb::knob("SFB_SP_LAT_MAXW");
     // ... for any amount of work: two LAT waves per CU (loop vectors in LDS, factors from the Infinity Cache) also move more
     // item-iterations per microsecond (21) than the standard form on the whole chip (17-18.5): 12 288 agents 90.7 -> 80.9 ms,
     // 16 384: 120.6 -> 106.4, 32 768: 218.6 -> 205.3 (scripts/r3/batch_sweep.sh)
-    const int lat_max = lm ? atoi(lm) : 0x7FFFFFFF;
+    const int lat_max = 0x7FFFFFFF;
     hipLaunchKernelGGL(sp_rank_kernel, dim3(1), dim3(kRankThreads), 0, stream, keys, (int)batch, order2, count, (int)g_lo, (int)g_hi,
                        lat_lo, lat_hi, lat_max);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    const char *lw3 = sfb::knob("SFB_SP_LEAN_WAVES3");
-    const char *sl3 = sfb::knob("SFB_SP_SLICE3");
-    const uint32_t slice3 = sl3 ? (uint32_t)std::max(1, atoi(sl3)) : 0x40000000u;
+    const uint32_t slice3 = 0x40000000u;
     if (lat_hi > 0) {
       e = launch((unsigned)lat_hi, qarg, 0x7FFFFFFF, phases_pack(PH_ADMM, PH_ADMM), order2, slice3, nullptr, count, 1, true, lds_lat);
       if (e != hipSuccess) return e;
       e = launch(grid, qarg, lean_waves, phases_pack(PH_FINISH, PH_FINISH), order2, slice3, nullptr, count + 4, 1);
       if (e != hipSuccess) return e;
     }
-    return launch(g_hi, qarg, lw3 ? atoi(lw3) : (int)std::max(512.0, mall / stream_bytes), phases_pack(PH_ADMM, PH_FINISH), order2, slice3,
+    return launch(g_hi, qarg, (int)std::max(512.0, mall / stream_bytes), phases_pack(PH_ADMM, PH_FINISH), order2, slice3,
                   nullptr, count, lat_hi > 0 ? 0 : -1);
   }
   if (const char *fl = sfb::knob("SFB_SP_FORCE_LAT"); !phased && fl && atoi(fl) == 1) {  // measurements: the LAT form for a whole launch
@@ -2675,11 +2666,9 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
   // grid of the ADMM phase: items whose two schedule-ordered factor copies fit ~70 % of the MALL
   const double stream_bytes = (double)(pl.funits + pl.bunits) * 128.0 * sizeof(double);
   unsigned grid2 = (unsigned)std::max(256.0, 0.70 * 256.0 * 1024.0 * 1024.0 / stream_bytes);
-  if (const char *g2 = sfb::knob("SFB_SP_GRID2"); g2 && atoi(g2) > 0) grid2 = (unsigned)atoi(g2);
   grid2 = std::min(grid2, grid);
   // plain (cache-allocating) loads in the ADMM phase unless the grid is too large for the MALL anyway
-  const char *lw2       = sfb::knob("SFB_SP_LEAN_WAVES2");
-  const int lean_waves2 = lw2 ? atoi(lw2) : (grid2 < grid ? 0x7FFFFFFF : lean_waves);
+  const int lean_waves2 = grid2 < grid ? 0x7FFFFFFF : lean_waves;
   hipError_t e = launch(grid, qarg, lean_waves, phases_pack(PH_SETUP, PH_SETUP), order);
   if (e != hipSuccess) return e;
   e = launch(grid2, qarg, lean_waves2, phases_pack(PH_ADMM, PH_ADMM), order);

@@ -534,8 +534,7 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
       segs.clear();
       constexpr int kMinCols = 8;
       std::vector<char> in_lds(k, 0);
-      const char *no_lds = sfb::knob("SFB_PLAN_NO_LDS");  // A/B knob: every column a top column (accumulators in HBM)
-      for (int j = (no_lds && no_lds[0] == '1') ? -1 : k - 1; j >= 0;) {
+      for (int j = k - 1; j >= 0;) {
         const int c0 = fdesc[j], nc = j - c0 + 1, nL = FLp[j + 1] - FLp[c0];
         const int reserve = std::max(2 * maxR1[j], 384);  // panel + multipliers of the supernodes formed below
         const int ccj = FLp[j + 1] - FLp[j];
@@ -1023,8 +1022,7 @@ bool build_sparse_plan(int n, int m, const int32_t *Pp, const int32_t *Pi, const
     // the scratch entry k, whatever value the register holds).  full0/full1: the longest run of completely filled
     // units, cut to multiples of 8; the kernel uses unmasked loads there.
     xmask.assign((size_t)units + 2 * SparsePlanHost::kSweepPad, 63);  // padding units: lane 0 only
-    // SFB_PLAN_BANKS=0: the natural placement (slot e at lane e % lanes, half e / lanes) instead of the bank-aware one
-    const bool bank_aware = [] { const char *v = sfb::knob("SFB_PLAN_BANKS"); return !(v && v[0] == '0'); }();
+    constexpr bool bank_aware = true;  // (the natural placement -- slot e at lane e % lanes, half e / lanes -- is what the model is compared with)
     long cyc_before = 0, cyc_after = 0;
     UnitPlacer up;
     const int search_passes = ns <= 20000 ? 1 : 0;  // (one pass does nearly everything; the large whole-pattern fallback plans get the greedy placement only)

@@ -29,3 +29,26 @@ def sfb():
         g.build()
     import smooth_feedback_amd
     return smooth_feedback_amd
+
+
+@pytest.fixture
+def knobs(sfb):
+    """Debug knobs of libsfb.so (sfb_debug_set, csrc/knobs.h) for one test: knobs.set(SFB_SP_GRID=4), knobs.clear("SFB_SP_GRID");
+    everything the test set is cleared afterwards.  The library reads no environment variable."""
+    class K:
+        def __init__(self):
+            self.touched = set()
+
+        def set(self, **kw):
+            for k, v in kw.items():
+                sfb.debug_set(k, v)
+                self.touched.add(k)
+
+        def clear(self, *names):
+            for k in names:
+                sfb.debug_set(k, None)
+
+    k = K()
+    yield k
+    for name in k.touched:
+        sfb.debug_set(name, None)

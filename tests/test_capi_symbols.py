@@ -99,3 +99,27 @@ def test_header_is_plain_c_and_fronts_compile_standalone(tmp_path):
                    "#include <smooth/feedback/asif.hpp>\n#include <smooth/feedback/mesh.hpp>\n"
                    "int main() { smooth::feedback::QPSolverParams p; smooth::feedback::QuadraticProgram<2, 3> q; (void)p; (void)q; return 0; }\n")
     subprocess.run(["g++", "-std=c++20", "-Wall", "-fsyntax-only", "-I", os.path.join(root, "include"), str(cpp)], check=True)
+
+
+def test_debug_knobs_go_through_one_entry_point_and_never_the_environment(sfb):
+    """sfb_debug_set is the only way to steer a launch shape / engine choice: it knows its names (csrc/knobs.h), and no
+    translation unit of libsfb.so reads the environment."""
+    import glob
+    import os
+    import re
+    from smooth_feedback_amd import _capi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert _capi.lib.sfb_debug_set(b"SFB_SP_GRID", b"4") == _capi.SFB_OK
+    assert _capi.lib.sfb_debug_set(b"SFB_SP_GRID", None) == _capi.SFB_OK          # cleared
+    assert _capi.lib.sfb_debug_set(b"SFB_NO_SUCH_KNOB", b"1") == _capi.SFB_ERR_INVALID_ARG
+    assert "unknown knob" in _capi.lib.sfb_last_error().decode()
+    assert _capi.lib.sfb_debug_set(None, b"1") == _capi.SFB_ERR_INVALID_ARG
+    names = set(re.findall(r'"(SFB_[A-Z0-9_]+)"', open(os.path.join(root, "smooth_feedback_amd", "csrc", "knobs.cpp")).read()))
+    assert 10 <= len(names) <= 16
+    used = set()
+    for f in glob.glob(os.path.join(root, "smooth_feedback_amd", "csrc", "*")):
+        if os.path.isfile(f) and f.endswith((".hip", ".cpp", ".h")):
+            text = open(f).read()
+            assert "getenv" not in text, f                                          # the library reads no environment variable
+            used |= set(re.findall(r'knob\("(SFB_[A-Z0-9_]+)"\)', text))
+    assert used <= names, used - names                                              # every knob that is read can be set

@@ -22,15 +22,16 @@ def test_randomised_parity_sweep(script, n):
 
 
 @pytest.mark.parametrize("script,n,knobs", [
-    ("fuzz_dense.py", 300, {"SFB_QP_DENSE_PA_LDS": "1"}),                      # 48 < k <= 64 with LDS copies of P and A (default: global)
-    ("fuzz_sparse.py", 150, {"SFB_SP_GRID": "4", "BMAX": "40"}),               # tiny grid: time slicing + launch in predicted order (LAT loop launch)
-    ("fuzz_sparse.py", 100, {"SFB_SP_GRID": "3", "SFB_SP_PAUSE": "2", "BMAX": "24"}),
-    ("fuzz_sparse.py", 100, {"SFB_SP_FORCE_LAT": "1"}),                        # the LAT form (chained sweeps, vectors in LDS) for whole launches
-    ("fuzz_sparse.py", 100, {"SFB_SP_GRID": "4", "SFB_SP_LAT": "0", "BMAX": "40"}),  # predicted order with the standard-form loop launch
+    ("fuzz_sparse.py", 150, {"KNOBS": "SFB_SP_GRID=4", "BMAX": "40"}),            # tiny grid: time slicing + launch in predicted order (LAT loop launch)
+    ("fuzz_sparse.py", 100, {"KNOBS": "SFB_SP_GRID=3,SFB_SP_PAUSE=2", "BMAX": "24"}),
+    ("fuzz_sparse.py", 100, {"KNOBS": "SFB_SP_FORCE_LAT=1"}),                      # the LAT form (chained sweeps, vectors in LDS) for whole launches
+    ("fuzz_sparse.py", 100, {"KNOBS": "SFB_SP_GRID=4,SFB_SP_LAT=0", "BMAX": "40"}),  # predicted order with the standard-form loop launch
+    ("fuzz_sparse.py", 150, {"KNOBS": "SFB_PLAN_UNITS=0"}),                        # the supernodal engine of the numeric factorisation for every plan
+    ("fuzz_sparse.py", 100, {"KNOBS": "SFB_PLAN_UNITS=0,SFB_SP_GRID=4", "BMAX": "40"}),
 ])
 def test_randomised_parity_sweep_of_the_other_launch_shapes(script, n, knobs):
-    """The same sweeps with the knobs that select the non-default kernels / launch shapes (read once per process, hence
-    the subprocesses): results never depend on them."""
+    """The same sweeps with the debug knobs that select the non-default engines / launch shapes (the scripts hand KNOBS to
+    sfb_debug_set): results never depend on them."""
     env = dict(os.environ, N=str(n), SEED="31337", **knobs)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script)], env=env, cwd=os.path.join(ROOT, "scripts"),
                          capture_output=True, text=True, timeout=900)

@@ -13,20 +13,14 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(params=["auto", "masked", "plain"])
-def sweep_mode(request):
+def sweep_mode(request, knobs):
     """The sparse kernel streams the factor with plain loads or, while many waves are resident, with loads masked
     to the lanes that carry entries (no HBM traffic for the padding of the sweep schedule).  'auto' is the
-    product's choice (plain for these small batches); the other two force one form (SFB_SP_LEAN_WAVES is read at
+    product's choice (plain for these small batches); the other two force one form (debug knob SFB_SP_LEAN_WAVES, read at
     every launch).  All three must agree with the oracle bit for bit."""
-    import os
-    old = os.environ.get("SFB_SP_LEAN_WAVES")
     if request.param != "auto":
-        os.environ["SFB_SP_LEAN_WAVES"] = "-1" if request.param == "masked" else "1000000000"
+        knobs.set(SFB_SP_LEAN_WAVES="-1" if request.param == "masked" else "1000000000")
     yield request.param
-    if old is None:
-        os.environ.pop("SFB_SP_LEAN_WAVES", None)
-    else:
-        os.environ["SFB_SP_LEAN_WAVES"] = old
 
 
 @pytest.mark.parametrize("variant,K,batch", [(6, 10, 48), (6, 50, 32), (12, 50, 24)])
@@ -130,7 +124,7 @@ def test_pruned_plan_guard_falls_back_to_the_whole_pattern(sfb, oracle, batch, n
 
 
 @pytest.mark.parametrize("grid,slice_iters", [(7, 25), (32, 50), (64, 1)])
-def test_time_sliced_launch_equals_one_block_per_item(sfb, oracle, grid, slice_iters, monkeypatch):
+def test_time_sliced_launch_equals_one_block_per_item(sfb, oracle, grid, slice_iters, knobs):
     """Batches larger than the chip holds run on a persistent grid: an item that has used its slice while others
     wait is suspended (its state stays in its workspace) and continued later by another block.  Forced here with a
     tiny grid and short slices (SFB_SP_GRID / SFB_SP_SLICE are test / tuning knobs read at every launch): the results
@@ -145,14 +139,14 @@ def test_time_sliced_launch_equals_one_block_per_item(sfb, oracle, grid, slice_i
     prm = sfb.QPSolverParams(max_iter=4000)
     for kp in (None, keep):
         plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K), keep=kp)
-        monkeypatch.setenv("SFB_SP_SLICE", "0")
+        knobs.set(SFB_SP_SLICE="0")
         base = plan.solve_batch_host(Px, q, Av, l, u, prm)
-        monkeypatch.setenv("SFB_SP_SLICE", str(slice_iters))
-        monkeypatch.setenv("SFB_SP_GRID", str(grid))
+        knobs.set(SFB_SP_SLICE=str(slice_iters))
+        knobs.set(SFB_SP_GRID=str(grid))
         r = plan.solve_batch_host(Px, q, Av, l, u, prm)
         r2 = plan.solve_batch_host(Px, q, Av, l, u, prm, warm_x=0.5 * r.primal, warm_y=0.5 * r.dual)
-        monkeypatch.delenv("SFB_SP_GRID")
-        monkeypatch.setenv("SFB_SP_SLICE", "0")
+        knobs.clear("SFB_SP_GRID")
+        knobs.set(SFB_SP_SLICE="0")
         base2 = plan.solve_batch_host(Px, q, Av, l, u, prm, warm_x=0.5 * r.primal, warm_y=0.5 * r.dual)
         for a, b in ((r, base), (r2, base2)):
             assert np.array_equal(a.code, b.code) and np.array_equal(a.iter, b.iter)
@@ -169,8 +163,8 @@ def test_time_sliced_launch_equals_one_block_per_item(sfb, oracle, grid, slice_i
         assert np.array_equal(r.iter[5:6], ref5["iter"]) and np.array_equal(r.primal[5:6], ref5["x"])
 
 
-@pytest.mark.parametrize("grid,grid2,slice_iters", [(16, 5, 25), (48, 48, 50), (32, 9, 1000000)])
-def test_phased_launch_equals_the_single_kernel(sfb, oracle, grid, grid2, slice_iters, monkeypatch):
+@pytest.mark.parametrize("grid,slice_iters", [(16, 25), (48, 50), (9, 1000000)])
+def test_phased_launch_equals_the_single_kernel(sfb, oracle, grid, slice_iters, knobs):
     """SFB_SP_PHASED=1 splits a time-sliced launch into three kernels (setup / ADMM loop / polish + report, each with
     its own grid; the item's state travels through its workspace header like a suspended item's).  Same bits as the
     single kernel: plain and pruned plans, cold and warm start, an item on the fallback path (solved completely in the
@@ -185,13 +179,12 @@ def test_phased_launch_equals_the_single_kernel(sfb, oracle, grid, grid2, slice_
     for prm in (sfb.QPSolverParams(max_iter=4000), sfb.QPSolverParams(max_iter=60, polish=False)):
         for kp in (None, keep):
             plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K), keep=kp)
-            monkeypatch.setenv("SFB_SP_SLICE", str(slice_iters))
-            monkeypatch.setenv("SFB_SP_GRID", str(grid))
-            monkeypatch.setenv("SFB_SP_PHASED", "0")
+            knobs.set(SFB_SP_SLICE=str(slice_iters))
+            knobs.set(SFB_SP_GRID=str(grid))
+            knobs.set(SFB_SP_PHASED="0")
             base = plan.solve_batch_host(Px, q, Av, l, u, prm)
             base2 = plan.solve_batch_host(Px, q, Av, l, u, prm, warm_x=0.5 * base.primal, warm_y=0.5 * base.dual)
-            monkeypatch.setenv("SFB_SP_PHASED", "1")
-            monkeypatch.setenv("SFB_SP_GRID2", str(grid2))
+            knobs.set(SFB_SP_PHASED="1")
             r = plan.solve_batch_host(Px, q, Av, l, u, prm)
             r2 = plan.solve_batch_host(Px, q, Av, l, u, prm, warm_x=0.5 * base.primal, warm_y=0.5 * base.dual)
             for a, b in ((r, base), (r2, base2)):
@@ -201,12 +194,11 @@ def test_phased_launch_equals_the_single_kernel(sfb, oracle, grid, grid2, slice_
             assert r.code[11] == 2 and r.iter[11] == 0
             if prm.max_iter == 60:
                 assert (r.code == 4).any() and r.iter.max() == 60
-    for k in ("SFB_SP_SLICE", "SFB_SP_GRID", "SFB_SP_PHASED", "SFB_SP_GRID2"):
-        monkeypatch.delenv(k)
+    knobs.clear("SFB_SP_SLICE", "SFB_SP_GRID", "SFB_SP_PHASED")
 
 
-@pytest.mark.parametrize("grid,grid3,pause,lat", [(16, 5, 27, 1), (48, 48, 2, 0), (32, 9, 60, 1), (24, 3, 27, 0)])
-def test_launch_in_predicted_order_equals_the_single_kernel(sfb, oracle, grid, grid3, pause, lat, monkeypatch):
+@pytest.mark.parametrize("grid,pause,lat", [(16, 27, 1), (48, 2, 0), (9, 60, 1), (5, 27, 0)])
+def test_launch_in_predicted_order_equals_the_single_kernel(sfb, oracle, grid, pause, lat, knobs):
     """Default for time-sliced launches: a first launch takes every item through setup and its first `pause` iterations
     (items done by then are polished and reported there), the survivors leave a score -- residual over tolerance at
     their last stopping check -- and wait in their workspace; a counting sort orders them by descending score and a second
@@ -221,19 +213,18 @@ def test_launch_in_predicted_order_equals_the_single_kernel(sfb, oracle, grid, g
     Av[9, np.nonzero(~keep)[0][1]] = 0.5          # violates the mask: fallback pool, solved completely in the first launch
     l[13, 2], u[13, 2] = 1.0, -1.0                 # u < l: PrimalInfeasible at the pre-check, no iteration
     Px, q = np.tile(Pv, (B, 1)), np.zeros((B, d["n"]))
-    knobs = ("SFB_SP_GRID", "SFB_SP_PREDICT", "SFB_SP_GRID3", "SFB_SP_PAUSE", "SFB_SP_LAT")
+    knob_names = ("SFB_SP_GRID", "SFB_SP_PREDICT", "SFB_SP_PAUSE", "SFB_SP_LAT")
     for prm in (sfb.QPSolverParams(max_iter=4000), sfb.QPSolverParams(max_iter=150, polish=False),
                 sfb.QPSolverParams(max_iter=4000, stop_check_iter=7)):
         for kp in (None, keep):
             plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K), keep=kp)
-            monkeypatch.setenv("SFB_SP_GRID", str(grid))
-            monkeypatch.setenv("SFB_SP_PREDICT", "0")
+            knobs.set(SFB_SP_GRID=str(grid))
+            knobs.set(SFB_SP_PREDICT="0")
             base = plan.solve_batch_host(Px, q, Av, l, u, prm)
             base2 = plan.solve_batch_host(Px, q, Av, l, u, prm, warm_x=0.5 * base.primal, warm_y=0.5 * base.dual)
-            monkeypatch.delenv("SFB_SP_PREDICT")
-            monkeypatch.setenv("SFB_SP_GRID3", str(grid3))
-            monkeypatch.setenv("SFB_SP_PAUSE", str(pause))
-            monkeypatch.setenv("SFB_SP_LAT", str(lat))
+            knobs.clear("SFB_SP_PREDICT")
+            knobs.set(SFB_SP_PAUSE=str(pause))
+            knobs.set(SFB_SP_LAT=str(lat))
             r = plan.solve_batch_host(Px, q, Av, l, u, prm)
             r2 = plan.solve_batch_host(Px, q, Av, l, u, prm, warm_x=0.5 * base.primal, warm_y=0.5 * base.dual)
             for a, b in ((r, base), (r2, base2)):
@@ -249,9 +240,8 @@ def test_launch_in_predicted_order_equals_the_single_kernel(sfb, oracle, grid, g
                 ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l, u, perm=plan.perm, forder=plan.factor_order(),
                                                    params=_oracle_params(oracle, prm), nthreads=8)
                 assert np.array_equal(r.iter, ref["iter"]) and np.array_equal(r.code, ref["code"]) and np.array_equal(r.primal, ref["x"])
-            for k in knobs[1:]:
-                monkeypatch.delenv(k, raising=False)
-    monkeypatch.delenv("SFB_SP_GRID")
+            knobs.clear(*knob_names[1:])
+    knobs.clear("SFB_SP_GRID")
 
 
 def test_max_time_on_the_sparse_path(sfb, oracle):
@@ -359,7 +349,7 @@ class _DeviceSolver:
 
 @pytest.mark.parametrize("pruned", [False, True])
 @pytest.mark.parametrize("polish", [True, False])
-def test_factor_reuse_gives_the_same_bits(sfb, pruned, polish, monkeypatch):
+def test_factor_reuse_gives_the_same_bits(sfb, pruned, polish, knobs):
     """sfb_qp_params::reuse_factor (f3, the exact case): the caller vouches that P and A are unchanged since the
     previous call on the workspace; the kernel keeps the compacted A, the scaling and the LDL' factor wherever they
     are provably what it would recompute (c and the rho vector are re-derived and compared) and recomputes otherwise.
@@ -369,7 +359,7 @@ def test_factor_reuse_gives_the_same_bits(sfb, pruned, polish, monkeypatch):
     with a new A and no flag, and a flagged tick after it.  With polish the ADMM factor has to survive the polish
     factorisation (second factor block of the workspace).  Small grid: the launches are time-sliced, items are
     suspended and resumed by other blocks in between."""
-    monkeypatch.setenv("SFB_SP_GRID", "16")
+    knobs.set(SFB_SP_GRID="16")
     variant, K, B = 6, 20, 48
     d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
     Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=21)

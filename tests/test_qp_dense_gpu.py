@@ -202,21 +202,9 @@ def test_full_size_batch_properties(sfb):
 
 
 @pytest.fixture
-def env_knob():
-    """Set kernel-selection environment knobs of libsfb.so (read at every launch) for one test."""
-    saved = {}
-
-    def set_(**kw):
-        for k, v in kw.items():
-            saved.setdefault(k, os.environ.get(k))
-            os.environ[k] = str(v)
-
-    yield set_
-    for k, v in saved.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+def env_knob(knobs):
+    """Debug knobs of libsfb.so for one test (conftest.knobs)."""
+    return knobs.set
 
 
 @pytest.mark.parametrize("waves", [1, 3])
@@ -285,23 +273,6 @@ def test_mid_kernel_time_sliced_launch(sfb, oracle, env_knob, waves, slice_check
     r = sfb.solve_qp_batch_host(P, q + 0.02, A, l, u, prm, warm_x=wx, warm_y=wy)
     ref2 = oracle.qp_dense_solve_batch(P, q + 0.02, A, l, u, params=op, warm_x=wx, warm_y=wy, nthreads=8)
     _compare(r, ref2)
-
-
-@pytest.mark.parametrize("n,m", [(10, 20), (5, 11), (16, 16)])
-def test_one_per_wave_kernels_still_agree(sfb, oracle, env_knob, n, m):
-    """k <= 32 through the one-QP-per-wavefront kernels (SFB_QP_DENSE4=0): same bits as the four-per-wave
-    kernel and the oracle."""
-    B = 300
-    P, q, A, l, u = sfb.random_qp_batch(21, B, m, n, 0.9)
-    prm = sfb.QPSolverParams(max_iter=3000)
-    r4 = sfb.solve_qp_batch_host(P, q, A, l, u, prm)
-    env_knob(SFB_QP_DENSE4=0)
-    r1 = sfb.solve_qp_batch_host(P, q, A, l, u, prm)
-    ref = oracle.qp_dense_solve_batch(P, q, A, l, u, params=_oracle_params(oracle, prm), nthreads=8)
-    _compare(r1, ref)
-    _compare(r4, ref)
-    assert np.array_equal(r1.primal, r4.primal, equal_nan=True) and np.array_equal(r1.dual, r4.dual, equal_nan=True)
-    assert np.array_equal(r1.iter, r4.iter) and np.array_equal(r1.code, r4.code)
 
 
 @pytest.mark.parametrize("n,m", [(40, 30), (64, 96), (3, 203), (4, 301), (33, 32), (120, 250)])
