@@ -167,3 +167,109 @@ def test_time_concept_relative_setters_weights_and_structure_refresh():
     assert 0 <= out[0] <= 1e-6, out[0]
     assert 0 <= out[1] <= 1e-6, out[1]
     assert list(out[2:]) == [1.0] * 7, out
+
+
+# ---- a SECOND, independently written restatement at the headline model (variant 12: SE2 x R3 x SE2 x R3, nx = 12, nu = 2,
+# K = 50 -> n = m = 740): everything from the formulas of SURVEY.md section 8-a11 -- the LGR differentiation matrix from the
+# Legendre polynomials, the agents' states from a Python mt19937_64 (the harness draws xi_b ~ U(-0.5, 0.5)^12 from
+# std::mt19937_64(seed + b) and sets x_b = xdes(t_b) (+) xi_b), the rows of ocp_to_qp_update_dyn / _cr / _ce
+# (ocp_to_qp.hpp:198-373, mpc.hpp:288-301) -- without the product's lie.hpp / mesh.hpp.  It does not pin the reference
+# (which holds no numeric test of the transcription); it halves the chance that the one restatement is wrong. ----
+class _MT64:
+    """std::mt19937_64 (Matsumoto-Nishimura 2004, the standard's parameters)."""
+    NN, MM, MASK = 312, 156, (1 << 64) - 1
+
+    def __init__(self, seed):
+        self.mt = [seed & self.MASK]
+        for i in range(1, self.NN):
+            self.mt.append((6364136223846793005 * (self.mt[-1] ^ (self.mt[-1] >> 62)) + i) & self.MASK)
+        self.i = self.NN
+
+    def __call__(self):
+        if self.i >= self.NN:
+            mt, NN, MM = self.mt, self.NN, self.MM
+            for k in range(NN):
+                x = (mt[k] & 0xFFFFFFFF80000000) | (mt[(k + 1) % NN] & 0x7FFFFFFF)
+                mt[k] = mt[(k + MM) % NN] ^ (x >> 1) ^ (0xB5026F5AA96619E9 if x & 1 else 0)
+            self.i = 0
+        x = self.mt[self.i]
+        self.i += 1
+        x ^= (x >> 29) & 0x5555555555555555
+        x ^= (x << 17) & 0x71D67FFFEDA60000
+        x ^= (x << 37) & 0xFFF7EEE000000000
+        x ^= x >> 43
+        return x & self.MASK
+
+
+def _uniform(rng, a, b):
+    """std::uniform_real_distribution<double>(a, b) of libstdc++: generate_canonical with ONE 64-bit draw."""
+    return float(rng()) / 18446744073709551616.0 * (b - a) + a
+
+
+def _lgr_diffmat(K):
+    """LGR collocation on [-1, 1]: the K roots of P_{K-1} + P_K (the first one is -1), the basis = those nodes and +1;
+    D[j, i] = l_j'(tau_i).  Scaled to the unit interval by the caller."""
+    from numpy.polynomial import legendre as L
+    c = np.zeros(K + 1); c[K - 1] = 1; c[K] = 1
+    tau = np.sort(L.legroots(c).real)
+    pts = np.concatenate([tau, [1.0]])
+    D = np.zeros((K + 1, K))
+    for j in range(K + 1):
+        others = np.delete(pts, j)
+        lj = np.poly(others) / np.prod(pts[j] - others)        # Lagrange basis polynomial through the K + 1 points
+        D[j] = np.polyval(np.polyder(lj), tau)
+    return tau, D
+
+
+def test_headline_model_transcription_matches_a_second_numpy_restatement():
+    variant, K, tf, B, seed = 12, 50, 5.0, 64, 1234567
+    d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K, tf)
+    Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=seed, tf=tf)
+    Nx, Nu, N, niv, Kn = 12, 2, 52, 13, 4
+    assert (d["n"], d["m"]) == (Nx * (N + 1) + Nu * N, Nx * N + Nu * N + Nx) == (740, 740)
+    tau, Dref = _lgr_diffmat(Kn)                                # reference interval [-1, 1]
+    alpha = 2.0 * niv                                           # d/dt on [0, 1] split into 13 intervals = (2 * 13) d/dtau
+    # the model (examples/vehicle_model.h, from mpc_asif_vehicle.cpp:73-79): two SE2 x R3 vehicles driven by one input
+    vd, wd = np.array([1.0, 0.0, 0.4]), np.array([0.8, 0.0, 0.3])
+    f = np.concatenate([vd, [-0.2 * vd[0], 0.0, -0.4 * vd[2]], wd, [-0.3 * wd[0], 0.0, -0.5 * wd[2]]])   # f(xdes, udes = 0)
+    dxl = np.concatenate([vd, np.zeros(3), wd, np.zeros(3)])                                            # d/dt xdes (body velocity)
+    dfdx = np.zeros((12, 12)); dfdu = np.zeros((12, 2))
+    dfdx[0, 3] = dfdx[1, 4] = dfdx[2, 5] = 1; dfdx[3, 3] = -0.2; dfdx[5, 5] = -0.4
+    dfdx[6, 9] = dfdx[7, 10] = dfdx[8, 11] = 1; dfdx[9, 9] = -0.3; dfdx[11, 11] = -0.5
+    dfdu[3, 0] = dfdu[5, 1] = dfdu[9, 0] = dfdu[11, 1] = 1
+    adm = np.zeros((12, 12)); adm[0:3, 0:3] = _ad((f + dxl)[0:3]); adm[6:9, 6:9] = _ad((f + dxl)[6:9])   # ad of the bundle: per part, 0 on R3
+    xcol = lambda i: slice(i * Nx, (i + 1) * Nx)
+    ucol = lambda i: slice(Nx * (N + 1) + i * Nu, Nx * (N + 1) + (i + 1) * Nu)
+    # rows that do not depend on the agent: dynamics defects (:240-275) and the input box (:300-330)
+    A0 = np.zeros((d["m"], d["n"])); lo0 = np.zeros(d["m"]); hi0 = np.zeros(d["m"])
+    for s in range(niv):
+        for i in range(Kn):
+            node = s * Kn + i
+            rows = slice(node * Nx, (node + 1) * Nx)
+            A0[rows, xcol(node)] += tf * dfdx - 0.5 * tf * adm                 # tf (df/dx - 1/2 ad(f + dxl))
+            A0[rows, ucol(node)] += tf * dfdu
+            for j in range(Kn + 1):
+                A0[rows, xcol(s * Kn + j)] -= alpha * Dref[j, i] * np.eye(Nx)  # - sum_j D_ji x_j
+            lo0[rows] = hi0[rows] = -tf * (f - dxl)
+    for node in range(N):
+        rows = slice(Nx * N + node * Nu, Nx * N + (node + 1) * Nu)
+        A0[rows, ucol(node)] = np.eye(Nu)
+        lo0[rows], hi0[rows] = -0.5, 0.5
+    ce = slice(Nx * N + Nu * N, d["m"])
+    worst = 0.0
+    for b in range(B):
+        rng = _MT64(seed + b)
+        xi = np.array([_uniform(rng, -0.5, 0.5) for _ in range(12)])
+        # x_b = xdes (+) xi  =>  e = xdes (-) x_b = log(exp(xi)^-1) = -xi, part by part (SE2: exact in exact arithmetic)
+        e = -xi
+        J = np.eye(12); J[0:3, 0:3] = _dr_expinv(e[0:3]); J[6:9, 6:9] = _dr_expinv(e[6:9])   # d/dx of the (-) : dr_expinv per SE2 part
+        A = A0.copy(); lo = lo0.copy(); hi = hi0.copy()
+        A[ce, xcol(0)] = J
+        lo[ce] = hi[ce] = -e
+        Ad = np.zeros_like(A)
+        for r in range(d["m"]):
+            Ad[r, Aj[Ap[r]:Ap[r + 1]]] = Av[b, Ap[r]:Ap[r + 1]]
+        worst = max(worst, np.abs(Ad - A).max(), np.abs(l[b] - lo).max(), np.abs(u[b] - hi).max())
+        assert np.abs(Ad - A).max() <= 1e-12, (b, np.abs(Ad - A).max())
+        assert np.abs(l[b] - lo).max() <= 1e-12 and np.abs(u[b] - hi).max() <= 1e-12, b
+    print("second restatement, 64 agents of the headline model: max |difference| over A, l, u =", worst)
