@@ -4,8 +4,9 @@
 cd ${GRAFT_REPO_ROOT:-.}
 ROOT=$PWD
 mkdir -p gpurun_out
-SFB_MPC_TIMING=1 timeout 300 python -c "
+timeout 300 python -c "
 import sys; sys.path.insert(0, '$ROOT')
+import smooth_feedback_amd as sfb; sfb.debug_set('SFB_MPC_TIMING', '1')
 from examples import models_lib as M
 r = M.mpc_swarm_devlin_step(12, 50, ${B:-8192}, 6, seed=1, want_records=False)
 print('ms per tick', [round(1e3 * s, 2) for s in r['seconds']], 'mean iterations', r['iter'].mean())

@@ -826,7 +826,7 @@ template<int DEPTH, bool BYTEOFF, bool LEAN, bool PRE = false, bool NEXT = false
 __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const int units, const double *vals, double *t,
                                  const int lane, const int32_t *__restrict__ mask32, const int full0, const int full1,
                                  vdouble2 (&lx)[DEPTH], vint2 (&ix)[DEPTH], const int32_t *__restrict__ idx_next = nullptr,
-                                 const double *vals_next = nullptr)
+                                 const double *vals_next = nullptr, const int32_t *__restrict__ mask_next = nullptr)
 {
   static_assert(!(PRE || NEXT) || (!LEAN && DEPTH == 8), "chained sweeps: cacheable form, prefetch distance 8");
   // lean == false (few waves left on the chip: latency matters, HBM traffic does not): every block issues plain loads
@@ -906,11 +906,20 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
                  : [tb] "v"(tb), [ixx] "v"(ix[0].x), [ixy] "v"(ix[0].y)
                  : "memory");  // (the units read and write t behind the compiler's back: no C-level LDS access moves across the sweep's ends)
     (void)cp0; (void)cp1;
+    // The VALUE load of a unit is masked to the lanes that carry slots (round 5; the lean form always did): the second launch
+    // holds the whole batch and runs at the fabric's read rate (5.9 of this box's 6.0-6.1 TB/s), 17 % of which was the padding
+    // of partly filled units.  The lane count of unit u + 8 comes by a scalar load issued at the head of unit u's statement and
+    // is used behind its `s_waitcnt lgkmcnt(0)` (scalar loads share that counter; the LDS reads return in order, so the counted
+    // lgkmcnt(2) still covers the first two of them whatever the scalar load does).  Masked lanes keep what their register
+    // holds: a factor value of an earlier unit, multiplied into the scratch entry t[k] only.
+    const int32_t *mt = mask32 + DEPTH;  // lane-mask shifts of the units the current block requests
     auto unit = [&]<int D>(std::integral_constant<int, D>) {
       constexpr int N = (D + 1) % DEPTH;
       const double vx = lx[D].x, vy = lx[D].y;
       unsigned nt0, np0, nt1, np1;
-      asm volatile("s_waitcnt vmcnt(12)\n\t"  // unit N's stream data (six younger units stay in flight)
+      int msk;
+      asm volatile("s_load_dword %[msk], %[mt], %[mo]\n\t"
+                   "s_waitcnt vmcnt(12)\n\t"  // unit N's stream data (six younger units stay in flight)
                    SFB_SDWA_HI("%[np0]", "%[ixx]") SFB_SDWA_LO("%[nt0]", "%[ixx]") SFB_SDWA_HI("%[np1]", "%[ixy]") SFB_SDWA_LO("%[nt1]", "%[ixy]")
                    "s_waitcnt lgkmcnt(2)\n\t"
                    "v_fma_f64 %[a0], -%[vx], %[a0], %[b0]\n\t"
@@ -922,25 +931,36 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
                    "ds_read_b64 %[b0], %[nt0]\n\t"
                    "ds_read_b64 %[a1], %[np1]\n\t"
                    "ds_read_b64 %[b1], %[nt1]\n\t"
+                   "s_lshr_b64 exec, -1, %[msk]\n\t"
                    "global_load_dwordx4 %[lxo], %[vp], off offset:%[vo]\n\t"
+                   "s_mov_b64 exec, -1\n\t"
                    "global_load_dwordx2 %[ixo], %[ip], off offset:%[io]"
                    : [a0] "+v"(a0), [b0] "+v"(b0), [a1] "+v"(a1), [b1] "+v"(b1), [np0] "=&v"(np0), [nt0] "=&v"(nt0), [np1] "=&v"(np1),
-                     [nt1] "=&v"(nt1), [lxo] "=v"(lx[D]), [ixo] "=v"(ix[D])
+                     [nt1] "=&v"(nt1), [lxo] "+v"(lx[D]), [ixo] "=v"(ix[D]), [msk] "=&s"(msk)
                    : [vx] "v"(vx), [vy] "v"(vy), [ct0] "v"(ct0), [ct1] "v"(ct1), [tb] "v"(tb), [ixx] "v"(ix[N].x), [ixy] "v"(ix[N].y),
-                     [vp] "v"(vp[D / 4]), [ip] "v"(ip[D / 8]), [vo] "n"((D % 4) * kWave * 16), [io] "n"((D % 8) * kWave * 8));
+                     [vp] "v"(vp[D / 4]), [ip] "v"(ip[D / 8]), [vo] "n"((D % 4) * kWave * 16), [io] "n"((D % 8) * kWave * 8), [mt] "s"(mt),
+                     [mo] "n"(D * 4)
+                   : "scc");
       ct0 = nt0;
       ct1 = nt1;
-      (void)np0; (void)np1;
+      (void)np0; (void)np1; (void)msk;
     };
     for (int u0 = 0; u0 + (NEXT ? DEPTH : 0) < units; u0 += DEPTH) {
       for_units(std::make_integer_sequence<int, DEPTH>{}, unit);
       advance(DEPTH);
+      mt += DEPTH;
     }
     if constexpr (NEXT) {  // the last block (units >= DEPTH, the caller's condition): its loads are the next stream's first units
 #pragma unroll
       for (int e = 0; e < NVP; ++e) vp[e] = reinterpret_cast<const vdouble2 *>(vals_next) + lane + e * 4 * kWave;
 #pragma unroll
       for (int e = 0; e < NIP; ++e) ip[e] = reinterpret_cast<const vint2 *>(idx_next) + lane + e * 8 * kWave;
+      {  // (the next stream's lane-mask shifts, as a scalar pointer like mask32 above)
+        const unsigned long long a = reinterpret_cast<unsigned long long>(mask_next);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+        mt = reinterpret_cast<const int32_t *>(((unsigned long long)hi << 32) | lo);
+      }
       for_units(std::make_integer_sequence<int, DEPTH>{}, unit);
     }
     // the reads issued behind the last unit (a padding unit's scratch entry, or the next stream's first unit before its
@@ -1054,8 +1074,8 @@ __device__ __forceinline__ void ldl_solve_lat(const SparsePlanDev &pl, const Ws 
                                               vdouble2 (&lx)[8], vint2 (&ix)[8], const bool pre, const bool next)
 {
   const int k = uni(pl.k);
-  if (pre) sweep_dev<8, true, false, true, true>(pl.fidx, uni(pl.funits), w.LxF, t, lane, pl.fmask, 0, 0, lx, ix, pl.bidx, w.LxB);
-  else sweep_dev<8, true, false, false, true>(pl.fidx, uni(pl.funits), w.LxF, t, lane, pl.fmask, 0, 0, lx, ix, pl.bidx, w.LxB);
+  if (pre) sweep_dev<8, true, false, true, true>(pl.fidx, uni(pl.funits), w.LxF, t, lane, pl.fmask, 0, 0, lx, ix, pl.bidx, w.LxB, pl.bmask);
+  else sweep_dev<8, true, false, false, true>(pl.fidx, uni(pl.funits), w.LxF, t, lane, pl.fmask, 0, 0, lx, ix, pl.bidx, w.LxB, pl.bmask);
   for (int j0 = lane; j0 < k; j0 += kWave * 8) {  // D^-1 (:458) from LDS
     double dv[8];
 #pragma unroll
@@ -1065,7 +1085,7 @@ __device__ __forceinline__ void ldl_solve_lat(const SparsePlanDev &pl, const Ws 
       if (j0 + e * kWave < k) t[j0 + e * kWave] = dv[e] * t[j0 + e * kWave];
   }
   wave_lds_fence();
-  if (next) sweep_dev<8, true, false, true, true>(pl.bidx, uni(pl.bunits), w.LxB, t, lane, pl.bmask, 0, 0, lx, ix, pl.fidx, w.LxF);
+  if (next) sweep_dev<8, true, false, true, true>(pl.bidx, uni(pl.bunits), w.LxB, t, lane, pl.bmask, 0, 0, lx, ix, pl.fidx, w.LxF, pl.fmask);
   else sweep_dev<8, true, false, true, false>(pl.bidx, uni(pl.bunits), w.LxB, t, lane, pl.bmask, 0, 0, lx, ix);
 }
 
@@ -1968,19 +1988,42 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
   double *vxs = w.xs, *vqc = w.qc, *vys = w.ys, *vzs = w.zs, *vrinv = w.rinv, *vrho = w.rho, *vlo = w.lo, *vhi = w.hi;
   const int32_t *vpinv = pl.pinv;
   [[maybe_unused]] double *vdinv = nullptr;  // LAT: 1 / D of the ADMM factor in LDS
+  // LAT, round 5: the second launch now holds the whole batch and its length is its total work, i.e. (waves) / (time of an
+  // iteration) -- so the LDS block of a LAT wave is cut from 77 KB (two waves per CU) to 45 KB (three): only what an iteration
+  // WRITES or gathers stays on chip (x, y, z, 1 / D, the permutation as 16-bit entries); rho and 1 / rho take three values
+  // (:361-374) and become a class byte per row; c q and the scaled bounds are read-only, read once per iteration with
+  // coalesced loads at a point where nothing waits for them: they go back to the workspace (L2-resident).
+  [[maybe_unused]] const uint16_t *vp16 = nullptr;
+  [[maybe_unused]] const uint8_t *vcls  = nullptr;
+  const double rho_c0 = 1e-6, rho_c1 = 1e3 * kp.rho_bar, rho_c2 = kp.rho_bar;  // the three values of :367-373 ...
+  const double rinv_c0 = 1.0 / rho_c0, rinv_c1 = 1.0 / rho_c1, rinv_c2 = 1.0 / rho_c2;  // ... and their reciprocals as the setup forms them
+  auto pinv_at = [&](const int e) -> int {
+    if constexpr (LAT) return (int)vp16[e];
+    else return vpinv[e];
+  };
+  auto rho_at = [&](const int i) -> double {
+    if constexpr (LAT) { const int cl = vcls[i]; return cl == 0 ? rho_c0 : (cl == 1 ? rho_c1 : rho_c2); }
+    else return vrho[i];
+  };
+  auto rinv_at = [&](const int i) -> double {
+    if constexpr (LAT) { const int cl = vcls[i]; return cl == 0 ? rinv_c0 : (cl == 1 ? rinv_c1 : rinv_c2); }
+    else return vrinv[i];
+  };
   const bool iterates  = ph0 <= PH_ADMM && iter != maxit && ret_code < 0;
   if constexpr (LAT) {
-    vxs = t + ((k + 2) & ~1); vqc = vxs + n; vys = vqc + n; vzs = vys + m; vrinv = vzs + m; vrho = vrinv + m; vlo = vrho + m;
-    vhi = vlo + m;
-    int32_t *lp = reinterpret_cast<int32_t *>(vhi + m);
-    vpinv       = lp;
-    vdinv       = reinterpret_cast<double *>(lp + ((k + 2) & ~1));
+    vxs = t + ((k + 2) & ~1); vys = vxs + n; vzs = vys + m; vdinv = vzs + m;
+    uint16_t *lp = reinterpret_cast<uint16_t *>(vdinv + k);
+    uint8_t *lc  = reinterpret_cast<uint8_t *>(lp + ((k + 3) & ~3));
+    vp16 = lp;
+    vcls = lc;
     if (iterates) {
-      for (int j = lane; j < n; j += kWave) { vxs[j] = w.xs[j]; vqc[j] = w.qc[j]; }
+      for (int j = lane; j < n; j += kWave) vxs[j] = w.xs[j];
       for (int i = lane; i < m; i += kWave) {
-        vys[i] = w.ys[i]; vzs[i] = w.zs[i]; vrinv[i] = w.rinv[i]; vrho[i] = w.rho[i]; vlo[i] = w.lo[i]; vhi[i] = w.hi[i];
+        vys[i] = w.ys[i]; vzs[i] = w.zs[i];
+        const double rho = w.rho[i];
+        lc[i] = (uint8_t)(rho == rho_c0 ? 0 : (rho == rho_c1 ? 1 : 2));
       }
-      for (int e = lane; e < k; e += kWave) lp[e] = pl.pinv[e];
+      for (int e = lane; e < k; e += kWave) lp[e] = (uint16_t)pl.pinv[e];
       for (int e = lane; e < k; e += kWave) vdinv[e] = w.Dinv[e];
       wave_sync();
     }
@@ -2013,7 +2056,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
         const bool on = j < n;
         xv[e] = on ? vxs[j] : 0.0;
         qv[e] = on ? vqc[j] : 0.0;
-        pv[e] = on ? vpinv[j] : k;
+        pv[e] = on ? pinv_at(j) : k;
       }
 #pragma unroll
       for (int e = 0; e < UNR; ++e)
@@ -2027,9 +2070,9 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
         const int i = i0 + e * kWave;
         const bool on = i < m;
         zv[e] = on ? vzs[i] : 0.0;
-        rv[e] = on ? vrinv[i] : 0.0;
+        rv[e] = on ? rinv_at(i) : 0.0;
         yv[e] = on ? vys[i] : 0.0;
-        pv[e] = on ? vpinv[n + i] : k;
+        pv[e] = on ? pinv_at(n + i) : k;
       }
 #pragma unroll
       for (int e = 0; e < UNR; ++e)
@@ -2072,7 +2115,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
         const bool on = !PRED || j < n;
         xo[e] = on ? vxs[j] : 0.0;
         qv[e] = on ? vqc[j] : 0.0;
-        pv[e] = on ? vpinv[j] : k;
+        pv[e] = on ? pinv_at(j) : k;
       }
 #pragma unroll
       for (int e = 0; e < U; ++e) {
@@ -2093,11 +2136,11 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
         const bool on = !PRED || i < m;
         yo[e] = on ? vys[i] : 0.0;
         zo[e] = on ? vzs[i] : 0.0;
-        ri[e] = on ? vrinv[i] : 0.0;
-        rh[e] = on ? vrho[i] : 0.0;
+        ri[e] = on ? rinv_at(i) : 0.0;
+        rh[e] = on ? rho_at(i) : 0.0;
         lo[e] = on ? vlo[i] : 0.0;
         hi[e] = on ? vhi[i] : 0.0;
-        pv[e] = on ? vpinv[n + i] : k;
+        pv[e] = on ? pinv_at(n + i) : k;
       }
 #pragma unroll
       for (int e = 0; e < U; ++e) {
@@ -2601,9 +2644,16 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
   // launch runs them longest-first, first come first served, on a grid small enough that a wave iterates at nearly the
   // speed of a lone wave (its factor stays in the 256 MB Infinity Cache).  The order is a schedule only: the results are
   // bit-identical (tests/test_mpc_gpu.py).
+  // WHERE the first launch pauses (round 5): at the FIRST stopping check (iteration 1; debug knob SFB_SP_PAUSE, rounds 3-4: 27).
+  // The iterations of the first launch stream their factors from HBM with every wave of the chip (18 item-iterations per
+  // microsecond), the second launch's from the Infinity Cache (21); while setup and polish cost 18 of a step's 53 ms the
+  // better-informed order after 26 iterations paid for the difference, with the unit engine of the factorisation it no
+  // longer does: 8 192 agents 51.3 -> 48.3 ms, 4 096: 36.8 -> 30.7, 16 384: 94.5 -> 94.0, a warm swarm tick 35 -> 30 ms.
+  // The residual-to-tolerance ratio after one iteration still puts the long runners first (the second launch now holds
+  // the whole batch, its length is its total work rather than its longest item).
   const char *pr       = sfb::knob("SFB_SP_PREDICT");
   const char *pa       = sfb::knob("SFB_SP_PAUSE");
-  const unsigned pause = pa ? (unsigned)std::max(0, atoi(pa)) : 27u;
+  const unsigned pause = pa ? (unsigned)std::max(0, atoi(pa)) : 2u;
   const bool predicted = sliced && !phased && !(pr && atoi(pr) == 0) && pause > 0 && kp.stop_check_iter >= 2 && kp.max_iter > 2 * pause;
   if (predicted) {
     int32_t *xtra   = aux + sparse_aux_queue_ints(batch);
@@ -2624,7 +2674,7 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     // wave; inside the few waves of the loop they took 40 % of the wave time).  Otherwise: the standard kernel, loop and
     // polish in one launch.  Both are enqueued, the blocks of the form that was not chosen leave at once.
     const int kk = pl.n + pl.m;
-    const size_t lds_lat = std::max(lds, (size_t)(((kk + 2) & ~1) + 2 * pl.n + 6 * pl.m + ((kk + 2) & ~1) / 2 + kk + 2) * sizeof(double));
+    const size_t lds_lat = std::max(lds, (size_t)(((kk + 2) & ~1) + pl.n + 2 * pl.m + kk + (kk + 3) / 4 + (pl.m + 7) / 8 + 4) * sizeof(double));
     int lat_hi = 0, lat_lo = 0;
     if (const char *lt = sfb::knob("SFB_SP_LAT"); !(lt && atoi(lt) == 0) && lds_lat <= 80 * 1024) {
       // (per call: the attribute belongs to the CURRENT device and the shards of a *_multi call run on several; cheap and idempotent.
@@ -2658,7 +2708,7 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
   }
   if (const char *fl = sfb::knob("SFB_SP_FORCE_LAT"); !phased && fl && atoi(fl) == 1) {  // measurements: the LAT form for a whole launch
     const int kk = pl.n + pl.m;
-    const size_t lds_lat = std::max(lds, (size_t)(((kk + 2) & ~1) + 2 * pl.n + 6 * pl.m + ((kk + 2) & ~1) / 2 + kk + 2) * sizeof(double));
+    const size_t lds_lat = std::max(lds, (size_t)(((kk + 2) & ~1) + pl.n + 2 * pl.m + kk + (kk + 3) / 4 + (pl.m + 7) / 8 + 4) * sizeof(double));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(qp_sparse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return launch(grid, qarg, lean_waves, PH_EVERYTHING, order, 0, nullptr, nullptr, -1, true, lds_lat);
   }
