@@ -1,4 +1,5 @@
 cd ${GRAFT_REPO_ROOT:-.}
 bash scripts/r4/chk_ab.sh
-KNOBS=SFB_SP_FORCE_LAT=1 N=400 SEED=77 timeout 300 python scripts/fuzz_sparse.py 2>&1 | tail -1
-KNOBS=SFB_SP_GRID=4 N=400 BMAX=40 SEED=78 timeout 300 python scripts/fuzz_sparse.py 2>&1 | tail -1
+timeout 600 python bench.py --steps 6 --warmup 2 --no-pipelined --no-secondary --no-closed-loop --workload mpc 2>&1 | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['parity_vs_oracle'])"

@@ -88,6 +88,16 @@ for a, b in regions:
             hazards += 1
             sys.exit("check_sweep_spills: line %d of %s touches a register of a stream load that is still in flight "
                      "(before its counted s_waitcnt): %s" % (i + 1, sys.argv[1], t))
+# Third check (round 5): the LAT kernel keeps the head of the forward factor stream RESIDENT in its AccVGPRs across compiler-
+# generated code (lat_resident_load / the resident prefix of the forward sweep).  The compiler does not know that: it must not use
+# AccVGPRs itself (as spill space for VGPRs, say).  Every AccVGPR access of the file has to be one of ours -- a literal
+# `v_accvgpr_read_b32 v, a[N]` of the prefix or a `global_load_dwordx4 a[N:M]` of the load.
+bad_acc = [i for i, l in enumerate(lines)
+           if re.search(r"\bv_accvgpr_(write|mov)", l) or (re.search(r"\ba\[?\d", l.split(";")[0]) and not re.search(
+               r"v_accvgpr_read_b32 v\d+, a\[|global_load_dwordx4 a\[", l))]
+if bad_acc:
+    sys.exit("check_sweep_spills: line %d of %s: an AccVGPR access that is not the resident stream's: %s"
+             % (bad_acc[0] + 1, sys.argv[1], lines[bad_acc[0]].strip()))
 nspill = sum(1 for l in lines if re.search(r"\bscratch_(load|store)", l))
 print("check_sweep_spills: %d sweep regions, %d scratch instructions, none inside a sweep; no instruction touches a register of a "
       "load in flight" % (len(regions), nspill))

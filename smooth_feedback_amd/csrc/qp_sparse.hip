@@ -822,7 +822,9 @@ __device__ __forceinline__ void stream_wait(vdouble2 &a, vint2 &b)
 // instead of padding and leaves them in flight in lx / ix; PRE: no prologue, lx / ix hold this sweep's first DEPTH units
 // already (issued by the sweep before).  A lone wave otherwise waits one full memory latency at the head of every sweep.
 // (Between chained sweeps nothing else may touch memory: the counted waits assume the stream's loads only.)
-template<int DEPTH, bool BYTEOFF, bool LEAN, bool PRE = false, bool NEXT = false>
+// RES > 0 (the LAT forward sweep): the values of the first RES units are RESIDENT in the wave's AccVGPRs a[4 u .. 4 u + 3]
+// (lat_resident_load) and are not streamed; see the static prefix in the hand-scheduled branch.
+template<int DEPTH, bool BYTEOFF, bool LEAN, bool PRE = false, bool NEXT = false, int RES = 0>
 __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const int units, const double *vals, double *t,
                                  const int lane, const int32_t *__restrict__ mask32, const int full0, const int full1,
                                  vdouble2 (&lx)[DEPTH], vint2 (&ix)[DEPTH], const int32_t *__restrict__ idx_next = nullptr,
@@ -873,6 +875,10 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
     mask_wait(mk);
     for_units(std::make_integer_sequence<int, DEPTH>{},
               [&]<int D>(std::integral_constant<int, D> dd) { issue(dd, std::integral_constant<int, 2>{}, mk); });
+  } else if constexpr (!PRE && RES > 0) {
+    static_assert(RES >= DEPTH, "the prologue's units are all resident");
+    for_units(std::make_integer_sequence<int, DEPTH>{},
+              [&]<int D>(std::integral_constant<int, D>) { stream_load<(D % 8) * kWave * 8>(ix[D], ip[D / 8]); });
   } else if constexpr (!PRE) {
     for_units(std::make_integer_sequence<int, DEPTH>{},
               [&]<int D>(std::integral_constant<int, D> dd) { issue(dd, std::integral_constant<int, 0>{}, mk); });
@@ -897,7 +903,8 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
 #define SFB_SDWA_HI(d, s) "v_add_u32_sdwa " d ", %[tb], " s " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
 #define SFB_SDWA_LO(d, s) "v_add_u32_sdwa " d ", %[tb], " s " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
     const unsigned tb = (unsigned)reinterpret_cast<unsigned long long>(t);  // LDS byte address of the work vector (low half of its flat address)
-    stream_wait<2 * (DEPTH - 1)>(lx[0], ix[0]);
+    if constexpr (RES > 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ix[0]) : "n"(DEPTH - 1));  // (one load per resident unit in flight)
+    else stream_wait<2 * (DEPTH - 1)>(lx[0], ix[0]);
     unsigned ct0, cp0, ct1, cp1;  // LDS addresses of the current unit's targets / pivots
     double a0, b0, a1, b1;        // what its reads return (in flight between the statements)
     asm volatile(SFB_SDWA_HI("%[p0]", "%[ixx]") SFB_SDWA_LO("%[t0]", "%[ixx]") SFB_SDWA_HI("%[p1]", "%[ixy]") SFB_SDWA_LO("%[t1]", "%[ixy]")
@@ -913,39 +920,99 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
     // lgkmcnt(2) still covers the first two of them whatever the scalar load does).  Masked lanes keep what their register
     // holds: a factor value of an earlier unit, multiplied into the scratch entry t[k] only.
     const int32_t *mt = mask32 + DEPTH;  // lane-mask shifts of the units the current block requests
-    auto unit = [&]<int D>(std::integral_constant<int, D>) {
+    // unit_g<D, W, TK>: the unit in register set D with the values (vx, vy); W = loads that may stay in flight when the NEXT
+    // unit's data is needed; TK = what it requests for the unit eight ahead: 0 = masked values + indices, 1 = indices only
+    // (that unit's values are resident)
+    auto unit_g = [&]<int D, int W, int TK>(std::integral_constant<int, D>, std::integral_constant<int, W>, std::integral_constant<int, TK>,
+                                            const double vx, const double vy) {
       constexpr int N = (D + 1) % DEPTH;
-      const double vx = lx[D].x, vy = lx[D].y;
       unsigned nt0, np0, nt1, np1;
-      int msk;
-      asm volatile("s_load_dword %[msk], %[mt], %[mo]\n\t"
-                   "s_waitcnt vmcnt(12)\n\t"  // unit N's stream data (six younger units stay in flight)
-                   SFB_SDWA_HI("%[np0]", "%[ixx]") SFB_SDWA_LO("%[nt0]", "%[ixx]") SFB_SDWA_HI("%[np1]", "%[ixy]") SFB_SDWA_LO("%[nt1]", "%[ixy]")
-                   "s_waitcnt lgkmcnt(2)\n\t"
-                   "v_fma_f64 %[a0], -%[vx], %[a0], %[b0]\n\t"
-                   "s_waitcnt lgkmcnt(0)\n\t"
-                   "v_fma_f64 %[a1], -%[vy], %[a1], %[b1]\n\t"
-                   "ds_write_b64 %[ct0], %[a0]\n\t"
-                   "ds_write_b64 %[ct1], %[a1]\n\t"
-                   "ds_read_b64 %[a0], %[np0]\n\t"
-                   "ds_read_b64 %[b0], %[nt0]\n\t"
-                   "ds_read_b64 %[a1], %[np1]\n\t"
-                   "ds_read_b64 %[b1], %[nt1]\n\t"
-                   "s_lshr_b64 exec, -1, %[msk]\n\t"
-                   "global_load_dwordx4 %[lxo], %[vp], off offset:%[vo]\n\t"
-                   "s_mov_b64 exec, -1\n\t"
-                   "global_load_dwordx2 %[ixo], %[ip], off offset:%[io]"
-                   : [a0] "+v"(a0), [b0] "+v"(b0), [a1] "+v"(a1), [b1] "+v"(b1), [np0] "=&v"(np0), [nt0] "=&v"(nt0), [np1] "=&v"(np1),
-                     [nt1] "=&v"(nt1), [lxo] "+v"(lx[D]), [ixo] "=v"(ix[D]), [msk] "=&s"(msk)
-                   : [vx] "v"(vx), [vy] "v"(vy), [ct0] "v"(ct0), [ct1] "v"(ct1), [tb] "v"(tb), [ixx] "v"(ix[N].x), [ixy] "v"(ix[N].y),
-                     [vp] "v"(vp[D / 4]), [ip] "v"(ip[D / 8]), [vo] "n"((D % 4) * kWave * 16), [io] "n"((D % 8) * kWave * 8), [mt] "s"(mt),
-                     [mo] "n"(D * 4)
-                   : "scc");
+      if constexpr (TK == 0) {
+        int msk;
+        asm volatile("s_load_dword %[msk], %[mt], %[mo]\n\t"
+                     "s_waitcnt vmcnt(%[w])\n\t"  // unit N's stream data (six younger units stay in flight)
+                     SFB_SDWA_HI("%[np0]", "%[ixx]") SFB_SDWA_LO("%[nt0]", "%[ixx]") SFB_SDWA_HI("%[np1]", "%[ixy]") SFB_SDWA_LO("%[nt1]", "%[ixy]")
+                     "s_waitcnt lgkmcnt(2)\n\t"
+                     "v_fma_f64 %[a0], -%[vx], %[a0], %[b0]\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "v_fma_f64 %[a1], -%[vy], %[a1], %[b1]\n\t"
+                     "ds_write_b64 %[ct0], %[a0]\n\t"
+                     "ds_write_b64 %[ct1], %[a1]\n\t"
+                     "ds_read_b64 %[a0], %[np0]\n\t"
+                     "ds_read_b64 %[b0], %[nt0]\n\t"
+                     "ds_read_b64 %[a1], %[np1]\n\t"
+                     "ds_read_b64 %[b1], %[nt1]\n\t"
+                     "s_lshr_b64 exec, -1, %[msk]\n\t"
+                     "global_load_dwordx4 %[lxo], %[vp], off offset:%[vo]\n\t"
+                     "s_mov_b64 exec, -1\n\t"
+                     "global_load_dwordx2 %[ixo], %[ip], off offset:%[io]"
+                     : [a0] "+v"(a0), [b0] "+v"(b0), [a1] "+v"(a1), [b1] "+v"(b1), [np0] "=&v"(np0), [nt0] "=&v"(nt0), [np1] "=&v"(np1),
+                       [nt1] "=&v"(nt1), [lxo] "+v"(lx[D]), [ixo] "=v"(ix[D]), [msk] "=&s"(msk)
+                     : [vx] "v"(vx), [vy] "v"(vy), [ct0] "v"(ct0), [ct1] "v"(ct1), [tb] "v"(tb), [ixx] "v"(ix[N].x), [ixy] "v"(ix[N].y),
+                       [vp] "v"(vp[D / 4]), [ip] "v"(ip[D / 8]), [vo] "n"((D % 4) * kWave * 16), [io] "n"((D % 8) * kWave * 8), [mt] "s"(mt),
+                       [mo] "n"(D * 4), [w] "n"(W)
+                     : "scc");
+        (void)msk;
+      } else {
+        asm volatile("s_waitcnt vmcnt(%[w])\n\t"
+                     SFB_SDWA_HI("%[np0]", "%[ixx]") SFB_SDWA_LO("%[nt0]", "%[ixx]") SFB_SDWA_HI("%[np1]", "%[ixy]") SFB_SDWA_LO("%[nt1]", "%[ixy]")
+                     "s_waitcnt lgkmcnt(2)\n\t"
+                     "v_fma_f64 %[a0], -%[vx], %[a0], %[b0]\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "v_fma_f64 %[a1], -%[vy], %[a1], %[b1]\n\t"
+                     "ds_write_b64 %[ct0], %[a0]\n\t"
+                     "ds_write_b64 %[ct1], %[a1]\n\t"
+                     "ds_read_b64 %[a0], %[np0]\n\t"
+                     "ds_read_b64 %[b0], %[nt0]\n\t"
+                     "ds_read_b64 %[a1], %[np1]\n\t"
+                     "ds_read_b64 %[b1], %[nt1]\n\t"
+                     "global_load_dwordx2 %[ixo], %[ip], off offset:%[io]"
+                     : [a0] "+v"(a0), [b0] "+v"(b0), [a1] "+v"(a1), [b1] "+v"(b1), [np0] "=&v"(np0), [nt0] "=&v"(nt0), [np1] "=&v"(np1),
+                       [nt1] "=&v"(nt1), [ixo] "=v"(ix[D])
+                     : [vx] "v"(vx), [vy] "v"(vy), [ct0] "v"(ct0), [ct1] "v"(ct1), [tb] "v"(tb), [ixx] "v"(ix[N].x), [ixy] "v"(ix[N].y),
+                       [ip] "v"(ip[D / 8]), [io] "n"((D % 8) * kWave * 8), [w] "n"(W));
+      }
       ct0 = nt0;
       ct1 = nt1;
-      (void)np0; (void)np1; (void)msk;
+      (void)np0; (void)np1;
     };
-    for (int u0 = 0; u0 + (NEXT ? DEPTH : 0) < units; u0 += DEPTH) {
+    auto unit = [&]<int D>(std::integral_constant<int, D> dd) {
+      unit_g(dd, std::integral_constant<int, 12>{}, std::integral_constant<int, 0>{}, lx[D].x, lx[D].y);
+    };
+    // RESIDENT PREFIX (RES > 0): units 0 .. RES + 7 with literal unit numbers.  Unit U < RES takes its two values per lane from the
+    // AccVGPRs a[4 U .. 4 U + 3]; the loads in flight behind unit U + 1's are one per resident unit and two per streamed one among
+    // the units U + 2 .. U + 7; unit U requests for unit U + 8 the indices only while that one is resident.  From unit RES + 8 on
+    // the eight units in flight are all streamed: the loop below takes over with its counts unchanged.
+    int u_first = 0;
+    if constexpr (RES > 0) {
+      auto for_prefix = [&]<int... U>(std::integer_sequence<int, U...>, auto &&fn) { (fn(std::integral_constant<int, U>{}), ...); };
+      for_prefix(std::make_integer_sequence<int, RES + DEPTH>{}, [&]<int U>(std::integral_constant<int, U>) {
+        constexpr int D = U % DEPTH;
+        constexpr auto loads = [](int v) { return v < RES ? 1 : 2; };
+        constexpr int W = loads(U + 2) + loads(U + 3) + loads(U + 4) + loads(U + 5) + loads(U + 6) + loads(U + 7);
+        constexpr int TK = (U + DEPTH < RES) ? 1 : 0;
+        double vx, vy;
+        if constexpr (U < RES) {
+          int l0, h0, l1, h1;
+          asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"
+                       : "=v"(l0), "=v"(h0), "=v"(l1), "=v"(h1)
+                       : "n"(4 * U), "n"(4 * U + 1), "n"(4 * U + 2), "n"(4 * U + 3));
+          vx = __hiloint2double(h0, l0);
+          vy = __hiloint2double(h1, l1);
+        } else {
+          vx = lx[D].x;
+          vy = lx[D].y;
+        }
+        unit_g(std::integral_constant<int, D>{}, std::integral_constant<int, W>{}, std::integral_constant<int, TK>{}, vx, vy);
+        if constexpr (D == DEPTH - 1) {
+          advance(DEPTH);
+          mt += DEPTH;
+        }
+      });
+      static_assert((RES + DEPTH) % DEPTH == 0, "whole blocks");
+      u_first = RES + DEPTH;
+    }
+    for (int u0 = u_first; u0 + (NEXT ? DEPTH : 0) < units; u0 += DEPTH) {
       for_units(std::make_integer_sequence<int, DEPTH>{}, unit);
       advance(DEPTH);
       mt += DEPTH;
@@ -1070,11 +1137,33 @@ __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, doubl
 // sweep's last block fetches the head of the backward stream, the backward sweep's last block the head of the forward
 // stream for the next iteration when the caller says there is one without a stopping check in between (`next`); `pre`:
 // lx / ix hold the forward stream's head from the previous call.  Requires byte offsets and funits, bunits >= 8.
+// `resident`: the first kLatResident units of the forward stream sit in the wave's AccVGPRs (lat_resident_load).
+constexpr int kLatResident = 64;  // all 256 AccVGPRs = 64 KB of the 232 KB a headline item streams per iteration
+__device__ __forceinline__ bool lat_resident_ok(const SparsePlanDev &pl) { return uni(pl.funits) >= kLatResident + 16; }
+__device__ __forceinline__ void lat_resident_load(const double *LxF, const int lane)
+{
+  asm volatile("" ::: "a255");  // (the kernel's AccVGPR count)
+  const vdouble2 *p = reinterpret_cast<const vdouble2 *>(LxF) + lane;
+  auto for_units = [&]<int... U>(std::integer_sequence<int, U...>, auto &&fn) { (fn(std::integral_constant<int, U>{}), ...); };
+  for_units(std::make_integer_sequence<int, kLatResident / 4>{}, [&]<int G>(std::integral_constant<int, G>) {
+    const vdouble2 *pg = p + G * 4 * kWave;  // four units (1 KB each) per address register
+    asm volatile("global_load_dwordx4 a[%1:%2], %0, off\n\t"
+                 "global_load_dwordx4 a[%3:%4], %0, off offset:1024\n\t"
+                 "global_load_dwordx4 a[%5:%6], %0, off offset:2048\n\t"
+                 "global_load_dwordx4 a[%7:%8], %0, off offset:3072"
+                 :
+                 : "v"(pg), "n"(16 * G), "n"(16 * G + 3), "n"(16 * G + 4), "n"(16 * G + 7), "n"(16 * G + 8), "n"(16 * G + 11), "n"(16 * G + 12),
+                   "n"(16 * G + 15)
+                 : "memory");
+  });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 __device__ __forceinline__ void ldl_solve_lat(const SparsePlanDev &pl, const Ws &w, double *t, const int lane, const double *Dinv,
-                                              vdouble2 (&lx)[8], vint2 (&ix)[8], const bool pre, const bool next)
+                                              vdouble2 (&lx)[8], vint2 (&ix)[8], const bool pre, const bool next, const bool resident = false)
 {
   const int k = uni(pl.k);
-  if (pre) sweep_dev<8, true, false, true, true>(pl.fidx, uni(pl.funits), w.LxF, t, lane, pl.fmask, 0, 0, lx, ix, pl.bidx, w.LxB, pl.bmask);
+  if (resident) sweep_dev<8, true, false, false, true, kLatResident>(pl.fidx, uni(pl.funits), w.LxF, t, lane, pl.fmask, 0, 0, lx, ix, pl.bidx, w.LxB, pl.bmask);
+  else if (pre) sweep_dev<8, true, false, true, true>(pl.fidx, uni(pl.funits), w.LxF, t, lane, pl.fmask, 0, 0, lx, ix, pl.bidx, w.LxB, pl.bmask);
   else sweep_dev<8, true, false, false, true>(pl.fidx, uni(pl.funits), w.LxF, t, lane, pl.fmask, 0, 0, lx, ix, pl.bidx, w.LxB, pl.bmask);
   for (int j0 = lane; j0 < k; j0 += kWave * 8) {  // D^-1 (:458) from LDS
     double dv[8];
@@ -2028,6 +2117,13 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
       wave_sync();
     }
   }
+  // LAT, round 5: the head of the forward stream resident in the wave's AccVGPRs for as long as it iterates on the item (the
+  // launch runs at the fabric's read rate: what is on chip is not streamed)
+  [[maybe_unused]] bool lat_resident = false;
+  if constexpr (LAT) {
+    lat_resident = iterates && uni(pl.idx_scale) == 8 && uni(pl.bunits) >= 8 && lat_resident_ok(pl);
+    if (lat_resident) lat_resident_load(w.LxF, lane);
+  }
   auto vectors_home = [&] {  // LAT: x, z, y back to the workspace (polish, report, or the next wave that takes the item up)
     if constexpr (LAT) {
       if (iterates) {
@@ -2088,7 +2184,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
         // is NOT done: the compiler is free to copy loop-carried registers while their loads are in flight (wrong results).
         vdouble2 lat_lx[8];
         vint2 lat_ix[8];
-        ldl_solve_lat(pl, w, t, lane, vdinv, lat_lx, lat_ix, false, false);
+        ldl_solve_lat(pl, w, t, lane, vdinv, lat_lx, lat_ix, false, false, lat_resident);
       } else {
         ldl_solve_dev<8>(pl, w, t, lane, lean, vdinv);
       }
@@ -2363,7 +2459,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
 constexpr int kFbSlots = 64;
 
 template<bool LAT, bool TRACE = false>
-__global__ void __launch_bounds__(64, (LAT || TRACE) ? 2 : 3) qp_sparse_kernel(const SparsePlanDev *__restrict__ plp, const DenseKernelParams kp,
+__global__ void __launch_bounds__(64, LAT ? 1 : (TRACE ? 2 : 3)) qp_sparse_kernel(const SparsePlanDev *__restrict__ plp, const DenseKernelParams kp,
                                                        const double *__restrict__ gPx, const double *__restrict__ gq,
                                                        const double *__restrict__ gAx, const double *__restrict__ gl,
                                                        const double *__restrict__ gu, const double *__restrict__ gwx,
