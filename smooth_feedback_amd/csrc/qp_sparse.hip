@@ -2783,6 +2783,10 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
           hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qp_sparse_kernel<true>, kWave, lds_lat) == hipSuccess &&
           hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
         lat_hi = std::min<int>(per_cu * cus, (int)grid);
+      // (measurements: 448 waves 56.3 ms, 512: 51.8, 640: 47.0, 768: 44.0 -- the launch is bound by waves x iteration rate, not by
+      //  bytes, up to three waves per CU; a FOURTH, bought by leaving part of 1 / D in the workspace, loses again: 896 waves 45.6,
+      //  1 024: 46.3, scripts/r5/experiments/lat_four_waves_partial_dinv.diff)
+      if (const char *lw = sfb::knob("SFB_SP_LAT_WAVES"); lw && atoi(lw) > 0) lat_hi = std::min(lat_hi, atoi(lw));
       lat_lo = std::min(lat_hi, 448);
     }
     // ... for any amount of work: two LAT waves per CU (loop vectors in LDS, factors from the Infinity Cache) also move more
