@@ -1,9 +1,7 @@
 cd ${GRAFT_REPO_ROOT:-.}
-bash scripts/r4/chk_ab.sh
-KNOBS=SFB_SP_FORCE_LAT=1 N=300 SEED=77 timeout 300 python scripts/fuzz_sparse.py 2>&1 | tail -1
-B="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-pipelined --no-secondary --no-closed-loop --workload mpc"
-for g in 1024 896; do
-  timeout 300 $B --debug-knob SFB_SP_LAT_WAVES=$g 2>&1 | tail -1 | python3 -c "
+timeout 400 python -m pytest tests/test_qp_sparse_gpu.py tests/test_mpc_gpu.py tests/test_mpc_devlin_gpu.py tests/test_mpc_assembly_gpu.py -x -q -m gpu 2>&1 | tail -2
+KNOBS=SFB_SP_GRID=4 N=300 BMAX=40 SEED=79 timeout 300 python scripts/fuzz_sparse.py 2>&1 | tail -1
+KNOBS=SFB_SP_GRID=3,SFB_SP_PAUSE=27 N=200 BMAX=30 SEED=80 timeout 300 python scripts/fuzz_sparse.py 2>&1 | tail -1
+timeout 300 python bench.py --steps 6 --warmup 2 --no-pipelined --no-secondary --no-closed-loop --workload mpc 2>&1 | tail -1 | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('lat waves %-6s %9.0f QP/s  %.3f ms' % ('$g', d['value'], d['ms_per_step']))"
-done
+d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], {k: d['parity_vs_oracle'][k] for k in ('sample','code_mismatches','iter_mismatches','max_abs_dx')})"

@@ -9,6 +9,7 @@
 //                                 SFB_SP_PREDICT     0: a single time-sliced launch instead of the launch in predicted order
 //                                 SFB_SP_LAT         0: the standard form of the kernel for the loop launch
 //                                 SFB_SP_FORCE_LAT   1: the LAT form of the kernel for a whole launch
+//                                 SFB_SP_POLISHERS   0: no polishers next to the loop launch (polish and report of everything in the finish launch)
 //                                 SFB_SP_LAT_WAVES   cap on the waves of the LAT loop launch (default: what the chip holds, three per CU)
 //                                 SFB_SP_PHASED      1: setup / ADMM loop / polish + report as three launches (profiling)
 //                                 SFB_SP_LEAN_WAVES  busy waves above which the sweeps use masked non-temporal loads

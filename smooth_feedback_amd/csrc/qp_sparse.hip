@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 #include <algorithm>
 #include <type_traits>
@@ -64,7 +66,10 @@ constexpr int kHdrCode = 10, kHdrComplete = 11;
 enum { PH_SETUP = 1, PH_ADMM = 2, PH_FINISH = 3 };
 // A launch performs the phases ph0 .. ph1 of every item it visits (packed into one kernel argument together with the
 // pause point, see qp_sparse_launch): [SETUP, FINISH] = everything.
-constexpr int phases_pack(int ph0, int ph1, unsigned pause_at = 0) { return ph0 | (ph1 << 4) | (int)(pause_at << 8); }
+constexpr int phases_pack(int ph0, int ph1, unsigned pause_at = 0, int dq_mode = 0)
+{
+  return ph0 | (ph1 << 4) | (int)((pause_at & 0xFFFFFu) << 8) | (dq_mode << 28);  // dq_mode: ring of finished items, see the kernel
+}
 constexpr int PH_EVERYTHING = phases_pack(PH_SETUP, PH_FINISH);
 constexpr unsigned long long kFactorStamp = 0x5FB0FAC7A11CE5EDull;
 
@@ -1765,7 +1770,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
   };
   if constexpr (TRACE) ph_clk = wall_clock64();
   const int ph0 = phases & 15, ph1 = (phases >> 4) & 15;  // the phases this launch performs
-  const uint32_t pause_at = (uint32_t)phases >> 8;        // != 0: leave the ADMM loop open at the first check from here on
+  const uint32_t pause_at = ((uint32_t)phases >> 8) & 0xFFFFFu;  // != 0: leave the ADMM loop open at the first check from here on
   const int n = uni(pl.n), m = uni(pl.m), k = uni(pl.k);
   const int nnzP = uni(pl.nnzP), nnzA = uni(pl.nnzA);  // (nnzA: what the kernel works on, the kept entries of a pruned plan)
   Item it{gPx + b * (size_t)nnzP, gq + b * (size_t)n, gAx + b * (size_t)uni(pl.nnzA_io), gl + b * (size_t)m,
@@ -2457,9 +2462,12 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
 // Launch-wide auxiliary memory (zeroed by the launcher): the queue of a time-sliced launch, then the flags of the
 // fallback pool of a pruned plan (kFbSlots ints, 0 = free).
 constexpr int kFbSlots = 64;
+// ring of the items whose ADMM loop has ended (see the kernel): counters on their own cache lines, then one entry per item
+constexpr int kDqTail = 0, kDqHead = 32, kDqOver = 64, kDqRing = 96;
 
-template<bool LAT, bool TRACE = false>
-__global__ void __launch_bounds__(64, LAT ? 1 : (TRACE ? 2 : 3)) qp_sparse_kernel(const SparsePlanDev *__restrict__ plp, const DenseKernelParams kp,
+// POLISHER: the instance the polishers run (dq_mode 2); the standard instance has no register to spare for their loop.
+template<bool LAT, bool TRACE = false, bool POLISHER = false>
+__global__ void __launch_bounds__(64, LAT ? 1 : ((TRACE || POLISHER) ? 2 : 3)) qp_sparse_kernel(const SparsePlanDev *__restrict__ plp, const DenseKernelParams kp,
                                                        const double *__restrict__ gPx, const double *__restrict__ gq,
                                                        const double *__restrict__ gAx, const double *__restrict__ gl,
                                                        const double *__restrict__ gu, const double *__restrict__ gwx,
@@ -2475,6 +2483,15 @@ __global__ void __launch_bounds__(64, LAT ? 1 : (TRACE ? 2 : 3)) qp_sparse_kerne
                                                        const int mode_sel, double *__restrict__ trace, const int trace_cap,
                                                        double *__restrict__ phase_us)
 {
+  // (no kernel arguments of their own -- the standard form has no register to spare: the mode rides in `phases`, the ring sits
+  //  behind the other auxiliary arrays of the launch: [fallback flags: kFbSlots][scores: batch][order: batch][count: 16][ring])
+  constexpr int dq_mode = POLISHER ? 2 : 0;  // (the producer side: every loop launch of the LAT instance pushes, see below)
+  // doneq / dq_mode (launches in predicted order with the LAT loop launch): the ring of items whose ADMM loop has ended.
+  //   dq_mode 1 (the loop launch): a wave that ends an item's loop pushes it;
+  //   dq_mode 2 (the POLISHERS, a small launch of this kernel's standard form on a second stream, running NEXT TO the loop launch
+  //   on the SIMD and the LDS its three LAT waves per CU leave free): a wave pops an item, polishes and reports it (phase FINISH)
+  //   and marks it complete; it leaves when the host has flagged the end of the loop launch.  The finish launch that follows
+  //   skips what the polishers did.  [kDqTail] pushes, [kDqHead] pops, [kDqOver] != 0: the loop launch has ended, [kDqRing + i].
   // keys (nullable): per item, the predictor score of a paused item (SP_PAUSED) or -1 (nothing left to do for the next launch)
   // nfresh_dev (nullable): the fresh items of this launch are order[0 .. *nfresh_dev - 1] (the survivors of the previous one)
   const int ph0    = phases & 15;
@@ -2494,7 +2511,26 @@ __global__ void __launch_bounds__(64, LAT ? 1 : (TRACE ? 2 : 3)) qp_sparse_kerne
   // of a ring and is continued later by whichever block is free (its state lives in ITS workspace slot = item).
   for (bool first = true;; first = false) {
     int item = -1, resume = 0;
-    if (queue == nullptr) {
+    if constexpr (dq_mode == 2) {
+      if (lane == 0) {
+        int32_t *const doneq = fbflags + kFbSlots + 2 * batch + 16;
+        for (;;) {
+          // (the loop launch has ended: what is still in the ring is done faster by the finish launch on the whole chip)
+          if (__hip_atomic_load(&doneq[kDqOver], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+          const int head = __hip_atomic_load(&doneq[kDqHead], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int tail = __hip_atomic_load(&doneq[kDqTail], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (head < tail) {
+            if (atomicCAS(&doneq[kDqHead], head, head + 1) != head) continue;
+            int v;
+            while ((v = __hip_atomic_load(&doneq[kDqRing + head], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) __builtin_amdgcn_s_sleep(4);
+            item = v - 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(100);
+        }
+      }
+      resume = 1;  // (an acquire below: the item's state was written by a wave of the loop launch)
+    } else if (queue == nullptr) {
       if (first) item = order ? order[blockIdx.x] : (int)blockIdx.x;
     } else if (lane == 0) {
       if (__hip_atomic_load(&queue[kQFresh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nfresh) {
@@ -2519,6 +2555,7 @@ __global__ void __launch_bounds__(64, LAT ? 1 : (TRACE ? 2 : 3)) qp_sparse_kerne
     const int lean_waves_item = lean_waves;
     if (item < 0) break;
     if (resume) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the suspending block's stores (other CU / XCD)
+    if constexpr (dq_mode == 2) resume = 0;  // (a polisher takes the item up like the finish launch does: from its workspace header)
     wave_sync();
     // Pruned plan: the declaration "these stored entries of A are zero" is checked for the item.  An item that
     // violates it is solved on the WHOLE pattern (plan plf, same elimination order) right here, in a workspace slot
@@ -2553,7 +2590,20 @@ __global__ void __launch_bounds__(64, LAT ? 1 : (TRACE ? 2 : 3)) qp_sparse_kerne
     if (keys != nullptr && st != SP_PAUSED && lane == 0) keys[item] = -1.0f;
     if (fbslot >= 0 && phases != PH_EVERYTHING && lane == 0)  // tell the later launches (the item's own slot is otherwise unused)
       carve_ws(gws + (size_t)item * ws_doubles, uni(plp->n), uni(plp->m), uni(plp->nnzL), uni(plp->funits), uni(plp->bunits)).hdr[kHdrComplete] = 1.0;
+    if (dq_mode == 2 && lane == 0)  // polished and reported: the finish launch skips it
+      carve_ws(gws + (size_t)item * ws_doubles, uni(plp->n), uni(plp->m), uni(plp->nnzL), uni(plp->funits), uni(plp->bunits)).hdr[kHdrComplete] = 1.0;
     wave_sync();
+    if constexpr (LAT) {
+      // the item's loop has ended in a loop launch (phases ADMM .. ADMM of a launch with auxiliary memory): hand it to the polishers
+      // (the ring is there and zeroed whether or not polishers run)
+      if (st == SP_DONE && (phases & 0xFF) == (PH_ADMM | (PH_ADMM << 4)) && ((phases >> 28) & 3) == 1 && lane == 0) {
+        int32_t *const doneq = fbflags + kFbSlots + 2 * batch + 16;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int tl = atomicAdd(&doneq[kDqTail], 1);
+        __hip_atomic_store(&doneq[kDqRing + tl], item + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     if (lane == 0) {
       atomicSub(&g_sparse_active, 1);
       if (fbslot >= 0) __hip_atomic_store(&fbflags[fbslot], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -2568,7 +2618,7 @@ __global__ void __launch_bounds__(64, LAT ? 1 : (TRACE ? 2 : 3)) qp_sparse_kerne
       }
     }
     wave_sync();
-    if (queue == nullptr) break;
+    if (queue == nullptr && dq_mode != 2) break;
   }
 }
 
@@ -2654,6 +2704,27 @@ __global__ __launch_bounds__(kRankThreads) void sp_rank_kernel(const float *__re
   }
 }
 
+// the polishers' stream of the current device (see qp_sparse_launch): lowest priority -- when both have workgroups to place, the
+// loop launch's go first --, not synchronising with the null stream; created once per device, nullptr when that fails
+static hipStream_t polisher_stream()
+{
+  static std::mutex mu;
+  static std::map<int, hipStream_t> streams;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> lk(mu);
+  const auto it = streams.find(dev);
+  if (it != streams.end()) return it->second;
+  int least = 0, greatest = 0;
+  hipStream_t s = nullptr;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess) {
+    (void)hipGetLastError();
+    s = nullptr;
+  }
+  streams[dev] = s;
+  return s;
+}
+
 // blocks of qp_sparse_kernel the device holds at once with `lds` bytes of dynamic LDS each
 static int sparse_resident_blocks(size_t lds)
 {
@@ -2667,7 +2738,7 @@ static int sparse_resident_blocks(size_t lds)
 // auxiliary memory of a launch: [queue: kQRing + batch][flags of the fallback pool: kFbSlots] (zeroed per kernel) and,
 // for launches in predicted order, [scores: batch floats][order of the survivors: batch][their count: 16]
 static size_t sparse_aux_queue_ints(int64_t batch) { return (size_t)batch + kQRing + kFbSlots; }
-size_t qp_sparse_aux_bytes(int64_t batch) { return (sparse_aux_queue_ints(batch) + 2 * (size_t)batch + 16) * sizeof(int32_t); }
+size_t qp_sparse_aux_bytes(int64_t batch) { return (sparse_aux_queue_ints(batch) + 2 * (size_t)batch + 16 + kDqRing + (size_t)batch) * sizeof(int32_t); }
 int qp_sparse_fallback_slots() { return kFbSlots; }
 
 hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp, int64_t batch, const double *Px,
@@ -2712,15 +2783,17 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
   // the three phases for the profiler (profiles/r3_mpc_phases).
   const char *ph    = sfb::knob("SFB_SP_PHASED");
   const bool phased = sliced && ph && atoi(ph) == 1;
+  struct DoneQ { int32_t *q = nullptr; int mode = 0; hipStream_t on = nullptr; };  // ring of finished items (see the kernel); `on`: the polishers' stream
   auto launch = [&](unsigned g, int32_t *qa, int lw, int phases, const int32_t *ord = nullptr, uint32_t slc = 0, float *keys = nullptr,
-                    const int32_t *nfresh = nullptr, int mode_sel = -1, bool lat = false, size_t lds_lat = 0) -> hipError_t {
-    if (qa != nullptr || pruned) {
+                    const int32_t *nfresh = nullptr, int mode_sel = -1, bool lat = false, size_t lds_lat = 0, DoneQ dq = DoneQ{}) -> hipError_t {
+    if ((qa != nullptr || pruned) && dq.mode != 2) {  // (the polishers take no tickets and run next to a launch that does)
       hipError_t e = hipMemsetAsync(aux, 0, sparse_aux_queue_ints(batch) * sizeof(int32_t), stream);
       if (e != hipSuccess) return e;
     }
-    auto *kern = (trace || phase_us) ? qp_sparse_kernel<false, true> : (lat ? qp_sparse_kernel<true> : qp_sparse_kernel<false>);
-    hipLaunchKernelGGL(kern, dim3(g), dim3(kWave), lat ? lds_lat : lds, stream, pl.self, kp, Px, q, Ax, l, u, wx, wy, x, y, obj, iter,
-                       code, workspace, wsd, lw, ord, qa, (int)batch, slc ? slc : (uint32_t)std::max(1, slice),
+    auto *kern = (trace || phase_us) ? qp_sparse_kernel<false, true>
+                                     : (dq.mode == 2 ? qp_sparse_kernel<false, false, true> : (lat ? qp_sparse_kernel<true> : qp_sparse_kernel<false>));
+    hipLaunchKernelGGL(kern, dim3(g), dim3(kWave), lat ? lds_lat : lds, dq.mode == 2 ? dq.on : stream, pl.self, kp, Px, q, Ax, l, u, wx, wy, x, y,
+                       obj, iter, code, workspace, wsd, lw, ord, qa, (int)batch, slc ? slc : (uint32_t)std::max(1, slice),
                        pruned ? fallback->self : nullptr, fallback_ws, pruned ? qp_sparse_ws_doubles(*fallback) : 0,
                        aux ? aux + batch + kQRing : nullptr, phases, (int)std::min<int64_t>(batch, kFbSlots), keys, nfresh, mode_sel,
                        trace, trace_cap, phase_us);
@@ -2798,7 +2871,36 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const uint32_t slice3 = 0x40000000u;
     if (lat_hi > 0) {
-      e = launch((unsigned)lat_hi, qarg, 0x7FFFFFFF, phases_pack(PH_ADMM, PH_ADMM), order2, slice3, nullptr, count, 1, true, lds_lat);
+      // POLISHERS (round 5).  Three LAT waves per CU leave one SIMD and 25 KB of LDS idle for the 30 ms of the loop launch, while
+      // polish and report of the whole batch wait behind it (7.6 ms on the whole chip).  One standard-form wave per CU, launched
+      // on a low-priority stream of its own next to the loop launch, takes the items whose loop has ended from a ring the LAT
+      // waves push them into, polishes and reports them; the finish launch does what is left when the loop launch ends (the
+      // last items' polish) and skips the rest.  Which wave polishes an item changes nothing in it.
+      DoneQ prod{}, cons{};
+      hipEvent_t ev1 = nullptr, ev2 = nullptr;
+      int cus = 0, dev = 0;
+      const char *po = sfb::knob("SFB_SP_POLISHERS");  // 0: no polishers (measurements, tests); N > 0: N of them (default: one per CU)
+      if (hipStream_t hs = (po && atoi(po) == 0) ? nullptr : polisher_stream(); hs != nullptr &&
+          hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+          hipEventCreateWithFlags(&ev1, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev2, hipEventDisableTiming) == hipSuccess) {
+        int32_t *dq = count + 16;  // (== fbflags + kFbSlots + 2 batch + 16: where the kernel looks for it)
+        if (hipMemsetAsync(dq, 0, (size_t)(kDqRing + batch) * sizeof(int32_t), stream) == hipSuccess && hipEventRecord(ev1, stream) == hipSuccess) {
+          prod = DoneQ{dq, 1, nullptr};
+          cons = DoneQ{dq, 2, hs};
+        }
+      }
+      (void)hipGetLastError();
+      e = launch((unsigned)lat_hi, qarg, 0x7FFFFFFF, phases_pack(PH_ADMM, PH_ADMM, 0, prod.mode), order2, slice3, nullptr, count, 1, true, lds_lat, prod);
+      if (e == hipSuccess && cons.mode == 2) {
+        // (the end of the loop launch, for the polishers: whatever happens from here on, this flag is set before the stream goes on)
+        e = hipMemsetAsync(cons.q + kDqOver, 0xFF, sizeof(int32_t), stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(cons.on, ev1, 0);
+        if (e == hipSuccess) e = launch((unsigned)std::min<int64_t>((po && atoi(po) > 0) ? atoi(po) : cus, batch), qarg, 0, phases_pack(PH_FINISH, PH_FINISH, 0, 2), nullptr, slice3, nullptr, nullptr, -1, false, 0, cons);
+        if (e == hipSuccess) e = hipEventRecord(ev2, cons.on);
+        if (e == hipSuccess) e = hipStreamWaitEvent(stream, ev2, 0);
+      }
+      if (ev1) (void)hipEventDestroy(ev1);
+      if (ev2) (void)hipEventDestroy(ev2);
       if (e != hipSuccess) return e;
       e = launch(grid, qarg, lean_waves, phases_pack(PH_FINISH, PH_FINISH), order2, slice3, nullptr, count + 4, 1);
       if (e != hipSuccess) return e;
