@@ -24,7 +24,7 @@ python - <<PY
 import csv
 rows = []
 for r in csv.DictReader(open("$OUT/t_kernel_trace.csv")):
-    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("void ", "").replace("sfb::", "").replace("(anonymous namespace)::", "").split("(")[0][:70], int(r["Grid_Size"])))
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("void ", "").replace("sfb::", "").replace("(anonymous namespace)::", "").split("(")[0][:70], int(r["Grid_Size_X"])))
 rows.sort()
 # ticks start at mpc_linearise_kernel
 starts = [i for i, r in enumerate(rows) if "mpc_linearise_kernel" in r[2]]

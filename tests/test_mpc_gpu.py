@@ -470,3 +470,34 @@ def test_factor_reuse_after_an_ordered_launch_is_safe(sfb):
     for a, b in zip(got, ref):
         assert np.array_equal(a, b)
     assert np.array_equal(x.cpu().numpy(), ref[2])
+
+
+def test_lat_loop_launch_with_resident_stream_and_polishers_at_the_headline_model(sfb, oracle, knobs):
+    """The headline model's plan (nx = 12, nu = 2, K = 50: forward stream of 168 units) through the launch in predicted order on
+    a tiny grid: the LAT loop launch keeps the first 64 units of the forward factor stream in its AccVGPRs (hand-scheduled
+    prefix with literal registers) and the polishers take finished items off its ring -- against the same launch without
+    polishers, with the standard-form loop launch, as a single time-sliced launch, and against the oracle: same bits."""
+    variant, K, B = 12, 50, 72
+    d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
+    Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=43)
+    keep = np.any(Av != 0.0, axis=0)
+    Px, q = np.tile(Pv, (B, 1)), np.zeros((B, d["n"]))
+    plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K), keep=keep)
+    prm = sfb.QPSolverParams()
+    knobs.set(SFB_SP_GRID=12)
+    res = {}
+    for name, kn in (("default", {}), ("no_polishers", {"SFB_SP_POLISHERS": 0}), ("two_polishers", {"SFB_SP_POLISHERS": 2}),
+                     ("standard_loop", {"SFB_SP_LAT": 0}), ("single_launch", {"SFB_SP_PREDICT": 0}), ("pause_27", {"SFB_SP_PAUSE": 27})):
+        knobs.set(**kn)
+        res[name] = plan.solve_batch_host(Px, q, Av, l, u, prm)
+        res[name + "_warm"] = plan.solve_batch_host(Px, q, Av, l, u, prm, warm_x=0.3 * res[name].primal, warm_y=0.3 * res[name].dual)
+        knobs.clear(*kn)
+    base = res["single_launch"]
+    for name, r in res.items():
+        b = res["single_launch_warm"] if name.endswith("_warm") else base
+        assert np.array_equal(r.code, b.code) and np.array_equal(r.iter, b.iter), name
+        assert np.array_equal(r.primal, b.primal) and np.array_equal(r.dual, b.dual) and np.array_equal(r.objective, b.objective), name
+    assert base.iter.max() > 100 and (base.code == 0).all()
+    ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l, u, perm=plan.perm, forder=plan.factor_order(),
+                                       params=_oracle_params(oracle, prm), nthreads=8)
+    assert np.array_equal(base.iter, ref["iter"]) and np.array_equal(base.code, ref["code"]) and np.array_equal(base.primal, ref["x"])
