@@ -269,3 +269,30 @@ def test_verbose_single_problem_prints_the_reference_summary(sfb, capfd):
     total = [float(ln.split()[-1]) for ln in tail.splitlines() if ln.startswith("Total time")][0]
     assert abs(sum(vals.values()) - total) <= 2.0  # the four lines add up to the total (printed as whole microseconds)
     assert int([ln for ln in tail.splitlines() if ln.startswith("Iterations")][0].split()[-1]) == int(r.iter[0]) - 1
+
+
+@pytest.mark.parametrize("units", [1, 0])
+def test_zero_pivot_ends_with_unknown_in_both_factorisation_engines(sfb, oracle, knobs, units):
+    """SimplicialLDLT info() == NumericalIssue -> QPSolutionStatus::Unknown (qp_solver.hpp:430-433): sigma = 0 and a zero on
+    the diagonal of P give the KKT matrix a zero pivot for some items of the batch.  The unit engine of the numeric
+    factorisation notices it when a segment's diagonal is final (after divisions by it have produced inf / NaN elsewhere),
+    the supernodal engine (SFB_PLAN_UNITS=0) at the column: same verdicts, and the other items are untouched."""
+    B, n, m = 48, 12, 18
+    P, q, A, l, u = sfb.random_qp_batch(31, B, m, n, 0.4)
+    Pm = P.reshape(B, n, n).copy()
+    bad = np.arange(B) % 3 == 0
+    Pm[bad, :, 0] = 0.0
+    Pm[bad, 0, :] = 0.0                                      # first variable: no quadratic cost at all
+    P = Pm.reshape(B, n * n)
+    Pp, Pi, Px, Ap, Aj, Ax = dense_batch_to_sparse(P, A, n, m, upper_only=True)
+    if not units:
+        knobs.set(SFB_PLAN_UNITS=0)
+    plan = sfb.SparseQPPlan(n, m, Pp, Pi, Ap, Aj, ordering=0)   # natural order: the zero comes first
+    prm = sfb.QPSolverParams(sigma=0.0, max_iter=400, scaling=False)
+    r = plan.solve_batch_host(Px, q, Ax, l, u, prm)
+    ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Ax, l, u, perm=plan.perm, forder=plan.factor_order(),
+                                       params=_oracle_params(oracle, prm), nthreads=4)
+    assert np.array_equal(r.code, ref["code"]) and np.array_equal(r.iter, ref["iter"])
+    assert (r.code[bad] == 6).all() and (r.iter[bad] == 0).all() and (r.code[~bad] != 6).any()
+    good = r.code != 6
+    assert np.array_equal(r.primal[good], ref["x"][good], equal_nan=True) and np.array_equal(r.dual[good], ref["y"][good], equal_nan=True)
