@@ -10,7 +10,7 @@ namespace sfb {
 
 namespace {
 const char *const kKnobs[] = {"SFB_SP_GRID",  "SFB_SP_SLICE",  "SFB_SP_PAUSE",      "SFB_SP_PREDICT",   "SFB_SP_LAT",
-                              "SFB_SP_FORCE_LAT", "SFB_SP_LAT_WAVES", "SFB_SP_POLISHERS", "SFB_SP_PHASED", "SFB_SP_LEAN_WAVES", "SFB_MID_GRID", "SFB_MID_SLICE",
+                              "SFB_SP_FORCE_LAT", "SFB_SP_LAT_WAVES", "SFB_SP_POLISHERS", "SFB_SP_LAT_HELP", "SFB_SP_PHASED", "SFB_SP_LEAN_WAVES", "SFB_MID_GRID", "SFB_MID_SLICE",
                               "SFB_QP4_MAX_WAVES", "SFB_QP_DENSE_BIG", "SFB_PLAN_UNITS", "SFB_PLAN_DEBUG", "SFB_MPC_TIMING"};
 std::mutex g_mu;
 // (node-based: the value strings stay where they are until their knob is set again or cleared)

@@ -1601,7 +1601,7 @@ __device__ __forceinline__ void sp_rows_chain(double (&acc)[RB], const int i0, c
   }
 }
 
-template<int SD>
+template<int SD, bool WIDE = false>
 __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const Ws &w, const Ws &wf, const DenseKernelParams &kp,
                                  double *t, const double c, const int lane, const bool lean)  // (its fill + factorisation count as "Polish", qp_solver.hpp:563)
 {
@@ -1627,7 +1627,12 @@ __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const 
 #define SFB_POLISH_RB 2
 #define SFB_POLISH_CE 2
 #endif
-    constexpr int RB = SFB_POLISH_RB, CE = SFB_POLISH_CE;
+#ifndef SFB_POLISH_WIDE_RB
+#define SFB_POLISH_WIDE_RB 2
+#define SFB_POLISH_WIDE_CE 4
+#endif
+    // (WIDE: the instances with a whole SIMD's registers to themselves -- polishers, LAT waves helping them -- fetch more per step)
+    constexpr int RB = WIDE ? SFB_POLISH_WIDE_RB : SFB_POLISH_RB, CE = WIDE ? SFB_POLISH_WIDE_CE : SFB_POLISH_CE;
     struct Ix { int a, b; };
     struct V3 { double a, b, c; };
     struct V4 { double a, b, c, d; };
@@ -1743,7 +1748,7 @@ __device__ __forceinline__ bool sp_guard_ok(const SparsePlanDev &pl, const doubl
 // has used its slice while others are waiting for a wave (SP_SUSPENDED: state saved, the caller queues the item).
 // LAT: the form for launches with few waves, each nearly alone on its SIMD (second launch of the predicted order): one
 // wave per SIMD pair of registers more (256 VGPRs) and the ADMM vectors of the loop in LDS, see the loop
-template<bool LAT, bool TRACE = false>
+template<bool LAT, bool TRACE = false, bool WIDE = false>
 __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const DenseKernelParams &kp, const double *__restrict__ gPx,
                                              const double *__restrict__ gq, const double *__restrict__ gAx,
                                              const double *__restrict__ gl, const double *__restrict__ gu,
@@ -2377,10 +2382,10 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
       const Ws wp = polish_ws(w, gws + slot * ws_doubles,
                               qp_sparse_polish_offset(n, m, uni(pl.nnzL), uni(pl.funits), uni(pl.bunits), pl.Aorig ? nnzA : 0), n, m,
                               uni(pl.nnzL), uni(pl.funits), uni(pl.bunits));
-      sp_polish<SFB_SWEEP_DEPTH>(pl, it, w, wp, kp, t, c, lane, lean);
+      sp_polish<SFB_SWEEP_DEPTH, WIDE>(pl, it, w, wp, kp, t, c, lane, lean);
     } else {
       if (lane == 0) w.hdr[kHdrStamp] = 0.0;  // the polish factorisation overwrites the ADMM factor
-      sp_polish<SFB_SWEEP_DEPTH>(pl, it, w, w, kp, t, c, lane, lean);
+      sp_polish<SFB_SWEEP_DEPTH, WIDE>(pl, it, w, w, kp, t, c, lane, lean);
     }
   }
 
@@ -2463,7 +2468,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
 // fallback pool of a pruned plan (kFbSlots ints, 0 = free).
 constexpr int kFbSlots = 64;
 // ring of the items whose ADMM loop has ended (see the kernel): counters on their own cache lines, then one entry per item
-constexpr int kDqTail = 0, kDqHead = 32, kDqOver = 64, kDqRing = 96;
+constexpr int kDqTail = 0, kDqHead = 32, kDqOver = 64, kDqOwn = 80, kDqRing = 96;  // ([kDqOwn]: busy waves of the loop launch + its polishers)
 
 // POLISHER: the instance the polishers run (dq_mode 2); the standard instance has no register to spare for their loop.
 template<bool LAT, bool TRACE = false, bool POLISHER = false>
@@ -2487,7 +2492,7 @@ __global__ void __launch_bounds__(64, LAT ? 1 : ((TRACE || POLISHER) ? 2 : 3)) q
   //  behind the other auxiliary arrays of the launch: [fallback flags: kFbSlots][scores: batch][order: batch][count: 16][ring])
   constexpr int dq_mode = POLISHER ? 2 : 0;  // (the producer side: every loop launch of the LAT instance pushes, see below)
   // doneq / dq_mode (launches in predicted order with the LAT loop launch): the ring of items whose ADMM loop has ended.
-  //   dq_mode 1 (the loop launch): a wave that ends an item's loop pushes it;
+  //   dq_mode 1 / 3 (the loop launch): a wave that ends an item's loop pushes it (3: and helps polishing once it has no item left);
   //   dq_mode 2 (the POLISHERS, a small launch of this kernel's standard form on a second stream, running NEXT TO the loop launch
   //   on the SIMD and the LDS its three LAT waves per CU leave free): a wave pops an item, polishes and reports it (phase FINISH)
   //   and marks it complete; it leaves when the host has flagged the end of the loop launch.  The finish launch that follows
@@ -2549,13 +2554,39 @@ __global__ void __launch_bounds__(64, LAT ? 1 : ((TRACE || POLISHER) ? 2 : 3)) q
         item   = v - 1;
         resume = 1;
       }
+      if constexpr (LAT) {
+        // A wave of the loop launch that finds no item left to iterate HELPS THE POLISHERS while their ring has a backlog (the
+        // tail of the launch belongs to a few long items: most of its waves would leave here), and leaves when it is empty.
+        // (Only while no OTHER launch has waves at work -- a LAT wave owns its SIMD's whole register file: with a second batch in
+        //  flight on another stream the chip does better when the wave leaves, that batch's waves take the SIMD and the finish
+        //  launch polishes three to a SIMD.  [kDqOwn] counts the busy waves of this loop launch and its polishers, g_sparse_active
+        //  those of every launch.)
+        if (item < 0 && ((phases >> 28) & 3) == 3) {
+          int32_t *const doneq = fbflags + kFbSlots + 2 * batch + 16;
+          for (;;) {
+            if (__hip_atomic_load(&g_sparse_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                    __hip_atomic_load(&doneq[kDqOwn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0)
+              break;
+            const int head = __hip_atomic_load(&doneq[kDqHead], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int tail = __hip_atomic_load(&doneq[kDqTail], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (head >= tail) break;
+            if (atomicCAS(&doneq[kDqHead], head, head + 1) != head) continue;
+            int v;
+            while ((v = __hip_atomic_load(&doneq[kDqRing + head], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) __builtin_amdgcn_s_sleep(4);
+            item   = v - 1;
+            resume = 2;
+            break;
+          }
+        }
+      }
     }
     item   = __builtin_amdgcn_readfirstlane(item);
     resume = __builtin_amdgcn_readfirstlane(resume);
     const int lean_waves_item = lean_waves;
     if (item < 0) break;
     if (resume) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the suspending block's stores (other CU / XCD)
-    if constexpr (dq_mode == 2) resume = 0;  // (a polisher takes the item up like the finish launch does: from its workspace header)
+    const bool helper = LAT && resume == 2;  // (this item: polish and report, as a polisher would)
+    if (dq_mode == 2 || helper) resume = 0;  // (a polisher takes the item up like the finish launch does: from its workspace header)
     wave_sync();
     // Pruned plan: the declaration "these stored entries of A are zero" is checked for the item.  An item that
     // violates it is solved on the WHOLE pattern (plan plf, same elimination order) right here, in a workspace slot
@@ -2580,23 +2611,27 @@ __global__ void __launch_bounds__(64, LAT ? 1 : ((TRACE || POLISHER) ? 2 : 3)) q
     // heuristic only: both forms compute the same thing.  (Balanced by every wave when it is done; shared by all
     // launches on purpose -- independent batches on other streams fill the chip just the same.)
     int seen = 0;
+    // (own count first, global count second -- and the other way round at the end: the difference never shows a wave of this launch)
+    const bool counts_own = dq_mode == 2 || (LAT && ((phases >> 28) & 1) == 1);
+    if (counts_own && lane == 0) atomicAdd(&(fbflags + kFbSlots + 2 * batch + 16)[kDqOwn], 1);
     if (lane == 0) seen = atomicAdd(&g_sparse_active, 1);
     const bool lean = (nwaves > lean_waves_item) || __builtin_amdgcn_readfirstlane(seen) >= lean_waves_item;
     // (phased launches: an item of the fallback pool runs all phases at once, in the setup launch)
-    const int st = sp_solve_item<LAT, TRACE>(*use, kp, gPx, gq, gAx, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode, wsb, wsd, lean_waves_item,
+    const int st = sp_solve_item<LAT, TRACE, LAT || POLISHER>(*use, kp, gPx, gq, gAx, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode, wsb, wsd, lean_waves_item,
                                  lean, (size_t)item, slot, t, lane, resume != 0, fbslot >= 0 ? nullptr : queue, nfresh, slice,
                                  /*allow_reuse: the item's own slot of the main workspace*/ fbslot < 0 && slot == (size_t)item,
-                                 fbslot >= 0 ? PH_EVERYTHING : phases, keys ? keys + item : nullptr, trace, trace_cap, phase_us);
+                                 fbslot >= 0 ? PH_EVERYTHING : (helper ? (PH_FINISH | (PH_FINISH << 4)) : phases), keys ? keys + item : nullptr, trace,
+                                 trace_cap, phase_us);
     if (keys != nullptr && st != SP_PAUSED && lane == 0) keys[item] = -1.0f;
     if (fbslot >= 0 && phases != PH_EVERYTHING && lane == 0)  // tell the later launches (the item's own slot is otherwise unused)
       carve_ws(gws + (size_t)item * ws_doubles, uni(plp->n), uni(plp->m), uni(plp->nnzL), uni(plp->funits), uni(plp->bunits)).hdr[kHdrComplete] = 1.0;
-    if (dq_mode == 2 && lane == 0)  // polished and reported: the finish launch skips it
+    if ((dq_mode == 2 || helper) && lane == 0)  // polished and reported: the finish launch skips it
       carve_ws(gws + (size_t)item * ws_doubles, uni(plp->n), uni(plp->m), uni(plp->nnzL), uni(plp->funits), uni(plp->bunits)).hdr[kHdrComplete] = 1.0;
     wave_sync();
     if constexpr (LAT) {
       // the item's loop has ended in a loop launch (phases ADMM .. ADMM of a launch with auxiliary memory): hand it to the polishers
       // (the ring is there and zeroed whether or not polishers run)
-      if (st == SP_DONE && (phases & 0xFF) == (PH_ADMM | (PH_ADMM << 4)) && ((phases >> 28) & 3) == 1 && lane == 0) {
+      if (st == SP_DONE && !helper && (phases & 0xFF) == (PH_ADMM | (PH_ADMM << 4)) && ((phases >> 28) & 1) == 1 && lane == 0) {
         int32_t *const doneq = fbflags + kFbSlots + 2 * batch + 16;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2606,6 +2641,7 @@ __global__ void __launch_bounds__(64, LAT ? 1 : ((TRACE || POLISHER) ? 2 : 3)) q
     }
     if (lane == 0) {
       atomicSub(&g_sparse_active, 1);
+      if (counts_own) atomicSub(&(fbflags + kFbSlots + 2 * batch + 16)[kDqOwn], 1);
       if (fbslot >= 0) __hip_atomic_store(&fbflags[fbslot], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       if (st == SP_SUSPENDED) {
         // publish the item's state (plain and non-temporal stores of this wave) before its id enters the ring
@@ -2885,7 +2921,8 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
           hipEventCreateWithFlags(&ev1, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev2, hipEventDisableTiming) == hipSuccess) {
         int32_t *dq = count + 16;  // (== fbflags + kFbSlots + 2 batch + 16: where the kernel looks for it)
         if (hipMemsetAsync(dq, 0, (size_t)(kDqRing + batch) * sizeof(int32_t), stream) == hipSuccess && hipEventRecord(ev1, stream) == hipSuccess) {
-          prod = DoneQ{dq, 1, nullptr};
+          const char *hp = sfb::knob("SFB_SP_LAT_HELP");  // 0: the LAT waves leave when their items are out (measurements)
+          prod = DoneQ{dq, (hp && atoi(hp) == 0) ? 1 : 3, nullptr};  // (3: ... and help the polishers, see the kernel)
           cons = DoneQ{dq, 2, hs};
         }
       }
