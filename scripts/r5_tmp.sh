@@ -1,24 +1,14 @@
 cd ${GRAFT_REPO_ROOT:-.}
-ROOT=$PWD
-cd /tmp; export TMPDIR=/tmp
-for K in "SFB_SP_LAT_HELP=1" "SFB_SP_LAT_HELP=0"; do
-OUT=$ROOT/gpurun_out/pipe_trace_$K
-rm -rf $OUT
-(cd $ROOT && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-closed-loop --workload mpc --debug-knob $K > $OUT.log 2>&1)
-echo "== $K"
-python3 - <<PY
-import csv, glob, json
-f = glob.glob("$OUT/**/t_kernel_trace.csv", recursive=True)[0]
-rows = []
-for r in csv.DictReader(open(f)):
-    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("void ", "").replace("sfb::", "").split("(")[0][:40], int(r["Grid_Size_X"]), r.get("Queue_Id"), r.get("Stream_Id")))
-rows.sort()
-rows = [r for r in rows if "sparse" in r[2] or "rank" in r[2]]
-last = rows[-44:]
-t0 = last[0][0]
-for s, e, k, g, q, st in last:
-    if e - s > 50000: print("  +%8.3f ms  %8.3f ms  grid %6d  q %s st %s %s" % ((s - t0) / 1e6, (e - s) / 1e6, g // 64, q, st, k))
-d = json.loads(open("$OUT.log").read().strip().splitlines()[-1])
-print(d["ms_per_step"], d["pipelined"])
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_mpc_gpu.py tests/test_qp_sparse_gpu.py -x -q -m gpu 2>&1 | tail -3
+for K in ""; do
+timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary $K > gpurun_out/bench_w.json 2> gpurun_out/bench_w.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/bench_w.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], 'pipelined', d['pipelined']['value'])
+c=d['closed_loop']
+print('tick', c['swarm_tick']['ms_per_tick'], 'half', c['swarm_tick']['half_swarm']['ms_per_tick'], 'e2e', c['end_to_end']['ms_per_step'], 'single', c['single_agent']['cold_ms'], c['single_agent'].get('warm_ms'))
+print(d['phases_ms'])
 PY
 done

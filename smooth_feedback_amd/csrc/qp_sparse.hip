@@ -1636,6 +1636,10 @@ __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const 
     struct Ix { int a, b; };
     struct V3 { double a, b, c; };
     struct V4 { double a, b, c, d; };
+    // (first round: tv = 0, every chain below is a sum of exact zeros -- the data are finite: polish follows a solve that ended
+    //  Optimal, i.e. with finite residuals of P x, A x and A' y -- so the rows are taken as empty and the residual is h, bit for
+    //  bit what the chains would give)
+    const bool zero_tv = iter == 0;
     for (int i0 = lane; i0 < n; i0 += kWave * RB) {
       double acc[RB], sxi[RB], qi[RB];
       int pv[RB];
@@ -1649,7 +1653,7 @@ __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const 
         pv[r]  = on ? pl.pinv[i] : k;
       }
       // P as selfadjointView<Upper>: entry (min, max)
-      sp_rows_chain<RB, CE>(acc, i0, n, [&](int i) { return Ix{pl.Sp[i], pl.Sp[i + 1]}; },
+      sp_rows_chain<RB, CE>(acc, i0, n, [&](int i) { return zero_tv ? Ix{0, 0} : Ix{pl.Sp[i], pl.Sp[i + 1]}; },
                             [&](int q) { return Ix{pl.Spos[q], pl.Sj[q]}; },
                             [&](const Ix &x) { return V3{it.Px[x.a], w.sx[x.b], w.tv[x.b]}; },
                             [&](int r, const Ix &x, const V3 &v, double a) {
@@ -1658,7 +1662,7 @@ __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const 
                               return fma(c * s_ec * s_er * v.a, v.c, a);
                             });
       // column i of A, active rows only
-      sp_rows_chain<RB, CE>(acc, i0, n, [&](int i) { return Ix{pl.Acp[i], pl.Acp[i + 1]}; },
+      sp_rows_chain<RB, CE>(acc, i0, n, [&](int i) { return zero_tv ? Ix{0, 0} : Ix{pl.Acp[i], pl.Acp[i + 1]}; },
                             [&](int q) { return Ix{pl.Acpos[q], pl.Aci[q]}; },
                             [&](const Ix &x) { return V4{w.act[x.b], w.sy[x.b], it.Ax[x.a], w.tv[n + x.b]}; },
                             [&](int r, const Ix &, const V4 &v, double a) { return (v.a != 0.0) ? fma(v.b * sxi[r] * v.c, v.d, a) : a; });
@@ -1683,7 +1687,7 @@ __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const 
         pv[r]  = on ? pl.pinv[n + rr] : k;
       }
       sp_rows_chain<RB, CE>(acc, r0, m,
-                            [&](int rr) { return (w.act[rr] != 0.0) ? Ix{pl.Ap[rr], pl.Ap[rr + 1]} : Ix{0, 0}; },  // inactive rows: h - acc = 0
+                            [&](int rr) { return (!zero_tv && w.act[rr] != 0.0) ? Ix{pl.Ap[rr], pl.Ap[rr + 1]} : Ix{0, 0}; },  // inactive rows: h - acc = 0
                             [&](int q) { return Ix{q, pl.Aj[q]}; },
                             [&](const Ix &x) { return V3{it.Ax[x.a], w.sx[x.b], w.tv[x.b]}; },
                             [&](int r, const Ix &, const V3 &v, double a) { return fma(syr[r] * v.b * v.a, v.c, a); });
