@@ -37,6 +37,10 @@ struct sfb_sparse_qp_plan {
     std::pair<char *, size_t> ws{nullptr, 0};  // (buffer, bytes)
     int64_t batch = -1;                        // batch of the last call whose workspace content is still in the buffer
     uint64_t origin = 0;                       // who made that call: 0 = a direct host call, else the signature of a *_multi call
+    // The stream the host entry launches on: its own, not synchronising with the null stream.  (Measured, round 5: once the
+    // application has recorded timing events on the null stream, a solve launched there from this entry takes 60 instead of
+    // 43 ms -- the runtime then tracks every dispatch of that queue; bench.py's event-timed loop did exactly that.)
+    hipStream_t stream = nullptr;
   };
   std::map<int, HostDev> host_dev;  // device ordinal -> state; entries are created under `mu` and never move
 };
@@ -268,8 +272,10 @@ void sfb_sparse_qp_plan_destroy(sfb_sparse_qp_plan *plan)
     if (kv.second.blob) (void)hipFree(kv.second.blob);
     if (kv.second.blob_full) (void)hipFree(kv.second.blob_full);
   }
-  for (auto &kv : plan->host_dev)
+  for (auto &kv : plan->host_dev) {
     if (kv.second.ws.first) (void)hipFree(kv.second.ws.first);
+    if (kv.second.stream) (void)hipStreamDestroy(kv.second.stream);
+  }
   delete plan;
 }
 
@@ -462,6 +468,10 @@ sfb_status sfb_sparse_qp_solve_batch_host_phases(sfb_sparse_qp_plan *plan, const
     cache.second = bytes;
     hd->batch    = -1;
   }
+  if (hd->stream == nullptr && (e = hipStreamCreateWithFlags(&hd->stream, hipStreamNonBlocking)) != hipSuccess) {
+    hd->stream = nullptr;
+    return sfb::hip_fail(e, "hipStreamCreateWithFlags");
+  }
   // reuse_factor refers to "the previous call on this workspace": the workspace sits at the start of the cached
   // buffer, so it is the same memory, item for item, exactly when the batch size is that of the previous call
   // -- and the call comes from where the previous one came from: a shard of a *_multi call holds the items its device
@@ -502,10 +512,14 @@ sfb_status sfb_sparse_qp_solve_batch_host_phases(sfb_sparse_qp_plan *plan, const
       if ((e = H2D(dtrace, trace, TR0 * 8)) != hipSuccess) break;
     }
     tv1 = clk::now();
-    st = solve_batch_impl(plan, prm, batch, dPx, dq, dAx, dl, du, dwx, dwy, dx, dy, dobj, dit, dcode, dws, nullptr, nullptr,
+    // (the uploads above are synchronous copies: complete before the first launch is enqueued)
+    st = solve_batch_impl(plan, prm, batch, dPx, dq, dAx, dl, du, dwx, dwy, dx, dy, dobj, dit, dcode, dws, nullptr, hd->stream,
                           trace ? dtrace : nullptr, trace ? trace_rows : 0, phase_us ? dtrace + TR0 : nullptr);
-    if (st != SFB_OK) break;
-    if ((e = hipDeviceSynchronize()) != hipSuccess) break;
+    if (st != SFB_OK) {
+      (void)hipStreamSynchronize(hd->stream);
+      break;
+    }
+    if ((e = hipStreamSynchronize(hd->stream)) != hipSuccess) break;
     tv2 = clk::now();
     if ((e = D2H(x, dx, B * N * 8)) != hipSuccess) break;
     if ((e = D2H(y, dy, B * M * 8)) != hipSuccess) break;

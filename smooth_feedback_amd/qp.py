@@ -349,9 +349,11 @@ class SparseQPPlan:
             pass
 
     def solve_batch_host(self, Px, q, Ax, l, u, prm: Optional[QPSolverParams] = None, warm_x=None, warm_y=None,
-                         multi_device=False, trace_rows=0, phases=False):
+                         multi_device=False, trace_rows=0, phases=False, out: Optional["QPBatchSolution"] = None):
         """sfb_sparse_qp_solve_batch_host[_multi | _trace]: Px (B, nnzP), q (B, n), Ax (B, nnzA), l,u (B, m).
-        trace_rows > 0: the reference's verbose table (qp_solver.hpp:490-501) as data in `.trace`."""
+        trace_rows > 0: the reference's verbose table (qp_solver.hpp:490-501) as data in `.trace`.
+        out: a QPBatchSolution of an earlier call with the same batch size whose arrays receive the results (the C entry writes
+        into the caller's buffers; a control loop keeps them from tick to tick instead of touching fresh pages every call)."""
         q = np.ascontiguousarray(q, dtype=np.float64)
         B = q.shape[0]
         Px = _f64(np.reshape(Px, (B, self.nnzP)), (B, self.nnzP))
@@ -361,8 +363,15 @@ class SparseQPPlan:
             raise ValueError("warm_x and warm_y must be given together")
         if warm_x is not None:
             warm_x = _f64(warm_x, (B, self.n)); warm_y = _f64(warm_y, (B, self.m))
-        x = np.empty((B, self.n)); y = np.empty((B, self.m)); obj = np.empty(B)
-        it = np.empty(B, dtype=np.uint32); code = np.empty(B, dtype=np.int32)
+        if out is not None:
+            x, y, obj, it, code = out.primal, out.dual, out.objective, out.iter, out.code
+            for a, shp, dt in ((x, (B, self.n), np.float64), (y, (B, self.m), np.float64), (obj, (B,), np.float64),
+                               (it, (B,), np.uint32), (code, (B,), np.int32)):
+                if a.shape != shp or a.dtype != dt or not a.flags.c_contiguous or not a.flags.writeable:
+                    raise ValueError("out: arrays of another batch size or layout")
+        else:
+            x = np.empty((B, self.n)); y = np.empty((B, self.m)); obj = np.empty(B)
+            it = np.empty(B, dtype=np.uint32); code = np.empty(B, dtype=np.int32)
         cp = (prm or QPSolverParams()).to_c()
         if trace_rows or phases:  # phases: the per-phase times of qp_solver.hpp:550-565 as data in `.phase_us`
             if multi_device:
