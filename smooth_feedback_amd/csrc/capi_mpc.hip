@@ -155,6 +155,7 @@ struct sfb_mpc_swarm {
          *wy = nullptr, *rec = nullptr, *shared = nullptr, *du0 = nullptr, *ws = nullptr;
   uint32_t *iter = nullptr;
   int32_t *code = nullptr, *order = nullptr;
+  sfb::MpcAsmDesc *table_own = nullptr, *table_shared = nullptr;  // the assembly kernel's tables (one allocation; mpc_kernel.h)
   std::vector<uint32_t> h_iter;   // iteration counts of the last tick (host), for the launch order of the next
   std::vector<int32_t> h_order;
   bool have_order = false;
@@ -293,6 +294,14 @@ sfb_status sfb_mpc_swarm_create(sfb_sparse_qp_plan *plan, const sfb_mpc_layout *
   S->h_iter.assign(B, 0);
   S->h_order.resize(B);
   do {
+    {  // the assembly tables of both record forms
+      std::vector<sfb::MpcAsmDesc> tb(2 * (size_t)p.nnzA);
+      sfb::mpc_build_table(S->rec_own, false, tb.data());
+      sfb::mpc_build_table(S->rec_shared, true, tb.data() + p.nnzA);
+      if ((e = hipMalloc(reinterpret_cast<void **>(&S->table_own), tb.size() * sizeof(sfb::MpcAsmDesc))) != hipSuccess) break;
+      S->table_shared = S->table_own + p.nnzA;
+      if ((e = hipMemcpy(S->table_own, tb.data(), tb.size() * sizeof(sfb::MpcAsmDesc), hipMemcpyHostToDevice)) != hipSuccess) break;
+    }
     if (h.nnzP > 0 && (e = hipMemcpy(stage, Px, (size_t)h.nnzP * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
     if ((e = hipMemcpy(stage + h.nnzP, q, N * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
     if ((e = sfb::mpc_replicate_launch(stage, h.nnzP, agents, S->Px, nullptr)) != hipSuccess) break;
@@ -302,6 +311,7 @@ sfb_status sfb_mpc_swarm_create(sfb_sparse_qp_plan *plan, const sfb_mpc_layout *
   } while (false);
   if (e != hipSuccess) {
     (void)hipFree(S->mem);
+    if (S->table_own) (void)hipFree(S->table_own);
     delete S;
     return sfb::hip_fail(e, "sfb_mpc_swarm_create");
   }
@@ -315,6 +325,7 @@ void sfb_mpc_swarm_destroy(sfb_mpc_swarm *swarm)
   if (swarm->up_stream) { (void)hipStreamSynchronize(swarm->up_stream); (void)hipStreamDestroy(swarm->up_stream); }
   if (swarm->pinned) (void)hipHostFree(swarm->pinned);
   if (swarm->mem) (void)hipFree(swarm->mem);
+  if (swarm->table_own) (void)hipFree(swarm->table_own);
   delete swarm;
 }
 
@@ -393,6 +404,12 @@ sfb_status sfb_mpc_swarm_set_jac_keep(sfb_mpc_swarm *S, const uint8_t *jac_keep,
   }
   set_packing(S->rec_own, false, jac_keep);
   if (record_doubles) *record_doubles = S->rec_own.rec_doubles;
+  {  // the assembly table of the new record form (a synchronous copy on the null stream: behind the ticks launched so far)
+    std::vector<sfb::MpcAsmDesc> tb((size_t)S->rec_own.nnzA);
+    sfb::mpc_build_table(S->rec_own, false, tb.data());
+    const hipError_t e = hipMemcpy(S->table_own, tb.data(), tb.size() * sizeof(sfb::MpcAsmDesc), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return sfb::hip_fail(e, "hipMemcpy(assembly table)");
+  }
   return SFB_OK;
 }
 
@@ -452,7 +469,8 @@ static sfb_status swarm_step_impl(sfb_mpc_swarm *S, const sfb_qp_params *prm, co
     } else if ((e = hipMemcpy(S->rec, records, B * (size_t)p.rec_doubles * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
     if (shared_jac && (e = hipMemcpy(S->shared, shared_jac, (size_t)S->shared_doubles * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
     lap("H2D");
-    if ((e = sfb::mpc_assemble_launch(p, S->agents, S->rec, shared_jac ? S->shared : nullptr, S->Ax, S->l, S->u, nullptr)) != hipSuccess) break;
+    if ((e = sfb::mpc_assemble_launch(p, S->agents, S->rec, shared_jac ? S->shared : nullptr, S->Ax, S->l, S->u, nullptr,
+                                      shared_jac ? S->table_shared : S->table_own)) != hipSuccess) break;
     lap("assemble");
     // Warm-started ticks: the agents that iterated longest in the previous tick are launched first (their counts
     // change little from tick to tick), so the stragglers overlap with the bulk of the batch.

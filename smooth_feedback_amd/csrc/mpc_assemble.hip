@@ -20,10 +20,69 @@ __device__ __forceinline__ double jac_entry(const double *__restrict__ blk, cons
   return blk[(size_t)block * kept + kp[d] + __popc(mk & ((1u << c) - 1u))];
 }
 
+// The place of entry `idx` of A in ocp_to_qp_update_dyn / _cr / _ce as a table row (host; mirrors the index arithmetic of the
+// kernel's direct form below, which stays as the form without a table and as the definition the table is tested against).
+void mpc_build_table(const MpcAsmParams &p, const bool shared, MpcAsmDesc *out)
+{
+  const int nx = p.nx, nu = p.nu, ncr = p.ncr, kmesh = p.kmesh;
+  const bool pk = p.packed != 0 && !shared;
+  // offset of entry (d, c) of block `block` of a Jacobian array at `base`, -1 when the packing leaves it out
+  auto jac_off = [&](int base, int kept, const uint32_t *km, const uint16_t *kp, int block, int d, int c, int rows, int cols) -> int {
+    if (!pk) return base + (block * rows + d) * cols + c;
+    const uint32_t mk = km[d];
+    if (((mk >> c) & 1u) == 0u) return -1;
+    return base + block * kept + kp[d] + __builtin_popcount(mk & ((1u << c) - 1u));
+  };
+  for (int idx = 0; idx < p.nnzA; ++idx) {
+    MpcAsmDesc e{-1, 0, 0.0};
+    if (idx < p.nnz_dyn) {
+      const int row = idx / p.rowlen_dyn, pos = idx - row * p.rowlen_dyn;
+      const int node = row / nx, d = row - node * nx;
+      const int s = node / kmesh, i = node - s * kmesh;
+      const double alpha = p.alpha[s];
+      if (pos >= kmesh + nx) {
+        e.src  = jac_off(p.o_dfdu, p.n_fu, p.km_fu, p.kp_fu, node, d, pos - (kmesh + nx), nx, nu);
+        e.meta = 0;
+      } else if (pos >= i && pos < i + nx) {
+        const int c = pos - i;
+        e.src  = jac_off(p.o_dfdx, p.n_fx, p.km_fx, p.kp_fx, node, d, c, nx, nx);
+        e.meta = 1;
+        if (p.has_ad) {
+          const int code = p.adsrc[d * nx + c];
+          if (code != 0) {
+            const int k = (code > 0 ? code : -code) - 1, off = node * nx + k + 1;
+            e.meta |= (code > 0 ? off : -off) * 16;
+          }
+        }
+        if (c == d) {
+          e.meta |= 4;
+          e.coef = alpha * p.D[i * kmesh + i];
+        }
+      } else {
+        const int j = (pos < i) ? pos : pos - nx + 1;
+        e.meta = 2;
+        e.coef = alpha * p.D[j * kmesh + i];
+      }
+    } else if (idx < p.nnz_dyn + p.nnz_cr) {
+      const int q = idx - p.nnz_dyn, row = q / (nx + nu), pos = q - row * (nx + nu);
+      const int cnode = row / ncr, cd = row - cnode * ncr;
+      e.src  = (pos < nx) ? jac_off(p.o_dcdx, p.n_cx, p.km_cx, p.kp_cx, cnode, cd, pos, ncr, nx)
+                          : jac_off(p.o_dcdu, p.n_cu, p.km_cu, p.kp_cu, cnode, cd, pos - nx, ncr, nu);
+      e.meta = 3;
+    } else {
+      const int q = idx - p.nnz_dyn - p.nnz_cr;
+      // (the terminal Jacobian always travels in the agent's record; packed with it when the record is packed)
+      e.src  = (p.packed != 0 && !shared) ? jac_off(p.o_J, p.n_J, p.km_J, p.kp_J, 0, q / nx, q % nx, nx, nx) : p.o_J + q;
+      e.meta = 3 | 8;
+    }
+    out[idx] = e;
+  }
+}
+
 __global__ void __launch_bounds__(256) mpc_assemble_kernel(const MpcAsmParams p, const double *__restrict__ records,
                                                            const double *__restrict__ shared_jac,
                                                            double *__restrict__ gAx, double *__restrict__ gl,
-                                                           double *__restrict__ gu)
+                                                           double *__restrict__ gu, const MpcAsmDesc *__restrict__ table)
 {
   const int64_t b  = blockIdx.y;
   const int idx    = blockIdx.x * 256 + threadIdx.x;
@@ -32,7 +91,34 @@ __global__ void __launch_bounds__(256) mpc_assemble_kernel(const MpcAsmParams p,
   const int nx = p.nx, nu = p.nu, ncr = p.ncr, kmesh = p.kmesh;
   const double tf = p.tf;
   const bool pk   = p.packed != 0 && shared_jac == nullptr;
-  if (idx < p.nnzA) {
+  if (table != nullptr && idx < p.nnzA) {
+    // TABLE FORM (swarms): one 16-byte row says where the entry's Jacobian value is and which terms it takes -- the same
+    // operations in the same order as the direct form below, without its divisions and mask arithmetic (the direct form spent
+    // 0.88 ms per 8 192 agents of the headline model on 840 MB of output: integer-bound, not HBM-bound)
+    const MpcAsmDesc e = table[idx];
+    const int kind     = e.meta & 3;
+    const double j     = e.src >= 0 ? ((e.meta & 8) ? rec : jac)[e.src] : 0.0;
+    double v;
+    if (kind == 3) {
+      v = j;
+    } else if (kind == 0) {
+      v = 0.0 + tf * j;
+    } else if (kind == 1) {
+      v = 0.0;
+      v += tf * j;
+      const int code = e.meta >> 4;
+      if (code != 0) {  // (no ad term, or one whose entry is 0.0: adding -tf/2 * 0.0 leaves v as it is)
+        const int k     = (code > 0 ? code : -code) - 1;
+        const double sk = rec[p.o_f + k] + rec[p.o_dx + k];
+        v += (-tf / 2) * ((code > 0) ? sk : -sk);
+      }
+      if (e.meta & 4) v -= e.coef;
+    } else {
+      v = 0.0;
+      v -= e.coef;
+    }
+    gAx[b * p.nnzA + idx] = v;
+  } else if (idx < p.nnzA) {
     double v;
     if (idx < p.nnz_dyn) {  // ocp_to_qp_update_dyn :240-275
       const int row = idx / p.rowlen_dyn, pos = idx - row * p.rowlen_dyn;
@@ -124,13 +210,13 @@ __global__ void __launch_bounds__(64) mpc_store_kernel(const int n, const int m,
 }
 
 hipError_t mpc_assemble_launch(const MpcAsmParams &p, int64_t batch, const double *records, const double *shared_jac,
-                               double *Ax, double *l, double *u, hipStream_t stream)
+                               double *Ax, double *l, double *u, hipStream_t stream, const MpcAsmDesc *table)
 {
   const int blocks = (p.nnzA + p.m + 255) / 256;
   for (int64_t b0 = 0; b0 < batch; b0 += 65535) {  // gridDim.y limit
     const int64_t nb = (batch - b0 < 65535) ? batch - b0 : 65535;
     hipLaunchKernelGGL(mpc_assemble_kernel, dim3(blocks, (unsigned)nb), dim3(256), 0, stream, p,
-                       records + b0 * p.rec_doubles, shared_jac, Ax + b0 * p.nnzA, l + b0 * p.m, u + b0 * p.m);
+                       records + b0 * p.rec_doubles, shared_jac, Ax + b0 * p.nnzA, l + b0 * p.m, u + b0 * p.m, table);
   }
   return hipGetLastError();
 }

@@ -32,8 +32,23 @@ struct MpcAsmParams {
   uint16_t kp_fx[kMpcMaxNx], kp_fu[kMpcMaxNx], kp_cx[kMpcMaxNcr], kp_cu[kMpcMaxNcr], kp_J[kMpcMaxNx];
 };
 
+// One stored entry of A as the assembly kernel's table form sees it (built once per layout / packing by mpc_build_table, the
+// same for every agent): where its Jacobian entry sits, which term of ocp_to_qp_update_* it takes part in, its constant.
+//   meta bits 0..1: 0 = u block of a dynamics row (0.0 + tf j), 1 = x block of the node itself (0.0 + tf j, ad term, - coef),
+//                   2 = another node of the interval (0.0 - coef), 3 = the entry itself (cr and ce rows)
+//        bit 2: subtract coef (kind 1: the diagonal), bit 3: src is an offset into the agent's record even when the Jacobians are
+//        shared (ce rows), bits 4..31 (signed): the ad term, +-(offset of s_k inside f / dxdes + 1), 0 = none
+//   src: offset (doubles) of j inside the record holding the Jacobians, -1 = a structural 0.0 (entry left out by the packing)
+struct MpcAsmDesc {
+  int32_t src, meta;
+  double coef;
+};
+// the table of a parameter set (nnzA entries); `shared`: the Jacobians come from the shared record
+void mpc_build_table(const MpcAsmParams &p, bool shared, MpcAsmDesc *out);
+
+// table (device, nullable): the entries of A through the table instead of recomputing their place from the index
 hipError_t mpc_assemble_launch(const MpcAsmParams &p, int64_t batch, const double *records, const double *shared_jac,
-                               double *Ax, double *l, double *u, hipStream_t stream);
+                               double *Ax, double *l, double *u, hipStream_t stream, const MpcAsmDesc *table = nullptr);
 // out[b][:] = src[:] for every b
 hipError_t mpc_replicate_launch(const double *src, int64_t len, int64_t batch, double *out, hipStream_t stream);
 // after a solve: agents whose code is Optimal / MaxIterations / MaxTime store (x, y) as their warm start
