@@ -296,3 +296,29 @@ def test_zero_pivot_ends_with_unknown_in_both_factorisation_engines(sfb, oracle,
     assert (r.code[bad] == 6).all() and (r.iter[bad] == 0).all() and (r.code[~bad] != 6).any()
     good = r.code != 6
     assert np.array_equal(r.primal[good], ref["x"][good], equal_nan=True) and np.array_equal(r.dual[good], ref["y"][good], equal_nan=True)
+
+
+def test_host_entry_writes_into_the_callers_result_buffers(sfb):
+    """solve_batch_host(..., out=earlier solution): the C entry writes into the caller's x / y / obj / iter / code, so a control
+    loop keeps its result arrays from tick to tick.  Same bits as a call that allocates; the arrays are the very ones handed
+    in; arrays of another batch size or dtype are refused before anything is launched."""
+    n, m, B = 10, 20, 96
+    P, q, A, l, u = sfb.random_qp_batch(5, B, m, n, 0.4)
+    Pp, Pi, Px, Ap, Aj, Ax = dense_batch_to_sparse(P, A, n, m, upper_only=True)
+    plan = sfb.SparseQPPlan(n, m, Pp, Pi, Ap, Aj)
+    prm = sfb.QPSolverParams(max_iter=2000)
+    fresh = plan.solve_batch_host(Px, q, Ax, l, u, prm)
+    keep = plan.solve_batch_host(Px, q + 1.0, Ax, l, u, prm)       # (other contents, to be overwritten)
+    ids = [id(a) for a in (keep.primal, keep.dual, keep.objective, keep.iter, keep.code)]
+    again = plan.solve_batch_host(Px, q, Ax, l, u, prm, out=keep)
+    assert [id(a) for a in (again.primal, again.dual, again.objective, again.iter, again.code)] == ids
+    for a, b in ((again.primal, fresh.primal), (again.dual, fresh.dual), (again.objective, fresh.objective),
+                 (again.iter, fresh.iter), (again.code, fresh.code)):
+        assert np.array_equal(a, b, equal_nan=True)
+    with pytest.raises(ValueError):
+        plan.solve_batch_host(Px[:8], q[:8], Ax[:8], l[:8], u[:8], prm, out=keep)
+    bad = plan.solve_batch_host(Px, q, Ax, l, u, prm)
+    bad.iter = bad.iter.astype(np.int64)
+    with pytest.raises(ValueError):
+        plan.solve_batch_host(Px, q, Ax, l, u, prm, out=bad)
+    plan.close()
