@@ -1,11 +1,7 @@
+# scratch script of round 5 (whatever was measured last on the GPU box); the recipes that matter are the named scripts next to it
 cd ${GRAFT_REPO_ROOT:-.}
-for P in 0 1 2 3; do
-echo "== policy $P"
-KNOBS_POLICY=$P PLAN_DEBUG=1 timeout 500 python - <<'PY' 2>&1 | grep -v "amdgpu.ids\|segment columns\|slots per unit\|debug knob" | grep "unit engine\|B=    1 polish_iter=5\|B= 8192 polish_iter=5" | cut -c1-250
-import os, sys, runpy
-import smooth_feedback_amd as sfb
-sfb.debug_set("SFB_PLAN_POLICY", os.environ["KNOBS_POLICY"])
-sys.argv = ["lone_phases.py"]
-runpy.run_path("scripts/r5/lone_phases.py", run_name="__main__")
-PY
-done
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 900 python bench.py > gpurun_out/bench_r5_final.json 2> gpurun_out/bench_r5_final.err
+cut -c1-400 gpurun_out/bench_r5_final.json
