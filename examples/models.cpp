@@ -13,6 +13,7 @@
 #include <smooth_feedback_amd/asif.hpp>
 #include <smooth_feedback_amd/ekf.hpp>
 #include <smooth_feedback_amd/mpc.hpp>
+#include <smooth/feedback/mpc.hpp>  // the reference's include path and namespace (sfbx_test_mpc_api)
 
 #include "vehicle_model.h"
 
@@ -451,7 +452,7 @@ int sfbx_test_ocp_to_qp_parabola(double * out)
   };
   MPCParams p;
   p.K = 10; p.tf = 2.0;
-  MPC<X2, U1, 1, Dyn, Cr, 5> mpc(Dyn{}, Cr{}, {-1.0}, {1.0}, p);
+  MPC<double, X2, U1, Dyn, Cr, 5> mpc(Dyn{}, Cr{}, {-1.0}, {1.0}, p);
   mpc.set_xdes([](double t) { X2 x; x.v = {0.05 * t * t, 0.1 * t}; return x; }, [](double t) { return Vec<2>{0.1 * t, 0.1}; });
   mpc.set_udes([](double) { U1 u; u.v = {0.1}; return u; });
   auto xtraj = [](double t) { X2 x; x.v = {3.0 - 0.3 * t + 0.05 * t * t, -0.3 + 0.1 * t}; return x; };
@@ -502,7 +503,7 @@ int sfbx_test_mpc_doubleintegrator(int ticks, double * u_out, uint32_t * iters, 
       setenv("SFB_QP_NO_REUSE", pass ? "1" : "0", 1);
       MPCParams p;
       p.K = 20; p.tf = 5.0;
-      MPC<X2, U1, 1, Dyn, Cr> mpc(Dyn{}, Cr{}, {-0.5}, {0.5}, p);
+      MPC<double, X2, U1, Dyn, Cr> mpc(Dyn{}, Cr{}, {-0.5}, {0.5}, p);
       mpc.set_xdes([](double t) { X2 x; x.v = {-0.5 * std::sin(0.3 * t), 0.0}; return x; },
                    [](double t) { return Vec<2>{-0.15 * std::cos(0.3 * t), 0.0}; });
       mpc.set_udes([](double) { U1 u; u.v = {0.0}; return u; });
@@ -553,7 +554,7 @@ int sfbx_test_mpc_time_and_setters(double * out)
   // (2) the Time concept (time.hpp:25-89): the same controller on a std::chrono clock
   using Clock = std::chrono::steady_clock;
   using TP    = Clock::time_point;
-  using MPC6c = MPC<X6, U2, 2, VehicleDyn6, sfbx::InputBox<X6>, 4, TP>;
+  using MPC6c = MPC<TP, X6, U2, VehicleDyn6, sfbx::InputBox<X6>>;
   static_assert(Time<TP> && Time<std::chrono::nanoseconds> && Time<double>);
   const TP epoch = TP{} + std::chrono::hours(1000);
   MPC6c c(mdl.f, mdl.cr, {-0.5, -0.5}, {0.5, 0.5}, p);
@@ -612,7 +613,7 @@ int sfbx_test_mpc_se2(double * u_out, int32_t * codes, int32_t * traj_sizes)
     for (int pass = 0; pass < 2; ++pass) {
       MPCParams p;  // defaults: K = 10, tf = 1 (tests/test_mpc.cpp:77)
       p.warmstart = (pass == 0);
-      MPC<SE2, U2, 2, Dyn, Cr> mpc(Dyn{}, Cr{}, {-1, -1}, {1, 1}, p);
+      MPC<double, SE2, U2, Dyn, Cr> mpc(Dyn{}, Cr{}, {-1, -1}, {1, 1}, p);
       mpc.set_udes([](double) { U2 u; u.v = {1.0, 1.0}; return u; });                      // :91
       mpc.set_xdes([](double) { return SE2::Identity(); }, [](double) { return Vec<3>{}; });  // :92
       const SE2 x = rplus(SE2::Identity(), SE2::Tangent{0.3, -0.2, 0.25});
@@ -629,6 +630,189 @@ int sfbx_test_mpc_se2(double * u_out, int32_t * codes, int32_t * traj_sizes)
     return -2;
   }
   return 0;
+}
+
+// ---- tests/test_mpc.cpp:34-155 written against <smooth/feedback/mpc.hpp> with only the Lie types renamed
+// (smooth::SE2d -> SE2, Eigen::Vector2d -> Rn<2> / Vec<2>, generic `template<typename S>` functors -> double) ----
+namespace ref_mpc_test {
+using T = double;
+using X = SE2;
+using U = U2;
+
+struct MyDynamics {  // tests/test_mpc.cpp:34-45
+  Vec<3> operator()(const X &, const U & u) const { return {u.v[0], 0.0, u.v[1]}; }
+  inline void set_time(double t) { t_ = t; }
+  double t_{0};
+};
+struct MyRunningConstraints {  // :47-58
+  Vec<2> operator()(const X &, const U & u) const { return {u.v[0], u.v[1]}; }
+  inline void set_time(double t) { t_ = t; }
+  double t_{0};
+};
+using MPC_t = smooth::feedback::MPC<T, X, U, MyDynamics, MyRunningConstraints>;  // :60
+// StaticProperties, :62-68
+static_assert(std::is_copy_constructible_v<MPC_t>);
+static_assert(std::is_copy_assignable_v<MPC_t>);
+static_assert(std::is_move_constructible_v<MPC_t>);
+static_assert(std::is_move_assignable_v<MPC_t>);
+// special type that maintains references to f and cr, :70-71
+using MPC_reft = smooth::feedback::MPC<T, X, U, MyDynamics &, MyRunningConstraints &>;
+static_assert(MPC_t::Ncr == 2 && MPC_reft::Ncr == 2);  // mpc.hpp:383: read off CR's result
+
+double rel_diff(const U & a, const U & b)
+{
+  const double d = std::hypot(a.v[0] - b.v[0], a.v[1] - b.v[1]);
+  return d / std::max(1e-300, std::min(std::hypot(a.v[0], a.v[1]), std::hypot(b.v[0], b.v[1])));
+}
+}  // namespace ref_mpc_test
+
+int sfbx_test_mpc_api(double * out, int32_t * codes)
+{
+  using namespace ref_mpc_test;
+  try {
+    const X x = rplus(X::Identity(), X::Tangent{0.3, -0.2, 0.25});  // X::Random()
+    {  // TEST(Mpc, Api), :73-117
+      MyDynamics f{};
+      MyRunningConstraints cr{};
+      Vec<2> crl{1, 1};
+      MPC_reft mpc{f, cr, Vec<2>{-1, -1}, crl};
+
+      // nothing set
+      auto [u0, code0] = mpc(1, x);
+      codes[0] = (int32_t)code0;
+
+      mpc.reset_warmstart();
+
+      mpc.set_weights({
+        .Q   = Mat<3, 3>::Identity(),
+        .Qtf = Mat<3, 3>::Identity(),
+        .R   = Mat<2, 2>::Identity(),
+      });
+
+      mpc.set_udes([](T) -> U { U u; u.v = {1.0, 1.0}; return u; });
+      mpc.set_xdes_rel([](double) -> X { return X::Identity(); });
+
+      // no warmstart
+      auto [u1, code1] = mpc(2, x);
+      codes[1] = (int32_t)code1;
+
+      // with warmstart
+      auto [u2, code2] = mpc(3, x);
+      codes[2] = (int32_t)code2;
+
+      out[0] = rel_diff(u1, u2);
+
+      // output stuff
+      std::vector<X> xs;
+      std::vector<U> us;
+      auto [u3, code3] = mpc(4, x, us, xs);
+      codes[3] = (int32_t)code3;
+
+      out[1] = rel_diff(u3, u1);
+      out[2] = (us.size() + 1 == xs.size()) ? 1.0 : 0.0;
+      out[3] = f.t_;   // ASSERT_GE(f.t_, 4)
+      out[4] = cr.t_;  // ASSERT_GE(cr.t_, 4)
+      // (not in the reference's test) the nullable-pointer overload gives the same answer
+      std::vector<U> us2;
+      auto [u3p, code3p] = mpc(4, x, &us2);
+      out[5] = (code3p == code3 && us2.size() == us.size()) ? rel_diff(u3p, u3) : 1.0;
+    }
+    {  // TEST(Mpc, Constructors), :119-155
+      MyDynamics f{};
+      MyRunningConstraints cr{};
+      Vec<2> crl{1, 1};
+      MPC_t mpc{f, cr, Vec<2>{-1, -1}, crl};
+
+      mpc.reset_warmstart();
+
+      mpc.set_weights({
+        .Q   = Mat<3, 3>::Identity(),
+        .Qtf = Mat<3, 3>::Identity(),
+        .R   = Mat<2, 2>::Identity(),
+      });
+
+      mpc.set_udes([](T) -> U { U u; u.v = {1.0, 1.0}; return u; });
+      mpc.set_xdes_rel([](double) -> X { return X::Identity(); });
+
+      auto [u1, code1] = mpc(0, x);
+
+      // copy construction
+      auto mpc2        = mpc;
+      auto [u2, code2] = mpc2(0, x);
+
+      // copy assignment
+      MPC_t mpc3;
+      mpc3             = mpc;
+      auto [u3, code3] = mpc3(0, x);
+
+      // (not in the reference's test) mpc.hpp:407, 607-608: copies SHARE the desired trajectories -- a setter on the copy
+      // is seen by the original -- and own their solvers (qp_solver.hpp:209-231: a copy analyses again)
+      out[11] = (mpc2.solver().plan() != nullptr && mpc2.solver().plan() != mpc.solver().plan() &&
+                 mpc3.solver().plan() != mpc.solver().plan()) ? 1.0 : 0.0;
+      mpc3.set_udes([](T) -> U { U u; u.v = {0.25, -0.5}; return u; });
+      auto [u6, code6] = mpc(0, x);  // the ORIGINAL, after the copy's setter
+      MPC_t fresh{f, cr, Vec<2>{-1, -1}, crl};
+      fresh.set_udes([](T) -> U { U u; u.v = {0.25, -0.5}; return u; });
+      fresh.set_xdes_rel([](double) -> X { return X::Identity(); });
+      auto [u7, code7] = fresh(0, x);
+      out[12] = rel_diff(u6, u7);
+      out[13] = rel_diff(u6, u1);  // and it did change the answer
+      codes[9] = (int32_t)code6; codes[10] = (int32_t)code7;
+      mpc3.set_udes([](T) -> U { U u; u.v = {1.0, 1.0}; return u; });
+      mpc.reset_warmstart();
+
+      // move construction
+      auto mpc4        = std::move(mpc);
+      auto [u4, code4] = mpc4(0, x);
+
+      // move assignment
+      MPC_t mpc5;
+      mpc5             = std::move(mpc2);
+      auto [u5, code5] = mpc5(0, x);
+
+      out[6] = rel_diff(u1, u2);
+      out[7] = rel_diff(u1, u3);
+      out[8] = rel_diff(u1, u4);
+      out[9] = rel_diff(u1, u5);
+      codes[4] = (int32_t)code1; codes[5] = (int32_t)code2; codes[6] = (int32_t)code3; codes[7] = (int32_t)code4;
+      codes[8] = (int32_t)code5;
+    }
+    {  // examples/mpc_asif_vehicle.cpp:27-64, 73-96: the controller's declaration with Time = std::chrono::duration<double>
+      using Time = std::chrono::duration<double>;
+      using Xd   = X6;
+      using Ud   = U2;
+      auto f = [](const Xd & x, const Ud & u) -> Vec<6> {
+        const auto & v = x.part<1>().v;
+        return {v[0], v[1], v[2], -0.2 * v[0] + u.v[0], 0.0, -0.4 * v[2] + u.v[1]};
+      };
+      auto cr = [](const Xd &, const Ud & u) -> Vec<2> { return {u.v[0], u.v[1]}; };
+      Vec<2> crl{-0.5, -0.5};
+      Vec<2> cru{0.5, 0.5};
+      smooth::feedback::MPC<Time, Xd, Ud, decltype(f), decltype(cr)> mpc{
+        f,
+        cr,
+        crl,
+        cru,
+        {.K = 30, .tf = 5},
+      };
+      auto xdes = [](double t) -> Xd { return sfbx::VehicleModel6{}.xdes(t); };
+      mpc.set_weights({
+        .Q   = Mat<6, 6>::Identity(),
+        .Qtf = 0.1 * Mat<6, 6>::Identity(),
+        .R   = Mat<2, 2>::Identity(),
+      });
+      mpc.set_xdes_rel(xdes);
+      mpc.set_udes_rel([](double) -> Ud { return Ud{}; });
+      using namespace std::chrono_literals;
+      auto [u, code] = mpc(Time(25ms), perturbed(xdes(0.025), 3));
+      codes[11] = (int32_t)code;
+      out[10]   = std::max(std::fabs(u.v[0]), std::fabs(u.v[1]));  // inside cr's box
+    }
+    return 0;
+  } catch (const std::exception & e) {
+    std::fprintf(stderr, "sfbx_test_mpc_api: %s\n", e.what());
+    return -1;
+  }
 }
 
 double sfbx_lie_selftest(void)

@@ -23,6 +23,14 @@ int sfbx_mpc_assemble_batch(int variant, int K, double tf, int64_t batch, uint64
 /* Closed loop of tests/test_mpc.cpp:34-117 (SE2 state, R2 input, f = (u0, 0, u1), -1 <= u <= 1):
  * three consecutive MPC calls with warm start, then three without. u_out[6][2], codes[6]. Needs a GPU. */
 int sfbx_test_mpc_se2(double *u_out, int32_t *codes, int32_t *traj_sizes);
+/* tests/test_mpc.cpp:60-155 (StaticProperties as static_asserts, Api, Constructors) written against
+ * <smooth/feedback/mpc.hpp> with only the Lie types renamed, plus the declaration of examples/mpc_asif_vehicle.cpp:64.
+ * codes[12]: Api code0..3, Constructors code1..5, original-after-the-copy's-setter / fresh controller, the vehicle.
+ * out[14]: [0] rel |u1 - u2|, [1] rel |u3 - u1|, [2] us.size() + 1 == xs.size(), [3] f.t_, [4] cr.t_, [5] pointer overload,
+ * [6..9] rel |u1 - u2..5| of the copies / moves, [10] max |u| of the vehicle, [11] copies own their analyses,
+ * [12] rel |original after set_udes on a COPY - fresh controller with that udes| (copies share the desired
+ * trajectories, mpc.hpp:407, 607-608), [13] ... and that input differs from before.  Needs a GPU. */
+int sfbx_test_mpc_api(double *out, int32_t *codes);
 /* MPC API beyond operator(): out[0] set_xdes_rel / set_udes_rel (mpc.hpp:539-586) vs the absolute-time setters (max abs
  * difference of A, l, u), out[1] the same controller with Time = std::chrono::steady_clock::time_point (time.hpp:25-89),
  * out[2..4] set_weights (mpc.hpp:593-598: stored, not transcribed; the constructor transcribes), out[5..8] lazy structure

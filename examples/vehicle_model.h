@@ -167,8 +167,8 @@ inline void vehicle_state_out(const X6 & g, double * s)
   s[0] = p.x; s[1] = p.y; s[2] = p.c; s[3] = p.s; s[4] = v[0]; s[5] = v[1]; s[6] = v[2];
 }
 
-using MPC6  = MPC<X6, U2, 2, VehicleDyn6, InputBox<X6>>;
-using MPC12 = MPC<X12, U2, 2, VehicleDyn12, InputBox<X12>>;
+using MPC6  = MPC<double, X6, U2, VehicleDyn6, InputBox<X6>>;
+using MPC12 = MPC<double, X12, U2, VehicleDyn12, InputBox<X12>>;
 template<class MPCT, class Model>
 MPCT make_vehicle_mpc(int K, double tf)
 {

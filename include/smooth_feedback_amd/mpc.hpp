@@ -9,8 +9,9 @@
 //   ocp_to_qp_update_ce       :326-373 with MPCCE (mpc.hpp:275-302)
 // Deviations, all on the host: Jacobians of user functions are analytic when the functor has
 // `jacobian(...)`, else forward differences with step sqrt(eps) (the reference's default without the
-// autodiff header).  Time is the trailing template parameter T (any type with a time_trait, time.hpp:
-// double seconds by default, std::chrono time points / durations as in the reference's time.hpp:25-89).
+// autodiff header).  The template parameters are the reference's, in its order (mpc.hpp:372-380):
+// MPC<T, X, U, F, CR, Kmesh> with T any type with a time_trait (time.hpp: double seconds, std::chrono time points /
+// durations as in the reference's time.hpp:25-89) and the number of running constraints read off CR's result type.
 // set_weights() stores the weights like the reference does and, like the reference at v1, does NOT
 // re-transcribe the cost: P is built once in the constructor (mpc.hpp:423 vs :593-598).
 #pragma once
@@ -60,6 +61,29 @@ SFB_LIE_HD void xu_jacobian(const Fn & fn, const X & x, const U & u, Vec<NO> & v
     }
   }
 }
+/// number of entries of a functor's result (Vec<N> = std::array<double, N>): Ncr of mpc.hpp:383
+template<class V>
+inline constexpr int result_size_v = (int)std::tuple_size_v<std::remove_cvref_t<V>>;
+
+/// Desired trajectories (detail::XDes / UDes, mpc.hpp:32-56).  Held through a shared_ptr: copies of an MPC share them
+/// (mpc.hpp:407, 607-608), so set_xdes / set_udes on a copy are seen by the original.  `generation` counts the setter
+/// calls: every controller looks at a new trajectory once (refresh_structure).
+template<class T, class X, class U>
+struct MPCDes {
+  std::function<X(T)> xdes = [](T) { return X::Identity(); };
+  std::function<typename X::Tangent(T)> dxdes = [](T) { return typename X::Tangent{}; };
+  std::function<U(T)> udes = [](T) { return U::Identity(); };
+  uint64_t generation = 0;
+};
+
+/// MPCDyn / MPCCR (mpc.hpp:122-147, 230-263): a functor with set_time(T) is told the absolute time of the node first
+template<class T, class Fn>
+inline void set_time_if(Fn & fn, const T & t)
+{
+  if constexpr (requires(Fn & fvar, T tvar) { fvar.set_time(tvar); }) fn.set_time(t);
+}
+template<class T, class Fn>
+inline constexpr bool has_set_time_v = requires(std::remove_reference_t<Fn> & fvar, T tvar) { fvar.set_time(tvar); };
 }  // namespace detail
 
 /// mpc.hpp:309-333
@@ -82,55 +106,72 @@ struct MPCWeights {
   Mat<U::Dof, U::Dof> R   = Mat<U::Dof, U::Dof>::Identity();
 };
 
-template<class X, class U, int Ncr_, class F, class CR, int Kmesh = 4, Time T = double>
+/// smooth::feedback::MPC, mpc.hpp:372-636: the reference's template parameters in the reference's order (its trailing
+/// diff::Type is not a parameter here: Jacobians are the functor's own `jacobian` or forward differences, see the top
+/// of this file).  F and CR may be reference types (tests/test_mpc.cpp:69: `MPC<T, X, U, MyDynamics &, ...>`).
+/// Copies (mpc.hpp:437-445): a copy is a controller of its own -- own QP, own warm start, own solver that analyses the
+/// pattern again at its first solve like a copied QPSolver does (qp_solver.hpp:209-231) -- and SHARES the desired
+/// trajectories with the original (mpc.hpp:407, 607-608).  Swarms share ONE analysis explicitly (MPCSwarm* take the
+/// prototype by reference).
+template<Time T, class X, class U, class F, class CR, std::size_t Kmesh_ = 4>
 class MPC {
 public:
-  static constexpr int Nx = X::Dof, Nu = U::Dof, Ncr = Ncr_;
+  static constexpr int Kmesh = (int)Kmesh_;
+  static constexpr int Nx = X::Dof, Nu = U::Dof;
+  /// mpc.hpp:383
+  static constexpr int Ncr = detail::result_size_v<std::invoke_result_t<std::remove_reference_t<CR> &, const X &, const U &>>;
   using TangentX = Vec<Nx>;
   using TimeT    = T;
   /// absolute time t plus a horizon offset in seconds
   static T tplus(const T & t, double s) { return time_trait<T>::plus(t, s); }
 
+  /// mpc.hpp:405-434 (by value: serves the reference's rvalue and lvalue constructors alike).  `w` (not in the
+  /// reference's constructor): the weights to transcribe -- the reference transcribes its defaults here and
+  /// set_weights() never reaches the QP (see set_weights).
   MPC(F f, CR cr, Vec<Ncr> crl, Vec<Ncr> cru, MPCParams prm = {}, MPCWeights<X, U> w = {})
-      : f_(std::move(f)), cr_(std::move(cr)), crl_(crl), cru_(cru), prm_(std::move(prm)),
-        mesh_(int((prm_.K + Kmesh - 1) / Kmesh), Kmesh), solver_(std::make_shared<SparseQPSolver>(prm_.qp)), weights_(w)
+      : f_(std::forward<F>(f)), cr_(std::forward<CR>(cr)), crl_(crl), cru_(cru), prm_(std::move(prm)),
+        mesh_(int((prm_.K + Kmesh - 1) / Kmesh), Kmesh), des_(std::make_shared<Des>()), solver_(prm_.qp), weights_(w)
   {
-    xdes_ = [](T) { return X::Identity(); };
-    dxdes_ = [](T) { return TangentX{}; };
-    udes_ = [](T) { return U::Identity(); };
     allocate(w);
   }
+  /// mpc.hpp:435-447: default constructor, default copies and moves
+  MPC()                        = default;
+  MPC(const MPC &)             = default;
+  MPC(MPC &&)                  = default;
+  MPC & operator=(const MPC &) = default;
+  MPC & operator=(MPC &&)      = default;
+  ~MPC()                       = default;
 
   // ---- desired trajectories, mpc.hpp:520-586 ----
   /// absolute time: x_des(t) and its body velocity dx_des(t)
   void set_xdes(std::function<X(T)> x_des, std::function<TangentX(T)> dx_des)
   {
-    xdes_ = std::move(x_des);
-    dxdes_ = std::move(dx_des);
+    des_->xdes  = std::move(x_des);
+    des_->dxdes = std::move(dx_des);
     structure_changed();
   }
   /// absolute time, derivative by central differences of x(t) (the reference autodiffs / finite-differences x(t))
   void set_xdes(std::function<X(T)> x_des)
   {
-    auto xd = x_des;
-    dxdes_  = [xd](T t) {
+    auto xd     = x_des;
+    des_->dxdes = [xd](T t) {
       const double h = 1e-6;
       TangentX d     = rminus(xd(tplus(t, h)), xd(tplus(t, -h)));
       for (auto & v : d) v /= (2 * h);
       return d;
     };
-    xdes_ = std::move(x_des);
+    des_->xdes = std::move(x_des);
     structure_changed();
   }
   void set_udes(std::function<U(T)> u_des)
   {
-    udes_ = std::move(u_des);
+    des_->udes = std::move(u_des);
     structure_changed();
   }
   /// relative time, mpc.hpp:539-545: u_des(t) = f(t - t0) with f: double (seconds) -> U
   template<class Fun>
     requires std::is_same_v<std::invoke_result_t<Fun, double>, U>
-  void set_udes_rel(Fun && f, T t0 = T{})
+  void set_udes_rel(Fun && f, T t0 = T(0))
   {
     set_udes([t0, f = std::forward<Fun>(f)](T t_abs) -> U { return f(time_trait<T>::minus(t_abs, t0)); });
   }
@@ -138,7 +179,7 @@ public:
   /// differences with step 1e-6 s, or f.velocity(t_rel) when the functor provides it)
   template<class Fun>
     requires std::is_same_v<std::invoke_result_t<Fun, double>, X>
-  void set_xdes_rel(Fun && f, T t0 = T{})
+  void set_xdes_rel(Fun && f, T t0 = T(0))
   {
     std::function<X(T)> xd = [t0, f](T t_abs) -> X { return f(time_trait<T>::minus(t_abs, t0)); };
     std::function<TangentX(T)> dxd = [t0, f](T t_abs) -> TangentX {
@@ -169,7 +210,7 @@ public:
   const QuadraticProgramSparse<> & qp() const { return qp_; }
   const Mesh & mesh() const { return mesh_; }
   const MPCParams & params() const { return prm_; }
-  SparseQPSolver & solver() { return *solver_; }
+  SparseQPSolver & solver() { return solver_; }
   /// Elimination stages for the solver's constrained minimum-degree order (unknowns of a lower stage are eliminated
   /// before any of a higher stage).  Stage 0: everything interior to a mesh interval -- the intervals decouple once
   /// the states they share (x at nodes 0, Kmesh, 2 Kmesh, ..., N: the separators) are held back.  The separators,
@@ -219,7 +260,7 @@ public:
         lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
         v   = (double(lcg >> 11) / 9007199254740992.0 - 0.5);
       }
-      probe_structure(ts, rplus(xdes_(ts), xi), keep);
+      probe_structure(ts, rplus(des_->xdes(ts), xi), keep);
     }
   }
   void probe_values(const double * Aval, std::vector<uint8_t> & keep) const
@@ -233,12 +274,12 @@ public:
   /// problem that violates it is solved on the whole pattern (sfb_sparse_qp_plan_create_pruned).
   void analyze_solver(const std::vector<uint8_t> * keep = nullptr)
   {
-    if (!solver_->analyzed()) {
+    if (!solver_.analyzed()) {
       const auto st = elimination_stage();
-      solver_->analyze(qp_, nullptr, st.data(), (keep && prm_.prune_explicit_zeros) ? keep->data() : nullptr);
+      solver_.analyze(qp_, nullptr, st.data(), (keep && prm_.prune_explicit_zeros) ? keep->data() : nullptr);
       if (keep && prm_.prune_explicit_zeros) keep_analysed_ = *keep;
       else keep_analysed_.clear();
-      structure_dirty_ = false;
+      seen_generation_ = des_->generation;
     }
   }
   /// After set_xdes / set_udes the linearisations may have non-zeros where the analysed ones had explicit zeros.  The
@@ -248,9 +289,9 @@ public:
   /// (QPSolver::pin_plan: the swarm keeps the raw plan pointer, sfb.h).  Aval (nullable): values of A to probe as well.
   void refresh_structure(const T & t, const double * Aval = nullptr)
   {
-    if (!structure_dirty_ || !solver_->analyzed()) return;
-    structure_dirty_ = false;
-    if (!prm_.prune_explicit_zeros || keep_analysed_.empty() || solver_->plan_pinned()) return;
+    if (!structure_dirty() || !solver_.analyzed()) return;
+    seen_generation_ = des_->generation;
+    if (!prm_.prune_explicit_zeros || keep_analysed_.empty() || solver_.plan_pinned()) return;
     std::vector<uint8_t> keep;
     if (Aval) probe_values(Aval, keep);
     probe_default(t, keep);
@@ -258,13 +299,28 @@ public:
     for (size_t e = 0; e < keep.size() && inside; ++e) inside = !keep[e] || keep_analysed_[e];
     if (inside) return;
     for (size_t e = 0; e < keep.size(); ++e) keep[e] |= keep_analysed_[e];
-    solver_->reset();
+    solver_.reset();
     analyze_solver(&keep);
   }
 
   /// Numeric part of MPC::operator() before the solve (mpc.hpp:473-486): writes the values of A (in
   /// the pattern of qp().A_*), l and u for current time t and state x.  Thread-safe (const).
+  /// Functors with set_time(T) (MPCDyn / MPCCR, mpc.hpp:131, 247) are told the absolute time of every node: here on
+  /// COPIES of the functors (const, callable from many threads); operator() tells the controller's own functors.
   void assemble(const T & t, const X & x, double * Aval, double * l, double * u) const
+  {
+    if constexpr (kTimedFunctors) {
+      std::remove_cvref_t<F> fc   = f_;
+      std::remove_cvref_t<CR> crc = cr_;
+      assemble_with(fc, crc, t, x, Aval, l, u);
+    } else {
+      assemble_with(f_, cr_, t, x, Aval, l, u);
+    }
+  }
+
+private:
+  template<class Fn, class CRn>
+  void assemble_with(Fn & fn, CRn & crn, const T & t, const X & x, double * Aval, double * l, double * u) const
   {
     const int Nn = N();
     const double tf = prm_.tf;
@@ -275,13 +331,14 @@ public:
       for (int i = 0; i < Kmesh; ++i) {
         const int node   = M + i;
         const double t_i = tf * mesh_.node(node);
-        const X xl       = xdes_(tplus(t, t_i));
-        const TangentX dxl = dxdes_(tplus(t, t_i));
-        const U ul       = udes_(tplus(t, t_i));
+        const X xl       = des_->xdes(tplus(t, t_i));
+        const TangentX dxl = des_->dxdes(tplus(t, t_i));
+        const U ul       = des_->udes(tplus(t, t_i));
         Vec<Nx> fv;
         Mat<Nx, Nx> dfdx;
         Mat<Nx, Nu> dfdu;
-        dyn_jacobian(xl, ul, fv, dfdx, dfdu);
+        detail::set_time_if<T>(fn, tplus(t, t_i));
+        detail::xu_jacobian<Nx>(fn, xl, ul, fv, dfdx, dfdu);
         Mat<Nx, Nx> adm{};
         if constexpr (!X::IsCommutative) {
           TangentX s2;
@@ -317,12 +374,13 @@ public:
     //     set_time, which leaves the constructor-time values -- identical for time-invariant cr) ---
     for (int node = 0; node < Nn; ++node) {
       const double t_i = tf * mesh_.node(node);
-      const X xl       = xdes_(tplus(t, t_i));
-      const U ul       = udes_(tplus(t, t_i));
+      const X xl       = des_->xdes(tplus(t, t_i));
+      const U ul       = des_->udes(tplus(t, t_i));
       Vec<Ncr> cv;
       Mat<Ncr, Nx> dcdx;
       Mat<Ncr, Nu> dcdu;
-      cr_jacobian(xl, ul, cv, dcdx, dcdu);
+      detail::set_time_if<T>(crn, tplus(t, t_i));
+      detail::xu_jacobian<Ncr>(crn, xl, ul, cv, dcdx, dcdu);
       for (int d = 0; d < Ncr; ++d) {
         const int row = crcon_B() + node * Ncr + d;
         int p         = qp_.A_rowptr[row];
@@ -334,7 +392,7 @@ public:
     }
     // --- ocp_to_qp_update_ce :326-373 with MPCCE: ce = x0 (-) x0_fix linearised at xl(0) ---
     {
-      const X xl0      = xdes_(t);
+      const X xl0      = des_->xdes(t);
       const TangentX e = rminus(xl0, x);  // MPCCE::operator(), mpc.hpp:288-291
       const auto J     = X::dr_expinv(e); // MPCCE::jacobian,  mpc.hpp:293-301
       for (int d = 0; d < Nx; ++d) {
@@ -347,6 +405,7 @@ public:
     }
   }
 
+public:
   /// Description of this transcription for the device-side assembly (sfb_mpc_layout, sfb.h); owns the arrays.
   struct DeviceLayout {
     std::vector<double> alpha, D, crl, cru;
@@ -414,7 +473,7 @@ public:
         lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
         v   = (double(lcg >> 11) / 9007199254740992.0 - 0.5);
       }
-      fill_record(ts, rplus(xdes_(ts), xi), rec.data());
+      fill_record(ts, rplus(des_->xdes(ts), xi), rec.data());
       probe_record(rec.data(), pk);
     }
     return pk;
@@ -453,23 +512,38 @@ public:
   /// sfb_mpc_assemble_batch (layout in sfb.h; matrices row-major).  Thread-safe (const).
   void fill_record(const T & t, const X & x, double * rec) const
   {
+    if constexpr (kTimedFunctors) {
+      std::remove_cvref_t<F> fc   = f_;
+      std::remove_cvref_t<CR> crc = cr_;
+      fill_record_with(fc, crc, t, x, rec);
+    } else {
+      fill_record_with(f_, cr_, t, x, rec);
+    }
+  }
+
+private:
+  template<class Fn, class CRn>
+  void fill_record_with(Fn & fn, CRn & crn, const T & t, const X & x, double * rec) const
+  {
     const int Nn = N();
     const double tf = prm_.tf;
     double *f = rec, *dx = f + Nn * Nx, *dfx = dx + Nn * Nx, *dfu = dfx + Nn * Nx * Nx, *cc = dfu + Nn * Nx * Nu,
            *dcx = cc + Nn * Ncr, *dcu = dcx + Nn * Ncr * Nx, *e0 = dcu + Nn * Ncr * Nu, *Jm = e0 + Nx;
     for (int node = 0; node < Nn; ++node) {
       const double t_i   = tf * mesh_.node(node);
-      const X xl         = xdes_(tplus(t, t_i));
-      const TangentX dxl = dxdes_(tplus(t, t_i));
-      const U ul         = udes_(tplus(t, t_i));
+      const X xl         = des_->xdes(tplus(t, t_i));
+      const TangentX dxl = des_->dxdes(tplus(t, t_i));
+      const U ul         = des_->udes(tplus(t, t_i));
       Vec<Nx> fv;
       Mat<Nx, Nx> dfdx;
       Mat<Nx, Nu> dfdu;
-      dyn_jacobian(xl, ul, fv, dfdx, dfdu);
+      detail::set_time_if<T>(fn, tplus(t, t_i));
+      detail::xu_jacobian<Nx>(fn, xl, ul, fv, dfdx, dfdu);
       Vec<Ncr> cv;
       Mat<Ncr, Nx> dcdx;
       Mat<Ncr, Nu> dcdu;
-      cr_jacobian(xl, ul, cv, dcdx, dcdu);
+      detail::set_time_if<T>(crn, tplus(t, t_i));
+      detail::xu_jacobian<Ncr>(crn, xl, ul, cv, dcdx, dcdu);
       for (int d = 0; d < Nx; ++d) {
         f[node * Nx + d]  = fv[d];
         dx[node * Nx + d] = dxl[d];
@@ -482,7 +556,7 @@ public:
         for (int c = 0; c < Nu; ++c) dcu[(node * Ncr + d) * Nu + c] = dcdu(d, c);
       }
     }
-    const X xl0      = xdes_(t);
+    const X xl0      = des_->xdes(t);
     const TangentX e = rminus(xl0, x);
     const auto J     = X::dr_expinv(e);
     for (int d = 0; d < Nx; ++d) {
@@ -491,41 +565,54 @@ public:
     }
   }
 
+public:
   /// mpc.hpp:518   udes(0) (+) primal[uvar_B : +Nu]
   U input_from_primal(const T & t, const double * primal) const
   {
     typename U::Tangent du{};
     for (int c = 0; c < Nu; ++c) du[c] = primal[uvar_B() + c];
-    return rplus(udes_(t), du);
+    return rplus(des_->udes(t), du);
   }
 
   U input_from_du0(const T & t, const double * du0) const
   {
     typename U::Tangent du{};
     for (int c = 0; c < Nu; ++c) du[c] = du0[c];
-    return rplus(udes_(t), du);
+    return rplus(des_->udes(t), du);
   }
 
-  /// MPC::operator(), mpc.hpp:458-519
-  std::pair<U, QPSolutionStatus> operator()(const T & t, const X & x, std::vector<U> * u_traj = nullptr,
-                                            std::vector<X> * x_traj = nullptr)
+  /// MPC::operator(), mpc.hpp:458-519, with the reference's signature
+  std::pair<U, QPSolutionStatus> operator()(const T & t, const X & x,
+                                            std::optional<std::reference_wrapper<std::vector<U>>> u_traj = std::nullopt,
+                                            std::optional<std::reference_wrapper<std::vector<X>>> x_traj = std::nullopt)
   {
-    assemble(t, x, qp_.A_val.data(), qp_.l.data(), qp_.u.data());
+    return solve_tick(t, x, u_traj ? &u_traj->get() : nullptr, x_traj ? &x_traj->get() : nullptr);
+  }
+  /// the same with nullable pointers (u_traj has no default here: `mpc(t, x)` is the reference's overload)
+  std::pair<U, QPSolutionStatus> operator()(const T & t, const X & x, std::vector<U> * u_traj, std::vector<X> * x_traj = nullptr)
+  {
+    return solve_tick(t, x, u_traj, x_traj);
+  }
+
+private:
+  std::pair<U, QPSolutionStatus> solve_tick(const T & t, const X & x, std::vector<U> * u_traj, std::vector<X> * x_traj)
+  {
+    assemble_with(f_, cr_, t, x, qp_.A_val.data(), qp_.l.data(), qp_.u.data());  // the controller's own functors see set_time
     refresh_structure(t, qp_.A_val.data());
-    if (!solver_->analyzed()) {
+    if (!solver_.analyzed()) {
       std::vector<uint8_t> keep;
       probe_values(qp_.A_val.data(), keep);
       probe_default(t, keep);
       analyze_solver(&keep);
     }
-    const QPSolution<> sol = solver_->solve(qp_, warm_ ? &*warm_ : nullptr);  // :491
+    const QPSolution<> sol = solver_.solve(qp_, warm_ ? &*warm_ : nullptr);  // :491
     const int Nn = N();
     if (u_traj) {  // :494-500
       u_traj->resize(Nn);
       for (int i = 0; i < Nn; ++i) {
         typename U::Tangent du{};
         for (int c = 0; c < Nu; ++c) du[c] = sol.primal[uvar_B() + i * Nu + c];
-        (*u_traj)[i] = rplus(udes_(tplus(t, prm_.tf * mesh_.node(i))), du);
+        (*u_traj)[i] = rplus(des_->udes(tplus(t, prm_.tf * mesh_.node(i))), du);
       }
     }
     if (x_traj) {  // :501-507
@@ -533,7 +620,7 @@ public:
       for (int i = 0; i <= Nn; ++i) {
         TangentX dx{};
         for (int c = 0; c < Nx; ++c) dx[c] = sol.primal[i * Nx + c];
-        (*x_traj)[i] = rplus(xdes_(tplus(t, prm_.tf * mesh_.node(i))), dx);
+        (*x_traj)[i] = rplus(des_->xdes(tplus(t, prm_.tf * mesh_.node(i))), dx);
       }
     }
     if (prm_.warmstart &&
@@ -543,9 +630,10 @@ public:
     return {input_from_primal(t, sol.primal.data()), sol.code};
   }
 
-private:
   // a new linearisation trajectory may have other explicit zeros: looked at by refresh_structure() at the next solve
-  void structure_changed() { structure_dirty_ = true; }
+  // of every controller that shares it
+  void structure_changed() { ++des_->generation; }
+  bool structure_dirty() const { return des_ && des_->generation != seen_generation_; }
   int dcon_B() const { return 0; }
   int crcon_B() const { return Nx * N(); }
   int cecon_B() const { return Nx * N() + Ncr * N(); }
@@ -621,29 +709,20 @@ private:
     }
   }
 
-  // f and its right-Jacobians at (x, u)
-  void dyn_jacobian(const X & x, const U & u, Vec<Nx> & fv, Mat<Nx, Nx> & dfdx, Mat<Nx, Nu> & dfdu) const
-  {
-    detail::xu_jacobian<Nx>(f_, x, u, fv, dfdx, dfdu);
-  }
-  void cr_jacobian(const X & x, const U & u, Vec<Ncr> & cv, Mat<Ncr, Nx> & dcdx, Mat<Ncr, Nu> & dcdu) const
-  {
-    detail::xu_jacobian<Ncr>(cr_, x, u, cv, dcdx, dcdu);
-  }
+  using Des = detail::MPCDes<T, X, U>;
+  static constexpr bool kTimedFunctors = detail::has_set_time_v<T, F> || detail::has_set_time_v<T, CR>;
 
   F f_;
   CR cr_;
-  Vec<Ncr> crl_, cru_;
-  MPCParams prm_;
-  Mesh mesh_;
-  std::function<X(T)> xdes_;
-  std::function<TangentX(T)> dxdes_;
-  std::function<U(T)> udes_;
+  Vec<Ncr> crl_{}, cru_{};
+  MPCParams prm_{};
+  Mesh mesh_{};
+  std::shared_ptr<Des> des_ = std::make_shared<Des>();  // shared by copies, mpc.hpp:407
   QuadraticProgramSparse<> qp_;
-  std::shared_ptr<SparseQPSolver> solver_;
-  MPCWeights<X, U> weights_;
+  SparseQPSolver solver_;     // a copy drops the analysis (qp.hpp PlanHolder, qp_solver.hpp:209-231)
+  MPCWeights<X, U> weights_{};
   std::vector<uint8_t> keep_analysed_;  // the A_keep mask of the current analysis (empty: whole pattern)
-  bool structure_dirty_ = false;
+  uint64_t seen_generation_ = 0;        // des_->generation this controller's analysis has looked at
   std::optional<QPSolution<>> warm_;
 };
 

@@ -276,6 +276,25 @@ def test_mpc_closed_loop_like_reference_test(sfb):
     assert np.all(np.abs(u) <= 2.0 + 1e-6)  # udes (1) (+) du with |u_total| <= ... cr bounds total u in [-1, 1]
 
 
+def test_reference_shaped_mpc_caller_code(sfb):
+    """tests/test_mpc.cpp:60-155 transcribed against <smooth/feedback/mpc.hpp> with only the Lie types renamed
+    (examples/models.cpp::sfbx_test_mpc_api): MPC<T, X, U, F, CR>, `mpc(1, x)`, `mpc(4, x, us, xs)`, functors held by
+    reference that see set_time, copies / moves; plus the declaration of examples/mpc_asif_vehicle.cpp:64 on a
+    std::chrono::duration clock.  Copies own their solvers and share the desired trajectories (mpc.hpp:407, 607-608)."""
+    out = np.full(14, np.nan); codes = np.full(12, -1, np.int32)
+    rc = M.lib().sfbx_test_mpc_api(out.ctypes.data_as(C.c_void_p), codes.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    assert (codes == 0).all(), codes                       # ASSERT_EQ(code, Optimal) everywhere
+    assert out[0] < 1e-6 and out[1] < 1e-6                 # u1 ~ u2 (warm start), u3 ~ u1
+    assert out[2] == 1.0                                   # us.size() + 1 == xs.size()
+    assert out[3] >= 4.0 and out[4] >= 4.0                 # ASSERT_GE(f.t_, 4), ASSERT_GE(cr.t_, 4)
+    assert out[5] < 1e-6                                   # pointer overload (warm-started from the solve before)
+    assert (out[6:10] < 1e-6).all(), out[6:10]             # copy / copy-assign / move / move-assign
+    assert out[10] <= 0.5 + 1e-9                           # the vehicle's input inside its box
+    assert out[11] == 1.0                                  # every copy analysed for itself
+    assert out[12] < 1e-6 and out[13] > 1e-3               # a setter on a copy reaches the original
+
+
 def test_mpc_swarm_tick(sfb):
     """MPCSwarm: host assembly on threads + ONE batched GPU solve per tick, warm-started ticks."""
     B = 64
