@@ -320,7 +320,8 @@ void dense_native_table(const sfb_qp_params *prm, int n, int m, const double *P,
   double ph[6] = {0, 0, 0, 0, 0, 0};
   uint32_t it2 = 0;
   int32_t code2 = -1;
-  const bool ok = hipMemcpy(dtr, tr.data(), tr.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+  // (the phase scratch is zeroed: whatever stamps a kernel variant leaves out read as 0, not as what the allocation held)
+  const bool ok = hipMemcpy(dtr, tr.data(), tr.size() * 8, hipMemcpyHostToDevice) == hipSuccess && hipMemset(dph, 0, 16 * 8) == hipSuccess &&
                   sfb::qp_dense_mid_trace_launch(kp, 1, g, nullptr, dtr, rows, dph) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
                   hipMemcpy(tr.data(), dtr, tr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess &&
                   hipMemcpy(ph, dph, sizeof(ph), hipMemcpyDeviceToHost) == hipSuccess &&
@@ -882,6 +883,7 @@ sfb_status sfb_qp_dense_solve_batch_host_phases(const sfb_qp_params *prm, int64_
       for (size_t r = 0; r < TR; r += 5) init[r] = -1.0;
       if ((e = H2D(dtr, init.data(), TR * 8)) != hipSuccess) break;
     }
+    if (PH && (e = hipMemset(dph, 0, PH * 8)) != hipSuccess) break;
     st = sfb_qp_dense_solve_batch_phases(prm, batch, n, m, dP, dq, dA, dl, du, dwx, dwy, dx, dy, dobj, dit, dcode, TR ? dtr : nullptr, trace_rows,
                                          PH ? dph : nullptr, nullptr);
     if (st != SFB_OK) break;

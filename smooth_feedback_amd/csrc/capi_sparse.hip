@@ -41,6 +41,7 @@ struct sfb_sparse_qp_plan {
     // application has recorded timing events on the null stream, a solve launched there from this entry takes 60 instead of
     // 43 ms -- the runtime then tracks every dispatch of that queue; bench.py's event-timed loop did exactly that.)
     hipStream_t stream = nullptr;
+    hipEvent_t uploaded = nullptr;  // recorded on the null stream behind the uploads; `stream` waits for it before the first launch
   };
   std::map<int, HostDev> host_dev;  // device ordinal -> state; entries are created under `mu` and never move
 };
@@ -93,6 +94,10 @@ sfb_status upload_plan(const sfb::SparsePlanHost &h, const std::vector<int32_t> 
   d.nnzA_io = nnzA_io;
   d.nmasked = Amasked ? (int)Amasked->size() - 512 : 0;  // without the padding
   if (!Aorig) d.Aorig = d.Amasked = nullptr;
+  if ((e = sfb::sparse_device_words(&d.dev_active, &d.dev_busy)) != hipSuccess) {
+    (void)hipFree(dblob);
+    return sfb::hip_fail(e, "launch bookkeeping of the device");
+  }
   d.self = reinterpret_cast<const sfb::SparsePlanDev *>(dblob + off[NA]);
   e      = hipMemcpy(dblob + off[NA], &d, sizeof(d), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -275,6 +280,7 @@ void sfb_sparse_qp_plan_destroy(sfb_sparse_qp_plan *plan)
   for (auto &kv : plan->host_dev) {
     if (kv.second.ws.first) (void)hipFree(kv.second.ws.first);
     if (kv.second.stream) (void)hipStreamDestroy(kv.second.stream);
+    if (kv.second.uploaded) (void)hipEventDestroy(kv.second.uploaded);
   }
   delete plan;
 }
@@ -472,6 +478,10 @@ sfb_status sfb_sparse_qp_solve_batch_host_phases(sfb_sparse_qp_plan *plan, const
     hd->stream = nullptr;
     return sfb::hip_fail(e, "hipStreamCreateWithFlags");
   }
+  if (hd->uploaded == nullptr && (e = hipEventCreateWithFlags(&hd->uploaded, hipEventDisableTiming)) != hipSuccess) {
+    hd->uploaded = nullptr;
+    return sfb::hip_fail(e, "hipEventCreateWithFlags");
+  }
   // reuse_factor refers to "the previous call on this workspace": the workspace sits at the start of the cached
   // buffer, so it is the same memory, item for item, exactly when the batch size is that of the previous call
   // -- and the call comes from where the previous one came from: a shard of a *_multi call holds the items its device
@@ -512,7 +522,11 @@ sfb_status sfb_sparse_qp_solve_batch_host_phases(sfb_sparse_qp_plan *plan, const
       if ((e = H2D(dtrace, trace, TR0 * 8)) != hipSuccess) break;
     }
     tv1 = clk::now();
-    // (the uploads above are synchronous copies: complete before the first launch is enqueued)
+    // The uploads are synchronous copies on the null stream, the launches go to a stream that does not synchronise with it:
+    // a copy out of pageable memory may return once its data is STAGED, so the launch stream is made to wait for the null
+    // stream's work up to here explicitly.
+    if ((e = hipEventRecord(hd->uploaded, nullptr)) != hipSuccess) break;
+    if ((e = hipStreamWaitEvent(hd->stream, hd->uploaded, 0)) != hipSuccess) break;
     st = solve_batch_impl(plan, prm, batch, dPx, dq, dAx, dl, du, dwx, dwy, dx, dy, dobj, dit, dcode, dws, nullptr, hd->stream,
                           trace ? dtrace : nullptr, trace ? trace_rows : 0, phase_us ? dtrace + TR0 : nullptr);
     if (st != SFB_OK) {

@@ -1709,8 +1709,6 @@ __device__ inline void sp_polish(const SparsePlanDev &pl, const Item &it, const 
   wave_sync();
 }
 
-__device__ int g_sparse_active = 0;  // resident waves of qp_sparse_kernel (all launches of the process), see the kernel
-
 // Queue of a time-sliced launch (device memory, zeroed by the launcher; counters on their own cache lines):
 //   q[kQFresh]  fresh items handed out so far (ticket counter, items 0 .. batch-1 in launch order)
 //   q[kQHead], q[kQTail]  ring of SUSPENDED items: pushes reserve q[kQTail]++, pops claim q[kQHead] by CAS
@@ -2302,7 +2300,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
       }
       if (ret_code < 0 && max_time_exceeded(kp.max_time_ns, t0_ticks)) ret_code = SFB_QP_MAX_TIME;  // :504-507
       wave_sync();
-      lean = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_sparse_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >
+      lean = __builtin_amdgcn_readfirstlane(__hip_atomic_load(pl.dev_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >
              lean_waves;
       // Items that are still iterating after many checks are the ones the whole launch waits for:
       // raise their issue priority over the co-resident waves that are in their first iterations.
@@ -2561,14 +2559,18 @@ __global__ void __launch_bounds__(64, LAT ? 1 : ((TRACE || POLISHER) ? 2 : 3)) q
       if constexpr (LAT) {
         // A wave of the loop launch that finds no item left to iterate HELPS THE POLISHERS while their ring has a backlog (the
         // tail of the launch belongs to a few long items: most of its waves would leave here), and leaves when it is empty.
-        // (Only while no OTHER launch has waves at work -- a LAT wave owns its SIMD's whole register file: with a second batch in
-        //  flight on another stream the chip does better when the wave leaves, that batch's waves take the SIMD and the finish
-        //  launch polishes three to a SIMD.  [kDqOwn] counts the busy waves of this loop launch and its polishers, g_sparse_active
-        //  those of every launch.)
+        // (Only while nothing ELSE wants the chip -- a LAT wave owns its SIMD's whole register file: with a second batch on
+        //  another stream the chip does better when the wave leaves, that batch's waves take the SIMD and the finish launch
+        //  polishes three to a SIMD.  Two signs, both kept per device (SparsePlanDev::dev_busy / dev_active): the HOST marks a
+        //  caller stream busy from the moment a solve is ENQUEUED on it until it is known finished -- a launch that is still
+        //  waiting for a SIMD shows there --, and [kDqOwn] against dev_active shows the busy waves of other launches.
+        //  nfresh_dev[8] = this launch's own stream bit.)
         if (item < 0 && ((phases >> 28) & 3) == 3) {
           int32_t *const doneq = fbflags + kFbSlots + 2 * batch + 16;
+          const unsigned long long own_bit = 1ull << (nfresh_dev[8] & 63);
           for (;;) {
-            if (__hip_atomic_load(&g_sparse_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+            if ((__hip_atomic_load(plp->dev_busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) & ~own_bit) != 0ull) break;
+            if (__hip_atomic_load(plp->dev_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
                     __hip_atomic_load(&doneq[kDqOwn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0)
               break;
             const int head = __hip_atomic_load(&doneq[kDqHead], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2609,7 +2611,7 @@ __global__ void __launch_bounds__(64, LAT ? 1 : ((TRACE || POLISHER) ? 2 : 3)) q
       fbslot = __builtin_amdgcn_readfirstlane(fbslot);
       use = plf; wsb = gwsf; wsd = wsf_doubles; slot = (size_t)fbslot;
     }
-    // Waves busy with an item right now (all launches of the process).  While there are many, the launch is
+    // Waves busy with an item right now (all launches on this device: SparsePlanDev::dev_active).  While there are many, the launch is
     // HBM-bound and the sweeps skip the padding of the factor stream (masked loads: fewer bytes, a few more
     // instructions); when only stragglers are left, latency is what counts and they switch to plain loads.  A
     // heuristic only: both forms compute the same thing.  (Balanced by every wave when it is done; shared by all
@@ -2618,7 +2620,8 @@ __global__ void __launch_bounds__(64, LAT ? 1 : ((TRACE || POLISHER) ? 2 : 3)) q
     // (own count first, global count second -- and the other way round at the end: the difference never shows a wave of this launch)
     const bool counts_own = dq_mode == 2 || (LAT && ((phases >> 28) & 1) == 1);
     if (counts_own && lane == 0) atomicAdd(&(fbflags + kFbSlots + 2 * batch + 16)[kDqOwn], 1);
-    if (lane == 0) seen = atomicAdd(&g_sparse_active, 1);
+    int32_t *const active = plp->dev_active;
+    if (lane == 0) seen = atomicAdd(active, 1);
     const bool lean = (nwaves > lean_waves_item) || __builtin_amdgcn_readfirstlane(seen) >= lean_waves_item;
     // (phased launches: an item of the fallback pool runs all phases at once, in the setup launch)
     const int st = sp_solve_item<LAT, TRACE, LAT || POLISHER>(*use, kp, gPx, gq, gAx, gl, gu, gwx, gwy, gx, gy, gobj, giter, gcode, wsb, wsd, lean_waves_item,
@@ -2644,7 +2647,7 @@ __global__ void __launch_bounds__(64, LAT ? 1 : ((TRACE || POLISHER) ? 2 : 3)) q
       }
     }
     if (lane == 0) {
-      atomicSub(&g_sparse_active, 1);
+      atomicSub(active, 1);
       if (counts_own) atomicSub(&(fbflags + kFbSlots + 2 * batch + 16)[kDqOwn], 1);
       if (fbslot >= 0) __hip_atomic_store(&fbflags[fbslot], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       if (st == SP_SUSPENDED) {
@@ -2675,7 +2678,7 @@ constexpr int kRankBins = 4096, kRankThreads = 1024;
 __global__ __launch_bounds__(kRankThreads) void sp_rank_kernel(const float *__restrict__ keys, const int batch,
                                                                int32_t *__restrict__ order2, int32_t *__restrict__ count,
                                                                const int g_lo, const int g_hi, const int lat_lo, const int lat_hi,
-                                                               const int lat_max)
+                                                               const int lat_max, const int stream_bit)
 {
   __shared__ int hist[kRankBins];
   __shared__ int psum[kRankThreads];
@@ -2735,6 +2738,7 @@ __global__ __launch_bounds__(kRankThreads) void sp_rank_kernel(const float *__re
       count[4] = total;
       count[5] = g_hi;
       count[6] = lat;
+      count[8] = stream_bit;  // (the caller stream's bit in SparsePlanDev::dev_busy: the helpers look past their own)
     }
   }
   __syncthreads();
@@ -2744,35 +2748,152 @@ __global__ __launch_bounds__(kRankThreads) void sp_rank_kernel(const float *__re
   }
 }
 
-// the polishers' stream of the current device (see qp_sparse_launch): lowest priority -- when both have workgroups to place, the
-// loop launch's go first --, not synchronising with the null stream; created once per device, nullptr when that fails
-static hipStream_t polisher_stream()
+// LAUNCH BOOKKEEPING, per device, kept by the HOST (created on first use, never freed):
+//   * what a launch needs to know about the device and the kernels, asked ONCE (compute units, resident blocks per LDS size,
+//     the LDS opt-in of the LAT form) -- a steady-state solve makes no HIP call besides launches, memsets and event record / wait;
+//   * per caller stream ("slot", at most 64; further streams share slots): its bit in the busy word, the polishers' stream that
+//     goes with it (lowest priority -- when both have workgroups to place, the loop launch's go first --, not synchronising with
+//     the null stream), the two events of the hand-off between the two, and the event that marks the end of the stream's most
+//     recent solve;
+//   * the two words the kernels read (SparsePlanDev::dev_active / dev_busy).  The busy word lives in mapped host memory: the
+//     host sets a stream's bit when it ENQUEUES a solve there and clears it when it next looks (at an enqueue) and finds the
+//     stream's last solve finished.  A stale bit costs the helpers of other streams' launches, never a result.
+struct SparseDeviceBook {
+  struct Slot {
+    int bit = 0;
+    hipStream_t polish = nullptr;  // nullptr: could not be created -- no polishers for this stream
+    hipEvent_t ev1 = nullptr, ev2 = nullptr, last = nullptr;
+    int inflight = 0;  // solves enqueued whose end `last` has not been seen yet
+  };
+  std::mutex mu;
+  int dev = -1, cus = 0;
+  int lat_opt_in = -1;  // hipFuncSetAttribute(LAT form, 80 KB of dynamic LDS): -1 not asked, 0 refused, 1 granted
+  std::map<size_t, int> per_cu_std, per_cu_lat;  // dynamic LDS bytes -> resident blocks per CU
+  int32_t *active = nullptr;                     // device memory
+  unsigned long long *busy_host = nullptr;       // mapped host memory (or nullptr: `busy_dev` points at a device word that stays 0)
+  const unsigned long long *busy_dev = nullptr;
+  std::map<hipStream_t, Slot> slots;
+  int next_bit = 0;
+};
+
+static SparseDeviceBook *sparse_book()
 {
   static std::mutex mu;
-  static std::map<int, hipStream_t> streams;
+  static std::map<int, SparseDeviceBook *> books;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   std::lock_guard<std::mutex> lk(mu);
-  const auto it = streams.find(dev);
-  if (it != streams.end()) return it->second;
-  int least = 0, greatest = 0;
-  hipStream_t s = nullptr;
-  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess) {
+  const auto it = books.find(dev);
+  if (it != books.end()) return it->second;
+  auto *b = new SparseDeviceBook();
+  b->dev  = dev;
+  int32_t *words = nullptr;  // [0]: busy waves; [32]: the always-zero stand-in of the busy word
+  if (hipDeviceGetAttribute(&b->cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&words), 64 * sizeof(int32_t)) != hipSuccess ||
+      hipMemset(words, 0, 64 * sizeof(int32_t)) != hipSuccess) {
     (void)hipGetLastError();
-    s = nullptr;
+    if (words) (void)hipFree(words);
+    delete b;
+    return nullptr;
   }
-  streams[dev] = s;
-  return s;
+  b->active   = words;
+  b->busy_dev = reinterpret_cast<const unsigned long long *>(words + 32);
+  void *hostw = nullptr, *devw = nullptr;
+  if (hipHostMalloc(&hostw, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&devw, hostw, 0) == hipSuccess) {
+    b->busy_host  = static_cast<unsigned long long *>(hostw);
+    *b->busy_host = 0ull;
+    b->busy_dev   = static_cast<const unsigned long long *>(devw);
+  } else {
+    (void)hipGetLastError();
+    if (hostw) (void)hipHostFree(hostw);
+  }
+  books[dev] = b;
+  return b;
 }
 
-// blocks of qp_sparse_kernel the device holds at once with `lds` bytes of dynamic LDS each
-static int sparse_resident_blocks(size_t lds)
+hipError_t sparse_device_words(int32_t **active, const unsigned long long **busy)
 {
-  int dev = 0, per_cu = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qp_sparse_kernel<false>, kWave, lds) != hipSuccess) return 0;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-  return per_cu * cus;
+  SparseDeviceBook *b = sparse_book();
+  if (b == nullptr) return hipErrorOutOfMemory;
+  *active = b->active;
+  *busy   = b->busy_dev;
+  return hipSuccess;
+}
+
+// the slot of a caller stream (created on first use; book.mu held)
+static SparseDeviceBook::Slot &sparse_slot(SparseDeviceBook &b, hipStream_t stream)
+{
+  const auto it = b.slots.find(stream);
+  if (it != b.slots.end()) return it->second;
+  if (b.slots.size() >= 64) {  // more caller streams than bits: share a slot (and its polishers' stream: still correct, see the kernel)
+    auto sh = b.slots.begin();
+    std::advance(sh, (size_t)(reinterpret_cast<uintptr_t>(stream) >> 6) % b.slots.size());
+    return sh->second;
+  }
+  SparseDeviceBook::Slot sl;
+  sl.bit = b.next_bit++ & 63;
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+      hipStreamCreateWithPriority(&sl.polish, hipStreamNonBlocking, least) != hipSuccess) {
+    (void)hipGetLastError();
+    sl.polish = nullptr;
+  }
+  if (hipEventCreateWithFlags(&sl.ev1, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&sl.ev2, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&sl.last, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    if (sl.polish) (void)hipStreamDestroy(sl.polish);
+    sl.polish = nullptr;  // (without the events: no polishers and no busy bit for this stream)
+    sl.ev1 = sl.ev2 = sl.last = nullptr;
+  }
+  return b.slots.emplace(stream, sl).first->second;
+}
+
+// A solve is about to be enqueued on `stream`: look at the other streams' last solves (clearing the bits of those that have
+// finished), mark this one busy.  Returns the stream's slot (a copy) and whether ANOTHER stream has work in flight.
+static SparseDeviceBook::Slot sparse_enqueue_begin(SparseDeviceBook &b, hipStream_t stream, bool *others_busy)
+{
+  std::lock_guard<std::mutex> lk(b.mu);
+  SparseDeviceBook::Slot &mine = sparse_slot(b, stream);
+  bool others = false;
+  for (auto &kv : b.slots) {
+    SparseDeviceBook::Slot &sl = kv.second;
+    if (&sl == &mine || sl.inflight == 0) continue;
+    const hipError_t q = hipEventQuery(sl.last);
+    if (q == hipErrorNotReady) {
+      (void)hipGetLastError();
+      others = true;
+      continue;
+    }
+    (void)hipGetLastError();  // finished (or the event is in error: nothing to wait for either way)
+    sl.inflight = 0;
+    if (b.busy_host) __atomic_fetch_and(b.busy_host, ~(1ull << sl.bit), __ATOMIC_RELEASE);
+  }
+  if (mine.last != nullptr) {
+    mine.inflight = 1;
+    if (b.busy_host) __atomic_fetch_or(b.busy_host, 1ull << mine.bit, __ATOMIC_RELEASE);
+  }
+  *others_busy = others;
+  return mine;
+}
+// ... and its last launch has been enqueued (or the enqueue failed half-way: the stream's work up to here still ends there)
+static void sparse_enqueue_end(const SparseDeviceBook::Slot &sl, hipStream_t stream)
+{
+  if (sl.last != nullptr && hipEventRecord(sl.last, stream) != hipSuccess) (void)hipGetLastError();
+}
+
+// blocks of qp_sparse_kernel (standard / LAT form) the device holds at once with `lds` bytes of dynamic LDS each
+static int sparse_resident_blocks(SparseDeviceBook &b, size_t lds, bool lat = false)
+{
+  std::lock_guard<std::mutex> lk(b.mu);
+  auto &cache = lat ? b.per_cu_lat : b.per_cu_std;
+  const auto it = cache.find(lds);
+  if (it != cache.end()) return it->second * b.cus;
+  int per_cu = 0;
+  const hipError_t e = lat ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qp_sparse_kernel<true>, kWave, lds)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qp_sparse_kernel<false>, kWave, lds);
+  if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+  cache[lds] = per_cu;
+  return per_cu * b.cus;
 }
 
 // auxiliary memory of a launch: [queue: kQRing + batch][flags of the fallback pool: kFbSlots] (zeroed per kernel) and,
@@ -2788,6 +2909,8 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
                             const SparsePlanDev *fallback, double *fallback_ws, double *trace, int trace_cap, double *phase_us)
 {
   if (pl.Aorig != nullptr && (fallback == nullptr || fallback_ws == nullptr || aux == nullptr)) return hipErrorInvalidValue;
+  SparseDeviceBook *const book = sparse_book();  // (exists: the plan's device copy was uploaded with its words)
+  if (book == nullptr) return hipErrorInvalidDevice;
   const bool pruned = pl.Aorig != nullptr;
   const size_t lds = (size_t)std::max(pl.lds_doubles, pruned ? fallback->lds_doubles : 0) * sizeof(double);
   const size_t wsd = qp_sparse_ws_doubles(pl);
@@ -2802,7 +2925,7 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
   int32_t *qarg    = nullptr;
   bool sliced      = false;
   if (aux != nullptr && slice > 0) {
-    int resident = sparse_resident_blocks(lds);
+    int resident = sparse_resident_blocks(*book, lds);
     if (const char *g = sfb::knob("SFB_SP_GRID"); g && atoi(g) > 0) resident = std::min(resident, atoi(g));  // tests: force slicing
     if (resident > 0 && batch > resident) {
       grid   = (unsigned)resident;
@@ -2868,6 +2991,15 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     int32_t *xtra   = aux + sparse_aux_queue_ints(batch);
     float *keys     = reinterpret_cast<float *>(xtra);
     int32_t *order2 = xtra + batch, *count = xtra + 2 * batch;
+    // the stream's slot of the device's bookkeeping; from here on the stream counts as busy, until the event recorded when this
+    // block is left (the last launch is enqueued, or the enqueue failed half-way) is seen finished
+    bool others_busy = false;
+    const SparseDeviceBook::Slot slot = sparse_enqueue_begin(*book, stream, &others_busy);
+    struct EnqueueEnd {
+      const SparseDeviceBook::Slot &sl;
+      hipStream_t st;
+      ~EnqueueEnd() { sparse_enqueue_end(sl, st); }
+    } enqueue_end{slot, stream};
     hipError_t e = launch(grid, qarg, lean_waves, phases_pack(PH_SETUP, PH_FINISH, pause), order, 0, keys);
     if (e != hipSuccess) return e;
     // Waves of the second launch: at least as many items as keep their two schedule-ordered factor copies in ~70 % of the
@@ -2886,16 +3018,19 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     const size_t lds_lat = std::max(lds, (size_t)(((kk + 2) & ~1) + pl.n + 2 * pl.m + kk + (kk + 3) / 4 + (pl.m + 7) / 8 + 4) * sizeof(double));
     int lat_hi = 0, lat_lo = 0;
     if (const char *lt = sfb::knob("SFB_SP_LAT"); !(lt && atoi(lt) == 0) && lds_lat <= 80 * 1024) {
-      // (per call: the attribute belongs to the CURRENT device and the shards of a *_multi call run on several; cheap and idempotent.
-      // A runtime that refuses the opt-in leaves lat_hi = 0: the standard form runs.)
-      const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(qp_sparse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              80 * 1024) == hipSuccess;
-      if (!lds_ok) (void)hipGetLastError();
-      int dev = 0, per_cu = 0, cus = 0;
-      if (lds_ok && hipGetDevice(&dev) == hipSuccess &&
-          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qp_sparse_kernel<true>, kWave, lds_lat) == hipSuccess &&
-          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
-        lat_hi = std::min<int>(per_cu * cus, (int)grid);
+      // (asked once per device -- the attribute belongs to the device, the shards of a *_multi call run on several.  A runtime
+      // that refuses the opt-in leaves lat_hi = 0: the standard form runs.)
+      bool lds_ok;
+      {
+        std::lock_guard<std::mutex> lk(book->mu);
+        if (book->lat_opt_in < 0) {
+          book->lat_opt_in = hipFuncSetAttribute(reinterpret_cast<const void *>(qp_sparse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 80 * 1024) == hipSuccess;
+          if (!book->lat_opt_in) (void)hipGetLastError();
+        }
+        lds_ok = book->lat_opt_in == 1;
+      }
+      if (lds_ok) lat_hi = std::min<int>(sparse_resident_blocks(*book, lds_lat, true), (int)grid);
       // (measurements: 448 waves 56.3 ms, 512: 51.8, 640: 47.0, 768: 44.0 -- the launch is bound by waves x iteration rate, not by
       //  bytes, up to three waves per CU; a FOURTH, bought by leaving part of 1 / D in the workspace, loses again: 896 waves 45.6,
       //  1 024: 46.3, scripts/r5/experiments/lat_four_waves_partial_dinv.diff)
@@ -2907,26 +3042,27 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     // 16 384: 120.6 -> 106.4, 32 768: 218.6 -> 205.3 (scripts/r3/batch_sweep.sh)
     const int lat_max = 0x7FFFFFFF;
     hipLaunchKernelGGL(sp_rank_kernel, dim3(1), dim3(kRankThreads), 0, stream, keys, (int)batch, order2, count, (int)g_lo, (int)g_hi,
-                       lat_lo, lat_hi, lat_max);
+                       lat_lo, lat_hi, lat_max, slot.bit);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const uint32_t slice3 = 0x40000000u;
     if (lat_hi > 0) {
       // POLISHERS (round 5).  Three LAT waves per CU leave one SIMD and 25 KB of LDS idle for the 30 ms of the loop launch, while
       // polish and report of the whole batch wait behind it (7.6 ms on the whole chip).  One standard-form wave per CU, launched
-      // on a low-priority stream of its own next to the loop launch, takes the items whose loop has ended from a ring the LAT
-      // waves push them into, polishes and reports them; the finish launch does what is left when the loop launch ends (the
+      // on a low-priority stream that belongs to the CALLER's stream (round 6: polishers spin until their loop launch is over,
+      // so two callers must not queue theirs on one stream), takes the items whose loop has ended from a ring the LAT waves
+      // push them into, polishes and reports them; the finish launch does what is left when the loop launch ends (the
       // last items' polish) and skips the rest.  Which wave polishes an item changes nothing in it.
       DoneQ prod{}, cons{};
-      hipEvent_t ev1 = nullptr, ev2 = nullptr;
-      int cus = 0, dev = 0;
-      const char *po = sfb::knob("SFB_SP_POLISHERS");  // 0: no polishers (measurements, tests); N > 0: N of them (default: one per CU)
-      if (hipStream_t hs = (po && atoi(po) == 0) ? nullptr : polisher_stream(); hs != nullptr &&
-          hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-          hipEventCreateWithFlags(&ev1, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev2, hipEventDisableTiming) == hipSuccess) {
+      const int cus   = book->cus;
+      const char *po  = sfb::knob("SFB_SP_POLISHERS");  // 0: no polishers (measurements, tests); N > 0: N of them (default: one per CU)
+      if (hipStream_t hs = (po && atoi(po) == 0) ? nullptr : slot.polish; hs != nullptr) {
         int32_t *dq = count + 16;  // (== fbflags + kFbSlots + 2 batch + 16: where the kernel looks for it)
-        if (hipMemsetAsync(dq, 0, (size_t)(kDqRing + batch) * sizeof(int32_t), stream) == hipSuccess && hipEventRecord(ev1, stream) == hipSuccess) {
-          const char *hp = sfb::knob("SFB_SP_LAT_HELP");  // 0: the LAT waves leave when their items are out (measurements)
-          prod = DoneQ{dq, (hp && atoi(hp) == 0) ? 1 : 3, nullptr};  // (3: ... and help the polishers, see the kernel)
+        if (hipMemsetAsync(dq, 0, (size_t)(kDqRing + batch) * sizeof(int32_t), stream) == hipSuccess && hipEventRecord(slot.ev1, stream) == hipSuccess) {
+          // helpers (3: LAT waves without an item help the polishers, see the kernel) unless another stream has work in flight
+          // right now -- those that do start look at the device's busy word before every item they take; SFB_SP_LAT_HELP=0:
+          // never (measurements)
+          const char *hp = sfb::knob("SFB_SP_LAT_HELP");
+          prod = DoneQ{dq, ((hp && atoi(hp) == 0) || others_busy) ? 1 : 3, nullptr};
           cons = DoneQ{dq, 2, hs};
         }
       }
@@ -2935,13 +3071,22 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
       if (e == hipSuccess && cons.mode == 2) {
         // (the end of the loop launch, for the polishers: whatever happens from here on, this flag is set before the stream goes on)
         e = hipMemsetAsync(cons.q + kDqOver, 0xFF, sizeof(int32_t), stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(cons.on, ev1, 0);
-        if (e == hipSuccess) e = launch((unsigned)std::min<int64_t>((po && atoi(po) > 0) ? atoi(po) : cus, batch), qarg, 0, phases_pack(PH_FINISH, PH_FINISH, 0, 2), nullptr, slice3, nullptr, nullptr, -1, false, 0, cons);
-        if (e == hipSuccess) e = hipEventRecord(ev2, cons.on);
-        if (e == hipSuccess) e = hipStreamWaitEvent(stream, ev2, 0);
+        bool polishers_out = false;
+        if (e == hipSuccess) e = hipStreamWaitEvent(cons.on, slot.ev1, 0);
+        if (e == hipSuccess) {
+          e = launch((unsigned)std::min<int64_t>((po && atoi(po) > 0) ? atoi(po) : cus, batch), qarg, 0, phases_pack(PH_FINISH, PH_FINISH, 0, 2), nullptr, slice3, nullptr, nullptr, -1, false, 0, cons);
+          polishers_out = e == hipSuccess;
+        }
+        if (e == hipSuccess) e = hipEventRecord(slot.ev2, cons.on);
+        if (e == hipSuccess) e = hipStreamWaitEvent(stream, slot.ev2, 0);
+        if (e != hipSuccess && polishers_out) {
+          // the polishers are out and the stream could not be made to wait for them: they may still write the caller's
+          // workspace and outputs when this call returns its error -- wait here, on the host (the flag above ends their spin
+          // once the stream gets there)
+          (void)hipStreamSynchronize(stream);
+          (void)hipStreamSynchronize(cons.on);
+        }
       }
-      if (ev1) (void)hipEventDestroy(ev1);
-      if (ev2) (void)hipEventDestroy(ev2);
       if (e != hipSuccess) return e;
       e = launch(grid, qarg, lean_waves, phases_pack(PH_FINISH, PH_FINISH), order2, slice3, nullptr, count + 4, 1);
       if (e != hipSuccess) return e;

@@ -37,8 +37,17 @@ struct SparsePlanDev {
   int units, nunits;
   int nnzA_io, nmasked;
   const int32_t *Aorig, *Amasked;
+  // Launch bookkeeping of the DEVICE the copy lives on (sparse_device_words below; owned by the library per device, shared
+  // by every plan): [0] of dev_active = waves of the sparse kernel busy with an item right now (all launches on the device:
+  // masked or plain factor loads); *dev_busy = one bit per caller stream that has a solve enqueued and not known finished,
+  // kept by the HOST at enqueue time in mapped host memory (the helpers of a loop launch leave when another stream has work).
+  int32_t *dev_active;
+  const unsigned long long *dev_busy;
   const SparsePlanDev *self;  // device copy of this struct (what the kernel is handed)
 };
+
+// The two words above for the current device (created on first use, never freed).
+hipError_t sparse_device_words(int32_t **active, const unsigned long long **busy);
 
 // per-item workspace, in doubles
 constexpr int kSweepPadDev = 16;  // == SparsePlanHost::kSweepPad

@@ -119,3 +119,60 @@ def test_rccl_carries_the_collectives_of_the_n_gpu_path(workload, batch, dtype, 
     assert d["gather_check"] == {"own_rows_intact": True, "peer_rows_received": True, "peer_rows_differ_from_own": True,
                                  "gathered_rows": batch, "ranks_checked": 1, "backend": "nccl", "gathered_dtype": dtype,
                                  "checksum_via_all_reduce_matches": True}
+
+
+def _run_rccl_ranks(world, B, port, timeout=240):
+    """tests/helpers/rccl_ranks.py under torch.distributed.run in a session of its own (a hung rendezvous is ended by killing
+    exactly that process group)."""
+    import signal
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.Popen([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "helpers", "rccl_ranks.py"), str(B)],
+                         cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+        timed_out = False
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, err = p.communicate()
+        timed_out = True
+    rows = [json.loads(ln[len("RCCL_RANKS "):]) for ln in out.splitlines() if ln.startswith("RCCL_RANKS ")]
+    return rows, timed_out, err
+
+
+def _record(name, payload):
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", name), "w") as f:
+        json.dump(payload, f, indent=1)
+
+
+def test_rccl_unequal_shards_through_the_padding_path():
+    """sharding.gather_small_outputs(force=True) on RCCL with total = 2 B + 1 rows: the padded all_gather and the trimming of
+    sharding.py:27-31 on the real backend (one rank on the one GPU: its shard is the whole odd-sized batch), plus the checksum
+    and MAX all_reduce of bench.py."""
+    rows, timed_out, err = _run_rccl_ranks(1, 48, 29581)
+    _record("rccl_one_rank_unequal.json", {"rows": rows, "timed_out": timed_out, "stderr_tail": err[-1500:]})
+    assert not timed_out and len(rows) == 1, err[-2000:]
+    r = rows[0]
+    assert "error" not in r, r
+    assert r["gathered_rows"] == 97 and r["gather_exact"] and r["checksum_ok"] and r["max_ok"]
+
+
+def test_rccl_two_ranks_one_device():
+    """TWO ranks, both bound to cuda:0, process group on nccl: more than one RCCL peer on the hardware there is.  RCCL may refuse
+    duplicate devices (NCCL does: "Duplicate GPU detected"); then the refusal's text is the record (gpurun_out/
+    rccl_two_ranks_one_device.json, quoted in DESIGN section 7) and the gloo variants (tests/test_sharding_gloo.py, the 2- and
+    8-rank bench runs on one device above) stay the coverage of N > 1.  If it accepts them: shards of 49 and 48 rows through
+    the padded all_gather, the checksum and the MAX all_reduce must be exact on both ranks."""
+    rows, timed_out, err = _run_rccl_ranks(2, 48, 29583)
+    refused = timed_out or len(rows) < 2 or any("error" in r for r in rows)
+    _record("rccl_two_ranks_one_device.json", {"accepted": not refused, "rows": rows, "timed_out": timed_out, "stderr_tail": err[-3000:]})
+    if refused:
+        text = " ".join(r.get("error", "") for r in rows) + err
+        # a refusal must be RCCL's own (duplicate device / invalid usage / a rendezvous that never completes), not a bug of ours
+        assert timed_out or any(k in text for k in ("Duplicate GPU", "duplicate", "invalid usage", "ncclInvalidUsage", "NCCL error",
+                                                    "ncclUnhandledCudaError", "ncclSystemError", "DistBackendError")), text[-3000:]
+        return
+    assert sorted(r["shard_rows"] for r in rows) == [48, 49]
+    for r in rows:
+        assert r["gathered_rows"] == 97 and r["gather_exact"] and r["checksum_ok"] and r["max_ok"], r

@@ -520,3 +520,47 @@ def test_lat_loop_launch_with_resident_stream_and_polishers_at_the_headline_mode
     ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l, u, perm=plan.perm, forder=plan.factor_order(),
                                        params=_oracle_params(oracle, prm), nthreads=8)
     assert np.array_equal(base.iter, ref["iter"]) and np.array_equal(base.code, ref["code"]) and np.array_equal(base.primal, ref["x"])
+
+
+def test_two_plans_on_two_streams_concurrently(sfb, oracle, knobs):
+    """Two DIFFERENT plans (the headline model and the README's vehicle), each on its own HIP stream with its own buffers,
+    several solves enqueued back to back without a synchronisation in between: every caller stream has its own polishers'
+    stream, hand-off events and bit in the device's busy word (csrc/qp_sparse.hip SparseDeviceBook), the helpers of one launch
+    leave when the other stream has work.  Every result of every round equals the oracle's, bit for bit."""
+    import torch
+    dev = torch.device("cuda:0")
+    knobs.set(SFB_SP_GRID=12)  # both batches go through the launch in predicted order (LAT loop launch + polishers)
+    prm = sfb.QPSolverParams()
+    jobs = []
+    for variant, K, B, seed in ((12, 50, 72, 47), (6, 30, 60, 48)):
+        d, Pp, Pi, Pv, Ap, Aj = M.mpc_pattern(variant, K)
+        Av, l, u = M.mpc_assemble_batch(variant, K, B, seed=seed)
+        keep = np.any(Av != 0.0, axis=0)
+        Px, q = np.tile(Pv, (B, 1)), np.zeros((B, d["n"]))
+        plan = sfb.SparseQPPlan(d["n"], d["m"], Pp, Pi, Ap, Aj, stage=M.mpc_stage(variant, K), keep=keep)
+        ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Av, l, u, perm=plan.perm, forder=plan.factor_order(),
+                                           params=_oracle_params(oracle, prm), nthreads=8)
+        f64 = dict(dtype=torch.float64, device=dev)
+        din = [torch.tensor(a, **f64) for a in (Px, q, Av, l, u)]
+        rounds = []
+        for _ in range(3):  # own outputs and workspace per round: nothing is overwritten before it is compared
+            rounds.append(dict(x=torch.empty((B, d["n"]), **f64), y=torch.empty((B, d["m"]), **f64), obj=torch.empty(B, **f64),
+                               it=torch.empty(B, dtype=torch.int32, device=dev), code=torch.empty(B, dtype=torch.int32, device=dev),
+                               ws=torch.empty(plan.workspace_bytes(B), dtype=torch.uint8, device=dev)))
+        jobs.append(dict(plan=plan, B=B, din=din, rounds=rounds, ref=ref, stream=torch.cuda.Stream()))
+    torch.cuda.synchronize()
+    for r in range(3):
+        for j in jobs:  # alternating: both streams always have a solve enqueued
+            o = j["rounds"][r]
+            j["plan"].solve_batch_device(j["B"], *[t.data_ptr() for t in j["din"]], o["x"].data_ptr(), o["y"].data_ptr(),
+                                         o["obj"].data_ptr(), o["it"].data_ptr(), o["code"].data_ptr(), o["ws"].data_ptr(), prm,
+                                         stream=j["stream"].cuda_stream)
+    torch.cuda.synchronize()
+    for j in jobs:
+        ref = j["ref"]
+        assert ref["iter"].max() > 50
+        for o in j["rounds"]:
+            assert np.array_equal(o["code"].cpu().numpy(), ref["code"])
+            assert np.array_equal(o["it"].cpu().numpy().astype(np.uint32), ref["iter"])
+            assert np.array_equal(o["x"].cpu().numpy(), ref["x"]) and np.array_equal(o["y"].cpu().numpy(), ref["y"])
+            assert np.array_equal(o["obj"].cpu().numpy(), ref["obj"])
