@@ -1143,6 +1143,17 @@ __device__ inline void ldl_solve_dev(const SparsePlanDev &pl, const Ws &w, doubl
 // stream for the next iteration when the caller says there is one without a stopping check in between (`next`); `pre`:
 // lx / ix hold the forward stream's head from the previous call.  Requires byte offsets and funits, bunits >= 8.
 // `resident`: the first kLatResident units of the forward stream sit in the wave's AccVGPRs (lat_resident_load).
+// rows of 64 elements per vector of the iterate a LAT wave keeps in its registers (sp_solve_item): the LAT form takes plans with
+// n, m <= 64 kLatRegRows (the launcher's condition; the headline plan has n = m = 740)
+constexpr int kLatRegRows = 12;
+// LDS of a LAT wave, in doubles: [work vector k + 2 | c q (n) | scaled bounds (2 m) | 1 / D (k) | positions of the x and of the
+// y / z elements in the work vector as 16-bit byte offsets, PADDED to 64 kLatRegRows entries each with the scratch slot k -- the
+// update phases run whole rows of 64 lanes without a predicate -- | class of rho per row (bytes, padded alike)]; between 1 / D and the
+// positions: the table {1 / rho of the three classes, rho of the three classes} (a class byte is an offset into it)
+__host__ __device__ constexpr size_t lat_lds_doubles(const int n, const int m)
+{
+  return (size_t)(((n + m + 2) + 1) & ~1) + n + 2 * (size_t)m + (n + m) + 8 + (2 * kLatRegRows * 64) / 4 + (kLatRegRows * 64) / 8 + 4;
+}
 constexpr int kLatResident = 64;  // all 256 AccVGPRs = 64 KB of the 232 KB a headline item streams per iteration
 __device__ __forceinline__ bool lat_resident_ok(const SparsePlanDev &pl) { return uni(pl.funits) >= kLatResident + 16; }
 __device__ __forceinline__ void lat_resident_load(const double *LxF, const int lane)
@@ -2111,22 +2122,79 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     else return vrinv[i];
   };
   const bool iterates  = ph0 <= PH_ADMM && iter != maxit && ret_code < 0;
+  // LAT, round 6: the ITERATE (x, y, z) lives in the wave's registers for as long as it iterates on the item -- lane l owns the
+  // elements l, l + 64, ... (kLatRows rows per vector: n, m <= 64 kLatRows, the launcher's condition for this form) -- and what
+  // the update phases read besides it, c q and the scaled bounds, sits in LDS where the iterate used to be: an iteration of the
+  // loop makes no global access outside the factor stream (the round trips to the L2 for c q and the bounds cost 1.7 of the
+  // 25.5 us of an iteration with the chip full, the iterate's LDS traffic comes on top; scripts/r6/iter_parts.sh).  Same
+  // expressions on the same operands as the standard form below: bit-identical.
+  // Between registers and the workspace the iterate always travels THROUGH LDS (unrolled register <-> LDS moves with immediate
+  // offsets, then compact loops LDS <-> global): unrolled global accesses make the compiler hoist a hundred 64-bit addresses
+  // out of the loop and park them in the AccVGPRs, which belong to the resident head of the factor stream.
+  constexpr int kLatRows = kLatRegRows;
   if constexpr (LAT) {
-    vxs = t + ((k + 2) & ~1); vys = vxs + n; vzs = vys + m; vdinv = vzs + m;
-    uint16_t *lp = reinterpret_cast<uint16_t *>(vdinv + k);
-    uint8_t *lc  = reinterpret_cast<uint8_t *>(lp + ((k + 3) & ~3));
+    if (n > kLatRows * kWave || m > kLatRows * kWave) __builtin_trap();  // (never launched: qp_sparse_launch)
+  }
+  [[maybe_unused]] double xr[kLatRows], yr[kLatRows], zr[kLatRows];
+  [[maybe_unused]] double *lqc = nullptr, *llo = nullptr, *lhi = nullptr;
+  [[maybe_unused]] const double *lrtab = nullptr;
+  // registers -> LDS block `dst` / back, lane l <-> elements l + 64 r (len <= 64 kLatRows)
+  auto regs_to_lds = [&](const double (&v)[kLatRows], double *dst, const int len) {
+#pragma unroll
+    for (int r = 0; r < kLatRows; ++r)
+      if (lane + r * kWave < len) dst[lane + r * kWave] = v[r];
+  };
+  auto lds_to_regs = [&](double (&v)[kLatRows], const double *src, const int len) {
+#pragma unroll
+    for (int r = 0; r < kLatRows; ++r) v[r] = (lane + r * kWave < len) ? src[lane + r * kWave] : 0.0;
+  };
+  // the iterate from the workspace into the registers (t is free: x and y through t[0 .. n + m), z through the block of the upper
+  // bounds, which is restored from the workspace afterwards)
+  auto iterate_in = [&] {
+    if constexpr (LAT) {
+      for (int j = lane; j < n; j += kWave) t[j] = w.xs[j];
+      for (int i = lane; i < m; i += kWave) { t[n + i] = w.ys[i]; lhi[i] = w.zs[i]; }
+      wave_sync();
+      lds_to_regs(xr, t, n);
+      lds_to_regs(yr, t + n, m);
+      lds_to_regs(zr, lhi, m);
+      wave_sync();
+      for (int i = lane; i < m; i += kWave) lhi[i] = w.hi[i];
+      wave_sync();
+    }
+  };
+  if constexpr (LAT) {
+    double *cq = t + ((k + 2) & ~1), *clo = cq + n, *chi = clo + m;
+    lqc = cq; llo = clo; lhi = chi;
+    vdinv = chi + m;
+    constexpr int kPad = kLatRows * kWave;
+    double *ltab = vdinv + k;  // {1 / rho of class 0, 1, 2, rho of class 0, 1, 2, -, -}: a class byte is 8 x class
+    lrtab = ltab;
+    uint16_t *lp = reinterpret_cast<uint16_t *>(ltab + 8);  // [x: kPad][y / z: kPad] byte offsets into t
+    uint8_t *lc  = reinterpret_cast<uint8_t *>(lp + 2 * kPad);
     vp16 = lp;
     vcls = lc;
+#pragma unroll
+    for (int r = 0; r < kLatRows; ++r) xr[r] = yr[r] = zr[r] = 0.0;
     if (iterates) {
-      for (int j = lane; j < n; j += kWave) vxs[j] = w.xs[j];
-      for (int i = lane; i < m; i += kWave) {
-        vys[i] = w.ys[i]; vzs[i] = w.zs[i];
-        const double rho = w.rho[i];
-        lc[i] = (uint8_t)(rho == rho_c0 ? 0 : (rho == rho_c1 ? 1 : 2));
+      for (int j = lane; j < n; j += kWave) cq[j] = w.qc[j];
+      for (int i = lane; i < m; i += kWave) clo[i] = w.lo[i];
+      for (int e = lane; e < kPad; e += kWave) {
+        lp[e]        = (uint16_t)(8 * (e < n ? pl.pinv[e] : k));
+        lp[kPad + e] = (uint16_t)(8 * (e < m ? pl.pinv[n + e] : k));
+        int cl = 2;
+        if (e < m) {
+          const double rho = w.rho[e];
+          cl = rho == rho_c0 ? 0 : (rho == rho_c1 ? 1 : 2);
+        }
+        lc[e] = (uint8_t)(8 * cl);
       }
-      for (int e = lane; e < k; e += kWave) lp[e] = (uint16_t)pl.pinv[e];
+      if (lane < 3) {
+        ltab[lane]     = lane == 0 ? rinv_c0 : (lane == 1 ? rinv_c1 : rinv_c2);
+        ltab[3 + lane] = lane == 0 ? rho_c0 : (lane == 1 ? rho_c1 : rho_c2);
+      }
       for (int e = lane; e < k; e += kWave) vdinv[e] = w.Dinv[e];
-      wave_sync();
+      iterate_in();
     }
   }
   // LAT, round 5: the head of the forward stream resident in the wave's AccVGPRs for as long as it iterates on the item (the
@@ -2138,12 +2206,21 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
   }
   auto vectors_home = [&] {  // LAT: x, z, y back to the workspace (polish, report, or the next wave that takes the item up)
     if constexpr (LAT) {
-      if (iterates) {
-        for (int j = lane; j < n; j += kWave) w.xs[j] = vxs[j];
-        for (int i = lane; i < m; i += kWave) { w.ys[i] = vys[i]; w.zs[i] = vzs[i]; }
+      if (iterates) {  // (t is free wherever this is called: behind a stopping check or at the end of the loop)
+        wave_sync();
+        regs_to_lds(xr, t, n);
+        regs_to_lds(yr, t + n, m);
+        regs_to_lds(zr, lhi, m);
+        wave_sync();
+        for (int j = lane; j < n; j += kWave) w.xs[j] = t[j];
+        for (int i = lane; i < m; i += kWave) { w.ys[i] = t[n + i]; w.zs[i] = lhi[i]; }
+        wave_sync();
       }
     }
   };
+#if defined(SFB_ITER_EXP) && SFB_ITER_EXP >= 3  // ... c q and the scaled bounds read from LDS (whatever is there)
+  if constexpr (LAT) { vqc = vxs; vlo = vys; vhi = vzs; }
+#endif
   [[maybe_unused]] const bool lat_chain = LAT && uni(pl.idx_scale) == 8 && uni(pl.funits) >= 8 && uni(pl.bunits) >= 8;
   for (; ph0 <= PH_ADMM && iter != maxit && ret_code < 0; ++iter) {
     // element-wise phases: the loads of UNR strided elements are issued together (one memory round
@@ -2153,6 +2230,49 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     // The right-hand side of the NEXT solve is written by the update phase below from the values it has just
     // computed (same expressions, no re-read of x, z, y, 1/rho); only the first iteration and the one after a
     // stopping check (which uses t as scratch) build it here.
+    // (LAT) an element of the work vector by its byte offset; rows of 64 lanes run without predicates: the padding lanes of a
+    // vector's last row (and whole padding rows of a smaller problem) carry the scratch slot t[k] and whatever the LDS holds
+    // behind the constants
+    [[maybe_unused]] auto t_at = [&](const int off) -> double & { return *reinterpret_cast<double *>(reinterpret_cast<char *>(t) + off); };
+    // (the loop's scalars in VGPRs: the kernel's SGPRs are spilled to VGPR lanes and every use of a spilled one is a v_readlane)
+    [[maybe_unused]] double v_alpha = kp.alpha, v_alphac = kp.alpha_comp, v_sigma = kp.sigma;
+    if constexpr (LAT) asm volatile("" : "+v"(v_alpha), "+v"(v_alphac), "+v"(v_sigma));
+    [[maybe_unused]] auto tab_at = [&](const int off) -> double { return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lrtab) + off); };
+    [[maybe_unused]] auto rhs_from_regs = [&] {
+      constexpr int kPad = kLatRows * kWave;
+      int pv[kLatRows];
+      double qv[kLatRows];
+#pragma unroll
+      for (int r = 0; r < kLatRows; ++r) {  // :450
+        pv[r] = (int)vp16[lane + r * kWave];
+        qv[r] = lqc[lane + r * kWave];
+      }
+#pragma unroll
+      for (int r = 0; r < kLatRows; ++r) t_at(pv[r]) = v_sigma * xr[r] - qv[r];
+#pragma unroll
+      for (int r = 0; r < kLatRows; ++r) {  // :451
+        pv[r] = (int)vp16[kPad + lane + r * kWave];
+        qv[r] = tab_at((int)vcls[lane + r * kWave]);
+      }
+#pragma unroll
+      for (int r = 0; r < kLatRows; ++r) t_at(pv[r]) = zr[r] - qv[r] * yr[r];
+    };
+    if constexpr (LAT) {
+      if (iter == next_chk) {
+        // the old iterate is parked in dx_us / dy_us (the oracle's memcpy, qp_solver.hpp:466-467; x and y do not change during
+        // the solve, so it can happen here) -- through t, whose right-hand side is then built again from the registers: the same
+        // expressions on the same values the update phase wrote it from
+        wave_sync();
+        regs_to_lds(xr, t, n);
+        regs_to_lds(yr, t + n, m);
+        wave_sync();
+        for (int j = lane; j < n; j += kWave) w.dxus[j] = t[j];
+        for (int i = lane; i < m; i += kWave) w.dyus[i] = t[n + i];
+        wave_sync();
+        need_rhs = true;
+      }
+      if (need_rhs) rhs_from_regs();
+    } else
     if (need_rhs) {
     constexpr int UNR = UNR_A;
     for (int j0 = lane; j0 < n; j0 += kWave * UNR) {  // :450
@@ -2189,6 +2309,9 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     }
     const bool chk = (iter == next_chk);
     wave_sync();
+#if defined(SFB_ITER_EXP) && SFB_ITER_EXP == 2  // measurement builds (scripts/r6/iter_parts.sh; results are garbage): no sweeps
+    if (false)
+#endif
     if constexpr (LAT) {
       if (lat_chain && !lean) {
         // chained sweeps (ldl_solve_lat): the backward stream's head is fetched by the forward sweep's last block.  Carrying the
@@ -2210,9 +2333,11 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     // here: per element it cost a lone wave more instructions than the update itself (the check's pointers and divisions,
     // reloaded from spilled SGPRs).  At a check the old iterate is parked in dx_us / dy_us first (the oracle's memcpy,
     // qp_solver.hpp:466-467) and the unscaled vectors are formed by a pass of their own below -- same expressions, same bits.
-    if (chk) {
-      for (int j = lane; j < n; j += kWave) w.dxus[j] = vxs[j];
-      for (int i = lane; i < m; i += kWave) w.dyus[i] = vys[i];
+    if constexpr (!LAT) {
+      if (chk) {
+        for (int j = lane; j < n; j += kWave) w.dxus[j] = vxs[j];
+        for (int i = lane; i < m; i += kWave) w.dyus[i] = vys[i];
+      }
     }
     auto xrows = [&]<int U, bool PRED>(std::integral_constant<int, U>, std::bool_constant<PRED>, const int r0) {
       double xo[U], qv[U];
@@ -2274,8 +2399,81 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
       if constexpr (U > 1) if (r + 1 <= full) { rows(std::integral_constant<int, 1>{}, std::false_type{}, r); r += 1; }
       if (full * kWave < len) rows(std::integral_constant<int, 1>{}, std::true_type{}, r);
     };
+#if defined(SFB_ITER_EXP) && SFB_ITER_EXP == 1  // ... no update phases
+    if (false)
+#endif
+    if constexpr (LAT) {
+      // the register form of the two phases above: every LDS read of a batch of rows is issued before the first result is used
+      constexpr int kPad = kLatRows * kWave;
+      auto xbatch = [&]<int R0, int RN>(std::integral_constant<int, R0>, std::integral_constant<int, RN>) {
+        if (R0 * kWave >= n) return;
+        int pv[RN];
+        double qv[RN], tv[RN];
+#pragma unroll
+        for (int e = 0; e < RN; ++e) {
+          pv[e] = (int)vp16[lane + (R0 + e) * kWave];
+          qv[e] = lqc[lane + (R0 + e) * kWave];
+        }
+#pragma unroll
+        for (int e = 0; e < RN; ++e) tv[e] = t_at(pv[e]);
+#pragma unroll
+        for (int e = 0; e < RN; ++e) {
+          const double xn = v_alpha * tv[e] + v_alphac * xr[R0 + e];
+          xr[R0 + e]  = xn;
+          t_at(pv[e]) = v_sigma * xn - qv[e];  // rhs of the next solve (:450)
+        }
+      };
+      auto ybatch = [&]<int R0, int RN>(std::integral_constant<int, R0>, std::integral_constant<int, RN>) {
+        if (R0 * kWave >= m) return;
+        int pv[RN], cl[RN];
+        double lo[RN], hi[RN], tv[RN], riv[RN], rhv[RN];
+#pragma unroll
+        for (int e = 0; e < RN; ++e) {
+          const int i = lane + (R0 + e) * kWave;
+          pv[e] = (int)vp16[kPad + i];
+          cl[e] = (int)vcls[i];
+          lo[e] = llo[i];
+          hi[e] = lhi[i];
+        }
+#pragma unroll
+        for (int e = 0; e < RN; ++e) {
+          tv[e]  = t_at(pv[e]);
+          riv[e] = tab_at(cl[e]);
+          rhv[e] = tab_at(cl[e] + 24);
+        }
+#pragma unroll
+        for (int e = 0; e < RN; ++e) {
+          const double ri = riv[e], rh = rhv[e];
+          const double nu = tv[e], yo = yr[R0 + e], zo = zr[R0 + e];
+          double zn = v_alpha * (ri * nu) + v_alphac * (ri * yo) + zo;
+          zn = (zn < lo[e]) ? lo[e] : zn;
+          zn = (hi[e] < zn) ? hi[e] : zn;
+          const double yn = v_alphac * yo + v_alpha * nu + rh * zo - rh * zn;
+          yr[R0 + e]  = yn;
+          zr[R0 + e]  = zn;
+          t_at(pv[e]) = zn - ri * yn;  // rhs of the next solve (:451)
+        }
+      };
+      static_assert(kLatRows == 12, "batches of the register form");
+      xbatch(std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{});
+      xbatch(std::integral_constant<int, 6>{}, std::integral_constant<int, 6>{});
+      ybatch(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+      ybatch(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
+      ybatch(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{});
+    } else
+    {
     all_rows(std::integral_constant<int, UNR_A>{}, n, xrows);
     all_rows(std::integral_constant<int, UNR_B>{}, m, yrows);
+    }
+    if constexpr (LAT) {
+      if (chk) {
+        // the new iterate goes HOME here (x, y through t, z through the block of the upper bounds: the pass below then reads them
+        // where the standard form has them), and comes back behind the check if the loop goes on: during the check no register
+        // of the wave holds it
+        vectors_home();
+        vxs = t; vys = t + n; vzs = lhi;
+      }
+    }
     if (chk) {  // :481-488 unscaled iterate and differences for the check
       for (int j = lane; j < n; j += kWave) {
         const double xn = vxs[j], sxj = w.sx[j], xo = w.dxus[j];
@@ -2300,6 +2498,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
       }
       if (ret_code < 0 && max_time_exceeded(kp.max_time_ns, t0_ticks)) ret_code = SFB_QP_MAX_TIME;  // :504-507
       wave_sync();
+      if constexpr (LAT) iterate_in();  // (restores the block of the upper bounds as well)
       lean = __builtin_amdgcn_readfirstlane(__hip_atomic_load(pl.dev_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >
              lean_waves;
       // Items that are still iterating after many checks are the ones the whole launch waits for:
@@ -3014,10 +3213,10 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     // report of the survivors then follow as a launch of their own on the whole chip (they are latency-bound and want every
     // wave; inside the few waves of the loop they took 40 % of the wave time).  Otherwise: the standard kernel, loop and
     // polish in one launch.  Both are enqueued, the blocks of the form that was not chosen leave at once.
-    const int kk = pl.n + pl.m;
-    const size_t lds_lat = std::max(lds, (size_t)(((kk + 2) & ~1) + pl.n + 2 * pl.m + kk + (kk + 3) / 4 + (pl.m + 7) / 8 + 4) * sizeof(double));
+    const size_t lds_lat = std::max(lds, lat_lds_doubles(pl.n, pl.m) * sizeof(double));
     int lat_hi = 0, lat_lo = 0;
-    if (const char *lt = sfb::knob("SFB_SP_LAT"); !(lt && atoi(lt) == 0) && lds_lat <= 80 * 1024) {
+    const bool lat_fits = lds_lat <= 80 * 1024 && pl.n <= kLatRegRows * kWave && pl.m <= kLatRegRows * kWave;  // (the iterate in registers)
+    if (const char *lt = sfb::knob("SFB_SP_LAT"); !(lt && atoi(lt) == 0) && lat_fits) {
       // (asked once per device -- the attribute belongs to the device, the shards of a *_multi call run on several.  A runtime
       // that refuses the opt-in leaves lat_hi = 0: the standard form runs.)
       bool lds_ok;
@@ -3094,9 +3293,8 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     return launch(g_hi, qarg, (int)std::max(512.0, mall / stream_bytes), phases_pack(PH_ADMM, PH_FINISH), order2, slice3,
                   nullptr, count, lat_hi > 0 ? 0 : -1);
   }
-  if (const char *fl = sfb::knob("SFB_SP_FORCE_LAT"); !phased && fl && atoi(fl) == 1) {  // measurements: the LAT form for a whole launch
-    const int kk = pl.n + pl.m;
-    const size_t lds_lat = std::max(lds, (size_t)(((kk + 2) & ~1) + pl.n + 2 * pl.m + kk + (kk + 3) / 4 + (pl.m + 7) / 8 + 4) * sizeof(double));
+  if (const char *fl = sfb::knob("SFB_SP_FORCE_LAT"); !phased && fl && atoi(fl) == 1 && pl.n <= kLatRegRows * kWave && pl.m <= kLatRegRows * kWave) {  // measurements: the LAT form for a whole launch
+    const size_t lds_lat = std::max(lds, lat_lds_doubles(pl.n, pl.m) * sizeof(double));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(qp_sparse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return launch(grid, qarg, lean_waves, PH_EVERYTHING, order, 0, nullptr, nullptr, -1, true, lds_lat);
   }
