@@ -88,16 +88,29 @@ for a, b in regions:
             hazards += 1
             sys.exit("check_sweep_spills: line %d of %s touches a register of a stream load that is still in flight "
                      "(before its counted s_waitcnt): %s" % (i + 1, sys.argv[1], t))
-# Third check (round 5): the LAT kernel keeps the head of the forward factor stream RESIDENT in its AccVGPRs across compiler-
-# generated code (lat_resident_load / the resident prefix of the forward sweep).  The compiler does not know that: it must not use
-# AccVGPRs itself (as spill space for VGPRs, say).  Every AccVGPR access of the file has to be one of ours -- a literal
-# `v_accvgpr_read_b32 v, a[N]` of the prefix or a `global_load_dwordx4 a[N:M]` of the load.
-bad_acc = [i for i, l in enumerate(lines)
-           if re.search(r"\bv_accvgpr_(write|mov)", l) or (re.search(r"\ba\[?\d", l.split(";")[0]) and not re.search(
-               r"v_accvgpr_read_b32 v\d+, a\[|global_load_dwordx4 a\[", l))]
-if bad_acc:
-    sys.exit("check_sweep_spills: line %d of %s: an AccVGPR access that is not the resident stream's: %s"
-             % (bad_acc[0] + 1, sys.argv[1], lines[bad_acc[0]].strip()))
+# Third check (rounds 5-6): the LAT kernel keeps the head of the forward factor stream RESIDENT in its AccVGPRs across compiler-
+# generated code (lat_resident_load / the resident prefix of the forward sweep).  The compiler does not know that, and it does use
+# AccVGPRs itself when the architectural registers are short (gfx950 allocates long-lived values there).  The two sides share the
+# file by number: a[0 .. kAgprFree) are the compiler's, a[kAgprFree .. 255] the resident stream's (kAgprFree: a constant of
+# qp_sparse.hip, read from the source next to this script).  Every access to an AccVGPR >= kAgprFree has to be one of ours -- a
+# literal `v_accvgpr_read_b32 v, a[N]` of the prefix or a `global_load_dwordx4 a[N:M]` of the load -- and none of ours may name
+# one below it.
+import os
+src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "qp_sparse.hip")).read()
+AGPR_FREE = int(re.search(r"constexpr int kAgprFree\s*=\s*(\d+)\s*;", src).group(1))
+NUM = r"(0x[0-9a-fA-F]+|\d+)"  # (the assembler prints a literal register number the way the operand was formed: a[64:0x43])
+ours = re.compile(r"v_accvgpr_read_b32 v\d+, a\[" + NUM + r"\]|global_load_dwordx4 a\[" + NUM + ":" + NUM + r"\]")
+for i, l in enumerate(lines):
+    code = l.split(";")[0]
+    idx = [int(x, 0) for x in re.findall(r"\ba\[?" + NUM, code)] + [int(x, 0) for pr in re.findall(r"\ba\[" + NUM + ":" + NUM + r"\]", code) for x in pr]
+    if not idx:
+        continue
+    if ours.search(code):
+        if min(idx) < AGPR_FREE:
+            sys.exit("check_sweep_spills: line %d of %s: the resident stream names an AccVGPR that belongs to the compiler: %s" % (i + 1, sys.argv[1], l.strip()))
+    elif max(idx) >= AGPR_FREE:
+        sys.exit("check_sweep_spills: line %d of %s: an access to the resident stream's AccVGPRs (a%d and up) that is not the resident stream's: %s"
+                 % (i + 1, sys.argv[1], AGPR_FREE, l.strip()))
 nspill = sum(1 for l in lines if re.search(r"\bscratch_(load|store)", l))
 print("check_sweep_spills: %d sweep regions, %d scratch instructions, none inside a sweep; no instruction touches a register of a "
       "load in flight" % (len(regions), nspill))

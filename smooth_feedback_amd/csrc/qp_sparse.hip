@@ -829,6 +829,12 @@ __device__ __forceinline__ void stream_wait(vdouble2 &a, vint2 &b)
 // (Between chained sweeps nothing else may touch memory: the counted waits assume the stream's loads only.)
 // RES > 0 (the LAT forward sweep): the values of the first RES units are RESIDENT in the wave's AccVGPRs a[4 u .. 4 u + 3]
 // (lat_resident_load) and are not streamed; see the static prefix in the hand-scheduled branch.
+// The AccVGPR file is shared BY NUMBER between the compiler and the resident head of the factor stream (round 6): on gfx950 the
+// compiler allocates long-lived values to AccVGPRs whenever the 256 architectural registers are short -- it does not know that the
+// hand-written prefix keeps factor values there -- so a[0 .. kAgprFree) are left to it and the resident stream takes
+// a[kAgprFree .. 255].  check_sweep_spills.py reads this constant and holds both sides to it.  Every 4 registers given away are
+// one unit (1 KB per iteration) less resident: 64 free registers cost the headline 0.45 ms.  0: the kernel as it stands needs none.
+constexpr int kAgprFree = 0;
 template<int DEPTH, bool BYTEOFF, bool LEAN, bool PRE = false, bool NEXT = false, int RES = 0>
 __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const int units, const double *vals, double *t,
                                  const int lane, const int32_t *__restrict__ mask32, const int full0, const int full1,
@@ -985,7 +991,7 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
       unit_g(dd, std::integral_constant<int, 12>{}, std::integral_constant<int, 0>{}, lx[D].x, lx[D].y);
     };
     // RESIDENT PREFIX (RES > 0): units 0 .. RES + 7 with literal unit numbers.  Unit U < RES takes its two values per lane from the
-    // AccVGPRs a[4 U .. 4 U + 3]; the loads in flight behind unit U + 1's are one per resident unit and two per streamed one among
+    // AccVGPRs a[kAgprFree + 4 U .. + 3]; the loads in flight behind unit U + 1's are one per resident unit and two per streamed one among
     // the units U + 2 .. U + 7; unit U requests for unit U + 8 the indices only while that one is resident.  From unit RES + 8 on
     // the eight units in flight are all streamed: the loop below takes over with its counts unchanged.
     int u_first = 0;
@@ -1001,7 +1007,7 @@ __device__ __forceinline__ void sweep_dev(const int32_t *__restrict__ idx, const
           int l0, h0, l1, h1;
           asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"
                        : "=v"(l0), "=v"(h0), "=v"(l1), "=v"(h1)
-                       : "n"(4 * U), "n"(4 * U + 1), "n"(4 * U + 2), "n"(4 * U + 3));
+                       : "n"(kAgprFree + 4 * U), "n"(kAgprFree + 4 * U + 1), "n"(kAgprFree + 4 * U + 2), "n"(kAgprFree + 4 * U + 3));
           vx = __hiloint2double(h0, l0);
           vy = __hiloint2double(h1, l1);
         } else {
@@ -1154,7 +1160,7 @@ __host__ __device__ constexpr size_t lat_lds_doubles(const int n, const int m)
 {
   return (size_t)(((n + m + 2) + 1) & ~1) + n + 2 * (size_t)m + (n + m) + 8 + (2 * kLatRegRows * 64) / 4 + (kLatRegRows * 64) / 8 + 4;
 }
-constexpr int kLatResident = 64;  // all 256 AccVGPRs = 64 KB of the 232 KB a headline item streams per iteration
+constexpr int kLatResident = (256 - kAgprFree) / 4;  // kAgprFree == 0: all 256 AccVGPRs = 64 KB of the 232 KB a headline item streams per iteration
 __device__ __forceinline__ bool lat_resident_ok(const SparsePlanDev &pl) { return uni(pl.funits) >= kLatResident + 16; }
 __device__ __forceinline__ void lat_resident_load(const double *LxF, const int lane)
 {
@@ -1168,8 +1174,8 @@ __device__ __forceinline__ void lat_resident_load(const double *LxF, const int l
                  "global_load_dwordx4 a[%5:%6], %0, off offset:2048\n\t"
                  "global_load_dwordx4 a[%7:%8], %0, off offset:3072"
                  :
-                 : "v"(pg), "n"(16 * G), "n"(16 * G + 3), "n"(16 * G + 4), "n"(16 * G + 7), "n"(16 * G + 8), "n"(16 * G + 11), "n"(16 * G + 12),
-                   "n"(16 * G + 15)
+                 : "v"(pg), "n"(kAgprFree + 16 * G), "n"(kAgprFree + 16 * G + 3), "n"(kAgprFree + 16 * G + 4), "n"(kAgprFree + 16 * G + 7),
+                   "n"(kAgprFree + 16 * G + 8), "n"(kAgprFree + 16 * G + 11), "n"(kAgprFree + 16 * G + 12), "n"(kAgprFree + 16 * G + 15)
                  : "memory");
   });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2139,14 +2145,17 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
   [[maybe_unused]] double *lqc = nullptr, *llo = nullptr, *lhi = nullptr;
   [[maybe_unused]] const double *lrtab = nullptr;
   // registers -> LDS block `dst` / back, lane l <-> elements l + 64 r (len <= 64 kLatRows)
+  // (predicates as `lane < scalar`, addresses as one lane pointer plus immediates: no per-row lane index is kept in a register)
   auto regs_to_lds = [&](const double (&v)[kLatRows], double *dst, const int len) {
+    double *const dl = dst + lane;
 #pragma unroll
     for (int r = 0; r < kLatRows; ++r)
-      if (lane + r * kWave < len) dst[lane + r * kWave] = v[r];
+      if (lane < len - r * kWave) dl[r * kWave] = v[r];
   };
   auto lds_to_regs = [&](double (&v)[kLatRows], const double *src, const int len) {
+    const double *const sl = src + lane;
 #pragma unroll
-    for (int r = 0; r < kLatRows; ++r) v[r] = (lane + r * kWave < len) ? src[lane + r * kWave] : 0.0;
+    for (int r = 0; r < kLatRows; ++r) v[r] = (lane < len - r * kWave) ? sl[r * kWave] : 0.0;
   };
   // the iterate from the workspace into the registers (t is free: x and y through t[0 .. n + m), z through the block of the upper
   // bounds, which is restored from the workspace afterwards)
@@ -2179,6 +2188,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
     if (iterates) {
       for (int j = lane; j < n; j += kWave) cq[j] = w.qc[j];
       for (int i = lane; i < m; i += kWave) clo[i] = w.lo[i];
+#pragma unroll 1  // (a constant trip count: unrolled, its twelve lane indices are hoisted and kept for the life of the kernel)
       for (int e = lane; e < kPad; e += kWave) {
         lp[e]        = (uint16_t)(8 * (e < n ? pl.pinv[e] : k));
         lp[kPad + e] = (uint16_t)(8 * (e < m ? pl.pinv[n + e] : k));
