@@ -15,10 +15,14 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
+#include <map>
+#include <mutex>
 
 #include "../../include/sfb.h"
 #include "../../include/smooth_feedback_amd/detail/ekf_lane.hpp"
 #include "ekf_kernel.h"
+#include "knobs.h"
 #include "ldlt_wave.h"
 #include "wave_util.h"
 
@@ -112,6 +116,133 @@ __global__ void __launch_bounds__(64, SFB_EKF_WPE) ekf_kernel(const EkfArgs a)
   }
   wave_sync();
   tile_store<NN>(a.P, item0, a.batch, lds, lane);
+}
+
+// The fused step as a PERSISTENT wave (round 6; N * N even: 16-byte granules).  The kernel above is HBM-bound while a wave
+// loads and idle towards the memory system while it computes (2 260 VALU instructions per tile of 64 filters, a quarter of a
+// tile's time, with one wave per SIMD and nothing of its own in flight).  Here a wave walks over tiles and, before the update's
+// arithmetic of tile i, requests the covariances of tile i + 1 STRAIGHT INTO LDS (global_load_lds_dwordx4: no register of the
+// wave is involved, which is what the register-staged prefetch of round 4 ran out of): they land while the wave computes and
+// stores.  Only the covariances: a request costs the wave ~100 cycles of issue per KB, and with EVERY input tile requested that
+// way (built and measured: 0.298 ms per 1 048 576 filters against 0.284 for this form and 0.297-0.305 for the kernel above) the
+// issue time eats what the overlap gains.  The LDS image of such a load is lane-linear (destination = base + 16 lane), so the
+// odd-stride padding of the staged tiles is not available; the bank conflicts of the per-lane walk (18 granules per filter:
+// lanes l and l + 8 of a 16-lane pass meet) are removed by exchanging the two granules of every pair for the filters with bit 3
+// of the lane set -- on the SOURCE side, granule g of the tile is fetched into position g ^ ((g / (8 * G)) & 1), and the reader
+// applies the same involution.  Same arithmetic on the same values as ekf_kernel: bit-identical.
+#ifndef SFB_EKF_GLDS_AUX
+#define SFB_EKF_GLDS_AUX 0  // cache policy of the requests (2: non-temporal)
+#endif
+#ifndef SFB_EKF_LANDED_EARLY
+#define SFB_EKF_LANDED_EARLY 0  // 1: wait for the next tile's covariances BEFORE this tile's stores join the queue (0: at the next tile's start)
+#endif
+template<int N, int M>
+__global__ void __launch_bounds__(64, 1) ekf_fused_persistent_kernel(const EkfArgs a, const int64_t ntiles)
+{
+  constexpr int NN = N * N, NP = NN | 1, G = NN / 2;  // G: 16-byte granules per filter
+  static_assert(NN % 2 == 0, "16-byte granules");
+  constexpr int WMAX = (NN > M * N ? NN : M * N) > M * M ? (NN > M * N ? NN : M * N) : M * M;
+  constexpr int TILE = (WMAX | 1) * kWave;
+  __shared__ double lds[TILE];
+  __shared__ __attribute__((aligned(16))) double nextP[NN * kWave];  // the next tile's covariances, swizzled lane-linear image
+  const int lane = threadIdx.x;
+  using lds_ptr  = __attribute__((address_space(3))) void *;
+  auto request_P = [&](const int64_t tile) {
+    const int64_t item0 = tile * kWave;
+    const int granules  = (int)(a.batch - item0 < kWave ? a.batch - item0 : kWave) * G;
+    const double *src   = a.P + item0 * NN;
+#pragma unroll
+    for (int w = 0; w < G; ++w) {  // G windows of 64 granules (1 KB per wave instruction)
+      const int p = w * kWave + lane;
+      int g       = p ^ ((p / (8 * G)) & 1);
+      g           = g < granules ? g : 0;  // (a partial last tile: lanes beyond it fetch something valid, nobody reads it)
+      __builtin_amdgcn_global_load_lds(src + 2 * g, (lds_ptr)(nextP + 2 * w * kWave), 16, 0, SFB_EKF_GLDS_AUX);
+    }
+  };
+  auto landed = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) request_P(tile);
+  landed();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int64_t item0 = tile * kWave;
+    const int64_t item  = item0 + lane;
+    const bool live     = item < a.batch;
+    if constexpr (!SFB_EKF_LANDED_EARLY) landed();
+    wave_sync();
+    double P[NN];
+    {
+      const int sw = (lane >> 3) & 1;
+#pragma unroll
+      for (int c = 0; c < G; ++c) {
+        const vd2 v  = *reinterpret_cast<const vd2 *>(nextP + 2 * ((lane * G + c) ^ sw));
+        P[2 * c]     = live ? v.x : 0.0;
+        P[2 * c + 1] = live ? v.y : 0.0;
+      }
+    }
+    wave_sync();  // (every lane has its covariance: the buffer is free for the next request)
+
+    {  // predict, as in ekf_kernel
+      double A[NN];
+      tile_load<NN>(a.A, item0, a.batch, lds, lane);
+      wave_sync();
+#pragma unroll
+      for (int e = 0; e < NN; ++e) A[e] = live ? lds[lane * NP + e] : 0.0;
+      wave_sync();
+      if (!a.q_shared) {
+        tile_load<NN>(a.Q, item0, a.batch, lds, lane);
+        wave_sync();
+      }
+      const double dt = live ? (a.dt_shared ? a.dt[0] : a.dt[item]) : 0.0;
+      ekf_lane_predict<N>(P, A, [&](const int i, const int j) {
+        return a.q_shared ? a.Q[i + j * N] : (live ? lds[lane * NP + i + j * N] : 0.0);
+      }, dt);
+      wave_sync();
+    }
+
+    constexpr int MN = M * N, MNP = MN | 1;
+    double H[MN];
+    tile_load<MN>(a.H, item0, a.batch, lds, lane);
+    wave_sync();
+#pragma unroll
+    for (int e = 0; e < MN; ++e) H[e] = live ? lds[lane * MNP + e] : 0.0;
+    wave_sync();
+    constexpr int MM = M * M, MMP = MM | 1;
+    if (!a.r_shared) {
+      tile_load<MM>(a.R, item0, a.batch, lds, lane);
+      wave_sync();
+    }
+    double Rv[MM];
+#pragma unroll
+    for (int b = 0; b < M; ++b) {
+#pragma unroll
+      for (int aa = 0; aa < M; ++aa)
+        Rv[aa + b * M] = (aa <= b) ? (a.r_shared ? a.R[aa + b * M] : (live ? lds[lane * MMP + aa + b * M] : ((aa == b) ? 1.0 : 0.0))) : 0.0;
+    }
+    wave_sync();
+    double rv[M], delta[N];
+#pragma unroll
+    for (int aa = 0; aa < M; ++aa) rv[aa] = live ? a.r[item * M + aa] : 0.0;
+    // every ordinary load of this tile is consumed before the next tile's covariances are requested (the compiler waits for
+    // ALL outstanding loads at the first use of an ordinary one: with the request in flight that would be the request too)
+#pragma unroll
+    for (int aa = 0; aa < M; ++aa) asm volatile("" : "+v"(rv[aa]));
+    landed();
+    if (tile + gridDim.x < ntiles) request_P(tile + gridDim.x);
+    const bool ok = ekf_lane_update<N, M>(P, H, [&](const int aa, const int b) { return Rv[aa + b * M]; }, rv, delta);
+    if (live) {
+#pragma unroll
+      for (int e = 0; e < NN; ++e) lds[lane * NP + e] = P[e];
+    }
+    if constexpr (SFB_EKF_LANDED_EARLY) landed();  // (... so that the wait at the next tile's start is not one for these stores' acknowledgements)
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) a.delta[item * N + i] = delta[i];
+    }
+    if (a.info != nullptr && live) a.info[item] = ok ? 0 : 1;
+    wave_sync();
+    tile_store<NN>(a.P, item0, a.batch, lds, lane);
+    wave_sync();  // (the staging tile is free again)
+  }
 }
 
 // The update for 6 < dof <= 10 (ny <= 3): one filter per lane as in ekf_kernel, but P alone fills a third of the
@@ -523,6 +654,34 @@ template<int N, int M>
 static hipError_t launch_nm(const EkfArgs &a, bool predict, bool update, hipStream_t stream)
 {
   const dim3 grid((unsigned)((a.batch + kWave - 1) / kWave)), block(kWave);
+  if constexpr (N == 6 && M <= 3) {  // (the pair exchange of the kernel is what an N = 6 tile needs; M N + M M <= N N)
+    // the persistent form of the fused step (see the kernel): as many waves as the device holds at once -- its LDS admits four
+    // per compute unit -- when there are tiles for several rounds of them; SFB_EKF_PERSISTENT=0: the one-tile-per-wave kernel
+    const char *pk = sfb::knob("SFB_EKF_PERSISTENT");
+    if (predict && update && !(pk && atoi(pk) == 0)) {
+      static std::mutex mu;
+      static std::map<int, int> resident;  // device -> waves of this kernel it holds
+      int dev = 0, waves = 0;
+      if (hipGetDevice(&dev) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(mu);
+        const auto it = resident.find(dev);
+        if (it != resident.end()) waves = it->second;
+        else {
+          int per_cu = 0, cus = 0;
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ekf_fused_persistent_kernel<N, M>, kWave, 0) == hipSuccess &&
+              hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+            waves = per_cu * cus;
+          else (void)hipGetLastError();
+          resident[dev] = waves;
+        }
+      } else (void)hipGetLastError();
+      const int64_t ntiles = (a.batch + kWave - 1) / kWave;
+      if (waves > 0 && ntiles >= 4 * (int64_t)waves) {
+        hipLaunchKernelGGL((ekf_fused_persistent_kernel<N, M>), dim3((unsigned)waves), block, 0, stream, a, ntiles);
+        return hipGetLastError();
+      }
+    }
+  }
   if (predict && update) hipLaunchKernelGGL((ekf_kernel<N, M, true, true>), grid, block, 0, stream, a);
   else if (predict) hipLaunchKernelGGL((ekf_kernel<N, M, true, false>), grid, block, 0, stream, a);
   else hipLaunchKernelGGL((ekf_kernel<N, M, false, true>), grid, block, 0, stream, a);

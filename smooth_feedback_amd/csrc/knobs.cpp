@@ -13,7 +13,7 @@ namespace sfb {
 namespace {
 const char *const kKnobs[] = {"SFB_SP_GRID",  "SFB_SP_SLICE",  "SFB_SP_PAUSE",      "SFB_SP_PREDICT",   "SFB_SP_LAT",
                               "SFB_SP_FORCE_LAT", "SFB_SP_LAT_WAVES", "SFB_SP_POLISHERS", "SFB_SP_LAT_HELP", "SFB_SP_PHASED", "SFB_SP_LEAN_WAVES", "SFB_MID_GRID", "SFB_MID_SLICE",
-                              "SFB_QP4_MAX_WAVES", "SFB_QP_DENSE_BIG", "SFB_PLAN_UNITS", "SFB_PLAN_DEBUG", "SFB_MPC_TIMING"};
+                              "SFB_QP4_MAX_WAVES", "SFB_QP_DENSE_BIG", "SFB_EKF_PERSISTENT", "SFB_PLAN_UNITS", "SFB_PLAN_DEBUG", "SFB_MPC_TIMING"};
 std::mutex g_mu;
 std::atomic<int> g_set{0};  // knobs set right now: a production process never sets one and never takes the lock
 // Values are INTERNED: a string handed out by knob() stays valid for the life of the process, whatever a concurrent

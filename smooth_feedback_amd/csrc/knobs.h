@@ -16,6 +16,8 @@
 //   dense kernels                 SFB_MID_GRID, SFB_MID_SLICE   32 < n + m <= 128: resident waves / checks per slice
 //                                 SFB_QP4_MAX_WAVES  n + m <= 32: cap on the persistent grid
 //                                 SFB_QP_DENSE_BIG   0: sizes beyond 128 through the sparse kernel
+//   EKF                           SFB_EKF_PERSISTENT 0: the fused step as one tile per wave instead of persistent waves with the next tile's
+//                                                    covariances requested straight into LDS
 //   plan                          SFB_PLAN_UNITS     0: the supernodal engine of the numeric factorisation for every plan
 //                                 SFB_PLAN_DEBUG     1: print segments, units and sweep schedules of a plan
 //   MPC swarm                     SFB_MPC_TIMING     1: synchronise after every stage of a tick and print its wall time
