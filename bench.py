@@ -479,7 +479,7 @@ WORKLOADS = {"mpc": MPCWorkload, "qp_dense": DenseQPWorkload, "ekf": EKFWorkload
 # The sparse kernel mixes 16-byte streams (factor, vectors) with 8-byte gathers (factorisation, checks): x2 is exact
 # for the former (~85 % of its reads) and over-counts the latter, so its traffic figure is an upper bound (~ +10 %).
 FETCH_CORRECTION = {"mpc": 2.0, "ekf": 2.0, "qp_dense": 1.0 / 0.58}
-PROFILE_TAG = "r5"
+PROFILE_TAG = "r6"
 FP64_VALU_PEAK = 78.6e12  # MI355X vector FP64 (half the 157.3 TFLOP/s FP32 vector rate of MI355X_MICROARCH.md)
 
 
@@ -518,7 +518,7 @@ def pmc_traffic(workload, workload_name):
 
 
 KERNEL_NAME = {"mpc": "qp_sparse_kernel (launch in predicted order: first launch to the first check, rank kernel, LAT loop launch with the polishers next to it, finish launch)", "qp_dense": "qp_dense4_iterate_kernel (+ setup and finish kernels of the same launch)",
-               "ekf": "ekf_kernel"}
+               "ekf": "ekf_fused_persistent_kernel (persistent waves, the next tile's covariances requested straight into LDS)"}
 
 
 def roofline_of(workload, wl, kern_ms, with_traffic):

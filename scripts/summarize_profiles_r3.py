@@ -8,7 +8,7 @@ import csv, json, os, shutil, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-DOMINANT = {"mpc": "qp_sparse_kernel", "mpc_phases": "qp_sparse_kernel", "qp_dense": "qp_dense4_iterate_kernel", "ekf": "ekf_kernel",
+DOMINANT = {"mpc": "qp_sparse_kernel", "mpc_phases": "qp_sparse_kernel", "qp_dense": "qp_dense4_iterate_kernel", "ekf": "ekf_",
             "dense_mid": "qp_dense"}
 
 

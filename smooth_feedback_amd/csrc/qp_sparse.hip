@@ -278,6 +278,12 @@ __device__ __forceinline__ bool panel_eliminate(double (&reg)[kPanelCols], const
 // wave but costs the batch more HBM traffic than this gather + coalesced write -- measured.
 // (branch-free, DEPTH gathers in flight per lane: padding slots read the always-zero accumulator; the copies'
 //  lengths are multiples of 8 * 128 >= DEPTH * 64)
+#ifndef SFB_COPY_DEPTH
+#define SFB_COPY_DEPTH 16
+#endif
+#ifndef SFB_COPY_UB
+#define SFB_COPY_UB 8
+#endif
 template<int DEPTH>
 __device__ __forceinline__ void ldl_sweep_copies(const SparsePlanDev &pl, const Ws &w, const int lane)
 {
@@ -357,7 +363,7 @@ __device__ inline int ldl_numeric_units(const SparsePlanDev &pl, const Item &it,
   const vint4u *__restrict__ stream = reinterpret_cast<const vint4u *>(pl.ustream);
   auto at = [&](const unsigned off) -> double & { return *reinterpret_cast<double *>(reinterpret_cast<char *>(t) + off); };
   bool zero_pivot = false;
-  constexpr int UB = 8;  // loads in flight per lane in the copy loops
+  constexpr int UB = SFB_COPY_UB;  // loads in flight per lane in the copy loops
   for (int sg = 0, nseg = uni(pl.nseg); sg < nseg; ++sg) {
     const int32_t *sgp = pl.seg + 12 * sg;
     const int u0 = uni(sgp[0]), u1 = uni(sgp[1]), c0 = uni(sgp[2]), c1 = uni(sgp[3]), closed = uni(sgp[4]), nLs = uni(sgp[5]);
@@ -465,7 +471,7 @@ __device__ inline int ldl_numeric_units(const SparsePlanDev &pl, const Item &it,
     fill_lap(false);
   }
   if (wave_ballot(zero_pivot)) return 0;
-  ldl_sweep_copies<DEPTH>(pl, w, lane);
+  ldl_sweep_copies<SFB_COPY_DEPTH>(pl, w, lane);  // (gathers in flight per lane: a block of the copy is one memory round trip)
   SFB_ULAP(4)
 #ifdef SFB_PROF_LDL
   if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
