@@ -161,6 +161,10 @@ void sfb_qp_params_default(sfb_qp_params *prm);
  * Outputs (QPSolution, qp.hpp:95-108):
  *   x [batch][n] primal, y [batch][m] dual, obj [batch] (nullable), iter [batch] (nullable),
  *   code [batch] (sfb_qp_status values).
+ * Non-finite data: like the reference, no input is validated -- NaN / inf in P, q, A propagate through the IEEE arithmetic
+ * (l = +inf or u = -inf is the pre-check's PrimalInfeasible), and the kernels make of them exactly what the CPU restatement
+ * does (tests/test_qp_dense_gpu.py, tests/test_qp_sparse_gpu.py::test_non_finite_*: codes, iteration counts and values up to
+ * NaN payloads).  Shortcuts that rest on "0 times an entry is 0" (the first refinement round of polish) are covered by them.
  * Requires 1 <= n, 1 <= m (n+m > SFB_QP_DENSE_MAX_K: see there; n+m <= 19 198).
  * Working memory: sizes with n+m <= 32 (the four-per-wave kernel's records and queue) and n+m > SFB_QP_DENSE_MAX_K
  * (the factor in HBM) need device memory beyond the arguments.  This entry point takes it stream-ordered

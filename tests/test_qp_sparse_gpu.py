@@ -138,6 +138,31 @@ def test_non_finite_inputs_follow_the_reference_semantics_sparse(sfb, oracle):
         assert np.array_equal(rc.primal[b], r.primal[b]) and rc.iter[b] == r.iter[b]
 
 
+@pytest.mark.parametrize("n,m,density,seed", [(10, 20, 0.5, 11), (30, 50, 0.15, 12), (16, 12, 0.4, 13)])
+def test_non_finite_matrix_entries_at_random_places(sfb, oracle, n, m, density, seed):
+    """inf / -inf / NaN at random positions of the STORED values of P and A (one to three per item, every item): whatever the
+    reference's arithmetic makes of them -- including a solve that still ends Optimal and is polished, where the first refinement
+    round of polish takes its residual as h (x = 0: csrc/qp_sparse.hip sp_polish; the reference forms h - H 0) -- the kernel makes
+    the same of them: codes, iteration counts, and primal / dual bit for bit up to NaN payloads against the sparse oracle."""
+    B = 24
+    P, q, A, l, u = sfb.random_qp_batch(seed, B, m, n, density)
+    Pp, Pi, Px, Ap, Aj, Ax = dense_batch_to_sparse(P, A, n, m)
+    rng = np.random.default_rng(seed)
+    vals = (np.inf, -np.inf, np.nan)
+    for b in range(B):
+        for _ in range(1 + rng.integers(3)):
+            arr = Px if rng.random() < 0.4 and Px.shape[1] > 0 else Ax
+            arr[b, rng.integers(arr.shape[1])] = vals[rng.integers(3)]
+    plan = sfb.SparseQPPlan(n, m, Pp, Pi, Ap, Aj)
+    prm = sfb.QPSolverParams(max_iter=200)
+    r = plan.solve_batch_host(Px, q, Ax, l, u, prm)
+    ref = oracle.qp_sparse_solve_batch(Pp, Pi, Px, q, Ap, Aj, Ax, l, u, perm=plan.perm, forder=plan.factor_order(),
+                                       params=_oracle_params(oracle, prm))
+    assert np.array_equal(r.code, ref["code"]) and np.array_equal(r.iter, ref["iter"]), (r.code, ref["code"], r.iter, ref["iter"])
+    assert np.array_equal(r.primal, ref["x"], equal_nan=True) and np.array_equal(r.dual, ref["y"], equal_nan=True)
+    assert np.array_equal(r.objective, ref["obj"], equal_nan=True)
+
+
 def test_solve_after_solve_batch_does_not_reuse_a_foreign_factor(sfb):
     """QPSolver<QuadraticProgramSparse>::solve() flags reuse_factor when it is handed the previous solve()'s matrices
     again; solve_batch() on the same solver shares the device workspace, so it must end that claim (round-2 advisor
