@@ -2686,6 +2686,7 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
 constexpr int kFbSlots = 64;
 // ring of the items whose ADMM loop has ended (see the kernel): counters on their own cache lines, then one entry per item
 constexpr int kDqTail = 0, kDqHead = 32, kDqOver = 64, kDqOwn = 80, kDqRing = 96;  // ([kDqOwn]: busy waves of the loop launch + its polishers)
+constexpr int kDqStarted = 88;  // != 0: the loop launch's waves are on the chip (its block 0 has begun), see sp_gate_kernel
 
 // POLISHER: the instance the polishers run (dq_mode 2); the standard instance has no register to spare for their loop.
 template<bool LAT, bool TRACE = false, bool POLISHER = false>
@@ -2717,6 +2718,10 @@ __global__ void __launch_bounds__(64, LAT ? 1 : ((TRACE || POLISHER) ? 2 : 3)) q
   // keys (nullable): per item, the predictor score of a paused item (SP_PAUSED) or -1 (nothing left to do for the next launch)
   // nfresh_dev (nullable): the fresh items of this launch are order[0 .. *nfresh_dev - 1] (the survivors of the previous one)
   const int ph0    = phases & 15;
+  if constexpr (LAT) {  // (the loop launch announces itself to the gate in front of its polishers, whichever form the rank kernel chose)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && ((phases >> 28) & 1) == 1)
+      __hip_atomic_store(&(fbflags + kFbSlots + 2 * batch + 16)[kDqStarted], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   const int nfresh = nfresh_dev ? __builtin_amdgcn_readfirstlane(nfresh_dev[0]) : batch;
   // ... worked on by the first nfresh_dev[1] blocks of the grid only (the rank kernel sizes the launch, see there)
   const int nwaves = nfresh_dev ? __builtin_amdgcn_readfirstlane(nfresh_dev[1]) : (queue == nullptr ? (int)gridDim.x : batch);
@@ -2734,6 +2739,9 @@ __global__ void __launch_bounds__(64, LAT ? 1 : ((TRACE || POLISHER) ? 2 : 3)) q
   for (bool first = true;; first = false) {
     int item = -1, resume = 0;
     if constexpr (dq_mode == 2) {
+      // (as many polishers as the rank kernel asked for, count[10]: one per compute unit when the iterations are the bulk of
+      //  the work, two when polish is -- see sp_rank_kernel; the launch always holds the larger number)
+      if (first && (int)blockIdx.x >= __builtin_amdgcn_readfirstlane((fbflags + kFbSlots + 2 * batch)[10])) return;
       if (lane == 0) {
         int32_t *const doneq = fbflags + kFbSlots + 2 * batch + 16;
         for (;;) {
@@ -2889,11 +2897,24 @@ __global__ void __launch_bounds__(64, LAT ? 1 : ((TRACE || POLISHER) ? 2 : 3)) q
 // itself (headline batch: 25, 30, 50, 77, 127, 327, 968 iterations on average for scores in [2, 4), [4, 8), ... --
 // sum / max of the scores 493, of the true counts 443): waves = sum_k score_k / score_max, clamped to [g_lo, g_hi] --
 // g_lo: the items whose factors fit the Infinity Cache (fewer waves do not saturate it), g_hi: what the chip holds.
+// GATE in front of the polishers (round 6): one wave on the polishers' stream that waits until the loop launch's waves are on the
+// chip.  A LAT wave needs a SIMD's whole register file; polishers that are placed FIRST -- two fit a SIMD -- take SIMDs away from
+// the loop launch for its whole length (round 5: 512 polishers, 48.8 instead of 42.8 ms).  Behind the gate they only ever get
+// what the LAT waves leave: the fourth SIMD of every compute unit at once, and the SIMDs of LAT waves that have run out of items.
+// Bounded (a loop launch that never starts must not hang the stream: the polishers then simply start early).
+__global__ void sp_gate_kernel(const int32_t *__restrict__ started)
+{
+  for (int spin = 0; spin < 200000; ++spin) {  // (~0.1 s)
+    if (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+    __builtin_amdgcn_s_sleep(32);
+  }
+}
+
 constexpr int kRankBins = 4096, kRankThreads = 1024;
 __global__ __launch_bounds__(kRankThreads) void sp_rank_kernel(const float *__restrict__ keys, const int batch,
                                                                int32_t *__restrict__ order2, int32_t *__restrict__ count,
                                                                const int g_lo, const int g_hi, const int lat_lo, const int lat_hi,
-                                                               const int lat_max, const int stream_bit)
+                                                               const int lat_max, const int stream_bit, const int pol_lo, const int pol_hi)
 {
   __shared__ int hist[kRankBins];
   __shared__ int psum[kRankThreads];
@@ -2954,6 +2975,13 @@ __global__ __launch_bounds__(kRankThreads) void sp_rank_kernel(const float *__re
       count[5] = g_hi;
       count[6] = lat;
       count[8] = stream_bit;  // (the caller stream's bit in SparsePlanDev::dev_busy: the helpers look past their own)
+      // POLISHERS at work next to the loop launch: pol_lo (one per compute unit) or pol_hi (two).  Polish under load costs an
+      // item ~1.7 ms of wave time whatever it iterated; the polishers' traffic slows the LAT waves' iterations down.  With a
+      // cold start's ~90 iterations per item the iterations are the bulk and a second polisher per unit costs more than it
+      // brings (headline 38.6 -> 45.2 ms); with the ~38 of a warm-started tick polish is two thirds of the launch's wave
+      // time and it pays (25.5 -> 24.7 ms).  What tells the two apart at this point is the mean score (residual over tolerance
+      // at the first check): ~600 for the cold headline batch, ~20 for warm ticks of the same swarm.
+      count[10] = (total > 0 && fsum[0] / (float)total < 100.0f) ? pol_hi : pol_lo;
     }
   }
   __syncthreads();
@@ -2978,7 +3006,8 @@ struct SparseDeviceBook {
     int bit = 0;
     hipStream_t polish = nullptr;  // nullptr: could not be created -- no polishers for this stream
     hipEvent_t ev1 = nullptr, ev2 = nullptr, last = nullptr;
-    int inflight = 0;  // solves enqueued whose end `last` has not been seen yet
+    int inflight = 0;    // solves enqueued whose end `last` has not been seen yet
+    int enqueueing = 0;  // ... of which the enqueue is still going on (another thread): `last` is not recorded yet -- busy, no query
   };
   std::mutex mu;
   int dev = -1, cus = 0;
@@ -3073,6 +3102,10 @@ static SparseDeviceBook::Slot sparse_enqueue_begin(SparseDeviceBook &b, hipStrea
   for (auto &kv : b.slots) {
     SparseDeviceBook::Slot &sl = kv.second;
     if (&sl == &mine || sl.inflight == 0) continue;
+    if (sl.enqueueing > 0) {  // (its event still marks the end of an OLDER solve)
+      others = true;
+      continue;
+    }
     const hipError_t q = hipEventQuery(sl.last);
     if (q == hipErrorNotReady) {
       (void)hipGetLastError();
@@ -3085,15 +3118,20 @@ static SparseDeviceBook::Slot sparse_enqueue_begin(SparseDeviceBook &b, hipStrea
   }
   if (mine.last != nullptr) {
     mine.inflight = 1;
+    ++mine.enqueueing;
     if (b.busy_host) __atomic_fetch_or(b.busy_host, 1ull << mine.bit, __ATOMIC_RELEASE);
   }
   *others_busy = others;
   return mine;
 }
 // ... and its last launch has been enqueued (or the enqueue failed half-way: the stream's work up to here still ends there)
-static void sparse_enqueue_end(const SparseDeviceBook::Slot &sl, hipStream_t stream)
+static void sparse_enqueue_end(SparseDeviceBook &b, const SparseDeviceBook::Slot &sl, hipStream_t stream)
 {
-  if (sl.last != nullptr && hipEventRecord(sl.last, stream) != hipSuccess) (void)hipGetLastError();
+  if (sl.last == nullptr) return;
+  if (hipEventRecord(sl.last, stream) != hipSuccess) (void)hipGetLastError();
+  std::lock_guard<std::mutex> lk(b.mu);
+  for (auto &kv : b.slots)
+    if (kv.second.last == sl.last && kv.second.enqueueing > 0) --kv.second.enqueueing;
 }
 
 // blocks of qp_sparse_kernel (standard / LAT form) the device holds at once with `lds` bytes of dynamic LDS each
@@ -3211,10 +3249,11 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     bool others_busy = false;
     const SparseDeviceBook::Slot slot = sparse_enqueue_begin(*book, stream, &others_busy);
     struct EnqueueEnd {
+      SparseDeviceBook &bk;
       const SparseDeviceBook::Slot &sl;
       hipStream_t st;
-      ~EnqueueEnd() { sparse_enqueue_end(sl, st); }
-    } enqueue_end{slot, stream};
+      ~EnqueueEnd() { sparse_enqueue_end(bk, sl, st); }
+    } enqueue_end{*book, slot, stream};
     hipError_t e = launch(grid, qarg, lean_waves, phases_pack(PH_SETUP, PH_FINISH, pause), order, 0, keys);
     if (e != hipSuccess) return e;
     // Waves of the second launch: at least as many items as keep their two schedule-ordered factor copies in ~70 % of the
@@ -3256,8 +3295,13 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     // item-iterations per microsecond (21) than the standard form on the whole chip (17-18.5): 12 288 agents 90.7 -> 80.9 ms,
     // 16 384: 120.6 -> 106.4, 32 768: 218.6 -> 205.3 (scripts/r3/batch_sweep.sh)
     const int lat_max = 0x7FFFFFFF;
+    // polishers next to the loop launch (see the rank kernel and below): SFB_SP_POLISHERS=N forces N, 0 none
+    int pol_lo = book->cus, pol_hi = 2 * book->cus;
+    if (const char *pk = sfb::knob("SFB_SP_POLISHERS"); pk && atoi(pk) > 0) pol_lo = pol_hi = atoi(pk);
+    pol_lo = (int)std::min<int64_t>(pol_lo, batch);
+    pol_hi = (int)std::min<int64_t>(pol_hi, batch);
     hipLaunchKernelGGL(sp_rank_kernel, dim3(1), dim3(kRankThreads), 0, stream, keys, (int)batch, order2, count, (int)g_lo, (int)g_hi,
-                       lat_lo, lat_hi, lat_max, slot.bit);
+                       lat_lo, lat_hi, lat_max, slot.bit, pol_lo, pol_hi);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const uint32_t slice3 = 0x40000000u;
     if (lat_hi > 0) {
@@ -3268,8 +3312,9 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
       // push them into, polishes and reports them; the finish launch does what is left when the loop launch ends (the
       // last items' polish) and skips the rest.  Which wave polishes an item changes nothing in it.
       DoneQ prod{}, cons{};
-      const int cus   = book->cus;
-      const char *po  = sfb::knob("SFB_SP_POLISHERS");  // 0: no polishers (measurements, tests); N > 0: N of them (default: one per CU)
+      // 0: no polishers (measurements, tests); N > 0: N of them; default: one or two per CU, the rank kernel's choice (pol_lo / pol_hi)
+      const char *po  = sfb::knob("SFB_SP_POLISHERS");
+      const int npolish = pol_hi;
       if (hipStream_t hs = (po && atoi(po) == 0) ? nullptr : slot.polish; hs != nullptr) {
         int32_t *dq = count + 16;  // (== fbflags + kFbSlots + 2 batch + 16: where the kernel looks for it)
         if (hipMemsetAsync(dq, 0, (size_t)(kDqRing + batch) * sizeof(int32_t), stream) == hipSuccess && hipEventRecord(slot.ev1, stream) == hipSuccess) {
@@ -3289,7 +3334,11 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
         bool polishers_out = false;
         if (e == hipSuccess) e = hipStreamWaitEvent(cons.on, slot.ev1, 0);
         if (e == hipSuccess) {
-          e = launch((unsigned)std::min<int64_t>((po && atoi(po) > 0) ? atoi(po) : cus, batch), qarg, 0, phases_pack(PH_FINISH, PH_FINISH, 0, 2), nullptr, slice3, nullptr, nullptr, -1, false, 0, cons);
+          hipLaunchKernelGGL(sp_gate_kernel, dim3(1), dim3(1), 0, cons.on, cons.q + kDqStarted);
+          e = hipGetLastError();
+        }
+        if (e == hipSuccess) {
+          e = launch((unsigned)npolish, qarg, 0, phases_pack(PH_FINISH, PH_FINISH, 0, 2), nullptr, slice3, nullptr, nullptr, -1, false, 0, cons);
           polishers_out = e == hipSuccess;
         }
         if (e == hipSuccess) e = hipEventRecord(slot.ev2, cons.on);

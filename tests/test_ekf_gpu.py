@@ -40,6 +40,29 @@ def test_predict_update_matches_oracle(sfb, oracle, dof, ny, B):
     assert np.array_equal(P3, ref3) and np.array_equal(d3, dref3) and (i3 == 0).all()
 
 
+@pytest.mark.parametrize("ny", [1, 2, 3])
+@pytest.mark.parametrize("shared", [False, True])
+def test_persistent_fused_step_matches_oracle_and_the_one_tile_kernel(sfb, oracle, knobs, ny, shared):
+    """The persistent form of the fused step at dof 6 (csrc/ekf.hip ekf_fused_persistent_kernel: waves walk over tiles, the next
+    tile's covariances are requested straight into LDS through a source-side swizzle) takes batches of at least four rounds of
+    the device's waves; here 262 144 + 37 filters -- a partial last tile -- with per-filter and with shared Q / R / dt: against
+    the oracle and against the one-tile-per-wave kernel (debug knob), bit for bit."""
+    dof, B = 6, 4 * 1024 * 64 + 37
+    rng = np.random.default_rng(600 + ny + 10 * shared)
+    P = _flat(_spd(rng, B, dof)); A = _flat(rng.uniform(-1, 1, (B, dof, dof)))
+    Q = _flat(0.1 * np.tile(np.eye(dof), (B, 1, 1)) + 0.01 * rng.uniform(-1, 1, (B, dof, dof)))
+    dt = rng.uniform(0.01, 0.05, B)
+    H = _flat(rng.uniform(-1, 1, (B, ny, dof))); R = _flat(0.1 * np.tile(np.eye(ny), (B, 1, 1)) + 0.01 * _spd(rng, B, ny))
+    r = rng.uniform(-1, 1, (B, ny))
+    Qa, Ra, dta = (Q[0].copy(), R[0].copy(), 0.025) if shared else (Q, R, dt)
+    P1, d1, i1 = sfb.ekf_step_batch_host(P, dof, A=A, Q=Qa, dt=dta, H=H, R=Ra, r=r)
+    knobs.set(SFB_EKF_PERSISTENT=0)
+    P0, d0, i0 = sfb.ekf_step_batch_host(P, dof, A=A, Q=Qa, dt=dta, H=H, R=Ra, r=r)
+    assert np.array_equal(P1, P0) and np.array_equal(d1, d0) and np.array_equal(i1, i0)
+    ref, dref, iref = oracle.ekf_update_batch(H, Ra, r, oracle.ekf_predict_batch(A, Qa, dta, P), dof)
+    assert np.array_equal(P1, ref) and np.array_equal(d1, dref) and np.array_equal(i1, iref)
+
+
 def test_update_linear_identities_on_device(sfb):
     """tests/test_ekf.cpp:50-103 through the device path (tolerance 1e-6 as in the reference)."""
     rng = np.random.default_rng(3)
