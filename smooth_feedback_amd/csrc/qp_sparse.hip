@@ -3134,6 +3134,17 @@ static void sparse_enqueue_end(SparseDeviceBook &b, const SparseDeviceBook::Slot
     if (kv.second.last == sl.last && kv.second.enqueueing > 0) --kv.second.enqueueing;
 }
 
+// the LDS opt-in of the LAT form (80 KB of dynamic LDS), asked once per device
+static bool sparse_lat_opt_in(SparseDeviceBook &b)
+{
+  std::lock_guard<std::mutex> lk(b.mu);
+  if (b.lat_opt_in < 0) {
+    b.lat_opt_in = hipFuncSetAttribute(reinterpret_cast<const void *>(qp_sparse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+    if (!b.lat_opt_in) (void)hipGetLastError();
+  }
+  return b.lat_opt_in == 1;
+}
+
 // blocks of qp_sparse_kernel (standard / LAT form) the device holds at once with `lds` bytes of dynamic LDS each
 static int sparse_resident_blocks(SparseDeviceBook &b, size_t lds, bool lat = false)
 {
@@ -3274,17 +3285,7 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     if (const char *lt = sfb::knob("SFB_SP_LAT"); !(lt && atoi(lt) == 0) && lat_fits) {
       // (asked once per device -- the attribute belongs to the device, the shards of a *_multi call run on several.  A runtime
       // that refuses the opt-in leaves lat_hi = 0: the standard form runs.)
-      bool lds_ok;
-      {
-        std::lock_guard<std::mutex> lk(book->mu);
-        if (book->lat_opt_in < 0) {
-          book->lat_opt_in = hipFuncSetAttribute(reinterpret_cast<const void *>(qp_sparse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 80 * 1024) == hipSuccess;
-          if (!book->lat_opt_in) (void)hipGetLastError();
-        }
-        lds_ok = book->lat_opt_in == 1;
-      }
-      if (lds_ok) lat_hi = std::min<int>(sparse_resident_blocks(*book, lds_lat, true), (int)grid);
+      if (sparse_lat_opt_in(*book)) lat_hi = std::min<int>(sparse_resident_blocks(*book, lds_lat, true), (int)grid);
       // (measurements: 448 waves 56.3 ms, 512: 51.8, 640: 47.0, 768: 44.0 -- the launch is bound by waves x iteration rate, not by
       //  bytes, up to three waves per CU; a FOURTH, bought by leaving part of 1 / D in the workspace, loses again: 896 waves 45.6,
       //  1 024: 46.3, scripts/r5/experiments/lat_four_waves_partial_dinv.diff)
@@ -3362,6 +3363,18 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
     const size_t lds_lat = std::max(lds, lat_lds_doubles(pl.n, pl.m) * sizeof(double));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(qp_sparse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return launch(grid, qarg, lean_waves, PH_EVERYTHING, order, 0, nullptr, nullptr, -1, true, lds_lat);
+  }
+  // SMALL BATCHES (round 6): a launch of one block per item that the LAT form holds at once -- up to three per compute unit -- runs
+  // in the LAT form as a whole (setup, loop with the iterate in registers and the resident stream head, polish in the wide form):
+  // what a single controller or a small swarm waits for is the latency of its items' chains, and the LAT form's iteration is 18.6
+  // against 24.6 us.  One QP of the headline model through the host entry 1.89 -> 1.81 ms, 64: 12.2 -> 10.8 ms, 512: 24.2 -> 21.0 ms
+  // (scripts/single_agent_latency.py); same results (the form is a schedule: fuzzed as SFB_SP_FORCE_LAT=1).  SFB_SP_LAT=0: never.
+  if (!phased && !sliced) {
+    const char *lt       = sfb::knob("SFB_SP_LAT");
+    const size_t lds_lat = std::max(lds, lat_lds_doubles(pl.n, pl.m) * sizeof(double));
+    if (!(lt && atoi(lt) == 0) && batch <= 3 * (int64_t)book->cus && lds_lat <= 80 * 1024 && pl.n <= kLatRegRows * kWave &&
+        pl.m <= kLatRegRows * kWave && sparse_lat_opt_in(*book))
+      return launch(grid, qarg, 0x7FFFFFFF /* plain loads: the latency form of the sweeps */, PH_EVERYTHING, order, 0, nullptr, nullptr, -1, true, lds_lat);
   }
   if (!phased) return launch(grid, qarg, lean_waves, PH_EVERYTHING, order);
   // grid of the ADMM phase: items whose two schedule-ordered factor copies fit ~70 % of the MALL
