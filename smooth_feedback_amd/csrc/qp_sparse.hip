@@ -3191,8 +3191,14 @@ hipError_t qp_sparse_launch(const SparsePlanDev &pl, const DenseKernelParams &kp
   if (aux != nullptr && slice > 0) {
     int resident = sparse_resident_blocks(*book, lds);
     if (const char *g = sfb::knob("SFB_SP_GRID"); g && atoi(g) > 0) resident = std::min(resident, atoi(g));  // tests: force slicing
-    if (resident > 0 && batch > resident) {
-      grid   = (unsigned)resident;
+    // (round 6: a batch beyond what the LAT form holds at once -- three per CU -- goes through the queue even when the standard form
+    //  would hold it at once: the launch in predicted order with its LAT loop launch is the faster way through the iterations.
+    //  Host entry, headline model: 1 024 QPs 31.7 -> 28.2 ms, 2 048: 41.3 -> 34.5, 3 072: 52.6 -> 40.9; up to 768 the whole launch
+    //  runs in the LAT form, see below)
+    const bool lat_ok  = pl.n <= kLatRegRows * kWave && pl.m <= kLatRegRows * kWave && lat_lds_doubles(pl.n, pl.m) * sizeof(double) <= 80 * 1024;
+    const int64_t hold = lat_ok ? std::min<int64_t>(resident, 3 * (int64_t)book->cus) : resident;
+    if (resident > 0 && batch > hold) {
+      grid   = (unsigned)std::min<int64_t>(resident, batch);
       qarg   = aux;
       sliced = true;
     }
