@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import smooth_feedback_amd as sfb
 from examples import models_lib as M
 
-batch, K, ticks = 8192, 50, 8
+import os
+batch, K, ticks = int(os.environ.get("B", 8192)), 50, 8
 for spec in (sys.argv[1:] or [""]):
     pairs = sfb.debug_set_from(spec) if spec else {}
     r = M.mpc_swarm_devlin_step(12, K, batch, ticks, seed=1, want_records=False)

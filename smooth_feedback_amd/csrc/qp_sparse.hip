@@ -2981,7 +2981,10 @@ __global__ __launch_bounds__(kRankThreads) void sp_rank_kernel(const float *__re
       // brings (headline 38.6 -> 45.2 ms); with the ~38 of a warm-started tick polish is two thirds of the launch's wave
       // time and it pays (25.5 -> 24.7 ms).  What tells the two apart at this point is the mean score (residual over tolerance
       // at the first check): ~600 for the cold headline batch, ~20 for warm ticks of the same swarm.
-      count[10] = (total > 0 && fsum[0] / (float)total < 100.0f) ? pol_hi : pol_lo;
+      // ... and only when the LAT waves have many rounds of items in front of them: with a few items per wave they run out soon
+      // and polish themselves, a second polisher per unit only adds its traffic (warm ticks, one / two per unit: 2 048 agents
+      // 8.5 / 9.5 ms, 4 096: 13.5 / 14.5, 8 192: 25.5 / 24.7, 16 384: 49.3 / 47.6).
+      count[10] = (total >= 8 * max(1, lat_hi) && fsum[0] / (float)total < 100.0f) ? pol_hi : pol_lo;
     }
   }
   __syncthreads();
