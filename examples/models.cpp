@@ -666,6 +666,41 @@ double rel_diff(const U & a, const U & b)
 }
 }  // namespace ref_mpc_test
 
+int sfbx_test_mpc_front_host(double * out)
+{
+  // The host-only half of the reference-shaped front (no solve, no GPU): what tests/test_mpc.cpp relies on before it ever calls
+  // operator() -- template parameters in the reference's order with Ncr read off CR, default construction, copies that share
+  // the desired trajectories (mpc.hpp:407, 607-608) and own everything else, functors by reference.
+  using namespace ref_mpc_test;
+  const X x = rplus(X::Identity(), X::Tangent{0.3, -0.2, 0.25});
+  MyDynamics f{};
+  MyRunningConstraints cr{};
+  Vec<2> crl{1, 1};
+  MPC_t mpc{f, cr, Vec<2>{-1, -1}, crl};
+  MPC_t copy = mpc;  // copy construction
+  MPC_t assigned;    // default construction, copy assignment
+  assigned = mpc;
+  const int nA = (int)mpc.qp().A_val.size(), m = mpc.qp().m;
+  std::vector<double> A0(nA), l0(m), u0(m), A1(nA), l1(m), u1(m), A2(nA), l2(m), u2(m);
+  mpc.assemble(0.5, x, A0.data(), l0.data(), u0.data());
+  copy.set_udes([](T) -> U { U u; u.v = {0.25, -0.5}; return u; });  // a setter on the COPY ...
+  mpc.assemble(0.5, x, A1.data(), l1.data(), u1.data());              // ... is seen by the original
+  assigned.assemble(0.5, x, A2.data(), l2.data(), u2.data());         // ... and by the other copy
+  double d01 = 0, d12 = 0;
+  for (int e = 0; e < m; ++e) { d01 = std::max(d01, std::fabs(l0[e] - l1[e])); d12 = std::max(d12, std::fabs(l1[e] - l2[e])); }
+  out[0] = d01;  // > 0: the running-constraint bounds moved with udes
+  out[1] = d12;  // == 0
+  out[2] = (copy.qp().A_val.data() != mpc.qp().A_val.data()) ? 1.0 : 0.0;  // own QP storage
+  out[3] = (!copy.solver().analyzed() && !assigned.solver().analyzed()) ? 1.0 : 0.0;  // no analysis travels with a copy
+  // functors held BY REFERENCE see set_time through operator()'s assembly path only; the const assembly used by swarms tells copies
+  MPC_reft byref{f, cr, Vec<2>{-1, -1}, crl};
+  byref.assemble(7.0, x, A0.data(), l0.data(), u0.data());
+  out[4] = f.t_;  // untouched by the const path: 0
+  out[5] = (double)MPC_t::Ncr + 10.0 * (double)MPC_reft::Nx + 100.0 * (double)MPC_reft::Nu;  // 2 + 30 + 200
+  out[6] = (std::is_default_constructible_v<MPC_t> && std::is_copy_assignable_v<MPC_t> && std::is_move_constructible_v<MPC_t>) ? 1.0 : 0.0;
+  return 0;
+}
+
 int sfbx_test_mpc_api(double * out, int32_t * codes)
 {
   using namespace ref_mpc_test;

@@ -31,6 +31,10 @@ int sfbx_test_mpc_se2(double *u_out, int32_t *codes, int32_t *traj_sizes);
  * [12] rel |original after set_udes on a COPY - fresh controller with that udes| (copies share the desired
  * trajectories, mpc.hpp:407, 607-608), [13] ... and that input differs from before.  Needs a GPU. */
 int sfbx_test_mpc_api(double *out, int32_t *codes);
+/* The host-only half of that front (no GPU): out[0] > 0 a setter on a COPY moves the original's assembly, out[1] == 0 every copy
+ * sees the same desired trajectories, out[2] copies own their QP, out[3] no analysis travels with a copy, out[4] == 0 the const
+ * assembly path leaves a by-reference functor's set_time alone, out[5] == 232 (Ncr 2, Nx 3, Nu 2), out[6] type properties. */
+int sfbx_test_mpc_front_host(double *out);
 /* MPC API beyond operator(): out[0] set_xdes_rel / set_udes_rel (mpc.hpp:539-586) vs the absolute-time setters (max abs
  * difference of A, l, u), out[1] the same controller with Time = std::chrono::steady_clock::time_point (time.hpp:25-89),
  * out[2..4] set_weights (mpc.hpp:593-598: stored, not transcribed; the constructor transcribes), out[5..8] lazy structure

@@ -2,6 +2,8 @@
 harness): Lie-group identities, LGR mesh properties (reference tests/test_collocation_mesh.cpp), problem
 sizes, and the transcription values against an independent numpy restatement of
 ocp_to_qp_update_dyn/cr/ce (ocp_to_qp.hpp:198-373) for the SE2xR3 vehicle.  CPU only."""
+import ctypes as C
+
 import numpy as np
 
 from examples import models_lib as M
@@ -273,3 +275,15 @@ def test_headline_model_transcription_matches_a_second_numpy_restatement():
         assert np.abs(Ad - A).max() <= 1e-12, (b, np.abs(Ad - A).max())
         assert np.abs(l[b] - lo).max() <= 1e-12 and np.abs(u[b] - hi).max() <= 1e-12, b
     print("second restatement, 64 agents of the headline model: max |difference| over A, l, u =", worst)
+
+
+def test_reference_shaped_mpc_front_host_side():
+    """The host-only half of the reference-shaped `MPC<T, X, U, F, CR, Kmesh>` (examples/models.cpp::sfbx_test_mpc_front_host; the
+    solves of tests/test_mpc.cpp run in tests/test_mpc_gpu.py::test_reference_shaped_mpc_caller_code): copies share the desired
+    trajectories (mpc.hpp:407, 607-608) and own their QP and their (un-analysed) solver, Ncr is read off CR's result (mpc.hpp:383)."""
+    out = np.full(7, np.nan)
+    assert M.lib().sfbx_test_mpc_front_host(out.ctypes.data_as(C.c_void_p)) == 0
+    assert out[0] > 1e-3 and out[1] == 0.0
+    assert out[2] == 1.0 and out[3] == 1.0
+    assert out[4] == 0.0
+    assert out[5] == 232.0 and out[6] == 1.0
