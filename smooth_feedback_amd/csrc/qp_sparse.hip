@@ -1206,6 +1206,21 @@ __device__ __forceinline__ void ldl_solve_lat(const SparsePlanDev &pl, const Ws 
   else sweep_dev<8, true, false, true, false>(pl.bidx, uni(pl.bunits), w.LxB, t, lane, pl.bmask, 0, 0, lx, ix);
 }
 
+// the same with the loads of UB rows of 64 elements issued together (one memory round trip per UB rows instead of one per row:
+// the short vectors of a stopping check are 12 rows, and a loaded LAT wave waits ~2 us for each trip)
+template<int UB>
+__device__ __forceinline__ double lane_max_abs_b(const double *v, const int len, const int lane)
+{
+  double r = 0.0;
+  for (int e0 = lane; e0 < len; e0 += kWave * UB) {
+    double x[UB];
+#pragma unroll
+    for (int e = 0; e < UB; ++e) x[e] = (e0 + e * kWave < len) ? v[e0 + e * kWave] : 0.0;
+#pragma unroll
+    for (int e = 0; e < UB; ++e) r = fmax(r, fabs(x[e]));
+  }
+  return wave_max(r);
+}
 __device__ __forceinline__ double lane_max_abs(const double *v, int len, int lane)
 {
   double r = 0.0;
@@ -1391,7 +1406,8 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
   }
   {  // PRIMAL INFEASIBILITY: max(|A'dy|, certificate sum) < thr.  The cheap certificate sum is formed first and
      // A'dy only when the sum leaves the verdict open (same result, NaN included).
-    const double Edy_norm = lane_max_abs(w.dyus, m, lane);
+    constexpr int UBV     = RBX > 4 ? 6 : 1;  // rows of the short vectors fetched together (round 6; the standard form has no register to spare)
+    const double Edy_norm = lane_max_abs_b<UBV>(w.dyus, m, lane);
     const double thr      = kp.eps_pinf * Edy_norm;
     // FAST PATH.  What the verdict needs of the ordered sum is the side of thr it lies on, and its terms summed in ANY order
     // (per lane, then across the wave) differ from the ordered sum by at most 2 gamma_N S, S = the sum of the |terms|, N = 2 m
@@ -1405,14 +1421,28 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
     {
       double ps = 0.0, pa = 0.0;
       bool brk0 = false;
-      for (int i = lane; i < m; i += kWave) {
-        const double ui = it.u[i], li = it.l[i], dyi = w.dyus[i];
-        const double ta = (ui != inf) ? ui * fmax(0.0, dyi) : 0.0, tb = (li != -inf) ? li * fmin(0.0, dyi) : 0.0;
-        ps += ta;
-        ps += tb;
-        pa += fabs(ta);
-        pa += fabs(tb);
-        brk0 = brk0 || (ui == inf && dyi > thr) || (li == -inf && dyi < -thr);
+      for (int i0 = lane; i0 < m; i0 += kWave * UBV) {  // (per lane the rows in ascending order, as before; UBV rows per round trip)
+        double uv[UBV], lv[UBV], dv[UBV];
+#pragma unroll
+        for (int e = 0; e < UBV; ++e) {
+          const int i   = i0 + e * kWave;
+          const bool on = i < m;
+          uv[e] = on ? it.u[i] : 0.0;
+          lv[e] = on ? it.l[i] : 0.0;
+          dv[e] = on ? w.dyus[i] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < UBV; ++e) {
+          if (i0 + e * kWave < m) {
+            const double ui = uv[e], li = lv[e], dyi = dv[e];
+            const double ta = (ui != inf) ? ui * fmax(0.0, dyi) : 0.0, tb = (li != -inf) ? li * fmin(0.0, dyi) : 0.0;
+            ps += ta;
+            ps += tb;
+            pa += fabs(ta);
+            pa += fabs(tb);
+            brk0 = brk0 || (ui == inf && dyi > thr) || (li == -inf && dyi < -thr);
+          }
+        }
       }
       const double sum = wave_sum(ps), S = wave_sum(pa);
       const double err = 4.0 * (2.0 * (double)m) * DBL_EPSILON * S;
@@ -1479,10 +1509,17 @@ __device__ inline int sp_check_stopping(const SparsePlanDev &pl, const Item &it,
   {  // DUAL INFEASIBILITY: |P dx| <= thr, q'dx <= thr and the row conditions on A dx, each evaluated only while
      // the verdict is still open.
     double dmx = 0.0;  // |dx|_inf, and dx into the work vector for the gathers of P dx (LDS instead of global round trips)
-    for (int e = lane; e < n; e += kWave) {
-      const double v = w.dxus[e];
-      t[e] = v;
-      dmx  = fmax(dmx, fabs(v));
+    constexpr int UBV = RBX > 4 ? 6 : 1;
+    for (int e0 = lane; e0 < n; e0 += kWave * UBV) {
+      double v[UBV];
+#pragma unroll
+      for (int e = 0; e < UBV; ++e) v[e] = (e0 + e * kWave < n) ? w.dxus[e0 + e * kWave] : 0.0;
+#pragma unroll
+      for (int e = 0; e < UBV; ++e)
+        if (e0 + e * kWave < n) {
+          t[e0 + e * kWave] = v[e];
+          dmx               = fmax(dmx, fabs(v[e]));
+        }
     }
     const double dx_norm = wave_max(dmx);
     const double thr     = kp.eps_dinf * dx_norm;
@@ -2163,18 +2200,32 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
 #pragma unroll
     for (int r = 0; r < kLatRows; ++r) v[r] = (lane < len - r * kWave) ? sl[r * kWave] : 0.0;
   };
+  // workspace -> LDS, six rows of 64 per memory round trip (the vectors of the LAT form are 12 or 24 rows, and a loaded wave waits
+  // ~2 us for every trip: one row per trip was 4 % of the loop launch in item set-up alone)
+  [[maybe_unused]] auto copy_in = [&](double *dst, const double *src, const int len) {
+    constexpr int UB = 6;
+    for (int e0 = lane; e0 < len; e0 += kWave * UB) {
+      double v[UB];
+#pragma unroll
+      for (int e = 0; e < UB; ++e) v[e] = (e0 + e * kWave < len) ? src[e0 + e * kWave] : 0.0;
+#pragma unroll
+      for (int e = 0; e < UB; ++e)
+        if (e0 + e * kWave < len) dst[e0 + e * kWave] = v[e];
+    }
+  };
   // the iterate from the workspace into the registers (t is free: x and y through t[0 .. n + m), z through the block of the upper
   // bounds, which is restored from the workspace afterwards)
   auto iterate_in = [&] {
     if constexpr (LAT) {
-      for (int j = lane; j < n; j += kWave) t[j] = w.xs[j];
-      for (int i = lane; i < m; i += kWave) { t[n + i] = w.ys[i]; lhi[i] = w.zs[i]; }
+      copy_in(t, w.xs, n);
+      copy_in(t + n, w.ys, m);
+      copy_in(lhi, w.zs, m);
       wave_sync();
       lds_to_regs(xr, t, n);
       lds_to_regs(yr, t + n, m);
       lds_to_regs(zr, lhi, m);
       wave_sync();
-      for (int i = lane; i < m; i += kWave) lhi[i] = w.hi[i];
+      copy_in(lhi, w.hi, m);
       wave_sync();
     }
   };
@@ -2192,24 +2243,32 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
 #pragma unroll
     for (int r = 0; r < kLatRows; ++r) xr[r] = yr[r] = zr[r] = 0.0;
     if (iterates) {
-      for (int j = lane; j < n; j += kWave) cq[j] = w.qc[j];
-      for (int i = lane; i < m; i += kWave) clo[i] = w.lo[i];
-#pragma unroll 1  // (a constant trip count: unrolled, its twelve lane indices are hoisted and kept for the life of the kernel)
-      for (int e = lane; e < kPad; e += kWave) {
-        lp[e]        = (uint16_t)(8 * (e < n ? pl.pinv[e] : k));
-        lp[kPad + e] = (uint16_t)(8 * (e < m ? pl.pinv[n + e] : k));
-        int cl = 2;
-        if (e < m) {
-          const double rho = w.rho[e];
-          cl = rho == rho_c0 ? 0 : (rho == rho_c1 ? 1 : 2);
+      copy_in(cq, w.qc, n);
+      copy_in(clo, w.lo, m);
+#pragma unroll 1  // (a constant trip count: unrolled, its lane indices are hoisted and kept for the life of the kernel)
+      for (int e0 = lane; e0 < kPad; e0 += 4 * kWave) {  // (four rows per round trip)
+        int px[4], py[4];
+        double rho[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int e = e0 + q * kWave;
+          px[q]  = e < n ? pl.pinv[e] : k;
+          py[q]  = e < m ? pl.pinv[n + e] : k;
+          rho[q] = e < m ? w.rho[e] : rho_c2;
         }
-        lc[e] = (uint8_t)(8 * cl);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int e  = e0 + q * kWave;
+          lp[e]        = (uint16_t)(8 * px[q]);
+          lp[kPad + e] = (uint16_t)(8 * py[q]);
+          lc[e]        = (uint8_t)(8 * (rho[q] == rho_c0 ? 0 : (rho[q] == rho_c1 ? 1 : 2)));
+        }
       }
       if (lane < 3) {
         ltab[lane]     = lane == 0 ? rinv_c0 : (lane == 1 ? rinv_c1 : rinv_c2);
         ltab[3 + lane] = lane == 0 ? rho_c0 : (lane == 1 ? rho_c1 : rho_c2);
       }
-      for (int e = lane; e < k; e += kWave) vdinv[e] = w.Dinv[e];
+      copy_in(vdinv, w.Dinv, k);
       iterate_in();
     }
   }
@@ -2491,18 +2550,46 @@ __device__ __forceinline__ int sp_solve_item(const SparsePlanDev &pl, const Dens
       }
     }
     if (chk) {  // :481-488 unscaled iterate and differences for the check
-      for (int j = lane; j < n; j += kWave) {
-        const double xn = vxs[j], sxj = w.sx[j], xo = w.dxus[j];
-        w.xus[j]  = sxj * xn;
-        t[j]      = sxj * xn;  // (the check's mat-vecs gather x and y from the work vector, free until the next right-hand side)
-        w.dxus[j] = sxj * (xn - xo);
+      // (LAT: six rows of 64 per memory round trip -- the same expressions element by element)
+      constexpr int UBU = LAT ? 6 : 1;
+      for (int j0 = lane; j0 < n; j0 += kWave * UBU) {
+        double sxv[UBU], xov[UBU];
+#pragma unroll
+        for (int e = 0; e < UBU; ++e) {
+          const bool on = j0 + e * kWave < n;
+          sxv[e] = on ? w.sx[j0 + e * kWave] : 0.0;
+          xov[e] = on ? w.dxus[j0 + e * kWave] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < UBU; ++e) {
+          const int j = j0 + e * kWave;
+          if (j < n) {
+            const double xn = vxs[j], sxj = sxv[e], xo = xov[e];
+            w.xus[j]  = sxj * xn;
+            t[j]      = sxj * xn;  // (the check's mat-vecs gather x and y from the work vector, free until the next right-hand side)
+            w.dxus[j] = sxj * (xn - xo);
+          }
+        }
       }
-      for (int i = lane; i < m; i += kWave) {
-        const double yn = vys[i], zn = vzs[i], syi = w.sy[i], yo = w.dyus[i];
-        w.yus[i]  = syi * yn / c;
-        t[n + i]  = syi * yn / c;
-        w.zus[i]  = (1.0 / syi) * zn;
-        w.dyus[i] = syi * (yn - yo) / c;
+      for (int i0 = lane; i0 < m; i0 += kWave * UBU) {
+        double syv[UBU], yov[UBU];
+#pragma unroll
+        for (int e = 0; e < UBU; ++e) {
+          const bool on = i0 + e * kWave < m;
+          syv[e] = on ? w.sy[i0 + e * kWave] : 1.0;
+          yov[e] = on ? w.dyus[i0 + e * kWave] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < UBU; ++e) {
+          const int i = i0 + e * kWave;
+          if (i < m) {
+            const double yn = vys[i], zn = vzs[i], syi = syv[e], yo = yov[e];
+            w.yus[i]  = syi * yn / c;
+            t[n + i]  = syi * yn / c;
+            w.zus[i]  = (1.0 / syi) * zn;
+            w.dyus[i] = syi * (yn - yo) / c;
+          }
+        }
       }
     }
     wave_sync();
