@@ -52,6 +52,21 @@ using lds_b = __attribute__((address_space(3))) unsigned char;
 __device__ __forceinline__ int mtri(const int i) { return (i * (i + 1)) >> 1; }
 __device__ __forceinline__ int muni(const int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ bool mfinite(const double v) { return fabs(v) < INFINITY; }
+// the lane number from the hardware (workgroups of one wave), opaque: a value made where it is used instead of one copy of
+// threadIdx.x that lives -- in scratch memory, when registers are short -- across the persistent loops of the launches below
+__device__ __forceinline__ int mid_lane_now()
+{
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+// a wave-uniform double as a scalar (two SGPRs instead of two VGPRs; the bits are untouched)
+__device__ __forceinline__ double muni_d(const double v)
+{
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)muni((int)(unsigned)b), hi = (unsigned)muni((int)(unsigned)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 
 // profiling build (scripts/r4/build_variant.sh prof qp_dense_mid.hip -DSFB_MID_PROF): block 0 prints where its time went
 // Stamps at the phase boundaries of a solve.  C.stamps (nullptr outside the TRACE instance: the branch folds away at compile
@@ -334,7 +349,7 @@ __device__ inline int mid_ldlt(const int K_, lds_d *const T, lds_d *const Dg, ld
 struct MidRow {
   bool isx, isc;
   int xi, ci;
-  double qc, sxv, syv, rho, rinv, lo, hi, x, y, z;
+  double qc, sc, rho, rinv, lo, hi, x, y, z;  // sc: the row's scale factor, sx_j or sy_i (1 for a row that does not exist) -- every use is under isx / isc
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -793,20 +808,19 @@ __device__ __forceinline__ int mid_setup(const MidC &C, const DenseKernelParams 
     w.isc = in && v >= n;
     w.xi  = w.isx ? v : 0;
     w.ci  = w.isc ? v - n : 0;
-    w.sxv = w.isx ? SX[w.xi] : 1.0;
-    w.syv = w.isc ? SY[w.ci] : 1.0;
-    w.qc  = w.isx ? c * w.sxv * q[w.xi] : 0.0;  // (c sx_j) q_j of the right-hand side :450
+    w.sc  = w.isx ? SX[w.xi] : (w.isc ? SY[w.ci] : 1.0);
+    w.qc  = w.isx ? c * w.sc * q[w.xi] : 0.0;  // (c sx_j) q_j of the right-hand side :450
     const double li = w.isc ? l[w.ci] : 0.0, ui = w.isc ? u[w.ci] : 0.0;
     double rho = 1.0;
     if (w.isc) {
       if (li == -inf && ui == inf) rho = 1e-6;
-      else if (w.syv * fabs(li - ui) < 1e-5) rho = 1e3 * kp.rho_bar;
+      else if (w.sc * fabs(li - ui) < 1e-5) rho = 1e3 * kp.rho_bar;
       else rho = kp.rho_bar;
     }
     w.rho  = rho;
     w.rinv = 1.0 / rho;
-    w.lo   = w.isc ? w.syv * li : 0.0;
-    w.hi   = w.isc ? w.syv * ui : 0.0;
+    w.lo   = w.isc ? w.sc * li : 0.0;
+    w.hi   = w.isc ? w.sc * ui : 0.0;
     w.x = w.y = w.z = 0.0;
   }
   // ---- initial iterate :436-445 ----
@@ -818,11 +832,11 @@ __device__ __forceinline__ int mid_setup(const MidC &C, const DenseKernelParams 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       MidRow &w = h[r];
-      if (w.isx) w.x = (1.0 / w.sxv) * wx[w.xi];
+      if (w.isx) w.x = (1.0 / w.sc) * wx[w.xi];
       if (w.isc) {
-        w.y      = c * ((1.0 / w.syv) * wy[w.ci]);
+        w.y      = c * ((1.0 / w.sc) * wy[w.ci]);
         double s = 0.0;
-        const double syv = w.syv;
+        const double syv = w.sc;
         mrun(A + w.ci, m, n, [&](int j, double a) { s = fma(syv * a, WX[j], s); });
         w.z = s;
       }
@@ -867,7 +881,7 @@ __device__ __forceinline__ void mid_save_state(const MidC &C, const MidRec rec, 
     const int row = lane + kWave * r;
     if (row < k) {
       const MidRow &w = h[r];
-      rec.rows[3 * row]     = w.isx ? w.sxv : w.syv;
+      rec.rows[3 * row]     = w.sc;
       rec.rows[3 * row + 1] = w.isx ? w.x : w.y;
       rec.rows[3 * row + 2] = w.z;
     }
@@ -902,11 +916,12 @@ __device__ __forceinline__ void mid_load_state(const MidC &C, const DenseKernelP
     const unsigned char *const pb = reinterpret_cast<const unsigned char *>(rec.perm);
     for (int e = lane; e < k; e += kWave) perm[e] = pb[e];
   }
-  c        = sv_hdr[0];
-  iter     = (uint32_t)sv_hdr[1];
-  next_chk = (uint32_t)sv_hdr[2];
-  t0_ticks = (unsigned long long)__double_as_longlong(sv_hdr[3]);
-  code     = (int)sv_hdr[4];
+  // (the header is the same for every lane: scalars -- as vector values they were live in VGPRs across the whole ADMM loop)
+  c        = muni_d(sv_hdr[0]);
+  iter     = (uint32_t)muni((int)(uint32_t)sv_hdr[1]);
+  next_chk = (uint32_t)muni((int)(uint32_t)sv_hdr[2]);
+  t0_ticks = (unsigned long long)__double_as_longlong(muni_d(sv_hdr[3]));
+  code     = muni((int)sv_hdr[4]);
   wave_lds_fence();
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -919,20 +934,21 @@ __device__ __forceinline__ void mid_load_state(const MidC &C, const DenseKernelP
     w.xi  = w.isx ? v : 0;
     w.ci  = w.isc ? v - n : 0;
     const double sc = in ? sv_rows[3 * row] : 1.0, a0 = in ? sv_rows[3 * row + 1] : 0.0, a1 = in ? sv_rows[3 * row + 2] : 0.0;
-    w.sxv = w.isx ? sc : 1.0;
-    w.syv = w.isc ? sc : 1.0;
-    w.qc  = w.isx ? c * w.sxv * q[w.xi] : 0.0;
+    double rho_bar = kp.rho_bar, rho_free = 1e-6;  // (opaque: 1e3 rho_bar and the literal are made here, per QP, not once per kernel and then held in scratch memory)
+    asm volatile("" : "+s"(rho_bar), "+s"(rho_free));
+    w.sc  = sc;
+    w.qc  = w.isx ? c * w.sc * q[w.xi] : 0.0;
     const double li = w.isc ? l[w.ci] : 0.0, ui = w.isc ? u[w.ci] : 0.0;
     double rho = 1.0;
     if (w.isc) {
-      if (li == -inf && ui == inf) rho = 1e-6;
-      else if (w.syv * fabs(li - ui) < 1e-5) rho = 1e3 * kp.rho_bar;
-      else rho = kp.rho_bar;
+      if (li == -inf && ui == inf) rho = rho_free;
+      else if (w.sc * fabs(li - ui) < 1e-5) rho = 1e3 * rho_bar;
+      else rho = rho_bar;
     }
     w.rho  = rho;
     w.rinv = 1.0 / rho;
-    w.lo   = w.isc ? w.syv * li : 0.0;
-    w.hi   = w.isc ? w.syv * ui : 0.0;
+    w.lo   = w.isc ? w.sc * li : 0.0;
+    w.hi   = w.isc ? w.sc * ui : 0.0;
     w.x = w.isx ? a0 : 0.0;
     w.y = w.isc ? a0 : 0.0;
     w.z = w.isc ? a1 : 0.0;
@@ -958,8 +974,8 @@ __device__ __forceinline__ void mid_finish(const MidC &C, const DenseKernelParam
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const MidRow &w = h[r];
-    if (w.isx) { SX[w.xi] = w.sxv; XS[w.xi] = w.x; }
-    if (w.isc) { SY[w.ci] = w.syv; YS[w.ci] = w.y; }
+    if (w.isx) { SX[w.xi] = w.sc; XS[w.xi] = w.x; }
+    if (w.isc) { SY[w.ci] = w.sc; YS[w.ci] = w.y; }
   }
   wave_lds_fence();
 
@@ -1213,13 +1229,13 @@ __device__ __forceinline__ bool mid_admm(const MidC &C, const DenseKernelParams 
     w.z       = zn;
     if (chk) {  // :481-485
       if (w.isx) {
-        xus[w.xi]  = w.sxv * w.x;
-        dxus[w.xi] = w.sxv * (w.x - xo);
+        xus[w.xi]  = w.sc * w.x;
+        dxus[w.xi] = w.sc * (w.x - xo);
       }
       if (w.isc) {
-        yus[w.ci]  = w.syv * w.y / c;
-        zus[w.ci]  = (1.0 / w.syv) * w.z;
-        dyus[w.ci] = w.syv * (w.y - yo) / c;
+        yus[w.ci]  = w.sc * w.y / c;
+        zus[w.ci]  = (1.0 / w.sc) * w.z;
+        dyus[w.ci] = w.sc * (w.y - yo) / c;
       }
     }
   };
@@ -1265,7 +1281,8 @@ __device__ __forceinline__ bool mid_admm(const MidC &C, const DenseKernelParams 
       // registers-only engine: the check is INLINED (an outlined call would save and restore the live factor registers
       // through scratch memory); SFB_MID_CHK_KEEP: the factor registers stay live across it and the check requests the
       // matrix entries in short batches that fit next to them, otherwise they are dead across it and re-filled from LDS behind it
-      if constexpr (kRegs) ret_code = mid_stop_check_body<R, kChkKeep ? (NB <= 3 ? 4 : 8) : 16>(n, m, lane, P, q, A, l, u, V, tmp, kp.eps_abs, kp.eps_rel, kp.eps_pinf, kp.eps_dinf);
+      const int lane_c = mid_lane_now();  // (the same per check: its addresses are made inside it instead of living across the iterations)
+      if constexpr (kRegs) ret_code = mid_stop_check_body<R, kChkKeep ? (NB <= 3 ? 4 : 8) : 16>(n, m, lane_c, P, q, A, l, u, V, tmp, kp.eps_abs, kp.eps_rel, kp.eps_pinf, kp.eps_dinf);
       else ret_code = mid_stop_check<R>(n, m, lane, P, q, A, l, u, V, tmp, kp.eps_abs, kp.eps_rel, kp.eps_pinf, kp.eps_dinf);
       if (ret_code < 0 && max_time_exceeded(kp.max_time_ns, t0_ticks)) ret_code = SFB_QP_MAX_TIME;  // :504-507
       wave_lds_fence();
@@ -1399,7 +1416,6 @@ __global__ void __launch_bounds__(64, WPE) qp_dense_mid_loop_kernel(const DenseK
 {
   constexpr int R = NB > 4 ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int lane = threadIdx.x;
   unsigned *const q_fresh = queue, *const q_rhead = queue + 16, *const q_tail = queue + 32, *const q_done = queue + 48;
   unsigned long long *const ring = reinterpret_cast<unsigned long long *>(queue + 64);
   const unsigned ring_n = 2u * batch;
@@ -1407,6 +1423,9 @@ __global__ void __launch_bounds__(64, WPE) qp_dense_mid_loop_kernel(const DenseK
   unsigned pend   = kNone;  // ring ticket this wave is waiting for
   bool fresh_left = true;
   for (;;) {
+    // (per QP: what depends on the lane alone -- index vectors and addresses of the record traffic, of the stopping check --
+    // is otherwise hoisted out of this persistent loop and held in scratch memory across it)
+    const int lane = mid_lane_now();
     int item = -1;
     if (pend == kNone) {
       if (fresh_left) {
@@ -1448,16 +1467,21 @@ __global__ void __launch_bounds__(64, WPE) qp_dense_mid_loop_kernel(const DenseK
     int ret_code = -1;
     mid_load_state<R>(C, kp, rec, h, c, iter, next_chk, t0_ticks, ret_code, true);
     const bool suspended = mid_admm<NB, R, true>(C, kp, h, c, iter, next_chk, ret_code, t0_ticks, slice, q_fresh, q_rhead, q_tail, batch);
-    mid_save_state<R>(C, rec, h, c, iter, next_chk, t0_ticks, ret_code, suspended);
+    {  // (the record's addresses are made again behind the loop instead of living across it)
+      MidC Cs = C;
+      Cs.lane = mid_lane_now();
+      mid_save_state<R>(Cs, rec, h, c, iter, next_chk, t0_ticks, ret_code, suspended);
+    }
+    const int lane_e = mid_lane_now();
     if (suspended) {
       __threadfence();  // the record is complete (device scope) before the id can be popped
-      if (lane == 0) {
+      if (lane_e == 0) {
         const unsigned j           = atomicAdd(q_tail, 1u);
         unsigned long long *slot   = ring + (j % ring_n);
         const unsigned long long v = ((unsigned long long)(j + 1u) << 32) | ((unsigned)item + 1u);
         while (atomicCAS(slot, 0ull, v) != 0ull) __builtin_amdgcn_s_sleep(1);
       }
-    } else if (lane == 0) {
+    } else if (lane_e == 0) {
       atomicAdd(q_done, 1u);
     }
   }
