@@ -68,10 +68,14 @@ __global__ void __launch_bounds__(64) mpc_linearise_kernel(const int64_t B, cons
     Mat<Nx, Nx> dfdx;
     Mat<Nx, Nu> dfdu;
     xu_jacobian<Nx>(model.f, xl, ul, fv, dfdx, dfdu);
+    // (every loop over matrix entries unrolled: with run-time indices the matrices live in scratch memory -- 1.4 KB per lane at Nx = 12)
+#pragma unroll
     for (int d = 0; d < Nx; ++d) {
       rec[map.o_f + node * Nx + d]  = fv[d];
       rec[map.o_dx + node * Nx + d] = dxl[d];
+#pragma unroll
       for (int c = 0; c < Nx; ++c) put(rec + map.o_dfdx, map.pos_fx, map.n_fx, node, d * Nx + c, dfdx(d, c));
+#pragma unroll
       for (int c = 0; c < Nu; ++c) put(rec + map.o_dfdu, map.pos_fu, map.n_fu, node, d * Nu + c, dfdu(d, c));
     }
     if constexpr (Ncr > 0) {
@@ -79,17 +83,22 @@ __global__ void __launch_bounds__(64) mpc_linearise_kernel(const int64_t B, cons
       Mat<Ncr, Nx> dcdx;
       Mat<Ncr, Nu> dcdu;
       xu_jacobian<Ncr>(model.cr, xl, ul, cv, dcdx, dcdu);
+#pragma unroll
       for (int d = 0; d < Ncr; ++d) {
         rec[map.o_c + node * Ncr + d] = cv[d];
+#pragma unroll
         for (int c = 0; c < Nx; ++c) put(rec + map.o_dcdx, map.pos_cx, map.n_cx, node, d * Nx + c, dcdx(d, c));
+#pragma unroll
         for (int c = 0; c < Nu; ++c) put(rec + map.o_dcdu, map.pos_cu, map.n_cu, node, d * Nu + c, dcdu(d, c));
       }
     }
   } else {  // the initial-state constraint: e = xdes(t) (-) x, J = d^r exp^-1(e)   (MPCCE, mpc.hpp:288-301)
     const auto e = rminus(model.xdes(t[b]), xs[b]);
     const auto J = X::dr_expinv(e);
+#pragma unroll
     for (int d = 0; d < Nx; ++d) {
       rec[map.o_e + d] = e[d];
+#pragma unroll
       for (int c = 0; c < Nx; ++c) put(rec + map.o_J, map.pos_J, map.n_J, 0, d * Nx + c, J(d, c));
     }
   }

@@ -79,46 +79,98 @@ void mpc_build_table(const MpcAsmParams &p, const bool shared, MpcAsmDesc *out)
   }
 }
 
-__global__ void __launch_bounds__(256) mpc_assemble_kernel(const MpcAsmParams p, const double *__restrict__ records,
+// bounds of row r of the QP: l = u of a dynamics / initial-state row, crl - c .. cru - c of a running-constraint row
+__device__ __forceinline__ void mpc_bounds_entry(const MpcAsmParams &p, const double *const rec, const int r, double &lo, double &hi)
+{
+  const int nx = p.nx, ncr = p.ncr;
+  if (r < p.N * nx) {  // :272-273
+    lo = -p.tf * (rec[p.o_f + r] - rec[p.o_dx + r]);
+    hi = lo;
+  } else if (r < p.N * (nx + ncr)) {  // :321-322
+    const int q = r - p.N * nx, d = q % ncr;
+    const double cv = rec[p.o_c + q];
+    lo = p.crl[d] - cv;
+    hi = p.cru[d] - cv;
+  } else {  // :371-372
+    lo = 0.0 - rec[p.o_e + (r - p.N * (nx + ncr))];
+    hi = lo;
+  }
+}
+
+#ifndef SFB_MPC_ASM_AGENTS
+#define SFB_MPC_ASM_AGENTS 4
+#endif
+constexpr int kMpcAsmAgents = SFB_MPC_ASM_AGENTS;  // agents per thread of the table form
+
+__global__ void __launch_bounds__(256) mpc_assemble_kernel(const MpcAsmParams p, const int64_t agents, const double *__restrict__ records,
                                                            const double *__restrict__ shared_jac,
                                                            double *__restrict__ gAx, double *__restrict__ gl,
                                                            double *__restrict__ gu, const MpcAsmDesc *__restrict__ table)
 {
-  const int64_t b  = blockIdx.y;
   const int idx    = blockIdx.x * 256 + threadIdx.x;
-  const double *rec = records + b * p.rec_doubles;
-  const double *jac = shared_jac ? shared_jac : rec;
   const int nx = p.nx, nu = p.nu, ncr = p.ncr, kmesh = p.kmesh;
   const double tf = p.tf;
   const bool pk   = p.packed != 0 && shared_jac == nullptr;
-  if (table != nullptr && idx < p.nnzA) {
+  if (table != nullptr) {
     // TABLE FORM (swarms): one 16-byte row says where the entry's Jacobian value is and which terms it takes -- the same
     // operations in the same order as the direct form below, without its divisions and mask arithmetic (the direct form spent
-    // 0.88 ms per 8 192 agents of the headline model on 840 MB of output: integer-bound, not HBM-bound)
-    const MpcAsmDesc e = table[idx];
-    const int kind     = e.meta & 3;
-    const double j     = e.src >= 0 ? ((e.meta & 8) ? rec : jac)[e.src] : 0.0;
-    double v;
-    if (kind == 3) {
-      v = j;
-    } else if (kind == 0) {
-      v = 0.0 + tf * j;
-    } else if (kind == 1) {
-      v = 0.0;
-      v += tf * j;
-      const int code = e.meta >> 4;
-      if (code != 0) {  // (no ad term, or one whose entry is 0.0: adding -tf/2 * 0.0 leaves v as it is)
-        const int k     = (code > 0 ? code : -code) - 1;
-        const double sk = rec[p.o_f + k] + rec[p.o_dx + k];
-        v += (-tf / 2) * ((code > 0) ? sk : -sk);
+    // 0.88 ms per 8 192 agents of the headline model on 840 MB of output: integer-bound, not HBM-bound).  A thread takes its
+    // entry for kMpcAsmAgents agents in a row: the row of the table is read once and the agents' operands are requested
+    // together (one 8-byte result per thread behind two dependent loads left the launch at 1.6 TB/s of writes, latency-bound).
+    const int64_t b0 = (int64_t)blockIdx.y * kMpcAsmAgents;
+    if (idx < p.nnzA) {
+      const MpcAsmDesc e = table[idx];
+      const int kind     = e.meta & 3;
+      const int code     = (kind == 1) ? (e.meta >> 4) : 0;
+      const int k        = (code > 0 ? code : -code) - 1;
+      double j[kMpcAsmAgents], sf[kMpcAsmAgents], sd[kMpcAsmAgents];
+#pragma unroll
+      for (int a = 0; a < kMpcAsmAgents; ++a) {
+        const bool on      = b0 + a < agents;
+        const double *reca = records + (on ? b0 + a : b0) * p.rec_doubles;
+        const double *jaca = shared_jac ? shared_jac : reca;
+        j[a]  = e.src >= 0 ? ((e.meta & 8) ? reca : jaca)[e.src] : 0.0;
+        sf[a] = code != 0 ? reca[p.o_f + k] : 0.0;
+        sd[a] = code != 0 ? reca[p.o_dx + k] : 0.0;
       }
-      if (e.meta & 4) v -= e.coef;
-    } else {
-      v = 0.0;
-      v -= e.coef;
+#pragma unroll
+      for (int a = 0; a < kMpcAsmAgents; ++a) {
+        double v;
+        if (kind == 3) {
+          v = j[a];
+        } else if (kind == 0) {
+          v = 0.0 + tf * j[a];
+        } else if (kind == 1) {
+          v = 0.0;
+          v += tf * j[a];
+          if (code != 0) {  // (no ad term, or one whose entry is 0.0: adding -tf/2 * 0.0 leaves v as it is)
+            const double sk = sf[a] + sd[a];
+            v += (-tf / 2) * ((code > 0) ? sk : -sk);
+          }
+          if (e.meta & 4) v -= e.coef;
+        } else {
+          v = 0.0;
+          v -= e.coef;
+        }
+        if (b0 + a < agents) gAx[(b0 + a) * p.nnzA + idx] = v;
+      }
+    } else if (idx < p.nnzA + p.m) {
+      const int r = idx - p.nnzA;
+#pragma unroll
+      for (int a = 0; a < kMpcAsmAgents; ++a) {
+        if (b0 + a >= agents) break;
+        double lo, hi;
+        mpc_bounds_entry(p, records + (b0 + a) * p.rec_doubles, r, lo, hi);
+        gl[(b0 + a) * p.m + r] = lo;
+        gu[(b0 + a) * p.m + r] = hi;
+      }
     }
-    gAx[b * p.nnzA + idx] = v;
-  } else if (idx < p.nnzA) {
+    return;
+  }
+  const int64_t b  = blockIdx.y;
+  const double *rec = records + b * p.rec_doubles;
+  const double *jac = shared_jac ? shared_jac : rec;
+  if (idx < p.nnzA) {
     double v;
     if (idx < p.nnz_dyn) {  // ocp_to_qp_update_dyn :240-275
       const int row = idx / p.rowlen_dyn, pos = idx - row * p.rowlen_dyn;
@@ -168,18 +220,7 @@ __global__ void __launch_bounds__(256) mpc_assemble_kernel(const MpcAsmParams p,
   } else if (idx < p.nnzA + p.m) {
     const int r = idx - p.nnzA;
     double lo, hi;
-    if (r < p.N * nx) {  // :272-273
-      lo = -tf * (rec[p.o_f + r] - rec[p.o_dx + r]);
-      hi = lo;
-    } else if (r < p.N * (nx + ncr)) {  // :321-322
-      const int q = r - p.N * nx, d = q % ncr;
-      const double cv = rec[p.o_c + q];
-      lo = p.crl[d] - cv;
-      hi = p.cru[d] - cv;
-    } else {  // :371-372
-      lo = 0.0 - rec[p.o_e + (r - p.N * (nx + ncr))];
-      hi = lo;
-    }
+    mpc_bounds_entry(p, rec, r, lo, hi);
     gl[b * p.m + r] = lo;
     gu[b * p.m + r] = hi;
   }
@@ -213,9 +254,10 @@ hipError_t mpc_assemble_launch(const MpcAsmParams &p, int64_t batch, const doubl
                                double *Ax, double *l, double *u, hipStream_t stream, const MpcAsmDesc *table)
 {
   const int blocks = (p.nnzA + p.m + 255) / 256;
-  for (int64_t b0 = 0; b0 < batch; b0 += 65535) {  // gridDim.y limit
-    const int64_t nb = (batch - b0 < 65535) ? batch - b0 : 65535;
-    hipLaunchKernelGGL(mpc_assemble_kernel, dim3(blocks, (unsigned)nb), dim3(256), 0, stream, p,
+  const int64_t per = table != nullptr ? kMpcAsmAgents : 1;  // agents per row of the grid
+  for (int64_t b0 = 0; b0 < batch; b0 += 65535 * per) {    // gridDim.y limit
+    const int64_t nb = (batch - b0 < 65535 * per) ? batch - b0 : 65535 * per;
+    hipLaunchKernelGGL(mpc_assemble_kernel, dim3(blocks, (unsigned)((nb + per - 1) / per)), dim3(256), 0, stream, p, nb,
                        records + b0 * p.rec_doubles, shared_jac, Ax + b0 * p.nnzA, l + b0 * p.m, u + b0 * p.m, table);
   }
   return hipGetLastError();

@@ -86,10 +86,11 @@ def test_swarm_tick_equals_host_assembly_plus_solve(sfb):
     swarm.close()
 
 
-@pytest.mark.parametrize("variant,K,B", [(6, 30, 64), (12, 50, 40)])
+@pytest.mark.parametrize("variant,K,B", [(6, 30, 64), (12, 50, 40), (6, 10, 7), (12, 20, 13), (6, 10, 1)])
 def test_device_swarm_front_matches_host_swarm_front(sfb, variant, K, B):
     """MPCSwarmDevice (records -> device assembly, device-resident warm start) against MPCSwarm (host assembly,
-    warm start through the host) over three closed-loop ticks: same inputs, codes and iteration counts."""
+    warm start through the host) over three closed-loop ticks: same inputs, codes and iteration counts.  (The device
+    assembly's table form takes four agents per thread: 7, 13 and 1 leave its last group ragged.)"""
     u_h, c_h, i_h = M.mpc_swarm_step(variant, K, B, 3)
     u_d, c_d, i_d = M.mpc_swarm_step(variant, K, B, 3, device=True)
     assert np.array_equal(c_h, c_d) and np.array_equal(i_h, i_d) and np.array_equal(u_h, u_d)
