@@ -17,6 +17,32 @@
 #include "qp_sparse_kernel.h"
 #include "sparse_plan.h"
 
+namespace sfb {
+// order[] = the indices 0 .. B-1 sorted by count DESCENDING, equal counts in index order (what std::stable_sort gives): a counting
+// sort when the counts are small numbers (iteration counts: they are), two passes over B entries instead of B log B comparisons
+static void order_by_count_descending(const std::vector<uint32_t> &count, std::vector<int32_t> &order)
+{
+  const size_t B = count.size();
+  order.resize(B);
+  uint32_t top = 0;
+  for (size_t b = 0; b < B; ++b) top = std::max(top, count[b]);
+  if ((size_t)top > 4 * B + 65536) {  // (sparse keys: the general sort)
+    for (size_t b = 0; b < B; ++b) order[b] = (int32_t)b;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t c) { return count[a] > count[c]; });
+    return;
+  }
+  std::vector<uint32_t> start((size_t)top + 2, 0);  // start[v] = number of entries with a count > v, after the prefix pass
+  for (size_t b = 0; b < B; ++b) ++start[count[b]];
+  uint32_t run = 0;
+  for (size_t v = (size_t)top + 1; v-- > 0;) {
+    const uint32_t c = start[v];
+    start[v]         = run;
+    run += c;
+  }
+  for (size_t b = 0; b < B; ++b) order[start[count[b]]++] = (int32_t)b;
+}
+}  // namespace sfb
+
 namespace {
 
 struct Sizes {
@@ -156,9 +182,11 @@ struct sfb_mpc_swarm {
   uint32_t *iter = nullptr;
   int32_t *code = nullptr, *order = nullptr;
   sfb::MpcAsmDesc *table_own = nullptr, *table_shared = nullptr;  // the assembly kernel's tables (one allocation; mpc_kernel.h)
+  char *h_out = nullptr;          // pinned: [du0 | iter | code] of a tick come back in ONE copy (they are adjacent on the device)
   std::vector<uint32_t> h_iter;   // iteration counts of the last tick (host), for the launch order of the next
   std::vector<int32_t> h_order;
   bool have_order = false;
+  bool order_sorted = false;      // h_order has been made from h_iter
   // pipelined upload (sfb_mpc_swarm_host_records / _upload): pinned host records, a copy stream, and which agents'
   // records of the CURRENT tick are already on their way
   double *pinned = nullptr;
@@ -285,9 +313,9 @@ sfb_status sfb_mpc_swarm_create(sfb_sparse_qp_plan *plan, const sfb_mpc_layout *
   S->wy = d; d += B * M;
   S->rec = d; d += B * pfull.rec_doubles;
   S->shared = d; d += S->shared_doubles;
-  S->du0 = d; d += B * layout->nu;
   double *stage = d; d += h.nnzP + N;  // one copy of Px and q, replicated below
   S->ws = d; d += S->wsd;
+  S->du0 = d; d += B * layout->nu;     // du0 | iter | code one behind the other: a tick brings them back in one copy
   S->iter = reinterpret_cast<uint32_t *>(d);
   S->code  = reinterpret_cast<int32_t *>(S->iter + B);
   S->order = S->code + B;
@@ -307,9 +335,11 @@ sfb_status sfb_mpc_swarm_create(sfb_sparse_qp_plan *plan, const sfb_mpc_layout *
     if ((e = sfb::mpc_replicate_launch(stage, h.nnzP, agents, S->Px, nullptr)) != hipSuccess) break;
     if ((e = sfb::mpc_replicate_launch(stage + h.nnzP, (int64_t)N, agents, S->q, nullptr)) != hipSuccess) break;
     if ((e = hipMemset(S->wx, 0, B * (N + M) * 8)) != hipSuccess) break;  // wx and wy are adjacent
+    if ((e = hipHostMalloc(reinterpret_cast<void **>(&S->h_out), B * ((size_t)layout->nu * 8 + 8), hipHostMallocDefault)) != hipSuccess) break;
     e = hipDeviceSynchronize();
   } while (false);
   if (e != hipSuccess) {
+    if (S->h_out) (void)hipHostFree(S->h_out);
     (void)hipFree(S->mem);
     if (S->table_own) (void)hipFree(S->table_own);
     delete S;
@@ -324,6 +354,7 @@ void sfb_mpc_swarm_destroy(sfb_mpc_swarm *swarm)
   if (!swarm) return;
   if (swarm->up_stream) { (void)hipStreamSynchronize(swarm->up_stream); (void)hipStreamDestroy(swarm->up_stream); }
   if (swarm->pinned) (void)hipHostFree(swarm->pinned);
+  if (swarm->h_out) (void)hipHostFree(swarm->h_out);
   if (swarm->mem) (void)hipFree(swarm->mem);
   if (swarm->table_own) (void)hipFree(swarm->table_own);
   delete swarm;
@@ -474,7 +505,13 @@ static sfb_status swarm_step_impl(sfb_mpc_swarm *S, const sfb_qp_params *prm, co
     lap("assemble");
     // Warm-started ticks: the agents that iterated longest in the previous tick are launched first (their counts
     // change little from tick to tick), so the stragglers overlap with the bulk of the batch.
+    // The order is made HERE, from the counts the previous tick brought back, while the assembly kernel (and a device-side
+    // linearisation in front of it) runs: at the end of the previous tick the same sort was 0.2 ms of a tick's wall time.
     const bool ordered = warmstart && S->have_order;
+    if (ordered && !S->order_sorted) {
+      sfb::order_by_count_descending(S->h_iter, S->h_order);
+      S->order_sorted = true;
+    }
     if (ordered && (e = hipMemcpy(S->order, S->h_order.data(), B * 4, hipMemcpyHostToDevice)) != hipSuccess) break;
     st = sfb_sparse_qp_solve_batch_ordered(S->plan, prm, S->agents, S->Px, S->q, S->Ax, S->l, S->u,
                                            warmstart ? S->wx : nullptr, warmstart ? S->wy : nullptr, S->x, S->y, nullptr,
@@ -483,16 +520,16 @@ static sfb_status swarm_step_impl(sfb_mpc_swarm *S, const sfb_qp_params *prm, co
     lap("solve");
     if ((e = sfb::mpc_store_launch(S->agents, S->n, S->m, S->uoff, S->nu, warmstart != 0, S->x, S->y, S->code, S->wx, S->wy,
                                    S->du0, nullptr)) != hipSuccess) break;
-    if ((e = hipMemcpy(du0, S->du0, B * (size_t)S->nu * 8, hipMemcpyDeviceToHost)) != hipSuccess) break;
-    if ((e = hipMemcpy(S->h_iter.data(), S->iter, B * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
-    if (iter) std::memcpy(iter, S->h_iter.data(), B * 4);
-    {
-      for (size_t b = 0; b < B; ++b) S->h_order[b] = (int32_t)b;
-      std::stable_sort(S->h_order.begin(), S->h_order.end(),
-                       [&](int32_t a, int32_t c) { return S->h_iter[a] > S->h_iter[c]; });
-      S->have_order = true;
+    {  // du0, iter and code lie one behind the other on the device: one copy into pinned memory instead of three into pageable
+      const size_t nb_u = B * (size_t)S->nu * 8;
+      if ((e = hipMemcpy(S->h_out, S->du0, nb_u + B * 8, hipMemcpyDeviceToHost)) != hipSuccess) break;
+      std::memcpy(du0, S->h_out, nb_u);
+      std::memcpy(S->h_iter.data(), S->h_out + nb_u, B * 4);
+      std::memcpy(code, S->h_out + nb_u + B * 4, B * 4);
     }
-    if ((e = hipMemcpy(code, S->code, B * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
+    if (iter) std::memcpy(iter, S->h_iter.data(), B * 4);
+    S->have_order   = true;  // (sorted at the start of the next tick, behind its first kernels)
+    S->order_sorted = false;
     if (primal && (e = hipMemcpy(primal, S->x, B * (size_t)S->n * 8, hipMemcpyDeviceToHost)) != hipSuccess) break;
     if (dual && (e = hipMemcpy(dual, S->y, B * (size_t)S->m * 8, hipMemcpyDeviceToHost)) != hipSuccess) break;
     lap("store+D2H");
